@@ -1,0 +1,234 @@
+/*
+ * pprhip.h — C ABI of the MI355X-native Personalized-PageRank engine.
+ *
+ * This is the drop-in boundary for the hot path of
+ * joezie/Personalized-PageRank-Algorithms-on-Neo4j (FORA single-source / top-k and
+ * All-Pair-Backward-Search).  The reference has no FFI of its own; the seam is its three Java
+ * interfaces plus the one-shot graph lift.  Every entry point below names the reference
+ * interface it stands behind (paths relative to
+ * /root/reference/src/main/java/joezie/fora_neo4j/).  INTEGRATION.md shows the JNI stub that
+ * binds these symbols from the reference's Java classes.
+ *
+ * Conventions
+ *   - plain C, opaque handles, caller-owned output buffers, no torch / STL types;
+ *   - every function returns 0 (PPRHIP_OK) or a negative PPRHIP_ERR_* code; the message for the
+ *     calling thread's last error is pprhip_last_error();
+ *   - node ids are the dense mapped ids 0..n-1 (the harness assumes this too: Gen_Util.java:99-107);
+ *   - all arithmetic on reserve / residue is IEEE double, as in the reference;
+ *   - one handle belongs to one GPU and is used by one thread at a time (the reference objects
+ *     are single-threaded and keep per-query state in fields, e.g. Forward_Push.java:33-43);
+ *   - output pointers documented "may be NULL" leave the result resident in HBM; fetch it later
+ *     with pprhip_get_reserve / pprhip_get_residue;
+ *   - there is NO CPU fallback: every compute entry point fails with PPRHIP_ERR_NO_DEVICE when
+ *     no gfx950 device is usable.
+ */
+#ifndef PPRHIP_H
+#define PPRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPRHIP_OK 0
+#define PPRHIP_ERR_INVALID (-1)   /* bad argument (null pointer, id out of range, k < 1 ...) */
+#define PPRHIP_ERR_NO_DEVICE (-2) /* no usable HIP device / device index out of range */
+#define PPRHIP_ERR_HIP (-3)       /* a HIP runtime call failed; see pprhip_last_error() */
+#define PPRHIP_ERR_OOM (-4)       /* host or device allocation failed */
+#define PPRHIP_ERR_IO (-5)        /* file could not be read / parsed / written */
+#define PPRHIP_ERR_STATE (-6)     /* call sequence error (e.g. topk round before reset) */
+
+#define PPRHIP_VERSION 100
+
+typedef struct pprhip_graph pprhip_graph_t;       /* device-resident CSR pair + per-query workspace */
+typedef struct pprhip_edgelist pprhip_edgelist_t; /* host edge list produced by the ingest helpers */
+typedef struct pprhip_index pprhip_index_t;       /* all-pair inverted index (host, CSR by source) */
+
+/* Counters every compute call fills; all device-side counts, not estimates. */
+typedef struct pprhip_stats {
+  uint64_t pops;           /* frontier nodes pushed in sparse levels */
+  uint64_t edge_pushes;    /* edges traversed in sparse levels */
+  uint64_t enqueues;       /* nodes appended to a next frontier */
+  uint64_t dead_end_pops;  /* pushed nodes with out-degree 0 (mass returned to the source) */
+  uint64_t dense_nodes;    /* nodes pushed inside dense pull sweeps */
+  uint32_t levels;         /* frontier levels run (sparse + dense) */
+  uint32_t dense_levels;   /* levels run as dense pull sweeps */
+  uint32_t rounds;         /* FORA: threshold rounds run (1 + halvings); top-k: delta rounds */
+  uint32_t reserved0;
+  uint64_t mc_sources;     /* residue entries that started walks */
+  uint64_t walks;          /* random walks run */
+  uint64_t walk_steps;     /* edges followed by all walks (dead-end restarts included) */
+  uint64_t select_passes;  /* radix-select passes over the reserve vector */
+  double rsum;             /* sum of residues the walk budget was derived from */
+  double rmax_final;       /* last push threshold used */
+  double omega;            /* walk budget at rsum = 1 */
+  double kth_value;        /* top-k: k-th largest estimate (0 when fewer than k entries) */
+  double push_ms;          /* HIP-event time of the push phase */
+  double mc_ms;            /* HIP-event time of the walk phase */
+  double select_ms;        /* HIP-event time of the top-k selection */
+  double total_ms;         /* HIP-event time of the whole call (device work only) */
+  uint64_t push_bytes;     /* algorithmic bytes of the push phase (DESIGN.md byte model) */
+  uint64_t mc_bytes;       /* algorithmic bytes of the walk phase */
+  uint64_t select_bytes;   /* algorithmic bytes of the selection */
+  double dominant_kernel_ms;    /* summed duration of the dominant kernel's launches */
+  uint64_t dominant_kernel_bytes; /* algorithmic bytes those launches moved */
+  uint32_t dominant_kernel_launches;
+  uint32_t dominant_kernel_id;  /* PPRHIP_KERNEL_* */
+} pprhip_stats_t;
+
+#define PPRHIP_KERNEL_NONE 0
+#define PPRHIP_KERNEL_DENSE_PULL 1
+#define PPRHIP_KERNEL_SPARSE_PUSH 2
+#define PPRHIP_KERNEL_WALK 3
+#define PPRHIP_KERNEL_BACKWARD_BATCH 4
+
+/* Engine tuning: the deterministic replacement of the reference's wall-clock push/walk balance
+ * (Fora_Whole_Graph.java:35,75-79,93-103) and the sparse/dense switch.  Zero means "default". */
+typedef struct pprhip_tuning {
+  double c_walk_ns;        /* modelled cost of one random walk (reference constant: 400 ns) */
+  double c_edge_ns;        /* modelled cost of one sparse edge push */
+  double c_pop_ns;         /* modelled cost of one frontier pop */
+  double c_level_ns;       /* modelled fixed cost of one level */
+  double c_dense_edge_ns;  /* modelled cost per edge of a dense pull sweep */
+  double c_dense_node_ns;  /* modelled cost per node of a dense pull sweep */
+  double dense_frac;       /* a level runs dense when frontier_edges + frontier_nodes >= dense_frac * m */
+  int32_t max_rounds;      /* cap on threshold halvings in auto mode (default 24) */
+  int32_t reserved;
+} pprhip_tuning_t;
+
+/* Parameters Algo_Conf derives (Algo_Conf.java:29-81). */
+typedef struct pprhip_fora_conf {
+  double alpha;      /* stop probability */
+  double delta;      /* reserve threshold: 1/n (whole graph) or 1/k (top-k start) */
+  double pfail;      /* failure probability: 1/n, or 1/n^2/ln(n div k) for top-k */
+  double rsum;       /* initial residue sum: 1.0 */
+  double min_delta;  /* top-k only: 1/n */
+  int32_t k;         /* top-k only */
+  uint32_t n;        /* node_amount */
+  uint64_t m;        /* rel_amount */
+} pprhip_fora_conf_t;
+
+/* ---------------------------------------------------------------- errors / build info */
+const char* pprhip_last_error(void);
+int pprhip_version(void);
+int pprhip_device_count(int* count_out);
+void pprhip_tuning_default(pprhip_tuning_t* t);
+
+/* ---------------------------------------------------------------- parameter derivation (a10) */
+/* Algo_Conf.set_conf_fora_whole_graph (Algo_Conf.java:45-53): delta = pfail = 1/n, rsum = 1. */
+int pprhip_conf_fora_whole_graph(uint32_t n, uint64_t m, double alpha, pprhip_fora_conf_t* conf);
+/* Algo_Conf.set_conf_fora_topk (Algo_Conf.java:71-81): min_delta = 1/n, delta = 1/k,
+ * pfail = 1/n/n/ln(n div k) with integer division. */
+int pprhip_conf_fora_topk(uint32_t n, uint64_t m, int k, double alpha, pprhip_fora_conf_t* conf);
+/* Fora_Whole_Graph.java:86-87: rmax0 = eps*sqrt(delta/3/m/ln(2/pfail))/(1-alpha),
+ * omega = (eps+2)*ln(2/pfail)/eps^2/delta. */
+int pprhip_fora_whole_params(const pprhip_fora_conf_t* conf, double eps, double* rmax0, double* omega);
+/* Fora_Topk.java:110-125,133 for one delta: eps' = eps/2; min_rmax, scaled rmax, omega. */
+int pprhip_fora_topk_params(const pprhip_fora_conf_t* conf, double eps, double delta,
+                            double* min_rmax, double* rmax_scaled, double* omega);
+
+/* ---------------------------------------------------------------- graph ingest (host side) */
+/* Seeded R-MAT edge list (Graph500 quadrants .57/.19/.19/.05), m = edge_factor << scale, labels
+ * scrambled by a seeded permutation, parallel edges and self loops kept (the reference's
+ * container is a multigraph: Forward_Push.java:119-139 visits every relationship). */
+int pprhip_rmat_edges(int scale, int edge_factor, uint64_t seed, int32_t* src_out, int32_t* dst_out);
+/* neo4j-admin-import CSVs (":ID,name" / ":START_ID,:END_ID,:TYPE"), id = node row index
+ * (dataset/got/GOT_Nodes.csv, GOT_Rels.csv). */
+int pprhip_edgelist_from_neo4j_csv(const char* nodes_csv, const char* rels_csv, pprhip_edgelist_t** out);
+int pprhip_edgelist_info(const pprhip_edgelist_t* e, uint32_t* n, uint64_t* m);
+int pprhip_edgelist_edges(const pprhip_edgelist_t* e, const int32_t** src, const int32_t** dst);
+const char* pprhip_edgelist_node_name(const pprhip_edgelist_t* e, uint32_t id);
+void pprhip_edgelist_destroy(pprhip_edgelist_t* e);
+/* CSR by `key` (stable counting sort).  newest_first != 0 lists each row in descending edge
+ * index, the order HeavyGraph inherits from Neo4j's relationship chains for got.db. */
+int pprhip_csr_build(uint32_t n, uint64_t m, const int32_t* key, const int32_t* val, int newest_first,
+                     uint32_t* row_ptr_out /* n+1 */, int32_t* col_idx_out /* m */);
+
+/* ---------------------------------------------------------------- graph lift (a11) */
+/* Replaces PPR.setupAdjMatrix + set_configuration (PPR.java:121-152): uploads the out- and
+ * in-adjacency once.  in_* may be NULL, then the in-CSR is derived from the out-CSR. */
+int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_row_ptr, const int32_t* out_col_idx,
+                        const uint32_t* in_row_ptr, const int32_t* in_col_idx, int device,
+                        pprhip_graph_t** graph_out);
+void pprhip_graph_destroy(pprhip_graph_t* g);
+int pprhip_graph_info(const pprhip_graph_t* g, uint32_t* n, uint64_t* m, int* device);
+int pprhip_graph_set_tuning(pprhip_graph_t* g, const pprhip_tuning_t* t);
+int pprhip_graph_get_tuning(const pprhip_graph_t* g, pprhip_tuning_t* t);
+/* Results of the last compute call that left them in HBM. */
+int pprhip_get_reserve(pprhip_graph_t* g, double* reserve_out /* n */);
+int pprhip_get_residue(pprhip_graph_t* g, double* residue_out /* n */);
+
+/* ---------------------------------------------------------------- forward push (a1, a2) */
+/* Forward_Push.computeWholeGraphPPR(Long s, Object rmax) (Forward_Push.java:63-142), run as a
+ * frontier-synchronous schedule.  reserve_out / residue_out / rsum_out / stats may be NULL. */
+int pprhip_forward_push(pprhip_graph_t* g, int32_t src, double alpha, double rmax, double* reserve_out,
+                        double* residue_out, double* rsum_out, pprhip_stats_t* stats);
+/* Forward_Push.forward_push_topk (Forward_Push.java:144-250): resumable two-threshold push.
+ * reset = new Forward_Push(rsum = 1) + Q = {s}; each round resumes from the parked queue. */
+int pprhip_fwdpush_topk_reset(pprhip_graph_t* g, int32_t src, double alpha);
+int pprhip_fwdpush_topk_round(pprhip_graph_t* g, double min_rmax, double rmax, double* rsum_out,
+                              pprhip_stats_t* stats);
+
+/* ---------------------------------------------------------------- random walks (a3, a4) */
+/* Monte_Carlo.random_walk / random_walk_no_zero_hop (Monte_Carlo.java:60-133) on the engine's
+ * counter-based generator: walk (seed, stream, start, walk_idx) is a pure function, so the
+ * terminal of every walk can be compared one by one. */
+int pprhip_random_walk_batch(pprhip_graph_t* g, const int32_t* starts, const uint64_t* walk_idx, uint64_t count,
+                             double alpha, uint64_t seed, uint32_t stream, int no_zero_hop,
+                             int32_t* terminals_out, uint32_t* steps_out /* may be NULL */);
+
+/* ---------------------------------------------------------------- FORA (a5, a6, a7) */
+/* Fora_Whole_Graph.computeWholeGraphPPR(Long s, Object eps) (Fora_Whole_Graph.java:82-146).
+ * n_rounds > 0 runs exactly that many threshold rounds (rmax0, rmax0/2, ...); 0 picks the count
+ * with the deterministic cost model in pprhip_tuning_t.  reserve_out may be NULL. */
+int pprhip_fora_single_source(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf,
+                              uint64_t seed, int n_rounds, double* reserve_out, pprhip_stats_t* stats);
+/* Fora_Topk.computeTopKPPR + getTopKNodeIds (Fora_Topk.java:82-199).  Writes at most `cap`
+ * (id, value) pairs ordered by value descending then id ascending; *n_out is the number the
+ * reference's rule selects (all entries >= the k-th value, can exceed k on ties) and can exceed
+ * cap.  reserve_out may be NULL. */
+int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf, uint64_t seed,
+                     int32_t* ids_out, double* vals_out, int cap, int* n_out, double* reserve_out,
+                     pprhip_stats_t* stats);
+/* Algo_Util.kth_ppr + retrieveTopK (Algo_Util.java:32-53, Fora_Topk.java:186-199) over the
+ * reserve vector currently in HBM (entries == 0 do not exist in the reference's map). */
+int pprhip_topk_select(pprhip_graph_t* g, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
+                       double* kth_out, pprhip_stats_t* stats);
+/* Monte_Carlo.computeWholeGraphPPR (Monte_Carlo.java:136-158): omega = 3 ln(2/pfail)/eps^2/delta walks. */
+int pprhip_monte_carlo(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf, uint64_t seed,
+                       double* ppr_out, pprhip_stats_t* stats);
+/* Batched FORA top-k for the sources of one shard (config #4): q queries one after another on
+ * this handle's GPU; ids_out/vals_out are q*k, rows padded with id -1 / value 0. */
+int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k, double eps, double alpha,
+                           uint64_t seed, int32_t* ids_out, double* vals_out, pprhip_stats_t* stats_sum);
+
+/* ---------------------------------------------------------------- backward search (a8, a9) */
+/* Backward_Search.backward_search_whole_graph(Long t) (Backward_Search.java:38-100). */
+int pprhip_backward_push(pprhip_graph_t* g, int32_t target, double alpha, double rmax, double* reserve_out,
+                         double* residue_out, pprhip_stats_t* stats);
+/* Base_Whole_Graph.preprocessing(threshold, k) (Base_Whole_Graph.java:58-164) for the targets
+ * [t_begin, t_end): backward search per target, entries >= threshold inverted into per-source
+ * lists; k >= 0 keeps entries >= the k-th largest and sorts them descending, k < 0 keeps all in
+ * target order.  The result covers all n sources for this shard of targets. */
+int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, int k, uint32_t t_begin,
+                             uint32_t t_end, pprhip_index_t** index_out, pprhip_stats_t* stats);
+/* Merge the shards of several target ranges (one per GPU) into one index, re-applying the k rule. */
+int pprhip_index_merge(const pprhip_index_t* const* shards, int n_shards, int k, pprhip_index_t** merged_out);
+int pprhip_index_info(const pprhip_index_t* ix, uint32_t* n, uint64_t* entries);
+int pprhip_index_arrays(const pprhip_index_t* ix, const uint64_t** offsets /* n+1 */, const int32_t** targets,
+                        const double** values);
+/* Per-source text files "<t>\t<Double.toString(pi)>\n" (Base_Whole_Graph.java:118-126,152-156). */
+int pprhip_index_write_dir(const pprhip_index_t* ix, const char* dir);
+void pprhip_index_destroy(pprhip_index_t* ix);
+
+/* ---------------------------------------------------------------- ground truth (a12) */
+/* Power_Method.computeWholeGraphPPR (Power_Method.java:44-101): `iters` synchronous sweeps. */
+int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters, double* reserve_out,
+                        pprhip_stats_t* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPRHIP_H */

@@ -1,0 +1,405 @@
+"""pprhip — MI355X-native Personalized PageRank (FORA + All-Pair-Backward-Search).
+
+Thin ctypes binding of the C ABI in include/pprhip.h.  The compute path lives entirely in
+libpprhip.so (hand-written HIP kernels for gfx950); there is no Python or CPU fallback: importing
+this package without the built library raises, and every compute call fails loudly when no GPU is
+usable.  Build with `make -C personalized-pagerank-algorithms-on-neo4j_amd` or
+`__graft_entry__.build()`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpprhip.so")
+
+OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_IO, ERR_STATE = -1, -2, -3, -4, -5, -6
+
+KERNEL_NAMES = {0: "none", 1: "dense_pull", 2: "sparse_push", 3: "walk", 4: "backward_batch"}
+
+
+class PprhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pprhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("pops", C.c_uint64), ("edge_pushes", C.c_uint64), ("enqueues", C.c_uint64),
+                ("dead_end_pops", C.c_uint64), ("dense_nodes", C.c_uint64), ("levels", C.c_uint32),
+                ("dense_levels", C.c_uint32), ("rounds", C.c_uint32), ("reserved0", C.c_uint32),
+                ("mc_sources", C.c_uint64), ("walks", C.c_uint64), ("walk_steps", C.c_uint64),
+                ("select_passes", C.c_uint64), ("rsum", C.c_double), ("rmax_final", C.c_double),
+                ("omega", C.c_double), ("kth_value", C.c_double), ("push_ms", C.c_double), ("mc_ms", C.c_double),
+                ("select_ms", C.c_double), ("total_ms", C.c_double), ("push_bytes", C.c_uint64),
+                ("mc_bytes", C.c_uint64), ("select_bytes", C.c_uint64), ("dominant_kernel_ms", C.c_double),
+                ("dominant_kernel_bytes", C.c_uint64), ("dominant_kernel_launches", C.c_uint32),
+                ("dominant_kernel_id", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
+
+
+class Tuning(C.Structure):
+    _fields_ = [("c_walk_ns", C.c_double), ("c_edge_ns", C.c_double), ("c_pop_ns", C.c_double),
+                ("c_level_ns", C.c_double), ("c_dense_edge_ns", C.c_double), ("c_dense_node_ns", C.c_double),
+                ("dense_frac", C.c_double), ("max_rounds", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ForaConf(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("delta", C.c_double), ("pfail", C.c_double), ("rsum", C.c_double),
+                ("min_delta", C.c_double), ("k", C.c_int32), ("n", C.c_uint32), ("m", C.c_uint64)]
+
+
+# every symbol include/pprhip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "pprhip_last_error", "pprhip_version", "pprhip_device_count", "pprhip_tuning_default",
+    "pprhip_conf_fora_whole_graph", "pprhip_conf_fora_topk", "pprhip_fora_whole_params", "pprhip_fora_topk_params",
+    "pprhip_rmat_edges", "pprhip_edgelist_from_neo4j_csv", "pprhip_edgelist_info", "pprhip_edgelist_edges",
+    "pprhip_edgelist_node_name", "pprhip_edgelist_destroy", "pprhip_csr_build", "pprhip_graph_create",
+    "pprhip_graph_destroy", "pprhip_graph_info", "pprhip_graph_set_tuning", "pprhip_graph_get_tuning",
+    "pprhip_get_reserve", "pprhip_get_residue", "pprhip_forward_push", "pprhip_fwdpush_topk_reset",
+    "pprhip_fwdpush_topk_round", "pprhip_random_walk_batch", "pprhip_fora_single_source", "pprhip_fora_topk",
+    "pprhip_topk_select", "pprhip_monte_carlo", "pprhip_fora_batch_topk", "pprhip_backward_push",
+    "pprhip_all_pair_backward", "pprhip_index_merge", "pprhip_index_info", "pprhip_index_arrays",
+    "pprhip_index_write_dir", "pprhip_index_destroy", "pprhip_power_method",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libpprhip.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libpprhip.so is not built (%s); run `make -C %s`" % (LIB_PATH, _HERE))
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64, dbl, ci = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_double, C.c_int
+    P = C.POINTER
+    L.pprhip_last_error.restype = C.c_char_p
+    L.pprhip_version.restype = ci
+    L.pprhip_device_count.argtypes = [P(ci)]
+    L.pprhip_tuning_default.argtypes = [P(Tuning)]
+    L.pprhip_tuning_default.restype = None
+    L.pprhip_conf_fora_whole_graph.argtypes = [u32, u64, dbl, P(ForaConf)]
+    L.pprhip_conf_fora_topk.argtypes = [u32, u64, ci, dbl, P(ForaConf)]
+    L.pprhip_fora_whole_params.argtypes = [P(ForaConf), dbl, P(dbl), P(dbl)]
+    L.pprhip_fora_topk_params.argtypes = [P(ForaConf), dbl, dbl, P(dbl), P(dbl), P(dbl)]
+    L.pprhip_rmat_edges.argtypes = [ci, ci, u64, vp, vp]
+    L.pprhip_edgelist_from_neo4j_csv.argtypes = [C.c_char_p, C.c_char_p, P(vp)]
+    L.pprhip_edgelist_info.argtypes = [vp, P(u32), P(u64)]
+    L.pprhip_edgelist_edges.argtypes = [vp, P(vp), P(vp)]
+    L.pprhip_edgelist_node_name.argtypes = [vp, u32]
+    L.pprhip_edgelist_node_name.restype = C.c_char_p
+    L.pprhip_edgelist_destroy.argtypes = [vp]
+    L.pprhip_edgelist_destroy.restype = None
+    L.pprhip_csr_build.argtypes = [u32, u64, vp, vp, ci, vp, vp]
+    L.pprhip_graph_create.argtypes = [u32, u64, vp, vp, vp, vp, ci, P(vp)]
+    L.pprhip_graph_destroy.argtypes = [vp]
+    L.pprhip_graph_destroy.restype = None
+    L.pprhip_graph_info.argtypes = [vp, P(u32), P(u64), P(ci)]
+    L.pprhip_graph_set_tuning.argtypes = [vp, P(Tuning)]
+    L.pprhip_graph_get_tuning.argtypes = [vp, P(Tuning)]
+    L.pprhip_get_reserve.argtypes = [vp, vp]
+    L.pprhip_get_residue.argtypes = [vp, vp]
+    L.pprhip_forward_push.argtypes = [vp, i32, dbl, dbl, vp, vp, P(dbl), P(Stats)]
+    L.pprhip_fwdpush_topk_reset.argtypes = [vp, i32, dbl]
+    L.pprhip_fwdpush_topk_round.argtypes = [vp, dbl, dbl, P(dbl), P(Stats)]
+    L.pprhip_random_walk_batch.argtypes = [vp, vp, vp, u64, dbl, u64, u32, ci, vp, vp]
+    L.pprhip_fora_single_source.argtypes = [vp, i32, dbl, P(ForaConf), u64, ci, vp, P(Stats)]
+    L.pprhip_fora_topk.argtypes = [vp, i32, dbl, P(ForaConf), u64, vp, vp, ci, P(ci), vp, P(Stats)]
+    L.pprhip_topk_select.argtypes = [vp, ci, vp, vp, ci, P(ci), P(dbl), P(Stats)]
+    L.pprhip_monte_carlo.argtypes = [vp, i32, dbl, P(ForaConf), u64, vp, P(Stats)]
+    L.pprhip_fora_batch_topk.argtypes = [vp, vp, ci, ci, dbl, dbl, u64, vp, vp, P(Stats)]
+    L.pprhip_backward_push.argtypes = [vp, i32, dbl, dbl, vp, vp, P(Stats)]
+    L.pprhip_all_pair_backward.argtypes = [vp, dbl, dbl, ci, u32, u32, P(vp), P(Stats)]
+    L.pprhip_index_merge.argtypes = [P(vp), ci, ci, P(vp)]
+    L.pprhip_index_info.argtypes = [vp, P(u32), P(u64)]
+    L.pprhip_index_arrays.argtypes = [vp, P(vp), P(vp), P(vp)]
+    L.pprhip_index_write_dir.argtypes = [vp, C.c_char_p]
+    L.pprhip_index_destroy.argtypes = [vp]
+    L.pprhip_index_destroy.restype = None
+    L.pprhip_power_method.argtypes = [vp, i32, dbl, ci, vp, P(Stats)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise PprhipError(rc, lib().pprhip_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    c = C.c_int(0)
+    _check(lib().pprhip_device_count(C.byref(c)))
+    return c.value
+
+
+# ------------------------------------------------------------------ ingest helpers (host side)
+def rmat_edges(scale, edge_factor=16, seed=1):
+    m = edge_factor << scale
+    src = np.empty(m, dtype=np.int32)
+    dst = np.empty(m, dtype=np.int32)
+    _check(lib().pprhip_rmat_edges(scale, edge_factor, seed, _ptr(src), _ptr(dst)))
+    return src, dst
+
+
+def csr_build(n, key, val, newest_first=False):
+    key = np.ascontiguousarray(key, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.int32)
+    rp = np.empty(n + 1, dtype=np.uint32)
+    ci = np.empty(max(key.size, 1), dtype=np.int32)
+    _check(lib().pprhip_csr_build(n, key.size, _ptr(key), _ptr(val), int(newest_first), _ptr(rp), _ptr(ci)))
+    return rp, ci[:key.size]
+
+
+def load_neo4j_csv(nodes_csv, rels_csv):
+    """Returns (n, src, dst, names) with node id = row index of the nodes file."""
+    h = C.c_void_p()
+    _check(lib().pprhip_edgelist_from_neo4j_csv(nodes_csv.encode(), rels_csv.encode(), C.byref(h)))
+    try:
+        n, m = C.c_uint32(), C.c_uint64()
+        _check(lib().pprhip_edgelist_info(h, C.byref(n), C.byref(m)))
+        ps, pd = C.c_void_p(), C.c_void_p()
+        _check(lib().pprhip_edgelist_edges(h, C.byref(ps), C.byref(pd)))
+        if m.value:
+            src = np.ctypeslib.as_array(C.cast(ps, C.POINTER(C.c_int32)), shape=(m.value,)).copy()
+            dst = np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_int32)), shape=(m.value,)).copy()
+        else:
+            src = np.zeros(0, dtype=np.int32)
+            dst = np.zeros(0, dtype=np.int32)
+        names = [lib().pprhip_edgelist_node_name(h, i).decode() for i in range(n.value)]
+    finally:
+        lib().pprhip_edgelist_destroy(h)
+    return n.value, src, dst, names
+
+
+class HostCsr:
+    """Host out-/in-CSR pair built by the product's ingest code (input data for engine and oracle)."""
+
+    def __init__(self, n, src, dst, newest_first=False):
+        self.n = int(n)
+        self.m = int(len(src))
+        self.out_rp, self.out_ci = csr_build(n, src, dst, newest_first)
+        self.in_rp, self.in_ci = csr_build(n, dst, src, newest_first)
+
+    @classmethod
+    def rmat(cls, scale, edge_factor=16, seed=1):
+        src, dst = rmat_edges(scale, edge_factor, seed)
+        return cls(1 << scale, src, dst)
+
+    @classmethod
+    def from_neo4j_csv(cls, nodes_csv, rels_csv):
+        n, src, dst, names = load_neo4j_csv(nodes_csv, rels_csv)
+        h = cls(n, src, dst, newest_first=True)  # HeavyGraph lists newest relationships first
+        h.names = names
+        return h
+
+
+# ------------------------------------------------------------------ device graph
+def conf_whole_graph(n, m, alpha):
+    c = ForaConf()
+    _check(lib().pprhip_conf_fora_whole_graph(n, m, alpha, C.byref(c)))
+    return c
+
+
+def conf_topk(n, m, k, alpha):
+    c = ForaConf()
+    _check(lib().pprhip_conf_fora_topk(n, m, k, alpha, C.byref(c)))
+    return c
+
+
+def fora_whole_params(conf, eps):
+    a, b = C.c_double(), C.c_double()
+    _check(lib().pprhip_fora_whole_params(C.byref(conf), eps, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def fora_topk_params(conf, eps, delta):
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    _check(lib().pprhip_fora_topk_params(C.byref(conf), eps, delta, C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
+def tuning_default():
+    t = Tuning()
+    lib().pprhip_tuning_default(C.byref(t))
+    return t
+
+
+class Index:
+    """All-pair inverted index (CSR by source)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def arrays(self):
+        n, e = C.c_uint32(), C.c_uint64()
+        _check(lib().pprhip_index_info(self.h, C.byref(n), C.byref(e)))
+        po, pt, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().pprhip_index_arrays(self.h, C.byref(po), C.byref(pt), C.byref(pv)))
+        off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
+        if e.value:
+            tg = np.ctypeslib.as_array(C.cast(pt, C.POINTER(C.c_int32)), shape=(e.value,)).copy()
+            vl = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_double)), shape=(e.value,)).copy()
+        else:
+            tg, vl = np.zeros(0, dtype=np.int32), np.zeros(0)
+        return off, tg, vl
+
+    def write_dir(self, path):
+        _check(lib().pprhip_index_write_dir(self.h, path.encode()))
+
+    def close(self):
+        if self.h:
+            lib().pprhip_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def merge_indexes(shards, k):
+    arr = (C.c_void_p * len(shards))(*[s.h for s in shards])
+    out = C.c_void_p()
+    _check(lib().pprhip_index_merge(arr, len(shards), k, C.byref(out)))
+    return Index(out)
+
+
+class Graph:
+    """Device-resident CSR pair + per-query workspace (one per GPU, one thread at a time)."""
+
+    def __init__(self, host, device=0):
+        self.n, self.m = host.n, host.m
+        self.h = C.c_void_p()
+        _check(lib().pprhip_graph_create(host.n, host.m, _ptr(host.out_rp), _ptr(host.out_ci), _ptr(host.in_rp),
+                                         _ptr(host.in_ci), device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().pprhip_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_tuning(self, t):
+        _check(lib().pprhip_graph_set_tuning(self.h, C.byref(t)))
+
+    def get_tuning(self):
+        t = Tuning()
+        _check(lib().pprhip_graph_get_tuning(self.h, C.byref(t)))
+        return t
+
+    def reserve(self):
+        out = np.empty(self.n)
+        _check(lib().pprhip_get_reserve(self.h, _ptr(out)))
+        return out
+
+    def residue(self):
+        out = np.empty(self.n)
+        _check(lib().pprhip_get_residue(self.h, _ptr(out)))
+        return out
+
+    def forward_push(self, src, alpha, rmax, fetch=True):
+        reserve = np.empty(self.n) if fetch else None
+        residue = np.empty(self.n) if fetch else None
+        rsum, st = C.c_double(), Stats()
+        _check(lib().pprhip_forward_push(self.h, src, alpha, rmax, _ptr(reserve), _ptr(residue), C.byref(rsum),
+                                         C.byref(st)))
+        return reserve, residue, rsum.value, st
+
+    def topk_push_reset(self, src, alpha):
+        _check(lib().pprhip_fwdpush_topk_reset(self.h, src, alpha))
+
+    def topk_push_round(self, min_rmax, rmax):
+        rsum, st = C.c_double(), Stats()
+        _check(lib().pprhip_fwdpush_topk_round(self.h, min_rmax, rmax, C.byref(rsum), C.byref(st)))
+        return rsum.value, st
+
+    def random_walks(self, starts, idx, alpha, seed, stream=0, no_zero_hop=False):
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        term = np.empty(starts.size, dtype=np.int32)
+        steps = np.empty(starts.size, dtype=np.uint32)
+        _check(lib().pprhip_random_walk_batch(self.h, _ptr(starts), _ptr(idx), starts.size, alpha, seed, stream,
+                                              int(no_zero_hop), _ptr(term), _ptr(steps)))
+        return term, steps
+
+    def fora_single_source(self, src, eps, alpha, seed, n_rounds=0, conf=None, fetch=True):
+        conf = conf or conf_whole_graph(self.n, self.m, alpha)
+        out = np.empty(self.n) if fetch else None
+        st = Stats()
+        _check(lib().pprhip_fora_single_source(self.h, src, eps, C.byref(conf), seed, n_rounds, _ptr(out),
+                                               C.byref(st)))
+        return out, st
+
+    def fora_topk(self, src, eps, alpha, k, seed, cap=None, conf=None, fetch=False):
+        conf = conf or conf_topk(self.n, self.m, k, alpha)
+        cap = cap if cap is not None else k
+        ids = np.empty(max(cap, 1), dtype=np.int32)
+        vals = np.empty(max(cap, 1))
+        nsel, st = C.c_int(0), Stats()
+        out = np.empty(self.n) if fetch else None
+        _check(lib().pprhip_fora_topk(self.h, src, eps, C.byref(conf), seed, _ptr(ids), _ptr(vals), cap,
+                                      C.byref(nsel), _ptr(out), C.byref(st)))
+        w = min(nsel.value, cap)
+        return nsel.value, ids[:w].copy(), vals[:w].copy(), out, st
+
+    def topk_select(self, k, cap=None):
+        cap = cap if cap is not None else k
+        ids = np.empty(max(cap, 1), dtype=np.int32)
+        vals = np.empty(max(cap, 1))
+        nsel, kth, st = C.c_int(0), C.c_double(0.0), Stats()
+        _check(lib().pprhip_topk_select(self.h, k, _ptr(ids), _ptr(vals), cap, C.byref(nsel), C.byref(kth),
+                                        C.byref(st)))
+        w = min(nsel.value, cap)
+        return nsel.value, ids[:w].copy(), vals[:w].copy(), kth.value, st
+
+    def monte_carlo(self, src, eps, alpha, seed, conf=None):
+        conf = conf or conf_whole_graph(self.n, self.m, alpha)
+        out = np.empty(self.n)
+        st = Stats()
+        _check(lib().pprhip_monte_carlo(self.h, src, eps, C.byref(conf), seed, _ptr(out), C.byref(st)))
+        return out, st
+
+    def fora_batch_topk(self, srcs, k, eps, alpha, seed):
+        srcs = np.ascontiguousarray(srcs, dtype=np.int32)
+        ids = np.empty((srcs.size, k), dtype=np.int32)
+        vals = np.empty((srcs.size, k))
+        st = Stats()
+        _check(lib().pprhip_fora_batch_topk(self.h, _ptr(srcs), srcs.size, k, eps, alpha, seed, _ptr(ids), _ptr(vals),
+                                            C.byref(st)))
+        return ids, vals, st
+
+    def backward_push(self, target, alpha, rmax):
+        reserve = np.empty(self.n)
+        residue = np.empty(self.n)
+        st = Stats()
+        _check(lib().pprhip_backward_push(self.h, target, alpha, rmax, _ptr(reserve), _ptr(residue), C.byref(st)))
+        return reserve, residue, st
+
+    def all_pair_backward(self, alpha, threshold, k, t_begin=0, t_end=None):
+        t_end = self.n if t_end is None else t_end
+        out, st = C.c_void_p(), Stats()
+        _check(lib().pprhip_all_pair_backward(self.h, alpha, threshold, k, t_begin, t_end, C.byref(out), C.byref(st)))
+        return Index(out), st
+
+    def power_method(self, src, alpha, iters=100):
+        out = np.empty(self.n)
+        st = Stats()
+        _check(lib().pprhip_power_method(self.h, src, alpha, iters, _ptr(out), C.byref(st)))
+        return out, st

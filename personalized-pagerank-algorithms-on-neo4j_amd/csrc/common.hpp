@@ -1,0 +1,44 @@
+// common.hpp — shared declarations of the pprhip engine (host side).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/pprhip.h"
+
+namespace pprhip {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define PPRHIP_CHECK_HIP(expr)                                                                     \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      ::pprhip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return PPRHIP_ERR_HIP;                                                                       \
+    }                                                                                              \
+  } while (0)
+
+#define PPRHIP_TRY(expr)       \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != PPRHIP_OK) return _rc; \
+  } while (0)
+
+// Layout constants shared by graph build (host) and kernels (device).
+constexpr int kTileEdges = 2048;  // in-edges gathered by one workgroup of the dense pull sweep
+constexpr int kTileRows = 256;    // rows one workgroup applies (one per thread)
+constexpr int kHubChunk = 8192;   // in-edges of a hub row summed by one workgroup
+constexpr int kBlock = 256;
+
+// packed frontier counter: entries in the high 28 bits, edge total in the low 36 bits
+constexpr int kPackShift = 36;
+constexpr unsigned long long kPackMask = (1ull << kPackShift) - 1ull;
+
+}  // namespace pprhip

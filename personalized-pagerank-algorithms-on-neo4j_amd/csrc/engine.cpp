@@ -1,0 +1,1379 @@
+// engine.cpp — host-side drivers of the pprhip engine: graph lift, level loop, FORA, top-k,
+// backward search.  Everything numerical runs in the HIP kernels; the host only sequences
+// launches on the handle's stream and reads back 8-byte counters between levels.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <numeric>
+
+#include "engine.hpp"
+
+using namespace pprhip;
+
+namespace {
+
+struct LevelCtx {
+  int fcur = 0;   // F/eoff buffer holding the current frontier list
+  int ccur = 0;   // dense contribution buffer holding the current level's contributions
+  int pslot = 0;  // packed counter slot describing the current frontier
+  int dslot = 0;  // dead-mass cell pending for the current level
+  uint32_t nf = 0;
+  uint64_t ef = 0;
+  bool dense_prepared = false;
+};
+
+// kernel-class timing with an event pool; resolved once per call after the final sync
+struct KernelTimer {
+  std::vector<hipEvent_t> ev;
+  struct Rec { int cls; size_t i; uint64_t bytes; };
+  std::vector<Rec> recs;
+  size_t used = 0;
+  hipStream_t stream = nullptr;
+  // events are deliberately never destroyed: this object outlives the HIP runtime at thread exit
+  hipEvent_t next() {
+    if (used == ev.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      ev.push_back(e);
+    }
+    return ev[used++];
+  }
+  void begin(int cls, uint64_t bytes) {
+    hipEvent_t a = next();
+    if (!a) return;
+    recs.push_back({cls, used - 1, bytes});
+    (void)hipEventRecord(a, stream);
+  }
+  void end() {
+    hipEvent_t b = next();
+    if (b) (void)hipEventRecord(b, stream);
+  }
+  void reset() {
+    used = 0;
+    recs.clear();
+  }
+};
+
+thread_local KernelTimer g_timer;
+
+int alloc_dev(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? PPRHIP_ERR_OOM : PPRHIP_ERR_HIP;
+  }
+  return PPRHIP_OK;
+}
+
+int read_packed(pprhip_graph* g, int slot, uint32_t* nf, uint64_t* ef) {
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->packed[slot], &g->ctr->packed[slot], sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  const unsigned long long pk = g->h_ctr->packed[slot];
+  *nf = (uint32_t)(pk >> kPackShift);
+  *ef = pk & kPackMask;
+  return PPRHIP_OK;
+}
+
+int zero_packed(pprhip_graph* g, int slot) {
+  PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->packed[slot], 0, sizeof(unsigned long long), g->stream));
+  return PPRHIP_OK;
+}
+
+int write_packed(pprhip_graph* g, int slot, uint32_t nf, uint64_t ef) {
+  g->h_ctr->packed[slot] = ((unsigned long long)nf << kPackShift) | ef;
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->ctr->packed[slot], &g->h_ctr->packed[slot], sizeof(unsigned long long),
+                                  hipMemcpyHostToDevice, g->stream));
+  return PPRHIP_OK;
+}
+
+// the same expression the oracle's twin evaluates (oracle/ppr_oracle.c level_model_cost)
+double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense) {
+  const pprhip_tuning_t& t = g->tun;
+  const bool d = (double)(ef + nf) >= t.dense_frac * (double)g->m;
+  *dense = d;
+  if (d) return t.c_level_ns + t.c_dense_edge_ns * (double)g->m + t.c_dense_node_ns * (double)g->n;
+  return t.c_level_ns + t.c_edge_ns * (double)ef + t.c_pop_ns * (double)nf;
+}
+
+uint64_t dense_level_bytes(const pprhip_graph* g) { return 12ull * g->m + 36ull * g->n + 4ull; }
+
+// Runs levels until the frontier is empty.
+int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost) {
+  const bool bwd = a.mode == kBackward;
+  while (L.nf > 0) {
+    bool dense = false;
+    const double c = level_cost(g, L.nf, L.ef, &dense);
+    if (bwd) dense = false;  // backward levels always run sparse
+    if (model_cost) *model_cost += c;
+    if (dense) {
+      if (!L.dense_prepared) {
+        PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
+        PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, L.nf, true, L.ccur, L.dslot));
+        L.dense_prepared = true;
+      }
+      const int out = L.pslot ^ 1;
+      PPRHIP_TRY(zero_packed(g, out));
+      g_timer.begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
+      PPRHIP_TRY(launch_dense_level(g, a, L.ccur, out, L.dslot));
+      g_timer.end();
+      L.ccur ^= 1;
+      L.dslot ^= 1;
+      L.pslot = out;
+      st.dense_levels++;
+      st.dense_nodes += L.nf;
+      st.push_bytes += dense_level_bytes(g);
+    } else {
+      if (L.dense_prepared) {
+        const int cs = L.pslot ^ 1;
+        PPRHIP_TRY(zero_packed(g, cs));
+        PPRHIP_TRY(launch_compact_prepared(g, L.ccur, L.fcur, cs, bwd));
+        L.pslot = cs;
+        L.dense_prepared = false;
+      } else {
+        PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, L.nf, false, 0, L.dslot));
+      }
+      const int out = L.pslot ^ 1;
+      PPRHIP_TRY(zero_packed(g, out));
+      const uint64_t bytes = 44ull * L.nf + 28ull * L.ef;
+      g_timer.begin(PPRHIP_KERNEL_SPARSE_PUSH, bytes);
+      PPRHIP_TRY(launch_sparse_push(g, a, L.fcur, &g->ctr->packed[L.pslot], L.ef, L.fcur ^ 1, out, L.dslot));
+      g_timer.end();
+      L.fcur ^= 1;
+      L.pslot = out;
+      st.pops += L.nf;
+      st.edge_pushes += L.ef;
+      st.push_bytes += bytes;
+    }
+    PPRHIP_TRY(read_packed(g, L.pslot, &L.nf, &L.ef));
+    st.levels++;
+    st.enqueues += L.nf;
+    st.push_bytes += 5ull * L.nf;
+  }
+  return PPRHIP_OK;
+}
+
+int reset_query_state(pprhip_graph* g, bool clear_flags) {
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->residue, 0, sizeof(double) * g->n, g->stream));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->reserve, 0, sizeof(double) * g->n, g->stream));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->ctr, 0, sizeof(DevCounters), g->stream));
+  if (clear_flags) PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags, 0, g->n, g->stream));
+  g->result_in_est = false;
+  return PPRHIP_OK;
+}
+
+int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree) {
+  // frontier = {node}; the first node is pushed unconditionally (Forward_Push.java:81-86)
+  g->h_ctr->pad[0] = (unsigned long long)(uint32_t)node;  // staging for the 4-byte node id
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(g->F[L.fcur], &g->h_ctr->pad[0], sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->eoff[L.fcur], 0, sizeof(uint32_t), g->stream));
+  PPRHIP_TRY(write_packed(g, L.pslot, 1, degree));
+  L.nf = 1;
+  L.ef = degree;
+  L.dense_prepared = false;
+  return PPRHIP_OK;
+}
+
+// frontier from a predicate over all nodes (round starts)
+int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
+  PPRHIP_TRY(zero_packed(g, L.pslot));
+  PPRHIP_TRY(launch_count_active(g, a, kind, L.pslot));
+  PPRHIP_TRY(read_packed(g, L.pslot, &L.nf, &L.ef));
+  L.dense_prepared = false;
+  if (L.nf == 0) {
+    if (kind == 1) {  // still drop parked nodes that fell below min_rmax (Forward_Push.java:241-247)
+      PPRHIP_TRY(zero_packed(g, L.pslot));
+      PPRHIP_TRY(launch_seed_list(g, a, kind, L.fcur, L.pslot));
+    }
+    return PPRHIP_OK;
+  }
+  bool dense = false;
+  (void)level_cost(g, L.nf, L.ef, &dense);
+  if (dense) {
+    const int scratch = L.pslot ^ 1;
+    PPRHIP_TRY(zero_packed(g, scratch));
+    PPRHIP_TRY(launch_seed_dense(g, a, kind, L.ccur, scratch, L.dslot));
+    L.dense_prepared = true;
+  } else {
+    PPRHIP_TRY(zero_packed(g, L.pslot));
+    PPRHIP_TRY(launch_seed_list(g, a, kind, L.fcur, L.pslot));
+  }
+  return PPRHIP_OK;
+}
+
+int device_sum(pprhip_graph* g, const double* x, double* out) {
+  PPRHIP_TRY(launch_sum(g, x, g->n));
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sum_out, &g->ctr->sum_out, sizeof(double), hipMemcpyDeviceToHost,
+                                  g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  *out = g->h_ctr->sum_out;
+  return PPRHIP_OK;
+}
+
+int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st) {
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->dead_pops, &g->ctr->dead_pops, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  st.dead_end_pops = g->h_ctr->dead_pops;
+  st.push_bytes += 16ull * st.dead_end_pops;
+  return PPRHIP_OK;
+}
+
+// walk phase shared by FORA whole-graph (variant 0) and top-k (variant 1)
+int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,
+                   double* target, pprhip_stats_t& st) {
+  PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->mc_packed, 0, sizeof(unsigned long long), g->stream));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->walk_steps, 0, sizeof(unsigned long long), g->stream));
+  if ((double)nrw + (double)g->n >= (double)(1ull << kPackShift)) {
+    set_error("walk budget %lld exceeds the engine's 2^36 walk limit", nrw);
+    return PPRHIP_ERR_INVALID;
+  }
+  PPRHIP_TRY(launch_mc_plan(g, variant, alpha, rsum, (double)nrw, target));
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->mc_packed, &g->ctr->mc_packed, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  const uint64_t n_src = g->h_ctr->mc_packed >> kPackShift;
+  const uint64_t n_walks = g->h_ctr->mc_packed & kPackMask;
+  g_timer.begin(PPRHIP_KERNEL_WALK, 0);
+  PPRHIP_TRY(launch_mc_walk(g, n_src, n_walks, alpha, seed, stream, variant == 0 ? 1 : 0, target));
+  g_timer.end();
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->walk_steps, &g->ctr->walk_steps, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  st.mc_sources += n_src;
+  st.walks += n_walks;
+  st.walk_steps += g->h_ctr->walk_steps;
+  const uint64_t bytes = 12ull * g->h_ctr->walk_steps + 16ull * n_walks + 12ull * n_src;
+  st.mc_bytes += bytes;
+  if (!g_timer.recs.empty() && g_timer.recs.back().cls == PPRHIP_KERNEL_WALK) g_timer.recs.back().bytes = bytes;
+  return PPRHIP_OK;
+}
+
+struct CallTimer {
+  pprhip_graph* g;
+  explicit CallTimer(pprhip_graph* g_) : g(g_) {
+    g_timer.stream = g->stream;
+    g_timer.reset();
+    (void)hipEventRecord(g->ev[0], g->stream);
+  }
+  void mark(int i) { (void)hipEventRecord(g->ev[i], g->stream); }
+  static double ms(hipEvent_t a, hipEvent_t b) {
+    float f = 0.f;
+    if (hipEventElapsedTime(&f, a, b) != hipSuccess) return 0.0;
+    return (double)f;
+  }
+  // resolves per-class kernel times; picks the class with the largest total as dominant
+  void finish(pprhip_stats_t& st) {
+    (void)hipEventRecord(g->ev[5], g->stream);
+    (void)hipStreamSynchronize(g->stream);
+    st.total_ms = ms(g->ev[0], g->ev[5]);
+    double tot[8] = {0};
+    uint64_t bytes[8] = {0};
+    uint32_t cnt[8] = {0};
+    for (auto& r : g_timer.recs) {
+      if (r.i + 1 >= g_timer.used) continue;
+      const double t = ms(g_timer.ev[r.i], g_timer.ev[r.i + 1]);
+      tot[r.cls] += t;
+      bytes[r.cls] += r.bytes;
+      cnt[r.cls]++;
+    }
+    int best = 0;
+    for (int c = 1; c < 8; ++c)
+      if (tot[c] > tot[best]) best = c;
+    st.dominant_kernel_id = (uint32_t)best;
+    st.dominant_kernel_ms = tot[best];
+    st.dominant_kernel_bytes = bytes[best];
+    st.dominant_kernel_launches = cnt[best];
+  }
+};
+
+int copy_out(pprhip_graph* g, const double* dev, double* host) {
+  if (!host) return PPRHIP_OK;
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(host, dev, sizeof(double) * g->n, hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  return PPRHIP_OK;
+}
+
+int check_graph(const pprhip_graph* g, const char* fn) {
+  if (!g) {
+    set_error("%s: null graph handle", fn);
+    return PPRHIP_ERR_INVALID;
+  }
+  hipError_t e = hipSetDevice(g->device);
+  if (e != hipSuccess) {
+    set_error("%s: hipSetDevice(%d) failed: %s", fn, g->device, hipGetErrorString(e));
+    return PPRHIP_ERR_NO_DEVICE;
+  }
+  return PPRHIP_OK;
+}
+
+int check_node(const pprhip_graph* g, int32_t v, const char* fn) {
+  if (v < 0 || (uint32_t)v >= g->n) {
+    set_error("%s: node id %d outside [0, %u)", fn, v, g->n);
+    return PPRHIP_ERR_INVALID;
+  }
+  return PPRHIP_OK;
+}
+
+uint32_t hdeg_out(const pprhip_graph* g, int32_t v) { return g->h_out_rp[v + 1] - g->h_out_rp[v]; }
+uint32_t hdeg_in(const pprhip_graph* g, int32_t v) { return g->h_in_rp[v + 1] - g->h_in_rp[v]; }
+
+// ------------------------------------------------------------------ top-k selection driver
+struct IdVal {
+  int32_t id;
+  double val;
+};
+
+int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
+                double* kth_out, bool* have_kth, pprhip_stats_t& st) {
+  std::vector<uint32_t> hist(4096);
+  unsigned long long prefix = 0;
+  int pbits = 0;
+  uint64_t k_rem = (uint64_t)k;
+  uint64_t above = 0;  // entries in bins above the chosen prefix
+  uint64_t total = 0;
+  bool have = true;
+  unsigned long long lower_bits = 1ull;  // smallest positive pattern: "everything"
+  for (int pass = 0; pbits < 64; ++pass) {
+    const int dbits = std::min(12, 64 - pbits);
+    PPRHIP_TRY(launch_select_hist(g, x, g->n, prefix, pbits, dbits));
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(hist.data(), g->hist, sizeof(uint32_t) * (1u << dbits), hipMemcpyDeviceToHost,
+                                    g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    st.select_passes++;
+    st.select_bytes += 8ull * g->n;
+    if (pass == 0) {
+      for (uint32_t b = 0; b < (1u << dbits); ++b) total += hist[b];
+      if (total == 0) {
+        *n_out = 0;
+        *have_kth = false;
+        if (kth_out) *kth_out = 0.0;
+        return PPRHIP_OK;
+      }
+      if ((uint64_t)k > total) {  // kth_ppr returns null: everything is kept (Fora_Topk.java:187-191)
+        have = false;
+        break;
+      }
+    }
+    uint64_t cum = 0;
+    int chosen = -1;
+    for (int b = (1 << dbits) - 1; b >= 0; --b) {
+      if (cum + hist[b] >= k_rem) {
+        chosen = b;
+        break;
+      }
+      cum += hist[b];
+    }
+    if (chosen < 0) {
+      set_error("select_topk: histogram inconsistent (k_rem=%llu)", (unsigned long long)k_rem);
+      return PPRHIP_ERR_STATE;
+    }
+    above += cum;
+    k_rem -= cum;
+    prefix = (prefix << dbits) | (unsigned long long)chosen;
+    pbits += dbits;
+    lower_bits = pbits < 64 ? (prefix << (64 - pbits)) : prefix;
+    if (above + hist[chosen] <= g->sel_cap) break;  // few enough candidates: finish on the host
+  }
+  PPRHIP_TRY(launch_select_gather(g, x, g->n, have ? lower_bits : 1ull));
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  st.select_bytes += 8ull * g->n;
+  uint64_t cnt = g->h_ctr->sel_count;
+  std::vector<IdVal> cand;
+  if (cnt <= g->sel_cap) {
+    std::vector<int32_t> ids(cnt);
+    std::vector<double> vals(cnt);
+    if (cnt) {
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    }
+    cand.resize(cnt);
+    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {ids[i], vals[i]};
+  } else {
+    // more ties at the k-th value than the candidate buffer holds: finish on the whole vector
+    std::vector<double> all(g->n);
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(all.data(), x, sizeof(double) * g->n, hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    const double lb = [&] { double d; std::memcpy(&d, &lower_bits, 8); return d; }();
+    for (uint32_t i = 0; i < g->n; ++i)
+      if (all[i] > 0.0 && (!have || all[i] >= lb)) cand.push_back({(int32_t)i, all[i]});
+  }
+  std::sort(cand.begin(), cand.end(), [](const IdVal& a, const IdVal& b) {
+    if (a.val != b.val) return a.val > b.val;
+    return a.id < b.id;
+  });
+  size_t n_sel = cand.size();
+  double kth = 0.0;
+  if (have) {
+    kth = cand[(size_t)k - 1].val;
+    n_sel = 0;
+    while (n_sel < cand.size() && cand[n_sel].val >= kth) ++n_sel;
+  }
+  for (size_t i = 0; i < n_sel && (int)i < cap; ++i) {
+    if (ids_out) ids_out[i] = cand[i].id;
+    if (vals_out) vals_out[i] = cand[i].val;
+  }
+  *n_out = (int)n_sel;
+  *have_kth = have;
+  if (kth_out) *kth_out = kth;
+  st.kth_value = kth;
+  return PPRHIP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int pprhip_device_count(int* count_out) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) c = 0;
+  if (count_out) *count_out = c;
+  return PPRHIP_OK;
+}
+
+void pprhip_tuning_default(pprhip_tuning_t* t) {
+  if (!t) return;
+  // keep in step with orc_tuning_default() (oracle/ppr_oracle.c); calibrated on MI355X
+  t->c_walk_ns = 0.35;
+  t->c_edge_ns = 0.06;
+  t->c_pop_ns = 0.10;
+  t->c_level_ns = 12000.0;
+  t->c_dense_edge_ns = 0.012;
+  t->c_dense_node_ns = 0.02;
+  t->dense_frac = 0.08;
+  t->max_rounds = 24;
+  t->reserved = 0;
+}
+
+int pprhip_conf_fora_whole_graph(uint32_t n, uint64_t m, double alpha, pprhip_fora_conf_t* c) {
+  if (!c || n == 0) {
+    set_error("pprhip_conf_fora_whole_graph: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  std::memset(c, 0, sizeof *c);
+  c->alpha = alpha;
+  c->delta = 1.0 / (double)n;  // Algo_Conf.java:47
+  c->pfail = 1.0 / (double)n;  // :48
+  c->rsum = 1.0;               // :49
+  c->n = n;
+  c->m = m;
+  return PPRHIP_OK;
+}
+
+int pprhip_conf_fora_topk(uint32_t n, uint64_t m, int k, double alpha, pprhip_fora_conf_t* c) {
+  if (!c || n == 0 || k < 1) {
+    set_error("pprhip_conf_fora_topk: bad arguments (n=%u k=%d)", n, k);
+    return PPRHIP_ERR_INVALID;
+  }
+  std::memset(c, 0, sizeof *c);
+  c->alpha = alpha;
+  c->min_delta = 1.0 / (double)n;  // Algo_Conf.java:73
+  c->k = k;
+  c->delta = 1.0 / (double)k;  // :75
+  c->pfail = 1.0 / (double)n / (double)n / std::log((double)((int32_t)n / k));  // :76 (int division)
+  c->rsum = 1.0;
+  c->n = n;
+  c->m = m;
+  return PPRHIP_OK;
+}
+
+int pprhip_fora_whole_params(const pprhip_fora_conf_t* c, double eps, double* rmax0, double* omega) {
+  if (!c || !rmax0 || !omega) {
+    set_error("pprhip_fora_whole_params: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  *rmax0 = eps * std::sqrt(c->delta / 3.0 / (double)c->m / std::log(2.0 / c->pfail)) / (1.0 - c->alpha);
+  *omega = (eps + 2.0) * std::log(2.0 / c->pfail) / eps / eps / c->delta;
+  return PPRHIP_OK;
+}
+
+int pprhip_fora_topk_params(const pprhip_fora_conf_t* c, double eps, double delta, double* min_rmax,
+                            double* rmax_scaled, double* omega) {
+  if (!c || !min_rmax || !rmax_scaled || !omega) {
+    set_error("pprhip_fora_topk_params: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  const double e = eps * 0.5;  // Fora_Topk.java:109-110
+  *min_rmax = e * std::sqrt(c->min_delta / 3 / (double)c->m / std::log(2 / c->pfail));  // :113
+  double rmax = e * std::sqrt(delta / 3.0 / (double)c->m / std::log(2.0 / c->pfail));     // :124
+  *omega = (e + 2.0) * std::log(2.0 / c->pfail) / e / e / delta;                           // :125
+  rmax *= std::sqrt((double)c->m * rmax) * 3.0;                                            // :133
+  *rmax_scaled = rmax;
+  return PPRHIP_OK;
+}
+
+// ------------------------------------------------------------------ graph lift
+int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out_ci, const uint32_t* in_rp,
+                        const int32_t* in_ci, int device, pprhip_graph_t** graph_out) {
+  if (!graph_out || !out_rp || (!out_ci && m) || n == 0 || n >= (1u << 28) || m >= (1ull << 32)) {
+    set_error("pprhip_graph_create: bad arguments (n=%u m=%llu; limits n < 2^28, m < 2^32)", n,
+              (unsigned long long)m);
+    return PPRHIP_ERR_INVALID;
+  }
+  if (out_rp[0] != 0 || out_rp[n] != m) {
+    set_error("pprhip_graph_create: out_row_ptr[0] must be 0 and out_row_ptr[n] must equal m");
+    return PPRHIP_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("pprhip_graph_create: no HIP device available (the engine has no CPU fallback)");
+    return PPRHIP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) {
+    set_error("pprhip_graph_create: device %d outside [0, %d)", device, ndev);
+    return PPRHIP_ERR_NO_DEVICE;
+  }
+  PPRHIP_CHECK_HIP(hipSetDevice(device));
+  for (uint64_t e = 0; e < m; ++e)
+    if (out_ci[e] < 0 || (uint32_t)out_ci[e] >= n) {
+      set_error("pprhip_graph_create: out_col_idx[%llu] = %d outside [0, %u)", (unsigned long long)e, out_ci[e], n);
+      return PPRHIP_ERR_INVALID;
+    }
+  std::unique_ptr<pprhip_graph> g(new (std::nothrow) pprhip_graph());
+  if (!g) return PPRHIP_ERR_OOM;
+  g->device = device;
+  g->n = n;
+  g->m = m;
+  pprhip_tuning_default(&g->tun);
+  g->h_out_rp.assign(out_rp, out_rp + n + 1);
+  std::vector<int32_t> in_ci_built;
+  if (in_rp && (in_ci || m == 0)) {
+    if (in_rp[0] != 0 || in_rp[n] != m) {
+      set_error("pprhip_graph_create: in_row_ptr[0] must be 0 and in_row_ptr[n] must equal m");
+      return PPRHIP_ERR_INVALID;
+    }
+    g->h_in_rp.assign(in_rp, in_rp + n + 1);
+  } else {
+    // derive the in-adjacency: edges in out-CSR order, grouped by destination
+    std::vector<int32_t> src(m);
+    for (uint32_t v = 0; v < n; ++v)
+      for (uint32_t e = out_rp[v]; e < out_rp[v + 1]; ++e) src[e] = (int32_t)v;
+    g->h_in_rp.resize((size_t)n + 1);
+    in_ci_built.resize(m);
+    int rc = pprhip_csr_build(n, m, out_ci, src.data(), 0, g->h_in_rp.data(), in_ci_built.data());
+    if (rc != PPRHIP_OK) return rc;
+    in_ci = in_ci_built.data();
+  }
+  // dense pull-sweep layout: row-aligned tiles over the in-CSR, hub rows chunked
+  std::vector<uint32_t> tile_row;
+  std::vector<int32_t> hubs;
+  std::vector<uint32_t> chunks;
+  {
+    const std::vector<uint32_t>& rp = g->h_in_rp;
+    uint32_t r = 0;
+    while (r < n) {
+      tile_row.push_back(r);
+      uint32_t d = rp[r + 1] - rp[r];
+      if (d > (uint32_t)kTileEdges) {
+        const uint32_t h = (uint32_t)hubs.size();
+        hubs.push_back((int32_t)r);
+        for (uint32_t e = rp[r]; e < rp[r + 1]; e += kHubChunk) {
+          chunks.push_back(h);
+          chunks.push_back(e);
+          chunks.push_back(std::min(rp[r + 1], e + (uint32_t)kHubChunk));
+        }
+        ++r;
+        continue;
+      }
+      uint32_t edges = 0, rows = 0;
+      while (r < n && rows < (uint32_t)kTileRows) {
+        d = rp[r + 1] - rp[r];
+        if (d > (uint32_t)kTileEdges || edges + d > (uint32_t)kTileEdges) break;
+        edges += d;
+        ++rows;
+        ++r;
+      }
+    }
+    tile_row.push_back(n);
+  }
+  g->n_tiles = (uint32_t)tile_row.size() - 1;
+  g->n_hubs = (uint32_t)hubs.size();
+  g->n_hub_chunks = (uint32_t)(chunks.size() / 3);
+
+  pprhip_graph* G = g.get();
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+    PPRHIP_TRY(alloc_dev(dst, bytes));
+    if (bytes) PPRHIP_CHECK_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return PPRHIP_OK;
+  };
+  int rc = PPRHIP_OK;
+  auto fail = [&](int code) {
+    pprhip_graph_destroy(g.release());
+    return code;
+  };
+  if ((rc = up((void**)&G->out_rp, out_rp, sizeof(uint32_t) * ((size_t)n + 1)))) return fail(rc);
+  if ((rc = up((void**)&G->out_ci, out_ci, sizeof(int32_t) * m))) return fail(rc);
+  if ((rc = up((void**)&G->in_rp, G->h_in_rp.data(), sizeof(uint32_t) * ((size_t)n + 1)))) return fail(rc);
+  if ((rc = up((void**)&G->in_ci, in_ci, sizeof(int32_t) * m))) return fail(rc);
+  if ((rc = up((void**)&G->tile_row, tile_row.data(), sizeof(uint32_t) * tile_row.size()))) return fail(rc);
+  if ((rc = up((void**)&G->hub_rows, hubs.data(), sizeof(int32_t) * hubs.size()))) return fail(rc);
+  if ((rc = up((void**)&G->hub_chunks, chunks.data(), sizeof(uint32_t) * chunks.size()))) return fail(rc);
+  const size_t nd = sizeof(double) * (size_t)n;
+  void** dbl[] = {(void**)&G->residue, (void**)&G->reserve, (void**)&G->est,    (void**)&G->cdense[0],
+                  (void**)&G->cdense[1], (void**)&G->cF,    (void**)&G->mc_inc};
+  for (void** p : dbl)
+    if ((rc = alloc_dev(p, nd))) return fail(rc);
+  if ((rc = alloc_dev((void**)&G->hubacc, sizeof(double) * std::max<size_t>(1, hubs.size())))) return fail(rc);
+  for (int i = 0; i < 2; ++i) {
+    if ((rc = alloc_dev((void**)&G->F[i], sizeof(int32_t) * (size_t)n))) return fail(rc);
+    if ((rc = alloc_dev((void**)&G->eoff[i], sizeof(uint32_t) * (size_t)n))) return fail(rc);
+  }
+  if ((rc = alloc_dev((void**)&G->flags, n))) return fail(rc);
+  if ((rc = alloc_dev((void**)&G->mc_node, sizeof(int32_t) * (size_t)n))) return fail(rc);
+  if ((rc = alloc_dev((void**)&G->mc_woff, sizeof(unsigned long long) * (size_t)n))) return fail(rc);
+  if ((rc = alloc_dev((void**)&G->partial, sizeof(double) * 1024))) return fail(rc);
+  if ((rc = alloc_dev((void**)&G->hist, sizeof(uint32_t) * 4096))) return fail(rc);
+  G->sel_cap = 1u << 18;
+  if ((rc = alloc_dev((void**)&G->sel_ids, sizeof(int32_t) * G->sel_cap))) return fail(rc);
+  if ((rc = alloc_dev((void**)&G->sel_vals, sizeof(double) * G->sel_cap))) return fail(rc);
+  if ((rc = alloc_dev((void**)&G->ctr, sizeof(DevCounters)))) return fail(rc);
+  if (hipHostMalloc((void**)&G->h_ctr, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) {
+    set_error("hipHostMalloc failed");
+    return fail(PPRHIP_ERR_OOM);
+  }
+  std::memset(G->h_ctr, 0, sizeof(DevCounters));
+  if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    return fail(PPRHIP_ERR_HIP);
+  }
+  for (auto& e : G->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      set_error("hipEventCreate failed");
+      return fail(PPRHIP_ERR_HIP);
+    }
+  (void)hipMemsetAsync(G->hubacc, 0, sizeof(double) * std::max<size_t>(1, hubs.size()), G->stream);
+  (void)hipMemsetAsync(G->est, 0, nd, G->stream);
+  (void)hipMemsetAsync(G->flags, 0, n, G->stream);
+  if (reset_query_state(G, true) != PPRHIP_OK) return fail(PPRHIP_ERR_HIP);
+  if (hipStreamSynchronize(G->stream) != hipSuccess) {
+    set_error("stream sync after graph upload failed");
+    return fail(PPRHIP_ERR_HIP);
+  }
+  *graph_out = g.release();
+  return PPRHIP_OK;
+}
+
+void pprhip_graph_destroy(pprhip_graph_t* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  void* ptrs[] = {g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->tile_row, g->hub_rows, g->hub_chunks, g->hubacc,
+                  g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1], g->eoff[0],
+                  g->eoff[1], g->flags, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist, g->sel_ids,
+                  g->sel_vals, g->ctr};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (g->h_ctr) (void)hipHostFree(g->h_ctr);
+  for (auto e : g->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  delete g;
+}
+
+int pprhip_graph_info(const pprhip_graph_t* g, uint32_t* n, uint64_t* m, int* device) {
+  if (!g) {
+    set_error("pprhip_graph_info: null graph handle");
+    return PPRHIP_ERR_INVALID;
+  }
+  if (n) *n = g->n;
+  if (m) *m = g->m;
+  if (device) *device = g->device;
+  return PPRHIP_OK;
+}
+
+int pprhip_graph_set_tuning(pprhip_graph_t* g, const pprhip_tuning_t* t) {
+  if (!g || !t) {
+    set_error("pprhip_graph_set_tuning: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_tuning_t d;
+  pprhip_tuning_default(&d);
+  g->tun = *t;
+  if (!(g->tun.c_walk_ns > 0)) g->tun.c_walk_ns = d.c_walk_ns;
+  if (!(g->tun.c_edge_ns > 0)) g->tun.c_edge_ns = d.c_edge_ns;
+  if (!(g->tun.c_pop_ns > 0)) g->tun.c_pop_ns = d.c_pop_ns;
+  if (!(g->tun.c_level_ns > 0)) g->tun.c_level_ns = d.c_level_ns;
+  if (!(g->tun.c_dense_edge_ns > 0)) g->tun.c_dense_edge_ns = d.c_dense_edge_ns;
+  if (!(g->tun.c_dense_node_ns > 0)) g->tun.c_dense_node_ns = d.c_dense_node_ns;
+  if (!(g->tun.dense_frac > 0)) g->tun.dense_frac = d.dense_frac;
+  if (g->tun.max_rounds <= 0) g->tun.max_rounds = d.max_rounds;
+  return PPRHIP_OK;
+}
+
+int pprhip_graph_get_tuning(const pprhip_graph_t* g, pprhip_tuning_t* t) {
+  if (!g || !t) {
+    set_error("pprhip_graph_get_tuning: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  *t = g->tun;
+  return PPRHIP_OK;
+}
+
+int pprhip_get_reserve(pprhip_graph_t* g, double* out) {
+  PPRHIP_TRY(check_graph(g, "pprhip_get_reserve"));
+  if (!out) {
+    set_error("pprhip_get_reserve: null output");
+    return PPRHIP_ERR_INVALID;
+  }
+  return copy_out(g, g->result_in_est ? g->est : g->reserve, out);
+}
+
+int pprhip_get_residue(pprhip_graph_t* g, double* out) {
+  PPRHIP_TRY(check_graph(g, "pprhip_get_residue"));
+  if (!out) {
+    set_error("pprhip_get_residue: null output");
+    return PPRHIP_ERR_INVALID;
+  }
+  return copy_out(g, g->residue, out);
+}
+
+// ------------------------------------------------------------------ forward push (a1)
+int pprhip_forward_push(pprhip_graph_t* g, int32_t src, double alpha, double rmax, double* reserve_out,
+                        double* residue_out, double* rsum_out, pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_forward_push"));
+  PPRHIP_TRY(check_node(g, src, "pprhip_forward_push"));
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  g->topk_active = false;
+  PPRHIP_TRY(reset_query_state(g, false));
+  CallTimer tm(g);
+  double rsum = 0.0;
+  if (hdeg_out(g, src) == 0) {  // Forward_Push.java:72-76
+    PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)src, 1.0));
+  } else {
+    PushArgs a{alpha, rmax, 0.0, src, kFwdWhole};
+    LevelCtx L;
+    PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)src, 1.0));
+    PPRHIP_TRY(seed_single(g, L, src, hdeg_out(g, src)));
+    PPRHIP_TRY(run_levels(g, a, L, st, nullptr));
+    PPRHIP_TRY(device_sum(g, g->residue, &rsum));
+    PPRHIP_TRY(read_dead_pops(g, st));
+  }
+  tm.mark(1);
+  tm.finish(st);
+  st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  st.rsum = rsum;
+  st.rmax_final = rmax;
+  st.rounds = 1;
+  if (rsum_out) *rsum_out = rsum;
+  PPRHIP_TRY(copy_out(g, g->reserve, reserve_out));
+  PPRHIP_TRY(copy_out(g, g->residue, residue_out));
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+// ------------------------------------------------------------------ resumable top-k push (a2)
+int pprhip_fwdpush_topk_reset(pprhip_graph_t* g, int32_t src, double alpha) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fwdpush_topk_reset"));
+  PPRHIP_TRY(check_node(g, src, "pprhip_fwdpush_topk_reset"));
+  PPRHIP_TRY(reset_query_state(g, true));
+  // Q = {s} (Fora_Topk.java:117-118): the source starts parked
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags + src, 1, 1, g->stream));
+  g->topk_active = true;
+  g->topk_first = true;
+  g->topk_src = src;
+  g->topk_alpha = alpha;
+  g->topk_rsum = 1.0;
+  return PPRHIP_OK;
+}
+
+static int topk_round_impl(pprhip_graph_t* g, double min_rmax, double rmax, pprhip_stats_t& st) {
+  const int32_t src = g->topk_src;
+  if (hdeg_out(g, src) == 0) {  // Forward_Push.java:149-153
+    PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)src, 1.0));
+    g->topk_rsum = 0.0;
+    return PPRHIP_OK;
+  }
+  if (g->topk_first) PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)src, 1.0));  // :155-156
+  PushArgs a{g->topk_alpha, rmax, min_rmax, src, kFwdTopk};
+  LevelCtx L;
+  PPRHIP_TRY(seed_scan(g, a, 1, L));
+  PPRHIP_TRY(run_levels(g, a, L, st, nullptr));
+  PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
+  g->topk_first = false;
+  return PPRHIP_OK;
+}
+
+int pprhip_fwdpush_topk_round(pprhip_graph_t* g, double min_rmax, double rmax, double* rsum_out,
+                              pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fwdpush_topk_round"));
+  if (!g->topk_active) {
+    set_error("pprhip_fwdpush_topk_round: call pprhip_fwdpush_topk_reset first");
+    return PPRHIP_ERR_STATE;
+  }
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  CallTimer tm(g);
+  PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax, st));
+  PPRHIP_TRY(read_dead_pops(g, st));
+  tm.mark(1);
+  tm.finish(st);
+  st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  st.rsum = g->topk_rsum;
+  st.rmax_final = rmax;
+  st.rounds = 1;
+  if (rsum_out) *rsum_out = g->topk_rsum;
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+// ------------------------------------------------------------------ walker exposure (a3, a4)
+int pprhip_random_walk_batch(pprhip_graph_t* g, const int32_t* starts, const uint64_t* walk_idx, uint64_t count,
+                             double alpha, uint64_t seed, uint32_t stream, int no_zero_hop, int32_t* terminals_out,
+                             uint32_t* steps_out) {
+  PPRHIP_TRY(check_graph(g, "pprhip_random_walk_batch"));
+  if ((!starts || !walk_idx || !terminals_out) && count) {
+    set_error("pprhip_random_walk_batch: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  if (stream >= 65536) {
+    set_error("pprhip_random_walk_batch: stream must be < 65536");
+    return PPRHIP_ERR_INVALID;
+  }
+  for (uint64_t i = 0; i < count; ++i) PPRHIP_TRY(check_node(g, starts[i], "pprhip_random_walk_batch"));
+  if (count == 0) return PPRHIP_OK;
+  int32_t *d_s = nullptr, *d_t = nullptr;
+  uint64_t* d_i = nullptr;
+  uint32_t* d_n = nullptr;
+  int rc = PPRHIP_OK;
+  if ((rc = alloc_dev((void**)&d_s, sizeof(int32_t) * count)) || (rc = alloc_dev((void**)&d_t, sizeof(int32_t) * count)) ||
+      (rc = alloc_dev((void**)&d_i, sizeof(uint64_t) * count)) || (rc = alloc_dev((void**)&d_n, sizeof(uint32_t) * count))) {
+    (void)hipFree(d_s); (void)hipFree(d_t); (void)hipFree(d_i); (void)hipFree(d_n);
+    return rc;
+  }
+  auto done = [&](int code) {
+    (void)hipFree(d_s); (void)hipFree(d_t); (void)hipFree(d_i); (void)hipFree(d_n);
+    return code;
+  };
+  if (hipMemcpyAsync(d_s, starts, sizeof(int32_t) * count, hipMemcpyHostToDevice, g->stream) != hipSuccess ||
+      hipMemcpyAsync(d_i, walk_idx, sizeof(uint64_t) * count, hipMemcpyHostToDevice, g->stream) != hipSuccess) {
+    set_error("pprhip_random_walk_batch: upload failed");
+    return done(PPRHIP_ERR_HIP);
+  }
+  rc = launch_walk_batch(g, d_s, d_i, count, alpha, seed, stream, no_zero_hop, d_t, d_n);
+  if (rc) return done(rc);
+  if (hipMemcpyAsync(terminals_out, d_t, sizeof(int32_t) * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+      (steps_out &&
+       hipMemcpyAsync(steps_out, d_n, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess) ||
+      hipStreamSynchronize(g->stream) != hipSuccess) {
+    set_error("pprhip_random_walk_batch: download failed: %s", hipGetErrorString(hipGetLastError()));
+    return done(PPRHIP_ERR_HIP);
+  }
+  return done(PPRHIP_OK);
+}
+
+// ------------------------------------------------------------------ FORA whole graph (a5)
+int pprhip_fora_single_source(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf,
+                              uint64_t seed, int n_rounds, double* reserve_out, pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fora_single_source"));
+  PPRHIP_TRY(check_node(g, src, "pprhip_fora_single_source"));
+  if (!conf || !(eps > 0.0) || n_rounds < 0) {
+    set_error("pprhip_fora_single_source: bad arguments (eps=%g n_rounds=%d)", eps, n_rounds);
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  g->topk_active = false;
+  PPRHIP_TRY(reset_query_state(g, false));
+  CallTimer tm(g);
+  const double alpha = conf->alpha;
+  double rsum_local = conf->rsum, rmax_local = 0.0, omega_local = 0.0;
+  PPRHIP_TRY(pprhip_fora_whole_params(conf, eps, &rmax_local, &omega_local));  // Fora_Whole_Graph.java:86-87
+  double rmax_used = rmax_local;
+  double model_cost = 0.0;
+  int rounds = 0;
+  const bool dead_src = hdeg_out(g, src) == 0;
+  LevelCtx L;
+  for (;;) {  // Fora_Whole_Graph.java:93-103, clock replaced by the level cost model
+    const bool more = n_rounds > 0
+                          ? rounds < n_rounds
+                          : (model_cost < g->tun.c_walk_ns * rsum_local * omega_local && rounds < g->tun.max_rounds);
+    if (!more) break;
+    if (dead_src) {  // Forward_Push.java:72-76
+      PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)src, 1.0));
+      rsum_local = 0.0;
+      rmax_used = rmax_local;
+      rounds++;
+      break;
+    }
+    PushArgs a{alpha, rmax_local, 0.0, src, kFwdWhole};
+    if (rounds == 0) {
+      PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)src, 1.0));
+      PPRHIP_TRY(seed_single(g, L, src, hdeg_out(g, src)));
+    } else {
+      PPRHIP_TRY(seed_scan(g, a, 0, L));
+    }
+    PPRHIP_TRY(run_levels(g, a, L, st, &model_cost));
+    double sum = 0.0;
+    PPRHIP_TRY(device_sum(g, g->residue, &sum));
+    rsum_local = sum * (1 - alpha);  // :101 (rsum is the exact residue sum here)
+    rmax_used = rmax_local;
+    rmax_local /= 2.0;  // :102
+    rounds++;
+    if (n_rounds > 0 && !(rsum_local > 0.0)) break;
+  }
+  PPRHIP_TRY(read_dead_pops(g, st));
+  tm.mark(1);
+  // Fora_Whole_Graph.java:112-140
+  const double nrw_d = omega_local * rsum_local;
+  const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;
+  if (!dead_src) PPRHIP_TRY(run_walk_phase(g, 0, alpha, rsum_local, nrw, seed, 0, g->reserve, st));
+  tm.mark(2);
+  tm.finish(st);
+  st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  st.mc_ms = CallTimer::ms(g->ev[1], g->ev[2]);
+  st.rounds = (uint32_t)rounds;
+  st.rsum = rsum_local;
+  st.rmax_final = rmax_used;
+  st.omega = omega_local;
+  PPRHIP_TRY(copy_out(g, g->reserve, reserve_out));
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+// ------------------------------------------------------------------ top-k select (a7)
+int pprhip_topk_select(pprhip_graph_t* g, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
+                       double* kth_out, pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_topk_select"));
+  if (k < 1 || cap < 0 || !n_out || (cap > 0 && (!ids_out || !vals_out))) {
+    set_error("pprhip_topk_select: bad arguments (k=%d cap=%d)", k, cap);
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  CallTimer tm(g);
+  bool have = false;
+  PPRHIP_TRY(select_topk(g, g->result_in_est ? g->est : g->reserve, k, ids_out, vals_out, cap, n_out, kth_out, &have,
+                         st));
+  tm.mark(1);
+  tm.finish(st);
+  st.select_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+// ------------------------------------------------------------------ FORA top-k (a6)
+int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf, uint64_t seed,
+                     int32_t* ids_out, double* vals_out, int cap, int* n_out, double* reserve_out,
+                     pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fora_topk"));
+  PPRHIP_TRY(check_node(g, src, "pprhip_fora_topk"));
+  if (!conf || conf->k < 1 || !(eps > 0.0) || cap < 0 || (cap > 0 && (!ids_out || !vals_out))) {
+    set_error("pprhip_fora_topk: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  PPRHIP_TRY(pprhip_fwdpush_topk_reset(g, src, conf->alpha));
+  g->topk_rsum = conf->rsum;
+  CallTimer tm(g);
+  const double alpha = conf->alpha;
+  const double epsilon = eps * 0.5;  // Fora_Topk.java:109-110
+  double delta_local = conf->delta;
+  const double min_delta = conf->min_delta;
+  const double min_rmax = epsilon * std::sqrt(min_delta / 3 / (double)conf->m / std::log(2 / conf->pfail));  // :113
+  double rsum_local = conf->rsum, omega_local = 0.0, rmax_local = 0.0;
+  double push_ms = 0.0, mc_ms = 0.0, sel_ms = 0.0;
+  uint32_t round = 0;
+  const size_t nd = sizeof(double) * (size_t)g->n;
+  bool dead_src = false;
+  while (delta_local >= min_delta) {  // :123
+    rmax_local = epsilon * std::sqrt(delta_local / 3.0 / (double)conf->m / std::log(2.0 / conf->pfail));  // :124
+    omega_local = (epsilon + 2.0) * std::log(2.0 / conf->pfail) / epsilon / epsilon / delta_local;          // :125
+    if (hdeg_out(g, src) == 0) {  // :126-132
+      PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
+      PPRHIP_TRY(launch_set_f64(g, g->est, (uint32_t)src, 1.0));
+      rsum_local = 0.0;
+      dead_src = true;
+      break;
+    }
+    rmax_local *= std::sqrt((double)conf->m * rmax_local) * 3.0;  // :133
+    (void)hipEventRecord(g->ev[1], g->stream);
+    PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax_local, st));  // :137
+    rsum_local = g->topk_rsum;                                 // :142
+    (void)hipEventRecord(g->ev[2], g->stream);
+    // :143 reserve := copy of the push reserve (walk increments of earlier rounds are dropped)
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
+    const double rsum_rw = rsum_local * (1.0 - alpha);  // :148
+    const double nrw_d = omega_local * rsum_rw;
+    const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;  // :151
+    PPRHIP_TRY(run_walk_phase(g, 1, alpha, rsum_rw, nrw, seed, round, g->est, st));  // :155-168
+    (void)hipEventRecord(g->ev[3], g->stream);
+    round++;
+    double kth = 0.0;
+    bool have = false;
+    int nsel = 0;
+    PPRHIP_TRY(select_topk(g, g->est, conf->k, nullptr, nullptr, 0, &nsel, &kth, &have, st));  // :173
+    if (!have) kth = 0.0;                                                                        // :174
+    (void)hipEventRecord(g->ev[4], g->stream);
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    push_ms += CallTimer::ms(g->ev[1], g->ev[2]);
+    mc_ms += CallTimer::ms(g->ev[2], g->ev[3]);
+    sel_ms += CallTimer::ms(g->ev[3], g->ev[4]);
+    st.kth_value = kth;
+    if (kth >= (1 + epsilon) * delta_local || delta_local <= min_delta) break;  // :175-176
+    delta_local = std::max(min_delta, delta_local / 4.0);                       // :178
+  }
+  if (round == 0 && !dead_src) {  // delta below min_delta from the start: nothing ran
+    PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
+  }
+  g->result_in_est = true;
+  PPRHIP_TRY(read_dead_pops(g, st));
+  int nsel = 0;
+  bool have = false;
+  double kth = 0.0;
+  (void)hipEventRecord(g->ev[3], g->stream);
+  PPRHIP_TRY(select_topk(g, g->est, conf->k, ids_out, vals_out, cap, &nsel, &kth, &have, st));
+  (void)hipEventRecord(g->ev[4], g->stream);
+  tm.finish(st);
+  sel_ms += CallTimer::ms(g->ev[3], g->ev[4]);
+  st.push_ms = push_ms;
+  st.mc_ms = mc_ms;
+  st.select_ms = sel_ms;
+  st.rounds = round;
+  st.rsum = rsum_local;
+  st.rmax_final = rmax_local;
+  st.omega = omega_local;
+  if (n_out) *n_out = nsel;
+  PPRHIP_TRY(copy_out(g, g->est, reserve_out));
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k, double eps, double alpha,
+                           uint64_t seed, int32_t* ids_out, double* vals_out, pprhip_stats_t* stats_sum) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_topk"));
+  if (q < 0 || k < 1 || (q > 0 && (!srcs || !ids_out || !vals_out))) {
+    set_error("pprhip_fora_batch_topk: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_fora_conf_t conf;
+  PPRHIP_TRY(pprhip_conf_fora_topk(g->n, g->m, k, alpha, &conf));
+  pprhip_stats_t sum;
+  std::memset(&sum, 0, sizeof sum);
+  for (int i = 0; i < q; ++i) {
+    pprhip_stats_t st;
+    int nsel = 0;
+    int32_t* ids = ids_out + (size_t)i * k;
+    double* vals = vals_out + (size_t)i * k;
+    PPRHIP_TRY(pprhip_fora_topk(g, srcs[i], eps, &conf, seed + (uint64_t)i, ids, vals, k, &nsel, nullptr, &st));
+    for (int j = std::min(nsel, k); j < k; ++j) {
+      ids[j] = -1;
+      vals[j] = 0.0;
+    }
+    sum.pops += st.pops; sum.edge_pushes += st.edge_pushes; sum.enqueues += st.enqueues;
+    sum.dead_end_pops += st.dead_end_pops; sum.dense_nodes += st.dense_nodes; sum.levels += st.levels;
+    sum.dense_levels += st.dense_levels; sum.rounds += st.rounds; sum.mc_sources += st.mc_sources;
+    sum.walks += st.walks; sum.walk_steps += st.walk_steps; sum.select_passes += st.select_passes;
+    sum.push_ms += st.push_ms; sum.mc_ms += st.mc_ms; sum.select_ms += st.select_ms; sum.total_ms += st.total_ms;
+    sum.push_bytes += st.push_bytes; sum.mc_bytes += st.mc_bytes; sum.select_bytes += st.select_bytes;
+  }
+  if (stats_sum) *stats_sum = sum;
+  return PPRHIP_OK;
+}
+
+// ------------------------------------------------------------------ pure Monte-Carlo
+int pprhip_monte_carlo(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf, uint64_t seed,
+                       double* ppr_out, pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_monte_carlo"));
+  PPRHIP_TRY(check_node(g, src, "pprhip_monte_carlo"));
+  if (!conf || !(eps > 0.0)) {
+    set_error("pprhip_monte_carlo: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  g->topk_active = false;
+  PPRHIP_TRY(reset_query_state(g, false));
+  CallTimer tm(g);
+  const double omega = 3 * std::log(2 / conf->pfail) / eps / eps / conf->delta;  // Monte_Carlo.java:145
+  const uint64_t nw = (uint64_t)std::floor(omega);                                // :149 (i <= omega)
+  if (nw >= (1ull << kPackShift)) {
+    set_error("pprhip_monte_carlo: %llu walks exceed the engine's 2^36 limit", (unsigned long long)nw);
+    return PPRHIP_ERR_INVALID;
+  }
+  if (hdeg_out(g, src) == 0) {
+    PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)src, (double)nw / omega));  // every walk returns src (:70-72)
+    st.walks = nw;
+  } else {
+    PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->walk_steps, 0, sizeof(unsigned long long), g->stream));
+    g_timer.begin(PPRHIP_KERNEL_WALK, 0);
+    PPRHIP_TRY(launch_mc_pure(g, src, nw, conf->alpha, seed, 1.0 / omega, g->reserve));
+    g_timer.end();
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->walk_steps, &g->ctr->walk_steps, sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    st.walks = nw;
+    st.walk_steps = g->h_ctr->walk_steps;
+    st.mc_bytes = 12ull * st.walk_steps + 16ull * nw + 12ull;
+    if (!g_timer.recs.empty()) g_timer.recs.back().bytes = st.mc_bytes;
+  }
+  st.mc_sources = 1;
+  st.omega = omega;
+  tm.mark(1);
+  tm.finish(st);
+  st.mc_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  PPRHIP_TRY(copy_out(g, g->reserve, ppr_out));
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+// ------------------------------------------------------------------ backward search (a8)
+static int backward_push_impl(pprhip_graph_t* g, int32_t target, double alpha, double rmax, pprhip_stats_t& st) {
+  PPRHIP_TRY(reset_query_state(g, false));
+  if (hdeg_in(g, target) == 0) {  // Backward_Search.java:46-49
+    PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)target, 1.0));
+    return PPRHIP_OK;
+  }
+  PushArgs a{alpha, rmax, 0.0, target, kBackward};
+  LevelCtx L;
+  PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)target, 1.0));
+  PPRHIP_TRY(seed_single(g, L, target, hdeg_in(g, target)));
+  PPRHIP_TRY(run_levels(g, a, L, st, nullptr));
+  return PPRHIP_OK;
+}
+
+int pprhip_backward_push(pprhip_graph_t* g, int32_t target, double alpha, double rmax, double* reserve_out,
+                         double* residue_out, pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_backward_push"));
+  PPRHIP_TRY(check_node(g, target, "pprhip_backward_push"));
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  g->topk_active = false;
+  CallTimer tm(g);
+  PPRHIP_TRY(backward_push_impl(g, target, alpha, rmax, st));
+  tm.mark(1);
+  tm.finish(st);
+  st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  st.rmax_final = rmax;
+  st.rounds = 1;
+  PPRHIP_TRY(copy_out(g, g->reserve, reserve_out));
+  PPRHIP_TRY(copy_out(g, g->residue, residue_out));
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+// ------------------------------------------------------------------ ground truth (a12)
+int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters, double* reserve_out,
+                        pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_power_method"));
+  PPRHIP_TRY(check_node(g, src, "pprhip_power_method"));
+  if (iters < 0) {
+    set_error("pprhip_power_method: iters must be >= 0");
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  g->topk_active = false;
+  PPRHIP_TRY(reset_query_state(g, false));
+  CallTimer tm(g);
+  if (iters > 0) {
+    // iteration 1 (Power_Method.java:59-96 with residue = {s: 1})
+    LevelCtx L;
+    PushArgs a{alpha, 0.0, 0.0, src, kPower};
+    PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
+    PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)src, 1.0 * alpha));
+    const uint32_t d = hdeg_out(g, src);
+    const double remain = 1.0 * (1 - alpha);
+    if (d == 0)
+      PPRHIP_TRY(launch_set_f64(g, &g->ctr->dead[L.dslot], 0, remain));
+    else
+      PPRHIP_TRY(launch_set_f64(g, g->cdense[L.ccur], (uint32_t)src, remain / (double)d));
+    for (int it = 1; it < iters; ++it) {
+      const int out = L.pslot ^ 1;
+      PPRHIP_TRY(zero_packed(g, out));
+      g_timer.begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
+      PPRHIP_TRY(launch_dense_level(g, a, L.ccur, out, L.dslot));
+      g_timer.end();
+      L.ccur ^= 1;
+      L.dslot ^= 1;
+      L.pslot = out;
+      st.dense_levels++;
+      st.levels++;
+      st.push_bytes += dense_level_bytes(g);
+    }
+  }
+  tm.mark(1);
+  tm.finish(st);
+  st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  st.rounds = (uint32_t)iters;
+  PPRHIP_TRY(copy_out(g, g->reserve, reserve_out));
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// All-Pair-Backward-Search (a9) — first correct path: one backward search per target on the
+// global arrays, entries >= threshold compacted on the device, inverted index built on the host.
+// =================================================================================================
+struct pprhip_index {
+  uint32_t n = 0;
+  std::vector<uint64_t> offsets;
+  std::vector<int32_t> targets;
+  std::vector<double> values;
+};
+
+namespace {
+
+struct Triple {
+  int32_t v, t;
+  double p;
+};
+
+// Base_Whole_Graph.java:112-163: per source, k < 0 keeps insertion (target) order; k >= 0 keeps
+// entries >= the k-th largest (all when fewer than k) sorted descending (stable: ties stay in
+// target order).
+void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix) {
+  ix->n = n;
+  ix->offsets.assign((size_t)n + 1, 0);
+  std::stable_sort(tr.begin(), tr.end(), [](const Triple& a, const Triple& b) {
+    if (a.v != b.v) return a.v < b.v;
+    return a.t < b.t;
+  });
+  ix->targets.clear();
+  ix->values.clear();
+  size_t i = 0;
+  for (uint32_t v = 0; v < n; ++v) {
+    ix->offsets[v] = ix->targets.size();
+    size_t b = i;
+    while (i < tr.size() && (uint32_t)tr[i].v == v) ++i;
+    const size_t len = i - b;
+    if (len == 0) continue;
+    if (k < 0) {
+      for (size_t j = b; j < i; ++j) {
+        ix->targets.push_back(tr[j].t);
+        ix->values.push_back(tr[j].p);
+      }
+      continue;
+    }
+    bool have = false;
+    double kth = 0.0;
+    if (k >= 1 && (size_t)k <= len) {
+      std::vector<double> tmp(len);
+      for (size_t j = 0; j < len; ++j) tmp[j] = tr[b + j].p;
+      std::nth_element(tmp.begin(), tmp.begin() + (k - 1), tmp.end(), std::greater<double>());
+      kth = tmp[k - 1];
+      have = true;
+    }
+    std::vector<Triple> keep;
+    for (size_t j = b; j < i; ++j)
+      if (!have || tr[j].p >= kth) keep.push_back(tr[j]);
+    std::stable_sort(keep.begin(), keep.end(), [](const Triple& a, const Triple& b2) { return a.p > b2.p; });
+    for (auto& e : keep) {
+      ix->targets.push_back(e.t);
+      ix->values.push_back(e.p);
+    }
+  }
+  ix->offsets[n] = ix->targets.size();
+}
+
+}  // namespace
+
+extern "C" {
+
+int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, int k, uint32_t t_begin, uint32_t t_end,
+                             pprhip_index_t** index_out, pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_all_pair_backward"));
+  if (!index_out || t_begin > t_end || t_end > g->n) {
+    set_error("pprhip_all_pair_backward: bad target range [%u, %u) for n=%u", t_begin, t_end, g->n);
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  g->topk_active = false;
+  CallTimer tm(g);
+  std::vector<Triple> tr;
+  unsigned long long thr_bits = 1ull;
+  if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
+  std::vector<int32_t> ids(g->sel_cap);
+  std::vector<double> vals(g->sel_cap);
+  for (uint32_t t = t_begin; t < t_end; ++t) {  // Base_Whole_Graph.java:76-92
+    PPRHIP_TRY(backward_push_impl(g, (int32_t)t, alpha, threshold, st));
+    PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits));  // :83 pi >= threshold
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    const uint64_t cnt = g->h_ctr->sel_count;
+    if (cnt > g->sel_cap) {
+      std::vector<double> all(g->n);
+      PPRHIP_TRY(copy_out(g, g->reserve, all.data()));
+      for (uint32_t v = 0; v < g->n; ++v)
+        if (all[v] > 0.0 && all[v] >= threshold) tr.push_back({(int32_t)v, (int32_t)t, all[v]});
+    } else if (cnt) {
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      for (uint64_t i = 0; i < cnt; ++i) tr.push_back({ids[i], (int32_t)t, vals[i]});
+    }
+  }
+  tm.mark(1);
+  tm.finish(st);
+  st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  st.rmax_final = threshold;
+  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
+  if (!ix) return PPRHIP_ERR_OOM;
+  finalize_rows(g->n, tr, k, ix.get());
+  *index_out = ix.release();
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+int pprhip_index_merge(const pprhip_index_t* const* shards, int n_shards, int k, pprhip_index_t** merged_out) {
+  if (!shards || n_shards < 1 || !merged_out) {
+    set_error("pprhip_index_merge: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  const uint32_t n = shards[0]->n;
+  std::vector<Triple> tr;
+  for (int s = 0; s < n_shards; ++s) {
+    if (!shards[s] || shards[s]->n != n) {
+      set_error("pprhip_index_merge: shard %d does not match", s);
+      return PPRHIP_ERR_INVALID;
+    }
+    for (uint32_t v = 0; v < n; ++v)
+      for (uint64_t i = shards[s]->offsets[v]; i < shards[s]->offsets[v + 1]; ++i)
+        tr.push_back({(int32_t)v, shards[s]->targets[i], shards[s]->values[i]});
+  }
+  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
+  if (!ix) return PPRHIP_ERR_OOM;
+  finalize_rows(n, tr, k, ix.get());
+  *merged_out = ix.release();
+  return PPRHIP_OK;
+}
+
+int pprhip_index_info(const pprhip_index_t* ix, uint32_t* n, uint64_t* entries) {
+  if (!ix) {
+    set_error("pprhip_index_info: null index");
+    return PPRHIP_ERR_INVALID;
+  }
+  if (n) *n = ix->n;
+  if (entries) *entries = ix->targets.size();
+  return PPRHIP_OK;
+}
+
+int pprhip_index_arrays(const pprhip_index_t* ix, const uint64_t** offsets, const int32_t** targets,
+                        const double** values) {
+  if (!ix || !offsets || !targets || !values) {
+    set_error("pprhip_index_arrays: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  *offsets = ix->offsets.data();
+  *targets = ix->targets.data();
+  *values = ix->values.data();
+  return PPRHIP_OK;
+}
+
+void pprhip_index_destroy(pprhip_index_t* ix) { delete ix; }
+
+}  // extern "C"

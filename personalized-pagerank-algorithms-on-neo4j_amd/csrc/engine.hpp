@@ -1,0 +1,109 @@
+// engine.hpp — device-resident graph handle and the kernel launchers the drivers call.
+#pragma once
+
+#include "common.hpp"
+
+namespace pprhip {
+
+// Device-side counter block (one per graph handle), mirrored into pinned host memory.
+struct DevCounters {
+  unsigned long long packed[2];   // frontier being produced: entries << 36 | edge total
+  double dead[2];                 // dead-end mass waiting to land on the source
+  unsigned long long dead_pops;   // pushed nodes with out-degree 0
+  unsigned long long mc_packed;   // walk plan: sources << 36 | walks
+  unsigned long long walk_steps;  // edges followed by walks
+  unsigned long long sel_count;   // top-k candidate count
+  double sum_out;                 // reduction result
+  unsigned long long pad[7];
+};
+
+enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
+
+struct PushArgs {
+  double alpha;
+  double rmax;
+  double min_rmax;  // kFwdTopk only
+  int32_t src;      // source (forward) or target (backward)
+  int mode;
+};
+
+}  // namespace pprhip
+
+struct pprhip_graph {
+  int device = 0;
+  uint32_t n = 0;
+  uint64_t m = 0;
+  hipStream_t stream = nullptr;
+  // CSR pair in HBM: uint32 row pointers, int32 column indices
+  uint32_t *out_rp = nullptr, *in_rp = nullptr;
+  int32_t *out_ci = nullptr, *in_ci = nullptr;
+  std::vector<uint32_t> h_out_rp, h_in_rp;  // host copies for degree checks on the call path
+  // dense pull-sweep layout over the in-CSR
+  uint32_t* tile_row = nullptr;  // n_tiles + 1 row boundaries
+  uint32_t n_tiles = 0;
+  int32_t* hub_rows = nullptr;  // rows with in-degree > kTileEdges
+  uint32_t n_hubs = 0;
+  uint32_t* hub_chunks = nullptr;  // triples (hub index, edge begin, edge end)
+  uint32_t n_hub_chunks = 0;
+  double* hubacc = nullptr;
+  // per-query state
+  double *residue = nullptr, *reserve = nullptr, *est = nullptr;
+  double* cdense[2] = {nullptr, nullptr};
+  double* cF = nullptr;
+  int32_t* F[2] = {nullptr, nullptr};
+  uint32_t* eoff[2] = {nullptr, nullptr};
+  uint8_t* flags = nullptr;
+  // walk plan
+  int32_t* mc_node = nullptr;
+  double* mc_inc = nullptr;
+  unsigned long long* mc_woff = nullptr;
+  // reductions / selection scratch
+  double* partial = nullptr;       // 1024 partial sums
+  uint32_t* hist = nullptr;        // 4096-bin histogram
+  int32_t* sel_ids = nullptr;      // candidate list
+  double* sel_vals = nullptr;
+  uint32_t sel_cap = 0;
+  pprhip::DevCounters* ctr = nullptr;    // device
+  pprhip::DevCounters* h_ctr = nullptr;  // pinned host mirror
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  pprhip_tuning_t tun{};
+  // resumable top-k push session (Forward_Push object state)
+  bool topk_active = false;
+  bool topk_first = true;
+  int32_t topk_src = -1;
+  double topk_alpha = 0.0;
+  double topk_rsum = 1.0;
+  // what `reserve`/`est` currently hold
+  bool result_in_est = false;
+};
+
+namespace pprhip {
+
+// ---- kernels_push.hip
+int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, uint32_t nf, bool scatter_dense, int cbuf,
+                          int dead_slot);
+int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, const unsigned long long* d_in_counter,
+                       uint64_t ef_upper, int out_fbuf, int out_slot, int dead_slot);
+int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot);
+int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, int out_slot, bool backward);
+int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot);
+int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, int out_slot);
+int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbuf, int out_slot, int dead_slot);
+int launch_sum(pprhip_graph* g, const double* x, uint32_t n);  // result -> ctr->sum_out
+int launch_set_f64(pprhip_graph* g, double* p, uint32_t idx, double value);
+
+// ---- kernels_walk.hip
+int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double* target);
+int launch_mc_walk(pprhip_graph* g, uint64_t n_sources, uint64_t n_walks, double alpha, uint64_t seed, uint32_t stream,
+                   int no_zero_hop, double* target);
+int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* d_idx, uint64_t count, double alpha,
+                      uint64_t seed, uint32_t stream, int no_zero_hop, int32_t* d_term, uint32_t* d_steps);
+int launch_mc_pure(pprhip_graph* g, int32_t src, uint64_t n_walks, double alpha, uint64_t seed, double inc,
+                   double* target);
+
+// ---- kernels_select.hip
+int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned long long prefix, int prefix_bits,
+                       int digit_bits);
+int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits);
+
+}  // namespace pprhip

@@ -1,0 +1,236 @@
+// ingest.cpp — host-side graph ingest: seeded R-MAT generator, neo4j-admin-import CSV reader and
+// CSR construction.  This is the data-format side of the graph lift (PPR.java:136-152 loads the
+// Neo4j store into HeavyGraph's two jagged adjacency arrays); nothing here touches the GPU.
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "common.hpp"
+
+namespace pprhip {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+const char* get_error() { return g_error.c_str(); }
+
+static inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+static unsigned worker_count() {
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 4;
+  return std::min(hw, 32u);
+}
+
+}  // namespace pprhip
+
+using namespace pprhip;
+
+struct pprhip_edgelist {
+  uint32_t n = 0;
+  std::vector<int32_t> src, dst;
+  std::vector<std::string> names;
+};
+
+extern "C" {
+
+const char* pprhip_last_error(void) { return get_error(); }
+int pprhip_version(void) { return PPRHIP_VERSION; }
+
+int pprhip_rmat_edges(int scale, int edge_factor, uint64_t seed, int32_t* src_out, int32_t* dst_out) {
+  if (scale < 1 || scale > 30 || edge_factor < 1 || !src_out || !dst_out) {
+    set_error("pprhip_rmat_edges: bad arguments (scale=%d edge_factor=%d)", scale, edge_factor);
+    return PPRHIP_ERR_INVALID;
+  }
+  const uint64_t n = 1ull << scale;
+  const uint64_t m = (uint64_t)edge_factor << scale;
+  // seeded label scramble (Fisher-Yates on a splitmix64 stream)
+  std::vector<int32_t> perm(n);
+  for (uint64_t i = 0; i < n; ++i) perm[i] = (int32_t)i;
+  uint64_t st = splitmix64(seed ^ 0x5851F42D4C957F2Dull);
+  for (uint64_t i = n - 1; i > 0; --i) {
+    st = splitmix64(st);
+    uint64_t j = (uint64_t)(((unsigned __int128)st * (i + 1)) >> 64);
+    std::swap(perm[i], perm[j]);
+  }
+  // Graph500 quadrant probabilities as 32-bit thresholds
+  const uint32_t ta = (uint32_t)(0.57 * 4294967296.0);
+  const uint32_t tab = (uint32_t)((0.57 + 0.19) * 4294967296.0);
+  const uint32_t tabc = (uint32_t)((0.57 + 0.19 + 0.19) * 4294967296.0);
+  const uint64_t key = splitmix64(seed);
+  auto work = [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t e = lo; e < hi; ++e) {
+      uint32_t u = 0, v = 0;
+      uint64_t word = 0;
+      for (int l = 0; l < scale; ++l) {
+        if ((l & 1) == 0) word = splitmix64(key ^ (e * 32ull + (uint64_t)(l >> 1)) * 0xD1342543DE82EF95ull);
+        uint32_t r = (l & 1) ? (uint32_t)(word >> 32) : (uint32_t)word;
+        uint32_t ub = r >= tab;                             // quadrants c, d: source bit set
+        uint32_t vb = (r >= ta && r < tab) || (r >= tabc);  // quadrants b, d: destination bit set
+        u = (u << 1) | ub;
+        v = (v << 1) | vb;
+      }
+      src_out[e] = perm[u];
+      dst_out[e] = perm[v];
+    }
+  };
+  unsigned nt = worker_count();
+  std::vector<std::thread> th;
+  uint64_t chunk = (m + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    uint64_t lo = t * chunk, hi = std::min(m, lo + chunk);
+    if (lo < hi) th.emplace_back(work, lo, hi);
+  }
+  for (auto& t : th) t.join();
+  return PPRHIP_OK;
+}
+
+static bool read_lines(const char* path, std::vector<std::string>& lines) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::string s;
+  while (std::getline(f, s)) {
+    while (!s.empty() && (s.back() == '\r' || s.back() == '\n')) s.pop_back();
+    lines.push_back(s);
+  }
+  if (!lines.empty() && lines[0].size() >= 3 && (unsigned char)lines[0][0] == 0xEF &&
+      (unsigned char)lines[0][1] == 0xBB && (unsigned char)lines[0][2] == 0xBF)
+    lines[0].erase(0, 3);  // UTF-8 byte-order mark (GOT_Nodes.csv has one)
+  return true;
+}
+
+static std::string field(const std::string& line, int idx) {
+  size_t b = 0;
+  for (int i = 0; i < idx; ++i) {
+    b = line.find(',', b);
+    if (b == std::string::npos) return std::string();
+    ++b;
+  }
+  size_t e = line.find(',', b);
+  return line.substr(b, e == std::string::npos ? std::string::npos : e - b);
+}
+
+int pprhip_edgelist_from_neo4j_csv(const char* nodes_csv, const char* rels_csv, pprhip_edgelist_t** out) {
+  if (!nodes_csv || !rels_csv || !out) {
+    set_error("pprhip_edgelist_from_neo4j_csv: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  std::vector<std::string> nl, rl;
+  if (!read_lines(nodes_csv, nl)) {
+    set_error("cannot read %s", nodes_csv);
+    return PPRHIP_ERR_IO;
+  }
+  if (!read_lines(rels_csv, rl)) {
+    set_error("cannot read %s", rels_csv);
+    return PPRHIP_ERR_IO;
+  }
+  if (nl.empty() || nl[0].find(":ID") == std::string::npos) {
+    set_error("%s: expected a ':ID,...' header", nodes_csv);
+    return PPRHIP_ERR_IO;
+  }
+  if (rl.empty() || rl[0].find(":START_ID") == std::string::npos) {
+    set_error("%s: expected a ':START_ID,:END_ID,...' header", rels_csv);
+    return PPRHIP_ERR_IO;
+  }
+  auto* e = new pprhip_edgelist();
+  std::unordered_map<std::string, int32_t> ids;
+  for (size_t i = 1; i < nl.size(); ++i) {
+    if (nl[i].empty()) continue;
+    std::string id = field(nl[i], 0);
+    std::string name = field(nl[i], 1);
+    if (ids.count(id)) {
+      set_error("%s: duplicate node id '%s'", nodes_csv, id.c_str());
+      delete e;
+      return PPRHIP_ERR_IO;
+    }
+    ids[id] = (int32_t)e->names.size();  // node id = row index, as neo4j-admin import assigns them
+    e->names.push_back(name.empty() ? id : name);
+  }
+  e->n = (uint32_t)e->names.size();
+  for (size_t i = 1; i < rl.size(); ++i) {
+    if (rl[i].empty()) continue;
+    auto a = ids.find(field(rl[i], 0));
+    auto b = ids.find(field(rl[i], 1));
+    if (a == ids.end() || b == ids.end()) {
+      set_error("%s line %zu: unknown node id", rels_csv, i + 1);
+      delete e;
+      return PPRHIP_ERR_IO;
+    }
+    e->src.push_back(a->second);
+    e->dst.push_back(b->second);
+  }
+  *out = e;
+  return PPRHIP_OK;
+}
+
+int pprhip_edgelist_info(const pprhip_edgelist_t* e, uint32_t* n, uint64_t* m) {
+  if (!e) {
+    set_error("pprhip_edgelist_info: null edge list");
+    return PPRHIP_ERR_INVALID;
+  }
+  if (n) *n = e->n;
+  if (m) *m = e->src.size();
+  return PPRHIP_OK;
+}
+
+int pprhip_edgelist_edges(const pprhip_edgelist_t* e, const int32_t** src, const int32_t** dst) {
+  if (!e || !src || !dst) {
+    set_error("pprhip_edgelist_edges: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  *src = e->src.data();
+  *dst = e->dst.data();
+  return PPRHIP_OK;
+}
+
+const char* pprhip_edgelist_node_name(const pprhip_edgelist_t* e, uint32_t id) {
+  if (!e || id >= e->n) return nullptr;
+  return e->names[id].c_str();
+}
+
+void pprhip_edgelist_destroy(pprhip_edgelist_t* e) { delete e; }
+
+int pprhip_csr_build(uint32_t n, uint64_t m, const int32_t* key, const int32_t* val, int newest_first,
+                     uint32_t* row_ptr_out, int32_t* col_idx_out) {
+  if (!key || !val || !row_ptr_out || (!col_idx_out && m) || m > 0xFFFFFFFFull) {
+    set_error("pprhip_csr_build: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  std::vector<uint32_t> cnt((size_t)n + 1, 0);
+  for (uint64_t e = 0; e < m; ++e) {
+    if (key[e] < 0 || (uint32_t)key[e] >= n || val[e] < 0 || (uint32_t)val[e] >= n) {
+      set_error("pprhip_csr_build: edge %llu has an endpoint outside [0, %u)", (unsigned long long)e, n);
+      return PPRHIP_ERR_INVALID;
+    }
+    cnt[(size_t)key[e] + 1]++;
+  }
+  row_ptr_out[0] = 0;
+  for (uint32_t v = 0; v < n; ++v) row_ptr_out[v + 1] = row_ptr_out[v] + cnt[v + 1];
+  std::vector<uint32_t> fill(n);
+  if (newest_first) {
+    for (uint32_t v = 0; v < n; ++v) fill[v] = row_ptr_out[v + 1];
+    for (uint64_t e = 0; e < m; ++e) col_idx_out[--fill[key[e]]] = val[e];
+  } else {
+    for (uint32_t v = 0; v < n; ++v) fill[v] = row_ptr_out[v];
+    for (uint64_t e = 0; e < m; ++e) col_idx_out[fill[key[e]]++] = val[e];
+  }
+  return PPRHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// kernels_select.hip — k-th largest / top-k over the reserve vector (Algo_Util.kth_ppr,
+// Algo_Util.java:32-53, and retrieveTopK, Fora_Topk.java:186-199).
+//
+// The reference quickselects over the values of its sparse map; here the estimates sit in a dense
+// fp64 vector in HBM, entries > 0 are the map's entries, and positive doubles order like their bit
+// patterns, so a radix select over the 64-bit patterns (12-bit digits, LDS histograms) finds the
+// k-th value in a few 8n-byte streaming passes; a final pass gathers every entry >= that value.
+#include "device_utils.hpp"
+#include "engine.hpp"
+
+namespace pprhip {
+
+constexpr int kHistBins = 4096;
+
+__global__ __launch_bounds__(256) void k_select_hist(const double* __restrict__ x, uint32_t n,
+                                                      unsigned long long prefix, int prefix_bits, int digit_bits,
+                                                      uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_hist[kHistBins];
+  const int bins = 1 << digit_bits;
+  for (int b = threadIdx.x; b < bins; b += blockDim.x) s_hist[b] = 0;
+  __syncthreads();
+  const int shift = 64 - prefix_bits - digit_bits;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double v = x[i];
+    if (!(v > 0.0)) continue;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (prefix_bits > 0 && (bits >> (64 - prefix_bits)) != prefix) continue;
+    atomicAdd(&s_hist[(bits >> shift) & (unsigned long long)(bins - 1)], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += blockDim.x) {
+    const uint32_t c = s_hist[b];
+    if (c) atomicAdd(&hist[b], c);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_select_gather(const double* __restrict__ x, uint32_t n,
+                                                        unsigned long long lower_bits, int32_t* __restrict__ ids,
+                                                        double* __restrict__ vals, uint32_t cap, DevCounters* ctr) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nround = (n + stride - 1) / stride * stride;
+  const int lane = lane_id();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+    double v = 0.0;
+    bool take = false;
+    if (i < n) {
+      v = x[i];
+      take = v > 0.0 && (unsigned long long)__double_as_longlong(v) >= lower_bits;
+    }
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0) continue;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomic_add_u64(&ctr->sel_count, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader);
+    if (take) {
+      const unsigned long long pos = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < cap) {
+        ids[pos] = (int32_t)i;
+        vals[pos] = v;
+      }
+    }
+  }
+}
+
+int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned long long prefix, int prefix_bits,
+                       int digit_bits) {
+  uint64_t b = ((uint64_t)n + 256 * 8 - 1) / (256 * 8);
+  const uint32_t grid = (uint32_t)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->hist, 0, sizeof(uint32_t) * kHistBins, g->stream));
+  hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(256), 0, g->stream, x, n, prefix, prefix_bits, digit_bits,
+                     g->hist);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits) {
+  uint64_t b = ((uint64_t)n + 255) / 256;
+  const uint32_t grid = (uint32_t)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->sel_count, 0, sizeof(unsigned long long), g->stream));
+  hipLaunchKernelGGL(k_select_gather, dim3(grid), dim3(256), 0, g->stream, x, n, lower_bits, g->sel_ids, g->sel_vals,
+                     g->sel_cap, g->ctr);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+}  // namespace pprhip

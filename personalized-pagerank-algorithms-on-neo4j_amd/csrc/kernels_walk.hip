@@ -1,0 +1,316 @@
+// kernels_walk.hip — Monte-Carlo refinement: one random walk per lane with refill (gfx950).
+//
+// Replaces Monte_Carlo.random_walk / random_walk_no_zero_hop (Monte_Carlo.java:60-133) and the
+// walk loops of Fora_Whole_Graph.java:119-140 / Fora_Topk.java:155-168.  The reference draws from
+// an unseeded ThreadLocalRandom; here walk (seed, stream, start, walk_idx) is a pure function of
+// its counter: Philox4x32-10 with key = seed and counter = (start, idx_lo, idx_hi16 | stream<<16,
+// block).  Decision k of a walk uses block k>>1, words 2(k&1) (stop test: word * 2^-32 < alpha)
+// and 2(k&1)+1 (neighbour pick: (word * degree) >> 32).  The CPU oracle restates the same
+// function, so terminals can be compared walk by walk.
+//
+// Memory-bound random gathers (row_ptr pair + one col_idx per step); no MFMA.
+#include "device_utils.hpp"
+#include "engine.hpp"
+
+namespace pprhip {
+
+struct Philox {
+  uint32_t x[4];
+};
+
+__device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  Philox p;
+  p.x[0] = c0; p.x[1] = c1; p.x[2] = c2; p.x[3] = c3;
+  return p;
+}
+
+// Per-lane walk state machine: one decision per call of step().
+struct Walker {
+  int32_t start, cur;
+  uint32_t c1, c2;     // counter words 1, 2 (walk index, stream)
+  uint32_t k;          // next decision number
+  uint32_t w_stop, w_pick, w_stop2, w_pick2;  // cached Philox block
+  uint32_t moves;
+  bool forced;         // the next decision is the forced first hop (no_zero_hop)
+};
+
+__device__ __forceinline__ void walker_init(Walker& w, int32_t start, unsigned long long idx, uint32_t stream,
+                                            bool no_zero_hop) {
+  w.start = start;
+  w.cur = start;
+  w.c1 = (uint32_t)idx;
+  w.c2 = (uint32_t)((idx >> 32) & 0xFFFFu) | (stream << 16);
+  w.k = 0;
+  w.moves = 0;
+  w.forced = no_zero_hop;
+}
+
+// Returns true when the walk has stopped (w.cur is the terminal).
+__device__ __forceinline__ bool walker_step(Walker& w, const uint32_t* __restrict__ out_rp,
+                                            const int32_t* __restrict__ out_ci, double alpha, uint32_t k0,
+                                            uint32_t k1) {
+  uint32_t ws, wp;
+  if ((w.k & 1u) == 0) {
+    const Philox p = philox4x32_10((uint32_t)w.start, w.c1, w.c2, w.k >> 1, k0, k1);
+    ws = p.x[0];
+    wp = p.x[1];
+    w.w_stop2 = p.x[2];
+    w.w_pick2 = p.x[3];
+  } else {
+    ws = w.w_stop2;
+    wp = w.w_pick2;
+  }
+  w.k++;
+  if (!w.forced) {
+    if ((double)ws * (1.0 / 4294967296.0) < alpha) return true;  // Monte_Carlo.java:76-78
+  }
+  w.forced = false;
+  const uint32_t b = out_rp[w.cur], e = out_rp[w.cur + 1];
+  const uint32_t d = e - b;
+  if (d > 0)
+    w.cur = out_ci[b + (uint32_t)(((unsigned long long)wp * d) >> 32)];  // :81-86
+  else
+    w.cur = w.start;  // :87-90 dead end: restart at the walk's start node
+  w.moves++;
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// walk plan: one entry per residue node, walk ranges as an exclusive prefix over entries
+// ------------------------------------------------------------------------------------------------
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __restrict__ res, double* __restrict__ target,
+                                                  double alpha, double rsum, double nrw, int32_t* __restrict__ mc_node,
+                                                  double* __restrict__ mc_inc, unsigned long long* __restrict__ mc_woff,
+                                                  DevCounters* ctr) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nround = (n + stride - 1) / stride * stride;
+  const int lane = lane_id();
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nround; v += stride) {
+    bool take = false;
+    unsigned long long omega_i = 0;
+    double incr = 0.0;
+    if (v < n) {
+      double r = res[v];
+      if (r > 0.0) {
+        if (VARIANT == 0) {  // Fora_Whole_Graph.java:119-131
+          const double incr_cur = r * alpha;
+          r *= (1.0 - alpha);
+          target[v] = target[v] + incr_cur;
+          if (nrw > 0.0 && rsum > 0.0) {
+            const double x = r / rsum * nrw;
+            omega_i = (unsigned long long)ceil(x);
+            const double a_i = x / (double)omega_i;
+            incr = a_i / nrw * rsum;
+            take = omega_i > 0;
+          }
+        } else if (nrw > 0.0) {  // Fora_Topk.java:155-160
+          const double x = r * nrw;
+          omega_i = (unsigned long long)ceil(x);
+          const double a_i = x / (double)omega_i;
+          incr = a_i / nrw;
+          take = omega_i > 0;
+        }
+      }
+    }
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0) continue;
+    const unsigned long long mine = take ? omega_i : 0ull;
+    const unsigned long long incl = wave_incl_scan_u64(mine);
+    const unsigned long long total = __shfl(incl, 63);
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader)
+      base = atomic_add_u64(&ctr->mc_packed, ((unsigned long long)__popcll(mask) << kPackShift) | total);
+    base = __shfl(base, leader);
+    if (take) {
+      const uint32_t pos = (uint32_t)(base >> kPackShift) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      mc_node[pos] = (int32_t)v;
+      mc_inc[pos] = incr;
+      mc_woff[pos] = (base & kPackMask) + incl - mine;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// walk kernel: a workgroup takes chunks of 1024 consecutive walks; its four waves each own 256 of
+// them; a lane whose walk has stopped immediately takes the wave's next walk, so lanes stay busy
+// although walk lengths are geometric.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWalkChunk = 1024;
+
+__global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long long n_walks,
+                                                  const int32_t* __restrict__ mc_node,
+                                                  const double* __restrict__ mc_inc,
+                                                  const unsigned long long* __restrict__ mc_woff,
+                                                  const uint32_t* __restrict__ out_rp,
+                                                  const int32_t* __restrict__ out_ci, double* __restrict__ target,
+                                                  double alpha, uint32_t k0, uint32_t k1, uint32_t stream,
+                                                  int no_zero_hop, DevCounters* ctr) {
+  __shared__ unsigned long long s_woff[kWalkChunk + 1];
+  __shared__ int32_t s_node[kWalkChunk];
+  __shared__ double s_inc[kWalkChunk];
+  __shared__ uint32_t s_e0;
+  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  unsigned long long steps_total = 0;
+  const unsigned long long n_chunks = (n_walks + kWalkChunk - 1) / kWalkChunk;
+  for (unsigned long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const unsigned long long lo = ch * kWalkChunk;
+    const unsigned long long hi = lo + kWalkChunk < n_walks ? lo + kWalkChunk : n_walks;
+    if (tid == 0) {  // last entry whose walk range starts at or before lo
+      uint32_t a = 0, b = n_src;
+      while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        if (mc_woff[mid] <= lo) a = mid + 1; else b = mid;
+      }
+      s_e0 = a - 1;
+    }
+    __syncthreads();
+    const uint32_t e0 = s_e0;
+    // entries overlapping [lo, hi): at most hi - lo of them (every entry owns >= 1 walk)
+    uint32_t cnt = n_src - e0 < (uint32_t)kWalkChunk ? n_src - e0 : (uint32_t)kWalkChunk;
+    for (uint32_t j = tid; j <= cnt; j += 256) {
+      const uint32_t idx = e0 + j;
+      s_woff[j] = idx < n_src ? mc_woff[idx] : n_walks;
+      if (j < cnt) {
+        s_node[j] = mc_node[idx];
+        s_inc[j] = mc_inc[idx];
+      }
+    }
+    __syncthreads();
+    // this wave's share of the chunk
+    unsigned long long cursor = lo + (unsigned long long)wv * (kWalkChunk / 4);
+    unsigned long long wend = cursor + (kWalkChunk / 4);
+    if (cursor > hi) cursor = hi;
+    if (wend > hi) wend = hi;
+    Walker w;
+    double inc = 0.0;
+    bool walking = false;
+    for (;;) {
+      const unsigned long long need = __ballot(!walking);
+      const unsigned long long avail = wend - cursor;
+      if (need && avail) {
+        const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
+        if (!walking && rank < avail) {
+          const unsigned long long gidx = cursor + rank;
+          uint32_t a = 0, b = cnt;  // last staged entry with woff <= gidx
+          while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if (s_woff[mid] <= gidx) a = mid + 1; else b = mid;
+          }
+          const uint32_t j = a - 1;
+          const int32_t start = s_node[j];
+          inc = s_inc[j];
+          walker_init(w, start, gidx - s_woff[j], stream, no_zero_hop != 0);
+          if (out_rp[start + 1] == out_rp[start]) {
+            atomic_add_noret(&target[start], inc);  // Monte_Carlo.java:70-72 / :106-108
+          } else {
+            walking = true;
+          }
+        }
+        const unsigned long long want = __popcll(need);
+        cursor += want < avail ? want : avail;
+      }
+      if (__ballot(walking) == 0) {
+        if (wend == cursor) break;
+        continue;
+      }
+      if (walking) {
+        if (walker_step(w, out_rp, out_ci, alpha, k0, k1)) {
+          atomic_add_noret(&target[w.cur], inc);
+          steps_total += w.moves;
+          walking = false;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  steps_total = wave_sum_u64(steps_total);
+  if (lane == 0 && steps_total) atomic_add_u64(&ctr->walk_steps, steps_total);
+}
+
+// one walk per thread, terminals written out (walker parity tests, pprhip_random_walk_batch)
+__global__ __launch_bounds__(256) void k_walk_batch(const int32_t* __restrict__ starts,
+                                                     const unsigned long long* __restrict__ idx,
+                                                     unsigned long long count, const uint32_t* __restrict__ out_rp,
+                                                     const int32_t* __restrict__ out_ci, double alpha, uint32_t k0,
+                                                     uint32_t k1, uint32_t stream, int no_zero_hop,
+                                                     int32_t* __restrict__ term, uint32_t* __restrict__ steps) {
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < count;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const int32_t s = starts[i];
+    Walker w;
+    walker_init(w, s, idx[i], stream, no_zero_hop != 0);
+    if (out_rp[s + 1] != out_rp[s]) {
+      while (!walker_step(w, out_rp, out_ci, alpha, k0, k1)) {
+      }
+    }
+    term[i] = w.cur;
+    if (steps) steps[i] = w.moves;
+  }
+}
+
+__global__ void k_plan_single(int32_t src, double inc, int32_t* mc_node, double* mc_inc, unsigned long long* mc_woff) {
+  mc_node[0] = src;
+  mc_inc[0] = inc;
+  mc_woff[0] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double* target) {
+  uint64_t b = ((uint64_t)g->n + 255) / 256;
+  const uint32_t grid = (uint32_t)(b > 2048 ? 2048 : b);
+  if (variant == 0)
+    hipLaunchKernelGGL(k_mc_plan<0>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, target, alpha, rsum, nrw,
+                       g->mc_node, g->mc_inc, g->mc_woff, g->ctr);
+  else
+    hipLaunchKernelGGL(k_mc_plan<1>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, target, alpha, rsum, nrw,
+                       g->mc_node, g->mc_inc, g->mc_woff, g->ctr);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+int launch_mc_walk(pprhip_graph* g, uint64_t n_sources, uint64_t n_walks, double alpha, uint64_t seed, uint32_t stream,
+                   int no_zero_hop, double* target) {
+  if (n_walks == 0 || n_sources == 0) return PPRHIP_OK;
+  uint64_t chunks = (n_walks + kWalkChunk - 1) / kWalkChunk;
+  const uint32_t grid = (uint32_t)(chunks > 4096 ? 4096 : chunks);
+  hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(256), 0, g->stream, (uint32_t)n_sources,
+                     (unsigned long long)n_walks, g->mc_node, g->mc_inc, g->mc_woff, g->out_rp, g->out_ci, target, alpha,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, g->ctr);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* d_idx, uint64_t count, double alpha,
+                      uint64_t seed, uint32_t stream, int no_zero_hop, int32_t* d_term, uint32_t* d_steps) {
+  if (count == 0) return PPRHIP_OK;
+  uint64_t b = (count + 255) / 256;
+  const uint32_t grid = (uint32_t)(b > 4096 ? 4096 : b);
+  hipLaunchKernelGGL(k_walk_batch, dim3(grid), dim3(256), 0, g->stream, d_starts,
+                     (const unsigned long long*)d_idx, (unsigned long long)count, g->out_rp, g->out_ci, alpha,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, d_term, d_steps);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+int launch_mc_pure(pprhip_graph* g, int32_t src, uint64_t n_walks, double alpha, uint64_t seed, double inc,
+                   double* target) {
+  hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(1), 0, g->stream, src, inc, g->mc_node, g->mc_inc, g->mc_woff);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return launch_mc_walk(g, 1, n_walks, alpha, seed, 0, 0, target);
+}
+
+}  // namespace pprhip
