@@ -114,4 +114,68 @@ __device__ __forceinline__ uint32_t wave_append(bool take, int32_t node, uint32_
   return 0xFFFFFFFFu;
 }
 
+
+// Workgroup exclusive scan of one value per thread (256 threads); returns the exclusive prefix and
+// writes the workgroup total to *total.  `scratch` holds 4 slots.
+template <class T>
+__device__ __forceinline__ T block_excl_scan_256(T x, T* scratch, T* total) {
+  const int lane = lane_id(), wv = wave_id();
+  T incl = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) scratch[wv] = incl;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const T s = scratch[w];
+    if (w < wv) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - x;
+}
+
+// Two-pass compaction of the contiguous item range owned by one workgroup (256 threads).
+// eval(i, &weight) says whether item i is taken and what it weighs (degree / walk count); pass 1
+// totals the range, ONE packed atomic reserves list slots (high bits) and the weight range (low 36
+// bits), pass 2 re-evaluates and emits items in ascending order with their exclusive weight
+// offsets.  eval must be a pure function of data that does not change during the kernel.
+template <class Eval, class Emit>
+__device__ __forceinline__ void block_range_compact(uint32_t lo, uint32_t hi, unsigned long long* counter, Eval eval,
+                                                    Emit emit) {
+  __shared__ unsigned long long s_scan[4];
+  __shared__ unsigned long long s_base, s_tot;
+  unsigned long long pack = 0;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    unsigned long long w = 0;
+    if (eval(i, &w)) pack += (1ull << kPackShift) | w;
+  }
+  const unsigned long long tot = block_sum_u64(pack, s_scan);  // valid in thread 0
+  if (threadIdx.x == 0) {
+    s_tot = tot;
+    s_base = tot ? atomic_add_u64(counter, tot) : 0ull;
+  }
+  __syncthreads();
+  if (s_tot == 0) return;
+  unsigned long long run = s_base;  // running (count << 36 | weight) offset, uniform across the workgroup
+  for (uint32_t c = lo; c < hi; c += 256) {
+    const uint32_t i = c + threadIdx.x;
+    unsigned long long w = 0;
+    const bool take = (i < hi) && eval(i, &w);
+    const unsigned long long mine = take ? ((1ull << kPackShift) | w) : 0ull;
+    unsigned long long chunk_total = 0;
+    const unsigned long long excl = block_excl_scan_256<unsigned long long>(mine, s_scan, &chunk_total);
+    if (take) {
+      const unsigned long long at = run + excl;
+      emit(i, (uint32_t)(at >> kPackShift), at & kPackMask, w);
+    }
+    run += chunk_total;
+  }
+}
+
 }  // namespace pprhip

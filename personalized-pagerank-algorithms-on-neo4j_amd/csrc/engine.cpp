@@ -100,22 +100,33 @@ double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense) 
 
 uint64_t dense_level_bytes(const pprhip_graph* g) { return 12ull * g->m + 36ull * g->n + 4ull; }
 
-// Runs levels until the frontier is empty.
+int write_hist0(pprhip_graph* g, uint32_t nf, uint64_t ef) {
+  g->h_ctr->hist[0] = ((unsigned long long)nf << kPackShift) | ef;
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long),
+                                  hipMemcpyHostToDevice, g->stream));
+  return PPRHIP_OK;
+}
+
+// Runs levels until the frontier is empty.  Dense levels cost one host round trip each; sparse
+// levels are launched kMaxBatch at a time and continue on the device (kernels_push.hip).
 int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost) {
   const bool bwd = a.mode == kBackward;
+  // smallest integer x with (double)x >= dense_frac * m: the device-side form of level_cost()'s test
+  const unsigned long long dense_thresh =
+      bwd ? ~0ull : (unsigned long long)std::ceil(g->tun.dense_frac * (double)g->m);
   while (L.nf > 0) {
     bool dense = false;
     const double c = level_cost(g, L.nf, L.ef, &dense);
     if (bwd) dense = false;  // backward levels always run sparse
-    if (model_cost) *model_cost += c;
     if (dense) {
+      if (model_cost) *model_cost += c;
       if (!L.dense_prepared) {
         PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
-        PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, L.nf, true, L.ccur, L.dslot));
+        PPRHIP_TRY(write_hist0(g, L.nf, L.ef));
+        PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, 0, L.nf, dense_thresh, true, L.ccur, L.dslot));
         L.dense_prepared = true;
       }
       const int out = L.pslot ^ 1;
-      PPRHIP_TRY(zero_packed(g, out));
       g_timer.begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
       PPRHIP_TRY(launch_dense_level(g, a, L.ccur, out, L.dslot));
       g_timer.end();
@@ -125,32 +136,61 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       st.dense_levels++;
       st.dense_nodes += L.nf;
       st.push_bytes += dense_level_bytes(g);
-    } else {
-      if (L.dense_prepared) {
-        const int cs = L.pslot ^ 1;
-        PPRHIP_TRY(zero_packed(g, cs));
-        PPRHIP_TRY(launch_compact_prepared(g, L.ccur, L.fcur, cs, bwd));
-        L.pslot = cs;
-        L.dense_prepared = false;
-      } else {
-        PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, L.nf, false, 0, L.dslot));
-      }
-      const int out = L.pslot ^ 1;
-      PPRHIP_TRY(zero_packed(g, out));
-      const uint64_t bytes = 44ull * L.nf + 28ull * L.ef;
-      g_timer.begin(PPRHIP_KERNEL_SPARSE_PUSH, bytes);
-      PPRHIP_TRY(launch_sparse_push(g, a, L.fcur, &g->ctr->packed[L.pslot], L.ef, L.fcur ^ 1, out, L.dslot));
-      g_timer.end();
-      L.fcur ^= 1;
-      L.pslot = out;
-      st.pops += L.nf;
-      st.edge_pushes += L.ef;
-      st.push_bytes += bytes;
+      PPRHIP_TRY(read_packed(g, L.pslot, &L.nf, &L.ef));
+      st.levels++;
+      st.enqueues += L.nf;
+      st.push_bytes += 5ull * L.nf;
+      continue;
     }
-    PPRHIP_TRY(read_packed(g, L.pslot, &L.nf, &L.ef));
-    st.levels++;
-    st.enqueues += L.nf;
-    st.push_bytes += 5ull * L.nf;
+    // ---- a batch of sparse levels
+    PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->hist[0], 0, sizeof(unsigned long long) * (kMaxBatch + 1), g->stream));
+    const bool first_prepared = L.dense_prepared;
+    if (first_prepared) {
+      // dense-prepared state -> list form; the compaction recounts (dead-end nodes carry no edges)
+      PPRHIP_TRY(launch_compact_prepared(g, L.ccur, L.fcur, &g->ctr->hist[0], bwd));
+      L.dense_prepared = false;
+    } else {
+      PPRHIP_TRY(write_hist0(g, L.nf, L.ef));
+    }
+    g_timer.begin(PPRHIP_KERNEL_SPARSE_PUSH, 0);
+    for (int i = 0; i < kMaxBatch; ++i) {
+      const int fb = L.fcur ^ (i & 1);
+      if (!(i == 0 && first_prepared))
+        PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot));
+      PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot));
+    }
+    g_timer.end();
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->hist[0], &g->ctr->hist[0], sizeof(unsigned long long) * (kMaxBatch + 1),
+                                    hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    uint64_t batch_bytes = 0;
+    int ran = 0;
+    for (int i = 0; i < kMaxBatch; ++i) {
+      // level i ran with the frontier the host knows (i == 0) or the one level i-1 produced
+      const uint32_t nf_i = i == 0 ? L.nf : (uint32_t)(g->h_ctr->hist[i] >> kPackShift);
+      const uint64_t ef_i = i == 0 ? L.ef : (g->h_ctr->hist[i] & kPackMask);
+      if (i > 0) {
+        bool d2 = false;
+        const double ci = level_cost(g, nf_i, ef_i, &d2);
+        if (nf_i == 0 || (d2 && !bwd)) break;  // the device stopped here too (level_runs)
+        if (model_cost) *model_cost += ci;
+      } else if (model_cost) {
+        *model_cost += c;
+      }
+      const uint32_t nf_next = (uint32_t)(g->h_ctr->hist[i + 1] >> kPackShift);
+      st.pops += nf_i;
+      st.edge_pushes += ef_i;
+      st.levels++;
+      st.enqueues += nf_next;
+      batch_bytes += 44ull * nf_i + 28ull * ef_i + 5ull * nf_next;
+      ran++;
+    }
+    st.push_bytes += batch_bytes;
+    if (!g_timer.recs.empty() && g_timer.recs.back().cls == PPRHIP_KERNEL_SPARSE_PUSH)
+      g_timer.recs.back().bytes = batch_bytes;
+    L.nf = (uint32_t)(g->h_ctr->hist[ran] >> kPackShift);
+    L.ef = g->h_ctr->hist[ran] & kPackMask;
+    if (ran & 1) L.fcur ^= 1;
   }
   return PPRHIP_OK;
 }
@@ -169,7 +209,6 @@ int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree) {
   g->h_ctr->pad[0] = (unsigned long long)(uint32_t)node;  // staging for the 4-byte node id
   PPRHIP_CHECK_HIP(hipMemcpyAsync(g->F[L.fcur], &g->h_ctr->pad[0], sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
   PPRHIP_CHECK_HIP(hipMemsetAsync(g->eoff[L.fcur], 0, sizeof(uint32_t), g->stream));
-  PPRHIP_TRY(write_packed(g, L.pslot, 1, degree));
   L.nf = 1;
   L.ef = degree;
   L.dense_prepared = false;
@@ -178,27 +217,19 @@ int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree) {
 
 // frontier from a predicate over all nodes (round starts)
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
-  PPRHIP_TRY(zero_packed(g, L.pslot));
   PPRHIP_TRY(launch_count_active(g, a, kind, L.pslot));
   PPRHIP_TRY(read_packed(g, L.pslot, &L.nf, &L.ef));
   L.dense_prepared = false;
-  if (L.nf == 0) {
-    if (kind == 1) {  // still drop parked nodes that fell below min_rmax (Forward_Push.java:241-247)
-      PPRHIP_TRY(zero_packed(g, L.pslot));
-      PPRHIP_TRY(launch_seed_list(g, a, kind, L.fcur, L.pslot));
-    }
-    return PPRHIP_OK;
-  }
   bool dense = false;
-  (void)level_cost(g, L.nf, L.ef, &dense);
+  if (L.nf) (void)level_cost(g, L.nf, L.ef, &dense);
   if (dense) {
-    const int scratch = L.pslot ^ 1;
-    PPRHIP_TRY(zero_packed(g, scratch));
-    PPRHIP_TRY(launch_seed_dense(g, a, kind, L.ccur, scratch, L.dslot));
+    PPRHIP_TRY(launch_seed_dense(g, a, kind, L.ccur, L.pslot, L.dslot));
     L.dense_prepared = true;
-  } else {
-    PPRHIP_TRY(zero_packed(g, L.pslot));
-    PPRHIP_TRY(launch_seed_list(g, a, kind, L.fcur, L.pslot));
+  } else if (L.nf || kind == 1) {
+    // kind 1 also runs for an empty start set: parked nodes below min_rmax still leave the set
+    // (Forward_Push.java:241-247)
+    PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->hist[kMaxBatch + 2], 0, sizeof(unsigned long long), g->stream));
+    PPRHIP_TRY(launch_seed_list(g, a, kind, L.fcur, &g->ctr->hist[kMaxBatch + 2]));
   }
   return PPRHIP_OK;
 }
@@ -632,6 +663,12 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
   if ((rc = alloc_dev((void**)&G->mc_woff, sizeof(unsigned long long) * (size_t)n))) return fail(rc);
   if ((rc = alloc_dev((void**)&G->partial, sizeof(double) * 1024))) return fail(rc);
   if ((rc = alloc_dev((void**)&G->hist, sizeof(uint32_t) * 4096))) return fail(rc);
+  {
+    const size_t nblk = std::max<size_t>(1024, (size_t)G->n_tiles + (G->n_hubs + 255) / 256);
+    if ((rc = alloc_dev((void**)&G->blk_pack, sizeof(unsigned long long) * nblk))) return fail(rc);
+    if ((rc = alloc_dev((void**)&G->blk_dead, sizeof(double) * nblk))) return fail(rc);
+    if ((rc = alloc_dev((void**)&G->blk_ndead, sizeof(uint32_t) * nblk))) return fail(rc);
+  }
   G->sel_cap = 1u << 18;
   if ((rc = alloc_dev((void**)&G->sel_ids, sizeof(int32_t) * G->sel_cap))) return fail(rc);
   if ((rc = alloc_dev((void**)&G->sel_vals, sizeof(double) * G->sel_cap))) return fail(rc);
@@ -669,7 +706,7 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   void* ptrs[] = {g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->tile_row, g->hub_rows, g->hub_chunks, g->hubacc,
                   g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1], g->eoff[0],
                   g->eoff[1], g->flags, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist, g->sel_ids,
-                  g->sel_vals, g->ctr};
+                  g->sel_vals, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
@@ -1190,7 +1227,6 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
       PPRHIP_TRY(launch_set_f64(g, g->cdense[L.ccur], (uint32_t)src, remain / (double)d));
     for (int it = 1; it < iters; ++it) {
       const int out = L.pslot ^ 1;
-      PPRHIP_TRY(zero_packed(g, out));
       g_timer.begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
       PPRHIP_TRY(launch_dense_level(g, a, L.ccur, out, L.dslot));
       g_timer.end();

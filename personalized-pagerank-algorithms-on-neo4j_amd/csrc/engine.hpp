@@ -6,8 +6,11 @@
 namespace pprhip {
 
 // Device-side counter block (one per graph handle), mirrored into pinned host memory.
+constexpr int kMaxBatch = 8;  // sparse levels launched per host round trip
+
 struct DevCounters {
-  unsigned long long packed[2];   // frontier being produced: entries << 36 | edge total
+  unsigned long long hist[16];    // sparse batch: hist[i] = frontier of level i (entries << 36 | edges)
+  unsigned long long packed[2];   // dense level / seeding output: entries << 36 | edge total
   double dead[2];                 // dead-end mass waiting to land on the source
   unsigned long long dead_pops;   // pushed nodes with out-degree 0
   unsigned long long mc_packed;   // walk plan: sources << 36 | walks
@@ -60,6 +63,9 @@ struct pprhip_graph {
   // reductions / selection scratch
   double* partial = nullptr;       // 1024 partial sums
   uint32_t* hist = nullptr;        // 4096-bin histogram
+  unsigned long long* blk_pack = nullptr;  // per-workgroup partial counters of the dense sweep
+  double* blk_dead = nullptr;
+  uint32_t* blk_ndead = nullptr;
   int32_t* sel_ids = nullptr;      // candidate list
   double* sel_vals = nullptr;
   uint32_t sel_cap = 0;
@@ -80,14 +86,14 @@ struct pprhip_graph {
 namespace pprhip {
 
 // ---- kernels_push.hip
-int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, uint32_t nf, bool scatter_dense, int cbuf,
-                          int dead_slot);
-int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, const unsigned long long* d_in_counter,
-                       uint64_t ef_upper, int out_fbuf, int out_slot, int dead_slot);
+int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t nf_upper,
+                          unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot);
+int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
+                       unsigned long long dense_thresh, int dead_slot);
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot);
-int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, int out_slot, bool backward);
+int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);
 int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot);
-int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, int out_slot);
+int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter);
 int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbuf, int out_slot, int dead_slot);
 int launch_sum(pprhip_graph* g, const double* x, uint32_t n);  // result -> ctr->sum_out
 int launch_set_f64(pprhip_graph* g, double* p, uint32_t idx, double value);

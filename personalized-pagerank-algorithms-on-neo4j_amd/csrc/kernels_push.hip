@@ -6,12 +6,18 @@
 //
 //   sparse  k_sparse_prepare (per frontier node: take the residue, credit the reserve, compute the
 //           per-edge contribution) then k_sparse_push (edge-parallel over the frontier's edges:
-//           coalesced col_idx reads, one returning fp64 atomic per edge, threshold-crossing
-//           detection on (old, old + c), wave-aggregated append to the next frontier);
-//   dense   k_hub_pull + k_dense_tiles: a pull sweep over the in-CSR in row-aligned tiles of
-//           <= 2048 edges; contributions are gathered through LDS and every row is applied and, if
-//           it crosses the threshold, prepared for the next level in the same kernel (no atomics
-//           on the residue vector).
+//           frontier entries staged in LDS, coalesced col_idx reads, one returning fp64 atomic per
+//           edge, threshold-crossing detection on (old, old + c), crossings collected in LDS and
+//           appended to the next frontier with one packed atomic per 2048-edge tile).  Sparse
+//           levels are launched in batches: every level's (nodes, edges) counter lives in a small
+//           device-side history, and a level's kernels return at once when the previous level left
+//           nothing to do (or left so much that the host should switch to the dense shape), so the
+//           host reads counters back once per batch, not once per level.
+//   dense   k_hub_pull + k_dense_tiles + k_dense_reduce: a pull sweep over the in-CSR in
+//           row-aligned tiles of <= 2048 edges; contributions are gathered through LDS, every row
+//           is applied and, if it crosses the threshold, prepared for the next level in the same
+//           kernel (no atomics on the residue vector, no same-address atomics at all: per-tile
+//           counters go to a partials array that a one-workgroup kernel sums).
 //
 // HBM-bound integer/fp64 work: no MFMA anywhere.  All arithmetic is IEEE double with
 // -ffp-contract=off so each product / quotient rounds exactly as the reference's Java does.
@@ -23,24 +29,35 @@ namespace pprhip {
 constexpr int kPushTile = 2048;  // edges per workgroup iteration of k_sparse_push
 constexpr int kStageCap = 512;   // frontier entries staged in LDS at a time
 
+// A batched sparse level runs iff the level before it produced a non-empty frontier that is still
+// worth running sparse (the host took that decision itself for the first level of a batch).
+__device__ __forceinline__ bool level_runs(unsigned long long pk, int level, unsigned long long dense_thresh) {
+  const unsigned long long nf = pk >> kPackShift, ef = pk & kPackMask;
+  if (nf == 0) return false;
+  return level == 0 || (nf + ef) < dense_thresh;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sparse level, step 1: every frontier node gives up its residue
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restrict__ F, uint32_t nf,
+__global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restrict__ F,
                                                          const uint32_t* __restrict__ out_rp,
                                                          double* __restrict__ res, double* __restrict__ reserve,
                                                          double* __restrict__ cF, double* __restrict__ c_dense,
-                                                         DevCounters* ctr, int dead_slot, PushArgs a) {
+                                                         DevCounters* ctr, int level, unsigned long long dense_thresh,
+                                                         int dead_slot, PushArgs a) {
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long pk = ctr->hist[level];
+  if (!level_runs(pk, level, dense_thresh)) return;
+  const uint32_t nf = (uint32_t)(pk >> kPackShift);
   double dead = 0.0;
   unsigned long long ndead = 0;
-  if (i < nf) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) {
     const int32_t v = F[i];
     const double rc = res[v];
-    res[v] = 0.0;                         // Forward_Push.java:89
+    res[v] = 0.0;                            // Forward_Push.java:89
     reserve[v] = reserve[v] + rc * a.alpha;  // :91-95
     double c;
     if (MODE == kBackward) {
@@ -49,8 +66,8 @@ __global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restric
       const uint32_t d = out_rp[v + 1] - out_rp[v];
       if (d == 0) {  // Forward_Push.java:101-104: the mass goes back to the source
         c = 0.0;
-        dead = rc * (1.0 - a.alpha);
-        ndead = 1;
+        dead += rc * (1.0 - a.alpha);
+        ndead++;
       } else {
         c = ((1.0 - a.alpha) * rc) / (double)d;  // :117
       }
@@ -73,59 +90,107 @@ __global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restric
 // ------------------------------------------------------------------------------------------------
 // sparse level, step 2: contributions land edge by edge
 // ------------------------------------------------------------------------------------------------
+struct NewList {  // crossings of the current tile, collected in LDS
+  int32_t node[kPushTile + 1];
+  uint32_t deg[kPushTile + 1];
+  uint32_t count;
+};
+
 template <int MODE>
-__device__ __forceinline__ void push_one(bool valid, int32_t u, double c, const uint32_t* __restrict__ out_rp,
+__device__ __forceinline__ void push_one(int32_t u, double c, const uint32_t* __restrict__ out_rp,
                                          const uint32_t* __restrict__ in_rp, double* __restrict__ res,
-                                         uint8_t* __restrict__ flags, int32_t* __restrict__ Fn,
-                                         uint32_t* __restrict__ eoffn, unsigned long long* out_counter,
-                                         const PushArgs& a) {
-  bool crossing = false;
-  uint32_t adeg = 0;
-  if (valid) {
-    const uint32_t du = out_rp[u + 1] - out_rp[u];
-    if (MODE == kBackward) {
-      const double add = c / (double)du;  // Backward_Search.java:84-85
-      const double old = atomic_add_ret(&res[u], add);
-      const double nw = old + add;
-      crossing = !(old > a.rmax) && (nw > a.rmax);  // :89 strict, un-normalised
-      if (crossing) adeg = in_rp[u + 1] - in_rp[u];
-    } else {
-      const double old = atomic_add_ret(&res[u], c);  // Forward_Push.java:123-127
-      const double nw = old + c;
-      crossing = !active_fwd(old, du, a.rmax) && active_fwd(nw, du, a.rmax);  // :132
-      adeg = du;
-      if (MODE == kFwdTopk && active_fwd(nw, du, a.min_rmax)) flags[u] = 1;  // :232-237 (parked)
-    }
+                                         uint8_t* __restrict__ flags, NewList* nl, const PushArgs& a) {
+  const uint32_t du = out_rp[u + 1] - out_rp[u];
+  bool crossing;
+  uint32_t adeg;
+  if (MODE == kBackward) {
+    const double add = c / (double)du;  // Backward_Search.java:84-85
+    const double old = atomic_add_ret(&res[u], add);
+    const double nw = old + add;
+    crossing = !(old > a.rmax) && (nw > a.rmax);  // :89 strict, un-normalised
+    adeg = crossing ? in_rp[u + 1] - in_rp[u] : 0u;
+  } else {
+    const double old = atomic_add_ret(&res[u], c);  // Forward_Push.java:123-127
+    const double nw = old + c;
+    crossing = !active_fwd(old, du, a.rmax) && active_fwd(nw, du, a.rmax);  // :132
+    adeg = du;
+    if (MODE == kFwdTopk && active_fwd(nw, du, a.min_rmax)) flags[u] = 1;  // :232-237 (parked)
   }
-  wave_append(crossing, u, adeg, Fn, eoffn, out_counter);
+  if (crossing) {
+    const uint32_t slot = atomicAdd(&nl->count, 1u);
+    nl->node[slot] = u;
+    nl->deg[slot] = adeg;
+  }
+}
+
+// Appends the tile's crossings to the next frontier: one packed atomic reserves list slots and
+// the edge range, a workgroup scan turns the degrees into edge offsets.
+__device__ __forceinline__ void flush_new(NewList* nl, int32_t* __restrict__ Fn, uint32_t* __restrict__ eoffn,
+                                          unsigned long long* out_counter) {
+  __shared__ unsigned long long s_scan[4];
+  __shared__ unsigned long long s_base;
+  __syncthreads();
+  const uint32_t cnt = nl->count;
+  if (cnt == 0) return;  // uniform
+  const int tid = threadIdx.x;
+  // each thread owns up to 9 consecutive collected entries (2049 / 256 rounded up)
+  constexpr int kPer = (kPushTile + 1 + 255) / 256;
+  const uint32_t b = tid * kPer;
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; ++j)
+    if (b + j < cnt) mine += nl->deg[b + j];
+  unsigned long long total = 0;
+  const unsigned long long excl = block_excl_scan_256<unsigned long long>(mine, s_scan, &total);
+  if (tid == 0) s_base = atomic_add_u64(out_counter, ((unsigned long long)cnt << kPackShift) | total);
+  __syncthreads();
+  const uint32_t pos0 = (uint32_t)(s_base >> kPackShift);
+  unsigned long long e = (s_base & kPackMask) + excl;
+#pragma unroll
+  for (int j = 0; j < kPer; ++j)
+    if (b + j < cnt) {
+      Fn[pos0 + b + j] = nl->node[b + j];
+      eoffn[pos0 + b + j] = (uint32_t)e;
+      e += nl->deg[b + j];
+    }
+  __syncthreads();
+  if (tid == 0) nl->count = 0;
+  __syncthreads();
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__ F, const double* __restrict__ cF,
                                                       const uint32_t* __restrict__ eoff,
-                                                      const unsigned long long* __restrict__ in_counter,
                                                       const uint32_t* __restrict__ trp, const int32_t* __restrict__ tci,
                                                       const uint32_t* __restrict__ out_rp,
                                                       const uint32_t* __restrict__ in_rp, double* __restrict__ res,
                                                       uint8_t* __restrict__ flags, int32_t* __restrict__ Fn,
-                                                      uint32_t* __restrict__ eoffn, DevCounters* ctr, int out_slot,
-                                                      int dead_slot, PushArgs a) {
+                                                      uint32_t* __restrict__ eoffn, DevCounters* ctr, int level,
+                                                      unsigned long long dense_thresh, int dead_slot, PushArgs a) {
   __shared__ uint32_t s_eoff[kStageCap + 1];
   __shared__ uint32_t s_row[kStageCap];
   __shared__ double s_c[kStageCap];
   __shared__ uint32_t s_i0;
+  __shared__ NewList s_new;
   const int tid = threadIdx.x;
-  const unsigned long long pk = *in_counter;
+  const unsigned long long pk = ctr->hist[level];
+  if (!level_runs(pk, level, dense_thresh)) return;
   const uint32_t nf = (uint32_t)(pk >> kPackShift);
   const unsigned long long E = pk & kPackMask;
-  unsigned long long* out_counter = &ctr->packed[out_slot];
+  unsigned long long* out_counter = &ctr->hist[level + 1];
+  if (tid == 0) s_new.count = 0;
+  __syncthreads();
 
-  if (MODE != kBackward && blockIdx.x == 0 && wave_id() == 0) {
+  if (MODE != kBackward && blockIdx.x == 0) {
     // dead-end mass of this level lands on the source (Forward_Push.java:101-113)
-    const double dead = ctr->dead[dead_slot];
-    const bool valid = (lane_id() == 0) && (dead > 0.0);
-    push_one<MODE>(valid, a.src, dead, out_rp, in_rp, res, flags, Fn, eoffn, out_counter, a);
-    if (valid) ctr->dead[dead_slot] = 0.0;
+    if (tid == 0) {
+      const double dead = ctr->dead[dead_slot];
+      if (dead > 0.0) {
+        push_one<MODE>(a.src, dead, out_rp, in_rp, res, flags, &s_new, a);
+        ctr->dead[dead_slot] = 0.0;
+      }
+    }
+    flush_new(&s_new, Fn, eoffn, out_counter);
   }
 
   const unsigned long long n_tiles = (E + kPushTile - 1) / kPushTile;
@@ -156,31 +221,21 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
       }
       __syncthreads();
       const unsigned long long cov_hi = ((unsigned long long)s_eoff[cnt] < tile_hi) ? s_eoff[cnt] : tile_hi;
-      const uint32_t span = cov_hi > ce ? (uint32_t)(cov_hi - ce) : 0u;
-      const uint32_t iters = (span + 255u) >> 8;
-      for (uint32_t it = 0; it < iters; ++it) {
-        const unsigned long long e = ce + (unsigned long long)it * 256ull + tid;
-        const bool valid = e < cov_hi;
-        int32_t u = 0;
-        double c = 0.0;
-        if (valid) {
-          const uint32_t e32 = (uint32_t)e;
-          uint32_t lo = 0, hi = cnt;
-          while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_eoff[mid] <= e32) lo = mid + 1; else hi = mid;
-          }
-          const uint32_t j = lo - 1;
-          u = tci[s_row[j] + (e32 - s_eoff[j])];
-          c = s_c[j];
+      for (unsigned long long e = ce + tid; e < cov_hi; e += 256) {
+        const uint32_t e32 = (uint32_t)e;
+        uint32_t lo = 0, hi = cnt;  // last staged entry whose range starts at or before e
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_eoff[mid] <= e32) lo = mid + 1; else hi = mid;
         }
-        push_one<MODE>(valid, u, c, out_rp, in_rp, res, flags, Fn, eoffn, out_counter, a);
+        const uint32_t j = lo - 1;
+        push_one<MODE>(tci[s_row[j] + (e32 - s_eoff[j])], s_c[j], out_rp, in_rp, res, flags, &s_new, a);
       }
       __syncthreads();
       ce = cov_hi;
       ci0 += cnt;
     }
-    __syncthreads();
+    flush_new(&s_new, Fn, eoffn, out_counter);
   }
 }
 
@@ -208,7 +263,13 @@ __global__ __launch_bounds__(256) void k_hub_pull(const uint32_t* __restrict__ c
   }
 }
 
-__device__ __forceinline__ int swz(int k) { return k ^ ((k >> 5) & 31); }
+// LDS image of a tile's gathered contributions: element k lives in its 8-element group at a
+// position rotated by the group number, so that both the coalesced writes (lane = k) and the
+// per-thread reads of 8 consecutive elements (lane = group) spread over the banks.
+__device__ __forceinline__ int tile_slot(int k) {
+  const int g = k >> 3;
+  return (k & ~7) | ((k + g + (g >> 3)) & 7);
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_dense_tiles(const uint32_t* __restrict__ tile_row, uint32_t n_tiles,
@@ -219,8 +280,12 @@ __global__ __launch_bounds__(256) void k_dense_tiles(const uint32_t* __restrict_
                                                       double* __restrict__ res, double* __restrict__ reserve,
                                                       uint8_t* __restrict__ flags, const int32_t* __restrict__ hub_rows,
                                                       uint32_t n_hubs, double* __restrict__ hubacc, DevCounters* ctr,
-                                                      int out_slot, int dead_slot, PushArgs a) {
+                                                      unsigned long long* __restrict__ blk_pack,
+                                                      double* __restrict__ blk_dead, uint32_t* __restrict__ blk_ndead,
+                                                      int dead_slot, PushArgs a) {
   __shared__ double s_val[kTileEdges];
+  __shared__ double s_acc[kTileRows];
+  __shared__ uint32_t s_rp[kTileRows + 1];
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
   const int tid = threadIdx.x;
@@ -230,9 +295,11 @@ __global__ __launch_bounds__(256) void k_dense_tiles(const uint32_t* __restrict_
   double acc = 0.0;
   if (t < n_tiles) {
     const uint32_t r0 = tile_row[t], r1 = tile_row[t + 1];
+    const uint32_t nrows = r1 - r0;
     const uint32_t e0 = in_rp[r0], e1 = in_rp[r1];
     const uint32_t ne = e1 - e0;
     if (ne <= (uint32_t)kTileEdges) {  // a hub row is a tile of its own and is applied by the hub blocks
+      // 1. coalesced col_idx reads, contribution gathers, LDS image
       int32_t idx[8];
       double val[8];
 #pragma unroll
@@ -245,13 +312,45 @@ __global__ __launch_bounds__(256) void k_dense_tiles(const uint32_t* __restrict_
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const uint32_t k = tid + 256 * j;
-        if (k < ne) s_val[swz((int)k)] = val[j];
+        if (k < ne) s_val[tile_slot((int)k)] = val[j];
+      }
+      if ((uint32_t)tid <= nrows) s_rp[tid] = in_rp[r0 + tid] - e0;
+      if (tid == 0 && nrows == (uint32_t)kTileRows) s_rp[kTileRows] = ne;
+      s_acc[tid] = 0.0;
+      __syncthreads();
+      // 2. segmented sum: every thread owns 8 consecutive edges and adds its per-row partials
+      const uint32_t k0 = 8u * tid;
+      if (k0 < ne) {
+        uint32_t lo = 0, hi = nrows;  // last row starting at or before k0 (skips empty rows)
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_rp[mid] <= k0) lo = mid + 1; else hi = mid;
+        }
+        uint32_t row = lo - 1;
+        uint32_t row_end = s_rp[row + 1];
+        double part = 0.0;
+        const int g8 = (int)k0;
+        const int rot = (tid + (tid >> 3)) & 7;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t k = k0 + j;
+          if (k < ne) {
+            while (k >= row_end) {
+              if (part != 0.0) atomicAdd(&s_acc[row], part);
+              part = 0.0;
+              ++row;
+              row_end = s_rp[row + 1];
+            }
+            part += s_val[g8 | ((j + rot) & 7)];
+          }
+        }
+        if (part != 0.0) atomicAdd(&s_acc[row], part);
       }
       __syncthreads();
-      if ((uint32_t)tid < r1 - r0) {
+      // 3. one row per thread
+      if ((uint32_t)tid < nrows) {
         u = (int32_t)(r0 + tid);
-        const int kb = (int)(in_rp[u] - e0), ke = (int)(in_rp[u + 1] - e0);
-        for (int k = kb; k < ke; ++k) acc += s_val[swz(k)];
+        acc = s_acc[tid];
         have = true;
       }
     }
@@ -298,14 +397,42 @@ __global__ __launch_bounds__(256) void k_dense_tiles(const uint32_t* __restrict_
     }
     c_next[u] = cn;
   }
+  // per-workgroup partials; k_dense_reduce sums them (no same-address atomics in this kernel)
   const double ds = block_sum_f64(dead_next, s_red);
   const unsigned long long ps = block_sum_u64(pack, s_red2);
   const unsigned long long nd = block_sum_u64(ndead, s_red2);
   if (tid == 0) {
-    if (ps) atomic_add_u64(&ctr->packed[out_slot], ps);
+    blk_pack[t] = ps;
+    blk_dead[t] = ds;
+    blk_ndead[t] = (uint32_t)nd;
+  }
+}
+
+// sums the per-workgroup partials of a dense level into the level counter, the dead-mass cell
+// and the dead-end pop count
+__global__ __launch_bounds__(1024) void k_dense_reduce(const unsigned long long* __restrict__ blk_pack,
+                                                        const double* __restrict__ blk_dead,
+                                                        const uint32_t* __restrict__ blk_ndead, uint32_t n_blocks,
+                                                        DevCounters* ctr, int out_slot, int dead_slot_next) {
+  __shared__ double s_red[16];
+  __shared__ unsigned long long s_red2[16];
+  unsigned long long pack = 0, ndead = 0;
+  double dead = 0.0;
+  for (uint32_t i = threadIdx.x; i < n_blocks; i += blockDim.x) {
+    pack += blk_pack[i];
+    if (blk_dead) {
+      dead += blk_dead[i];
+      ndead += blk_ndead[i];
+    }
+  }
+  const unsigned long long ps = block_sum_u64(pack, s_red2);
+  const unsigned long long nd = block_sum_u64(ndead, s_red2);
+  const double ds = block_sum_f64(dead, s_red);
+  if (threadIdx.x == 0) {
+    ctr->packed[out_slot] = ps;
     if (nd) {
-      atomic_add_noret(&ctr->dead[dead_slot ^ 1], ds);
-      atomic_add_u64(&ctr->dead_pops, nd);
+      ctr->dead[dead_slot_next] = ctr->dead[dead_slot_next] + ds;
+      ctr->dead_pops += nd;
     }
   }
 }
@@ -317,55 +444,68 @@ __global__ __launch_bounds__(256) void k_dense_tiles(const uint32_t* __restrict_
 //             1 = top-k round start from the parked set (Forward_Push.java:163,173,241-247)
 template <int KIND>
 __device__ __forceinline__ bool seed_pred(uint32_t v, const double* __restrict__ res, uint32_t d,
-                                          uint8_t* __restrict__ flags, const PushArgs& a, bool mutate) {
+                                          const uint8_t* __restrict__ flags, const PushArgs& a) {
+  if (KIND == 1 && !flags[v]) return false;
+  return active_fwd(res[v], d, a.rmax);
+}
+
+// top-k round start: parked nodes that start the round leave the parked set; parked nodes that
+// fell below min_rmax are dropped (Forward_Push.java:241-247 keeps the others parked)
+__device__ __forceinline__ void unpark(uint32_t v, const double* __restrict__ res, uint32_t d,
+                                       uint8_t* __restrict__ flags, const PushArgs& a) {
+  if (!flags[v]) return;
   const double r = res[v];
-  if (KIND == 0) return active_fwd(r, d, a.rmax);
-  if (!flags[v]) return false;
-  if (active_fwd(r, d, a.rmax)) {
-    if (mutate) flags[v] = 0;
-    return true;
-  }
-  if (mutate && !active_fwd(r, d, a.min_rmax)) flags[v] = 0;
-  return false;
+  if (active_fwd(r, d, a.rmax) || !active_fwd(r, d, a.min_rmax)) flags[v] = 0;
 }
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_count_active(uint32_t n, const double* __restrict__ res,
-                                                       const uint32_t* __restrict__ out_rp, uint8_t* __restrict__ flags,
-                                                       DevCounters* ctr, int out_slot, PushArgs a) {
+                                                       const uint32_t* __restrict__ out_rp,
+                                                       const uint8_t* __restrict__ flags,
+                                                       unsigned long long* __restrict__ blk_pack, PushArgs a) {
   __shared__ unsigned long long s_red2[4];
   unsigned long long pack = 0;
   for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
     const uint32_t d = out_rp[v + 1] - out_rp[v];
-    if (seed_pred<KIND>(v, res, d, flags, a, false)) pack += (1ull << kPackShift) | (unsigned long long)d;
+    if (seed_pred<KIND>(v, res, d, flags, a)) pack += (1ull << kPackShift) | (unsigned long long)d;
   }
   const unsigned long long ps = block_sum_u64(pack, s_red2);
-  if (threadIdx.x == 0 && ps) atomic_add_u64(&ctr->packed[out_slot], ps);
+  if (threadIdx.x == 0) blk_pack[blockIdx.x] = ps;
 }
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_seed_list(uint32_t n, const double* __restrict__ res,
                                                     const uint32_t* __restrict__ out_rp, uint8_t* __restrict__ flags,
                                                     int32_t* __restrict__ Fn, uint32_t* __restrict__ eoffn,
-                                                    DevCounters* ctr, int out_slot, PushArgs a) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t nround = (n + stride - 1) / stride * stride;  // keep whole waves convergent
-  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nround; v += stride) {
-    bool take = false;
-    uint32_t d = 0;
-    if (v < n) {
-      d = out_rp[v + 1] - out_rp[v];
-      take = seed_pred<KIND>(v, res, d, flags, a, true);
-    }
-    wave_append(take, (int32_t)v, d, Fn, eoffn, &ctr->packed[out_slot]);
+                                                    unsigned long long* counter, PushArgs a) {
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per;
+  const uint32_t hi = lo + per < n ? lo + per : n;
+  if (lo >= hi) return;
+  block_range_compact(
+      lo, hi, counter,
+      [&](uint32_t v, unsigned long long* w) {
+        const uint32_t d = out_rp[v + 1] - out_rp[v];
+        *w = d;
+        return seed_pred<KIND>(v, res, d, flags, a);
+      },
+      [&](uint32_t v, uint32_t pos, unsigned long long eo, unsigned long long) {
+        Fn[pos] = (int32_t)v;
+        eoffn[pos] = (uint32_t)eo;
+      });
+  if (KIND == 1) {
+    __syncthreads();
+    for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) unpark(v, res, out_rp[v + 1] - out_rp[v], flags, a);
   }
 }
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_seed_dense(uint32_t n, double* __restrict__ res, double* __restrict__ reserve,
                                                      const uint32_t* __restrict__ out_rp, uint8_t* __restrict__ flags,
-                                                     double* __restrict__ c_dense, DevCounters* ctr, int out_slot,
-                                                     int dead_slot, PushArgs a) {
+                                                     double* __restrict__ c_dense,
+                                                     unsigned long long* __restrict__ blk_pack,
+                                                     double* __restrict__ blk_dead, uint32_t* __restrict__ blk_ndead,
+                                                     PushArgs a) {
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
   double dead = 0.0;
@@ -373,7 +513,9 @@ __global__ __launch_bounds__(256) void k_seed_dense(uint32_t n, double* __restri
   for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
     const uint32_t d = out_rp[v + 1] - out_rp[v];
     double c = 0.0;
-    if (seed_pred<KIND>(v, res, d, flags, a, true)) {
+    const bool take = seed_pred<KIND>(v, res, d, flags, a);
+    if (KIND == 1) unpark(v, res, d, flags, a);
+    if (take) {
       const double rc = res[v];
       res[v] = 0.0;
       reserve[v] = reserve[v] + rc * a.alpha;
@@ -391,11 +533,9 @@ __global__ __launch_bounds__(256) void k_seed_dense(uint32_t n, double* __restri
   const unsigned long long ps = block_sum_u64(pack, s_red2);
   const unsigned long long nd = block_sum_u64(ndead, s_red2);
   if (threadIdx.x == 0) {
-    if (ps) atomic_add_u64(&ctr->packed[out_slot], ps);
-    if (nd) {
-      atomic_add_noret(&ctr->dead[dead_slot], ds);
-      atomic_add_u64(&ctr->dead_pops, nd);
-    }
+    blk_pack[blockIdx.x] = ps;
+    blk_dead[blockIdx.x] = ds;
+    blk_ndead[blockIdx.x] = (uint32_t)nd;
   }
 }
 
@@ -403,19 +543,23 @@ __global__ __launch_bounds__(256) void k_seed_dense(uint32_t n, double* __restri
 __global__ __launch_bounds__(256) void k_compact_prepared(uint32_t n, const double* __restrict__ c_dense,
                                                            const uint32_t* __restrict__ trp, int32_t* __restrict__ Fn,
                                                            uint32_t* __restrict__ eoffn, double* __restrict__ cF,
-                                                           DevCounters* ctr, int out_slot) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t nround = (n + stride - 1) / stride * stride;
-  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nround; v += stride) {
-    double c = 0.0;
-    uint32_t d = 0;
-    if (v < n) {
-      c = c_dense[v];
-      if (c > 0.0) d = trp[v + 1] - trp[v];
-    }
-    const uint32_t pos = wave_append(c > 0.0, (int32_t)v, d, Fn, eoffn, &ctr->packed[out_slot]);
-    if (c > 0.0) cF[pos] = c;
-  }
+                                                           unsigned long long* counter) {
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per;
+  const uint32_t hi = lo + per < n ? lo + per : n;
+  if (lo >= hi) return;
+  block_range_compact(
+      lo, hi, counter,
+      [&](uint32_t v, unsigned long long* w) {
+        if (!(c_dense[v] > 0.0)) return false;
+        *w = trp[v + 1] - trp[v];
+        return true;
+      },
+      [&](uint32_t v, uint32_t pos, unsigned long long eo, unsigned long long) {
+        Fn[pos] = (int32_t)v;
+        eoffn[pos] = (uint32_t)eo;
+        cF[pos] = c_dense[v];
+      });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,99 +602,110 @@ static inline uint32_t grid_for(uint64_t work, uint32_t per_block, uint32_t cap)
     default: { constexpr int M = kPower; __VA_ARGS__; } break;            \
   }
 
-int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, uint32_t nf, bool scatter_dense, int cbuf,
-                          int dead_slot) {
-  if (nf == 0) return PPRHIP_OK;
-  const uint32_t grid = (nf + 255) / 256;
+int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t nf_upper,
+                          unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot) {
+  const uint32_t grid = grid_for(nf_upper, 256, 512);
   double* cd = scatter_dense ? g->cdense[cbuf] : nullptr;
   DISPATCH_MODE(a.mode, k_sparse_prepare<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                            g->F[fbuf], nf, g->out_rp, g->residue, g->reserve, g->cF, cd, g->ctr, dead_slot, a));
+                            g->F[fbuf], g->out_rp, g->residue, g->reserve, g->cF, cd, g->ctr, level, dense_thresh,
+                            dead_slot, a));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
-int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, const unsigned long long* d_in_counter,
-                       uint64_t ef_upper, int out_fbuf, int out_slot, int dead_slot) {
+int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
+                       unsigned long long dense_thresh, int dead_slot) {
   const uint32_t grid = grid_for(ef_upper, kPushTile, 2048);
   const bool bwd = a.mode == kBackward;
   const uint32_t* trp = bwd ? g->in_rp : g->out_rp;
   const int32_t* tci = bwd ? g->in_ci : g->out_ci;
   DISPATCH_MODE(a.mode, k_sparse_push<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                            g->F[fbuf], g->cF, g->eoff[fbuf], d_in_counter, trp, tci, g->out_rp, g->in_rp, g->residue,
-                            g->flags, g->F[out_fbuf], g->eoff[out_fbuf], g->ctr, out_slot, dead_slot, a));
+                            g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_rp, g->in_rp, g->residue, g->flags,
+                            g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot, a));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot) {
   if (g->n_hub_chunks) {
-    hipLaunchKernelGGL(k_hub_pull, dim3(grid_for(g->n_hub_chunks, 1, 4096)), dim3(256), 0, g->stream, g->hub_chunks,
-                       g->n_hub_chunks, g->in_ci, g->cdense[cbuf], g->hubacc);
+    k_hub_pull<<<dim3(grid_for(g->n_hub_chunks, 1, 8192)), dim3(256), 0, g->stream>>>(
+        g->hub_chunks, g->n_hub_chunks, g->in_ci, g->cdense[cbuf], g->hubacc);
     PPRHIP_CHECK_HIP(hipGetLastError());
   }
   const uint32_t grid = g->n_tiles + (g->n_hubs + 255) / 256;
   DISPATCH_MODE(a.mode, k_dense_tiles<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
                             g->tile_row, g->n_tiles, g->in_rp, g->in_ci, g->out_rp, g->cdense[cbuf],
                             g->cdense[cbuf ^ 1], g->residue, g->reserve, g->flags, g->hub_rows, g->n_hubs, g->hubacc,
-                            g->ctr, out_slot, dead_slot, a));
+                            g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead, dead_slot, a));
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, g->blk_dead, g->blk_ndead, grid, g->ctr,
+                                                        out_slot, dead_slot ^ 1);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
-int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, int out_slot, bool backward) {
-  const uint32_t grid = grid_for(g->n, 256, 2048);
-  hipLaunchKernelGGL(k_compact_prepared, dim3(grid), dim3(256), 0, g->stream, g->n, g->cdense[cbuf],
-                     backward ? g->in_rp : g->out_rp, g->F[out_fbuf], g->eoff[out_fbuf], g->cF, g->ctr, out_slot);
+int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward) {
+  const uint32_t grid = grid_for(g->n, 1024, 1024);
+  k_compact_prepared<<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->cdense[cbuf], backward ? g->in_rp : g->out_rp,
+                                                              g->F[out_fbuf], g->eoff[out_fbuf], g->cF, d_counter);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+// block partial counts -> ctr->packed[out_slot] (reuses the dense reducer with no dead mass)
+static int reduce_partials(pprhip_graph* g, uint32_t n_blocks, int out_slot, int dead_slot, bool with_dead) {
+  k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, with_dead ? g->blk_dead : nullptr, g->blk_ndead,
+                                                        n_blocks, g->ctr, out_slot, dead_slot);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
 int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot) {
-  const uint32_t grid = grid_for(g->n, 256, 2048);
+  const uint32_t grid = grid_for(g->n, 256 * 8, 1024);
   if (seed_kind == 0)
-    hipLaunchKernelGGL(k_count_active<0>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, g->out_rp, g->flags,
-                       g->ctr, out_slot, a);
+    k_count_active<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->blk_pack, a);
   else
-    hipLaunchKernelGGL(k_count_active<1>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, g->out_rp, g->flags,
-                       g->ctr, out_slot, a);
+    k_count_active<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->blk_pack, a);
   PPRHIP_CHECK_HIP(hipGetLastError());
-  return PPRHIP_OK;
+  return reduce_partials(g, grid, out_slot, 0, false);
 }
 
-int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, int out_slot) {
-  const uint32_t grid = grid_for(g->n, 256, 2048);
+int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter) {
+  const uint32_t grid = grid_for(g->n, 1024, 1024);
   if (seed_kind == 0)
-    hipLaunchKernelGGL(k_seed_list<0>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, g->out_rp, g->flags,
-                       g->F[out_fbuf], g->eoff[out_fbuf], g->ctr, out_slot, a);
+    k_seed_list<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->F[out_fbuf],
+                                                            g->eoff[out_fbuf], d_counter, a);
   else
-    hipLaunchKernelGGL(k_seed_list<1>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, g->out_rp, g->flags,
-                       g->F[out_fbuf], g->eoff[out_fbuf], g->ctr, out_slot, a);
+    k_seed_list<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->F[out_fbuf],
+                                                            g->eoff[out_fbuf], d_counter, a);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
 int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbuf, int out_slot, int dead_slot) {
-  const uint32_t grid = grid_for(g->n, 256, 2048);
+  const uint32_t grid = grid_for(g->n, 256 * 8, 1024);
   if (seed_kind == 0)
-    hipLaunchKernelGGL(k_seed_dense<0>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, g->reserve, g->out_rp,
-                       g->flags, g->cdense[cbuf], g->ctr, out_slot, dead_slot, a);
+    k_seed_dense<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->reserve, g->out_rp, g->flags,
+                                                             g->cdense[cbuf], g->blk_pack, g->blk_dead,
+                                                             g->blk_ndead, a);
   else
-    hipLaunchKernelGGL(k_seed_dense<1>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, g->reserve, g->out_rp,
-                       g->flags, g->cdense[cbuf], g->ctr, out_slot, dead_slot, a);
+    k_seed_dense<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->reserve, g->out_rp, g->flags,
+                                                             g->cdense[cbuf], g->blk_pack, g->blk_dead,
+                                                             g->blk_ndead, a);
   PPRHIP_CHECK_HIP(hipGetLastError());
-  return PPRHIP_OK;
+  return reduce_partials(g, grid, out_slot, dead_slot, true);
 }
 
 int launch_sum(pprhip_graph* g, const double* x, uint32_t n) {
   const uint32_t np = grid_for(n, 256 * 16, 1024);
-  hipLaunchKernelGGL(k_sum_partial, dim3(np), dim3(256), 0, g->stream, x, n, g->partial);
-  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, g->stream, g->partial, np, g->ctr);
+  k_sum_partial<<<dim3(np), dim3(256), 0, g->stream>>>(x, n, g->partial);
+  k_sum_final<<<dim3(1), dim3(256), 0, g->stream>>>(g->partial, np, g->ctr);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
 int launch_set_f64(pprhip_graph* g, double* p, uint32_t idx, double value) {
-  hipLaunchKernelGGL(k_set_f64, dim3(1), dim3(1), 0, g->stream, p, idx, value);
+  k_set_f64<<<dim3(1), dim3(1), 0, g->stream>>>(p, idx, value);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

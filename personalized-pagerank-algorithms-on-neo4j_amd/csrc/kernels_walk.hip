@@ -88,56 +88,54 @@ __device__ __forceinline__ bool walker_step(Walker& w, const uint32_t* __restric
 // ------------------------------------------------------------------------------------------------
 // walk plan: one entry per residue node, walk ranges as an exclusive prefix over entries
 // ------------------------------------------------------------------------------------------------
+// walks a residue entry starts, and the increment each of them carries
+template <int VARIANT>
+__device__ __forceinline__ bool plan_entry(double r, double alpha, double rsum, double nrw, unsigned long long* omega_i,
+                                           double* incr) {
+  if (!(r > 0.0) || !(nrw > 0.0)) return false;
+  if (VARIANT == 0) {  // Fora_Whole_Graph.java:123,129-131
+    if (!(rsum > 0.0)) return false;
+    r *= (1.0 - alpha);
+    const double x = r / rsum * nrw;
+    *omega_i = (unsigned long long)ceil(x);
+    const double a_i = x / (double)*omega_i;
+    *incr = a_i / nrw * rsum;
+  } else {  // Fora_Topk.java:157-159
+    const double x = r * nrw;
+    *omega_i = (unsigned long long)ceil(x);
+    const double a_i = x / (double)*omega_i;
+    *incr = a_i / nrw;
+  }
+  return *omega_i > 0;
+}
+
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __restrict__ res, double* __restrict__ target,
                                                   double alpha, double rsum, double nrw, int32_t* __restrict__ mc_node,
                                                   double* __restrict__ mc_inc, unsigned long long* __restrict__ mc_woff,
                                                   DevCounters* ctr) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t nround = (n + stride - 1) / stride * stride;
-  const int lane = lane_id();
-  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nround; v += stride) {
-    bool take = false;
-    unsigned long long omega_i = 0;
-    double incr = 0.0;
-    if (v < n) {
-      double r = res[v];
-      if (r > 0.0) {
-        if (VARIANT == 0) {  // Fora_Whole_Graph.java:119-131
-          const double incr_cur = r * alpha;
-          r *= (1.0 - alpha);
-          target[v] = target[v] + incr_cur;
-          if (nrw > 0.0 && rsum > 0.0) {
-            const double x = r / rsum * nrw;
-            omega_i = (unsigned long long)ceil(x);
-            const double a_i = x / (double)omega_i;
-            incr = a_i / nrw * rsum;
-            take = omega_i > 0;
-          }
-        } else if (nrw > 0.0) {  // Fora_Topk.java:155-160
-          const double x = r * nrw;
-          omega_i = (unsigned long long)ceil(x);
-          const double a_i = x / (double)omega_i;
-          incr = a_i / nrw;
-          take = omega_i > 0;
-        }
-      }
-    }
-    const unsigned long long mask = __ballot(take);
-    if (mask == 0) continue;
-    const unsigned long long mine = take ? omega_i : 0ull;
-    const unsigned long long incl = wave_incl_scan_u64(mine);
-    const unsigned long long total = __shfl(incl, 63);
-    const int leader = __ffsll((long long)mask) - 1;
-    unsigned long long base = 0;
-    if (lane == leader)
-      base = atomic_add_u64(&ctr->mc_packed, ((unsigned long long)__popcll(mask) << kPackShift) | total);
-    base = __shfl(base, leader);
-    if (take) {
-      const uint32_t pos = (uint32_t)(base >> kPackShift) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      mc_node[pos] = (int32_t)v;
-      mc_inc[pos] = incr;
-      mc_woff[pos] = (base & kPackMask) + incl - mine;
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per;
+  const uint32_t hi = lo + per < n ? lo + per : n;
+  if (lo >= hi) return;
+  block_range_compact(
+      lo, hi, &ctr->mc_packed,
+      [&](uint32_t v, unsigned long long* w) {
+        double incr;
+        return plan_entry<VARIANT>(res[v], alpha, rsum, nrw, w, &incr);
+      },
+      [&](uint32_t v, uint32_t pos, unsigned long long woff, unsigned long long) {
+        unsigned long long w;
+        double incr = 0.0;
+        (void)plan_entry<VARIANT>(res[v], alpha, rsum, nrw, &w, &incr);
+        mc_node[pos] = (int32_t)v;
+        mc_inc[pos] = incr;
+        mc_woff[pos] = woff;
+      });
+  if (VARIANT == 0) {  // Fora_Whole_Graph.java:122,124-127: every residue entry credits alpha * r to its own reserve
+    for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
+      const double r = res[v];
+      if (r > 0.0) target[v] = target[v] + r * alpha;
     }
   }
 }
@@ -270,8 +268,8 @@ __global__ void k_plan_single(int32_t src, double inc, int32_t* mc_node, double*
 // launchers
 // ------------------------------------------------------------------------------------------------
 int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double* target) {
-  uint64_t b = ((uint64_t)g->n + 255) / 256;
-  const uint32_t grid = (uint32_t)(b > 2048 ? 2048 : b);
+  uint64_t b = ((uint64_t)g->n + 1023) / 1024;
+  const uint32_t grid = (uint32_t)(b > 1024 ? 1024 : b);
   if (variant == 0)
     hipLaunchKernelGGL(k_mc_plan<0>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, target, alpha, rsum, nrw,
                        g->mc_node, g->mc_inc, g->mc_woff, g->ctr);

@@ -137,7 +137,8 @@ def test_fora_single_source_got(pkg, orc, got, dev_got, n_rounds):
         assert st.rounds == sto.rounds
         assert st.walks == sto.walks and st.walk_steps == sto.walk_steps
         assert_close(est, ref, TOL_MC, "fora src=%d" % s)
-        assert abs(est.sum() - 1.0) < 1e-9
+        # all mass is delivered unless floor(omega * rsum) == 0 (then the reference drops (1-alpha)*rsum too)
+        assert abs(est.sum() - 1.0) < 1e-9 or (st.walks == 0 and abs(est.sum() + st.rsum - 1.0) < 1e-9)
 
 
 def test_fora_single_source_rmat12(pkg, orc, rmat12, dev_rmat12):
