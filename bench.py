@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — single-source FORA queries/sec on a synthetic R-MAT graph (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (N = 1): R-MAT scale 22 (n = 4 194 304, m = 67 108 864, generator seed 1), single-source
+FORA with alpha = 0.15, eps = 0.5; a *step* is one batch of `--queries-per-step` sources drawn
+uniformly from [0, n) with seed 2 (as Gen_Util.getQueryNodes does, so dead-end sources, which
+short-circuit, are in the mix).  The graph is lifted into HBM once before the timed region;
+results stay in HBM.  `value` = queries / second over all ranks.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): the CSR is replicated, every rank
+runs its own batch per step (weak scaling, no data-path collective), extracts each query's top-32
+on the device and the per-step top-k blocks are gathered to rank 0 over RCCL.
+
+Extra objects on the JSON line: `roofline` (dominant kernel, HIP-event time on the engine's
+stream, algorithmic bytes from DESIGN.md's byte model) and `cpu_baseline` (the CPU oracle's
+clock-driven FIFO FORA, one core, bounded sample; rank 0 at N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALPHA = 0.15
+EPS = 0.5
+TOPK = 32
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scale", type=int, default=22)
+    ap.add_argument("--queries-per-step", type=int, default=8)
+    ap.add_argument("--rounds", type=int, default=0, help="FORA threshold rounds (0 = cost model)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-walk-divisor", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    import torch  # first: libpprhip.so then binds to the HIP runtime torch already loaded
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
+
+    # ---- graph lift (outside the timed region)
+    t0 = time.time()
+    host = pkg.HostCsr.rmat(args.scale, 16, seed=1)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    g = pkg.Graph(host, device=local_rank)
+    t_lift = time.time() - t0
+    conf = pkg.conf_whole_graph(host.n, host.m, ALPHA)
+    outdeg = np.diff(host.out_rp)
+
+    q = args.queries_per_step
+    total_steps = args.warmup + args.steps
+    rng = np.random.default_rng(2 + 7919 * rank)
+    srcs = rng.integers(0, host.n, size=(total_steps, q)).astype(np.int32)
+
+    ids_blk = torch.empty((q, TOPK), dtype=torch.int32, device="cuda")
+    vals_blk = torch.empty((q, TOPK), dtype=torch.float64, device="cuda")
+    gather_ids = [torch.empty_like(ids_blk) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_vals = [torch.empty_like(vals_blk) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    acc = {"class_ms": [0.0] * 8, "class_bytes": [0] * 8, "class_launches": [0] * 8, "rounds": 0, "live": 0,
+           "walks": 0, "walk_steps": 0, "levels": 0, "dense_levels": 0, "push_ms": 0.0, "mc_ms": 0.0}
+
+    def run_step(i, record):
+        for j in range(q):
+            s = int(srcs[i, j])
+            _, st = g.fora_single_source(s, EPS, ALPHA, seed=3 + i * q + j, n_rounds=args.rounds, conf=conf,
+                                         fetch=False)
+            if record:
+                for c in range(8):
+                    acc["class_ms"][c] += st.class_ms[c]
+                    acc["class_bytes"][c] += st.class_bytes[c]
+                    acc["class_launches"][c] += st.class_launches[c]
+                acc["rounds"] += st.rounds
+                acc["live"] += int(outdeg[s] > 0)
+                acc["walks"] += st.walks
+                acc["walk_steps"] += st.walk_steps
+                acc["levels"] += st.levels
+                acc["dense_levels"] += st.dense_levels
+                acc["push_ms"] += st.push_ms
+                acc["mc_ms"] += st.mc_ms
+            if world > 1:
+                nsel, ids, vals, _, _ = g.topk_select(TOPK)
+                row_i = np.full(TOPK, -1, dtype=np.int32)
+                row_v = np.zeros(TOPK)
+                row_i[:len(ids)] = ids
+                row_v[:len(vals)] = vals
+                ids_blk[j].copy_(torch.from_numpy(row_i))
+                vals_blk[j].copy_(torch.from_numpy(row_v))
+        if world > 1:  # the only exchange on the path: top-k blocks to rank 0 (xGMI / RCCL)
+            dist.gather(ids_blk, gather_ids, dst=0)
+            dist.gather(vals_blk, gather_vals, dst=0)
+
+    for i in range(args.warmup):
+        run_step(i, False)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        run_step(i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n_queries = args.steps * q * world
+        value = n_queries / elapsed
+        live_frac = acc["live"] / max(1, args.steps * q)
+        # dominant kernel = the class with the largest summed HIP-event time over the timed region
+        dom = max(range(1, 8), key=lambda c: acc["class_ms"][c])
+        dom_ms, dom_bytes, dom_n = acc["class_ms"][dom], acc["class_bytes"][dom], acc["class_launches"][dom]
+        achieved = (dom_bytes / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(pkg.KERNEL_NAMES[dom], {}).get("scale%d" % args.scale)
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "kernel": pkg.KERNEL_NAMES[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "launches": dom_n, "avg_launch_us": round(1e3 * dom_ms / max(1, dom_n), 2),
+            "algorithmic_bytes_per_launch": int(dom_bytes / max(1, dom_n)),
+            "other_kernels": {
+                pkg.KERNEL_NAMES[c]: {
+                    "ms": round(acc["class_ms"][c], 3), "launches": acc["class_launches"][c],
+                    "achieved_GBps": round((acc["class_bytes"][c] / 1e9) / (acc["class_ms"][c] / 1e3), 1)
+                    if acc["class_ms"][c] > 0 else 0.0}
+                for c in range(1, 4) if c != dom},
+        }
+        out = {
+            "metric": "single-source PPR queries/sec (FORA, alpha=0.15, eps=0.5)", "value": round(value, 3),
+            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "RMAT scale-%d (n=%d, m=%d, seed 1) single-source FORA, %d uniformly drawn "
+                                   "sources per step per GPU (seed 2; dead-end sources included)"
+                                   % (args.scale, host.n, host.m, q),
+                       "alpha": ALPHA, "eps": EPS, "queries_per_step": q, "rounds": args.rounds or "cost-model",
+                       "sharding": "replicated CSR, sources sharded by rank, top-%d gather to rank 0" % TOPK
+                       if world > 1 else "single GPU"},
+            "queries_per_s_live_sources": round(acc["live"] * world / elapsed, 3),
+            "live_source_fraction": round(live_frac, 3),
+            "avg_rounds": round(acc["rounds"] / max(1, args.steps * q), 2),
+            "phase_ms_per_live_query": {"push": round(acc["push_ms"] / max(1, acc["live"]), 3),
+                                        "walk": round(acc["mc_ms"] / max(1, acc["live"]), 3)},
+            "graph_lift_s": {"generate_and_csr": round(t_gen, 2), "upload_and_tile": round(t_lift, 2)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host, srcs[args.warmup:], outdeg, live_frac, args.cpu_walk_divisor)
+        print(json.dumps(out), flush=True)
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(host, srcs, outdeg, live_frac, walk_divisor):
+    """The CPU oracle's clock-driven FIFO FORA (the reference's algorithm as written, dense-array
+    port) on one core: one live source of the timed batch, first push round in full, every
+    `walk_divisor`-th walk, scaled back.  Dead-end sources cost ~0 on the CPU as well."""
+    from oracle import oracle as orc
+    og = orc.OracleGraph(host.n, host.out_rp, host.out_ci, host.in_rp, host.in_ci)
+    live = [int(s) for s in srcs.ravel() if outdeg[int(s)] > 0]
+    if not live:
+        return {"value": None, "unit": "queries/s", "cores": 1, "kind": "port", "sample": "no live source in batch"}
+    s = live[0]
+    t0 = time.time()
+    _, push_s, walk_s, st = og.fora_whole_baseline(s, EPS, ALPHA, seed=3, walk_divisor=walk_divisor, max_rounds=0)
+    wall = time.time() - t0
+    t_live = push_s + walk_s * walk_divisor
+    value = 1.0 / (t_live * max(live_frac, 1e-9))
+    return {"value": round(value, 5), "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": "source %d (out-degree %d): the reference's clock-driven push loop in full (%d FIFO rounds, "
+                      "%.1f s, %d edge pushes) + every %d-th of its %d walks (%.1f s), scaled to one query = %.1f s; "
+                      "divided by the batch's live-source fraction %.3f (dead-end sources return at once on the CPU "
+                      "too); %.0f s of CPU work" % (s, int(outdeg[s]), st.rounds, push_s, st.edge_pushes,
+                                                    walk_divisor, st.walks * walk_divisor, walk_s, t_live, live_frac,
+                                                    wall),
+            "seconds_per_live_query": round(t_live, 2)}
+
+
+if __name__ == "__main__":
+    main()

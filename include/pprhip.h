@@ -76,6 +76,11 @@ typedef struct pprhip_stats {
   uint64_t dominant_kernel_bytes; /* algorithmic bytes those launches moved */
   uint32_t dominant_kernel_launches;
   uint32_t dominant_kernel_id;  /* PPRHIP_KERNEL_* */
+  /* the same three figures for every kernel class, indexed by PPRHIP_KERNEL_* (HIP events on the
+   * engine's stream around each launch; a sparse batch counts as one launch of class 2) */
+  double class_ms[8];
+  uint64_t class_bytes[8];
+  uint32_t class_launches[8];
 } pprhip_stats_t;
 
 #define PPRHIP_KERNEL_NONE 0

@@ -75,6 +75,9 @@ def lib():
         L.orc_fora_whole.restype = None
         L.orc_fora_whole.argtypes = [C.POINTER(Graph), C.c_int, C.c_int32, C.c_double, C.POINTER(Conf), C.c_uint64,
                                      C.c_int, C.POINTER(Tuning), C.c_void_p, C.POINTER(Stats)]
+        L.orc_fora_whole_baseline.restype = None
+        L.orc_fora_whole_baseline.argtypes = [C.POINTER(Graph), C.c_int32, C.c_double, C.POINTER(Conf), C.c_uint64,
+                                              C.c_uint64, C.c_int, dp, dp, C.c_void_p, C.POINTER(Stats)]
         L.orc_fora_topk.restype = None
         L.orc_fora_topk.argtypes = [C.POINTER(Graph), C.c_int, C.c_int32, C.c_double, C.POINTER(Conf), C.c_uint64,
                                     C.c_void_p, C.POINTER(Stats)]
@@ -178,6 +181,16 @@ class OracleGraph:
         lib().orc_fora_whole(C.byref(self.c), schedule, src, eps, C.byref(conf), seed, n_rounds,
                              C.byref(tuning) if tuning is not None else None, _ptr(out), C.byref(st))
         return out, st
+
+    def fora_whole_baseline(self, src, eps, alpha, seed, walk_divisor=1, max_rounds=0):
+        """Clock-driven FIFO FORA as the reference wrote it; returns (estimate, push_s, walk_s, stats)."""
+        conf = self.conf_whole(alpha)
+        out = np.zeros(self.n)
+        st = Stats()
+        ps, ws = C.c_double(), C.c_double()
+        lib().orc_fora_whole_baseline(C.byref(self.c), src, eps, C.byref(conf), seed, walk_divisor, max_rounds,
+                                      C.byref(ps), C.byref(ws), _ptr(out), C.byref(st))
+        return out, ps.value, ws.value, st
 
     def fora_topk(self, src, eps, alpha, k, seed, schedule=SYNC, conf=None):
         conf = conf or self.conf_topk(k, alpha)

@@ -12,11 +12,13 @@
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math (no FMA contraction, so the doubles match the
  * HIP kernels, which are built with -ffp-contract=off too).
  */
+#define _POSIX_C_SOURCE 199309L
 #include "ppr_oracle.h"
 
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ helpers */
 
@@ -994,6 +996,75 @@ void orc_all_pair_backward(const orc_graph* g, int schedule, double alpha, doubl
   *offsets_out = off;
   *targets_out = ot;
   *values_out = ov;
+}
+
+
+/* ------------------------------------------------------------------ CPU baseline (bench.py cpu_baseline leg) */
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void orc_fora_whole_baseline(const orc_graph* g, int32_t src, double eps, const orc_conf* c, uint64_t seed,
+                             uint64_t walk_divisor, int max_rounds, double* push_s, double* walk_s, double* reserve,
+                             orc_stats* st) {
+  /* Fora_Whole_Graph.java:82-146 exactly as written: FIFO pushes restarted from scratch while the
+   * measured push time is below 400 ns * rsum * omega (:35,75-79,93-103), then the walks.  Only
+   * every walk_divisor-th walk is run (and timed) so that a bench sample stays bounded; the
+   * caller scales walk_s by walk_divisor.  max_rounds > 0 also caps the push loop (a run the
+   * reference's clock can produce as well, with more walks in exchange). */
+  uint32_t n = g->n;
+  orc_stats local;
+  if (!st) st = &local;
+  memset(st, 0, sizeof *st);
+  double alpha = c->alpha, rsum_local = c->rsum, rmax_local, omega_local;
+  orc_fora_whole_params(c, eps, &rmax_local, &omega_local);
+  double* residue = (double*)xcalloc(n, sizeof(double));
+  double dur_ns = 0.0;
+  int rounds = 0;
+  while (dur_ns < 400.0 * rsum_local * omega_local && (max_rounds <= 0 || rounds < max_rounds)) {
+    orc_stats ps;
+    memset(&ps, 0, sizeof ps);
+    double t0 = now_s();
+    double fp_rsum = fwd_push_fifo(g, src, alpha, rmax_local, reserve, residue, &ps);
+    dur_ns += (now_s() - t0) * 1e9;
+    st->pops += ps.pops; st->edge_pushes += ps.edge_pushes; st->enqueues += ps.enqueues;
+    rsum_local = fp_rsum * (1 - alpha);
+    st->rmax_final = rmax_local;
+    rmax_local /= 2.0;
+    rounds++;
+  }
+  *push_s = dur_ns * 1e-9;
+  st->rounds = (uint32_t)rounds;
+  st->rsum = rsum_local;
+  st->omega = omega_local;
+  double t0 = now_s();
+  double nrw_d = omega_local * rsum_local;
+  long long nrw = (nrw_d == nrw_d) ? (long long)nrw_d : 0;
+  uint64_t counter = 0;
+  if (walk_divisor == 0) walk_divisor = 1;
+  for (uint32_t v = 0; v < n; ++v) {
+    double r = residue[v];
+    if (!(r > 0.0)) continue;
+    reserve[v] = reserve[v] + r * alpha;
+    r *= (1.0 - alpha);
+    if (nrw <= 0 || !(rsum_local > 0.0)) continue;
+    long long omega_i = (long long)ceil(r / rsum_local * (double)nrw);
+    double a_i = r / rsum_local * (double)nrw / (double)omega_i;
+    double incr = a_i / (double)nrw * rsum_local;
+    for (long long j = 0; j < omega_i; ++j) {
+      if (counter++ % walk_divisor) continue;
+      uint32_t steps;
+      int32_t t = orc_random_walk(g, (int32_t)v, alpha, seed, 0, (uint64_t)j, 1, &steps);
+      reserve[t] = reserve[t] + incr;
+      st->walks++;
+      st->walk_steps += steps;
+    }
+  }
+  *walk_s = now_s() - t0;
+  free(residue);
 }
 
 /* ------------------------------------------------------------------ error metrics */

@@ -99,6 +99,12 @@ int32_t orc_random_walk(const orc_graph* g, int32_t start, double alpha, uint64_
 void orc_fora_whole(const orc_graph* g, int schedule, int32_t src, double eps, const orc_conf* c, uint64_t seed,
                     int n_rounds, const orc_tuning* tun, double* reserve, orc_stats* st);
 
+/* The reference's clock-driven FORA (Fora_Whole_Graph.java:93-103 with its 400 ns constant and the
+ * real clock), timed per phase; runs every walk_divisor-th walk only.  bench.py's cpu_baseline. */
+void orc_fora_whole_baseline(const orc_graph* g, int32_t src, double eps, const orc_conf* c, uint64_t seed,
+                             uint64_t walk_divisor, int max_rounds, double* push_s, double* walk_s, double* reserve,
+                             orc_stats* st);
+
 /* Fora_Topk.java:102-184 */
 void orc_fora_topk(const orc_graph* g, int schedule, int32_t src, double eps, const orc_conf* c, uint64_t seed,
                    double* reserve, orc_stats* st);

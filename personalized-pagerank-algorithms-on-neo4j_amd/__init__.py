@@ -36,10 +36,14 @@ class Stats(C.Structure):
                 ("select_ms", C.c_double), ("total_ms", C.c_double), ("push_bytes", C.c_uint64),
                 ("mc_bytes", C.c_uint64), ("select_bytes", C.c_uint64), ("dominant_kernel_ms", C.c_double),
                 ("dominant_kernel_bytes", C.c_uint64), ("dominant_kernel_launches", C.c_uint32),
-                ("dominant_kernel_id", C.c_uint32)]
+                ("dominant_kernel_id", C.c_uint32), ("class_ms", C.c_double * 8), ("class_bytes", C.c_uint64 * 8),
+                ("class_launches", C.c_uint32 * 8)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0" and not k.startswith("class_")}
+        for k in ("class_ms", "class_bytes", "class_launches"):
+            d[k] = list(getattr(self, k))
+        return d
 
 
 class Tuning(C.Structure):

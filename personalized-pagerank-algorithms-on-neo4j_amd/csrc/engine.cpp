@@ -313,6 +313,11 @@ struct CallTimer {
     int best = 0;
     for (int c = 1; c < 8; ++c)
       if (tot[c] > tot[best]) best = c;
+    for (int c = 0; c < 8; ++c) {
+      st.class_ms[c] = tot[c];
+      st.class_bytes[c] = bytes[c];
+      st.class_launches[c] = cnt[c];
+    }
     st.dominant_kernel_id = (uint32_t)best;
     st.dominant_kernel_ms = tot[best];
     st.dominant_kernel_bytes = bytes[best];
@@ -1113,6 +1118,11 @@ int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k,
     sum.walks += st.walks; sum.walk_steps += st.walk_steps; sum.select_passes += st.select_passes;
     sum.push_ms += st.push_ms; sum.mc_ms += st.mc_ms; sum.select_ms += st.select_ms; sum.total_ms += st.total_ms;
     sum.push_bytes += st.push_bytes; sum.mc_bytes += st.mc_bytes; sum.select_bytes += st.select_bytes;
+    for (int c = 0; c < 8; ++c) {
+      sum.class_ms[c] += st.class_ms[c];
+      sum.class_bytes[c] += st.class_bytes[c];
+      sum.class_launches[c] += st.class_launches[c];
+    }
   }
   if (stats_sum) *stats_sum = sum;
   return PPRHIP_OK;

@@ -56,9 +56,10 @@ for rounds in [int(x) for x in a.rounds.split(",")]:
         wall = (time.time() - t0) * 1e3
         d = st.as_dict()
         print("src=%d deg=%d rounds=%d wall=%.2fms total=%.2f push=%.2f mc=%.2f sel=%.2f levels=%d dense=%d pops=%d edges=%d "
-              "walks=%d steps=%d rsum=%.4g rmax=%.3g dom=%s %.3fms x%d %.1fGB/s" % (
+              "walks=%d steps=%d rsum=%.4g rmax=%.3g dense=%.1fus/lvl sparse=%.1fus/batch dom=%s %.3fms x%d %.1fGB/s" % (
                   s, host.out_rp[s + 1] - host.out_rp[s], d["rounds"], wall, d["total_ms"], d["push_ms"], d["mc_ms"],
                   d["select_ms"], d["levels"], d["dense_levels"], d["pops"], d["edge_pushes"], d["walks"],
-                  d["walk_steps"], d["rsum"], d["rmax_final"], pkg.KERNEL_NAMES[d["dominant_kernel_id"]],
+                  d["walk_steps"], d["rsum"], d["rmax_final"], 1e3 * d["class_ms"][1] / max(1, d["class_launches"][1]),
+                  1e3 * d["class_ms"][2] / max(1, d["class_launches"][2]), pkg.KERNEL_NAMES[d["dominant_kernel_id"]],
                   d["dominant_kernel_ms"], d["dominant_kernel_launches"],
                   d["dominant_kernel_bytes"] / max(d["dominant_kernel_ms"], 1e-9) / 1e6), flush=True)
