@@ -32,9 +32,7 @@ const char* get_error();
   } while (0)
 
 // Layout constants shared by graph build (host) and kernels (device).
-constexpr int kTileEdges = 2048;  // in-edges gathered by one workgroup of the dense pull sweep
-constexpr int kTileRows = 256;    // rows one workgroup applies (one per thread)
-constexpr int kHubChunk = 8192;   // in-edges of a hub row summed by one workgroup
+constexpr int kChunkPad = 512;  // in-edges one wave of the dense pull sweep owns (8 per lane)
 constexpr int kBlock = 256;
 
 // packed frontier counter: entries in the high 28 bits, edge total in the low 36 bits

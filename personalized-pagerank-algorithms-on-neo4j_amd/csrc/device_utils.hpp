@@ -86,6 +86,57 @@ __device__ __forceinline__ unsigned long long atomic_add_u64(unsigned long long*
   return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+
+// ---- DPP cross-lane helpers (gfx9 family: row_shr within 16-lane rows, row_bcast across rows).
+// A wave scan built from these costs a few dozen VALU instructions; the generic __shfl_up path
+// goes through ds_bpermute and a wait per step.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v));
+  const int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// inclusive scan of one u32 per lane over the wave
+__device__ __forceinline__ uint32_t wave_incl_scan_u32_dpp(uint32_t x) {
+  x += (uint32_t)dpp_i32<0x111, 0xf>((int)x);  // row_shr:1
+  x += (uint32_t)dpp_i32<0x112, 0xf>((int)x);  // row_shr:2
+  x += (uint32_t)dpp_i32<0x114, 0xf>((int)x);  // row_shr:4
+  x += (uint32_t)dpp_i32<0x118, 0xf>((int)x);  // row_shr:8
+  x += (uint32_t)dpp_i32<0x142, 0xa>((int)x);  // row_bcast:15 -> rows 1, 3
+  x += (uint32_t)dpp_i32<0x143, 0xc>((int)x);  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+// inclusive segmented sum over the wave: S(l) = x(l) + (head(l) ? 0 : S(l-1))
+__device__ __forceinline__ double wave_seg_scan_f64_dpp(double val, bool head) {
+  int flag = head ? 1 : 0;
+#define PPRHIP_SEG_STEP(CTRL, RM)                       \
+  {                                                     \
+    const double tv = dpp_f64<CTRL, RM>(val);           \
+    const int tf = dpp_i32<CTRL, RM>(flag);             \
+    if (!flag) {                                        \
+      val += tv;                                        \
+      flag = tf;                                        \
+    }                                                   \
+  }
+  PPRHIP_SEG_STEP(0x111, 0xf)
+  PPRHIP_SEG_STEP(0x112, 0xf)
+  PPRHIP_SEG_STEP(0x114, 0xf)
+  PPRHIP_SEG_STEP(0x118, 0xf)
+  PPRHIP_SEG_STEP(0x142, 0xa)
+  PPRHIP_SEG_STEP(0x143, 0xc)
+#undef PPRHIP_SEG_STEP
+  return val;
+}
+
+// value of the previous lane (0 for lane 0)
+__device__ __forceinline__ double wave_prev_f64_dpp(double v) { return dpp_f64<0x138, 0xf>(v); }  // wave_shr:1
+
 // Wave-aggregated append of (node, degree) pairs to a frontier.  One packed 64-bit atomic per
 // wave reserves both the list slots (high bits) and the edge range (low 36 bits), so the list's
 // edge offsets are an exclusive prefix sum in list order without any scan kernel.

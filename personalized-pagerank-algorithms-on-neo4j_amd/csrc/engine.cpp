@@ -22,6 +22,7 @@ struct LevelCtx {
   uint32_t nf = 0;
   uint64_t ef = 0;
   bool dense_prepared = false;
+  int dense_run = 0;  // dense levels run since the current dense phase was seeded
 };
 
 // kernel-class timing with an event pool; resolved once per call after the final sync
@@ -125,11 +126,20 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
         PPRHIP_TRY(write_hist0(g, L.nf, L.ef));
         PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, 0, L.nf, dense_thresh, true, L.ccur, L.dslot));
         L.dense_prepared = true;
+        L.dense_run = 0;
       }
+      // The sweep writes contributions of non-empty rows only.  Rows without in-edges can hold one
+      // solely from a phase's seeding, so the other buffer is cleared when a dense phase starts
+      // and the seeded buffer right after its first level has consumed it.
+      if (L.dense_run == 0)
+        PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur ^ 1], 0, sizeof(double) * g->n, g->stream));
       const int out = L.pslot ^ 1;
       g_timer.begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
       PPRHIP_TRY(launch_dense_level(g, a, L.ccur, out, L.dslot));
       g_timer.end();
+      if (L.dense_run == 0)
+        PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
+      L.dense_run++;
       L.ccur ^= 1;
       L.dslot ^= 1;
       L.pslot = out;
@@ -225,6 +235,7 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
   if (dense) {
     PPRHIP_TRY(launch_seed_dense(g, a, kind, L.ccur, L.pslot, L.dslot));
     L.dense_prepared = true;
+    L.dense_run = 0;
   } else if (L.nf || kind == 1) {
     // kind 1 also runs for an empty start set: parked nodes below min_rmax still leave the set
     // (Forward_Push.java:241-247)
@@ -327,7 +338,12 @@ struct CallTimer {
 
 int copy_out(pprhip_graph* g, const double* dev, double* host) {
   if (!host) return PPRHIP_OK;
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(host, dev, sizeof(double) * g->n, hipMemcpyDeviceToHost, g->stream));
+  const double* srcp = dev;
+  if (g->relabeled) {  // back to the caller's ids: out[old] = x[old2new[old]]
+    PPRHIP_TRY(launch_permute_out(g, dev, g->cF));
+    srcp = g->cF;
+  }
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(host, srcp, sizeof(double) * g->n, hipMemcpyDeviceToHost, g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   return PPRHIP_OK;
 }
@@ -429,7 +445,7 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     }
     cand.resize(cnt);
-    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {ids[i], vals[i]};
+    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {g->h_new2old[ids[i]], vals[i]};
   } else {
     // more ties at the k-th value than the candidate buffer holds: finish on the whole vector
     std::vector<double> all(g->n);
@@ -437,7 +453,7 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     const double lb = [&] { double d; std::memcpy(&d, &lower_bits, 8); return d; }();
     for (uint32_t i = 0; i < g->n; ++i)
-      if (all[i] > 0.0 && (!have || all[i] >= lb)) cand.push_back({(int32_t)i, all[i]});
+      if (all[i] > 0.0 && (!have || all[i] >= lb)) cand.push_back({g->h_new2old[i], all[i]});
   }
   std::sort(cand.begin(), cand.end(), [](const IdVal& a, const IdVal& b) {
     if (a.val != b.val) return a.val > b.val;
@@ -550,8 +566,8 @@ int pprhip_fora_topk_params(const pprhip_fora_conf_t* c, double eps, double delt
 // ------------------------------------------------------------------ graph lift
 int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out_ci, const uint32_t* in_rp,
                         const int32_t* in_ci, int device, pprhip_graph_t** graph_out) {
-  if (!graph_out || !out_rp || (!out_ci && m) || n == 0 || n >= (1u << 28) || m >= (1ull << 32)) {
-    set_error("pprhip_graph_create: bad arguments (n=%u m=%llu; limits n < 2^28, m < 2^32)", n,
+  if (!graph_out || !out_rp || (!out_ci && m) || n == 0 || n >= (1u << 28) || m >= (1ull << 32) - 1024) {
+    set_error("pprhip_graph_create: bad arguments (n=%u m=%llu; limits n < 2^28, m < 2^32 - 1024)", n,
               (unsigned long long)m);
     return PPRHIP_ERR_INVALID;
   }
@@ -574,66 +590,80 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
       set_error("pprhip_graph_create: out_col_idx[%llu] = %d outside [0, %u)", (unsigned long long)e, out_ci[e], n);
       return PPRHIP_ERR_INVALID;
     }
+  const bool have_in = in_rp && (in_ci || m == 0);
+  if (have_in && (in_rp[0] != 0 || in_rp[n] != m)) {
+    set_error("pprhip_graph_create: in_row_ptr[0] must be 0 and in_row_ptr[n] must equal m");
+    return PPRHIP_ERR_INVALID;
+  }
   std::unique_ptr<pprhip_graph> g(new (std::nothrow) pprhip_graph());
   if (!g) return PPRHIP_ERR_OOM;
   g->device = device;
   g->n = n;
   g->m = m;
   pprhip_tuning_default(&g->tun);
-  g->h_out_rp.assign(out_rp, out_rp + n + 1);
-  std::vector<int32_t> in_ci_built;
-  if (in_rp && (in_ci || m == 0)) {
-    if (in_rp[0] != 0 || in_rp[n] != m) {
-      set_error("pprhip_graph_create: in_row_ptr[0] must be 0 and in_row_ptr[n] must equal m");
-      return PPRHIP_ERR_INVALID;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      g->n_cus = prop.multiProcessorCount;
+  }
+
+  // ---- internal vertex order: out-degree descending, ties by original id (PPRHIP_RELABEL=0 keeps ids)
+  const char* env = getenv("PPRHIP_RELABEL");
+  g->relabeled = !(env && env[0] == '0');
+  g->h_new2old.resize(n);
+  g->h_old2new.resize(n);
+  std::iota(g->h_new2old.begin(), g->h_new2old.end(), 0);
+  if (g->relabeled)
+    std::stable_sort(g->h_new2old.begin(), g->h_new2old.end(), [&](int32_t x, int32_t y) {
+      return out_rp[x + 1] - out_rp[x] > out_rp[y + 1] - out_rp[y];
+    });
+  for (uint32_t v = 0; v < n; ++v) g->h_old2new[g->h_new2old[v]] = (int32_t)v;
+  const std::vector<int32_t>& o2n = g->h_old2new;
+  // rows move, entries are renamed, the order inside a row is kept (walks index rows by position)
+  auto relabel_csr = [&](const uint32_t* rp, const int32_t* ci, std::vector<uint32_t>& nrp, std::vector<int32_t>& nci) {
+    nrp.assign((size_t)n + 1, 0);
+    for (uint32_t v = 0; v < n; ++v) {
+      const int32_t o = g->h_new2old[v];
+      nrp[v + 1] = nrp[v] + (rp[o + 1] - rp[o]);
     }
-    g->h_in_rp.assign(in_rp, in_rp + n + 1);
+    nci.resize(((size_t)m + kChunkPad - 1) / kChunkPad * kChunkPad + kChunkPad, 0);
+    for (uint32_t v = 0; v < n; ++v) {
+      const int32_t o = g->h_new2old[v];
+      uint32_t w = nrp[v];
+      for (uint32_t e = rp[o]; e < rp[o + 1]; ++e) nci[w++] = o2n[ci[e]];
+    }
+  };
+  std::vector<int32_t> n_out_ci, n_in_ci;
+  relabel_csr(out_rp, out_ci, g->h_out_rp, n_out_ci);
+  if (have_in) {
+    relabel_csr(in_rp, in_ci, g->h_in_rp, n_in_ci);
   } else {
-    // derive the in-adjacency: edges in out-CSR order, grouped by destination
+    // derive the in-adjacency: edges in (new) out-CSR order, grouped by destination
     std::vector<int32_t> src(m);
     for (uint32_t v = 0; v < n; ++v)
-      for (uint32_t e = out_rp[v]; e < out_rp[v + 1]; ++e) src[e] = (int32_t)v;
+      for (uint32_t e = g->h_out_rp[v]; e < g->h_out_rp[v + 1]; ++e) src[e] = (int32_t)v;
     g->h_in_rp.resize((size_t)n + 1);
-    in_ci_built.resize(m);
-    int rc = pprhip_csr_build(n, m, out_ci, src.data(), 0, g->h_in_rp.data(), in_ci_built.data());
+    n_in_ci.assign(((size_t)m + kChunkPad - 1) / kChunkPad * kChunkPad + kChunkPad, 0);
+    int rc = pprhip_csr_build(n, m, n_out_ci.data(), src.data(), 0, g->h_in_rp.data(), n_in_ci.data());
     if (rc != PPRHIP_OK) return rc;
-    in_ci = in_ci_built.data();
   }
-  // dense pull-sweep layout: row-aligned tiles over the in-CSR, hub rows chunked
-  std::vector<uint32_t> tile_row;
-  std::vector<int32_t> hubs;
-  std::vector<uint32_t> chunks;
-  {
-    const std::vector<uint32_t>& rp = g->h_in_rp;
-    uint32_t r = 0;
-    while (r < n) {
-      tile_row.push_back(r);
-      uint32_t d = rp[r + 1] - rp[r];
-      if (d > (uint32_t)kTileEdges) {
-        const uint32_t h = (uint32_t)hubs.size();
-        hubs.push_back((int32_t)r);
-        for (uint32_t e = rp[r]; e < rp[r + 1]; e += kHubChunk) {
-          chunks.push_back(h);
-          chunks.push_back(e);
-          chunks.push_back(std::min(rp[r + 1], e + (uint32_t)kHubChunk));
-        }
-        ++r;
-        continue;
-      }
-      uint32_t edges = 0, rows = 0;
-      while (r < n && rows < (uint32_t)kTileRows) {
-        d = rp[r + 1] - rp[r];
-        if (d > (uint32_t)kTileEdges || edges + d > (uint32_t)kTileEdges) break;
-        edges += d;
-        ++rows;
-        ++r;
-      }
-    }
-    tile_row.push_back(n);
+
+  // ---- dense pull-sweep layout: non-empty rows, row-start flags per in-edge, starts before each chunk
+  const std::vector<uint32_t>& irp = g->h_in_rp;
+  std::vector<int32_t> nz_rows;
+  const size_t n_chunks = ((size_t)m + kChunkPad - 1) / kChunkPad;
+  std::vector<uint8_t> flags((n_chunks + 1) * (kChunkPad / 8), 0);
+  std::vector<uint32_t> chunk_starts(n_chunks + 1, 0);
+  for (uint32_t v = 0; v < n; ++v) {
+    if (irp[v + 1] == irp[v]) continue;
+    nz_rows.push_back((int32_t)v);
+    const uint32_t e = irp[v];
+    flags[e >> 3] |= (uint8_t)(1u << (e & 7));
+    chunk_starts[(size_t)e / kChunkPad + 1]++;  // counted into every later chunk by the prefix sum below
   }
-  g->n_tiles = (uint32_t)tile_row.size() - 1;
-  g->n_hubs = (uint32_t)hubs.size();
-  g->n_hub_chunks = (uint32_t)(chunks.size() / 3);
+  for (size_t c = 1; c <= n_chunks; ++c) chunk_starts[c] += chunk_starts[c - 1];
+  g->n_chunks = (uint32_t)n_chunks;
+  g->n_nz = (uint32_t)nz_rows.size();
 
   pprhip_graph* G = g.get();
   auto up = [&](void** dst, const void* src, size_t bytes) -> int {
@@ -646,19 +676,20 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
     pprhip_graph_destroy(g.release());
     return code;
   };
-  if ((rc = up((void**)&G->out_rp, out_rp, sizeof(uint32_t) * ((size_t)n + 1)))) return fail(rc);
-  if ((rc = up((void**)&G->out_ci, out_ci, sizeof(int32_t) * m))) return fail(rc);
+  if ((rc = up((void**)&G->out_rp, G->h_out_rp.data(), sizeof(uint32_t) * ((size_t)n + 1)))) return fail(rc);
+  if ((rc = up((void**)&G->out_ci, n_out_ci.data(), sizeof(int32_t) * n_out_ci.size()))) return fail(rc);
   if ((rc = up((void**)&G->in_rp, G->h_in_rp.data(), sizeof(uint32_t) * ((size_t)n + 1)))) return fail(rc);
-  if ((rc = up((void**)&G->in_ci, in_ci, sizeof(int32_t) * m))) return fail(rc);
-  if ((rc = up((void**)&G->tile_row, tile_row.data(), sizeof(uint32_t) * tile_row.size()))) return fail(rc);
-  if ((rc = up((void**)&G->hub_rows, hubs.data(), sizeof(int32_t) * hubs.size()))) return fail(rc);
-  if ((rc = up((void**)&G->hub_chunks, chunks.data(), sizeof(uint32_t) * chunks.size()))) return fail(rc);
+  if ((rc = up((void**)&G->in_ci, n_in_ci.data(), sizeof(int32_t) * n_in_ci.size()))) return fail(rc);
+  if ((rc = up((void**)&G->new2old, G->h_new2old.data(), sizeof(int32_t) * (size_t)n))) return fail(rc);
+  if ((rc = up((void**)&G->old2new, G->h_old2new.data(), sizeof(int32_t) * (size_t)n))) return fail(rc);
+  if ((rc = up((void**)&G->start_flags, flags.data(), flags.size()))) return fail(rc);
+  if ((rc = up((void**)&G->chunk_starts, chunk_starts.data(), sizeof(uint32_t) * chunk_starts.size()))) return fail(rc);
+  if ((rc = up((void**)&G->nz_rows, nz_rows.data(), sizeof(int32_t) * nz_rows.size()))) return fail(rc);
   const size_t nd = sizeof(double) * (size_t)n;
   void** dbl[] = {(void**)&G->residue, (void**)&G->reserve, (void**)&G->est,    (void**)&G->cdense[0],
-                  (void**)&G->cdense[1], (void**)&G->cF,    (void**)&G->mc_inc};
+                  (void**)&G->cdense[1], (void**)&G->cF,    (void**)&G->mc_inc, (void**)&G->acc_nz};
   for (void** p : dbl)
     if ((rc = alloc_dev(p, nd))) return fail(rc);
-  if ((rc = alloc_dev((void**)&G->hubacc, sizeof(double) * std::max<size_t>(1, hubs.size())))) return fail(rc);
   for (int i = 0; i < 2; ++i) {
     if ((rc = alloc_dev((void**)&G->F[i], sizeof(int32_t) * (size_t)n))) return fail(rc);
     if ((rc = alloc_dev((void**)&G->eoff[i], sizeof(uint32_t) * (size_t)n))) return fail(rc);
@@ -669,7 +700,7 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
   if ((rc = alloc_dev((void**)&G->partial, sizeof(double) * 1024))) return fail(rc);
   if ((rc = alloc_dev((void**)&G->hist, sizeof(uint32_t) * 4096))) return fail(rc);
   {
-    const size_t nblk = std::max<size_t>(1024, (size_t)G->n_tiles + (G->n_hubs + 255) / 256);
+    const size_t nblk = std::max<size_t>(1024, ((size_t)n + 1 + 255) / 256);
     if ((rc = alloc_dev((void**)&G->blk_pack, sizeof(unsigned long long) * nblk))) return fail(rc);
     if ((rc = alloc_dev((void**)&G->blk_dead, sizeof(double) * nblk))) return fail(rc);
     if ((rc = alloc_dev((void**)&G->blk_ndead, sizeof(uint32_t) * nblk))) return fail(rc);
@@ -692,8 +723,10 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
       set_error("hipEventCreate failed");
       return fail(PPRHIP_ERR_HIP);
     }
-  (void)hipMemsetAsync(G->hubacc, 0, sizeof(double) * std::max<size_t>(1, hubs.size()), G->stream);
+  (void)hipMemsetAsync(G->acc_nz, 0, nd, G->stream);
   (void)hipMemsetAsync(G->est, 0, nd, G->stream);
+  (void)hipMemsetAsync(G->cdense[0], 0, nd, G->stream);
+  (void)hipMemsetAsync(G->cdense[1], 0, nd, G->stream);
   (void)hipMemsetAsync(G->flags, 0, n, G->stream);
   if (reset_query_state(G, true) != PPRHIP_OK) return fail(PPRHIP_ERR_HIP);
   if (hipStreamSynchronize(G->stream) != hipSuccess) {
@@ -708,10 +741,10 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
-  void* ptrs[] = {g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->tile_row, g->hub_rows, g->hub_chunks, g->hubacc,
-                  g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1], g->eoff[0],
-                  g->eoff[1], g->flags, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist, g->sel_ids,
-                  g->sel_vals, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
+  void* ptrs[] = {g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags, g->chunk_starts,
+                  g->nz_rows, g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0],
+                  g->F[1], g->eoff[0], g->eoff[1], g->flags, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist,
+                  g->sel_ids, g->sel_vals, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
@@ -783,6 +816,7 @@ int pprhip_forward_push(pprhip_graph_t* g, int32_t src, double alpha, double rma
                         double* residue_out, double* rsum_out, pprhip_stats_t* stats) {
   PPRHIP_TRY(check_graph(g, "pprhip_forward_push"));
   PPRHIP_TRY(check_node(g, src, "pprhip_forward_push"));
+  src = g->h_old2new[src];  // internal (degree-sorted) id
   pprhip_stats_t st;
   std::memset(&st, 0, sizeof st);
   g->topk_active = false;
@@ -817,6 +851,7 @@ int pprhip_forward_push(pprhip_graph_t* g, int32_t src, double alpha, double rma
 int pprhip_fwdpush_topk_reset(pprhip_graph_t* g, int32_t src, double alpha) {
   PPRHIP_TRY(check_graph(g, "pprhip_fwdpush_topk_reset"));
   PPRHIP_TRY(check_node(g, src, "pprhip_fwdpush_topk_reset"));
+  src = g->h_old2new[src];  // internal (degree-sorted) id
   PPRHIP_TRY(reset_query_state(g, true));
   // Q = {s} (Fora_Topk.java:117-118): the source starts parked
   PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags + src, 1, 1, g->stream));
@@ -896,7 +931,9 @@ int pprhip_random_walk_batch(pprhip_graph_t* g, const int32_t* starts, const uin
     (void)hipFree(d_s); (void)hipFree(d_t); (void)hipFree(d_i); (void)hipFree(d_n);
     return code;
   };
-  if (hipMemcpyAsync(d_s, starts, sizeof(int32_t) * count, hipMemcpyHostToDevice, g->stream) != hipSuccess ||
+  std::vector<int32_t> mapped(count);
+  for (uint64_t i = 0; i < count; ++i) mapped[i] = g->h_old2new[starts[i]];
+  if (hipMemcpy(d_s, mapped.data(), sizeof(int32_t) * count, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpyAsync(d_i, walk_idx, sizeof(uint64_t) * count, hipMemcpyHostToDevice, g->stream) != hipSuccess) {
     set_error("pprhip_random_walk_batch: upload failed");
     return done(PPRHIP_ERR_HIP);
@@ -910,6 +947,7 @@ int pprhip_random_walk_batch(pprhip_graph_t* g, const int32_t* starts, const uin
     set_error("pprhip_random_walk_batch: download failed: %s", hipGetErrorString(hipGetLastError()));
     return done(PPRHIP_ERR_HIP);
   }
+  for (uint64_t i = 0; i < count; ++i) terminals_out[i] = g->h_new2old[terminals_out[i]];
   return done(PPRHIP_OK);
 }
 
@@ -918,6 +956,7 @@ int pprhip_fora_single_source(pprhip_graph_t* g, int32_t src, double eps, const 
                               uint64_t seed, int n_rounds, double* reserve_out, pprhip_stats_t* stats) {
   PPRHIP_TRY(check_graph(g, "pprhip_fora_single_source"));
   PPRHIP_TRY(check_node(g, src, "pprhip_fora_single_source"));
+  src = g->h_old2new[src];  // internal (degree-sorted) id
   if (!conf || !(eps > 0.0) || n_rounds < 0) {
     set_error("pprhip_fora_single_source: bad arguments (eps=%g n_rounds=%d)", eps, n_rounds);
     return PPRHIP_ERR_INVALID;
@@ -1017,6 +1056,7 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
   std::memset(&st, 0, sizeof st);
   PPRHIP_TRY(pprhip_fwdpush_topk_reset(g, src, conf->alpha));
   g->topk_rsum = conf->rsum;
+  src = g->h_old2new[src];  // internal (degree-sorted) id
   CallTimer tm(g);
   const double alpha = conf->alpha;
   const double epsilon = eps * 0.5;  // Fora_Topk.java:109-110
@@ -1133,6 +1173,7 @@ int pprhip_monte_carlo(pprhip_graph_t* g, int32_t src, double eps, const pprhip_
                        double* ppr_out, pprhip_stats_t* stats) {
   PPRHIP_TRY(check_graph(g, "pprhip_monte_carlo"));
   PPRHIP_TRY(check_node(g, src, "pprhip_monte_carlo"));
+  src = g->h_old2new[src];  // internal (degree-sorted) id
   if (!conf || !(eps > 0.0)) {
     set_error("pprhip_monte_carlo: bad arguments");
     return PPRHIP_ERR_INVALID;
@@ -1193,6 +1234,7 @@ int pprhip_backward_push(pprhip_graph_t* g, int32_t target, double alpha, double
                          double* residue_out, pprhip_stats_t* stats) {
   PPRHIP_TRY(check_graph(g, "pprhip_backward_push"));
   PPRHIP_TRY(check_node(g, target, "pprhip_backward_push"));
+  target = g->h_old2new[target];  // internal (degree-sorted) id
   pprhip_stats_t st;
   std::memset(&st, 0, sizeof st);
   g->topk_active = false;
@@ -1214,6 +1256,7 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
                         pprhip_stats_t* stats) {
   PPRHIP_TRY(check_graph(g, "pprhip_power_method"));
   PPRHIP_TRY(check_node(g, src, "pprhip_power_method"));
+  src = g->h_old2new[src];  // internal (degree-sorted) id
   if (iters < 0) {
     set_error("pprhip_power_method: iters must be >= 0");
     return PPRHIP_ERR_INVALID;
@@ -1237,9 +1280,11 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
       PPRHIP_TRY(launch_set_f64(g, g->cdense[L.ccur], (uint32_t)src, remain / (double)d));
     for (int it = 1; it < iters; ++it) {
       const int out = L.pslot ^ 1;
+      if (it == 1) PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur ^ 1], 0, sizeof(double) * g->n, g->stream));
       g_timer.begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
       PPRHIP_TRY(launch_dense_level(g, a, L.ccur, out, L.dslot));
       g_timer.end();
+      if (it == 1) PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
       L.ccur ^= 1;
       L.dslot ^= 1;
       L.pslot = out;
@@ -1345,7 +1390,7 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   std::vector<int32_t> ids(g->sel_cap);
   std::vector<double> vals(g->sel_cap);
   for (uint32_t t = t_begin; t < t_end; ++t) {  // Base_Whole_Graph.java:76-92
-    PPRHIP_TRY(backward_push_impl(g, (int32_t)t, alpha, threshold, st));
+    PPRHIP_TRY(backward_push_impl(g, g->h_old2new[t], alpha, threshold, st));
     PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits));  // :83 pi >= threshold
     PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
                                     hipMemcpyDeviceToHost, g->stream));
@@ -1354,13 +1399,13 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
     if (cnt > g->sel_cap) {
       std::vector<double> all(g->n);
       PPRHIP_TRY(copy_out(g, g->reserve, all.data()));
-      for (uint32_t v = 0; v < g->n; ++v)
+      for (uint32_t v = 0; v < g->n; ++v)  // copy_out already returned original ids
         if (all[v] > 0.0 && all[v] >= threshold) tr.push_back({(int32_t)v, (int32_t)t, all[v]});
     } else if (cnt) {
       PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-      for (uint64_t i = 0; i < cnt; ++i) tr.push_back({ids[i], (int32_t)t, vals[i]});
+      for (uint64_t i = 0; i < cnt; ++i) tr.push_back({g->h_new2old[ids[i]], (int32_t)t, vals[i]});
     }
   }
   tm.mark(1);

@@ -34,6 +34,7 @@ struct PushArgs {
 
 struct pprhip_graph {
   int device = 0;
+  int n_cus = 256;  // compute units of the device (persistent-kernel grid sizing)
   uint32_t n = 0;
   uint64_t m = 0;
   hipStream_t stream = nullptr;
@@ -41,14 +42,18 @@ struct pprhip_graph {
   uint32_t *out_rp = nullptr, *in_rp = nullptr;
   int32_t *out_ci = nullptr, *in_ci = nullptr;
   std::vector<uint32_t> h_out_rp, h_in_rp;  // host copies for degree checks on the call path
-  // dense pull-sweep layout over the in-CSR
-  uint32_t* tile_row = nullptr;  // n_tiles + 1 row boundaries
-  uint32_t n_tiles = 0;
-  int32_t* hub_rows = nullptr;  // rows with in-degree > kTileEdges
-  uint32_t n_hubs = 0;
-  uint32_t* hub_chunks = nullptr;  // triples (hub index, edge begin, edge end)
-  uint32_t n_hub_chunks = 0;
-  double* hubacc = nullptr;
+  // internal vertex order: ids sorted by out-degree (descending) so that the contributions the
+  // dense sweep gathers most often sit next to each other; the C ABI speaks original ids
+  bool relabeled = false;
+  int32_t *new2old = nullptr, *old2new = nullptr;
+  std::vector<int32_t> h_new2old, h_old2new;
+  // dense pull-sweep layout over the in-CSR (in_ci is padded to a multiple of 512 edges)
+  uint8_t* start_flags = nullptr;    // bit e: in-edge e is the first of its row
+  uint32_t* chunk_starts = nullptr;  // row starts before each 512-edge chunk
+  uint32_t n_chunks = 0;
+  int32_t* nz_rows = nullptr;  // rows with in-degree > 0, ascending
+  uint32_t n_nz = 0;
+  double* acc_nz = nullptr;  // per non-empty row: sum of this level's contributions
   // per-query state
   double *residue = nullptr, *reserve = nullptr, *est = nullptr;
   double* cdense[2] = {nullptr, nullptr};
@@ -97,6 +102,7 @@ int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_
 int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbuf, int out_slot, int dead_slot);
 int launch_sum(pprhip_graph* g, const double* x, uint32_t n);  // result -> ctr->sum_out
 int launch_set_f64(pprhip_graph* g, double* p, uint32_t idx, double value);
+int launch_permute_out(pprhip_graph* g, const double* x, double* out);  // out[old] = x[old2new[old]]
 
 // ---- kernels_walk.hip
 int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double* target);

@@ -13,14 +13,18 @@
 //           device-side history, and a level's kernels return at once when the previous level left
 //           nothing to do (or left so much that the host should switch to the dense shape), so the
 //           host reads counters back once per batch, not once per level.
-//   dense   k_hub_pull + k_dense_tiles + k_dense_reduce: a pull sweep over the in-CSR in
-//           row-aligned tiles of <= 2048 edges; contributions are gathered through LDS, every row
-//           is applied and, if it crosses the threshold, prepared for the next level in the same
-//           kernel (no atomics on the residue vector, no same-address atomics at all: per-tile
-//           counters go to a partials array that a one-workgroup kernel sums).
+//   dense   k_dense_edges + k_dense_apply + k_dense_reduce: a pull sweep over the non-empty rows of
+//           the in-CSR.  Every wave owns 512 consecutive in-edges (8 per lane: two 16-byte column
+//           index loads, 8 contribution gathers in flight), sums them by row with a segmented wave
+//           scan and stores one value per row; only rows crossing a chunk boundary use an atomic.
+//           A streaming kernel then lands each row sum, tests the threshold and prepares crossing
+//           rows for the next level (no atomics on the residue vector; per-workgroup counters go
+//           to a partials array that a one-workgroup kernel sums).
 //
 // HBM-bound integer/fp64 work: no MFMA anywhere.  All arithmetic is IEEE double with
 // -ffp-contract=off so each product / quotient rounds exactly as the reference's Java does.
+#include <algorithm>
+
 #include "device_utils.hpp"
 #include "engine.hpp"
 
@@ -240,130 +244,165 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// dense level: pull sweep over the in-CSR
+// dense level: pull sweep over the non-empty rows of the in-CSR
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hub_pull(const uint32_t* __restrict__ chunks, uint32_t n_chunks,
-                                                   const int32_t* __restrict__ in_ci,
-                                                   const double* __restrict__ c_cur, double* __restrict__ hubacc) {
-  __shared__ double s_red[4];
-  for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const uint32_t h = chunks[3 * ch], e0 = chunks[3 * ch + 1], e1 = chunks[3 * ch + 2];
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    uint32_t e = e0 + threadIdx.x;
-    for (; e + 768 < e1; e += 1024) {
-      const int32_t i0 = in_ci[e], i1 = in_ci[e + 256], i2 = in_ci[e + 512], i3 = in_ci[e + 768];
-      acc0 += c_cur[i0];
-      acc1 += c_cur[i1];
-      acc2 += c_cur[i2];
-      acc3 += c_cur[i3];
+// k_dense_edges: one wave per chunk of 512 consecutive in-edges, 8 per lane.  A lane reads its 8
+// column indices as two 16-byte loads and one byte of row-start flags, gathers the 8 contributions
+// and sums them by row; rows that end inside the wave are completed with a segmented wave scan and
+// stored, only the (at most two) rows that cross the chunk boundary use an fp64 atomic.  No LDS,
+// no workgroup barrier, no special case for hub rows: every wave carries the same 512 gathers.
+constexpr int kChunkEdges = 512;
+constexpr int kHotMax = 16384;  // contributions of the 16K highest-out-degree vertices live in LDS (128 KB)
+
+// Vertex ids are sorted by out-degree (graph lift), so ids < n_hot are the contributions gathered
+// most often (about 40 % of all in-edges at R-MAT scale 22).  A persistent workgroup per CU
+// stages them in LDS once per level and serves those gathers from LDS; an L2 hit would cost a
+// whole 64-byte transaction per 8-byte value, which is what bounds this kernel otherwise.
+struct ChunkRegs {  // one lane's share of a chunk: 8 column indices + their row-start flags
+  int4 ia, ib;
+  uint32_t fb;
+};
+
+__device__ __forceinline__ ChunkRegs load_chunk(const int32_t* __restrict__ in_ci,
+                                                const uint8_t* __restrict__ start_flags, uint32_t c, int lane) {
+  const unsigned long long e0 = (unsigned long long)c * kChunkEdges + 8ull * lane;
+  const int4* p = reinterpret_cast<const int4*>(in_ci + e0);
+  ChunkRegs r;
+  r.ia = p[0];
+  r.ib = p[1];
+  r.fb = start_flags[e0 >> 3];
+  return r;
+}
+
+template <bool HOT>
+__global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict__ in_ci,
+                                                       const uint8_t* __restrict__ start_flags,
+                                                       const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
+                                                       unsigned long long m, const double* __restrict__ c_cur,
+                                                       double* __restrict__ acc_nz, uint32_t n_hot) {
+  extern __shared__ __attribute__((aligned(16))) double s_hot[];
+  const int lane = lane_id();
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  const uint32_t stride = gridDim.x * waves_per_block;
+  uint32_t c = blockIdx.x * waves_per_block + (uint32_t)wave_id();
+  ChunkRegs cur;
+  if (c < n_chunks) cur = load_chunk(in_ci, start_flags, c, lane);  // in flight while the hot table loads
+  if (HOT) {
+    // 16 values per thread, loaded in one batch
+    double t[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t i = threadIdx.x + j * 1024u;
+      t[j] = i < n_hot ? c_cur[i] : 0.0;
     }
-    for (; e < e1; e += 256) acc0 += c_cur[in_ci[e]];
-    const double s = block_sum_f64((acc0 + acc1) + (acc2 + acc3), s_red);
-    if (threadIdx.x == 0 && s != 0.0) atomic_add_noret(&hubacc[h], s);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t i = threadIdx.x + j * 1024u;
+      if (i < n_hot) s_hot[i] = t[j];
+    }
+    __syncthreads();
+  }
+  for (; c < n_chunks; c += stride) {
+    // next chunk's indices are requested before this chunk's gathers, so their latency is hidden
+    ChunkRegs nxt = cur;
+    const uint32_t cn = c + stride;
+    if (cn < n_chunks) nxt = load_chunk(in_ci, start_flags, cn, lane);
+    const uint32_t cs = chunk_starts[c];
+    const unsigned long long e0 = (unsigned long long)c * kChunkEdges + 8ull * lane;
+    const uint32_t fb = cur.fb;
+    const int32_t idx[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
+    double v[8];
+    if (HOT) {
+      // branch-free: every lane issues both loads (hot lanes read c_cur[0], one shared line; cold
+      // lanes read s_hot[0]) so that all 8 global gathers of the lane stay in flight together
+      double gl[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gl[i] = c_cur[(uint32_t)idx[i] < n_hot ? 0 : idx[i]];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double hv = s_hot[(uint32_t)idx[i] < n_hot ? idx[i] : 0];
+        v[i] = (uint32_t)idx[i] < n_hot ? hv : gl[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = c_cur[idx[i]];
+    }
+    if (e0 + 8 > m) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (e0 + i >= m) v[i] = 0.0;
+    }
+    // row index of a segment = (row starts at or before its first edge) - 1
+    const uint32_t pc = __popc(fb);
+    const uint32_t incl = wave_incl_scan_u32_dpp(pc);
+    const uint32_t before = cs + incl - pc;  // row starts before this lane's first edge
+    double seg = 0.0, first_seg = 0.0;
+    uint32_t k = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if ((fb >> i) & 1u) {
+        if (k == 0)
+          first_seg = seg;               // closes the row carried in from earlier lanes
+        else
+          acc_nz[before + k - 1] = seg;  // a row that starts and ends inside this lane
+        seg = 0.0;
+        ++k;
+      }
+      seg += v[i];
+    }
+    // segmented scan over lanes: S(l) = x(l) + (lane l holds a row start ? 0 : S(l-1))
+    const bool h = k != 0;
+    const double sval = wave_seg_scan_f64_dpp(seg, h);
+    const double carry = wave_prev_f64_dpp(sval);
+    const unsigned long long hmask = __ballot(h);
+    if (h) {
+      // the row that ends at this lane's first start flag: edges carried in + this lane's head
+      const bool nonempty = lane > 0 || (fb & 1u) == 0;
+      if (nonempty && before > 0) {
+        const double total = carry + first_seg;
+        const bool started_here = (hmask & ((1ull << lane) - 1ull)) != 0;  // an earlier lane starts a row
+        if (started_here)
+          acc_nz[before - 1] = total;
+        else
+          atomic_add_noret(&acc_nz[before - 1], total);  // began in an earlier chunk
+      }
+    }
+    if (lane == 63) {  // the row still open at the end of the chunk
+      const uint32_t starts = cs + incl;
+      if (starts > 0 && sval != 0.0) atomic_add_noret(&acc_nz[starts - 1], sval);
+    }
+    cur = nxt;
   }
 }
 
-// LDS image of a tile's gathered contributions: element k lives in its 8-element group at a
-// position rotated by the group number, so that both the coalesced writes (lane = k) and the
-// per-thread reads of 8 consecutive elements (lane = group) spread over the banks.
-__device__ __forceinline__ int tile_slot(int k) {
-  const int g = k >> 3;
-  return (k & ~7) | ((k + g + (g >> 3)) & 7);
-}
-
+// k_dense_apply: one thread per non-empty row (plus one for a source without in-edges, which
+// only ever receives returned dead-end mass): lands the row sum, detects the threshold crossing
+// and prepares the row for the next level in place.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_dense_tiles(const uint32_t* __restrict__ tile_row, uint32_t n_tiles,
-                                                      const uint32_t* __restrict__ in_rp,
-                                                      const int32_t* __restrict__ in_ci,
+__global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
+                                                      double* __restrict__ acc_nz,
                                                       const uint32_t* __restrict__ out_rp,
-                                                      const double* __restrict__ c_cur, double* __restrict__ c_next,
-                                                      double* __restrict__ res, double* __restrict__ reserve,
-                                                      uint8_t* __restrict__ flags, const int32_t* __restrict__ hub_rows,
-                                                      uint32_t n_hubs, double* __restrict__ hubacc, DevCounters* ctr,
-                                                      unsigned long long* __restrict__ blk_pack,
+                                                      double* __restrict__ c_next, double* __restrict__ res,
+                                                      double* __restrict__ reserve, uint8_t* __restrict__ flags,
+                                                      DevCounters* ctr, unsigned long long* __restrict__ blk_pack,
                                                       double* __restrict__ blk_dead, uint32_t* __restrict__ blk_ndead,
-                                                      int dead_slot, PushArgs a) {
-  __shared__ double s_val[kTileEdges];
-  __shared__ double s_acc[kTileRows];
-  __shared__ uint32_t s_rp[kTileRows + 1];
+                                                      int dead_slot, int src_extra, PushArgs a) {
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
   const int tid = threadIdx.x;
-  const uint32_t t = blockIdx.x;
+  const uint32_t j = blockIdx.x * 256u + tid;
   bool have = false;
   int32_t u = -1;
   double acc = 0.0;
-  if (t < n_tiles) {
-    const uint32_t r0 = tile_row[t], r1 = tile_row[t + 1];
-    const uint32_t nrows = r1 - r0;
-    const uint32_t e0 = in_rp[r0], e1 = in_rp[r1];
-    const uint32_t ne = e1 - e0;
-    if (ne <= (uint32_t)kTileEdges) {  // a hub row is a tile of its own and is applied by the hub blocks
-      // 1. coalesced col_idx reads, contribution gathers, LDS image
-      int32_t idx[8];
-      double val[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t k = tid + 256 * j;
-        idx[j] = k < ne ? in_ci[e0 + k] : -1;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) val[j] = idx[j] >= 0 ? c_cur[idx[j]] : 0.0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t k = tid + 256 * j;
-        if (k < ne) s_val[tile_slot((int)k)] = val[j];
-      }
-      if ((uint32_t)tid <= nrows) s_rp[tid] = in_rp[r0 + tid] - e0;
-      if (tid == 0 && nrows == (uint32_t)kTileRows) s_rp[kTileRows] = ne;
-      s_acc[tid] = 0.0;
-      __syncthreads();
-      // 2. segmented sum: every thread owns 8 consecutive edges and adds its per-row partials
-      const uint32_t k0 = 8u * tid;
-      if (k0 < ne) {
-        uint32_t lo = 0, hi = nrows;  // last row starting at or before k0 (skips empty rows)
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_rp[mid] <= k0) lo = mid + 1; else hi = mid;
-        }
-        uint32_t row = lo - 1;
-        uint32_t row_end = s_rp[row + 1];
-        double part = 0.0;
-        const int g8 = (int)k0;
-        const int rot = (tid + (tid >> 3)) & 7;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t k = k0 + j;
-          if (k < ne) {
-            while (k >= row_end) {
-              if (part != 0.0) atomicAdd(&s_acc[row], part);
-              part = 0.0;
-              ++row;
-              row_end = s_rp[row + 1];
-            }
-            part += s_val[g8 | ((j + rot) & 7)];
-          }
-        }
-        if (part != 0.0) atomicAdd(&s_acc[row], part);
-      }
-      __syncthreads();
-      // 3. one row per thread
-      if ((uint32_t)tid < nrows) {
-        u = (int32_t)(r0 + tid);
-        acc = s_acc[tid];
-        have = true;
-      }
-    }
-  } else {
-    const uint32_t h = (t - n_tiles) * 256u + tid;
-    if (h < n_hubs) {
-      u = hub_rows[h];
-      acc = hubacc[h];
-      hubacc[h] = 0.0;
-      have = true;
-    }
+  if (j < n_nz) {
+    u = nz_rows[j];
+    acc = acc_nz[j];
+    acc_nz[j] = 0.0;
+    have = true;
+  } else if (j == n_nz && src_extra) {
+    u = a.src;
+    have = true;
   }
-
   double dead_next = 0.0;
   unsigned long long pack = 0, ndead = 0;
   if (have) {
@@ -402,9 +441,9 @@ __global__ __launch_bounds__(256) void k_dense_tiles(const uint32_t* __restrict_
   const unsigned long long ps = block_sum_u64(pack, s_red2);
   const unsigned long long nd = block_sum_u64(ndead, s_red2);
   if (tid == 0) {
-    blk_pack[t] = ps;
-    blk_dead[t] = ds;
-    blk_ndead[t] = (uint32_t)nd;
+    blk_pack[blockIdx.x] = ps;
+    blk_dead[blockIdx.x] = ds;
+    blk_ndead[blockIdx.x] = (uint32_t)nd;
   }
 }
 
@@ -584,6 +623,11 @@ __global__ __launch_bounds__(256) void k_sum_final(const double* __restrict__ pa
 
 __global__ void k_set_f64(double* p, uint32_t idx, double value) { p[idx] = value; }
 
+__global__ __launch_bounds__(256) void k_permute_out(const double* __restrict__ x, const int32_t* __restrict__ old2new,
+                                                      double* __restrict__ out, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = x[old2new[i]];
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -627,17 +671,39 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
 }
 
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot) {
-  if (g->n_hub_chunks) {
-    k_hub_pull<<<dim3(grid_for(g->n_hub_chunks, 1, 8192)), dim3(256), 0, g->stream>>>(
-        g->hub_chunks, g->n_hub_chunks, g->in_ci, g->cdense[cbuf], g->hubacc);
+  if (g->n_chunks) {
+    // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
+    const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
+    const uint32_t want = (g->n_chunks + 15) / 16;
+    if (n_hot) {
+      static bool lds_opt_in = false;  // dynamic LDS above 64 KB needs an explicit opt-in
+      if (!lds_opt_in) {
+        PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(sizeof(double) * kHotMax)));
+        lds_opt_in = true;
+      }
+      const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
+      k_dense_edges<true><<<dim3(grid), dim3(1024), sizeof(double) * n_hot, g->stream>>>(
+          g->in_ci, g->start_flags, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz,
+          n_hot);
+    } else {
+      const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
+      k_dense_edges<false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
+          g->in_ci, g->start_flags, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz,
+          0u);
+    }
     PPRHIP_CHECK_HIP(hipGetLastError());
   }
-  const uint32_t grid = g->n_tiles + (g->n_hubs + 255) / 256;
-  DISPATCH_MODE(a.mode, k_dense_tiles<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                            g->tile_row, g->n_tiles, g->in_rp, g->in_ci, g->out_rp, g->cdense[cbuf],
-                            g->cdense[cbuf ^ 1], g->residue, g->reserve, g->flags, g->hub_rows, g->n_hubs, g->hubacc,
-                            g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead, dead_slot, a));
-  PPRHIP_CHECK_HIP(hipGetLastError());
+  // a source without in-edges still receives returned dead-end mass: one extra apply thread
+  const int src_extra = (a.mode != kBackward && a.src >= 0 && g->h_in_rp[a.src + 1] == g->h_in_rp[a.src]) ? 1 : 0;
+  const uint32_t grid = (g->n_nz + (uint32_t)src_extra + 255) / 256;
+  if (grid) {
+    DISPATCH_MODE(a.mode, k_dense_apply<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
+                              g->nz_rows, g->n_nz, g->acc_nz, g->out_rp, g->cdense[cbuf ^ 1], g->residue, g->reserve,
+                              g->flags, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead, dead_slot, src_extra, a));
+    PPRHIP_CHECK_HIP(hipGetLastError());
+  }
   k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, g->blk_dead, g->blk_ndead, grid, g->ctr,
                                                         out_slot, dead_slot ^ 1);
   PPRHIP_CHECK_HIP(hipGetLastError());
@@ -700,6 +766,12 @@ int launch_sum(pprhip_graph* g, const double* x, uint32_t n) {
   const uint32_t np = grid_for(n, 256 * 16, 1024);
   k_sum_partial<<<dim3(np), dim3(256), 0, g->stream>>>(x, n, g->partial);
   k_sum_final<<<dim3(1), dim3(256), 0, g->stream>>>(g->partial, np, g->ctr);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+int launch_permute_out(pprhip_graph* g, const double* x, double* out) {
+  k_permute_out<<<dim3(grid_for(g->n, 256, 4096)), dim3(256), 0, g->stream>>>(x, g->old2new, out, g->n);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

@@ -37,17 +37,18 @@ __device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32
 // Per-lane walk state machine: one decision per call of step().
 struct Walker {
   int32_t start, cur;
-  uint32_t c1, c2;     // counter words 1, 2 (walk index, stream)
+  uint32_t c0, c1, c2;  // counter words 0-2 (original id of the start node, walk index, stream)
   uint32_t k;          // next decision number
   uint32_t w_stop, w_pick, w_stop2, w_pick2;  // cached Philox block
   uint32_t moves;
   bool forced;         // the next decision is the forced first hop (no_zero_hop)
 };
 
-__device__ __forceinline__ void walker_init(Walker& w, int32_t start, unsigned long long idx, uint32_t stream,
-                                            bool no_zero_hop) {
+__device__ __forceinline__ void walker_init(Walker& w, int32_t start, int32_t start_orig, unsigned long long idx,
+                                            uint32_t stream, bool no_zero_hop) {
   w.start = start;
   w.cur = start;
+  w.c0 = (uint32_t)start_orig;
   w.c1 = (uint32_t)idx;
   w.c2 = (uint32_t)((idx >> 32) & 0xFFFFu) | (stream << 16);
   w.k = 0;
@@ -61,7 +62,7 @@ __device__ __forceinline__ bool walker_step(Walker& w, const uint32_t* __restric
                                             uint32_t k1) {
   uint32_t ws, wp;
   if ((w.k & 1u) == 0) {
-    const Philox p = philox4x32_10((uint32_t)w.start, w.c1, w.c2, w.k >> 1, k0, k1);
+    const Philox p = philox4x32_10(w.c0, w.c1, w.c2, w.k >> 1, k0, k1);
     ws = p.x[0];
     wp = p.x[1];
     w.w_stop2 = p.x[2];
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
                                                   const double* __restrict__ mc_inc,
                                                   const unsigned long long* __restrict__ mc_woff,
                                                   const uint32_t* __restrict__ out_rp,
-                                                  const int32_t* __restrict__ out_ci, double* __restrict__ target,
+                                                  const int32_t* __restrict__ out_ci,
+                                                  const int32_t* __restrict__ new2old, double* __restrict__ target,
                                                   double alpha, uint32_t k0, uint32_t k1, uint32_t stream,
                                                   int no_zero_hop, DevCounters* ctr) {
   __shared__ unsigned long long s_woff[kWalkChunk + 1];
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
           const uint32_t j = a - 1;
           const int32_t start = s_node[j];
           inc = s_inc[j];
-          walker_init(w, start, gidx - s_woff[j], stream, no_zero_hop != 0);
+          walker_init(w, start, new2old[start], gidx - s_woff[j], stream, no_zero_hop != 0);
           if (out_rp[start + 1] == out_rp[start]) {
             atomic_add_noret(&target[start], inc);  // Monte_Carlo.java:70-72 / :106-108
           } else {
@@ -241,14 +243,15 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
 __global__ __launch_bounds__(256) void k_walk_batch(const int32_t* __restrict__ starts,
                                                      const unsigned long long* __restrict__ idx,
                                                      unsigned long long count, const uint32_t* __restrict__ out_rp,
-                                                     const int32_t* __restrict__ out_ci, double alpha, uint32_t k0,
+                                                     const int32_t* __restrict__ out_ci,
+                                                     const int32_t* __restrict__ new2old, double alpha, uint32_t k0,
                                                      uint32_t k1, uint32_t stream, int no_zero_hop,
                                                      int32_t* __restrict__ term, uint32_t* __restrict__ steps) {
   for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < count;
        i += (unsigned long long)gridDim.x * blockDim.x) {
     const int32_t s = starts[i];
     Walker w;
-    walker_init(w, s, idx[i], stream, no_zero_hop != 0);
+    walker_init(w, s, new2old[s], idx[i], stream, no_zero_hop != 0);
     if (out_rp[s + 1] != out_rp[s]) {
       while (!walker_step(w, out_rp, out_ci, alpha, k0, k1)) {
       }
@@ -286,7 +289,7 @@ int launch_mc_walk(pprhip_graph* g, uint64_t n_sources, uint64_t n_walks, double
   uint64_t chunks = (n_walks + kWalkChunk - 1) / kWalkChunk;
   const uint32_t grid = (uint32_t)(chunks > 4096 ? 4096 : chunks);
   hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(256), 0, g->stream, (uint32_t)n_sources,
-                     (unsigned long long)n_walks, g->mc_node, g->mc_inc, g->mc_woff, g->out_rp, g->out_ci, target, alpha,
+                     (unsigned long long)n_walks, g->mc_node, g->mc_inc, g->mc_woff, g->out_rp, g->out_ci, g->new2old, target, alpha,
                      (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, g->ctr);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
@@ -298,7 +301,7 @@ int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* 
   uint64_t b = (count + 255) / 256;
   const uint32_t grid = (uint32_t)(b > 4096 ? 4096 : b);
   hipLaunchKernelGGL(k_walk_batch, dim3(grid), dim3(256), 0, g->stream, d_starts,
-                     (const unsigned long long*)d_idx, (unsigned long long)count, g->out_rp, g->out_ci, alpha,
+                     (const unsigned long long*)d_idx, (unsigned long long)count, g->out_rp, g->out_ci, g->new2old, alpha,
                      (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, d_term, d_steps);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
