@@ -221,11 +221,17 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
                              uint32_t t_end, pprhip_index_t** index_out, pprhip_stats_t* stats);
 /* Merge the shards of several target ranges (one per GPU) into one index, re-applying the k rule. */
 int pprhip_index_merge(const pprhip_index_t* const* shards, int n_shards, int k, pprhip_index_t** merged_out);
+/* Rebuild a shard from its arrays (what a rank receives from another rank before merging). */
+int pprhip_index_from_arrays(uint32_t n, const uint64_t* offsets /* n+1 */, const int32_t* targets,
+                             const double* values, pprhip_index_t** index_out);
 int pprhip_index_info(const pprhip_index_t* ix, uint32_t* n, uint64_t* entries);
 int pprhip_index_arrays(const pprhip_index_t* ix, const uint64_t** offsets /* n+1 */, const int32_t** targets,
                         const double** values);
 /* Per-source text files "<t>\t<Double.toString(pi)>\n" (Base_Whole_Graph.java:118-126,152-156). */
 int pprhip_index_write_dir(const pprhip_index_t* ix, const char* dir);
+/* java.lang.Double.toString(d) as the reference's writers print it (shortest round-trip digits,
+ * "1.0E-4" style outside [1e-3, 1e7)); returns the length written (without the NUL) or < 0. */
+int pprhip_format_double(double d, char* buf, size_t cap);
 void pprhip_index_destroy(pprhip_index_t* ix);
 
 /* ---------------------------------------------------------------- ground truth (a12) */

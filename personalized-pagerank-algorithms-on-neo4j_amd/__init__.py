@@ -68,7 +68,8 @@ EXPORTS = [
     "pprhip_fwdpush_topk_round", "pprhip_random_walk_batch", "pprhip_fora_single_source", "pprhip_fora_topk",
     "pprhip_topk_select", "pprhip_monte_carlo", "pprhip_fora_batch_topk", "pprhip_backward_push",
     "pprhip_all_pair_backward", "pprhip_index_merge", "pprhip_index_info", "pprhip_index_arrays",
-    "pprhip_index_write_dir", "pprhip_index_destroy", "pprhip_power_method",
+    "pprhip_index_write_dir", "pprhip_index_destroy", "pprhip_power_method", "pprhip_index_from_arrays",
+    "pprhip_format_double",
 ]
 
 _lib = None
@@ -122,6 +123,8 @@ def lib():
     L.pprhip_backward_push.argtypes = [vp, i32, dbl, dbl, vp, vp, P(Stats)]
     L.pprhip_all_pair_backward.argtypes = [vp, dbl, dbl, ci, u32, u32, P(vp), P(Stats)]
     L.pprhip_index_merge.argtypes = [P(vp), ci, ci, P(vp)]
+    L.pprhip_index_from_arrays.argtypes = [u32, vp, vp, vp, P(vp)]
+    L.pprhip_format_double.argtypes = [dbl, C.c_char_p, C.c_size_t]
     L.pprhip_index_info.argtypes = [vp, P(u32), P(u64)]
     L.pprhip_index_arrays.argtypes = [vp, P(vp), P(vp), P(vp)]
     L.pprhip_index_write_dir.argtypes = [vp, C.c_char_p]
@@ -268,6 +271,24 @@ class Index:
 
     def __del__(self):
         self.close()
+
+
+def index_from_arrays(n, offsets, targets, values):
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    targets = np.ascontiguousarray(targets, dtype=np.int32)
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    out = C.c_void_p()
+    _check(lib().pprhip_index_from_arrays(n, _ptr(offsets), _ptr(targets), _ptr(values), C.byref(out)))
+    return Index(out)
+
+
+def format_double(d):
+    """java.lang.Double.toString(d), the number format of the reference's result files."""
+    buf = C.create_string_buffer(64)
+    n = lib().pprhip_format_double(d, buf, 64)
+    if n < 0:
+        raise PprhipError(n, "pprhip_format_double failed")
+    return buf.value.decode()
 
 
 def merge_indexes(shards, k):

@@ -90,7 +90,7 @@ int write_packed(pprhip_graph* g, int slot, uint32_t nf, uint64_t ef) {
   return PPRHIP_OK;
 }
 
-// the same expression the oracle's twin evaluates (oracle/ppr_oracle.c level_model_cost)
+// level cost model; the test twin evaluates the same expression
 double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense) {
   const pprhip_tuning_t& t = g->tun;
   const bool d = (double)(ef + nf) >= t.dense_frac * (double)g->m;
@@ -494,7 +494,7 @@ int pprhip_device_count(int* count_out) {
 
 void pprhip_tuning_default(pprhip_tuning_t* t) {
   if (!t) return;
-  // keep in step with orc_tuning_default() (oracle/ppr_oracle.c); calibrated on MI355X
+  // calibrated on MI355X; tests/test_host.py checks the test twin uses the same numbers
   t->c_walk_ns = 0.35;
   t->c_edge_ns = 0.06;
   t->c_pop_ns = 0.10;
@@ -1440,6 +1440,27 @@ int pprhip_index_merge(const pprhip_index_t* const* shards, int n_shards, int k,
   if (!ix) return PPRHIP_ERR_OOM;
   finalize_rows(n, tr, k, ix.get());
   *merged_out = ix.release();
+  return PPRHIP_OK;
+}
+
+int pprhip_index_from_arrays(uint32_t n, const uint64_t* offsets, const int32_t* targets, const double* values,
+                             pprhip_index_t** index_out) {
+  if (!offsets || !index_out || offsets[0] != 0 || (offsets[n] && (!targets || !values))) {
+    set_error("pprhip_index_from_arrays: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  for (uint32_t v = 0; v < n; ++v)
+    if (offsets[v + 1] < offsets[v]) {
+      set_error("pprhip_index_from_arrays: offsets must be non-decreasing");
+      return PPRHIP_ERR_INVALID;
+    }
+  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
+  if (!ix) return PPRHIP_ERR_OOM;
+  ix->n = n;
+  ix->offsets.assign(offsets, offsets + n + 1);
+  ix->targets.assign(targets, targets + offsets[n]);
+  ix->values.assign(values, values + offsets[n]);
+  *index_out = ix.release();
   return PPRHIP_OK;
 }
 

@@ -56,6 +56,14 @@ std::string java_double_to_string(double d) {
 
 extern "C" {
 
+int pprhip_format_double(double d, char* buf, size_t cap) {
+  if (!buf || cap == 0) return PPRHIP_ERR_INVALID;
+  const std::string s = pprhip::java_double_to_string(d);
+  if (s.size() + 1 > cap) return PPRHIP_ERR_INVALID;
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
 int pprhip_index_write_dir(const pprhip_index_t* ix, const char* dir) {
   using namespace pprhip;
   if (!ix || !dir) {

@@ -1,0 +1,95 @@
+"""world_size-2 `gloo` tests of the N > 1 paths (runs on CPU): query sharding + top-k gather
+(config #4) and target-range sharding + index gather/merge (config #5).  The per-rank compute is
+played by the CPU oracle here — on a GPU node the same sharding code carries the engine's results
+over RCCL; what is under test is the sharding, the exchange and the product's merge."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+A = 0.15
+K = 5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    from conftest import GOT_NODES, GOT_RELS
+    from oracle import oracle as orc
+    pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
+    sh = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd.sharding")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        got = pkg.HostCsr.from_neo4j_csv(GOT_NODES, GOT_RELS)
+        og = orc.OracleGraph(got.n, got.out_rp, got.out_ci, got.in_rp, got.in_ci)
+        # ---- batched FORA top-k: query i on rank i mod world, gather top-k blocks to rank 0
+        sources = np.random.default_rng(2).integers(0, got.n, size=7)
+        idx, mine = sh.shard_sources(sources, rank, world)
+        ids, vals = [], []
+        for i, s in zip(idx, mine):
+            est, _ = og.fora_topk(int(s), 0.5, A, K, seed=100 + int(i), schedule=orc.SYNC)
+            cnt, ti, tv = orc.topk(est, K, cap=K)
+            row_i, row_v = np.full(K, -1, dtype=np.int32), np.zeros(K)
+            row_i[:len(ti)], row_v[:len(tv)] = ti, tv
+            ids.append(row_i)
+            vals.append(row_v)
+        res = sh.gather_topk(dist, torch, ids, vals, len(sources), K, rank, world)
+        # ---- All-Pair-Backward-Search: contiguous target ranges, gather shard arrays, merge on rank 0
+        lo, hi = sh.target_range(rank, world, got.n)
+        off, tg, vl = og.all_pair_backward(A, 1e-3, -1, lo, hi)
+        shards = sh.gather_index(dist, torch, off, tg, vl, rank, world)
+        if rank == 0:
+            parts = [pkg.index_from_arrays(got.n, o, t, v) for o, t, v in shards]
+            m_off, m_tg, m_vl = pkg.merge_indexes(parts, 3).arrays()
+            np.savez(os.path.join(outdir, "rank0.npz"), ids=res[0], vals=res[1], sources=sources, off=m_off, tg=m_tg,
+                     vl=m_vl)
+        else:
+            assert res is None and shards is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo(tmp_path, orc, got):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d = np.load(tmp_path / "rank0.npz")
+    from conftest import to_oracle
+    og = to_oracle(orc, got)
+    # every query's row equals the single-process result, in query order
+    for i, s in enumerate(d["sources"]):
+        est, _ = og.fora_topk(int(s), 0.5, A, K, seed=100 + i, schedule=orc.SYNC)
+        cnt, ti, tv = orc.topk(est, K, cap=K)
+        assert list(d["ids"][i][:len(ti)]) == list(ti) and np.array_equal(d["vals"][i][:len(tv)], tv)
+        assert np.all(d["ids"][i][len(ti):] == -1)
+    off, tg, vl = og.all_pair_backward(A, 1e-3, 3)
+    assert np.array_equal(d["off"], off) and np.array_equal(d["tg"], tg) and np.array_equal(d["vl"], vl)
+
+
+def test_shard_helpers(pkg):
+    import importlib
+    sh = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd.sharding")
+    for n in (1, 7, 8, 107, 1 << 20):
+        for w in (1, 2, 3, 8):
+            r = [sh.target_range(i, w, n) for i in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    src = np.arange(10) * 3
+    seen = np.concatenate([sh.shard_sources(src, r, 4)[0] for r in range(4)])
+    assert sorted(seen) == list(range(10))
