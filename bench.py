@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=0, help="FORA threshold rounds (0 = cost model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-walk-divisor", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -58,10 +59,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    # one process per GPU; the modulo only matters when a launch is rehearsed on fewer devices (gloo)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    xdev = "cuda" if args.backend == "nccl" else "cpu"  # where the gathered top-k blocks live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
 
@@ -80,8 +87,8 @@ def main():
     rng = np.random.default_rng(2 + 7919 * rank)
     srcs = rng.integers(0, host.n, size=(total_steps, q)).astype(np.int32)
 
-    ids_blk = torch.empty((q, TOPK), dtype=torch.int32, device="cuda")
-    vals_blk = torch.empty((q, TOPK), dtype=torch.float64, device="cuda")
+    ids_blk = torch.empty((q, TOPK), dtype=torch.int32, device=xdev)
+    vals_blk = torch.empty((q, TOPK), dtype=torch.float64, device=xdev)
     gather_ids = [torch.empty_like(ids_blk) for _ in range(world)] if (world > 1 and rank == 0) else None
     gather_vals = [torch.empty_like(vals_blk) for _ in range(world)] if (world > 1 and rank == 0) else None
 
@@ -132,7 +139,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

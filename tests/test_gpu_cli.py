@@ -1,0 +1,53 @@
+"""GPU test of the native `ppr` command line (host mirror of PPR.main / Gen_Util over the C ABI):
+same flags as the reference, same report file layout."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+PPR = os.path.join(ROOT, "personalized-pagerank-algorithms-on-neo4j_amd", "ppr")
+GOT_DIR = os.path.join(ROOT, "tests", "golden", "got")
+
+
+def test_help_lists_reference_flags():
+    out = subprocess.run([PPR, "-help"], capture_output=True, text=True, timeout=60).stdout
+    for flag in ("-alpha", "-eps", "-query", "-k", "-node", "-label", "-rel", "-db", "-help"):
+        assert flag in out  # PPR.java:157-166
+
+
+def test_batch_report_on_got(tmp_path):
+    r = subprocess.run([PPR, "-alpha", "0.15", "-eps", "0.5", "-query", "6", "-k", "10", "-db", GOT_DIR],
+                       capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert r.returncode == 0 and "failed" not in r.stdout, r.stdout[-2000:]
+    rep = (tmp_path / "got_AlgoPerfResults.txt").read_text()  # <db>_AlgoPerfResults.txt (Gen_Util.java:329)
+    assert re.match(r"\d{4}-\d\d-\d\d \d\d:\d\d:\d\d\n", rep)
+    for h in ("Test 1. Whole-Graph test", "1.1 FORA_WHOLE_GRAPH", "1.2 FWDPUSH", "1.3 MC", "1.4 BASE_WHOLE_GRAPH",
+              "Test 2. Top-k test", "2.1 FORA_TOPK", "2.4 BASE_WHOLE_GRAPH"):
+        assert h in rep
+    sec = rep.split("1.1 FORA_WHOLE_GRAPH\n")[1].split("\n\n")[0].strip().splitlines()
+    assert len(sec) == 5                                   # five epsilons
+    eps, ms, err = sec[2].split(",")                       # "param,avg ms,avg max err" (Gen_Util.java:179,244,247)
+    assert eps == "0.5" and float(err) < 0.1
+    errs = [float(l.split(",")[2]) for l in sec]
+    assert errs[-1] < errs[0]                              # smaller epsilon, smaller error
+    push = rep.split("1.2 FWDPUSH\n")[1].split("\n\n")[0].strip().splitlines()
+    assert float(push[-1].split(",")[2]) < 1e-6            # rmax = 1e-8: push alone is exact to 1e-6 on GOT
+    top = rep.split("2.1 FORA_TOPK\n")[1].split("\n\n")[0].strip().splitlines()
+    p, k, ms, prec, ndcg = top[2].split(",")               # "param,k,avg ms,precision,NDCG" (:142,171)
+    assert k == "10" and float(prec) >= 0.8 and float(ndcg) >= 0.95
+    base = rep.split("2.4 BASE_WHOLE_GRAPH\n")[1].strip().splitlines()
+    thr, k, prep_ms, size, ms, prec, ndcg = base[-1].split(",")  # "thr,k,prep ms,bytes,avg ms,precision,NDCG" (:139)
+    assert thr == "5.0E-7" and int(size) > 0 and float(prec) >= 0.8
+
+
+def test_single_source_print(tmp_path, got):
+    tyrion = str(got.names.index("Tyrion"))
+    r = subprocess.run([PPR, "-db", GOT_DIR, "-single", tyrion, "-k", "5"], capture_output=True, text=True,
+                       timeout=120, cwd=tmp_path)
+    assert "Fora-Whole-Graph PPR:" in r.stdout and "Fora-Top5 PPR:" in r.stdout
+    rows = r.stdout.split("Fora-Top5 PPR:\n")[1].strip().splitlines()
+    assert len(rows) == 5 and all(l.startswith("@") for l in rows) and rows[0].startswith("@Tyrion")
