@@ -52,7 +52,7 @@ void orc_tuning_default(orc_tuning* t) {
   t->c_level_ns = 12000.0;
   t->c_dense_edge_ns = 0.012;
   t->c_dense_node_ns = 0.02;
-  t->dense_frac = 0.08;
+  t->dense_frac = 0.05;
   t->max_rounds = 24;
   t->reserved = 0;
 }

@@ -501,7 +501,7 @@ void pprhip_tuning_default(pprhip_tuning_t* t) {
   t->c_level_ns = 12000.0;
   t->c_dense_edge_ns = 0.012;
   t->c_dense_node_ns = 0.02;
-  t->dense_frac = 0.08;
+  t->dense_frac = 0.05;
   t->max_rounds = 24;
   t->reserved = 0;
 }
@@ -678,6 +678,12 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
   };
   if ((rc = up((void**)&G->out_rp, G->h_out_rp.data(), sizeof(uint32_t) * ((size_t)n + 1)))) return fail(rc);
   if ((rc = up((void**)&G->out_ci, n_out_ci.data(), sizeof(int32_t) * n_out_ci.size()))) return fail(rc);
+  {
+    std::vector<unsigned long long> ext(n);
+    for (uint32_t v = 0; v < n; ++v)
+      ext[v] = (unsigned long long)G->h_out_rp[v] | ((unsigned long long)(G->h_out_rp[v + 1] - G->h_out_rp[v]) << 32);
+    if ((rc = up((void**)&G->out_ext, ext.data(), sizeof(unsigned long long) * (size_t)n))) return fail(rc);
+  }
   if ((rc = up((void**)&G->in_rp, G->h_in_rp.data(), sizeof(uint32_t) * ((size_t)n + 1)))) return fail(rc);
   if ((rc = up((void**)&G->in_ci, n_in_ci.data(), sizeof(int32_t) * n_in_ci.size()))) return fail(rc);
   if ((rc = up((void**)&G->new2old, G->h_new2old.data(), sizeof(int32_t) * (size_t)n))) return fail(rc);
@@ -741,7 +747,7 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
-  void* ptrs[] = {g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags, g->chunk_starts,
+  void* ptrs[] = {g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags, g->chunk_starts,
                   g->nz_rows, g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0],
                   g->F[1], g->eoff[0], g->eoff[1], g->flags, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist,
                   g->sel_ids, g->sel_vals, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};

@@ -40,6 +40,7 @@ struct pprhip_graph {
   hipStream_t stream = nullptr;
   // CSR pair in HBM: uint32 row pointers, int32 column indices
   uint32_t *out_rp = nullptr, *in_rp = nullptr;
+  unsigned long long* out_ext = nullptr;  // per vertex: out row begin | out-degree << 32 (one gather instead of two)
   int32_t *out_ci = nullptr, *in_ci = nullptr;
   std::vector<uint32_t> h_out_rp, h_in_rp;  // host copies for degree checks on the call path
   // internal vertex order: ids sorted by out-degree (descending) so that the contributions the

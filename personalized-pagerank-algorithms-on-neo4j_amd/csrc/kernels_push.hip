@@ -100,23 +100,20 @@ struct NewList {  // crossings of the current tile, collected in LDS
   uint32_t count;
 };
 
+// One edge lands in three steps so that a thread can keep several edges in flight: the degree
+// gather and the returning atomic are issued for a batch of edges before any result is used.
 template <int MODE>
-__device__ __forceinline__ void push_one(int32_t u, double c, const uint32_t* __restrict__ out_rp,
-                                         const uint32_t* __restrict__ in_rp, double* __restrict__ res,
-                                         uint8_t* __restrict__ flags, NewList* nl, const PushArgs& a) {
-  const uint32_t du = out_rp[u + 1] - out_rp[u];
+__device__ __forceinline__ void push_finish(int32_t u, double add, double old, uint32_t du,
+                                            const uint32_t* __restrict__ in_rp, uint8_t* __restrict__ flags,
+                                            NewList* nl, const PushArgs& a) {
+  const double nw = old + add;
   bool crossing;
   uint32_t adeg;
   if (MODE == kBackward) {
-    const double add = c / (double)du;  // Backward_Search.java:84-85
-    const double old = atomic_add_ret(&res[u], add);
-    const double nw = old + add;
-    crossing = !(old > a.rmax) && (nw > a.rmax);  // :89 strict, un-normalised
+    crossing = !(old > a.rmax) && (nw > a.rmax);  // Backward_Search.java:89 strict, un-normalised
     adeg = crossing ? in_rp[u + 1] - in_rp[u] : 0u;
   } else {
-    const double old = atomic_add_ret(&res[u], c);  // Forward_Push.java:123-127
-    const double nw = old + c;
-    crossing = !active_fwd(old, du, a.rmax) && active_fwd(nw, du, a.rmax);  // :132
+    crossing = !active_fwd(old, du, a.rmax) && active_fwd(nw, du, a.rmax);  // Forward_Push.java:132
     adeg = du;
     if (MODE == kFwdTopk && active_fwd(nw, du, a.min_rmax)) flags[u] = 1;  // :232-237 (parked)
   }
@@ -125,6 +122,16 @@ __device__ __forceinline__ void push_one(int32_t u, double c, const uint32_t* __
     nl->node[slot] = u;
     nl->deg[slot] = adeg;
   }
+}
+
+template <int MODE>
+__device__ __forceinline__ void push_one(int32_t u, double c, const unsigned long long* __restrict__ out_ext,
+                                         const uint32_t* __restrict__ in_rp, double* __restrict__ res,
+                                         uint8_t* __restrict__ flags, NewList* nl, const PushArgs& a) {
+  const uint32_t du = (uint32_t)(out_ext[u] >> 32);  // packed row extent: one gather for the degree
+  const double add = (MODE == kBackward) ? c / (double)du : c;  // Backward_Search.java:84-85
+  const double old = atomic_add_ret(&res[u], add);               // Forward_Push.java:123-127
+  push_finish<MODE>(u, add, old, du, in_rp, flags, nl, a);
 }
 
 // Appends the tile's crossings to the next frontier: one packed atomic reserves list slots and
@@ -166,7 +173,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__ F, const double* __restrict__ cF,
                                                       const uint32_t* __restrict__ eoff,
                                                       const uint32_t* __restrict__ trp, const int32_t* __restrict__ tci,
-                                                      const uint32_t* __restrict__ out_rp,
+                                                      const unsigned long long* __restrict__ out_ext,
                                                       const uint32_t* __restrict__ in_rp, double* __restrict__ res,
                                                       uint8_t* __restrict__ flags, int32_t* __restrict__ Fn,
                                                       uint32_t* __restrict__ eoffn, DevCounters* ctr, int level,
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
     if (tid == 0) {
       const double dead = ctr->dead[dead_slot];
       if (dead > 0.0) {
-        push_one<MODE>(a.src, dead, out_rp, in_rp, res, flags, &s_new, a);
+        push_one<MODE>(a.src, dead, out_ext, in_rp, res, flags, &s_new, a);
         ctr->dead[dead_slot] = 0.0;
       }
     }
@@ -225,15 +232,44 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
       }
       __syncthreads();
       const unsigned long long cov_hi = ((unsigned long long)s_eoff[cnt] < tile_hi) ? s_eoff[cnt] : tile_hi;
-      for (unsigned long long e = ce + tid; e < cov_hi; e += 256) {
-        const uint32_t e32 = (uint32_t)e;
-        uint32_t lo = 0, hi = cnt;  // last staged entry whose range starts at or before e
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_eoff[mid] <= e32) lo = mid + 1; else hi = mid;
+      // four edges per thread in flight: col_idx loads, then degree gathers, then atomics, then tests
+      for (unsigned long long base = ce + tid; base < cov_hi; base += 1024) {
+        int32_t u[4];
+        double add[4], old[4];
+        uint32_t du[4];
+        bool valid[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned long long e = base + 256ull * q;
+          valid[q] = e < cov_hi;
+          u[q] = 0;
+          add[q] = 0.0;
+          if (valid[q]) {
+            const uint32_t e32 = (uint32_t)e;
+            uint32_t lo = 0, hi = cnt;  // last staged entry whose range starts at or before e
+            while (lo < hi) {
+              const uint32_t mid = (lo + hi) >> 1;
+              if (s_eoff[mid] <= e32) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t j = lo - 1;
+            u[q] = tci[s_row[j] + (e32 - s_eoff[j])];
+            add[q] = s_c[j];
+          }
         }
-        const uint32_t j = lo - 1;
-        push_one<MODE>(tci[s_row[j] + (e32 - s_eoff[j])], s_c[j], out_rp, in_rp, res, flags, &s_new, a);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) du[q] = valid[q] ? (uint32_t)(out_ext[u[q]] >> 32) : 1u;
+        if (MODE == kBackward) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) add[q] = add[q] / (double)du[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          old[q] = 0.0;
+          if (valid[q]) old[q] = atomic_add_ret(&res[u[q]], add[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (valid[q]) push_finish<MODE>(u[q], add[q], old[q], du[q], in_rp, flags, &s_new, a);
       }
       __syncthreads();
       ce = cov_hi;
@@ -664,7 +700,7 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
   const uint32_t* trp = bwd ? g->in_rp : g->out_rp;
   const int32_t* tci = bwd ? g->in_ci : g->out_ci;
   DISPATCH_MODE(a.mode, k_sparse_push<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                            g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_rp, g->in_rp, g->residue, g->flags,
+                            g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_ext, g->in_rp, g->residue, g->flags,
                             g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot, a));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;

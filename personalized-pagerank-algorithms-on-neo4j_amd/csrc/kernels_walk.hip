@@ -8,7 +8,7 @@
 // and 2(k&1)+1 (neighbour pick: (word * degree) >> 32).  The CPU oracle restates the same
 // function, so terminals can be compared walk by walk.
 //
-// Memory-bound random gathers (row_ptr pair + one col_idx per step); no MFMA.
+// Memory-bound random gathers (one packed row extent + one col_idx per step); no MFMA.
 #include "device_utils.hpp"
 #include "engine.hpp"
 
@@ -57,7 +57,7 @@ __device__ __forceinline__ void walker_init(Walker& w, int32_t start, int32_t st
 }
 
 // Returns true when the walk has stopped (w.cur is the terminal).
-__device__ __forceinline__ bool walker_step(Walker& w, const uint32_t* __restrict__ out_rp,
+__device__ __forceinline__ bool walker_step(Walker& w, const unsigned long long* __restrict__ out_ext,
                                             const int32_t* __restrict__ out_ci, double alpha, uint32_t k0,
                                             uint32_t k1) {
   uint32_t ws, wp;
@@ -76,8 +76,8 @@ __device__ __forceinline__ bool walker_step(Walker& w, const uint32_t* __restric
     if ((double)ws * (1.0 / 4294967296.0) < alpha) return true;  // Monte_Carlo.java:76-78
   }
   w.forced = false;
-  const uint32_t b = out_rp[w.cur], e = out_rp[w.cur + 1];
-  const uint32_t d = e - b;
+  const unsigned long long ext = out_ext[w.cur];  // row begin | out-degree << 32: one 8-byte gather per step
+  const uint32_t b = (uint32_t)ext, d = (uint32_t)(ext >> 32);
   if (d > 0)
     w.cur = out_ci[b + (uint32_t)(((unsigned long long)wp * d) >> 32)];  // :81-86
   else
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
                                                   const int32_t* __restrict__ mc_node,
                                                   const double* __restrict__ mc_inc,
                                                   const unsigned long long* __restrict__ mc_woff,
-                                                  const uint32_t* __restrict__ out_rp,
+                                                  const unsigned long long* __restrict__ out_ext,
                                                   const int32_t* __restrict__ out_ci,
                                                   const int32_t* __restrict__ new2old, double* __restrict__ target,
                                                   double alpha, uint32_t k0, uint32_t k1, uint32_t stream,
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
           const int32_t start = s_node[j];
           inc = s_inc[j];
           walker_init(w, start, new2old[start], gidx - s_woff[j], stream, no_zero_hop != 0);
-          if (out_rp[start + 1] == out_rp[start]) {
+          if ((out_ext[start] >> 32) == 0) {
             atomic_add_noret(&target[start], inc);  // Monte_Carlo.java:70-72 / :106-108
           } else {
             walking = true;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
         continue;
       }
       if (walking) {
-        if (walker_step(w, out_rp, out_ci, alpha, k0, k1)) {
+        if (walker_step(w, out_ext, out_ci, alpha, k0, k1)) {
           atomic_add_noret(&target[w.cur], inc);
           steps_total += w.moves;
           walking = false;
@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
 // one walk per thread, terminals written out (walker parity tests, pprhip_random_walk_batch)
 __global__ __launch_bounds__(256) void k_walk_batch(const int32_t* __restrict__ starts,
                                                      const unsigned long long* __restrict__ idx,
-                                                     unsigned long long count, const uint32_t* __restrict__ out_rp,
+                                                     unsigned long long count,
+                                                     const unsigned long long* __restrict__ out_ext,
                                                      const int32_t* __restrict__ out_ci,
                                                      const int32_t* __restrict__ new2old, double alpha, uint32_t k0,
                                                      uint32_t k1, uint32_t stream, int no_zero_hop,
@@ -252,8 +253,8 @@ __global__ __launch_bounds__(256) void k_walk_batch(const int32_t* __restrict__ 
     const int32_t s = starts[i];
     Walker w;
     walker_init(w, s, new2old[s], idx[i], stream, no_zero_hop != 0);
-    if (out_rp[s + 1] != out_rp[s]) {
-      while (!walker_step(w, out_rp, out_ci, alpha, k0, k1)) {
+    if ((out_ext[s] >> 32) != 0) {
+      while (!walker_step(w, out_ext, out_ci, alpha, k0, k1)) {
       }
     }
     term[i] = w.cur;
@@ -287,9 +288,9 @@ int launch_mc_walk(pprhip_graph* g, uint64_t n_sources, uint64_t n_walks, double
                    int no_zero_hop, double* target) {
   if (n_walks == 0 || n_sources == 0) return PPRHIP_OK;
   uint64_t chunks = (n_walks + kWalkChunk - 1) / kWalkChunk;
-  const uint32_t grid = (uint32_t)(chunks > 4096 ? 4096 : chunks);
+  const uint32_t grid = (uint32_t)(chunks > (1u << 22) ? (1u << 22) : chunks);  // one chunk per workgroup: the dispatcher balances
   hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(256), 0, g->stream, (uint32_t)n_sources,
-                     (unsigned long long)n_walks, g->mc_node, g->mc_inc, g->mc_woff, g->out_rp, g->out_ci, g->new2old, target, alpha,
+                     (unsigned long long)n_walks, g->mc_node, g->mc_inc, g->mc_woff, g->out_ext, g->out_ci, g->new2old, target, alpha,
                      (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, g->ctr);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
@@ -301,7 +302,7 @@ int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* 
   uint64_t b = (count + 255) / 256;
   const uint32_t grid = (uint32_t)(b > 4096 ? 4096 : b);
   hipLaunchKernelGGL(k_walk_batch, dim3(grid), dim3(256), 0, g->stream, d_starts,
-                     (const unsigned long long*)d_idx, (unsigned long long)count, g->out_rp, g->out_ci, g->new2old, alpha,
+                     (const unsigned long long*)d_idx, (unsigned long long)count, g->out_ext, g->out_ci, g->new2old, alpha,
                      (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, d_term, d_steps);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
