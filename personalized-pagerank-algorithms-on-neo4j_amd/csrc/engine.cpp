@@ -1391,11 +1391,112 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   g->topk_active = false;
   CallTimer tm(g);
   std::vector<Triple> tr;
-  unsigned long long thr_bits = 1ull;
-  if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
+  const uint32_t n_targets = t_end - t_begin;
+  // PPRHIP_APBS_TIER = 2 / 3 starts at a later tier (tests exercise every tier that way)
+  const int first_tier = getenv("PPRHIP_APBS_TIER") ? atoi(getenv("PPRHIP_APBS_TIER")) : 1;
+
+  // ---- device buffers of this call
+  ApbsBuffers B;
+  unsigned long long* cells = nullptr;  // next_target, out_count, out_valid, overflow_count, pops, edges
+  int rc = PPRHIP_OK;
+  auto release = [&]() {
+    void* p[] = {cells, B.out_v, B.out_t, B.out_p, B.overflow, B.g_tables};
+    for (void* q : p)
+      if (q) (void)hipFree(q);
+  };
+  B.out_cap = std::min<unsigned long long>(1ull << 24, std::max<unsigned long long>(1ull << 16, 64ull * g->n));
+  if ((rc = alloc_dev((void**)&cells, sizeof(unsigned long long) * 8)) ||
+      (rc = alloc_dev((void**)&B.out_v, sizeof(int32_t) * B.out_cap)) ||
+      (rc = alloc_dev((void**)&B.out_t, sizeof(int32_t) * B.out_cap)) ||
+      (rc = alloc_dev((void**)&B.out_p, sizeof(double) * B.out_cap)) ||
+      (rc = alloc_dev((void**)&B.overflow, sizeof(int32_t) * std::max<uint32_t>(1, n_targets)))) {
+    release();
+    return rc;
+  }
+  B.next_target = cells;
+  B.out_count = cells + 1;
+  B.out_valid = cells + 2;
+  B.overflow_count = cells + 3;
+  B.stat_pops = cells + 4;
+  B.stat_edges = cells + 5;
+  std::vector<int32_t> h_v, h_t, h_ovf;
+  std::vector<double> h_p;
+  unsigned long long h_cells[8];
+
+  // runs one tier over `list` (or the range when list is empty and use_range) until every target
+  // has either produced its triples or landed in `give_up`
+  auto run_tier = [&](bool global_tier, std::vector<int32_t> list, bool use_range, std::vector<int32_t>& give_up) -> int {
+    int32_t* d_list = nullptr;
+    for (int pass = 0; pass < 1000; ++pass) {
+      const uint32_t cnt = use_range ? n_targets : (uint32_t)list.size();
+      if (cnt == 0) break;
+      if (!use_range) {
+        if (!d_list) PPRHIP_TRY(alloc_dev((void**)&d_list, sizeof(int32_t) * list.size()));
+        PPRHIP_CHECK_HIP(hipMemcpyAsync(d_list, list.data(), sizeof(int32_t) * cnt, hipMemcpyHostToDevice, g->stream));
+      }
+      const unsigned long long init[8] = {0, 0, ~0ull, 0, 0, 0, 0, 0};
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(cells, init, sizeof init, hipMemcpyHostToDevice, g->stream));
+      g_timer.begin(PPRHIP_KERNEL_BACKWARD_BATCH, 0);
+      PPRHIP_TRY(launch_apbs(g, global_tier, use_range ? nullptr : d_list, t_begin, cnt, alpha, threshold, B));
+      g_timer.end();
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(h_cells, cells, sizeof h_cells, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      const unsigned long long valid = std::min(std::min(h_cells[1], h_cells[2]), B.out_cap);
+      st.pops += h_cells[4];
+      st.edge_pushes += h_cells[5];
+      const uint64_t bytes = 44ull * h_cells[4] + 28ull * h_cells[5] + 16ull * valid;
+      st.push_bytes += bytes;
+      if (!g_timer.recs.empty()) g_timer.recs.back().bytes = bytes;
+      if (valid) {
+        h_v.resize(valid); h_t.resize(valid); h_p.resize(valid);
+        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_v.data(), B.out_v, sizeof(int32_t) * valid, hipMemcpyDeviceToHost, g->stream));
+        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_t.data(), B.out_t, sizeof(int32_t) * valid, hipMemcpyDeviceToHost, g->stream));
+        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_p.data(), B.out_p, sizeof(double) * valid, hipMemcpyDeviceToHost, g->stream));
+        PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+        for (unsigned long long i = 0; i < valid; ++i) tr.push_back({h_v[i], h_t[i], h_p[i]});
+      }
+      std::vector<int32_t> again;
+      const unsigned long long novf = h_cells[3];
+      if (novf) {
+        h_ovf.resize(novf);
+        PPRHIP_CHECK_HIP(hipMemcpy(h_ovf.data(), B.overflow, sizeof(int32_t) * novf, hipMemcpyDeviceToHost));
+        for (int32_t x : h_ovf) {
+          if (x >= 0) give_up.push_back(x);  // table too small for this target
+          else again.push_back(-(x + 1));    // triple buffer was full: same tier again
+        }
+      }
+      list.swap(again);
+      use_range = false;
+      if (d_list && list.size()) {
+        (void)hipFree(d_list);
+        d_list = nullptr;
+      }
+    }
+    if (d_list) (void)hipFree(d_list);
+    return PPRHIP_OK;
+  };
+
+  std::vector<int32_t> to_tier2, to_tier3;
+  if (first_tier <= 1) {
+    rc = run_tier(false, {}, true, to_tier2);
+  } else {
+    for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
+  }
+  if (rc == PPRHIP_OK && !to_tier2.empty()) {
+    B.g_cap = 65536;
+    B.g_blocks = (uint32_t)std::min<size_t>((size_t)g->n_cus, to_tier2.size());
+    rc = alloc_dev((void**)&B.g_tables, (size_t)B.g_blocks * B.g_cap * 40);
+    if (rc == PPRHIP_OK) rc = run_tier(true, to_tier2, false, to_tier3);
+  }
+  release();
+  if (rc != PPRHIP_OK) return rc;
+
+  // ---- tier 3: the few targets whose search outgrows a 48K-node table run on the whole vectors
   std::vector<int32_t> ids(g->sel_cap);
   std::vector<double> vals(g->sel_cap);
-  for (uint32_t t = t_begin; t < t_end; ++t) {  // Base_Whole_Graph.java:76-92
+  unsigned long long thr_bits = 1ull;
+  if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
+  for (int32_t t : to_tier3) {  // Base_Whole_Graph.java:76-92
     PPRHIP_TRY(backward_push_impl(g, g->h_old2new[t], alpha, threshold, st));
     PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits));  // :83 pi >= threshold
     PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
@@ -1406,18 +1507,20 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
       std::vector<double> all(g->n);
       PPRHIP_TRY(copy_out(g, g->reserve, all.data()));
       for (uint32_t v = 0; v < g->n; ++v)  // copy_out already returned original ids
-        if (all[v] > 0.0 && all[v] >= threshold) tr.push_back({(int32_t)v, (int32_t)t, all[v]});
+        if (all[v] > 0.0 && all[v] >= threshold) tr.push_back({(int32_t)v, t, all[v]});
     } else if (cnt) {
       PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-      for (uint64_t i = 0; i < cnt; ++i) tr.push_back({g->h_new2old[ids[i]], (int32_t)t, vals[i]});
+      for (uint64_t i = 0; i < cnt; ++i) tr.push_back({g->h_new2old[ids[i]], t, vals[i]});
     }
   }
   tm.mark(1);
   tm.finish(st);
   st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
   st.rmax_final = threshold;
+  st.rounds = (uint32_t)(to_tier2.size());      // targets that needed the HBM tier
+  st.dense_nodes = (uint64_t)to_tier3.size();   // targets that needed the whole-vector path
   std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
   if (!ix) return PPRHIP_ERR_OOM;
   finalize_rows(g->n, tr, k, ix.get());

@@ -114,6 +114,19 @@ int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* 
 int launch_mc_pure(pprhip_graph* g, int32_t src, uint64_t n_walks, double alpha, uint64_t seed, double inc,
                    double* target);
 
+// ---- kernels_apbs.hip
+struct ApbsBuffers {
+  unsigned long long *next_target = nullptr, *out_count = nullptr, *out_valid = nullptr, *overflow_count = nullptr;
+  unsigned long long *stat_pops = nullptr, *stat_edges = nullptr;
+  int32_t *out_v = nullptr, *out_t = nullptr, *overflow = nullptr;
+  double* out_p = nullptr;
+  unsigned long long out_cap = 0;
+  char* g_tables = nullptr;  // tier 2: per-workgroup hash tables in HBM
+  uint32_t g_cap = 0, g_blocks = 0;
+};
+int launch_apbs(pprhip_graph* g, bool global_tier, const int32_t* d_targets, uint32_t t_begin, uint32_t n_targets,
+                double alpha, double rmax, ApbsBuffers& b);
+
 // ---- kernels_select.hip
 int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned long long prefix, int prefix_bits,
                        int digit_bits);

@@ -234,6 +234,34 @@ def test_all_pair_backward_got(pkg, orc, got, dev_got, k):
     ix.close()
 
 
+@pytest.mark.parametrize("tier", ["1", "2", "3"])
+def test_all_pair_tiers_rmat12(pkg, orc, rmat12, dev_rmat12, tier, monkeypatch):
+    """LDS hash tier, HBM hash tier and whole-vector tier give the same index (targets that outgrow
+    a tier fall through to the next one on their own; the variable only moves the starting tier)."""
+    monkeypatch.setenv("PPRHIP_APBS_TIER", tier)
+    og = to_oracle(orc, rmat12)
+    lo, hi = 100, 100 + (40 if tier == "3" else 300)
+    for thr, k in ((1e-3, -1), (2e-4, 8)):
+        ix, st = dev_rmat12.all_pair_backward(ALPHA, thr, k, lo, hi)
+        off, tg, vl = ix.arrays()
+        ooff, otg, ovl = og.all_pair_backward(ALPHA, thr, k, lo, hi, schedule=orc.SYNC)
+        assert np.array_equal(off, ooff) and np.array_equal(tg, otg)
+        assert np.max(np.abs(vl - ovl)) <= TOL_PUSH
+        ix.close()
+
+
+def test_all_pair_whole_rmat12_counts(pkg, orc, rmat12, dev_rmat12):
+    """Every target of the graph in one call; hub targets overflow the LDS table and are finished by the
+    HBM tier.  Pops and edge pushes equal the twin's."""
+    og = to_oracle(orc, rmat12)
+    ix, st = dev_rmat12.all_pair_backward(ALPHA, 1e-3, 4)
+    off, tg, vl = ix.arrays()
+    ooff, otg, ovl = og.all_pair_backward(ALPHA, 1e-3, 4, schedule=orc.SYNC)
+    assert np.array_equal(off, ooff) and np.array_equal(tg, otg)
+    assert np.max(np.abs(vl - ovl)) <= TOL_PUSH
+    ix.close()
+
+
 def test_all_pair_sharded_merge(pkg, orc, got, dev_got):
     og = to_oracle(orc, got)
     a, _ = dev_got.all_pair_backward(ALPHA, 5e-4, 5, 0, 50)
