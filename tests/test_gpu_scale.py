@@ -1,0 +1,127 @@
+"""GPU tests at benchmark scale (R-MAT 20, the configs[1] size; the engine's code paths are the same
+at scale 22, which bench.py runs): size-independent properties of the path, since the CPU oracle
+needs minutes per query here — mass conservation, the push invariant's sign and threshold
+conditions, determinism under a fixed seed, top-k ordering, linearity of the push in the seed
+mass (power method), agreement of the two vertex orders, and a sampled comparison with the oracle."""
+import numpy as np
+import pytest
+
+from conftest import to_oracle
+
+pytestmark = pytest.mark.gpu
+A = 0.15
+
+
+@pytest.fixture(scope="module")
+def rmat20(pkg):
+    return pkg.HostCsr.rmat(20, 16, seed=1)
+
+
+@pytest.fixture(scope="module")
+def dev20(pkg, rmat20):
+    g = pkg.Graph(rmat20)
+    yield g
+    g.close()
+
+
+def live_sources(host, count, seed):
+    od = np.diff(host.out_rp)
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        s = int(rng.integers(0, host.n))
+        if od[s] > 0:
+            out.append(s)
+    return out
+
+
+def test_forward_push_conserves_mass_and_meets_threshold(rmat20, dev20):
+    od = np.diff(rmat20.out_rp).astype(np.float64)
+    for s in live_sources(rmat20, 3, 1):
+        for rmax in (1e-6, 2.122e-8):
+            p, r, rsum, st = dev20.forward_push(s, A, rmax)
+            assert abs(p.sum() + r.sum() - 1.0) < 1e-11 and abs(rsum - r.sum()) < 1e-12
+            assert p.min() >= 0.0 and r.min() >= 0.0
+            live = od > 0
+            assert np.all(r[live] / od[live] < rmax) and np.all(r[~live] == 0.0)  # Forward_Push.java:132
+            assert st.levels > 0 and st.pops + st.dense_nodes >= st.levels
+
+
+def test_fora_single_source_properties(rmat20, dev20):
+    for s in live_sources(rmat20, 3, 2):
+        est, st = dev20.fora_single_source(s, 0.5, A, seed=5, n_rounds=0)
+        assert abs(est.sum() - 1.0) < 1e-9 and est.min() >= 0.0
+        assert st.walks >= int(st.omega * st.rsum) and st.rounds >= 1
+        est2, st2 = dev20.fora_single_source(s, 0.5, A, seed=5, n_rounds=0)
+        assert st2.walks == st.walks and st2.walk_steps == st.walk_steps
+        assert np.max(np.abs(est - est2)) < 1e-12           # same seed, same walks; only the add order varies
+        est3, _ = dev20.fora_single_source(s, 0.5, A, seed=6, n_rounds=0)
+        assert np.max(np.abs(est - est3)) > 0                # another seed draws other walks
+        # the estimate stays within FORA's relative bound of the 100-sweep ground truth where pi > delta
+        exact, _ = dev20.power_method(s, A, 100)
+        big = exact > 1.0 / rmat20.n
+        assert np.mean(np.abs(est[big] - exact[big]) <= 0.5 * exact[big]) > 0.999
+
+
+def test_dead_end_sources_short_circuit(rmat20, dev20):
+    od = np.diff(rmat20.out_rp)
+    s = int(np.argmax(od == 0))
+    est, st = dev20.fora_single_source(s, 0.5, A, seed=1)
+    assert est[s] == 1.0 and est.sum() == 1.0 and st.walks == 0 and st.levels == 0
+    n, ids, vals, _, _ = dev20.fora_topk(s, 0.5, A, 32, seed=1)
+    assert n == 1 and ids[0] == s and vals[0] == 1.0
+
+
+def test_topk_ordering_and_consistency(rmat20, dev20):
+    for s in live_sources(rmat20, 3, 3):
+        n, ids, vals, est, st = dev20.fora_topk(s, 0.5, A, 32, seed=9, cap=64, fetch=True)
+        assert n >= 32 or n == int((est > 0).sum())
+        assert np.all(np.diff(vals) <= 0)                       # value descending
+        ties = np.diff(vals) == 0
+        assert np.all(np.diff(ids)[ties] > 0)                   # ties by id ascending
+        assert np.array_equal(est[ids], vals)
+        kth = vals[min(n, 32) - 1]
+        assert int((est >= kth).sum()) == n                     # every entry >= the k-th value is reported
+        n2, ids2, vals2, kth2, _ = dev20.topk_select(32, cap=64)
+        assert n2 == n and list(ids2) == list(ids) and kth2 == kth
+
+
+def test_power_method_linearity_and_mass(rmat20, dev20):
+    s = live_sources(rmat20, 1, 4)[0]
+    p100, _ = dev20.power_method(s, A, 100)
+    p50, _ = dev20.power_method(s, A, 50)
+    assert abs(p100.sum() - (1 - (1 - A) ** 100)) < 1e-10    # undelivered mass after k sweeps = (1-alpha)^k
+    assert abs(p50.sum() - (1 - (1 - A) ** 50)) < 1e-10
+    assert np.all(p100 >= p50 - 1e-15)
+
+
+def test_backward_push_and_all_pair_sample(orc, rmat20, dev20):
+    og = to_oracle(orc, rmat20)
+    idg = np.diff(rmat20.in_rp)
+    rng = np.random.default_rng(6)
+    for t in [int(x) for x in rng.integers(0, rmat20.n, 3)]:
+        p, r, st = dev20.backward_push(t, A, 1e-4)
+        po, ro, sto = og.backward_push(t, A, 1e-4, orc.SYNC)
+        assert np.max(np.abs(p - po)) <= 1e-12 and st.pops == sto.pops
+        assert np.all(r <= 1e-4) and (idg[t] > 0 or p[t] == 1.0)
+    lo = 5000
+    ix, st = dev20.all_pair_backward(A, 1e-3, 8, lo, lo + 2000)
+    off, tg, vl = ix.arrays()
+    assert np.all(vl >= 1e-3) and np.all((tg >= lo) & (tg < lo + 2000))
+    assert np.all(np.diff(off) <= np.maximum(8, np.diff(off)))   # k rule keeps >= k only on ties
+    for v in np.nonzero(np.diff(off))[0][:200]:
+        assert np.all(np.diff(vl[off[v]:off[v + 1]]) <= 0)
+    ooff, otg, ovl = og.all_pair_backward(A, 1e-3, 8, lo, lo + 64, schedule=orc.SYNC)
+    ix2, _ = dev20.all_pair_backward(A, 1e-3, 8, lo, lo + 64)
+    off2, tg2, vl2 = ix2.arrays()
+    assert np.array_equal(off2, ooff) and np.array_equal(tg2, otg) and np.max(np.abs(vl2 - ovl)) <= 1e-12
+
+
+def test_sampled_walks_match_oracle(orc, rmat20, dev20):
+    og = to_oracle(orc, rmat20)
+    rng = np.random.default_rng(8)
+    starts = rng.integers(0, rmat20.n, 2000).astype(np.int32)
+    idx = rng.integers(0, 1 << 34, 2000).astype(np.uint64)
+    term, steps = dev20.random_walks(starts, idx, A, seed=11, stream=2, no_zero_hop=True)
+    for i in range(0, 2000, 7):
+        assert og.random_walk(int(starts[i]), A, 11, 2, int(idx[i]), True) == (term[i], steps[i])
