@@ -142,7 +142,18 @@ int pprhip_rmat_edges(int scale, int edge_factor, uint64_t seed, int32_t* src_ou
 /* neo4j-admin-import CSVs (":ID,name" / ":START_ID,:END_ID,:TYPE"), id = node row index
  * (dataset/got/GOT_Nodes.csv, GOT_Rels.csv). */
 int pprhip_edgelist_from_neo4j_csv(const char* nodes_csv, const char* rels_csv, pprhip_edgelist_t** out);
+/* A Neo4j 3.x store directory read without a JVM: neostore.nodestore.db (15-byte records: in-use
+ * bit, first relationship of the chain, dense flag) and neostore.relationshipstore.db (34-byte
+ * records: first/second node, type, the four chain pointers); what PPR.createDb + setupAdjMatrix
+ * get through the Neo4j kernel (PPR.java:52-60,136-152).  Node id = record id.  The adjacency
+ * order is the relationship-chain order HeavyGraph sees.  Dense nodes (relationship groups) are
+ * not supported and reported as PPRHIP_ERR_IO. */
+int pprhip_edgelist_from_neo4j_store(const char* store_dir, pprhip_edgelist_t** out);
 int pprhip_edgelist_info(const pprhip_edgelist_t* e, uint32_t* n, uint64_t* m);
+/* Out- (incoming = 0) or in-adjacency (incoming = 1) of an edge list in the order HeavyGraph
+ * holds it: chain order for a store, newest relationship first for import CSVs. */
+int pprhip_edgelist_build_csr(const pprhip_edgelist_t* e, int incoming, uint32_t* row_ptr_out /* n+1 */,
+                              int32_t* col_idx_out /* m */);
 int pprhip_edgelist_edges(const pprhip_edgelist_t* e, const int32_t** src, const int32_t** dst);
 const char* pprhip_edgelist_node_name(const pprhip_edgelist_t* e, uint32_t id);
 void pprhip_edgelist_destroy(pprhip_edgelist_t* e);

@@ -69,7 +69,7 @@ EXPORTS = [
     "pprhip_topk_select", "pprhip_monte_carlo", "pprhip_fora_batch_topk", "pprhip_backward_push",
     "pprhip_all_pair_backward", "pprhip_index_merge", "pprhip_index_info", "pprhip_index_arrays",
     "pprhip_index_write_dir", "pprhip_index_destroy", "pprhip_power_method", "pprhip_index_from_arrays",
-    "pprhip_format_double",
+    "pprhip_format_double", "pprhip_edgelist_from_neo4j_store", "pprhip_edgelist_build_csr",
 ]
 
 _lib = None
@@ -96,6 +96,8 @@ def lib():
     L.pprhip_fora_topk_params.argtypes = [P(ForaConf), dbl, dbl, P(dbl), P(dbl), P(dbl)]
     L.pprhip_rmat_edges.argtypes = [ci, ci, u64, vp, vp]
     L.pprhip_edgelist_from_neo4j_csv.argtypes = [C.c_char_p, C.c_char_p, P(vp)]
+    L.pprhip_edgelist_from_neo4j_store.argtypes = [C.c_char_p, P(vp)]
+    L.pprhip_edgelist_build_csr.argtypes = [vp, ci, vp, vp]
     L.pprhip_edgelist_info.argtypes = [vp, P(u32), P(u64)]
     L.pprhip_edgelist_edges.argtypes = [vp, P(vp), P(vp)]
     L.pprhip_edgelist_node_name.argtypes = [vp, u32]
@@ -202,6 +204,28 @@ class HostCsr:
     def rmat(cls, scale, edge_factor=16, seed=1):
         src, dst = rmat_edges(scale, edge_factor, seed)
         return cls(1 << scale, src, dst)
+
+    @classmethod
+    def from_neo4j_store(cls, store_dir):
+        """A Neo4j 3.x store directory (e.g. target/got.db) read without a JVM; adjacency in chain order."""
+        h = C.c_void_p()
+        _check(lib().pprhip_edgelist_from_neo4j_store(store_dir.encode(), C.byref(h)))
+        try:
+            n, m = C.c_uint32(), C.c_uint64()
+            _check(lib().pprhip_edgelist_info(h, C.byref(n), C.byref(m)))
+            self = cls.__new__(cls)
+            self.n, self.m = n.value, m.value
+            self.out_rp = np.empty(self.n + 1, dtype=np.uint32)
+            self.in_rp = np.empty(self.n + 1, dtype=np.uint32)
+            self.out_ci = np.empty(max(self.m, 1), dtype=np.int32)
+            self.in_ci = np.empty(max(self.m, 1), dtype=np.int32)
+            _check(lib().pprhip_edgelist_build_csr(h, 0, _ptr(self.out_rp), _ptr(self.out_ci)))
+            _check(lib().pprhip_edgelist_build_csr(h, 1, _ptr(self.in_rp), _ptr(self.in_ci)))
+            self.out_ci, self.in_ci = self.out_ci[:self.m], self.in_ci[:self.m]
+            self.names = [lib().pprhip_edgelist_node_name(h, i).decode() for i in range(self.n)]
+        finally:
+            lib().pprhip_edgelist_destroy(h)
+        return self
 
     @classmethod
     def from_neo4j_csv(cls, nodes_csv, rels_csv):

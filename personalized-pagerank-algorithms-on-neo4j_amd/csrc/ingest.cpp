@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -46,7 +47,21 @@ struct pprhip_edgelist {
   uint32_t n = 0;
   std::vector<int32_t> src, dst;
   std::vector<std::string> names;
+  // adjacency in relationship-chain order when the list came from a Neo4j store
+  bool from_store = false;
+  std::vector<uint32_t> out_rp, in_rp;
+  std::vector<int32_t> out_ci, in_ci;
 };
+
+static bool read_file(const std::string& path, std::vector<unsigned char>& buf) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  buf.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  return true;
+}
+static inline uint32_t be32(const unsigned char* p) {
+  return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
 
 extern "C" {
 
@@ -177,6 +192,126 @@ int pprhip_edgelist_from_neo4j_csv(const char* nodes_csv, const char* rels_csv, 
   }
   *out = e;
   return PPRHIP_OK;
+}
+
+int pprhip_edgelist_from_neo4j_store(const char* store_dir, pprhip_edgelist_t** out) {
+  if (!store_dir || !out) {
+    set_error("pprhip_edgelist_from_neo4j_store: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  const std::string dir(store_dir);
+  std::vector<unsigned char> nodes, rels, nid;
+  if (!read_file(dir + "/neostore.nodestore.db", nodes) || !read_file(dir + "/neostore.relationshipstore.db", rels)) {
+    set_error("cannot read neostore.nodestore.db / neostore.relationshipstore.db under %s", store_dir);
+    return PPRHIP_ERR_IO;
+  }
+  constexpr size_t kNode = 15, kRel = 34;
+  constexpr uint64_t kNoRel = 0x7FFFFFFFFull;  // all 35 id bits set = "no relationship"
+  uint64_t n = nodes.size() / kNode;
+  if (read_file(dir + "/neostore.nodestore.db.id", nid) && nid.size() >= 9) {  // 1 flag byte + 8-byte high id
+    uint64_t hi = 0;
+    for (int i = 1; i <= 8; ++i) hi = (hi << 8) | nid[i];
+    if (hi <= n) n = hi;
+  }
+  while (n > 0 && !(nodes[(n - 1) * kNode] & 1)) --n;  // trailing unused records
+  const uint64_t nrel = rels.size() / kRel;
+  if (n == 0 || n >= (1ull << 28)) {
+    set_error("%s: %llu node records (unsupported)", store_dir, (unsigned long long)n);
+    return PPRHIP_ERR_IO;
+  }
+  auto* e = new pprhip_edgelist();
+  e->n = (uint32_t)n;
+  e->from_store = true;
+  struct Rel { bool in_use; uint64_t first, second, first_next, second_next; };
+  auto rel = [&](uint64_t id) {
+    const unsigned char* x = &rels[id * kRel];
+    const uint32_t type_int = be32(x + 9);
+    Rel r;
+    r.in_use = x[0] & 1;
+    r.first = be32(x + 1) | ((uint64_t)(x[0] & 0x0E) << 31);
+    r.second = be32(x + 5) | ((uint64_t)(type_int & 0x70000000u) << 4);
+    r.first_next = be32(x + 17) | ((uint64_t)(type_int & 0x01C00000u) << 10);
+    r.second_next = be32(x + 25) | ((uint64_t)(type_int & 0x00070000u) << 16);
+    return r;
+  };
+  for (uint64_t id = 0; id < nrel; ++id) {  // relationships in id order (= import row order)
+    const Rel r = rel(id);
+    if (!r.in_use) continue;
+    if (r.first >= n || r.second >= n) {
+      set_error("%s: relationship %llu references a node outside the store", store_dir, (unsigned long long)id);
+      delete e;
+      return PPRHIP_ERR_IO;
+    }
+    e->src.push_back((int32_t)r.first);
+    e->dst.push_back((int32_t)r.second);
+  }
+  const uint64_t m = e->src.size();
+  e->out_rp.assign(n + 1, 0);
+  e->in_rp.assign(n + 1, 0);
+  for (uint64_t v = 0; v < n; ++v) {  // walk every node's relationship chain, as HeavyGraph's loader does
+    const unsigned char* x = &nodes[v * kNode];
+    e->out_rp[v + 1] = e->out_rp[v];
+    e->in_rp[v + 1] = e->in_rp[v];
+    if (!(x[0] & 1)) continue;
+    if (x[14] & 1) {
+      set_error("%s: node %llu is dense (relationship groups are not supported)", store_dir, (unsigned long long)v);
+      delete e;
+      return PPRHIP_ERR_IO;
+    }
+    uint64_t r = be32(x + 1) | ((uint64_t)(x[0] & 0x0E) << 31);
+    for (uint64_t steps = 0; r != kNoRel && (r & 0xFFFFFFFFull) != 0xFFFFFFFFull; ++steps) {
+      if (r >= nrel || steps > m) {
+        set_error("%s: broken relationship chain at node %llu", store_dir, (unsigned long long)v);
+        delete e;
+        return PPRHIP_ERR_IO;
+      }
+      const Rel rr = rel(r);
+      if (rr.first == v) {
+        e->out_ci.push_back((int32_t)rr.second);
+        e->out_rp[v + 1]++;
+        if (rr.second == v) {  // self loop: one record, both directions
+          e->in_ci.push_back((int32_t)v);
+          e->in_rp[v + 1]++;
+        }
+        r = rr.first_next;
+      } else if (rr.second == v) {
+        e->in_ci.push_back((int32_t)rr.first);
+        e->in_rp[v + 1]++;
+        r = rr.second_next;
+      } else {
+        set_error("%s: relationship %llu is on node %llu's chain but does not touch it", store_dir,
+                  (unsigned long long)r, (unsigned long long)v);
+        delete e;
+        return PPRHIP_ERR_IO;
+      }
+    }
+  }
+  if (e->out_ci.size() != m || e->in_ci.size() != m) {
+    set_error("%s: chains cover %zu out / %zu in of %llu relationships", store_dir, e->out_ci.size(), e->in_ci.size(),
+              (unsigned long long)m);
+    delete e;
+    return PPRHIP_ERR_IO;
+  }
+  for (uint64_t v = 0; v < n; ++v) e->names.push_back(std::to_string(v));
+  *out = e;
+  return PPRHIP_OK;
+}
+
+int pprhip_edgelist_build_csr(const pprhip_edgelist_t* e, int incoming, uint32_t* row_ptr_out, int32_t* col_idx_out) {
+  if (!e || !row_ptr_out || (!col_idx_out && !e->src.empty())) {
+    set_error("pprhip_edgelist_build_csr: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  if (e->from_store) {
+    const auto& rp = incoming ? e->in_rp : e->out_rp;
+    const auto& ci = incoming ? e->in_ci : e->out_ci;
+    std::copy(rp.begin(), rp.end(), row_ptr_out);
+    std::copy(ci.begin(), ci.end(), col_idx_out);
+    return PPRHIP_OK;
+  }
+  // import CSVs: HeavyGraph lists the newest relationship first (descending relationship id)
+  return pprhip_csr_build(e->n, e->src.size(), incoming ? e->dst.data() : e->src.data(),
+                          incoming ? e->src.data() : e->dst.data(), 1, row_ptr_out, col_idx_out);
 }
 
 int pprhip_edgelist_info(const pprhip_edgelist_t* e, uint32_t* n, uint64_t* m) {

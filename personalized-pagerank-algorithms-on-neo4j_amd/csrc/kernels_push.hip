@@ -36,9 +36,12 @@ constexpr int kStageCap = 512;   // frontier entries staged in LDS at a time
 // A batched sparse level runs iff the level before it produced a non-empty frontier that is still
 // worth running sparse (the host took that decision itself for the first level of a batch).
 __device__ __forceinline__ bool level_runs(unsigned long long pk, int level, unsigned long long dense_thresh) {
+  // The first level of a batch always runs: its list can be empty when it was compacted out of a
+  // dense level that prepared dead-end nodes only, and their mass still has to land on the source.
+  if (level == 0) return true;
   const unsigned long long nf = pk >> kPackShift, ef = pk & kPackMask;
   if (nf == 0) return false;
-  return level == 0 || (nf + ef) < dense_thresh;
+  return (nf + ef) < dense_thresh;
 }
 
 // ------------------------------------------------------------------------------------------------

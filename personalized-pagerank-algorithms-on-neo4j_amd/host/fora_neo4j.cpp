@@ -119,6 +119,33 @@ std::shared_ptr<Graph> Graph::fromNeo4jCsv(const std::string& nodes_csv, const s
   return g;
 }
 
+void Graph::liftEdgelist(int device, pprhip_edgelist_t* el) {
+  const double t0 = now_ms();
+  check(pprhip_edgelist_info(el, &n_, &m_));
+  std::vector<uint32_t> in_rp((size_t)n_ + 1);
+  std::vector<int32_t> out_ci(std::max<size_t>(1, m_)), in_ci(std::max<size_t>(1, m_));
+  out_rp_.resize((size_t)n_ + 1);
+  check(pprhip_edgelist_build_csr(el, 0, out_rp_.data(), out_ci.data()));
+  check(pprhip_edgelist_build_csr(el, 1, in_rp.data(), in_ci.data()));
+  for (uint32_t v = 0; v < n_; ++v) names_.push_back(pprhip_edgelist_node_name(el, v));
+  check(pprhip_graph_create(n_, m_, out_rp_.data(), out_ci.data(), in_rp.data(), in_ci.data(), device, &g_));
+  load_ms_ = now_ms() - t0;
+}
+
+std::shared_ptr<Graph> Graph::fromNeo4jStore(const std::string& store_dir, int device) {
+  std::shared_ptr<Graph> g(new Graph());
+  pprhip_edgelist_t* el = nullptr;
+  check(pprhip_edgelist_from_neo4j_store(store_dir.c_str(), &el));
+  try {
+    g->liftEdgelist(device, el);
+  } catch (...) {
+    pprhip_edgelist_destroy(el);
+    throw;
+  }
+  pprhip_edgelist_destroy(el);
+  return g;
+}
+
 std::shared_ptr<Graph> Graph::fromRmat(int scale, int edge_factor, uint64_t seed, int device) {
   std::shared_ptr<Graph> g(new Graph());
   g->n_ = 1u << scale;

@@ -36,6 +36,8 @@ struct PprError : std::runtime_error {
 class Graph {
  public:
   static std::shared_ptr<Graph> fromNeo4jCsv(const std::string& nodes_csv, const std::string& rels_csv, int device = 0);
+  // a Neo4j 3.x store directory such as target/got.db, read without a JVM (PPR.createDb, PPR.java:52-60)
+  static std::shared_ptr<Graph> fromNeo4jStore(const std::string& store_dir, int device = 0);
   static std::shared_ptr<Graph> fromRmat(int scale, int edge_factor, uint64_t seed, int device = 0);
   ~Graph();
   long nodeCount() const { return n_; }          // PPR.java:129
@@ -48,6 +50,7 @@ class Graph {
  private:
   Graph() = default;
   void lift(int device, const std::vector<int32_t>& src, const std::vector<int32_t>& dst, bool newest_first);
+  void liftEdgelist(int device, pprhip_edgelist_t* el);
   pprhip_graph_t* g_ = nullptr;
   uint32_t n_ = 0;
   uint64_t m_ = 0;

@@ -4,9 +4,9 @@
 //
 //   ppr -alpha 0.15 -eps 0.5 -query 50 -k 10 -db <dir>
 //
-// -db names a directory holding neo4j-admin-import CSVs (<X>_Nodes.csv / <X>_Rels.csv, e.g.
-// dataset/got) or "rmat:<scale>[:<seed>]".  The reference opens a Neo4j store directory here; a
-// store reader (nodestore / relationshipstore records) is the next row of SURVEY.md §8(f).
+// -db names a Neo4j 3.x store directory (e.g. target/got.db: the node and relationship record
+// files are read directly, no JVM), a directory holding neo4j-admin-import CSVs
+// (<X>_Nodes.csv / <X>_Rels.csv, e.g. dataset/got) or "rmat:<scale>[:<seed>]".
 // -node/-label/-rel are accepted for command-line compatibility; the lift takes every label and
 // relationship type, as PPR.setupAdjMatrix does (PPR.java:141-147).
 #include <dirent.h>
@@ -83,7 +83,14 @@ int main(int argc, char** argv) {
       dir_db = "rmat" + std::to_string(scale);
     } else {
       std::string nodes, rels;
-      if (DIR* d = opendir(db.c_str())) {
+      bool store = false;
+      if (FILE* f = fopen((db + "/neostore.nodestore.db").c_str(), "rb")) {
+        fclose(f);
+        store = true;
+      }
+      if (store) {
+        adjM = Graph::fromNeo4jStore(db);
+      } else if (DIR* d = opendir(db.c_str())) {
         while (dirent* e = readdir(d)) {
           std::string f = e->d_name;
           if (endsWith(f, "_Nodes.csv")) nodes = db + "/" + f;
@@ -91,10 +98,11 @@ int main(int argc, char** argv) {
         }
         closedir(d);
       }
-      if (nodes.empty() || rels.empty())
-        throw PprError(PPRHIP_ERR_IO, "no *_Nodes.csv / *_Rels.csv under " + db +
-                                          " (a Neo4j store directory needs the store reader, SURVEY.md §8(f))");
-      adjM = Graph::fromNeo4jCsv(nodes, rels);
+      if (!store) {
+        if (nodes.empty() || rels.empty())
+          throw PprError(PPRHIP_ERR_IO, "neither a Neo4j store nor *_Nodes.csv / *_Rels.csv under " + db);
+        adjM = Graph::fromNeo4jCsv(nodes, rels);
+      }
     }
     std::cout << "\nFinish graph loading in " << (long)adjM->loadMillis() << "(ms)" << std::endl;
     std::cout << "node_amount = " << adjM->nodeCount() << ", rel_amount = " << adjM->relationshipCount() << std::endl;

@@ -44,6 +44,19 @@ def test_batch_report_on_got(tmp_path):
     assert thr == "5.0E-7" and int(size) > 0 and float(prec) >= 0.8
 
 
+def test_store_directory_as_db(tmp_path, got):
+    """-db pointing at a Neo4j store directory (the reference's default is target/got.db)."""
+    store = os.path.join(ROOT, "tests", "golden", "got.db")
+    tyrion = str(got.names.index("Tyrion"))
+    a = subprocess.run([PPR, "-db", store, "-single", tyrion, "-k", "5"], capture_output=True, text=True, timeout=120,
+                       cwd=tmp_path).stdout
+    assert "node_amount = 107, rel_amount = 352" in a
+    b = subprocess.run([PPR, "-db", GOT_DIR, "-single", tyrion, "-k", "5"], capture_output=True, text=True,
+                       timeout=120, cwd=tmp_path).stdout
+    vals = lambda out: [l.split("\t")[1] for l in out.split("Fora-Top5 PPR:\n")[1].strip().splitlines()]
+    assert vals(a) == vals(b)  # same graph, same seed: same numbers (the store has ids, the CSVs names)
+
+
 def test_single_source_print(tmp_path, got):
     tyrion = str(got.names.index("Tyrion"))
     r = subprocess.run([PPR, "-db", GOT_DIR, "-single", tyrion, "-k", "5"], capture_output=True, text=True,

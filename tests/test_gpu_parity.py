@@ -175,6 +175,25 @@ def test_fora_topk_got(pkg, orc, got, dev_got, k):
         assert np.max(np.abs(vals - ovals)) <= TOL_MC if cnt else True
 
 
+@pytest.mark.parametrize("dense_frac", [0.02, 0.05, 0.1, 0.3])
+def test_fora_topk_got_mixed_level_shapes(pkg, orc, got, dev_got, dense_frac):
+    """Every switch point between sparse and dense levels gives the twin's vectors (regression: a dense level
+    that prepares only dead-end nodes hands the sparse shape an empty list but pending source mass)."""
+    og = to_oracle(orc, got)
+    t = pkg.tuning_default()
+    t.dense_frac = dense_frac
+    dev_got.set_tuning(t)
+    try:
+        for k in (10, 50):
+            for s in (0, 17, 42, 99, 106):
+                nsel, ids, vals, est, st = dev_got.fora_topk(s, 0.5, ALPHA, k, seed=4, cap=got.n, fetch=True)
+                ref, sto = og.fora_topk(s, 0.5, ALPHA, k, seed=4, schedule=orc.SYNC)
+                assert st.levels == sto.levels and st.walks == sto.walks
+                assert_close(est, ref, TOL_MC, "topk est src=%d k=%d" % (s, k))
+    finally:
+        dev_got.set_tuning(pkg.tuning_default())
+
+
 def test_fora_topk_rmat12(pkg, orc, rmat12, dev_rmat12):
     og = to_oracle(orc, rmat12)
     for s in sources(rmat12, 3, seed=8):

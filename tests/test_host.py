@@ -86,6 +86,26 @@ def test_neo4j_csv_reader(pkg, tmp_path):
         pkg.load_neo4j_csv(str(tmp_path / "missing.csv"), GOT_RELS)
 
 
+def test_neo4j_store_reader(pkg, got, tmp_path):
+    """target/got.db's record files, read without a JVM, give the same adjacency (incl. HeavyGraph's
+    neighbour order = relationship-chain order) as the import CSVs the store was built from."""
+    st = pkg.HostCsr.from_neo4j_store(os.path.join(ROOT, "tests", "golden", "got.db"))
+    assert (st.n, st.m) == (107, 352)
+    for k in ("out_rp", "out_ci", "in_rp", "in_ci"):
+        assert np.array_equal(getattr(st, k), getattr(got, k)), k
+    with pytest.raises(pkg.PprhipError) as e:
+        pkg.HostCsr.from_neo4j_store(str(tmp_path))
+    assert e.value.code == pkg.ERR_IO
+    # a truncated relationship store breaks a chain and is reported, not mis-read
+    import shutil
+    d = tmp_path / "bad.db"
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "got.db"), d)
+    rel = d / "neostore.relationshipstore.db"
+    rel.write_bytes(rel.read_bytes()[:34 * 100])
+    with pytest.raises(pkg.PprhipError):
+        pkg.HostCsr.from_neo4j_store(str(d))
+
+
 def test_java_double_to_string(pkg):
     cases = {1.0: "1.0", 0.5: "0.5", 0.001: "0.001", 9.999e-4: "9.999E-4", 1.0e-4: "1.0E-4", 1234567.0: "1234567.0",
              1.0e7: "1.0E7", 12345678.9: "1.23456789E7", 0.1: "0.1", 1 / 3: "0.3333333333333333",
