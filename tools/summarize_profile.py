@@ -82,11 +82,12 @@ def main():
         return sum(v) / len(v) if v else 0.0
 
     dense_keys = [k for k in fetch if k.startswith("k_dense_tiles") or k.startswith("k_dense_edges")
-                  or k in ("k_hub_pull", "k_dense_reduce", "k_dense_apply")]
+                  or k.startswith("k_dense_apply") or k == "k_dense_reduce"]
     if dense_keys:
         raw_f = sum(avg(fetch, k) for k in dense_keys) * 1024.0
         raw_w = sum(avg(write, k) for k in dense_keys) * 1024.0
-        streaming = 4.0 * m + 4.0 * (n + 1) * 2 + 8.0 * n * 2  # col_idx, two row-pointer arrays, residue + reserve
+        # in-edge columns, row-start flag bits, and per row: row id, row sum, residue, reserve, packed out extent
+        streaming = 4.0 * m + m / 8.0 + (4.0 + 8.0 + 8.0 + 8.0 + 8.0) * n
         corrected = raw_f + streaming / 2.0 + raw_w
         alg = 12 * m + 36 * n + 4
         lines.append("Dense pull level (%s): FETCH_SIZE %.0f MB + WRITE_SIZE %.0f MB raw; sequential reads of the "
