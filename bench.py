@@ -6,12 +6,15 @@
 Workload (N = 1): R-MAT scale 22 (n = 4 194 304, m = 67 108 864, generator seed 1), single-source
 FORA with alpha = 0.15, eps = 0.5; a *step* is one batch of `--queries-per-step` sources drawn
 uniformly from [0, n) with seed 2 (as Gen_Util.getQueryNodes does, so dead-end sources, which
-short-circuit, are in the mix).  The graph is lifted into HBM once before the timed region;
-results stay in HBM.  `value` = queries / second over all ranks.
+short-circuit, are in the mix), handed to pprhip_fora_batch_single_source: the queries are
+independent single-source computations, 8 of them in flight at a time, and every query's top-32 is
+selected on the device.  The graph is lifted into HBM once before the timed region; the PPR
+vectors stay in HBM.  `value` = queries / second over all ranks.  (`--mode single` runs the same
+queries one after another through pprhip_fora_single_source.)
 
 N > 1 (one process per GPU, launched by torch.distributed.run): the CSR is replicated, every rank
-runs its own batch per step (weak scaling, no data-path collective), extracts each query's top-32
-on the device and the per-step top-k blocks are gathered to rank 0 over RCCL.
+runs its own batch per step (weak scaling, no data-path collective) and the per-step top-k blocks
+are gathered to rank 0 over RCCL.
 
 Extra objects on the JSON line: `roofline` (dominant kernel, HIP-event time on the engine's
 stream, algorithmic bytes from DESIGN.md's byte model) and `cpu_baseline` (the CPU oracle's
@@ -41,10 +44,12 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=int, default=22)
-    ap.add_argument("--queries-per-step", type=int, default=8)
+    ap.add_argument("--queries-per-step", type=int, default=64)
+    ap.add_argument("--mode", choices=["batch", "single"], default="batch")
     ap.add_argument("--rounds", type=int, default=0, help="FORA threshold rounds (0 = cost model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-walk-divisor", type=int, default=16)
+    ap.add_argument("--tuning", default="", help="cost-model overrides, e.g. c_dense_edge_ns=0.002,max_rounds=30")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
@@ -80,6 +85,11 @@ def main():
     g = pkg.Graph(host, device=local_rank)
     t_lift = time.time() - t0
     conf = pkg.conf_whole_graph(host.n, host.m, ALPHA)
+    tuning = pkg.tuning_default()
+    for kv in filter(None, args.tuning.split(",")):
+        key, val = kv.split("=")
+        setattr(tuning, key, type(getattr(tuning, key))(float(val)))
+    g.set_tuning(tuning)
     outdeg = np.diff(host.out_rp)
 
     q = args.queries_per_step
@@ -95,32 +105,43 @@ def main():
     acc = {"class_ms": [0.0] * 8, "class_bytes": [0] * 8, "class_launches": [0] * 8, "rounds": 0, "live": 0,
            "walks": 0, "walk_steps": 0, "levels": 0, "dense_levels": 0, "push_ms": 0.0, "mc_ms": 0.0}
 
+    def record_stats(st, live):
+        for c in range(8):
+            acc["class_ms"][c] += st.class_ms[c]
+            acc["class_bytes"][c] += st.class_bytes[c]
+            acc["class_launches"][c] += st.class_launches[c]
+        acc["rounds"] += st.rounds
+        acc["live"] += live
+        acc["walks"] += st.walks
+        acc["walk_steps"] += st.walk_steps
+        acc["levels"] += st.levels
+        acc["dense_levels"] += st.dense_levels
+        acc["push_ms"] += st.push_ms
+        acc["mc_ms"] += st.mc_ms
+
     def run_step(i, record):
-        for j in range(q):
-            s = int(srcs[i, j])
-            _, st = g.fora_single_source(s, EPS, ALPHA, seed=3 + i * q + j, n_rounds=args.rounds, conf=conf,
-                                         fetch=False)
+        if args.mode == "batch":
+            _, ids, vals, _, _, st = g.fora_batch_single_source(srcs[i], EPS, ALPHA, seed=3 + i, n_rounds=args.rounds,
+                                                                k=TOPK, conf=conf)
             if record:
-                for c in range(8):
-                    acc["class_ms"][c] += st.class_ms[c]
-                    acc["class_bytes"][c] += st.class_bytes[c]
-                    acc["class_launches"][c] += st.class_launches[c]
-                acc["rounds"] += st.rounds
-                acc["live"] += int(outdeg[s] > 0)
-                acc["walks"] += st.walks
-                acc["walk_steps"] += st.walk_steps
-                acc["levels"] += st.levels
-                acc["dense_levels"] += st.dense_levels
-                acc["push_ms"] += st.push_ms
-                acc["mc_ms"] += st.mc_ms
+                record_stats(st, int((outdeg[srcs[i]] > 0).sum()))
             if world > 1:
+                ids_blk.copy_(torch.from_numpy(ids))
+                vals_blk.copy_(torch.from_numpy(vals))
+        else:
+            for j in range(q):
+                s = int(srcs[i, j])
+                _, st = g.fora_single_source(s, EPS, ALPHA, seed=3 + i, n_rounds=args.rounds, conf=conf, fetch=False)
+                if record:
+                    record_stats(st, int(outdeg[s] > 0))
                 nsel, ids, vals, _, _ = g.topk_select(TOPK)
-                row_i = np.full(TOPK, -1, dtype=np.int32)
-                row_v = np.zeros(TOPK)
-                row_i[:len(ids)] = ids
-                row_v[:len(vals)] = vals
-                ids_blk[j].copy_(torch.from_numpy(row_i))
-                vals_blk[j].copy_(torch.from_numpy(row_v))
+                if world > 1:
+                    row_i = np.full(TOPK, -1, dtype=np.int32)
+                    row_v = np.zeros(TOPK)
+                    row_i[:len(ids)] = ids
+                    row_v[:len(vals)] = vals
+                    ids_blk[j].copy_(torch.from_numpy(row_i))
+                    vals_blk[j].copy_(torch.from_numpy(row_v))
         if world > 1:  # the only exchange on the path: top-k blocks to rank 0 (xGMI / RCCL)
             dist.gather(ids_blk, gather_ids, dst=0)
             dist.gather(vals_blk, gather_vals, dst=0)
@@ -169,7 +190,7 @@ def main():
                     "ms": round(acc["class_ms"][c], 3), "launches": acc["class_launches"][c],
                     "achieved_GBps": round((acc["class_bytes"][c] / 1e9) / (acc["class_ms"][c] / 1e3), 1)
                     if acc["class_ms"][c] > 0 else 0.0}
-                for c in range(1, 4) if c != dom},
+                for c in (1, 2, 3, 5) if c != dom and acc["class_launches"][c]},
         }
         out = {
             "metric": "single-source PPR queries/sec (FORA, alpha=0.15, eps=0.5)", "value": round(value, 3),
@@ -180,13 +201,16 @@ def main():
                                    "sources per step per GPU (seed 2; dead-end sources included)"
                                    % (args.scale, host.n, host.m, q),
                        "alpha": ALPHA, "eps": EPS, "queries_per_step": q, "rounds": args.rounds or "cost-model",
+                       "mode": "8 queries in flight (pprhip_fora_batch_single_source), top-%d per query" % TOPK
+                       if args.mode == "batch" else "one query at a time (pprhip_fora_single_source)",
                        "sharding": "replicated CSR, sources sharded by rank, top-%d gather to rank 0" % TOPK
                        if world > 1 else "single GPU"},
             "queries_per_s_live_sources": round(acc["live"] * world / elapsed, 3),
             "live_source_fraction": round(live_frac, 3),
             "avg_rounds": round(acc["rounds"] / max(1, args.steps * q), 2),
-            "phase_ms_per_live_query": {"push": round(acc["push_ms"] / max(1, acc["live"]), 3),
-                                        "walk": round(acc["mc_ms"] / max(1, acc["live"]), 3)},
+            "kernel_ms_per_live_query": {pkg.KERNEL_NAMES[c]: round(acc["class_ms"][c] / max(1, acc["live"]), 3)
+                                         for c in (1, 2, 3, 5) if acc["class_launches"][c]},
+            "dense_levels_per_live_query": round(acc["dense_levels"] / max(1, acc["live"]), 1),
             "graph_lift_s": {"generate_and_csr": round(t_gen, 2), "upload_and_tile": round(t_lift, 2)},
             "roofline": roofline,
         }

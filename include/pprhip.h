@@ -88,6 +88,8 @@ typedef struct pprhip_stats {
 #define PPRHIP_KERNEL_SPARSE_PUSH 2
 #define PPRHIP_KERNEL_WALK 3
 #define PPRHIP_KERNEL_BACKWARD_BATCH 4
+#define PPRHIP_KERNEL_DENSE_PULL_BATCH 5 /* one dense level for up to PPRHIP_BATCH queries */
+#define PPRHIP_BATCH 8                   /* queries in flight in pprhip_fora_batch_single_source */
 
 /* Engine tuning: the deterministic replacement of the reference's wall-clock push/walk balance
  * (Fora_Whole_Graph.java:35,75-79,93-103) and the sparse/dense switch.  Zero means "default". */
@@ -215,6 +217,20 @@ int pprhip_topk_select(pprhip_graph_t* g, int k, int32_t* ids_out, double* vals_
 /* Monte_Carlo.computeWholeGraphPPR (Monte_Carlo.java:136-158): omega = 3 ln(2/pfail)/eps^2/delta walks. */
 int pprhip_monte_carlo(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf, uint64_t seed,
                        double* ppr_out, pprhip_stats_t* stats);
+/* q single-source FORA queries (the loop of Gen_Util.java:208-232 over Fora_Whole_Graph.
+ * computeWholeGraphPPR), up to PPRHIP_BATCH of them in flight on this GPU.  Each query runs the
+ * algorithm of pprhip_fora_single_source unchanged (same levels, thresholds, round count and, for
+ * the same seed, the same walks: results agree up to the order of fp64 additions); dense levels of
+ * concurrent queries share one sweep over the in-CSR, whose gathers fetch one 64-byte line per
+ * vertex holding the contributions of all queries in flight.
+ * reserve_out: q*n doubles (query-major) or NULL.  k > 0 additionally selects each query's top-k by
+ * Algo_Util.kth_ppr's rule into ids_out/vals_out (q*k, rows padded with id -1 / value 0) and
+ * n_out[i] (entries >= the k-th value; may exceed k on ties, NULL allowed).  per_query: q entries
+ * or NULL; stats_sum: counters summed, kernel-class times of the whole call. */
+int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
+                                    const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
+                                    double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
+                                    pprhip_stats_t* per_query, pprhip_stats_t* stats_sum);
 /* Batched FORA top-k for the sources of one shard (config #4): q queries one after another on
  * this handle's GPU; ids_out/vals_out are q*k, rows padded with id -1 / value 0. */
 int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k, double eps, double alpha,

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libpprhip.so")
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_IO, ERR_STATE = -1, -2, -3, -4, -5, -6
 
-KERNEL_NAMES = {0: "none", 1: "dense_pull", 2: "sparse_push", 3: "walk", 4: "backward_batch"}
+KERNEL_NAMES = {0: "none", 1: "dense_pull", 2: "sparse_push", 3: "walk", 4: "backward_batch", 5: "dense_pull_batch"}
+BATCH = 8  # PPRHIP_BATCH: queries in flight in fora_batch_single_source
 
 
 class PprhipError(RuntimeError):
@@ -70,6 +71,7 @@ EXPORTS = [
     "pprhip_all_pair_backward", "pprhip_index_merge", "pprhip_index_info", "pprhip_index_arrays",
     "pprhip_index_write_dir", "pprhip_index_destroy", "pprhip_power_method", "pprhip_index_from_arrays",
     "pprhip_format_double", "pprhip_edgelist_from_neo4j_store", "pprhip_edgelist_build_csr",
+    "pprhip_fora_batch_single_source",
 ]
 
 _lib = None
@@ -121,6 +123,7 @@ def lib():
     L.pprhip_fora_topk.argtypes = [vp, i32, dbl, P(ForaConf), u64, vp, vp, ci, P(ci), vp, P(Stats)]
     L.pprhip_topk_select.argtypes = [vp, ci, vp, vp, ci, P(ci), P(dbl), P(Stats)]
     L.pprhip_monte_carlo.argtypes = [vp, i32, dbl, P(ForaConf), u64, vp, P(Stats)]
+    L.pprhip_fora_batch_single_source.argtypes = [vp, vp, ci, dbl, P(ForaConf), u64, ci, vp, ci, vp, vp, vp, vp, P(Stats)]
     L.pprhip_fora_batch_topk.argtypes = [vp, vp, ci, ci, dbl, dbl, u64, vp, vp, P(Stats)]
     L.pprhip_backward_push.argtypes = [vp, i32, dbl, dbl, vp, vp, P(Stats)]
     L.pprhip_all_pair_backward.argtypes = [vp, dbl, dbl, ci, u32, u32, P(vp), P(Stats)]
@@ -424,6 +427,23 @@ class Graph:
         st = Stats()
         _check(lib().pprhip_monte_carlo(self.h, src, eps, C.byref(conf), seed, _ptr(out), C.byref(st)))
         return out, st
+
+    def fora_batch_single_source(self, srcs, eps, alpha, seed, n_rounds=0, k=0, conf=None, fetch=False, per_query=False):
+        """q single-source FORA queries, BATCH of them in flight; returns (reserve[q, n] | None, ids[q, k] | None,
+        vals[q, k] | None, n_sel[q] | None, per-query Stats list | None, summed Stats)."""
+        srcs = np.ascontiguousarray(srcs, dtype=np.int32)
+        q = int(srcs.size)
+        conf = conf or conf_whole_graph(self.n, self.m, alpha)
+        out = np.empty((q, self.n)) if fetch else None
+        ids = np.empty((q, k), dtype=np.int32) if k > 0 else None
+        vals = np.empty((q, k)) if k > 0 else None
+        nsel = np.zeros(q, dtype=np.int32) if k > 0 else None
+        pq = (Stats * q)() if per_query and q else None
+        st = Stats()
+        _check(lib().pprhip_fora_batch_single_source(self.h, _ptr(srcs), q, eps, C.byref(conf), seed, n_rounds, _ptr(out),
+                                                     k, _ptr(ids), _ptr(vals), _ptr(nsel),
+                                                     C.cast(pq, C.c_void_p) if pq is not None else None, C.byref(st)))
+        return out, ids, vals, nsel, (list(pq) if pq is not None else None), st
 
     def fora_batch_topk(self, srcs, k, eps, alpha, seed):
         srcs = np.ascontiguousarray(srcs, dtype=np.int32)

@@ -2,15 +2,52 @@
 // backward search.  Everything numerical runs in the HIP kernels; the host only sequences
 // launches on the handle's stream and reads back 8-byte counters between levels.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <numeric>
+#include <thread>
 
 #include "engine.hpp"
 
 using namespace pprhip;
+
+namespace pprhip {
+
+struct ForaRun;
+
+// Rendezvous of the batch workers (one host thread and one stream per slot) with the sweeper
+// thread.  Workers run their queries' sparse levels, walks and selections concurrently; a worker
+// whose next level is dense waits here.  The sweeper runs a batched sweep whenever somebody waits
+// and no slot "holds": a slot holds from the moment a sweep releases it until it has said what it
+// does next (waits again, goes on with sparse levels, ends its push phase), and while it writes its
+// column of the shared contribution array.  Slots busy with sparse levels or walks hold nothing,
+// so their kernels overlap the sweeps of the others.
+struct BatchSync {
+  std::mutex mu;
+  std::condition_variable cv;
+  pprhip_graph* P = nullptr;
+  ForaRun* runs = nullptr;
+  int n_wait = 0, n_hold = 0, n_workers = 0;
+  bool sweeping = false;
+  bool waitflag[kBatch] = {false, false, false, false, false, false, false, false};
+  bool hold[kBatch] = {false, false, false, false, false, false, false, false};
+  int err = 0;
+  std::string errmsg;
+  void release(int s);  // the slot stops holding (no-op when it does not)
+  void c8_enter(int s);  // before a slot's kernels touch its column of the shared arrays
+  int arrive(int s);     // the slot's next level is dense and prepared; returns after the sweep
+  void fail(int rc);
+  void worker_done(int s);
+  void sweeper();
+};
+
+}  // namespace pprhip
 
 namespace {
 
@@ -25,39 +62,10 @@ struct LevelCtx {
   int dense_run = 0;  // dense levels run since the current dense phase was seeded
 };
 
-// kernel-class timing with an event pool; resolved once per call after the final sync
-struct KernelTimer {
-  std::vector<hipEvent_t> ev;
-  struct Rec { int cls; size_t i; uint64_t bytes; };
-  std::vector<Rec> recs;
-  size_t used = 0;
-  hipStream_t stream = nullptr;
-  // events are deliberately never destroyed: this object outlives the HIP runtime at thread exit
-  hipEvent_t next() {
-    if (used == ev.size()) {
-      hipEvent_t e;
-      if (hipEventCreate(&e) != hipSuccess) return nullptr;
-      ev.push_back(e);
-    }
-    return ev[used++];
-  }
-  void begin(int cls, uint64_t bytes) {
-    hipEvent_t a = next();
-    if (!a) return;
-    recs.push_back({cls, used - 1, bytes});
-    (void)hipEventRecord(a, stream);
-  }
-  void end() {
-    hipEvent_t b = next();
-    if (b) (void)hipEventRecord(b, stream);
-  }
-  void reset() {
-    used = 0;
-    recs.clear();
-  }
-};
-
-thread_local KernelTimer g_timer;
+// kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
+thread_local KernelTimer g_timer_own;
+thread_local KernelTimer* g_timer_cur = &g_timer_own;
+#define g_timer (*g_timer_cur)
 
 int alloc_dev(void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes ? bytes : 8);
@@ -108,10 +116,32 @@ int write_hist0(pprhip_graph* g, uint32_t nf, uint64_t ef) {
   return PPRHIP_OK;
 }
 
+constexpr int kYield = 1;  // run_levels: the next level is dense and the caller runs it (batched sweeps)
+
+// bookkeeping after a dense level: the frontier it produced becomes the current one
+void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_t nf_next, uint64_t ef_next) {
+  L.dense_run++;
+  L.ccur ^= 1;
+  L.dslot ^= 1;
+  L.pslot ^= 1;
+  st.dense_levels++;
+  st.dense_nodes += L.nf;
+  st.push_bytes += level_bytes;
+  L.nf = nf_next;
+  L.ef = ef_next;
+  st.levels++;
+  st.enqueues += L.nf;
+  st.push_bytes += 5ull * L.nf;
+}
+
 // Runs levels until the frontier is empty.  Dense levels cost one host round trip each; sparse
-// levels are launched kMaxBatch at a time and continue on the device (kernels_push.hip).
-int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost) {
+// levels are launched kMaxBatch at a time and continue on the device (kernels_push.hip).  With
+// yield_dense the function prepares a dense level and returns kYield instead of running it: the
+// batch driver runs one sweep for every slot waiting at that point and calls back in.
+int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost,
+               bool yield_dense = false) {
   const bool bwd = a.mode == kBackward;
+  const bool slot = g->parent != nullptr;
   // smallest integer x with (double)x >= dense_frac * m: the device-side form of level_cost()'s test
   const unsigned long long dense_thresh =
       bwd ? ~0ull : (unsigned long long)std::ceil(g->tun.dense_frac * (double)g->m);
@@ -122,12 +152,17 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     if (dense) {
       if (model_cost) *model_cost += c;
       if (!L.dense_prepared) {
-        PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
+        if (slot) {
+          if (g->sync) g->sync->c8_enter(g->slot_index);
+          L.ccur = g->parent->c8cur;  // the slot's column of the shared array is all-zero here
+        } else
+          PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
         PPRHIP_TRY(write_hist0(g, L.nf, L.ef));
         PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, 0, L.nf, dense_thresh, true, L.ccur, L.dslot));
         L.dense_prepared = true;
         L.dense_run = 0;
       }
+      if (yield_dense) return kYield;
       // The sweep writes contributions of non-empty rows only.  Rows without in-edges can hold one
       // solely from a phase's seeding, so the other buffer is cleared when a dense phase starts
       // and the seeded buffer right after its first level has consumed it.
@@ -139,17 +174,10 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       g_timer.end();
       if (L.dense_run == 0)
         PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
-      L.dense_run++;
-      L.ccur ^= 1;
-      L.dslot ^= 1;
-      L.pslot = out;
-      st.dense_levels++;
-      st.dense_nodes += L.nf;
-      st.push_bytes += dense_level_bytes(g);
-      PPRHIP_TRY(read_packed(g, L.pslot, &L.nf, &L.ef));
-      st.levels++;
-      st.enqueues += L.nf;
-      st.push_bytes += 5ull * L.nf;
+      uint32_t nf_next = 0;
+      uint64_t ef_next = 0;
+      PPRHIP_TRY(read_packed(g, out, &nf_next, &ef_next));
+      finish_dense(L, st, dense_level_bytes(g), nf_next, ef_next);
       continue;
     }
     // ---- a batch of sparse levels
@@ -159,9 +187,12 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       // dense-prepared state -> list form; the compaction recounts (dead-end nodes carry no edges)
       PPRHIP_TRY(launch_compact_prepared(g, L.ccur, L.fcur, &g->ctr->hist[0], bwd));
       L.dense_prepared = false;
+      // the column must be read (and handed back zeroed) before another sweep may run
+      if (g->sync) PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     } else {
       PPRHIP_TRY(write_hist0(g, L.nf, L.ef));
     }
+    if (g->sync) g->sync->release(g->slot_index);
     g_timer.begin(PPRHIP_KERNEL_SPARSE_PUSH, 0);
     for (int i = 0; i < kMaxBatch; ++i) {
       const int fb = L.fcur ^ (i & 1);
@@ -214,6 +245,142 @@ int reset_query_state(pprhip_graph* g, bool clear_flags) {
   return PPRHIP_OK;
 }
 
+// per-query workspace of a handle (the graph's own, or a batch slot's)
+int alloc_workspace(pprhip_graph* G) {
+  const uint32_t n = G->n;
+  const size_t nd = sizeof(double) * (size_t)n;
+  void** dbl[] = {(void**)&G->residue, (void**)&G->reserve, (void**)&G->est, (void**)&G->cF, (void**)&G->mc_inc};
+  for (void** p : dbl) PPRHIP_TRY(alloc_dev(p, nd));
+  if (!G->parent) {  // single-query dense levels; slots use the parent's interleaved arrays
+    PPRHIP_TRY(alloc_dev((void**)&G->cdense[0], nd));
+    PPRHIP_TRY(alloc_dev((void**)&G->cdense[1], nd));
+    PPRHIP_TRY(alloc_dev((void**)&G->acc_nz, nd));
+  }
+  for (int i = 0; i < 2; ++i) {
+    PPRHIP_TRY(alloc_dev((void**)&G->F[i], sizeof(int32_t) * (size_t)n));
+    PPRHIP_TRY(alloc_dev((void**)&G->eoff[i], sizeof(uint32_t) * (size_t)n));
+  }
+  PPRHIP_TRY(alloc_dev((void**)&G->flags, n));
+  PPRHIP_TRY(alloc_dev((void**)&G->mc_node, sizeof(int32_t) * (size_t)n));
+  PPRHIP_TRY(alloc_dev((void**)&G->mc_woff, sizeof(unsigned long long) * (size_t)n));
+  PPRHIP_TRY(alloc_dev((void**)&G->partial, sizeof(double) * 1024));
+  PPRHIP_TRY(alloc_dev((void**)&G->hist, sizeof(uint32_t) * 4096));
+  {
+    const size_t nblk = std::max<size_t>(1024, ((size_t)n + 1 + 255) / 256);
+    PPRHIP_TRY(alloc_dev((void**)&G->blk_pack, sizeof(unsigned long long) * nblk));
+    PPRHIP_TRY(alloc_dev((void**)&G->blk_dead, sizeof(double) * nblk));
+    PPRHIP_TRY(alloc_dev((void**)&G->blk_ndead, sizeof(uint32_t) * nblk));
+  }
+  G->sel_cap = 1u << 18;
+  PPRHIP_TRY(alloc_dev((void**)&G->sel_ids, sizeof(int32_t) * G->sel_cap));
+  PPRHIP_TRY(alloc_dev((void**)&G->sel_vals, sizeof(double) * G->sel_cap));
+  PPRHIP_TRY(alloc_dev((void**)&G->ctr, sizeof(DevCounters)));
+  if (hipHostMalloc((void**)&G->h_ctr, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) {
+    set_error("hipHostMalloc failed");
+    return PPRHIP_ERR_OOM;
+  }
+  std::memset(G->h_ctr, 0, sizeof(DevCounters));
+  for (auto& e : G->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      set_error("hipEventCreate failed");
+      return PPRHIP_ERR_HIP;
+    }
+  if (!G->parent) {
+    PPRHIP_CHECK_HIP(hipMemsetAsync(G->acc_nz, 0, nd, G->stream));
+    PPRHIP_CHECK_HIP(hipMemsetAsync(G->cdense[0], 0, nd, G->stream));
+    PPRHIP_CHECK_HIP(hipMemsetAsync(G->cdense[1], 0, nd, G->stream));
+  }
+  PPRHIP_CHECK_HIP(hipMemsetAsync(G->est, 0, nd, G->stream));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(G->flags, 0, n, G->stream));
+  return reset_query_state(G, true);
+}
+
+void free_workspace(pprhip_graph* g) {
+  void* ptrs[] = {g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1],
+                  g->eoff[0], g->eoff[1], g->flags, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist, g->sel_ids,
+                  g->sel_vals, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (g->h_ctr) (void)hipHostFree(g->h_ctr);
+  for (auto e : g->ev)
+    if (e) (void)hipEventDestroy(e);
+}
+
+// Batch slots and the interleaved dense-level arrays, created on the first batched call.
+int ensure_batch(pprhip_graph* P) {
+  if (!P->slots.empty()) return PPRHIP_OK;
+  const size_t n = P->n;
+  for (int i = 0; i < 2; ++i) {
+    PPRHIP_TRY(alloc_dev((void**)&P->c8[i], sizeof(double) * n * kBatch));
+    PPRHIP_CHECK_HIP(hipMemsetAsync(P->c8[i], 0, sizeof(double) * n * kBatch, P->stream));
+  }
+  PPRHIP_TRY(alloc_dev((void**)&P->acc8, sizeof(double) * ((size_t)P->n_nz + 1) * kBatch));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * ((size_t)P->n_nz + 1) * kBatch, P->stream));
+  PPRHIP_TRY(alloc_dev((void**)&P->d_slot_args, sizeof(SlotArgs) * kBatch));
+  if (hipHostMalloc((void**)&P->h_slot_args, sizeof(SlotArgs) * kBatch, hipHostMallocDefault) != hipSuccess) {
+    set_error("hipHostMalloc failed");
+    return PPRHIP_ERR_OOM;
+  }
+  std::memset(P->h_slot_args, 0, sizeof(SlotArgs) * kBatch);
+  PPRHIP_TRY(alloc_dev((void**)&P->blk_pack8, sizeof(unsigned long long) * kBatch * kApplyBlocks8));
+  PPRHIP_TRY(alloc_dev((void**)&P->blk_dead8, sizeof(double) * kBatch * kApplyBlocks8));
+  PPRHIP_TRY(alloc_dev((void**)&P->blk_ndead8, sizeof(uint32_t) * kBatch * kApplyBlocks8));
+  P->c8cur = 0;
+  for (int s = 0; s < kBatch; ++s) {
+    pprhip_graph* S = new (std::nothrow) pprhip_graph();
+    if (!S) return PPRHIP_ERR_OOM;
+    P->slots.push_back(S);
+    S->parent = P;
+    S->slot_index = s;
+    S->device = P->device;
+    S->n_cus = P->n_cus;
+    S->n = P->n;
+    S->m = P->m;
+    if (hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking) != hipSuccess) {
+      set_error("hipStreamCreate failed");
+      return PPRHIP_ERR_HIP;
+    }
+    S->stream = P->stream;
+    S->out_rp = P->out_rp;
+    S->in_rp = P->in_rp;
+    S->out_ext = P->out_ext;
+    S->out_ci = P->out_ci;
+    S->in_ci = P->in_ci;
+    S->relabeled = P->relabeled;
+    S->new2old = P->new2old;
+    S->old2new = P->old2new;
+    S->start_flags = P->start_flags;
+    S->chunk_starts = P->chunk_starts;
+    S->n_chunks = P->n_chunks;
+    S->nz_rows = P->nz_rows;
+    S->n_nz = P->n_nz;
+    S->tun = P->tun;
+    PPRHIP_TRY(alloc_workspace(S));
+  }
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
+  return PPRHIP_OK;
+}
+
+void free_batch(pprhip_graph* P) {
+  for (pprhip_graph* S : P->slots) {
+    free_workspace(S);
+    S->ktimer.destroy();
+    if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
+    delete S;
+  }
+  P->ktimer.destroy();
+  P->slots.clear();
+  void* ptrs[] = {P->c8[0], P->c8[1], P->acc8, P->d_slot_args, P->blk_pack8, P->blk_dead8, P->blk_ndead8};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (P->h_slot_args) (void)hipHostFree(P->h_slot_args);
+  P->c8[0] = P->c8[1] = P->acc8 = nullptr;
+  P->d_slot_args = P->h_slot_args = nullptr;
+  P->blk_pack8 = nullptr;
+  P->blk_dead8 = nullptr;
+  P->blk_ndead8 = nullptr;
+}
+
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree) {
   // frontier = {node}; the first node is pushed unconditionally (Forward_Push.java:81-86)
   g->h_ctr->pad[0] = (unsigned long long)(uint32_t)node;  // staging for the 4-byte node id
@@ -233,6 +400,10 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
   bool dense = false;
   if (L.nf) (void)level_cost(g, L.nf, L.ef, &dense);
   if (dense) {
+    if (g->parent) {
+      if (g->sync) g->sync->c8_enter(g->slot_index);
+      L.ccur = g->parent->c8cur;
+    }
     PPRHIP_TRY(launch_seed_dense(g, a, kind, L.ccur, L.pslot, L.dslot));
     L.dense_prepared = true;
     L.dense_run = 0;
@@ -314,13 +485,7 @@ struct CallTimer {
     double tot[8] = {0};
     uint64_t bytes[8] = {0};
     uint32_t cnt[8] = {0};
-    for (auto& r : g_timer.recs) {
-      if (r.i + 1 >= g_timer.used) continue;
-      const double t = ms(g_timer.ev[r.i], g_timer.ev[r.i + 1]);
-      tot[r.cls] += t;
-      bytes[r.cls] += r.bytes;
-      cnt[r.cls]++;
-    }
+    g_timer.resolve(tot, bytes, cnt);
     int best = 0;
     for (int c = 1; c < 8; ++c)
       if (tot[c] > tot[best]) best = c;
@@ -369,8 +534,10 @@ int check_node(const pprhip_graph* g, int32_t v, const char* fn) {
   return PPRHIP_OK;
 }
 
-uint32_t hdeg_out(const pprhip_graph* g, int32_t v) { return g->h_out_rp[v + 1] - g->h_out_rp[v]; }
-uint32_t hdeg_in(const pprhip_graph* g, int32_t v) { return g->h_in_rp[v + 1] - g->h_in_rp[v]; }
+// host-side CSR facts live on the graph handle; batch slots borrow them
+const pprhip_graph* host_of(const pprhip_graph* g) { return g->parent ? g->parent : g; }
+uint32_t hdeg_out(const pprhip_graph* g, int32_t v) { return host_of(g)->h_out_rp[v + 1] - host_of(g)->h_out_rp[v]; }
+uint32_t hdeg_in(const pprhip_graph* g, int32_t v) { return host_of(g)->h_in_rp[v + 1] - host_of(g)->h_in_rp[v]; }
 
 // ------------------------------------------------------------------ top-k selection driver
 struct IdVal {
@@ -445,7 +612,7 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     }
     cand.resize(cnt);
-    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {g->h_new2old[ids[i]], vals[i]};
+    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {host_of(g)->h_new2old[ids[i]], vals[i]};
   } else {
     // more ties at the k-th value than the candidate buffer holds: finish on the whole vector
     std::vector<double> all(g->n);
@@ -453,7 +620,7 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     const double lb = [&] { double d; std::memcpy(&d, &lower_bits, 8); return d; }();
     for (uint32_t i = 0; i < g->n; ++i)
-      if (all[i] > 0.0 && (!have || all[i] >= lb)) cand.push_back({g->h_new2old[i], all[i]});
+      if (all[i] > 0.0 && (!have || all[i] >= lb)) cand.push_back({host_of(g)->h_new2old[i], all[i]});
   }
   std::sort(cand.begin(), cand.end(), [](const IdVal& a, const IdVal& b) {
     if (a.val != b.val) return a.val > b.val;
@@ -691,50 +858,18 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
   if ((rc = up((void**)&G->start_flags, flags.data(), flags.size()))) return fail(rc);
   if ((rc = up((void**)&G->chunk_starts, chunk_starts.data(), sizeof(uint32_t) * chunk_starts.size()))) return fail(rc);
   if ((rc = up((void**)&G->nz_rows, nz_rows.data(), sizeof(int32_t) * nz_rows.size()))) return fail(rc);
-  const size_t nd = sizeof(double) * (size_t)n;
-  void** dbl[] = {(void**)&G->residue, (void**)&G->reserve, (void**)&G->est,    (void**)&G->cdense[0],
-                  (void**)&G->cdense[1], (void**)&G->cF,    (void**)&G->mc_inc, (void**)&G->acc_nz};
-  for (void** p : dbl)
-    if ((rc = alloc_dev(p, nd))) return fail(rc);
-  for (int i = 0; i < 2; ++i) {
-    if ((rc = alloc_dev((void**)&G->F[i], sizeof(int32_t) * (size_t)n))) return fail(rc);
-    if ((rc = alloc_dev((void**)&G->eoff[i], sizeof(uint32_t) * (size_t)n))) return fail(rc);
-  }
-  if ((rc = alloc_dev((void**)&G->flags, n))) return fail(rc);
-  if ((rc = alloc_dev((void**)&G->mc_node, sizeof(int32_t) * (size_t)n))) return fail(rc);
-  if ((rc = alloc_dev((void**)&G->mc_woff, sizeof(unsigned long long) * (size_t)n))) return fail(rc);
-  if ((rc = alloc_dev((void**)&G->partial, sizeof(double) * 1024))) return fail(rc);
-  if ((rc = alloc_dev((void**)&G->hist, sizeof(uint32_t) * 4096))) return fail(rc);
-  {
-    const size_t nblk = std::max<size_t>(1024, ((size_t)n + 1 + 255) / 256);
-    if ((rc = alloc_dev((void**)&G->blk_pack, sizeof(unsigned long long) * nblk))) return fail(rc);
-    if ((rc = alloc_dev((void**)&G->blk_dead, sizeof(double) * nblk))) return fail(rc);
-    if ((rc = alloc_dev((void**)&G->blk_ndead, sizeof(uint32_t) * nblk))) return fail(rc);
-  }
-  G->sel_cap = 1u << 18;
-  if ((rc = alloc_dev((void**)&G->sel_ids, sizeof(int32_t) * G->sel_cap))) return fail(rc);
-  if ((rc = alloc_dev((void**)&G->sel_vals, sizeof(double) * G->sel_cap))) return fail(rc);
-  if ((rc = alloc_dev((void**)&G->ctr, sizeof(DevCounters)))) return fail(rc);
-  if (hipHostMalloc((void**)&G->h_ctr, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) {
-    set_error("hipHostMalloc failed");
-    return fail(PPRHIP_ERR_OOM);
-  }
-  std::memset(G->h_ctr, 0, sizeof(DevCounters));
   if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) {
     set_error("hipStreamCreate failed");
     return fail(PPRHIP_ERR_HIP);
   }
-  for (auto& e : G->ev)
-    if (hipEventCreate(&e) != hipSuccess) {
-      set_error("hipEventCreate failed");
-      return fail(PPRHIP_ERR_HIP);
-    }
-  (void)hipMemsetAsync(G->acc_nz, 0, nd, G->stream);
-  (void)hipMemsetAsync(G->est, 0, nd, G->stream);
-  (void)hipMemsetAsync(G->cdense[0], 0, nd, G->stream);
-  (void)hipMemsetAsync(G->cdense[1], 0, nd, G->stream);
-  (void)hipMemsetAsync(G->flags, 0, n, G->stream);
-  if (reset_query_state(G, true) != PPRHIP_OK) return fail(PPRHIP_ERR_HIP);
+  {
+    std::vector<int32_t> zin;
+    for (uint32_t v = 0; v < n; ++v)
+      if (irp[v + 1] == irp[v]) zin.push_back((int32_t)v);
+    G->n_zin = (uint32_t)zin.size();
+    if ((rc = up((void**)&G->zin_rows, zin.data(), sizeof(int32_t) * zin.size()))) return fail(rc);
+  }
+  if ((rc = alloc_workspace(G))) return fail(rc);
   if (hipStreamSynchronize(G->stream) != hipSuccess) {
     set_error("stream sync after graph upload failed");
     return fail(PPRHIP_ERR_HIP);
@@ -747,15 +882,12 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
-  void* ptrs[] = {g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags, g->chunk_starts,
-                  g->nz_rows, g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0],
-                  g->F[1], g->eoff[0], g->eoff[1], g->flags, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist,
-                  g->sel_ids, g->sel_vals, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
+  free_batch(g);
+  void* ptrs[] = {g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags,
+                  g->chunk_starts, g->nz_rows, g->zin_rows};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (g->h_ctr) (void)hipHostFree(g->h_ctr);
-  for (auto e : g->ev)
-    if (e) (void)hipEventDestroy(e);
+  free_workspace(g);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -958,6 +1090,140 @@ int pprhip_random_walk_batch(pprhip_graph_t* g, const int32_t* starts, const uin
 }
 
 // ------------------------------------------------------------------ FORA whole graph (a5)
+namespace pprhip {
+
+// One FORA query as a resumable run: step() advances it until it is finished or (yield_dense)
+// until its next level is dense, so that the batch driver can run that level for many queries
+// in one sweep.  pprhip_fora_single_source drives the same code without yielding.
+struct ForaRun {
+  pprhip_graph* g = nullptr;
+  int32_t src = 0;  // internal id
+  const pprhip_fora_conf_t* conf = nullptr;
+  uint64_t seed = 0;
+  int n_rounds = 0;
+  CallTimer* tm = nullptr;  // single-query calls: push / walk phase marks
+  pprhip_stats_t st;
+  double alpha = 0, rsum_local = 0, rmax_local = 0, omega_local = 0, rmax_used = 0, model_cost = 0;
+  int rounds = 0;
+  bool dead_src = false;
+  LevelCtx L;
+  PushArgs a;
+  enum Phase { kRoundStart, kLevels, kWalks, kDone } phase = kDone;
+  int query = -1;  // batch driver: index of the query this run serves
+  bool waiting = false;
+  bool in_push = false;  // counted in BatchSync::n_push
+};
+
+}  // namespace pprhip
+
+namespace {
+
+void leave_push(ForaRun& r) {
+  if (r.in_push) {
+    r.in_push = false;
+    if (r.g->sync) r.g->sync->release(r.g->slot_index);
+  }
+}
+
+int fora_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, const pprhip_fora_conf_t* conf,
+               uint64_t seed, int n_rounds) {
+  r.g = g;
+  r.src = src_internal;
+  r.conf = conf;
+  r.seed = seed;
+  r.n_rounds = n_rounds;
+  std::memset(&r.st, 0, sizeof r.st);
+  g->topk_active = false;
+  PPRHIP_TRY(reset_query_state(g, false));
+  r.alpha = conf->alpha;
+  r.rsum_local = conf->rsum;
+  PPRHIP_TRY(pprhip_fora_whole_params(conf, eps, &r.rmax_local, &r.omega_local));  // Fora_Whole_Graph.java:86-87
+  r.rmax_used = r.rmax_local;
+  r.model_cost = 0.0;
+  r.rounds = 0;
+  r.dead_src = hdeg_out(g, src_internal) == 0;
+  r.L = LevelCtx();
+  r.phase = ForaRun::kRoundStart;
+  r.waiting = false;
+  r.in_push = true;
+  return PPRHIP_OK;
+}
+
+int fora_step(ForaRun& r, bool yield_dense) {
+  pprhip_graph* g = r.g;
+  for (;;) {
+    if (r.phase == ForaRun::kRoundStart) {  // Fora_Whole_Graph.java:93-103, clock replaced by the level cost model
+      const bool more = r.n_rounds > 0 ? r.rounds < r.n_rounds
+                                       : (r.model_cost < g->tun.c_walk_ns * r.rsum_local * r.omega_local &&
+                                          r.rounds < g->tun.max_rounds);
+      if (!more) {
+        r.phase = ForaRun::kWalks;
+        continue;
+      }
+      if (r.dead_src) {  // Forward_Push.java:72-76
+        PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)r.src, 1.0));
+        r.rsum_local = 0.0;
+        r.rmax_used = r.rmax_local;
+        r.rounds++;
+        r.phase = ForaRun::kWalks;
+        continue;
+      }
+      r.a = PushArgs{r.alpha, r.rmax_local, 0.0, r.src, kFwdWhole};
+      if (r.rounds == 0) {
+        PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)r.src, 1.0));
+        PPRHIP_TRY(seed_single(g, r.L, r.src, hdeg_out(g, r.src)));
+      } else {
+        PPRHIP_TRY(seed_scan(g, r.a, 0, r.L));
+      }
+      r.phase = ForaRun::kLevels;
+    }
+    if (r.phase == ForaRun::kLevels) {
+      const int rc = run_levels(g, r.a, r.L, r.st, &r.model_cost, yield_dense);
+      if (rc != PPRHIP_OK) return rc;  // kYield or an error
+      double sum = 0.0;
+      PPRHIP_TRY(device_sum(g, g->residue, &sum));
+      r.rsum_local = sum * (1 - r.alpha);  // :101 (rsum is the exact residue sum here)
+      r.rmax_used = r.rmax_local;
+      r.rmax_local /= 2.0;  // :102
+      r.rounds++;
+      r.phase = (r.n_rounds > 0 && !(r.rsum_local > 0.0)) ? ForaRun::kWalks : ForaRun::kRoundStart;
+      continue;
+    }
+    if (r.phase == ForaRun::kWalks) {
+      leave_push(r);
+      PPRHIP_TRY(read_dead_pops(g, r.st));
+      if (r.tm) r.tm->mark(1);
+      // Fora_Whole_Graph.java:112-140
+      const double nrw_d = r.omega_local * r.rsum_local;
+      const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;
+      if (!r.dead_src) PPRHIP_TRY(run_walk_phase(g, 0, r.alpha, r.rsum_local, nrw, r.seed, 0, g->reserve, r.st));
+      if (r.tm) r.tm->mark(2);
+      r.st.rounds = (uint32_t)r.rounds;
+      r.st.rsum = r.rsum_local;
+      r.st.rmax_final = r.rmax_used;
+      r.st.omega = r.omega_local;
+      r.phase = ForaRun::kDone;
+    }
+    return PPRHIP_OK;
+  }
+}
+
+void add_stats(pprhip_stats_t& sum, const pprhip_stats_t& st) {
+  sum.pops += st.pops; sum.edge_pushes += st.edge_pushes; sum.enqueues += st.enqueues;
+  sum.dead_end_pops += st.dead_end_pops; sum.dense_nodes += st.dense_nodes; sum.levels += st.levels;
+  sum.dense_levels += st.dense_levels; sum.rounds += st.rounds; sum.mc_sources += st.mc_sources;
+  sum.walks += st.walks; sum.walk_steps += st.walk_steps; sum.select_passes += st.select_passes;
+  sum.push_ms += st.push_ms; sum.mc_ms += st.mc_ms; sum.select_ms += st.select_ms; sum.total_ms += st.total_ms;
+  sum.push_bytes += st.push_bytes; sum.mc_bytes += st.mc_bytes; sum.select_bytes += st.select_bytes;
+  for (int c = 0; c < 8; ++c) {
+    sum.class_ms[c] += st.class_ms[c];
+    sum.class_bytes[c] += st.class_bytes[c];
+    sum.class_launches[c] += st.class_launches[c];
+  }
+}
+
+}  // namespace
+
 int pprhip_fora_single_source(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf,
                               uint64_t seed, int n_rounds, double* reserve_out, pprhip_stats_t* stats) {
   PPRHIP_TRY(check_graph(g, "pprhip_fora_single_source"));
@@ -967,63 +1233,386 @@ int pprhip_fora_single_source(pprhip_graph_t* g, int32_t src, double eps, const 
     set_error("pprhip_fora_single_source: bad arguments (eps=%g n_rounds=%d)", eps, n_rounds);
     return PPRHIP_ERR_INVALID;
   }
-  pprhip_stats_t st;
-  std::memset(&st, 0, sizeof st);
-  g->topk_active = false;
-  PPRHIP_TRY(reset_query_state(g, false));
+  ForaRun r;
+  PPRHIP_TRY(fora_begin(r, g, src, eps, conf, seed, n_rounds));
   CallTimer tm(g);
-  const double alpha = conf->alpha;
-  double rsum_local = conf->rsum, rmax_local = 0.0, omega_local = 0.0;
-  PPRHIP_TRY(pprhip_fora_whole_params(conf, eps, &rmax_local, &omega_local));  // Fora_Whole_Graph.java:86-87
-  double rmax_used = rmax_local;
-  double model_cost = 0.0;
-  int rounds = 0;
-  const bool dead_src = hdeg_out(g, src) == 0;
-  LevelCtx L;
-  for (;;) {  // Fora_Whole_Graph.java:93-103, clock replaced by the level cost model
-    const bool more = n_rounds > 0
-                          ? rounds < n_rounds
-                          : (model_cost < g->tun.c_walk_ns * rsum_local * omega_local && rounds < g->tun.max_rounds);
-    if (!more) break;
-    if (dead_src) {  // Forward_Push.java:72-76
-      PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)src, 1.0));
-      rsum_local = 0.0;
-      rmax_used = rmax_local;
-      rounds++;
-      break;
-    }
-    PushArgs a{alpha, rmax_local, 0.0, src, kFwdWhole};
-    if (rounds == 0) {
-      PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)src, 1.0));
-      PPRHIP_TRY(seed_single(g, L, src, hdeg_out(g, src)));
-    } else {
-      PPRHIP_TRY(seed_scan(g, a, 0, L));
-    }
-    PPRHIP_TRY(run_levels(g, a, L, st, &model_cost));
-    double sum = 0.0;
-    PPRHIP_TRY(device_sum(g, g->residue, &sum));
-    rsum_local = sum * (1 - alpha);  // :101 (rsum is the exact residue sum here)
-    rmax_used = rmax_local;
-    rmax_local /= 2.0;  // :102
-    rounds++;
-    if (n_rounds > 0 && !(rsum_local > 0.0)) break;
-  }
-  PPRHIP_TRY(read_dead_pops(g, st));
-  tm.mark(1);
-  // Fora_Whole_Graph.java:112-140
-  const double nrw_d = omega_local * rsum_local;
-  const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;
-  if (!dead_src) PPRHIP_TRY(run_walk_phase(g, 0, alpha, rsum_local, nrw, seed, 0, g->reserve, st));
-  tm.mark(2);
-  tm.finish(st);
-  st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
-  st.mc_ms = CallTimer::ms(g->ev[1], g->ev[2]);
-  st.rounds = (uint32_t)rounds;
-  st.rsum = rsum_local;
-  st.rmax_final = rmax_used;
-  st.omega = omega_local;
+  r.tm = &tm;
+  PPRHIP_TRY(fora_step(r, false));
+  tm.finish(r.st);
+  r.st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  r.st.mc_ms = CallTimer::ms(g->ev[1], g->ev[2]);
   PPRHIP_TRY(copy_out(g, g->reserve, reserve_out));
-  if (stats) *stats = st;
+  if (stats) *stats = r.st;
+  return PPRHIP_OK;
+}
+
+namespace {
+
+// One batched dense level for the slots flagged in `active`: stages their arguments, orders the
+// parent stream behind the slots' prepare work, runs the sweep and brings the new frontier counters
+// back.  The caller holds the sweep exclusively (sequential driver, or BatchSync::sweeping).
+int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) {
+  for (int s = 0; s < kBatch; ++s) {
+    pprhip_graph* S = P->slots[s];
+    SlotArgs& sa = P->h_slot_args[s];
+    sa.res = S->residue;
+    sa.reserve = S->reserve;
+    sa.flags = S->flags;
+    sa.ctr = S->ctr;
+    sa.active = active[s] ? 1 : 0;
+    if (!active[s]) continue;
+    const ForaRun& r = runs[s];
+    sa.alpha = r.a.alpha;
+    sa.rmax = r.a.rmax;
+    sa.min_rmax = r.a.min_rmax;
+    sa.src = r.a.src;
+    sa.mode = r.a.mode;
+    sa.dead_slot = r.L.dslot;
+    sa.out_slot = r.L.pslot ^ 1;
+    if (S->stream != P->stream) {
+      PPRHIP_CHECK_HIP(hipEventRecord(S->ev[3], S->stream));
+      PPRHIP_CHECK_HIP(hipStreamWaitEvent(P->stream, S->ev[3], 0));
+    }
+  }
+  const uint64_t sweep_bytes = 4ull * P->m + (uint64_t)n_active * (8ull * P->m + 36ull * P->n + 4ull);
+  P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
+  PPRHIP_TRY(launch_dense_level_b8(P));
+  P->ktimer.end();
+  for (int s = 0; s < kBatch; ++s)
+    if (active[s]) {
+      pprhip_graph* S = P->slots[s];
+      const int out = P->h_slot_args[s].out_slot;
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(&S->h_ctr->packed[out], &S->ctr->packed[out], sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, P->stream));
+    }
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
+  P->c8cur ^= 1;
+  for (int s = 0; s < kBatch; ++s)
+    if (active[s]) {
+      ForaRun& r = runs[s];
+      const unsigned long long pk = P->slots[s]->h_ctr->packed[P->h_slot_args[s].out_slot];
+      // the sweep's index stream is shared: each query is charged its own gathers and row work
+      finish_dense(r.L, r.st, 8ull * P->m + 36ull * P->n + 4ull + 4ull * P->m / (uint64_t)n_active,
+                   (uint32_t)(pk >> kPackShift), pk & kPackMask);
+    }
+  return PPRHIP_OK;
+}
+
+struct BatchJob {
+  pprhip_graph* P;
+  const int32_t* srcs;
+  int q;
+  double eps;
+  const pprhip_fora_conf_t* conf;
+  uint64_t seed;
+  int n_rounds;
+  double* reserve_out;
+  int k;
+  int32_t* ids_out;
+  double* vals_out;
+  int* n_out;
+  pprhip_stats_t* per_query;
+  pprhip_stats_t sum;
+  std::mutex sum_mu;
+  std::atomic<int> next_query{0};
+};
+
+// outputs of a finished query (its slot still holds the vectors)
+int finish_query(BatchJob& J, ForaRun& r) {
+  pprhip_graph* S = r.g;
+  const int i = r.query;
+  if (J.reserve_out) PPRHIP_TRY(copy_out(S, S->reserve, J.reserve_out + (size_t)i * J.P->n));
+  if (J.k > 0) {
+    int nsel = 0;
+    bool have = false;
+    int32_t* ids = J.ids_out + (size_t)i * J.k;
+    double* vals = J.vals_out + (size_t)i * J.k;
+    PPRHIP_TRY(select_topk(S, S->reserve, J.k, ids, vals, J.k, &nsel, nullptr, &have, r.st));
+    for (int j = std::min(nsel, J.k); j < J.k; ++j) {
+      ids[j] = -1;
+      vals[j] = 0.0;
+    }
+    if (J.n_out) J.n_out[i] = nsel;
+  }
+  if (J.per_query) J.per_query[i] = r.st;
+  {
+    std::lock_guard<std::mutex> lk(J.sum_mu);
+    add_stats(J.sum, r.st);
+  }
+  r.phase = ForaRun::kDone;
+  r.query = -1;
+  return PPRHIP_OK;
+}
+
+int begin_query(BatchJob& J, ForaRun& r, pprhip_graph* S, int i) {
+  S->tun = J.P->tun;
+  PPRHIP_TRY(fora_begin(r, S, J.P->h_old2new[J.srcs[i]], J.eps, J.conf, J.seed, J.n_rounds));
+  r.query = i;
+  return PPRHIP_OK;
+}
+
+// all slots on the calling thread and the graph's stream, one after another
+int batch_sequential(BatchJob& J, ForaRun* runs) {
+  pprhip_graph* P = J.P;
+  int busy = 0;
+  for (;;) {
+    // every slot advances until it waits at a dense level; finished slots take the next query
+    for (int s = 0; s < kBatch; ++s) {
+      ForaRun& r = runs[s];
+      for (;;) {
+        if (r.query < 0) {
+          const int i = J.next_query.load();
+          if (i >= J.q) break;
+          J.next_query.store(i + 1);
+          PPRHIP_TRY(begin_query(J, r, P->slots[s], i));
+          busy++;
+        }
+        if (r.waiting) break;
+        const int rc = fora_step(r, true);
+        if (rc == kYield) {
+          r.waiting = true;
+          break;
+        }
+        if (rc != PPRHIP_OK) return rc;
+        PPRHIP_TRY(finish_query(J, r));
+        busy--;
+      }
+    }
+    if (busy == 0) break;
+    bool active[kBatch];
+    int n_wait = 0;
+    for (int s = 0; s < kBatch; ++s) {
+      active[s] = runs[s].query >= 0 && runs[s].waiting;
+      n_wait += active[s] ? 1 : 0;
+    }
+    PPRHIP_TRY(run_sweep(P, runs, active, n_wait));
+    for (int s = 0; s < kBatch; ++s)
+      if (active[s]) runs[s].waiting = false;
+  }
+  return PPRHIP_OK;
+}
+
+// one worker thread per slot
+void batch_worker(BatchJob* J, BatchSync* B, ForaRun* runs, int s) {
+  pprhip_graph* P = J->P;
+  pprhip_graph* S = P->slots[s];
+  ForaRun& r = runs[s];
+  int rc = PPRHIP_OK;
+  if (hipSetDevice(P->device) != hipSuccess) {
+    set_error("hipSetDevice(%d) failed in a batch worker", P->device);
+    rc = PPRHIP_ERR_HIP;
+  }
+  g_timer_cur = &S->ktimer;
+  S->ktimer.stream = S->stream;
+  S->ktimer.reset();
+  while (rc == PPRHIP_OK) {
+    {
+      std::lock_guard<std::mutex> lk(B->mu);
+      if (B->err) break;
+    }
+    const int i = J->next_query.fetch_add(1);
+    if (i >= J->q) break;
+    rc = begin_query(*J, r, S, i);
+    while (rc == PPRHIP_OK) {
+      rc = fora_step(r, true);
+      if (rc != kYield) break;
+      rc = B->arrive(s);
+    }
+    if (rc == PPRHIP_OK) rc = finish_query(*J, r);
+  }
+  if (rc != PPRHIP_OK) {
+    leave_push(r);
+    B->fail(rc);
+  }
+  (void)hipStreamSynchronize(S->stream);
+  g_timer_cur = &g_timer_own;
+  B->worker_done(s);
+}
+
+}  // namespace
+
+namespace pprhip {
+
+void BatchSync::release(int s) {
+  std::lock_guard<std::mutex> lk(mu);
+  if (hold[s]) {
+    hold[s] = false;
+    n_hold--;
+    cv.notify_all();
+  }
+}
+
+void BatchSync::c8_enter(int s) {
+  std::unique_lock<std::mutex> lk(mu);
+  cv.wait(lk, [&] { return !sweeping || err != 0; });
+  if (!hold[s]) {
+    hold[s] = true;
+    n_hold++;
+  }
+}
+
+void BatchSync::fail(int rc) {
+  std::lock_guard<std::mutex> lk(mu);
+  if (!err) {
+    err = rc;
+    errmsg = get_error();
+  }
+  cv.notify_all();
+}
+
+void BatchSync::worker_done(int s) {
+  std::lock_guard<std::mutex> lk(mu);
+  if (hold[s]) {
+    hold[s] = false;
+    n_hold--;
+  }
+  n_workers--;
+  cv.notify_all();
+}
+
+int BatchSync::arrive(int s) {
+  std::unique_lock<std::mutex> lk(mu);
+  if (err) return err;
+  if (hold[s]) {
+    hold[s] = false;
+    n_hold--;
+  }
+  waitflag[s] = true;
+  n_wait++;
+  cv.notify_all();
+  cv.wait(lk, [&] { return !waitflag[s] || err != 0; });
+  return err;
+}
+
+// the sweeper thread: one batched sweep whenever somebody waits and nobody holds
+void BatchSync::sweeper() {
+  (void)hipSetDevice(P->device);
+  std::unique_lock<std::mutex> lk(mu);
+  for (;;) {
+    cv.wait(lk, [&] { return n_workers == 0 || err != 0 || (n_wait > 0 && n_hold == 0); });
+    if (n_workers == 0 || err != 0) return;
+    sweeping = true;
+    bool active[kBatch];
+    int n_active = 0;
+    for (int s = 0; s < kBatch; ++s) {
+      active[s] = waitflag[s];
+      n_active += active[s] ? 1 : 0;
+    }
+    lk.unlock();
+    const int rc = run_sweep(P, runs, active, n_active);
+    const std::string msg = rc != PPRHIP_OK ? get_error() : "";
+    lk.lock();
+    if (rc != PPRHIP_OK && !err) {
+      err = rc;
+      errmsg = msg;
+    }
+    for (int s = 0; s < kBatch; ++s)
+      if (active[s]) {
+        waitflag[s] = false;
+        n_wait--;
+        hold[s] = true;  // until the slot has said what it does next
+        n_hold++;
+      }
+    sweeping = false;
+    cv.notify_all();
+  }
+}
+
+}  // namespace pprhip
+
+// Batched single-source FORA: up to kBatch queries in flight on kBatch workspaces of this handle.
+// Every query runs the single-query algorithm unchanged (same levels, same thresholds, same walks
+// for the same seed); whenever the queries in a push phase all stand at a dense level, one sweep of
+// the batched kernels serves them.  By default every slot has a worker thread and a stream of its
+// own, so sparse levels, walks and selections of different queries overlap on the GPU
+// (PPRHIP_BATCH_THREADS=0: all slots on the calling thread and one stream).
+int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
+                                    const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
+                                    double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
+                                    pprhip_stats_t* per_query, pprhip_stats_t* stats_sum) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_single_source"));
+  if (q < 0 || !conf || !(eps > 0.0) || n_rounds < 0 || (q > 0 && !srcs) || k < 0 ||
+      (k > 0 && q > 0 && (!ids_out || !vals_out))) {
+    set_error("pprhip_fora_batch_single_source: bad arguments (q=%d eps=%g n_rounds=%d k=%d)", q, eps, n_rounds, k);
+    return PPRHIP_ERR_INVALID;
+  }
+  for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_single_source"));
+  PPRHIP_TRY(ensure_batch(g));
+  const char* env = getenv("PPRHIP_BATCH_THREADS");
+  const bool threaded = !(env && env[0] == '0') && q > 1;
+  BatchJob J;
+  J.P = g;
+  J.srcs = srcs;
+  J.q = q;
+  J.eps = eps;
+  J.conf = conf;
+  J.seed = seed;
+  J.n_rounds = n_rounds;
+  J.reserve_out = reserve_out;
+  J.k = k;
+  J.ids_out = ids_out;
+  J.vals_out = vals_out;
+  J.n_out = n_out;
+  J.per_query = per_query;
+  std::memset(&J.sum, 0, sizeof J.sum);
+  ForaRun runs[kBatch];
+  g->ktimer.stream = g->stream;
+  g->ktimer.reset();
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = PPRHIP_OK;
+  double tot[8] = {0};
+  uint64_t bytes[8] = {0};
+  uint32_t cnt[8] = {0};
+  if (threaded) {
+    BatchSync B;
+    B.P = g;
+    B.runs = runs;
+    for (pprhip_graph* S : g->slots) {
+      S->stream = S->own_stream;
+      S->sync = &B;
+    }
+    B.n_workers = kBatch;
+    std::thread sweeper(&BatchSync::sweeper, &B);
+    std::vector<std::thread> workers;
+    for (int s = 0; s < kBatch; ++s) workers.emplace_back(batch_worker, &J, &B, runs, s);
+    for (auto& w : workers) w.join();
+    sweeper.join();
+    for (pprhip_graph* S : g->slots) {
+      S->sync = nullptr;
+      S->ktimer.resolve(tot, bytes, cnt);
+    }
+    if (B.err) {
+      set_error("%s", B.errmsg.c_str());
+      rc = B.err;
+    }
+  } else {
+    for (pprhip_graph* S : g->slots) {
+      S->stream = g->stream;
+      S->sync = nullptr;
+    }
+    g_timer.stream = g->stream;
+    g_timer.reset();
+    rc = batch_sequential(J, runs);
+    (void)hipStreamSynchronize(g->stream);
+    g_timer.resolve(tot, bytes, cnt);
+  }
+  (void)hipStreamSynchronize(g->stream);
+  if (rc != PPRHIP_OK) return rc;
+  g->ktimer.resolve(tot, bytes, cnt);
+  pprhip_stats_t& sum = J.sum;
+  sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  int best = 0;
+  for (int c = 0; c < 8; ++c) {
+    sum.class_ms[c] = tot[c];
+    sum.class_bytes[c] = bytes[c];
+    sum.class_launches[c] = cnt[c];
+    if (tot[c] > tot[best]) best = c;
+  }
+  sum.dominant_kernel_id = (uint32_t)best;
+  sum.dominant_kernel_ms = tot[best];
+  sum.dominant_kernel_bytes = bytes[best];
+  sum.dominant_kernel_launches = cnt[best];
+  if (stats_sum) *stats_sum = sum;
   return PPRHIP_OK;
 }
 
@@ -1598,3 +2187,56 @@ int pprhip_index_arrays(const pprhip_index_t* ix, const uint64_t** offsets, cons
 void pprhip_index_destroy(pprhip_index_t* ix) { delete ix; }
 
 }  // extern "C"
+
+// development hook (not part of include/pprhip.h): times the batched dense edge sweep on random
+// contributions and checks it against host row sums on small graphs
+extern "C" int pprhip_dev_dense_b8(pprhip_graph_t* g, int reps, double* ms_out, double* maxdiff_out) {
+  const size_t n = g->n, nnz = g->n_nz;
+  std::vector<double> h(n * 8);
+  uint64_t x = 88172645463325252ull;
+  for (auto& v : h) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    v = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+  }
+  double *c8 = nullptr, *acc8 = nullptr;
+  PPRHIP_TRY(alloc_dev((void**)&c8, sizeof(double) * n * 8));
+  PPRHIP_TRY(alloc_dev((void**)&acc8, sizeof(double) * (nnz + 1) * 8));
+  PPRHIP_CHECK_HIP(hipMemcpy(c8, h.data(), sizeof(double) * n * 8, hipMemcpyHostToDevice));
+  PPRHIP_CHECK_HIP(hipMemset(acc8, 0, sizeof(double) * (nnz + 1) * 8));
+  PPRHIP_TRY(launch_dense_edges_b8(g, c8, acc8));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  double maxdiff = -1.0;
+  if (g->m <= (1ull << 24)) {
+    std::vector<double> got(nnz * 8);
+    std::vector<int32_t> ci(g->m);
+    PPRHIP_CHECK_HIP(hipMemcpy(got.data(), acc8, sizeof(double) * nnz * 8, hipMemcpyDeviceToHost));
+    PPRHIP_CHECK_HIP(hipMemcpy(ci.data(), g->in_ci, sizeof(int32_t) * g->m, hipMemcpyDeviceToHost));
+    maxdiff = 0.0;
+    size_t j = 0;
+    for (size_t v = 0; v < n; ++v) {
+      if (g->h_in_rp[v + 1] == g->h_in_rp[v]) continue;
+      for (int s = 0; s < 8; ++s) {
+        double sum = 0.0;
+        for (uint32_t e = g->h_in_rp[v]; e < g->h_in_rp[v + 1]; ++e) sum += h[(size_t)ci[e] * 8 + s];
+        maxdiff = std::max(maxdiff, std::fabs(sum - got[j * 8 + s]) / std::max(1.0, std::fabs(sum)));
+      }
+      ++j;
+    }
+  }
+  hipEvent_t a, b;
+  PPRHIP_CHECK_HIP(hipEventCreate(&a));
+  PPRHIP_CHECK_HIP(hipEventCreate(&b));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(acc8, 0, sizeof(double) * (nnz + 1) * 8, g->stream));
+  PPRHIP_CHECK_HIP(hipEventRecord(a, g->stream));
+  for (int i = 0; i < reps; ++i) PPRHIP_TRY(launch_dense_edges_b8(g, c8, acc8));
+  PPRHIP_CHECK_HIP(hipEventRecord(b, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  float ms = 0.f;
+  PPRHIP_CHECK_HIP(hipEventElapsedTime(&ms, a, b));
+  *ms_out = (double)ms / reps;
+  *maxdiff_out = maxdiff;
+  (void)hipFree(c8);
+  (void)hipFree(acc8);
+  return PPRHIP_OK;
+}
+

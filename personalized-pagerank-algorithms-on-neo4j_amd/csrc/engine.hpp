@@ -30,6 +30,79 @@ struct PushArgs {
   int mode;
 };
 
+// Kernel-class timing with an event pool, resolved after the stream has drained.  Events are
+// created on demand and reused across calls.
+struct KernelTimer {
+  std::vector<hipEvent_t> ev;
+  struct Rec { int cls; size_t i; uint64_t bytes; };
+  std::vector<Rec> recs;
+  size_t used = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t next() {
+    if (used == ev.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      ev.push_back(e);
+    }
+    return ev[used++];
+  }
+  void begin(int cls, uint64_t bytes) {
+    hipEvent_t a = next();
+    if (!a) return;
+    recs.push_back({cls, used - 1, bytes});
+    (void)hipEventRecord(a, stream);
+  }
+  void end() {
+    hipEvent_t b = next();
+    if (b) (void)hipEventRecord(b, stream);
+  }
+  void reset() {
+    used = 0;
+    recs.clear();
+  }
+  // adds the recorded intervals to per-class totals (call after the stream has been synchronized)
+  void resolve(double tot[8], uint64_t bytes[8], uint32_t cnt[8]) const {
+    for (const Rec& r : recs) {
+      if (r.i + 1 >= used) continue;
+      float f = 0.f;
+      if (hipEventElapsedTime(&f, ev[r.i], ev[r.i + 1]) != hipSuccess) continue;
+      tot[r.cls] += (double)f;
+      bytes[r.cls] += r.bytes;
+      cnt[r.cls]++;
+    }
+  }
+  void destroy() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    ev.clear();
+    reset();
+  }
+};
+
+struct BatchSync;  // engine.cpp: rendezvous of the batch workers at dense levels
+
+// Contribution vector of a dense level: a plain array for a single query (stride 1), or one
+// column of the interleaved c8[v][slot] array that kBatch concurrent queries share.
+constexpr int kBatch = 8;
+struct CView {
+  double* p;
+  uint32_t stride, off;
+  __host__ __device__ double& at(uint32_t v) const { return p[(size_t)v * stride + off]; }
+};
+
+// Per-slot arguments of a batched dense level, read by the kernels from device memory.
+struct SlotArgs {
+  double* res;
+  double* reserve;
+  uint8_t* flags;
+  DevCounters* ctr;
+  double alpha, rmax, min_rmax;
+  int32_t src;
+  int32_t active;  // the slot takes part in this sweep
+  int32_t mode;
+  int32_t dead_slot, out_slot;
+  int32_t pad;
+};
+
 }  // namespace pprhip
 
 struct pprhip_graph {
@@ -55,6 +128,24 @@ struct pprhip_graph {
   int32_t* nz_rows = nullptr;  // rows with in-degree > 0, ascending
   uint32_t n_nz = 0;
   double* acc_nz = nullptr;  // per non-empty row: sum of this level's contributions
+  // batched queries: kBatch workspaces ("slots") borrow this handle's CSR and stream; their dense
+  // levels run as one sweep over the interleaved contribution array c8[v][slot]
+  pprhip_graph* parent = nullptr;  // set on a slot
+  int slot_index = -1;
+  pprhip::BatchSync* sync = nullptr;  // set on a slot while a batched call is running
+  hipStream_t own_stream = nullptr;   // slot: the stream its worker thread uses
+  pprhip::KernelTimer ktimer;         // slot: its worker's kernel-class timer; graph: the sweeps' timer
+  std::vector<pprhip_graph*> slots;
+  double* c8[2] = {nullptr, nullptr};
+  int c8cur = 0;
+  double* acc8 = nullptr;      // [n_nz][kBatch] row sums
+  int32_t* zin_rows = nullptr;  // rows without in-edges
+  uint32_t n_zin = 0;
+  pprhip::SlotArgs* d_slot_args = nullptr;
+  pprhip::SlotArgs* h_slot_args = nullptr;  // pinned
+  unsigned long long* blk_pack8 = nullptr;  // [kBatch][kApplyBlocks8]
+  double* blk_dead8 = nullptr;
+  uint32_t* blk_ndead8 = nullptr;
   // per-query state
   double *residue = nullptr, *reserve = nullptr, *est = nullptr;
   double* cdense[2] = {nullptr, nullptr};
@@ -97,6 +188,9 @@ int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int leve
 int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
                        unsigned long long dense_thresh, int dead_slot);
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot);
+int launch_dense_edges_b8(pprhip_graph* g, const double* c8, double* acc8);
+constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply kernel (per-slot partials each)
+int launch_dense_level_b8(pprhip_graph* parent);  // slot arguments already staged in parent->h_slot_args
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);
 int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot);
 int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter);

@@ -51,7 +51,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restrict__ F,
                                                          const uint32_t* __restrict__ out_rp,
                                                          double* __restrict__ res, double* __restrict__ reserve,
-                                                         double* __restrict__ cF, double* __restrict__ c_dense,
+                                                         double* __restrict__ cF, CView c_dense,
                                                          DevCounters* ctr, int level, unsigned long long dense_thresh,
                                                          int dead_slot, PushArgs a) {
   __shared__ double s_red[4];
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restric
         c = ((1.0 - a.alpha) * rc) / (double)d;  // :117
       }
     }
-    if (c_dense)
-      c_dense[v] = c;
+    if (c_dense.p)
+      c_dense.at((uint32_t)v) = c;
     else
       cF[i] = c;
   }
@@ -414,6 +414,168 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// batched dense level: kBatch queries per sweep
+// ------------------------------------------------------------------------------------------------
+// A gather costs one 64-byte request whether 8 or 64 of its bytes are used.  The batched sweep keeps
+// the contributions of kBatch = 8 concurrent queries interleaved, c8[v][slot], so the line a gather
+// brings in carries that vertex's contribution for every query in flight, and the column indices
+// are read once for all of them.  Eight lanes (one per slot) share an edge: a wave still owns a
+// 512-edge chunk, lane group g = lane / 8 walks edges [64g, 64g + 64) of it in order.  The group's
+// column indices sit in its own 8 lanes' registers (two coalesced 16-byte loads per lane) and are
+// broadcast inside the group with ds_swizzle; row sums close inside the group where a row starts
+// and ends there, cross groups with a 3-step segmented scan, and only rows crossing the chunk
+// boundary use atomics.
+constexpr int kHotMaxB = 2048;  // 2048 vertices x 64 B = 128 KB of LDS
+
+template <int K>
+__device__ __forceinline__ int group8_bcast(int x) {  // value of lane K of the caller's 8-lane group
+  return __builtin_amdgcn_ds_swizzle(x, 0x18 | (K << 5));
+}
+
+struct ChunkRegsB {
+  int4 ia, ib;
+  unsigned long long mask;  // row-start bits of the lane group's 64 edges
+};
+
+__device__ __forceinline__ ChunkRegsB load_chunk_b(const int32_t* __restrict__ in_ci,
+                                                   const unsigned long long* __restrict__ flags64, uint32_t c,
+                                                   int lane) {
+  const unsigned long long e0 = (unsigned long long)c * kChunkEdges + 8ull * lane;
+  const int4* p = reinterpret_cast<const int4*>(in_ci + e0);
+  ChunkRegsB r;
+  r.ia = p[0];
+  r.ib = p[1];
+  r.mask = flags64[(size_t)c * 8 + (lane >> 3)];
+  return r;
+}
+
+template <bool HOT, int JB>
+__device__ __forceinline__ void edges_b8_block(const ChunkRegsB& cur, const double* __restrict__ c8,
+                                               const double* s_hot, uint32_t n_hot, int s, bool tail,
+                                               unsigned long long e_first, unsigned long long m, uint32_t before,
+                                               double* __restrict__ acc8, double& seg, double& first_seg, uint32_t& k) {
+  const int32_t own[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
+  uint32_t v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (uint32_t)group8_bcast<JB>(own[i]);
+  double val[8];
+  if (HOT) {
+    double gl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gl[i] = c8[(size_t)(v[i] < n_hot ? 0u : v[i]) * kBatch + s];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double hv = s_hot[(v[i] < n_hot ? v[i] : 0u) * kBatch + s];
+      val[i] = v[i] < n_hot ? hv : gl[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) val[i] = c8[(size_t)v[i] * kBatch + s];
+  }
+  if (tail) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (e_first + JB * 8 + i >= m) val[i] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if ((cur.mask >> (JB * 8 + i)) & 1ull) {
+      if (k == 0)
+        first_seg = seg;  // closes the row carried in from earlier groups
+      else
+        acc8[(size_t)(before + k - 1) * kBatch + s] = seg;  // a row that starts and ends inside this group
+      seg = 0.0;
+      ++k;
+    }
+    seg += val[i];
+  }
+}
+
+template <bool HOT>
+__global__ __launch_bounds__(1024) void k_dense_edges_b8(const int32_t* __restrict__ in_ci,
+                                                          const unsigned long long* __restrict__ flags64,
+                                                          const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
+                                                          unsigned long long m, const double* __restrict__ c8,
+                                                          double* __restrict__ acc8, uint32_t n_hot) {
+  extern __shared__ __attribute__((aligned(16))) double s_hot[];
+  const int lane = lane_id();
+  const int grp = lane >> 3, s = lane & 7;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  const uint32_t stride = gridDim.x * waves_per_block;
+  uint32_t c = blockIdx.x * waves_per_block + (uint32_t)wave_id();
+  ChunkRegsB cur;
+  if (c < n_chunks) cur = load_chunk_b(in_ci, flags64, c, lane);
+  if (HOT) {
+    double t[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t i = threadIdx.x + j * 1024u;
+      t[j] = i < n_hot * kBatch ? c8[i] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t i = threadIdx.x + j * 1024u;
+      if (i < n_hot * kBatch) s_hot[i] = t[j];
+    }
+    __syncthreads();
+  }
+  for (; c < n_chunks; c += stride) {
+    ChunkRegsB nxt = cur;
+    const uint32_t cn = c + stride;
+    if (cn < n_chunks) nxt = load_chunk_b(in_ci, flags64, cn, lane);
+    const uint32_t cs = chunk_starts[c];
+    const uint32_t pc = (uint32_t)__popcll(cur.mask);
+    const uint32_t incl = wave_incl_scan_u32_dpp(s == 0 ? pc : 0u);  // row starts up to and including this group
+    const uint32_t before = cs + incl - pc;
+    const unsigned long long e_first = (unsigned long long)c * kChunkEdges + 64ull * grp;
+    const bool tail = (unsigned long long)(c + 1) * kChunkEdges > m;
+    double seg = 0.0, first_seg = 0.0;
+    uint32_t k = 0;
+    edges_b8_block<HOT, 0>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
+    edges_b8_block<HOT, 1>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
+    edges_b8_block<HOT, 2>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
+    edges_b8_block<HOT, 3>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
+    edges_b8_block<HOT, 4>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
+    edges_b8_block<HOT, 5>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
+    edges_b8_block<HOT, 6>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
+    edges_b8_block<HOT, 7>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
+    // segmented scan over the 8 groups: S(g) = tail(g) + (group g holds a row start ? 0 : S(g-1))
+    const bool h = k != 0;
+    double S = seg;
+    int F = h ? 1 : 0;
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) {
+      const double ps = __shfl_up(S, d);
+      const int pf = __shfl_up(F, d);
+      if (lane >= d) {
+        if (!F) S += ps;
+        F |= pf;
+      }
+    }
+    double carry = __shfl_up(S, 8);
+    if (lane < 8) carry = 0.0;
+    const unsigned long long hmask = __ballot(h);
+    if (h) {
+      const bool nonempty = grp > 0 || (cur.mask & 1ull) == 0;
+      if (nonempty && before > 0) {
+        const double total = carry + first_seg;
+        const bool started_here = (hmask & ((1ull << (grp * 8)) - 1ull)) != 0;
+        double* dst = &acc8[(size_t)(before - 1) * kBatch + s];
+        if (started_here)
+          *dst = total;
+        else
+          atomic_add_noret(dst, total);  // began in an earlier chunk
+      }
+    }
+    if (grp == 7) {  // the row still open at the end of the chunk
+      const uint32_t starts = cs + incl;
+      if (starts > 0 && S != 0.0) atomic_add_noret(&acc8[(size_t)(starts - 1) * kBatch + s], S);
+    }
+    cur = nxt;
+  }
+}
+
 // k_dense_apply: one thread per non-empty row (plus one for a source without in-edges, which
 // only ever receives returned dead-end mass): lands the row sum, detects the threshold crossing
 // and prepares the row for the next level in place.
@@ -483,6 +645,120 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
     blk_pack[blockIdx.x] = ps;
     blk_dead[blockIdx.x] = ds;
     blk_ndead[blockIdx.x] = (uint32_t)nd;
+  }
+}
+
+// k_dense_apply_b8: the batched form of k_dense_apply.  One thread per (row, slot), rows without
+// in-edges included (their contribution for the next level is written as 0, or holds the source's
+// returned dead-end mass), so the sweep rewrites every entry of c8_next and a column a slot has
+// left stays all-zero.  Slot arguments come from device memory; counters go to per-slot partials.
+__global__ __launch_bounds__(256) void k_dense_apply_b8(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
+                                                         const int32_t* __restrict__ zin_rows, uint32_t n_zin,
+                                                         double* __restrict__ acc8,
+                                                         const uint32_t* __restrict__ out_rp,
+                                                         double* __restrict__ c8_next,
+                                                         const SlotArgs* __restrict__ slots,
+                                                         unsigned long long* __restrict__ blk_pack8,
+                                                         double* __restrict__ blk_dead8,
+                                                         uint32_t* __restrict__ blk_ndead8) {
+  __shared__ unsigned long long s_pack[256];
+  __shared__ double s_dead[256];
+  __shared__ uint32_t s_nd[256];
+  const int tid = threadIdx.x;
+  const int s = tid & 7;
+  const SlotArgs a = slots[s];
+  const unsigned long long total = (unsigned long long)(n_nz + n_zin) * kBatch;
+  double dead_next = 0.0;
+  unsigned long long pack = 0;
+  uint32_t ndead = 0;
+  for (unsigned long long t = (unsigned long long)blockIdx.x * 256u + tid; t < total;
+       t += (unsigned long long)gridDim.x * 256u) {
+    const uint32_t j = (uint32_t)(t >> 3);
+    int32_t u;
+    double acc = 0.0;
+    if (j < n_nz) {
+      u = nz_rows[j];
+      acc = acc8[t];
+      if (acc != 0.0) acc8[t] = 0.0;
+    } else {
+      u = zin_rows[j - n_nz];
+    }
+    double cn = 0.0;
+    if (a.active) {
+      if (u == a.src) {
+        const double dd = a.ctr->dead[a.dead_slot];
+        if (dd > 0.0) {
+          acc += dd;
+          a.ctr->dead[a.dead_slot] = 0.0;
+        }
+      }
+      if (acc > 0.0) {
+        const uint32_t d = out_rp[u + 1] - out_rp[u];
+        const double old = a.res[u];
+        const double nw = old + acc;
+        const bool crossing = !active_fwd(old, d, a.rmax) && active_fwd(nw, d, a.rmax);
+        if (a.mode == kFwdTopk && active_fwd(nw, d, a.min_rmax)) a.flags[u] = 1;
+        if (crossing) {
+          a.reserve[u] = a.reserve[u] + nw * a.alpha;
+          a.res[u] = 0.0;
+          if (d == 0) {
+            dead_next += nw * (1.0 - a.alpha);
+            ndead++;
+          } else {
+            cn = ((1.0 - a.alpha) * nw) / (double)d;
+          }
+          pack += (1ull << kPackShift) | (unsigned long long)d;
+        } else {
+          a.res[u] = nw;
+        }
+      }
+    }
+    c8_next[(size_t)u * kBatch + s] = cn;
+  }
+  s_pack[tid] = pack;
+  s_dead[tid] = dead_next;
+  s_nd[tid] = ndead;
+  __syncthreads();
+  if (tid < kBatch) {
+    unsigned long long ps = 0;
+    double ds = 0.0;
+    uint32_t nd = 0;
+    for (int r = 0; r < 32; ++r) {
+      ps += s_pack[r * kBatch + tid];
+      ds += s_dead[r * kBatch + tid];
+      nd += s_nd[r * kBatch + tid];
+    }
+    blk_pack8[(size_t)tid * gridDim.x + blockIdx.x] = ps;
+    blk_dead8[(size_t)tid * gridDim.x + blockIdx.x] = ds;
+    blk_ndead8[(size_t)tid * gridDim.x + blockIdx.x] = nd;
+  }
+}
+
+// workgroup s sums slot s's partials into that slot's counters
+__global__ __launch_bounds__(1024) void k_dense_reduce_b8(const unsigned long long* __restrict__ blk_pack8,
+                                                           const double* __restrict__ blk_dead8,
+                                                           const uint32_t* __restrict__ blk_ndead8, uint32_t n_blocks,
+                                                           const SlotArgs* __restrict__ slots) {
+  __shared__ double s_red[16];
+  __shared__ unsigned long long s_red2[16];
+  const SlotArgs a = slots[blockIdx.x];
+  if (!a.active) return;
+  unsigned long long pack = 0, ndead = 0;
+  double dead = 0.0;
+  for (uint32_t i = threadIdx.x; i < n_blocks; i += blockDim.x) {
+    pack += blk_pack8[(size_t)blockIdx.x * n_blocks + i];
+    dead += blk_dead8[(size_t)blockIdx.x * n_blocks + i];
+    ndead += blk_ndead8[(size_t)blockIdx.x * n_blocks + i];
+  }
+  const unsigned long long ps = block_sum_u64(pack, s_red2);
+  const unsigned long long nd = block_sum_u64(ndead, s_red2);
+  const double ds = block_sum_f64(dead, s_red);
+  if (threadIdx.x == 0) {
+    a.ctr->packed[a.out_slot] = ps;
+    if (nd) {
+      a.ctr->dead[a.dead_slot ^ 1] = a.ctr->dead[a.dead_slot ^ 1] + ds;
+      a.ctr->dead_pops += nd;
+    }
   }
 }
 
@@ -580,8 +856,7 @@ __global__ __launch_bounds__(256) void k_seed_list(uint32_t n, const double* __r
 template <int KIND>
 __global__ __launch_bounds__(256) void k_seed_dense(uint32_t n, double* __restrict__ res, double* __restrict__ reserve,
                                                      const uint32_t* __restrict__ out_rp, uint8_t* __restrict__ flags,
-                                                     double* __restrict__ c_dense,
-                                                     unsigned long long* __restrict__ blk_pack,
+                                                     CView c_dense, unsigned long long* __restrict__ blk_pack,
                                                      double* __restrict__ blk_dead, uint32_t* __restrict__ blk_ndead,
                                                      PushArgs a) {
   __shared__ double s_red[4];
@@ -605,7 +880,7 @@ __global__ __launch_bounds__(256) void k_seed_dense(uint32_t n, double* __restri
       }
       pack += (1ull << kPackShift) | (unsigned long long)d;
     }
-    c_dense[v] = c;
+    c_dense.at(v) = c;
   }
   const double ds = block_sum_f64(dead, s_red);
   const unsigned long long ps = block_sum_u64(pack, s_red2);
@@ -618,7 +893,7 @@ __global__ __launch_bounds__(256) void k_seed_dense(uint32_t n, double* __restri
 }
 
 // dense-prepared state -> sparse-prepared state: list every node holding a contribution
-__global__ __launch_bounds__(256) void k_compact_prepared(uint32_t n, const double* __restrict__ c_dense,
+__global__ __launch_bounds__(256) void k_compact_prepared(uint32_t n, CView c_dense, bool clear,
                                                            const uint32_t* __restrict__ trp, int32_t* __restrict__ Fn,
                                                            uint32_t* __restrict__ eoffn, double* __restrict__ cF,
                                                            unsigned long long* counter) {
@@ -629,14 +904,15 @@ __global__ __launch_bounds__(256) void k_compact_prepared(uint32_t n, const doub
   block_range_compact(
       lo, hi, counter,
       [&](uint32_t v, unsigned long long* w) {
-        if (!(c_dense[v] > 0.0)) return false;
+        if (!(c_dense.at(v) > 0.0)) return false;
         *w = trp[v + 1] - trp[v];
         return true;
       },
       [&](uint32_t v, uint32_t pos, unsigned long long eo, unsigned long long) {
         Fn[pos] = (int32_t)v;
         eoffn[pos] = (uint32_t)eo;
-        cF[pos] = c_dense[v];
+        cF[pos] = c_dense.at(v);
+        if (clear) c_dense.at(v) = 0.0;  // a slot leaving the dense shape hands back an all-zero column
       });
 }
 
@@ -677,6 +953,12 @@ static inline uint32_t grid_for(uint64_t work, uint32_t per_block, uint32_t cap)
   return (uint32_t)b;
 }
 
+// contribution buffer `cbuf` of a handle: its own array, or its column of the parent's c8 array
+static inline CView cview(pprhip_graph* g, int cbuf) {
+  if (g->parent) return CView{g->parent->c8[cbuf], (uint32_t)kBatch, (uint32_t)g->slot_index};
+  return CView{g->cdense[cbuf], 1u, 0u};
+}
+
 #define DISPATCH_MODE(MODEVAR, ...)                                       \
   switch (MODEVAR) {                                                      \
     case kFwdWhole: { constexpr int M = kFwdWhole; __VA_ARGS__; } break;  \
@@ -688,7 +970,7 @@ static inline uint32_t grid_for(uint64_t work, uint32_t per_block, uint32_t cap)
 int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t nf_upper,
                           unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot) {
   const uint32_t grid = grid_for(nf_upper, 256, 512);
-  double* cd = scatter_dense ? g->cdense[cbuf] : nullptr;
+  const CView cd = scatter_dense ? cview(g, cbuf) : CView{nullptr, 1, 0};
   DISPATCH_MODE(a.mode, k_sparse_prepare<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
                             g->F[fbuf], g->out_rp, g->residue, g->reserve, g->cF, cd, g->ctr, level, dense_thresh,
                             dead_slot, a));
@@ -749,10 +1031,52 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   return PPRHIP_OK;
 }
 
+int launch_dense_edges_b8(pprhip_graph* g, const double* c8, double* acc8) {
+  if (!g->n_chunks) return PPRHIP_OK;
+  const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMaxB) : 0u;
+  const uint32_t want = (g->n_chunks + 15) / 16;
+  const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(g->start_flags);
+  if (n_hot) {
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+      PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b8<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(double) * kHotMaxB * kBatch)));
+      lds_opt_in = true;
+    }
+    const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
+    k_dense_edges_b8<true><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * kBatch, g->stream>>>(
+        g->in_ci, flags64, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, c8, acc8, n_hot);
+  } else {
+    const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
+    k_dense_edges_b8<false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
+        g->in_ci, flags64, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, c8, acc8, 0u);
+  }
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+int launch_dense_level_b8(pprhip_graph* P) {
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(P->d_slot_args, P->h_slot_args, sizeof(SlotArgs) * kBatch, hipMemcpyHostToDevice,
+                                  P->stream));
+  PPRHIP_TRY(launch_dense_edges_b8(P, P->c8[P->c8cur], P->acc8));
+  const unsigned long long work = (unsigned long long)P->n * kBatch;
+  const uint32_t grid = grid_for(work, 256, kApplyBlocks8);
+  k_dense_apply_b8<<<dim3(grid), dim3(256), 0, P->stream>>>(P->nz_rows, P->n_nz, P->zin_rows, P->n_zin, P->acc8,
+                                                            P->out_rp, P->c8[P->c8cur ^ 1], P->d_slot_args,
+                                                            P->blk_pack8, P->blk_dead8, P->blk_ndead8);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  k_dense_reduce_b8<<<dim3(kBatch), dim3(1024), 0, P->stream>>>(P->blk_pack8, P->blk_dead8, P->blk_ndead8, grid,
+                                                                P->d_slot_args);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward) {
   const uint32_t grid = grid_for(g->n, 1024, 1024);
-  k_compact_prepared<<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->cdense[cbuf], backward ? g->in_rp : g->out_rp,
-                                                              g->F[out_fbuf], g->eoff[out_fbuf], g->cF, d_counter);
+  k_compact_prepared<<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, cview(g, cbuf), g->parent != nullptr,
+                                                              backward ? g->in_rp : g->out_rp, g->F[out_fbuf],
+                                                              g->eoff[out_fbuf], g->cF, d_counter);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -791,11 +1115,11 @@ int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbu
   const uint32_t grid = grid_for(g->n, 256 * 8, 1024);
   if (seed_kind == 0)
     k_seed_dense<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->reserve, g->out_rp, g->flags,
-                                                             g->cdense[cbuf], g->blk_pack, g->blk_dead,
+                                                             cview(g, cbuf), g->blk_pack, g->blk_dead,
                                                              g->blk_ndead, a);
   else
     k_seed_dense<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->reserve, g->out_rp, g->flags,
-                                                             g->cdense[cbuf], g->blk_pack, g->blk_dead,
+                                                             cview(g, cbuf), g->blk_pack, g->blk_dead,
                                                              g->blk_ndead, a);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return reduce_partials(g, grid, out_slot, dead_slot, true);

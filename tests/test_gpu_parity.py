@@ -160,6 +160,59 @@ def test_fora_auto_rounds_match_twin(pkg, orc, rmat12, dev_rmat12):
     assert_close(est, ref, TOL_MC, "fora auto")
 
 
+# ------------------------------------------------------------------ batched FORA (config #4 shape, a5 per query)
+@pytest.mark.parametrize("dense_frac", [0.05, 1e-9, 1e9])
+def test_fora_batch_got(pkg, orc, got, dev_got, dense_frac):
+    """Queries in flight together give what each gives alone: against the twin and against the single-query
+    entry point, for every level shape (the batched dense sweep serves up to 8 queries at once)."""
+    og = to_oracle(orc, got)
+    t = pkg.tuning_default()
+    t.dense_frac = dense_frac
+    dev_got.set_tuning(t)
+    try:
+        srcs = [0, 17, 42, 106, 90, 3] + sources(got, 13, seed=19)      # 19 queries: more than two rounds of slots
+        for n_rounds in (1, 3, 0):
+            out, ids, vals, nsel, pq, st = dev_got.fora_batch_single_source(srcs, 0.5, ALPHA, seed=3, n_rounds=n_rounds,
+                                                                            k=10, fetch=True, per_query=True)
+            assert st.levels == sum(x.levels for x in pq)
+            for i, s in enumerate(srcs):
+                ref, sto = og.fora_whole(s, 0.5, ALPHA, seed=3, n_rounds=n_rounds, schedule=orc.SYNC)
+                assert pq[i].rounds == sto.rounds and pq[i].levels == sto.levels
+                assert pq[i].walks == sto.walks and pq[i].walk_steps == sto.walk_steps
+                assert_close(out[i], ref, TOL_MC, "batch src=%d" % s)
+                single, sts = dev_got.fora_single_source(s, 0.5, ALPHA, seed=3, n_rounds=n_rounds)
+                assert sts.walks == pq[i].walks and sts.dense_levels == pq[i].dense_levels
+                assert_close(out[i], single, TOL_PUSH, "batch vs single src=%d" % s)
+                cnt, oids, ovals = orc.topk(out[i], 10, cap=10)
+                assert nsel[i] == cnt
+                m = min(cnt, 10)
+                assert list(ids[i][:m]) == list(oids[:m]) and np.array_equal(vals[i][:m], ovals[:m])
+                assert np.all(ids[i][m:] == -1) and np.all(vals[i][m:] == 0.0)
+    finally:
+        dev_got.set_tuning(pkg.tuning_default())
+
+
+def test_fora_batch_rmat12(pkg, orc, rmat12, dev_rmat12):
+    og = to_oracle(orc, rmat12)
+    srcs = sources(rmat12, 11, seed=8)
+    out, _, _, _, pq, st = dev_rmat12.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, n_rounds=2, fetch=True,
+                                                               per_query=True)
+    assert st.dense_levels > 0 and st.class_launches[5] > 0      # the batched sweep ran
+    assert st.class_launches[5] < st.dense_levels                 # and served several queries per launch
+    for i, s in enumerate(srcs):
+        ref, sto = og.fora_whole(s, 0.5, ALPHA, seed=9, n_rounds=2, schedule=orc.SYNC)
+        assert pq[i].walks == sto.walks and pq[i].levels == sto.levels
+        assert_close(out[i], ref, TOL_MC, "batch src=%d" % s)
+    # an empty batch and a batch of dead-end sources only
+    out, _, _, _, _, st = dev_rmat12.fora_batch_single_source([], 0.5, ALPHA, seed=1, fetch=True)
+    assert out.shape == (0, rmat12.n) and st.levels == 0
+    dead = [int(v) for v in np.nonzero(np.diff(rmat12.out_rp) == 0)[0][:3]]
+    if dead:
+        out, _, _, _, _, st = dev_rmat12.fora_batch_single_source(dead, 0.5, ALPHA, seed=1, fetch=True)
+        for i, s in enumerate(dead):
+            assert out[i][s] == 1.0 and out[i].sum() == 1.0
+
+
 # ------------------------------------------------------------------ FORA top-k (a6, a7)
 @pytest.mark.parametrize("k", [1, 10, 50, 200])
 def test_fora_topk_got(pkg, orc, got, dev_got, k):
