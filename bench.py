@@ -7,7 +7,7 @@ Workload (N = 1): R-MAT scale 22 (n = 4 194 304, m = 67 108 864, generator seed 
 FORA with alpha = 0.15, eps = 0.5; a *step* is one batch of `--queries-per-step` sources drawn
 uniformly from [0, n) with seed 2 (as Gen_Util.getQueryNodes does, so dead-end sources, which
 short-circuit, are in the mix), handed to pprhip_fora_batch_single_source: the queries are
-independent single-source computations, 8 of them in flight at a time, and every query's top-32 is
+independent single-source computations, 16 of them in flight at a time, and every query's top-32 is
 selected on the device.  The graph is lifted into HBM once before the timed region; the PPR
 vectors stay in HBM.  `value` = queries / second over all ranks.  (`--mode single` runs the same
 queries one after another through pprhip_fora_single_source.)
@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=int, default=22)
-    ap.add_argument("--queries-per-step", type=int, default=64)
+    ap.add_argument("--queries-per-step", type=int, default=128)
     ap.add_argument("--mode", choices=["batch", "single"], default="batch")
     ap.add_argument("--rounds", type=int, default=0, help="FORA threshold rounds (0 = cost model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,7 +85,7 @@ def main():
     g = pkg.Graph(host, device=local_rank)
     t_lift = time.time() - t0
     conf = pkg.conf_whole_graph(host.n, host.m, ALPHA)
-    tuning = pkg.tuning_default()
+    tuning = pkg.tuning_batch() if args.mode == "batch" else pkg.tuning_default()
     for kv in filter(None, args.tuning.split(",")):
         key, val = kv.split("=")
         setattr(tuning, key, type(getattr(tuning, key))(float(val)))
@@ -201,7 +201,7 @@ def main():
                                    "sources per step per GPU (seed 2; dead-end sources included)"
                                    % (args.scale, host.n, host.m, q),
                        "alpha": ALPHA, "eps": EPS, "queries_per_step": q, "rounds": args.rounds or "cost-model",
-                       "mode": "8 queries in flight (pprhip_fora_batch_single_source), top-%d per query" % TOPK
+                       "mode": "16 queries in flight (pprhip_fora_batch_single_source), top-%d per query" % TOPK
                        if args.mode == "batch" else "one query at a time (pprhip_fora_single_source)",
                        "sharding": "replicated CSR, sources sharded by rank, top-%d gather to rank 0" % TOPK
                        if world > 1 else "single GPU"},

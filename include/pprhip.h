@@ -89,7 +89,7 @@ typedef struct pprhip_stats {
 #define PPRHIP_KERNEL_WALK 3
 #define PPRHIP_KERNEL_BACKWARD_BATCH 4
 #define PPRHIP_KERNEL_DENSE_PULL_BATCH 5 /* one dense level for up to PPRHIP_BATCH queries */
-#define PPRHIP_BATCH 8                   /* queries in flight in pprhip_fora_batch_single_source */
+#define PPRHIP_BATCH 16                  /* queries in flight in pprhip_fora_batch_single_source */
 
 /* Engine tuning: the deterministic replacement of the reference's wall-clock push/walk balance
  * (Fora_Whole_Graph.java:35,75-79,93-103) and the sparse/dense switch.  Zero means "default". */
@@ -122,6 +122,9 @@ const char* pprhip_last_error(void);
 int pprhip_version(void);
 int pprhip_device_count(int* count_out);
 void pprhip_tuning_default(pprhip_tuning_t* t);
+/* Cost-model constants for pprhip_fora_batch_single_source: a dense level costs a query 1/PPRHIP_BATCH
+ * of a sweep, so the model values it lower and lets levels go dense earlier. */
+void pprhip_tuning_batch(pprhip_tuning_t* t);
 
 /* ---------------------------------------------------------------- parameter derivation (a10) */
 /* Algo_Conf.set_conf_fora_whole_graph (Algo_Conf.java:45-53): delta = pfail = 1/n, rsum = 1. */
@@ -221,7 +224,7 @@ int pprhip_monte_carlo(pprhip_graph_t* g, int32_t src, double eps, const pprhip_
  * computeWholeGraphPPR), up to PPRHIP_BATCH of them in flight on this GPU.  Each query runs the
  * algorithm of pprhip_fora_single_source unchanged (same levels, thresholds, round count and, for
  * the same seed, the same walks: results agree up to the order of fp64 additions); dense levels of
- * concurrent queries share one sweep over the in-CSR, whose gathers fetch one 64-byte line per
+ * concurrent queries share one sweep over the in-CSR, whose gathers fetch one 128-byte line per
  * vertex holding the contributions of all queries in flight.
  * reserve_out: q*n doubles (query-major) or NULL.  k > 0 additionally selects each query's top-k by
  * Algo_Util.kth_ppr's rule into ids_out/vals_out (q*k, rows padded with id -1 / value 0) and

@@ -18,7 +18,7 @@ OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_IO, ERR_STATE = -1, -2, -3, -4, -5, -6
 
 KERNEL_NAMES = {0: "none", 1: "dense_pull", 2: "sparse_push", 3: "walk", 4: "backward_batch", 5: "dense_pull_batch"}
-BATCH = 8  # PPRHIP_BATCH: queries in flight in fora_batch_single_source
+BATCH = 16  # PPRHIP_BATCH: queries in flight in fora_batch_single_source
 
 
 class PprhipError(RuntimeError):
@@ -71,7 +71,7 @@ EXPORTS = [
     "pprhip_all_pair_backward", "pprhip_index_merge", "pprhip_index_info", "pprhip_index_arrays",
     "pprhip_index_write_dir", "pprhip_index_destroy", "pprhip_power_method", "pprhip_index_from_arrays",
     "pprhip_format_double", "pprhip_edgelist_from_neo4j_store", "pprhip_edgelist_build_csr",
-    "pprhip_fora_batch_single_source",
+    "pprhip_fora_batch_single_source", "pprhip_tuning_batch",
 ]
 
 _lib = None
@@ -92,6 +92,8 @@ def lib():
     L.pprhip_device_count.argtypes = [P(ci)]
     L.pprhip_tuning_default.argtypes = [P(Tuning)]
     L.pprhip_tuning_default.restype = None
+    L.pprhip_tuning_batch.argtypes = [P(Tuning)]
+    L.pprhip_tuning_batch.restype = None
     L.pprhip_conf_fora_whole_graph.argtypes = [u32, u64, dbl, P(ForaConf)]
     L.pprhip_conf_fora_topk.argtypes = [u32, u64, ci, dbl, P(ForaConf)]
     L.pprhip_fora_whole_params.argtypes = [P(ForaConf), dbl, P(dbl), P(dbl)]
@@ -266,6 +268,12 @@ def fora_topk_params(conf, eps, delta):
 def tuning_default():
     t = Tuning()
     lib().pprhip_tuning_default(C.byref(t))
+    return t
+
+
+def tuning_batch():
+    t = Tuning()
+    lib().pprhip_tuning_batch(C.byref(t))
     return t
 
 

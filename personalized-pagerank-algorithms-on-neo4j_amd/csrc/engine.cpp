@@ -35,8 +35,8 @@ struct BatchSync {
   ForaRun* runs = nullptr;
   int n_wait = 0, n_hold = 0, n_workers = 0;
   bool sweeping = false;
-  bool waitflag[kBatch] = {false, false, false, false, false, false, false, false};
-  bool hold[kBatch] = {false, false, false, false, false, false, false, false};
+  bool waitflag[kBatch] = {};
+  bool hold[kBatch] = {};
   int err = 0;
   std::string errmsg;
   void release(int s);  // the slot stops holding (no-op when it does not)
@@ -316,6 +316,8 @@ int ensure_batch(pprhip_graph* P) {
   }
   PPRHIP_TRY(alloc_dev((void**)&P->acc8, sizeof(double) * ((size_t)P->n_nz + 1) * kBatch));
   PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * ((size_t)P->n_nz + 1) * kBatch, P->stream));
+  PPRHIP_TRY(alloc_dev((void**)&P->prep_bits, sizeof(unsigned long long) * kBatch * (n / 64 + 2)));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(P->prep_bits, 0, sizeof(unsigned long long) * kBatch * (n / 64 + 2), P->stream));
   PPRHIP_TRY(alloc_dev((void**)&P->d_slot_args, sizeof(SlotArgs) * kBatch));
   if (hipHostMalloc((void**)&P->h_slot_args, sizeof(SlotArgs) * kBatch, hipHostMallocDefault) != hipSuccess) {
     set_error("hipHostMalloc failed");
@@ -370,7 +372,8 @@ void free_batch(pprhip_graph* P) {
   }
   P->ktimer.destroy();
   P->slots.clear();
-  void* ptrs[] = {P->c8[0], P->c8[1], P->acc8, P->d_slot_args, P->blk_pack8, P->blk_dead8, P->blk_ndead8};
+  void* ptrs[] = {P->c8[0], P->c8[1], P->acc8, P->prep_bits, P->d_slot_args, P->blk_pack8, P->blk_dead8, P->blk_ndead8};
+  P->prep_bits = nullptr;
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (P->h_slot_args) (void)hipHostFree(P->h_slot_args);
@@ -673,6 +676,15 @@ void pprhip_tuning_default(pprhip_tuning_t* t) {
   t->reserved = 0;
 }
 
+void pprhip_tuning_batch(pprhip_tuning_t* t) {
+  pprhip_tuning_default(t);
+  if (!t) return;
+  // fitted on R-MAT 22 with all slots busy: a sweep of 1.6 ms serves ~14.5 queries
+  t->c_dense_edge_ns = 0.002;
+  t->c_dense_node_ns = 0.003;
+  t->dense_frac = 0.01;
+}
+
 int pprhip_conf_fora_whole_graph(uint32_t n, uint64_t m, double alpha, pprhip_fora_conf_t* c) {
   if (!c || n == 0) {
     set_error("pprhip_conf_fora_whole_graph: bad arguments");
@@ -868,6 +880,15 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
       if (irp[v + 1] == irp[v]) zin.push_back((int32_t)v);
     G->n_zin = (uint32_t)zin.size();
     if ((rc = up((void**)&G->zin_rows, zin.data(), sizeof(int32_t) * zin.size()))) return fail(rc);
+    std::vector<unsigned long long> cross(((size_t)n + 63) / 64 + 1, 0ull);
+    for (size_t j = 0; j < nz_rows.size(); ++j) {
+      const uint32_t v = (uint32_t)nz_rows[j];
+      // summed with atomics (so cleared after every sweep): rows holding the last edge of a chunk
+      const uint32_t last = irp[v + 1] - 1;
+      if (irp[v] / kChunkPad != last / kChunkPad || (last + 1) % kChunkPad == 0 || (uint64_t)last + 1 == m)
+        cross[j >> 6] |= 1ull << (j & 63);
+    }
+    if ((rc = up((void**)&G->cross_bits, cross.data(), sizeof(unsigned long long) * cross.size()))) return fail(rc);
   }
   if ((rc = alloc_workspace(G))) return fail(rc);
   if (hipStreamSynchronize(G->stream) != hipSuccess) {
@@ -884,7 +905,7 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   free_batch(g);
   void* ptrs[] = {g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags,
-                  g->chunk_starts, g->nz_rows, g->zin_rows};
+                  g->chunk_starts, g->nz_rows, g->zin_rows, g->cross_bits};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   free_workspace(g);
@@ -1523,9 +1544,10 @@ void BatchSync::sweeper() {
 // Batched single-source FORA: up to kBatch queries in flight on kBatch workspaces of this handle.
 // Every query runs the single-query algorithm unchanged (same levels, same thresholds, same walks
 // for the same seed); whenever the queries in a push phase all stand at a dense level, one sweep of
-// the batched kernels serves them.  By default every slot has a worker thread and a stream of its
-// own, so sparse levels, walks and selections of different queries overlap on the GPU
-// (PPRHIP_BATCH_THREADS=0: all slots on the calling thread and one stream).
+// the batched kernels serves them.  All slots run on the calling thread and the handle's stream;
+// with PPRHIP_BATCH_THREADS=1 every slot gets a worker thread and a stream of its own, so sparse
+// levels, walks and selections of different queries overlap on the GPU (a few percent on R-MAT 22,
+// where the kernels already keep the memory system busy).
 int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
                                     const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
                                     double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
@@ -1539,7 +1561,7 @@ int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int 
   for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_single_source"));
   PPRHIP_TRY(ensure_batch(g));
   const char* env = getenv("PPRHIP_BATCH_THREADS");
-  const bool threaded = !(env && env[0] == '0') && q > 1;
+  const bool threaded = env && env[0] == '1' && q > 1;
   BatchJob J;
   J.P = g;
   J.srcs = srcs;
@@ -2190,35 +2212,37 @@ void pprhip_index_destroy(pprhip_index_t* ix) { delete ix; }
 
 // development hook (not part of include/pprhip.h): times the batched dense edge sweep on random
 // contributions and checks it against host row sums on small graphs
-extern "C" int pprhip_dev_dense_b8(pprhip_graph_t* g, int reps, double* ms_out, double* maxdiff_out) {
+extern "C" int pprhip_dev_dense_b8(pprhip_graph_t* g, int reps, int width, double* ms_out, double* maxdiff_out) {
+  const size_t W = (size_t)width;
+  auto launch = [&](const double* c, double* a) { return width == 32 ? launch_dense_edges_b32(g, c, a) : width == 16 ? launch_dense_edges_b16(g, c, a) : launch_dense_edges_b8(g, c, a); };
   const size_t n = g->n, nnz = g->n_nz;
-  std::vector<double> h(n * 8);
+  std::vector<double> h(n * W);
   uint64_t x = 88172645463325252ull;
   for (auto& v : h) {
     x ^= x << 13; x ^= x >> 7; x ^= x << 17;
     v = (double)(x >> 11) * (1.0 / 9007199254740992.0);
   }
   double *c8 = nullptr, *acc8 = nullptr;
-  PPRHIP_TRY(alloc_dev((void**)&c8, sizeof(double) * n * 8));
-  PPRHIP_TRY(alloc_dev((void**)&acc8, sizeof(double) * (nnz + 1) * 8));
-  PPRHIP_CHECK_HIP(hipMemcpy(c8, h.data(), sizeof(double) * n * 8, hipMemcpyHostToDevice));
-  PPRHIP_CHECK_HIP(hipMemset(acc8, 0, sizeof(double) * (nnz + 1) * 8));
-  PPRHIP_TRY(launch_dense_edges_b8(g, c8, acc8));
+  PPRHIP_TRY(alloc_dev((void**)&c8, sizeof(double) * n * W));
+  PPRHIP_TRY(alloc_dev((void**)&acc8, sizeof(double) * (nnz + 1) * W));
+  PPRHIP_CHECK_HIP(hipMemcpy(c8, h.data(), sizeof(double) * n * W, hipMemcpyHostToDevice));
+  PPRHIP_CHECK_HIP(hipMemset(acc8, 0, sizeof(double) * (nnz + 1) * W));
+  PPRHIP_TRY(launch(c8, acc8));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   double maxdiff = -1.0;
   if (g->m <= (1ull << 24)) {
-    std::vector<double> got(nnz * 8);
+    std::vector<double> got(nnz * W);
     std::vector<int32_t> ci(g->m);
-    PPRHIP_CHECK_HIP(hipMemcpy(got.data(), acc8, sizeof(double) * nnz * 8, hipMemcpyDeviceToHost));
+    PPRHIP_CHECK_HIP(hipMemcpy(got.data(), acc8, sizeof(double) * nnz * W, hipMemcpyDeviceToHost));
     PPRHIP_CHECK_HIP(hipMemcpy(ci.data(), g->in_ci, sizeof(int32_t) * g->m, hipMemcpyDeviceToHost));
     maxdiff = 0.0;
     size_t j = 0;
     for (size_t v = 0; v < n; ++v) {
       if (g->h_in_rp[v + 1] == g->h_in_rp[v]) continue;
-      for (int s = 0; s < 8; ++s) {
+      for (int s = 0; s < width; ++s) {
         double sum = 0.0;
-        for (uint32_t e = g->h_in_rp[v]; e < g->h_in_rp[v + 1]; ++e) sum += h[(size_t)ci[e] * 8 + s];
-        maxdiff = std::max(maxdiff, std::fabs(sum - got[j * 8 + s]) / std::max(1.0, std::fabs(sum)));
+        for (uint32_t e = g->h_in_rp[v]; e < g->h_in_rp[v + 1]; ++e) sum += h[(size_t)ci[e] * W + s];
+        maxdiff = std::max(maxdiff, std::fabs(sum - got[j * W + s]) / std::max(1.0, std::fabs(sum)));
       }
       ++j;
     }
@@ -2226,9 +2250,9 @@ extern "C" int pprhip_dev_dense_b8(pprhip_graph_t* g, int reps, double* ms_out, 
   hipEvent_t a, b;
   PPRHIP_CHECK_HIP(hipEventCreate(&a));
   PPRHIP_CHECK_HIP(hipEventCreate(&b));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(acc8, 0, sizeof(double) * (nnz + 1) * 8, g->stream));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(acc8, 0, sizeof(double) * (nnz + 1) * W, g->stream));
   PPRHIP_CHECK_HIP(hipEventRecord(a, g->stream));
-  for (int i = 0; i < reps; ++i) PPRHIP_TRY(launch_dense_edges_b8(g, c8, acc8));
+  for (int i = 0; i < reps; ++i) PPRHIP_TRY(launch(c8, acc8));
   PPRHIP_CHECK_HIP(hipEventRecord(b, g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   float ms = 0.f;

@@ -82,7 +82,7 @@ struct BatchSync;  // engine.cpp: rendezvous of the batch workers at dense level
 
 // Contribution vector of a dense level: a plain array for a single query (stride 1), or one
 // column of the interleaved c8[v][slot] array that kBatch concurrent queries share.
-constexpr int kBatch = 8;
+constexpr int kBatch = 16;
 struct CView {
   double* p;
   uint32_t stride, off;
@@ -140,6 +140,8 @@ struct pprhip_graph {
   int c8cur = 0;
   double* acc8 = nullptr;      // [n_nz][kBatch] row sums
   int32_t* zin_rows = nullptr;  // rows without in-edges
+  unsigned long long* cross_bits = nullptr;  // per row ordinal (non-empty rows first): row spans two 512-edge chunks
+  unsigned long long* prep_bits = nullptr;   // [kBatch][tiles]: rows holding a contribution after the last sweep
   uint32_t n_zin = 0;
   pprhip::SlotArgs* d_slot_args = nullptr;
   pprhip::SlotArgs* h_slot_args = nullptr;  // pinned
@@ -189,6 +191,8 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
                        unsigned long long dense_thresh, int dead_slot);
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot);
 int launch_dense_edges_b8(pprhip_graph* g, const double* c8, double* acc8);
+int launch_dense_edges_b16(pprhip_graph* g, const double* c16, double* acc16);
+int launch_dense_edges_b32(pprhip_graph* g, const double* c32, double* acc32);
 constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply kernel (per-slot partials each)
 int launch_dense_level_b8(pprhip_graph* parent);  // slot arguments already staged in parent->h_slot_args
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);

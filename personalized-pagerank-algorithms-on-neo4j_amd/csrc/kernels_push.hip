@@ -417,61 +417,68 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 // batched dense level: kBatch queries per sweep
 // ------------------------------------------------------------------------------------------------
-// A gather costs one 64-byte request whether 8 or 64 of its bytes are used.  The batched sweep keeps
-// the contributions of kBatch = 8 concurrent queries interleaved, c8[v][slot], so the line a gather
-// brings in carries that vertex's contribution for every query in flight, and the column indices
-// are read once for all of them.  Eight lanes (one per slot) share an edge: a wave still owns a
-// 512-edge chunk, lane group g = lane / 8 walks edges [64g, 64g + 64) of it in order.  The group's
-// column indices sit in its own 8 lanes' registers (two coalesced 16-byte loads per lane) and are
-// broadcast inside the group with ds_swizzle; row sums close inside the group where a row starts
-// and ends there, cross groups with a 3-step segmented scan, and only rows crossing the chunk
-// boundary use atomics.
-constexpr int kHotMaxB = 2048;  // 2048 vertices x 64 B = 128 KB of LDS
+// A gather costs one memory request whether 8 bytes of the line are used or all of it, and the rate
+// of requests that miss L2 is what bounds the sweep.  The batched sweep keeps the contributions of
+// kBatch = 16 concurrent queries interleaved, c8[v][slot] (128 bytes per vertex = one L2 line), so
+// the line a gather brings in carries that vertex's contribution for every query in flight, and
+// the column indices are read once for all of them.  G = kBatch lanes (one per slot) share an
+// edge: a wave still owns a 512-edge chunk, lane group g = lane / G walks edges [8Gg, 8G(g+1)) of
+// it in order.  The group's column indices sit in its own lanes' registers (two coalesced 16-byte
+// loads per lane) and are broadcast inside the group with ds_swizzle; row sums close inside the
+// group where a row starts and ends there, cross groups with a short segmented scan, and only rows
+// crossing the chunk boundary use atomics.  (Measured on R-MAT 22, all slots busy: 0.69 ms per
+// sweep at G = 8, 0.83 ms at G = 16, 1.85 ms at G = 32.)
+constexpr int kHotBytes = 128 * 1024;  // LDS table of the hottest vertices' lines (2048 x 64 B or 1024 x 128 B)
 
-template <int K>
-__device__ __forceinline__ int group8_bcast(int x) {  // value of lane K of the caller's 8-lane group
-  return __builtin_amdgcn_ds_swizzle(x, 0x18 | (K << 5));
+// value of lane K of the caller's lane group (G = 8 or 16 lanes)
+template <int G, int K>
+__device__ __forceinline__ int group_bcast(int x) {
+  return __builtin_amdgcn_ds_swizzle(x, (0x1f & ~(G - 1)) | (K << 5));
 }
 
+template <int G>
 struct ChunkRegsB {
   int4 ia, ib;
-  unsigned long long mask;  // row-start bits of the lane group's 64 edges
+  unsigned long long mask[G / 8];  // row-start bits of the lane group's 8 * G edges
 };
 
-__device__ __forceinline__ ChunkRegsB load_chunk_b(const int32_t* __restrict__ in_ci,
-                                                   const unsigned long long* __restrict__ flags64, uint32_t c,
-                                                   int lane) {
+template <int G>
+__device__ __forceinline__ ChunkRegsB<G> load_chunk_b(const int32_t* __restrict__ in_ci,
+                                                      const unsigned long long* __restrict__ flags64, uint32_t c,
+                                                      int lane) {
   const unsigned long long e0 = (unsigned long long)c * kChunkEdges + 8ull * lane;
   const int4* p = reinterpret_cast<const int4*>(in_ci + e0);
-  ChunkRegsB r;
+  ChunkRegsB<G> r;
   r.ia = p[0];
   r.ib = p[1];
-  r.mask = flags64[(size_t)c * 8 + (lane >> 3)];
+#pragma unroll
+  for (int w = 0; w < G / 8; ++w) r.mask[w] = flags64[(size_t)c * 8 + (size_t)(lane / G) * (G / 8) + w];
   return r;
 }
 
-template <bool HOT, int JB>
-__device__ __forceinline__ void edges_b8_block(const ChunkRegsB& cur, const double* __restrict__ c8,
-                                               const double* s_hot, uint32_t n_hot, int s, bool tail,
-                                               unsigned long long e_first, unsigned long long m, uint32_t before,
-                                               double* __restrict__ acc8, double& seg, double& first_seg, uint32_t& k) {
+// 8 edges of the group: the indices sit in lane JB of the group
+template <bool HOT, int G, int JB>
+__device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const double* __restrict__ cB,
+                                              const double* s_hot, uint32_t n_hot, int s, bool tail,
+                                              unsigned long long e_first, unsigned long long m, uint32_t before,
+                                              double* __restrict__ accB, double& seg, double& first_seg, uint32_t& k) {
   const int32_t own[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
   uint32_t v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = (uint32_t)group8_bcast<JB>(own[i]);
+  for (int i = 0; i < 8; ++i) v[i] = (uint32_t)group_bcast<G, JB>(own[i]);
   double val[8];
   if (HOT) {
     double gl[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gl[i] = c8[(size_t)(v[i] < n_hot ? 0u : v[i]) * kBatch + s];
+    for (int i = 0; i < 8; ++i) gl[i] = cB[(size_t)(v[i] < n_hot ? 0u : v[i]) * G + s];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const double hv = s_hot[(v[i] < n_hot ? v[i] : 0u) * kBatch + s];
+      const double hv = s_hot[(v[i] < n_hot ? v[i] : 0u) * G + s];
       val[i] = v[i] < n_hot ? hv : gl[i];
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) val[i] = c8[(size_t)v[i] * kBatch + s];
+    for (int i = 0; i < 8; ++i) val[i] = cB[(size_t)v[i] * G + s];
   }
   if (tail) {
 #pragma unroll
@@ -480,11 +487,11 @@ __device__ __forceinline__ void edges_b8_block(const ChunkRegsB& cur, const doub
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    if ((cur.mask >> (JB * 8 + i)) & 1ull) {
+    if ((cur.mask[(JB * 8 + i) >> 6] >> ((JB * 8 + i) & 63)) & 1ull) {
       if (k == 0)
         first_seg = seg;  // closes the row carried in from earlier groups
       else
-        acc8[(size_t)(before + k - 1) * kBatch + s] = seg;  // a row that starts and ends inside this group
+        accB[(size_t)(before + k - 1) * G + s] = seg;  // a row that starts and ends inside this group
       seg = 0.0;
       ++k;
     }
@@ -492,60 +499,73 @@ __device__ __forceinline__ void edges_b8_block(const ChunkRegsB& cur, const doub
   }
 }
 
-template <bool HOT>
-__global__ __launch_bounds__(1024) void k_dense_edges_b8(const int32_t* __restrict__ in_ci,
-                                                          const unsigned long long* __restrict__ flags64,
-                                                          const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
-                                                          unsigned long long m, const double* __restrict__ c8,
-                                                          double* __restrict__ acc8, uint32_t n_hot) {
+template <bool HOT, int G, int JB>
+struct EdgeBlocks {
+  static __device__ __forceinline__ void run(const ChunkRegsB<G>& cur, const double* __restrict__ cB,
+                                             const double* s_hot, uint32_t n_hot, int s, bool tail,
+                                             unsigned long long e_first, unsigned long long m, uint32_t before,
+                                             double* __restrict__ accB, double& seg, double& first_seg, uint32_t& k) {
+    EdgeBlocks<HOT, G, JB - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, m, before, accB, seg, first_seg, k);
+    edges_b_block<HOT, G, JB>(cur, cB, s_hot, n_hot, s, tail, e_first, m, before, accB, seg, first_seg, k);
+  }
+};
+template <bool HOT, int G>
+struct EdgeBlocks<HOT, G, -1> {
+  static __device__ __forceinline__ void run(const ChunkRegsB<G>&, const double*, const double*, uint32_t, int, bool,
+                                             unsigned long long, unsigned long long, uint32_t, double*, double&,
+                                             double&, uint32_t&) {}
+};
+
+// G = queries per sweep = lanes per edge; the wave's 64 / G lane groups walk 8 * G edges each
+template <bool HOT, int G>
+__global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restrict__ in_ci,
+                                                         const unsigned long long* __restrict__ flags64,
+                                                         const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
+                                                         unsigned long long m, const double* __restrict__ cB,
+                                                         double* __restrict__ accB, uint32_t n_hot) {
   extern __shared__ __attribute__((aligned(16))) double s_hot[];
   const int lane = lane_id();
-  const int grp = lane >> 3, s = lane & 7;
+  const int grp = lane / G, s = lane & (G - 1);
   const uint32_t waves_per_block = blockDim.x >> 6;
   const uint32_t stride = gridDim.x * waves_per_block;
   uint32_t c = blockIdx.x * waves_per_block + (uint32_t)wave_id();
-  ChunkRegsB cur;
-  if (c < n_chunks) cur = load_chunk_b(in_ci, flags64, c, lane);
+  ChunkRegsB<G> cur;
+  if (c < n_chunks) cur = load_chunk_b<G>(in_ci, flags64, c, lane);
   if (HOT) {
     double t[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const uint32_t i = threadIdx.x + j * 1024u;
-      t[j] = i < n_hot * kBatch ? c8[i] : 0.0;
+      t[j] = i < n_hot * G ? cB[i] : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const uint32_t i = threadIdx.x + j * 1024u;
-      if (i < n_hot * kBatch) s_hot[i] = t[j];
+      if (i < n_hot * G) s_hot[i] = t[j];
     }
     __syncthreads();
   }
   for (; c < n_chunks; c += stride) {
-    ChunkRegsB nxt = cur;
+    ChunkRegsB<G> nxt = cur;
     const uint32_t cn = c + stride;
-    if (cn < n_chunks) nxt = load_chunk_b(in_ci, flags64, cn, lane);
+    if (cn < n_chunks) nxt = load_chunk_b<G>(in_ci, flags64, cn, lane);
     const uint32_t cs = chunk_starts[c];
-    const uint32_t pc = (uint32_t)__popcll(cur.mask);
+    uint32_t pc = 0;
+#pragma unroll
+    for (int w = 0; w < G / 8; ++w) pc += (uint32_t)__popcll(cur.mask[w]);
     const uint32_t incl = wave_incl_scan_u32_dpp(s == 0 ? pc : 0u);  // row starts up to and including this group
     const uint32_t before = cs + incl - pc;
-    const unsigned long long e_first = (unsigned long long)c * kChunkEdges + 64ull * grp;
+    const unsigned long long e_first = (unsigned long long)c * kChunkEdges + (unsigned long long)(8 * G) * grp;
     const bool tail = (unsigned long long)(c + 1) * kChunkEdges > m;
     double seg = 0.0, first_seg = 0.0;
     uint32_t k = 0;
-    edges_b8_block<HOT, 0>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
-    edges_b8_block<HOT, 1>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
-    edges_b8_block<HOT, 2>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
-    edges_b8_block<HOT, 3>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
-    edges_b8_block<HOT, 4>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
-    edges_b8_block<HOT, 5>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
-    edges_b8_block<HOT, 6>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
-    edges_b8_block<HOT, 7>(cur, c8, s_hot, n_hot, s, tail, e_first, m, before, acc8, seg, first_seg, k);
-    // segmented scan over the 8 groups: S(g) = tail(g) + (group g holds a row start ? 0 : S(g-1))
+    EdgeBlocks<HOT, G, G - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, m, before, accB, seg, first_seg, k);
+    // segmented scan over the lane groups: S(g) = tail(g) + (group g holds a row start ? 0 : S(g-1))
     const bool h = k != 0;
     double S = seg;
     int F = h ? 1 : 0;
 #pragma unroll
-    for (int d = 8; d < 64; d <<= 1) {
+    for (int d = G; d < 64; d <<= 1) {
       const double ps = __shfl_up(S, d);
       const int pf = __shfl_up(F, d);
       if (lane >= d) {
@@ -553,24 +573,24 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b8(const int32_t* __restri
         F |= pf;
       }
     }
-    double carry = __shfl_up(S, 8);
-    if (lane < 8) carry = 0.0;
+    double carry = __shfl_up(S, G);
+    if (lane < G) carry = 0.0;
     const unsigned long long hmask = __ballot(h);
     if (h) {
-      const bool nonempty = grp > 0 || (cur.mask & 1ull) == 0;
+      const bool nonempty = grp > 0 || (cur.mask[0] & 1ull) == 0;
       if (nonempty && before > 0) {
         const double total = carry + first_seg;
-        const bool started_here = (hmask & ((1ull << (grp * 8)) - 1ull)) != 0;
-        double* dst = &acc8[(size_t)(before - 1) * kBatch + s];
+        const bool started_here = (hmask & ((1ull << (grp * G)) - 1ull)) != 0;
+        double* dst = &accB[(size_t)(before - 1) * G + s];
         if (started_here)
           *dst = total;
         else
           atomic_add_noret(dst, total);  // began in an earlier chunk
       }
     }
-    if (grp == 7) {  // the row still open at the end of the chunk
+    if (grp == 64 / G - 1) {  // the row still open at the end of the chunk
       const uint32_t starts = cs + incl;
-      if (starts > 0 && S != 0.0) atomic_add_noret(&acc8[(size_t)(starts - 1) * kBatch + s], S);
+      if (starts > 0 && S != 0.0) atomic_add_noret(&accB[(size_t)(starts - 1) * G + s], S);
     }
     cur = nxt;
   }
@@ -648,94 +668,138 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
   }
 }
 
-// k_dense_apply_b8: the batched form of k_dense_apply.  One thread per (row, slot), rows without
-// in-edges included (their contribution for the next level is written as 0, or holds the source's
-// returned dead-end mass), so the sweep rewrites every entry of c8_next and a column a slot has
-// left stays all-zero.  Slot arguments come from device memory; counters go to per-slot partials.
-__global__ __launch_bounds__(256) void k_dense_apply_b8(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
-                                                         const int32_t* __restrict__ zin_rows, uint32_t n_zin,
-                                                         double* __restrict__ acc8,
-                                                         const uint32_t* __restrict__ out_rp,
-                                                         double* __restrict__ c8_next,
-                                                         const SlotArgs* __restrict__ slots,
-                                                         unsigned long long* __restrict__ blk_pack8,
-                                                         double* __restrict__ blk_dead8,
-                                                         uint32_t* __restrict__ blk_ndead8) {
-  __shared__ unsigned long long s_pack[256];
-  __shared__ double s_dead[256];
-  __shared__ uint32_t s_nd[256];
-  const int tid = threadIdx.x;
-  const int s = tid & 7;
-  const SlotArgs a = slots[s];
-  const unsigned long long total = (unsigned long long)(n_nz + n_zin) * kBatch;
-  double dead_next = 0.0;
-  unsigned long long pack = 0;
-  uint32_t ndead = 0;
-  for (unsigned long long t = (unsigned long long)blockIdx.x * 256u + tid; t < total;
-       t += (unsigned long long)gridDim.x * 256u) {
-    const uint32_t j = (uint32_t)(t >> 3);
-    int32_t u;
-    double acc = 0.0;
-    if (j < n_nz) {
-      u = nz_rows[j];
-      acc = acc8[t];
-      if (acc != 0.0) acc8[t] = 0.0;
-    } else {
-      u = zin_rows[j - n_nz];
-    }
-    double cn = 0.0;
-    if (a.active) {
-      if (u == a.src) {
-        const double dd = a.ctr->dead[a.dead_slot];
-        if (dd > 0.0) {
-          acc += dd;
-          a.ctr->dead[a.dead_slot] = 0.0;
-        }
-      }
-      if (acc > 0.0) {
-        const uint32_t d = out_rp[u + 1] - out_rp[u];
-        const double old = a.res[u];
-        const double nw = old + acc;
-        const bool crossing = !active_fwd(old, d, a.rmax) && active_fwd(nw, d, a.rmax);
-        if (a.mode == kFwdTopk && active_fwd(nw, d, a.min_rmax)) a.flags[u] = 1;
-        if (crossing) {
-          a.reserve[u] = a.reserve[u] + nw * a.alpha;
-          a.res[u] = 0.0;
-          if (d == 0) {
-            dead_next += nw * (1.0 - a.alpha);
-            ndead++;
-          } else {
-            cn = ((1.0 - a.alpha) * nw) / (double)d;
-          }
-          pack += (1ull << kPackShift) | (unsigned long long)d;
-        } else {
-          a.res[u] = nw;
-        }
-      }
-    }
-    c8_next[(size_t)u * kBatch + s] = cn;
+// k_dense_apply_batch: the batched form of k_dense_apply.  Rows without in-edges are included (their
+// contribution for the next level is written as 0, or holds the source's returned dead-end mass),
+// so the sweep rewrites every entry of c8_next and a column a slot has left stays all-zero.
+// A workgroup takes 64 rows at a time through an LDS tile [row][slot]: row sums come in and next
+// contributions go out in the interleaved layout (whole 128-byte lines), while the per-slot
+// residue / reserve vectors are walked with a lane per row, i.e. coalesced as in the single-query
+// kernel.  Wave w serves slots [w * kBatch / 4, (w + 1) * kBatch / 4); slot arguments are
+// wave-uniform.  Counters go to per-slot partials.
+constexpr int kApplyRows = 64;
+constexpr int kSlotsPerWave = kBatch / 4;
+
+__global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
+                                                            const int32_t* __restrict__ zin_rows, uint32_t n_zin,
+                                                            double* __restrict__ acc8,
+                                                            const uint32_t* __restrict__ out_rp,
+                                                            double* __restrict__ c8_next,
+                                                            const SlotArgs* __restrict__ slots,
+                                                            const unsigned long long* __restrict__ cross_bits,
+                                                            unsigned long long* __restrict__ prep_bits,
+                                                            unsigned long long* __restrict__ blk_pack8,
+                                                            double* __restrict__ blk_dead8,
+                                                            uint32_t* __restrict__ blk_ndead8) {
+  __shared__ double tile[kApplyRows][kBatch + 1];
+  __shared__ int32_t s_u[kApplyRows];
+  __shared__ uint32_t s_d[kApplyRows];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t n_rows = n_nz + n_zin;
+  const uint32_t n_tiles = (n_rows + kApplyRows - 1) / kApplyRows;
+  SlotArgs a[kSlotsPerWave];
+#pragma unroll
+  for (int i = 0; i < kSlotsPerWave; ++i) a[i] = slots[w * kSlotsPerWave + i];
+  double dead_next[kSlotsPerWave];
+  unsigned long long pack[kSlotsPerWave];
+  uint32_t ndead[kSlotsPerWave];
+#pragma unroll
+  for (int i = 0; i < kSlotsPerWave; ++i) {
+    dead_next[i] = 0.0;
+    pack[i] = 0;
+    ndead[i] = 0;
   }
-  s_pack[tid] = pack;
-  s_dead[tid] = dead_next;
-  s_nd[tid] = ndead;
-  __syncthreads();
-  if (tid < kBatch) {
-    unsigned long long ps = 0;
-    double ds = 0.0;
-    uint32_t nd = 0;
-    for (int r = 0; r < 32; ++r) {
-      ps += s_pack[r * kBatch + tid];
-      ds += s_dead[r * kBatch + tid];
-      nd += s_nd[r * kBatch + tid];
+  for (uint32_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const uint32_t row0 = tl * kApplyRows;
+    // rows inside one 512-edge chunk are rewritten by plain stores every sweep; only the rows that
+    // cross a chunk boundary are summed with atomics and have to be cleared for the next sweep
+    const unsigned long long cw = cross_bits[tl];
+#pragma unroll
+    for (int i = 0; i < kApplyRows * kBatch / 256; ++i) {
+      const uint32_t idx = (uint32_t)i * 256u + tid;
+      const uint32_t r = idx / kBatch, s = idx % kBatch;
+      const uint32_t j = row0 + r;
+      double v = 0.0;
+      if (j < n_nz) {
+        const size_t t = (size_t)j * kBatch + s;
+        v = acc8[t];
+        if (v != 0.0 && ((cw >> r) & 1ull)) acc8[t] = 0.0;
+      }
+      tile[r][s] = v;
     }
-    blk_pack8[(size_t)tid * gridDim.x + blockIdx.x] = ps;
-    blk_dead8[(size_t)tid * gridDim.x + blockIdx.x] = ds;
-    blk_ndead8[(size_t)tid * gridDim.x + blockIdx.x] = nd;
+    if (tid < kApplyRows) {
+      const uint32_t j = row0 + tid;
+      const int32_t u = j < n_nz ? nz_rows[j] : (j < n_rows ? zin_rows[j - n_nz] : -1);
+      s_u[tid] = u;
+      s_d[tid] = u >= 0 ? out_rp[u + 1] - out_rp[u] : 0u;
+    }
+    __syncthreads();
+    const int32_t u = s_u[lane];
+    const uint32_t d = s_d[lane];
+#pragma unroll
+    for (int i = 0; i < kSlotsPerWave; ++i) {
+      const int s = w * kSlotsPerWave + i;
+      double acc = tile[lane][s];
+      double cn = 0.0;
+      if (a[i].active && u >= 0) {
+        if (u == a[i].src) {
+          const double dd = a[i].ctr->dead[a[i].dead_slot];
+          if (dd > 0.0) {
+            acc += dd;
+            a[i].ctr->dead[a[i].dead_slot] = 0.0;
+          }
+        }
+        if (acc > 0.0) {
+          const double old = a[i].res[u];
+          const double nw = old + acc;
+          const bool crossing = !active_fwd(old, d, a[i].rmax) && active_fwd(nw, d, a[i].rmax);
+          if (a[i].mode == kFwdTopk && active_fwd(nw, d, a[i].min_rmax)) a[i].flags[u] = 1;
+          if (crossing) {  // becomes a frontier node of the next level: prepare it right here
+            a[i].reserve[u] = a[i].reserve[u] + nw * a[i].alpha;
+            a[i].res[u] = 0.0;
+            if (d == 0) {
+              dead_next[i] += nw * (1.0 - a[i].alpha);
+              ndead[i]++;
+            } else {
+              cn = ((1.0 - a[i].alpha) * nw) / (double)d;
+            }
+            pack[i] += (1ull << kPackShift) | (unsigned long long)d;
+          } else {
+            a[i].res[u] = nw;
+          }
+        }
+      }
+      tile[lane][s] = cn;
+      // rows of this tile that hold a contribution for the slot's next level (read when the slot
+      // goes back to list form)
+      const unsigned long long bits = __ballot(cn > 0.0);
+      if (lane == 0 && a[i].active) prep_bits[(size_t)s * n_tiles + tl] = bits;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kApplyRows * kBatch / 256; ++i) {
+      const uint32_t idx = (uint32_t)i * 256u + tid;
+      const uint32_t r = idx / kBatch, s = idx % kBatch;
+      const int32_t ur = s_u[r];
+      if (ur >= 0) c8_next[(size_t)ur * kBatch + s] = tile[r][s];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < kSlotsPerWave; ++i) {
+    const double ds = wave_sum_f64(dead_next[i]);
+    const unsigned long long ps = wave_sum_u64(pack[i]);
+    const unsigned long long nd = wave_sum_u64((unsigned long long)ndead[i]);
+    if (lane == 0) {
+      const size_t o = (size_t)(w * kSlotsPerWave + i) * gridDim.x + blockIdx.x;
+      blk_pack8[o] = ps;
+      blk_dead8[o] = ds;
+      blk_ndead8[o] = (uint32_t)nd;
+    }
   }
 }
 
 // workgroup s sums slot s's partials into that slot's counters
-__global__ __launch_bounds__(1024) void k_dense_reduce_b8(const unsigned long long* __restrict__ blk_pack8,
+__global__ __launch_bounds__(1024) void k_dense_reduce_batch(const unsigned long long* __restrict__ blk_pack8,
                                                            const double* __restrict__ blk_dead8,
                                                            const uint32_t* __restrict__ blk_ndead8, uint32_t n_blocks,
                                                            const SlotArgs* __restrict__ slots) {
@@ -880,7 +944,7 @@ __global__ __launch_bounds__(256) void k_seed_dense(uint32_t n, double* __restri
       }
       pack += (1ull << kPackShift) | (unsigned long long)d;
     }
-    c_dense.at(v) = c;
+    if (c_dense.stride == 1 || c != 0.0) c_dense.at(v) = c;  // a slot's column is all-zero beforehand
   }
   const double ds = block_sum_f64(dead, s_red);
   const unsigned long long ps = block_sum_u64(pack, s_red2);
@@ -913,6 +977,36 @@ __global__ __launch_bounds__(256) void k_compact_prepared(uint32_t n, CView c_de
         eoffn[pos] = (uint32_t)eo;
         cF[pos] = c_dense.at(v);
         if (clear) c_dense.at(v) = 0.0;  // a slot leaving the dense shape hands back an all-zero column
+      });
+}
+
+// the same for a batch slot after a sweep: the apply kernel left one bit per row ordinal that holds a
+// contribution, so only those entries of the slot's column are read (and handed back as zero)
+__global__ __launch_bounds__(256) void k_compact_bits(uint32_t n_rows, uint32_t n_nz,
+                                                       const unsigned long long* __restrict__ bits,
+                                                       const int32_t* __restrict__ nz_rows,
+                                                       const int32_t* __restrict__ zin_rows, CView c_dense,
+                                                       const uint32_t* __restrict__ trp, int32_t* __restrict__ Fn,
+                                                       uint32_t* __restrict__ eoffn, double* __restrict__ cF,
+                                                       unsigned long long* counter) {
+  const uint32_t per = (((n_rows + gridDim.x - 1) / gridDim.x) + 63u) & ~63u;
+  const uint32_t lo = blockIdx.x * per;
+  const uint32_t hi = lo + per < n_rows ? lo + per : n_rows;
+  if (lo >= hi) return;
+  block_range_compact(
+      lo, hi, counter,
+      [&](uint32_t j, unsigned long long* w) {
+        if (!((bits[j >> 6] >> (j & 63)) & 1ull)) return false;
+        const int32_t u = j < n_nz ? nz_rows[j] : zin_rows[j - n_nz];
+        *w = trp[u + 1] - trp[u];
+        return true;
+      },
+      [&](uint32_t j, uint32_t pos, unsigned long long eo, unsigned long long) {
+        const int32_t u = j < n_nz ? nz_rows[j] : zin_rows[j - n_nz];
+        Fn[pos] = u;
+        eoffn[pos] = (uint32_t)eo;
+        cF[pos] = c_dense.at((uint32_t)u);
+        c_dense.at((uint32_t)u) = 0.0;
       });
 }
 
@@ -1031,42 +1125,53 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   return PPRHIP_OK;
 }
 
-int launch_dense_edges_b8(pprhip_graph* g, const double* c8, double* acc8) {
+template <int G>
+static int launch_dense_edges_bG(pprhip_graph* g, const double* cB, double* accB) {
   if (!g->n_chunks) return PPRHIP_OK;
-  const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMaxB) : 0u;
+  const uint32_t hot_max = (uint32_t)(kHotBytes / (8 * G));
+  const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, hot_max) : 0u;
   const uint32_t want = (g->n_chunks + 15) / 16;
   const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(g->start_flags);
   if (n_hot) {
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-      PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b8<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(double) * kHotMaxB * kBatch)));
+      PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, G>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
       lds_opt_in = true;
     }
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
-    k_dense_edges_b8<true><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * kBatch, g->stream>>>(
-        g->in_ci, flags64, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, c8, acc8, n_hot);
+    k_dense_edges_b<true, G><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * G, g->stream>>>(
+        g->in_ci, flags64, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, cB, accB, n_hot);
   } else {
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
-    k_dense_edges_b8<false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
-        g->in_ci, flags64, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, c8, acc8, 0u);
+    k_dense_edges_b<false, G><<<dim3(grid), dim3(1024), 0, g->stream>>>(
+        g->in_ci, flags64, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, cB, accB, 0u);
   }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
+int launch_dense_edges_b8(pprhip_graph* g, const double* c8, double* acc8) {
+  return launch_dense_edges_bG<8>(g, c8, acc8);
+}
+int launch_dense_edges_b16(pprhip_graph* g, const double* c16, double* acc16) {
+  return launch_dense_edges_bG<16>(g, c16, acc16);
+}
+int launch_dense_edges_b32(pprhip_graph* g, const double* c32, double* acc32) {
+  return launch_dense_edges_bG<32>(g, c32, acc32);
+}
+
 int launch_dense_level_b8(pprhip_graph* P) {
   PPRHIP_CHECK_HIP(hipMemcpyAsync(P->d_slot_args, P->h_slot_args, sizeof(SlotArgs) * kBatch, hipMemcpyHostToDevice,
                                   P->stream));
-  PPRHIP_TRY(launch_dense_edges_b8(P, P->c8[P->c8cur], P->acc8));
-  const unsigned long long work = (unsigned long long)P->n * kBatch;
-  const uint32_t grid = grid_for(work, 256, kApplyBlocks8);
-  k_dense_apply_b8<<<dim3(grid), dim3(256), 0, P->stream>>>(P->nz_rows, P->n_nz, P->zin_rows, P->n_zin, P->acc8,
+  PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, P->c8[P->c8cur], P->acc8));
+  const uint32_t grid = grid_for(P->n, kApplyRows, kApplyBlocks8);
+  k_dense_apply_batch<<<dim3(grid), dim3(256), 0, P->stream>>>(P->nz_rows, P->n_nz, P->zin_rows, P->n_zin, P->acc8,
                                                             P->out_rp, P->c8[P->c8cur ^ 1], P->d_slot_args,
-                                                            P->blk_pack8, P->blk_dead8, P->blk_ndead8);
+                                                            P->cross_bits, P->prep_bits, P->blk_pack8, P->blk_dead8,
+                                                            P->blk_ndead8);
   PPRHIP_CHECK_HIP(hipGetLastError());
-  k_dense_reduce_b8<<<dim3(kBatch), dim3(1024), 0, P->stream>>>(P->blk_pack8, P->blk_dead8, P->blk_ndead8, grid,
+  k_dense_reduce_batch<<<dim3(kBatch), dim3(1024), 0, P->stream>>>(P->blk_pack8, P->blk_dead8, P->blk_ndead8, grid,
                                                                 P->d_slot_args);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
@@ -1074,9 +1179,17 @@ int launch_dense_level_b8(pprhip_graph* P) {
 
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward) {
   const uint32_t grid = grid_for(g->n, 1024, 1024);
-  k_compact_prepared<<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, cview(g, cbuf), g->parent != nullptr,
-                                                              backward ? g->in_rp : g->out_rp, g->F[out_fbuf],
-                                                              g->eoff[out_fbuf], g->cF, d_counter);
+  if (g->parent) {
+    pprhip_graph* P = g->parent;
+    const uint32_t n_tiles = (P->n + kApplyRows - 1) / kApplyRows;
+    k_compact_bits<<<dim3(grid), dim3(256), 0, g->stream>>>(P->n, P->n_nz, P->prep_bits + (size_t)g->slot_index * n_tiles,
+                                                            P->nz_rows, P->zin_rows, cview(g, cbuf), g->out_rp,
+                                                            g->F[out_fbuf], g->eoff[out_fbuf], g->cF, d_counter);
+  } else {
+    k_compact_prepared<<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, cview(g, cbuf), false,
+                                                                backward ? g->in_rp : g->out_rp, g->F[out_fbuf],
+                                                                g->eoff[out_fbuf], g->cF, d_counter);
+  }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

@@ -192,17 +192,34 @@ def test_fora_batch_got(pkg, orc, got, dev_got, dense_frac):
         dev_got.set_tuning(pkg.tuning_default())
 
 
-def test_fora_batch_rmat12(pkg, orc, rmat12, dev_rmat12):
+def to_orc_tuning(orc, t):
+    o = orc.tuning_default()
+    for f, _ in o._fields_:
+        setattr(o, f, getattr(t, f))
+    return o
+
+
+@pytest.mark.parametrize("threads", ["0", "1"])
+def test_fora_batch_rmat12(pkg, orc, rmat12, dev_rmat12, threads, monkeypatch):
+    """Batch profile of the cost model on both sides; one worker thread per slot (1) or all slots on the caller (0)."""
+    monkeypatch.setenv("PPRHIP_BATCH_THREADS", threads)
     og = to_oracle(orc, rmat12)
-    srcs = sources(rmat12, 11, seed=8)
-    out, _, _, _, pq, st = dev_rmat12.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, n_rounds=2, fetch=True,
-                                                               per_query=True)
-    assert st.dense_levels > 0 and st.class_launches[5] > 0      # the batched sweep ran
-    assert st.class_launches[5] < st.dense_levels                 # and served several queries per launch
-    for i, s in enumerate(srcs):
-        ref, sto = og.fora_whole(s, 0.5, ALPHA, seed=9, n_rounds=2, schedule=orc.SYNC)
-        assert pq[i].walks == sto.walks and pq[i].levels == sto.levels
-        assert_close(out[i], ref, TOL_MC, "batch src=%d" % s)
+    srcs = sources(rmat12, 21, seed=8)
+    t = pkg.tuning_batch()
+    dev_rmat12.set_tuning(t)
+    try:
+        for n_rounds in (2, 0):
+            out, _, _, _, pq, st = dev_rmat12.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, n_rounds=n_rounds,
+                                                                       fetch=True, per_query=True)
+            assert st.dense_levels > 0 and st.class_launches[5] > 0      # the batched sweep ran
+            assert st.class_launches[5] < st.dense_levels                 # and served several queries per launch
+            for i, s in enumerate(srcs):
+                ref, sto = og.fora_whole(s, 0.5, ALPHA, seed=9, n_rounds=n_rounds, schedule=orc.SYNC,
+                                         tuning=to_orc_tuning(orc, t))
+                assert pq[i].rounds == sto.rounds and pq[i].walks == sto.walks and pq[i].levels == sto.levels
+                assert_close(out[i], ref, TOL_MC, "batch src=%d" % s)
+    finally:
+        dev_rmat12.set_tuning(pkg.tuning_default())
     # an empty batch and a batch of dead-end sources only
     out, _, _, _, _, st = dev_rmat12.fora_batch_single_source([], 0.5, ALPHA, seed=1, fetch=True)
     assert out.shape == (0, rmat12.n) and st.levels == 0
@@ -211,6 +228,32 @@ def test_fora_batch_rmat12(pkg, orc, rmat12, dev_rmat12):
         out, _, _, _, _, st = dev_rmat12.fora_batch_single_source(dead, 0.5, ALPHA, seed=1, fetch=True)
         for i, s in enumerate(dead):
             assert out[i][s] == 1.0 and out[i].sum() == 1.0
+
+
+def test_fora_batch_rmat15_many_queries(pkg, orc, rmat15, dev_rmat15):
+    """More queries than slots on a graph whose pushes run many dense levels; a sample is checked against the twin,
+    every query against mass conservation, and a second call on the same handle gives the same vectors."""
+    og = to_oracle(orc, rmat15)
+    srcs = sources(rmat15, 40, seed=4)
+    t = pkg.tuning_batch()
+    dev_rmat15.set_tuning(t)
+    try:
+        out, ids, vals, nsel, pq, st = dev_rmat15.fora_batch_single_source(srcs, 0.5, ALPHA, seed=5, k=16, fetch=True,
+                                                                           per_query=True)
+        out2, _, _, _, _, _ = dev_rmat15.fora_batch_single_source(srcs, 0.5, ALPHA, seed=5, fetch=True)
+        assert np.max(np.abs(out - out2)) < 1e-12
+        for i, s in enumerate(srcs):
+            assert abs(out[i].sum() - 1.0) < 1e-9 and out[i].min() >= 0.0
+            cnt, oids, ovals = orc.topk(out[i], 16, cap=16)
+            m = min(cnt, 16)
+            assert nsel[i] == cnt and list(ids[i][:m]) == list(oids[:m]) and np.array_equal(vals[i][:m], ovals[:m])
+        for i in (0, 7, 23, 39):
+            ref, sto = og.fora_whole(srcs[i], 0.5, ALPHA, seed=5, n_rounds=0, schedule=orc.SYNC,
+                                     tuning=to_orc_tuning(orc, t))
+            assert pq[i].rounds == sto.rounds and pq[i].walks == sto.walks
+            assert_close(out[i], ref, TOL_MC, "batch src=%d" % srcs[i])
+    finally:
+        dev_rmat15.set_tuning(pkg.tuning_default())
 
 
 # ------------------------------------------------------------------ FORA top-k (a6, a7)

@@ -13,7 +13,8 @@ for scale in [int(x) for x in sys.argv[1:]] or [16, 22]:
     ms = ctypes.c_double()
     md = ctypes.c_double()
     f = pkg.lib().pprhip_dev_dense_b8
-    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    rc = f(g.h, 20, ctypes.byref(ms), ctypes.byref(md))
-    print("scale", scale, "rc", rc, "ms per 8-query sweep %.4f" % ms.value, "maxdiff", md.value, flush=True)
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    for width in (8, 16, 32):
+      rc = f(g.h, 20, width, ctypes.byref(ms), ctypes.byref(md))
+      print("scale", scale, "width", width, "rc", rc, "ms per sweep %.4f" % ms.value, "maxdiff", md.value, flush=True)
     g.close()
