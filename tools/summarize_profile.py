@@ -54,7 +54,7 @@ def main():
         scale = int(wl.split("scale-")[1].split(" ")[0])
         n, m = 1 << scale, 16 << scale
     lines = ["# rocprofv3 summary `%s`" % tag, "",
-             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline` "
+             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` "
              "(PMC passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, each its own run with --kernel-trace only).", "",
              "| kernel | calls | total ms | avg us | % | FETCH_SIZE avg KB | WRITE_SIZE avg KB |", "|---|---|---|---|---|---|---|"]
     for r in stats:
@@ -81,9 +81,9 @@ def main():
         v = d.get(k, [])
         return sum(v) / len(v) if v else 0.0
 
-    dense_keys = [k for k in fetch if k.startswith("k_dense_tiles") or k.startswith("k_dense_edges")
-                  or k.startswith("k_dense_apply") or k == "k_dense_reduce"]
-    if dense_keys:
+    dense_keys = [k for k in fetch if k.startswith("k_dense_tiles") or k.startswith("k_dense_edges<")
+                  or k.startswith("k_dense_apply<") or k == "k_dense_reduce"]
+    if any(k.startswith("k_dense_edges<") or k.startswith("k_dense_tiles") for k in dense_keys):
         raw_f = sum(avg(fetch, k) for k in dense_keys) * 1024.0
         raw_w = sum(avg(write, k) for k in dense_keys) * 1024.0
         # in-edge columns, row-start flag bits, and per row: row id, row sum, residue, reserve, packed out extent
@@ -95,6 +95,21 @@ def main():
                      "%.0f MB algorithmic (x%.2f)." % (" + ".join(sorted(dense_keys)), raw_f / 1e6, raw_w / 1e6,
                                                        streaming / 1e6, corrected / 1e6, alg / 1e6, corrected / alg))
         traffic.setdefault("dense_pull", {})["scale%d" % scale] = int(corrected)
+    batch_keys = [k for k in fetch if k.startswith("k_dense_edges_b<") or k in ("k_dense_apply_batch",
+                                                                                "k_dense_reduce_batch")]
+    if batch_keys:
+        raw_f = sum(avg(fetch, k) for k in batch_keys) * 1024.0
+        raw_w = sum(avg(write, k) for k in batch_keys) * 1024.0
+        # coalesced reads of a sweep: in-edge columns + flag bits (edge kernel); row sums, row ids, degrees and
+        # the slots' residue / reserve vectors (apply kernel, upper bound: every slot busy and crossing)
+        B = 16
+        streaming = 4.0 * m + m / 8.0 + (8.0 * B + 4.0 + 8.0 + 16.0 * B) * n
+        corrected = raw_f + streaming / 2.0 + raw_w
+        lines.append("Batched dense sweep (%s): FETCH_SIZE %.0f MB + WRITE_SIZE %.0f MB raw per sweep; coalesced "
+                     "reads of a sweep <= %.0f MB, half of which FETCH_SIZE misses => corrected HBM-side traffic "
+                     "<= %.0f MB per sweep (the gathers' 128-byte lines are counted in full)."
+                     % (" + ".join(sorted(batch_keys)), raw_f / 1e6, raw_w / 1e6, streaming / 1e6, corrected / 1e6))
+        traffic.setdefault("dense_pull_batch", {})["scale%d" % scale] = int(corrected)
     if "k_mc_walk" in fetch:
         raw = avg(fetch, "k_mc_walk") * 1024.0 + avg(write, "k_mc_walk") * 1024.0
         lines.append("Walk kernel: FETCH_SIZE + WRITE_SIZE = %.0f MB per launch (random 64-byte requests, counted "
