@@ -234,8 +234,10 @@ int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int 
                                     const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
                                     double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
                                     pprhip_stats_t* per_query, pprhip_stats_t* stats_sum);
-/* Batched FORA top-k for the sources of one shard (config #4): q queries one after another on
- * this handle's GPU; ids_out/vals_out are q*k, rows padded with id -1 / value 0. */
+/* FORA top-k (pprhip_fora_topk) for q sources, up to PPRHIP_BATCH of them in flight: every query runs
+ * Fora_Topk's loop on delta unchanged (query i with seed + i), the dense levels of its forward_push_topk
+ * rounds share sweeps with the other queries in flight.  ids_out/vals_out are q*k, rows padded with
+ * id -1 / value 0 (entries beyond k that tie with the k-th value are dropped). */
 int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k, double eps, double alpha,
                            uint64_t seed, int32_t* ids_out, double* vals_out, pprhip_stats_t* stats_sum);
 

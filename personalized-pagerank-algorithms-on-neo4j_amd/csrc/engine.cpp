@@ -1129,10 +1129,17 @@ struct ForaRun {
   bool dead_src = false;
   LevelCtx L;
   PushArgs a;
-  enum Phase { kRoundStart, kLevels, kWalks, kDone } phase = kDone;
+  enum Phase { kRoundStart, kLevels, kWalks, kTopkRoundStart, kTopkLevels, kTopkFinal, kDone } phase = kDone;
   int query = -1;  // batch driver: index of the query this run serves
   bool waiting = false;
-  bool in_push = false;  // counted in BatchSync::n_push
+  bool in_push = false;  // between a push phase's start and its end (BatchSync: may hold sweeps off)
+  // top-k runs (Fora_Topk.computeTopKPPR, kind 1): the trial-and-error loop on delta
+  int kind = 0;
+  double eps_half = 0, delta_local = 0, min_delta = 0, min_rmax = 0;
+  uint32_t round = 0;
+  int cap = 0, nsel = 0;
+  int32_t* ids_out = nullptr;
+  double* vals_out = nullptr;
 };
 
 }  // namespace pprhip
@@ -1222,6 +1229,116 @@ int fora_step(ForaRun& r, bool yield_dense) {
       r.st.rounds = (uint32_t)r.rounds;
       r.st.rsum = r.rsum_local;
       r.st.rmax_final = r.rmax_used;
+      r.st.omega = r.omega_local;
+      r.phase = ForaRun::kDone;
+    }
+    return PPRHIP_OK;
+  }
+}
+
+// Fora_Topk.computeTopKPPR (Fora_Topk.java:102-184) as a resumable run; the same sequence as
+// pprhip_fora_topk, which keeps the per-phase timing of a single call.
+int topk_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, const pprhip_fora_conf_t* conf,
+               uint64_t seed, int32_t* ids_out, double* vals_out, int cap) {
+  r.g = g;
+  r.kind = 1;
+  r.src = src_internal;
+  r.conf = conf;
+  r.seed = seed;
+  std::memset(&r.st, 0, sizeof r.st);
+  PPRHIP_TRY(reset_query_state(g, true));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags + src_internal, 1, 1, g->stream));  // Q = {s} (:117-118)
+  g->topk_active = true;
+  g->topk_first = true;
+  g->topk_src = src_internal;
+  g->topk_alpha = conf->alpha;
+  g->topk_rsum = conf->rsum;
+  r.alpha = conf->alpha;
+  r.eps_half = eps * 0.5;  // :109-110
+  r.delta_local = conf->delta;
+  r.min_delta = conf->min_delta;
+  r.min_rmax = r.eps_half * std::sqrt(r.min_delta / 3 / (double)conf->m / std::log(2 / conf->pfail));  // :113
+  r.rsum_local = conf->rsum;
+  r.omega_local = r.rmax_local = 0.0;
+  r.round = 0;
+  r.dead_src = false;
+  r.ids_out = ids_out;
+  r.vals_out = vals_out;
+  r.cap = cap;
+  r.nsel = 0;
+  r.phase = ForaRun::kTopkRoundStart;
+  r.waiting = false;
+  r.in_push = false;
+  return PPRHIP_OK;
+}
+
+int topk_step(ForaRun& r, bool yield_dense) {
+  pprhip_graph* g = r.g;
+  const pprhip_fora_conf_t* conf = r.conf;
+  const size_t nd = sizeof(double) * (size_t)g->n;
+  for (;;) {
+    if (r.phase == ForaRun::kTopkRoundStart) {
+      if (!(r.delta_local >= r.min_delta)) {  // :123
+        r.phase = ForaRun::kTopkFinal;
+        continue;
+      }
+      r.rmax_local = r.eps_half * std::sqrt(r.delta_local / 3.0 / (double)conf->m / std::log(2.0 / conf->pfail));  // :124
+      r.omega_local = (r.eps_half + 2.0) * std::log(2.0 / conf->pfail) / r.eps_half / r.eps_half / r.delta_local;  // :125
+      if (hdeg_out(g, r.src) == 0) {  // :126-132
+        PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
+        PPRHIP_TRY(launch_set_f64(g, g->est, (uint32_t)r.src, 1.0));
+        r.rsum_local = 0.0;
+        r.dead_src = true;
+        r.phase = ForaRun::kTopkFinal;
+        continue;
+      }
+      r.rmax_local *= std::sqrt((double)conf->m * r.rmax_local) * 3.0;  // :133
+      // forward_push_topk (:137; Forward_Push.java:144-250)
+      if (g->topk_first) PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)r.src, 1.0));
+      r.a = PushArgs{r.alpha, r.rmax_local, r.min_rmax, r.src, kFwdTopk};
+      r.L = LevelCtx();
+      r.in_push = true;
+      PPRHIP_TRY(seed_scan(g, r.a, 1, r.L));
+      r.phase = ForaRun::kTopkLevels;
+    }
+    if (r.phase == ForaRun::kTopkLevels) {
+      const int rc = run_levels(g, r.a, r.L, r.st, nullptr, yield_dense);
+      if (rc != PPRHIP_OK) return rc;  // kYield or an error
+      leave_push(r);
+      PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
+      g->topk_first = false;
+      r.rsum_local = g->topk_rsum;  // :142
+      // :143 reserve := copy of the push reserve (walk increments of earlier rounds are dropped)
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
+      const double rsum_rw = r.rsum_local * (1.0 - r.alpha);  // :148
+      const double nrw_d = r.omega_local * rsum_rw;
+      const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;  // :151
+      PPRHIP_TRY(run_walk_phase(g, 1, r.alpha, rsum_rw, nrw, r.seed, r.round, g->est, r.st));  // :155-168
+      r.round++;
+      double kth = 0.0;
+      bool have = false;
+      int nsel = 0;
+      PPRHIP_TRY(select_topk(g, g->est, conf->k, nullptr, nullptr, 0, &nsel, &kth, &have, r.st));  // :173
+      if (!have) kth = 0.0;                                                                          // :174
+      r.st.kth_value = kth;
+      if (kth >= (1 + r.eps_half) * r.delta_local || r.delta_local <= r.min_delta) {  // :175-176
+        r.phase = ForaRun::kTopkFinal;
+      } else {
+        r.delta_local = std::max(r.min_delta, r.delta_local / 4.0);  // :178
+        r.phase = ForaRun::kTopkRoundStart;
+      }
+      continue;
+    }
+    if (r.phase == ForaRun::kTopkFinal) {
+      if (r.round == 0 && !r.dead_src) PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
+      g->result_in_est = true;
+      PPRHIP_TRY(read_dead_pops(g, r.st));
+      bool have = false;
+      double kth = 0.0;
+      PPRHIP_TRY(select_topk(g, g->est, conf->k, r.ids_out, r.vals_out, r.cap, &r.nsel, &kth, &have, r.st));
+      r.st.rounds = r.round;
+      r.st.rsum = r.rsum_local;
+      r.st.rmax_final = r.rmax_local;
       r.st.omega = r.omega_local;
       r.phase = ForaRun::kDone;
     }
@@ -1333,17 +1450,26 @@ struct BatchJob {
   double* vals_out;
   int* n_out;
   pprhip_stats_t* per_query;
+  int kind = 0;  // 0: whole-graph FORA per query, 1: FORA top-k per query (seed + query index)
   pprhip_stats_t sum;
   std::mutex sum_mu;
   std::atomic<int> next_query{0};
 };
 
+int run_step(ForaRun& r, bool yield_dense) { return r.kind == 1 ? topk_step(r, yield_dense) : fora_step(r, yield_dense); }
+
 // outputs of a finished query (its slot still holds the vectors)
 int finish_query(BatchJob& J, ForaRun& r) {
   pprhip_graph* S = r.g;
   const int i = r.query;
-  if (J.reserve_out) PPRHIP_TRY(copy_out(S, S->reserve, J.reserve_out + (size_t)i * J.P->n));
-  if (J.k > 0) {
+  if (J.reserve_out) PPRHIP_TRY(copy_out(S, r.kind == 1 ? S->est : S->reserve, J.reserve_out + (size_t)i * J.P->n));
+  if (r.kind == 1) {  // the run's final selection wrote the first min(nsel, k) pairs
+    for (int j = std::min(r.nsel, J.k); j < J.k; ++j) {
+      r.ids_out[j] = -1;
+      r.vals_out[j] = 0.0;
+    }
+    if (J.n_out) J.n_out[i] = r.nsel;
+  } else if (J.k > 0) {
     int nsel = 0;
     bool have = false;
     int32_t* ids = J.ids_out + (size_t)i * J.k;
@@ -1367,7 +1493,14 @@ int finish_query(BatchJob& J, ForaRun& r) {
 
 int begin_query(BatchJob& J, ForaRun& r, pprhip_graph* S, int i) {
   S->tun = J.P->tun;
-  PPRHIP_TRY(fora_begin(r, S, J.P->h_old2new[J.srcs[i]], J.eps, J.conf, J.seed, J.n_rounds));
+  const int32_t src = J.P->h_old2new[J.srcs[i]];
+  if (J.kind == 1) {
+    PPRHIP_TRY(topk_begin(r, S, src, J.eps, J.conf, J.seed + (uint64_t)i, J.ids_out + (size_t)i * J.k,
+                          J.vals_out + (size_t)i * J.k, J.k));
+  } else {
+    r.kind = 0;
+    PPRHIP_TRY(fora_begin(r, S, src, J.eps, J.conf, J.seed, J.n_rounds));
+  }
   r.query = i;
   return PPRHIP_OK;
 }
@@ -1389,7 +1522,7 @@ int batch_sequential(BatchJob& J, ForaRun* runs) {
           busy++;
         }
         if (r.waiting) break;
-        const int rc = fora_step(r, true);
+        const int rc = run_step(r, true);
         if (rc == kYield) {
           r.waiting = true;
           break;
@@ -1435,7 +1568,7 @@ void batch_worker(BatchJob* J, BatchSync* B, ForaRun* runs, int s) {
     if (i >= J->q) break;
     rc = begin_query(*J, r, S, i);
     while (rc == PPRHIP_OK) {
-      rc = fora_step(r, true);
+      rc = run_step(r, true);
       if (rc != kYield) break;
       rc = B->arrive(s);
     }
@@ -1545,37 +1678,17 @@ void BatchSync::sweeper() {
 // Every query runs the single-query algorithm unchanged (same levels, same thresholds, same walks
 // for the same seed); whenever the queries in a push phase all stand at a dense level, one sweep of
 // the batched kernels serves them.  All slots run on the calling thread and the handle's stream;
-// with PPRHIP_BATCH_THREADS=1 every slot gets a worker thread and a stream of its own, so sparse
-// levels, walks and selections of different queries overlap on the GPU (a few percent on R-MAT 22,
-// where the kernels already keep the memory system busy).
-int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
-                                    const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
-                                    double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
-                                    pprhip_stats_t* per_query, pprhip_stats_t* stats_sum) {
-  PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_single_source"));
-  if (q < 0 || !conf || !(eps > 0.0) || n_rounds < 0 || (q > 0 && !srcs) || k < 0 ||
-      (k > 0 && q > 0 && (!ids_out || !vals_out))) {
-    set_error("pprhip_fora_batch_single_source: bad arguments (q=%d eps=%g n_rounds=%d k=%d)", q, eps, n_rounds, k);
-    return PPRHIP_ERR_INVALID;
-  }
-  for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_single_source"));
+// with PPRHIP_BATCH_THREADS=1 (the default of the top-k entry point) every slot gets a worker
+// thread and a stream of its own, so sparse levels, walks and selections of different queries
+// overlap on the GPU.
+// runs a prepared job on the handle's slots (both batched entry points)
+static int batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* stats_sum) {
   PPRHIP_TRY(ensure_batch(g));
+  const int q = J.q;
+  // Worker threads pay off where queries are latency-bound (top-k: short rounds of sparse levels, walks
+  // and selections, 2.4x on R-MAT 22); whole-graph FORA keeps the memory system busy from one thread.
   const char* env = getenv("PPRHIP_BATCH_THREADS");
-  const bool threaded = env && env[0] == '1' && q > 1;
-  BatchJob J;
-  J.P = g;
-  J.srcs = srcs;
-  J.q = q;
-  J.eps = eps;
-  J.conf = conf;
-  J.seed = seed;
-  J.n_rounds = n_rounds;
-  J.reserve_out = reserve_out;
-  J.k = k;
-  J.ids_out = ids_out;
-  J.vals_out = vals_out;
-  J.n_out = n_out;
-  J.per_query = per_query;
+  const bool threaded = q > 1 && (env ? env[0] == '1' : J.kind == 1);
   std::memset(&J.sum, 0, sizeof J.sum);
   ForaRun runs[kBatch];
   g->ktimer.stream = g->stream;
@@ -1636,6 +1749,34 @@ int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int 
   sum.dominant_kernel_launches = cnt[best];
   if (stats_sum) *stats_sum = sum;
   return PPRHIP_OK;
+}
+
+int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
+                                    const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
+                                    double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
+                                    pprhip_stats_t* per_query, pprhip_stats_t* stats_sum) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_single_source"));
+  if (q < 0 || !conf || !(eps > 0.0) || n_rounds < 0 || (q > 0 && !srcs) || k < 0 ||
+      (k > 0 && q > 0 && (!ids_out || !vals_out))) {
+    set_error("pprhip_fora_batch_single_source: bad arguments (q=%d eps=%g n_rounds=%d k=%d)", q, eps, n_rounds, k);
+    return PPRHIP_ERR_INVALID;
+  }
+  for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_single_source"));
+  BatchJob J;
+  J.P = g;
+  J.srcs = srcs;
+  J.q = q;
+  J.eps = eps;
+  J.conf = conf;
+  J.seed = seed;
+  J.n_rounds = n_rounds;
+  J.reserve_out = reserve_out;
+  J.k = k;
+  J.ids_out = ids_out;
+  J.vals_out = vals_out;
+  J.n_out = n_out;
+  J.per_query = per_query;
+  return batch_run(g, J, stats_sum);
 }
 
 // ------------------------------------------------------------------ top-k select (a7)
@@ -1751,38 +1892,29 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
 int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k, double eps, double alpha,
                            uint64_t seed, int32_t* ids_out, double* vals_out, pprhip_stats_t* stats_sum) {
   PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_topk"));
-  if (q < 0 || k < 1 || (q > 0 && (!srcs || !ids_out || !vals_out))) {
+  if (q < 0 || k < 1 || !(eps > 0.0) || (q > 0 && (!srcs || !ids_out || !vals_out))) {
     set_error("pprhip_fora_batch_topk: bad arguments");
     return PPRHIP_ERR_INVALID;
   }
+  for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_topk"));
   pprhip_fora_conf_t conf;
   PPRHIP_TRY(pprhip_conf_fora_topk(g->n, g->m, k, alpha, &conf));
-  pprhip_stats_t sum;
-  std::memset(&sum, 0, sizeof sum);
-  for (int i = 0; i < q; ++i) {
-    pprhip_stats_t st;
-    int nsel = 0;
-    int32_t* ids = ids_out + (size_t)i * k;
-    double* vals = vals_out + (size_t)i * k;
-    PPRHIP_TRY(pprhip_fora_topk(g, srcs[i], eps, &conf, seed + (uint64_t)i, ids, vals, k, &nsel, nullptr, &st));
-    for (int j = std::min(nsel, k); j < k; ++j) {
-      ids[j] = -1;
-      vals[j] = 0.0;
-    }
-    sum.pops += st.pops; sum.edge_pushes += st.edge_pushes; sum.enqueues += st.enqueues;
-    sum.dead_end_pops += st.dead_end_pops; sum.dense_nodes += st.dense_nodes; sum.levels += st.levels;
-    sum.dense_levels += st.dense_levels; sum.rounds += st.rounds; sum.mc_sources += st.mc_sources;
-    sum.walks += st.walks; sum.walk_steps += st.walk_steps; sum.select_passes += st.select_passes;
-    sum.push_ms += st.push_ms; sum.mc_ms += st.mc_ms; sum.select_ms += st.select_ms; sum.total_ms += st.total_ms;
-    sum.push_bytes += st.push_bytes; sum.mc_bytes += st.mc_bytes; sum.select_bytes += st.select_bytes;
-    for (int c = 0; c < 8; ++c) {
-      sum.class_ms[c] += st.class_ms[c];
-      sum.class_bytes[c] += st.class_bytes[c];
-      sum.class_launches[c] += st.class_launches[c];
-    }
-  }
-  if (stats_sum) *stats_sum = sum;
-  return PPRHIP_OK;
+  BatchJob J;
+  J.P = g;
+  J.kind = 1;
+  J.srcs = srcs;
+  J.q = q;
+  J.eps = eps;
+  J.conf = &conf;
+  J.seed = seed;  // query i runs with seed + i, as pprhip_fora_topk(srcs[i], ..., seed + i) would
+  J.n_rounds = 0;
+  J.reserve_out = nullptr;
+  J.k = k;
+  J.ids_out = ids_out;
+  J.vals_out = vals_out;
+  J.n_out = nullptr;
+  J.per_query = nullptr;
+  return batch_run(g, J, stats_sum);
 }
 
 // ------------------------------------------------------------------ pure Monte-Carlo

@@ -290,6 +290,30 @@ def test_fora_topk_got_mixed_level_shapes(pkg, orc, got, dev_got, dense_frac):
         dev_got.set_tuning(pkg.tuning_default())
 
 
+@pytest.mark.parametrize("threads", ["0", "1"])
+def test_fora_batch_topk(pkg, orc, got, dev_got, rmat12, dev_rmat12, threads, monkeypatch):
+    """Top-k queries in flight together: query i equals pprhip_fora_topk(src_i, seed + i) and the twin's top-k."""
+    monkeypatch.setenv("PPRHIP_BATCH_THREADS", threads)
+    for host, dev, k, srcs, tun in ((got, dev_got, 10, [0, 17, 42, 90, 106] + sources(got, 14, seed=3), pkg.tuning_default()),
+                                    (rmat12, dev_rmat12, 32, sources(rmat12, 19, seed=6), pkg.tuning_batch())):
+        og = to_oracle(orc, host)
+        dev.set_tuning(tun)
+        try:
+            ids, vals, st = dev.fora_batch_topk(srcs, k, 0.5, ALPHA, seed=11)
+            assert ids.shape == (len(srcs), k)
+            for i, s in enumerate(srcs):
+                nsel, sids, svals, _, sst = dev.fora_topk(s, 0.5, ALPHA, k, seed=11 + i, cap=k)
+                m = min(nsel, k)
+                assert list(ids[i][:m]) == list(sids[:m]) and np.max(np.abs(vals[i][:m] - svals[:m]), initial=0) < 1e-12
+                assert np.all(ids[i][m:] == -1) and np.all(vals[i][m:] == 0.0)
+                ref, sto = og.fora_topk(s, 0.5, ALPHA, k, seed=11 + i, schedule=orc.SYNC)
+                cnt, oids, ovals = orc.topk(ref, k, cap=k)
+                assert min(cnt, k) == m and list(oids[:m]) == list(ids[i][:m])
+            assert st.levels > 0 and st.rounds >= len(srcs) - int(np.sum(np.diff(host.out_rp)[srcs] == 0))
+        finally:
+            dev.set_tuning(pkg.tuning_default())
+
+
 def test_fora_topk_rmat12(pkg, orc, rmat12, dev_rmat12):
     og = to_oracle(orc, rmat12)
     for s in sources(rmat12, 3, seed=8):
