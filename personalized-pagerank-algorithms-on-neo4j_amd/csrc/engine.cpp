@@ -2341,58 +2341,3 @@ int pprhip_index_arrays(const pprhip_index_t* ix, const uint64_t** offsets, cons
 void pprhip_index_destroy(pprhip_index_t* ix) { delete ix; }
 
 }  // extern "C"
-
-// development hook (not part of include/pprhip.h): times the batched dense edge sweep on random
-// contributions and checks it against host row sums on small graphs
-extern "C" int pprhip_dev_dense_b8(pprhip_graph_t* g, int reps, int width, double* ms_out, double* maxdiff_out) {
-  const size_t W = (size_t)width;
-  auto launch = [&](const double* c, double* a) { return width == 32 ? launch_dense_edges_b32(g, c, a) : width == 16 ? launch_dense_edges_b16(g, c, a) : launch_dense_edges_b8(g, c, a); };
-  const size_t n = g->n, nnz = g->n_nz;
-  std::vector<double> h(n * W);
-  uint64_t x = 88172645463325252ull;
-  for (auto& v : h) {
-    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-    v = (double)(x >> 11) * (1.0 / 9007199254740992.0);
-  }
-  double *c8 = nullptr, *acc8 = nullptr;
-  PPRHIP_TRY(alloc_dev((void**)&c8, sizeof(double) * n * W));
-  PPRHIP_TRY(alloc_dev((void**)&acc8, sizeof(double) * (nnz + 1) * W));
-  PPRHIP_CHECK_HIP(hipMemcpy(c8, h.data(), sizeof(double) * n * W, hipMemcpyHostToDevice));
-  PPRHIP_CHECK_HIP(hipMemset(acc8, 0, sizeof(double) * (nnz + 1) * W));
-  PPRHIP_TRY(launch(c8, acc8));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-  double maxdiff = -1.0;
-  if (g->m <= (1ull << 24)) {
-    std::vector<double> got(nnz * W);
-    std::vector<int32_t> ci(g->m);
-    PPRHIP_CHECK_HIP(hipMemcpy(got.data(), acc8, sizeof(double) * nnz * W, hipMemcpyDeviceToHost));
-    PPRHIP_CHECK_HIP(hipMemcpy(ci.data(), g->in_ci, sizeof(int32_t) * g->m, hipMemcpyDeviceToHost));
-    maxdiff = 0.0;
-    size_t j = 0;
-    for (size_t v = 0; v < n; ++v) {
-      if (g->h_in_rp[v + 1] == g->h_in_rp[v]) continue;
-      for (int s = 0; s < width; ++s) {
-        double sum = 0.0;
-        for (uint32_t e = g->h_in_rp[v]; e < g->h_in_rp[v + 1]; ++e) sum += h[(size_t)ci[e] * W + s];
-        maxdiff = std::max(maxdiff, std::fabs(sum - got[j * W + s]) / std::max(1.0, std::fabs(sum)));
-      }
-      ++j;
-    }
-  }
-  hipEvent_t a, b;
-  PPRHIP_CHECK_HIP(hipEventCreate(&a));
-  PPRHIP_CHECK_HIP(hipEventCreate(&b));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(acc8, 0, sizeof(double) * (nnz + 1) * W, g->stream));
-  PPRHIP_CHECK_HIP(hipEventRecord(a, g->stream));
-  for (int i = 0; i < reps; ++i) PPRHIP_TRY(launch(c8, acc8));
-  PPRHIP_CHECK_HIP(hipEventRecord(b, g->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-  float ms = 0.f;
-  PPRHIP_CHECK_HIP(hipEventElapsedTime(&ms, a, b));
-  *ms_out = (double)ms / reps;
-  *maxdiff_out = maxdiff;
-  (void)hipFree(c8);
-  (void)hipFree(acc8);
-  return PPRHIP_OK;
-}
-

@@ -190,9 +190,6 @@ int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int leve
 int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
                        unsigned long long dense_thresh, int dead_slot);
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot);
-int launch_dense_edges_b8(pprhip_graph* g, const double* c8, double* acc8);
-int launch_dense_edges_b16(pprhip_graph* g, const double* c16, double* acc16);
-int launch_dense_edges_b32(pprhip_graph* g, const double* c32, double* acc32);
 constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply kernel (per-slot partials each)
 int launch_dense_level_b8(pprhip_graph* parent);  // slot arguments already staged in parent->h_slot_args
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);

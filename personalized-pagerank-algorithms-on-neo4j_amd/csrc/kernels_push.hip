@@ -1151,16 +1151,6 @@ static int launch_dense_edges_bG(pprhip_graph* g, const double* cB, double* accB
   return PPRHIP_OK;
 }
 
-int launch_dense_edges_b8(pprhip_graph* g, const double* c8, double* acc8) {
-  return launch_dense_edges_bG<8>(g, c8, acc8);
-}
-int launch_dense_edges_b16(pprhip_graph* g, const double* c16, double* acc16) {
-  return launch_dense_edges_bG<16>(g, c16, acc16);
-}
-int launch_dense_edges_b32(pprhip_graph* g, const double* c32, double* acc32) {
-  return launch_dense_edges_bG<32>(g, c32, acc32);
-}
-
 int launch_dense_level_b8(pprhip_graph* P) {
   PPRHIP_CHECK_HIP(hipMemcpyAsync(P->d_slot_args, P->h_slot_args, sizeof(SlotArgs) * kBatch, hipMemcpyHostToDevice,
                                   P->stream));

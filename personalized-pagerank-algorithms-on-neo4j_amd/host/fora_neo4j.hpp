@@ -165,10 +165,17 @@ class Fora_Whole_Graph : public Algo_Util, public Whole_Graph_Util_Interface, pu
   void deletePrepDir() override;
   int rounds = 0;  // 0: the engine's cost model picks the number of threshold halvings (:93-103)
 
+  // Extension over the reference: the harness's query loop (Gen_Util.java:208-232) as one call, 16 queries in
+  // flight on the GPU (pprhip_fora_batch_single_source).  selectBatchResult(i) makes result i the current one
+  // for getWholeGraphPPR / printWholeGraphResult.
+  void computeWholeGraphPPRBatch(const std::vector<long>& sources, double epsilon);
+  void selectBatchResult(size_t i);
+
  private:
   pprhip_fora_conf_t conf{};
   uint64_t seed, query_counter = 0;
   std::string preprocessing_dirName;
+  std::vector<double> batch_dense;  // results of the last batch, query-major
 };
 
 // Fora_Topk.java
