@@ -51,6 +51,11 @@ struct BatchSync {
 
 namespace {
 
+struct Triple {  // one index entry of All-Pair-Backward-Search: pi(v, t) = p
+  int32_t v, t;
+  double p;
+};
+
 struct LevelCtx {
   int fcur = 0;   // F/eoff buffer holding the current frontier list
   int ccur = 0;   // dense contribution buffer holding the current level's contributions
@@ -143,12 +148,14 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
   const bool bwd = a.mode == kBackward;
   const bool slot = g->parent != nullptr;
   // smallest integer x with (double)x >= dense_frac * m: the device-side form of level_cost()'s test
+  // backward levels run dense only on batch slots (the sweep over the out-CSR exists in batched form)
+  const bool sparse_only = bwd && !slot;
   const unsigned long long dense_thresh =
-      bwd ? ~0ull : (unsigned long long)std::ceil(g->tun.dense_frac * (double)g->m);
+      sparse_only ? ~0ull : (unsigned long long)std::ceil(g->tun.dense_frac * (double)g->m);
   while (L.nf > 0) {
     bool dense = false;
     const double c = level_cost(g, L.nf, L.ef, &dense);
-    if (bwd) dense = false;  // backward levels always run sparse
+    if (sparse_only) dense = false;
     if (dense) {
       if (model_cost) *model_cost += c;
       if (!L.dense_prepared) {
@@ -213,7 +220,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       if (i > 0) {
         bool d2 = false;
         const double ci = level_cost(g, nf_i, ef_i, &d2);
-        if (nf_i == 0 || (d2 && !bwd)) break;  // the device stopped here too (level_runs)
+        if (nf_i == 0 || (d2 && !sparse_only)) break;  // the device stopped here too (level_runs)
         if (model_cost) *model_cost += ci;
       } else if (model_cost) {
         *model_cost += c;
@@ -314,8 +321,8 @@ int ensure_batch(pprhip_graph* P) {
     PPRHIP_TRY(alloc_dev((void**)&P->c8[i], sizeof(double) * n * kBatch));
     PPRHIP_CHECK_HIP(hipMemsetAsync(P->c8[i], 0, sizeof(double) * n * kBatch, P->stream));
   }
-  PPRHIP_TRY(alloc_dev((void**)&P->acc8, sizeof(double) * ((size_t)P->n_nz + 1) * kBatch));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * ((size_t)P->n_nz + 1) * kBatch, P->stream));
+  PPRHIP_TRY(alloc_dev((void**)&P->acc8, sizeof(double) * (n + 1) * kBatch));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * (n + 1) * kBatch, P->stream));
   PPRHIP_TRY(alloc_dev((void**)&P->prep_bits, sizeof(unsigned long long) * kBatch * (n / 64 + 2)));
   PPRHIP_CHECK_HIP(hipMemsetAsync(P->prep_bits, 0, sizeof(unsigned long long) * kBatch * (n / 64 + 2), P->stream));
   PPRHIP_TRY(alloc_dev((void**)&P->d_slot_args, sizeof(SlotArgs) * kBatch));
@@ -382,6 +389,49 @@ void free_batch(pprhip_graph* P) {
   P->blk_pack8 = nullptr;
   P->blk_dead8 = nullptr;
   P->blk_ndead8 = nullptr;
+}
+
+// sweep layout over the out-CSR for batched backward searches (the forward one is built at graph lift)
+int ensure_bwd_layout(pprhip_graph* P) {
+  if (P->start_flags_o) return PPRHIP_OK;
+  const uint32_t n = P->n;
+  const uint64_t m = P->m;
+  const std::vector<uint32_t>& rp = P->h_out_rp;
+  const size_t n_chunks = ((size_t)m + kChunkPad - 1) / kChunkPad;
+  std::vector<uint8_t> flags((n_chunks + 1) * (kChunkPad / 8), 0);
+  std::vector<uint32_t> chunk_starts(n_chunks + 1, 0);
+  std::vector<int32_t> nz, zr;
+  for (uint32_t v = 0; v < n; ++v) {
+    if (rp[v + 1] == rp[v]) {
+      zr.push_back((int32_t)v);
+      continue;
+    }
+    nz.push_back((int32_t)v);
+    const uint32_t e = rp[v];
+    flags[e >> 3] |= (uint8_t)(1u << (e & 7));
+    chunk_starts[(size_t)e / kChunkPad + 1]++;
+  }
+  for (size_t c = 1; c <= n_chunks; ++c) chunk_starts[c] += chunk_starts[c - 1];
+  std::vector<unsigned long long> cross(((size_t)n + 63) / 64 + 1, 0ull);
+  for (size_t j = 0; j < nz.size(); ++j) {
+    const uint32_t v = (uint32_t)nz[j];
+    const uint32_t last = rp[v + 1] - 1;
+    if (rp[v] / kChunkPad != last / kChunkPad || (last + 1) % kChunkPad == 0 || (uint64_t)last + 1 == m)
+      cross[j >> 6] |= 1ull << (j & 63);
+  }
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+    PPRHIP_TRY(alloc_dev(dst, bytes));
+    if (bytes) PPRHIP_CHECK_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return PPRHIP_OK;
+  };
+  P->n_nz_o = (uint32_t)nz.size();
+  P->n_z_o = (uint32_t)zr.size();
+  PPRHIP_TRY(up((void**)&P->chunk_starts_o, chunk_starts.data(), sizeof(uint32_t) * chunk_starts.size()));
+  PPRHIP_TRY(up((void**)&P->nz_rows_o, nz.data(), sizeof(int32_t) * nz.size()));
+  PPRHIP_TRY(up((void**)&P->z_rows_o, zr.data(), sizeof(int32_t) * zr.size()));
+  PPRHIP_TRY(up((void**)&P->cross_bits_o, cross.data(), sizeof(unsigned long long) * cross.size()));
+  PPRHIP_TRY(up((void**)&P->start_flags_o, flags.data(), flags.size()));
+  return PPRHIP_OK;
 }
 
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree) {
@@ -905,7 +955,8 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   free_batch(g);
   void* ptrs[] = {g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags,
-                  g->chunk_starts, g->nz_rows, g->zin_rows, g->cross_bits};
+                  g->chunk_starts, g->nz_rows, g->zin_rows, g->cross_bits, g->start_flags_o, g->chunk_starts_o,
+                  g->nz_rows_o, g->z_rows_o, g->cross_bits_o};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   free_workspace(g);
@@ -1129,7 +1180,7 @@ struct ForaRun {
   bool dead_src = false;
   LevelCtx L;
   PushArgs a;
-  enum Phase { kRoundStart, kLevels, kWalks, kTopkRoundStart, kTopkLevels, kTopkFinal, kDone } phase = kDone;
+  enum Phase { kRoundStart, kLevels, kWalks, kTopkRoundStart, kTopkLevels, kTopkFinal, kBwdLevels, kBwdFinal, kDone } phase = kDone;
   int query = -1;  // batch driver: index of the query this run serves
   bool waiting = false;
   bool in_push = false;  // between a push phase's start and its end (BatchSync: may hold sweeps off)
@@ -1140,6 +1191,9 @@ struct ForaRun {
   int cap = 0, nsel = 0;
   int32_t* ids_out = nullptr;
   double* vals_out = nullptr;
+  // backward searches of All-Pair (kind 2): entries >= threshold of the finished search
+  int32_t target_orig = -1;
+  std::vector<Triple> triples;
 };
 
 }  // namespace pprhip
@@ -1346,6 +1400,71 @@ int topk_step(ForaRun& r, bool yield_dense) {
   }
 }
 
+// One backward search of All-Pair (Backward_Search.java:38-100 + the >= threshold filter of
+// Base_Whole_Graph.java:80-88) as a resumable run.
+int bwd_begin(ForaRun& r, pprhip_graph* g, int32_t target_internal, int32_t target_orig, double alpha, double rmax) {
+  r.g = g;
+  r.kind = 2;
+  r.src = target_internal;
+  r.target_orig = target_orig;
+  r.alpha = alpha;
+  r.rmax_local = rmax;
+  r.triples.clear();
+  std::memset(&r.st, 0, sizeof r.st);
+  g->topk_active = false;
+  PPRHIP_TRY(reset_query_state(g, false));
+  r.waiting = false;
+  r.in_push = false;
+  if (hdeg_in(g, target_internal) == 0) {  // :46-49
+    PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)target_internal, 1.0));
+    r.phase = ForaRun::kBwdFinal;
+    return PPRHIP_OK;
+  }
+  r.a = PushArgs{alpha, rmax, 0.0, target_internal, kBackward};
+  r.L = LevelCtx();
+  PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)target_internal, 1.0));
+  PPRHIP_TRY(seed_single(g, r.L, target_internal, hdeg_in(g, target_internal)));
+  r.in_push = true;
+  r.phase = ForaRun::kBwdLevels;
+  return PPRHIP_OK;
+}
+
+int bwd_step(ForaRun& r, bool yield_dense) {
+  pprhip_graph* g = r.g;
+  if (r.phase == ForaRun::kBwdLevels) {
+    const int rc = run_levels(g, r.a, r.L, r.st, nullptr, yield_dense);
+    if (rc != PPRHIP_OK) return rc;  // kYield or an error
+    leave_push(r);
+    r.phase = ForaRun::kBwdFinal;
+  }
+  if (r.phase == ForaRun::kBwdFinal) {
+    const double threshold = r.rmax_local;
+    unsigned long long thr_bits = 1ull;
+    if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
+    PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits));  // Base_Whole_Graph.java:83 pi >= threshold
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    const uint64_t cnt = g->h_ctr->sel_count;
+    const std::vector<int32_t>& n2o = host_of(g)->h_new2old;
+    if (cnt > g->sel_cap) {
+      std::vector<double> all(g->n);
+      PPRHIP_TRY(copy_out(g, g->reserve, all.data()));
+      for (uint32_t v = 0; v < g->n; ++v)  // copy_out already returned original ids
+        if (all[v] > 0.0 && all[v] >= threshold) r.triples.push_back({(int32_t)v, r.target_orig, all[v]});
+    } else if (cnt) {
+      std::vector<int32_t> ids(cnt);
+      std::vector<double> vals(cnt);
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      for (uint64_t i = 0; i < cnt; ++i) r.triples.push_back({n2o[ids[i]], r.target_orig, vals[i]});
+    }
+    r.phase = ForaRun::kDone;
+  }
+  return PPRHIP_OK;
+}
+
 void add_stats(pprhip_stats_t& sum, const pprhip_stats_t& st) {
   sum.pops += st.pops; sum.edge_pushes += st.edge_pushes; sum.enqueues += st.enqueues;
   sum.dead_end_pops += st.dead_end_pops; sum.dense_nodes += st.dense_nodes; sum.levels += st.levels;
@@ -1413,8 +1532,11 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
     }
   }
   const uint64_t sweep_bytes = 4ull * P->m + (uint64_t)n_active * (8ull * P->m + 36ull * P->n + 4ull);
+  bool backward = false;
+  for (int s = 0; s < kBatch; ++s)
+    if (active[s] && runs[s].a.mode == kBackward) backward = true;  // a job's runs all push the same way
   P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
-  PPRHIP_TRY(launch_dense_level_b8(P));
+  PPRHIP_TRY(launch_dense_level_b8(P, backward));
   P->ktimer.end();
   for (int s = 0; s < kBatch; ++s)
     if (active[s]) {
@@ -1450,18 +1572,31 @@ struct BatchJob {
   double* vals_out;
   int* n_out;
   pprhip_stats_t* per_query;
-  int kind = 0;  // 0: whole-graph FORA per query, 1: FORA top-k per query (seed + query index)
+  int kind = 0;  // 0: whole-graph FORA per query, 1: FORA top-k per query (seed + query index), 2: backward search
+  double alpha = 0.0, threshold = 0.0;   // kind 2
+  std::vector<Triple>* triples = nullptr;  // kind 2: every search's entries >= threshold
   pprhip_stats_t sum;
   std::mutex sum_mu;
   std::atomic<int> next_query{0};
 };
 
-int run_step(ForaRun& r, bool yield_dense) { return r.kind == 1 ? topk_step(r, yield_dense) : fora_step(r, yield_dense); }
+int run_step(ForaRun& r, bool yield_dense) {
+  return r.kind == 2 ? bwd_step(r, yield_dense) : r.kind == 1 ? topk_step(r, yield_dense) : fora_step(r, yield_dense);
+}
 
 // outputs of a finished query (its slot still holds the vectors)
 int finish_query(BatchJob& J, ForaRun& r) {
   pprhip_graph* S = r.g;
   const int i = r.query;
+  if (r.kind == 2) {
+    std::lock_guard<std::mutex> lk(J.sum_mu);
+    J.triples->insert(J.triples->end(), r.triples.begin(), r.triples.end());
+    add_stats(J.sum, r.st);
+    r.triples.clear();
+    r.phase = ForaRun::kDone;
+    r.query = -1;
+    return PPRHIP_OK;
+  }
   if (J.reserve_out) PPRHIP_TRY(copy_out(S, r.kind == 1 ? S->est : S->reserve, J.reserve_out + (size_t)i * J.P->n));
   if (r.kind == 1) {  // the run's final selection wrote the first min(nsel, k) pairs
     for (int j = std::min(r.nsel, J.k); j < J.k; ++j) {
@@ -1494,7 +1629,10 @@ int finish_query(BatchJob& J, ForaRun& r) {
 int begin_query(BatchJob& J, ForaRun& r, pprhip_graph* S, int i) {
   S->tun = J.P->tun;
   const int32_t src = J.P->h_old2new[J.srcs[i]];
-  if (J.kind == 1) {
+  if (J.kind == 2) {
+    pprhip_tuning_batch(&S->tun);  // level shapes only: a backward search has no cost-model decisions
+    PPRHIP_TRY(bwd_begin(r, S, src, J.srcs[i], J.alpha, J.threshold));
+  } else if (J.kind == 1) {
     PPRHIP_TRY(topk_begin(r, S, src, J.eps, J.conf, J.seed + (uint64_t)i, J.ids_out + (size_t)i * J.k,
                           J.vals_out + (size_t)i * J.k, J.k));
   } else {
@@ -1684,11 +1822,12 @@ void BatchSync::sweeper() {
 // runs a prepared job on the handle's slots (both batched entry points)
 static int batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* stats_sum) {
   PPRHIP_TRY(ensure_batch(g));
+  if (J.kind == 2) PPRHIP_TRY(ensure_bwd_layout(g));
   const int q = J.q;
   // Worker threads pay off where queries are latency-bound (top-k: short rounds of sparse levels, walks
   // and selections, 2.4x on R-MAT 22); whole-graph FORA keeps the memory system busy from one thread.
   const char* env = getenv("PPRHIP_BATCH_THREADS");
-  const bool threaded = q > 1 && (env ? env[0] == '1' : J.kind == 1);
+  const bool threaded = q > 1 && (env ? env[0] == '1' : J.kind != 0);
   std::memset(&J.sum, 0, sizeof J.sum);
   ForaRun runs[kBatch];
   g->ktimer.stream = g->stream;
@@ -1725,11 +1864,15 @@ static int batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* stats_sum) 
       S->stream = g->stream;
       S->sync = nullptr;
     }
-    g_timer.stream = g->stream;
-    g_timer.reset();
+    KernelTimer local;  // the caller's timer may be in use (All-Pair times its own tiers)
+    KernelTimer* const saved = g_timer_cur;
+    g_timer_cur = &local;
+    local.stream = g->stream;
     rc = batch_sequential(J, runs);
     (void)hipStreamSynchronize(g->stream);
-    g_timer.resolve(tot, bytes, cnt);
+    local.resolve(tot, bytes, cnt);
+    local.destroy();
+    g_timer_cur = saved;
   }
   (void)hipStreamSynchronize(g->stream);
   if (rc != PPRHIP_OK) return rc;
@@ -2066,56 +2209,75 @@ struct pprhip_index {
 
 namespace {
 
-struct Triple {
-  int32_t v, t;
-  double p;
-};
-
 // Base_Whole_Graph.java:112-163: per source, k < 0 keeps insertion (target) order; k >= 0 keeps
 // entries >= the k-th largest (all when fewer than k) sorted descending (stable: ties stay in
 // target order).
 void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix) {
   ix->n = n;
   ix->offsets.assign((size_t)n + 1, 0);
-  std::stable_sort(tr.begin(), tr.end(), [](const Triple& a, const Triple& b) {
-    if (a.v != b.v) return a.v < b.v;
-    return a.t < b.t;
-  });
-  ix->targets.clear();
-  ix->values.clear();
-  size_t i = 0;
-  for (uint32_t v = 0; v < n; ++v) {
-    ix->offsets[v] = ix->targets.size();
-    size_t b = i;
-    while (i < tr.size() && (uint32_t)tr[i].v == v) ++i;
-    const size_t len = i - b;
-    if (len == 0) continue;
-    if (k < 0) {
-      for (size_t j = b; j < i; ++j) {
-        ix->targets.push_back(tr[j].t);
-        ix->values.push_back(tr[j].p);
-      }
-      continue;
-    }
-    bool have = false;
-    double kth = 0.0;
-    if (k >= 1 && (size_t)k <= len) {
-      std::vector<double> tmp(len);
-      for (size_t j = 0; j < len; ++j) tmp[j] = tr[b + j].p;
-      std::nth_element(tmp.begin(), tmp.begin() + (k - 1), tmp.end(), std::greater<double>());
-      kth = tmp[k - 1];
-      have = true;
-    }
-    std::vector<Triple> keep;
-    for (size_t j = b; j < i; ++j)
-      if (!have || tr[j].p >= kth) keep.push_back(tr[j]);
-    std::stable_sort(keep.begin(), keep.end(), [](const Triple& a, const Triple& b2) { return a.p > b2.p; });
-    for (auto& e : keep) {
-      ix->targets.push_back(e.t);
-      ix->values.push_back(e.p);
-    }
+  // bucket by source (counting sort), then every bucket on its own: order by target, apply the k rule
+  const size_t N = tr.size();
+  std::vector<uint64_t> start((size_t)n + 1, 0);
+  for (const Triple& e : tr) start[(size_t)e.v + 1]++;
+  for (uint32_t v = 0; v < n; ++v) start[v + 1] += start[v];
+  std::vector<Triple> by_v(N);
+  {
+    std::vector<uint64_t> at(start.begin(), start.end() - 1);
+    for (const Triple& e : tr) by_v[at[e.v]++] = e;
   }
-  ix->offsets[n] = ix->targets.size();
+  std::vector<Triple>().swap(tr);
+  std::vector<uint64_t> kept((size_t)n + 1, 0);
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  const unsigned T = N < (1u << 16) ? 1u : hw;
+  auto for_ranges = [&](auto&& fn) {
+    std::vector<std::thread> th;
+    for (unsigned w = 1; w < T; ++w) th.emplace_back(fn, (uint32_t)((uint64_t)n * w / T), (uint32_t)((uint64_t)n * (w + 1) / T));
+    fn(0u, (uint32_t)((uint64_t)n / T));
+    for (auto& x : th) x.join();
+  };
+  // pass 1: each bucket sorted by target; for k >= 0 the kept entries move to the bucket's front, by value
+  for_ranges([&](uint32_t lo, uint32_t hi) {
+    std::vector<double> tmp;
+    for (uint32_t v = lo; v < hi; ++v) {
+      Triple* b = by_v.data() + start[v];
+      const size_t len = (size_t)(start[v + 1] - start[v]);
+      if (len == 0) continue;
+      std::sort(b, b + len, [](const Triple& x, const Triple& y) { return x.t < y.t; });
+      if (k < 0) {
+        kept[v + 1] = len;
+        continue;
+      }
+      bool have = false;
+      double kth = 0.0;
+      if (k >= 1 && (size_t)k <= len) {
+        tmp.resize(len);
+        for (size_t j = 0; j < len; ++j) tmp[j] = b[j].p;
+        std::nth_element(tmp.begin(), tmp.begin() + (k - 1), tmp.end(), std::greater<double>());
+        kth = tmp[k - 1];
+        have = true;
+      }
+      size_t w = 0;
+      for (size_t j = 0; j < len; ++j)
+        if (!have || b[j].p >= kth) b[w++] = b[j];
+      std::stable_sort(b, b + w, [](const Triple& x, const Triple& y) { return x.p > y.p; });
+      kept[v + 1] = w;
+    }
+  });
+  for (uint32_t v = 0; v < n; ++v) kept[v + 1] += kept[v];
+  ix->targets.resize(kept[n]);
+  ix->values.resize(kept[n]);
+  for (uint32_t v = 0; v <= n; ++v) ix->offsets[v] = kept[v];
+  // pass 2: into the index arrays
+  for_ranges([&](uint32_t lo, uint32_t hi) {
+    for (uint32_t v = lo; v < hi; ++v) {
+      const Triple* b = by_v.data() + start[v];
+      const size_t len = (size_t)(kept[v + 1] - kept[v]);
+      for (size_t j = 0; j < len; ++j) {
+        ix->targets[kept[v] + j] = b[j].t;
+        ix->values[kept[v] + j] = b[j].p;
+      }
+    }
+  });
 }
 
 }  // namespace
@@ -2234,32 +2396,44 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   release();
   if (rc != PPRHIP_OK) return rc;
 
-  // ---- tier 3: the few targets whose search outgrows a 48K-node table run on the whole vectors
-  std::vector<int32_t> ids(g->sel_cap);
-  std::vector<double> vals(g->sel_cap);
-  unsigned long long thr_bits = 1ull;
-  if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
-  for (int32_t t : to_tier3) {  // Base_Whole_Graph.java:76-92
-    PPRHIP_TRY(backward_push_impl(g, g->h_old2new[t], alpha, threshold, st));
-    PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits));  // :83 pi >= threshold
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, g->stream));
-    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-    const uint64_t cnt = g->h_ctr->sel_count;
-    if (cnt > g->sel_cap) {
-      std::vector<double> all(g->n);
-      PPRHIP_TRY(copy_out(g, g->reserve, all.data()));
-      for (uint32_t v = 0; v < g->n; ++v)  // copy_out already returned original ids
-        if (all[v] > 0.0 && all[v] >= threshold) tr.push_back({(int32_t)v, t, all[v]});
-    } else if (cnt) {
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
-      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-      for (uint64_t i = 0; i < cnt; ++i) tr.push_back({g->h_new2old[ids[i]], t, vals[i]});
-    }
+  // ---- tier 3: the targets whose search outgrows a 48K-node table run on whole vectors, 16 of them in flight
+  // on the batch slots; levels that touch a large part of the graph run as batched sweeps over the out-CSR
+  pprhip_stats_t st3;
+  std::memset(&st3, 0, sizeof st3);
+  if (!to_tier3.empty()) {  // Base_Whole_Graph.java:76-92
+    BatchJob J;
+    J.P = g;
+    J.kind = 2;
+    J.srcs = to_tier3.data();
+    J.q = (int)to_tier3.size();
+    J.eps = 0.0;
+    J.conf = nullptr;
+    J.seed = 0;
+    J.n_rounds = 0;
+    J.reserve_out = nullptr;
+    J.k = 0;
+    J.ids_out = nullptr;
+    J.vals_out = nullptr;
+    J.n_out = nullptr;
+    J.per_query = nullptr;
+    J.alpha = alpha;
+    J.threshold = threshold;
+    J.triples = &tr;
+    PPRHIP_TRY(batch_run(g, J, &st3));
+    st.pops += st3.pops;
+    st.edge_pushes += st3.edge_pushes;
+    st.enqueues += st3.enqueues;
+    st.levels += st3.levels;
+    st.dense_levels += st3.dense_levels;
+    st.push_bytes += st3.push_bytes;
   }
   tm.mark(1);
   tm.finish(st);
+  for (int c = 0; c < 8; ++c) {
+    st.class_ms[c] += st3.class_ms[c];
+    st.class_bytes[c] += st3.class_bytes[c];
+    st.class_launches[c] += st3.class_launches[c];
+  }
   st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
   st.rmax_final = threshold;
   st.rounds = (uint32_t)(to_tier2.size());      // targets that needed the HBM tier

@@ -140,6 +140,13 @@ struct pprhip_graph {
   int c8cur = 0;
   double* acc8 = nullptr;      // [n_nz][kBatch] row sums
   int32_t* zin_rows = nullptr;  // rows without in-edges
+  // the same sweep layout over the out-CSR (backward search: a row pulls from its out-neighbours), built on
+  // the first batched backward call
+  uint8_t* start_flags_o = nullptr;
+  uint32_t* chunk_starts_o = nullptr;
+  int32_t *nz_rows_o = nullptr, *z_rows_o = nullptr;  // rows with / without out-edges
+  uint32_t n_nz_o = 0, n_z_o = 0;
+  unsigned long long* cross_bits_o = nullptr;
   unsigned long long* cross_bits = nullptr;  // per row ordinal (non-empty rows first): row spans two 512-edge chunks
   unsigned long long* prep_bits = nullptr;   // [kBatch][tiles]: rows holding a contribution after the last sweep
   uint32_t n_zin = 0;
@@ -191,7 +198,7 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
                        unsigned long long dense_thresh, int dead_slot);
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot);
 constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply kernel (per-slot partials each)
-int launch_dense_level_b8(pprhip_graph* parent);  // slot arguments already staged in parent->h_slot_args
+int launch_dense_level_b8(pprhip_graph* parent, bool backward);  // slot arguments already staged in parent->h_slot_args
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);
 int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot);
 int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter);

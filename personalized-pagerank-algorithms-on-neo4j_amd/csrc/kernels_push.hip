@@ -683,6 +683,7 @@ __global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __rest
                                                             const int32_t* __restrict__ zin_rows, uint32_t n_zin,
                                                             double* __restrict__ acc8,
                                                             const uint32_t* __restrict__ out_rp,
+                                                            const uint32_t* __restrict__ in_rp_bwd,
                                                             double* __restrict__ c8_next,
                                                             const SlotArgs* __restrict__ slots,
                                                             const unsigned long long* __restrict__ cross_bits,
@@ -693,6 +694,7 @@ __global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __rest
   __shared__ double tile[kApplyRows][kBatch + 1];
   __shared__ int32_t s_u[kApplyRows];
   __shared__ uint32_t s_d[kApplyRows];
+  __shared__ uint32_t s_din[kApplyRows];  // backward sweeps: in-degree = edges the row pushes when it is popped
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t n_rows = n_nz + n_zin;
   const uint32_t n_tiles = (n_rows + kApplyRows - 1) / kApplyRows;
@@ -731,16 +733,33 @@ __global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __rest
       const int32_t u = j < n_nz ? nz_rows[j] : (j < n_rows ? zin_rows[j - n_nz] : -1);
       s_u[tid] = u;
       s_d[tid] = u >= 0 ? out_rp[u + 1] - out_rp[u] : 0u;
+      s_din[tid] = (u >= 0 && in_rp_bwd) ? in_rp_bwd[u + 1] - in_rp_bwd[u] : 0u;
     }
     __syncthreads();
     const int32_t u = s_u[lane];
     const uint32_t d = s_d[lane];
+    const uint32_t din = s_din[lane];
 #pragma unroll
     for (int i = 0; i < kSlotsPerWave; ++i) {
       const int s = w * kSlotsPerWave + i;
       double acc = tile[lane][s];
       double cn = 0.0;
-      if (a[i].active && u >= 0) {
+      if (a[i].active && u >= 0 && a[i].mode == kBackward) {
+        // Backward_Search.java:73-96 in pull form: the row's out-neighbours' (1 - alpha) * residue, divided by
+        // this row's out-degree; strict un-normalised threshold
+        if (acc > 0.0) {
+          const double old = a[i].res[u];
+          const double nw = old + acc / (double)d;
+          if (!(old > a[i].rmax) && nw > a[i].rmax) {
+            a[i].reserve[u] = a[i].reserve[u] + nw * a[i].alpha;
+            a[i].res[u] = 0.0;
+            cn = (1.0 - a[i].alpha) * nw;
+            pack[i] += (1ull << kPackShift) | (unsigned long long)din;
+          } else {
+            a[i].res[u] = nw;
+          }
+        }
+      } else if (a[i].active && u >= 0) {
         if (u == a[i].src) {
           const double dd = a[i].ctr->dead[a[i].dead_slot];
           if (dd > 0.0) {
@@ -1126,12 +1145,13 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
 }
 
 template <int G>
-static int launch_dense_edges_bG(pprhip_graph* g, const double* cB, double* accB) {
+static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8_t* start_flags,
+                                 const uint32_t* chunk_starts, const double* cB, double* accB) {
   if (!g->n_chunks) return PPRHIP_OK;
   const uint32_t hot_max = (uint32_t)(kHotBytes / (8 * G));
   const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, hot_max) : 0u;
   const uint32_t want = (g->n_chunks + 15) / 16;
-  const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(g->start_flags);
+  const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(start_flags);
   if (n_hot) {
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
@@ -1141,28 +1161,36 @@ static int launch_dense_edges_bG(pprhip_graph* g, const double* cB, double* accB
     }
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
     k_dense_edges_b<true, G><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * G, g->stream>>>(
-        g->in_ci, flags64, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, cB, accB, n_hot);
+        ci, flags64, chunk_starts, g->n_chunks, (unsigned long long)g->m, cB, accB, n_hot);
   } else {
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
     k_dense_edges_b<false, G><<<dim3(grid), dim3(1024), 0, g->stream>>>(
-        g->in_ci, flags64, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, cB, accB, 0u);
+        ci, flags64, chunk_starts, g->n_chunks, (unsigned long long)g->m, cB, accB, 0u);
   }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
-int launch_dense_level_b8(pprhip_graph* P) {
+int launch_dense_level_b8(pprhip_graph* P, bool backward) {
   PPRHIP_CHECK_HIP(hipMemcpyAsync(P->d_slot_args, P->h_slot_args, sizeof(SlotArgs) * kBatch, hipMemcpyHostToDevice,
                                   P->stream));
-  PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, P->c8[P->c8cur], P->acc8));
+  // forward levels pull over the in-CSR, backward levels over the out-CSR
+  const int32_t* ci = backward ? P->out_ci : P->in_ci;
+  const uint8_t* flags = backward ? P->start_flags_o : P->start_flags;
+  const uint32_t* cstarts = backward ? P->chunk_starts_o : P->chunk_starts;
+  const int32_t* nz = backward ? P->nz_rows_o : P->nz_rows;
+  const int32_t* zr = backward ? P->z_rows_o : P->zin_rows;
+  const uint32_t n_nz = backward ? P->n_nz_o : P->n_nz, n_z = backward ? P->n_z_o : P->n_zin;
+  const unsigned long long* cross = backward ? P->cross_bits_o : P->cross_bits;
+  PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8));
   const uint32_t grid = grid_for(P->n, kApplyRows, kApplyBlocks8);
-  k_dense_apply_batch<<<dim3(grid), dim3(256), 0, P->stream>>>(P->nz_rows, P->n_nz, P->zin_rows, P->n_zin, P->acc8,
-                                                            P->out_rp, P->c8[P->c8cur ^ 1], P->d_slot_args,
-                                                            P->cross_bits, P->prep_bits, P->blk_pack8, P->blk_dead8,
-                                                            P->blk_ndead8);
+  k_dense_apply_batch<<<dim3(grid), dim3(256), 0, P->stream>>>(nz, n_nz, zr, n_z, P->acc8, P->out_rp,
+                                                               backward ? P->in_rp : nullptr, P->c8[P->c8cur ^ 1],
+                                                               P->d_slot_args, cross, P->prep_bits, P->blk_pack8,
+                                                               P->blk_dead8, P->blk_ndead8);
   PPRHIP_CHECK_HIP(hipGetLastError());
   k_dense_reduce_batch<<<dim3(kBatch), dim3(1024), 0, P->stream>>>(P->blk_pack8, P->blk_dead8, P->blk_ndead8, grid,
-                                                                P->d_slot_args);
+                                                                   P->d_slot_args);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -1172,9 +1200,10 @@ int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned lo
   if (g->parent) {
     pprhip_graph* P = g->parent;
     const uint32_t n_tiles = (P->n + kApplyRows - 1) / kApplyRows;
-    k_compact_bits<<<dim3(grid), dim3(256), 0, g->stream>>>(P->n, P->n_nz, P->prep_bits + (size_t)g->slot_index * n_tiles,
-                                                            P->nz_rows, P->zin_rows, cview(g, cbuf), g->out_rp,
-                                                            g->F[out_fbuf], g->eoff[out_fbuf], g->cF, d_counter);
+    k_compact_bits<<<dim3(grid), dim3(256), 0, g->stream>>>(
+        P->n, backward ? P->n_nz_o : P->n_nz, P->prep_bits + (size_t)g->slot_index * n_tiles,
+        backward ? P->nz_rows_o : P->nz_rows, backward ? P->z_rows_o : P->zin_rows, cview(g, cbuf),
+        backward ? g->in_rp : g->out_rp, g->F[out_fbuf], g->eoff[out_fbuf], g->cF, d_counter);
   } else {
     k_compact_prepared<<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, cview(g, cbuf), false,
                                                                 backward ? g->in_rp : g->out_rp, g->F[out_fbuf],
