@@ -2389,7 +2389,8 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   }
   if (rc == PPRHIP_OK && !to_tier2.empty()) {
     B.g_cap = 65536;
-    B.g_blocks = (uint32_t)std::min<size_t>((size_t)g->n_cus, to_tier2.size());
+    // 8 workgroups per CU: the HBM tier is a chain of L2 round trips per edge, hidden only by occupancy
+    B.g_blocks = (uint32_t)std::min<size_t>((size_t)g->n_cus * 8, to_tier2.size());
     rc = alloc_dev((void**)&B.g_tables, (size_t)B.g_blocks * B.g_cap * 40);
     if (rc == PPRHIP_OK) rc = run_tier(true, to_tier2, false, to_tier3);
   }
