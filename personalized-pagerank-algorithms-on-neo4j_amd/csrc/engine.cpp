@@ -313,9 +313,10 @@ void free_workspace(pprhip_graph* g) {
     if (e) (void)hipEventDestroy(e);
 }
 
+void free_batch(pprhip_graph* P);
+
 // Batch slots and the interleaved dense-level arrays, created on the first batched call.
-int ensure_batch(pprhip_graph* P) {
-  if (!P->slots.empty()) return PPRHIP_OK;
+int build_batch(pprhip_graph* P) {
   const size_t n = P->n;
   for (int i = 0; i < 2; ++i) {
     PPRHIP_TRY(alloc_dev((void**)&P->c8[i], sizeof(double) * n * kBatch));
@@ -368,6 +369,13 @@ int ensure_batch(pprhip_graph* P) {
   }
   PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
   return PPRHIP_OK;
+}
+
+int ensure_batch(pprhip_graph* P) {
+  if (!P->slots.empty()) return PPRHIP_OK;
+  const int rc = build_batch(P);
+  if (rc != PPRHIP_OK) free_batch(P);  // e.g. out of memory half-way: leave no partial batch state behind
+  return rc;
 }
 
 void free_batch(pprhip_graph* P) {

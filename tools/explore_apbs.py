@@ -1,6 +1,7 @@
 """Times All-Pair-Backward-Search on an R-MAT graph (developer tool)."""
 import argparse, importlib, os, sys, time
 import numpy as np
+import torch  # noqa: F401  (loads the HIP runtime first)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
