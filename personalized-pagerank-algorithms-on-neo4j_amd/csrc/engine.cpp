@@ -393,6 +393,7 @@ void free_batch(pprhip_graph* P) {
     if (p) (void)hipFree(p);
   if (P->h_slot_args) (void)hipHostFree(P->h_slot_args);
   P->c8[0] = P->c8[1] = P->acc8 = nullptr;
+  P->acc8_dir = 0;
   P->d_slot_args = P->h_slot_args = nullptr;
   P->blk_pack8 = nullptr;
   P->blk_dead8 = nullptr;
@@ -1543,6 +1544,11 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
   bool backward = false;
   for (int s = 0; s < kBatch; ++s)
     if (active[s] && runs[s].a.mode == kBackward) backward = true;  // a job's runs all push the same way
+  if ((int)backward != P->acc8_dir) {
+    // rows summed with atomics are cleared by the apply kernel of their own layout only: start clean
+    PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * ((size_t)P->n + 1) * kBatch, P->stream));
+    P->acc8_dir = (int)backward;
+  }
   P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
   PPRHIP_TRY(launch_dense_level_b8(P, backward));
   P->ktimer.end();
@@ -1883,7 +1889,12 @@ static int batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* stats_sum) 
     g_timer_cur = saved;
   }
   (void)hipStreamSynchronize(g->stream);
-  if (rc != PPRHIP_OK) return rc;
+  if (rc != PPRHIP_OK) {
+    const std::string msg = get_error();
+    free_batch(g);  // slots may hold half-pushed levels: the next batched call builds clean ones
+    set_error("%s", msg.c_str());
+    return rc;
+  }
   g->ktimer.resolve(tot, bytes, cnt);
   pprhip_stats_t& sum = J.sum;
   sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -138,7 +138,8 @@ struct pprhip_graph {
   std::vector<pprhip_graph*> slots;
   double* c8[2] = {nullptr, nullptr};
   int c8cur = 0;
-  double* acc8 = nullptr;      // [n_nz][kBatch] row sums
+  double* acc8 = nullptr;      // [row ordinal][kBatch] row sums
+  int acc8_dir = 0;            // layout the row sums were last written in (0 forward, 1 backward)
   int32_t* zin_rows = nullptr;  // rows without in-edges
   // the same sweep layout over the out-CSR (backward search: a row pulls from its out-neighbours), built on
   // the first batched backward call

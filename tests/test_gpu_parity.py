@@ -389,6 +389,33 @@ def test_all_pair_tiers_rmat12(pkg, orc, rmat12, dev_rmat12, tier, monkeypatch):
         ix.close()
 
 
+def test_batch_directions_share_a_handle(pkg, orc, rmat12, dev_rmat12, monkeypatch):
+    """Forward batches and batched backward searches (All-Pair tier 3) alternate on one handle: the shared sweep
+    arrays are handed over clean in both directions."""
+    og = to_oracle(orc, rmat12)
+    srcs = sources(rmat12, 9, seed=31)
+    t = pkg.tuning_batch()
+    dev_rmat12.set_tuning(t)
+    monkeypatch.setenv("PPRHIP_APBS_TIER", "3")
+    try:
+        for _ in range(2):
+            out, _, _, _, pq, _ = dev_rmat12.fora_batch_single_source(srcs, 0.5, ALPHA, seed=2, n_rounds=2, fetch=True,
+                                                                      per_query=True)
+            for i, s in enumerate(srcs):
+                ref, sto = og.fora_whole(s, 0.5, ALPHA, seed=2, n_rounds=2, schedule=orc.SYNC,
+                                         tuning=to_orc_tuning(orc, t))
+                assert pq[i].walks == sto.walks
+                assert_close(out[i], ref, TOL_MC, "forward batch src=%d" % s)
+            ix, st = dev_rmat12.all_pair_backward(ALPHA, 2e-5, -1, 100, 140)
+            off, tg, vl = ix.arrays()
+            ooff, otg, ovl = og.all_pair_backward(ALPHA, 2e-5, -1, 100, 140, schedule=orc.SYNC)
+            assert st.dense_levels > 0                      # the backward sweeps ran
+            assert np.array_equal(off, ooff) and np.array_equal(tg, otg) and np.max(np.abs(vl - ovl)) <= 1e-12
+            ix.close()
+    finally:
+        dev_rmat12.set_tuning(pkg.tuning_default())
+
+
 def test_all_pair_whole_rmat12_counts(pkg, orc, rmat12, dev_rmat12):
     """Every target of the graph in one call; hub targets overflow the LDS table and are finished by the
     HBM tier.  Pops and edge pushes equal the twin's."""
