@@ -214,12 +214,36 @@ def main():
             "graph_lift_s": {"generate_and_csr": round(t_gen, 2), "upload_and_tile": round(t_lift, 2)},
             "roofline": roofline,
         }
+        if world == 1 and args.mode == "batch":
+            out["one_query_at_a_time"] = single_mode_sample(pkg, g, srcs[args.warmup], outdeg, conf, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, srcs[args.warmup:], outdeg, live_frac, args.cpu_walk_divisor)
         print(json.dumps(out), flush=True)
     g.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def single_mode_sample(pkg, g, srcs, outdeg, conf, args):
+    """The same queries through pprhip_fora_single_source, one after another (latency path; outside the timed
+    region): the first 32 sources of the first timed step, default cost-model profile."""
+    g.set_tuning(pkg.tuning_default())
+    sample = [int(s) for s in srcs[:32]]
+    g.fora_single_source(sample[0], EPS, ALPHA, seed=1, n_rounds=args.rounds, conf=conf, fetch=False)
+    ms, by, n_lv, live = 0.0, 0, 0, 0
+    t0 = time.perf_counter()
+    for j, s in enumerate(sample):
+        _, st = g.fora_single_source(s, EPS, ALPHA, seed=3 + j, n_rounds=args.rounds, conf=conf, fetch=False)
+        ms += st.class_ms[1]
+        by += st.class_bytes[1]
+        n_lv += st.class_launches[1]
+        live += int(outdeg[s] > 0)
+    dt = time.perf_counter() - t0
+    return {"value": round(len(sample) / dt, 3), "unit": "queries/s", "queries": len(sample),
+            "ms_per_live_query": round(1e3 * dt / max(1, live), 3),
+            "dense_pull": {"launches": n_lv, "avg_launch_us": round(1e3 * ms / max(1, n_lv), 2),
+                           "achieved_GBps": round((by / 1e9) / (ms / 1e3), 1) if ms > 0 else 0.0,
+                           "frac": round((by / 1e9) / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else 0.0}}
 
 
 def cpu_baseline(host, srcs, outdeg, live_frac, walk_divisor):

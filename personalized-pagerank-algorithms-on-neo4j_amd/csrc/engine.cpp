@@ -70,7 +70,7 @@ struct LevelCtx {
 // kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
 thread_local KernelTimer g_timer_own;
 thread_local KernelTimer* g_timer_cur = &g_timer_own;
-#define g_timer (*g_timer_cur)
+inline KernelTimer& ktimer() { return *g_timer_cur; }
 
 int alloc_dev(void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes ? bytes : 8);
@@ -176,9 +176,9 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       if (L.dense_run == 0)
         PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur ^ 1], 0, sizeof(double) * g->n, g->stream));
       const int out = L.pslot ^ 1;
-      g_timer.begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
+      ktimer().begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
       PPRHIP_TRY(launch_dense_level(g, a, L.ccur, out, L.dslot));
-      g_timer.end();
+      ktimer().end();
       if (L.dense_run == 0)
         PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
       uint32_t nf_next = 0;
@@ -200,14 +200,14 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       PPRHIP_TRY(write_hist0(g, L.nf, L.ef));
     }
     if (g->sync) g->sync->release(g->slot_index);
-    g_timer.begin(PPRHIP_KERNEL_SPARSE_PUSH, 0);
+    ktimer().begin(PPRHIP_KERNEL_SPARSE_PUSH, 0);
     for (int i = 0; i < kMaxBatch; ++i) {
       const int fb = L.fcur ^ (i & 1);
       if (!(i == 0 && first_prepared))
         PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot));
       PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot));
     }
-    g_timer.end();
+    ktimer().end();
     PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->hist[0], &g->ctr->hist[0], sizeof(unsigned long long) * (kMaxBatch + 1),
                                     hipMemcpyDeviceToHost, g->stream));
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
@@ -234,8 +234,8 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       ran++;
     }
     st.push_bytes += batch_bytes;
-    if (!g_timer.recs.empty() && g_timer.recs.back().cls == PPRHIP_KERNEL_SPARSE_PUSH)
-      g_timer.recs.back().bytes = batch_bytes;
+    if (!ktimer().recs.empty() && ktimer().recs.back().cls == PPRHIP_KERNEL_SPARSE_PUSH)
+      ktimer().recs.back().bytes = batch_bytes;
     L.nf = (uint32_t)(g->h_ctr->hist[ran] >> kPackShift);
     L.ef = g->h_ctr->hist[ran] & kPackMask;
     if (ran & 1) L.fcur ^= 1;
@@ -511,9 +511,9 @@ int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   const uint64_t n_src = g->h_ctr->mc_packed >> kPackShift;
   const uint64_t n_walks = g->h_ctr->mc_packed & kPackMask;
-  g_timer.begin(PPRHIP_KERNEL_WALK, 0);
+  ktimer().begin(PPRHIP_KERNEL_WALK, 0);
   PPRHIP_TRY(launch_mc_walk(g, n_src, n_walks, alpha, seed, stream, variant == 0 ? 1 : 0, target));
-  g_timer.end();
+  ktimer().end();
   PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->walk_steps, &g->ctr->walk_steps, sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
@@ -522,15 +522,15 @@ int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long
   st.walk_steps += g->h_ctr->walk_steps;
   const uint64_t bytes = 12ull * g->h_ctr->walk_steps + 16ull * n_walks + 12ull * n_src;
   st.mc_bytes += bytes;
-  if (!g_timer.recs.empty() && g_timer.recs.back().cls == PPRHIP_KERNEL_WALK) g_timer.recs.back().bytes = bytes;
+  if (!ktimer().recs.empty() && ktimer().recs.back().cls == PPRHIP_KERNEL_WALK) ktimer().recs.back().bytes = bytes;
   return PPRHIP_OK;
 }
 
 struct CallTimer {
   pprhip_graph* g;
   explicit CallTimer(pprhip_graph* g_) : g(g_) {
-    g_timer.stream = g->stream;
-    g_timer.reset();
+    ktimer().stream = g->stream;
+    ktimer().reset();
     (void)hipEventRecord(g->ev[0], g->stream);
   }
   void mark(int i) { (void)hipEventRecord(g->ev[i], g->stream); }
@@ -547,7 +547,7 @@ struct CallTimer {
     double tot[8] = {0};
     uint64_t bytes[8] = {0};
     uint32_t cnt[8] = {0};
-    g_timer.resolve(tot, bytes, cnt);
+    ktimer().resolve(tot, bytes, cnt);
     int best = 0;
     for (int c = 1; c < 8; ++c)
       if (tot[c] > tot[best]) best = c;
@@ -2105,16 +2105,16 @@ int pprhip_monte_carlo(pprhip_graph_t* g, int32_t src, double eps, const pprhip_
     st.walks = nw;
   } else {
     PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->walk_steps, 0, sizeof(unsigned long long), g->stream));
-    g_timer.begin(PPRHIP_KERNEL_WALK, 0);
+    ktimer().begin(PPRHIP_KERNEL_WALK, 0);
     PPRHIP_TRY(launch_mc_pure(g, src, nw, conf->alpha, seed, 1.0 / omega, g->reserve));
-    g_timer.end();
+    ktimer().end();
     PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->walk_steps, &g->ctr->walk_steps, sizeof(unsigned long long),
                                     hipMemcpyDeviceToHost, g->stream));
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     st.walks = nw;
     st.walk_steps = g->h_ctr->walk_steps;
     st.mc_bytes = 12ull * st.walk_steps + 16ull * nw + 12ull;
-    if (!g_timer.recs.empty()) g_timer.recs.back().bytes = st.mc_bytes;
+    if (!ktimer().recs.empty()) ktimer().recs.back().bytes = st.mc_bytes;
   }
   st.mc_sources = 1;
   st.omega = omega;
@@ -2192,9 +2192,9 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
     for (int it = 1; it < iters; ++it) {
       const int out = L.pslot ^ 1;
       if (it == 1) PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur ^ 1], 0, sizeof(double) * g->n, g->stream));
-      g_timer.begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
+      ktimer().begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
       PPRHIP_TRY(launch_dense_level(g, a, L.ccur, out, L.dslot));
-      g_timer.end();
+      ktimer().end();
       if (it == 1) PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
       L.ccur ^= 1;
       L.dslot ^= 1;
@@ -2360,9 +2360,9 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
       }
       const unsigned long long init[8] = {0, 0, ~0ull, 0, 0, 0, 0, 0};
       PPRHIP_CHECK_HIP(hipMemcpyAsync(cells, init, sizeof init, hipMemcpyHostToDevice, g->stream));
-      g_timer.begin(PPRHIP_KERNEL_BACKWARD_BATCH, 0);
+      ktimer().begin(PPRHIP_KERNEL_BACKWARD_BATCH, 0);
       PPRHIP_TRY(launch_apbs(g, global_tier, use_range ? nullptr : d_list, t_begin, cnt, alpha, threshold, B));
-      g_timer.end();
+      ktimer().end();
       PPRHIP_CHECK_HIP(hipMemcpyAsync(h_cells, cells, sizeof h_cells, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
       const unsigned long long valid = std::min(std::min(h_cells[1], h_cells[2]), B.out_cap);
@@ -2370,7 +2370,7 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
       st.edge_pushes += h_cells[5];
       const uint64_t bytes = 44ull * h_cells[4] + 28ull * h_cells[5] + 16ull * valid;
       st.push_bytes += bytes;
-      if (!g_timer.recs.empty()) g_timer.recs.back().bytes = bytes;
+      if (!ktimer().recs.empty()) ktimer().recs.back().bytes = bytes;
       if (valid) {
         h_v.resize(valid); h_t.resize(valid); h_p.resize(valid);
         PPRHIP_CHECK_HIP(hipMemcpyAsync(h_v.data(), B.out_v, sizeof(int32_t) * valid, hipMemcpyDeviceToHost, g->stream));
