@@ -5,9 +5,13 @@ loops targets), so the CSR is replicated and the work is sharded with no data-pa
 
   * batched FORA: query i runs on rank i mod world; the only exchange is a gather of the per-query
     top-k blocks to rank 0;
-  * All-Pair-Backward-Search: rank r owns the contiguous target range target_range(r); its shard
-    index (entries keyed by source) is gathered to rank 0 and merged there with the reference's
-    k rule (pprhip_index_merge).
+  * All-Pair-Backward-Search: rank r owns the contiguous target range target_range(r).  The result
+    is keyed by *source* (Base_Whole_Graph.java:84-86), so one exchange follows: either every shard
+    index is gathered to rank 0 and merged there (gather_index: small graphs), or - the form that
+    scales - rank r also owns the sources target_range(r) and every rank sends each owner its rows
+    (exchange_index_by_source: one all-to-all, a message per peer, i.e. per xGMI link), after which
+    each rank merges the partial lists of its own sources with the reference's k rule
+    (pprhip_index_merge) and holds that slice of the index.
 
 Backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  Only plain tensors travel.
 """
@@ -81,3 +85,43 @@ def gather_index(dist, torch, offsets, targets, values, rank, world, device="cpu
         c = int(cnts[r].item())
         out.append((go[r].cpu().numpy().astype(np.uint64), gt[r].cpu().numpy()[:c], gv[r].cpu().numpy()[:c]))
     return out
+
+
+def exchange_index_by_source(dist, torch, offsets, targets, values, rank, world, n, device="cpu"):
+    """All-Pair's exchange by owner of the source.  `offsets/targets/values` is this rank's shard index
+    (rows = all n sources, entries = its own targets).  Returns `world` partial indexes restricted to
+    the sources this rank owns, as (offsets[n + 1], targets, values) ready for index_from_arrays +
+    merge_indexes; rows outside the owned range are empty.  Rows arrive in target-shard order
+    (sender 0 first), which is the reference's target-iteration order."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    targets = np.asarray(targets, dtype=np.int32)
+    values = np.asarray(values, dtype=np.float64)
+    ranges = [target_range(r, world, n) for r in range(world)]
+    lo, hi = ranges[rank]
+    lengths = np.diff(offsets)
+    if world == 1:
+        return [(offsets.astype(np.uint64), targets, values)]
+    # 1) row lengths of every owner's range (split sizes are the range sizes, known everywhere)
+    len_send = torch.as_tensor(lengths, dtype=torch.int64, device=device)
+    len_recv = torch.empty((hi - lo) * world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(len_recv, len_send, output_split_sizes=[hi - lo] * world,
+                           input_split_sizes=[e - b for b, e in ranges])
+    # 2) the entries themselves: to owner o go the entries of rows [begin_o, end_o), contiguous in the CSR-style arrays
+    cnt_send = [int(offsets[e] - offsets[b]) for b, e in ranges]
+    len_recv_np = len_recv.cpu().numpy().reshape(world, hi - lo)
+    cnt_recv = [int(x) for x in len_recv_np.sum(axis=1)]
+    tg_recv = torch.empty(sum(cnt_recv), dtype=torch.int32, device=device)
+    vl_recv = torch.empty(sum(cnt_recv), dtype=torch.float64, device=device)
+    dist.all_to_all_single(tg_recv, torch.as_tensor(targets, device=device), output_split_sizes=cnt_recv,
+                           input_split_sizes=cnt_send)
+    dist.all_to_all_single(vl_recv, torch.as_tensor(values, device=device), output_split_sizes=cnt_recv,
+                           input_split_sizes=cnt_send)
+    tg_np, vl_np = tg_recv.cpu().numpy(), vl_recv.cpu().numpy()
+    parts, at = [], 0
+    for p in range(world):
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[lo + 1:hi + 1] = np.cumsum(len_recv_np[p])
+        off[hi + 1:] = off[hi]
+        parts.append((off, tg_np[at:at + cnt_recv[p]], vl_np[at:at + cnt_recv[p]]))
+        at += cnt_recv[p]
+    return parts

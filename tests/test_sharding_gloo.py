@@ -52,6 +52,11 @@ def _worker(rank, world, port, outdir):
         # ---- All-Pair-Backward-Search: contiguous target ranges, gather shard arrays, merge on rank 0
         lo, hi = sh.target_range(rank, world, got.n)
         off, tg, vl = og.all_pair_backward(A, 1e-3, -1, lo, hi)
+        # the exchange that scales: every rank ends with the merged lists of the sources it owns
+        mine_parts = sh.exchange_index_by_source(dist, torch, off, tg, vl, rank, world, got.n)
+        own = pkg.merge_indexes([pkg.index_from_arrays(got.n, o, t, v) for o, t, v in mine_parts], 3)
+        o_off, o_tg, o_vl = own.arrays()
+        np.savez(os.path.join(outdir, "own%d.npz" % rank), off=o_off, tg=o_tg, vl=o_vl, lo=lo, hi=hi)
         shards = sh.gather_index(dist, torch, off, tg, vl, rank, world)
         if rank == 0:
             parts = [pkg.index_from_arrays(got.n, o, t, v) for o, t, v in shards]
@@ -80,6 +85,15 @@ def test_two_rank_gloo(tmp_path, orc, got):
         assert np.all(d["ids"][i][len(ti):] == -1)
     off, tg, vl = og.all_pair_backward(A, 1e-3, 3)
     assert np.array_equal(d["off"], off) and np.array_equal(d["tg"], tg) and np.array_equal(d["vl"], vl)
+    # the all-to-all form: rank r holds exactly the rows of its own sources, equal to the unsharded result
+    for r in range(2):
+        o = np.load(tmp_path / ("own%d.npz" % r))
+        lo, hi = int(o["lo"]), int(o["hi"])
+        assert o["off"][lo] == 0 and o["off"][-1] == o["off"][hi]                # nothing outside [lo, hi)
+        for v in range(lo, hi):
+            a, b = int(o["off"][v]), int(o["off"][v + 1])
+            c, e = int(off[v]), int(off[v + 1])
+            assert np.array_equal(o["tg"][a:b], tg[c:e]) and np.array_equal(o["vl"][a:b], vl[c:e])
 
 
 def test_shard_helpers(pkg):
