@@ -121,6 +121,8 @@ int write_hist0(pprhip_graph* g, uint32_t nf, uint64_t ef) {
   return PPRHIP_OK;
 }
 
+int ensure_bwd_layout(pprhip_graph* P);
+
 constexpr int kYield = 1;  // run_levels: the next level is dense and the caller runs it (batched sweeps)
 
 // bookkeeping after a dense level: the frontier it produced becomes the current one
@@ -148,8 +150,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
   const bool bwd = a.mode == kBackward;
   const bool slot = g->parent != nullptr;
   // smallest integer x with (double)x >= dense_frac * m: the device-side form of level_cost()'s test
-  // backward levels run dense only on batch slots (the sweep over the out-CSR exists in batched form)
-  const bool sparse_only = bwd && !slot;
+  const bool sparse_only = false;  // every push direction has both level shapes
   const unsigned long long dense_thresh =
       sparse_only ? ~0ull : (unsigned long long)std::ceil(g->tun.dense_frac * (double)g->m);
   while (L.nf > 0) {
@@ -158,6 +159,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     if (sparse_only) dense = false;
     if (dense) {
       if (model_cost) *model_cost += c;
+      if (bwd && !slot) PPRHIP_TRY(ensure_bwd_layout(g));  // sweep layout over the out-CSR, built on first use
       if (!L.dense_prepared) {
         if (slot) {
           if (g->sync) g->sync->c8_enter(g->slot_index);

@@ -603,6 +603,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
                                                       double* __restrict__ acc_nz,
                                                       const uint32_t* __restrict__ out_rp,
+                                                      const uint32_t* __restrict__ in_rp,
                                                       double* __restrict__ c_next, double* __restrict__ res,
                                                       double* __restrict__ reserve, uint8_t* __restrict__ flags,
                                                       DevCounters* ctr, unsigned long long* __restrict__ blk_pack,
@@ -636,7 +637,22 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
     }
     const uint32_t d = out_rp[u + 1] - out_rp[u];
     double cn = 0.0;
-    if (acc > 0.0) {
+    if (MODE == kBackward) {
+      // Backward_Search.java:73-96 in pull form over the out-CSR: the row's out-neighbours gave (1 - alpha) *
+      // residue each, this row takes its share 1 / d_out; strict un-normalised threshold (:89)
+      if (acc > 0.0) {
+        const double old = res[u];
+        const double nw = old + acc / (double)d;
+        if (!(old > a.rmax) && nw > a.rmax) {
+          reserve[u] = reserve[u] + nw * a.alpha;
+          res[u] = 0.0;
+          cn = (1.0 - a.alpha) * nw;
+          pack = (1ull << kPackShift) | (unsigned long long)(in_rp[u + 1] - in_rp[u]);
+        } else {
+          res[u] = nw;
+        }
+      }
+    } else if (acc > 0.0) {
       const double old = res[u];
       const double nw = old + acc;
       const bool crossing = (MODE == kPower) ? true : (!active_fwd(old, d, a.rmax) && active_fwd(nw, d, a.rmax));
@@ -1105,6 +1121,13 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
 }
 
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot) {
+  // forward levels pull over the in-CSR, backward levels over the out-CSR (layout built by the caller)
+  const bool bwd = a.mode == kBackward;
+  const int32_t* ci = bwd ? g->out_ci : g->in_ci;
+  const uint8_t* flags = bwd ? g->start_flags_o : g->start_flags;
+  const uint32_t* cstarts = bwd ? g->chunk_starts_o : g->chunk_starts;
+  const int32_t* nz = bwd ? g->nz_rows_o : g->nz_rows;
+  const uint32_t n_nz = bwd ? g->n_nz_o : g->n_nz;
   if (g->n_chunks) {
     // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
     const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
@@ -1119,22 +1142,20 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
       }
       const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
       k_dense_edges<true><<<dim3(grid), dim3(1024), sizeof(double) * n_hot, g->stream>>>(
-          g->in_ci, g->start_flags, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz,
-          n_hot);
+          ci, flags, cstarts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, n_hot);
     } else {
       const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
       k_dense_edges<false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
-          g->in_ci, g->start_flags, g->chunk_starts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz,
-          0u);
+          ci, flags, cstarts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, 0u);
     }
     PPRHIP_CHECK_HIP(hipGetLastError());
   }
   // a source without in-edges still receives returned dead-end mass: one extra apply thread
-  const int src_extra = (a.mode != kBackward && a.src >= 0 && g->h_in_rp[a.src + 1] == g->h_in_rp[a.src]) ? 1 : 0;
-  const uint32_t grid = (g->n_nz + (uint32_t)src_extra + 255) / 256;
+  const int src_extra = (!bwd && a.src >= 0 && g->h_in_rp[a.src + 1] == g->h_in_rp[a.src]) ? 1 : 0;
+  const uint32_t grid = (n_nz + (uint32_t)src_extra + 255) / 256;
   if (grid) {
     DISPATCH_MODE(a.mode, k_dense_apply<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                              g->nz_rows, g->n_nz, g->acc_nz, g->out_rp, g->cdense[cbuf ^ 1], g->residue, g->reserve,
+                              nz, n_nz, g->acc_nz, g->out_rp, g->in_rp, g->cdense[cbuf ^ 1], g->residue, g->reserve,
                               g->flags, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead, dead_slot, src_extra, a));
     PPRHIP_CHECK_HIP(hipGetLastError());
   }

@@ -349,7 +349,9 @@ def test_backward_push_got(pkg, orc, got, dev_got, rmax):
         po, ro, sto = og.backward_push(t, ALPHA, rmax, orc.SYNC)
         assert_close(p, po, TOL_PUSH, "bwd reserve t=%d" % t)
         assert_close(r, ro, TOL_PUSH, "bwd residue t=%d" % t)
-        assert st.levels == sto.levels and st.pops == sto.pops and st.edge_pushes == sto.edge_pushes
+        # dense levels count their nodes apart (the twin's backward search has one level shape)
+        assert st.levels == sto.levels and st.pops + st.dense_nodes == sto.pops
+        assert st.dense_levels > 0 or st.edge_pushes == sto.edge_pushes
 
 
 def test_backward_push_rmat12(pkg, orc, rmat12, dev_rmat12):
@@ -359,6 +361,30 @@ def test_backward_push_rmat12(pkg, orc, rmat12, dev_rmat12):
         po, ro, sto = og.backward_push(t, ALPHA, 1e-5, orc.SYNC)
         assert_close(p, po, TOL_PUSH, "bwd reserve t=%d" % t)
         assert_close(r, ro, TOL_PUSH, "bwd residue t=%d" % t)
+
+
+@pytest.mark.parametrize("dense_frac", [0.01, 0.05, 1e9])
+def test_backward_push_level_shapes(pkg, orc, rmat12, dev_rmat12, rmat15, dev_rmat15, dense_frac):
+    """Backward levels that touch much of the graph run as pull sweeps over the out-CSR; every switch point
+    gives the twin's vectors."""
+    t = pkg.tuning_default()
+    t.dense_frac = dense_frac
+    for host, dev, rmax in ((rmat12, dev_rmat12, 1e-7), (rmat15, dev_rmat15, 1e-6)):
+        og = to_oracle(orc, host)
+        dev.set_tuning(t)
+        try:
+            hub = int(np.argmax(np.diff(host.in_rp)))
+            for tgt in [hub] + sources(host, 3, seed=12):
+                p, r, st = dev.backward_push(tgt, ALPHA, rmax)
+                po, ro, sto = og.backward_push(tgt, ALPHA, rmax, orc.SYNC)
+                assert st.levels == sto.levels
+                assert_close(p, po, TOL_PUSH, "backward reserve t=%d" % tgt)
+                assert_close(r, ro, TOL_PUSH, "backward residue t=%d" % tgt)
+            if dense_frac < 1:
+                p, r, st = dev.backward_push(hub, ALPHA, rmax)
+                assert st.dense_levels > 0          # the hub's search does go dense
+        finally:
+            dev.set_tuning(pkg.tuning_default())
 
 
 @pytest.mark.parametrize("k", [-1, 3, 10])

@@ -102,7 +102,7 @@ def test_backward_push_and_all_pair_sample(orc, rmat20, dev20):
     for t in [int(x) for x in rng.integers(0, rmat20.n, 3)]:
         p, r, st = dev20.backward_push(t, A, 1e-4)
         po, ro, sto = og.backward_push(t, A, 1e-4, orc.SYNC)
-        assert np.max(np.abs(p - po)) <= 1e-12 and st.pops == sto.pops
+        assert np.max(np.abs(p - po)) <= 1e-12 and st.pops + st.dense_nodes == sto.pops
         assert np.all(r <= 1e-4) and (idg[t] > 0 or p[t] == 1.0)
     lo = 5000
     ix, st = dev20.all_pair_backward(A, 1e-3, 8, lo, lo + 2000)
