@@ -32,3 +32,4 @@ if a.cpu:
         og.backward_push(t, 0.15, a.thr, orc.FIFO)
     dt = time.time() - t0
     print("cpu oracle FIFO: %d targets in %.2fs = %.1f targets/s (dense-array port, incl. O(n) clears)" % (a.cpu, dt, a.cpu / dt))
+g.close()
