@@ -18,7 +18,9 @@ are gathered to rank 0 over RCCL.
 
 Extra objects on the JSON line: `roofline` (dominant kernel, HIP-event time on the engine's
 stream, algorithmic bytes from DESIGN.md's byte model) and `cpu_baseline` (the CPU oracle's
-clock-driven FIFO FORA, one core, bounded sample; rank 0 at N = 1 only).
+clock-driven FIFO FORA, one core, bounded sample; rank 0 at N = 1 only); after the timed region,
+at N = 1, also `one_query_at_a_time` (the same queries through the single-query entry point)
+and `all_pair_sample` (All-Pair-Backward-Search on 2^18 targets of the same graph).
 """
 import argparse
 import importlib
@@ -216,6 +218,8 @@ def main():
         }
         if world == 1 and args.mode == "batch":
             out["one_query_at_a_time"] = single_mode_sample(pkg, g, srcs[args.warmup], outdeg, conf, args)
+        if world == 1 and args.mode == "batch":
+            out["all_pair_sample"] = all_pair_sample(pkg, g, host)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, srcs[args.warmup:], outdeg, live_frac, args.cpu_walk_divisor)
         print(json.dumps(out), flush=True)
@@ -244,6 +248,23 @@ def single_mode_sample(pkg, g, srcs, outdeg, conf, args):
             "dense_pull": {"launches": n_lv, "avg_launch_us": round(1e3 * ms / max(1, n_lv), 2),
                            "achieved_GBps": round((by / 1e9) / (ms / 1e3), 1) if ms > 0 else 0.0,
                            "frac": round((by / 1e9) / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else 0.0}}
+
+
+def all_pair_sample(pkg, g, host):
+    """The path's other workload, All-Pair-Backward-Search (config #5), on a bounded target range of the same
+    graph (outside the timed region): 2^18 targets, threshold 1e-3, k = 32, index finalised on the host."""
+    g.set_tuning(pkg.tuning_default())
+    nt = min(host.n, 1 << 18)
+    ix, _ = g.all_pair_backward(ALPHA, 1e-3, TOPK, 0, min(nt, 4096))
+    ix.close()
+    t0 = time.perf_counter()
+    ix, st = g.all_pair_backward(ALPHA, 1e-3, TOPK, 0, nt)
+    dt = time.perf_counter() - t0
+    entries = int(len(ix.arrays()[1]))
+    ix.close()
+    return {"value": round(nt / dt, 1), "unit": "targets/s", "targets": nt, "threshold": 1e-3, "k": TOPK,
+            "index_entries": entries, "tier2_targets": int(st.rounds), "tier3_targets": int(st.dense_nodes),
+            "device_ms": round(st.total_ms, 1)}
 
 
 def cpu_baseline(host, srcs, outdeg, live_frac, walk_divisor):
