@@ -213,6 +213,7 @@ def main():
             "kernel_ms_per_live_query": {pkg.KERNEL_NAMES[c]: round(acc["class_ms"][c] / max(1, acc["live"]), 3)
                                          for c in (1, 2, 3, 5) if acc["class_launches"][c]},
             "dense_levels_per_live_query": round(acc["dense_levels"] / max(1, acc["live"]), 1),
+            "levels_per_live_query": round(acc["levels"] / max(1, acc["live"]), 1),
             "graph_lift_s": {"generate_and_csr": round(t_gen, 2), "upload_and_tile": round(t_lift, 2)},
             "roofline": roofline,
         }

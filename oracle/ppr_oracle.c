@@ -240,11 +240,24 @@ static double level_model_cost(const orc_graph* g, const orc_tuning* t, uint64_t
   return t->c_level_ns + t->c_edge_ns * (double)ef + t->c_pop_ns * (double)nf;
 }
 
+/* FORA rounds that are certain to be followed by another halving do not need their sparse tail: the
+ * nodes it would push are picked up by the next round's lower threshold.  The engine and this twin end
+ * such a round after the first sparse level that follows its dense levels (a round without dense
+ * levels is short anyway).  fixed: the caller knows another round follows; otherwise the round loop's
+ * own condition (model cost so far < c_walk * rsum * omega) is evaluated at that point. */
+typedef struct round_cut {
+  int enabled, fixed, had_dense, checked, taken;
+  double omega, c_walk;
+} round_cut;
+
+static double sum_array(const double* a, uint32_t n);
+
 /* Runs levels from the frontier in w->cur until it is empty.  One level = every frontier node
  * pushed at once from its residue at level start (Forward_Push.java:86-139 per node).
  * parked/min_rmax != NULL adds the second threshold of forward_push_topk (:226-237). */
 static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double rmax, double* reserve, double* residue,
-                            sync_ws* w, uint8_t* parked, double min_rmax, const orc_tuning* tun, orc_stats* st) {
+                            sync_ws* w, uint8_t* parked, double min_rmax, const orc_tuning* tun, orc_stats* st,
+                            round_cut* cut) {
   uint32_t d_s = deg_out(g, s);
   while (w->ncur) {
     uint64_t ef = 0;
@@ -300,6 +313,19 @@ static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double 
         st->edge_pushes += ef;
       }
       st->enqueues += w->nnxt;
+      if (cut && cut->enabled) {
+        if (dense) {
+          cut->had_dense = 1;
+        } else if (cut->had_dense && !cut->checked) {
+          cut->checked = 1;
+          int more = 1;
+          if (!cut->fixed) more = st->model_cost_ns < cut->c_walk * (sum_array(residue, g->n) * (1 - alpha)) * cut->omega;
+          if (more) {
+            cut->taken = 1;
+            w->nnxt = 0; /* the rest of this round's frontier waits for the next threshold */
+          }
+        }
+      }
     }
     int32_t* t = w->cur; w->cur = w->nxt; w->nxt = t;
     w->ncur = w->nnxt;
@@ -326,7 +352,7 @@ static double fwd_push_sync(const orc_graph* g, int32_t s, double alpha, double 
   residue[s] = 1.0;
   w.cur[0] = s; /* the source is pushed unconditionally first (:81-86) */
   w.ncur = 1;
-  fwd_levels_sync(g, s, alpha, rmax, reserve, residue, &w, NULL, 0.0, tun, st);
+  fwd_levels_sync(g, s, alpha, rmax, reserve, residue, &w, NULL, 0.0, tun, st, NULL);
   sync_ws_free(&w);
   return sum_array(residue, n);
 }
@@ -511,7 +537,7 @@ static double topk_round_sync(orc_topk_push* p, double min_rmax, double rmax, or
   }
   orc_tuning tun;
   orc_tuning_default(&tun);
-  fwd_levels_sync(g, s, p->alpha, rmax, p->reserve, p->residue, &p->w, p->parked, min_rmax, &tun, st);
+  fwd_levels_sync(g, s, p->alpha, rmax, p->reserve, p->residue, &p->w, p->parked, min_rmax, &tun, st, NULL);
   p->rsum = sum_array(p->residue, n);
   p->first = 0;
   return p->rsum;
@@ -652,7 +678,13 @@ void orc_fora_whole(const orc_graph* g, int schedule, int32_t src, double eps, c
         for (uint32_t v = 0; v < n; ++v)
           if (active_fwd(residue[v], deg_out(g, (int32_t)v), rmax_local)) w.cur[w.ncur++] = (int32_t)v;
       }
-      fwd_levels_sync(g, src, alpha, rmax_local, reserve, residue, &w, NULL, 0.0, &tun, st);
+      round_cut cut;
+      memset(&cut, 0, sizeof cut);
+      cut.fixed = n_rounds > 0;
+      cut.enabled = n_rounds > 0 ? rounds + 1 < n_rounds : rounds + 1 < tun.max_rounds;
+      cut.omega = omega_local;
+      cut.c_walk = tun.c_walk_ns;
+      fwd_levels_sync(g, src, alpha, rmax_local, reserve, residue, &w, NULL, 0.0, &tun, st, &cut);
       rsum_local = sum_array(residue, n) * (1 - alpha);
       rmax_used = rmax_local;
       rmax_local /= 2.0;

@@ -67,6 +67,17 @@ struct LevelCtx {
   int dense_run = 0;  // dense levels run since the current dense phase was seeded
 };
 
+// FORA rounds that are certain to be followed by another halving do not need their sparse tail: what it
+// would push is picked up by the next round's lower threshold.  Such a round ends after the first sparse
+// level that follows its dense levels.  fixed: the caller knows another round follows; otherwise the round
+// loop's own condition (model cost so far < c_walk * rsum * omega) is evaluated at that point.  The test
+// twin applies the same rule (oracle/ppr_oracle.c: round_cut).
+struct RoundCut {
+  bool enabled = false, fixed = false, had_dense = false, checked = false, taken = false;
+  double omega = 0.0, c_walk = 0.0, alpha = 0.0;
+  double rsum = 0.0;  // (1 - alpha) * residue sum measured at the check (valid when !fixed and checked)
+};
+
 // kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
 thread_local KernelTimer g_timer_own;
 thread_local KernelTimer* g_timer_cur = &g_timer_own;
@@ -145,8 +156,10 @@ void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_
 // levels are launched kMaxBatch at a time and continue on the device (kernels_push.hip).  With
 // yield_dense the function prepares a dense level and returns kYield instead of running it: the
 // batch driver runs one sweep for every slot waiting at that point and calls back in.
+int device_sum(pprhip_graph* g, const double* x, double* out);
+
 int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost,
-               bool yield_dense = false) {
+               bool yield_dense = false, RoundCut* cut = nullptr) {
   const bool bwd = a.mode == kBackward;
   const bool slot = g->parent != nullptr;
   // smallest integer x with (double)x >= dense_frac * m: the device-side form of level_cost()'s test
@@ -159,6 +172,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     if (sparse_only) dense = false;
     if (dense) {
       if (model_cost) *model_cost += c;
+      if (cut) cut->had_dense = true;
       if (bwd && !slot) PPRHIP_TRY(ensure_bwd_layout(g));  // sweep layout over the out-CSR, built on first use
       if (!L.dense_prepared) {
         if (slot) {
@@ -202,8 +216,11 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       PPRHIP_TRY(write_hist0(g, L.nf, L.ef));
     }
     if (g->sync) g->sync->release(g->slot_index);
+    // the round-cut check looks at the state after exactly one sparse level
+    const bool cut_check = cut && cut->enabled && cut->had_dense && !cut->checked;
+    const int n_batch = cut_check ? 1 : kMaxBatch;
     ktimer().begin(PPRHIP_KERNEL_SPARSE_PUSH, 0);
-    for (int i = 0; i < kMaxBatch; ++i) {
+    for (int i = 0; i < n_batch; ++i) {
       const int fb = L.fcur ^ (i & 1);
       if (!(i == 0 && first_prepared))
         PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot));
@@ -215,7 +232,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     uint64_t batch_bytes = 0;
     int ran = 0;
-    for (int i = 0; i < kMaxBatch; ++i) {
+    for (int i = 0; i < n_batch; ++i) {
       // level i ran with the frontier the host knows (i == 0) or the one level i-1 produced
       const uint32_t nf_i = i == 0 ? L.nf : (uint32_t)(g->h_ctr->hist[i] >> kPackShift);
       const uint64_t ef_i = i == 0 ? L.ef : (g->h_ctr->hist[i] & kPackMask);
@@ -241,6 +258,21 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     L.nf = (uint32_t)(g->h_ctr->hist[ran] >> kPackShift);
     L.ef = g->h_ctr->hist[ran] & kPackMask;
     if (ran & 1) L.fcur ^= 1;
+    if (cut_check) {
+      cut->checked = true;
+      bool more = true;
+      if (!cut->fixed) {
+        double sum = 0.0;
+        PPRHIP_TRY(device_sum(g, g->residue, &sum));
+        cut->rsum = sum * (1 - cut->alpha);
+        more = model_cost && *model_cost < cut->c_walk * cut->rsum * cut->omega;
+      }
+      if (more) {
+        cut->taken = true;
+        L.nf = 0;  // the rest of this round's frontier waits for the next threshold
+        L.ef = 0;
+      }
+    }
   }
   return PPRHIP_OK;
 }
@@ -740,10 +772,11 @@ void pprhip_tuning_default(pprhip_tuning_t* t) {
 void pprhip_tuning_batch(pprhip_tuning_t* t) {
   pprhip_tuning_default(t);
   if (!t) return;
-  // fitted on R-MAT 22 with all slots busy: a sweep of 1.6 ms serves ~14.5 queries
+  // fitted on R-MAT 22 with all slots busy: a sweep of 1.6 ms serves ~14.5 queries; a level that touches
+  // fewer than 2 % of the edges is cheaper as a sparse level (one memory-side atomic per edge)
   t->c_dense_edge_ns = 0.002;
   t->c_dense_node_ns = 0.003;
-  t->dense_frac = 0.01;
+  t->dense_frac = 0.02;
 }
 
 int pprhip_conf_fora_whole_graph(uint32_t n, uint64_t m, double alpha, pprhip_fora_conf_t* c) {
@@ -1191,6 +1224,7 @@ struct ForaRun {
   bool dead_src = false;
   LevelCtx L;
   PushArgs a;
+  RoundCut cut;
   enum Phase { kRoundStart, kLevels, kWalks, kTopkRoundStart, kTopkLevels, kTopkFinal, kBwdLevels, kBwdFinal, kDone } phase = kDone;
   int query = -1;  // batch driver: index of the query this run serves
   bool waiting = false;
@@ -1262,6 +1296,12 @@ int fora_step(ForaRun& r, bool yield_dense) {
         continue;
       }
       r.a = PushArgs{r.alpha, r.rmax_local, 0.0, r.src, kFwdWhole};
+      r.cut = RoundCut();
+      r.cut.fixed = r.n_rounds > 0;
+      r.cut.enabled = r.n_rounds > 0 ? r.rounds + 1 < r.n_rounds : r.rounds + 1 < g->tun.max_rounds;
+      r.cut.omega = r.omega_local;
+      r.cut.c_walk = g->tun.c_walk_ns;
+      r.cut.alpha = r.alpha;
       if (r.rounds == 0) {
         PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)r.src, 1.0));
         PPRHIP_TRY(seed_single(g, r.L, r.src, hdeg_out(g, r.src)));
@@ -1271,11 +1311,15 @@ int fora_step(ForaRun& r, bool yield_dense) {
       r.phase = ForaRun::kLevels;
     }
     if (r.phase == ForaRun::kLevels) {
-      const int rc = run_levels(g, r.a, r.L, r.st, &r.model_cost, yield_dense);
+      const int rc = run_levels(g, r.a, r.L, r.st, &r.model_cost, yield_dense, &r.cut);
       if (rc != PPRHIP_OK) return rc;  // kYield or an error
-      double sum = 0.0;
-      PPRHIP_TRY(device_sum(g, g->residue, &sum));
-      r.rsum_local = sum * (1 - r.alpha);  // :101 (rsum is the exact residue sum here)
+      if (r.cut.taken && !r.cut.fixed) {
+        r.rsum_local = r.cut.rsum;  // measured when the round was cut; nothing was pushed since
+      } else {
+        double sum = 0.0;
+        PPRHIP_TRY(device_sum(g, g->residue, &sum));
+        r.rsum_local = sum * (1 - r.alpha);  // :101 (rsum is the exact residue sum here)
+      }
       r.rmax_used = r.rmax_local;
       r.rmax_local /= 2.0;  // :102
       r.rounds++;

@@ -46,6 +46,13 @@ def assert_close(a, b, tol, what):
     assert err <= TOL_SPEC
 
 
+def to_orc_tuning(orc, t):
+    o = orc.tuning_default()
+    for f, _ in o._fields_:
+        setattr(o, f, getattr(t, f))
+    return o
+
+
 def sources(host, count, seed=2):
     rng = np.random.default_rng(seed)
     return [int(x) for x in rng.integers(0, host.n, size=count)]
@@ -176,7 +183,8 @@ def test_fora_batch_got(pkg, orc, got, dev_got, dense_frac):
                                                                             k=10, fetch=True, per_query=True)
             assert st.levels == sum(x.levels for x in pq)
             for i, s in enumerate(srcs):
-                ref, sto = og.fora_whole(s, 0.5, ALPHA, seed=3, n_rounds=n_rounds, schedule=orc.SYNC)
+                ref, sto = og.fora_whole(s, 0.5, ALPHA, seed=3, n_rounds=n_rounds, schedule=orc.SYNC,
+                                         tuning=to_orc_tuning(orc, t))   # level shapes decide where a round is cut
                 assert pq[i].rounds == sto.rounds and pq[i].levels == sto.levels
                 assert pq[i].walks == sto.walks and pq[i].walk_steps == sto.walk_steps
                 assert_close(out[i], ref, TOL_MC, "batch src=%d" % s)
@@ -190,13 +198,6 @@ def test_fora_batch_got(pkg, orc, got, dev_got, dense_frac):
                 assert np.all(ids[i][m:] == -1) and np.all(vals[i][m:] == 0.0)
     finally:
         dev_got.set_tuning(pkg.tuning_default())
-
-
-def to_orc_tuning(orc, t):
-    o = orc.tuning_default()
-    for f, _ in o._fields_:
-        setattr(o, f, getattr(t, f))
-    return o
 
 
 @pytest.mark.parametrize("threads", ["0", "1"])
