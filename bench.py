@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--mode", choices=["batch", "single"], default="batch")
     ap.add_argument("--rounds", type=int, default=0, help="FORA threshold rounds (0 = cost model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the one-query-at-a-time and All-Pair samples")
     ap.add_argument("--cpu-walk-divisor", type=int, default=16)
     ap.add_argument("--tuning", default="", help="cost-model overrides, e.g. c_dense_edge_ns=0.002,max_rounds=30")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -217,9 +218,9 @@ def main():
             "graph_lift_s": {"generate_and_csr": round(t_gen, 2), "upload_and_tile": round(t_lift, 2)},
             "roofline": roofline,
         }
-        if world == 1 and args.mode == "batch":
+        if world == 1 and args.mode == "batch" and not args.no_extras:
             out["one_query_at_a_time"] = single_mode_sample(pkg, g, srcs[args.warmup], outdeg, conf, args)
-        if world == 1 and args.mode == "batch":
+        if world == 1 and args.mode == "batch" and not args.no_extras:
             out["all_pair_sample"] = all_pair_sample(pkg, g, host)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, srcs[args.warmup:], outdeg, live_frac, args.cpu_walk_divisor)

@@ -101,8 +101,10 @@ typedef struct pprhip_tuning {
   double c_dense_edge_ns;  /* modelled cost per edge of a dense pull sweep */
   double c_dense_node_ns;  /* modelled cost per node of a dense pull sweep */
   double dense_frac;       /* a level runs dense when frontier_edges + frontier_nodes >= dense_frac * m */
-  int32_t max_rounds;      /* cap on threshold halvings in auto mode (default 24) */
-  int32_t reserved;
+  int32_t max_rounds;      /* cap on push rounds in auto mode (default 24) */
+  int32_t max_halvings;    /* halvings of rmax one round may be followed by (default 6) */
+  double halving_ratio;    /* a round is followed by 1 + k halvings when the modelled walk cost is still
+                            * >= halving_ratio^k times the push cost so far (default 2) */
 } pprhip_tuning_t;
 
 /* Parameters Algo_Conf derives (Algo_Conf.java:29-81). */

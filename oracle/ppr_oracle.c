@@ -54,7 +54,8 @@ void orc_tuning_default(orc_tuning* t) {
   t->c_dense_node_ns = 0.02;
   t->dense_frac = 0.05;
   t->max_rounds = 24;
-  t->reserved = 0;
+  t->max_halvings = 6;
+  t->halving_ratio = 2.0;
 }
 
 /* ------------------------------------------------------------------ Philox4x32-10 */
@@ -688,6 +689,16 @@ void orc_fora_whole(const orc_graph* g, int schedule, int32_t src, double eps, c
       rsum_local = sum_array(residue, n) * (1 - alpha);
       rmax_used = rmax_local;
       rmax_local /= 2.0;
+      /* The reference's loop would turn again (and restart the push from scratch at half the threshold) as
+       * long as the push stays cheaper than the walks; when the walks outweigh the push so far by ratio^k, the
+       * engine and this twin take k further halvings at once instead of pushing at every threshold between. */
+      if (n_rounds == 0 && st->model_cost_ns > 0.0 && tun.halving_ratio > 1.0) {
+        double ratio = tun.c_walk_ns * rsum_local * omega_local / st->model_cost_ns;
+        for (int h = 1; ratio >= tun.halving_ratio && h < tun.max_halvings; ++h) {
+          ratio /= tun.halving_ratio;
+          rmax_local /= 2.0;
+        }
+      }
       rounds++;
       if (n_rounds > 0 && !(rsum_local > 0.0)) break;
     }

@@ -366,6 +366,11 @@ int build_batch(pprhip_graph* P) {
     return PPRHIP_ERR_OOM;
   }
   std::memset(P->h_slot_args, 0, sizeof(SlotArgs) * kBatch);
+  PPRHIP_TRY(alloc_dev((void**)&P->sweep_out, sizeof(unsigned long long) * kBatch));
+  if (hipHostMalloc((void**)&P->h_sweep_out, sizeof(unsigned long long) * kBatch, hipHostMallocDefault) != hipSuccess) {
+    set_error("hipHostMalloc failed");
+    return PPRHIP_ERR_OOM;
+  }
   PPRHIP_TRY(alloc_dev((void**)&P->blk_pack8, sizeof(unsigned long long) * kBatch * kApplyBlocks8));
   PPRHIP_TRY(alloc_dev((void**)&P->blk_dead8, sizeof(double) * kBatch * kApplyBlocks8));
   PPRHIP_TRY(alloc_dev((void**)&P->blk_ndead8, sizeof(uint32_t) * kBatch * kApplyBlocks8));
@@ -421,7 +426,10 @@ void free_batch(pprhip_graph* P) {
   }
   P->ktimer.destroy();
   P->slots.clear();
-  void* ptrs[] = {P->c8[0], P->c8[1], P->acc8, P->prep_bits, P->d_slot_args, P->blk_pack8, P->blk_dead8, P->blk_ndead8};
+  void* ptrs[] = {P->c8[0], P->c8[1], P->acc8, P->prep_bits, P->d_slot_args, P->sweep_out, P->blk_pack8, P->blk_dead8,
+                  P->blk_ndead8};
+  if (P->h_sweep_out) (void)hipHostFree(P->h_sweep_out);
+  P->sweep_out = P->h_sweep_out = nullptr;
   P->prep_bits = nullptr;
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -766,7 +774,8 @@ void pprhip_tuning_default(pprhip_tuning_t* t) {
   t->c_dense_node_ns = 0.02;
   t->dense_frac = 0.05;
   t->max_rounds = 24;
-  t->reserved = 0;
+  t->max_halvings = 6;
+  t->halving_ratio = 2.0;
 }
 
 void pprhip_tuning_batch(pprhip_tuning_t* t) {
@@ -1035,6 +1044,8 @@ int pprhip_graph_set_tuning(pprhip_graph_t* g, const pprhip_tuning_t* t) {
   if (!(g->tun.c_dense_node_ns > 0)) g->tun.c_dense_node_ns = d.c_dense_node_ns;
   if (!(g->tun.dense_frac > 0)) g->tun.dense_frac = d.dense_frac;
   if (g->tun.max_rounds <= 0) g->tun.max_rounds = d.max_rounds;
+  if (g->tun.max_halvings <= 0) g->tun.max_halvings = d.max_halvings;
+  if (!(g->tun.halving_ratio > 0)) g->tun.halving_ratio = d.halving_ratio;  // a value <= 1 switches the rule off
   return PPRHIP_OK;
 }
 
@@ -1322,6 +1333,16 @@ int fora_step(ForaRun& r, bool yield_dense) {
       }
       r.rmax_used = r.rmax_local;
       r.rmax_local /= 2.0;  // :102
+      // The reference's loop would turn again (and restart the push from scratch at half the threshold) as
+      // long as the push stays cheaper than the walks; when the walks outweigh the push so far by ratio^k, k
+      // further halvings are taken at once instead of pushing at every threshold between (the twin does the same).
+      if (r.n_rounds == 0 && r.model_cost > 0.0 && g->tun.halving_ratio > 1.0) {
+        double ratio = g->tun.c_walk_ns * r.rsum_local * r.omega_local / r.model_cost;
+        for (int h = 1; ratio >= g->tun.halving_ratio && h < g->tun.max_halvings; ++h) {
+          ratio /= g->tun.halving_ratio;
+          r.rmax_local /= 2.0;
+        }
+      }
       r.rounds++;
       r.phase = (r.n_rounds > 0 && !(r.rsum_local > 0.0)) ? ForaRun::kWalks : ForaRun::kRoundStart;
       continue;
@@ -1598,19 +1619,14 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
   P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
   PPRHIP_TRY(launch_dense_level_b8(P, backward));
   P->ktimer.end();
-  for (int s = 0; s < kBatch; ++s)
-    if (active[s]) {
-      pprhip_graph* S = P->slots[s];
-      const int out = P->h_slot_args[s].out_slot;
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(&S->h_ctr->packed[out], &S->ctr->packed[out], sizeof(unsigned long long),
-                                      hipMemcpyDeviceToHost, P->stream));
-    }
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(P->h_sweep_out, P->sweep_out, sizeof(unsigned long long) * kBatch,
+                                  hipMemcpyDeviceToHost, P->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
   P->c8cur ^= 1;
   for (int s = 0; s < kBatch; ++s)
     if (active[s]) {
       ForaRun& r = runs[s];
-      const unsigned long long pk = P->slots[s]->h_ctr->packed[P->h_slot_args[s].out_slot];
+      const unsigned long long pk = P->h_sweep_out[s];
       // the sweep's index stream is shared: each query is charged its own gathers and row work
       finish_dense(r.L, r.st, 8ull * P->m + 36ull * P->n + 4ull + 4ull * P->m / (uint64_t)n_active,
                    (uint32_t)(pk >> kPackShift), pk & kPackMask);

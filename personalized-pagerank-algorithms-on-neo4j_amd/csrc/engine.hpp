@@ -153,6 +153,8 @@ struct pprhip_graph {
   uint32_t n_zin = 0;
   pprhip::SlotArgs* d_slot_args = nullptr;
   pprhip::SlotArgs* h_slot_args = nullptr;  // pinned
+  unsigned long long* sweep_out = nullptr;    // [kBatch] frontier counters a sweep produced
+  unsigned long long* h_sweep_out = nullptr;  // pinned
   unsigned long long* blk_pack8 = nullptr;  // [kBatch][kApplyBlocks8]
   double* blk_dead8 = nullptr;
   uint32_t* blk_ndead8 = nullptr;

@@ -837,7 +837,8 @@ __global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __rest
 __global__ __launch_bounds__(1024) void k_dense_reduce_batch(const unsigned long long* __restrict__ blk_pack8,
                                                            const double* __restrict__ blk_dead8,
                                                            const uint32_t* __restrict__ blk_ndead8, uint32_t n_blocks,
-                                                           const SlotArgs* __restrict__ slots) {
+                                                           const SlotArgs* __restrict__ slots,
+                                                           unsigned long long* __restrict__ sweep_out) {
   __shared__ double s_red[16];
   __shared__ unsigned long long s_red2[16];
   const SlotArgs a = slots[blockIdx.x];
@@ -854,6 +855,7 @@ __global__ __launch_bounds__(1024) void k_dense_reduce_batch(const unsigned long
   const double ds = block_sum_f64(dead, s_red);
   if (threadIdx.x == 0) {
     a.ctr->packed[a.out_slot] = ps;
+    sweep_out[blockIdx.x] = ps;  // all slots' new frontier counters side by side: one read-back per sweep
     if (nd) {
       a.ctr->dead[a.dead_slot ^ 1] = a.ctr->dead[a.dead_slot ^ 1] + ds;
       a.ctr->dead_pops += nd;
@@ -1211,7 +1213,7 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward) {
                                                                P->blk_dead8, P->blk_ndead8);
   PPRHIP_CHECK_HIP(hipGetLastError());
   k_dense_reduce_batch<<<dim3(kBatch), dim3(1024), 0, P->stream>>>(P->blk_pack8, P->blk_dead8, P->blk_ndead8, grid,
-                                                                   P->d_slot_args);
+                                                                   P->d_slot_args, P->sweep_out);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
