@@ -105,6 +105,10 @@ typedef struct pprhip_tuning {
   int32_t max_halvings;    /* halvings of rmax one round may be followed by (default 6) */
   double halving_ratio;    /* a round is followed by 1 + k halvings when the modelled walk cost is still
                             * >= halving_ratio^k times the push cost so far (default 2) */
+  int32_t prior_levels;    /* the first round starts below rmax0 by as many halvings as keep the a-priori walk
+                            * bound c_walk * omega * (1 - alpha) * rmax * m >= prior_levels dense levels' cost
+                            * (default 16; negative: always start at rmax0) */
+  int32_t reserved;
 } pprhip_tuning_t;
 
 /* Parameters Algo_Conf derives (Algo_Conf.java:29-81). */

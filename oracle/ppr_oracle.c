@@ -56,6 +56,8 @@ void orc_tuning_default(orc_tuning* t) {
   t->max_rounds = 24;
   t->max_halvings = 6;
   t->halving_ratio = 2.0;
+  t->prior_levels = 16;
+  t->reserved = 0;
 }
 
 /* ------------------------------------------------------------------ Philox4x32-10 */
@@ -659,6 +661,19 @@ void orc_fora_whole(const orc_graph* g, int schedule, int32_t src, double eps, c
     sync_ws w;
     sync_ws_init(&w, n);
     int dead_src = deg_out(g, src) == 0;
+    if (n_rounds == 0 && tun.prior_levels > 0 && tun.halving_ratio > 1.0) {
+      /* Loop turns that are known to pass before any push: after a push at rmax every r(v) < rmax * d(v), so
+       * rsum <= rmax * m and the walks cost at most c_walk * omega * (1 - alpha) * rmax * m; while that bound
+       * still covers prior_levels dense levels the turn would be repeated at half the threshold anyway. */
+      double walk_bound = tun.c_walk_ns * omega_local * (1 - alpha) * rmax_local * (double)g->m;
+      double push_est = (double)tun.prior_levels *
+                        (tun.c_level_ns + tun.c_dense_edge_ns * (double)g->m + tun.c_dense_node_ns * (double)g->n);
+      for (int h = 0; h < tun.max_halvings && walk_bound >= push_est; ++h) {
+        walk_bound /= 2.0;
+        rmax_local /= 2.0;
+      }
+      rmax_used = rmax_local;
+    }
     for (;;) {
       int more = n_rounds > 0 ? rounds < n_rounds
                               : (st->model_cost_ns < tun.c_walk_ns * rsum_local * omega_local && rounds < tun.max_rounds);

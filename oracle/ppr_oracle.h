@@ -49,6 +49,7 @@ typedef struct orc_tuning {
   double c_walk_ns, c_edge_ns, c_pop_ns, c_level_ns, c_dense_edge_ns, c_dense_node_ns, dense_frac;
   int32_t max_rounds, max_halvings;
   double halving_ratio;
+  int32_t prior_levels, reserved;
 } orc_tuning;
 
 typedef struct orc_conf { /* Algo_Conf.java:29-81 */

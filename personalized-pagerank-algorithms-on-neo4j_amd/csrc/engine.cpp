@@ -776,6 +776,8 @@ void pprhip_tuning_default(pprhip_tuning_t* t) {
   t->max_rounds = 24;
   t->max_halvings = 6;
   t->halving_ratio = 2.0;
+  t->prior_levels = 16;
+  t->reserved = 0;
 }
 
 void pprhip_tuning_batch(pprhip_tuning_t* t) {
@@ -1046,6 +1048,7 @@ int pprhip_graph_set_tuning(pprhip_graph_t* g, const pprhip_tuning_t* t) {
   if (g->tun.max_rounds <= 0) g->tun.max_rounds = d.max_rounds;
   if (g->tun.max_halvings <= 0) g->tun.max_halvings = d.max_halvings;
   if (!(g->tun.halving_ratio > 0)) g->tun.halving_ratio = d.halving_ratio;  // a value <= 1 switches the rule off
+  if (g->tun.prior_levels == 0) g->tun.prior_levels = d.prior_levels;        // negative: off
   return PPRHIP_OK;
 }
 
@@ -1276,6 +1279,19 @@ int fora_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, co
   r.alpha = conf->alpha;
   r.rsum_local = conf->rsum;
   PPRHIP_TRY(pprhip_fora_whole_params(conf, eps, &r.rmax_local, &r.omega_local));  // Fora_Whole_Graph.java:86-87
+  if (n_rounds == 0 && g->tun.prior_levels > 0 && g->tun.halving_ratio > 1.0) {
+    // Loop turns that are known to pass before any push: after a push at rmax every r(v) < rmax * d(v), so
+    // rsum <= rmax * m and the walks cost at most c_walk * omega * (1 - alpha) * rmax * m; while that bound still
+    // covers prior_levels dense levels the turn would be repeated at half the threshold anyway (twin: same rule).
+    const pprhip_tuning_t& t = g->tun;
+    double walk_bound = t.c_walk_ns * r.omega_local * (1 - r.alpha) * r.rmax_local * (double)g->m;
+    const double push_est =
+        (double)t.prior_levels * (t.c_level_ns + t.c_dense_edge_ns * (double)g->m + t.c_dense_node_ns * (double)g->n);
+    for (int h = 0; h < t.max_halvings && walk_bound >= push_est; ++h) {
+      walk_bound /= 2.0;
+      r.rmax_local /= 2.0;
+    }
+  }
   r.rmax_used = r.rmax_local;
   r.model_cost = 0.0;
   r.rounds = 0;
