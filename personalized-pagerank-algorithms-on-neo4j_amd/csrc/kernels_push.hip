@@ -690,12 +690,13 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
 // A workgroup takes 64 rows at a time through an LDS tile [row][slot]: row sums come in and next
 // contributions go out in the interleaved layout (whole 128-byte lines), while the per-slot
 // residue / reserve vectors are walked with a lane per row, i.e. coalesced as in the single-query
-// kernel.  Wave w serves slots [w * kBatch / 4, (w + 1) * kBatch / 4); slot arguments are
+// kernel.  Wave w serves kSlotsPerWave consecutive slots; slot arguments are
 // wave-uniform.  Counters go to per-slot partials.
 constexpr int kApplyRows = 64;
-constexpr int kSlotsPerWave = kBatch / 4;
+constexpr int kApplyThreads = 512;  // 8 waves, 2 slots each: few enough slot arguments to stay in SGPRs
+constexpr int kSlotsPerWave = kBatch / (kApplyThreads / 64);
 
-__global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
+__global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
                                                             const int32_t* __restrict__ zin_rows, uint32_t n_zin,
                                                             double* __restrict__ acc8,
                                                             const uint32_t* __restrict__ out_rp,
@@ -711,7 +712,8 @@ __global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __rest
   __shared__ int32_t s_u[kApplyRows];
   __shared__ uint32_t s_d[kApplyRows];
   __shared__ uint32_t s_din[kApplyRows];  // backward sweeps: in-degree = edges the row pushes when it is popped
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the slot arguments load into SGPRs
   const uint32_t n_rows = n_nz + n_zin;
   const uint32_t n_tiles = (n_rows + kApplyRows - 1) / kApplyRows;
   SlotArgs a[kSlotsPerWave];
@@ -732,8 +734,8 @@ __global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __rest
     // cross a chunk boundary are summed with atomics and have to be cleared for the next sweep
     const unsigned long long cw = cross_bits[tl];
 #pragma unroll
-    for (int i = 0; i < kApplyRows * kBatch / 256; ++i) {
-      const uint32_t idx = (uint32_t)i * 256u + tid;
+    for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
+      const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
       const uint32_t r = idx / kBatch, s = idx % kBatch;
       const uint32_t j = row0 + r;
       double v = 0.0;
@@ -755,52 +757,63 @@ __global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __rest
     const int32_t u = s_u[lane];
     const uint32_t d = s_d[lane];
     const uint32_t din = s_din[lane];
+    // the wave's slots in three passes, so that all their residue / reserve loads are in flight together:
+    // (1) row sums (+ the source's returned dead-end mass), (2) loads, (3) arithmetic and stores
+    double accv[kSlotsPerWave], oldv[kSlotsPerWave], rsvv[kSlotsPerWave];
+    bool live[kSlotsPerWave];
+#pragma unroll
+    for (int i = 0; i < kSlotsPerWave; ++i) {
+      double acc = tile[lane][w * kSlotsPerWave + i];
+      const bool on = a[i].active && u >= 0;
+      if (on && a[i].mode != kBackward && u == a[i].src) {
+        const double dd = a[i].ctr->dead[a[i].dead_slot];
+        if (dd > 0.0) {
+          acc += dd;
+          a[i].ctr->dead[a[i].dead_slot] = 0.0;
+        }
+      }
+      accv[i] = acc;
+      live[i] = on && acc > 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < kSlotsPerWave; ++i) {
+      oldv[i] = live[i] ? a[i].res[u] : 0.0;
+      rsvv[i] = live[i] ? a[i].reserve[u] : 0.0;  // needed when the row crosses, which most rows of a dense level do
+    }
 #pragma unroll
     for (int i = 0; i < kSlotsPerWave; ++i) {
       const int s = w * kSlotsPerWave + i;
-      double acc = tile[lane][s];
       double cn = 0.0;
-      if (a[i].active && u >= 0 && a[i].mode == kBackward) {
+      if (live[i] && a[i].mode == kBackward) {
         // Backward_Search.java:73-96 in pull form: the row's out-neighbours' (1 - alpha) * residue, divided by
         // this row's out-degree; strict un-normalised threshold
-        if (acc > 0.0) {
-          const double old = a[i].res[u];
-          const double nw = old + acc / (double)d;
-          if (!(old > a[i].rmax) && nw > a[i].rmax) {
-            a[i].reserve[u] = a[i].reserve[u] + nw * a[i].alpha;
-            a[i].res[u] = 0.0;
-            cn = (1.0 - a[i].alpha) * nw;
-            pack[i] += (1ull << kPackShift) | (unsigned long long)din;
-          } else {
-            a[i].res[u] = nw;
-          }
+        const double old = oldv[i];
+        const double nw = old + accv[i] / (double)d;
+        if (!(old > a[i].rmax) && nw > a[i].rmax) {
+          a[i].reserve[u] = rsvv[i] + nw * a[i].alpha;
+          a[i].res[u] = 0.0;
+          cn = (1.0 - a[i].alpha) * nw;
+          pack[i] += (1ull << kPackShift) | (unsigned long long)din;
+        } else {
+          a[i].res[u] = nw;
         }
-      } else if (a[i].active && u >= 0) {
-        if (u == a[i].src) {
-          const double dd = a[i].ctr->dead[a[i].dead_slot];
-          if (dd > 0.0) {
-            acc += dd;
-            a[i].ctr->dead[a[i].dead_slot] = 0.0;
-          }
-        }
-        if (acc > 0.0) {
-          const double old = a[i].res[u];
-          const double nw = old + acc;
-          const bool crossing = !active_fwd(old, d, a[i].rmax) && active_fwd(nw, d, a[i].rmax);
-          if (a[i].mode == kFwdTopk && active_fwd(nw, d, a[i].min_rmax)) a[i].flags[u] = 1;
-          if (crossing) {  // becomes a frontier node of the next level: prepare it right here
-            a[i].reserve[u] = a[i].reserve[u] + nw * a[i].alpha;
-            a[i].res[u] = 0.0;
-            if (d == 0) {
-              dead_next[i] += nw * (1.0 - a[i].alpha);
-              ndead[i]++;
-            } else {
-              cn = ((1.0 - a[i].alpha) * nw) / (double)d;
-            }
-            pack[i] += (1ull << kPackShift) | (unsigned long long)d;
+      } else if (live[i]) {
+        const double old = oldv[i];
+        const double nw = old + accv[i];
+        const bool crossing = !active_fwd(old, d, a[i].rmax) && active_fwd(nw, d, a[i].rmax);
+        if (a[i].mode == kFwdTopk && active_fwd(nw, d, a[i].min_rmax)) a[i].flags[u] = 1;
+        if (crossing) {  // becomes a frontier node of the next level: prepare it right here
+          a[i].reserve[u] = rsvv[i] + nw * a[i].alpha;
+          a[i].res[u] = 0.0;
+          if (d == 0) {
+            dead_next[i] += nw * (1.0 - a[i].alpha);
+            ndead[i]++;
           } else {
-            a[i].res[u] = nw;
+            cn = ((1.0 - a[i].alpha) * nw) / (double)d;
           }
+          pack[i] += (1ull << kPackShift) | (unsigned long long)d;
+        } else {
+          a[i].res[u] = nw;
         }
       }
       tile[lane][s] = cn;
@@ -811,8 +824,8 @@ __global__ __launch_bounds__(256) void k_dense_apply_batch(const int32_t* __rest
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kApplyRows * kBatch / 256; ++i) {
-      const uint32_t idx = (uint32_t)i * 256u + tid;
+    for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
+      const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
       const uint32_t r = idx / kBatch, s = idx % kBatch;
       const int32_t ur = s_u[r];
       if (ur >= 0) c8_next[(size_t)ur * kBatch + s] = tile[r][s];
@@ -1207,7 +1220,7 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward) {
   const unsigned long long* cross = backward ? P->cross_bits_o : P->cross_bits;
   PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8));
   const uint32_t grid = grid_for(P->n, kApplyRows, kApplyBlocks8);
-  k_dense_apply_batch<<<dim3(grid), dim3(256), 0, P->stream>>>(nz, n_nz, zr, n_z, P->acc8, P->out_rp,
+  k_dense_apply_batch<<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(nz, n_nz, zr, n_z, P->acc8, P->out_rp,
                                                                backward ? P->in_rp : nullptr, P->c8[P->c8cur ^ 1],
                                                                P->d_slot_args, cross, P->prep_bits, P->blk_pack8,
                                                                P->blk_dead8, P->blk_ndead8);
