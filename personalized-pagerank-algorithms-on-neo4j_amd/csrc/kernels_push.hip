@@ -449,10 +449,15 @@ __device__ __forceinline__ ChunkRegsB<G> load_chunk_b(const int32_t* __restrict_
   const unsigned long long e0 = (unsigned long long)c * kChunkEdges + 8ull * lane;
   const int4* p = reinterpret_cast<const int4*>(in_ci + e0);
   ChunkRegsB<G> r;
-  r.ia = p[0];
-  r.ib = p[1];
+  // the index stream is read once per sweep: non-temporal, so that it does not push gathered lines out of L2
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i* q = reinterpret_cast<const v4i*>(p);
+  const v4i x = __builtin_nontemporal_load(q), y = __builtin_nontemporal_load(q + 1);
+  r.ia = make_int4(x.x, x.y, x.z, x.w);
+  r.ib = make_int4(y.x, y.y, y.z, y.w);
 #pragma unroll
-  for (int w = 0; w < G / 8; ++w) r.mask[w] = flags64[(size_t)c * 8 + (size_t)(lane / G) * (G / 8) + w];
+  for (int w = 0; w < G / 8; ++w)
+    r.mask[w] = __builtin_nontemporal_load(&flags64[(size_t)c * 8 + (size_t)(lane / G) * (G / 8) + w]);
   return r;
 }
 
@@ -491,7 +496,7 @@ __device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const do
       if (k == 0)
         first_seg = seg;  // closes the row carried in from earlier groups
       else
-        accB[(size_t)(before + k - 1) * G + s] = seg;  // a row that starts and ends inside this group
+        __builtin_nontemporal_store(seg, &accB[(size_t)(before + k - 1) * G + s]);  // a row that starts and ends inside this group
       seg = 0.0;
       ++k;
     }
@@ -741,7 +746,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
       double v = 0.0;
       if (j < n_nz) {
         const size_t t = (size_t)j * kBatch + s;
-        v = acc8[t];
+        v = __builtin_nontemporal_load(&acc8[t]);
         if (v != 0.0 && ((cw >> r) & 1ull)) acc8[t] = 0.0;
       }
       tile[r][s] = v;
