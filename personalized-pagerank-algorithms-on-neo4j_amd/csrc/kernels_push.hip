@@ -305,11 +305,14 @@ struct ChunkRegs {  // one lane's share of a chunk: 8 column indices + their row
 __device__ __forceinline__ ChunkRegs load_chunk(const int32_t* __restrict__ in_ci,
                                                 const uint8_t* __restrict__ start_flags, uint32_t c, int lane) {
   const unsigned long long e0 = (unsigned long long)c * kChunkEdges + 8ull * lane;
-  const int4* p = reinterpret_cast<const int4*>(in_ci + e0);
+  // read once per sweep: non-temporal, so that the index stream does not push gathered lines out of L2
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i* q = reinterpret_cast<const v4i*>(in_ci + e0);
+  const v4i x = __builtin_nontemporal_load(q), y = __builtin_nontemporal_load(q + 1);
   ChunkRegs r;
-  r.ia = p[0];
-  r.ib = p[1];
-  r.fb = start_flags[e0 >> 3];
+  r.ia = make_int4(x.x, x.y, x.z, x.w);
+  r.ib = make_int4(y.x, y.y, y.z, y.w);
+  r.fb = __builtin_nontemporal_load(&start_flags[e0 >> 3]);
   return r;
 }
 
