@@ -233,6 +233,39 @@ def test_fora_rounds_trade_push_for_walks(orc, rmat12):
     assert 1 <= st0.rounds <= 24
 
 
+def test_threshold_rules_of_the_twin(orc, rmat12):
+    """The three rules that stand in for the reference's wall-clock loop (cut rounds, halvings taken at once,
+    a-priori start below rmax0) choose thresholds only: every choice is a power-of-two fraction of rmax0, the
+    estimate keeps FORA's guarantee against the power method, and with the rules switched off the twin pushes
+    at rmax0, rmax0/2, ... to the end of every round."""
+    og = to_oracle(orc, rmat12)
+    rmax0 = orc.fora_whole_params(og.conf_whole(A), 0.5)[0]
+    od = np.diff(rmat12.out_rp)
+    s = int(np.argmax(od > 2))
+    exact = og.power_method(s, A, 100)
+    big = exact > 1.0 / rmat12.n
+    results = {}
+    for name, patch in (("default", {}), ("batch", {"c_dense_edge_ns": 0.002, "c_dense_node_ns": 0.003, "dense_frac": 0.02}),
+                        ("plain", {"halving_ratio": 1.0, "prior_levels": -1})):
+        t = orc.tuning_default()
+        for k, v in patch.items():
+            setattr(t, k, v)
+        est, st = og.fora_whole(s, 0.5, A, seed=1, n_rounds=0, schedule=orc.SYNC, tuning=t)
+        results[name] = st
+        frac = rmax0 / st.rmax_final
+        assert abs(frac - 2 ** round(math.log2(frac))) < 1e-9 * frac          # a power-of-two fraction of rmax0
+        assert abs(est.sum() - 1.0) < 1e-9 and np.all(np.abs(est[big] - exact[big]) <= 0.5 * exact[big])
+        assert st.walks >= math.floor(st.omega * st.rsum)
+    # a cheaper dense level (batch profile) can only push further: lower final threshold, fewer walks
+    assert results["batch"].rmax_final <= results["default"].rmax_final
+    assert results["batch"].walks <= results["default"].walks
+    # rules off: one halving per round, so the final threshold is rmax0 / 2^(rounds - 1)
+    assert results["plain"].rmax_final == pytest.approx(rmax0 / 2 ** (results["plain"].rounds - 1))
+    # explicit round counts ignore the halving rules altogether
+    est, st = og.fora_whole(s, 0.5, A, seed=1, n_rounds=3, schedule=orc.SYNC)
+    assert st.rounds == 3 and st.rmax_final == pytest.approx(rmax0 / 4)
+
+
 def test_fora_topk_precision_got(orc, got):
     og = to_oracle(orc, got)
     for s in (17, 42):
