@@ -209,7 +209,7 @@ int pprhip_random_walk_batch(pprhip_graph_t* g, const int32_t* starts, const uin
 /* ---------------------------------------------------------------- FORA (a5, a6, a7) */
 /* Fora_Whole_Graph.computeWholeGraphPPR(Long s, Object eps) (Fora_Whole_Graph.java:82-146).
  * n_rounds > 0 runs exactly that many threshold rounds (rmax0, rmax0/2, ...); 0 picks the thresholds
- * with the deterministic cost model in pprhip_tuning_t (the stand-in for the reference's wall-clock
+ * with the deterministic cost model of the tuning struct (the stand-in for the reference's wall-clock
  * loop, :93-103: first threshold, halvings per round, when to stop).  reserve_out may be NULL. */
 int pprhip_fora_single_source(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf,
                               uint64_t seed, int n_rounds, double* reserve_out, pprhip_stats_t* stats);

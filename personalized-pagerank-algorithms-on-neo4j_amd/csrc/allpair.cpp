@@ -1,0 +1,333 @@
+// allpair.cpp — All-Pair-Backward-Search (Base_Whole_Graph.preprocessing) and the inverted index.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <thread>
+
+#include "engine_internal.hpp"
+
+using namespace pprhip;
+using namespace pprhip::detail;
+
+// =================================================================================================
+// All-Pair-Backward-Search (a9) — first correct path: one backward search per target on the
+// global arrays, entries >= threshold compacted on the device, inverted index built on the host.
+// =================================================================================================
+struct pprhip_index {
+  uint32_t n = 0;
+  std::vector<uint64_t> offsets;
+  std::vector<int32_t> targets;
+  std::vector<double> values;
+};
+
+namespace {
+
+// Base_Whole_Graph.java:112-163: per source, k < 0 keeps insertion (target) order; k >= 0 keeps
+// entries >= the k-th largest (all when fewer than k) sorted descending (stable: ties stay in
+// target order).
+void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix) {
+  ix->n = n;
+  ix->offsets.assign((size_t)n + 1, 0);
+  // bucket by source (counting sort), then every bucket on its own: order by target, apply the k rule
+  const size_t N = tr.size();
+  std::vector<uint64_t> start((size_t)n + 1, 0);
+  for (const Triple& e : tr) start[(size_t)e.v + 1]++;
+  for (uint32_t v = 0; v < n; ++v) start[v + 1] += start[v];
+  std::vector<Triple> by_v(N);
+  {
+    std::vector<uint64_t> at(start.begin(), start.end() - 1);
+    for (const Triple& e : tr) by_v[at[e.v]++] = e;
+  }
+  std::vector<Triple>().swap(tr);
+  std::vector<uint64_t> kept((size_t)n + 1, 0);
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  const unsigned T = N < (1u << 16) ? 1u : hw;
+  auto for_ranges = [&](auto&& fn) {
+    std::vector<std::thread> th;
+    for (unsigned w = 1; w < T; ++w) th.emplace_back(fn, (uint32_t)((uint64_t)n * w / T), (uint32_t)((uint64_t)n * (w + 1) / T));
+    fn(0u, (uint32_t)((uint64_t)n / T));
+    for (auto& x : th) x.join();
+  };
+  // pass 1: each bucket sorted by target; for k >= 0 the kept entries move to the bucket's front, by value
+  for_ranges([&](uint32_t lo, uint32_t hi) {
+    std::vector<double> tmp;
+    for (uint32_t v = lo; v < hi; ++v) {
+      Triple* b = by_v.data() + start[v];
+      const size_t len = (size_t)(start[v + 1] - start[v]);
+      if (len == 0) continue;
+      std::sort(b, b + len, [](const Triple& x, const Triple& y) { return x.t < y.t; });
+      if (k < 0) {
+        kept[v + 1] = len;
+        continue;
+      }
+      bool have = false;
+      double kth = 0.0;
+      if (k >= 1 && (size_t)k <= len) {
+        tmp.resize(len);
+        for (size_t j = 0; j < len; ++j) tmp[j] = b[j].p;
+        std::nth_element(tmp.begin(), tmp.begin() + (k - 1), tmp.end(), std::greater<double>());
+        kth = tmp[k - 1];
+        have = true;
+      }
+      size_t w = 0;
+      for (size_t j = 0; j < len; ++j)
+        if (!have || b[j].p >= kth) b[w++] = b[j];
+      std::stable_sort(b, b + w, [](const Triple& x, const Triple& y) { return x.p > y.p; });
+      kept[v + 1] = w;
+    }
+  });
+  for (uint32_t v = 0; v < n; ++v) kept[v + 1] += kept[v];
+  ix->targets.resize(kept[n]);
+  ix->values.resize(kept[n]);
+  for (uint32_t v = 0; v <= n; ++v) ix->offsets[v] = kept[v];
+  // pass 2: into the index arrays
+  for_ranges([&](uint32_t lo, uint32_t hi) {
+    for (uint32_t v = lo; v < hi; ++v) {
+      const Triple* b = by_v.data() + start[v];
+      const size_t len = (size_t)(kept[v + 1] - kept[v]);
+      for (size_t j = 0; j < len; ++j) {
+        ix->targets[kept[v] + j] = b[j].t;
+        ix->values[kept[v] + j] = b[j].p;
+      }
+    }
+  });
+}
+
+}  // namespace
+
+extern "C" {
+
+int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, int k, uint32_t t_begin, uint32_t t_end,
+                             pprhip_index_t** index_out, pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_all_pair_backward"));
+  if (!index_out || t_begin > t_end || t_end > g->n) {
+    set_error("pprhip_all_pair_backward: bad target range [%u, %u) for n=%u", t_begin, t_end, g->n);
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  g->topk_active = false;
+  CallTimer tm(g);
+  std::vector<Triple> tr;
+  const uint32_t n_targets = t_end - t_begin;
+  // PPRHIP_APBS_TIER = 2 / 3 starts at a later tier (tests exercise every tier that way)
+  const int first_tier = getenv("PPRHIP_APBS_TIER") ? atoi(getenv("PPRHIP_APBS_TIER")) : 1;
+
+  // ---- device buffers of this call
+  ApbsBuffers B;
+  unsigned long long* cells = nullptr;  // next_target, out_count, out_valid, overflow_count, pops, edges
+  int rc = PPRHIP_OK;
+  auto release = [&]() {
+    void* p[] = {cells, B.out_v, B.out_t, B.out_p, B.overflow, B.g_tables};
+    for (void* q : p)
+      if (q) (void)hipFree(q);
+  };
+  B.out_cap = std::min<unsigned long long>(1ull << 24, std::max<unsigned long long>(1ull << 16, 64ull * g->n));
+  if ((rc = alloc_dev((void**)&cells, sizeof(unsigned long long) * 8)) ||
+      (rc = alloc_dev((void**)&B.out_v, sizeof(int32_t) * B.out_cap)) ||
+      (rc = alloc_dev((void**)&B.out_t, sizeof(int32_t) * B.out_cap)) ||
+      (rc = alloc_dev((void**)&B.out_p, sizeof(double) * B.out_cap)) ||
+      (rc = alloc_dev((void**)&B.overflow, sizeof(int32_t) * std::max<uint32_t>(1, n_targets)))) {
+    release();
+    return rc;
+  }
+  B.next_target = cells;
+  B.out_count = cells + 1;
+  B.out_valid = cells + 2;
+  B.overflow_count = cells + 3;
+  B.stat_pops = cells + 4;
+  B.stat_edges = cells + 5;
+  std::vector<int32_t> h_v, h_t, h_ovf;
+  std::vector<double> h_p;
+  unsigned long long h_cells[8];
+
+  // runs one tier over `list` (or the range when list is empty and use_range) until every target
+  // has either produced its triples or landed in `give_up`
+  auto run_tier = [&](bool global_tier, std::vector<int32_t> list, bool use_range, std::vector<int32_t>& give_up) -> int {
+    int32_t* d_list = nullptr;
+    for (int pass = 0; pass < 1000; ++pass) {
+      const uint32_t cnt = use_range ? n_targets : (uint32_t)list.size();
+      if (cnt == 0) break;
+      if (!use_range) {
+        if (!d_list) PPRHIP_TRY(alloc_dev((void**)&d_list, sizeof(int32_t) * list.size()));
+        PPRHIP_CHECK_HIP(hipMemcpyAsync(d_list, list.data(), sizeof(int32_t) * cnt, hipMemcpyHostToDevice, g->stream));
+      }
+      const unsigned long long init[8] = {0, 0, ~0ull, 0, 0, 0, 0, 0};
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(cells, init, sizeof init, hipMemcpyHostToDevice, g->stream));
+      ktimer().begin(PPRHIP_KERNEL_BACKWARD_BATCH, 0);
+      PPRHIP_TRY(launch_apbs(g, global_tier, use_range ? nullptr : d_list, t_begin, cnt, alpha, threshold, B));
+      ktimer().end();
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(h_cells, cells, sizeof h_cells, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      const unsigned long long valid = std::min(std::min(h_cells[1], h_cells[2]), B.out_cap);
+      st.pops += h_cells[4];
+      st.edge_pushes += h_cells[5];
+      const uint64_t bytes = 44ull * h_cells[4] + 28ull * h_cells[5] + 16ull * valid;
+      st.push_bytes += bytes;
+      if (!ktimer().recs.empty()) ktimer().recs.back().bytes = bytes;
+      if (valid) {
+        h_v.resize(valid); h_t.resize(valid); h_p.resize(valid);
+        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_v.data(), B.out_v, sizeof(int32_t) * valid, hipMemcpyDeviceToHost, g->stream));
+        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_t.data(), B.out_t, sizeof(int32_t) * valid, hipMemcpyDeviceToHost, g->stream));
+        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_p.data(), B.out_p, sizeof(double) * valid, hipMemcpyDeviceToHost, g->stream));
+        PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+        for (unsigned long long i = 0; i < valid; ++i) tr.push_back({h_v[i], h_t[i], h_p[i]});
+      }
+      std::vector<int32_t> again;
+      const unsigned long long novf = h_cells[3];
+      if (novf) {
+        h_ovf.resize(novf);
+        PPRHIP_CHECK_HIP(hipMemcpy(h_ovf.data(), B.overflow, sizeof(int32_t) * novf, hipMemcpyDeviceToHost));
+        for (int32_t x : h_ovf) {
+          if (x >= 0) give_up.push_back(x);  // table too small for this target
+          else again.push_back(-(x + 1));    // triple buffer was full: same tier again
+        }
+      }
+      list.swap(again);
+      use_range = false;
+      if (d_list && list.size()) {
+        (void)hipFree(d_list);
+        d_list = nullptr;
+      }
+    }
+    if (d_list) (void)hipFree(d_list);
+    return PPRHIP_OK;
+  };
+
+  std::vector<int32_t> to_tier2, to_tier3;
+  if (first_tier <= 1) {
+    rc = run_tier(false, {}, true, to_tier2);
+  } else {
+    for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
+  }
+  if (rc == PPRHIP_OK && !to_tier2.empty()) {
+    B.g_cap = 65536;
+    // 8 workgroups per CU: the HBM tier is a chain of L2 round trips per edge, hidden only by occupancy
+    B.g_blocks = (uint32_t)std::min<size_t>((size_t)g->n_cus * 8, to_tier2.size());
+    rc = alloc_dev((void**)&B.g_tables, (size_t)B.g_blocks * B.g_cap * 40);
+    if (rc == PPRHIP_OK) rc = run_tier(true, to_tier2, false, to_tier3);
+  }
+  release();
+  if (rc != PPRHIP_OK) return rc;
+
+  // ---- tier 3: the targets whose search outgrows a 48K-node table run on whole vectors, 16 of them in flight
+  // on the batch slots; levels that touch a large part of the graph run as batched sweeps over the out-CSR
+  pprhip_stats_t st3;
+  std::memset(&st3, 0, sizeof st3);
+  if (!to_tier3.empty()) {  // Base_Whole_Graph.java:76-92
+    BatchJob J;
+    J.P = g;
+    J.kind = 2;
+    J.srcs = to_tier3.data();
+    J.q = (int)to_tier3.size();
+    J.eps = 0.0;
+    J.conf = nullptr;
+    J.seed = 0;
+    J.n_rounds = 0;
+    J.reserve_out = nullptr;
+    J.k = 0;
+    J.ids_out = nullptr;
+    J.vals_out = nullptr;
+    J.n_out = nullptr;
+    J.per_query = nullptr;
+    J.alpha = alpha;
+    J.threshold = threshold;
+    J.triples = &tr;
+    PPRHIP_TRY(batch_run(g, J, &st3));
+    st.pops += st3.pops;
+    st.edge_pushes += st3.edge_pushes;
+    st.enqueues += st3.enqueues;
+    st.levels += st3.levels;
+    st.dense_levels += st3.dense_levels;
+    st.push_bytes += st3.push_bytes;
+  }
+  tm.mark(1);
+  tm.finish(st);
+  for (int c = 0; c < 8; ++c) {
+    st.class_ms[c] += st3.class_ms[c];
+    st.class_bytes[c] += st3.class_bytes[c];
+    st.class_launches[c] += st3.class_launches[c];
+  }
+  st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  st.rmax_final = threshold;
+  st.rounds = (uint32_t)(to_tier2.size());      // targets that needed the HBM tier
+  st.dense_nodes = (uint64_t)to_tier3.size();   // targets that needed the whole-vector path
+  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
+  if (!ix) return PPRHIP_ERR_OOM;
+  finalize_rows(g->n, tr, k, ix.get());
+  *index_out = ix.release();
+  if (stats) *stats = st;
+  return PPRHIP_OK;
+}
+
+int pprhip_index_merge(const pprhip_index_t* const* shards, int n_shards, int k, pprhip_index_t** merged_out) {
+  if (!shards || n_shards < 1 || !merged_out) {
+    set_error("pprhip_index_merge: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  const uint32_t n = shards[0]->n;
+  std::vector<Triple> tr;
+  for (int s = 0; s < n_shards; ++s) {
+    if (!shards[s] || shards[s]->n != n) {
+      set_error("pprhip_index_merge: shard %d does not match", s);
+      return PPRHIP_ERR_INVALID;
+    }
+    for (uint32_t v = 0; v < n; ++v)
+      for (uint64_t i = shards[s]->offsets[v]; i < shards[s]->offsets[v + 1]; ++i)
+        tr.push_back({(int32_t)v, shards[s]->targets[i], shards[s]->values[i]});
+  }
+  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
+  if (!ix) return PPRHIP_ERR_OOM;
+  finalize_rows(n, tr, k, ix.get());
+  *merged_out = ix.release();
+  return PPRHIP_OK;
+}
+
+int pprhip_index_from_arrays(uint32_t n, const uint64_t* offsets, const int32_t* targets, const double* values,
+                             pprhip_index_t** index_out) {
+  if (!offsets || !index_out || offsets[0] != 0 || (offsets[n] && (!targets || !values))) {
+    set_error("pprhip_index_from_arrays: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  for (uint32_t v = 0; v < n; ++v)
+    if (offsets[v + 1] < offsets[v]) {
+      set_error("pprhip_index_from_arrays: offsets must be non-decreasing");
+      return PPRHIP_ERR_INVALID;
+    }
+  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
+  if (!ix) return PPRHIP_ERR_OOM;
+  ix->n = n;
+  ix->offsets.assign(offsets, offsets + n + 1);
+  ix->targets.assign(targets, targets + offsets[n]);
+  ix->values.assign(values, values + offsets[n]);
+  *index_out = ix.release();
+  return PPRHIP_OK;
+}
+
+int pprhip_index_info(const pprhip_index_t* ix, uint32_t* n, uint64_t* entries) {
+  if (!ix) {
+    set_error("pprhip_index_info: null index");
+    return PPRHIP_ERR_INVALID;
+  }
+  if (n) *n = ix->n;
+  if (entries) *entries = ix->targets.size();
+  return PPRHIP_OK;
+}
+
+int pprhip_index_arrays(const pprhip_index_t* ix, const uint64_t** offsets, const int32_t** targets,
+                        const double** values) {
+  if (!ix || !offsets || !targets || !values) {
+    set_error("pprhip_index_arrays: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  *offsets = ix->offsets.data();
+  *targets = ix->targets.data();
+  *values = ix->values.data();
+  return PPRHIP_OK;
+}
+
+void pprhip_index_destroy(pprhip_index_t* ix) { delete ix; }
+
+}  // extern "C"

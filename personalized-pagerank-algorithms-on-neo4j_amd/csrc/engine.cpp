@@ -13,75 +13,16 @@
 #include <numeric>
 #include <thread>
 
-#include "engine.hpp"
+#include "engine_internal.hpp"
 
 using namespace pprhip;
+using namespace pprhip::detail;
 
 namespace pprhip {
+namespace detail {
 
-struct ForaRun;
-
-// Rendezvous of the batch workers (one host thread and one stream per slot) with the sweeper
-// thread.  Workers run their queries' sparse levels, walks and selections concurrently; a worker
-// whose next level is dense waits here.  The sweeper runs a batched sweep whenever somebody waits
-// and no slot "holds": a slot holds from the moment a sweep releases it until it has said what it
-// does next (waits again, goes on with sparse levels, ends its push phase), and while it writes its
-// column of the shared contribution array.  Slots busy with sparse levels or walks hold nothing,
-// so their kernels overlap the sweeps of the others.
-struct BatchSync {
-  std::mutex mu;
-  std::condition_variable cv;
-  pprhip_graph* P = nullptr;
-  ForaRun* runs = nullptr;
-  int n_wait = 0, n_hold = 0, n_workers = 0;
-  bool sweeping = false;
-  bool waitflag[kBatch] = {};
-  bool hold[kBatch] = {};
-  int err = 0;
-  std::string errmsg;
-  void release(int s);  // the slot stops holding (no-op when it does not)
-  void c8_enter(int s);  // before a slot's kernels touch its column of the shared arrays
-  int arrive(int s);     // the slot's next level is dense and prepared; returns after the sweep
-  void fail(int rc);
-  void worker_done(int s);
-  void sweeper();
-};
-
-}  // namespace pprhip
-
-namespace {
-
-struct Triple {  // one index entry of All-Pair-Backward-Search: pi(v, t) = p
-  int32_t v, t;
-  double p;
-};
-
-struct LevelCtx {
-  int fcur = 0;   // F/eoff buffer holding the current frontier list
-  int ccur = 0;   // dense contribution buffer holding the current level's contributions
-  int pslot = 0;  // packed counter slot describing the current frontier
-  int dslot = 0;  // dead-mass cell pending for the current level
-  uint32_t nf = 0;
-  uint64_t ef = 0;
-  bool dense_prepared = false;
-  int dense_run = 0;  // dense levels run since the current dense phase was seeded
-};
-
-// FORA rounds that are certain to be followed by another halving do not need their sparse tail: what it
-// would push is picked up by the next round's lower threshold.  Such a round ends after the first sparse
-// level that follows its dense levels.  fixed: the caller knows another round follows; otherwise the round
-// loop's own condition (model cost so far < c_walk * rsum * omega) is evaluated at that point.  The test
-// twin applies the same rule (oracle/ppr_oracle.c: round_cut).
-struct RoundCut {
-  bool enabled = false, fixed = false, had_dense = false, checked = false, taken = false;
-  double omega = 0.0, c_walk = 0.0, alpha = 0.0;
-  double rsum = 0.0;  // (1 - alpha) * residue sum measured at the check (valid when !fixed and checked)
-};
-
-// kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
 thread_local KernelTimer g_timer_own;
 thread_local KernelTimer* g_timer_cur = &g_timer_own;
-inline KernelTimer& ktimer() { return *g_timer_cur; }
 
 int alloc_dev(void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes ? bytes : 8);
@@ -134,7 +75,6 @@ int write_hist0(pprhip_graph* g, uint32_t nf, uint64_t ef) {
 
 int ensure_bwd_layout(pprhip_graph* P);
 
-constexpr int kYield = 1;  // run_levels: the next level is dense and the caller runs it (batched sweeps)
 
 // bookkeeping after a dense level: the frontier it produced becomes the current one
 void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_t nf_next, uint64_t ef_next) {
@@ -159,7 +99,7 @@ void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_
 int device_sum(pprhip_graph* g, const double* x, double* out);
 
 int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost,
-               bool yield_dense = false, RoundCut* cut = nullptr) {
+               bool yield_dense, RoundCut* cut) {
   const bool bwd = a.mode == kBackward;
   const bool slot = g->parent != nullptr;
   // smallest integer x with (double)x >= dense_frac * m: the device-side form of level_cost()'s test
@@ -568,42 +508,6 @@ int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long
   return PPRHIP_OK;
 }
 
-struct CallTimer {
-  pprhip_graph* g;
-  explicit CallTimer(pprhip_graph* g_) : g(g_) {
-    ktimer().stream = g->stream;
-    ktimer().reset();
-    (void)hipEventRecord(g->ev[0], g->stream);
-  }
-  void mark(int i) { (void)hipEventRecord(g->ev[i], g->stream); }
-  static double ms(hipEvent_t a, hipEvent_t b) {
-    float f = 0.f;
-    if (hipEventElapsedTime(&f, a, b) != hipSuccess) return 0.0;
-    return (double)f;
-  }
-  // resolves per-class kernel times; picks the class with the largest total as dominant
-  void finish(pprhip_stats_t& st) {
-    (void)hipEventRecord(g->ev[5], g->stream);
-    (void)hipStreamSynchronize(g->stream);
-    st.total_ms = ms(g->ev[0], g->ev[5]);
-    double tot[8] = {0};
-    uint64_t bytes[8] = {0};
-    uint32_t cnt[8] = {0};
-    ktimer().resolve(tot, bytes, cnt);
-    int best = 0;
-    for (int c = 1; c < 8; ++c)
-      if (tot[c] > tot[best]) best = c;
-    for (int c = 0; c < 8; ++c) {
-      st.class_ms[c] = tot[c];
-      st.class_bytes[c] = bytes[c];
-      st.class_launches[c] = cnt[c];
-    }
-    st.dominant_kernel_id = (uint32_t)best;
-    st.dominant_kernel_ms = tot[best];
-    st.dominant_kernel_bytes = bytes[best];
-    st.dominant_kernel_launches = cnt[best];
-  }
-};
 
 int copy_out(pprhip_graph* g, const double* dev, double* host) {
   if (!host) return PPRHIP_OK;
@@ -748,7 +652,8 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
   return PPRHIP_OK;
 }
 
-}  // namespace
+}  // namespace detail
+}  // namespace pprhip
 
 // =================================================================================================
 // C ABI
@@ -1219,806 +1124,6 @@ int pprhip_random_walk_batch(pprhip_graph_t* g, const int32_t* starts, const uin
   return done(PPRHIP_OK);
 }
 
-// ------------------------------------------------------------------ FORA whole graph (a5)
-namespace pprhip {
-
-// One FORA query as a resumable run: step() advances it until it is finished or (yield_dense)
-// until its next level is dense, so that the batch driver can run that level for many queries
-// in one sweep.  pprhip_fora_single_source drives the same code without yielding.
-struct ForaRun {
-  pprhip_graph* g = nullptr;
-  int32_t src = 0;  // internal id
-  const pprhip_fora_conf_t* conf = nullptr;
-  uint64_t seed = 0;
-  int n_rounds = 0;
-  CallTimer* tm = nullptr;  // single-query calls: push / walk phase marks
-  pprhip_stats_t st;
-  double alpha = 0, rsum_local = 0, rmax_local = 0, omega_local = 0, rmax_used = 0, model_cost = 0;
-  int rounds = 0;
-  bool dead_src = false;
-  LevelCtx L;
-  PushArgs a;
-  RoundCut cut;
-  enum Phase { kRoundStart, kLevels, kWalks, kTopkRoundStart, kTopkLevels, kTopkFinal, kBwdLevels, kBwdFinal, kDone } phase = kDone;
-  int query = -1;  // batch driver: index of the query this run serves
-  bool waiting = false;
-  bool in_push = false;  // between a push phase's start and its end (BatchSync: may hold sweeps off)
-  // top-k runs (Fora_Topk.computeTopKPPR, kind 1): the trial-and-error loop on delta
-  int kind = 0;
-  double eps_half = 0, delta_local = 0, min_delta = 0, min_rmax = 0;
-  uint32_t round = 0;
-  int cap = 0, nsel = 0;
-  int32_t* ids_out = nullptr;
-  double* vals_out = nullptr;
-  // backward searches of All-Pair (kind 2): entries >= threshold of the finished search
-  int32_t target_orig = -1;
-  std::vector<Triple> triples;
-};
-
-}  // namespace pprhip
-
-namespace {
-
-void leave_push(ForaRun& r) {
-  if (r.in_push) {
-    r.in_push = false;
-    if (r.g->sync) r.g->sync->release(r.g->slot_index);
-  }
-}
-
-int fora_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, const pprhip_fora_conf_t* conf,
-               uint64_t seed, int n_rounds) {
-  r.g = g;
-  r.src = src_internal;
-  r.conf = conf;
-  r.seed = seed;
-  r.n_rounds = n_rounds;
-  std::memset(&r.st, 0, sizeof r.st);
-  g->topk_active = false;
-  PPRHIP_TRY(reset_query_state(g, false));
-  r.alpha = conf->alpha;
-  r.rsum_local = conf->rsum;
-  PPRHIP_TRY(pprhip_fora_whole_params(conf, eps, &r.rmax_local, &r.omega_local));  // Fora_Whole_Graph.java:86-87
-  if (n_rounds == 0 && g->tun.prior_levels > 0 && g->tun.halving_ratio > 1.0) {
-    // Loop turns that are known to pass before any push: after a push at rmax every r(v) < rmax * d(v), so
-    // rsum <= rmax * m and the walks cost at most c_walk * omega * (1 - alpha) * rmax * m; while that bound still
-    // covers prior_levels dense levels the turn would be repeated at half the threshold anyway (twin: same rule).
-    const pprhip_tuning_t& t = g->tun;
-    double walk_bound = t.c_walk_ns * r.omega_local * (1 - r.alpha) * r.rmax_local * (double)g->m;
-    const double push_est =
-        (double)t.prior_levels * (t.c_level_ns + t.c_dense_edge_ns * (double)g->m + t.c_dense_node_ns * (double)g->n);
-    for (int h = 0; h < t.max_halvings && walk_bound >= push_est; ++h) {
-      walk_bound /= 2.0;
-      r.rmax_local /= 2.0;
-    }
-  }
-  r.rmax_used = r.rmax_local;
-  r.model_cost = 0.0;
-  r.rounds = 0;
-  r.dead_src = hdeg_out(g, src_internal) == 0;
-  r.L = LevelCtx();
-  r.phase = ForaRun::kRoundStart;
-  r.waiting = false;
-  r.in_push = true;
-  return PPRHIP_OK;
-}
-
-int fora_step(ForaRun& r, bool yield_dense) {
-  pprhip_graph* g = r.g;
-  for (;;) {
-    if (r.phase == ForaRun::kRoundStart) {  // Fora_Whole_Graph.java:93-103, clock replaced by the level cost model
-      const bool more = r.n_rounds > 0 ? r.rounds < r.n_rounds
-                                       : (r.model_cost < g->tun.c_walk_ns * r.rsum_local * r.omega_local &&
-                                          r.rounds < g->tun.max_rounds);
-      if (!more) {
-        r.phase = ForaRun::kWalks;
-        continue;
-      }
-      if (r.dead_src) {  // Forward_Push.java:72-76
-        PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)r.src, 1.0));
-        r.rsum_local = 0.0;
-        r.rmax_used = r.rmax_local;
-        r.rounds++;
-        r.phase = ForaRun::kWalks;
-        continue;
-      }
-      r.a = PushArgs{r.alpha, r.rmax_local, 0.0, r.src, kFwdWhole};
-      r.cut = RoundCut();
-      r.cut.fixed = r.n_rounds > 0;
-      r.cut.enabled = r.n_rounds > 0 ? r.rounds + 1 < r.n_rounds : r.rounds + 1 < g->tun.max_rounds;
-      r.cut.omega = r.omega_local;
-      r.cut.c_walk = g->tun.c_walk_ns;
-      r.cut.alpha = r.alpha;
-      if (r.rounds == 0) {
-        PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)r.src, 1.0));
-        PPRHIP_TRY(seed_single(g, r.L, r.src, hdeg_out(g, r.src)));
-      } else {
-        PPRHIP_TRY(seed_scan(g, r.a, 0, r.L));
-      }
-      r.phase = ForaRun::kLevels;
-    }
-    if (r.phase == ForaRun::kLevels) {
-      const int rc = run_levels(g, r.a, r.L, r.st, &r.model_cost, yield_dense, &r.cut);
-      if (rc != PPRHIP_OK) return rc;  // kYield or an error
-      if (r.cut.taken && !r.cut.fixed) {
-        r.rsum_local = r.cut.rsum;  // measured when the round was cut; nothing was pushed since
-      } else {
-        double sum = 0.0;
-        PPRHIP_TRY(device_sum(g, g->residue, &sum));
-        r.rsum_local = sum * (1 - r.alpha);  // :101 (rsum is the exact residue sum here)
-      }
-      r.rmax_used = r.rmax_local;
-      r.rmax_local /= 2.0;  // :102
-      // The reference's loop would turn again (and restart the push from scratch at half the threshold) as
-      // long as the push stays cheaper than the walks; when the walks outweigh the push so far by ratio^k, k
-      // further halvings are taken at once instead of pushing at every threshold between (the twin does the same).
-      if (r.n_rounds == 0 && r.model_cost > 0.0 && g->tun.halving_ratio > 1.0) {
-        double ratio = g->tun.c_walk_ns * r.rsum_local * r.omega_local / r.model_cost;
-        for (int h = 1; ratio >= g->tun.halving_ratio && h < g->tun.max_halvings; ++h) {
-          ratio /= g->tun.halving_ratio;
-          r.rmax_local /= 2.0;
-        }
-      }
-      r.rounds++;
-      r.phase = (r.n_rounds > 0 && !(r.rsum_local > 0.0)) ? ForaRun::kWalks : ForaRun::kRoundStart;
-      continue;
-    }
-    if (r.phase == ForaRun::kWalks) {
-      leave_push(r);
-      PPRHIP_TRY(read_dead_pops(g, r.st));
-      if (r.tm) r.tm->mark(1);
-      // Fora_Whole_Graph.java:112-140
-      const double nrw_d = r.omega_local * r.rsum_local;
-      const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;
-      if (!r.dead_src) PPRHIP_TRY(run_walk_phase(g, 0, r.alpha, r.rsum_local, nrw, r.seed, 0, g->reserve, r.st));
-      if (r.tm) r.tm->mark(2);
-      r.st.rounds = (uint32_t)r.rounds;
-      r.st.rsum = r.rsum_local;
-      r.st.rmax_final = r.rmax_used;
-      r.st.omega = r.omega_local;
-      r.phase = ForaRun::kDone;
-    }
-    return PPRHIP_OK;
-  }
-}
-
-// Fora_Topk.computeTopKPPR (Fora_Topk.java:102-184) as a resumable run; the same sequence as
-// pprhip_fora_topk, which keeps the per-phase timing of a single call.
-int topk_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, const pprhip_fora_conf_t* conf,
-               uint64_t seed, int32_t* ids_out, double* vals_out, int cap) {
-  r.g = g;
-  r.kind = 1;
-  r.src = src_internal;
-  r.conf = conf;
-  r.seed = seed;
-  std::memset(&r.st, 0, sizeof r.st);
-  PPRHIP_TRY(reset_query_state(g, true));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags + src_internal, 1, 1, g->stream));  // Q = {s} (:117-118)
-  g->topk_active = true;
-  g->topk_first = true;
-  g->topk_src = src_internal;
-  g->topk_alpha = conf->alpha;
-  g->topk_rsum = conf->rsum;
-  r.alpha = conf->alpha;
-  r.eps_half = eps * 0.5;  // :109-110
-  r.delta_local = conf->delta;
-  r.min_delta = conf->min_delta;
-  r.min_rmax = r.eps_half * std::sqrt(r.min_delta / 3 / (double)conf->m / std::log(2 / conf->pfail));  // :113
-  r.rsum_local = conf->rsum;
-  r.omega_local = r.rmax_local = 0.0;
-  r.round = 0;
-  r.dead_src = false;
-  r.ids_out = ids_out;
-  r.vals_out = vals_out;
-  r.cap = cap;
-  r.nsel = 0;
-  r.phase = ForaRun::kTopkRoundStart;
-  r.waiting = false;
-  r.in_push = false;
-  return PPRHIP_OK;
-}
-
-int topk_step(ForaRun& r, bool yield_dense) {
-  pprhip_graph* g = r.g;
-  const pprhip_fora_conf_t* conf = r.conf;
-  const size_t nd = sizeof(double) * (size_t)g->n;
-  for (;;) {
-    if (r.phase == ForaRun::kTopkRoundStart) {
-      if (!(r.delta_local >= r.min_delta)) {  // :123
-        r.phase = ForaRun::kTopkFinal;
-        continue;
-      }
-      r.rmax_local = r.eps_half * std::sqrt(r.delta_local / 3.0 / (double)conf->m / std::log(2.0 / conf->pfail));  // :124
-      r.omega_local = (r.eps_half + 2.0) * std::log(2.0 / conf->pfail) / r.eps_half / r.eps_half / r.delta_local;  // :125
-      if (hdeg_out(g, r.src) == 0) {  // :126-132
-        PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
-        PPRHIP_TRY(launch_set_f64(g, g->est, (uint32_t)r.src, 1.0));
-        r.rsum_local = 0.0;
-        r.dead_src = true;
-        r.phase = ForaRun::kTopkFinal;
-        continue;
-      }
-      r.rmax_local *= std::sqrt((double)conf->m * r.rmax_local) * 3.0;  // :133
-      // forward_push_topk (:137; Forward_Push.java:144-250)
-      if (g->topk_first) PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)r.src, 1.0));
-      r.a = PushArgs{r.alpha, r.rmax_local, r.min_rmax, r.src, kFwdTopk};
-      r.L = LevelCtx();
-      r.in_push = true;
-      PPRHIP_TRY(seed_scan(g, r.a, 1, r.L));
-      r.phase = ForaRun::kTopkLevels;
-    }
-    if (r.phase == ForaRun::kTopkLevels) {
-      const int rc = run_levels(g, r.a, r.L, r.st, nullptr, yield_dense);
-      if (rc != PPRHIP_OK) return rc;  // kYield or an error
-      leave_push(r);
-      PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
-      g->topk_first = false;
-      r.rsum_local = g->topk_rsum;  // :142
-      // :143 reserve := copy of the push reserve (walk increments of earlier rounds are dropped)
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
-      const double rsum_rw = r.rsum_local * (1.0 - r.alpha);  // :148
-      const double nrw_d = r.omega_local * rsum_rw;
-      const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;  // :151
-      PPRHIP_TRY(run_walk_phase(g, 1, r.alpha, rsum_rw, nrw, r.seed, r.round, g->est, r.st));  // :155-168
-      r.round++;
-      double kth = 0.0;
-      bool have = false;
-      int nsel = 0;
-      PPRHIP_TRY(select_topk(g, g->est, conf->k, nullptr, nullptr, 0, &nsel, &kth, &have, r.st));  // :173
-      if (!have) kth = 0.0;                                                                          // :174
-      r.st.kth_value = kth;
-      if (kth >= (1 + r.eps_half) * r.delta_local || r.delta_local <= r.min_delta) {  // :175-176
-        r.phase = ForaRun::kTopkFinal;
-      } else {
-        r.delta_local = std::max(r.min_delta, r.delta_local / 4.0);  // :178
-        r.phase = ForaRun::kTopkRoundStart;
-      }
-      continue;
-    }
-    if (r.phase == ForaRun::kTopkFinal) {
-      if (r.round == 0 && !r.dead_src) PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
-      g->result_in_est = true;
-      PPRHIP_TRY(read_dead_pops(g, r.st));
-      bool have = false;
-      double kth = 0.0;
-      PPRHIP_TRY(select_topk(g, g->est, conf->k, r.ids_out, r.vals_out, r.cap, &r.nsel, &kth, &have, r.st));
-      r.st.rounds = r.round;
-      r.st.rsum = r.rsum_local;
-      r.st.rmax_final = r.rmax_local;
-      r.st.omega = r.omega_local;
-      r.phase = ForaRun::kDone;
-    }
-    return PPRHIP_OK;
-  }
-}
-
-// One backward search of All-Pair (Backward_Search.java:38-100 + the >= threshold filter of
-// Base_Whole_Graph.java:80-88) as a resumable run.
-int bwd_begin(ForaRun& r, pprhip_graph* g, int32_t target_internal, int32_t target_orig, double alpha, double rmax) {
-  r.g = g;
-  r.kind = 2;
-  r.src = target_internal;
-  r.target_orig = target_orig;
-  r.alpha = alpha;
-  r.rmax_local = rmax;
-  r.triples.clear();
-  std::memset(&r.st, 0, sizeof r.st);
-  g->topk_active = false;
-  PPRHIP_TRY(reset_query_state(g, false));
-  r.waiting = false;
-  r.in_push = false;
-  if (hdeg_in(g, target_internal) == 0) {  // :46-49
-    PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)target_internal, 1.0));
-    r.phase = ForaRun::kBwdFinal;
-    return PPRHIP_OK;
-  }
-  r.a = PushArgs{alpha, rmax, 0.0, target_internal, kBackward};
-  r.L = LevelCtx();
-  PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)target_internal, 1.0));
-  PPRHIP_TRY(seed_single(g, r.L, target_internal, hdeg_in(g, target_internal)));
-  r.in_push = true;
-  r.phase = ForaRun::kBwdLevels;
-  return PPRHIP_OK;
-}
-
-int bwd_step(ForaRun& r, bool yield_dense) {
-  pprhip_graph* g = r.g;
-  if (r.phase == ForaRun::kBwdLevels) {
-    const int rc = run_levels(g, r.a, r.L, r.st, nullptr, yield_dense);
-    if (rc != PPRHIP_OK) return rc;  // kYield or an error
-    leave_push(r);
-    r.phase = ForaRun::kBwdFinal;
-  }
-  if (r.phase == ForaRun::kBwdFinal) {
-    const double threshold = r.rmax_local;
-    unsigned long long thr_bits = 1ull;
-    if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
-    PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits));  // Base_Whole_Graph.java:83 pi >= threshold
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, g->stream));
-    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-    const uint64_t cnt = g->h_ctr->sel_count;
-    const std::vector<int32_t>& n2o = host_of(g)->h_new2old;
-    if (cnt > g->sel_cap) {
-      std::vector<double> all(g->n);
-      PPRHIP_TRY(copy_out(g, g->reserve, all.data()));
-      for (uint32_t v = 0; v < g->n; ++v)  // copy_out already returned original ids
-        if (all[v] > 0.0 && all[v] >= threshold) r.triples.push_back({(int32_t)v, r.target_orig, all[v]});
-    } else if (cnt) {
-      std::vector<int32_t> ids(cnt);
-      std::vector<double> vals(cnt);
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
-      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-      for (uint64_t i = 0; i < cnt; ++i) r.triples.push_back({n2o[ids[i]], r.target_orig, vals[i]});
-    }
-    r.phase = ForaRun::kDone;
-  }
-  return PPRHIP_OK;
-}
-
-void add_stats(pprhip_stats_t& sum, const pprhip_stats_t& st) {
-  sum.pops += st.pops; sum.edge_pushes += st.edge_pushes; sum.enqueues += st.enqueues;
-  sum.dead_end_pops += st.dead_end_pops; sum.dense_nodes += st.dense_nodes; sum.levels += st.levels;
-  sum.dense_levels += st.dense_levels; sum.rounds += st.rounds; sum.mc_sources += st.mc_sources;
-  sum.walks += st.walks; sum.walk_steps += st.walk_steps; sum.select_passes += st.select_passes;
-  sum.push_ms += st.push_ms; sum.mc_ms += st.mc_ms; sum.select_ms += st.select_ms; sum.total_ms += st.total_ms;
-  sum.push_bytes += st.push_bytes; sum.mc_bytes += st.mc_bytes; sum.select_bytes += st.select_bytes;
-  for (int c = 0; c < 8; ++c) {
-    sum.class_ms[c] += st.class_ms[c];
-    sum.class_bytes[c] += st.class_bytes[c];
-    sum.class_launches[c] += st.class_launches[c];
-  }
-}
-
-}  // namespace
-
-int pprhip_fora_single_source(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf,
-                              uint64_t seed, int n_rounds, double* reserve_out, pprhip_stats_t* stats) {
-  PPRHIP_TRY(check_graph(g, "pprhip_fora_single_source"));
-  PPRHIP_TRY(check_node(g, src, "pprhip_fora_single_source"));
-  src = g->h_old2new[src];  // internal (degree-sorted) id
-  if (!conf || !(eps > 0.0) || n_rounds < 0) {
-    set_error("pprhip_fora_single_source: bad arguments (eps=%g n_rounds=%d)", eps, n_rounds);
-    return PPRHIP_ERR_INVALID;
-  }
-  ForaRun r;
-  PPRHIP_TRY(fora_begin(r, g, src, eps, conf, seed, n_rounds));
-  CallTimer tm(g);
-  r.tm = &tm;
-  PPRHIP_TRY(fora_step(r, false));
-  tm.finish(r.st);
-  r.st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
-  r.st.mc_ms = CallTimer::ms(g->ev[1], g->ev[2]);
-  PPRHIP_TRY(copy_out(g, g->reserve, reserve_out));
-  if (stats) *stats = r.st;
-  return PPRHIP_OK;
-}
-
-namespace {
-
-// One batched dense level for the slots flagged in `active`: stages their arguments, orders the
-// parent stream behind the slots' prepare work, runs the sweep and brings the new frontier counters
-// back.  The caller holds the sweep exclusively (sequential driver, or BatchSync::sweeping).
-int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) {
-  for (int s = 0; s < kBatch; ++s) {
-    pprhip_graph* S = P->slots[s];
-    SlotArgs& sa = P->h_slot_args[s];
-    sa.res = S->residue;
-    sa.reserve = S->reserve;
-    sa.flags = S->flags;
-    sa.ctr = S->ctr;
-    sa.active = active[s] ? 1 : 0;
-    if (!active[s]) continue;
-    const ForaRun& r = runs[s];
-    sa.alpha = r.a.alpha;
-    sa.rmax = r.a.rmax;
-    sa.min_rmax = r.a.min_rmax;
-    sa.src = r.a.src;
-    sa.mode = r.a.mode;
-    sa.dead_slot = r.L.dslot;
-    sa.out_slot = r.L.pslot ^ 1;
-    if (S->stream != P->stream) {
-      PPRHIP_CHECK_HIP(hipEventRecord(S->ev[3], S->stream));
-      PPRHIP_CHECK_HIP(hipStreamWaitEvent(P->stream, S->ev[3], 0));
-    }
-  }
-  const uint64_t sweep_bytes = 4ull * P->m + (uint64_t)n_active * (8ull * P->m + 36ull * P->n + 4ull);
-  bool backward = false;
-  for (int s = 0; s < kBatch; ++s)
-    if (active[s] && runs[s].a.mode == kBackward) backward = true;  // a job's runs all push the same way
-  if ((int)backward != P->acc8_dir) {
-    // rows summed with atomics are cleared by the apply kernel of their own layout only: start clean
-    PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * ((size_t)P->n + 1) * kBatch, P->stream));
-    P->acc8_dir = (int)backward;
-  }
-  P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
-  PPRHIP_TRY(launch_dense_level_b8(P, backward));
-  P->ktimer.end();
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(P->h_sweep_out, P->sweep_out, sizeof(unsigned long long) * kBatch,
-                                  hipMemcpyDeviceToHost, P->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
-  P->c8cur ^= 1;
-  for (int s = 0; s < kBatch; ++s)
-    if (active[s]) {
-      ForaRun& r = runs[s];
-      const unsigned long long pk = P->h_sweep_out[s];
-      // the sweep's index stream is shared: each query is charged its own gathers and row work
-      finish_dense(r.L, r.st, 8ull * P->m + 36ull * P->n + 4ull + 4ull * P->m / (uint64_t)n_active,
-                   (uint32_t)(pk >> kPackShift), pk & kPackMask);
-    }
-  return PPRHIP_OK;
-}
-
-struct BatchJob {
-  pprhip_graph* P;
-  const int32_t* srcs;
-  int q;
-  double eps;
-  const pprhip_fora_conf_t* conf;
-  uint64_t seed;
-  int n_rounds;
-  double* reserve_out;
-  int k;
-  int32_t* ids_out;
-  double* vals_out;
-  int* n_out;
-  pprhip_stats_t* per_query;
-  int kind = 0;  // 0: whole-graph FORA per query, 1: FORA top-k per query (seed + query index), 2: backward search
-  double alpha = 0.0, threshold = 0.0;   // kind 2
-  std::vector<Triple>* triples = nullptr;  // kind 2: every search's entries >= threshold
-  pprhip_stats_t sum;
-  std::mutex sum_mu;
-  std::atomic<int> next_query{0};
-};
-
-int run_step(ForaRun& r, bool yield_dense) {
-  return r.kind == 2 ? bwd_step(r, yield_dense) : r.kind == 1 ? topk_step(r, yield_dense) : fora_step(r, yield_dense);
-}
-
-// outputs of a finished query (its slot still holds the vectors)
-int finish_query(BatchJob& J, ForaRun& r) {
-  pprhip_graph* S = r.g;
-  const int i = r.query;
-  if (r.kind == 2) {
-    std::lock_guard<std::mutex> lk(J.sum_mu);
-    J.triples->insert(J.triples->end(), r.triples.begin(), r.triples.end());
-    add_stats(J.sum, r.st);
-    r.triples.clear();
-    r.phase = ForaRun::kDone;
-    r.query = -1;
-    return PPRHIP_OK;
-  }
-  if (J.reserve_out) PPRHIP_TRY(copy_out(S, r.kind == 1 ? S->est : S->reserve, J.reserve_out + (size_t)i * J.P->n));
-  if (r.kind == 1) {  // the run's final selection wrote the first min(nsel, k) pairs
-    for (int j = std::min(r.nsel, J.k); j < J.k; ++j) {
-      r.ids_out[j] = -1;
-      r.vals_out[j] = 0.0;
-    }
-    if (J.n_out) J.n_out[i] = r.nsel;
-  } else if (J.k > 0) {
-    int nsel = 0;
-    bool have = false;
-    int32_t* ids = J.ids_out + (size_t)i * J.k;
-    double* vals = J.vals_out + (size_t)i * J.k;
-    PPRHIP_TRY(select_topk(S, S->reserve, J.k, ids, vals, J.k, &nsel, nullptr, &have, r.st));
-    for (int j = std::min(nsel, J.k); j < J.k; ++j) {
-      ids[j] = -1;
-      vals[j] = 0.0;
-    }
-    if (J.n_out) J.n_out[i] = nsel;
-  }
-  if (J.per_query) J.per_query[i] = r.st;
-  {
-    std::lock_guard<std::mutex> lk(J.sum_mu);
-    add_stats(J.sum, r.st);
-  }
-  r.phase = ForaRun::kDone;
-  r.query = -1;
-  return PPRHIP_OK;
-}
-
-int begin_query(BatchJob& J, ForaRun& r, pprhip_graph* S, int i) {
-  S->tun = J.P->tun;
-  const int32_t src = J.P->h_old2new[J.srcs[i]];
-  if (J.kind == 2) {
-    pprhip_tuning_batch(&S->tun);  // level shapes only: a backward search has no cost-model decisions
-    PPRHIP_TRY(bwd_begin(r, S, src, J.srcs[i], J.alpha, J.threshold));
-  } else if (J.kind == 1) {
-    PPRHIP_TRY(topk_begin(r, S, src, J.eps, J.conf, J.seed + (uint64_t)i, J.ids_out + (size_t)i * J.k,
-                          J.vals_out + (size_t)i * J.k, J.k));
-  } else {
-    r.kind = 0;
-    PPRHIP_TRY(fora_begin(r, S, src, J.eps, J.conf, J.seed, J.n_rounds));
-  }
-  r.query = i;
-  return PPRHIP_OK;
-}
-
-// all slots on the calling thread and the graph's stream, one after another
-int batch_sequential(BatchJob& J, ForaRun* runs) {
-  pprhip_graph* P = J.P;
-  int busy = 0;
-  for (;;) {
-    // every slot advances until it waits at a dense level; finished slots take the next query
-    for (int s = 0; s < kBatch; ++s) {
-      ForaRun& r = runs[s];
-      for (;;) {
-        if (r.query < 0) {
-          const int i = J.next_query.load();
-          if (i >= J.q) break;
-          J.next_query.store(i + 1);
-          PPRHIP_TRY(begin_query(J, r, P->slots[s], i));
-          busy++;
-        }
-        if (r.waiting) break;
-        const int rc = run_step(r, true);
-        if (rc == kYield) {
-          r.waiting = true;
-          break;
-        }
-        if (rc != PPRHIP_OK) return rc;
-        PPRHIP_TRY(finish_query(J, r));
-        busy--;
-      }
-    }
-    if (busy == 0) break;
-    bool active[kBatch];
-    int n_wait = 0;
-    for (int s = 0; s < kBatch; ++s) {
-      active[s] = runs[s].query >= 0 && runs[s].waiting;
-      n_wait += active[s] ? 1 : 0;
-    }
-    PPRHIP_TRY(run_sweep(P, runs, active, n_wait));
-    for (int s = 0; s < kBatch; ++s)
-      if (active[s]) runs[s].waiting = false;
-  }
-  return PPRHIP_OK;
-}
-
-// one worker thread per slot
-void batch_worker(BatchJob* J, BatchSync* B, ForaRun* runs, int s) {
-  pprhip_graph* P = J->P;
-  pprhip_graph* S = P->slots[s];
-  ForaRun& r = runs[s];
-  int rc = PPRHIP_OK;
-  if (hipSetDevice(P->device) != hipSuccess) {
-    set_error("hipSetDevice(%d) failed in a batch worker", P->device);
-    rc = PPRHIP_ERR_HIP;
-  }
-  g_timer_cur = &S->ktimer;
-  S->ktimer.stream = S->stream;
-  S->ktimer.reset();
-  while (rc == PPRHIP_OK) {
-    {
-      std::lock_guard<std::mutex> lk(B->mu);
-      if (B->err) break;
-    }
-    const int i = J->next_query.fetch_add(1);
-    if (i >= J->q) break;
-    rc = begin_query(*J, r, S, i);
-    while (rc == PPRHIP_OK) {
-      rc = run_step(r, true);
-      if (rc != kYield) break;
-      rc = B->arrive(s);
-    }
-    if (rc == PPRHIP_OK) rc = finish_query(*J, r);
-  }
-  if (rc != PPRHIP_OK) {
-    leave_push(r);
-    B->fail(rc);
-  }
-  (void)hipStreamSynchronize(S->stream);
-  g_timer_cur = &g_timer_own;
-  B->worker_done(s);
-}
-
-}  // namespace
-
-namespace pprhip {
-
-void BatchSync::release(int s) {
-  std::lock_guard<std::mutex> lk(mu);
-  if (hold[s]) {
-    hold[s] = false;
-    n_hold--;
-    cv.notify_all();
-  }
-}
-
-void BatchSync::c8_enter(int s) {
-  std::unique_lock<std::mutex> lk(mu);
-  cv.wait(lk, [&] { return !sweeping || err != 0; });
-  if (!hold[s]) {
-    hold[s] = true;
-    n_hold++;
-  }
-}
-
-void BatchSync::fail(int rc) {
-  std::lock_guard<std::mutex> lk(mu);
-  if (!err) {
-    err = rc;
-    errmsg = get_error();
-  }
-  cv.notify_all();
-}
-
-void BatchSync::worker_done(int s) {
-  std::lock_guard<std::mutex> lk(mu);
-  if (hold[s]) {
-    hold[s] = false;
-    n_hold--;
-  }
-  n_workers--;
-  cv.notify_all();
-}
-
-int BatchSync::arrive(int s) {
-  std::unique_lock<std::mutex> lk(mu);
-  if (err) return err;
-  if (hold[s]) {
-    hold[s] = false;
-    n_hold--;
-  }
-  waitflag[s] = true;
-  n_wait++;
-  cv.notify_all();
-  cv.wait(lk, [&] { return !waitflag[s] || err != 0; });
-  return err;
-}
-
-// the sweeper thread: one batched sweep whenever somebody waits and nobody holds
-void BatchSync::sweeper() {
-  (void)hipSetDevice(P->device);
-  std::unique_lock<std::mutex> lk(mu);
-  for (;;) {
-    cv.wait(lk, [&] { return n_workers == 0 || err != 0 || (n_wait > 0 && n_hold == 0); });
-    if (n_workers == 0 || err != 0) return;
-    sweeping = true;
-    bool active[kBatch];
-    int n_active = 0;
-    for (int s = 0; s < kBatch; ++s) {
-      active[s] = waitflag[s];
-      n_active += active[s] ? 1 : 0;
-    }
-    lk.unlock();
-    const int rc = run_sweep(P, runs, active, n_active);
-    const std::string msg = rc != PPRHIP_OK ? get_error() : "";
-    lk.lock();
-    if (rc != PPRHIP_OK && !err) {
-      err = rc;
-      errmsg = msg;
-    }
-    for (int s = 0; s < kBatch; ++s)
-      if (active[s]) {
-        waitflag[s] = false;
-        n_wait--;
-        hold[s] = true;  // until the slot has said what it does next
-        n_hold++;
-      }
-    sweeping = false;
-    cv.notify_all();
-  }
-}
-
-}  // namespace pprhip
-
-// Batched single-source FORA: up to kBatch queries in flight on kBatch workspaces of this handle.
-// Every query runs the single-query algorithm unchanged (same levels, same thresholds, same walks
-// for the same seed); whenever the queries in a push phase all stand at a dense level, one sweep of
-// the batched kernels serves them.  All slots run on the calling thread and the handle's stream;
-// with PPRHIP_BATCH_THREADS=1 (the default of the top-k entry point) every slot gets a worker
-// thread and a stream of its own, so sparse levels, walks and selections of different queries
-// overlap on the GPU.
-// runs a prepared job on the handle's slots (both batched entry points)
-static int batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* stats_sum) {
-  PPRHIP_TRY(ensure_batch(g));
-  if (J.kind == 2) PPRHIP_TRY(ensure_bwd_layout(g));
-  const int q = J.q;
-  // Worker threads pay off where queries are latency-bound (top-k: short rounds of sparse levels, walks
-  // and selections, 2.4x on R-MAT 22); whole-graph FORA keeps the memory system busy from one thread.
-  const char* env = getenv("PPRHIP_BATCH_THREADS");
-  const bool threaded = q > 1 && (env ? env[0] == '1' : J.kind != 0);
-  std::memset(&J.sum, 0, sizeof J.sum);
-  ForaRun runs[kBatch];
-  g->ktimer.stream = g->stream;
-  g->ktimer.reset();
-  const auto t0 = std::chrono::steady_clock::now();
-  int rc = PPRHIP_OK;
-  double tot[8] = {0};
-  uint64_t bytes[8] = {0};
-  uint32_t cnt[8] = {0};
-  if (threaded) {
-    BatchSync B;
-    B.P = g;
-    B.runs = runs;
-    for (pprhip_graph* S : g->slots) {
-      S->stream = S->own_stream;
-      S->sync = &B;
-    }
-    B.n_workers = kBatch;
-    std::thread sweeper(&BatchSync::sweeper, &B);
-    std::vector<std::thread> workers;
-    for (int s = 0; s < kBatch; ++s) workers.emplace_back(batch_worker, &J, &B, runs, s);
-    for (auto& w : workers) w.join();
-    sweeper.join();
-    for (pprhip_graph* S : g->slots) {
-      S->sync = nullptr;
-      S->ktimer.resolve(tot, bytes, cnt);
-    }
-    if (B.err) {
-      set_error("%s", B.errmsg.c_str());
-      rc = B.err;
-    }
-  } else {
-    for (pprhip_graph* S : g->slots) {
-      S->stream = g->stream;
-      S->sync = nullptr;
-    }
-    KernelTimer local;  // the caller's timer may be in use (All-Pair times its own tiers)
-    KernelTimer* const saved = g_timer_cur;
-    g_timer_cur = &local;
-    local.stream = g->stream;
-    rc = batch_sequential(J, runs);
-    (void)hipStreamSynchronize(g->stream);
-    local.resolve(tot, bytes, cnt);
-    local.destroy();
-    g_timer_cur = saved;
-  }
-  (void)hipStreamSynchronize(g->stream);
-  if (rc != PPRHIP_OK) {
-    const std::string msg = get_error();
-    free_batch(g);  // slots may hold half-pushed levels: the next batched call builds clean ones
-    set_error("%s", msg.c_str());
-    return rc;
-  }
-  g->ktimer.resolve(tot, bytes, cnt);
-  pprhip_stats_t& sum = J.sum;
-  sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  int best = 0;
-  for (int c = 0; c < 8; ++c) {
-    sum.class_ms[c] = tot[c];
-    sum.class_bytes[c] = bytes[c];
-    sum.class_launches[c] = cnt[c];
-    if (tot[c] > tot[best]) best = c;
-  }
-  sum.dominant_kernel_id = (uint32_t)best;
-  sum.dominant_kernel_ms = tot[best];
-  sum.dominant_kernel_bytes = bytes[best];
-  sum.dominant_kernel_launches = cnt[best];
-  if (stats_sum) *stats_sum = sum;
-  return PPRHIP_OK;
-}
-
-int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
-                                    const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
-                                    double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
-                                    pprhip_stats_t* per_query, pprhip_stats_t* stats_sum) {
-  PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_single_source"));
-  if (q < 0 || !conf || !(eps > 0.0) || n_rounds < 0 || (q > 0 && !srcs) || k < 0 ||
-      (k > 0 && q > 0 && (!ids_out || !vals_out))) {
-    set_error("pprhip_fora_batch_single_source: bad arguments (q=%d eps=%g n_rounds=%d k=%d)", q, eps, n_rounds, k);
-    return PPRHIP_ERR_INVALID;
-  }
-  for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_single_source"));
-  BatchJob J;
-  J.P = g;
-  J.srcs = srcs;
-  J.q = q;
-  J.eps = eps;
-  J.conf = conf;
-  J.seed = seed;
-  J.n_rounds = n_rounds;
-  J.reserve_out = reserve_out;
-  J.k = k;
-  J.ids_out = ids_out;
-  J.vals_out = vals_out;
-  J.n_out = n_out;
-  J.per_query = per_query;
-  return batch_run(g, J, stats_sum);
-}
-
 // ------------------------------------------------------------------ top-k select (a7)
 int pprhip_topk_select(pprhip_graph_t* g, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
                        double* kth_out, pprhip_stats_t* stats) {
@@ -2127,34 +1232,6 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
   PPRHIP_TRY(copy_out(g, g->est, reserve_out));
   if (stats) *stats = st;
   return PPRHIP_OK;
-}
-
-int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k, double eps, double alpha,
-                           uint64_t seed, int32_t* ids_out, double* vals_out, pprhip_stats_t* stats_sum) {
-  PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_topk"));
-  if (q < 0 || k < 1 || !(eps > 0.0) || (q > 0 && (!srcs || !ids_out || !vals_out))) {
-    set_error("pprhip_fora_batch_topk: bad arguments");
-    return PPRHIP_ERR_INVALID;
-  }
-  for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_topk"));
-  pprhip_fora_conf_t conf;
-  PPRHIP_TRY(pprhip_conf_fora_topk(g->n, g->m, k, alpha, &conf));
-  BatchJob J;
-  J.P = g;
-  J.kind = 1;
-  J.srcs = srcs;
-  J.q = q;
-  J.eps = eps;
-  J.conf = &conf;
-  J.seed = seed;  // query i runs with seed + i, as pprhip_fora_topk(srcs[i], ..., seed + i) would
-  J.n_rounds = 0;
-  J.reserve_out = nullptr;
-  J.k = k;
-  J.ids_out = ids_out;
-  J.vals_out = vals_out;
-  J.n_out = nullptr;
-  J.per_query = nullptr;
-  return batch_run(g, J, stats_sum);
 }
 
 // ------------------------------------------------------------------ pure Monte-Carlo
@@ -2290,326 +1367,5 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
   if (stats) *stats = st;
   return PPRHIP_OK;
 }
-
-}  // extern "C"
-
-// =================================================================================================
-// All-Pair-Backward-Search (a9) — first correct path: one backward search per target on the
-// global arrays, entries >= threshold compacted on the device, inverted index built on the host.
-// =================================================================================================
-struct pprhip_index {
-  uint32_t n = 0;
-  std::vector<uint64_t> offsets;
-  std::vector<int32_t> targets;
-  std::vector<double> values;
-};
-
-namespace {
-
-// Base_Whole_Graph.java:112-163: per source, k < 0 keeps insertion (target) order; k >= 0 keeps
-// entries >= the k-th largest (all when fewer than k) sorted descending (stable: ties stay in
-// target order).
-void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix) {
-  ix->n = n;
-  ix->offsets.assign((size_t)n + 1, 0);
-  // bucket by source (counting sort), then every bucket on its own: order by target, apply the k rule
-  const size_t N = tr.size();
-  std::vector<uint64_t> start((size_t)n + 1, 0);
-  for (const Triple& e : tr) start[(size_t)e.v + 1]++;
-  for (uint32_t v = 0; v < n; ++v) start[v + 1] += start[v];
-  std::vector<Triple> by_v(N);
-  {
-    std::vector<uint64_t> at(start.begin(), start.end() - 1);
-    for (const Triple& e : tr) by_v[at[e.v]++] = e;
-  }
-  std::vector<Triple>().swap(tr);
-  std::vector<uint64_t> kept((size_t)n + 1, 0);
-  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  const unsigned T = N < (1u << 16) ? 1u : hw;
-  auto for_ranges = [&](auto&& fn) {
-    std::vector<std::thread> th;
-    for (unsigned w = 1; w < T; ++w) th.emplace_back(fn, (uint32_t)((uint64_t)n * w / T), (uint32_t)((uint64_t)n * (w + 1) / T));
-    fn(0u, (uint32_t)((uint64_t)n / T));
-    for (auto& x : th) x.join();
-  };
-  // pass 1: each bucket sorted by target; for k >= 0 the kept entries move to the bucket's front, by value
-  for_ranges([&](uint32_t lo, uint32_t hi) {
-    std::vector<double> tmp;
-    for (uint32_t v = lo; v < hi; ++v) {
-      Triple* b = by_v.data() + start[v];
-      const size_t len = (size_t)(start[v + 1] - start[v]);
-      if (len == 0) continue;
-      std::sort(b, b + len, [](const Triple& x, const Triple& y) { return x.t < y.t; });
-      if (k < 0) {
-        kept[v + 1] = len;
-        continue;
-      }
-      bool have = false;
-      double kth = 0.0;
-      if (k >= 1 && (size_t)k <= len) {
-        tmp.resize(len);
-        for (size_t j = 0; j < len; ++j) tmp[j] = b[j].p;
-        std::nth_element(tmp.begin(), tmp.begin() + (k - 1), tmp.end(), std::greater<double>());
-        kth = tmp[k - 1];
-        have = true;
-      }
-      size_t w = 0;
-      for (size_t j = 0; j < len; ++j)
-        if (!have || b[j].p >= kth) b[w++] = b[j];
-      std::stable_sort(b, b + w, [](const Triple& x, const Triple& y) { return x.p > y.p; });
-      kept[v + 1] = w;
-    }
-  });
-  for (uint32_t v = 0; v < n; ++v) kept[v + 1] += kept[v];
-  ix->targets.resize(kept[n]);
-  ix->values.resize(kept[n]);
-  for (uint32_t v = 0; v <= n; ++v) ix->offsets[v] = kept[v];
-  // pass 2: into the index arrays
-  for_ranges([&](uint32_t lo, uint32_t hi) {
-    for (uint32_t v = lo; v < hi; ++v) {
-      const Triple* b = by_v.data() + start[v];
-      const size_t len = (size_t)(kept[v + 1] - kept[v]);
-      for (size_t j = 0; j < len; ++j) {
-        ix->targets[kept[v] + j] = b[j].t;
-        ix->values[kept[v] + j] = b[j].p;
-      }
-    }
-  });
-}
-
-}  // namespace
-
-extern "C" {
-
-int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, int k, uint32_t t_begin, uint32_t t_end,
-                             pprhip_index_t** index_out, pprhip_stats_t* stats) {
-  PPRHIP_TRY(check_graph(g, "pprhip_all_pair_backward"));
-  if (!index_out || t_begin > t_end || t_end > g->n) {
-    set_error("pprhip_all_pair_backward: bad target range [%u, %u) for n=%u", t_begin, t_end, g->n);
-    return PPRHIP_ERR_INVALID;
-  }
-  pprhip_stats_t st;
-  std::memset(&st, 0, sizeof st);
-  g->topk_active = false;
-  CallTimer tm(g);
-  std::vector<Triple> tr;
-  const uint32_t n_targets = t_end - t_begin;
-  // PPRHIP_APBS_TIER = 2 / 3 starts at a later tier (tests exercise every tier that way)
-  const int first_tier = getenv("PPRHIP_APBS_TIER") ? atoi(getenv("PPRHIP_APBS_TIER")) : 1;
-
-  // ---- device buffers of this call
-  ApbsBuffers B;
-  unsigned long long* cells = nullptr;  // next_target, out_count, out_valid, overflow_count, pops, edges
-  int rc = PPRHIP_OK;
-  auto release = [&]() {
-    void* p[] = {cells, B.out_v, B.out_t, B.out_p, B.overflow, B.g_tables};
-    for (void* q : p)
-      if (q) (void)hipFree(q);
-  };
-  B.out_cap = std::min<unsigned long long>(1ull << 24, std::max<unsigned long long>(1ull << 16, 64ull * g->n));
-  if ((rc = alloc_dev((void**)&cells, sizeof(unsigned long long) * 8)) ||
-      (rc = alloc_dev((void**)&B.out_v, sizeof(int32_t) * B.out_cap)) ||
-      (rc = alloc_dev((void**)&B.out_t, sizeof(int32_t) * B.out_cap)) ||
-      (rc = alloc_dev((void**)&B.out_p, sizeof(double) * B.out_cap)) ||
-      (rc = alloc_dev((void**)&B.overflow, sizeof(int32_t) * std::max<uint32_t>(1, n_targets)))) {
-    release();
-    return rc;
-  }
-  B.next_target = cells;
-  B.out_count = cells + 1;
-  B.out_valid = cells + 2;
-  B.overflow_count = cells + 3;
-  B.stat_pops = cells + 4;
-  B.stat_edges = cells + 5;
-  std::vector<int32_t> h_v, h_t, h_ovf;
-  std::vector<double> h_p;
-  unsigned long long h_cells[8];
-
-  // runs one tier over `list` (or the range when list is empty and use_range) until every target
-  // has either produced its triples or landed in `give_up`
-  auto run_tier = [&](bool global_tier, std::vector<int32_t> list, bool use_range, std::vector<int32_t>& give_up) -> int {
-    int32_t* d_list = nullptr;
-    for (int pass = 0; pass < 1000; ++pass) {
-      const uint32_t cnt = use_range ? n_targets : (uint32_t)list.size();
-      if (cnt == 0) break;
-      if (!use_range) {
-        if (!d_list) PPRHIP_TRY(alloc_dev((void**)&d_list, sizeof(int32_t) * list.size()));
-        PPRHIP_CHECK_HIP(hipMemcpyAsync(d_list, list.data(), sizeof(int32_t) * cnt, hipMemcpyHostToDevice, g->stream));
-      }
-      const unsigned long long init[8] = {0, 0, ~0ull, 0, 0, 0, 0, 0};
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(cells, init, sizeof init, hipMemcpyHostToDevice, g->stream));
-      ktimer().begin(PPRHIP_KERNEL_BACKWARD_BATCH, 0);
-      PPRHIP_TRY(launch_apbs(g, global_tier, use_range ? nullptr : d_list, t_begin, cnt, alpha, threshold, B));
-      ktimer().end();
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(h_cells, cells, sizeof h_cells, hipMemcpyDeviceToHost, g->stream));
-      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-      const unsigned long long valid = std::min(std::min(h_cells[1], h_cells[2]), B.out_cap);
-      st.pops += h_cells[4];
-      st.edge_pushes += h_cells[5];
-      const uint64_t bytes = 44ull * h_cells[4] + 28ull * h_cells[5] + 16ull * valid;
-      st.push_bytes += bytes;
-      if (!ktimer().recs.empty()) ktimer().recs.back().bytes = bytes;
-      if (valid) {
-        h_v.resize(valid); h_t.resize(valid); h_p.resize(valid);
-        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_v.data(), B.out_v, sizeof(int32_t) * valid, hipMemcpyDeviceToHost, g->stream));
-        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_t.data(), B.out_t, sizeof(int32_t) * valid, hipMemcpyDeviceToHost, g->stream));
-        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_p.data(), B.out_p, sizeof(double) * valid, hipMemcpyDeviceToHost, g->stream));
-        PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-        for (unsigned long long i = 0; i < valid; ++i) tr.push_back({h_v[i], h_t[i], h_p[i]});
-      }
-      std::vector<int32_t> again;
-      const unsigned long long novf = h_cells[3];
-      if (novf) {
-        h_ovf.resize(novf);
-        PPRHIP_CHECK_HIP(hipMemcpy(h_ovf.data(), B.overflow, sizeof(int32_t) * novf, hipMemcpyDeviceToHost));
-        for (int32_t x : h_ovf) {
-          if (x >= 0) give_up.push_back(x);  // table too small for this target
-          else again.push_back(-(x + 1));    // triple buffer was full: same tier again
-        }
-      }
-      list.swap(again);
-      use_range = false;
-      if (d_list && list.size()) {
-        (void)hipFree(d_list);
-        d_list = nullptr;
-      }
-    }
-    if (d_list) (void)hipFree(d_list);
-    return PPRHIP_OK;
-  };
-
-  std::vector<int32_t> to_tier2, to_tier3;
-  if (first_tier <= 1) {
-    rc = run_tier(false, {}, true, to_tier2);
-  } else {
-    for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
-  }
-  if (rc == PPRHIP_OK && !to_tier2.empty()) {
-    B.g_cap = 65536;
-    // 8 workgroups per CU: the HBM tier is a chain of L2 round trips per edge, hidden only by occupancy
-    B.g_blocks = (uint32_t)std::min<size_t>((size_t)g->n_cus * 8, to_tier2.size());
-    rc = alloc_dev((void**)&B.g_tables, (size_t)B.g_blocks * B.g_cap * 40);
-    if (rc == PPRHIP_OK) rc = run_tier(true, to_tier2, false, to_tier3);
-  }
-  release();
-  if (rc != PPRHIP_OK) return rc;
-
-  // ---- tier 3: the targets whose search outgrows a 48K-node table run on whole vectors, 16 of them in flight
-  // on the batch slots; levels that touch a large part of the graph run as batched sweeps over the out-CSR
-  pprhip_stats_t st3;
-  std::memset(&st3, 0, sizeof st3);
-  if (!to_tier3.empty()) {  // Base_Whole_Graph.java:76-92
-    BatchJob J;
-    J.P = g;
-    J.kind = 2;
-    J.srcs = to_tier3.data();
-    J.q = (int)to_tier3.size();
-    J.eps = 0.0;
-    J.conf = nullptr;
-    J.seed = 0;
-    J.n_rounds = 0;
-    J.reserve_out = nullptr;
-    J.k = 0;
-    J.ids_out = nullptr;
-    J.vals_out = nullptr;
-    J.n_out = nullptr;
-    J.per_query = nullptr;
-    J.alpha = alpha;
-    J.threshold = threshold;
-    J.triples = &tr;
-    PPRHIP_TRY(batch_run(g, J, &st3));
-    st.pops += st3.pops;
-    st.edge_pushes += st3.edge_pushes;
-    st.enqueues += st3.enqueues;
-    st.levels += st3.levels;
-    st.dense_levels += st3.dense_levels;
-    st.push_bytes += st3.push_bytes;
-  }
-  tm.mark(1);
-  tm.finish(st);
-  for (int c = 0; c < 8; ++c) {
-    st.class_ms[c] += st3.class_ms[c];
-    st.class_bytes[c] += st3.class_bytes[c];
-    st.class_launches[c] += st3.class_launches[c];
-  }
-  st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
-  st.rmax_final = threshold;
-  st.rounds = (uint32_t)(to_tier2.size());      // targets that needed the HBM tier
-  st.dense_nodes = (uint64_t)to_tier3.size();   // targets that needed the whole-vector path
-  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
-  if (!ix) return PPRHIP_ERR_OOM;
-  finalize_rows(g->n, tr, k, ix.get());
-  *index_out = ix.release();
-  if (stats) *stats = st;
-  return PPRHIP_OK;
-}
-
-int pprhip_index_merge(const pprhip_index_t* const* shards, int n_shards, int k, pprhip_index_t** merged_out) {
-  if (!shards || n_shards < 1 || !merged_out) {
-    set_error("pprhip_index_merge: bad arguments");
-    return PPRHIP_ERR_INVALID;
-  }
-  const uint32_t n = shards[0]->n;
-  std::vector<Triple> tr;
-  for (int s = 0; s < n_shards; ++s) {
-    if (!shards[s] || shards[s]->n != n) {
-      set_error("pprhip_index_merge: shard %d does not match", s);
-      return PPRHIP_ERR_INVALID;
-    }
-    for (uint32_t v = 0; v < n; ++v)
-      for (uint64_t i = shards[s]->offsets[v]; i < shards[s]->offsets[v + 1]; ++i)
-        tr.push_back({(int32_t)v, shards[s]->targets[i], shards[s]->values[i]});
-  }
-  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
-  if (!ix) return PPRHIP_ERR_OOM;
-  finalize_rows(n, tr, k, ix.get());
-  *merged_out = ix.release();
-  return PPRHIP_OK;
-}
-
-int pprhip_index_from_arrays(uint32_t n, const uint64_t* offsets, const int32_t* targets, const double* values,
-                             pprhip_index_t** index_out) {
-  if (!offsets || !index_out || offsets[0] != 0 || (offsets[n] && (!targets || !values))) {
-    set_error("pprhip_index_from_arrays: bad arguments");
-    return PPRHIP_ERR_INVALID;
-  }
-  for (uint32_t v = 0; v < n; ++v)
-    if (offsets[v + 1] < offsets[v]) {
-      set_error("pprhip_index_from_arrays: offsets must be non-decreasing");
-      return PPRHIP_ERR_INVALID;
-    }
-  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
-  if (!ix) return PPRHIP_ERR_OOM;
-  ix->n = n;
-  ix->offsets.assign(offsets, offsets + n + 1);
-  ix->targets.assign(targets, targets + offsets[n]);
-  ix->values.assign(values, values + offsets[n]);
-  *index_out = ix.release();
-  return PPRHIP_OK;
-}
-
-int pprhip_index_info(const pprhip_index_t* ix, uint32_t* n, uint64_t* entries) {
-  if (!ix) {
-    set_error("pprhip_index_info: null index");
-    return PPRHIP_ERR_INVALID;
-  }
-  if (n) *n = ix->n;
-  if (entries) *entries = ix->targets.size();
-  return PPRHIP_OK;
-}
-
-int pprhip_index_arrays(const pprhip_index_t* ix, const uint64_t** offsets, const int32_t** targets,
-                        const double** values) {
-  if (!ix || !offsets || !targets || !values) {
-    set_error("pprhip_index_arrays: null argument");
-    return PPRHIP_ERR_INVALID;
-  }
-  *offsets = ix->offsets.data();
-  *targets = ix->targets.data();
-  *values = ix->values.data();
-  return PPRHIP_OK;
-}
-
-void pprhip_index_destroy(pprhip_index_t* ix) { delete ix; }
 
 }  // extern "C"

@@ -1,0 +1,172 @@
+// engine_internal.hpp — declarations shared by the engine's translation units (engine.cpp: graph
+// lifecycle, level loop, single-query entry points; fora.cpp: resumable FORA / top-k / backward runs
+// and the batched entry points; allpair.cpp: All-Pair-Backward-Search and the inverted index).
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+
+namespace pprhip {
+
+struct ForaRun;
+
+// Rendezvous of the batch workers (one host thread and one stream per slot) with the sweeper
+// thread.  Workers run their queries' sparse levels, walks and selections concurrently; a worker
+// whose next level is dense waits here.  The sweeper runs a batched sweep whenever somebody waits
+// and no slot "holds": a slot holds from the moment a sweep releases it until it has said what it
+// does next (waits again, goes on with sparse levels, ends its push phase), and while it writes its
+// column of the shared contribution array.  Slots busy with sparse levels or walks hold nothing,
+// so their kernels overlap the sweeps of the others.
+struct BatchSync {
+  std::mutex mu;
+  std::condition_variable cv;
+  pprhip_graph* P = nullptr;
+  ForaRun* runs = nullptr;
+  int n_wait = 0, n_hold = 0, n_workers = 0;
+  bool sweeping = false;
+  bool waitflag[kBatch] = {};
+  bool hold[kBatch] = {};
+  int err = 0;
+  std::string errmsg;
+  void release(int s);  // the slot stops holding (no-op when it does not)
+  void c8_enter(int s);  // before a slot's kernels touch its column of the shared arrays
+  int arrive(int s);     // the slot's next level is dense and prepared; returns after the sweep
+  void fail(int rc);
+  void worker_done(int s);
+  void sweeper();
+};
+
+}  // namespace pprhip
+
+namespace pprhip {
+namespace detail {
+
+struct Triple {  // one index entry of All-Pair-Backward-Search: pi(v, t) = p
+  int32_t v, t;
+  double p;
+};
+
+struct LevelCtx {
+  int fcur = 0;   // F/eoff buffer holding the current frontier list
+  int ccur = 0;   // dense contribution buffer holding the current level's contributions
+  int pslot = 0;  // packed counter slot describing the current frontier
+  int dslot = 0;  // dead-mass cell pending for the current level
+  uint32_t nf = 0;
+  uint64_t ef = 0;
+  bool dense_prepared = false;
+  int dense_run = 0;  // dense levels run since the current dense phase was seeded
+};
+
+// FORA rounds that are certain to be followed by another halving do not need their sparse tail: what it
+// would push is picked up by the next round's lower threshold.  Such a round ends after the first sparse
+// level that follows its dense levels.  fixed: the caller knows another round follows; otherwise the round
+// loop's own condition (model cost so far < c_walk * rsum * omega) is evaluated at that point.  The test
+// twin applies the same rule (oracle/ppr_oracle.c: round_cut).
+struct RoundCut {
+  bool enabled = false, fixed = false, had_dense = false, checked = false, taken = false;
+  double omega = 0.0, c_walk = 0.0, alpha = 0.0;
+  double rsum = 0.0;  // (1 - alpha) * residue sum measured at the check (valid when !fixed and checked)
+};
+
+// kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
+
+constexpr int kYield = 1;  // run_levels: the next level is dense and the caller runs it (batched sweeps)
+
+// kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
+extern thread_local KernelTimer* g_timer_cur;
+inline KernelTimer& ktimer() { return *g_timer_cur; }
+
+int alloc_dev(void** p, size_t bytes);
+double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense);
+uint64_t dense_level_bytes(const pprhip_graph* g);
+void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_t nf_next, uint64_t ef_next);
+int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost,
+               bool yield_dense = false, RoundCut* cut = nullptr);
+int reset_query_state(pprhip_graph* g, bool clear_flags);
+int ensure_batch(pprhip_graph* P);
+void free_batch(pprhip_graph* P);
+int ensure_bwd_layout(pprhip_graph* P);
+int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree);
+int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L);
+int device_sum(pprhip_graph* g, const double* x, double* out);
+int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st);
+int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,
+                   double* target, pprhip_stats_t& st);
+int copy_out(pprhip_graph* g, const double* dev, double* host);
+int check_graph(const pprhip_graph* g, const char* fn);
+int check_node(const pprhip_graph* g, int32_t v, const char* fn);
+const pprhip_graph* host_of(const pprhip_graph* g);
+uint32_t hdeg_out(const pprhip_graph* g, int32_t v);
+uint32_t hdeg_in(const pprhip_graph* g, int32_t v);
+int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
+                double* kth_out, bool* have_kth, pprhip_stats_t& st);
+
+struct CallTimer {
+  pprhip_graph* g;
+  explicit CallTimer(pprhip_graph* g_) : g(g_) {
+    ktimer().stream = g->stream;
+    ktimer().reset();
+    (void)hipEventRecord(g->ev[0], g->stream);
+  }
+  void mark(int i) { (void)hipEventRecord(g->ev[i], g->stream); }
+  static double ms(hipEvent_t a, hipEvent_t b) {
+    float f = 0.f;
+    if (hipEventElapsedTime(&f, a, b) != hipSuccess) return 0.0;
+    return (double)f;
+  }
+  // resolves per-class kernel times; picks the class with the largest total as dominant
+  void finish(pprhip_stats_t& st) {
+    (void)hipEventRecord(g->ev[5], g->stream);
+    (void)hipStreamSynchronize(g->stream);
+    st.total_ms = ms(g->ev[0], g->ev[5]);
+    double tot[8] = {0};
+    uint64_t bytes[8] = {0};
+    uint32_t cnt[8] = {0};
+    ktimer().resolve(tot, bytes, cnt);
+    int best = 0;
+    for (int c = 1; c < 8; ++c)
+      if (tot[c] > tot[best]) best = c;
+    for (int c = 0; c < 8; ++c) {
+      st.class_ms[c] = tot[c];
+      st.class_bytes[c] = bytes[c];
+      st.class_launches[c] = cnt[c];
+    }
+    st.dominant_kernel_id = (uint32_t)best;
+    st.dominant_kernel_ms = tot[best];
+    st.dominant_kernel_bytes = bytes[best];
+    st.dominant_kernel_launches = cnt[best];
+  }
+};
+
+// a batch of queries for the slot engine (fora.cpp)
+struct BatchJob {
+  pprhip_graph* P;
+  const int32_t* srcs;
+  int q;
+  double eps;
+  const pprhip_fora_conf_t* conf;
+  uint64_t seed;
+  int n_rounds;
+  double* reserve_out;
+  int k;
+  int32_t* ids_out;
+  double* vals_out;
+  int* n_out;
+  pprhip_stats_t* per_query;
+  int kind = 0;  // 0: whole-graph FORA per query, 1: FORA top-k per query (seed + query index), 2: backward search
+  double alpha = 0.0, threshold = 0.0;   // kind 2
+  std::vector<Triple>* triples = nullptr;  // kind 2: every search's entries >= threshold
+  pprhip_stats_t sum;
+  std::mutex sum_mu;
+  std::atomic<int> next_query{0};
+};
+
+int batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* stats_sum);
+
+}  // namespace detail
+}  // namespace pprhip

@@ -1,0 +1,825 @@
+// fora.cpp — FORA, FORA top-k and backward searches as resumable runs, and the batched entry points
+// that keep kBatch of them in flight on the handle's slots (dense levels share one sweep).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+
+#include "engine_internal.hpp"
+
+using namespace pprhip;
+using namespace pprhip::detail;
+
+// ------------------------------------------------------------------ FORA whole graph (a5)
+namespace pprhip {
+
+// One FORA query as a resumable run: step() advances it until it is finished or (yield_dense)
+// until its next level is dense, so that the batch driver can run that level for many queries
+// in one sweep.  pprhip_fora_single_source drives the same code without yielding.
+struct ForaRun {
+  pprhip_graph* g = nullptr;
+  int32_t src = 0;  // internal id
+  const pprhip_fora_conf_t* conf = nullptr;
+  uint64_t seed = 0;
+  int n_rounds = 0;
+  CallTimer* tm = nullptr;  // single-query calls: push / walk phase marks
+  pprhip_stats_t st;
+  double alpha = 0, rsum_local = 0, rmax_local = 0, omega_local = 0, rmax_used = 0, model_cost = 0;
+  int rounds = 0;
+  bool dead_src = false;
+  LevelCtx L;
+  PushArgs a;
+  RoundCut cut;
+  enum Phase { kRoundStart, kLevels, kWalks, kTopkRoundStart, kTopkLevels, kTopkFinal, kBwdLevels, kBwdFinal, kDone } phase = kDone;
+  int query = -1;  // batch driver: index of the query this run serves
+  bool waiting = false;
+  bool in_push = false;  // between a push phase's start and its end (BatchSync: may hold sweeps off)
+  // top-k runs (Fora_Topk.computeTopKPPR, kind 1): the trial-and-error loop on delta
+  int kind = 0;
+  double eps_half = 0, delta_local = 0, min_delta = 0, min_rmax = 0;
+  uint32_t round = 0;
+  int cap = 0, nsel = 0;
+  int32_t* ids_out = nullptr;
+  double* vals_out = nullptr;
+  // backward searches of All-Pair (kind 2): entries >= threshold of the finished search
+  int32_t target_orig = -1;
+  std::vector<Triple> triples;
+};
+
+}  // namespace pprhip
+
+namespace {
+
+void leave_push(ForaRun& r) {
+  if (r.in_push) {
+    r.in_push = false;
+    if (r.g->sync) r.g->sync->release(r.g->slot_index);
+  }
+}
+
+int fora_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, const pprhip_fora_conf_t* conf,
+               uint64_t seed, int n_rounds) {
+  r.g = g;
+  r.src = src_internal;
+  r.conf = conf;
+  r.seed = seed;
+  r.n_rounds = n_rounds;
+  std::memset(&r.st, 0, sizeof r.st);
+  g->topk_active = false;
+  PPRHIP_TRY(reset_query_state(g, false));
+  r.alpha = conf->alpha;
+  r.rsum_local = conf->rsum;
+  PPRHIP_TRY(pprhip_fora_whole_params(conf, eps, &r.rmax_local, &r.omega_local));  // Fora_Whole_Graph.java:86-87
+  if (n_rounds == 0 && g->tun.prior_levels > 0 && g->tun.halving_ratio > 1.0) {
+    // Loop turns that are known to pass before any push: after a push at rmax every r(v) < rmax * d(v), so
+    // rsum <= rmax * m and the walks cost at most c_walk * omega * (1 - alpha) * rmax * m; while that bound still
+    // covers prior_levels dense levels the turn would be repeated at half the threshold anyway (twin: same rule).
+    const pprhip_tuning_t& t = g->tun;
+    double walk_bound = t.c_walk_ns * r.omega_local * (1 - r.alpha) * r.rmax_local * (double)g->m;
+    const double push_est =
+        (double)t.prior_levels * (t.c_level_ns + t.c_dense_edge_ns * (double)g->m + t.c_dense_node_ns * (double)g->n);
+    for (int h = 0; h < t.max_halvings && walk_bound >= push_est; ++h) {
+      walk_bound /= 2.0;
+      r.rmax_local /= 2.0;
+    }
+  }
+  r.rmax_used = r.rmax_local;
+  r.model_cost = 0.0;
+  r.rounds = 0;
+  r.dead_src = hdeg_out(g, src_internal) == 0;
+  r.L = LevelCtx();
+  r.phase = ForaRun::kRoundStart;
+  r.waiting = false;
+  r.in_push = true;
+  return PPRHIP_OK;
+}
+
+int fora_step(ForaRun& r, bool yield_dense) {
+  pprhip_graph* g = r.g;
+  for (;;) {
+    if (r.phase == ForaRun::kRoundStart) {  // Fora_Whole_Graph.java:93-103, clock replaced by the level cost model
+      const bool more = r.n_rounds > 0 ? r.rounds < r.n_rounds
+                                       : (r.model_cost < g->tun.c_walk_ns * r.rsum_local * r.omega_local &&
+                                          r.rounds < g->tun.max_rounds);
+      if (!more) {
+        r.phase = ForaRun::kWalks;
+        continue;
+      }
+      if (r.dead_src) {  // Forward_Push.java:72-76
+        PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)r.src, 1.0));
+        r.rsum_local = 0.0;
+        r.rmax_used = r.rmax_local;
+        r.rounds++;
+        r.phase = ForaRun::kWalks;
+        continue;
+      }
+      r.a = PushArgs{r.alpha, r.rmax_local, 0.0, r.src, kFwdWhole};
+      r.cut = RoundCut();
+      r.cut.fixed = r.n_rounds > 0;
+      r.cut.enabled = r.n_rounds > 0 ? r.rounds + 1 < r.n_rounds : r.rounds + 1 < g->tun.max_rounds;
+      r.cut.omega = r.omega_local;
+      r.cut.c_walk = g->tun.c_walk_ns;
+      r.cut.alpha = r.alpha;
+      if (r.rounds == 0) {
+        PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)r.src, 1.0));
+        PPRHIP_TRY(seed_single(g, r.L, r.src, hdeg_out(g, r.src)));
+      } else {
+        PPRHIP_TRY(seed_scan(g, r.a, 0, r.L));
+      }
+      r.phase = ForaRun::kLevels;
+    }
+    if (r.phase == ForaRun::kLevels) {
+      const int rc = run_levels(g, r.a, r.L, r.st, &r.model_cost, yield_dense, &r.cut);
+      if (rc != PPRHIP_OK) return rc;  // kYield or an error
+      if (r.cut.taken && !r.cut.fixed) {
+        r.rsum_local = r.cut.rsum;  // measured when the round was cut; nothing was pushed since
+      } else {
+        double sum = 0.0;
+        PPRHIP_TRY(device_sum(g, g->residue, &sum));
+        r.rsum_local = sum * (1 - r.alpha);  // :101 (rsum is the exact residue sum here)
+      }
+      r.rmax_used = r.rmax_local;
+      r.rmax_local /= 2.0;  // :102
+      // The reference's loop would turn again (and restart the push from scratch at half the threshold) as
+      // long as the push stays cheaper than the walks; when the walks outweigh the push so far by ratio^k, k
+      // further halvings are taken at once instead of pushing at every threshold between (the twin does the same).
+      if (r.n_rounds == 0 && r.model_cost > 0.0 && g->tun.halving_ratio > 1.0) {
+        double ratio = g->tun.c_walk_ns * r.rsum_local * r.omega_local / r.model_cost;
+        for (int h = 1; ratio >= g->tun.halving_ratio && h < g->tun.max_halvings; ++h) {
+          ratio /= g->tun.halving_ratio;
+          r.rmax_local /= 2.0;
+        }
+      }
+      r.rounds++;
+      r.phase = (r.n_rounds > 0 && !(r.rsum_local > 0.0)) ? ForaRun::kWalks : ForaRun::kRoundStart;
+      continue;
+    }
+    if (r.phase == ForaRun::kWalks) {
+      leave_push(r);
+      PPRHIP_TRY(read_dead_pops(g, r.st));
+      if (r.tm) r.tm->mark(1);
+      // Fora_Whole_Graph.java:112-140
+      const double nrw_d = r.omega_local * r.rsum_local;
+      const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;
+      if (!r.dead_src) PPRHIP_TRY(run_walk_phase(g, 0, r.alpha, r.rsum_local, nrw, r.seed, 0, g->reserve, r.st));
+      if (r.tm) r.tm->mark(2);
+      r.st.rounds = (uint32_t)r.rounds;
+      r.st.rsum = r.rsum_local;
+      r.st.rmax_final = r.rmax_used;
+      r.st.omega = r.omega_local;
+      r.phase = ForaRun::kDone;
+    }
+    return PPRHIP_OK;
+  }
+}
+
+// Fora_Topk.computeTopKPPR (Fora_Topk.java:102-184) as a resumable run; the same sequence as
+// pprhip_fora_topk, which keeps the per-phase timing of a single call.
+int topk_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, const pprhip_fora_conf_t* conf,
+               uint64_t seed, int32_t* ids_out, double* vals_out, int cap) {
+  r.g = g;
+  r.kind = 1;
+  r.src = src_internal;
+  r.conf = conf;
+  r.seed = seed;
+  std::memset(&r.st, 0, sizeof r.st);
+  PPRHIP_TRY(reset_query_state(g, true));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags + src_internal, 1, 1, g->stream));  // Q = {s} (:117-118)
+  g->topk_active = true;
+  g->topk_first = true;
+  g->topk_src = src_internal;
+  g->topk_alpha = conf->alpha;
+  g->topk_rsum = conf->rsum;
+  r.alpha = conf->alpha;
+  r.eps_half = eps * 0.5;  // :109-110
+  r.delta_local = conf->delta;
+  r.min_delta = conf->min_delta;
+  r.min_rmax = r.eps_half * std::sqrt(r.min_delta / 3 / (double)conf->m / std::log(2 / conf->pfail));  // :113
+  r.rsum_local = conf->rsum;
+  r.omega_local = r.rmax_local = 0.0;
+  r.round = 0;
+  r.dead_src = false;
+  r.ids_out = ids_out;
+  r.vals_out = vals_out;
+  r.cap = cap;
+  r.nsel = 0;
+  r.phase = ForaRun::kTopkRoundStart;
+  r.waiting = false;
+  r.in_push = false;
+  return PPRHIP_OK;
+}
+
+int topk_step(ForaRun& r, bool yield_dense) {
+  pprhip_graph* g = r.g;
+  const pprhip_fora_conf_t* conf = r.conf;
+  const size_t nd = sizeof(double) * (size_t)g->n;
+  for (;;) {
+    if (r.phase == ForaRun::kTopkRoundStart) {
+      if (!(r.delta_local >= r.min_delta)) {  // :123
+        r.phase = ForaRun::kTopkFinal;
+        continue;
+      }
+      r.rmax_local = r.eps_half * std::sqrt(r.delta_local / 3.0 / (double)conf->m / std::log(2.0 / conf->pfail));  // :124
+      r.omega_local = (r.eps_half + 2.0) * std::log(2.0 / conf->pfail) / r.eps_half / r.eps_half / r.delta_local;  // :125
+      if (hdeg_out(g, r.src) == 0) {  // :126-132
+        PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
+        PPRHIP_TRY(launch_set_f64(g, g->est, (uint32_t)r.src, 1.0));
+        r.rsum_local = 0.0;
+        r.dead_src = true;
+        r.phase = ForaRun::kTopkFinal;
+        continue;
+      }
+      r.rmax_local *= std::sqrt((double)conf->m * r.rmax_local) * 3.0;  // :133
+      // forward_push_topk (:137; Forward_Push.java:144-250)
+      if (g->topk_first) PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)r.src, 1.0));
+      r.a = PushArgs{r.alpha, r.rmax_local, r.min_rmax, r.src, kFwdTopk};
+      r.L = LevelCtx();
+      r.in_push = true;
+      PPRHIP_TRY(seed_scan(g, r.a, 1, r.L));
+      r.phase = ForaRun::kTopkLevels;
+    }
+    if (r.phase == ForaRun::kTopkLevels) {
+      const int rc = run_levels(g, r.a, r.L, r.st, nullptr, yield_dense);
+      if (rc != PPRHIP_OK) return rc;  // kYield or an error
+      leave_push(r);
+      PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
+      g->topk_first = false;
+      r.rsum_local = g->topk_rsum;  // :142
+      // :143 reserve := copy of the push reserve (walk increments of earlier rounds are dropped)
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
+      const double rsum_rw = r.rsum_local * (1.0 - r.alpha);  // :148
+      const double nrw_d = r.omega_local * rsum_rw;
+      const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;  // :151
+      PPRHIP_TRY(run_walk_phase(g, 1, r.alpha, rsum_rw, nrw, r.seed, r.round, g->est, r.st));  // :155-168
+      r.round++;
+      double kth = 0.0;
+      bool have = false;
+      int nsel = 0;
+      PPRHIP_TRY(select_topk(g, g->est, conf->k, nullptr, nullptr, 0, &nsel, &kth, &have, r.st));  // :173
+      if (!have) kth = 0.0;                                                                          // :174
+      r.st.kth_value = kth;
+      if (kth >= (1 + r.eps_half) * r.delta_local || r.delta_local <= r.min_delta) {  // :175-176
+        r.phase = ForaRun::kTopkFinal;
+      } else {
+        r.delta_local = std::max(r.min_delta, r.delta_local / 4.0);  // :178
+        r.phase = ForaRun::kTopkRoundStart;
+      }
+      continue;
+    }
+    if (r.phase == ForaRun::kTopkFinal) {
+      if (r.round == 0 && !r.dead_src) PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
+      g->result_in_est = true;
+      PPRHIP_TRY(read_dead_pops(g, r.st));
+      bool have = false;
+      double kth = 0.0;
+      PPRHIP_TRY(select_topk(g, g->est, conf->k, r.ids_out, r.vals_out, r.cap, &r.nsel, &kth, &have, r.st));
+      r.st.rounds = r.round;
+      r.st.rsum = r.rsum_local;
+      r.st.rmax_final = r.rmax_local;
+      r.st.omega = r.omega_local;
+      r.phase = ForaRun::kDone;
+    }
+    return PPRHIP_OK;
+  }
+}
+
+// One backward search of All-Pair (Backward_Search.java:38-100 + the >= threshold filter of
+// Base_Whole_Graph.java:80-88) as a resumable run.
+int bwd_begin(ForaRun& r, pprhip_graph* g, int32_t target_internal, int32_t target_orig, double alpha, double rmax) {
+  r.g = g;
+  r.kind = 2;
+  r.src = target_internal;
+  r.target_orig = target_orig;
+  r.alpha = alpha;
+  r.rmax_local = rmax;
+  r.triples.clear();
+  std::memset(&r.st, 0, sizeof r.st);
+  g->topk_active = false;
+  PPRHIP_TRY(reset_query_state(g, false));
+  r.waiting = false;
+  r.in_push = false;
+  if (hdeg_in(g, target_internal) == 0) {  // :46-49
+    PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)target_internal, 1.0));
+    r.phase = ForaRun::kBwdFinal;
+    return PPRHIP_OK;
+  }
+  r.a = PushArgs{alpha, rmax, 0.0, target_internal, kBackward};
+  r.L = LevelCtx();
+  PPRHIP_TRY(launch_set_f64(g, g->residue, (uint32_t)target_internal, 1.0));
+  PPRHIP_TRY(seed_single(g, r.L, target_internal, hdeg_in(g, target_internal)));
+  r.in_push = true;
+  r.phase = ForaRun::kBwdLevels;
+  return PPRHIP_OK;
+}
+
+int bwd_step(ForaRun& r, bool yield_dense) {
+  pprhip_graph* g = r.g;
+  if (r.phase == ForaRun::kBwdLevels) {
+    const int rc = run_levels(g, r.a, r.L, r.st, nullptr, yield_dense);
+    if (rc != PPRHIP_OK) return rc;  // kYield or an error
+    leave_push(r);
+    r.phase = ForaRun::kBwdFinal;
+  }
+  if (r.phase == ForaRun::kBwdFinal) {
+    const double threshold = r.rmax_local;
+    unsigned long long thr_bits = 1ull;
+    if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
+    PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits));  // Base_Whole_Graph.java:83 pi >= threshold
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    const uint64_t cnt = g->h_ctr->sel_count;
+    const std::vector<int32_t>& n2o = host_of(g)->h_new2old;
+    if (cnt > g->sel_cap) {
+      std::vector<double> all(g->n);
+      PPRHIP_TRY(copy_out(g, g->reserve, all.data()));
+      for (uint32_t v = 0; v < g->n; ++v)  // copy_out already returned original ids
+        if (all[v] > 0.0 && all[v] >= threshold) r.triples.push_back({(int32_t)v, r.target_orig, all[v]});
+    } else if (cnt) {
+      std::vector<int32_t> ids(cnt);
+      std::vector<double> vals(cnt);
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      for (uint64_t i = 0; i < cnt; ++i) r.triples.push_back({n2o[ids[i]], r.target_orig, vals[i]});
+    }
+    r.phase = ForaRun::kDone;
+  }
+  return PPRHIP_OK;
+}
+
+void add_stats(pprhip_stats_t& sum, const pprhip_stats_t& st) {
+  sum.pops += st.pops; sum.edge_pushes += st.edge_pushes; sum.enqueues += st.enqueues;
+  sum.dead_end_pops += st.dead_end_pops; sum.dense_nodes += st.dense_nodes; sum.levels += st.levels;
+  sum.dense_levels += st.dense_levels; sum.rounds += st.rounds; sum.mc_sources += st.mc_sources;
+  sum.walks += st.walks; sum.walk_steps += st.walk_steps; sum.select_passes += st.select_passes;
+  sum.push_ms += st.push_ms; sum.mc_ms += st.mc_ms; sum.select_ms += st.select_ms; sum.total_ms += st.total_ms;
+  sum.push_bytes += st.push_bytes; sum.mc_bytes += st.mc_bytes; sum.select_bytes += st.select_bytes;
+  for (int c = 0; c < 8; ++c) {
+    sum.class_ms[c] += st.class_ms[c];
+    sum.class_bytes[c] += st.class_bytes[c];
+    sum.class_launches[c] += st.class_launches[c];
+  }
+}
+
+}  // namespace
+
+int pprhip_fora_single_source(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf,
+                              uint64_t seed, int n_rounds, double* reserve_out, pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fora_single_source"));
+  PPRHIP_TRY(check_node(g, src, "pprhip_fora_single_source"));
+  src = g->h_old2new[src];  // internal (degree-sorted) id
+  if (!conf || !(eps > 0.0) || n_rounds < 0) {
+    set_error("pprhip_fora_single_source: bad arguments (eps=%g n_rounds=%d)", eps, n_rounds);
+    return PPRHIP_ERR_INVALID;
+  }
+  ForaRun r;
+  PPRHIP_TRY(fora_begin(r, g, src, eps, conf, seed, n_rounds));
+  CallTimer tm(g);
+  r.tm = &tm;
+  PPRHIP_TRY(fora_step(r, false));
+  tm.finish(r.st);
+  r.st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
+  r.st.mc_ms = CallTimer::ms(g->ev[1], g->ev[2]);
+  PPRHIP_TRY(copy_out(g, g->reserve, reserve_out));
+  if (stats) *stats = r.st;
+  return PPRHIP_OK;
+}
+
+namespace {
+
+// One batched dense level for the slots flagged in `active`: stages their arguments, orders the
+// parent stream behind the slots' prepare work, runs the sweep and brings the new frontier counters
+// back.  The caller holds the sweep exclusively (sequential driver, or BatchSync::sweeping).
+int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) {
+  for (int s = 0; s < kBatch; ++s) {
+    pprhip_graph* S = P->slots[s];
+    SlotArgs& sa = P->h_slot_args[s];
+    sa.res = S->residue;
+    sa.reserve = S->reserve;
+    sa.flags = S->flags;
+    sa.ctr = S->ctr;
+    sa.active = active[s] ? 1 : 0;
+    if (!active[s]) continue;
+    const ForaRun& r = runs[s];
+    sa.alpha = r.a.alpha;
+    sa.rmax = r.a.rmax;
+    sa.min_rmax = r.a.min_rmax;
+    sa.src = r.a.src;
+    sa.mode = r.a.mode;
+    sa.dead_slot = r.L.dslot;
+    sa.out_slot = r.L.pslot ^ 1;
+    if (S->stream != P->stream) {
+      PPRHIP_CHECK_HIP(hipEventRecord(S->ev[3], S->stream));
+      PPRHIP_CHECK_HIP(hipStreamWaitEvent(P->stream, S->ev[3], 0));
+    }
+  }
+  const uint64_t sweep_bytes = 4ull * P->m + (uint64_t)n_active * (8ull * P->m + 36ull * P->n + 4ull);
+  bool backward = false;
+  for (int s = 0; s < kBatch; ++s)
+    if (active[s] && runs[s].a.mode == kBackward) backward = true;  // a job's runs all push the same way
+  if ((int)backward != P->acc8_dir) {
+    // rows summed with atomics are cleared by the apply kernel of their own layout only: start clean
+    PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * ((size_t)P->n + 1) * kBatch, P->stream));
+    P->acc8_dir = (int)backward;
+  }
+  P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
+  PPRHIP_TRY(launch_dense_level_b8(P, backward));
+  P->ktimer.end();
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(P->h_sweep_out, P->sweep_out, sizeof(unsigned long long) * kBatch,
+                                  hipMemcpyDeviceToHost, P->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
+  P->c8cur ^= 1;
+  for (int s = 0; s < kBatch; ++s)
+    if (active[s]) {
+      ForaRun& r = runs[s];
+      const unsigned long long pk = P->h_sweep_out[s];
+      // the sweep's index stream is shared: each query is charged its own gathers and row work
+      finish_dense(r.L, r.st, 8ull * P->m + 36ull * P->n + 4ull + 4ull * P->m / (uint64_t)n_active,
+                   (uint32_t)(pk >> kPackShift), pk & kPackMask);
+    }
+  return PPRHIP_OK;
+}
+
+
+int run_step(ForaRun& r, bool yield_dense) {
+  return r.kind == 2 ? bwd_step(r, yield_dense) : r.kind == 1 ? topk_step(r, yield_dense) : fora_step(r, yield_dense);
+}
+
+// outputs of a finished query (its slot still holds the vectors)
+int finish_query(BatchJob& J, ForaRun& r) {
+  pprhip_graph* S = r.g;
+  const int i = r.query;
+  if (r.kind == 2) {
+    std::lock_guard<std::mutex> lk(J.sum_mu);
+    J.triples->insert(J.triples->end(), r.triples.begin(), r.triples.end());
+    add_stats(J.sum, r.st);
+    r.triples.clear();
+    r.phase = ForaRun::kDone;
+    r.query = -1;
+    return PPRHIP_OK;
+  }
+  if (J.reserve_out) PPRHIP_TRY(copy_out(S, r.kind == 1 ? S->est : S->reserve, J.reserve_out + (size_t)i * J.P->n));
+  if (r.kind == 1) {  // the run's final selection wrote the first min(nsel, k) pairs
+    for (int j = std::min(r.nsel, J.k); j < J.k; ++j) {
+      r.ids_out[j] = -1;
+      r.vals_out[j] = 0.0;
+    }
+    if (J.n_out) J.n_out[i] = r.nsel;
+  } else if (J.k > 0) {
+    int nsel = 0;
+    bool have = false;
+    int32_t* ids = J.ids_out + (size_t)i * J.k;
+    double* vals = J.vals_out + (size_t)i * J.k;
+    PPRHIP_TRY(select_topk(S, S->reserve, J.k, ids, vals, J.k, &nsel, nullptr, &have, r.st));
+    for (int j = std::min(nsel, J.k); j < J.k; ++j) {
+      ids[j] = -1;
+      vals[j] = 0.0;
+    }
+    if (J.n_out) J.n_out[i] = nsel;
+  }
+  if (J.per_query) J.per_query[i] = r.st;
+  {
+    std::lock_guard<std::mutex> lk(J.sum_mu);
+    add_stats(J.sum, r.st);
+  }
+  r.phase = ForaRun::kDone;
+  r.query = -1;
+  return PPRHIP_OK;
+}
+
+int begin_query(BatchJob& J, ForaRun& r, pprhip_graph* S, int i) {
+  S->tun = J.P->tun;
+  const int32_t src = J.P->h_old2new[J.srcs[i]];
+  if (J.kind == 2) {
+    pprhip_tuning_batch(&S->tun);  // level shapes only: a backward search has no cost-model decisions
+    PPRHIP_TRY(bwd_begin(r, S, src, J.srcs[i], J.alpha, J.threshold));
+  } else if (J.kind == 1) {
+    PPRHIP_TRY(topk_begin(r, S, src, J.eps, J.conf, J.seed + (uint64_t)i, J.ids_out + (size_t)i * J.k,
+                          J.vals_out + (size_t)i * J.k, J.k));
+  } else {
+    r.kind = 0;
+    PPRHIP_TRY(fora_begin(r, S, src, J.eps, J.conf, J.seed, J.n_rounds));
+  }
+  r.query = i;
+  return PPRHIP_OK;
+}
+
+// all slots on the calling thread and the graph's stream, one after another
+int batch_sequential(BatchJob& J, ForaRun* runs) {
+  pprhip_graph* P = J.P;
+  int busy = 0;
+  for (;;) {
+    // every slot advances until it waits at a dense level; finished slots take the next query
+    for (int s = 0; s < kBatch; ++s) {
+      ForaRun& r = runs[s];
+      for (;;) {
+        if (r.query < 0) {
+          const int i = J.next_query.load();
+          if (i >= J.q) break;
+          J.next_query.store(i + 1);
+          PPRHIP_TRY(begin_query(J, r, P->slots[s], i));
+          busy++;
+        }
+        if (r.waiting) break;
+        const int rc = run_step(r, true);
+        if (rc == kYield) {
+          r.waiting = true;
+          break;
+        }
+        if (rc != PPRHIP_OK) return rc;
+        PPRHIP_TRY(finish_query(J, r));
+        busy--;
+      }
+    }
+    if (busy == 0) break;
+    bool active[kBatch];
+    int n_wait = 0;
+    for (int s = 0; s < kBatch; ++s) {
+      active[s] = runs[s].query >= 0 && runs[s].waiting;
+      n_wait += active[s] ? 1 : 0;
+    }
+    PPRHIP_TRY(run_sweep(P, runs, active, n_wait));
+    for (int s = 0; s < kBatch; ++s)
+      if (active[s]) runs[s].waiting = false;
+  }
+  return PPRHIP_OK;
+}
+
+// one worker thread per slot
+void batch_worker(BatchJob* J, BatchSync* B, ForaRun* runs, int s) {
+  pprhip_graph* P = J->P;
+  pprhip_graph* S = P->slots[s];
+  ForaRun& r = runs[s];
+  int rc = PPRHIP_OK;
+  if (hipSetDevice(P->device) != hipSuccess) {
+    set_error("hipSetDevice(%d) failed in a batch worker", P->device);
+    rc = PPRHIP_ERR_HIP;
+  }
+  KernelTimer* const own_timer = g_timer_cur;
+  g_timer_cur = &S->ktimer;
+  S->ktimer.stream = S->stream;
+  S->ktimer.reset();
+  while (rc == PPRHIP_OK) {
+    {
+      std::lock_guard<std::mutex> lk(B->mu);
+      if (B->err) break;
+    }
+    const int i = J->next_query.fetch_add(1);
+    if (i >= J->q) break;
+    rc = begin_query(*J, r, S, i);
+    while (rc == PPRHIP_OK) {
+      rc = run_step(r, true);
+      if (rc != kYield) break;
+      rc = B->arrive(s);
+    }
+    if (rc == PPRHIP_OK) rc = finish_query(*J, r);
+  }
+  if (rc != PPRHIP_OK) {
+    leave_push(r);
+    B->fail(rc);
+  }
+  (void)hipStreamSynchronize(S->stream);
+  g_timer_cur = own_timer;
+  B->worker_done(s);
+}
+
+}  // namespace
+
+namespace pprhip {
+
+void BatchSync::release(int s) {
+  std::lock_guard<std::mutex> lk(mu);
+  if (hold[s]) {
+    hold[s] = false;
+    n_hold--;
+    cv.notify_all();
+  }
+}
+
+void BatchSync::c8_enter(int s) {
+  std::unique_lock<std::mutex> lk(mu);
+  cv.wait(lk, [&] { return !sweeping || err != 0; });
+  if (!hold[s]) {
+    hold[s] = true;
+    n_hold++;
+  }
+}
+
+void BatchSync::fail(int rc) {
+  std::lock_guard<std::mutex> lk(mu);
+  if (!err) {
+    err = rc;
+    errmsg = get_error();
+  }
+  cv.notify_all();
+}
+
+void BatchSync::worker_done(int s) {
+  std::lock_guard<std::mutex> lk(mu);
+  if (hold[s]) {
+    hold[s] = false;
+    n_hold--;
+  }
+  n_workers--;
+  cv.notify_all();
+}
+
+int BatchSync::arrive(int s) {
+  std::unique_lock<std::mutex> lk(mu);
+  if (err) return err;
+  if (hold[s]) {
+    hold[s] = false;
+    n_hold--;
+  }
+  waitflag[s] = true;
+  n_wait++;
+  cv.notify_all();
+  cv.wait(lk, [&] { return !waitflag[s] || err != 0; });
+  return err;
+}
+
+// the sweeper thread: one batched sweep whenever somebody waits and nobody holds
+void BatchSync::sweeper() {
+  (void)hipSetDevice(P->device);
+  std::unique_lock<std::mutex> lk(mu);
+  for (;;) {
+    cv.wait(lk, [&] { return n_workers == 0 || err != 0 || (n_wait > 0 && n_hold == 0); });
+    if (n_workers == 0 || err != 0) return;
+    sweeping = true;
+    bool active[kBatch];
+    int n_active = 0;
+    for (int s = 0; s < kBatch; ++s) {
+      active[s] = waitflag[s];
+      n_active += active[s] ? 1 : 0;
+    }
+    lk.unlock();
+    const int rc = run_sweep(P, runs, active, n_active);
+    const std::string msg = rc != PPRHIP_OK ? get_error() : "";
+    lk.lock();
+    if (rc != PPRHIP_OK && !err) {
+      err = rc;
+      errmsg = msg;
+    }
+    for (int s = 0; s < kBatch; ++s)
+      if (active[s]) {
+        waitflag[s] = false;
+        n_wait--;
+        hold[s] = true;  // until the slot has said what it does next
+        n_hold++;
+      }
+    sweeping = false;
+    cv.notify_all();
+  }
+}
+
+}  // namespace pprhip
+
+// Batched single-source FORA: up to kBatch queries in flight on kBatch workspaces of this handle.
+// Every query runs the single-query algorithm unchanged (same levels, same thresholds, same walks
+// for the same seed); whenever the queries in a push phase all stand at a dense level, one sweep of
+// the batched kernels serves them.  All slots run on the calling thread and the handle's stream;
+// with PPRHIP_BATCH_THREADS=1 (the default of the top-k entry point) every slot gets a worker
+// thread and a stream of its own, so sparse levels, walks and selections of different queries
+// overlap on the GPU.
+// runs a prepared job on the handle's slots (both batched entry points)
+int pprhip::detail::batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* stats_sum) {
+  PPRHIP_TRY(ensure_batch(g));
+  if (J.kind == 2) PPRHIP_TRY(ensure_bwd_layout(g));
+  const int q = J.q;
+  // Worker threads pay off where queries are latency-bound (top-k: short rounds of sparse levels, walks
+  // and selections, 2.4x on R-MAT 22); whole-graph FORA keeps the memory system busy from one thread.
+  const char* env = getenv("PPRHIP_BATCH_THREADS");
+  const bool threaded = q > 1 && (env ? env[0] == '1' : J.kind != 0);
+  std::memset(&J.sum, 0, sizeof J.sum);
+  ForaRun runs[kBatch];
+  g->ktimer.stream = g->stream;
+  g->ktimer.reset();
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = PPRHIP_OK;
+  double tot[8] = {0};
+  uint64_t bytes[8] = {0};
+  uint32_t cnt[8] = {0};
+  if (threaded) {
+    BatchSync B;
+    B.P = g;
+    B.runs = runs;
+    for (pprhip_graph* S : g->slots) {
+      S->stream = S->own_stream;
+      S->sync = &B;
+    }
+    B.n_workers = kBatch;
+    std::thread sweeper(&BatchSync::sweeper, &B);
+    std::vector<std::thread> workers;
+    for (int s = 0; s < kBatch; ++s) workers.emplace_back(batch_worker, &J, &B, runs, s);
+    for (auto& w : workers) w.join();
+    sweeper.join();
+    for (pprhip_graph* S : g->slots) {
+      S->sync = nullptr;
+      S->ktimer.resolve(tot, bytes, cnt);
+    }
+    if (B.err) {
+      set_error("%s", B.errmsg.c_str());
+      rc = B.err;
+    }
+  } else {
+    for (pprhip_graph* S : g->slots) {
+      S->stream = g->stream;
+      S->sync = nullptr;
+    }
+    KernelTimer local;  // the caller's timer may be in use (All-Pair times its own tiers)
+    KernelTimer* const saved = g_timer_cur;
+    g_timer_cur = &local;
+    local.stream = g->stream;
+    rc = batch_sequential(J, runs);
+    (void)hipStreamSynchronize(g->stream);
+    local.resolve(tot, bytes, cnt);
+    local.destroy();
+    g_timer_cur = saved;
+  }
+  (void)hipStreamSynchronize(g->stream);
+  if (rc != PPRHIP_OK) {
+    const std::string msg = get_error();
+    free_batch(g);  // slots may hold half-pushed levels: the next batched call builds clean ones
+    set_error("%s", msg.c_str());
+    return rc;
+  }
+  g->ktimer.resolve(tot, bytes, cnt);
+  pprhip_stats_t& sum = J.sum;
+  sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  int best = 0;
+  for (int c = 0; c < 8; ++c) {
+    sum.class_ms[c] = tot[c];
+    sum.class_bytes[c] = bytes[c];
+    sum.class_launches[c] = cnt[c];
+    if (tot[c] > tot[best]) best = c;
+  }
+  sum.dominant_kernel_id = (uint32_t)best;
+  sum.dominant_kernel_ms = tot[best];
+  sum.dominant_kernel_bytes = bytes[best];
+  sum.dominant_kernel_launches = cnt[best];
+  if (stats_sum) *stats_sum = sum;
+  return PPRHIP_OK;
+}
+
+int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
+                                    const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
+                                    double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
+                                    pprhip_stats_t* per_query, pprhip_stats_t* stats_sum) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_single_source"));
+  if (q < 0 || !conf || !(eps > 0.0) || n_rounds < 0 || (q > 0 && !srcs) || k < 0 ||
+      (k > 0 && q > 0 && (!ids_out || !vals_out))) {
+    set_error("pprhip_fora_batch_single_source: bad arguments (q=%d eps=%g n_rounds=%d k=%d)", q, eps, n_rounds, k);
+    return PPRHIP_ERR_INVALID;
+  }
+  for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_single_source"));
+  BatchJob J;
+  J.P = g;
+  J.srcs = srcs;
+  J.q = q;
+  J.eps = eps;
+  J.conf = conf;
+  J.seed = seed;
+  J.n_rounds = n_rounds;
+  J.reserve_out = reserve_out;
+  J.k = k;
+  J.ids_out = ids_out;
+  J.vals_out = vals_out;
+  J.n_out = n_out;
+  J.per_query = per_query;
+  return batch_run(g, J, stats_sum);
+}
+
+int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k, double eps, double alpha,
+                           uint64_t seed, int32_t* ids_out, double* vals_out, pprhip_stats_t* stats_sum) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_topk"));
+  if (q < 0 || k < 1 || !(eps > 0.0) || (q > 0 && (!srcs || !ids_out || !vals_out))) {
+    set_error("pprhip_fora_batch_topk: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_topk"));
+  pprhip_fora_conf_t conf;
+  PPRHIP_TRY(pprhip_conf_fora_topk(g->n, g->m, k, alpha, &conf));
+  BatchJob J;
+  J.P = g;
+  J.kind = 1;
+  J.srcs = srcs;
+  J.q = q;
+  J.eps = eps;
+  J.conf = &conf;
+  J.seed = seed;  // query i runs with seed + i, as pprhip_fora_topk(srcs[i], ..., seed + i) would
+  J.n_rounds = 0;
+  J.reserve_out = nullptr;
+  J.k = k;
+  J.ids_out = ids_out;
+  J.vals_out = vals_out;
+  J.n_out = nullptr;
+  J.per_query = nullptr;
+  return batch_run(g, J, stats_sum);
+}
+
