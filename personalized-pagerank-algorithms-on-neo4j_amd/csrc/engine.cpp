@@ -1,17 +1,15 @@
-// engine.cpp — host-side drivers of the pprhip engine: graph lift, level loop, FORA, top-k,
-// backward search.  Everything numerical runs in the HIP kernels; the host only sequences
-// launches on the handle's stream and reads back 8-byte counters between levels.
+// engine.cpp — host-side core of the pprhip engine: graph lift and workspaces, the level loop, and the
+// single-query entry points (forward push, top-k push rounds, FORA top-k, Monte-Carlo, backward push,
+// power method).  Everything numerical runs in the HIP kernels; the host only sequences launches on
+// the handle's stream and reads back 8-byte counters between levels.  FORA runs and the batched entry
+// points live in fora.cpp, All-Pair and the index in allpair.cpp (shared declarations:
+// engine_internal.hpp).
 #include <algorithm>
-#include <atomic>
-#include <chrono>
 #include <cmath>
-#include <condition_variable>
 #include <cstring>
 #include <memory>
-#include <mutex>
 #include <new>
 #include <numeric>
-#include <thread>
 
 #include "engine_internal.hpp"
 
