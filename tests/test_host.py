@@ -154,7 +154,13 @@ def test_conf_validation(pkg):
 
 def test_tuning_defaults_match_oracle_twin(pkg, orc):
     """The twin takes the same round count only if both sides evaluate the same cost model."""
+    import ctypes
     a, b = pkg.tuning_default(), orc.tuning_default()
-    for f in ("c_walk_ns", "c_edge_ns", "c_pop_ns", "c_level_ns", "c_dense_edge_ns", "c_dense_node_ns", "dense_frac",
-              "max_rounds"):
+    assert [f for f, _ in a._fields_] == [f for f, _ in b._fields_]
+    assert ctypes.sizeof(a) == ctypes.sizeof(b) == 88          # 8 doubles + 4 int32 (include/pprhip.h, oracle/ppr_oracle.h)
+    for f, _ in a._fields_:
         assert getattr(a, f) == getattr(b, f), f
+    assert (a.halving_ratio, a.max_halvings, a.prior_levels) == (2.0, 6, 16)
+    t = pkg.tuning_batch()                                       # the batch profile changes the dense-level terms only
+    changed = [f for f, _ in t._fields_ if getattr(t, f) != getattr(a, f)]
+    assert sorted(changed) == ["c_dense_edge_ns", "c_dense_node_ns", "dense_frac"]
