@@ -63,6 +63,33 @@ def test_fora_single_source_properties(rmat20, dev20):
         assert np.mean(np.abs(est[big] - exact[big]) <= 0.5 * exact[big]) > 0.999
 
 
+def test_fora_batch_at_scale(pkg, rmat20, dev20):
+    """The batched entry point at benchmark scale: every query conserves mass, equals the single-query entry point
+    (same thresholds, same walks; sums in another order), repeats exactly, and its top-32 follows the rule."""
+    srcs = live_sources(rmat20, 20, 7) + [int(np.argmax(np.diff(rmat20.out_rp) == 0))]
+    t = pkg.tuning_batch()
+    dev20.set_tuning(t)
+    try:
+        out, ids, vals, nsel, pq, st = dev20.fora_batch_single_source(srcs, 0.5, A, seed=5, k=32, fetch=True,
+                                                                      per_query=True)
+        assert st.class_launches[5] > 0 and st.class_launches[5] < st.dense_levels    # sweeps shared by several queries
+        out2, _, _, _, pq2, _ = dev20.fora_batch_single_source(srcs, 0.5, A, seed=5, fetch=True, per_query=True)
+        assert np.max(np.abs(out - out2)) < 1e-12
+        for i, s in enumerate(srcs):
+            assert abs(out[i].sum() - 1.0) < 1e-9 and out[i].min() >= 0.0
+            assert pq[i].walks == pq2[i].walks and pq[i].levels == pq2[i].levels
+            m = min(int(nsel[i]), 32)
+            assert np.all(np.diff(vals[i][:m]) <= 0) and np.array_equal(out[i][ids[i][:m]], vals[i][:m])
+            if m == 32:
+                assert int((out[i] >= vals[i][31]).sum()) == int(nsel[i])
+        for i in (0, 9, 20):
+            single, sts = dev20.fora_single_source(srcs[i], 0.5, A, seed=5, n_rounds=0)
+            assert sts.walks == pq[i].walks and sts.rounds == pq[i].rounds and sts.levels == pq[i].levels
+            assert np.max(np.abs(single - out[i])) < 1e-9
+    finally:
+        dev20.set_tuning(pkg.tuning_default())
+
+
 def test_dead_end_sources_short_circuit(rmat20, dev20):
     od = np.diff(rmat20.out_rp)
     s = int(np.argmax(od == 0))
