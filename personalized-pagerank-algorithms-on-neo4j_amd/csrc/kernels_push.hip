@@ -1156,7 +1156,8 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
     const uint32_t want = (g->n_chunks + 15) / 16;
     if (n_hot) {
-      static bool lds_opt_in = false;  // dynamic LDS above 64 KB needs an explicit opt-in
+      static bool lds_opt_in_dev[64] = {};  // dynamic LDS above 64 KB needs an explicit opt-in, per device
+      bool& lds_opt_in = lds_opt_in_dev[g->device & 63];
       if (!lds_opt_in) {
         PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1197,7 +1198,8 @@ static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8
   const uint32_t want = (g->n_chunks + 15) / 16;
   const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(start_flags);
   if (n_hot) {
-    static bool lds_opt_in = false;
+    static bool lds_opt_in_dev[64] = {};
+    bool& lds_opt_in = lds_opt_in_dev[g->device & 63];
     if (!lds_opt_in) {
       PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, G>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
