@@ -20,7 +20,8 @@ Extra objects on the JSON line: `roofline` (dominant kernel, HIP-event time on t
 stream, algorithmic bytes from DESIGN.md's byte model) and `cpu_baseline` (the CPU oracle's
 clock-driven FIFO FORA, one core, bounded sample; rank 0 at N = 1 only); after the timed region,
 at N = 1, also `one_query_at_a_time` (the same queries through the single-query entry point)
-and `all_pair_sample` (All-Pair-Backward-Search on 2^18 targets of the same graph).
+`topk_sample` (FORA top-32, batched and one at a time) and `all_pair_sample` (All-Pair-Backward-Search on
+2^18 targets of the same graph).
 """
 import argparse
 import importlib
@@ -221,6 +222,7 @@ def main():
         if world == 1 and args.mode == "batch" and not args.no_extras:
             out["one_query_at_a_time"] = single_mode_sample(pkg, g, srcs[args.warmup], outdeg, conf, args)
         if world == 1 and args.mode == "batch" and not args.no_extras:
+            out["topk_sample"] = topk_sample(pkg, g, srcs[args.warmup])
             out["all_pair_sample"] = all_pair_sample(pkg, g, host)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, srcs[args.warmup:], outdeg, live_frac, args.cpu_walk_divisor)
@@ -250,6 +252,24 @@ def single_mode_sample(pkg, g, srcs, outdeg, conf, args):
             "dense_pull": {"launches": n_lv, "avg_launch_us": round(1e3 * ms / max(1, n_lv), 2),
                            "achieved_GBps": round((by / 1e9) / (ms / 1e3), 1) if ms > 0 else 0.0,
                            "frac": round((by / 1e9) / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else 0.0}}
+
+
+def topk_sample(pkg, g, srcs):
+    """FORA top-k (Fora_Topk, k = 32; configs #3 / #4) on the sources of the first timed step, outside the timed
+    region: 16 queries in flight (pprhip_fora_batch_topk), and the first 32 of them one at a time."""
+    g.set_tuning(pkg.tuning_default())
+    srcs = np.ascontiguousarray(srcs, dtype=np.int32)
+    g.fora_batch_topk(srcs[:16], TOPK, EPS, ALPHA, seed=1)
+    t0 = time.perf_counter()
+    ids, vals, st = g.fora_batch_topk(srcs, TOPK, EPS, ALPHA, seed=7)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for j, s in enumerate(srcs[:32]):
+        g.fora_topk(int(s), EPS, ALPHA, TOPK, seed=7 + j)
+    dt1 = time.perf_counter() - t1
+    return {"value": round(len(srcs) / dt, 1), "unit": "queries/s", "queries": int(len(srcs)), "k": TOPK,
+            "rounds_per_query": round(st.rounds / max(1, len(srcs)), 2),
+            "one_at_a_time_queries_per_s": round(32 / dt1, 1)}
 
 
 def all_pair_sample(pkg, g, host):
