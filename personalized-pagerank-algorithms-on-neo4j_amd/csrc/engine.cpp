@@ -561,6 +561,7 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
   uint64_t total = 0;
   bool have = true;
   unsigned long long lower_bits = 1ull;  // smallest positive pattern: "everything"
+  uint64_t expected = ~0ull;              // candidates the gather will find, known from the histograms
   for (int pass = 0; pbits < 64; ++pass) {
     const int dbits = std::min(12, 64 - pbits);
     PPRHIP_TRY(launch_select_hist(g, x, g->n, prefix, pbits, dbits));
@@ -579,6 +580,7 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
       }
       if ((uint64_t)k > total) {  // kth_ppr returns null: everything is kept (Fora_Topk.java:187-191)
         have = false;
+        expected = total;
         break;
       }
     }
@@ -600,16 +602,30 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
     prefix = (prefix << dbits) | (unsigned long long)chosen;
     pbits += dbits;
     lower_bits = pbits < 64 ? (prefix << (64 - pbits)) : prefix;
-    if (above + hist[chosen] <= g->sel_cap) break;  // few enough candidates: finish on the host
+    expected = above + hist[chosen];
+    if (expected <= g->sel_cap) break;  // few enough candidates: finish on the host
   }
   PPRHIP_TRY(launch_select_gather(g, x, g->n, have ? lower_bits : 1ull));
   PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, g->stream));
+  // the histograms already say how many candidates there are: fetch them with the counter, one round trip
+  const bool prefetched = expected > 0 && expected <= g->sel_cap;
+  std::vector<int32_t> pre_ids(prefetched ? expected : 0);
+  std::vector<double> pre_vals(prefetched ? expected : 0);
+  if (prefetched) {
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(pre_ids.data(), g->sel_ids, sizeof(int32_t) * expected, hipMemcpyDeviceToHost,
+                                    g->stream));
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(pre_vals.data(), g->sel_vals, sizeof(double) * expected, hipMemcpyDeviceToHost,
+                                    g->stream));
+  }
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   st.select_bytes += 8ull * g->n;
   uint64_t cnt = g->h_ctr->sel_count;
   std::vector<IdVal> cand;
-  if (cnt <= g->sel_cap) {
+  if (prefetched && cnt == expected) {
+    cand.resize(cnt);
+    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {host_of(g)->h_new2old[pre_ids[i]], pre_vals[i]};
+  } else if (cnt <= g->sel_cap) {
     std::vector<int32_t> ids(cnt);
     std::vector<double> vals(cnt);
     if (cnt) {
