@@ -107,7 +107,7 @@ def main():
     gather_vals = [torch.empty_like(vals_blk) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     acc = {"class_ms": [0.0] * 8, "class_bytes": [0] * 8, "class_launches": [0] * 8, "rounds": 0, "live": 0,
-           "walks": 0, "walk_steps": 0, "levels": 0, "dense_levels": 0, "push_ms": 0.0, "mc_ms": 0.0}
+           "walks": 0, "walk_steps": 0, "levels": 0, "dense_levels": 0, "dense_edges": 0, "push_ms": 0.0, "mc_ms": 0.0}
 
     def record_stats(st, live):
         for c in range(8):
@@ -120,6 +120,7 @@ def main():
         acc["walk_steps"] += st.walk_steps
         acc["levels"] += st.levels
         acc["dense_levels"] += st.dense_levels
+        acc["dense_edges"] += st.dense_edges
         acc["push_ms"] += st.push_ms
         acc["mc_ms"] += st.mc_ms
 
@@ -216,6 +217,7 @@ def main():
                                          for c in (1, 2, 3, 5) if acc["class_launches"][c]},
             "dense_levels_per_live_query": round(acc["dense_levels"] / max(1, acc["live"]), 1),
             "levels_per_live_query": round(acc["levels"] / max(1, acc["live"]), 1),
+            "useful_edge_fraction": round(acc["dense_edges"] / max(1, acc["dense_levels"] * host.m), 4),
             "graph_lift_s": {"generate_and_csr": round(t_gen, 2), "upload_and_tile": round(t_lift, 2)},
             "roofline": roofline,
         }

@@ -81,6 +81,9 @@ typedef struct pprhip_stats {
   double class_ms[8];
   uint64_t class_bytes[8];
   uint32_t class_launches[8];
+  uint64_t dense_edges;    /* out-edges of the nodes pushed inside dense pull sweeps: the edges a sweep had to serve,
+                            * against dense_levels * m edges swept (useful-edge fraction of the sweeps) */
+  uint64_t reserved1[3];
 } pprhip_stats_t;
 
 #define PPRHIP_KERNEL_NONE 0

@@ -147,6 +147,13 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   // has either produced its triples or landed in `give_up`
   auto run_tier = [&](bool global_tier, std::vector<int32_t> list, bool use_range, std::vector<int32_t>& give_up) -> int {
     int32_t* d_list = nullptr;
+    struct ListGuard {  // frees the target list on every exit, error returns included
+      int32_t*& p;
+      ~ListGuard() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+      }
+    } list_guard{d_list};
     for (int pass = 0; pass < 1000; ++pass) {
       const uint32_t cnt = use_range ? n_targets : (uint32_t)list.size();
       if (cnt == 0) break;
@@ -192,7 +199,6 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
         d_list = nullptr;
       }
     }
-    if (d_list) (void)hipFree(d_list);
     return PPRHIP_OK;
   };
 
@@ -265,6 +271,10 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
 int pprhip_index_merge(const pprhip_index_t* const* shards, int n_shards, int k, pprhip_index_t** merged_out) {
   if (!shards || n_shards < 1 || !merged_out) {
     set_error("pprhip_index_merge: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  if (!shards[0]) {
+    set_error("pprhip_index_merge: shard 0 is null");
     return PPRHIP_ERR_INVALID;
   }
   const uint32_t n = shards[0]->n;

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <numeric>
 
@@ -21,6 +22,23 @@ namespace detail {
 
 thread_local KernelTimer g_timer_own;
 thread_local KernelTimer* g_timer_cur = &g_timer_own;
+
+// One-time work per device: code objects loaded and kernel attributes set by the thread that lifts the
+// first graph onto the device, under a lock, so that the launch paths (which worker threads run
+// concurrently) never touch function attributes or trigger a first-use module load.
+static std::mutex g_dev_init_mu;
+static std::vector<char> g_dev_inited;
+int init_device_once(int device) {
+  std::lock_guard<std::mutex> lk(g_dev_init_mu);
+  if ((size_t)device < g_dev_inited.size() && g_dev_inited[device]) return PPRHIP_OK;
+  PPRHIP_TRY(init_kernels_push());
+  PPRHIP_TRY(init_kernels_walk());
+  PPRHIP_TRY(init_kernels_select());
+  PPRHIP_TRY(init_kernels_apbs());
+  if ((size_t)device >= g_dev_inited.size()) g_dev_inited.resize((size_t)device + 1, 0);
+  g_dev_inited[device] = 1;
+  return PPRHIP_OK;
+}
 
 int alloc_dev(void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes ? bytes : 8);
@@ -82,6 +100,7 @@ void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_
   L.pslot ^= 1;
   st.dense_levels++;
   st.dense_nodes += L.nf;
+  st.dense_edges += L.ef;
   st.push_bytes += level_bytes;
   L.nf = nf_next;
   L.ef = ef_next;
@@ -788,15 +807,38 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
     return PPRHIP_ERR_NO_DEVICE;
   }
   PPRHIP_CHECK_HIP(hipSetDevice(device));
-  for (uint64_t e = 0; e < m; ++e)
-    if (out_ci[e] < 0 || (uint32_t)out_ci[e] >= n) {
-      set_error("pprhip_graph_create: out_col_idx[%llu] = %d outside [0, %u)", (unsigned long long)e, out_ci[e], n);
-      return PPRHIP_ERR_INVALID;
-    }
+  PPRHIP_TRY(init_device_once(device));
   const bool have_in = in_rp && (in_ci || m == 0);
   if (have_in && (in_rp[0] != 0 || in_rp[n] != m)) {
     set_error("pprhip_graph_create: in_row_ptr[0] must be 0 and in_row_ptr[n] must equal m");
     return PPRHIP_ERR_INVALID;
+  }
+  // caller-supplied arrays are validated before anything indexes with them: monotone row pointers,
+  // column indices in range, and (when given) an in-adjacency that is the transpose's degree sequence
+  for (int side = 0; side < (have_in ? 2 : 1); ++side) {
+    const uint32_t* rp = side ? in_rp : out_rp;
+    const int32_t* ci = side ? in_ci : out_ci;
+    const char* nm = side ? "in" : "out";
+    for (uint32_t v = 0; v < n; ++v)
+      if (rp[v + 1] < rp[v]) {
+        set_error("pprhip_graph_create: %s_row_ptr decreases at node %u (%u -> %u)", nm, v, rp[v], rp[v + 1]);
+        return PPRHIP_ERR_INVALID;
+      }
+    for (uint64_t e = 0; e < m; ++e)
+      if (ci[e] < 0 || (uint32_t)ci[e] >= n) {
+        set_error("pprhip_graph_create: %s_col_idx[%llu] = %d outside [0, %u)", nm, (unsigned long long)e, ci[e], n);
+        return PPRHIP_ERR_INVALID;
+      }
+  }
+  if (have_in) {
+    std::vector<uint32_t> indeg((size_t)n, 0u);
+    for (uint64_t e = 0; e < m; ++e) indeg[out_ci[e]]++;
+    for (uint32_t v = 0; v < n; ++v)
+      if (indeg[v] != in_rp[v + 1] - in_rp[v]) {
+        set_error("pprhip_graph_create: in-adjacency is not the transpose of the out-adjacency (node %u: %u in-edges "
+                  "listed, %u relationships point to it)", v, in_rp[v + 1] - in_rp[v], indeg[v]);
+        return PPRHIP_ERR_INVALID;
+      }
   }
   std::unique_ptr<pprhip_graph> g(new (std::nothrow) pprhip_graph());
   if (!g) return PPRHIP_ERR_OOM;

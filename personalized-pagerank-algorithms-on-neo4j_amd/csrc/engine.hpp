@@ -31,13 +31,19 @@ struct PushArgs {
 };
 
 // Kernel-class timing with an event pool, resolved after the stream has drained.  Events are
-// created on demand and reused across calls.
+// created on demand and reused across calls; the pool is capped: a call that records more intervals
+// than kMaxEvents / 2 (All-Pair's tier 3 launches ~1e5 sparse batches) drains the stream, folds what it
+// has into per-class accumulators and starts over, so neither the pool nor `recs` grows with the call.
 struct KernelTimer {
+  static constexpr size_t kMaxEvents = 4096;
   std::vector<hipEvent_t> ev;
   struct Rec { int cls; size_t i; uint64_t bytes; };
   std::vector<Rec> recs;
   size_t used = 0;
   hipStream_t stream = nullptr;
+  double acc_ms[8] = {0};
+  uint64_t acc_bytes[8] = {0};
+  uint32_t acc_cnt[8] = {0};
   hipEvent_t next() {
     if (used == ev.size()) {
       hipEvent_t e;
@@ -46,7 +52,24 @@ struct KernelTimer {
     }
     return ev[used++];
   }
+  // folds the recorded intervals into the accumulators (the stream must have drained)
+  void fold() {
+    for (const Rec& r : recs) {
+      if (r.i + 1 >= used) continue;
+      float f = 0.f;
+      if (hipEventElapsedTime(&f, ev[r.i], ev[r.i + 1]) != hipSuccess) continue;
+      acc_ms[r.cls] += (double)f;
+      acc_bytes[r.cls] += r.bytes;
+      acc_cnt[r.cls]++;
+    }
+    used = 0;
+    recs.clear();
+  }
   void begin(int cls, uint64_t bytes) {
+    if (used + 2 > kMaxEvents) {
+      if (hipStreamSynchronize(stream) != hipSuccess) return;
+      fold();
+    }
     hipEvent_t a = next();
     if (!a) return;
     recs.push_back({cls, used - 1, bytes});
@@ -59,16 +82,19 @@ struct KernelTimer {
   void reset() {
     used = 0;
     recs.clear();
+    for (int c = 0; c < 8; ++c) {
+      acc_ms[c] = 0.0;
+      acc_bytes[c] = 0;
+      acc_cnt[c] = 0;
+    }
   }
-  // adds the recorded intervals to per-class totals (call after the stream has been synchronized)
-  void resolve(double tot[8], uint64_t bytes[8], uint32_t cnt[8]) const {
-    for (const Rec& r : recs) {
-      if (r.i + 1 >= used) continue;
-      float f = 0.f;
-      if (hipEventElapsedTime(&f, ev[r.i], ev[r.i + 1]) != hipSuccess) continue;
-      tot[r.cls] += (double)f;
-      bytes[r.cls] += r.bytes;
-      cnt[r.cls]++;
+  // adds everything recorded since reset() to per-class totals (call after the stream has been synchronized)
+  void resolve(double tot[8], uint64_t bytes[8], uint32_t cnt[8]) {
+    fold();
+    for (int c = 0; c < 8; ++c) {
+      tot[c] += acc_ms[c];
+      bytes[c] += acc_bytes[c];
+      cnt[c] += acc_cnt[c];
     }
   }
   void destroy() {
@@ -209,6 +235,13 @@ int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbu
 int launch_sum(pprhip_graph* g, const double* x, uint32_t n);  // result -> ctr->sum_out
 int launch_set_f64(pprhip_graph* g, double* p, uint32_t idx, double value);
 int launch_permute_out(pprhip_graph* g, const double* x, double* out);  // out[old] = x[old2new[old]]
+// Once per device, from the thread that lifts the first graph onto it: loads the code object of every
+// kernel file and opts the persistent sweep kernels into their large dynamic LDS, so that no launch
+// path sets function attributes or triggers a module load later (worker threads launch concurrently).
+int init_kernels_push();
+int init_kernels_walk();
+int init_kernels_select();
+int init_kernels_apbs();
 
 // ---- kernels_walk.hip
 int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double* target);

@@ -355,7 +355,8 @@ int bwd_step(ForaRun& r, bool yield_dense) {
 
 void add_stats(pprhip_stats_t& sum, const pprhip_stats_t& st) {
   sum.pops += st.pops; sum.edge_pushes += st.edge_pushes; sum.enqueues += st.enqueues;
-  sum.dead_end_pops += st.dead_end_pops; sum.dense_nodes += st.dense_nodes; sum.levels += st.levels;
+  sum.dead_end_pops += st.dead_end_pops; sum.dense_nodes += st.dense_nodes; sum.dense_edges += st.dense_edges;
+  sum.levels += st.levels;
   sum.dense_levels += st.dense_levels; sum.rounds += st.rounds; sum.mc_sources += st.mc_sources;
   sum.walks += st.walks; sum.walk_steps += st.walk_steps; sum.select_passes += st.select_passes;
   sum.push_ms += st.push_ms; sum.mc_ms += st.mc_ms; sum.select_ms += st.select_ms; sum.total_ms += st.total_ms;

@@ -320,6 +320,13 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
   }
 }
 
+int init_kernels_apbs() {  // loads this file's code object on the current device (see init_kernels_push)
+  hipFuncAttributes fa;
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs<false>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs<true>)));
+  return PPRHIP_OK;
+}
+
 int launch_apbs(pprhip_graph* g, bool global_tier, const int32_t* d_targets, uint32_t t_begin, uint32_t n_targets,
                 double alpha, double rmax, ApbsBuffers& b) {
   const uint32_t grid = global_tier ? b.g_blocks : std::min<uint32_t>((uint32_t)g->n_cus * 2u, std::max(1u, n_targets));

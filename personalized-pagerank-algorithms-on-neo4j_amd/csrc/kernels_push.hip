@@ -1155,15 +1155,7 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
     const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
     const uint32_t want = (g->n_chunks + 15) / 16;
-    if (n_hot) {
-      static bool lds_opt_in_dev[64] = {};  // dynamic LDS above 64 KB needs an explicit opt-in, per device
-      bool& lds_opt_in = lds_opt_in_dev[g->device & 63];
-      if (!lds_opt_in) {
-        PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)(sizeof(double) * kHotMax)));
-        lds_opt_in = true;
-      }
+    if (n_hot) {  // (dynamic LDS above 64 KB: opted in by init_kernels_push at graph lift)
       const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
       k_dense_edges<true><<<dim3(grid), dim3(1024), sizeof(double) * n_hot, g->stream>>>(
           ci, flags, cstarts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, n_hot);
@@ -1198,13 +1190,6 @@ static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8
   const uint32_t want = (g->n_chunks + 15) / 16;
   const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(start_flags);
   if (n_hot) {
-    static bool lds_opt_in_dev[64] = {};
-    bool& lds_opt_in = lds_opt_in_dev[g->device & 63];
-    if (!lds_opt_in) {
-      PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, G>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
-      lds_opt_in = true;
-    }
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
     k_dense_edges_b<true, G><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * G, g->stream>>>(
         ci, flags64, chunk_starts, g->n_chunks, (unsigned long long)g->m, cB, accB, n_hot);
@@ -1314,6 +1299,19 @@ int launch_sum(pprhip_graph* g, const double* x, uint32_t n) {
 int launch_permute_out(pprhip_graph* g, const double* x, double* out) {
   k_permute_out<<<dim3(grid_for(g->n, 256, 4096)), dim3(256), 0, g->stream>>>(x, g->old2new, out, g->n);
   PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+// Current device: code object loaded, large dynamic LDS opted in (above 64 KB it needs an explicit opt-in per
+// device).  Called once per device under the graph-lift lock (engine.cpp), never from a launch path.
+int init_kernels_push() {
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
+  hipFuncAttributes fa;
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sparse_push<kBackward>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch)));
   return PPRHIP_OK;
 }
 

@@ -63,6 +63,12 @@ __global__ __launch_bounds__(256) void k_select_gather(const double* __restrict_
   }
 }
 
+int init_kernels_select() {  // loads this file's code object on the current device (see init_kernels_push)
+  hipFuncAttributes fa;
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_select_hist)));
+  return PPRHIP_OK;
+}
+
 int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned long long prefix, int prefix_bits,
                        int digit_bits) {
   uint64_t b = ((uint64_t)n + 256 * 8 - 1) / (256 * 8);

@@ -271,6 +271,12 @@ __global__ void k_plan_single(int32_t src, double inc, int32_t* mc_node, double*
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+int init_kernels_walk() {  // loads this file's code object on the current device (see init_kernels_push)
+  hipFuncAttributes fa;
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_mc_walk)));
+  return PPRHIP_OK;
+}
+
 int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double* target) {
   uint64_t b = ((uint64_t)g->n + 1023) / 1024;
   const uint32_t grid = (uint32_t)(b > 1024 ? 1024 : b);

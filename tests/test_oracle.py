@@ -342,3 +342,39 @@ def test_metrics(orc):
     d = sum((2 ** (exact[a] if a in (0, 1, 2) else 0.0) - 1) / math.log(i + 2) / math.log(2)
             for i, a in enumerate([0, 1, 4]))
     assert orc.ndcg([0, 1, 4], [0, 1, 2], exact) == pytest.approx(d / z)
+
+
+# ------------------------------------------------------------------ committed Java-faithful vectors
+def test_fifo_oracle_reproduces_committed_vectors(orc, got):
+    """tests/golden/got_fifo_golden.json (generator: tests/golden/make_fifo_golden.py) freezes the FIFO schedule and
+    the power method on the reference's dataset: the oracle must still produce them bit for bit, and the
+    frontier-synchronous twin must stay within the invariant's bound of them."""
+    import json
+    import os
+    from conftest import ROOT
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "got_fifo_golden.json")))
+    un = lambda v: np.array([float.fromhex(x) for x in v])
+    og = to_oracle(orc, got)
+    assert (g["graph"]["n"], g["graph"]["m"]) == (got.n, got.m) and len(g["sources"]) == 3
+    conf = og.conf_whole(A)
+    rmax0, omega = orc.fora_whole_params(conf, 0.5)
+    assert rmax0.hex() == g["fora_params"]["rmax0"] and omega.hex() == g["fora_params"]["omega"]
+    for name, e in g["sources"].items():
+        s = e["id"]
+        assert got.names[s] == e["name"]
+        assert np.array_equal(og.power_method(s, A, 100), un(e["power_method_100"]))
+        for tag in ("rmax0", "1e-10"):
+            rec = e["forward_push_" + tag]
+            rmax = float.fromhex(rec["rmax"])
+            p, r, rsum, st = og.forward_push(s, A, rmax, orc.FIFO)
+            assert np.array_equal(p, un(rec["reserve"])) and np.array_equal(r, un(rec["residue"]))
+            assert rsum.hex() == rec["rsum_field"] and st.pops == rec["pops"] and st.edge_pushes == rec["edge_pushes"]
+            ps, rs, _, _ = og.forward_push(s, A, rmax, orc.SYNC)
+            assert np.max(np.abs(ps - p)) <= rs.sum() + r.sum() + 1e-15
+        p, r, st = og.backward_push(s, A, 1e-8, orc.FIFO)
+        assert np.array_equal(p, un(e["backward_push_1e-8"]["reserve"])) and st.pops == e["backward_push_1e-8"]["pops"]
+        est, st = og.fora_whole(s, 0.5, A, seed=3, n_rounds=1, schedule=orc.FIFO)
+        rec = e["fora_whole_1round_seed3"]
+        assert np.array_equal(est, un(rec["estimate"])) and st.walks == rec["walks"] and st.walk_steps == rec["walk_steps"]
+        cnt, ids, _ = orc.topk(og.power_method(s, A, 100), 10, cap=got.n)
+        assert cnt == e["power_method_top10"]["count"] and ids.tolist() == e["power_method_top10"]["ids"]
