@@ -45,6 +45,7 @@ extern "C" {
 typedef struct pprhip_graph pprhip_graph_t;       /* device-resident CSR pair + per-query workspace */
 typedef struct pprhip_edgelist pprhip_edgelist_t; /* host edge list produced by the ingest helpers */
 typedef struct pprhip_index pprhip_index_t;       /* all-pair inverted index (host, CSR by source) */
+typedef struct pprhip_results pprhip_results_t;   /* device-resident result vectors of a batched call (q x n doubles) */
 
 /* Counters every compute call fills; all device-side counts, not estimates. */
 typedef struct pprhip_stats {
@@ -244,6 +245,24 @@ int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int 
                                     const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
                                     double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
                                     pprhip_stats_t* per_query, pprhip_stats_t* stats_sum);
+/* Device-resident result store: the whole-graph vectors of up to `capacity` queries of a batched call stay in HBM
+ * (capacity * n doubles; R-MAT 22, 128 queries: 4.3 GB of 288 GB), so that every query's getWholeGraphPPR()
+ * (Whole_Graph_Util_Interface.java:8, read by Gen_Util.java:309) can still be served after its slot has been
+ * reused, without moving q * n doubles over PCIe inside the call.  Slot i holds query i of the last call that
+ * was given the store. */
+int pprhip_results_create(pprhip_graph_t* g, int capacity, pprhip_results_t** results_out);
+void pprhip_results_destroy(pprhip_results_t* r);
+int pprhip_results_info(const pprhip_results_t* r, int* capacity, int* count, uint32_t* n);
+/* vector of query i, caller's ids (n doubles) */
+int pprhip_results_fetch(pprhip_results_t* r, int i, double* reserve_out);
+/* sum of the vector of query i, computed on the device (a cheap mass check: 1 up to rounding when walks ran) */
+int pprhip_results_sum(pprhip_results_t* r, int i, double* sum_out);
+/* pprhip_fora_batch_single_source with the vectors kept in `keep` (q <= capacity); reserve_out may still be given. */
+int pprhip_fora_batch_single_source_resident(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
+                                             const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
+                                             pprhip_results_t* keep, double* reserve_out, int k, int32_t* ids_out,
+                                             double* vals_out, int* n_out, pprhip_stats_t* per_query,
+                                             pprhip_stats_t* stats_sum);
 /* FORA top-k (pprhip_fora_topk) for q sources, up to PPRHIP_BATCH of them in flight: every query runs
  * Fora_Topk's loop on delta unchanged (query i with seed + i), the dense levels of its forward_push_topk
  * rounds share sweeps with the other queries in flight.  ids_out/vals_out are q*k, rows padded with

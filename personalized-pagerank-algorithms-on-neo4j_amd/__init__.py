@@ -72,7 +72,8 @@ EXPORTS = [
     "pprhip_all_pair_backward", "pprhip_index_merge", "pprhip_index_info", "pprhip_index_arrays",
     "pprhip_index_write_dir", "pprhip_index_destroy", "pprhip_power_method", "pprhip_index_from_arrays",
     "pprhip_format_double", "pprhip_edgelist_from_neo4j_store", "pprhip_edgelist_build_csr",
-    "pprhip_fora_batch_single_source", "pprhip_tuning_batch",
+    "pprhip_fora_batch_single_source", "pprhip_tuning_batch", "pprhip_results_create", "pprhip_results_destroy",
+    "pprhip_results_info", "pprhip_results_fetch", "pprhip_results_sum", "pprhip_fora_batch_single_source_resident",
 ]
 
 _lib = None
@@ -127,6 +128,14 @@ def lib():
     L.pprhip_topk_select.argtypes = [vp, ci, vp, vp, ci, P(ci), P(dbl), P(Stats)]
     L.pprhip_monte_carlo.argtypes = [vp, i32, dbl, P(ForaConf), u64, vp, P(Stats)]
     L.pprhip_fora_batch_single_source.argtypes = [vp, vp, ci, dbl, P(ForaConf), u64, ci, vp, ci, vp, vp, vp, vp, P(Stats)]
+    L.pprhip_fora_batch_single_source_resident.argtypes = [vp, vp, ci, dbl, P(ForaConf), u64, ci, vp, vp, ci, vp, vp, vp,
+                                                           vp, P(Stats)]
+    L.pprhip_results_create.argtypes = [vp, ci, P(vp)]
+    L.pprhip_results_destroy.argtypes = [vp]
+    L.pprhip_results_destroy.restype = None
+    L.pprhip_results_info.argtypes = [vp, P(ci), P(ci), P(u32)]
+    L.pprhip_results_fetch.argtypes = [vp, ci, vp]
+    L.pprhip_results_sum.argtypes = [vp, ci, P(dbl)]
     L.pprhip_fora_batch_topk.argtypes = [vp, vp, ci, ci, dbl, dbl, u64, vp, vp, P(Stats)]
     L.pprhip_backward_push.argtypes = [vp, i32, dbl, dbl, vp, vp, P(Stats)]
     L.pprhip_all_pair_backward.argtypes = [vp, dbl, dbl, ci, u32, u32, P(vp), P(Stats)]
@@ -334,6 +343,39 @@ def merge_indexes(shards, k):
     return Index(out)
 
 
+class Results:
+    """Device-resident result vectors of a batched call (slot i = query i)."""
+
+    def __init__(self, graph, capacity):
+        self.n = graph.n
+        self.graph = graph  # the store lives on the graph's device: keep the handle alive
+        self.h = C.c_void_p()
+        _check(lib().pprhip_results_create(graph.h, capacity, C.byref(self.h)))
+
+    def info(self):
+        cap, cnt, n = C.c_int(), C.c_int(), C.c_uint32()
+        _check(lib().pprhip_results_info(self.h, C.byref(cap), C.byref(cnt), C.byref(n)))
+        return cap.value, cnt.value, n.value
+
+    def fetch(self, i):
+        out = np.empty(self.n)
+        _check(lib().pprhip_results_fetch(self.h, i, _ptr(out)))
+        return out
+
+    def sum(self, i):
+        s = C.c_double()
+        _check(lib().pprhip_results_sum(self.h, i, C.byref(s)))
+        return s.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().pprhip_results_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Graph:
     """Device-resident CSR pair + per-query workspace (one per GPU, one thread at a time)."""
 
@@ -437,9 +479,11 @@ class Graph:
         _check(lib().pprhip_monte_carlo(self.h, src, eps, C.byref(conf), seed, _ptr(out), C.byref(st)))
         return out, st
 
-    def fora_batch_single_source(self, srcs, eps, alpha, seed, n_rounds=0, k=0, conf=None, fetch=False, per_query=False):
+    def fora_batch_single_source(self, srcs, eps, alpha, seed, n_rounds=0, k=0, conf=None, fetch=False, per_query=False,
+                                 keep=None):
         """q single-source FORA queries, BATCH of them in flight; returns (reserve[q, n] | None, ids[q, k] | None,
-        vals[q, k] | None, n_sel[q] | None, per-query Stats list | None, summed Stats)."""
+        vals[q, k] | None, n_sel[q] | None, per-query Stats list | None, summed Stats).  keep: a Results store that
+        receives every query's vector (device-resident)."""
         srcs = np.ascontiguousarray(srcs, dtype=np.int32)
         q = int(srcs.size)
         conf = conf or conf_whole_graph(self.n, self.m, alpha)
@@ -449,9 +493,9 @@ class Graph:
         nsel = np.zeros(q, dtype=np.int32) if k > 0 else None
         pq = (Stats * q)() if per_query and q else None
         st = Stats()
-        _check(lib().pprhip_fora_batch_single_source(self.h, _ptr(srcs), q, eps, C.byref(conf), seed, n_rounds, _ptr(out),
-                                                     k, _ptr(ids), _ptr(vals), _ptr(nsel),
-                                                     C.cast(pq, C.c_void_p) if pq is not None else None, C.byref(st)))
+        _check(lib().pprhip_fora_batch_single_source_resident(
+            self.h, _ptr(srcs), q, eps, C.byref(conf), seed, n_rounds, keep.h if keep is not None else None, _ptr(out),
+            k, _ptr(ids), _ptr(vals), _ptr(nsel), C.cast(pq, C.c_void_p) if pq is not None else None, C.byref(st)))
         return out, ids, vals, nsel, (list(pq) if pq is not None else None), st
 
     def fora_batch_topk(self, srcs, k, eps, alpha, seed):

@@ -11,6 +11,13 @@
 
 #include "engine.hpp"
 
+// Device-resident result vectors of a batched call (pprhip_results_create): slot i = query i, internal vertex order.
+struct pprhip_results {
+  pprhip_graph* g = nullptr;
+  int capacity = 0, count = 0;
+  double* buf = nullptr;  // capacity x n
+};
+
 namespace pprhip {
 
 struct ForaRun;
@@ -161,6 +168,7 @@ struct BatchJob {
   int kind = 0;  // 0: whole-graph FORA per query, 1: FORA top-k per query (seed + query index), 2: backward search
   double alpha = 0.0, threshold = 0.0;   // kind 2
   std::vector<Triple>* triples = nullptr;  // kind 2: every search's entries >= threshold
+  pprhip_results* keep = nullptr;          // kind 0: device-resident store of the queries' vectors
   pprhip_stats_t sum;
   std::mutex sum_mu;
   std::atomic<int> next_query{0};

@@ -465,6 +465,9 @@ int finish_query(BatchJob& J, ForaRun& r) {
     r.query = -1;
     return PPRHIP_OK;
   }
+  if (J.keep)  // the vector stays in HBM after the slot moves on (internal order; pprhip_results_fetch permutes)
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(J.keep->buf + (size_t)i * J.P->n, r.kind == 1 ? S->est : S->reserve,
+                                    sizeof(double) * (size_t)J.P->n, hipMemcpyDeviceToDevice, S->stream));
   if (J.reserve_out) PPRHIP_TRY(copy_out(S, r.kind == 1 ? S->est : S->reserve, J.reserve_out + (size_t)i * J.P->n));
   if (r.kind == 1) {  // the run's final selection wrote the first min(nsel, k) pairs
     for (int j = std::min(r.nsel, J.k); j < J.k; ++j) {
@@ -768,14 +771,20 @@ int pprhip::detail::batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* st
   return PPRHIP_OK;
 }
 
-int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
-                                    const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
-                                    double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
-                                    pprhip_stats_t* per_query, pprhip_stats_t* stats_sum) {
+int pprhip_fora_batch_single_source_resident(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
+                                             const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
+                                             pprhip_results_t* keep, double* reserve_out, int k, int32_t* ids_out,
+                                             double* vals_out, int* n_out, pprhip_stats_t* per_query,
+                                             pprhip_stats_t* stats_sum) {
   PPRHIP_TRY(check_graph(g, "pprhip_fora_batch_single_source"));
   if (q < 0 || !conf || !(eps > 0.0) || n_rounds < 0 || (q > 0 && !srcs) || k < 0 ||
       (k > 0 && q > 0 && (!ids_out || !vals_out))) {
     set_error("pprhip_fora_batch_single_source: bad arguments (q=%d eps=%g n_rounds=%d k=%d)", q, eps, n_rounds, k);
+    return PPRHIP_ERR_INVALID;
+  }
+  if (keep && (keep->g != g || q > keep->capacity)) {
+    set_error("pprhip_fora_batch_single_source_resident: the result store belongs to another graph or holds %d < %d "
+              "queries", keep->capacity, q);
     return PPRHIP_ERR_INVALID;
   }
   for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(g, srcs[i], "pprhip_fora_batch_single_source"));
@@ -793,7 +802,83 @@ int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int 
   J.vals_out = vals_out;
   J.n_out = n_out;
   J.per_query = per_query;
-  return batch_run(g, J, stats_sum);
+  J.keep = keep;
+  if (keep) keep->count = 0;
+  PPRHIP_TRY(batch_run(g, J, stats_sum));
+  if (keep) keep->count = q;
+  return PPRHIP_OK;
+}
+
+int pprhip_fora_batch_single_source(pprhip_graph_t* g, const int32_t* srcs, int q, double eps,
+                                    const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds,
+                                    double* reserve_out, int k, int32_t* ids_out, double* vals_out, int* n_out,
+                                    pprhip_stats_t* per_query, pprhip_stats_t* stats_sum) {
+  return pprhip_fora_batch_single_source_resident(g, srcs, q, eps, conf, seed, n_rounds, nullptr, reserve_out, k,
+                                                  ids_out, vals_out, n_out, per_query, stats_sum);
+}
+
+// ------------------------------------------------------------------ device-resident result store
+int pprhip_results_create(pprhip_graph_t* g, int capacity, pprhip_results_t** results_out) {
+  PPRHIP_TRY(check_graph(g, "pprhip_results_create"));
+  if (capacity < 1 || !results_out) {
+    set_error("pprhip_results_create: bad arguments (capacity=%d)", capacity);
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_results* r = new (std::nothrow) pprhip_results();
+  if (!r) return PPRHIP_ERR_OOM;
+  r->g = g;
+  r->capacity = capacity;
+  const int rc = alloc_dev((void**)&r->buf, sizeof(double) * (size_t)capacity * g->n);
+  if (rc != PPRHIP_OK) {
+    delete r;
+    return rc;
+  }
+  *results_out = r;
+  return PPRHIP_OK;
+}
+
+void pprhip_results_destroy(pprhip_results_t* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->g->device);
+  if (r->buf) (void)hipFree(r->buf);
+  delete r;
+}
+
+int pprhip_results_info(const pprhip_results_t* r, int* capacity, int* count, uint32_t* n) {
+  if (!r) {
+    set_error("pprhip_results_info: null store");
+    return PPRHIP_ERR_INVALID;
+  }
+  if (capacity) *capacity = r->capacity;
+  if (count) *count = r->count;
+  if (n) *n = r->g->n;
+  return PPRHIP_OK;
+}
+
+static int results_slot(pprhip_results_t* r, int i, const char* fn) {
+  if (!r || i < 0 || i >= r->count) {
+    set_error("%s: no result %d in the store (%d held)", fn, i, r ? r->count : 0);
+    return PPRHIP_ERR_INVALID;
+  }
+  return check_graph(r->g, fn);
+}
+
+int pprhip_results_fetch(pprhip_results_t* r, int i, double* reserve_out) {
+  PPRHIP_TRY(results_slot(r, i, "pprhip_results_fetch"));
+  if (!reserve_out) {
+    set_error("pprhip_results_fetch: null output");
+    return PPRHIP_ERR_INVALID;
+  }
+  return copy_out(r->g, r->buf + (size_t)i * r->g->n, reserve_out);
+}
+
+int pprhip_results_sum(pprhip_results_t* r, int i, double* sum_out) {
+  PPRHIP_TRY(results_slot(r, i, "pprhip_results_sum"));
+  if (!sum_out) {
+    set_error("pprhip_results_sum: null output");
+    return PPRHIP_ERR_INVALID;
+  }
+  return device_sum(r->g, r->buf + (size_t)i * r->g->n, sum_out);
 }
 
 int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k, double eps, double alpha,

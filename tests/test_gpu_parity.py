@@ -503,3 +503,31 @@ def test_dead_end_and_isolated_sources(pkg, orc, toy_graphs):
             g.forward_push(host.n, ALPHA, 1e-3)
         with pytest.raises(pkg.PprhipError):
             g.forward_push(-1, ALPHA, 1e-3)
+
+
+# ------------------------------------------------------------------ device-resident result store
+def test_result_store_keeps_every_query(pkg, orc, rmat12, dev_rmat12):
+    """pprhip_fora_batch_single_source_resident: every query's vector stays retrievable after its slot was reused
+    (getWholeGraphPPR of query i, Gen_Util.java:309), identical to what reserve_out delivers; sums on the device."""
+    srcs = sources(rmat12, 40, seed=21)  # more queries than slots: slots are reused
+    store = pkg.Results(dev_rmat12, 40)
+    try:
+        assert store.info() == (40, 0, rmat12.n)
+        out, ids, vals, nsel, _, _ = dev_rmat12.fora_batch_single_source(srcs, 0.5, ALPHA, seed=3, k=8, fetch=True,
+                                                                         keep=store)
+        assert store.info() == (40, 40, rmat12.n)
+        for i in range(40):
+            v = store.fetch(i)
+            assert np.array_equal(v, out[i])
+            assert abs(store.sum(i) - out[i].sum()) < 1e-12
+            m = min(int(nsel[i]), 8)
+            assert np.array_equal(v[ids[i][:m]], vals[i][:m])
+        # a second call with fewer queries: the store reports what it holds now
+        dev_rmat12.fora_batch_single_source(srcs[:3], 0.5, ALPHA, seed=3, keep=store)
+        assert store.info()[1] == 3
+        with pytest.raises(pkg.PprhipError):
+            store.fetch(3)
+        with pytest.raises(pkg.PprhipError):  # more queries than the store holds
+            dev_rmat12.fora_batch_single_source(srcs + srcs, 0.5, ALPHA, seed=3, keep=store)
+    finally:
+        store.close()

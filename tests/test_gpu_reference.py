@@ -191,7 +191,9 @@ def test_fora_vs_cpu_power_method(pkg, orc, got, dev_got, rmat12, dev_rmat12):
         for n_rounds in (0, 1, 3):
             for s in srcs:
                 est, st = dev.fora_single_source(s, EPS, A, seed=3, n_rounds=n_rounds)
-                assert abs(est.sum() - 1.0) < 1e-9
+                # floor(omega * rsum) = 0 walks leaves (1 - alpha) of the residues undelivered, in the reference too
+                # (Fora_Whole_Graph.java:112-113,123: omega_i = ceil(r / rsum * 0) = 0)
+                assert abs(est.sum() - 1.0) < 1e-9 or (st.walks == 0 and abs(est.sum() + st.rsum - 1.0) < 1e-12)
                 assert fora_bound_ok(est, exact[s], EPS, delta), (s, n_rounds)
         for tun in (pkg.tuning_default(), pkg.tuning_batch()):
             dev.set_tuning(tun)
