@@ -221,6 +221,7 @@ static double fwd_push_fifo(const orc_graph* g, int32_t s, double alpha, double 
 typedef struct sync_ws {
   int32_t *cur, *nxt;
   double* contrib;
+  uint8_t* inq; /* top-k rounds: membership in the next frontier (the reference's nodesInQueue) */
   uint32_t ncur, nnxt;
 } sync_ws;
 
@@ -228,12 +229,14 @@ static void sync_ws_init(sync_ws* w, uint32_t n) {
   w->cur = (int32_t*)xmalloc((size_t)n * sizeof(int32_t));
   w->nxt = (int32_t*)xmalloc((size_t)n * sizeof(int32_t));
   w->contrib = (double*)xmalloc((size_t)n * sizeof(double));
+  w->inq = (uint8_t*)xcalloc((size_t)n, 1);
   w->ncur = w->nnxt = 0;
 }
 static void sync_ws_free(sync_ws* w) {
   free(w->cur);
   free(w->nxt);
   free(w->contrib);
+  free(w->inq);
 }
 
 static double level_model_cost(const orc_graph* g, const orc_tuning* t, uint64_t nf, uint64_t ef, int* dense) {
@@ -292,7 +295,16 @@ static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double 
         double nr = old + c;
         residue[u] = nr;
         uint32_t du = deg_out(g, u);
-        if (!active_fwd(old, du, rmax) && active_fwd(nr, du, rmax)) w->nxt[w->nnxt++] = u;
+        /* Whole-graph pushes: every node at or above the threshold is in a frontier, so "joins the queue" is
+         * "crosses the threshold".  Top-k rounds test the new residue and queue membership only
+         * (Forward_Push.java:226-231): a node that already met the round's threshold without being queued
+         * (possible when the scaled rmax of Fora_Topk.java:133 is below min_rmax) joins with its first mass. */
+        int join = parked ? (active_fwd(nr, du, rmax) && !w->inq[u])
+                          : (!active_fwd(old, du, rmax) && active_fwd(nr, du, rmax));
+        if (join) {
+          w->nxt[w->nnxt++] = u;
+          if (parked) w->inq[u] = 1;
+        }
         if (parked && active_fwd(nr, du, min_rmax)) parked[u] = 1;
       }
     }
@@ -300,9 +312,16 @@ static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double 
       double old = residue[s];
       double nr = old + dead;
       residue[s] = nr;
-      if (!active_fwd(old, d_s, rmax) && active_fwd(nr, d_s, rmax)) w->nxt[w->nnxt++] = s;
+      int join = parked ? (active_fwd(nr, d_s, rmax) && !w->inq[s])
+                        : (!active_fwd(old, d_s, rmax) && active_fwd(nr, d_s, rmax));
+      if (join) {
+        w->nxt[w->nnxt++] = s;
+        if (parked) w->inq[s] = 1;
+      }
       if (parked && active_fwd(nr, d_s, min_rmax)) parked[s] = 1;
     }
+    if (parked) /* the next level pops these: they leave the queue */
+      for (uint32_t i = 0; i < w->nnxt; ++i) w->inq[w->nxt[i]] = 0;
     if (st) {
       int dense = 0;
       double c = tun ? level_model_cost(g, tun, w->ncur, ef, &dense) : 0.0;

@@ -143,21 +143,47 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
         L.dense_run = 0;
       }
       if (yield_dense) return kYield;
-      // The sweep writes contributions of non-empty rows only.  Rows without in-edges can hold one
-      // solely from a phase's seeding, so the other buffer is cleared when a dense phase starts
-      // and the seeded buffer right after its first level has consumed it.
-      if (L.dense_run == 0)
-        PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur ^ 1], 0, sizeof(double) * g->n, g->stream));
-      const int out = L.pslot ^ 1;
-      ktimer().begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
-      PPRHIP_TRY(launch_dense_level(g, a, L.ccur, out, L.dslot));
-      ktimer().end();
-      if (L.dense_run == 0)
-        PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
-      uint32_t nf_next = 0;
-      uint64_t ef_next = 0;
-      PPRHIP_TRY(read_packed(g, out, &nf_next, &ef_next));
-      finish_dense(L, st, dense_level_bytes(g), nf_next, ef_next);
+      // Dense levels are launched kDenseBatch at a time: level j > 0 of a batch starts with a device-side test of
+      // the frontier level j - 1 left (still non-empty and dense) and returns at once otherwise, so the host reads the
+      // batch's counters back in one round trip instead of one per level.
+      PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->dhist[0], 0, sizeof(unsigned long long) * (kDenseBatch + 1), g->stream));
+      size_t rec0[kDenseBatch];
+      ktimer().reserve(kDenseBatch);
+      for (int j = 0; j < kDenseBatch; ++j) {
+        const int cc = L.ccur ^ (j & 1), ds = L.dslot ^ (j & 1), out = L.pslot ^ 1 ^ (j & 1);
+        // The sweep writes contributions of non-empty rows only.  Rows without in-edges can hold one
+        // solely from a phase's seeding, so the other buffer is cleared when a dense phase starts
+        // and the seeded buffer right after its first level has consumed it.
+        const bool first_of_phase = j == 0 && L.dense_run == 0;
+        if (first_of_phase)
+          PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[cc ^ 1], 0, sizeof(double) * g->n, g->stream));
+        ktimer().begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
+        rec0[j] = ktimer().recs.size() - 1;
+        PPRHIP_TRY(launch_dense_level(g, a, cc, out, ds, j ? &g->ctr->dhist[j] : nullptr, dense_thresh,
+                                      &g->ctr->dhist[j + 1]));
+        ktimer().end();
+        if (first_of_phase)
+          PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[cc], 0, sizeof(double) * g->n, g->stream));
+      }
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->dhist[0], &g->ctr->dhist[0],
+                                      sizeof(unsigned long long) * (kDenseBatch + 1), hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      for (int j = 0; j < kDenseBatch; ++j) {
+        if (j > 0) {
+          // level j ran iff the device-side gate was open: the same test on the counter the host now holds
+          const unsigned long long pk = g->h_ctr->dhist[j];
+          const unsigned long long nfj = pk >> kPackShift, efj = pk & kPackMask;
+          const bool ran = nfj != 0 && (nfj + efj) >= dense_thresh;
+          if (!ran) {
+            for (int t = j; t < kDenseBatch; ++t)  // gated-off launches are not levels: keep them out of the class stats
+              if (rec0[t] < ktimer().recs.size()) ktimer().recs[rec0[t]].cls = PPRHIP_KERNEL_NONE;
+            break;
+          }
+          if (model_cost) *model_cost += c;  // a dense level costs the same whatever it pushes
+        }
+        const unsigned long long nx = g->h_ctr->dhist[j + 1];
+        finish_dense(L, st, dense_level_bytes(g), (uint32_t)(nx >> kPackShift), nx & kPackMask);
+      }
       continue;
     }
     // ---- a batch of sparse levels
@@ -259,6 +285,8 @@ int alloc_workspace(pprhip_graph* G) {
     PPRHIP_TRY(alloc_dev((void**)&G->eoff[i], sizeof(uint32_t) * (size_t)n));
   }
   PPRHIP_TRY(alloc_dev((void**)&G->flags, n));
+  PPRHIP_TRY(alloc_dev((void**)&G->armed, sizeof(uint32_t) * ((size_t)n / 32 + 2)));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(G->armed, 0, sizeof(uint32_t) * ((size_t)n / 32 + 2), G->stream));
   PPRHIP_TRY(alloc_dev((void**)&G->mc_node, sizeof(int32_t) * (size_t)n));
   PPRHIP_TRY(alloc_dev((void**)&G->mc_woff, sizeof(unsigned long long) * (size_t)n));
   PPRHIP_TRY(alloc_dev((void**)&G->partial, sizeof(double) * 1024));
@@ -295,7 +323,7 @@ int alloc_workspace(pprhip_graph* G) {
 
 void free_workspace(pprhip_graph* g) {
   void* ptrs[] = {g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1],
-                  g->eoff[0], g->eoff[1], g->flags, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist, g->sel_ids,
+                  g->eoff[0], g->eoff[1], g->flags, g->armed, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist, g->sel_ids,
                   g->sel_vals, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

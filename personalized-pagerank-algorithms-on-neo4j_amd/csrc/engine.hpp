@@ -18,7 +18,9 @@ struct DevCounters {
   unsigned long long sel_count;   // top-k candidate count
   double sum_out;                 // reduction result
   unsigned long long pad[7];
+  unsigned long long dhist[8];    // dense batch: dhist[i] = frontier that dense level i of the batch starts from
 };
+constexpr int kDenseBatch = 6;  // dense levels of a single query launched per host round trip
 
 enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
 
@@ -64,6 +66,10 @@ struct KernelTimer {
     }
     used = 0;
     recs.clear();
+  }
+  // room for k more intervals without a fold in between (callers that keep indices into `recs`)
+  void reserve(size_t k) {
+    if (used + 2 * k > kMaxEvents && hipStreamSynchronize(stream) == hipSuccess) fold();
   }
   void begin(int cls, uint64_t bytes) {
     if (used + 2 > kMaxEvents) {
@@ -120,6 +126,7 @@ struct SlotArgs {
   double* res;
   double* reserve;
   uint8_t* flags;
+  uint32_t* armed;
   DevCounters* ctr;
   double alpha, rmax, min_rmax;
   int32_t src;
@@ -191,6 +198,10 @@ struct pprhip_graph {
   int32_t* F[2] = {nullptr, nullptr};
   uint32_t* eoff[2] = {nullptr, nullptr};
   uint8_t* flags = nullptr;
+  // top-k rounds: one bit per node that meets the round's threshold at round start without being parked (possible
+  // when the scaled rmax of Fora_Topk.java:133 falls below min_rmax); such a node joins the frontier the first time
+  // it receives mass, as Forward_Push.java:226-231 enqueues it, although it does not *cross* the threshold
+  uint32_t* armed = nullptr;
   // walk plan
   int32_t* mc_node = nullptr;
   double* mc_inc = nullptr;
@@ -225,7 +236,11 @@ int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int leve
                           unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot);
 int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
                        unsigned long long dense_thresh, int dead_slot);
-int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot);
+// gate != nullptr: the level runs only if *gate (the frontier the level before it left) is non-empty and still
+// dense (entries + edges >= dense_thresh); hist_out receives the frontier this level leaves.
+int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot,
+                       const unsigned long long* gate = nullptr, unsigned long long dense_thresh = 0,
+                       unsigned long long* hist_out = nullptr);
 constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply kernel (per-slot partials each)
 int launch_dense_level_b8(pprhip_graph* parent, bool backward);  // slot arguments already staged in parent->h_slot_args
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);

@@ -404,6 +404,7 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
     sa.res = S->residue;
     sa.reserve = S->reserve;
     sa.flags = S->flags;
+    sa.armed = S->armed;
     sa.ctr = S->ctr;
     sa.active = active[s] ? 1 : 0;
     if (!active[s]) continue;

@@ -44,6 +44,16 @@ __device__ __forceinline__ bool level_runs(unsigned long long pk, int level, uns
   return (nf + ef) < dense_thresh;
 }
 
+// A dense level launched behind another one without a host round trip in between: it runs iff the level before
+// it left a frontier that is non-empty and still worth a sweep (the host applies the same test to the counters
+// when it reads them back).
+__device__ __forceinline__ bool dense_gate_open(const unsigned long long* gate, unsigned long long dense_thresh) {
+  if (!gate) return true;
+  const unsigned long long pk = *gate;
+  const unsigned long long nf = pk >> kPackShift, ef = pk & kPackMask;
+  return nf != 0 && (nf + ef) >= dense_thresh;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sparse level, step 1: every frontier node gives up its residue
 // ------------------------------------------------------------------------------------------------
@@ -105,10 +115,19 @@ struct NewList {  // crossings of the current tile, collected in LDS
 
 // One edge lands in three steps so that a thread can keep several edges in flight: the degree
 // gather and the returning atomic are issued for a batch of edges before any result is used.
+// A node that met the round's threshold at round start without being in the queue ("armed", see engine.hpp) is
+// enqueued by the first push that reaches it (Forward_Push.java:226-231 tests the new residue only): whoever clears
+// its bit appends it.
+__device__ __forceinline__ bool take_armed(uint32_t* __restrict__ armed, int32_t u) {
+  const uint32_t bit = 1u << ((uint32_t)u & 31u);
+  if (!(armed[(uint32_t)u >> 5] & bit)) return false;
+  return (atomicAnd(&armed[(uint32_t)u >> 5], ~bit) & bit) != 0;
+}
+
 template <int MODE>
 __device__ __forceinline__ void push_finish(int32_t u, double add, double old, uint32_t du,
                                             const uint32_t* __restrict__ in_rp, uint8_t* __restrict__ flags,
-                                            NewList* nl, const PushArgs& a) {
+                                            uint32_t* __restrict__ armed, NewList* nl, const PushArgs& a) {
   const double nw = old + add;
   bool crossing;
   uint32_t adeg;
@@ -116,9 +135,13 @@ __device__ __forceinline__ void push_finish(int32_t u, double add, double old, u
     crossing = !(old > a.rmax) && (nw > a.rmax);  // Backward_Search.java:89 strict, un-normalised
     adeg = crossing ? in_rp[u + 1] - in_rp[u] : 0u;
   } else {
-    crossing = !active_fwd(old, du, a.rmax) && active_fwd(nw, du, a.rmax);  // Forward_Push.java:132
+    const bool was = active_fwd(old, du, a.rmax);
+    crossing = !was && active_fwd(nw, du, a.rmax);  // Forward_Push.java:132
     adeg = du;
-    if (MODE == kFwdTopk && active_fwd(nw, du, a.min_rmax)) flags[u] = 1;  // :232-237 (parked)
+    if (MODE == kFwdTopk) {
+      if (was && a.rmax < a.min_rmax) crossing = take_armed(armed, u);
+      if (active_fwd(nw, du, a.min_rmax)) flags[u] = 1;  // :232-237 (parked)
+    }
   }
   if (crossing) {
     const uint32_t slot = atomicAdd(&nl->count, 1u);
@@ -130,11 +153,12 @@ __device__ __forceinline__ void push_finish(int32_t u, double add, double old, u
 template <int MODE>
 __device__ __forceinline__ void push_one(int32_t u, double c, const unsigned long long* __restrict__ out_ext,
                                          const uint32_t* __restrict__ in_rp, double* __restrict__ res,
-                                         uint8_t* __restrict__ flags, NewList* nl, const PushArgs& a) {
+                                         uint8_t* __restrict__ flags, uint32_t* __restrict__ armed, NewList* nl,
+                                         const PushArgs& a) {
   const uint32_t du = (uint32_t)(out_ext[u] >> 32);  // packed row extent: one gather for the degree
   const double add = (MODE == kBackward) ? c / (double)du : c;  // Backward_Search.java:84-85
   const double old = atomic_add_ret(&res[u], add);               // Forward_Push.java:123-127
-  push_finish<MODE>(u, add, old, du, in_rp, flags, nl, a);
+  push_finish<MODE>(u, add, old, du, in_rp, flags, armed, nl, a);
 }
 
 // Appends the tile's crossings to the next frontier: one packed atomic reserves list slots and
@@ -178,7 +202,8 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
                                                       const uint32_t* __restrict__ trp, const int32_t* __restrict__ tci,
                                                       const unsigned long long* __restrict__ out_ext,
                                                       const uint32_t* __restrict__ in_rp, double* __restrict__ res,
-                                                      uint8_t* __restrict__ flags, int32_t* __restrict__ Fn,
+                                                      uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
+                                                      int32_t* __restrict__ Fn,
                                                       uint32_t* __restrict__ eoffn, DevCounters* ctr, int level,
                                                       unsigned long long dense_thresh, int dead_slot, PushArgs a) {
   __shared__ uint32_t s_eoff[kStageCap + 1];
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
     if (tid == 0) {
       const double dead = ctr->dead[dead_slot];
       if (dead > 0.0) {
-        push_one<MODE>(a.src, dead, out_ext, in_rp, res, flags, &s_new, a);
+        push_one<MODE>(a.src, dead, out_ext, in_rp, res, flags, armed, &s_new, a);
         ctr->dead[dead_slot] = 0.0;
       }
     }
@@ -272,7 +297,7 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (valid[q]) push_finish<MODE>(u[q], add[q], old[q], du[q], in_rp, flags, &s_new, a);
+          if (valid[q]) push_finish<MODE>(u[q], add[q], old[q], du[q], in_rp, flags, armed, &s_new, a);
       }
       __syncthreads();
       ce = cov_hi;
@@ -321,8 +346,11 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
                                                        const uint8_t* __restrict__ start_flags,
                                                        const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
                                                        unsigned long long m, const double* __restrict__ c_cur,
-                                                       double* __restrict__ acc_nz, uint32_t n_hot) {
+                                                       double* __restrict__ acc_nz, uint32_t n_hot,
+                                                       const unsigned long long* gate,
+                                                       unsigned long long dense_thresh) {
   extern __shared__ __attribute__((aligned(16))) double s_hot[];
+  if (!dense_gate_open(gate, dense_thresh)) return;
   const int lane = lane_id();
   const uint32_t waves_per_block = blockDim.x >> 6;
   const uint32_t stride = gridDim.x * waves_per_block;
@@ -614,11 +642,14 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
                                                       const uint32_t* __restrict__ in_rp,
                                                       double* __restrict__ c_next, double* __restrict__ res,
                                                       double* __restrict__ reserve, uint8_t* __restrict__ flags,
+                                                      uint32_t* __restrict__ armed,
                                                       DevCounters* ctr, unsigned long long* __restrict__ blk_pack,
                                                       double* __restrict__ blk_dead, uint32_t* __restrict__ blk_ndead,
-                                                      int dead_slot, int src_extra, PushArgs a) {
+                                                      int dead_slot, int src_extra, PushArgs a,
+                                                      const unsigned long long* gate, unsigned long long dense_thresh) {
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
+  if (!dense_gate_open(gate, dense_thresh)) return;
   const int tid = threadIdx.x;
   const uint32_t j = blockIdx.x * 256u + tid;
   bool have = false;
@@ -663,8 +694,13 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
     } else if (acc > 0.0) {
       const double old = res[u];
       const double nw = old + acc;
-      const bool crossing = (MODE == kPower) ? true : (!active_fwd(old, d, a.rmax) && active_fwd(nw, d, a.rmax));
-      if (MODE == kFwdTopk && active_fwd(nw, d, a.min_rmax)) flags[u] = 1;
+      bool crossing = (MODE == kPower) ? true : (!active_fwd(old, d, a.rmax) && active_fwd(nw, d, a.rmax));
+      if (MODE == kFwdTopk) {
+        // a row is applied once per level, so "receives mass and meets the threshold" needs no queue test here: an
+        // armed node (met the threshold at round start, not queued) joins with its first mass (:226-231)
+        if (a.rmax < a.min_rmax && active_fwd(old, d, a.rmax)) crossing = take_armed(armed, u);
+        if (active_fwd(nw, d, a.min_rmax)) flags[u] = 1;
+      }
       if (crossing) {  // becomes a frontier node of the next level: prepare it right here
         reserve[u] = reserve[u] + nw * a.alpha;
         res[u] = 0.0;
@@ -808,8 +844,11 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
       } else if (live[i]) {
         const double old = oldv[i];
         const double nw = old + accv[i];
-        const bool crossing = !active_fwd(old, d, a[i].rmax) && active_fwd(nw, d, a[i].rmax);
-        if (a[i].mode == kFwdTopk && active_fwd(nw, d, a[i].min_rmax)) a[i].flags[u] = 1;
+        bool crossing = !active_fwd(old, d, a[i].rmax) && active_fwd(nw, d, a[i].rmax);
+        if (a[i].mode == kFwdTopk) {
+          if (a[i].rmax < a[i].min_rmax && active_fwd(old, d, a[i].rmax)) crossing = take_armed(a[i].armed, u);
+          if (active_fwd(nw, d, a[i].min_rmax)) a[i].flags[u] = 1;
+        }
         if (crossing) {  // becomes a frontier node of the next level: prepare it right here
           a[i].reserve[u] = rsvv[i] + nw * a[i].alpha;
           a[i].res[u] = 0.0;
@@ -889,9 +928,12 @@ __global__ __launch_bounds__(1024) void k_dense_reduce_batch(const unsigned long
 __global__ __launch_bounds__(1024) void k_dense_reduce(const unsigned long long* __restrict__ blk_pack,
                                                         const double* __restrict__ blk_dead,
                                                         const uint32_t* __restrict__ blk_ndead, uint32_t n_blocks,
-                                                        DevCounters* ctr, int out_slot, int dead_slot_next) {
+                                                        DevCounters* ctr, int out_slot, int dead_slot_next,
+                                                        const unsigned long long* gate, unsigned long long dense_thresh,
+                                                        unsigned long long* hist_out) {
   __shared__ double s_red[16];
   __shared__ unsigned long long s_red2[16];
+  if (!dense_gate_open(gate, dense_thresh)) return;
   unsigned long long pack = 0, ndead = 0;
   double dead = 0.0;
   for (uint32_t i = threadIdx.x; i < n_blocks; i += blockDim.x) {
@@ -906,6 +948,7 @@ __global__ __launch_bounds__(1024) void k_dense_reduce(const unsigned long long*
   const double ds = block_sum_f64(dead, s_red);
   if (threadIdx.x == 0) {
     ctr->packed[out_slot] = ps;
+    if (hist_out) *hist_out = ps;
     if (nd) {
       ctr->dead[dead_slot_next] = ctr->dead[dead_slot_next] + ds;
       ctr->dead_pops += nd;
@@ -937,13 +980,27 @@ __device__ __forceinline__ void unpark(uint32_t v, const double* __restrict__ re
 template <int KIND>
 __global__ __launch_bounds__(256) void k_count_active(uint32_t n, const double* __restrict__ res,
                                                        const uint32_t* __restrict__ out_rp,
-                                                       const uint8_t* __restrict__ flags,
+                                                       const uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
                                                        unsigned long long* __restrict__ blk_pack, PushArgs a) {
   __shared__ unsigned long long s_red2[4];
   unsigned long long pack = 0;
-  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
-    const uint32_t d = out_rp[v + 1] - out_rp[v];
-    if (seed_pred<KIND>(v, res, d, flags, a)) pack += (1ull << kPackShift) | (unsigned long long)d;
+  // wave-uniform trip count: a wave covers 64 consecutive nodes, whose "armed" bits it writes as one 64-bit word
+  for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += gridDim.x * blockDim.x) {
+    const uint32_t v = base + (threadIdx.x & 63u);
+    bool arm = false;
+    if (v < n) {
+      const uint32_t d = out_rp[v + 1] - out_rp[v];
+      if (seed_pred<KIND>(v, res, d, flags, a)) pack += (1ull << kPackShift) | (unsigned long long)d;
+      // top-k rounds: meets the round's threshold without being parked (only when rmax < min_rmax)
+      if (KIND == 1) arm = a.rmax < a.min_rmax && !flags[v] && active_fwd(res[v], d, a.rmax);
+    }
+    if (KIND == 1) {
+      const unsigned long long bits = __ballot(arm);
+      if ((threadIdx.x & 63u) == 0) {
+        armed[base >> 5] = (uint32_t)bits;
+        armed[(base >> 5) + 1] = (uint32_t)(bits >> 32);
+      }
+    }
   }
   const unsigned long long ps = block_sum_u64(pack, s_red2);
   if (threadIdx.x == 0) blk_pack[blockIdx.x] = ps;
@@ -1138,12 +1195,13 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
   const int32_t* tci = bwd ? g->in_ci : g->out_ci;
   DISPATCH_MODE(a.mode, k_sparse_push<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
                             g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_ext, g->in_rp, g->residue, g->flags,
-                            g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot, a));
+                            g->armed, g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot, a));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
-int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot) {
+int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot,
+                       const unsigned long long* gate, unsigned long long dense_thresh, unsigned long long* hist_out) {
   // forward levels pull over the in-CSR, backward levels over the out-CSR (layout built by the caller)
   const bool bwd = a.mode == kBackward;
   const int32_t* ci = bwd ? g->out_ci : g->in_ci;
@@ -1158,11 +1216,13 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     if (n_hot) {  // (dynamic LDS above 64 KB: opted in by init_kernels_push at graph lift)
       const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
       k_dense_edges<true><<<dim3(grid), dim3(1024), sizeof(double) * n_hot, g->stream>>>(
-          ci, flags, cstarts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, n_hot);
+          ci, flags, cstarts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, n_hot, gate,
+          dense_thresh);
     } else {
       const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
       k_dense_edges<false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
-          ci, flags, cstarts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, 0u);
+          ci, flags, cstarts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, 0u, gate,
+          dense_thresh);
     }
     PPRHIP_CHECK_HIP(hipGetLastError());
   }
@@ -1172,11 +1232,12 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   if (grid) {
     DISPATCH_MODE(a.mode, k_dense_apply<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
                               nz, n_nz, g->acc_nz, g->out_rp, g->in_rp, g->cdense[cbuf ^ 1], g->residue, g->reserve,
-                              g->flags, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead, dead_slot, src_extra, a));
+                              g->flags, g->armed, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead, dead_slot, src_extra, a, gate,
+                              dense_thresh));
     PPRHIP_CHECK_HIP(hipGetLastError());
   }
   k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, g->blk_dead, g->blk_ndead, grid, g->ctr,
-                                                        out_slot, dead_slot ^ 1);
+                                                        out_slot, dead_slot ^ 1, gate, dense_thresh, hist_out);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -1247,7 +1308,7 @@ int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned lo
 // block partial counts -> ctr->packed[out_slot] (reuses the dense reducer with no dead mass)
 static int reduce_partials(pprhip_graph* g, uint32_t n_blocks, int out_slot, int dead_slot, bool with_dead) {
   k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, with_dead ? g->blk_dead : nullptr, g->blk_ndead,
-                                                        n_blocks, g->ctr, out_slot, dead_slot);
+                                                        n_blocks, g->ctr, out_slot, dead_slot, nullptr, 0ull, nullptr);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -1255,9 +1316,11 @@ static int reduce_partials(pprhip_graph* g, uint32_t n_blocks, int out_slot, int
 int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot) {
   const uint32_t grid = grid_for(g->n, 256 * 8, 1024);
   if (seed_kind == 0)
-    k_count_active<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->blk_pack, a);
+    k_count_active<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->armed,
+                                                               g->blk_pack, a);
   else
-    k_count_active<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->blk_pack, a);
+    k_count_active<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->armed,
+                                                               g->blk_pack, a);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return reduce_partials(g, grid, out_slot, 0, false);
 }

@@ -274,7 +274,8 @@ void Forward_Push::deletePrepDir() { rmTree(preprocessing_dirName, false); }
 // ------------------------------------------------------------------ Monte_Carlo
 Monte_Carlo::Monte_Carlo(double alpha, double pfail, double delta, std::shared_ptr<Graph> adjM, std::string dir_db,
                          uint64_t seed)
-    : Algo_Util(std::move(adjM), alpha, dir_db), pfail(pfail), delta(delta), seed(seed) {}
+    : Algo_Util(std::move(adjM), alpha, dir_db), pfail(pfail), delta(delta), seed(seed),
+      preprocessing_dirName("MC_ppr_results/" + dir_db) {}  // Monte_Carlo.java:57
 
 long Monte_Carlo::random_walk(long s) {
   int32_t start = (int32_t)s, term = 0;
@@ -320,6 +321,26 @@ void Monte_Carlo::printTopKResult(int k) {
   for (int i = 0; i < k && i < (int)topk_nodeIds.size(); ++i)
     std::cout << "@" << adjM->nodeName(topk_nodeIds[i]) << '\t' << jdouble(topk_res[topk_nodeIds[i]]) << std::endl;
 }
+
+void Monte_Carlo::preprocessing(double, double epsilon) {  // Monte_Carlo.java:181-229
+  preprocessing_dirName += "/" + jdouble(epsilon);
+  std::cout << "\nMonte-Carlo preprocessing started..." << std::endl;
+  mkdirs(preprocessing_dirName);
+  rmTree(preprocessing_dirName, true);
+  for (long v = 0; v < adjM->nodeCount(); ++v) {  // adjM.forEachNode (:209)
+    computeWholeGraphPPR(v, epsilon);
+    fetchReserve();
+    std::vector<std::pair<long, double>> rows(ppr.begin(), ppr.end());
+    std::sort(rows.begin(), rows.end());  // the reference writes HashMap order; ascending ids here
+    writeMapFile(preprocessing_dirName + "/" + std::to_string(v) + ".txt", rows);
+  }
+}
+void Monte_Carlo::readPreprocessedPPR(long s) {  // :232-255
+  readMapFile(preprocessing_dirName + "/" + std::to_string(s) + ".txt", ppr, nullptr);
+  fetched = true;
+}
+long Monte_Carlo::getPrepSize() { return dirSize(preprocessing_dirName); }
+void Monte_Carlo::deletePrepDir() { rmTree(preprocessing_dirName, false); }
 
 // ------------------------------------------------------------------ Fora_Whole_Graph
 Fora_Whole_Graph::Fora_Whole_Graph(double alpha, double rsum, double pfail, double delta, std::shared_ptr<Graph> adjM,
@@ -670,7 +691,11 @@ void Gen_Util::algo_perf_test(AlgoType algoType, int query_num, int k, double pa
       prep = a.get();
       algo = std::move(a);
     } break;
-    case AlgoType::MC: algo = conf.set_conf_mc(adjM, dir_db); break;
+    case AlgoType::MC: {
+      auto a = conf.set_conf_mc(adjM, dir_db);
+      prep = a.get();
+      algo = std::move(a);
+    } break;
     case AlgoType::BASE_WHOLE_GRAPH: {
       auto a = conf.set_conf_base_whole_graph(adjM, dir_db);
       prep = a.get();
@@ -753,6 +778,20 @@ void Gen_Util::algo_perf_batch_test(int query_num, int k) {
     else
       for (double p : (a == AlgoType::MC ? eps_mc : a == AlgoType::FWDPUSH ? rmax_arr : eps_fora))
         algo_perf_test(a, query_num, k, p, -1.0, false, TestType::TOPK);
+  }
+  // Test 3. Preprocessing test (Gen_Util.java:602-645): every source's vector is computed up front and written to
+  // <ALGO>_ppr_results/<db>/<param>/<id>.txt; a query then reads its file (readPreprocessedPPR).  Same parameter
+  // arrays as Test 1 for GOT (:470-477); threshold_arr_other_prep = {-1.0}.
+  header("Test 3. Preprocessing test");
+  const AlgoType prep[] = {AlgoType::FORA_WHOLE_GRAPH, AlgoType::FWDPUSH, AlgoType::MC, AlgoType::BASE_WHOLE_GRAPH};
+  idx = 1;
+  for (AlgoType a : prep) {
+    header("3." + std::to_string(idx++) + " " + algoName(a));
+    if (a == AlgoType::BASE_WHOLE_GRAPH)
+      for (double t : thr_base) algo_perf_test(a, query_num, -1, -1, t, true, TestType::WHOLE_GRAPH);
+    else
+      for (double p : (a == AlgoType::MC ? eps_mc : a == AlgoType::FWDPUSH ? rmax_arr : eps_fora))
+        algo_perf_test(a, query_num, -1, p, -1.0, true, TestType::WHOLE_GRAPH);
   }
 }
 

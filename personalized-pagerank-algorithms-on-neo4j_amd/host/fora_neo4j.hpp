@@ -133,7 +133,8 @@ class Forward_Push : public Algo_Util, public Whole_Graph_Util_Interface, public
 };
 
 // Monte_Carlo.java
-class Monte_Carlo : public Algo_Util, public Whole_Graph_Util_Interface, public Topk_Util_Interface {
+class Monte_Carlo : public Algo_Util, public Whole_Graph_Util_Interface, public Topk_Util_Interface,
+                    public Preprocessing_Interface {
  public:
   Monte_Carlo(double alpha, double pfail, double delta, std::shared_ptr<Graph> adjM, std::string dir_db,
               uint64_t seed = 1);
@@ -145,10 +146,15 @@ class Monte_Carlo : public Algo_Util, public Whole_Graph_Util_Interface, public 
   void computeTopKPPR(long nodeId_start, int k, double epsilon) override;
   const std::vector<long>& getTopKNodeIds(int k) override;
   void printTopKResult(int k) override;
+  void preprocessing(double dummy, double epsilon) override;  // :181-229
+  void readPreprocessedPPR(long nodeId_start) override;       // :232-255
+  long getPrepSize() override;
+  void deletePrepDir() override;
 
  private:
   double pfail, delta;
   uint64_t seed, walk_counter = 0;
+  std::string preprocessing_dirName;
 };
 
 // Fora_Whole_Graph.java

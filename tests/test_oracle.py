@@ -378,3 +378,32 @@ def test_fifo_oracle_reproduces_committed_vectors(orc, got):
         assert np.array_equal(est, un(rec["estimate"])) and st.walks == rec["walks"] and st.walk_steps == rec["walk_steps"]
         cnt, ids, _ = orc.topk(og.power_method(s, A, 100), 10, cap=got.n)
         assert cnt == e["power_method_top10"]["count"] and ids.tolist() == e["power_method_top10"]["ids"]
+
+
+def test_topk_rounds_push_whatever_meets_the_threshold(orc, pkg, got, rmat12):
+    """Forward_Push.forward_push_topk (:173,226-237) enqueues on the *new* residue and queue membership only, so after a
+    round nothing at or above max(rmax, min_rmax) is left, in either schedule - also in the rounds whose scaled
+    rmax (Fora_Topk.java:133) is below min_rmax, where a node can meet the threshold without having been parked
+    (the frontier-synchronous twin once tested "crosses the threshold" and left such nodes behind)."""
+    hit = 0
+    for host, k, srcs in ((got, 10, [63, 1, 5, 17, 42]), (rmat12, 32, [350, 734, 969])):
+        og = to_oracle(orc, host)
+        od = np.diff(host.out_rp)
+        live = od > 0
+        conf = pkg.conf_topk(host.n, host.m, k, A)
+        for s in srcs:
+            for sch in (orc.SYNC, orc.FIFO):
+                tp = og.topk_push(s, A, sch)
+                delta = 1.0 / k
+                while True:
+                    min_rmax, rmax, _ = pkg.fora_topk_params(conf, 0.5, delta)
+                    hit += rmax < min_rmax
+                    tp.round(min_rmax, rmax)
+                    r = tp.residue
+                    assert np.all(r[live] / od[live] < max(rmax, min_rmax)), (s, sch, delta)
+                    if od[s] > 0:
+                        assert abs(tp.reserve.sum() + r.sum() - 1.0) < 1e-12
+                    if delta <= 1.0 / host.n:
+                        break
+                    delta = max(1.0 / host.n, delta / 4.0)
+    assert hit > 0  # the case is exercised (GOT's last round)
