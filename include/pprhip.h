@@ -46,6 +46,7 @@ typedef struct pprhip_graph pprhip_graph_t;       /* device-resident CSR pair + 
 typedef struct pprhip_edgelist pprhip_edgelist_t; /* host edge list produced by the ingest helpers */
 typedef struct pprhip_index pprhip_index_t;       /* all-pair inverted index (host, CSR by source) */
 typedef struct pprhip_results pprhip_results_t;   /* device-resident result vectors of a batched call (q x n doubles) */
+typedef struct pprhip_comm pprhip_comm_t;         /* one rank of a multi-GPU group (RCCL communicator + its graph replica) */
 
 /* Counters every compute call fills; all device-side counts, not estimates. */
 typedef struct pprhip_stats {
@@ -294,6 +295,46 @@ int pprhip_index_write_dir(const pprhip_index_t* ix, const char* dir);
  * "1.0E-4" style outside [1e-3, 1e7)); returns the length written (without the NUL) or < 0. */
 int pprhip_format_double(double d, char* buf, size_t cap);
 void pprhip_index_destroy(pprhip_index_t* ix);
+
+/* ---------------------------------------------------------------- multi-GPU
+ * Queries (Gen_Util.java:208-232) and targets (Base_Whole_Graph.java:76-92) are independent: every GPU holds a
+ * replica of the CSR (one pprhip_graph_t per GPU) and runs its share with the single-GPU code; nothing is exchanged
+ * inside a query or a search.  Two exchanges close a call, both over RCCL (librccl is loaded on first use):
+ * batched FORA gathers the per-query top-k blocks on rank 0; All-Pair, whose result is keyed by source
+ * (Base_Whole_Graph.java:84-86), sends every entry (v, t, pi) to the rank that owns source v - partitioned on the
+ * device, one message per peer (one xGMI link each), copied to the host once, by the owner that finalises it. */
+
+/* One process, n_gpu GPUs, one host thread per GPU inside the call: query i runs on per_gpu[i mod n_gpu] exactly as
+ * pprhip_fora_batch_single_source would run it (same seed, same walks), the top-k blocks are gathered on GPU 0.
+ * ids_out / vals_out: q * k (rows padded with id -1 / value 0), n_out[q] or NULL, stats_per_gpu[n_gpu] or NULL.
+ * Handles that share a device (a test set-up) exchange through in-process copies instead of RCCL. */
+int pprhip_fora_batch(pprhip_graph_t* const* per_gpu, int n_gpu, const int32_t* srcs, int q, int k, double eps,
+                      const pprhip_fora_conf_t* conf, uint64_t seed, int n_rounds, int32_t* ids_out, double* vals_out,
+                      int* n_out, pprhip_stats_t* stats_per_gpu);
+/* Base_Whole_Graph.preprocessing(threshold, k) over all n targets on n_gpu GPUs: GPU r searches the targets of
+ * pprhip_shard_target_range(r) and owns the sources of the same range; returns the whole index (identical to
+ * pprhip_all_pair_backward over [0, n) on one GPU). */
+int pprhip_all_pair_backward_multi(pprhip_graph_t* const* per_gpu, int n_gpu, double alpha, double threshold, int k,
+                                   pprhip_index_t** index_out, pprhip_stats_t* stats_per_gpu);
+
+/* One process per GPU (torch.distributed, MPI, one JVM per GPU): rank 0 draws an id, hands its PPRHIP_COMM_ID_BYTES
+ * bytes to every rank by any means, every rank creates its communicator (collective, like ncclCommInitRank). */
+#define PPRHIP_COMM_ID_BYTES 128
+int pprhip_comm_unique_id(void* id_out /* PPRHIP_COMM_ID_BYTES */);
+int pprhip_comm_create(pprhip_graph_t* g, const void* id, int rank, int world, pprhip_comm_t** comm_out);
+void pprhip_comm_destroy(pprhip_comm_t* c);
+int pprhip_comm_info(const pprhip_comm_t* c, int* rank, int* world);
+/* contiguous share [begin, end) of rank `rank` when [0, n) is cut into `world` ranges (targets and owned sources) */
+int pprhip_shard_target_range(int rank, int world, uint32_t n, uint32_t* begin, uint32_t* end);
+/* Collective: this rank searches its target range, entries are exchanged by owner of the source on the device, and
+ * own_out receives the finished rows (k rule applied) of the sources this rank owns (rows of other sources empty).
+ * stats: this rank's search; stats->mc_sources = entries it found, stats->select_bytes = bytes it received. */
+int pprhip_all_pair_backward_sharded(pprhip_comm_t* c, double alpha, double threshold, int k, pprhip_index_t** own_out,
+                                     pprhip_stats_t* stats);
+/* Collective: every rank contributes `rows` <= rows_max rows of k (id, value) pairs; rank 0 receives world blocks of
+ * rows_max rows each (short blocks padded with id -1 / value 0) in ids_root / vals_root. */
+int pprhip_topk_gather(pprhip_comm_t* c, const int32_t* ids, const double* vals, int rows, int rows_max, int k,
+                       int32_t* ids_root, double* vals_root);
 
 /* ---------------------------------------------------------------- ground truth (a12) */
 /* Power_Method.computeWholeGraphPPR (Power_Method.java:44-101): `iters` synchronous sweeps. */

@@ -74,7 +74,11 @@ EXPORTS = [
     "pprhip_format_double", "pprhip_edgelist_from_neo4j_store", "pprhip_edgelist_build_csr",
     "pprhip_fora_batch_single_source", "pprhip_tuning_batch", "pprhip_results_create", "pprhip_results_destroy",
     "pprhip_results_info", "pprhip_results_fetch", "pprhip_results_sum", "pprhip_fora_batch_single_source_resident",
+    "pprhip_fora_batch", "pprhip_all_pair_backward_multi", "pprhip_comm_unique_id", "pprhip_comm_create",
+    "pprhip_comm_destroy", "pprhip_comm_info", "pprhip_shard_target_range", "pprhip_all_pair_backward_sharded",
+    "pprhip_topk_gather",
 ]
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -137,6 +141,16 @@ def lib():
     L.pprhip_results_fetch.argtypes = [vp, ci, vp]
     L.pprhip_results_sum.argtypes = [vp, ci, P(dbl)]
     L.pprhip_fora_batch_topk.argtypes = [vp, vp, ci, ci, dbl, dbl, u64, vp, vp, P(Stats)]
+    L.pprhip_fora_batch.argtypes = [P(vp), ci, vp, ci, ci, dbl, P(ForaConf), u64, ci, vp, vp, vp, vp]
+    L.pprhip_all_pair_backward_multi.argtypes = [P(vp), ci, dbl, dbl, ci, P(vp), vp]
+    L.pprhip_comm_unique_id.argtypes = [vp]
+    L.pprhip_comm_create.argtypes = [vp, vp, ci, ci, P(vp)]
+    L.pprhip_comm_destroy.argtypes = [vp]
+    L.pprhip_comm_destroy.restype = None
+    L.pprhip_comm_info.argtypes = [vp, P(ci), P(ci)]
+    L.pprhip_shard_target_range.argtypes = [ci, ci, u32, P(u32), P(u32)]
+    L.pprhip_all_pair_backward_sharded.argtypes = [vp, dbl, dbl, ci, P(vp), P(Stats)]
+    L.pprhip_topk_gather.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
     L.pprhip_backward_push.argtypes = [vp, i32, dbl, dbl, vp, vp, P(Stats)]
     L.pprhip_all_pair_backward.argtypes = [vp, dbl, dbl, ci, u32, u32, P(vp), P(Stats)]
     L.pprhip_index_merge.argtypes = [P(vp), ci, ci, P(vp)]
@@ -341,6 +355,80 @@ def merge_indexes(shards, k):
     out = C.c_void_p()
     _check(lib().pprhip_index_merge(arr, len(shards), k, C.byref(out)))
     return Index(out)
+
+
+def shard_target_range(rank, world, n):
+    b, e = C.c_uint32(), C.c_uint32()
+    _check(lib().pprhip_shard_target_range(rank, world, n, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+def comm_unique_id():
+    """The bytes rank 0 hands to every rank before Comm() (an RCCL unique id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().pprhip_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """One rank of a multi-GPU group: an RCCL communicator bound to this rank's graph replica (collective create)."""
+
+    def __init__(self, graph, uid, rank, world):
+        self.graph = graph
+        self.rank, self.world = rank, world
+        self.h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
+        _check(lib().pprhip_comm_create(graph.h, buf, rank, world, C.byref(self.h)))
+
+    def all_pair_backward_sharded(self, alpha, threshold, k):
+        """Collective: returns (Index of the sources this rank owns, Stats)."""
+        out, st = C.c_void_p(), Stats()
+        _check(lib().pprhip_all_pair_backward_sharded(self.h, alpha, threshold, k, C.byref(out), C.byref(st)))
+        return Index(out), st
+
+    def topk_gather(self, ids, vals, rows_max):
+        """Collective: rank 0 gets (ids[world, rows_max, k], vals[...]), the others None."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        rows, k = ids.shape
+        ri = np.empty((self.world, rows_max, k), dtype=np.int32) if self.rank == 0 else None
+        rv = np.empty((self.world, rows_max, k)) if self.rank == 0 else None
+        _check(lib().pprhip_topk_gather(self.h, _ptr(ids), _ptr(vals), rows, rows_max, k, _ptr(ri), _ptr(rv)))
+        return (ri, rv) if self.rank == 0 else None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().pprhip_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def fora_batch_multi(graphs, srcs, k, eps, alpha, seed, n_rounds=0, conf=None):
+    """pprhip_fora_batch: q queries over len(graphs) GPUs of this process; returns (ids[q, k], vals[q, k], n_sel[q], [Stats])."""
+    srcs = np.ascontiguousarray(srcs, dtype=np.int32)
+    q = int(srcs.size)
+    g0 = graphs[0]
+    conf = conf or conf_whole_graph(g0.n, g0.m, alpha)
+    hs = (C.c_void_p * len(graphs))(*[g.h for g in graphs])
+    ids = np.empty((q, k), dtype=np.int32)
+    vals = np.empty((q, k))
+    nsel = np.zeros(q, dtype=np.int32)
+    sts = (Stats * len(graphs))()
+    _check(lib().pprhip_fora_batch(hs, len(graphs), _ptr(srcs), q, k, eps, C.byref(conf), seed, n_rounds, _ptr(ids),
+                                   _ptr(vals), _ptr(nsel), C.cast(sts, C.c_void_p)))
+    return ids, vals, nsel, list(sts)
+
+
+def all_pair_backward_multi(graphs, alpha, threshold, k):
+    """pprhip_all_pair_backward_multi: the whole index over len(graphs) GPUs of this process; returns (Index, [Stats])."""
+    hs = (C.c_void_p * len(graphs))(*[g.h for g in graphs])
+    out = C.c_void_p()
+    sts = (Stats * len(graphs))()
+    _check(lib().pprhip_all_pair_backward_multi(hs, len(graphs), alpha, threshold, k, C.byref(out),
+                                                C.cast(sts, C.c_void_p)))
+    return Index(out), list(sts)
 
 
 class Results:

@@ -97,20 +97,67 @@ void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix)
 
 }  // namespace
 
-extern "C" {
+namespace pprhip {
+namespace detail {
 
-int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, int k, uint32_t t_begin, uint32_t t_end,
-                             pprhip_index_t** index_out, pprhip_stats_t* stats) {
-  PPRHIP_TRY(check_graph(g, "pprhip_all_pair_backward"));
-  if (!index_out || t_begin > t_end || t_end > g->n) {
-    set_error("pprhip_all_pair_backward: bad target range [%u, %u) for n=%u", t_begin, t_end, g->n);
-    return PPRHIP_ERR_INVALID;
-  }
-  pprhip_stats_t st;
-  std::memset(&st, 0, sizeof st);
+// entries of the searches go to the host right away (single-GPU call) ...
+int HostTripleSink::take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
+                                unsigned long long count) {
+  h_v.resize(count); h_t.resize(count); h_p.resize(count);
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(h_v.data(), d_v, sizeof(int32_t) * count, hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(h_t.data(), d_t, sizeof(int32_t) * count, hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(h_p.data(), d_p, sizeof(double) * count, hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  for (unsigned long long i = 0; i < count; ++i) tr.push_back({h_v[i], h_t[i], h_p[i]});
+  return PPRHIP_OK;
+}
+int HostTripleSink::take_host(pprhip_graph*, std::vector<Triple>& more) {
+  tr.insert(tr.end(), more.begin(), more.end());
+  return PPRHIP_OK;
+}
+
+// ... or stay in HBM as 16-byte records until the exchange by owner of the source (sharded call)
+int DeviceTripleSink::reserve(pprhip_graph* g, unsigned long long extra) {
+  if (count + extra <= cap) return PPRHIP_OK;
+  unsigned long long ncap = std::max<unsigned long long>(cap * 2, std::max<unsigned long long>(count + extra, 1ull << 20));
+  TripleRec* nrec = nullptr;
+  PPRHIP_TRY(alloc_dev((void**)&nrec, sizeof(TripleRec) * ncap));
+  if (count)
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(nrec, rec, sizeof(TripleRec) * count, hipMemcpyDeviceToDevice, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  if (rec) (void)hipFree(rec);
+  rec = nrec;
+  cap = ncap;
+  return PPRHIP_OK;
+}
+int DeviceTripleSink::take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
+                                  unsigned long long n_new) {
+  PPRHIP_TRY(reserve(g, n_new));
+  PPRHIP_TRY(launch_pack_triples(g, d_v, d_t, d_p, n_new, rec + count));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));  // the source buffers are reused by the next pass
+  count += n_new;
+  return PPRHIP_OK;
+}
+int DeviceTripleSink::take_host(pprhip_graph* g, std::vector<Triple>& more) {
+  if (more.empty()) return PPRHIP_OK;
+  PPRHIP_TRY(reserve(g, more.size()));
+  static_assert(sizeof(Triple) == sizeof(TripleRec), "host and device entries share one layout");
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(rec + count, more.data(), sizeof(TripleRec) * more.size(), hipMemcpyHostToDevice,
+                                  g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  count += more.size();
+  return PPRHIP_OK;
+}
+DeviceTripleSink::~DeviceTripleSink() {
+  if (rec) (void)hipFree(rec);
+}
+
+// Base_Whole_Graph.java:76-92 for the targets [t_begin, t_end): every backward search's entries >= threshold go to
+// `sink`; the three tiers as described in kernels_apbs.hip.
+int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t t_begin, uint32_t t_end,
+                     TripleSink& sink, pprhip_stats_t& st) {
   g->topk_active = false;
   CallTimer tm(g);
-  std::vector<Triple> tr;
   const uint32_t n_targets = t_end - t_begin;
   // PPRHIP_APBS_TIER = 2 / 3 starts at a later tier (tests exercise every tier that way)
   const int first_tier = getenv("PPRHIP_APBS_TIER") ? atoi(getenv("PPRHIP_APBS_TIER")) : 1;
@@ -139,8 +186,7 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   B.overflow_count = cells + 3;
   B.stat_pops = cells + 4;
   B.stat_edges = cells + 5;
-  std::vector<int32_t> h_v, h_t, h_ovf;
-  std::vector<double> h_p;
+  std::vector<int32_t> h_ovf;
   unsigned long long h_cells[8];
 
   // runs one tier over `list` (or the range when list is empty and use_range) until every target
@@ -174,14 +220,7 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
       const uint64_t bytes = 44ull * h_cells[4] + 28ull * h_cells[5] + 16ull * valid;
       st.push_bytes += bytes;
       if (!ktimer().recs.empty()) ktimer().recs.back().bytes = bytes;
-      if (valid) {
-        h_v.resize(valid); h_t.resize(valid); h_p.resize(valid);
-        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_v.data(), B.out_v, sizeof(int32_t) * valid, hipMemcpyDeviceToHost, g->stream));
-        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_t.data(), B.out_t, sizeof(int32_t) * valid, hipMemcpyDeviceToHost, g->stream));
-        PPRHIP_CHECK_HIP(hipMemcpyAsync(h_p.data(), B.out_p, sizeof(double) * valid, hipMemcpyDeviceToHost, g->stream));
-        PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-        for (unsigned long long i = 0; i < valid; ++i) tr.push_back({h_v[i], h_t[i], h_p[i]});
-      }
+      if (valid) PPRHIP_TRY(sink.take_device(g, B.out_v, B.out_t, B.out_p, valid));
       std::vector<int32_t> again;
       const unsigned long long novf = h_cells[3];
       if (novf) {
@@ -223,6 +262,7 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   pprhip_stats_t st3;
   std::memset(&st3, 0, sizeof st3);
   if (!to_tier3.empty()) {  // Base_Whole_Graph.java:76-92
+    std::vector<Triple> tr3;
     BatchJob J;
     J.P = g;
     J.kind = 2;
@@ -240,8 +280,9 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
     J.per_query = nullptr;
     J.alpha = alpha;
     J.threshold = threshold;
-    J.triples = &tr;
+    J.triples = &tr3;
     PPRHIP_TRY(batch_run(g, J, &st3));
+    PPRHIP_TRY(sink.take_host(g, tr3));
     st.pops += st3.pops;
     st.edge_pushes += st3.edge_pushes;
     st.enqueues += st3.enqueues;
@@ -260,10 +301,58 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   st.rmax_final = threshold;
   st.rounds = (uint32_t)(to_tier2.size());      // targets that needed the HBM tier
   st.dense_nodes = (uint64_t)to_tier3.size();   // targets that needed the whole-vector path
+  return PPRHIP_OK;
+}
+
+// index over all n sources from entries of any targets, rows outside [v_lo, v_hi) must not occur
+int index_from_triples(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index_t** out) {
   std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
   if (!ix) return PPRHIP_ERR_OOM;
-  finalize_rows(g->n, tr, k, ix.get());
-  *index_out = ix.release();
+  finalize_rows(n, tr, k, ix.get());
+  *out = ix.release();
+  return PPRHIP_OK;
+}
+
+// rows of several indexes over disjoint source ranges, put together (no k rule to re-apply)
+int index_concat(const std::vector<pprhip_index_t*>& parts, pprhip_index_t** out) {
+  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
+  if (!ix) return PPRHIP_ERR_OOM;
+  const uint32_t n = parts[0]->n;
+  ix->n = n;
+  ix->offsets.assign((size_t)n + 1, 0);
+  for (const pprhip_index_t* p : parts)
+    for (uint32_t v = 0; v < n; ++v) ix->offsets[v + 1] += p->offsets[v + 1] - p->offsets[v];
+  for (uint32_t v = 0; v < n; ++v) ix->offsets[v + 1] += ix->offsets[v];
+  ix->targets.resize(ix->offsets[n]);
+  ix->values.resize(ix->offsets[n]);
+  std::vector<uint64_t> at(ix->offsets.begin(), ix->offsets.end() - 1);
+  for (const pprhip_index_t* p : parts)
+    for (uint32_t v = 0; v < n; ++v)
+      for (uint64_t i = p->offsets[v]; i < p->offsets[v + 1]; ++i) {
+        ix->targets[at[v]] = p->targets[i];
+        ix->values[at[v]++] = p->values[i];
+      }
+  *out = ix.release();
+  return PPRHIP_OK;
+}
+
+}  // namespace detail
+}  // namespace pprhip
+
+extern "C" {
+
+int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, int k, uint32_t t_begin, uint32_t t_end,
+                             pprhip_index_t** index_out, pprhip_stats_t* stats) {
+  PPRHIP_TRY(check_graph(g, "pprhip_all_pair_backward"));
+  if (!index_out || t_begin > t_end || t_end > g->n) {
+    set_error("pprhip_all_pair_backward: bad target range [%u, %u) for n=%u", t_begin, t_end, g->n);
+    return PPRHIP_ERR_INVALID;
+  }
+  pprhip_stats_t st;
+  std::memset(&st, 0, sizeof st);
+  HostTripleSink sink;
+  PPRHIP_TRY(all_pair_collect(g, alpha, threshold, t_begin, t_end, sink, st));
+  PPRHIP_TRY(index_from_triples(g->n, sink.tr, k, index_out));
   if (stats) *stats = st;
   return PPRHIP_OK;
 }

@@ -277,6 +277,14 @@ struct ApbsBuffers {
   char* g_tables = nullptr;  // tier 2: per-workgroup hash tables in HBM
   uint32_t g_cap = 0, g_blocks = 0;
 };
+struct TripleRec {  // one index entry of All-Pair-Backward-Search on the device: pi(v, t) = p
+  int32_t v, t;
+  double p;
+};
+int launch_pack_triples(pprhip_graph* g, const int32_t* v, const int32_t* t, const double* p, unsigned long long count,
+                        TripleRec* dst);
+int launch_owner_partition(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int world,
+                           unsigned long long* cursors, TripleRec* out);
 int launch_apbs(pprhip_graph* g, bool global_tier, const int32_t* d_targets, uint32_t t_begin, uint32_t n_targets,
                 double alpha, double rmax, ApbsBuffers& b);
 

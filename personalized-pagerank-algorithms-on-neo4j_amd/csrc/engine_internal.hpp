@@ -176,5 +176,35 @@ struct BatchJob {
 
 int batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* stats_sum);
 
+// where the entries of All-Pair's backward searches go: to the host at once, or into an HBM record store that the
+// sharded call partitions by owner of the source and exchanges over RCCL before anything crosses PCIe
+struct TripleSink {
+  virtual ~TripleSink() = default;
+  virtual int take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
+                          unsigned long long count) = 0;
+  virtual int take_host(pprhip_graph* g, std::vector<Triple>& more) = 0;
+};
+struct HostTripleSink : TripleSink {
+  std::vector<Triple> tr;
+  std::vector<int32_t> h_v, h_t;
+  std::vector<double> h_p;
+  int take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
+                  unsigned long long count) override;
+  int take_host(pprhip_graph* g, std::vector<Triple>& more) override;
+};
+struct DeviceTripleSink : TripleSink {
+  TripleRec* rec = nullptr;
+  unsigned long long count = 0, cap = 0;
+  ~DeviceTripleSink() override;
+  int reserve(pprhip_graph* g, unsigned long long extra);
+  int take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
+                  unsigned long long count) override;
+  int take_host(pprhip_graph* g, std::vector<Triple>& more) override;
+};
+int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t t_begin, uint32_t t_end,
+                     TripleSink& sink, pprhip_stats_t& st);
+int index_from_triples(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index_t** out);
+int index_concat(const std::vector<pprhip_index_t*>& parts, pprhip_index_t** out);
+
 }  // namespace detail
 }  // namespace pprhip

@@ -320,6 +320,91 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// sharded All-Pair: index entries as 16-byte records, partitioned by the owner of their source
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_triples(const int32_t* __restrict__ v, const int32_t* __restrict__ t,
+                                                       const double* __restrict__ p, unsigned long long count,
+                                                       TripleRec* __restrict__ dst) {
+  for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256ull) {
+    TripleRec r;
+    r.v = v[i];
+    r.t = t[i];
+    r.p = p[i];
+    dst[i] = r;
+  }
+}
+
+// rank that owns source v when [0, n) is cut into `world` contiguous ranges (the first n % world one longer)
+__device__ __forceinline__ uint32_t owner_of(uint32_t v, uint32_t base, uint32_t rem) {
+  const uint32_t cut = rem * (base + 1u);
+  return v < cut ? v / (base + 1u) : rem + (v - cut) / base;
+}
+
+constexpr int kMaxWorld = 64;
+constexpr int kPartTile = 2048;  // records per workgroup pass
+
+// pass 0 (out == nullptr): counts per owner; pass 1: records land in their owner's segment.  One global atomic
+// per owner and tile (LDS counts first), so 10^7-10^8 records do not pile onto `world` addresses.
+__global__ __launch_bounds__(256) void k_owner_partition(const TripleRec* __restrict__ rec, unsigned long long count,
+                                                          uint32_t base, uint32_t rem, int world,
+                                                          unsigned long long* __restrict__ cursors,
+                                                          TripleRec* __restrict__ out) {
+  __shared__ uint32_t s_cnt[kMaxWorld];
+  __shared__ unsigned long long s_base[kMaxWorld];
+  const unsigned long long n_tiles = (count + kPartTile - 1) / kPartTile;
+  for (unsigned long long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t own[kPartTile / 256], pos[kPartTile / 256];
+#pragma unroll
+    for (int j = 0; j < kPartTile / 256; ++j) {
+      const unsigned long long i = tl * kPartTile + (unsigned long long)j * 256 + threadIdx.x;
+      own[j] = 0xFFFFFFFFu;
+      if (i < count) {
+        own[j] = owner_of((uint32_t)rec[i].v, base, rem);
+        pos[j] = atomicAdd(&s_cnt[own[j]], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)world && s_cnt[threadIdx.x])
+      s_base[threadIdx.x] = atomic_add_u64(&cursors[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (out) {
+#pragma unroll
+      for (int j = 0; j < kPartTile / 256; ++j) {
+        const unsigned long long i = tl * kPartTile + (unsigned long long)j * 256 + threadIdx.x;
+        if (own[j] != 0xFFFFFFFFu) out[s_base[own[j]] + pos[j]] = rec[i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int launch_pack_triples(pprhip_graph* g, const int32_t* v, const int32_t* t, const double* p, unsigned long long count,
+                        TripleRec* dst) {
+  if (!count) return PPRHIP_OK;
+  const uint32_t grid = (uint32_t)std::min<unsigned long long>((count + 255) / 256, 4096ull);
+  k_pack_triples<<<dim3(grid), dim3(256), 0, g->stream>>>(v, t, p, count, dst);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+// cursors: `world` counters, zero before pass 0 (counts), holding the segment starts before pass 1
+int launch_owner_partition(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int world,
+                           unsigned long long* cursors, TripleRec* out) {
+  if (!count) return PPRHIP_OK;
+  if (world > kMaxWorld) {
+    set_error("owner partition: at most %d ranks", kMaxWorld);
+    return PPRHIP_ERR_INVALID;
+  }
+  const uint32_t grid = (uint32_t)std::min<unsigned long long>((count + kPartTile - 1) / kPartTile, 2048ull);
+  k_owner_partition<<<dim3(grid), dim3(256), 0, g->stream>>>(rec, count, g->n / (uint32_t)world, g->n % (uint32_t)world,
+                                                             world, cursors, out);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
 int init_kernels_apbs() {  // loads this file's code object on the current device (see init_kernels_push)
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs<false>)));

@@ -1,0 +1,252 @@
+// pprhip_jni.cpp — JNI side of joezie.fora_neo4j.PprHip: every native method is one call of the C ABI
+// (include/pprhip.h).  Build where a JDK exists (this image has none, so this file is compile-gated):
+//   make -C personalized-pagerank-algorithms-on-neo4j_amd jni JAVA_HOME=/path/to/jdk
+#include <jni.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../../include/pprhip.h"
+
+namespace {
+
+jfieldID fid(JNIEnv* e, jobject self, const char* name) { return e->GetFieldID(e->GetObjectClass(self), name, "J"); }
+pprhip_graph_t* G(JNIEnv* e, jobject self) { return (pprhip_graph_t*)e->GetLongField(self, fid(e, self, "handle")); }
+pprhip_results_t* R(JNIEnv* e, jobject self) { return (pprhip_results_t*)e->GetLongField(self, fid(e, self, "store")); }
+
+// error code -> RuntimeException carrying the engine's message; returns true when an exception is pending
+bool fail(JNIEnv* e, int rc) {
+  if (rc == PPRHIP_OK) return false;
+  e->ThrowNew(e->FindClass("java/lang/RuntimeException"), pprhip_last_error());
+  return true;
+}
+
+struct Dims {
+  uint32_t n = 0;
+  uint64_t m = 0;
+};
+Dims dims(pprhip_graph_t* g) {
+  Dims d;
+  pprhip_graph_info(g, &d.n, &d.m, nullptr);
+  return d;
+}
+
+jdoubleArray dense(JNIEnv* e, pprhip_graph_t* g, int (*get)(pprhip_graph_t*, double*)) {
+  const Dims d = dims(g);
+  std::vector<double> v(d.n);
+  if (fail(e, get(g, v.data()))) return nullptr;
+  jdoubleArray out = e->NewDoubleArray((jsize)d.n);
+  e->SetDoubleArrayRegion(out, 0, (jsize)d.n, v.data());
+  return out;
+}
+
+void batch(JNIEnv* e, jobject self, jintArray srcs, jdouble eps, jdouble alpha, jlong seed, jint k, jintArray idsOut,
+           jdoubleArray valsOut, bool resident) {
+  pprhip_graph_t* g = G(e, self);
+  const Dims d = dims(g);
+  pprhip_fora_conf_t conf;
+  if (fail(e, pprhip_conf_fora_whole_graph(d.n, d.m, alpha, &conf))) return;  // Algo_Conf.java:45-53
+  const jsize q = e->GetArrayLength(srcs);
+  std::vector<jint> s(q);
+  e->GetIntArrayRegion(srcs, 0, q, s.data());
+  std::vector<int32_t> ids((size_t)q * k);
+  std::vector<double> vals((size_t)q * k);
+  pprhip_results_t* keep = nullptr;
+  if (resident) {
+    keep = R(e, self);
+    int cap = 0;
+    if (keep) pprhip_results_info(keep, &cap, nullptr, nullptr);
+    if (!keep || cap < q) {  // (re)size the store to this batch
+      if (keep) pprhip_results_destroy(keep);
+      keep = nullptr;
+      e->SetLongField(self, fid(e, self, "store"), 0);
+      if (fail(e, pprhip_results_create(g, q, &keep))) return;
+      e->SetLongField(self, fid(e, self, "store"), (jlong)keep);
+    }
+  }
+  if (fail(e, pprhip_fora_batch_single_source_resident(g, (const int32_t*)s.data(), q, eps, &conf, (uint64_t)seed, 0, keep,
+                                                       nullptr, k, ids.data(), vals.data(), nullptr, nullptr, nullptr)))
+    return;
+  e->SetIntArrayRegion(idsOut, 0, (jsize)ids.size(), (const jint*)ids.data());
+  e->SetDoubleArrayRegion(valsOut, 0, (jsize)vals.size(), vals.data());
+}
+
+}  // namespace
+
+extern "C" {
+
+JNIEXPORT jlong JNICALL Java_joezie_fora_1neo4j_PprHip_create(JNIEnv* e, jclass, jint n, jintArray outRp, jintArray outCi,
+                                                              jintArray inRp, jintArray inCi, jint device) {
+  jint *orp = e->GetIntArrayElements(outRp, nullptr), *oci = e->GetIntArrayElements(outCi, nullptr);
+  jint *irp = e->GetIntArrayElements(inRp, nullptr), *ici = e->GetIntArrayElements(inCi, nullptr);
+  pprhip_graph_t* g = nullptr;
+  const int rc = pprhip_graph_create((uint32_t)n, (uint64_t)orp[n], (const uint32_t*)orp, oci, (const uint32_t*)irp, ici,
+                                     device, &g);
+  e->ReleaseIntArrayElements(outRp, orp, JNI_ABORT);
+  e->ReleaseIntArrayElements(outCi, oci, JNI_ABORT);
+  e->ReleaseIntArrayElements(inRp, irp, JNI_ABORT);
+  e->ReleaseIntArrayElements(inCi, ici, JNI_ABORT);
+  fail(e, rc);
+  return (jlong)g;
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_foraSingleSource(JNIEnv* e, jobject self, jint src, jdouble eps,
+                                                                       jdouble alpha, jlong seed, jint rounds) {
+  pprhip_graph_t* g = G(e, self);
+  const Dims d = dims(g);
+  pprhip_fora_conf_t conf;
+  if (fail(e, pprhip_conf_fora_whole_graph(d.n, d.m, alpha, &conf))) return;  // Algo_Conf.java:45-53
+  fail(e, pprhip_fora_single_source(g, src, eps, &conf, (uint64_t)seed, rounds, nullptr, nullptr));
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_foraBatch(JNIEnv* e, jobject self, jintArray srcs, jdouble eps,
+                                                                jdouble alpha, jlong seed, jint k, jintArray idsOut,
+                                                                jdoubleArray valsOut) {
+  batch(e, self, srcs, eps, alpha, seed, k, idsOut, valsOut, false);
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_foraBatchResident(JNIEnv* e, jobject self, jintArray srcs,
+                                                                        jdouble eps, jdouble alpha, jlong seed, jint k,
+                                                                        jintArray idsOut, jdoubleArray valsOut) {
+  batch(e, self, srcs, eps, alpha, seed, k, idsOut, valsOut, true);
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_joezie_fora_1neo4j_PprHip_batchResult(JNIEnv* e, jobject self, jint i) {
+  pprhip_results_t* r = R(e, self);
+  uint32_t n = 0;
+  if (!r || fail(e, pprhip_results_info(r, nullptr, nullptr, &n))) {
+    if (!r) e->ThrowNew(e->FindClass("java/lang/IllegalStateException"), "no foraBatchResident call yet");
+    return nullptr;
+  }
+  std::vector<double> v(n);
+  if (fail(e, pprhip_results_fetch(r, i, v.data()))) return nullptr;
+  jdoubleArray out = e->NewDoubleArray((jsize)n);
+  e->SetDoubleArrayRegion(out, 0, (jsize)n, v.data());
+  return out;
+}
+
+JNIEXPORT jint JNICALL Java_joezie_fora_1neo4j_PprHip_foraTopk(JNIEnv* e, jobject self, jint src, jint k, jdouble eps,
+                                                               jdouble alpha, jlong seed, jintArray idsOut,
+                                                               jdoubleArray valsOut) {
+  pprhip_graph_t* g = G(e, self);
+  const Dims d = dims(g);
+  pprhip_fora_conf_t conf;
+  if (fail(e, pprhip_conf_fora_topk(d.n, d.m, k, alpha, &conf))) return 0;  // Algo_Conf.java:71-81
+  const jsize cap = e->GetArrayLength(idsOut);
+  std::vector<int32_t> ids(cap > 0 ? cap : 1);
+  std::vector<double> vals(cap > 0 ? cap : 1);
+  int n_sel = 0;
+  if (fail(e, pprhip_fora_topk(g, src, eps, &conf, (uint64_t)seed, ids.data(), vals.data(), cap, &n_sel, nullptr, nullptr)))
+    return 0;
+  const jsize w = n_sel < cap ? n_sel : cap;
+  e->SetIntArrayRegion(idsOut, 0, w, (const jint*)ids.data());
+  e->SetDoubleArrayRegion(valsOut, 0, w, vals.data());
+  return n_sel;
+}
+
+JNIEXPORT jdouble JNICALL Java_joezie_fora_1neo4j_PprHip_forwardPush(JNIEnv* e, jobject self, jint src, jdouble alpha,
+                                                                     jdouble rmax) {
+  double rsum = 0.0;
+  fail(e, pprhip_forward_push(G(e, self), src, alpha, rmax, nullptr, nullptr, &rsum, nullptr));
+  return rsum;
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_fwdpushTopkReset(JNIEnv* e, jobject self, jint src, jdouble alpha) {
+  fail(e, pprhip_fwdpush_topk_reset(G(e, self), src, alpha));
+}
+
+JNIEXPORT jdouble JNICALL Java_joezie_fora_1neo4j_PprHip_fwdpushTopkRound(JNIEnv* e, jobject self, jdouble minRmax,
+                                                                          jdouble rmax) {
+  double rsum = 0.0;
+  fail(e, pprhip_fwdpush_topk_round(G(e, self), minRmax, rmax, &rsum, nullptr));
+  return rsum;
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_monteCarlo(JNIEnv* e, jobject self, jint src, jdouble eps,
+                                                                 jdouble alpha, jlong seed) {
+  pprhip_graph_t* g = G(e, self);
+  const Dims d = dims(g);
+  pprhip_fora_conf_t conf;
+  if (fail(e, pprhip_conf_fora_whole_graph(d.n, d.m, alpha, &conf))) return;  // Algo_Conf.java:29-35: same delta, pfail
+  fail(e, pprhip_monte_carlo(g, src, eps, &conf, (uint64_t)seed, nullptr, nullptr));
+}
+
+JNIEXPORT jintArray JNICALL Java_joezie_fora_1neo4j_PprHip_randomWalks(JNIEnv* e, jobject self, jintArray starts,
+                                                                       jlongArray walkIdx, jdouble alpha, jlong seed,
+                                                                       jint stream, jboolean noZeroHop) {
+  const jsize c = e->GetArrayLength(starts);
+  std::vector<jint> s(c);
+  std::vector<jlong> ix(c);
+  e->GetIntArrayRegion(starts, 0, c, s.data());
+  e->GetLongArrayRegion(walkIdx, 0, c, ix.data());
+  std::vector<int32_t> term(c > 0 ? c : 1);
+  if (fail(e, pprhip_random_walk_batch(G(e, self), (const int32_t*)s.data(), (const uint64_t*)ix.data(), (uint64_t)c, alpha,
+                                       (uint64_t)seed, (uint32_t)stream, noZeroHop ? 1 : 0, term.data(), nullptr)))
+    return nullptr;
+  jintArray out = e->NewIntArray(c);
+  e->SetIntArrayRegion(out, 0, c, (const jint*)term.data());
+  return out;
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_backwardPush(JNIEnv* e, jobject self, jint target, jdouble alpha,
+                                                                   jdouble rmax) {
+  fail(e, pprhip_backward_push(G(e, self), target, alpha, rmax, nullptr, nullptr, nullptr));
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_powerMethod(JNIEnv* e, jobject self, jint src, jdouble alpha,
+                                                                  jint iters) {
+  fail(e, pprhip_power_method(G(e, self), src, alpha, iters, nullptr, nullptr));
+}
+
+JNIEXPORT jlong JNICALL Java_joezie_fora_1neo4j_PprHip_allPairBackward(JNIEnv* e, jobject self, jdouble alpha,
+                                                                       jdouble threshold, jint k, jstring dir) {
+  pprhip_graph_t* g = G(e, self);
+  const Dims d = dims(g);
+  pprhip_index_t* ix = nullptr;
+  if (fail(e, pprhip_all_pair_backward(g, alpha, threshold, k, 0, d.n, &ix, nullptr))) return 0;
+  const char* path = e->GetStringUTFChars(dir, nullptr);
+  const int rc = pprhip_index_write_dir(ix, path);  // "<t>\t<Double.toString>\n" files (Base_Whole_Graph.java:118-126)
+  e->ReleaseStringUTFChars(dir, path);
+  uint64_t entries = 0;
+  pprhip_index_info(ix, nullptr, &entries);
+  pprhip_index_destroy(ix);
+  fail(e, rc);
+  return (jlong)entries;
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_joezie_fora_1neo4j_PprHip_reserve(JNIEnv* e, jobject self) {
+  return dense(e, G(e, self), pprhip_get_reserve);
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_joezie_fora_1neo4j_PprHip_residue(JNIEnv* e, jobject self) {
+  return dense(e, G(e, self), pprhip_get_residue);
+}
+
+JNIEXPORT jint JNICALL Java_joezie_fora_1neo4j_PprHip_topk(JNIEnv* e, jobject self, jint k, jintArray idsOut,
+                                                           jdoubleArray valsOut) {
+  const jsize cap = e->GetArrayLength(idsOut);
+  std::vector<int32_t> ids(cap > 0 ? cap : 1);
+  std::vector<double> vals(cap > 0 ? cap : 1);
+  int n_sel = 0;
+  if (fail(e, pprhip_topk_select(G(e, self), k, ids.data(), vals.data(), cap, &n_sel, nullptr, nullptr))) return 0;
+  const jsize w = n_sel < cap ? n_sel : cap;
+  e->SetIntArrayRegion(idsOut, 0, w, (const jint*)ids.data());
+  e->SetDoubleArrayRegion(valsOut, 0, w, vals.data());
+  return n_sel;
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_setBatchTuning(JNIEnv* e, jobject self, jboolean on) {
+  pprhip_tuning_t t;
+  if (on) pprhip_tuning_batch(&t);
+  else pprhip_tuning_default(&t);
+  fail(e, pprhip_graph_set_tuning(G(e, self), &t));
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_close(JNIEnv* e, jobject self) {
+  if (pprhip_results_t* r = R(e, self)) pprhip_results_destroy(r);
+  e->SetLongField(self, fid(e, self, "store"), 0);
+  pprhip_graph_destroy(G(e, self));
+  e->SetLongField(self, fid(e, self, "handle"), 0);
+}
+
+}  // extern "C"

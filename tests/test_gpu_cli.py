@@ -43,22 +43,20 @@ def test_batch_report_on_got(tmp_path):
     base = rep.split("2.4 BASE_WHOLE_GRAPH\n")[1].split("\n\n")[0].strip().splitlines()
     thr, k, prep_ms, size, ms, prec, ndcg = base[-1].split(",")  # "thr,k,prep ms,bytes,avg ms,precision,NDCG" (:139)
     assert thr == "5.0E-7" and int(size) > 0 and float(prec) >= 0.8
-    # Test 3 (Gen_Util.java:602-645): "param,threshold,prep ms,prep bytes,avg max err" (:203,247), five rows per algorithm;
-    # the preprocessed answers are the same algorithms' answers, so their errors follow Test 1's
-    t1 = {}
-    for name in ("FORA_WHOLE_GRAPH", "FWDPUSH", "MC"):
-        rows1 = rep.split("1.%d %s\n" % (["FORA_WHOLE_GRAPH", "FWDPUSH", "MC"].index(name) + 1, name))[1].split("\n\n")[0]
-        t1[name] = [float(l.split(",")[2]) for l in rows1.strip().splitlines()]
+    # Test 3 (Gen_Util.java:602-645): "param,threshold,prep ms,prep bytes,avg max err" (:203,247), five rows per
+    # algorithm.  The preprocessed answers are the same algorithms' answers read back from Double.toString files (which
+    # round-trip), on freshly drawn query nodes: errors of the same size as Test 1's, falling with the parameter.
     for i, name in enumerate(("FORA_WHOLE_GRAPH", "FWDPUSH", "MC"), 1):
         rows = rep.split("3.%d %s\n" % (i, name))[1].split("\n\n")[0].strip().splitlines()
         assert len(rows) == 5
-        for j, l in enumerate(rows):
+        errs3 = []
+        for l in rows:
             param, thr, prep_ms, size, err = l.split(",")
             assert thr == "-1.0" and int(size) > 0 and int(prep_ms) >= 0
-            # files hold Double.toString values, which round-trip: the error is that of a fresh run of the algorithm
-            assert float(err) <= max(2.5 * t1[name][j], 1e-7) or name != "FWDPUSH"
-        if name == "FWDPUSH":  # deterministic: the preprocessed error equals the computed one
-            assert [float(l.split(",")[4]) for l in rows] == pytest.approx(t1[name], rel=1e-9, abs=1e-15)
+            errs3.append(float(err))
+        assert errs3[-1] < errs3[0] and errs3[0] < 0.5
+        if name == "FWDPUSH":
+            assert errs3[-1] < 1e-6  # rmax = 1e-8: exact to 1e-6 from the files as well
     b3 = rep.split("3.4 BASE_WHOLE_GRAPH\n")[1].strip().splitlines()
     assert len(b3) == 5 and b3[0].split(",")[0] == "-1" and b3[0].split(",")[1] == "0.001"
     # no result directory is left behind (deletePrepDir, :250-252)

@@ -1,0 +1,99 @@
+"""GPU tests of the multi-GPU entry points behind the C ABI.
+
+A gpurun box has one GPU, so the cases with several ranks put their graph replicas on that one device: the calls
+then run one host thread per replica, shard queries / targets exactly as on n GPUs, partition the index entries by
+owner of the source on the device and exchange them through the in-process transport (RCCL refuses two ranks on one
+device).  The RCCL transport itself is exercised with a group of one rank (communicator, self send/recv of the
+grouped exchange).  Results must be identical to the single-GPU entry points."""
+import numpy as np
+import pytest
+
+from conftest import to_oracle
+
+pytestmark = pytest.mark.gpu
+A = 0.15
+
+
+@pytest.fixture(scope="module")
+def replicas(pkg, rmat12):
+    gs = [pkg.Graph(rmat12) for _ in range(3)]
+    for g in gs:
+        g.set_tuning(pkg.tuning_batch())
+    yield gs
+    for g in gs:
+        g.close()
+
+
+def test_shard_ranges(pkg):
+    for n, w in ((107, 4), (4096, 3), (10, 10), (1 << 22, 8)):
+        r = [pkg.shard_target_range(i, w, n) for i in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+
+
+@pytest.mark.parametrize("n_gpu", [1, 2, 3])
+def test_fora_batch_over_replicas_equals_single_gpu(pkg, rmat12, replicas, n_gpu):
+    rng = np.random.default_rng(5)
+    srcs = rng.integers(0, rmat12.n, size=23).astype(np.int32)
+    ids, vals, nsel, sts = pkg.fora_batch_multi(replicas[:n_gpu], srcs, 8, 0.5, A, seed=3)
+    _, ids1, vals1, nsel1, _, _ = replicas[0].fora_batch_single_source(srcs, 0.5, A, seed=3, k=8)
+    assert np.array_equal(ids, ids1) and np.array_equal(nsel, nsel1)
+    assert np.max(np.abs(vals - vals1)) <= 1e-9            # same walks, sums in another order
+    assert sum(st.walks for st in sts) > 0 and len(sts) == n_gpu
+    if n_gpu > 1:
+        assert all(st.levels > 0 for st in sts)            # every replica took part
+
+
+@pytest.mark.parametrize("n_gpu,k", [(1, -1), (2, -1), (3, 4), (2, 0)])
+def test_all_pair_over_replicas_equals_single_gpu(pkg, orc, rmat12, replicas, n_gpu, k):
+    thr = 2e-3
+    ix, sts = pkg.all_pair_backward_multi(replicas[:n_gpu], A, thr, k)
+    off, tg, vl = ix.arrays()
+    ix1, _ = replicas[0].all_pair_backward(A, thr, k)
+    off1, tg1, vl1 = ix1.arrays()
+    assert np.array_equal(off, off1) and np.array_equal(tg, tg1) and np.max(np.abs(vl - vl1)) <= 1e-12
+    # every entry was found by exactly one rank, and every rank's received bytes are whole 16-byte records
+    assert sum(st.mc_sources for st in sts) >= len(tg) and all(st.select_bytes % 16 == 0 for st in sts)
+    # and against the CPU oracle
+    ooff, otg, ovl = to_oracle(orc, rmat12).all_pair_backward(A, thr, k, schedule=orc.SYNC)
+    assert np.array_equal(off, ooff) and np.array_equal(tg, otg) and np.max(np.abs(vl - ovl)) <= 1e-12
+
+
+def test_all_pair_tier3_entries_join_the_exchange(pkg, rmat12, replicas, monkeypatch):
+    monkeypatch.setenv("PPRHIP_APBS_TIER", "3")  # whole-vector searches: their entries reach the store from the host
+    ix, _ = pkg.all_pair_backward_multi(replicas[:2], A, 5e-3, 4)
+    monkeypatch.delenv("PPRHIP_APBS_TIER")
+    ix1, _ = replicas[0].all_pair_backward(A, 5e-3, 4)
+    a, b = ix.arrays(), ix1.arrays()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.max(np.abs(a[2] - b[2])) <= 1e-12
+
+
+def test_rccl_group_of_one(pkg, rmat12, replicas):
+    """The RCCL transport: unique id, communicator, grouped send/recv to self, through the sharded entry points."""
+    uid = pkg.comm_unique_id()
+    assert len(uid) == pkg.COMM_ID_BYTES
+    c = pkg.Comm(replicas[0], uid, 0, 1)
+    try:
+        own, st = c.all_pair_backward_sharded(A, 2e-3, 4)
+        ix1, _ = replicas[0].all_pair_backward(A, 2e-3, 4)
+        a, b = own.arrays(), ix1.arrays()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.max(np.abs(a[2] - b[2])) <= 1e-12
+        assert st.select_bytes == 16 * st.mc_sources       # everything it found came back through the exchange
+        ids = np.arange(12, dtype=np.int32).reshape(3, 4)
+        vals = np.linspace(1.0, 0.1, 12).reshape(3, 4)
+        ri, rv = c.topk_gather(ids, vals, rows_max=5)
+        assert ri.shape == (1, 5, 4) and np.array_equal(ri[0, :3], ids) and np.all(ri[0, 3:] == -1)
+        assert np.array_equal(rv[0, :3], vals) and np.all(rv[0, 3:] == 0.0)
+    finally:
+        c.close()
+
+
+def test_multi_argument_errors(pkg, rmat12, replicas, got):
+    with pytest.raises(pkg.PprhipError):          # the same handle twice
+        pkg.fora_batch_multi([replicas[0], replicas[0]], [1, 2], 4, 0.5, A, seed=1)
+    other = pkg.Graph(got)
+    try:
+        with pytest.raises(pkg.PprhipError):      # replicas of different graphs
+            pkg.all_pair_backward_multi([replicas[0], other], A, 1e-3, 4)
+    finally:
+        other.close()
