@@ -265,6 +265,11 @@ static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double 
                             sync_ws* w, uint8_t* parked, double min_rmax, const orc_tuning* tun, orc_stats* st,
                             round_cut* cut) {
   uint32_t d_s = deg_out(g, s);
+  /* Only a top-k round whose threshold lies below min_rmax can hold a node that meets the threshold without being
+   * queued; everywhere else the membership rule and the crossing rule pick the same nodes, and the crossing rule also
+   * ends on the degenerate configurations (n div k = 1 makes pfail infinite and every threshold 0, where the
+   * reference's own loop would never end). */
+  const int general = parked != NULL && rmax < min_rmax;
   while (w->ncur) {
     uint64_t ef = 0;
     double dead = 0.0;
@@ -299,11 +304,11 @@ static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double 
          * "crosses the threshold".  Top-k rounds test the new residue and queue membership only
          * (Forward_Push.java:226-231): a node that already met the round's threshold without being queued
          * (possible when the scaled rmax of Fora_Topk.java:133 is below min_rmax) joins with its first mass. */
-        int join = parked ? (active_fwd(nr, du, rmax) && !w->inq[u])
-                          : (!active_fwd(old, du, rmax) && active_fwd(nr, du, rmax));
+        int join = general ? (active_fwd(nr, du, rmax) && !w->inq[u])
+                           : (!active_fwd(old, du, rmax) && active_fwd(nr, du, rmax));
         if (join) {
           w->nxt[w->nnxt++] = u;
-          if (parked) w->inq[u] = 1;
+          if (general) w->inq[u] = 1;
         }
         if (parked && active_fwd(nr, du, min_rmax)) parked[u] = 1;
       }
@@ -312,15 +317,15 @@ static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double 
       double old = residue[s];
       double nr = old + dead;
       residue[s] = nr;
-      int join = parked ? (active_fwd(nr, d_s, rmax) && !w->inq[s])
-                        : (!active_fwd(old, d_s, rmax) && active_fwd(nr, d_s, rmax));
+      int join = general ? (active_fwd(nr, d_s, rmax) && !w->inq[s])
+                         : (!active_fwd(old, d_s, rmax) && active_fwd(nr, d_s, rmax));
       if (join) {
         w->nxt[w->nnxt++] = s;
-        if (parked) w->inq[s] = 1;
+        if (general) w->inq[s] = 1;
       }
       if (parked && active_fwd(nr, d_s, min_rmax)) parked[s] = 1;
     }
-    if (parked) /* the next level pops these: they leave the queue */
+    if (general) /* the next level pops these: they leave the queue */
       for (uint32_t i = 0; i < w->nnxt; ++i) w->inq[w->nxt[i]] = 0;
     if (st) {
       int dense = 0;
