@@ -19,7 +19,8 @@ check prints no line.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): the CSR is replicated, every rank runs its own
 batch per step (weak scaling, no data-path collective) and the per-step top-k blocks are gathered to rank 0 over
-RCCL; `all_pair_scaling` reports the path's other workload at the same N.
+RCCL; `all_pair_scaling` reports the path's other workload, All-Pair-Backward-Search over all n targets, at the same
+N (strong scaling; the exchange by owner of the source runs inside the library over RCCL).
 
 Extra objects on the JSON line: `roofline` (dominant kernel class: HIP-event time on the engine's stream,
 algorithmic bytes from DESIGN.md's byte model, HBM traffic from two `rocprofv3 --pmc` passes of this same build
@@ -219,7 +220,7 @@ def main():
         check = self_check(pkg, store, srcs[last["step"]], last["ids"], last["vals"], last["nsel"], last["pq"], host.n)
 
     all_pair_scaling = None
-    if world > 1 and not args.no_extras:
+    if not args.no_extras and not args.pmc_child and args.mode == "batch":
         all_pair_scaling = all_pair_scaling_sample(pkg, g, host, dist, torch, rank, world, xdev)
 
     if rank == 0:
@@ -423,33 +424,41 @@ def all_pair_sample(pkg, g, host):
 
 
 def all_pair_scaling_sample(pkg, g, host, dist, torch, rank, world, xdev):
-    """N > 1: All-Pair-Backward-Search, weak scaling (every rank runs 2^16 targets of its own contiguous range),
-    then the path's one exchange: owner-of-source all-to-all over RCCL + merge with the reference's k rule."""
-    sh = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd.sharding")
+    """All-Pair-Backward-Search over ALL n targets of the graph (config #5's shape; threshold 1e-3, k = 32) on `world`
+    GPUs: strong scaling of the whole job.  Rank r searches the targets of its contiguous range, the entries are
+    partitioned by owner of their source on the device and exchanged over RCCL inside the library
+    (pprhip_all_pair_backward_sharded: one message per peer, one PCIe crossing per entry, at its owner), and every
+    rank finalises the rows of its own sources.  Time = max over ranks, barrier to barrier."""
     g.set_tuning(pkg.tuning_default())
-    per = 1 << 16
-    lo, hi = sh.target_range(rank, world, host.n)
-    hi = min(hi, lo + per)
-    ix, _ = g.all_pair_backward(ALPHA, 1e-3, TOPK, lo, min(hi, lo + 1024))
+    uid = [pkg.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    comm = pkg.Comm(g, uid[0], rank, world)  # collective (ncclCommInitRank)
+    lo, hi = pkg.shard_target_range(rank, world, host.n)
+    ix, _ = g.all_pair_backward(ALPHA, 1e-3, TOPK, lo, min(hi, lo + 1024))  # warm-up of the kernels
     ix.close()
-    dist.barrier()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ix, st = g.all_pair_backward(ALPHA, 1e-3, TOPK, lo, hi)
-    t_search = time.perf_counter() - t0
-    off, tg, vl = ix.arrays()
-    parts = sh.exchange_index_by_source(dist, torch, off, tg, vl, rank, world, host.n, device=xdev)
-    own = pkg.merge_indexes([pkg.index_from_arrays(host.n, o, t, v) for o, t, v in parts], TOPK)
+    own, st = comm.all_pair_backward_sharded(ALPHA, 1e-3, TOPK)
     t_all = time.perf_counter() - t0
-    times = torch.tensor([t_search, t_all], dtype=torch.float64, device=xdev)
-    dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    n_t = (hi - lo) * world
-    res = {"unit": "targets/s", "scaling": "weak", "targets": int(n_t), "threshold": 1e-3, "k": TOPK,
-           "targets_per_s_search": round(n_t / float(times[0]), 1),
-           "targets_per_s_with_exchange_and_merge": round(n_t / float(times[1]), 1),
-           "entries_rank0_shard": int(len(tg)), "entries_rank0_owned": int(len(own.arrays()[1]))}
-    ix.close()
+    n_own = int(len(own.arrays()[1]))
+    stats = torch.tensor([t_all, st.total_ms / 1e3, float(st.mc_sources), float(st.select_bytes), float(n_own)],
+                         dtype=torch.float64, device=xdev)
+    tmax = stats.clone()
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    res = {"unit": "targets/s", "scaling": "strong", "targets": int(host.n), "threshold": 1e-3, "k": TOPK,
+           "value": round(host.n / float(tmax[0]), 1), "seconds": round(float(tmax[0]), 3),
+           "search_seconds_max_rank": round(float(tmax[1]), 3),
+           "entries_found": int(stats[2]), "entries_kept_after_k_rule": int(stats[4]),
+           "exchange_bytes_received": int(stats[3]),
+           "exchange": "owner-of-source, 16-byte records partitioned on the device, grouped ncclSend/ncclRecv inside "
+                       "libpprhip.so (pprhip_all_pair_backward_sharded)"}
     own.close()
+    comm.close()
     g.set_tuning(pkg.tuning_batch())
     return res
 

@@ -1,7 +1,9 @@
 """world_size-2 `gloo` tests of the N > 1 paths (runs on CPU): query sharding + top-k gather
-(config #4) and target-range sharding + index gather/merge (config #5).  The per-rank compute is
-played by the CPU oracle here — on a GPU node the same sharding code carries the engine's results
-over RCCL; what is under test is the sharding, the exchange and the product's merge."""
+(config #4) and target-range sharding + index gather/merge (config #5).  No GPU exists here, so each
+rank's compute is a recorded result of the HIP engine on an MI355X (tests/golden/got_engine_shards.npz,
+written by tests/golden/make_engine_fixture.py: FORA top-5 rows and the All-Pair shard index of every
+rank); what is under test is the sharding, the exchange and the product's merge, and the outcome is
+compared with the unsharded CPU oracle."""
 import os
 import socket
 import sys
@@ -36,22 +38,18 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     try:
         got = pkg.HostCsr.from_neo4j_csv(GOT_NODES, GOT_RELS)
-        og = orc.OracleGraph(got.n, got.out_rp, got.out_ci, got.in_rp, got.in_ci)
+        rec = np.load(os.path.join(ROOT, "tests", "golden", "got_engine_shards.npz"))  # the engine's results
+        assert int(rec["world"]) == world and int(rec["k"]) == K
         # ---- batched FORA top-k: query i on rank i mod world, gather top-k blocks to rank 0
         sources = np.random.default_rng(2).integers(0, got.n, size=7)
+        assert np.array_equal(sources, rec["sources"])
         idx, mine = sh.shard_sources(sources, rank, world)
-        ids, vals = [], []
-        for i, s in zip(idx, mine):
-            est, _ = og.fora_topk(int(s), 0.5, A, K, seed=100 + int(i), schedule=orc.SYNC)
-            cnt, ti, tv = orc.topk(est, K, cap=K)
-            row_i, row_v = np.full(K, -1, dtype=np.int32), np.zeros(K)
-            row_i[:len(ti)], row_v[:len(tv)] = ti, tv
-            ids.append(row_i)
-            vals.append(row_v)
+        ids = [rec["topk_ids"][int(i)] for i in idx]
+        vals = [rec["topk_vals"][int(i)] for i in idx]
         res = sh.gather_topk(dist, torch, ids, vals, len(sources), K, rank, world)
         # ---- All-Pair-Backward-Search: contiguous target ranges, gather shard arrays, merge on rank 0
         lo, hi = sh.target_range(rank, world, got.n)
-        off, tg, vl = og.all_pair_backward(A, 1e-3, -1, lo, hi)
+        off, tg, vl = rec["off%d" % rank], rec["tg%d" % rank], rec["vl%d" % rank]
         # the exchange that scales: every rank ends with the merged lists of the sources it owns
         mine_parts = sh.exchange_index_by_source(dist, torch, off, tg, vl, rank, world, got.n)
         own = pkg.merge_indexes([pkg.index_from_arrays(got.n, o, t, v) for o, t, v in mine_parts], 3)
@@ -81,10 +79,10 @@ def test_two_rank_gloo(tmp_path, orc, got):
     for i, s in enumerate(d["sources"]):
         est, _ = og.fora_topk(int(s), 0.5, A, K, seed=100 + i, schedule=orc.SYNC)
         cnt, ti, tv = orc.topk(est, K, cap=K)
-        assert list(d["ids"][i][:len(ti)]) == list(ti) and np.array_equal(d["vals"][i][:len(tv)], tv)
+        assert list(d["ids"][i][:len(ti)]) == list(ti) and np.max(np.abs(d["vals"][i][:len(tv)] - tv), initial=0) <= 1e-9
         assert np.all(d["ids"][i][len(ti):] == -1)
     off, tg, vl = og.all_pair_backward(A, 1e-3, 3)
-    assert np.array_equal(d["off"], off) and np.array_equal(d["tg"], tg) and np.array_equal(d["vl"], vl)
+    assert np.array_equal(d["off"], off) and np.array_equal(d["tg"], tg) and np.max(np.abs(d["vl"] - vl)) <= 1e-12
     # the all-to-all form: rank r holds exactly the rows of its own sources, equal to the unsharded result
     for r in range(2):
         o = np.load(tmp_path / ("own%d.npz" % r))
@@ -93,7 +91,7 @@ def test_two_rank_gloo(tmp_path, orc, got):
         for v in range(lo, hi):
             a, b = int(o["off"][v]), int(o["off"][v + 1])
             c, e = int(off[v]), int(off[v + 1])
-            assert np.array_equal(o["tg"][a:b], tg[c:e]) and np.array_equal(o["vl"][a:b], vl[c:e])
+            assert np.array_equal(o["tg"][a:b], tg[c:e]) and np.max(np.abs(o["vl"][a:b] - vl[c:e]), initial=0) <= 1e-12
 
 
 def test_shard_helpers(pkg):
