@@ -430,10 +430,26 @@ def all_pair_scaling_sample(pkg, g, host, dist, torch, rank, world, xdev):
     (pprhip_all_pair_backward_sharded: one message per peer, one PCIe crossing per entry, at its owner), and every
     rank finalises the rows of its own sources.  Time = max over ranks, barrier to barrier."""
     g.set_tuning(pkg.tuning_default())
-    uid = [pkg.comm_unique_id() if rank == 0 else None]
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        uid = [pkg.comm_unique_id() if rank == 0 else None]
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
-    comm = pkg.Comm(g, uid[0], rank, world)  # collective (ncclCommInitRank)
+    # RCCL prints a version banner on stdout when its first communicator comes up; this file's stdout is one JSON line
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        comm = pkg.Comm(g, uid[0], rank, world)  # collective (ncclCommInitRank)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
     lo, hi = pkg.shard_target_range(rank, world, host.n)
     ix, _ = g.all_pair_backward(ALPHA, 1e-3, TOPK, lo, min(hi, lo + 1024))  # warm-up of the kernels
     ix.close()
