@@ -113,7 +113,11 @@ typedef struct pprhip_tuning {
   int32_t prior_levels;    /* the first round starts below rmax0 by as many halvings as keep the a-priori walk
                             * bound c_walk * omega * (1 - alpha) * rmax * m >= prior_levels dense levels' cost
                             * (default 16; negative: always start at rmax0) */
-  int32_t reserved;
+  int32_t gs_blocks;       /* dense sweeps run block by block (Gauss-Seidel): rows are cut into gs_blocks blocks of equal
+                            * in-edge count and a block reads the contributions the blocks before it have just written
+                            * (default 4; 1: plain Jacobi sweeps) */
+  double gs_frac;          /* ... while the frontier holds at least gs_frac * m edges + nodes (default 0.25); thinner
+                            * dense levels run as Jacobi sweeps */
 } pprhip_tuning_t;
 
 /* Parameters Algo_Conf derives (Algo_Conf.java:29-81). */

@@ -46,7 +46,8 @@ class Tuning(C.Structure):
     _fields_ = [("c_walk_ns", C.c_double), ("c_edge_ns", C.c_double), ("c_pop_ns", C.c_double),
                 ("c_level_ns", C.c_double), ("c_dense_edge_ns", C.c_double), ("c_dense_node_ns", C.c_double),
                 ("dense_frac", C.c_double), ("max_rounds", C.c_int32), ("max_halvings", C.c_int32),
-                ("halving_ratio", C.c_double), ("prior_levels", C.c_int32), ("reserved", C.c_int32)]
+                ("halving_ratio", C.c_double), ("prior_levels", C.c_int32), ("gs_blocks", C.c_int32),
+                ("gs_frac", C.c_double)]
 
 
 class Conf(C.Structure):
@@ -118,6 +119,8 @@ def lib():
         L.orc_fora_topk_params.restype = None
         L.orc_tuning_default.argtypes = [C.POINTER(Tuning)]
         L.orc_tuning_default.restype = None
+        L.orc_set_sync_tuning.argtypes = [C.POINTER(Tuning)]
+        L.orc_set_sync_tuning.restype = None
         L.orc_max_err.restype = C.c_double
         L.orc_max_err.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_precision.restype = C.c_double
@@ -300,6 +303,18 @@ def tuning_default():
     t = Tuning()
     lib().orc_tuning_default(C.byref(t))
     return t
+
+
+def set_sync_tuning(t=None):
+    """Tuning of the twin's entry points that take none (forward_push, topk_push, fora_topk); None: defaults.
+    Accepts the product's Tuning struct as well (same fields)."""
+    if t is None:
+        lib().orc_set_sync_tuning(None)
+        return
+    o = Tuning()
+    for f, _ in o._fields_:
+        setattr(o, f, getattr(t, f))
+    lib().orc_set_sync_tuning(C.byref(o))
 
 
 def max_err(est, exact):

@@ -44,6 +44,17 @@ static void* xmalloc(size_t bytes) {
 
 void orc_free(void* p) { free(p); }
 
+/* Tuning of the frontier-synchronous entry points that take no tuning argument (orc_forward_push, the top-k push
+ * rounds, orc_fora_topk): tests that change the engine's tuning hand the same values to the twin. */
+static orc_tuning g_sync_tuning;
+static int g_sync_tuning_set = 0;
+void orc_set_sync_tuning(const orc_tuning* t) {
+  if (t) { g_sync_tuning = *t; g_sync_tuning_set = 1; } else g_sync_tuning_set = 0;
+}
+static void sync_tuning(orc_tuning* t) {
+  if (g_sync_tuning_set) *t = g_sync_tuning; else orc_tuning_default(t);
+}
+
 void orc_tuning_default(orc_tuning* t) {
   /* keep in step with pprhip_tuning_default() in csrc/pprhip_api.cpp */
   t->c_walk_ns = 0.35;
@@ -57,7 +68,8 @@ void orc_tuning_default(orc_tuning* t) {
   t->max_halvings = 6;
   t->halving_ratio = 2.0;
   t->prior_levels = 16;
-  t->reserved = 0;
+  t->gs_blocks = 4;
+  t->gs_frac = 0.25;
 }
 
 /* ------------------------------------------------------------------ Philox4x32-10 */
@@ -223,6 +235,10 @@ typedef struct sync_ws {
   double* contrib;
   uint8_t* inq; /* top-k rounds: membership in the next frontier (the reference's nodesInQueue) */
   uint32_t ncur, nnxt;
+  /* dense sweeps (engine: k_dense_edges + k_dense_apply): pending contributions per node, current and next */
+  double *P, *Q, *acc;
+  uint8_t* blk; /* block of every node for the Gauss-Seidel sweeps (NULL until first needed) */
+  int blk_B;    /* block count blk[] was built for */
 } sync_ws;
 
 static void sync_ws_init(sync_ws* w, uint32_t n) {
@@ -230,6 +246,11 @@ static void sync_ws_init(sync_ws* w, uint32_t n) {
   w->nxt = (int32_t*)xmalloc((size_t)n * sizeof(int32_t));
   w->contrib = (double*)xmalloc((size_t)n * sizeof(double));
   w->inq = (uint8_t*)xcalloc((size_t)n, 1);
+  w->P = (double*)xcalloc((size_t)n, sizeof(double));
+  w->Q = (double*)xcalloc((size_t)n, sizeof(double));
+  w->acc = (double*)xcalloc((size_t)n, sizeof(double));
+  w->blk = NULL;
+  w->blk_B = 0;
   w->ncur = w->nnxt = 0;
 }
 static void sync_ws_free(sync_ws* w) {
@@ -237,6 +258,10 @@ static void sync_ws_free(sync_ws* w) {
   free(w->nxt);
   free(w->contrib);
   free(w->inq);
+  free(w->P);
+  free(w->Q);
+  free(w->acc);
+  free(w->blk);
 }
 
 static double level_model_cost(const orc_graph* g, const orc_tuning* t, uint64_t nf, uint64_t ef, int* dense) {
@@ -258,46 +283,212 @@ typedef struct round_cut {
 
 static double sum_array(const double* a, uint32_t n);
 
+/* Block of every node for the Gauss-Seidel form of the dense sweeps: the engine's rule.  Rows of a sweep are the
+ * nodes with in-edges in the engine's internal order (out-degree descending, ties by id); block b holds the row
+ * ordinals [jb[b], jb[b + 1]) where jb[b] is the first ordinal whose in-edge prefix reaches b * m / B, rounded down
+ * to a multiple of 256 (whole workgroup tiles).  Nodes without in-edges are applied with the last block. */
+typedef struct deg_id { uint32_t d; int32_t id; } deg_id;
+static int cmp_deg_desc(const void* a, const void* b) {
+  const deg_id* x = (const deg_id*)a; const deg_id* y = (const deg_id*)b;
+  if (x->d != y->d) return (x->d < y->d) - (x->d > y->d);
+  return (x->id > y->id) - (x->id < y->id);
+}
+static void build_blocks(const orc_graph* g, sync_ws* w, int B) {
+  uint32_t n = g->n;
+  if (w->blk && w->blk_B == B) return;
+  free(w->blk);
+  w->blk = (uint8_t*)xmalloc(n);
+  w->blk_B = B;
+  deg_id* order = (deg_id*)xmalloc((size_t)n * sizeof(deg_id));
+  for (uint32_t v = 0; v < n; ++v) { order[v].d = deg_out(g, (int32_t)v); order[v].id = (int32_t)v; }
+  qsort(order, n, sizeof(deg_id), cmp_deg_desc); /* stable by construction: ties ordered by id */
+  /* ordinals of the rows with in-edges, their in-edge prefix, block starts */
+  uint32_t* rows = (uint32_t*)xmalloc((size_t)n * sizeof(uint32_t));
+  uint64_t* pre = (uint64_t*)xmalloc(((size_t)n + 1) * sizeof(uint64_t));
+  uint32_t n_nz = 0;
+  pre[0] = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    int32_t v = order[i].id;
+    uint32_t din = g->in_rp[v + 1] - g->in_rp[v];
+    if (!din) continue;
+    rows[n_nz] = (uint32_t)v;
+    pre[n_nz + 1] = pre[n_nz] + din;
+    n_nz++;
+  }
+  uint32_t jb[65];
+  jb[0] = 0;
+  for (int b = 1; b < B; ++b) {
+    uint64_t target = (uint64_t)b * g->m / (uint64_t)B;
+    uint32_t lo = 0, hi = n_nz; /* first ordinal with prefix >= target */
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (pre[mid] >= target) hi = mid; else lo = mid + 1; }
+    uint32_t j = lo & ~255u;
+    jb[b] = j < jb[b - 1] ? jb[b - 1] : j;
+  }
+  jb[B] = n_nz;
+  memset(w->blk, B - 1, n); /* nodes without in-edges: last block */
+  for (int b = 0; b < B; ++b)
+    for (uint32_t j = jb[b]; j < jb[b + 1]; ++j) w->blk[rows[j]] = (uint8_t)b;
+  free(order); free(rows); free(pre);
+}
+
+enum { GS_J = 0, GS_E = 1, GS_G = 2, GS_F = 3 }; /* Jacobi, entry, in-place, flush (see engine.hpp) */
+
+/* One dense sweep in the engine's form: block by block, every row of the block first sums the pending
+ * contributions of its in-neighbours as they stand (k_dense_edges), then the block's rows are applied
+ * (k_dense_apply): the sum lands on the residue; a row that now belongs to the queue is prepared at once for the
+ * next level (residue taken, reserve credited: Forward_Push.java:86-97 moved to the moment the node is enqueued) and
+ * its contribution written to Q; what it leaves in P depends on the sweep's state:
+ *   Jacobi   P untouched: every contribution of this sweep is read by all rows (today's schedule, B = 1 semantics);
+ *   entry    P[u] += new: later blocks read old + new, earlier ones have read old;
+ *   in-place P[u]  = new: P holds contributions that still have to reach the blocks up to their own;
+ *   flush    P[u]  = 0: pending contributions are delivered, new ones reach nobody in this sweep (clean state).
+ * Returns the frontier the sweep leaves in *nf / *ef; dead-end mass of prepared nodes goes to *dead_next. */
+static void dense_sweep(const orc_graph* g, int32_t s, double alpha, double rmax, double* reserve, double* residue,
+                        sync_ws* w, uint8_t* parked, double min_rmax, int general, int B, int state, double* dead_cell,
+                        double* dead_next, uint64_t* nf, uint64_t* ef, orc_stats* st) {
+  uint32_t n = g->n;
+  double* P = w->P; double* Q = w->Q; double* acc = w->acc;
+  *nf = 0; *ef = 0;
+  for (int b = 0; b < B; ++b) {
+    for (uint32_t u = 0; u < n; ++u) { /* k_dense_edges over the block's rows */
+      if (B > 1 && w->blk[u] != b) continue;
+      double a = 0.0;
+      for (uint32_t e = g->in_rp[u]; e < g->in_rp[u + 1]; ++e) a += P[g->in_ci[e]];
+      acc[u] = a;
+    }
+    for (uint32_t u = 0; u < n; ++u) { /* k_dense_apply over the block's rows */
+      if (B > 1 && w->blk[u] != b) continue;
+      double a = acc[u];
+      if ((int32_t)u == s && *dead_cell > 0.0) { a += *dead_cell; *dead_cell = 0.0; } /* Forward_Push.java:101-113 */
+      double cn = 0.0;
+      if (a > 0.0) {
+        uint32_t d = deg_out(g, (int32_t)u);
+        double old = residue[u], nw = old + a;
+        int was = active_fwd(old, d, rmax);
+        int join = !was && active_fwd(nw, d, rmax);
+        if (general && was) join = 1; /* met the threshold without being queued: joins with its first mass */
+        if (parked && active_fwd(nw, d, min_rmax)) parked[u] = 1;
+        if (join) {
+          reserve[u] = reserve[u] + nw * alpha;
+          residue[u] = 0.0;
+          if (d == 0) { *dead_next += nw * (1.0 - alpha); if (st) st->dead_end_pops++; }
+          else cn = ((1.0 - alpha) * nw) / (double)d;
+          (*nf)++; *ef += d;
+        } else {
+          residue[u] = nw;
+        }
+      }
+      Q[u] = cn;
+      if (state == GS_E) P[u] = P[u] + cn;
+      else if (state == GS_G) P[u] = cn;
+      else if (state == GS_F) P[u] = 0.0;
+    }
+  }
+}
+
 /* Runs levels from the frontier in w->cur until it is empty.  One level = every frontier node
- * pushed at once from its residue at level start (Forward_Push.java:86-139 per node).
+ * pushed at once from its residue at level start (Forward_Push.java:86-139 per node); a level that touches a large
+ * part of the graph runs as a dense sweep (above), others edge by edge.
  * parked/min_rmax != NULL adds the second threshold of forward_push_topk (:226-237). */
 static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double rmax, double* reserve, double* residue,
                             sync_ws* w, uint8_t* parked, double min_rmax, const orc_tuning* tun, orc_stats* st,
                             round_cut* cut) {
+  uint32_t n = g->n;
   uint32_t d_s = deg_out(g, s);
   /* Only a top-k round whose threshold lies below min_rmax can hold a node that meets the threshold without being
    * queued; everywhere else the membership rule and the crossing rule pick the same nodes, and the crossing rule also
    * ends on the degenerate configurations (n div k = 1 makes pfail infinite and every threshold 0, where the
    * reference's own loop would never end). */
   const int general = parked != NULL && rmax < min_rmax;
-  while (w->ncur) {
-    uint64_t ef = 0;
-    double dead = 0.0;
-    /* phase 1: every frontier node gives up its residue */
-    for (uint32_t i = 0; i < w->ncur; ++i) {
-      int32_t v = w->cur[i];
-      double rc = residue[v];
-      residue[v] = 0.0;
-      reserve[v] = reserve[v] + rc * alpha;
-      uint32_t d = deg_out(g, v);
-      ef += d;
-      if (d == 0) {
-        dead += rc * (1.0 - alpha);
-        w->contrib[i] = 0.0;
-        if (st) st->dead_end_pops++;
-      } else {
-        w->contrib[i] = ((1.0 - alpha) * rc) / (double)d;
+  const int B = (tun && tun->gs_blocks > 1 && tun->gs_blocks <= 64) ? tun->gs_blocks : 1;
+  const double gs_thresh = (tun && B > 1) ? ceil(tun->gs_frac * (double)g->m) : 0.0;
+  if (B > 1) build_blocks(g, w, B);
+  int prepared = 0; /* the frontier is held as prepared contributions in w->P (after a dense sweep) */
+  int dirty = 0;    /* w->P is in the in-place state: its contributions have reached the later blocks only */
+  uint64_t nf = w->ncur, ef = 0;
+  double dead = 0.0; /* dead-end mass waiting to land on the source */
+  for (uint32_t i = 0; i < w->ncur; ++i) ef += deg_out(g, w->cur[i]);
+  while (nf) {
+    int dense = 0;
+    double c = tun ? level_model_cost(g, tun, nf, ef, &dense) : 0.0;
+    if (!tun) dense = 0;
+    if (dirty && !dense) /* a sweep that only runs to flush the contribution array costs a dense level */
+      c = tun->c_level_ns + tun->c_dense_edge_ns * (double)g->m + tun->c_dense_node_ns * (double)g->n;
+    if (dense || dirty) {
+      if (!prepared) { /* list form -> contributions in place (k_sparse_prepare with scatter) */
+        for (uint32_t i = 0; i < w->ncur; ++i) {
+          int32_t v = w->cur[i];
+          double rc = residue[v];
+          residue[v] = 0.0;
+          reserve[v] = reserve[v] + rc * alpha;
+          uint32_t d = deg_out(g, v);
+          if (d == 0) { dead += rc * (1.0 - alpha); if (st) st->dead_end_pops++; w->P[v] = 0.0; }
+          else w->P[v] = ((1.0 - alpha) * rc) / (double)d;
+        }
+        prepared = 1;
+        dirty = 0;
+      }
+      int state;
+      const int big = B > 1 && (double)(nf + ef) >= gs_thresh;
+      if (dirty) state = big ? GS_G : GS_F;
+      else state = big ? GS_E : GS_J;
+      uint64_t nf2 = 0, ef2 = 0;
+      double dead_next = 0.0;
+      dense_sweep(g, s, alpha, rmax, reserve, residue, w, parked, min_rmax, general, B, state, &dead, &dead_next, &nf2,
+                  &ef2, st);
+      dead += dead_next; /* lands with the next level */
+      double* t = w->P; w->P = w->Q; w->Q = t;
+      /* what the sweep left in the other buffer is overwritten by the next sweep; nodes that no sweep applies
+       * (none here: every node is applied) keep nothing */
+      dirty = (state == GS_E || state == GS_G) && nf2 > 0;
+      if (st) {
+        st->model_cost_ns += c;
+        st->levels++;
+        st->dense_levels++;
+        st->dense_nodes += nf;
+        st->enqueues += nf2;
+        if (cut && cut->enabled) cut->had_dense = 1;
+      }
+      nf = nf2; ef = ef2;
+      if (nf == 0) { /* nothing pending: leave no stale contribution behind */
+        memset(w->P, 0, (size_t)n * sizeof(double));
+        prepared = 0;
+      }
+      continue;
+    }
+    /* ---- a sparse level */
+    uint64_t ef_l = 0;
+    if (prepared) { /* contributions in place -> list (k_compact_prepared); dead-end nodes carry none */
+      w->ncur = 0;
+      for (uint32_t v = 0; v < n; ++v)
+        if (w->P[v] > 0.0) { w->contrib[w->ncur] = w->P[v]; w->cur[w->ncur++] = (int32_t)v; w->P[v] = 0.0; }
+      prepared = 0;
+    } else { /* phase 1: every frontier node gives up its residue */
+      for (uint32_t i = 0; i < w->ncur; ++i) {
+        int32_t v = w->cur[i];
+        double rc = residue[v];
+        residue[v] = 0.0;
+        reserve[v] = reserve[v] + rc * alpha;
+        uint32_t d = deg_out(g, v);
+        if (d == 0) {
+          dead += rc * (1.0 - alpha);
+          w->contrib[i] = 0.0;
+          if (st) st->dead_end_pops++;
+        } else {
+          w->contrib[i] = ((1.0 - alpha) * rc) / (double)d;
+        }
       }
     }
     /* phase 2: contributions land; a node joins the next frontier when it crosses the threshold */
     w->nnxt = 0;
     for (uint32_t i = 0; i < w->ncur; ++i) {
       int32_t v = w->cur[i];
-      double c = w->contrib[i];
+      double cc = w->contrib[i];
+      ef_l += deg_out(g, v);
       for (uint32_t e = g->out_rp[v]; e < g->out_rp[v + 1]; ++e) {
         int32_t u = g->out_ci[e];
         double old = residue[u];
-        double nr = old + c;
+        double nr = old + cc;
         residue[u] = nr;
         uint32_t du = deg_out(g, u);
         /* Whole-graph pushes: every node at or above the threshold is in a frontier, so "joins the queue" is
@@ -317,6 +508,7 @@ static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double 
       double old = residue[s];
       double nr = old + dead;
       residue[s] = nr;
+      dead = 0.0;
       int join = general ? (active_fwd(nr, d_s, rmax) && !w->inq[s])
                          : (!active_fwd(old, d_s, rmax) && active_fwd(nr, d_s, rmax));
       if (join) {
@@ -328,34 +520,27 @@ static void fwd_levels_sync(const orc_graph* g, int32_t s, double alpha, double 
     if (general) /* the next level pops these: they leave the queue */
       for (uint32_t i = 0; i < w->nnxt; ++i) w->inq[w->nxt[i]] = 0;
     if (st) {
-      int dense = 0;
-      double c = tun ? level_model_cost(g, tun, w->ncur, ef, &dense) : 0.0;
       st->model_cost_ns += c;
       st->levels++;
-      if (dense) {
-        st->dense_levels++;
-        st->dense_nodes += w->ncur;
-      } else {
-        st->pops += w->ncur;
-        st->edge_pushes += ef;
-      }
+      st->pops += nf;
+      st->edge_pushes += ef;
       st->enqueues += w->nnxt;
-      if (cut && cut->enabled) {
-        if (dense) {
-          cut->had_dense = 1;
-        } else if (cut->had_dense && !cut->checked) {
-          cut->checked = 1;
-          int more = 1;
-          if (!cut->fixed) more = st->model_cost_ns < cut->c_walk * (sum_array(residue, g->n) * (1 - alpha)) * cut->omega;
-          if (more) {
-            cut->taken = 1;
-            w->nnxt = 0; /* the rest of this round's frontier waits for the next threshold */
-          }
+      if (cut && cut->enabled && cut->had_dense && !cut->checked) {
+        cut->checked = 1;
+        int more = 1;
+        if (!cut->fixed) more = st->model_cost_ns < cut->c_walk * (sum_array(residue, g->n) * (1 - alpha)) * cut->omega;
+        if (more) {
+          cut->taken = 1;
+          w->nnxt = 0; /* the rest of this round's frontier waits for the next threshold */
         }
       }
     }
+    (void)ef_l;
     int32_t* t = w->cur; w->cur = w->nxt; w->nxt = t;
     w->ncur = w->nnxt;
+    nf = w->ncur;
+    ef = 0;
+    for (uint32_t i = 0; i < w->ncur; ++i) ef += deg_out(g, w->cur[i]);
   }
 }
 
@@ -388,7 +573,7 @@ double orc_forward_push(const orc_graph* g, int schedule, int32_t src, double al
                         double* residue, orc_stats* st) {
   if (st) memset(st, 0, sizeof *st);
   orc_tuning tun;
-  orc_tuning_default(&tun);
+  sync_tuning(&tun);
   double rsum = schedule == ORC_FIFO ? fwd_push_fifo(g, src, alpha, rmax, reserve, residue, st)
                                      : fwd_push_sync(g, src, alpha, rmax, reserve, residue, &tun, st);
   if (st) {
@@ -563,7 +748,7 @@ static double topk_round_sync(orc_topk_push* p, double min_rmax, double rmax, or
     }
   }
   orc_tuning tun;
-  orc_tuning_default(&tun);
+  sync_tuning(&tun);
   fwd_levels_sync(g, s, p->alpha, rmax, p->reserve, p->residue, &p->w, p->parked, min_rmax, &tun, st, NULL);
   p->rsum = sum_array(p->residue, n);
   p->first = 0;

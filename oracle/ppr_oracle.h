@@ -49,7 +49,8 @@ typedef struct orc_tuning {
   double c_walk_ns, c_edge_ns, c_pop_ns, c_level_ns, c_dense_edge_ns, c_dense_node_ns, dense_frac;
   int32_t max_rounds, max_halvings;
   double halving_ratio;
-  int32_t prior_levels, reserved;
+  int32_t prior_levels, gs_blocks;
+  double gs_frac;
 } orc_tuning;
 
 typedef struct orc_conf { /* Algo_Conf.java:29-81 */
@@ -63,6 +64,9 @@ typedef struct orc_conf { /* Algo_Conf.java:29-81 */
 #define ORC_SYNC 1
 
 void orc_tuning_default(orc_tuning* t);
+/* Tuning used by the frontier-synchronous entry points that take none (orc_forward_push, top-k push rounds,
+ * orc_fora_topk); NULL restores the defaults.  Level shapes matter to the twin since the Gauss-Seidel sweeps. */
+void orc_set_sync_tuning(const orc_tuning* t);
 
 /* Philox4x32-10 (Salmon et al., SC'11), the counter-based generator that replaces the
  * reference's unseeded ThreadLocalRandom (Monte_Carlo.java:76,84,111,115,123). */

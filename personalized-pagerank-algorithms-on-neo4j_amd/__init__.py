@@ -51,7 +51,8 @@ class Tuning(C.Structure):
     _fields_ = [("c_walk_ns", C.c_double), ("c_edge_ns", C.c_double), ("c_pop_ns", C.c_double),
                 ("c_level_ns", C.c_double), ("c_dense_edge_ns", C.c_double), ("c_dense_node_ns", C.c_double),
                 ("dense_frac", C.c_double), ("max_rounds", C.c_int32), ("max_halvings", C.c_int32),
-                ("halving_ratio", C.c_double), ("prior_levels", C.c_int32), ("reserved", C.c_int32)]
+                ("halving_ratio", C.c_double), ("prior_levels", C.c_int32), ("gs_blocks", C.c_int32),
+                ("gs_frac", C.c_double)]
 
 
 class ForaConf(C.Structure):

@@ -82,6 +82,59 @@ double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense) 
 
 uint64_t dense_level_bytes(const pprhip_graph* g) { return 12ull * g->m + 36ull * g->n + 4ull; }
 
+// modelled cost of a dense sweep (level_cost's dense branch): also what a sweep costs that only runs because the
+// contribution array has to be flushed
+double dense_sweep_cost(const pprhip_graph* g) {
+  const pprhip_tuning_t& t = g->tun;
+  return t.c_level_ns + t.c_dense_edge_ns * (double)g->m + t.c_dense_node_ns * (double)g->n;
+}
+
+// smallest frontier (nodes + edges) that runs as Gauss-Seidel sweeps; ~0 when they are switched off
+unsigned long long gs_thresh_of(const pprhip_graph* g) {
+  const pprhip_graph* H = host_of(g);
+  if (g->tun.gs_blocks <= 1 || !H->relabeled) return ~0ull;
+  return (unsigned long long)std::ceil(g->tun.gs_frac * (double)g->m);
+}
+
+// Blocks of the forward sweep (rows = nodes with in-edges in internal order): block b holds the row ordinals
+// [jb[b], jb[b + 1]), jb[b] = first ordinal whose in-edge prefix reaches b * m / B, rounded down to a multiple of
+// 256 (whole apply tiles), and the in-edges of those rows.  The test twin builds the same blocks
+// (oracle/ppr_oracle.c: build_blocks).
+const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks) {
+  pprhip_graph* H = g->parent ? g->parent : g;
+  const int B = g->tun.gs_blocks;
+  *n_blocks = 1;
+  if (B <= 1 || !H->relabeled || H->n_nz == 0) return nullptr;
+  if (H->gs_plan_B != B) {
+    const std::vector<uint32_t>& irp = H->h_in_rp;
+    const std::vector<int32_t>& rows = H->h_nz_rows;
+    const uint32_t n_nz = H->n_nz;
+    std::vector<uint32_t> jb((size_t)B + 1, 0);
+    for (int b = 1; b < B; ++b) {
+      const uint64_t target = (uint64_t)b * H->m / (uint64_t)B;
+      uint32_t lo = 0, hi = n_nz;  // first ordinal whose in-edge prefix (= row start) reaches the target
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)irp[rows[mid]] >= target) hi = mid; else lo = mid + 1;
+      }
+      const uint32_t j = lo & ~255u;
+      jb[b] = std::max(jb[b - 1], j);
+    }
+    jb[B] = n_nz;
+    H->gs_plan.assign((size_t)B, GsBlock{0, 0, 0, 0});
+    for (int b = 0; b < B; ++b) {
+      GsBlock& K = H->gs_plan[b];
+      K.j_lo = jb[b];
+      K.j_hi = jb[b + 1];
+      K.e_lo = K.j_lo < n_nz ? irp[rows[K.j_lo]] : H->m;
+      K.e_hi = K.j_hi < n_nz ? irp[rows[K.j_hi]] : H->m;
+    }
+    H->gs_plan_B = B;
+  }
+  *n_blocks = B;
+  return H->gs_plan.data();
+}
+
 int write_hist0(pprhip_graph* g, uint32_t nf, uint64_t ef) {
   g->h_ctr->hist[0] = ((unsigned long long)nf << kPackShift) | ef;
   PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long),
@@ -94,6 +147,9 @@ int ensure_bwd_layout(pprhip_graph* P);
 
 // bookkeeping after a dense level: the frontier it produced becomes the current one
 void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_t nf_next, uint64_t ef_next) {
+  // after an entry / in-place sweep the new contributions have reached the later blocks only (nothing is pending
+  // when the sweep prepared no node)
+  L.gs_dirty = (L.gs_state == kGsEntry || L.gs_state == kGsInPlace) && nf_next > 0;
   L.dense_run++;
   L.ccur ^= 1;
   L.dslot ^= 1;
@@ -123,10 +179,17 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
   const bool sparse_only = false;  // every push direction has both level shapes
   const unsigned long long dense_thresh =
       sparse_only ? ~0ull : (unsigned long long)std::ceil(g->tun.dense_frac * (double)g->m);
+  const unsigned long long gs_thresh = bwd ? ~0ull : gs_thresh_of(g);
+  int n_gs = 1;
+  const GsBlock* gs_blocks = gs_thresh != ~0ull ? gs_blocks_of(g, &n_gs) : nullptr;
   while (L.nf > 0) {
     bool dense = false;
-    const double c = level_cost(g, L.nf, L.ef, &dense);
+    double c = level_cost(g, L.nf, L.ef, &dense);
     if (sparse_only) dense = false;
+    if (L.gs_dirty && !dense) {  // the contribution array has to be flushed by one more sweep
+      dense = true;
+      c = dense_sweep_cost(g);
+    }
     if (dense) {
       if (model_cost) *model_cost += c;
       if (cut) cut->had_dense = true;
@@ -141,12 +204,18 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
         PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, 0, L.nf, dense_thresh, true, L.ccur, L.dslot));
         L.dense_prepared = true;
         L.dense_run = 0;
+        L.gs_dirty = false;
+      }
+      // state of this sweep (engine.hpp: GsState; the twin takes the same decision)
+      {
+        const bool big = (unsigned long long)L.nf + L.ef >= gs_thresh;
+        L.gs_state = L.gs_dirty ? (big ? kGsInPlace : kGsFlush) : (big ? kGsEntry : kGsJacobi);
       }
       if (yield_dense) return kYield;
-      // Dense levels are launched kDenseBatch at a time: level j > 0 of a batch starts with a device-side test of
-      // the frontier level j - 1 left (still non-empty and dense) and returns at once otherwise, so the host reads the
-      // batch's counters back in one round trip instead of one per level.
-      PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->dhist[0], 0, sizeof(unsigned long long) * (kDenseBatch + 1), g->stream));
+      // Dense levels are launched kDenseBatch at a time: level j > 0 of a batch reads its state from a device cell
+      // that the level before it wrote (gs_next_state of the frontier it left; kGsNone: nothing left to sweep, the
+      // level's kernels return at once), so the host reads the batch's counters back in one round trip.
+      PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->dhist[0], 0, sizeof(unsigned long long) * 8 + sizeof(int) * 8, g->stream));
       size_t rec0[kDenseBatch];
       ktimer().reserve(kDenseBatch);
       for (int j = 0; j < kDenseBatch; ++j) {
@@ -159,27 +228,40 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
           PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[cc ^ 1], 0, sizeof(double) * g->n, g->stream));
         ktimer().begin(PPRHIP_KERNEL_DENSE_PULL, dense_level_bytes(g));
         rec0[j] = ktimer().recs.size() - 1;
-        PPRHIP_TRY(launch_dense_level(g, a, cc, out, ds, j ? &g->ctr->dhist[j] : nullptr, dense_thresh,
-                                      &g->ctr->dhist[j + 1]));
+        DenseLaunch dl;
+        dl.blocks = gs_blocks;
+        dl.n_blocks = n_gs;
+        dl.state_in = j ? &g->ctr->dstate[j] : nullptr;
+        dl.state0 = L.gs_state;
+        dl.hist_out = &g->ctr->dhist[j + 1];
+        dl.state_out = &g->ctr->dstate[j + 1];
+        dl.dense_thresh = dense_thresh;
+        dl.gs_thresh = gs_thresh;
+        PPRHIP_TRY(launch_dense_level(g, a, cc, out, ds, dl));
         ktimer().end();
         if (first_of_phase)
           PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[cc], 0, sizeof(double) * g->n, g->stream));
       }
       PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->dhist[0], &g->ctr->dhist[0],
-                                      sizeof(unsigned long long) * (kDenseBatch + 1), hipMemcpyDeviceToHost, g->stream));
+                                      sizeof(unsigned long long) * 8 + sizeof(int) * 8, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      int state = L.gs_state;
       for (int j = 0; j < kDenseBatch; ++j) {
         if (j > 0) {
-          // level j ran iff the device-side gate was open: the same test on the counter the host now holds
+          // level j ran in the state the device derived from level j - 1's counter: the same function here
           const unsigned long long pk = g->h_ctr->dhist[j];
-          const unsigned long long nfj = pk >> kPackShift, efj = pk & kPackMask;
-          const bool ran = nfj != 0 && (nfj + efj) >= dense_thresh;
-          if (!ran) {
+          state = gs_next_state(state, pk >> kPackShift, pk & kPackMask, dense_thresh, gs_thresh);
+          if (state != g->h_ctr->dstate[j]) {
+            set_error("dense batch: level %d ran in state %d, the host expects %d", j, g->h_ctr->dstate[j], state);
+            return PPRHIP_ERR_STATE;
+          }
+          if (state == kGsNone) {
             for (int t = j; t < kDenseBatch; ++t)  // gated-off launches are not levels: keep them out of the class stats
               if (rec0[t] < ktimer().recs.size()) ktimer().recs[rec0[t]].cls = PPRHIP_KERNEL_NONE;
             break;
           }
-          if (model_cost) *model_cost += c;  // a dense level costs the same whatever it pushes
+          if (model_cost) *model_cost += dense_sweep_cost(g);  // a dense level costs the same whatever it pushes
+          L.gs_state = state;
         }
         const unsigned long long nx = g->h_ctr->dhist[j + 1];
         finish_dense(L, st, dense_level_bytes(g), (uint32_t)(nx >> kPackShift), nx & kPackMask);
@@ -292,7 +374,7 @@ int alloc_workspace(pprhip_graph* G) {
   PPRHIP_TRY(alloc_dev((void**)&G->partial, sizeof(double) * 1024));
   PPRHIP_TRY(alloc_dev((void**)&G->hist, sizeof(uint32_t) * 4096));
   {
-    const size_t nblk = std::max<size_t>(1024, ((size_t)n + 1 + 255) / 256);
+    const size_t nblk = std::max<size_t>(1024, ((size_t)n + 1 + 255) / 256) + 72;
     PPRHIP_TRY(alloc_dev((void**)&G->blk_pack, sizeof(unsigned long long) * nblk));
     PPRHIP_TRY(alloc_dev((void**)&G->blk_dead, sizeof(double) * nblk));
     PPRHIP_TRY(alloc_dev((void**)&G->blk_ndead, sizeof(uint32_t) * nblk));
@@ -478,6 +560,7 @@ int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree) {
   L.nf = 1;
   L.ef = degree;
   L.dense_prepared = false;
+  L.gs_dirty = false;
   return PPRHIP_OK;
 }
 
@@ -486,6 +569,7 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
   PPRHIP_TRY(launch_count_active(g, a, kind, L.pslot));
   PPRHIP_TRY(read_packed(g, L.pslot, &L.nf, &L.ef));
   L.dense_prepared = false;
+  L.gs_dirty = false;
   bool dense = false;
   if (L.nf) (void)level_cost(g, L.nf, L.ef, &dense);
   if (dense) {
@@ -743,7 +827,8 @@ void pprhip_tuning_default(pprhip_tuning_t* t) {
   t->max_halvings = 6;
   t->halving_ratio = 2.0;
   t->prior_levels = 16;
-  t->reserved = 0;
+  t->gs_blocks = 4;
+  t->gs_frac = 0.25;
 }
 
 void pprhip_tuning_batch(pprhip_tuning_t* t) {
@@ -937,6 +1022,7 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
   for (size_t c = 1; c <= n_chunks; ++c) chunk_starts[c] += chunk_starts[c - 1];
   g->n_chunks = (uint32_t)n_chunks;
   g->n_nz = (uint32_t)nz_rows.size();
+  g->h_nz_rows = nz_rows;
 
   pprhip_graph* G = g.get();
   auto up = [&](void** dst, const void* src, size_t bytes) -> int {
@@ -1038,6 +1124,9 @@ int pprhip_graph_set_tuning(pprhip_graph_t* g, const pprhip_tuning_t* t) {
   if (g->tun.max_halvings <= 0) g->tun.max_halvings = d.max_halvings;
   if (!(g->tun.halving_ratio > 0)) g->tun.halving_ratio = d.halving_ratio;  // a value <= 1 switches the rule off
   if (g->tun.prior_levels == 0) g->tun.prior_levels = d.prior_levels;        // negative: off
+  if (g->tun.gs_blocks <= 0) g->tun.gs_blocks = d.gs_blocks;                  // 1: plain Jacobi sweeps
+  if (g->tun.gs_blocks > 64) g->tun.gs_blocks = 64;
+  if (!(g->tun.gs_frac > 0)) g->tun.gs_frac = d.gs_frac;
   return PPRHIP_OK;
 }
 

@@ -19,8 +19,35 @@ struct DevCounters {
   double sum_out;                 // reduction result
   unsigned long long pad[7];
   unsigned long long dhist[8];    // dense batch: dhist[i] = frontier that dense level i of the batch starts from
+  int dstate[8];                  // dense batch: sweep state of level i (kGsNone: the level does not run)
 };
 constexpr int kDenseBatch = 6;  // dense levels of a single query launched per host round trip
+
+// State of a dense sweep ("Gauss-Seidel sweeps").  Rows are cut into `gs_blocks` blocks of equal in-edge
+// count, processed one after another; what a row leaves in the *current* contribution array when it is applied decides
+// what the later blocks of the same sweep read:
+//   kGsJacobi   nothing: every row reads the contributions of the level before (one block is enough);
+//   kGsEntry    old + new: first sweep of a long dense phase; later blocks get both, earlier ones have read the old;
+//   kGsInPlace  new: the array holds contributions that still have to reach the blocks up to their own;
+//   kGsFlush    zero: pending contributions are delivered, the new ones reach nobody yet - after it (as after a Jacobi
+//               sweep) every contribution is wholly undelivered again, the only state a sparse level can start from.
+enum GsState : int { kGsNone = 0, kGsJacobi = 1, kGsEntry = 2, kGsInPlace = 3, kGsFlush = 4 };
+
+// state of the sweep that follows a sweep of state `prev` which left a frontier of nf nodes / ef edges
+__host__ __device__ inline int gs_next_state(int prev, unsigned long long nf, unsigned long long ef,
+                                             unsigned long long dense_thresh, unsigned long long gs_thresh) {
+  if (nf == 0) return kGsNone;
+  const unsigned long long tot = nf + ef;
+  if (prev == kGsEntry || prev == kGsInPlace) return tot >= gs_thresh ? kGsInPlace : kGsFlush;  // must be finished
+  if (tot < dense_thresh) return kGsNone;                                                      // sparse levels follow
+  return tot >= gs_thresh ? kGsEntry : kGsJacobi;
+}
+
+// one block of a Gauss-Seidel sweep: row ordinals [j_lo, j_hi), their in-edges [e_lo, e_hi)
+struct GsBlock {
+  uint32_t j_lo, j_hi;
+  unsigned long long e_lo, e_hi;
+};
 
 enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
 
@@ -133,7 +160,7 @@ struct SlotArgs {
   int32_t active;  // the slot takes part in this sweep
   int32_t mode;
   int32_t dead_slot, out_slot;
-  int32_t pad;
+  int32_t gs_state;  // GsState of this slot in this sweep
 };
 
 }  // namespace pprhip
@@ -160,6 +187,9 @@ struct pprhip_graph {
   uint32_t n_chunks = 0;
   int32_t* nz_rows = nullptr;  // rows with in-degree > 0, ascending
   uint32_t n_nz = 0;
+  std::vector<int32_t> h_nz_rows;         // host copy (block boundaries of the Gauss-Seidel sweeps)
+  std::vector<pprhip::GsBlock> gs_plan;   // blocks of the forward sweep for gs_plan_B blocks (built on demand)
+  int gs_plan_B = 0;
   double* acc_nz = nullptr;  // per non-empty row: sum of this level's contributions
   // batched queries: kBatch workspaces ("slots") borrow this handle's CSR and stream; their dense
   // levels run as one sweep over the interleaved contribution array c8[v][slot]
@@ -236,13 +266,24 @@ int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int leve
                           unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot);
 int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
                        unsigned long long dense_thresh, int dead_slot);
-// gate != nullptr: the level runs only if *gate (the frontier the level before it left) is non-empty and still
-// dense (entries + edges >= dense_thresh); hist_out receives the frontier this level leaves.
+// One dense level of a single query, block by block (blocks: nullptr / 1 = the whole sweep at once).  state_in:
+// device cell holding this level's GsState (a level launched behind another one without a host round trip; kGsNone:
+// the kernels return at once), or nullptr: `state0` applies.  hist_out / state_out (nullable) receive the frontier
+// the level leaves and the state the level after it has to run in (gs_next_state).
+struct DenseLaunch {
+  const pprhip::GsBlock* blocks = nullptr;
+  int n_blocks = 1;
+  const int* state_in = nullptr;
+  int state0 = pprhip::kGsJacobi;
+  unsigned long long* hist_out = nullptr;
+  int* state_out = nullptr;
+  unsigned long long dense_thresh = 0, gs_thresh = ~0ull;
+};
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot,
-                       const unsigned long long* gate = nullptr, unsigned long long dense_thresh = 0,
-                       unsigned long long* hist_out = nullptr);
+                       const DenseLaunch& d = DenseLaunch());
 constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply kernel (per-slot partials each)
-int launch_dense_level_b8(pprhip_graph* parent, bool backward);  // slot arguments already staged in parent->h_slot_args
+// slot arguments already staged in parent->h_slot_args; blocks: Gauss-Seidel blocks (nullptr / 1: one launch)
+int launch_dense_level_b8(pprhip_graph* parent, bool backward, const pprhip::GsBlock* blocks = nullptr, int n_blocks = 1);
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);
 int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot);
 int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter);

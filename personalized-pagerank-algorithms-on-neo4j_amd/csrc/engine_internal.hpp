@@ -67,6 +67,11 @@ struct LevelCtx {
   uint64_t ef = 0;
   bool dense_prepared = false;
   int dense_run = 0;  // dense levels run since the current dense phase was seeded
+  // Gauss-Seidel sweeps: the state the next dense sweep runs in (set when the level is prepared / yielded), and
+  // whether the contribution array is "dirty" (its contributions have reached the later blocks only, so another
+  // dense sweep - in place or flushing - has to follow whatever the frontier looks like)
+  int gs_state = kGsJacobi;
+  bool gs_dirty = false;
 };
 
 // FORA rounds that are certain to be followed by another halving do not need their sparse tail: what it
@@ -91,6 +96,7 @@ inline KernelTimer& ktimer() { return *g_timer_cur; }
 int alloc_dev(void** p, size_t bytes);
 double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense);
 uint64_t dense_level_bytes(const pprhip_graph* g);
+double dense_sweep_cost(const pprhip_graph* g);
 void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_t nf_next, uint64_t ef_next);
 int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost,
                bool yield_dense = false, RoundCut* cut = nullptr);
@@ -98,6 +104,9 @@ int reset_query_state(pprhip_graph* g, bool clear_flags);
 int ensure_batch(pprhip_graph* P);
 void free_batch(pprhip_graph* P);
 int ensure_bwd_layout(pprhip_graph* P);
+// blocks of the forward Gauss-Seidel sweep for the handle's tuning (nullptr / 1 block when switched off)
+const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks);
+unsigned long long gs_thresh_of(const pprhip_graph* g);
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree);
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L);
 int device_sum(pprhip_graph* g, const double* x, double* out);

@@ -416,6 +416,7 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
     sa.mode = r.a.mode;
     sa.dead_slot = r.L.dslot;
     sa.out_slot = r.L.pslot ^ 1;
+    sa.gs_state = r.L.gs_state;
     if (S->stream != P->stream) {
       PPRHIP_CHECK_HIP(hipEventRecord(S->ev[3], S->stream));
       PPRHIP_CHECK_HIP(hipStreamWaitEvent(P->stream, S->ev[3], 0));
@@ -430,8 +431,10 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
     PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * ((size_t)P->n + 1) * kBatch, P->stream));
     P->acc8_dir = (int)backward;
   }
+  int n_gs = 1;
+  const GsBlock* gs_blocks = backward ? nullptr : gs_blocks_of(P->slots[0], &n_gs);  // slots carry the call's tuning
   P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
-  PPRHIP_TRY(launch_dense_level_b8(P, backward));
+  PPRHIP_TRY(launch_dense_level_b8(P, backward, gs_blocks, n_gs));
   P->ktimer.end();
   PPRHIP_CHECK_HIP(hipMemcpyAsync(P->h_sweep_out, P->sweep_out, sizeof(unsigned long long) * kBatch,
                                   hipMemcpyDeviceToHost, P->stream));

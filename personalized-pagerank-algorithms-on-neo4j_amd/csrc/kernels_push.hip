@@ -44,15 +44,9 @@ __device__ __forceinline__ bool level_runs(unsigned long long pk, int level, uns
   return (nf + ef) < dense_thresh;
 }
 
-// A dense level launched behind another one without a host round trip in between: it runs iff the level before
-// it left a frontier that is non-empty and still worth a sweep (the host applies the same test to the counters
-// when it reads them back).
-__device__ __forceinline__ bool dense_gate_open(const unsigned long long* gate, unsigned long long dense_thresh) {
-  if (!gate) return true;
-  const unsigned long long pk = *gate;
-  const unsigned long long nf = pk >> kPackShift, ef = pk & kPackMask;
-  return nf != 0 && (nf + ef) >= dense_thresh;
-}
+// State of a dense level (GsState): given by the host, or - for a level launched behind another one without a host
+// round trip in between - read from the cell the level before it wrote (kGsNone: that level left nothing to sweep).
+__device__ __forceinline__ int dense_state(const int* state_in, int state0) { return state_in ? *state_in : state0; }
 
 // ------------------------------------------------------------------------------------------------
 // sparse level, step 1: every frontier node gives up its residue
@@ -347,14 +341,17 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
                                                        const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
                                                        unsigned long long m, const double* __restrict__ c_cur,
                                                        double* __restrict__ acc_nz, uint32_t n_hot,
-                                                       const unsigned long long* gate,
-                                                       unsigned long long dense_thresh) {
+                                                       uint32_t c_lo, unsigned long long e_lo, unsigned long long e_hi,
+                                                       const int* state_in) {
+  // One block of a sweep: the chunks [c_lo, n_chunks) that hold the in-edges [e_lo, e_hi) of the block's rows (the
+  // whole CSR when the sweep is not cut into blocks).  Edges of a boundary chunk that belong to a neighbouring block
+  // count as zero: that block's own launch sums them.
   extern __shared__ __attribute__((aligned(16))) double s_hot[];
-  if (!dense_gate_open(gate, dense_thresh)) return;
+  if (dense_state(state_in, kGsJacobi) == kGsNone) return;
   const int lane = lane_id();
   const uint32_t waves_per_block = blockDim.x >> 6;
   const uint32_t stride = gridDim.x * waves_per_block;
-  uint32_t c = blockIdx.x * waves_per_block + (uint32_t)wave_id();
+  uint32_t c = c_lo + blockIdx.x * waves_per_block + (uint32_t)wave_id();
   ChunkRegs cur;
   if (c < n_chunks) cur = load_chunk(in_ci, start_flags, c, lane);  // in flight while the hot table loads
   if (HOT) {
@@ -397,10 +394,10 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = c_cur[idx[i]];
     }
-    if (e0 + 8 > m) {
+    if (e0 < e_lo || e0 + 8 > e_hi) {  // first / last chunk of the block only
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (e0 + i >= m) v[i] = 0.0;
+        if (e0 + i < e_lo || e0 + i >= e_hi) v[i] = 0.0;
     }
     // row index of a segment = (row starts at or before its first edge) - 1
     const uint32_t pc = __popc(fb);
@@ -496,7 +493,8 @@ __device__ __forceinline__ ChunkRegsB<G> load_chunk_b(const int32_t* __restrict_
 template <bool HOT, int G, int JB>
 __device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const double* __restrict__ cB,
                                               const double* s_hot, uint32_t n_hot, int s, bool tail,
-                                              unsigned long long e_first, unsigned long long m, uint32_t before,
+                                              unsigned long long e_first, unsigned long long e_lo,
+                                              unsigned long long e_hi, uint32_t before,
                                               double* __restrict__ accB, double& seg, double& first_seg, uint32_t& k) {
   const int32_t own[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
   uint32_t v[8];
@@ -519,7 +517,7 @@ __device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const do
   if (tail) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (e_first + JB * 8 + i >= m) val[i] = 0.0;
+      if (e_first + JB * 8 + i < e_lo || e_first + JB * 8 + i >= e_hi) val[i] = 0.0;
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -539,17 +537,18 @@ template <bool HOT, int G, int JB>
 struct EdgeBlocks {
   static __device__ __forceinline__ void run(const ChunkRegsB<G>& cur, const double* __restrict__ cB,
                                              const double* s_hot, uint32_t n_hot, int s, bool tail,
-                                             unsigned long long e_first, unsigned long long m, uint32_t before,
+                                             unsigned long long e_first, unsigned long long e_lo,
+                                             unsigned long long e_hi, uint32_t before,
                                              double* __restrict__ accB, double& seg, double& first_seg, uint32_t& k) {
-    EdgeBlocks<HOT, G, JB - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, m, before, accB, seg, first_seg, k);
-    edges_b_block<HOT, G, JB>(cur, cB, s_hot, n_hot, s, tail, e_first, m, before, accB, seg, first_seg, k);
+    EdgeBlocks<HOT, G, JB - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
+    edges_b_block<HOT, G, JB>(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
   }
 };
 template <bool HOT, int G>
 struct EdgeBlocks<HOT, G, -1> {
   static __device__ __forceinline__ void run(const ChunkRegsB<G>&, const double*, const double*, uint32_t, int, bool,
-                                             unsigned long long, unsigned long long, uint32_t, double*, double&,
-                                             double&, uint32_t&) {}
+                                             unsigned long long, unsigned long long, unsigned long long, uint32_t,
+                                             double*, double&, double&, uint32_t&) {}
 };
 
 // G = queries per sweep = lanes per edge; the wave's 64 / G lane groups walk 8 * G edges each
@@ -558,13 +557,15 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
                                                          const unsigned long long* __restrict__ flags64,
                                                          const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
                                                          unsigned long long m, const double* __restrict__ cB,
-                                                         double* __restrict__ accB, uint32_t n_hot) {
+                                                         double* __restrict__ accB, uint32_t n_hot, uint32_t c_lo,
+                                                         unsigned long long e_lo, unsigned long long e_hi) {
+  // one block of a sweep: chunks [c_lo, n_chunks) holding the in-edges [e_lo, e_hi) (see k_dense_edges)
   extern __shared__ __attribute__((aligned(16))) double s_hot[];
   const int lane = lane_id();
   const int grp = lane / G, s = lane & (G - 1);
   const uint32_t waves_per_block = blockDim.x >> 6;
   const uint32_t stride = gridDim.x * waves_per_block;
-  uint32_t c = blockIdx.x * waves_per_block + (uint32_t)wave_id();
+  uint32_t c = c_lo + blockIdx.x * waves_per_block + (uint32_t)wave_id();
   ChunkRegsB<G> cur;
   if (c < n_chunks) cur = load_chunk_b<G>(in_ci, flags64, c, lane);
   if (HOT) {
@@ -592,10 +593,11 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
     const uint32_t incl = wave_incl_scan_u32_dpp(s == 0 ? pc : 0u);  // row starts up to and including this group
     const uint32_t before = cs + incl - pc;
     const unsigned long long e_first = (unsigned long long)c * kChunkEdges + (unsigned long long)(8 * G) * grp;
-    const bool tail = (unsigned long long)(c + 1) * kChunkEdges > m;
+    const unsigned long long c_e0 = (unsigned long long)c * kChunkEdges;
+    const bool tail = c_e0 < e_lo || c_e0 + kChunkEdges > e_hi;  // first / last chunk of the block: edges outside count 0
     double seg = 0.0, first_seg = 0.0;
     uint32_t k = 0;
-    EdgeBlocks<HOT, G, G - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, m, before, accB, seg, first_seg, k);
+    EdgeBlocks<HOT, G, G - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
     // segmented scan over the lane groups: S(g) = tail(g) + (group g holds a row start ? 0 : S(g-1))
     const bool h = k != 0;
     double S = seg;
@@ -636,22 +638,25 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
 // only ever receives returned dead-end mass): lands the row sum, detects the threshold crossing
 // and prepares the row for the next level in place.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
+__global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__ nz_rows, uint32_t j_lo, uint32_t n_nz,
                                                       double* __restrict__ acc_nz,
                                                       const uint32_t* __restrict__ out_rp,
                                                       const uint32_t* __restrict__ in_rp,
-                                                      double* __restrict__ c_next, double* __restrict__ res,
+                                                      double* __restrict__ c_cur, double* __restrict__ c_next,
+                                                      double* __restrict__ res,
                                                       double* __restrict__ reserve, uint8_t* __restrict__ flags,
                                                       uint32_t* __restrict__ armed,
                                                       DevCounters* ctr, unsigned long long* __restrict__ blk_pack,
                                                       double* __restrict__ blk_dead, uint32_t* __restrict__ blk_ndead,
                                                       int dead_slot, int src_extra, PushArgs a,
-                                                      const unsigned long long* gate, unsigned long long dense_thresh) {
+                                                      const int* state_in, int state0) {
+  // rows [j_lo, n_nz) of one block (n_nz = the block's end; + the source without in-edges behind the last block)
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
-  if (!dense_gate_open(gate, dense_thresh)) return;
+  const int state = dense_state(state_in, state0);
+  if (state == kGsNone) return;
   const int tid = threadIdx.x;
-  const uint32_t j = blockIdx.x * 256u + tid;
+  const uint32_t j = j_lo + blockIdx.x * 256u + tid;
   bool have = false;
   int32_t u = -1;
   double acc = 0.0;
@@ -716,6 +721,10 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
       }
     }
     c_next[u] = cn;
+    // what the later blocks of this sweep read from the current array (engine.hpp: GsState)
+    if (state == kGsEntry) c_cur[u] = c_cur[u] + cn;
+    else if (state == kGsInPlace) c_cur[u] = cn;
+    else if (state == kGsFlush) c_cur[u] = 0.0;
   }
   // per-workgroup partials; k_dense_reduce sums them (no same-address atomics in this kernel)
   const double ds = block_sum_f64(dead_next, s_red);
@@ -745,14 +754,20 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
                                                             double* __restrict__ acc8,
                                                             const uint32_t* __restrict__ out_rp,
                                                             const uint32_t* __restrict__ in_rp_bwd,
-                                                            double* __restrict__ c8_next,
+                                                            double* __restrict__ c8_cur, double* __restrict__ c8_next,
+                                                            uint32_t tile_lo, uint32_t tile_hi, uint32_t gs_mask,
+                                                            uint32_t entry_mask,
                                                             const SlotArgs* __restrict__ slots,
                                                             const unsigned long long* __restrict__ cross_bits,
                                                             unsigned long long* __restrict__ prep_bits,
                                                             unsigned long long* __restrict__ blk_pack8,
                                                             double* __restrict__ blk_dead8,
-                                                            uint32_t* __restrict__ blk_ndead8) {
+                                                            uint32_t* __restrict__ blk_ndead8, uint32_t part_base,
+                                                            uint32_t part_stride) {
+  // tiles [tile_lo, tile_hi) of one block of the sweep.  gs_mask: slots whose state writes the current array in place
+  // (entry / in-place / flush, engine.hpp: GsState); entry_mask: those of them that add to what it holds.
   __shared__ double tile[kApplyRows][kBatch + 1];
+  __shared__ double tile_p[kApplyRows][kBatch + 1];  // what the rows leave in the current array (slots in gs_mask)
   __shared__ int32_t s_u[kApplyRows];
   __shared__ uint32_t s_d[kApplyRows];
   __shared__ uint32_t s_din[kApplyRows];  // backward sweeps: in-degree = edges the row pushes when it is popped
@@ -772,7 +787,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
     pack[i] = 0;
     ndead[i] = 0;
   }
-  for (uint32_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+  for (uint32_t tl = tile_lo + blockIdx.x; tl < tile_hi; tl += gridDim.x) {
     const uint32_t row0 = tl * kApplyRows;
     // rows inside one 512-edge chunk are rewritten by plain stores every sweep; only the rows that
     // cross a chunk boundary are summed with atomics and have to be cleared for the next sweep
@@ -798,6 +813,16 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
       s_din[tid] = (u >= 0 && in_rp_bwd) ? in_rp_bwd[u + 1] - in_rp_bwd[u] : 0u;
     }
     __syncthreads();
+    if (entry_mask) {  // entry sweeps add to the row's own pending contribution: stage it (whole lines)
+#pragma unroll
+      for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
+        const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
+        const uint32_t r = idx / kBatch, s = idx % kBatch;
+        const int32_t ur = s_u[r];
+        tile_p[r][s] = (ur >= 0 && (entry_mask >> s & 1u)) ? c8_cur[(size_t)ur * kBatch + s] : 0.0;
+      }
+      __syncthreads();
+    }
     const int32_t u = s_u[lane];
     const uint32_t d = s_d[lane];
     const uint32_t din = s_din[lane];
@@ -864,6 +889,11 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
         }
       }
       tile[lane][s] = cn;
+      if (gs_mask >> s & 1u) {
+        const int gst = a[i].gs_state;
+        // entry: old + new (the old value is loaded below, before this line runs: see the staging of tile_p)
+        tile_p[lane][s] = gst == kGsEntry ? tile_p[lane][s] + cn : (gst == kGsInPlace ? cn : 0.0);
+      }
       // rows of this tile that hold a contribution for the slot's next level (read when the slot
       // goes back to list form)
       const unsigned long long bits = __ballot(cn > 0.0);
@@ -875,7 +905,10 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
       const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
       const uint32_t r = idx / kBatch, s = idx % kBatch;
       const int32_t ur = s_u[r];
-      if (ur >= 0) c8_next[(size_t)ur * kBatch + s] = tile[r][s];
+      if (ur >= 0) {
+        c8_next[(size_t)ur * kBatch + s] = tile[r][s];
+        if (gs_mask >> s & 1u) c8_cur[(size_t)ur * kBatch + s] = tile_p[r][s];
+      }
     }
     __syncthreads();
   }
@@ -885,7 +918,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
     const unsigned long long ps = wave_sum_u64(pack[i]);
     const unsigned long long nd = wave_sum_u64((unsigned long long)ndead[i]);
     if (lane == 0) {
-      const size_t o = (size_t)(w * kSlotsPerWave + i) * gridDim.x + blockIdx.x;
+      const size_t o = (size_t)(w * kSlotsPerWave + i) * part_stride + part_base + blockIdx.x;
       blk_pack8[o] = ps;
       blk_dead8[o] = ds;
       blk_ndead8[o] = (uint32_t)nd;
@@ -897,6 +930,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
 __global__ __launch_bounds__(1024) void k_dense_reduce_batch(const unsigned long long* __restrict__ blk_pack8,
                                                            const double* __restrict__ blk_dead8,
                                                            const uint32_t* __restrict__ blk_ndead8, uint32_t n_blocks,
+                                                           uint32_t part_stride,
                                                            const SlotArgs* __restrict__ slots,
                                                            unsigned long long* __restrict__ sweep_out) {
   __shared__ double s_red[16];
@@ -906,9 +940,9 @@ __global__ __launch_bounds__(1024) void k_dense_reduce_batch(const unsigned long
   unsigned long long pack = 0, ndead = 0;
   double dead = 0.0;
   for (uint32_t i = threadIdx.x; i < n_blocks; i += blockDim.x) {
-    pack += blk_pack8[(size_t)blockIdx.x * n_blocks + i];
-    dead += blk_dead8[(size_t)blockIdx.x * n_blocks + i];
-    ndead += blk_ndead8[(size_t)blockIdx.x * n_blocks + i];
+    pack += blk_pack8[(size_t)blockIdx.x * part_stride + i];
+    dead += blk_dead8[(size_t)blockIdx.x * part_stride + i];
+    ndead += blk_ndead8[(size_t)blockIdx.x * part_stride + i];
   }
   const unsigned long long ps = block_sum_u64(pack, s_red2);
   const unsigned long long nd = block_sum_u64(ndead, s_red2);
@@ -929,11 +963,16 @@ __global__ __launch_bounds__(1024) void k_dense_reduce(const unsigned long long*
                                                         const double* __restrict__ blk_dead,
                                                         const uint32_t* __restrict__ blk_ndead, uint32_t n_blocks,
                                                         DevCounters* ctr, int out_slot, int dead_slot_next,
-                                                        const unsigned long long* gate, unsigned long long dense_thresh,
-                                                        unsigned long long* hist_out) {
+                                                        const int* state_in, int state0, unsigned long long* hist_out,
+                                                        int* state_out, unsigned long long dense_thresh,
+                                                        unsigned long long gs_thresh) {
   __shared__ double s_red[16];
   __shared__ unsigned long long s_red2[16];
-  if (!dense_gate_open(gate, dense_thresh)) return;
+  const int state = dense_state(state_in, state0);
+  if (state == kGsNone) {
+    if (threadIdx.x == 0 && state_out) *state_out = kGsNone;
+    return;
+  }
   unsigned long long pack = 0, ndead = 0;
   double dead = 0.0;
   for (uint32_t i = threadIdx.x; i < n_blocks; i += blockDim.x) {
@@ -949,6 +988,7 @@ __global__ __launch_bounds__(1024) void k_dense_reduce(const unsigned long long*
   if (threadIdx.x == 0) {
     ctr->packed[out_slot] = ps;
     if (hist_out) *hist_out = ps;
+    if (state_out) *state_out = gs_next_state(state, ps >> kPackShift, ps & kPackMask, dense_thresh, gs_thresh);
     if (nd) {
       ctr->dead[dead_slot_next] = ctr->dead[dead_slot_next] + ds;
       ctr->dead_pops += nd;
@@ -1201,7 +1241,7 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
 }
 
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot,
-                       const unsigned long long* gate, unsigned long long dense_thresh, unsigned long long* hist_out) {
+                       const DenseLaunch& dl) {
   // forward levels pull over the in-CSR, backward levels over the out-CSR (layout built by the caller)
   const bool bwd = a.mode == kBackward;
   const int32_t* ci = bwd ? g->out_ci : g->in_ci;
@@ -1209,61 +1249,77 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   const uint32_t* cstarts = bwd ? g->chunk_starts_o : g->chunk_starts;
   const int32_t* nz = bwd ? g->nz_rows_o : g->nz_rows;
   const uint32_t n_nz = bwd ? g->n_nz_o : g->n_nz;
-  if (g->n_chunks) {
-    // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
-    const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
-    const uint32_t want = (g->n_chunks + 15) / 16;
-    if (n_hot) {  // (dynamic LDS above 64 KB: opted in by init_kernels_push at graph lift)
-      const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
-      k_dense_edges<true><<<dim3(grid), dim3(1024), sizeof(double) * n_hot, g->stream>>>(
-          ci, flags, cstarts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, n_hot, gate,
-          dense_thresh);
-    } else {
-      const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
-      k_dense_edges<false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
-          ci, flags, cstarts, g->n_chunks, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, 0u, gate,
-          dense_thresh);
-    }
-    PPRHIP_CHECK_HIP(hipGetLastError());
-  }
-  // a source without in-edges still receives returned dead-end mass: one extra apply thread
+  // a source without in-edges still receives returned dead-end mass: one extra apply thread, behind the last block
   const int src_extra = (!bwd && a.src >= 0 && g->h_in_rp[a.src + 1] == g->h_in_rp[a.src]) ? 1 : 0;
-  const uint32_t grid = (n_nz + (uint32_t)src_extra + 255) / 256;
-  if (grid) {
-    DISPATCH_MODE(a.mode, k_dense_apply<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                              nz, n_nz, g->acc_nz, g->out_rp, g->in_rp, g->cdense[cbuf ^ 1], g->residue, g->reserve,
-                              g->flags, g->armed, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead, dead_slot, src_extra, a, gate,
-                              dense_thresh));
-    PPRHIP_CHECK_HIP(hipGetLastError());
+  const GsBlock whole{0u, n_nz, 0ull, (unsigned long long)g->m};
+  const GsBlock* blocks = (dl.blocks && dl.n_blocks > 1 && !bwd) ? dl.blocks : &whole;
+  const int nb = blocks == &whole ? 1 : dl.n_blocks;
+  const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
+  uint32_t part_base = 0;
+  for (int b = 0; b < nb; ++b) {
+    const GsBlock& B = blocks[b];
+    if (g->n_chunks && B.e_hi > B.e_lo) {
+      // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
+      const uint32_t c_lo = (uint32_t)(B.e_lo / kChunkEdges);
+      const uint32_t c_hi = (uint32_t)((B.e_hi + kChunkEdges - 1) / kChunkEdges);
+      const uint32_t want = (c_hi - c_lo + 15) / 16;
+      if (n_hot) {  // (dynamic LDS above 64 KB: opted in by init_kernels_push at graph lift)
+        const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
+        k_dense_edges<true><<<dim3(grid), dim3(1024), sizeof(double) * n_hot, g->stream>>>(
+            ci, flags, cstarts, c_hi, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, n_hot, c_lo, B.e_lo, B.e_hi,
+            dl.state_in);
+      } else {
+        const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
+        k_dense_edges<false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
+            ci, flags, cstarts, c_hi, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, 0u, c_lo, B.e_lo, B.e_hi,
+            dl.state_in);
+      }
+      PPRHIP_CHECK_HIP(hipGetLastError());
+    }
+    const int extra = (b == nb - 1) ? src_extra : 0;
+    const uint32_t rows = B.j_hi - B.j_lo + (uint32_t)extra;
+    const uint32_t grid = (rows + 255) / 256;
+    if (grid) {
+      DISPATCH_MODE(a.mode, k_dense_apply<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
+                                nz, B.j_lo, B.j_hi, g->acc_nz, g->out_rp, g->in_rp, g->cdense[cbuf], g->cdense[cbuf ^ 1],
+                                g->residue, g->reserve, g->flags, g->armed, g->ctr, g->blk_pack + part_base,
+                                g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot, extra, a, dl.state_in,
+                                dl.state0));
+      PPRHIP_CHECK_HIP(hipGetLastError());
+      part_base += grid;
+    }
   }
-  k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, g->blk_dead, g->blk_ndead, grid, g->ctr,
-                                                        out_slot, dead_slot ^ 1, gate, dense_thresh, hist_out);
+  k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, g->blk_dead, g->blk_ndead, part_base, g->ctr,
+                                                        out_slot, dead_slot ^ 1, dl.state_in, dl.state0, dl.hist_out,
+                                                        dl.state_out, dl.dense_thresh, dl.gs_thresh);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
 template <int G>
 static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8_t* start_flags,
-                                 const uint32_t* chunk_starts, const double* cB, double* accB) {
-  if (!g->n_chunks) return PPRHIP_OK;
+                                 const uint32_t* chunk_starts, const double* cB, double* accB, const GsBlock& B) {
+  if (!g->n_chunks || B.e_hi <= B.e_lo) return PPRHIP_OK;
   const uint32_t hot_max = (uint32_t)(kHotBytes / (8 * G));
   const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, hot_max) : 0u;
-  const uint32_t want = (g->n_chunks + 15) / 16;
+  const uint32_t c_lo = (uint32_t)(B.e_lo / kChunkEdges);
+  const uint32_t c_hi = (uint32_t)((B.e_hi + kChunkEdges - 1) / kChunkEdges);
+  const uint32_t want = (c_hi - c_lo + 15) / 16;
   const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(start_flags);
   if (n_hot) {
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
     k_dense_edges_b<true, G><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * G, g->stream>>>(
-        ci, flags64, chunk_starts, g->n_chunks, (unsigned long long)g->m, cB, accB, n_hot);
+        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, n_hot, c_lo, B.e_lo, B.e_hi);
   } else {
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
     k_dense_edges_b<false, G><<<dim3(grid), dim3(1024), 0, g->stream>>>(
-        ci, flags64, chunk_starts, g->n_chunks, (unsigned long long)g->m, cB, accB, 0u);
+        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, 0u, c_lo, B.e_lo, B.e_hi);
   }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
-int launch_dense_level_b8(pprhip_graph* P, bool backward) {
+int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_blocks, int n_gs_blocks) {
   PPRHIP_CHECK_HIP(hipMemcpyAsync(P->d_slot_args, P->h_slot_args, sizeof(SlotArgs) * kBatch, hipMemcpyHostToDevice,
                                   P->stream));
   // forward levels pull over the in-CSR, backward levels over the out-CSR
@@ -1274,15 +1330,41 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward) {
   const int32_t* zr = backward ? P->z_rows_o : P->zin_rows;
   const uint32_t n_nz = backward ? P->n_nz_o : P->n_nz, n_z = backward ? P->n_z_o : P->n_zin;
   const unsigned long long* cross = backward ? P->cross_bits_o : P->cross_bits;
-  PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8));
-  const uint32_t grid = grid_for(P->n, kApplyRows, kApplyBlocks8);
-  k_dense_apply_batch<<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(nz, n_nz, zr, n_z, P->acc8, P->out_rp,
-                                                               backward ? P->in_rp : nullptr, P->c8[P->c8cur ^ 1],
-                                                               P->d_slot_args, cross, P->prep_bits, P->blk_pack8,
-                                                               P->blk_dead8, P->blk_ndead8);
-  PPRHIP_CHECK_HIP(hipGetLastError());
-  k_dense_reduce_batch<<<dim3(kBatch), dim3(1024), 0, P->stream>>>(P->blk_pack8, P->blk_dead8, P->blk_ndead8, grid,
-                                                                   P->d_slot_args, P->sweep_out);
+  // slots whose sweep state writes the current contribution array in place; without any, one launch serves the
+  // whole sweep (Jacobi rows do not care in which order the blocks run)
+  uint32_t gs_mask = 0, entry_mask = 0;
+  for (int s = 0; s < kBatch; ++s)
+    if (P->h_slot_args[s].active) {
+      const int st = P->h_slot_args[s].gs_state;
+      if (st == kGsEntry || st == kGsInPlace || st == kGsFlush) gs_mask |= 1u << s;
+      if (st == kGsEntry) entry_mask |= 1u << s;
+    }
+  const uint32_t n_rows = n_nz + n_z;
+  const uint32_t n_tiles = (n_rows + kApplyRows - 1) / kApplyRows;
+  const GsBlock whole{0u, n_nz, 0ull, (unsigned long long)P->m};
+  const bool cut = gs_mask && gs_blocks && n_gs_blocks > 1 && !backward;
+  const GsBlock* blocks = cut ? gs_blocks : &whole;
+  const int nb = cut ? n_gs_blocks : 1;
+  uint32_t part_base = 0;
+  for (int b = 0; b < nb; ++b) {
+    const GsBlock& B = blocks[b];
+    PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8, B));
+    // block boundaries are multiples of 256 row ordinals, so tiles never straddle; the rows without in-edges
+    // follow the last block
+    const uint32_t t_lo = B.j_lo / kApplyRows;
+    const uint32_t t_hi = (b == nb - 1) ? n_tiles : B.j_hi / kApplyRows;
+    if (t_hi <= t_lo) continue;
+    const uint32_t quota = kApplyBlocks8 / (uint32_t)nb;
+    const uint32_t grid = std::max(1u, std::min(t_hi - t_lo, quota));
+    k_dense_apply_batch<<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
+        nz, n_nz, zr, n_z, P->acc8, P->out_rp, backward ? P->in_rp : nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo,
+        t_hi, gs_mask, entry_mask, P->d_slot_args, cross, P->prep_bits, P->blk_pack8, P->blk_dead8, P->blk_ndead8,
+        part_base, kApplyBlocks8);
+    PPRHIP_CHECK_HIP(hipGetLastError());
+    part_base += grid;
+  }
+  k_dense_reduce_batch<<<dim3(kBatch), dim3(1024), 0, P->stream>>>(P->blk_pack8, P->blk_dead8, P->blk_ndead8, part_base,
+                                                                   kApplyBlocks8, P->d_slot_args, P->sweep_out);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -1308,7 +1390,8 @@ int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned lo
 // block partial counts -> ctr->packed[out_slot] (reuses the dense reducer with no dead mass)
 static int reduce_partials(pprhip_graph* g, uint32_t n_blocks, int out_slot, int dead_slot, bool with_dead) {
   k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, with_dead ? g->blk_dead : nullptr, g->blk_ndead,
-                                                        n_blocks, g->ctr, out_slot, dead_slot, nullptr, 0ull, nullptr);
+                                                        n_blocks, g->ctr, out_slot, dead_slot, nullptr, kGsJacobi, nullptr,
+                                                        nullptr, 0ull, ~0ull);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

@@ -71,3 +71,22 @@ def rmat12(pkg):
 @pytest.fixture(scope="session")
 def rmat15(pkg):
     return pkg.HostCsr.rmat(15, 16, seed=1)
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _twin_follows_engine_tuning(pkg):
+    """Since the Gauss-Seidel sweeps the level shapes (dense_frac, gs_blocks, gs_frac) change the push schedule, so
+    the twin's entry points that take no tuning argument (forward_push, topk_push, fora_topk) must run with the
+    tuning the engine was given: every Graph.set_tuning in a test also sets the twin's."""
+    from oracle import oracle
+    oracle.build()
+    orig = pkg.Graph.set_tuning
+
+    def set_tuning(self, t):
+        orig(self, t)
+        oracle.set_sync_tuning(t)
+
+    pkg.Graph.set_tuning = set_tuning
+    yield
+    pkg.Graph.set_tuning = orig
+    oracle.set_sync_tuning(None)

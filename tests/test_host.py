@@ -157,7 +157,7 @@ def test_tuning_defaults_match_oracle_twin(pkg, orc):
     import ctypes
     a, b = pkg.tuning_default(), orc.tuning_default()
     assert [f for f, _ in a._fields_] == [f for f, _ in b._fields_]
-    assert ctypes.sizeof(a) == ctypes.sizeof(b) == 80          # 8 doubles + 4 int32 (include/pprhip.h, oracle/ppr_oracle.h)
+    assert ctypes.sizeof(a) == ctypes.sizeof(b) == 88          # 9 doubles + 4 int32 (include/pprhip.h, oracle/ppr_oracle.h)
     for f, _ in a._fields_:
         assert getattr(a, f) == getattr(b, f), f
     assert (a.halving_ratio, a.max_halvings, a.prior_levels) == (2.0, 6, 16)
