@@ -115,8 +115,8 @@ typedef struct pprhip_tuning {
                             * (default 16; negative: always start at rmax0) */
   int32_t gs_blocks;       /* dense sweeps run block by block (Gauss-Seidel): rows are cut into gs_blocks blocks of equal
                             * in-edge count and a block reads the contributions the blocks before it have just written
-                            * (default 4; 1: plain Jacobi sweeps) */
-  double gs_frac;          /* ... while the frontier holds at least gs_frac * m edges + nodes (default 0.25); thinner
+                            * (default 2; 1: plain Jacobi sweeps) */
+  double gs_frac;          /* ... while the frontier holds at least gs_frac * m edges + nodes (default 0.1, batch profile 0.05); thinner
                             * dense levels run as Jacobi sweeps */
 } pprhip_tuning_t;
 

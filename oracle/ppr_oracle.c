@@ -68,8 +68,8 @@ void orc_tuning_default(orc_tuning* t) {
   t->max_halvings = 6;
   t->halving_ratio = 2.0;
   t->prior_levels = 16;
-  t->gs_blocks = 4;
-  t->gs_frac = 0.25;
+  t->gs_blocks = 2;
+  t->gs_frac = 0.1;
 }
 
 /* ------------------------------------------------------------------ Philox4x32-10 */

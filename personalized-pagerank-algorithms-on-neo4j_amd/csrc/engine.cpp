@@ -827,8 +827,8 @@ void pprhip_tuning_default(pprhip_tuning_t* t) {
   t->max_halvings = 6;
   t->halving_ratio = 2.0;
   t->prior_levels = 16;
-  t->gs_blocks = 4;
-  t->gs_frac = 0.25;
+  t->gs_blocks = 2;
+  t->gs_frac = 0.1;
 }
 
 void pprhip_tuning_batch(pprhip_tuning_t* t) {
@@ -839,6 +839,7 @@ void pprhip_tuning_batch(pprhip_tuning_t* t) {
   t->c_dense_edge_ns = 0.002;
   t->c_dense_node_ns = 0.003;
   t->dense_frac = 0.02;
+  t->gs_frac = 0.05;
 }
 
 int pprhip_conf_fora_whole_graph(uint32_t n, uint64_t m, double alpha, pprhip_fora_conf_t* c) {

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
                                                       DevCounters* ctr, unsigned long long* __restrict__ blk_pack,
                                                       double* __restrict__ blk_dead, uint32_t* __restrict__ blk_ndead,
                                                       int dead_slot, int src_extra, PushArgs a,
-                                                      const int* state_in, int state0) {
+                                                      const int* state_in, int state0, int last_block) {
   // rows [j_lo, n_nz) of one block (n_nz = the block's end; + the source without in-edges behind the last block)
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
@@ -721,10 +721,13 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
       }
     }
     c_next[u] = cn;
-    // what the later blocks of this sweep read from the current array (engine.hpp: GsState)
-    if (state == kGsEntry) c_cur[u] = c_cur[u] + cn;
-    else if (state == kGsInPlace) c_cur[u] = cn;
-    else if (state == kGsFlush) c_cur[u] = 0.0;
+    // what the later blocks of this sweep read from the current array (engine.hpp: GsState); nobody reads the last
+    // block's rows again in this sweep, and the next sweep reads c_next
+    if (!last_block) {
+      if (state == kGsEntry) c_cur[u] = c_cur[u] + cn;
+      else if (state == kGsInPlace) c_cur[u] = cn;
+      else if (state == kGsFlush) c_cur[u] = 0.0;
+    }
   }
   // per-workgroup partials; k_dense_reduce sums them (no same-address atomics in this kernel)
   const double ds = block_sum_f64(dead_next, s_red);
@@ -1284,7 +1287,7 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
                                 nz, B.j_lo, B.j_hi, g->acc_nz, g->out_rp, g->in_rp, g->cdense[cbuf], g->cdense[cbuf ^ 1],
                                 g->residue, g->reserve, g->flags, g->armed, g->ctr, g->blk_pack + part_base,
                                 g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot, extra, a, dl.state_in,
-                                dl.state0));
+                                dl.state0, b == nb - 1 ? 1 : 0));
       PPRHIP_CHECK_HIP(hipGetLastError());
       part_base += grid;
     }
@@ -1350,7 +1353,8 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_bloc
     const GsBlock& B = blocks[b];
     PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8, B));
     // block boundaries are multiples of 256 row ordinals, so tiles never straddle; the rows without in-edges
-    // follow the last block
+    // follow the last block.  The last block's rows are read by nobody again in this sweep (the next sweep reads the
+    // other array), so only the blocks before it write the current array in place.
     const uint32_t t_lo = B.j_lo / kApplyRows;
     const uint32_t t_hi = (b == nb - 1) ? n_tiles : B.j_hi / kApplyRows;
     if (t_hi <= t_lo) continue;
@@ -1358,7 +1362,7 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_bloc
     const uint32_t grid = std::max(1u, std::min(t_hi - t_lo, quota));
     k_dense_apply_batch<<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
         nz, n_nz, zr, n_z, P->acc8, P->out_rp, backward ? P->in_rp : nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo,
-        t_hi, gs_mask, entry_mask, P->d_slot_args, cross, P->prep_bits, P->blk_pack8, P->blk_dead8, P->blk_ndead8,
+        t_hi, b == nb - 1 ? 0u : gs_mask, b == nb - 1 ? 0u : entry_mask, P->d_slot_args, cross, P->prep_bits, P->blk_pack8, P->blk_dead8, P->blk_ndead8,
         part_base, kApplyBlocks8);
     PPRHIP_CHECK_HIP(hipGetLastError());
     part_base += grid;

@@ -161,6 +161,7 @@ def test_tuning_defaults_match_oracle_twin(pkg, orc):
     for f, _ in a._fields_:
         assert getattr(a, f) == getattr(b, f), f
     assert (a.halving_ratio, a.max_halvings, a.prior_levels) == (2.0, 6, 16)
+    assert (a.gs_blocks, a.gs_frac) == (2, 0.1)
     t = pkg.tuning_batch()                                       # the batch profile changes the dense-level terms only
     changed = [f for f, _ in t._fields_ if getattr(t, f) != getattr(a, f)]
-    assert sorted(changed) == ["c_dense_edge_ns", "c_dense_node_ns", "dense_frac"]
+    assert sorted(changed) == ["c_dense_edge_ns", "c_dense_node_ns", "dense_frac", "gs_frac"]
