@@ -51,6 +51,8 @@ EPS = 0.5
 TOPK = 32
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured streaming copy (79 %)
+RANDOM_REQUEST_ROOF_G = 55.0  # random 64-byte requests beyond L2 per second on MI355X, measured: tools/micro/gather_rate.hip
+                              # (flat from 128 MB to 2 GB tables: Infinity Cache and HBM alike; profiles/r02_gather_rate.txt)
 
 
 def live_draw(rng, live_ids, shape):
@@ -300,8 +302,14 @@ def main():
                 r1["traffic"] = pmc["dense_pull"]
                 r1["achieved_counter"] = round(pmc["dense_pull"] / 1e9 / (r1["avg_launch_us"] / 1e6), 1)
                 r1["frac_counter"] = round(r1["achieved_counter"] / HBM_PEAK_GBS, 4)
-            if pmc.get("walk"):
-                roofline["other_kernels"].setdefault("walk", {})["traffic_per_launch"] = pmc["walk"]
+            wk = roofline["other_kernels"].get("walk")
+            if pmc.get("walk") and wk and wk.get("launches"):
+                # the walk kernel is bound by the rate of random requests that leave L2, not by bytes
+                wk["traffic_per_launch"] = pmc["walk"]
+                avg_s = wk["ms"] / 1e3 / wk["launches"]
+                wk["requests_beyond_l2_G_per_s"] = round(pmc["walk"] / 64.0 / avg_s / 1e9, 1)
+                wk["random_request_roof_G_per_s"] = RANDOM_REQUEST_ROOF_G
+                wk["frac_of_request_roof"] = round(wk["requests_beyond_l2_G_per_s"] / RANDOM_REQUEST_ROOF_G, 3)
         if world == 1 and not args.no_cpu_baseline and not args.pmc_child:
             out["cpu_baseline"] = cpu_baseline(host, srcs[args.warmup:], args.cpu_walk_divisor)
             if out["cpu_baseline"].get("value"):

@@ -531,3 +531,39 @@ def test_result_store_keeps_every_query(pkg, orc, rmat12, dev_rmat12):
             dev_rmat12.fora_batch_single_source(srcs + srcs, 0.5, ALPHA, seed=3, keep=store)
     finally:
         store.close()
+
+
+# ------------------------------------------------------------------ Gauss-Seidel sweeps
+def test_gauss_seidel_sweeps(pkg, orc, rmat15, dev_rmat15):
+    """Dense levels cut into blocks (gs_blocks = 2, 3) against plain Jacobi sweeps (gs_blocks = 1): each schedule equals
+    its twin level for level, every one of them ends in a state that meets the threshold and conserves mass, the
+    blocked schedules need fewer dense levels, and FORA on top of them keeps its bound against the CPU power method."""
+    og = to_oracle(orc, rmat15)
+    od = np.diff(rmat15.out_rp).astype(np.float64)
+    live = od > 0
+    srcs = [s for s in sources(rmat15, 12, seed=31) if od[s] > 0][:3]
+    dense = {}
+    try:
+        for B in (1, 2, 3):
+            t = pkg.tuning_batch()
+            t.gs_blocks = B
+            dev_rmat15.set_tuning(t)   # (the twin's tuning follows: conftest)
+            for s in srcs:
+                p, r, rsum, st = dev_rmat15.forward_push(s, ALPHA, 1e-8)
+                po, ro, _, sto = og.forward_push(s, ALPHA, 1e-8, orc.SYNC)
+                assert_close(p, po, TOL_PUSH, "reserve B=%d src=%d" % (B, s))
+                assert_close(r, ro, TOL_PUSH, "residue B=%d src=%d" % (B, s))
+                assert st.levels == sto.levels and st.dense_levels == sto.dense_levels
+                assert abs(p.sum() + r.sum() - 1.0) < 1e-12 and np.all(r[live] / od[live] < 1e-8)
+                dense[(B, s)] = st.dense_levels
+                est, stf = dev_rmat15.fora_single_source(s, 0.5, ALPHA, seed=3)
+                ref, stfo = og.fora_whole(s, 0.5, ALPHA, seed=3, n_rounds=0, schedule=orc.SYNC, tuning=to_orc_tuning(orc, t))
+                assert stf.walks == stfo.walks and stf.levels == stfo.levels
+                assert_close(est, ref, TOL_MC, "FORA B=%d src=%d" % (B, s))
+                pm = og.power_method(s, ALPHA, 100)
+                big = pm > 1.0 / rmat15.n
+                assert np.all(np.abs(est[big] - pm[big]) <= 0.5 * pm[big])
+        for s in srcs:
+            assert dense[(2, s)] < dense[(1, s)] and dense[(3, s)] < dense[(1, s)]
+    finally:
+        dev_rmat15.set_tuning(pkg.tuning_default())
