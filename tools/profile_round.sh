@@ -23,6 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${what}_stat
 grep -v "simple_timer\|generateRocpd\|^W2\|^E2" $out/${tag}_${what}_stats.log | tail -4
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_${what}_fetch -- python3 $prog > $out/${tag}_${what}_fetch.log 2>&1 || { echo "FETCH_SIZE run failed"; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_${what}_write -- python3 $prog > $out/${tag}_${what}_write.log 2>&1 || { echo "WRITE_SIZE run failed"; exit 1; }
-# keep what travels back small: the per-dispatch traces are large, the summaries are not
-find $out/${tag}_${what}_stats -name "*kernel_trace.csv" -size +20M -delete
+# what travels back is the condensed form (gpurun merges at most 64 MiB; the per-dispatch CSVs are ~10 MB each)
+cd $root && python3 tools/summarize_profile.py $tag $what > /dev/null && mkdir -p $out/profiles_$tag && cp profiles/${tag}_${what}_* $out/profiles_$tag/
+rm -rf $out/${tag}_${what}_stats $out/${tag}_${what}_fetch $out/${tag}_${what}_write
 echo "profiled $what"
