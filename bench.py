@@ -221,9 +221,24 @@ def main():
     if args.mode == "batch" and last:
         check = self_check(pkg, store, srcs[last["step"]], last["ids"], last["vals"], last["nsel"], last["pq"], host.n)
 
-    all_pair_scaling = None
+    all_pair_scaling, hung = None, False
     if not args.no_extras and not args.pmc_child and args.mode == "batch":
-        all_pair_scaling = all_pair_scaling_sample(pkg, g, host, dist, torch, rank, world, xdev)
+        # a collective that never returns (a rank lost, a fabric fault) must not cost the headline line: the sample
+        # runs on a watched thread and the line is printed without it if it does not come back
+        import threading
+        box = {}
+
+        def run_sample():
+            try:
+                box["res"] = all_pair_scaling_sample(pkg, g, host, dist, torch, rank, world, xdev)
+            except Exception as e:  # noqa: BLE001
+                box["res"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+        th = threading.Thread(target=run_sample, daemon=True)
+        th.start()
+        th.join(timeout=600)
+        hung = th.is_alive()
+        all_pair_scaling = {"error": "no result after 600 s"} if hung else box.get("res")
 
     if rank == 0:
         n_queries = args.steps * q * world
@@ -315,6 +330,9 @@ def main():
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_faithful"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
+    if hung:  # the watched sample never returned: its thread still holds the library; leave without tearing down
+        sys.stdout.flush()
+        os._exit(0)
     if store is not None:
         store.close()
     g.close()
