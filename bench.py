@@ -553,21 +553,30 @@ def pmc_traffic(args, host):
         v = d.get(k, [])
         return sum(v) / len(v) if v else 0.0
 
+    def per_level(keys, level_kernel):
+        """Counter bytes of one dense level: a level is several launches of the edge / apply kernels (one per
+        Gauss-Seidel block) and exactly one launch of its reduce kernel."""
+        levels = max(1, len(fetch.get(level_kernel, [])))
+        return sum(sum(fetch.get(k, [])) + sum(write.get(k, [])) for k in keys) * 1024.0 / levels
+
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this build in this run, "
                      "corrected per MI355X_MICROARCH.md (coalesced reads counted at half)"}
     cal = fetch.get("k_sum_partial", [])
     if cal:
         res["calibration"] = round(avg(fetch, "k_sum_partial") * 1024.0 / (8.0 * n), 3)
     bk = [k for k in fetch if k.startswith("k_dense_edges_b<") or k in ("k_dense_apply_batch", "k_dense_reduce_batch")]
-    if bk:
-        raw = sum(avg(fetch, k) + avg(write, k) for k in bk) * 1024.0
+    if bk and "k_dense_reduce_batch" in fetch:
+        raw = per_level(bk, "k_dense_reduce_batch")
         # coalesced reads of a sweep: column indices + row-start bits; row sums, row ids, degrees, and the busy slots'
         # residue / reserve vectors (upper bound: all 16 slots busy and every row crossing)
         streaming = 4.0 * m + m / 8.0 + (8.0 * 16 + 4.0 + 8.0 + 16.0 * 16) * n
         res["dense_pull_batch"] = int(raw + streaming / 2.0)
     sk = [k for k in fetch if k.startswith("k_dense_edges<") or k.startswith("k_dense_apply<") or k == "k_dense_reduce"]
-    if any(k.startswith("k_dense_edges<") for k in sk):
-        raw = sum(avg(fetch, k) + avg(write, k) for k in sk) * 1024.0
+    if any(k.startswith("k_dense_edges<") for k in sk) and "k_dense_reduce" in fetch:
+        # a level = one launch of the apply kernel per Gauss-Seidel block (two blocks); levels launched behind another
+        # one whose frontier had already emptied return at once and fetch next to nothing: not counted
+        levels = sum(sum(1 for x in v if x > 256.0) for k, v in fetch.items() if k.startswith("k_dense_apply<")) / 2.0
+        raw = sum(sum(fetch.get(k, [])) + sum(write.get(k, [])) for k in sk) * 1024.0 / max(1.0, levels)
         streaming = 4.0 * m + m / 8.0 + (4.0 + 8.0 + 8.0 + 8.0 + 8.0) * n
         res["dense_pull"] = int(raw + streaming / 2.0)
     if "k_mc_walk" in fetch:
