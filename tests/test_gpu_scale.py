@@ -152,3 +152,60 @@ def test_sampled_walks_match_oracle(orc, rmat20, dev20):
     term, steps = dev20.random_walks(starts, idx, A, seed=11, stream=2, no_zero_hop=True)
     for i in range(0, 2000, 7):
         assert og.random_walk(int(starts[i]), A, 11, 2, int(idx[i]), True) == (term[i], steps[i])
+
+
+# ------------------------------------------------------------------ BASELINE.json's full sizes (configs #3-#5)
+def _full_size_checks(pkg, scale, n_batch):
+    """Size-independent properties at a benchmark size: the 36-bit packed (nodes | edges) counters, the uint32 edge
+    offsets and the chunked sweep layout work on more than 2^26 edges; results conserve mass, meet the threshold,
+    repeat, and the batched entry point equals the single-query one."""
+    host = pkg.HostCsr.rmat(scale, 16, seed=1)
+    od = np.diff(host.out_rp).astype(np.float64)
+    live = od > 0
+    srcs = live_sources(host, n_batch, 40 + scale)
+    conf = pkg.conf_whole_graph(host.n, host.m, A)
+    rmax0, omega = pkg.fora_whole_params(conf, 0.5)
+    with pkg.Graph(host) as g:
+        s = srcs[0]
+        p, r, rsum, st = g.forward_push(s, A, rmax0)
+        assert abs(p.sum() + r.sum() - 1.0) < 1e-10 and abs(rsum - r.sum()) < 1e-11
+        assert np.all(r[live] / od[live] < rmax0) and np.all(r[~live] == 0.0) and p.min() >= 0.0
+        assert st.dense_levels > 0 and st.dense_edges <= st.dense_levels * host.m
+        assert st.dense_edges > (1 << 32) or scale < 22        # the sweeps served more edges than 32 bits count
+        est, st1 = g.fora_single_source(s, 0.5, A, seed=5)
+        assert abs(est.sum() - 1.0) < 1e-9 and est.min() >= 0.0
+        assert st1.walks >= int(st1.omega * st1.rsum) > 0
+        n_sel, ids, vals, kth, _ = g.topk_select(32, cap=64)
+        assert n_sel >= 32 and np.all(np.diff(vals) <= 0) and np.array_equal(est[ids], vals)
+        assert int((est >= kth).sum()) == n_sel
+        g.set_tuning(pkg.tuning_batch())
+        store = pkg.Results(g, n_batch)
+        try:
+            _, bids, bvals, nsel, pq, stb = g.fora_batch_single_source(srcs, 0.5, A, seed=5, k=32, keep=store, per_query=True)
+            assert stb.class_launches[5] > 0
+            for i in range(n_batch):
+                assert abs(store.sum(i) - 1.0) < 1e-9
+                assert np.all(np.diff(bvals[i][:min(int(nsel[i]), 32)]) <= 0)
+            v0 = store.fetch(0)
+            est_b, st_b = g.fora_single_source(s, 0.5, A, seed=5)       # same profile, one at a time
+            assert st_b.walks == pq[0].walks and st_b.levels == pq[0].levels
+            assert np.max(np.abs(v0 - est_b)) < 1e-9
+        finally:
+            store.close()
+            g.set_tuning(pkg.tuning_default())
+        t0 = host.n // 3
+        ix, sta = g.all_pair_backward(A, 1e-3, 32, t0, t0 + 2048)
+        off, tg, vl = ix.arrays()
+        assert np.all(vl >= 1e-3) and np.all((tg >= t0) & (tg < t0 + 2048)) and sta.pops >= 2048
+        ix.close()
+
+
+@pytest.mark.timeout(900)
+def test_full_size_rmat22(pkg):
+    _full_size_checks(pkg, 22, 6)
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_rmat24(pkg):
+    """config #5's graph (n = 16.7 M, m = 268 M)."""
+    _full_size_checks(pkg, 24, 3)
