@@ -167,11 +167,11 @@ def _full_size_checks(pkg, scale, n_batch):
     rmax0, omega = pkg.fora_whole_params(conf, 0.5)
     with pkg.Graph(host) as g:
         s = srcs[0]
-        p, r, rsum, st = g.forward_push(s, A, rmax0)
+        rmax = rmax0 / 32.0
+        p, r, rsum, st = g.forward_push(s, A, rmax)
         assert abs(p.sum() + r.sum() - 1.0) < 1e-10 and abs(rsum - r.sum()) < 1e-11
-        assert np.all(r[live] / od[live] < rmax0) and np.all(r[~live] == 0.0) and p.min() >= 0.0
-        assert st.dense_levels > 0 and st.dense_edges <= st.dense_levels * host.m
-        assert st.dense_edges > (1 << 32) or scale < 22        # the sweeps served more edges than 32 bits count
+        assert np.all(r[live] / od[live] < rmax) and np.all(r[~live] == 0.0) and p.min() >= 0.0
+        assert st.dense_levels > 3 and host.m < st.dense_edges <= st.dense_levels * host.m  # several sweeps' worth
         est, st1 = g.fora_single_source(s, 0.5, A, seed=5)
         assert abs(est.sum() - 1.0) < 1e-9 and est.min() >= 0.0
         assert st1.walks >= int(st1.omega * st1.rsum) > 0
