@@ -236,9 +236,10 @@ def main():
 
         th = threading.Thread(target=run_sample, daemon=True)
         th.start()
-        th.join(timeout=600)
+        limit = float(os.environ.get("PPRHIP_BENCH_WATCHDOG_S", "600"))
+        th.join(timeout=limit)
         hung = th.is_alive()
-        all_pair_scaling = {"error": "no result after 600 s"} if hung else box.get("res")
+        all_pair_scaling = {"error": "no result after %.0f s" % limit} if hung else box.get("res")
 
     if rank == 0:
         n_queries = args.steps * q * world
