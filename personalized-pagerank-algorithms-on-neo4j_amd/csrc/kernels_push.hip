@@ -24,6 +24,7 @@
 // HBM-bound integer/fp64 work: no MFMA anywhere.  All arithmetic is IEEE double with
 // -ffp-contract=off so each product / quotient rounds exactly as the reference's Java does.
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_utils.hpp"
 #include "engine.hpp"
@@ -32,6 +33,9 @@ namespace pprhip {
 
 constexpr int kPushTile = 2048;  // edges per workgroup iteration of k_sparse_push
 constexpr int kStageCap = 512;   // frontier entries staged in LDS at a time
+constexpr int kCombSlots = 2048;     // LDS table that sums a tile's contributions per destination (power of two)
+constexpr int kCombProbes = 4;       // slots tried before an edge goes to memory on its own
+constexpr int kCombMinEdges = 262144;  // levels below this many edges skip the table (no gain measured there)
 
 // A batched sparse level runs iff the level before it produced a non-empty frontier that is still
 // worth running sparse (the host took that decision itself for the first level of a batch).
@@ -155,6 +159,24 @@ __device__ __forceinline__ void push_one(int32_t u, double c, const unsigned lon
   push_finish<MODE>(u, add, old, du, in_rp, flags, armed, nl, a);
 }
 
+// Adds one edge's contribution to its destination's slot of the tile's LDS table (open addressing, a few probes);
+// false when no slot could be had, and the edge then lands on its own.
+__device__ __forceinline__ bool comb_insert(int32_t* s_key, double* s_val, int32_t u, double add) {
+  uint32_t h = ((uint32_t)u * 2654435761u) >> (32 - 11);
+  static_assert(kCombSlots == (1 << 11), "hash width follows the table size");
+#pragma unroll
+  for (int p = 0; p < kCombProbes; ++p) {
+    int32_t k = s_key[h];
+    if (k == -1) k = atomicCAS(&s_key[h], -1, u);
+    if (k == -1 || k == u) {
+      __hip_atomic_fetch_add(&s_val[h], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return true;
+    }
+    h = (h + 1) & (kCombSlots - 1);
+  }
+  return false;
+}
+
 // Appends the tile's crossings to the next frontier: one packed atomic reserves list slots and
 // the edge range, a workgroup scan turns the degrees into edge offsets.
 __device__ __forceinline__ void flush_new(NewList* nl, int32_t* __restrict__ Fn, uint32_t* __restrict__ eoffn,
@@ -199,19 +221,31 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
                                                       uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
                                                       int32_t* __restrict__ Fn,
                                                       uint32_t* __restrict__ eoffn, DevCounters* ctr, int level,
-                                                      unsigned long long dense_thresh, int dead_slot, PushArgs a) {
+                                                      unsigned long long dense_thresh, int dead_slot,
+                                                      unsigned long long comb_min, PushArgs a) {
   __shared__ uint32_t s_eoff[kStageCap + 1];
   __shared__ uint32_t s_row[kStageCap];
   __shared__ double s_c[kStageCap];
   __shared__ uint32_t s_i0;
   __shared__ NewList s_new;
+  __shared__ int32_t s_key[kCombSlots];
+  __shared__ double s_val[kCombSlots];
   const int tid = threadIdx.x;
   const unsigned long long pk = ctr->hist[level];
   if (!level_runs(pk, level, dense_thresh)) return;
   const uint32_t nf = (uint32_t)(pk >> kPackShift);
   const unsigned long long E = pk & kPackMask;
   unsigned long long* out_counter = &ctr->hist[level + 1];
+  // Levels with enough edges to repeat destinations (hubs collect a large share of any R-MAT frontier's edges) sum
+  // a tile's contributions per destination in LDS first, so a destination costs one returning global atomic and one
+  // degree gather per tile instead of one per edge; small levels go straight to memory.
+  const bool combine = E >= comb_min;
   if (tid == 0) s_new.count = 0;
+  if (combine)
+    for (int j = tid; j < kCombSlots; j += 256) {
+      s_key[j] = -1;
+      s_val[j] = 0.0;
+    }
   __syncthreads();
 
   if (MODE != kBackward && blockIdx.x == 0) {
@@ -278,11 +312,22 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
             add[q] = s_c[j];
           }
         }
+        if (MODE == kBackward || !combine) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) du[q] = valid[q] ? (uint32_t)(out_ext[u[q]] >> 32) : 1u;
-        if (MODE == kBackward) {
+          for (int q = 0; q < 4; ++q) du[q] = valid[q] ? (uint32_t)(out_ext[u[q]] >> 32) : 1u;
+        }
+        if (MODE == kBackward) {  // every edge's quotient rounds on its own (Backward_Search.java:84-85)
 #pragma unroll
           for (int q = 0; q < 4; ++q) add[q] = add[q] / (double)du[q];
+        }
+        if (combine) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (valid[q] && comb_insert(s_key, s_val, u[q], add[q])) valid[q] = false;  // lands with its slot
+          if (MODE != kBackward) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) du[q] = valid[q] ? (uint32_t)(out_ext[u[q]] >> 32) : 1u;  // table full
+          }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -296,6 +341,33 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
       __syncthreads();
       ce = cov_hi;
       ci0 += cnt;
+    }
+    if (combine) {
+      // the tile's per-destination sums land: four slots per thread in flight, slots left empty for the next tile
+      for (int j0 = tid; j0 < kCombSlots; j0 += 1024) {
+        int32_t u[4];
+        double add[4], old[4];
+        uint32_t du[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u[q] = s_key[j0 + 256 * q];
+          add[q] = s_val[j0 + 256 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) du[q] = u[q] >= 0 ? (uint32_t)(out_ext[u[q]] >> 32) : 1u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          old[q] = 0.0;
+          if (u[q] >= 0) {
+            old[q] = atomic_add_ret(&res[u[q]], add[q]);
+            s_key[j0 + 256 * q] = -1;
+            s_val[j0 + 256 * q] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (u[q] >= 0) push_finish<MODE>(u[q], add[q], old[q], du[q], in_rp, flags, armed, &s_new, a);
+      }
     }
     flush_new(&s_new, Fn, eoffn, out_counter);
   }
@@ -1236,9 +1308,12 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
   const bool bwd = a.mode == kBackward;
   const uint32_t* trp = bwd ? g->in_rp : g->out_rp;
   const int32_t* tci = bwd ? g->in_ci : g->out_ci;
+  static const unsigned long long comb_min =
+      getenv("PPRHIP_COMB_MIN_EDGES") ? strtoull(getenv("PPRHIP_COMB_MIN_EDGES"), nullptr, 10) : kCombMinEdges;
   DISPATCH_MODE(a.mode, k_sparse_push<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
                             g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_ext, g->in_rp, g->residue, g->flags,
-                            g->armed, g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot, a));
+                            g->armed, g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot,
+                            comb_min, a));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
