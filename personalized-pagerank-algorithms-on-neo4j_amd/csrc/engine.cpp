@@ -135,6 +135,141 @@ const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks) {
   return H->gs_plan.data();
 }
 
+// Windows of the sliced layout (engine.hpp: SlicedLayout) for a sweep cut into the row blocks `blocks` (nullptr: one
+// block, every row): per block, for every slice, the edges of the block's rows in that slice; neighbouring ranges are
+// joined.  Cached per block count (the blocks of a count are always the same, gs_blocks_of).
+static std::mutex g_sl_plan_mu;
+const EdgeWindows* sliced_windows_of(pprhip_graph* g, const GsBlock* blocks, int nb) {
+  pprhip_graph* H = g->parent ? g->parent : g;
+  SlicedLayout* L = H->sl;
+  std::lock_guard<std::mutex> lock(g_sl_plan_mu);
+  if (L->plan_B == nb) return L->plan.data();
+  const GsBlock whole{0u, H->n_nz, 0ull, (unsigned long long)H->m};
+  if (!blocks || nb <= 1) {
+    blocks = &whole;
+    nb = 1;
+  }
+  L->plan.assign((size_t)nb, EdgeWindows{});
+  for (int b = 0; b < nb; ++b) {
+    EdgeWindows& W = L->plan[b];
+    W.n = 0;
+    for (int sl = 0; sl < L->S; ++sl) {
+      const uint32_t* lo = L->h_seg_row.data() + L->seg_base[sl];
+      const uint32_t* hi = L->h_seg_row.data() + L->seg_base[sl + 1];
+      const size_t g_lo = (size_t)(std::lower_bound(lo, hi, blocks[b].j_lo) - L->h_seg_row.data());
+      const size_t g_hi = (size_t)(std::lower_bound(lo, hi, blocks[b].j_hi) - L->h_seg_row.data());
+      const unsigned long long e_lo = g_lo < L->seg_base[sl + 1] ? L->h_seg_off[g_lo] : L->edge_base[sl + 1];
+      const unsigned long long e_hi = g_hi < L->seg_base[sl + 1] ? L->h_seg_off[g_hi] : L->edge_base[sl + 1];
+      if (e_hi <= e_lo) continue;
+      if (W.n && W.e_hi[W.n - 1] == e_lo) {
+        W.e_hi[W.n - 1] = e_hi;
+      } else {
+        W.e_lo[W.n] = e_lo;
+        W.e_hi[W.n] = e_hi;
+        W.n++;
+      }
+    }
+    W.c_pre[0] = 0;
+    for (uint32_t w = 0; w < W.n; ++w) {
+      W.c_lo[w] = (uint32_t)(W.e_lo[w] / kChunkPad);
+      const uint32_t c_hi = (uint32_t)((W.e_hi[w] + kChunkPad - 1) / kChunkPad);
+      W.c_pre[w + 1] = W.c_pre[w] + (c_hi - W.c_lo[w]);
+    }
+  }
+  L->plan_B = nb;
+  return L->plan.data();
+}
+
+// Builds the sliced copy of the (internal-order) in-CSR.  Slices are ranges of `width` source ids over the ids that
+// have out-edges (the first n_src ids of the out-degree order); no layout when they fit one slice.
+static int build_sliced_layout(pprhip_graph* G, const std::vector<int32_t>& in_ci) {
+  const uint32_t n = G->n;
+  const uint64_t m = G->m;
+  const char* off = getenv("PPRHIP_SLICED");
+  if (off && off[0] == '0') return PPRHIP_OK;
+  uint32_t n_src = n;
+  if (G->relabeled) {
+    n_src = 0;
+    while (n_src < n && G->h_out_rp[n_src + 1] > G->h_out_rp[n_src]) ++n_src;
+  }
+  const char* env = getenv("PPRHIP_SLICE_IDS");
+  uint64_t width = env ? strtoull(env, nullptr, 10) : 393216ull;  // 3 MB of contributions per slice
+  if (width < 1) width = 1;
+  uint64_t S = ((uint64_t)n_src + width - 1) / width;
+  if (S < 2 || m == 0 || G->n_nz == 0) return PPRHIP_OK;
+  if (S > (uint64_t)kMaxWindows) {
+    S = kMaxWindows;
+    width = ((uint64_t)n_src + S - 1) / S;
+  }
+  std::unique_ptr<SlicedLayout> L(new (std::nothrow) SlicedLayout());
+  if (!L) return PPRHIP_ERR_OOM;
+  L->S = (int)S;
+  L->width = (uint32_t)width;
+  const std::vector<uint32_t>& irp = G->h_in_rp;
+  const std::vector<int32_t>& rows = G->h_nz_rows;
+  auto slice_of = [&](int32_t u) {
+    const uint64_t q = (uint64_t)(uint32_t)u / width;
+    return (size_t)(q < S ? q : S - 1);
+  };
+  std::vector<uint64_t> ecnt(S, 0), scnt(S, 0);
+  std::vector<uint32_t> last(S, 0xffffffffu);
+  for (size_t j = 0; j < rows.size(); ++j) {
+    const uint32_t v = (uint32_t)rows[j];
+    for (uint32_t e = irp[v]; e < irp[v + 1]; ++e) {
+      const size_t q = slice_of(in_ci[e]);
+      ecnt[q]++;
+      if (last[q] != (uint32_t)j) {
+        last[q] = (uint32_t)j;
+        scnt[q]++;
+      }
+    }
+  }
+  L->edge_base.assign(S + 1, 0);
+  L->seg_base.assign(S + 1, 0);
+  for (size_t q = 0; q < S; ++q) {
+    L->edge_base[q + 1] = L->edge_base[q] + ecnt[q];
+    L->seg_base[q + 1] = L->seg_base[q] + scnt[q];
+  }
+  if (L->seg_base[S] >= 0xffffffffull) return PPRHIP_OK;  // segment ordinals are 32-bit: keep the row-major sweep
+  L->n_seg = (uint32_t)L->seg_base[S];
+  const size_t n_chunks = ((size_t)m + kChunkPad - 1) / kChunkPad;
+  std::vector<int32_t> ci(((size_t)m + kChunkPad - 1) / kChunkPad * kChunkPad + kChunkPad, 0);
+  std::vector<uint8_t> flags((n_chunks + 1) * (kChunkPad / 8), 0);
+  std::vector<uint32_t> chunk_starts(n_chunks + 1, 0);
+  L->h_seg_row.resize(L->n_seg);
+  L->h_seg_off.resize(L->n_seg);
+  std::vector<uint64_t> epos(L->edge_base.begin(), L->edge_base.end() - 1), spos(L->seg_base.begin(), L->seg_base.end() - 1);
+  std::fill(last.begin(), last.end(), 0xffffffffu);
+  for (size_t j = 0; j < rows.size(); ++j) {
+    const uint32_t v = (uint32_t)rows[j];
+    for (uint32_t e = irp[v]; e < irp[v + 1]; ++e) {
+      const size_t q = slice_of(in_ci[e]);
+      const uint64_t w = epos[q]++;
+      ci[w] = in_ci[e];
+      if (last[q] != (uint32_t)j) {
+        last[q] = (uint32_t)j;
+        const uint64_t sg = spos[q]++;
+        L->h_seg_row[sg] = (uint32_t)j;
+        L->h_seg_off[sg] = (uint32_t)w;
+        flags[w >> 3] |= (uint8_t)(1u << (w & 7));
+        chunk_starts[(size_t)w / kChunkPad + 1]++;
+      }
+    }
+  }
+  for (size_t c = 1; c <= n_chunks; ++c) chunk_starts[c] += chunk_starts[c - 1];
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+    PPRHIP_TRY(alloc_dev(dst, bytes));
+    if (bytes) PPRHIP_CHECK_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return PPRHIP_OK;
+  };
+  G->sl = L.release();  // from here on pprhip_graph_destroy frees what has been allocated
+  PPRHIP_TRY(up((void**)&G->sl->ci, ci.data(), sizeof(int32_t) * ci.size()));
+  PPRHIP_TRY(up((void**)&G->sl->flags, flags.data(), flags.size()));
+  PPRHIP_TRY(up((void**)&G->sl->chunk_starts, chunk_starts.data(), sizeof(uint32_t) * chunk_starts.size()));
+  PPRHIP_TRY(up((void**)&G->sl->seg_row, G->sl->h_seg_row.data(), sizeof(uint32_t) * G->sl->h_seg_row.size()));
+  return PPRHIP_OK;
+}
+
 int write_hist0(pprhip_graph* g, uint32_t nf, uint64_t ef) {
   g->h_ctr->hist[0] = ((unsigned long long)nf << kPackShift) | ef;
   PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long),
@@ -470,6 +605,7 @@ int build_batch(pprhip_graph* P) {
     S->n_chunks = P->n_chunks;
     S->nz_rows = P->nz_rows;
     S->n_nz = P->n_nz;
+    S->sl = P->sl;
     S->tun = P->tun;
     PPRHIP_TRY(alloc_workspace(S));
   }
@@ -521,7 +657,9 @@ int ensure_bwd_layout(pprhip_graph* P) {
   std::vector<int32_t> nz, zr;
   for (uint32_t v = 0; v < n; ++v) {
     if (rp[v + 1] == rp[v]) {
-      zr.push_back((int32_t)v);
+      // a row that never receives; it can still hold a contribution of its own when it is a search's target, which
+      // only matters to rows that pull from it - so rows that nobody points to are left out of the sweep altogether
+      if (P->h_in_rp[v + 1] > P->h_in_rp[v]) zr.push_back((int32_t)v);
       continue;
     }
     nz.push_back((int32_t)v);
@@ -1051,14 +1189,19 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
   if ((rc = up((void**)&G->start_flags, flags.data(), flags.size()))) return fail(rc);
   if ((rc = up((void**)&G->chunk_starts, chunk_starts.data(), sizeof(uint32_t) * chunk_starts.size()))) return fail(rc);
   if ((rc = up((void**)&G->nz_rows, nz_rows.data(), sizeof(int32_t) * nz_rows.size()))) return fail(rc);
+  if ((rc = build_sliced_layout(G, n_in_ci))) return fail(rc);
   if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) {
     set_error("hipStreamCreate failed");
     return fail(PPRHIP_ERR_HIP);
   }
   {
+    // Rows without in-edges never receive mass, so the only contribution such a row can hold is its own when it is
+    // a query's source - and a dead-end's contribution is zero (Forward_Push.java:101-104).  The batched sweep
+    // therefore carries the rows without in-edges that have out-edges and leaves the isolated ones (43 % of an
+    // R-MAT 22's nodes) out: their entries of the contribution arrays are never written and stay zero.
     std::vector<int32_t> zin;
     for (uint32_t v = 0; v < n; ++v)
-      if (irp[v + 1] == irp[v]) zin.push_back((int32_t)v);
+      if (irp[v + 1] == irp[v] && G->h_out_rp[v + 1] > G->h_out_rp[v]) zin.push_back((int32_t)v);
     G->n_zin = (uint32_t)zin.size();
     if ((rc = up((void**)&G->zin_rows, zin.data(), sizeof(int32_t) * zin.size()))) return fail(rc);
     std::vector<unsigned long long> cross(((size_t)n + 63) / 64 + 1, 0ull);
@@ -1090,6 +1233,13 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
                   g->nz_rows_o, g->z_rows_o, g->cross_bits_o};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (g->sl) {
+    void* sp[] = {g->sl->ci, g->sl->flags, g->sl->chunk_starts, g->sl->seg_row};
+    for (void* p : sp)
+      if (p) (void)hipFree(p);
+    delete g->sl;
+    g->sl = nullptr;
+  }
   free_workspace(g);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;

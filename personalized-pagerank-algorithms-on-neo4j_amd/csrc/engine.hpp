@@ -49,6 +49,38 @@ struct GsBlock {
   unsigned long long e_lo, e_hi;
 };
 
+// Edge ranges one launch of the single-query edge kernel walks, as 512-edge chunks in a virtual order: window w holds
+// the chunks c_lo[w] + (vc - c_pre[w]) for vc in [c_pre[w], c_pre[w + 1]); edges of a boundary chunk outside
+// [e_lo[w], e_hi[w]) count as zero (a neighbouring window or block sums them).
+constexpr int kMaxWindows = 16;
+struct EdgeWindows {
+  uint32_t n;
+  uint32_t c_pre[kMaxWindows + 1];
+  uint32_t c_lo[kMaxWindows];
+  unsigned long long e_lo[kMaxWindows], e_hi[kMaxWindows];
+};
+
+// Sliced copy of the in-CSR for the single-query sweep.  A gather of one 8-byte contribution costs a whole memory
+// request, and the rate of requests that leave L2 bounds the sweep (tools/micro/gather_rate.hip: 55 G/s on a 34 MB
+// table, 250 G/s on a 4 MB one).  So the in-edges are kept a second time sorted by (slice of the source id, row):
+// the sweep walks slice after slice, and while a slice is being walked the contributions it gathers - `width`
+// consecutive ids, a few MB - stay in every XCD's L2.  A row's edges inside one slice form a *segment*; segment sums
+// are added to the row's accumulator (seg_row: segment -> row ordinal), so a row receives one add per slice it has
+// sources in.  Built at graph lift when the sources span more than one slice.
+struct SlicedLayout {
+  int S = 0;                         // slices
+  uint32_t width = 0;                // source ids per slice
+  int32_t* ci = nullptr;             // [m padded] source ids, slice-major
+  uint8_t* flags = nullptr;          // bit e: edge e is the first of its segment
+  uint32_t* chunk_starts = nullptr;  // segments that start before each 512-edge chunk
+  uint32_t* seg_row = nullptr;       // [segments] row ordinal (index into nz_rows / acc_nz)
+  uint32_t n_seg = 0;
+  std::vector<uint64_t> edge_base, seg_base;   // [S + 1] first edge / segment of every slice
+  std::vector<uint32_t> h_seg_row, h_seg_off;  // host: row ordinal and first edge of every segment
+  std::vector<EdgeWindows> plan;               // windows of every Gauss-Seidel block for plan_B blocks
+  int plan_B = -1;
+};
+
 enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
 
 struct PushArgs {
@@ -191,6 +223,7 @@ struct pprhip_graph {
   std::vector<pprhip::GsBlock> gs_plan;   // blocks of the forward sweep for gs_plan_B blocks (built on demand)
   int gs_plan_B = 0;
   double* acc_nz = nullptr;  // per non-empty row: sum of this level's contributions
+  pprhip::SlicedLayout* sl = nullptr;  // single-query sweep layout (owned by the lifted graph, borrowed by slots)
   // batched queries: kBatch workspaces ("slots") borrow this handle's CSR and stream; their dense
   // levels run as one sweep over the interleaved contribution array c8[v][slot]
   pprhip_graph* parent = nullptr;  // set on a slot
@@ -281,6 +314,10 @@ struct DenseLaunch {
 };
 int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slot, int dead_slot,
                        const DenseLaunch& d = DenseLaunch());
+namespace detail {
+// engine.cpp: the sliced layout's edge windows of every block (nullptr / 1: the whole sweep)
+const EdgeWindows* sliced_windows_of(pprhip_graph* g, const GsBlock* blocks, int nb);
+}
 constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply kernel (per-slot partials each)
 // slot arguments already staged in parent->h_slot_args; blocks: Gauss-Seidel blocks (nullptr / 1: one launch)
 int launch_dense_level_b8(pprhip_graph* parent, bool backward, const pprhip::GsBlock* blocks = nullptr, int n_blocks = 1);

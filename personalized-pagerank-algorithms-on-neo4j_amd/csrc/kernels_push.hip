@@ -407,25 +407,42 @@ __device__ __forceinline__ ChunkRegs load_chunk(const int32_t* __restrict__ in_c
   return r;
 }
 
-template <bool HOT>
+// Window of a chunk in the launch's virtual order (engine.hpp: EdgeWindows); w only moves forward.
+__device__ __forceinline__ uint32_t window_chunk(const EdgeWindows& W, uint32_t vc, uint32_t* w) {
+  uint32_t x = *w;
+  while (x + 1 < W.n && vc >= W.c_pre[x + 1]) ++x;
+  *w = x;
+  return W.c_lo[x] + (vc - W.c_pre[x]);
+}
+
+// SLICED: the edge arrays are the sliced copy (engine.hpp: SlicedLayout): a flag starts a *segment*, seg_row maps it
+// to its row ordinal, and every segment sum is added to the row's accumulator with an fp64 atomic (a row has one
+// segment per slice; k_dense_apply leaves the accumulators zero).  Otherwise segments are rows and a row that starts
+// and ends inside a chunk is stored.
+template <bool HOT, bool SLICED>
 __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict__ in_ci,
                                                        const uint8_t* __restrict__ start_flags,
-                                                       const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
-                                                       unsigned long long m, const double* __restrict__ c_cur,
+                                                       const uint32_t* __restrict__ chunk_starts,
+                                                       const uint32_t* __restrict__ seg_row, EdgeWindows W,
+                                                       const double* __restrict__ c_cur,
                                                        double* __restrict__ acc_nz, uint32_t n_hot,
-                                                       uint32_t c_lo, unsigned long long e_lo, unsigned long long e_hi,
                                                        const int* state_in) {
-  // One block of a sweep: the chunks [c_lo, n_chunks) that hold the in-edges [e_lo, e_hi) of the block's rows (the
-  // whole CSR when the sweep is not cut into blocks).  Edges of a boundary chunk that belong to a neighbouring block
-  // count as zero: that block's own launch sums them.
+  // One block of a sweep: the chunks that hold the in-edges of the block's rows (the whole CSR when the sweep is not
+  // cut into blocks), as a list of windows.  Edges of a boundary chunk outside the window count as zero: the launch
+  // (or window) they belong to sums them.
   extern __shared__ __attribute__((aligned(16))) double s_hot[];
   if (dense_state(state_in, kGsJacobi) == kGsNone) return;
   const int lane = lane_id();
   const uint32_t waves_per_block = blockDim.x >> 6;
   const uint32_t stride = gridDim.x * waves_per_block;
-  uint32_t c = c_lo + blockIdx.x * waves_per_block + (uint32_t)wave_id();
+  const uint32_t total = W.c_pre[W.n];
+  uint32_t vc = blockIdx.x * waves_per_block + (uint32_t)__builtin_amdgcn_readfirstlane(wave_id());
+  uint32_t w = 0, c = 0;
   ChunkRegs cur;
-  if (c < n_chunks) cur = load_chunk(in_ci, start_flags, c, lane);  // in flight while the hot table loads
+  if (vc < total) {
+    c = window_chunk(W, vc, &w);
+    cur = load_chunk(in_ci, start_flags, c, lane);  // in flight while the hot table loads
+  }
   if (HOT) {
     // 16 values per thread, loaded in one batch
     double t[16];
@@ -441,11 +458,15 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
     }
     __syncthreads();
   }
-  for (; c < n_chunks; c += stride) {
+  for (; vc < total; vc += stride) {
     // next chunk's indices are requested before this chunk's gathers, so their latency is hidden
     ChunkRegs nxt = cur;
-    const uint32_t cn = c + stride;
-    if (cn < n_chunks) nxt = load_chunk(in_ci, start_flags, cn, lane);
+    uint32_t wn = w, cn = c;
+    if (vc + stride < total) {
+      cn = window_chunk(W, vc + stride, &wn);
+      nxt = load_chunk(in_ci, start_flags, cn, lane);
+    }
+    const unsigned long long e_lo = W.e_lo[w], e_hi = W.e_hi[w];
     const uint32_t cs = chunk_starts[c];
     const unsigned long long e0 = (unsigned long long)c * kChunkEdges + 8ull * lane;
     const uint32_t fb = cur.fb;
@@ -480,10 +501,13 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if ((fb >> i) & 1u) {
-        if (k == 0)
-          first_seg = seg;               // closes the row carried in from earlier lanes
-        else
+        if (k == 0) {
+          first_seg = seg;  // closes the row carried in from earlier lanes
+        } else if (SLICED) {
+          if (seg != 0.0) atomic_add_noret(&acc_nz[seg_row[before + k - 1]], seg);
+        } else {
           acc_nz[before + k - 1] = seg;  // a row that starts and ends inside this lane
+        }
         seg = 0.0;
         ++k;
       }
@@ -498,19 +522,24 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
       // the row that ends at this lane's first start flag: edges carried in + this lane's head
       const bool nonempty = lane > 0 || (fb & 1u) == 0;
       if (nonempty && before > 0) {
-        const double total = carry + first_seg;
+        const double tot = carry + first_seg;
         const bool started_here = (hmask & ((1ull << lane) - 1ull)) != 0;  // an earlier lane starts a row
-        if (started_here)
-          acc_nz[before - 1] = total;
-        else
-          atomic_add_noret(&acc_nz[before - 1], total);  // began in an earlier chunk
+        if (SLICED) {
+          if (tot != 0.0) atomic_add_noret(&acc_nz[seg_row[before - 1]], tot);
+        } else if (started_here) {
+          acc_nz[before - 1] = tot;
+        } else {
+          atomic_add_noret(&acc_nz[before - 1], tot);  // began in an earlier chunk
+        }
       }
     }
     if (lane == 63) {  // the row still open at the end of the chunk
       const uint32_t starts = cs + incl;
-      if (starts > 0 && sval != 0.0) atomic_add_noret(&acc_nz[starts - 1], sval);
+      if (starts > 0 && sval != 0.0) atomic_add_noret(&acc_nz[SLICED ? seg_row[starts - 1] : starts - 1], sval);
     }
     cur = nxt;
+    w = wn;
+    c = cn;
   }
 }
 
@@ -812,9 +841,10 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
   }
 }
 
-// k_dense_apply_batch: the batched form of k_dense_apply.  Rows without in-edges are included (their
-// contribution for the next level is written as 0, or holds the source's returned dead-end mass),
-// so the sweep rewrites every entry of c8_next and a column a slot has left stays all-zero.
+// k_dense_apply_batch: the batched form of k_dense_apply.  Rows without in-edges that can be a query's source
+// (those with out-edges) are included: their contribution for the next level is written as 0, or holds the source's
+// returned dead-end mass.  So the sweep rewrites every entry of c8_next that can ever be non-zero (isolated nodes'
+// entries are never written and stay zero) and a column a slot has left stays all-zero.
 // A workgroup takes 64 rows at a time through an LDS tile [row][slot]: row sums come in and next
 // contributions go out in the interleaved layout (whole 128-byte lines), while the per-slot
 // residue / reserve vectors are walked with a lane per row, i.e. coalesced as in the single-query
@@ -1332,26 +1362,48 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   const GsBlock whole{0u, n_nz, 0ull, (unsigned long long)g->m};
   const GsBlock* blocks = (dl.blocks && dl.n_blocks > 1 && !bwd) ? dl.blocks : &whole;
   const int nb = blocks == &whole ? 1 : dl.n_blocks;
-  const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
+  static const uint32_t hot_cap = getenv("PPRHIP_HOT_IDS") ? (uint32_t)atoi(getenv("PPRHIP_HOT_IDS")) : (uint32_t)kHotMax;
+  static const uint32_t wgs_per_cu = getenv("PPRHIP_EDGE_WGS") ? (uint32_t)atoi(getenv("PPRHIP_EDGE_WGS")) : 0u;
+  const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, hot_cap) : 0u;
+  // forward sweeps of a graph whose sources span several slices walk the sliced copy of the in-CSR
+  const SlicedLayout* sl = bwd ? nullptr : g->sl;
+  const EdgeWindows* wins = sl ? detail::sliced_windows_of(g, blocks == &whole ? nullptr : blocks, nb) : nullptr;
+  if (sl) {
+    ci = sl->ci;
+    flags = sl->flags;
+    cstarts = sl->chunk_starts;
+  }
   uint32_t part_base = 0;
   for (int b = 0; b < nb; ++b) {
     const GsBlock& B = blocks[b];
-    if (g->n_chunks && B.e_hi > B.e_lo) {
+    EdgeWindows one;
+    if (!sl) {
+      one.n = 1;
+      one.c_pre[0] = 0;
+      one.c_lo[0] = (uint32_t)(B.e_lo / kChunkEdges);
+      one.c_pre[1] = (uint32_t)((B.e_hi + kChunkEdges - 1) / kChunkEdges) - one.c_lo[0];
+      one.e_lo[0] = B.e_lo;
+      one.e_hi[0] = B.e_hi;
+    }
+    const EdgeWindows& W = sl ? wins[b] : one;
+    const uint32_t n_ch = W.n ? W.c_pre[W.n] : 0u;
+    if (g->n_chunks && n_ch) {
       // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
-      const uint32_t c_lo = (uint32_t)(B.e_lo / kChunkEdges);
-      const uint32_t c_hi = (uint32_t)((B.e_hi + kChunkEdges - 1) / kChunkEdges);
-      const uint32_t want = (c_hi - c_lo + 15) / 16;
-      if (n_hot) {  // (dynamic LDS above 64 KB: opted in by init_kernels_push at graph lift)
-        const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
-        k_dense_edges<true><<<dim3(grid), dim3(1024), sizeof(double) * n_hot, g->stream>>>(
-            ci, flags, cstarts, c_hi, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, n_hot, c_lo, B.e_lo, B.e_hi,
-            dl.state_in);
-      } else {
-        const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
-        k_dense_edges<false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
-            ci, flags, cstarts, c_hi, (unsigned long long)g->m, g->cdense[cbuf], g->acc_nz, 0u, c_lo, B.e_lo, B.e_hi,
-            dl.state_in);
-      }
+      const uint32_t want = (n_ch + 15) / 16;
+      const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * (wgs_per_cu ? wgs_per_cu : (n_hot ? 1u : 2u)));
+      const size_t lds = n_hot ? sizeof(double) * n_hot : 0;  // (above 64 KB: opted in by init_kernels_push)
+      if (n_hot && sl)
+        k_dense_edges<true, true><<<dim3(grid), dim3(1024), lds, g->stream>>>(
+            ci, flags, cstarts, sl->seg_row, W, g->cdense[cbuf], g->acc_nz, n_hot, dl.state_in);
+      else if (n_hot)
+        k_dense_edges<true, false><<<dim3(grid), dim3(1024), lds, g->stream>>>(
+            ci, flags, cstarts, nullptr, W, g->cdense[cbuf], g->acc_nz, n_hot, dl.state_in);
+      else if (sl)
+        k_dense_edges<false, true><<<dim3(grid), dim3(1024), 0, g->stream>>>(
+            ci, flags, cstarts, sl->seg_row, W, g->cdense[cbuf], g->acc_nz, 0u, dl.state_in);
+      else
+        k_dense_edges<false, false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
+            ci, flags, cstarts, nullptr, W, g->cdense[cbuf], g->acc_nz, 0u, dl.state_in);
       PPRHIP_CHECK_HIP(hipGetLastError());
     }
     const int extra = (b == nb - 1) ? src_extra : 0;
@@ -1452,9 +1504,11 @@ int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned lo
   const uint32_t grid = grid_for(g->n, 1024, 1024);
   if (g->parent) {
     pprhip_graph* P = g->parent;
-    const uint32_t n_tiles = (P->n + kApplyRows - 1) / kApplyRows;
+    // the rows the batched sweep carries (launch_dense_level_b8): one bit each, per slot
+    const uint32_t n_rows = backward ? P->n_nz_o + P->n_z_o : P->n_nz + P->n_zin;
+    const uint32_t n_tiles = (n_rows + kApplyRows - 1) / kApplyRows;
     k_compact_bits<<<dim3(grid), dim3(256), 0, g->stream>>>(
-        P->n, backward ? P->n_nz_o : P->n_nz, P->prep_bits + (size_t)g->slot_index * n_tiles,
+        n_rows, backward ? P->n_nz_o : P->n_nz, P->prep_bits + (size_t)g->slot_index * n_tiles,
         backward ? P->nz_rows_o : P->nz_rows, backward ? P->z_rows_o : P->zin_rows, cview(g, cbuf),
         backward ? g->in_rp : g->out_rp, g->F[out_fbuf], g->eoff[out_fbuf], g->cF, d_counter);
   } else {
@@ -1530,7 +1584,9 @@ int launch_permute_out(pprhip_graph* g, const double* x, double* out) {
 // Current device: code object loaded, large dynamic LDS opted in (above 64 KB it needs an explicit opt-in per
 // device).  Called once per device under the graph-lift lock (engine.cpp), never from a launch path.
 int init_kernels_push() {
-  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true>),
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
