@@ -80,7 +80,9 @@ double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense) 
   return t.c_level_ns + t.c_edge_ns * (double)ef + t.c_pop_ns * (double)nf;
 }
 
-uint64_t dense_level_bytes(const pprhip_graph* g) { return 12ull * g->m + 36ull * g->n + 4ull; }
+// SURVEY 8(d) sweep model, 12 m + 36 n + 4, with n = the rows the sweep carries: rows without in-edges receive
+// nothing and are not touched by the single-query sweep (the power method counts the same rows)
+uint64_t dense_level_bytes(const pprhip_graph* g) { return 12ull * g->m + 36ull * host_of(g)->n_nz + 4ull; }
 
 // modelled cost of a dense sweep (level_cost's dense branch): also what a sweep costs that only runs because the
 // contribution array has to be flushed
@@ -180,18 +182,15 @@ const EdgeWindows* sliced_windows_of(pprhip_graph* g, const GsBlock* blocks, int
   return L->plan.data();
 }
 
-// Builds the sliced copy of the (internal-order) in-CSR.  Slices are ranges of `width` source ids over the ids that
-// have out-edges (the first n_src ids of the out-degree order); no layout when they fit one slice.
+// Builds the sliced copy of the (internal-order) in-CSR.  Slices are ranges of `width` source ids up to the last id
+// that has out-edges; no layout when they fit one slice.
 static int build_sliced_layout(pprhip_graph* G, const std::vector<int32_t>& in_ci) {
   const uint32_t n = G->n;
   const uint64_t m = G->m;
   const char* off = getenv("PPRHIP_SLICED");
   if (off && off[0] == '0') return PPRHIP_OK;
-  uint32_t n_src = n;
-  if (G->relabeled) {
-    n_src = 0;
-    while (n_src < n && G->h_out_rp[n_src + 1] > G->h_out_rp[n_src]) ++n_src;
-  }
+  uint32_t n_src = n;  // ids above the last node with out-edges are never gathered
+  while (n_src > 0 && G->h_out_rp[n_src] == G->h_out_rp[n_src - 1]) --n_src;
   const char* env = getenv("PPRHIP_SLICE_IDS");
   uint64_t width = env ? strtoull(env, nullptr, 10) : 393216ull;  // 3 MB of contributions per slice
   if (width < 1) width = 1;
@@ -1104,16 +1103,23 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
       g->n_cus = prop.multiProcessorCount;
   }
 
-  // ---- internal vertex order: out-degree descending, ties by original id (PPRHIP_RELABEL=0 keeps ids)
+  // ---- internal vertex order: nodes with in-edges first, then out-degree descending, ties by original id
+  // (PPRHIP_RELABEL=0 keeps ids).  The rows a sweep applies (nodes with in-edges) are then the ids [0, n_nz): their
+  // residue / reserve / contribution entries are contiguous and every line a sweep touches is used in full; inside
+  // that range the most-gathered contributions (highest out-degree) still come first (hot table, slices).
   const char* env = getenv("PPRHIP_RELABEL");
   g->relabeled = !(env && env[0] == '0');
   g->h_new2old.resize(n);
   g->h_old2new.resize(n);
   std::iota(g->h_new2old.begin(), g->h_new2old.end(), 0);
-  if (g->relabeled)
+  if (g->relabeled) {
+    std::vector<uint8_t> no_in((size_t)n, 1);
+    for (uint64_t e = 0; e < m; ++e) no_in[out_ci[e]] = 0;
     std::stable_sort(g->h_new2old.begin(), g->h_new2old.end(), [&](int32_t x, int32_t y) {
+      if (no_in[x] != no_in[y]) return no_in[x] < no_in[y];
       return out_rp[x + 1] - out_rp[x] > out_rp[y + 1] - out_rp[y];
     });
+  }
   for (uint32_t v = 0; v < n; ++v) g->h_old2new[g->h_new2old[v]] = (int32_t)v;
   const std::vector<int32_t>& o2n = g->h_old2new;
   // rows move, entries are renamed, the order inside a row is kept (walks index rows by position)

@@ -208,7 +208,7 @@ struct pprhip_graph {
   unsigned long long* out_ext = nullptr;  // per vertex: out row begin | out-degree << 32 (one gather instead of two)
   int32_t *out_ci = nullptr, *in_ci = nullptr;
   std::vector<uint32_t> h_out_rp, h_in_rp;  // host copies for degree checks on the call path
-  // internal vertex order: ids sorted by out-degree (descending) so that the contributions the
+  // internal vertex order: nodes with in-edges first, then by out-degree (descending), so that the contributions the
   // dense sweep gathers most often sit next to each other; the C ABI speaks original ids
   bool relabeled = false;
   int32_t *new2old = nullptr, *old2new = nullptr;

@@ -422,10 +422,12 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
       PPRHIP_CHECK_HIP(hipStreamWaitEvent(P->stream, S->ev[3], 0));
     }
   }
-  const uint64_t sweep_bytes = 4ull * P->m + (uint64_t)n_active * (8ull * P->m + 36ull * P->n + 4ull);
   bool backward = false;
   for (int s = 0; s < kBatch; ++s)
     if (active[s] && runs[s].a.mode == kBackward) backward = true;  // a job's runs all push the same way
+  // SURVEY 8(d) sweep model with n = the rows the sweep carries (launch_dense_level_b8: isolated nodes are left out)
+  const uint64_t rows = backward ? (uint64_t)P->n_nz_o + P->n_z_o : (uint64_t)P->n_nz + P->n_zin;
+  const uint64_t sweep_bytes = 4ull * P->m + (uint64_t)n_active * (8ull * P->m + 36ull * rows + 4ull);
   if ((int)backward != P->acc8_dir) {
     // rows summed with atomics are cleared by the apply kernel of their own layout only: start clean
     PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * ((size_t)P->n + 1) * kBatch, P->stream));
@@ -445,7 +447,7 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
       ForaRun& r = runs[s];
       const unsigned long long pk = P->h_sweep_out[s];
       // the sweep's index stream is shared: each query is charged its own gathers and row work
-      finish_dense(r.L, r.st, 8ull * P->m + 36ull * P->n + 4ull + 4ull * P->m / (uint64_t)n_active,
+      finish_dense(r.L, r.st, 8ull * P->m + 36ull * rows + 4ull + 4ull * P->m / (uint64_t)n_active,
                    (uint32_t)(pk >> kPackShift), pk & kPackMask);
     }
   return PPRHIP_OK;
