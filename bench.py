@@ -51,8 +51,10 @@ EPS = 0.5
 TOPK = 32
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured streaming copy (79 %)
-RANDOM_REQUEST_ROOF_G = 55.0  # random 64-byte requests beyond L2 per second on MI355X, measured: tools/micro/gather_rate.hip
-                              # (flat from 128 MB to 2 GB tables: Infinity Cache and HBM alike; profiles/r02_gather_rate.txt)
+RANDOM_REQUEST_ROOF_G = 55.0  # random requests beyond L2 per second on MI355X, measured: tools/micro/gather_rate.hip (8-byte
+                              # gathers) and row_gather_rate.hip (rows up to 128 bytes: 52-55 G/s, flat from 128 MB to 2 GB
+                              # tables).  Every such request moves a 128-byte line (profiles/r02_fetch_calibration.txt), so
+                              # this roof is 6.7-7 TB/s of line traffic: the HBM roof met at line granularity.
 
 
 def live_draw(rng, live_ids, shape):
@@ -320,10 +322,13 @@ def main():
                 r1["frac_counter"] = round(r1["achieved_counter"] / HBM_PEAK_GBS, 4)
             wk = roofline["other_kernels"].get("walk")
             if pmc.get("walk") and wk and wk.get("launches"):
-                # the walk kernel is bound by the rate of random requests that leave L2, not by bytes
+                # the walk kernel's gathers use 4-8 bytes of every 128-byte line they move: bound by lines, not by
+                # algorithmic bytes (writes are a twentieth of its traffic and counted with the lines here)
                 wk["traffic_per_launch"] = pmc["walk"]
                 avg_s = wk["ms"] / 1e3 / wk["launches"]
-                wk["requests_beyond_l2_G_per_s"] = round(pmc["walk"] / 64.0 / avg_s / 1e9, 1)
+                wk["achieved_counter"] = round(pmc["walk"] / 1e9 / avg_s, 1)
+                wk["frac_counter"] = round(wk["achieved_counter"] / HBM_PEAK_GBS, 4)
+                wk["requests_beyond_l2_G_per_s"] = round(pmc["walk"] / 128.0 / avg_s / 1e9, 1)
                 wk["random_request_roof_G_per_s"] = RANDOM_REQUEST_ROOF_G
                 wk["frac_of_request_roof"] = round(wk["requests_beyond_l2_G_per_s"] / RANDOM_REQUEST_ROOF_G, 3)
         if world == 1 and not args.no_cpu_baseline and not args.pmc_child:
@@ -535,9 +540,11 @@ def _pmc_pass(counter, args, workdir):
 def pmc_traffic(args, host):
     """HBM-side bytes per launch of the dominant kernel classes, measured on this build in this run: FETCH_SIZE and
     WRITE_SIZE in separate passes (they do not fit one pass on gfx950), KB units, and the guide's gfx950 correction:
-    FETCH_SIZE counts a wide coalesced stream at half its size (re-checked on k_sum_partial, which reads exactly
-    8n bytes) while 64-/128-byte gathers are counted in full, so
-    corrected = FETCH_SIZE + (known coalesced read bytes) / 2 + WRITE_SIZE."""
+    FETCH_SIZE = TCC_EA0_RDREQ x 64 B while every memory-side read request of this chip is 128 bytes - a coalesced
+    stream and a random gather alike (profiles/r02_fetch_calibration.txt: TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ for row
+    gathers of 8 ... 512 bytes; FETCH_SIZE = 0.498 of the bytes of 128-byte rows; an 8-byte gather moves 128).  The
+    factor is re-measured in every run on k_sum_partial, which reads exactly 8n bytes:
+    bytes = FETCH_SIZE x 1024 x (8n / FETCH_SIZE(k_sum_partial)) + WRITE_SIZE x 1024."""
     if shutil.which("rocprofv3") is None:
         return {"source": "unmeasured: rocprofv3 not on PATH"}
     work = tempfile.mkdtemp(prefix="pprhip_pmc_", dir="/tmp")
@@ -548,40 +555,39 @@ def pmc_traffic(args, host):
         shutil.rmtree(work, ignore_errors=True)
         return {"source": "unmeasured: %s" % str(e)[:200]}
     shutil.rmtree(work, ignore_errors=True)
-    n, m = host.n, host.m
+    n = host.n
 
     def avg(d, k):
         v = d.get(k, [])
         return sum(v) / len(v) if v else 0.0
 
-    def per_level(keys, level_kernel):
-        """Counter bytes of one dense level: a level is several launches of the edge / apply kernels (one per
-        Gauss-Seidel block) and exactly one launch of its reduce kernel."""
-        levels = max(1, len(fetch.get(level_kernel, [])))
-        return sum(sum(fetch.get(k, [])) + sum(write.get(k, [])) for k in keys) * 1024.0 / levels
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this build in this run; read bytes = "
+                     "FETCH_SIZE x the factor measured on k_sum_partial (every memory-side read request is 128 bytes, "
+                     "tallied at 64: MI355X_MICROARCH.md, profiles/r02_fetch_calibration.txt)"}
+    factor = 2.0
+    if fetch.get("k_sum_partial"):
+        ratio = avg(fetch, "k_sum_partial") * 1024.0 / (8.0 * n)
+        res["calibration"] = round(ratio, 3)
+        if 0.4 < ratio < 1.1:
+            factor = 1.0 / ratio
 
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this build in this run, "
-                     "corrected per MI355X_MICROARCH.md (coalesced reads counted at half)"}
-    cal = fetch.get("k_sum_partial", [])
-    if cal:
-        res["calibration"] = round(avg(fetch, "k_sum_partial") * 1024.0 / (8.0 * n), 3)
+    def level_bytes(keys, levels):
+        rd = sum(sum(fetch.get(k, [])) for k in keys) * 1024.0 * factor
+        wr = sum(sum(write.get(k, [])) for k in keys) * 1024.0
+        return int((rd + wr) / max(1.0, levels))
+
+    # a dense level = several launches of the edge / apply kernels (one per Gauss-Seidel block) + one reduce launch
     bk = [k for k in fetch if k.startswith("k_dense_edges_b<") or k in ("k_dense_apply_batch", "k_dense_reduce_batch")]
     if bk and "k_dense_reduce_batch" in fetch:
-        raw = per_level(bk, "k_dense_reduce_batch")
-        # coalesced reads of a sweep: column indices + row-start bits; row sums, row ids, degrees, and the busy slots'
-        # residue / reserve vectors (upper bound: all 16 slots busy and every row crossing)
-        streaming = 4.0 * m + m / 8.0 + (8.0 * 16 + 4.0 + 8.0 + 16.0 * 16) * n
-        res["dense_pull_batch"] = int(raw + streaming / 2.0)
+        res["dense_pull_batch"] = level_bytes(bk, len(fetch["k_dense_reduce_batch"]))
     sk = [k for k in fetch if k.startswith("k_dense_edges<") or k.startswith("k_dense_apply<") or k == "k_dense_reduce"]
     if any(k.startswith("k_dense_edges<") for k in sk) and "k_dense_reduce" in fetch:
-        # a level = one launch of the apply kernel per Gauss-Seidel block (two blocks); levels launched behind another
-        # one whose frontier had already emptied return at once and fetch next to nothing: not counted
+        # levels launched behind another one whose frontier had already emptied return at once and fetch next to
+        # nothing: not counted (a counted level = one apply launch per Gauss-Seidel block, two blocks)
         levels = sum(sum(1 for x in v if x > 256.0) for k, v in fetch.items() if k.startswith("k_dense_apply<")) / 2.0
-        raw = sum(sum(fetch.get(k, [])) + sum(write.get(k, [])) for k in sk) * 1024.0 / max(1.0, levels)
-        streaming = 4.0 * m + m / 8.0 + (4.0 + 8.0 + 8.0 + 8.0 + 8.0) * n
-        res["dense_pull"] = int(raw + streaming / 2.0)
+        res["dense_pull"] = level_bytes(sk, levels)
     if "k_mc_walk" in fetch:
-        res["walk"] = int((avg(fetch, "k_mc_walk") + avg(write, "k_mc_walk")) * 1024.0)
+        res["walk"] = int(avg(fetch, "k_mc_walk") * 1024.0 * factor + avg(write, "k_mc_walk") * 1024.0)
     return res
 
 

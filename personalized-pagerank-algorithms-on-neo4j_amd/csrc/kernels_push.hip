@@ -1362,9 +1362,7 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   const GsBlock whole{0u, n_nz, 0ull, (unsigned long long)g->m};
   const GsBlock* blocks = (dl.blocks && dl.n_blocks > 1 && !bwd) ? dl.blocks : &whole;
   const int nb = blocks == &whole ? 1 : dl.n_blocks;
-  static const uint32_t hot_cap = getenv("PPRHIP_HOT_IDS") ? (uint32_t)atoi(getenv("PPRHIP_HOT_IDS")) : (uint32_t)kHotMax;
-  static const uint32_t wgs_per_cu = getenv("PPRHIP_EDGE_WGS") ? (uint32_t)atoi(getenv("PPRHIP_EDGE_WGS")) : 0u;
-  const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, hot_cap) : 0u;
+  const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
   // forward sweeps of a graph whose sources span several slices walk the sliced copy of the in-CSR
   const SlicedLayout* sl = bwd ? nullptr : g->sl;
   const EdgeWindows* wins = sl ? detail::sliced_windows_of(g, blocks == &whole ? nullptr : blocks, nb) : nullptr;
@@ -1390,7 +1388,7 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     if (g->n_chunks && n_ch) {
       // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
       const uint32_t want = (n_ch + 15) / 16;
-      const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * (wgs_per_cu ? wgs_per_cu : (n_hot ? 1u : 2u)));
+      const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * (n_hot ? 1u : 2u));
       const size_t lds = n_hot ? sizeof(double) * n_hot : 0;  // (above 64 KB: opted in by init_kernels_push)
       if (n_hot && sl)
         k_dense_edges<true, true><<<dim3(grid), dim3(1024), lds, g->stream>>>(

@@ -8,10 +8,11 @@ For every workload it reads gpurun_out/<tag>_<workload>_{stats,fetch,write}/ and
                                                `--pmc` passes and what follows from them.
 
 Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KB and are
-collected in separate passes (they do not fit one pass on gfx950); FETCH_SIZE = TCC_EA0_RDREQ x 64 B counts a wide
-coalesced read at half its size (re-checked here on k_sum_partial, which streams exactly 8n bytes) while 64- and
-128-byte gathers are counted in full.  So for gather-bound kernels FETCH_SIZE x 1024 / 64 is the number of requests
-that left L2, the quantity that bounds them (tools/micro/gather_rate.hip: about 55 G such requests per second).
+collected in separate passes (they do not fit one pass on gfx950); FETCH_SIZE = TCC_EA0_RDREQ x 64 B, while every
+memory-side read request of gfx950 is 128 bytes, coalesced stream and random gather alike
+(profiles/r02_fetch_calibration.txt; re-checked here on k_sum_partial, which streams exactly 8n bytes).  So
+FETCH_SIZE x 1024 / 64 is the number of 128-byte lines that left L2 and read bytes = 2 x FETCH_SIZE; about 52-55 G
+random lines per second is what the chip delivers (tools/micro/gather_rate.hip, row_gather_rate.hip) = 6.7-7 TB/s.
 """
 import collections
 import csv
@@ -61,21 +62,23 @@ def summarize(tag, what):
              "Command: `rocprofv3 --kernel-trace --stats -- %s`; PMC passes `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, "
              "each its own run (tools/profile_round.sh).  R-MAT scale 22 (n = 4 194 304, m = 67 108 864)."
              % COMMANDS.get(what, what), "",
-             "| kernel | calls | total ms | avg us | % | FETCH_SIZE avg KB | WRITE_SIZE avg KB | requests beyond L2 per s |",
-             "|---|---|---|---|---|---|---|---|"]
+             "| kernel | calls | total ms | avg us | % | FETCH_SIZE avg KB | WRITE_SIZE avg KB | 128-B lines beyond L2 per s | HBM-side GB/s (2 x FETCH + WRITE) |",
+             "|---|---|---|---|---|---|---|---|---|"]
     for r in stats:
         k = short(r["Name"])
         f, w = fetch.get(k, []), write.get(k, [])
         avg_us = float(r["AverageNs"]) / 1e3
         fk = sum(f) / len(f) if f else None
         req = "%.1f G" % (fk * 1024.0 / 64.0 / (avg_us * 1e-6) / 1e9) if fk and avg_us > 0 else "-"
-        lines.append("| %s | %s | %.3f | %.1f | %s | %s | %s | %s |" % (
+        wk = sum(w) / len(w) if w else None
+        gbs = "%.0f" % ((2.0 * (fk or 0.0) + (wk or 0.0)) * 1024.0 / (avg_us * 1e-6) / 1e9) if (fk or wk) and avg_us > 0 else "-"
+        lines.append("| %s | %s | %.3f | %.1f | %s | %s | %s | %s | %s |" % (
             k, r["Calls"], float(r["TotalDurationNs"]) / 1e6, avg_us, r["Percentage"],
-            "%.0f" % fk if fk is not None else "-", "%.0f" % (sum(w) / len(w)) if w else "-", req))
+            "%.0f" % fk if fk is not None else "-", "%.0f" % wk if wk is not None else "-", req, gbs))
     cal = fetch.get("k_sum_partial", [])
     if cal:
         lines += ["", "Calibration: `k_sum_partial` streams exactly 8n = %d bytes; FETCH_SIZE reports %.0f KB = %.3f of it "
-                  "(the guide's gfx950 half-count of coalesced reads)." % (8 * n, sum(cal) / len(cal),
+                  "(128-byte requests tallied at 64: the guide's gfx950 correction)." % (8 * n, sum(cal) / len(cal),
                                                                           sum(cal) / len(cal) * 1024.0 / (8.0 * n))]
     open(os.path.join(ROOT, "profiles", "%s_%s_summary.md" % (tag, what)), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:16]))
