@@ -596,6 +596,7 @@ int build_batch(pprhip_graph* P) {
     S->out_ext = P->out_ext;
     S->out_ci = P->out_ci;
     S->in_ci = P->in_ci;
+    S->walk_rec = P->walk_rec;
     S->relabeled = P->relabeled;
     S->new2old = P->new2old;
     S->old2new = P->old2new;
@@ -1220,6 +1221,8 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
     }
     if ((rc = up((void**)&G->cross_bits, cross.data(), sizeof(unsigned long long) * cross.size()))) return fail(rc);
   }
+  if ((rc = alloc_dev((void**)&G->walk_rec, sizeof(uint4) * (size_t)m))) return fail(rc);
+  if ((rc = launch_build_walk_rec(G))) return fail(rc);
   if ((rc = alloc_workspace(G))) return fail(rc);
   if (hipStreamSynchronize(G->stream) != hipSuccess) {
     set_error("stream sync after graph upload failed");
@@ -1234,7 +1237,7 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   free_batch(g);
-  void* ptrs[] = {g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags,
+  void* ptrs[] = {g->walk_rec, g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags,
                   g->chunk_starts, g->nz_rows, g->zin_rows, g->cross_bits, g->start_flags_o, g->chunk_starts_o,
                   g->nz_rows_o, g->z_rows_o, g->cross_bits_o};
   for (void* p : ptrs)

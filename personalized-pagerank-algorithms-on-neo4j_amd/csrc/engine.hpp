@@ -207,6 +207,7 @@ struct pprhip_graph {
   uint32_t *out_rp = nullptr, *in_rp = nullptr;
   unsigned long long* out_ext = nullptr;  // per vertex: out row begin | out-degree << 32 (one gather instead of two)
   int32_t *out_ci = nullptr, *in_ci = nullptr;
+  uint4* walk_rec = nullptr;  // per out-edge {neighbour, its first out-edge, its out-degree, 0}: one gather per walk step
   std::vector<uint32_t> h_out_rp, h_in_rp;  // host copies for degree checks on the call path
   // internal vertex order: nodes with in-edges first, then by out-degree (descending), so that the contributions the
   // dense sweep gathers most often sit next to each other; the C ABI speaks original ids
@@ -337,6 +338,7 @@ int init_kernels_select();
 int init_kernels_apbs();
 
 // ---- kernels_walk.hip
+int launch_build_walk_rec(pprhip_graph* g);
 int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double* target);
 int launch_mc_walk(pprhip_graph* g, uint64_t n_sources, uint64_t n_walks, double alpha, uint64_t seed, uint32_t stream,
                    int no_zero_hop, double* target);

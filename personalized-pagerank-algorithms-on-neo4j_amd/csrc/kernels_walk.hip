@@ -42,12 +42,16 @@ struct Walker {
   uint32_t w_stop, w_pick, w_stop2, w_pick2;  // cached Philox block
   uint32_t moves;
   bool forced;         // the next decision is the forced first hop (no_zero_hop)
+  uint32_t b, d;       // out-row of the current node: first edge, degree
+  uint32_t sb, sd;     // the same for the start node
 };
 
-__device__ __forceinline__ void walker_init(Walker& w, int32_t start, int32_t start_orig, unsigned long long idx,
-                                            uint32_t stream, bool no_zero_hop) {
+__device__ __forceinline__ void walker_init(Walker& w, int32_t start, unsigned long long start_ext, int32_t start_orig,
+                                            unsigned long long idx, uint32_t stream, bool no_zero_hop) {
   w.start = start;
   w.cur = start;
+  w.b = w.sb = (uint32_t)start_ext;
+  w.d = w.sd = (uint32_t)(start_ext >> 32);
   w.c0 = (uint32_t)start_orig;
   w.c1 = (uint32_t)idx;
   w.c2 = (uint32_t)((idx >> 32) & 0xFFFFu) | (stream << 16);
@@ -57,8 +61,10 @@ __device__ __forceinline__ void walker_init(Walker& w, int32_t start, int32_t st
 }
 
 // Returns true when the walk has stopped (w.cur is the terminal).
-__device__ __forceinline__ bool walker_step(Walker& w, const unsigned long long* __restrict__ out_ext,
-                                            const int32_t* __restrict__ out_ci, double alpha, uint32_t k0,
+// A step reads one 16-byte edge record {neighbour, the neighbour's first out-edge, its out-degree}: the row extent
+// the *next* step needs comes with the neighbour's id, so a step costs one random line instead of two (the extent
+// array was the second: 0.24 lines per step beyond L2 on R-MAT 22).
+__device__ __forceinline__ bool walker_step(Walker& w, const uint4* __restrict__ walk_rec, double alpha, uint32_t k0,
                                             uint32_t k1) {
   uint32_t ws, wp;
   if ((w.k & 1u) == 0) {
@@ -76,12 +82,16 @@ __device__ __forceinline__ bool walker_step(Walker& w, const unsigned long long*
     if ((double)ws * (1.0 / 4294967296.0) < alpha) return true;  // Monte_Carlo.java:76-78
   }
   w.forced = false;
-  const unsigned long long ext = out_ext[w.cur];  // row begin | out-degree << 32: one 8-byte gather per step
-  const uint32_t b = (uint32_t)ext, d = (uint32_t)(ext >> 32);
-  if (d > 0)
-    w.cur = out_ci[b + (uint32_t)(((unsigned long long)wp * d) >> 32)];  // :81-86
-  else
-    w.cur = w.start;  // :87-90 dead end: restart at the walk's start node
+  if (w.d > 0) {
+    const uint4 r = walk_rec[w.b + (uint32_t)(((unsigned long long)wp * w.d) >> 32)];  // :81-86
+    w.cur = (int32_t)r.x;
+    w.b = r.y;
+    w.d = r.z;
+  } else {  // :87-90 dead end: restart at the walk's start node
+    w.cur = w.start;
+    w.b = w.sb;
+    w.d = w.sd;
+  }
   w.moves++;
   return false;
 }
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
                                                   const double* __restrict__ mc_inc,
                                                   const unsigned long long* __restrict__ mc_woff,
                                                   const unsigned long long* __restrict__ out_ext,
-                                                  const int32_t* __restrict__ out_ci,
+                                                  const uint4* __restrict__ walk_rec,
                                                   const int32_t* __restrict__ new2old, double* __restrict__ target,
                                                   double alpha, uint32_t k0, uint32_t k1, uint32_t stream,
                                                   int no_zero_hop, DevCounters* ctr) {
@@ -211,8 +221,9 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
           const uint32_t j = a - 1;
           const int32_t start = s_node[j];
           inc = s_inc[j];
-          walker_init(w, start, new2old[start], gidx - s_woff[j], stream, no_zero_hop != 0);
-          if ((out_ext[start] >> 32) == 0) {
+          const unsigned long long sext = out_ext[start];
+          walker_init(w, start, sext, new2old[start], gidx - s_woff[j], stream, no_zero_hop != 0);
+          if ((sext >> 32) == 0) {
             atomic_add_noret(&target[start], inc);  // Monte_Carlo.java:70-72 / :106-108
           } else {
             walking = true;
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
         continue;
       }
       if (walking) {
-        if (walker_step(w, out_ext, out_ci, alpha, k0, k1)) {
+        if (walker_step(w, walk_rec, alpha, k0, k1)) {
           atomic_add_noret(&target[w.cur], inc);
           steps_total += w.moves;
           walking = false;
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(256) void k_walk_batch(const int32_t* __restrict__ 
                                                      const unsigned long long* __restrict__ idx,
                                                      unsigned long long count,
                                                      const unsigned long long* __restrict__ out_ext,
-                                                     const int32_t* __restrict__ out_ci,
+                                                     const uint4* __restrict__ walk_rec,
                                                      const int32_t* __restrict__ new2old, double alpha, uint32_t k0,
                                                      uint32_t k1, uint32_t stream, int no_zero_hop,
                                                      int32_t* __restrict__ term, uint32_t* __restrict__ steps) {
@@ -252,13 +263,26 @@ __global__ __launch_bounds__(256) void k_walk_batch(const int32_t* __restrict__ 
        i += (unsigned long long)gridDim.x * blockDim.x) {
     const int32_t s = starts[i];
     Walker w;
-    walker_init(w, s, new2old[s], idx[i], stream, no_zero_hop != 0);
-    if ((out_ext[s] >> 32) != 0) {
-      while (!walker_step(w, out_ext, out_ci, alpha, k0, k1)) {
+    const unsigned long long sext = out_ext[s];
+    walker_init(w, s, sext, new2old[s], idx[i], stream, no_zero_hop != 0);
+    if ((sext >> 32) != 0) {
+      while (!walker_step(w, walk_rec, alpha, k0, k1)) {
       }
     }
     term[i] = w.cur;
     if (steps) steps[i] = w.moves;
+  }
+}
+
+// edge records of the walk kernel, built once at graph lift
+__global__ __launch_bounds__(256) void k_build_walk_rec(unsigned long long m, const int32_t* __restrict__ out_ci,
+                                                         const unsigned long long* __restrict__ out_ext,
+                                                         uint4* __restrict__ walk_rec) {
+  for (unsigned long long e = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; e < m;
+       e += (unsigned long long)gridDim.x * blockDim.x) {
+    const int32_t u = out_ci[e];
+    const unsigned long long ext = out_ext[u];
+    walk_rec[e] = make_uint4((uint32_t)u, (uint32_t)ext, (uint32_t)(ext >> 32), 0u);
   }
 }
 
@@ -274,6 +298,14 @@ __global__ void k_plan_single(int32_t src, double inc, int32_t* mc_node, double*
 int init_kernels_walk() {  // loads this file's code object on the current device (see init_kernels_push)
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_mc_walk)));
+  return PPRHIP_OK;
+}
+
+int launch_build_walk_rec(pprhip_graph* g) {
+  if (g->m == 0) return PPRHIP_OK;
+  hipLaunchKernelGGL(k_build_walk_rec, dim3(4096), dim3(256), 0, g->stream, (unsigned long long)g->m, g->out_ci,
+                     g->out_ext, reinterpret_cast<uint4*>(g->walk_rec));
+  PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
@@ -296,7 +328,7 @@ int launch_mc_walk(pprhip_graph* g, uint64_t n_sources, uint64_t n_walks, double
   uint64_t chunks = (n_walks + kWalkChunk - 1) / kWalkChunk;
   const uint32_t grid = (uint32_t)(chunks > (1u << 22) ? (1u << 22) : chunks);  // one chunk per workgroup: the dispatcher balances
   hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(256), 0, g->stream, (uint32_t)n_sources,
-                     (unsigned long long)n_walks, g->mc_node, g->mc_inc, g->mc_woff, g->out_ext, g->out_ci, g->new2old, target, alpha,
+                     (unsigned long long)n_walks, g->mc_node, g->mc_inc, g->mc_woff, g->out_ext, g->walk_rec, g->new2old, target, alpha,
                      (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, g->ctr);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
@@ -308,7 +340,7 @@ int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* 
   uint64_t b = (count + 255) / 256;
   const uint32_t grid = (uint32_t)(b > 4096 ? 4096 : b);
   hipLaunchKernelGGL(k_walk_batch, dim3(grid), dim3(256), 0, g->stream, d_starts,
-                     (const unsigned long long*)d_idx, (unsigned long long)count, g->out_ext, g->out_ci, g->new2old, alpha,
+                     (const unsigned long long*)d_idx, (unsigned long long)count, g->out_ext, g->walk_rec, g->new2old, alpha,
                      (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, d_term, d_steps);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
