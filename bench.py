@@ -20,7 +20,8 @@ check prints no line.
 N > 1 (one process per GPU, launched by torch.distributed.run): the CSR is replicated, every rank runs its own
 batch per step (weak scaling, no data-path collective) and the per-step top-k blocks are gathered to rank 0 over
 RCCL; `all_pair_scaling` reports the path's other workload, All-Pair-Backward-Search over all n targets, at the same
-N (strong scaling; the exchange by owner of the source runs inside the library over RCCL).
+N (strong scaling; the exchange by owner of the source runs inside the library over RCCL; every rank's share runs in
+a watched child process, so a collective that hangs or faults costs that sample, not the line).
 
 Extra objects on the JSON line: `roofline` (dominant kernel class: HIP-event time on the engine's stream,
 algorithmic bytes from DESIGN.md's byte model, HBM traffic from two `rocprofv3 --pmc` passes of this same build
@@ -97,10 +98,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the one-query-at-a-time, top-k and All-Pair samples")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--all-pair-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-walk-divisor", type=int, default=32)
     ap.add_argument("--tuning", default="", help="cost-model overrides, e.g. c_dense_edge_ns=0.002,max_rounds=30")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
+    if args.all_pair_child:
+        return all_pair_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -223,25 +227,9 @@ def main():
     if args.mode == "batch" and last:
         check = self_check(pkg, store, srcs[last["step"]], last["ids"], last["vals"], last["nsel"], last["pq"], host.n)
 
-    all_pair_scaling, hung = None, False
+    all_pair_scaling = None
     if not args.no_extras and not args.pmc_child and args.mode == "batch":
-        # a collective that never returns (a rank lost, a fabric fault) must not cost the headline line: the sample
-        # runs on a watched thread and the line is printed without it if it does not come back
-        import threading
-        box = {}
-
-        def run_sample():
-            try:
-                box["res"] = all_pair_scaling_sample(pkg, g, host, dist, torch, rank, world, xdev)
-            except Exception as e:  # noqa: BLE001
-                box["res"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-
-        th = threading.Thread(target=run_sample, daemon=True)
-        th.start()
-        limit = float(os.environ.get("PPRHIP_BENCH_WATCHDOG_S", "600"))
-        th.join(timeout=limit)
-        hung = th.is_alive()
-        all_pair_scaling = {"error": "no result after %.0f s" % limit} if hung else box.get("res")
+        all_pair_scaling = all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xdev)
 
     if rank == 0:
         n_queries = args.steps * q * world
@@ -336,9 +324,6 @@ def main():
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_faithful"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if hung:  # the watched sample never returned: its thread still holds the library; leave without tearing down
-        sys.stdout.flush()
-        os._exit(0)
     if store is not None:
         store.close()
     g.close()
@@ -455,60 +440,95 @@ def all_pair_sample(pkg, g, host):
                                  "dependent gathers and LDS atomics, not by HBM streaming"}}
 
 
-def all_pair_scaling_sample(pkg, g, host, dist, torch, rank, world, xdev):
-    """All-Pair-Backward-Search over ALL n targets of the graph (config #5's shape; threshold 1e-3, k = 32) on `world`
-    GPUs: strong scaling of the whole job.  Rank r searches the targets of its contiguous range, the entries are
-    partitioned by owner of their source on the device and exchanged over RCCL inside the library
-    (pprhip_all_pair_backward_sharded: one message per peer, one PCIe crossing per entry, at its owner), and every
-    rank finalises the rows of its own sources.  Time = max over ranks, barrier to barrier."""
-    g.set_tuning(pkg.tuning_default())
+def _quiet_stdout(fn):
+    """Runs fn with file descriptor 1 pointed at stderr: RCCL prints a version banner on stdout when it is first
+    used, and this file's stdout is one JSON line."""
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
     try:
-        uid = [pkg.comm_unique_id() if rank == 0 else None]
-    finally:
-        os.dup2(saved, 1)
-        os.close(saved)
-    if world > 1:
-        dist.broadcast_object_list(uid, src=0)
-    # RCCL prints a version banner on stdout when its first communicator comes up; this file's stdout is one JSON line
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        comm = pkg.Comm(g, uid[0], rank, world)  # collective (ncclCommInitRank)
+        return fn()
     finally:
         sys.stdout.flush()
         os.dup2(saved, 1)
         os.close(saved)
-    lo, hi = pkg.shard_target_range(rank, world, host.n)
-    ix, _ = g.all_pair_backward(ALPHA, 1e-3, TOPK, lo, min(hi, lo + 1024))  # warm-up of the kernels
-    ix.close()
+
+
+def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xdev):
+    """All-Pair-Backward-Search over ALL n targets of the graph (config #5's shape; threshold 1e-3, k = 32) on `world`
+    GPUs: strong scaling of the whole job.  Rank r searches the targets of its contiguous range, the entries are
+    partitioned by owner of their source on the device and exchanged over RCCL inside the library
+    (pprhip_all_pair_backward_sharded: one message per peer, one PCIe crossing per entry, at its owner), and every
+    rank finalises the rows of its own sources.  Time = max over ranks.
+
+    Every rank runs its share in a child process of its own (this file with --all-pair-child: own graph replica, own
+    RCCL communicator from the id rank 0 made here): a collective that never returns or a fault inside it (a rank
+    lost, a fabric error) then costs this sample, not the headline line - the child is killed at the limit and the
+    line carries the error instead."""
+    uid = [_quiet_stdout(pkg.comm_unique_id).hex() if rank == 0 else None]
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    own, st = comm.all_pair_backward_sharded(ALPHA, 1e-3, TOPK)
-    t_all = time.perf_counter() - t0
-    n_own = int(len(own.arrays()[1]))
-    stats = torch.tensor([t_all, st.total_ms / 1e3, float(st.mc_sources), float(st.select_bytes), float(n_own)],
-                         dtype=torch.float64, device=xdev)
+        dist.broadcast_object_list(uid, src=0)
+    limit = float(os.environ.get("PPRHIP_BENCH_WATCHDOG_S", "600"))
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), PPRHIP_COMM_ID=uid[0])
+    cmd = [sys.executable, os.path.abspath(__file__), "--all-pair-child", "--scale", str(args.scale)]
+    res, err = None, None
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        out, errtxt = child.communicate(timeout=limit)
+        lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
+        if child.returncode == 0 and lines:
+            res = json.loads(lines[-1])
+            if "error" in res:
+                err, res = res["error"], None
+        else:
+            err = "child of rank %d exited with code %s: %s" % (rank, child.returncode, errtxt.decode(errors="replace")[-300:])
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        err = "no result from rank %d's child after %.0f s" % (rank, limit)
+    # t_all, search seconds, entries found, bytes received, entries kept; a failed rank poisons the sample
+    vals = [res["seconds"], res["search_seconds"], res["entries_found"], res["bytes_received"], res["entries_kept"]] \
+        if res else [0.0] * 5
+    stats = torch.tensor(vals + [0.0 if res else 1.0], dtype=torch.float64, device=xdev)
     tmax = stats.clone()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    res = {"unit": "targets/s", "scaling": "strong", "targets": int(host.n), "threshold": 1e-3, "k": TOPK,
-           "value": round(host.n / float(tmax[0]), 1), "seconds": round(float(tmax[0]), 3),
-           "search_seconds_max_rank": round(float(tmax[1]), 3),
-           "entries_found": int(stats[2]), "entries_kept_after_k_rule": int(stats[4]),
-           "exchange_bytes_received": int(stats[3]),
-           "exchange": "owner-of-source, 16-byte records partitioned on the device, grouped ncclSend/ncclRecv inside "
-                       "libpprhip.so (pprhip_all_pair_backward_sharded)"}
-    own.close()
-    comm.close()
-    g.set_tuning(pkg.tuning_batch())
-    return res
+    if float(stats[5]) > 0:
+        return {"error": err or "%d of %d ranks failed" % (int(stats[5]), world)}
+    n = 1 << args.scale
+    return {"unit": "targets/s", "scaling": "strong", "targets": n, "threshold": 1e-3, "k": TOPK,
+            "value": round(n / float(tmax[0]), 1), "seconds": round(float(tmax[0]), 3),
+            "search_seconds_max_rank": round(float(tmax[1]), 3),
+            "entries_found": int(stats[2]), "entries_kept_after_k_rule": int(stats[4]),
+            "exchange_bytes_received": int(stats[3]),
+            "exchange": "owner-of-source, 16-byte records partitioned on the device, grouped ncclSend/ncclRecv inside "
+                        "libpprhip.so (pprhip_all_pair_backward_sharded); one child process per rank"}
+
+
+def all_pair_child(args):
+    """One rank's share of all_pair_scaling_sample, in a process of its own; prints one JSON object."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    try:
+        import torch  # noqa: F401  first, as in the parent: the library then binds to the same HIP runtime and RCCL build
+        pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, pkg.device_count())
+        host = pkg.HostCsr.rmat(args.scale, 16, seed=1)
+        with pkg.Graph(host, device=device) as g:
+            comm = _quiet_stdout(lambda: pkg.Comm(g, bytes.fromhex(os.environ["PPRHIP_COMM_ID"]), rank, world))
+            lo, hi = pkg.shard_target_range(rank, world, host.n)
+            ix, _ = g.all_pair_backward(ALPHA, 1e-3, TOPK, lo, min(hi, lo + 1024))  # warm-up of the kernels
+            ix.close()
+            t0 = time.perf_counter()
+            own, st = _quiet_stdout(lambda: comm.all_pair_backward_sharded(ALPHA, 1e-3, TOPK))
+            t_all = time.perf_counter() - t0
+            res = {"seconds": t_all, "search_seconds": st.total_ms / 1e3, "entries_found": float(st.mc_sources),
+                   "bytes_received": float(st.select_bytes), "entries_kept": float(len(own.arrays()[1]))}
+            own.close()
+            comm.close()
+    except Exception as e:  # noqa: BLE001
+        res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    print(json.dumps(res), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------- HBM counters

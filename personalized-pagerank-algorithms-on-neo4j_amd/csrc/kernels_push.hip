@@ -1338,8 +1338,9 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
   const bool bwd = a.mode == kBackward;
   const uint32_t* trp = bwd ? g->in_rp : g->out_rp;
   const int32_t* tci = bwd ? g->in_ci : g->out_ci;
-  static const unsigned long long comb_min =
-      getenv("PPRHIP_COMB_MIN_EDGES") ? strtoull(getenv("PPRHIP_COMB_MIN_EDGES"), nullptr, 10) : kCombMinEdges;
+  // (the override exists for the tests, which run the table on graphs far below the default switch-over)
+  const char* comb_env = getenv("PPRHIP_COMB_MIN_EDGES");
+  const unsigned long long comb_min = comb_env ? strtoull(comb_env, nullptr, 10) : (unsigned long long)kCombMinEdges;
   DISPATCH_MODE(a.mode, k_sparse_push<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
                             g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_ext, g->in_rp, g->residue, g->flags,
                             g->armed, g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot,

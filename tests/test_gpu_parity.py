@@ -567,3 +567,93 @@ def test_gauss_seidel_sweeps(pkg, orc, rmat15, dev_rmat15):
             assert dense[(2, s)] < dense[(1, s)] and dense[(3, s)] < dense[(1, s)]
     finally:
         dev_rmat15.set_tuning(pkg.tuning_default())
+
+
+# ------------------------------------------------------------------ round-2 layouts: slices, LDS table, trimmed rows
+def test_sliced_sweep_layout(pkg, orc, rmat15, monkeypatch):
+    """The single-query sweep over the sliced copy of the in-CSR (slices of 1 000 source ids here, so the R-MAT 15 has
+    16 of them; the default width only slices graphs beyond 393 216 sources): same levels and values as the twin for
+    Jacobi and block Gauss-Seidel sweeps, the same as the row-major layout, and the power method's sweeps too."""
+    og = to_oracle(orc, rmat15)
+    od = np.diff(rmat15.out_rp)
+    srcs = [s for s in sources(rmat15, 12, seed=41) if od[s] > 0][:3]
+    monkeypatch.setenv("PPRHIP_SLICE_IDS", "1000")
+    g_sl = pkg.Graph(rmat15)
+    monkeypatch.setenv("PPRHIP_SLICED", "0")
+    g_rm = pkg.Graph(rmat15)
+    try:
+        for B in (1, 2, 3):
+            t = pkg.tuning_batch()
+            t.gs_blocks = B
+            g_sl.set_tuning(t)
+            g_rm.set_tuning(t)
+            for s in srcs:
+                p, r, rsum, st = g_sl.forward_push(s, ALPHA, 1e-8)
+                po, ro, _, sto = og.forward_push(s, ALPHA, 1e-8, orc.SYNC)
+                assert st.dense_levels > 0 and st.levels == sto.levels and st.dense_levels == sto.dense_levels
+                assert_close(p, po, TOL_PUSH, "sliced reserve B=%d src=%d" % (B, s))
+                assert_close(r, ro, TOL_PUSH, "sliced residue B=%d src=%d" % (B, s))
+                p2, r2, _, st2 = g_rm.forward_push(s, ALPHA, 1e-8)
+                assert st2.levels == st.levels and np.max(np.abs(p - p2)) <= TOL_PUSH
+        pm, _ = g_sl.power_method(srcs[0], ALPHA, 30)
+        assert_close(pm, og.power_method(srcs[0], ALPHA, 30), 1e-12, "power method over slices")
+    finally:
+        g_sl.set_tuning(pkg.tuning_default())
+        g_sl.close()
+        g_rm.close()
+
+
+def test_sparse_push_lds_table(pkg, orc, rmat15, dev_rmat15, monkeypatch):
+    """Sparse levels that sum a tile's contributions per destination in LDS before they land (forced on every level
+    here; by default only levels of 2^18 edges and more): levels, pops and values as without the table and as the twin."""
+    og = to_oracle(orc, rmat15)
+    od = np.diff(rmat15.out_rp)
+    srcs = [s for s in sources(rmat15, 12, seed=43) if od[s] > 0][:3]
+    t = pkg.tuning_default()
+    t.dense_frac = 4.0          # every level sparse: the largest ones carry hundreds of thousands of edges
+    dev_rmat15.set_tuning(t)
+    try:
+        for s in srcs:
+            monkeypatch.setenv("PPRHIP_COMB_MIN_EDGES", "1")
+            p, r, rsum, st = dev_rmat15.forward_push(s, ALPHA, 1e-7)
+            monkeypatch.setenv("PPRHIP_COMB_MIN_EDGES", "1000000000000")
+            p2, r2, _, st2 = dev_rmat15.forward_push(s, ALPHA, 1e-7)
+            po, ro, _, sto = og.forward_push(s, ALPHA, 1e-7, orc.SYNC)
+            assert st.dense_levels == 0 and st.levels == st2.levels == sto.levels and st.pops == st2.pops == sto.pops
+            assert_close(p, po, TOL_PUSH, "reserve with the table src=%d" % s)
+            assert_close(r, ro, TOL_PUSH, "residue with the table src=%d" % s)
+            assert np.max(np.abs(p - p2)) <= TOL_PUSH and abs(p.sum() + r.sum() - 1.0) < 1e-12
+        tb, _ = dev_rmat15.backward_push(srcs[0], ALPHA, 1e-6)[0:2]
+        monkeypatch.setenv("PPRHIP_COMB_MIN_EDGES", "1")
+        tb2, _ = dev_rmat15.backward_push(srcs[0], ALPHA, 1e-6)[0:2]
+        assert np.max(np.abs(tb - tb2)) <= TOL_PUSH
+    finally:
+        dev_rmat15.set_tuning(pkg.tuning_default())
+
+
+def test_batched_sweep_sources_without_in_edges(pkg, orc, rmat15, dev_rmat15):
+    """The batched sweep carries the rows with in-edges plus the rows without in-edges that have out-edges; a source of
+    the second kind holds its own contribution (and the dead-end mass that returns to it) in a row nothing else ever
+    writes.  Such sources next to ordinary ones: every query equals the single-query entry point and the twin."""
+    og = to_oracle(orc, rmat15)
+    od, idg = np.diff(rmat15.out_rp), np.diff(rmat15.in_rp)
+    zin = np.nonzero((idg == 0) & (od > 0))[0]
+    nz = np.nonzero((idg > 0) & (od > 0))[0]
+    assert zin.size >= 12
+    srcs = [int(x) for x in zin[:12]] + [int(x) for x in nz[:8]]
+    t = pkg.tuning_batch()
+    dev_rmat15.set_tuning(t)
+    try:
+        out, _, _, _, pq, st = dev_rmat15.fora_batch_single_source(srcs, 0.5, ALPHA, seed=7, fetch=True, per_query=True)
+        assert st.class_launches[5] > 0
+        for i, s in enumerate(srcs):
+            assert abs(out[i].sum() - 1.0) < 1e-9
+            single, sts = dev_rmat15.fora_single_source(s, 0.5, ALPHA, seed=7)
+            assert sts.walks == pq[i].walks and sts.levels == pq[i].levels
+            assert np.max(np.abs(single - out[i])) < 1e-9
+        for i in (0, 5, 11, 14):
+            ref, sto = og.fora_whole(srcs[i], 0.5, ALPHA, seed=7, n_rounds=0, schedule=orc.SYNC, tuning=to_orc_tuning(orc, t))
+            assert sto.walks == pq[i].walks
+            assert_close(out[i], ref, TOL_MC, "batched FORA, source without in-edges" if i < 12 else "batched FORA")
+    finally:
+        dev_rmat15.set_tuning(pkg.tuning_default())
