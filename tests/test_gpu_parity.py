@@ -657,3 +657,41 @@ def test_batched_sweep_sources_without_in_edges(pkg, orc, rmat15, dev_rmat15):
             assert_close(out[i], ref, TOL_MC, "batched FORA, source without in-edges" if i < 12 else "batched FORA")
     finally:
         dev_rmat15.set_tuning(pkg.tuning_default())
+
+
+def test_internal_order_is_invisible(pkg, orc, rmat15, monkeypatch):
+    """PPRHIP_RELABEL=0 keeps the caller's vertex ids as the internal order (no hot-first layout, rows with in-edges
+    scattered); with the sweeps' blocks off (they follow the internal order) both orders run the same levels and agree
+    to rounding on every entry point - the internal order is a layout, not a semantic.  Sliced copy included."""
+    od = np.diff(rmat15.out_rp)
+    srcs = [s for s in sources(rmat15, 12, seed=47) if od[s] > 0][:2]
+    monkeypatch.setenv("PPRHIP_SLICE_IDS", "3000")
+    g_def = pkg.Graph(rmat15)
+    monkeypatch.setenv("PPRHIP_RELABEL", "0")
+    g_ids = pkg.Graph(rmat15)
+    t = pkg.tuning_default()
+    t.gs_blocks = 1
+    try:
+        for g in (g_def, g_ids):
+            g.set_tuning(t)
+        for s in srcs:
+            a, b = g_def.forward_push(s, ALPHA, 1e-8), g_ids.forward_push(s, ALPHA, 1e-8)
+            assert a[3].levels == b[3].levels and a[3].pops == b[3].pops and a[3].dense_levels == b[3].dense_levels > 0
+            assert np.max(np.abs(a[0] - b[0])) <= TOL_PUSH and np.max(np.abs(a[1] - b[1])) <= TOL_PUSH
+            ea, sa = g_def.fora_single_source(s, 0.5, ALPHA, seed=9)
+            eb, sb = g_ids.fora_single_source(s, 0.5, ALPHA, seed=9)
+            assert sa.walks == sb.walks and sa.walk_steps == sb.walk_steps and np.max(np.abs(ea - eb)) <= TOL_MC
+            ba, bb = g_def.backward_push(s, ALPHA, 1e-6), g_ids.backward_push(s, ALPHA, 1e-6)
+            assert np.max(np.abs(ba[0] - bb[0])) <= TOL_PUSH
+            na, ia, va, _, _ = g_def.fora_topk(s, 0.5, ALPHA, 16, seed=4)
+            nb, ib, vb, _, _ = g_ids.fora_topk(s, 0.5, ALPHA, 16, seed=4)
+            assert na == nb and list(ia) == list(ib) and np.max(np.abs(va - vb)) <= TOL_MC
+        xa, _ = g_def.all_pair_backward(ALPHA, 1e-3, 8, 100, 400)
+        xb, _ = g_ids.all_pair_backward(ALPHA, 1e-3, 8, 100, 400)
+        (oa, ta, va), (ob, tb, vb) = xa.arrays(), xb.arrays()
+        assert np.array_equal(oa, ob) and np.array_equal(ta, tb) and np.max(np.abs(va - vb)) <= TOL_PUSH
+        xa.close()
+        xb.close()
+    finally:
+        g_def.close()
+        g_ids.close()
