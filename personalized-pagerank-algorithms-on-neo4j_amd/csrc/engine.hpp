@@ -60,9 +60,10 @@ struct EdgeWindows {
   unsigned long long e_lo[kMaxWindows], e_hi[kMaxWindows];
 };
 
-// Sliced copy of the in-CSR for the single-query sweep.  A gather of one 8-byte contribution costs a whole memory
-// request, and the rate of requests that leave L2 bounds the sweep (tools/micro/gather_rate.hip: 55 G/s on a 34 MB
-// table, 250 G/s on a 4 MB one).  So the in-edges are kept a second time sorted by (slice of the source id, row):
+// Sliced copy of the in-CSR for the single-query sweep.  A gather of one 8-byte contribution moves a whole 128-byte
+// line, and lines that leave L2 come at a fifth of the rate of lines that hit it (tools/micro/gather_rate.hip:
+// 55 G/s from a 34 MB table and beyond, 250 G/s from a 4 MB one).  So the in-edges are kept a second time sorted
+// by (slice of the source id, row):
 // the sweep walks slice after slice, and while a slice is being walked the contributions it gathers - `width`
 // consecutive ids, a few MB - stay in every XCD's L2.  A row's edges inside one slice form a *segment*; segment sums
 // are added to the row's accumulator (seg_row: segment -> row ordinal), so a row receives one add per slice it has

@@ -384,10 +384,11 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
 constexpr int kChunkEdges = 512;
 constexpr int kHotMax = 16384;  // contributions of the 16K highest-out-degree vertices live in LDS (128 KB)
 
-// Vertex ids are sorted by out-degree (graph lift), so ids < n_hot are the contributions gathered
-// most often (about 40 % of all in-edges at R-MAT scale 22).  A persistent workgroup per CU
-// stages them in LDS once per level and serves those gathers from LDS; an L2 hit would cost a
-// whole 64-byte transaction per 8-byte value, which is what bounds this kernel otherwise.
+// The internal vertex order puts the highest out-degrees first (graph lift), so ids < n_hot are the
+// contributions gathered most often (42 % of all in-edges at R-MAT scale 22).  A persistent workgroup
+// per CU stages them in LDS once per level and serves those gathers from LDS; from L2 every 8-byte
+// value costs the L1 a 128-byte line fill, and that line path is what bounds this kernel otherwise
+// (250 G gathers/s when everything hits L2; the LDS table buys 19 %).
 struct ChunkRegs {  // one lane's share of a chunk: 8 column indices + their row-start flags
   int4 ia, ib;
   uint32_t fb;
@@ -546,8 +547,9 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 // batched dense level: kBatch queries per sweep
 // ------------------------------------------------------------------------------------------------
-// A gather costs one memory request whether 8 bytes of the line are used or all of it, and the rate
-// of requests that miss L2 is what bounds the sweep.  The batched sweep keeps the contributions of
+// A gather moves a 128-byte line whether 8 bytes of it are used or all of it, and the rate of lines
+// that leave L2 (52-55 G/s = the HBM roof at line granularity) is what bounds the sweep: the edge
+// kernel below runs at 51.7 G lines/s.  The batched sweep keeps the contributions of
 // kBatch = 16 concurrent queries interleaved, c8[v][slot] (128 bytes per vertex = one L2 line), so
 // the line a gather brings in carries that vertex's contribution for every query in flight, and
 // the column indices are read once for all of them.  G = kBatch lanes (one per slot) share an
