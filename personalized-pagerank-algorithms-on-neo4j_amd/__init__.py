@@ -569,14 +569,19 @@ class Graph:
         return out, st
 
     def fora_batch_single_source(self, srcs, eps, alpha, seed, n_rounds=0, k=0, conf=None, fetch=False, per_query=False,
-                                 keep=None):
+                                 keep=None, out=None):
         """q single-source FORA queries, BATCH of them in flight; returns (reserve[q, n] | None, ids[q, k] | None,
         vals[q, k] | None, n_sel[q] | None, per-query Stats list | None, summed Stats).  keep: a Results store that
-        receives every query's vector (device-resident)."""
+        receives every query's vector (device-resident); out: caller's [q, n] float64 array for fetch=True."""
         srcs = np.ascontiguousarray(srcs, dtype=np.int32)
         q = int(srcs.size)
         conf = conf or conf_whole_graph(self.n, self.m, alpha)
-        out = np.empty((q, self.n)) if fetch else None
+        if fetch and out is not None:
+            assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.shape == (q, self.n)
+        elif fetch:
+            out = np.empty((q, self.n))
+        else:
+            out = None
         ids = np.empty((q, k), dtype=np.int32) if k > 0 else None
         vals = np.empty((q, k)) if k > 0 else None
         nsel = np.zeros(q, dtype=np.int32) if k > 0 else None

@@ -621,6 +621,11 @@ int ensure_batch(pprhip_graph* P) {
 }
 
 void free_batch(pprhip_graph* P) {
+  if (P->fetch) {
+    P->fetch->destroy();
+    delete P->fetch;
+    P->fetch = nullptr;
+  }
   for (pprhip_graph* S : P->slots) {
     free_workspace(S);
     S->ktimer.destroy();

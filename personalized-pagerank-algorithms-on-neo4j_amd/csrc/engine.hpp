@@ -198,6 +198,12 @@ struct SlotArgs {
 
 }  // namespace pprhip
 
+namespace pprhip {
+namespace detail {
+struct FetchPipe;
+}
+}  // namespace pprhip
+
 struct pprhip_graph {
   int device = 0;
   int n_cus = 256;  // compute units of the device (persistent-kernel grid sizing)
@@ -234,6 +240,7 @@ struct pprhip_graph {
   hipStream_t own_stream = nullptr;   // slot: the stream its worker thread uses
   pprhip::KernelTimer ktimer;         // slot: its worker's kernel-class timer; graph: the sweeps' timer
   std::vector<pprhip_graph*> slots;
+  pprhip::detail::FetchPipe* fetch = nullptr;  // delivery of batched queries' vectors to host memory (engine_internal.hpp)
   double* c8[2] = {nullptr, nullptr};
   int c8cur = 0;
   double* acc8 = nullptr;      // [row ordinal][kBatch] row sums

@@ -6,6 +6,8 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -160,6 +162,37 @@ struct CallTimer {
 };
 
 // a batch of queries for the slot engine (fora.cpp)
+// Delivery of the queries' vectors to the caller's (pageable) host memory while the batch keeps running: a finished
+// query's vector is permuted to the caller's ids into one of kRing device staging buffers on the query's own stream,
+// copied to a pinned host buffer on a copy stream, and moved from there to its destination by a copier thread.  The
+// compute stream never waits for PCIe or for the host copy; a query that finishes while all staging buffers are in
+// flight waits for one.
+struct FetchPipe {
+  static constexpr int kRing = 6;
+  static constexpr int kCopiers = 4;
+  pprhip_graph* P = nullptr;
+  size_t n = 0;
+  hipStream_t cs = nullptr;
+  double* dev[kRing] = {};
+  double* pin[kRing] = {};
+  hipEvent_t ready[kRing] = {};
+  hipEvent_t done[kRing] = {};
+  struct Item { int e; double* dst; };
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<int> free_q;
+  std::deque<Item> work;
+  bool closing = false;
+  int err = 0;
+  std::thread copiers[kCopiers];
+  int ensure(pprhip_graph* parent);  // buffers, stream and events: allocated once per handle, kept between calls
+  void start();                      // a call's copier threads
+  int submit(pprhip_graph* S, const double* dev_vec, double* dst);  // dev_vec in internal order, on S->stream
+  int finish();                      // drains and joins; first error of any stage
+  void destroy();
+  void copier();
+};
+
 struct BatchJob {
   pprhip_graph* P;
   const int32_t* srcs;
@@ -178,6 +211,7 @@ struct BatchJob {
   double alpha = 0.0, threshold = 0.0;   // kind 2
   std::vector<Triple>* triples = nullptr;  // kind 2: every search's entries >= threshold
   pprhip_results* keep = nullptr;          // kind 0: device-resident store of the queries' vectors
+  FetchPipe* pipe = nullptr;               // reserve_out given: asynchronous delivery (batch_run opens / closes it)
   pprhip_stats_t sum;
   std::mutex sum_mu;
   std::atomic<int> next_query{0};
