@@ -1,6 +1,8 @@
 """Differential test on random small graphs (self loops, multi-edges, dead ends, isolated nodes, empty graphs):
 every entry point of the path against the CPU oracle's frontier-synchronous twin, under the level shapes a tiny
 graph would otherwise never reach (dense levels forced from the first edge on).  GPU, through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -63,7 +65,9 @@ def orc_tuning(orc, t):
     return o
 
 
-@pytest.mark.parametrize("seed", range(12))
+# PPRHIP_FUZZ_SEEDS=<count> widens the campaign (run with 200 seeds, slices of 7 ids and the LDS table on every
+# level before the round's last commit; the default keeps the suite short)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PPRHIP_FUZZ_SEEDS", "12"))))
 def test_random_graph_against_twin(pkg, orc, seed):
     host = random_graph(pkg, seed)
     og = to_oracle(orc, host)
