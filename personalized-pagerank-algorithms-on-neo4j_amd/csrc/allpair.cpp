@@ -167,7 +167,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   unsigned long long* cells = nullptr;  // next_target, out_count, out_valid, overflow_count, pops, edges
   int rc = PPRHIP_OK;
   auto release = [&]() {
-    void* p[] = {cells, B.out_v, B.out_t, B.out_p, B.overflow, B.g_tables};
+    void* p[] = {cells, B.out_v, B.out_t, B.out_p, B.overflow};
     for (void* q : p)
       if (q) (void)hipFree(q);
   };
@@ -248,16 +248,24 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
   }
   if (rc == PPRHIP_OK && !to_tier2.empty()) {
-    B.g_cap = 65536;
-    // 8 workgroups per CU: the HBM tier is a chain of L2 round trips per edge, hidden only by occupancy
-    B.g_blocks = (uint32_t)std::min<size_t>((size_t)g->n_cus * 8, to_tier2.size());
-    rc = alloc_dev((void**)&B.g_tables, (size_t)B.g_blocks * B.g_cap * 40);
+    // searches of up to 65 536 nodes at a quarter load (kernels_apbs.hip); four workgroups per CU
+    B.g_cap = 262144u;
+    const uint32_t want = (uint32_t)std::min<size_t>((size_t)g->n_cus * 4, to_tier2.size());
+    if (g->apbs_blocks < want) {  // the tables stay with the handle: 8.2 MB per workgroup
+      if (g->apbs_tables) (void)hipFree(g->apbs_tables);
+      g->apbs_tables = nullptr;
+      g->apbs_blocks = 0;
+      rc = alloc_dev((void**)&g->apbs_tables, (size_t)want * apbs_table_bytes(B.g_cap));
+      if (rc == PPRHIP_OK) g->apbs_blocks = want;
+    }
+    B.g_blocks = std::min(want, g->apbs_blocks);
+    B.g_tables = g->apbs_tables;
     if (rc == PPRHIP_OK) rc = run_tier(true, to_tier2, false, to_tier3);
   }
   release();
   if (rc != PPRHIP_OK) return rc;
 
-  // ---- tier 3: the targets whose search outgrows a 48K-node table run on whole vectors, 16 of them in flight
+  // ---- tier 3: the targets whose search outgrows 65 536 nodes run on whole vectors, 16 of them in flight
   // on the batch slots; levels that touch a large part of the graph run as batched sweeps over the out-CSR
   pprhip_stats_t st3;
   std::memset(&st3, 0, sizeof st3);

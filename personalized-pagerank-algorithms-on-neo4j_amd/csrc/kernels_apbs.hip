@@ -15,6 +15,7 @@
 // (old, old + add) with the reference's strict un-normalised threshold (Backward_Search.java:89).
 // Entries with reserve >= threshold are appended as (source, target, pi) triples.
 #include <algorithm>
+#include <type_traits>
 
 #include "device_utils.hpp"
 #include "engine.hpp"
@@ -23,16 +24,23 @@ namespace pprhip {
 
 constexpr int kApLdsCap = 2048;
 constexpr int kApFront = 512;
+constexpr uint32_t kApGlobalLoadDiv = 4;  // the HBM tier hands a search on at cap / 4 nodes
+// entries of the HBM tier's lists: the node limit plus what one round of inserts can add before the limit is checked
+__host__ __device__ inline uint32_t ap_list_cap(uint32_t g_cap) { return g_cap / kApGlobalLoadDiv + 8192u; }
+size_t apbs_table_bytes(uint32_t g_cap) { return (size_t)g_cap * 28 + (size_t)ap_list_cap(g_cap) * 12; }
 
+template <bool G>
 struct ApTable {  // one target's state; arrays live in LDS (tier 1) or HBM (tier 2)
+  using Idx = typename std::conditional<G, uint32_t, uint16_t>::type;  // slot index (LDS tables have <= 65536 slots)
   int32_t* keys;   // node id or -1
   double* res;     // residue
   double* rsv;     // reserve
   double* pend;    // (1 - alpha) * residue taken at level start, per slot
-  uint16_t* used;  // slots in insertion order (capacity <= 65536, so 16 bits index every slot)
-  uint16_t* cur;   // frontier (slots)
-  uint16_t* nxt;
+  Idx* used;       // slots in insertion order
+  Idx* cur;        // frontier (slots)
+  Idx* nxt;
   uint32_t cap;    // power of two
+  uint32_t lcap;   // entries the three lists hold
 };
 
 template <bool G>
@@ -43,11 +51,11 @@ __device__ __forceinline__ int32_t ap_cas(int32_t* p, int32_t cmp, int32_t val) 
 // In the HBM tier the keys and residues are updated by atomics, which execute in L2: every read of
 // them must bypass this CU's L1 (agent-scope relaxed load / exchange), or it may see a stale line.
 template <bool G>
-__device__ __forceinline__ int32_t ap_key(const ApTable& T, uint32_t s) {
+__device__ __forceinline__ int32_t ap_key(const ApTable<G>& T, uint32_t s) {
   return G ? __hip_atomic_load(&T.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T.keys[s];
 }
 template <bool G>
-__device__ __forceinline__ double ap_take_residue(const ApTable& T, uint32_t s) {
+__device__ __forceinline__ double ap_take_residue(const ApTable<G>& T, uint32_t s) {
   if (G) return __hip_atomic_exchange(&T.res[s], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const double r = T.res[s];
   T.res[s] = 0.0;
@@ -56,7 +64,7 @@ __device__ __forceinline__ double ap_take_residue(const ApTable& T, uint32_t s) 
 
 // returns the slot of node u, inserting it if absent; 0xFFFFFFFF when the table is full
 template <bool G>
-__device__ __forceinline__ uint32_t ap_slot(const ApTable& T, int32_t u, uint32_t* used_count) {
+__device__ __forceinline__ uint32_t ap_slot(const ApTable<G>& T, int32_t u, uint32_t* used_count) {
   const uint32_t mask = T.cap - 1;
   uint32_t s = ((uint32_t)u * 2654435761u) >> 7 & mask;
   for (uint32_t probes = 0; probes < T.cap; ++probes) {
@@ -66,7 +74,7 @@ __device__ __forceinline__ uint32_t ap_slot(const ApTable& T, int32_t u, uint32_
       const int32_t prev = ap_cas<G>(&T.keys[s], -1, u);
       if (prev == -1) {
         const uint32_t idx = atomicAdd(used_count, 1u);
-        if (idx < T.cap) T.used[idx] = (uint16_t)s;
+        if (idx < T.lcap) T.used[idx] = (typename ApTable<G>::Idx)s;
         return s;
       }
       if (prev == u) return s;
@@ -92,9 +100,9 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
   __shared__ double s_res[G ? 1 : kApLdsCap];
   __shared__ double s_rsv[G ? 1 : kApLdsCap];
   __shared__ double s_pend[G ? 1 : kApLdsCap];
-  __shared__ uint16_t s_used[G ? 1 : kApLdsCap];
-  __shared__ uint16_t s_cur[G ? 1 : kApLdsCap];
-  __shared__ uint16_t s_nxt[G ? 1 : kApLdsCap];
+  __shared__ typename ApTable<G>::Idx s_used[G ? 1 : kApLdsCap];
+  __shared__ typename ApTable<G>::Idx s_cur[G ? 1 : kApLdsCap];
+  __shared__ typename ApTable<G>::Idx s_nxt[G ? 1 : kApLdsCap];
   __shared__ uint32_t f_row[kApFront];
   __shared__ uint32_t f_off[kApFront + 1];
   __shared__ double f_c[kApFront];
@@ -104,24 +112,34 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
   __shared__ unsigned long long s_t, s_out_base, s_tot;
   const int tid = threadIdx.x;
 
-  ApTable T;
+  ApTable<G> T;
+  using Idx = typename ApTable<G>::Idx;
   if (G) {
-    const size_t per = (size_t)g_cap * (8 + 8 + 8 + 4 + 2 + 2 + 2 + 6);  // 40 B per slot keeps 8-byte alignment
+    // 28 B per slot (residue, reserve, pending, key) + three lists of slot indices that only have to hold the nodes
+    // a search may reach before it is handed on (ap_list_cap)
+    const uint32_t lcap = ap_list_cap(g_cap);
+    const size_t per = (size_t)g_cap * 28 + (size_t)lcap * 12;
     char* base = g_tables + (size_t)blockIdx.x * per;
     T.res = (double*)base;
     T.rsv = T.res + g_cap;
     T.pend = T.rsv + g_cap;
     T.keys = (int32_t*)(T.pend + g_cap);
-    T.used = (uint16_t*)(T.keys + g_cap);
-    T.cur = T.used + g_cap;
-    T.nxt = T.cur + g_cap;
+    T.used = (Idx*)(T.keys + g_cap);
+    T.cur = T.used + lcap;
+    T.nxt = T.cur + lcap;
     T.cap = g_cap;
+    T.lcap = lcap;
   } else {
     T.keys = s_keys; T.res = s_res; T.rsv = s_rsv; T.pend = s_pend;
     T.used = s_used; T.cur = s_cur; T.nxt = s_nxt;
     T.cap = kApLdsCap;
+    T.lcap = kApLdsCap;
   }
-  const uint32_t limit = T.cap - T.cap / 4;  // give up at 75 % load
+  // LDS tier: give up at 75 % load.  HBM tier: at 25 % - a probe chain is a chain of L2 round trips there, and with
+  // linear probing (which keeps a chain inside the 128-byte line its first probe fetched) it is the load factor that
+  // decides their length: at the 65 536-slot table's 75 % the counters showed 15 probes per edge on average and
+  // 68 for the slowest lane of a wave
+  const uint32_t limit = G ? T.cap / kApGlobalLoadDiv : T.cap - T.cap / 4;
   for (uint32_t i = tid; i < T.cap; i += 256) {
     T.keys[i] = -1;
     T.res[i] = 0.0;
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
       if (tid == 0) {
         const uint32_t s = ap_slot<G>(T, t, &s_used_count);
         T.res[s] = 1.0;  // :54-56; the target is pushed unconditionally first
-        T.cur[0] = (uint16_t)s;
+        T.cur[0] = (Idx)s;
       }
       nf = 1;
     }
@@ -238,7 +256,7 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
             const double nw = old + add;
             if (!(old > rmax) && nw > rmax) {  // :89 strict, un-normalised; first crossing of the level
               const uint32_t pos = atomicAdd(&s_nnext, 1u);
-              if (pos < T.cap) T.nxt[pos] = (uint16_t)s;
+              if (pos < T.lcap) T.nxt[pos] = (Idx)s;
             }
           }
         }
@@ -247,11 +265,11 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
         __syncthreads();
       }
       nf = s_nnext;
-      uint16_t* tmp = T.cur; T.cur = T.nxt; T.nxt = tmp;
+      Idx* tmp = T.cur; T.cur = T.nxt; T.nxt = tmp;
       __syncthreads();
     }
 
-    const uint32_t used = s_used_count < T.cap ? s_used_count : T.cap;
+    const uint32_t used = s_used_count < T.lcap ? s_used_count : T.lcap;
     const bool ovf = s_overflow != 0;
     // ---- emit entries >= threshold (Base_Whole_Graph.java:80-88)
     bool retry = ovf;
