@@ -248,10 +248,12 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
   }
   if (rc == PPRHIP_OK && !to_tier2.empty()) {
-    // searches of up to 65 536 nodes at a quarter load (kernels_apbs.hip); four workgroups per CU
-    B.g_cap = 262144u;
+    // searches of up to 131 072 nodes at a quarter load (kernels_apbs.hip); four workgroups per CU.  Measured on
+    // R-MAT 22 (2^18 targets): 65 536-slot tables at 75 % load 466 K targets/s; 262 144 slots at 25 % 820 K;
+    // 524 288 slots at 25 % 935 K (156 instead of 532 searches left for tier 3)
+    B.g_cap = 524288u;
     const uint32_t want = (uint32_t)std::min<size_t>((size_t)g->n_cus * 4, to_tier2.size());
-    if (g->apbs_blocks < want) {  // the tables stay with the handle: 8.2 MB per workgroup
+    if (g->apbs_blocks < want) {  // the tables stay with the handle: 16.4 MB per workgroup
       if (g->apbs_tables) (void)hipFree(g->apbs_tables);
       g->apbs_tables = nullptr;
       g->apbs_blocks = 0;
@@ -265,7 +267,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   release();
   if (rc != PPRHIP_OK) return rc;
 
-  // ---- tier 3: the targets whose search outgrows 65 536 nodes run on whole vectors, 16 of them in flight
+  // ---- tier 3: the targets whose search outgrows 131 072 nodes run on whole vectors, 16 of them in flight
   // on the batch slots; levels that touch a large part of the graph run as batched sweeps over the out-CSR
   pprhip_stats_t st3;
   std::memset(&st3, 0, sizeof st3);

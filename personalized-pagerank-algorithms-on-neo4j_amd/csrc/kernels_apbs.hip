@@ -6,7 +6,7 @@
 // target's whole state (residue, reserve, frontier) in a hash table keyed by node id:
 //
 //   tier 1  table of 2048 entries in LDS (ds_cmpst / ds_add_rtn_f64), two workgroups per CU;
-//   tier 2  table of 65536 entries in HBM per workgroup, for the targets tier 1 had to give up;
+//   tier 2  table of 524288 entries in HBM per workgroup (filled to a quarter), for the targets tier 1 had to give up;
 //   tier 3  (host) the engine's whole-vector backward search for the few targets beyond that.
 //
 // Levels are frontier-synchronous exactly as in k_sparse_prepare / k_sparse_push: all frontier
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
   }
   // LDS tier: give up at 75 % load.  HBM tier: at 25 % - a probe chain is a chain of L2 round trips there, and with
   // linear probing (which keeps a chain inside the 128-byte line its first probe fetched) it is the load factor that
-  // decides their length: at the 65 536-slot table's 75 % the counters showed 15 probes per edge on average and
+  // decides their length: in a 65 536-slot table at 75 % the counters showed 15 probes per edge on average and
   // 68 for the slowest lane of a wave
   const uint32_t limit = G ? T.cap / kApGlobalLoadDiv : T.cap - T.cap / 4;
   for (uint32_t i = tid; i < T.cap; i += 256) {
