@@ -853,6 +853,7 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
 // kernel.  Wave w serves kSlotsPerWave consecutive slots; slot arguments are
 // wave-uniform.  Counters go to per-slot partials.
 constexpr int kApplyRows = 64;
+constexpr int kApplyGroups = 2;  // tiles of kApplyRows rows a workgroup carries through its phases together
 constexpr int kApplyThreads = 512;  // 8 waves, 2 slots each: few enough slot arguments to stay in SGPRs
 constexpr int kSlotsPerWave = kBatch / (kApplyThreads / 64);
 
@@ -873,11 +874,11 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
                                                             uint32_t part_stride) {
   // tiles [tile_lo, tile_hi) of one block of the sweep.  gs_mask: slots whose state writes the current array in place
   // (entry / in-place / flush, engine.hpp: GsState); entry_mask: those of them that add to what it holds.
-  __shared__ double tile[kApplyRows][kBatch + 1];
-  __shared__ double tile_p[kApplyRows][kBatch + 1];  // what the rows leave in the current array (slots in gs_mask)
-  __shared__ int32_t s_u[kApplyRows];
-  __shared__ uint32_t s_d[kApplyRows];
-  __shared__ uint32_t s_din[kApplyRows];  // backward sweeps: in-degree = edges the row pushes when it is popped
+  __shared__ double tile[kApplyGroups][kApplyRows][kBatch + 1];
+  __shared__ double tile_p[kApplyGroups][kApplyRows][kBatch + 1];  // what the rows leave in the current array (slots in gs_mask)
+  __shared__ int32_t s_u[kApplyGroups][kApplyRows];
+  __shared__ uint32_t s_d[kApplyGroups][kApplyRows];
+  __shared__ uint32_t s_din[kApplyGroups][kApplyRows];  // backward sweeps: in-degree = edges the row pushes when it is popped
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the slot arguments load into SGPRs
   const uint32_t n_rows = n_nz + n_zin;
@@ -894,127 +895,153 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
     pack[i] = 0;
     ndead[i] = 0;
   }
-  for (uint32_t tl = tile_lo + blockIdx.x; tl < tile_hi; tl += gridDim.x) {
-    const uint32_t row0 = tl * kApplyRows;
-    // rows inside one 512-edge chunk are rewritten by plain stores every sweep; only the rows that
-    // cross a chunk boundary are summed with atomics and have to be cleared for the next sweep
-    const unsigned long long cw = cross_bits[tl];
+  // kApplyGroups tiles of 64 rows per trip: every phase below issues the loads of all of them before the barrier that
+  // ends it (the waves of a workgroup spent four fifths of their cycles at those barriers with one tile per trip)
+  for (uint32_t tl0 = tile_lo + blockIdx.x * kApplyGroups; tl0 < tile_hi; tl0 += gridDim.x * kApplyGroups) {
 #pragma unroll
-    for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
-      const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
-      const uint32_t r = idx / kBatch, s = idx % kBatch;
-      const uint32_t j = row0 + r;
-      double v = 0.0;
-      if (j < n_nz) {
-        const size_t t = (size_t)j * kBatch + s;
-        v = __builtin_nontemporal_load(&acc8[t]);
-        if (v != 0.0 && ((cw >> r) & 1ull)) acc8[t] = 0.0;
-      }
-      tile[r][s] = v;
-    }
-    if (tid < kApplyRows) {
-      const uint32_t j = row0 + tid;
-      const int32_t u = j < n_nz ? nz_rows[j] : (j < n_rows ? zin_rows[j - n_nz] : -1);
-      s_u[tid] = u;
-      s_d[tid] = u >= 0 ? out_rp[u + 1] - out_rp[u] : 0u;
-      s_din[tid] = (u >= 0 && in_rp_bwd) ? in_rp_bwd[u + 1] - in_rp_bwd[u] : 0u;
-    }
-    __syncthreads();
-    if (entry_mask) {  // entry sweeps add to the row's own pending contribution: stage it (whole lines)
+    for (int g = 0; g < kApplyGroups; ++g) {
+      const uint32_t tl = tl0 + g;
+      const bool in = tl < tile_hi;
+      const uint32_t row0 = tl * kApplyRows;
+      // rows inside one 512-edge chunk are rewritten by plain stores every sweep; only the rows that
+      // cross a chunk boundary are summed with atomics and have to be cleared for the next sweep
+      const unsigned long long cw = in ? cross_bits[tl] : 0ull;
 #pragma unroll
       for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
         const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
         const uint32_t r = idx / kBatch, s = idx % kBatch;
-        const int32_t ur = s_u[r];
-        tile_p[r][s] = (ur >= 0 && (entry_mask >> s & 1u)) ? c8_cur[(size_t)ur * kBatch + s] : 0.0;
+        const uint32_t j = row0 + r;
+        double v = 0.0;
+        if (in && j < n_nz) {
+          const size_t t = (size_t)j * kBatch + s;
+          v = __builtin_nontemporal_load(&acc8[t]);
+          if (v != 0.0 && ((cw >> r) & 1ull)) acc8[t] = 0.0;
+        }
+        tile[g][r][s] = v;
+      }
+    }
+    if (tid < kApplyRows * kApplyGroups) {
+      const uint32_t g = tid / kApplyRows, r = tid % kApplyRows;
+      const uint32_t tl = tl0 + g;
+      const uint32_t j = tl * kApplyRows + r;
+      const int32_t u = tl >= tile_hi ? -1 : (j < n_nz ? nz_rows[j] : (j < n_rows ? zin_rows[j - n_nz] : -1));
+      s_u[g][r] = u;
+      s_d[g][r] = u >= 0 ? out_rp[u + 1] - out_rp[u] : 0u;
+      s_din[g][r] = (u >= 0 && in_rp_bwd) ? in_rp_bwd[u + 1] - in_rp_bwd[u] : 0u;
+    }
+    __syncthreads();
+    if (entry_mask) {  // entry sweeps add to the row's own pending contribution: stage it (whole lines)
+#pragma unroll
+      for (int g = 0; g < kApplyGroups; ++g) {
+#pragma unroll
+        for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
+          const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
+          const uint32_t r = idx / kBatch, s = idx % kBatch;
+          const int32_t ur = s_u[g][r];
+          tile_p[g][r][s] = (ur >= 0 && (entry_mask >> s & 1u)) ? c8_cur[(size_t)ur * kBatch + s] : 0.0;
+        }
       }
       __syncthreads();
     }
-    const int32_t u = s_u[lane];
-    const uint32_t d = s_d[lane];
-    const uint32_t din = s_din[lane];
     // the wave's slots in three passes, so that all their residue / reserve loads are in flight together:
     // (1) row sums (+ the source's returned dead-end mass), (2) loads, (3) arithmetic and stores
-    double accv[kSlotsPerWave], oldv[kSlotsPerWave], rsvv[kSlotsPerWave];
-    bool live[kSlotsPerWave];
+    int32_t u[kApplyGroups];
+    uint32_t d[kApplyGroups], din[kApplyGroups];
+    double accv[kApplyGroups][kSlotsPerWave], oldv[kApplyGroups][kSlotsPerWave], rsvv[kApplyGroups][kSlotsPerWave];
+    bool live[kApplyGroups][kSlotsPerWave];
 #pragma unroll
-    for (int i = 0; i < kSlotsPerWave; ++i) {
-      double acc = tile[lane][w * kSlotsPerWave + i];
-      const bool on = a[i].active && u >= 0;
-      if (on && a[i].mode != kBackward && u == a[i].src) {
-        const double dd = a[i].ctr->dead[a[i].dead_slot];
-        if (dd > 0.0) {
-          acc += dd;
-          a[i].ctr->dead[a[i].dead_slot] = 0.0;
-        }
-      }
-      accv[i] = acc;
-      live[i] = on && acc > 0.0;
-    }
+    for (int g = 0; g < kApplyGroups; ++g) {
+      u[g] = s_u[g][lane];
+      d[g] = s_d[g][lane];
+      din[g] = s_din[g][lane];
 #pragma unroll
-    for (int i = 0; i < kSlotsPerWave; ++i) {
-      oldv[i] = live[i] ? a[i].res[u] : 0.0;
-      rsvv[i] = live[i] ? a[i].reserve[u] : 0.0;  // needed when the row crosses, which most rows of a dense level do
-    }
-#pragma unroll
-    for (int i = 0; i < kSlotsPerWave; ++i) {
-      const int s = w * kSlotsPerWave + i;
-      double cn = 0.0;
-      if (live[i] && a[i].mode == kBackward) {
-        // Backward_Search.java:73-96 in pull form: the row's out-neighbours' (1 - alpha) * residue, divided by
-        // this row's out-degree; strict un-normalised threshold
-        const double old = oldv[i];
-        const double nw = old + accv[i] / (double)d;
-        if (!(old > a[i].rmax) && nw > a[i].rmax) {
-          a[i].reserve[u] = rsvv[i] + nw * a[i].alpha;
-          a[i].res[u] = 0.0;
-          cn = (1.0 - a[i].alpha) * nw;
-          pack[i] += (1ull << kPackShift) | (unsigned long long)din;
-        } else {
-          a[i].res[u] = nw;
-        }
-      } else if (live[i]) {
-        const double old = oldv[i];
-        const double nw = old + accv[i];
-        bool crossing = !active_fwd(old, d, a[i].rmax) && active_fwd(nw, d, a[i].rmax);
-        if (a[i].mode == kFwdTopk) {
-          if (a[i].rmax < a[i].min_rmax && active_fwd(old, d, a[i].rmax)) crossing = take_armed(a[i].armed, u);
-          if (active_fwd(nw, d, a[i].min_rmax)) a[i].flags[u] = 1;
-        }
-        if (crossing) {  // becomes a frontier node of the next level: prepare it right here
-          a[i].reserve[u] = rsvv[i] + nw * a[i].alpha;
-          a[i].res[u] = 0.0;
-          if (d == 0) {
-            dead_next[i] += nw * (1.0 - a[i].alpha);
-            ndead[i]++;
-          } else {
-            cn = ((1.0 - a[i].alpha) * nw) / (double)d;
+      for (int i = 0; i < kSlotsPerWave; ++i) {
+        double acc = tile[g][lane][w * kSlotsPerWave + i];
+        const bool on = a[i].active && u[g] >= 0;
+        if (on && a[i].mode != kBackward && u[g] == a[i].src) {
+          const double dd = a[i].ctr->dead[a[i].dead_slot];
+          if (dd > 0.0) {
+            acc += dd;
+            a[i].ctr->dead[a[i].dead_slot] = 0.0;
           }
-          pack[i] += (1ull << kPackShift) | (unsigned long long)d;
-        } else {
-          a[i].res[u] = nw;
         }
+        accv[g][i] = acc;
+        live[g][i] = on && acc > 0.0;
       }
-      tile[lane][s] = cn;
-      if (gs_mask >> s & 1u) {
-        const int gst = a[i].gs_state;
-        // entry: old + new (the old value is loaded below, before this line runs: see the staging of tile_p)
-        tile_p[lane][s] = gst == kGsEntry ? tile_p[lane][s] + cn : (gst == kGsInPlace ? cn : 0.0);
+    }
+#pragma unroll
+    for (int g = 0; g < kApplyGroups; ++g) {
+#pragma unroll
+      for (int i = 0; i < kSlotsPerWave; ++i) {
+        oldv[g][i] = live[g][i] ? a[i].res[u[g]] : 0.0;
+        rsvv[g][i] = live[g][i] ? a[i].reserve[u[g]] : 0.0;  // needed when the row crosses, which most rows of a dense level do
       }
-      // rows of this tile that hold a contribution for the slot's next level (read when the slot
-      // goes back to list form)
-      const unsigned long long bits = __ballot(cn > 0.0);
-      if (lane == 0 && a[i].active) prep_bits[(size_t)s * n_tiles + tl] = bits;
+    }
+#pragma unroll
+    for (int g = 0; g < kApplyGroups; ++g) {
+#pragma unroll
+      for (int i = 0; i < kSlotsPerWave; ++i) {
+        const int s = w * kSlotsPerWave + i;
+        double cn = 0.0;
+        if (live[g][i] && a[i].mode == kBackward) {
+          // Backward_Search.java:73-96 in pull form: the row's out-neighbours' (1 - alpha) * residue, divided by
+          // this row's out-degree; strict un-normalised threshold
+          const double old = oldv[g][i];
+          const double nw = old + accv[g][i] / (double)d[g];
+          if (!(old > a[i].rmax) && nw > a[i].rmax) {
+            a[i].reserve[u[g]] = rsvv[g][i] + nw * a[i].alpha;
+            a[i].res[u[g]] = 0.0;
+            cn = (1.0 - a[i].alpha) * nw;
+            pack[i] += (1ull << kPackShift) | (unsigned long long)din[g];
+          } else {
+            a[i].res[u[g]] = nw;
+          }
+        } else if (live[g][i]) {
+          const double old = oldv[g][i];
+          const double nw = old + accv[g][i];
+          bool crossing = !active_fwd(old, d[g], a[i].rmax) && active_fwd(nw, d[g], a[i].rmax);
+          if (a[i].mode == kFwdTopk) {
+            if (a[i].rmax < a[i].min_rmax && active_fwd(old, d[g], a[i].rmax)) crossing = take_armed(a[i].armed, u[g]);
+            if (active_fwd(nw, d[g], a[i].min_rmax)) a[i].flags[u[g]] = 1;
+          }
+          if (crossing) {  // becomes a frontier node of the next level: prepare it right here
+            a[i].reserve[u[g]] = rsvv[g][i] + nw * a[i].alpha;
+            a[i].res[u[g]] = 0.0;
+            if (d[g] == 0) {
+              dead_next[i] += nw * (1.0 - a[i].alpha);
+              ndead[i]++;
+            } else {
+              cn = ((1.0 - a[i].alpha) * nw) / (double)d[g];
+            }
+            pack[i] += (1ull << kPackShift) | (unsigned long long)d[g];
+          } else {
+            a[i].res[u[g]] = nw;
+          }
+        }
+        tile[g][lane][s] = cn;
+        if (gs_mask >> s & 1u) {
+          const int gst = a[i].gs_state;
+          // entry: old + new (the old value was staged in tile_p above)
+          tile_p[g][lane][s] = gst == kGsEntry ? tile_p[g][lane][s] + cn : (gst == kGsInPlace ? cn : 0.0);
+        }
+        // rows of this tile that hold a contribution for the slot's next level (read when the slot
+        // goes back to list form)
+        const unsigned long long bits = __ballot(cn > 0.0);
+        if (lane == 0 && a[i].active && tl0 + g < tile_hi) prep_bits[(size_t)s * n_tiles + tl0 + g] = bits;
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
-      const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
-      const uint32_t r = idx / kBatch, s = idx % kBatch;
-      const int32_t ur = s_u[r];
-      if (ur >= 0) {
-        c8_next[(size_t)ur * kBatch + s] = tile[r][s];
-        if (gs_mask >> s & 1u) c8_cur[(size_t)ur * kBatch + s] = tile_p[r][s];
+    for (int g = 0; g < kApplyGroups; ++g) {
+#pragma unroll
+      for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
+        const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
+        const uint32_t r = idx / kBatch, s = idx % kBatch;
+        const int32_t ur = s_u[g][r];
+        if (ur >= 0) {
+          c8_next[(size_t)ur * kBatch + s] = tile[g][r][s];
+          if (gs_mask >> s & 1u) c8_cur[(size_t)ur * kBatch + s] = tile_p[g][r][s];
+        }
       }
     }
     __syncthreads();
@@ -1487,7 +1514,7 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_bloc
     const uint32_t t_hi = (b == nb - 1) ? n_tiles : B.j_hi / kApplyRows;
     if (t_hi <= t_lo) continue;
     const uint32_t quota = kApplyBlocks8 / (uint32_t)nb;
-    const uint32_t grid = std::max(1u, std::min(t_hi - t_lo, quota));
+    const uint32_t grid = std::max(1u, std::min((t_hi - t_lo + kApplyGroups - 1) / kApplyGroups, quota));
     k_dense_apply_batch<<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
         nz, n_nz, zr, n_z, P->acc8, P->out_rp, backward ? P->in_rp : nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo,
         t_hi, b == nb - 1 ? 0u : gs_mask, b == nb - 1 ? 0u : entry_mask, P->d_slot_args, cross, P->prep_bits, P->blk_pack8, P->blk_dead8, P->blk_ndead8,
