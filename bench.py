@@ -303,6 +303,9 @@ def main():
             if roofline["traffic"]:
                 roofline["achieved_counter"] = round(roofline["traffic"] / 1e9 / (avg_us / 1e6), 1)
                 roofline["frac_counter"] = round(roofline["achieved_counter"] / HBM_PEAK_GBS, 4)
+                roofline["note"] = ("frac is SURVEY 8(d)'s algorithmic byte model over time and counts the gathers that "
+                                    "L2 / LDS serve (a third of them), so it can exceed the HBM roof; frac_counter is "
+                                    "the traffic the memory-side counters saw")
             if extras and pmc.get("dense_pull"):
                 r1 = out["one_query_at_a_time"]["roofline"]
                 r1["traffic"] = pmc["dense_pull"]
@@ -440,8 +443,9 @@ def all_pair_sample(pkg, g, host):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                          "launches": nl, "avg_launch_us": round(1e3 * ms / max(1, nl), 1),
                          "algorithmic_bytes_per_launch": int(by / max(1, nl)),
-                         "note": "per-target state lives in LDS / L2-resident hash tables: the kernel is bound by "
-                                 "dependent gathers and LDS atomics, not by HBM streaming"}}
+                         "note": "per-target state lives in LDS / HBM hash tables, one workgroup per target: the "
+                                 "kernel is bound by chains of dependent probes and atomics (DESIGN.md 5), not by "
+                                 "HBM streaming"}}
 
 
 def _quiet_stdout(fn):

@@ -252,7 +252,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     // R-MAT 22 (2^18 targets): 65 536-slot tables at 75 % load 466 K targets/s; 262 144 slots at 25 % 820 K;
     // 524 288 slots at 25 % 935 K (156 instead of 532 searches left for tier 3)
     B.g_cap = 524288u;
-    const uint32_t want = (uint32_t)std::min<size_t>((size_t)g->n_cus * 4, to_tier2.size());
+    const uint32_t want = (uint32_t)g->n_cus * 4u;  // all of them at the first use: one allocation per handle
     if (g->apbs_blocks < want) {  // the tables stay with the handle: 16.4 MB per workgroup
       if (g->apbs_tables) (void)hipFree(g->apbs_tables);
       g->apbs_tables = nullptr;
@@ -260,7 +260,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       rc = alloc_dev((void**)&g->apbs_tables, (size_t)want * apbs_table_bytes(B.g_cap));
       if (rc == PPRHIP_OK) g->apbs_blocks = want;
     }
-    B.g_blocks = std::min(want, g->apbs_blocks);
+    B.g_blocks = (uint32_t)std::min<size_t>(g->apbs_blocks, to_tier2.size());
     B.g_tables = g->apbs_tables;
     if (rc == PPRHIP_OK) rc = run_tier(true, to_tier2, false, to_tier3);
   }
