@@ -252,12 +252,14 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     // R-MAT 22 (2^18 targets): 65 536-slot tables at 75 % load 466 K targets/s; 262 144 slots at 25 % 820 K;
     // 524 288 slots at 25 % 935 K (156 instead of 532 searches left for tier 3)
     B.g_cap = 524288u;
-    const uint32_t want = (uint32_t)g->n_cus * 4u;  // all of them at the first use: one allocation per handle
-    if (g->apbs_blocks < want) {  // the tables stay with the handle: 16.4 MB per workgroup
-      if (g->apbs_tables) (void)hipFree(g->apbs_tables);
-      g->apbs_tables = nullptr;
-      g->apbs_blocks = 0;
-      rc = alloc_dev((void**)&g->apbs_tables, (size_t)want * apbs_table_bytes(B.g_cap));
+    uint32_t want = (uint32_t)g->n_cus * 4u;  // all of them at the first use: one allocation per handle
+    if (g->apbs_blocks == 0) {  // the tables stay with the handle: 16.4 MB per workgroup
+      // a device that cannot spare 17 GB runs the tier with fewer workgroups in flight
+      for (; want >= 64; want /= 2) {
+        rc = alloc_dev((void**)&g->apbs_tables, (size_t)want * apbs_table_bytes(B.g_cap));
+        if (rc != PPRHIP_ERR_OOM) break;
+        (void)hipGetLastError();
+      }
       if (rc == PPRHIP_OK) g->apbs_blocks = want;
     }
     B.g_blocks = (uint32_t)std::min<size_t>(g->apbs_blocks, to_tier2.size());
