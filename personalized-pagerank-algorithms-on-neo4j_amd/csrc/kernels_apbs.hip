@@ -62,9 +62,14 @@ __device__ __forceinline__ double ap_take_residue(const ApTable<G>& T, uint32_t 
   return r;
 }
 
-// returns the slot of node u, inserting it if absent; 0xFFFFFFFF when the table is full
+// returns the slot of node u, inserting it if absent; 0xFFFFFFFF when the table is full.  The insertion that takes
+// the table past `limit` nodes raises *overflow at once: the search is handed to the next tier anyway, and the
+// threads that see the flag stop inserting, so the table never fills up - in a full table every further lookup of a
+// new node walks all of it (measured in the LDS tier before this check: 4.3 M such walks of 2048 probes each, nine
+// tenths of all the probes of the tier)
 template <bool G>
-__device__ __forceinline__ uint32_t ap_slot(const ApTable<G>& T, int32_t u, uint32_t* used_count) {
+__device__ __forceinline__ uint32_t ap_slot(const ApTable<G>& T, int32_t u, uint32_t* used_count, uint32_t limit,
+                                            uint32_t* overflow) {
   const uint32_t mask = T.cap - 1;
   uint32_t s = ((uint32_t)u * 2654435761u) >> 7 & mask;
   for (uint32_t probes = 0; probes < T.cap; ++probes) {
@@ -75,6 +80,7 @@ __device__ __forceinline__ uint32_t ap_slot(const ApTable<G>& T, int32_t u, uint
       if (prev == -1) {
         const uint32_t idx = atomicAdd(used_count, 1u);
         if (idx < T.lcap) T.used[idx] = (typename ApTable<G>::Idx)s;
+        if (idx >= limit) *overflow = 1;
         return s;
       }
       if (prev == u) return s;
@@ -163,12 +169,12 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
     uint32_t nf = 0;
     if (in_rp[t + 1] == in_rp[t]) {  // Backward_Search.java:46-49: reserve = {t: 1.0}
       if (tid == 0) {
-        const uint32_t s = ap_slot<G>(T, t, &s_used_count);
+        const uint32_t s = ap_slot<G>(T, t, &s_used_count, limit, &s_overflow);
         T.rsv[s] = 1.0;
       }
     } else {
       if (tid == 0) {
-        const uint32_t s = ap_slot<G>(T, t, &s_used_count);
+        const uint32_t s = ap_slot<G>(T, t, &s_used_count, limit, &s_overflow);
         T.res[s] = 1.0;  // :54-56; the target is pushed unconditionally first
         T.cur[0] = (Idx)s;
       }
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
           for (int q = 0; q < 4; ++q) {
             if (u[q] < 0 || s_overflow) continue;
             const double add = cc[q] / (double)(uint32_t)(ext[q] >> 32);  // :84-85
-            const uint32_t s = ap_slot<G>(T, u[q], &s_used_count);
+            const uint32_t s = ap_slot<G>(T, u[q], &s_used_count, limit, &s_overflow);
             if (s == 0xFFFFFFFFu) {
               s_overflow = 1;
               continue;
