@@ -1,5 +1,6 @@
 // allpair.cpp — All-Pair-Backward-Search (Base_Whole_Graph.preprocessing) and the inverted index.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -30,20 +31,68 @@ namespace {
 void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix) {
   ix->n = n;
   ix->offsets.assign((size_t)n + 1, 0);
-  // bucket by source (counting sort), then every bucket on its own: order by target, apply the k rule
+  // bucket by source, then every bucket on its own: order by target, apply the k rule.  The bucketing is a two-level
+  // counting sort so that it runs on all threads: entries go to 256 coarse ranges of sources first (per-thread
+  // histograms, sequential writes), then every coarse range is sorted by source on its own (a working set of
+  // n / 256 counters); one thread's scatter over all n sources was a third of the call at 32 M entries.
   const size_t N = tr.size();
   std::vector<uint64_t> start((size_t)n + 1, 0);
-  for (const Triple& e : tr) start[(size_t)e.v + 1]++;
-  for (uint32_t v = 0; v < n; ++v) start[v + 1] += start[v];
   std::vector<Triple> by_v(N);
-  {
-    std::vector<uint64_t> at(start.begin(), start.end() - 1);
-    for (const Triple& e : tr) by_v[at[e.v]++] = e;
-  }
-  std::vector<Triple>().swap(tr);
-  std::vector<uint64_t> kept((size_t)n + 1, 0);
   const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   const unsigned T = N < (1u << 16) ? 1u : hw;
+  auto parallel = [&](unsigned parts, auto&& fn) {  // fn(part) for part in [0, parts), T threads
+    std::atomic<unsigned> next{0};
+    auto work = [&]() {
+      for (unsigned p = next.fetch_add(1); p < parts; p = next.fetch_add(1)) fn(p);
+    };
+    std::vector<std::thread> th;
+    for (unsigned w = 1; w < T; ++w) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+  };
+  {
+    constexpr unsigned kCoarse = 256;
+    const uint32_t span = (uint32_t)(((uint64_t)n + kCoarse - 1) / kCoarse);  // sources per coarse range
+    const unsigned chunks = T;
+    std::vector<uint64_t> hist((size_t)chunks * kCoarse, 0);
+    auto chunk_lo = [&](unsigned c) { return (size_t)((unsigned long long)N * c / chunks); };
+    parallel(chunks, [&](unsigned c) {
+      uint64_t* h = hist.data() + (size_t)c * kCoarse;
+      for (size_t i = chunk_lo(c); i < chunk_lo(c + 1); ++i) h[(uint32_t)tr[i].v / span]++;
+    });
+    // coarse range b of chunk c starts at: all of ranges < b, then chunks < c of range b
+    std::vector<uint64_t> base((size_t)chunks * kCoarse, 0), cstart(kCoarse + 1, 0);
+    uint64_t run = 0;
+    for (unsigned b = 0; b < kCoarse; ++b) {
+      cstart[b] = run;
+      for (unsigned c = 0; c < chunks; ++c) {
+        base[(size_t)c * kCoarse + b] = run;
+        run += hist[(size_t)c * kCoarse + b];
+      }
+    }
+    cstart[kCoarse] = run;
+    std::vector<Triple> coarse(N);
+    parallel(chunks, [&](unsigned c) {
+      uint64_t* at = base.data() + (size_t)c * kCoarse;
+      for (size_t i = chunk_lo(c); i < chunk_lo(c + 1); ++i) coarse[at[(uint32_t)tr[i].v / span]++] = tr[i];
+    });
+    std::vector<Triple>().swap(tr);
+    parallel(kCoarse, [&](unsigned b) {
+      const uint32_t v_lo = std::min<uint64_t>((uint64_t)b * span, n), v_hi = std::min<uint64_t>((uint64_t)(b + 1) * span, n);
+      if (v_lo >= v_hi) return;
+      std::vector<uint64_t> cnt((size_t)(v_hi - v_lo) + 1, 0);
+      for (uint64_t i = cstart[b]; i < cstart[b + 1]; ++i) cnt[(uint32_t)coarse[i].v - v_lo + 1]++;
+      uint64_t acc = cstart[b];  // entries of sources below v_lo = entries of the coarse ranges below b
+      for (uint32_t v = v_lo; v < v_hi; ++v) {
+        start[v] = acc;
+        acc += cnt[v - v_lo + 1];
+        cnt[v - v_lo + 1] = start[v];  // becomes the write cursor of source v
+      }
+      for (uint64_t i = cstart[b]; i < cstart[b + 1]; ++i) by_v[cnt[(uint32_t)coarse[i].v - v_lo + 1]++] = coarse[i];
+    });
+    start[n] = N;
+  }
+  std::vector<uint64_t> kept((size_t)n + 1, 0);
   auto for_ranges = [&](auto&& fn) {
     std::vector<std::thread> th;
     for (unsigned w = 1; w < T; ++w) th.emplace_back(fn, (uint32_t)((uint64_t)n * w / T), (uint32_t)((uint64_t)n * (w + 1) / T));
