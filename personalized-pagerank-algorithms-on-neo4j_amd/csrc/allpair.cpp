@@ -302,8 +302,8 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     // 524 288 slots at 25 % 935 K (156 instead of 532 searches left for tier 3)
     B.g_cap = 524288u;
     uint32_t want = (uint32_t)g->n_cus * 4u;  // all of them at the first use: one allocation per handle
-    if (g->apbs_blocks == 0) {  // the tables stay with the handle: 16.4 MB per workgroup
-      // a device that cannot spare 17 GB runs the tier with fewer workgroups in flight
+    if (g->apbs_blocks == 0) {  // the tables stay with the handle: 18.4 MB per workgroup
+      // a device that cannot spare 19 GB runs the tier with fewer workgroups in flight
       for (; want >= 64; want /= 2) {
         rc = alloc_dev((void**)&g->apbs_tables, (size_t)want * apbs_table_bytes(B.g_cap));
         if (rc != PPRHIP_ERR_OOM) break;

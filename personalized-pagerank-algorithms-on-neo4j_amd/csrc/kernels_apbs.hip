@@ -27,7 +27,7 @@ constexpr int kApFront = 512;
 constexpr uint32_t kApGlobalLoadDiv = 4;  // the HBM tier hands a search on at cap / 4 nodes
 // entries of the HBM tier's lists: the node limit plus what one round of inserts can add before the limit is checked
 __host__ __device__ inline uint32_t ap_list_cap(uint32_t g_cap) { return g_cap / kApGlobalLoadDiv + 8192u; }
-size_t apbs_table_bytes(uint32_t g_cap) { return (size_t)g_cap * 28 + (size_t)ap_list_cap(g_cap) * 12; }
+size_t apbs_table_bytes(uint32_t g_cap) { return (size_t)g_cap * 32 + (size_t)ap_list_cap(g_cap) * 12; }
 
 template <bool G>
 struct ApTable {  // one target's state; arrays live in LDS (tier 1) or HBM (tier 2)
@@ -41,6 +41,7 @@ struct ApTable {  // one target's state; arrays live in LDS (tier 1) or HBM (tie
   Idx* nxt;
   uint32_t cap;    // power of two
   uint32_t lcap;   // entries the three lists hold
+  uint32_t ds, ks; // element strides of the double fields / the keys (1 in LDS: separate arrays; 4 / 8 in HBM: slots)
 };
 
 template <bool G>
@@ -52,13 +53,13 @@ __device__ __forceinline__ int32_t ap_cas(int32_t* p, int32_t cmp, int32_t val) 
 // them must bypass this CU's L1 (agent-scope relaxed load / exchange), or it may see a stale line.
 template <bool G>
 __device__ __forceinline__ int32_t ap_key(const ApTable<G>& T, uint32_t s) {
-  return G ? __hip_atomic_load(&T.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T.keys[s];
+  return G ? __hip_atomic_load(&T.keys[(size_t)(s) * T.ks], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T.keys[(size_t)(s) * T.ks];
 }
 template <bool G>
 __device__ __forceinline__ double ap_take_residue(const ApTable<G>& T, uint32_t s) {
-  if (G) return __hip_atomic_exchange(&T.res[s], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const double r = T.res[s];
-  T.res[s] = 0.0;
+  if (G) return __hip_atomic_exchange(&T.res[(size_t)(s) * T.ds], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double r = T.res[(size_t)(s) * T.ds];
+  T.res[(size_t)(s) * T.ds] = 0.0;
   return r;
 }
 
@@ -76,7 +77,7 @@ __device__ __forceinline__ uint32_t ap_slot(const ApTable<G>& T, int32_t u, uint
     const int32_t k = ap_key<G>(T, s);
     if (k == u) return s;
     if (k == -1) {
-      const int32_t prev = ap_cas<G>(&T.keys[s], -1, u);
+      const int32_t prev = ap_cas<G>(&T.keys[(size_t)(s) * T.ks], -1, u);
       if (prev == -1) {
         const uint32_t idx = atomicAdd(used_count, 1u);
         if (idx < T.lcap) T.used[idx] = (typename ApTable<G>::Idx)s;
@@ -121,16 +122,20 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
   ApTable<G> T;
   using Idx = typename ApTable<G>::Idx;
   if (G) {
-    // 28 B per slot (residue, reserve, pending, key) + three lists of slot indices that only have to hold the nodes
-    // a search may reach before it is handed on (ap_list_cap)
+    // 32-byte slots + three lists of slot indices that only have to hold the nodes a search may reach before it is
+    // handed on (ap_list_cap)
     const uint32_t lcap = ap_list_cap(g_cap);
-    const size_t per = (size_t)g_cap * 28 + (size_t)lcap * 12;
+    const size_t per = (size_t)g_cap * 32 + (size_t)lcap * 12;
     char* base = g_tables + (size_t)blockIdx.x * per;
+    // 32-byte slots {residue, reserve, pending, key}: at a quarter load a lookup is one or two probes, so what counts
+    // is that the probe, the residue update and the pop of a node touch one 128-byte line, not three
     T.res = (double*)base;
-    T.rsv = T.res + g_cap;
-    T.pend = T.rsv + g_cap;
-    T.keys = (int32_t*)(T.pend + g_cap);
-    T.used = (Idx*)(T.keys + g_cap);
+    T.rsv = T.res + 1;
+    T.pend = T.res + 2;
+    T.keys = (int32_t*)(T.res + 3);
+    T.ds = 4;
+    T.ks = 8;
+    T.used = (Idx*)(base + (size_t)g_cap * 32);
     T.cur = T.used + lcap;
     T.nxt = T.cur + lcap;
     T.cap = g_cap;
@@ -140,6 +145,8 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
     T.used = s_used; T.cur = s_cur; T.nxt = s_nxt;
     T.cap = kApLdsCap;
     T.lcap = kApLdsCap;
+    T.ds = 1;
+    T.ks = 1;
   }
   // LDS tier: give up at 75 % load.  HBM tier: at 25 % - a probe chain is a chain of L2 round trips there, and with
   // linear probing (which keeps a chain inside the 128-byte line its first probe fetched) it is the load factor that
@@ -147,9 +154,9 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
   // 68 for the slowest lane of a wave
   const uint32_t limit = G ? T.cap / kApGlobalLoadDiv : T.cap - T.cap / 4;
   for (uint32_t i = tid; i < T.cap; i += 256) {
-    T.keys[i] = -1;
-    T.res[i] = 0.0;
-    T.rsv[i] = 0.0;
+    T.keys[(size_t)(i) * T.ks] = -1;
+    T.res[(size_t)(i) * T.ds] = 0.0;
+    T.rsv[(size_t)(i) * T.ds] = 0.0;
   }
   __syncthreads();
   unsigned long long pops = 0, edges = 0;
@@ -170,12 +177,12 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
     if (in_rp[t + 1] == in_rp[t]) {  // Backward_Search.java:46-49: reserve = {t: 1.0}
       if (tid == 0) {
         const uint32_t s = ap_slot<G>(T, t, &s_used_count, limit, &s_overflow);
-        T.rsv[s] = 1.0;
+        T.rsv[(size_t)(s) * T.ds] = 1.0;
       }
     } else {
       if (tid == 0) {
         const uint32_t s = ap_slot<G>(T, t, &s_used_count, limit, &s_overflow);
-        T.res[s] = 1.0;  // :54-56; the target is pushed unconditionally first
+        T.res[(size_t)(s) * T.ds] = 1.0;  // :54-56; the target is pushed unconditionally first
         T.cur[0] = (Idx)s;
       }
       nf = 1;
@@ -187,8 +194,8 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
       for (uint32_t i = tid; i < nf; i += 256) {
         const uint32_t s = T.cur[i];
         const double rc = ap_take_residue<G>(T, s);
-        T.rsv[s] = T.rsv[s] + rc * alpha;
-        T.pend[s] = (1.0 - alpha) * rc;
+        T.rsv[(size_t)(s) * T.ds] = T.rsv[(size_t)(s) * T.ds] + rc * alpha;
+        T.pend[(size_t)(s) * T.ds] = (1.0 - alpha) * rc;
       }
       if (tid == 0) s_nnext = 0;
       pops += (tid == 0) ? nf : 0;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
             const uint32_t b = in_rp[v];
             d0 = in_rp[v + 1] - b;
             f_row[i0] = b;
-            f_c[i0] = T.pend[s];
+            f_c[i0] = T.pend[(size_t)(s) * T.ds];
           }
           if (i1 < cnt) {
             const uint32_t s = T.cur[fb + i1];
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
             const uint32_t b = in_rp[v];
             d1 = in_rp[v + 1] - b;
             f_row[i1] = b;
-            f_c[i1] = T.pend[s];
+            f_c[i1] = T.pend[(size_t)(s) * T.ds];
           }
         }
         // exclusive prefix of the degrees over the sub-batch (two elements per thread: i, i + 256)
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
               s_overflow = 1;
               continue;
             }
-            const double old = atomic_add_ret(&T.res[s], add);
+            const double old = atomic_add_ret(&T.res[(size_t)(s) * T.ds], add);
             const double nw = old + add;
             if (!(old > rmax) && nw > rmax) {  // :89 strict, un-normalised; first crossing of the level
               const uint32_t pos = atomicAdd(&s_nnext, 1u);
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
       unsigned long long run = 0;
       for (uint32_t c0 = 0; c0 < used; c0 += 256) {  // count first, one reservation per target
         const uint32_t i = c0 + tid;
-        const bool take = i < used && T.rsv[T.used[i]] > 0.0 && T.rsv[T.used[i]] >= rmax;
+        const bool take = i < used && T.rsv[(size_t)T.used[i] * T.ds] > 0.0 && T.rsv[(size_t)T.used[i] * T.ds] >= rmax;
         run += take ? 1ull : 0ull;
       }
       const unsigned long long total = block_sum_u64(run, s_scan64);  // valid in thread 0
@@ -301,14 +308,14 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
         for (uint32_t c0 = 0; c0 < used; c0 += 256) {
           const uint32_t i = c0 + tid;
           const uint32_t s = i < used ? T.used[i] : 0u;
-          const bool take = i < used && T.rsv[s] > 0.0 && T.rsv[s] >= rmax;
+          const bool take = i < used && T.rsv[(size_t)(s) * T.ds] > 0.0 && T.rsv[(size_t)(s) * T.ds] >= rmax;
           unsigned long long chunk_total = 0;
           const unsigned long long ex =
               block_excl_scan_256<unsigned long long>(take ? 1ull : 0ull, s_scan64, &chunk_total);
           if (take) {
             out_v[at + ex] = new2old[ap_key<G>(T, s)];
             out_t[at + ex] = t_old;
-            out_p[at + ex] = T.rsv[s];
+            out_p[at + ex] = T.rsv[(size_t)(s) * T.ds];
           }
           at += chunk_total;
         }
@@ -322,16 +329,16 @@ __global__ __launch_bounds__(256) void k_apbs(const int32_t* __restrict__ target
     // ---- clear the touched slots (all of them after an overflow)
     if (ovf) {
       for (uint32_t i = tid; i < T.cap; i += 256) {
-        T.keys[i] = -1;
-        T.res[i] = 0.0;
-        T.rsv[i] = 0.0;
+        T.keys[(size_t)(i) * T.ks] = -1;
+        T.res[(size_t)(i) * T.ds] = 0.0;
+        T.rsv[(size_t)(i) * T.ds] = 0.0;
       }
     } else {
       for (uint32_t i = tid; i < used; i += 256) {
         const uint32_t s = T.used[i];
-        T.keys[s] = -1;
-        T.res[s] = 0.0;
-        T.rsv[s] = 0.0;
+        T.keys[(size_t)(s) * T.ks] = -1;
+        T.res[(size_t)(s) * T.ds] = 0.0;
+        T.rsv[(size_t)(s) * T.ds] = 0.0;
       }
     }
     __syncthreads();
