@@ -297,13 +297,14 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
   }
   if (rc == PPRHIP_OK && !to_tier2.empty()) {
-    // searches of up to 131 072 nodes at a quarter load (kernels_apbs.hip); four workgroups per CU.  Measured on
+    // searches of up to 131 072 nodes at a quarter load (kernels_apbs.hip); two workgroups per CU (1 / 2 / 3 / 4 /
+    // 8 per CU: 82 / 72 / 78 / 82 / 93 ms for tiers 1 + 2: more tables in flight cost more than they hide).  Measured on
     // R-MAT 22 (2^18 targets): 65 536-slot tables at 75 % load 466 K targets/s; 262 144 slots at 25 % 820 K;
     // 524 288 slots at 25 % 935 K (156 instead of 532 searches left for tier 3)
     B.g_cap = 524288u;
-    uint32_t want = (uint32_t)g->n_cus * 4u;  // all of them at the first use: one allocation per handle
+    uint32_t want = (uint32_t)g->n_cus * 2u;  // all of them at the first use: one allocation per handle
     if (g->apbs_blocks == 0) {  // the tables stay with the handle: 18.4 MB per workgroup
-      // a device that cannot spare 19 GB runs the tier with fewer workgroups in flight
+      // a device that cannot spare 9.4 GB runs the tier with fewer workgroups in flight
       for (; want >= 64; want /= 2) {
         rc = alloc_dev((void**)&g->apbs_tables, (size_t)want * apbs_table_bytes(B.g_cap));
         if (rc != PPRHIP_ERR_OOM) break;

@@ -240,7 +240,7 @@ struct pprhip_graph {
   hipStream_t own_stream = nullptr;   // slot: the stream its worker thread uses
   pprhip::KernelTimer ktimer;         // slot: its worker's kernel-class timer; graph: the sweeps' timer
   std::vector<pprhip_graph*> slots;
-  char* apbs_tables = nullptr;  // All-Pair tier 2: hash tables of apbs_blocks workgroups, kept between calls (19 GB:
+  char* apbs_tables = nullptr;  // All-Pair tier 2: hash tables of apbs_blocks workgroups, kept between calls (9.4 GB:
   uint32_t apbs_blocks = 0;     // allocating and releasing them per call cost up to seconds)
   pprhip::detail::FetchPipe* fetch = nullptr;  // delivery of batched queries' vectors to host memory (engine_internal.hpp)
   double* c8[2] = {nullptr, nullptr};
