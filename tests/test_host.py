@@ -165,3 +165,37 @@ def test_tuning_defaults_match_oracle_twin(pkg, orc):
     t = pkg.tuning_batch()                                       # the batch profile changes the dense-level terms only
     changed = [f for f, _ in t._fields_ if getattr(t, f) != getattr(a, f)]
     assert sorted(changed) == ["c_dense_edge_ns", "c_dense_node_ns", "dense_frac", "gs_frac"]
+
+
+def test_index_merge_large_runs_on_all_threads(pkg):
+    """Enough entries (> 2^16) for the multi-threaded path of the index finalisation: a two-level counting sort by
+    source on all threads, then the k rule per source - against a plain numpy restatement of Base_Whole_Graph's rule
+    (entries >= the k-th largest, value descending, ties in target order; k < 0: target order)."""
+    rng = np.random.default_rng(5)
+    n, per = 3000, 64
+    shards = []
+    rows = {}
+    for sh in range(3):                                  # three target shards with disjoint targets
+        off = np.zeros(n + 1, dtype=np.uint64)
+        tg, vl = [], []
+        for v in range(n):
+            cnt = int(rng.integers(0, per)) if v % 7 else 0
+            t = np.sort(rng.choice(np.arange(sh * 100000, sh * 100000 + 5000), size=cnt, replace=False)).astype(np.int32)
+            p = np.round(rng.random(cnt), 2)             # many ties
+            off[v + 1] = off[v] + cnt
+            tg.append(t)
+            vl.append(p)
+            rows.setdefault(v, []).extend(zip(t.tolist(), p.tolist()))
+        shards.append(pkg.index_from_arrays(n, off, np.concatenate(tg).astype(np.int32), np.concatenate(vl)))
+    assert sum(len(r) for r in rows.values()) > (1 << 16)
+    for k in (-1, 5):
+        off, tg, vl = pkg.merge_indexes(shards, k).arrays()
+        for v in range(0, n, 37):
+            r = sorted(rows.get(v, []))                  # target order
+            if k >= 0 and len(r) >= k:
+                kth = sorted((p for _, p in r), reverse=True)[k - 1]
+                r = [e for e in r if e[1] >= kth]
+            if k >= 0:
+                r = sorted(r, key=lambda e: -e[1])       # stable: ties stay in target order
+            got = list(zip(tg[off[v]:off[v + 1]].tolist(), vl[off[v]:off[v + 1]].tolist()))
+            assert got == r, (k, v)
