@@ -157,7 +157,9 @@ int HostTripleSink::take_device(pprhip_graph* g, const int32_t* d_v, const int32
   PPRHIP_CHECK_HIP(hipMemcpyAsync(h_t.data(), d_t, sizeof(int32_t) * count, hipMemcpyDeviceToHost, g->stream));
   PPRHIP_CHECK_HIP(hipMemcpyAsync(h_p.data(), d_p, sizeof(double) * count, hipMemcpyDeviceToHost, g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-  for (unsigned long long i = 0; i < count; ++i) tr.push_back({h_v[i], h_t[i], h_p[i]});
+  const size_t at = tr.size();
+  tr.resize(at + count);
+  for (unsigned long long i = 0; i < count; ++i) tr[at + i] = Triple{h_v[i], h_t[i], h_p[i]};
   return PPRHIP_OK;
 }
 int HostTripleSink::take_host(pprhip_graph*, std::vector<Triple>& more) {
