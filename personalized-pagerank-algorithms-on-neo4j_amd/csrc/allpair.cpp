@@ -30,7 +30,6 @@ namespace {
 // target order).
 void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix) {
   ix->n = n;
-  ix->offsets.assign((size_t)n + 1, 0);
   // bucket by source, then every bucket on its own: order by target, apply the k rule.  The bucketing is a two-level
   // counting sort so that it runs on all threads: entries go to 256 coarse ranges of sources first (per-thread
   // histograms, sequential writes), then every coarse range is sorted by source on its own (a working set of
@@ -130,7 +129,6 @@ void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix)
   for (uint32_t v = 0; v < n; ++v) kept[v + 1] += kept[v];
   ix->targets.resize(kept[n]);
   ix->values.resize(kept[n]);
-  for (uint32_t v = 0; v <= n; ++v) ix->offsets[v] = kept[v];
   // pass 2: into the index arrays
   for_ranges([&](uint32_t lo, uint32_t hi) {
     for (uint32_t v = lo; v < hi; ++v) {
@@ -142,6 +140,7 @@ void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix)
       }
     }
   });
+  ix->offsets.swap(kept);
 }
 
 }  // namespace
