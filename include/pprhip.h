@@ -339,6 +339,15 @@ int pprhip_all_pair_backward_sharded(pprhip_comm_t* c, double alpha, double thre
  * rows_max rows each (short blocks padded with id -1 / value 0) in ids_root / vals_root. */
 int pprhip_topk_gather(pprhip_comm_t* c, const int32_t* ids, const double* vals, int rows, int rows_max, int k,
                        int32_t* ids_root, double* vals_root);
+/* Failure behaviour of the collectives.  A rank that fails inside pprhip_all_pair_backward_sharded before the
+ * exchange still takes part in it with an error mark in its size words: every rank returns an error (the failing one
+ * its own, the others PPRHIP_ERR_STATE "rank r failed before the exchange"), none blocks.  No wait on the fabric is
+ * unbounded: after PPRHIP_COMM_TIMEOUT_S seconds (environment, default 1800) without completion, or when RCCL reports
+ * an asynchronous error, the communicator is aborted (ncclCommAbort: peers' pending operations end with an error as
+ * well) and every later collective on it fails at once.  A process that must leave a group early (its own failure
+ * outside these calls) calls pprhip_comm_abort before pprhip_comm_destroy so that its peers are released.
+ * (No reference counterpart: the Java is single-threaded, Gen_Util.java:208-232 / Base_Whole_Graph.java:76-92.) */
+int pprhip_comm_abort(pprhip_comm_t* c);
 
 /* ---------------------------------------------------------------- ground truth (a12) */
 /* Power_Method.computeWholeGraphPPR (Power_Method.java:44-101): `iters` synchronous sweeps. */

@@ -77,7 +77,7 @@ EXPORTS = [
     "pprhip_results_info", "pprhip_results_fetch", "pprhip_results_sum", "pprhip_fora_batch_single_source_resident",
     "pprhip_fora_batch", "pprhip_all_pair_backward_multi", "pprhip_comm_unique_id", "pprhip_comm_create",
     "pprhip_comm_destroy", "pprhip_comm_info", "pprhip_shard_target_range", "pprhip_all_pair_backward_sharded",
-    "pprhip_topk_gather",
+    "pprhip_topk_gather", "pprhip_comm_abort",
 ]
 COMM_ID_BYTES = 128
 
@@ -152,6 +152,7 @@ def lib():
     L.pprhip_shard_target_range.argtypes = [ci, ci, u32, P(u32), P(u32)]
     L.pprhip_all_pair_backward_sharded.argtypes = [vp, dbl, dbl, ci, P(vp), P(Stats)]
     L.pprhip_topk_gather.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
+    L.pprhip_comm_abort.argtypes = [vp]
     L.pprhip_backward_push.argtypes = [vp, i32, dbl, dbl, vp, vp, P(Stats)]
     L.pprhip_all_pair_backward.argtypes = [vp, dbl, dbl, ci, u32, u32, P(vp), P(Stats)]
     L.pprhip_index_merge.argtypes = [P(vp), ci, ci, P(vp)]
@@ -396,6 +397,11 @@ class Comm:
         rv = np.empty((self.world, rows_max, k)) if self.rank == 0 else None
         _check(lib().pprhip_topk_gather(self.h, _ptr(ids), _ptr(vals), rows, rows_max, k, _ptr(ri), _ptr(rv)))
         return (ri, rv) if self.rank == 0 else None
+
+    def abort(self):
+        """Leaves the group at once (peers' pending operations end with an error instead of waiting)."""
+        if getattr(self, "h", None):
+            _check(lib().pprhip_comm_abort(self.h))
 
     def close(self):
         if getattr(self, "h", None):

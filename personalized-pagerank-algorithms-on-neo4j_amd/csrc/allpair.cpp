@@ -241,7 +241,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
 
   // runs one tier over `list` (or the range when list is empty and use_range) until every target
   // has either produced its triples or landed in `give_up`
-  auto run_tier = [&](bool global_tier, std::vector<int32_t> list, bool use_range, std::vector<int32_t>& give_up) -> int {
+  auto run_tier = [&](bool dense_tier, std::vector<int32_t> list, bool use_range, std::vector<int32_t>& give_up) -> int {
     int32_t* d_list = nullptr;
     struct ListGuard {  // frees the target list on every exit, error returns included
       int32_t*& p;
@@ -260,7 +260,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       const unsigned long long init[8] = {0, 0, ~0ull, 0, 0, 0, 0, 0};
       PPRHIP_CHECK_HIP(hipMemcpyAsync(cells, init, sizeof init, hipMemcpyHostToDevice, g->stream));
       ktimer().begin(PPRHIP_KERNEL_BACKWARD_BATCH, 0);
-      PPRHIP_TRY(launch_apbs(g, global_tier, use_range ? nullptr : d_list, t_begin, cnt, alpha, threshold, B));
+      PPRHIP_TRY(launch_apbs(g, dense_tier, use_range ? nullptr : d_list, t_begin, cnt, alpha, threshold, B));
       ktimer().end();
       PPRHIP_CHECK_HIP(hipMemcpyAsync(h_cells, cells, sizeof h_cells, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
@@ -291,6 +291,19 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     return PPRHIP_OK;
   };
 
+  // in-edge records for both tiers' edge loops (8 B per edge; stays with the handle)
+  if (!g->in_rec) {
+    void* rec = nullptr;
+    if ((rc = alloc_dev(&rec, sizeof(unsigned long long) * std::max<uint64_t>(1, g->m))) == PPRHIP_OK &&
+        (rc = launch_build_in_rec(g, rec)) == PPRHIP_OK)
+      g->in_rec = rec;
+    else if (rec)
+      (void)hipFree(rec);
+    if (rc != PPRHIP_OK) {
+      release();
+      return rc;
+    }
+  }
   std::vector<int32_t> to_tier2, to_tier3;
   if (first_tier <= 1) {
     rc = run_tier(false, {}, true, to_tier2);
@@ -298,30 +311,88 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
   }
   if (rc == PPRHIP_OK && !to_tier2.empty()) {
-    // searches of up to 131 072 nodes at a quarter load (kernels_apbs.hip); two workgroups per CU (1 / 2 / 3 / 4 /
-    // 8 per CU: 82 / 72 / 78 / 82 / 93 ms for tiers 1 + 2: more tables in flight cost more than they hide).  Measured on
-    // R-MAT 22 (2^18 targets): 65 536-slot tables at 75 % load 466 K targets/s; 262 144 slots at 25 % 820 K;
-    // 524 288 slots at 25 % 935 K (156 instead of 532 searches left for tier 3)
-    B.g_cap = 524288u;
-    uint32_t want = (uint32_t)g->n_cus * 2u;  // all of them at the first use: one allocation per handle
-    if (g->apbs_blocks == 0) {  // the tables stay with the handle: 18.4 MB per workgroup
-      // a device that cannot spare 9.4 GB runs the tier with fewer workgroups in flight
-      for (; want >= 64; want /= 2) {
-        rc = alloc_dev((void**)&g->apbs_tables, (size_t)want * apbs_table_bytes(B.g_cap));
-        if (rc != PPRHIP_ERR_OOM) break;
+    // Dense workspaces, one per workgroup in flight (kernels_apbs.hip): 16n bytes of vectors + lists.  The lists hold
+    // what a search may list before it is handed to tier 3: nodes whose residue left zero (clean-up; on overflow the
+    // whole vector is cleared instead) and a level's frontier.  The workspaces stay with the handle: allocating and
+    // zeroing gigabytes per call would cost more than the searches of a small target range.
+    if (g->apbs_blocks == 0) {
+      // (PPRHIP_APBS_CAP_T / _CAP_F shrink the lists so that tests reach the overflow paths on small graphs)
+      const char* e_t = getenv("PPRHIP_APBS_CAP_T");
+      const char* e_f = getenv("PPRHIP_APBS_CAP_F");
+      const uint32_t cap_t = e_t ? (uint32_t)std::max(1, atoi(e_t)) : std::min<uint32_t>(g->n, 1u << 20) + 4096u;
+      const uint32_t cap_f = e_f ? (uint32_t)std::max(1, atoi(e_f)) : std::min<uint32_t>(g->n, 1u << 18) + 64u;
+      const char* per_cu = getenv("PPRHIP_APBS_WGS_PER_CU");
+      uint32_t want = (uint32_t)g->n_cus * (uint32_t)std::max(1, std::min(2, per_cu ? atoi(per_cu) : 1));
+      const size_t per = apbs_dense_bytes(g->n, cap_t, cap_f);
+      int arc = PPRHIP_ERR_OOM;
+      // a device that cannot spare them all runs the tier with fewer workgroups in flight
+      for (; want >= 8; want /= 2) {
+        arc = alloc_dev((void**)&g->apbs_ws, (size_t)want * per);
+        if (arc != PPRHIP_ERR_OOM) break;
         (void)hipGetLastError();
       }
-      if (rc == PPRHIP_OK) g->apbs_blocks = want;
+      if (arc == PPRHIP_OK && hipMemsetAsync(g->apbs_ws, 0, (size_t)want * per, g->stream) != hipSuccess) {
+        (void)hipFree(g->apbs_ws);
+        g->apbs_ws = nullptr;
+        set_error("All-Pair: clearing the dense workspaces failed");
+        arc = PPRHIP_ERR_HIP;
+      }
+      if (arc == PPRHIP_OK) {
+        g->apbs_blocks = want;
+        g->apbs_cap_t = cap_t;
+        g->apbs_cap_f = cap_f;
+      } else if (arc != PPRHIP_ERR_OOM) {
+        rc = arc;
+      }
     }
-    B.g_blocks = (uint32_t)std::min<size_t>(g->apbs_blocks, to_tier2.size());
-    B.g_tables = g->apbs_tables;
-    if (rc == PPRHIP_OK) rc = run_tier(true, to_tier2, false, to_tier3);
+    if (rc == PPRHIP_OK && g->apbs_blocks) {
+      B.ws = g->apbs_ws;
+      B.ws_blocks = g->apbs_blocks;
+      B.cap_t = g->apbs_cap_t;
+      B.cap_f = g->apbs_cap_f;
+      // targets with the most in-edges first: the searches that push the most edges start the level-1 fan-out from
+      // hubs, and a workgroup that draws such a search last would finish long after the others
+      {
+        const std::vector<uint32_t>& irp = g->h_in_rp;
+        const std::vector<int32_t>& o2n = g->h_old2new;
+        std::stable_sort(to_tier2.begin(), to_tier2.end(), [&](int32_t x, int32_t y) {
+          const int32_t a = o2n[x], b = o2n[y];
+          return irp[a + 1] - irp[a] > irp[b + 1] - irp[b];
+        });
+      }
+      const bool debug = getenv("PPRHIP_APBS_DEBUG") != nullptr;
+      if (debug && alloc_dev((void**)&B.dbg, sizeof(unsigned long long) * 8 * g->apbs_blocks) == PPRHIP_OK)
+        (void)hipMemsetAsync(B.dbg, 0, sizeof(unsigned long long) * 8 * g->apbs_blocks, g->stream);
+      rc = run_tier(true, to_tier2, false, to_tier3);
+      if (B.dbg) {
+        std::vector<unsigned long long> h((size_t)8 * g->apbs_blocks);
+        if (hipMemcpy(h.data(), B.dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+          unsigned long long tot[8] = {0}, t_end_max = 0, t_end_min = ~0ull, e_max = 0;
+          for (uint32_t w = 0; w < g->apbs_blocks; ++w) {
+            if (!h[8 * w]) continue;
+            for (int i = 0; i < 7; ++i) tot[i] += h[8 * w + i];
+            t_end_max = std::max(t_end_max, h[8 * w + 7]);
+            t_end_min = std::min(t_end_min, h[8 * w + 7]);
+            e_max = std::max(e_max, h[8 * w + 1]);
+          }
+          fprintf(stderr, "[apbs dense] searches %llu edges %llu (max per workgroup %llu); workgroup-ms in pops %.1f scans %.1f "
+                          "edges %.1f emit %.1f clear %.1f; first workgroup ended %.2f ms before the last\n",
+                  tot[0], tot[1], e_max, tot[2] / 1e5, tot[3] / 1e5, tot[4] / 1e5, tot[5] / 1e5, tot[6] / 1e5,
+                  (t_end_max - t_end_min) / 1e5);
+        }
+        (void)hipFree(B.dbg);
+        B.dbg = nullptr;
+      }
+    } else if (rc == PPRHIP_OK) {
+      to_tier3 = to_tier2;  // no memory for the dense tier: everything runs on the batch slots
+    }
   }
   release();
   if (rc != PPRHIP_OK) return rc;
 
-  // ---- tier 3: the targets whose search outgrows 131 072 nodes run on whole vectors, 16 of them in flight
-  // on the batch slots; levels that touch a large part of the graph run as batched sweeps over the out-CSR
+  // ---- tier 3 (fallback): searches whose frontier outgrows tier 2's lists run as whole-vector backward searches,
+  // 16 of them in flight on the batch slots; levels that touch a large part of the graph run as batched sweeps over
+  // the out-CSR
   pprhip_stats_t st3;
   std::memset(&st3, 0, sizeof st3);
   if (!to_tier3.empty()) {  // Base_Whole_Graph.java:76-92
@@ -362,13 +433,20 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   }
   st.push_ms = CallTimer::ms(g->ev[0], g->ev[1]);
   st.rmax_final = threshold;
-  st.rounds = (uint32_t)(to_tier2.size());      // targets that needed the HBM tier
+  st.rounds = (uint32_t)(to_tier2.size());      // targets that needed the dense tier
   st.dense_nodes = (uint64_t)to_tier3.size();   // targets that needed the whole-vector path
   return PPRHIP_OK;
 }
 
 // index over all n sources from entries of any targets, rows outside [v_lo, v_hi) must not occur
 int index_from_triples(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index_t** out) {
+  // entries may come from a device buffer, an exchange or a caller's arrays: a source or target outside [0, n) must
+  // be an error here, not an out-of-range write in the bucketing below
+  for (const Triple& x : tr)
+    if (x.v < 0 || (uint32_t)x.v >= n || x.t < 0 || (uint32_t)x.t >= n) {
+      set_error("index entry (source %d, target %d) outside [0, %u)", x.v, x.t, n);
+      return PPRHIP_ERR_INVALID;
+    }
   std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
   if (!ix) return PPRHIP_ERR_OOM;
   finalize_rows(n, tr, k, ix.get());
@@ -440,11 +518,7 @@ int pprhip_index_merge(const pprhip_index_t* const* shards, int n_shards, int k,
       for (uint64_t i = shards[s]->offsets[v]; i < shards[s]->offsets[v + 1]; ++i)
         tr.push_back({(int32_t)v, shards[s]->targets[i], shards[s]->values[i]});
   }
-  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
-  if (!ix) return PPRHIP_ERR_OOM;
-  finalize_rows(n, tr, k, ix.get());
-  *merged_out = ix.release();
-  return PPRHIP_OK;
+  return index_from_triples(n, tr, k, merged_out);
 }
 
 int pprhip_index_from_arrays(uint32_t n, const uint64_t* offsets, const int32_t* targets, const double* values,
@@ -456,6 +530,12 @@ int pprhip_index_from_arrays(uint32_t n, const uint64_t* offsets, const int32_t*
   for (uint32_t v = 0; v < n; ++v)
     if (offsets[v + 1] < offsets[v]) {
       set_error("pprhip_index_from_arrays: offsets must be non-decreasing");
+      return PPRHIP_ERR_INVALID;
+    }
+  for (uint64_t i = 0; i < offsets[n]; ++i)
+    if (targets[i] < 0 || (uint32_t)targets[i] >= n) {
+      set_error("pprhip_index_from_arrays: target %d at position %llu outside [0, %u)", targets[i],
+                (unsigned long long)i, n);
       return PPRHIP_ERR_INVALID;
     }
   std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());

@@ -17,14 +17,28 @@
 //     use (dlopen: the single-GPU paths, the tests and the `ppr` CLI never pay for a 570 MB library);
 //   * in-process (used by pprhip_fora_batch / pprhip_all_pair_backward_multi when several handles share one
 //     device, which RCCL does not allow): the same record layout and the same partition, copies by hipMemcpy.
+//
+// Failure protocol (both transports): an exchange is a collective, so a rank that fails before it still takes part -
+// it posts an error sentinel in the size words it sends, every peer sees it, nobody sends a payload and every rank
+// returns an error (the failing rank its own).  Nothing on this path waits without a bound: RCCL work is awaited by
+// polling the stream with a time limit (PPRHIP_COMM_TIMEOUT_S, default 1800) and the communicator's asynchronous
+// error state; on either the communicator is aborted (ncclCommAbort), which releases the peers' kernels as well.
+// One-process communicators are created with ncclCommInitAll from the calling thread (no rendezvous between
+// threads that one failing rank could leave the others in).
+// STATUS: the RCCL transport with more than one rank has not executed anywhere yet (no multi-GPU box was available
+// to this build; it runs with a group of one in tests/test_gpu_multi.py) - the in-process transport, which shares
+// the partition, the record layout, the sentinel protocol and every line outside comm_alltoallv's transport branch,
+// is what the 2- and 3-rank tests and the fault-injection tests exercise.
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 
 #include "engine_internal.hpp"
@@ -37,7 +51,7 @@ namespace {
 // ---- the handful of RCCL entry points the path needs (rccl/rccl.h), bound at first use
 typedef struct ncclComm* ncclComm_t;
 struct ncclUniqueId { char internal[128]; };
-enum { ncclSuccess = 0 };
+enum { ncclSuccess = 0, ncclInProgress = 7 };
 enum { ncclUint8 = 1 };
 
 struct RcclApi {
@@ -45,6 +59,9 @@ struct RcclApi {
   int (*GetUniqueId)(ncclUniqueId*) = nullptr;
   int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommAbort)(ncclComm_t) = nullptr;
+  int (*CommGetAsyncError)(ncclComm_t, int*) = nullptr;
+  int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
@@ -66,13 +83,16 @@ RcclApi* rccl() {
     api.GetUniqueId = (int (*)(ncclUniqueId*))sym("ncclGetUniqueId");
     api.CommInitRank = (int (*)(ncclComm_t*, int, ncclUniqueId, int))sym("ncclCommInitRank");
     api.CommDestroy = (int (*)(ncclComm_t))sym("ncclCommDestroy");
+    api.CommAbort = (int (*)(ncclComm_t))sym("ncclCommAbort");
+    api.CommGetAsyncError = (int (*)(ncclComm_t, int*))sym("ncclCommGetAsyncError");
+    api.CommInitAll = (int (*)(ncclComm_t*, int, const int*))sym("ncclCommInitAll");
     api.Send = (int (*)(const void*, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclSend");
     api.Recv = (int (*)(void*, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclRecv");
     api.GroupStart = (int (*)())sym("ncclGroupStart");
     api.GroupEnd = (int (*)())sym("ncclGroupEnd");
     api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
-    ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.Send && api.Recv && api.GroupStart &&
-         api.GroupEnd && api.GetErrorString;
+    ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.CommAbort && api.CommGetAsyncError &&
+         api.CommInitAll && api.Send && api.Recv && api.GroupStart && api.GroupEnd && api.GetErrorString;
   });
   return ok ? &api : nullptr;
 }
@@ -94,26 +114,42 @@ struct LocalGroup {
   uint64_t gen = 0;
   std::vector<const void*> send;                 // per rank: posted send buffer (device)
   std::vector<std::vector<uint64_t>> send_off;   // per rank: byte offsets per peer, world + 1
-  int err = 0;
-  // returns once every rank has arrived - or at once, for good, after a rank has called abort()
+  std::vector<int> posted_rc;                    // per rank: the error it entered the exchange with (0: none)
+  // Returns once every rank of the group has arrived.  Every rank takes part in every exchange, failed or not (it
+  // posts its error instead of data), so the count always completes and all ranks leave a barrier together: a send
+  // buffer is never released while a peer may still be copying from it.
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
-    if (err) return;
     const uint64_t my = gen;
     if (++arrived == world) {
       arrived = 0;
       ++gen;
       cv.notify_all();
     } else {
-      cv.wait(lk, [&] { return gen != my || err != 0; });
+      cv.wait(lk, [&] { return gen != my; });
     }
   }
-  void abort(int rc) {  // a rank that fails lets the others out of their barriers
-    std::lock_guard<std::mutex> lk(mu);
-    if (!err) err = rc;
-    cv.notify_all();
-  }
 };
+
+constexpr unsigned long long kFailedWord = ~0ull;  // size word of a rank that takes part in an exchange only to say it failed
+
+double comm_timeout_s() {
+  const char* e = getenv("PPRHIP_COMM_TIMEOUT_S");
+  const double v = e ? atof(e) : 0.0;
+  return v > 0.0 ? v : 1800.0;
+}
+
+// test switch: PPRHIP_FAULT_RANK=<r> makes rank r of a multi-GPU call fail at the point PPRHIP_FAULT_AT names
+// ("search", the default: before anything was found; "partition": after the search, before the exchange;
+// "exchange": inside the exchange, after the sizes are known), so that the failure protocol can be exercised
+bool fault_injected(int rank, const char* at) {
+  const char* r = getenv("PPRHIP_FAULT_RANK");
+  if (!r || atoi(r) != rank) return false;
+  const char* where = getenv("PPRHIP_FAULT_AT");
+  if (strcmp(where ? where : "search", at) != 0) return false;
+  set_error("injected fault on rank %d (%s)", rank, at);
+  return true;
+}
 
 }  // namespace
 
@@ -122,33 +158,94 @@ struct pprhip_comm {
   int rank = 0, world = 1;
   ncclComm_t nccl = nullptr;
   LocalGroup* local = nullptr;  // not owned
+  bool dead = false;            // the RCCL communicator was aborted: every later collective fails at once
 };
 
 namespace {
 
+// aborts the RCCL communicator (releases this rank's and, through the fabric, the peers' pending kernels)
+void comm_abort(pprhip_comm* c) {
+  if (c->nccl) {
+    (void)rccl()->CommAbort(c->nccl);
+    c->nccl = nullptr;
+  }
+  c->dead = true;
+}
+
+// Waits for the work queued on the rank's stream without ever blocking unboundedly: polls the stream, the
+// communicator's asynchronous error state and a clock.  On an error or at the limit the communicator is aborted.
+int comm_wait(pprhip_comm* c, const char* what) {
+  pprhip_graph* g = c->g;
+  const double limit = comm_timeout_s();
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  for (;;) {
+    const hipError_t q = hipStreamQuery(g->stream);
+    if (q == hipSuccess) return PPRHIP_OK;
+    if (q != hipErrorNotReady) {
+      set_error("%s: stream error on rank %d: %s", what, c->rank, hipGetErrorString(q));
+      comm_abort(c);
+      return PPRHIP_ERR_HIP;
+    }
+    if (c->nccl) {
+      int ae = ncclSuccess;
+      if (rccl()->CommGetAsyncError(c->nccl, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
+        set_error("%s: RCCL reports an asynchronous error on rank %d: %s", what, c->rank, rccl()->GetErrorString(ae));
+        comm_abort(c);
+        return PPRHIP_ERR_HIP;
+      }
+    }
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (el > limit) {
+      set_error("%s: rank %d gave up after %.0f s (PPRHIP_COMM_TIMEOUT_S); a peer has failed or left the group", what,
+                c->rank, el);
+      comm_abort(c);
+      return PPRHIP_ERR_STATE;
+    }
+    if (++spins < 2000) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 50 : 1000));
+  }
+}
+
 // Every rank sends bytes [off[p], off[p + 1]) of `send` to peer p and receives its peers' shares, in rank order,
 // into *recv (device, allocated here; caller frees) with their byte offsets in recv_off (world + 1).
+// local_rc != 0: this rank has failed already and only takes part to tell its peers (nothing is sent or received;
+// its own error message stays the thread's last error).  Returns local_rc when that is set; otherwise
+// PPRHIP_ERR_STATE when a peer failed (nothing was exchanged), a transport error, or PPRHIP_OK.
 int comm_alltoallv(pprhip_comm* c, const void* send, const std::vector<uint64_t>& off, void** recv,
-                   std::vector<uint64_t>& recv_off) {
+                   std::vector<uint64_t>& recv_off, int local_rc) {
   pprhip_graph* g = c->g;
   const int W = c->world;
   recv_off.assign((size_t)W + 1, 0);
   *recv = nullptr;
+  const std::string own_msg = local_rc != PPRHIP_OK ? std::string(get_error()) : std::string();
+  auto finish = [&](int rc) {
+    if (local_rc != PPRHIP_OK) {  // the caller reports what went wrong on this rank, not what the exchange made of it
+      set_error("%s", own_msg.c_str());
+      return local_rc;
+    }
+    return rc;
+  };
   if (c->local) {
     LocalGroup* L = c->local;
     {
       std::lock_guard<std::mutex> lk(L->mu);
       L->send[c->rank] = send;
-      L->send_off[c->rank] = off;
+      L->send_off[c->rank] = local_rc == PPRHIP_OK ? off : std::vector<uint64_t>((size_t)W + 1, 0);
+      L->posted_rc[c->rank] = local_rc;
     }
     L->barrier();  // everybody has posted
-    if (L->err) {
-      set_error("in-process exchange: another rank failed");
-      return L->err;
-    }
-    for (int p = 0; p < W; ++p) recv_off[p + 1] = recv_off[p] + (L->send_off[p][c->rank + 1] - L->send_off[p][c->rank]);
-    int rc = alloc_dev(recv, recv_off[W]);
-    if (rc == PPRHIP_OK)
+    int rc = PPRHIP_OK;
+    for (int p = 0; p < W; ++p)
+      if (L->posted_rc[p] != PPRHIP_OK && p != c->rank && rc == PPRHIP_OK) {
+        set_error("in-process exchange: rank %d failed before the exchange (code %d); nothing was exchanged", p,
+                  L->posted_rc[p]);
+        rc = PPRHIP_ERR_STATE;
+      }
+    if (rc == PPRHIP_OK && local_rc == PPRHIP_OK) {
+      for (int p = 0; p < W; ++p) recv_off[p + 1] = recv_off[p] + (L->send_off[p][c->rank + 1] - L->send_off[p][c->rank]);
+      if (fault_injected(c->rank, "exchange")) rc = PPRHIP_ERR_STATE;
+      if (rc == PPRHIP_OK) rc = alloc_dev(recv, recv_off[W]);
       for (int p = 0; p < W && rc == PPRHIP_OK; ++p) {
         const uint64_t bytes = recv_off[p + 1] - recv_off[p];
         if (bytes && hipMemcpyAsync((char*)*recv + recv_off[p], (const char*)L->send[p] + L->send_off[p][c->rank], bytes,
@@ -157,59 +254,101 @@ int comm_alltoallv(pprhip_comm* c, const void* send, const std::vector<uint64_t>
           rc = PPRHIP_ERR_HIP;
         }
       }
-    if (rc == PPRHIP_OK && hipStreamSynchronize(g->stream) != hipSuccess) rc = PPRHIP_ERR_HIP;
-    if (rc != PPRHIP_OK) L->abort(rc);
+      // drained in every case: a peer's send buffer must not be in use by a copy of ours once we pass the barrier
+      if (hipStreamSynchronize(g->stream) != hipSuccess && rc == PPRHIP_OK) {
+        set_error("in-process exchange: stream error on rank %d", c->rank);
+        rc = PPRHIP_ERR_HIP;
+      }
+    }
+    const std::string msg = rc != PPRHIP_OK ? std::string(get_error()) : std::string();
     L->barrier();  // everybody has read: send buffers may go
-    if (L->err && rc == PPRHIP_OK) set_error("in-process exchange: another rank failed");
-    return L->err ? (rc != PPRHIP_OK ? rc : L->err) : PPRHIP_OK;
+    if (rc != PPRHIP_OK) set_error("%s", msg.c_str());
+    return finish(rc);
+  }
+  if (c->dead) {
+    set_error("the communicator of rank %d was aborted by an earlier failure", c->rank);
+    return finish(PPRHIP_ERR_STATE);
   }
   RcclApi* R = rccl();
-  // 1) share sizes: one 8-byte message per peer
+  // 1) share sizes: one 8-byte message per peer; a failed rank sends the sentinel
   unsigned long long *d_cnt = nullptr;
-  PPRHIP_TRY(alloc_dev((void**)&d_cnt, sizeof(unsigned long long) * 2 * (size_t)W));
+  {
+    const int arc = alloc_dev((void**)&d_cnt, sizeof(unsigned long long) * 2 * (size_t)W);
+    if (arc != PPRHIP_OK) {  // cannot even take part: abort, so that the peers' size exchange ends with an error
+      comm_abort(c);
+      return finish(arc);
+    }
+  }
   std::vector<unsigned long long> h_cnt(2 * (size_t)W, 0);
-  for (int p = 0; p < W; ++p) h_cnt[p] = off[p + 1] - off[p];
+  for (int p = 0; p < W; ++p) h_cnt[p] = local_rc != PPRHIP_OK ? kFailedWord : off[p + 1] - off[p];
   auto done = [&](int rc) {
     (void)hipFree(d_cnt);
-    return rc;
+    return finish(rc);
   };
-  if (hipMemcpyAsync(d_cnt, h_cnt.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, g->stream) != hipSuccess)
+  // a call of the group that fails leaves the communicator in an unknown state: abort it (peers are released)
+  auto broken = [&](const char* what, int r) {
+    set_error("%s failed on rank %d: %s", what, c->rank, R->GetErrorString(r));
+    comm_abort(c);
     return done(PPRHIP_ERR_HIP);
-  if (R->GroupStart() != ncclSuccess) return done(PPRHIP_ERR_HIP);
-  for (int p = 0; p < W; ++p) {
-    (void)R->Send(d_cnt + p, 8, ncclUint8, p, c->nccl, g->stream);
-    (void)R->Recv(d_cnt + W + p, 8, ncclUint8, p, c->nccl, g->stream);
+  };
+  if (hipMemcpyAsync(d_cnt, h_cnt.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, g->stream) != hipSuccess) {
+    set_error("RCCL size exchange: upload failed on rank %d", c->rank);
+    comm_abort(c);
+    return done(PPRHIP_ERR_HIP);
   }
   {
-    const int r = R->GroupEnd();
-    if (r != ncclSuccess) {
-      set_error("RCCL size exchange failed: %s", R->GetErrorString(r));
-      return done(PPRHIP_ERR_HIP);
+    int r = R->GroupStart();
+    if (r != ncclSuccess) return broken("ncclGroupStart", r);
+    int first_bad = ncclSuccess;
+    for (int p = 0; p < W; ++p) {
+      const int rs = R->Send(d_cnt + p, 8, ncclUint8, p, c->nccl, g->stream);
+      const int rr = R->Recv(d_cnt + W + p, 8, ncclUint8, p, c->nccl, g->stream);
+      if (first_bad == ncclSuccess && rs != ncclSuccess) first_bad = rs;
+      if (first_bad == ncclSuccess && rr != ncclSuccess) first_bad = rr;
     }
+    r = R->GroupEnd();
+    if (first_bad != ncclSuccess) return broken("ncclSend/ncclRecv (sizes)", first_bad);
+    if (r != ncclSuccess) return broken("ncclGroupEnd (sizes)", r);
   }
   if (hipMemcpyAsync(h_cnt.data() + W, d_cnt + W, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, g->stream) !=
-          hipSuccess ||
-      hipStreamSynchronize(g->stream) != hipSuccess)
+      hipSuccess) {
+    set_error("RCCL size exchange: download failed on rank %d", c->rank);
+    comm_abort(c);
     return done(PPRHIP_ERR_HIP);
-  for (int p = 0; p < W; ++p) recv_off[p + 1] = recv_off[p] + h_cnt[W + p];
-  int rc = alloc_dev(recv, recv_off[W]);
-  if (rc != PPRHIP_OK) return done(rc);
-  // 2) the payload: one message per peer, all of them in flight together (each pair of GPUs has its own xGMI link)
-  if (R->GroupStart() != ncclSuccess) return done(PPRHIP_ERR_HIP);
-  for (int p = 0; p < W; ++p) {
-    const uint64_t sb = off[p + 1] - off[p], rb = recv_off[p + 1] - recv_off[p];
-    if (sb) (void)R->Send((const char*)send + off[p], sb, ncclUint8, p, c->nccl, g->stream);
-    if (rb) (void)R->Recv((char*)*recv + recv_off[p], rb, ncclUint8, p, c->nccl, g->stream);
   }
   {
-    const int r = R->GroupEnd();
-    if (r != ncclSuccess) {
-      set_error("RCCL payload exchange failed: %s", R->GetErrorString(r));
-      return done(PPRHIP_ERR_HIP);
-    }
+    const int wrc = comm_wait(c, "RCCL size exchange");
+    if (wrc != PPRHIP_OK) return done(wrc);
   }
-  if (hipStreamSynchronize(g->stream) != hipSuccess) return done(PPRHIP_ERR_HIP);
-  return done(PPRHIP_OK);
+  for (int p = 0; p < W; ++p)
+    if (h_cnt[W + p] == kFailedWord && p != c->rank) {
+      set_error("RCCL exchange: rank %d failed before the exchange; nothing was exchanged", p);
+      return done(PPRHIP_ERR_STATE);
+    }
+  if (local_rc != PPRHIP_OK) return done(local_rc);
+  for (int p = 0; p < W; ++p) recv_off[p + 1] = recv_off[p] + h_cnt[W + p];
+  int rc = fault_injected(c->rank, "exchange") ? PPRHIP_ERR_STATE : alloc_dev(recv, recv_off[W]);
+  if (rc != PPRHIP_OK) {  // the peers are past the point where they could be told: abort releases their payload group
+    comm_abort(c);
+    return done(rc);
+  }
+  // 2) the payload: one message per peer, all of them in flight together (each pair of GPUs has its own xGMI link)
+  {
+    int r = R->GroupStart();
+    if (r != ncclSuccess) return broken("ncclGroupStart", r);
+    int first_bad = ncclSuccess;
+    for (int p = 0; p < W; ++p) {
+      const uint64_t sb = off[p + 1] - off[p], rb = recv_off[p + 1] - recv_off[p];
+      const int rs = sb ? R->Send((const char*)send + off[p], sb, ncclUint8, p, c->nccl, g->stream) : ncclSuccess;
+      const int rr = rb ? R->Recv((char*)*recv + recv_off[p], rb, ncclUint8, p, c->nccl, g->stream) : ncclSuccess;
+      if (first_bad == ncclSuccess && rs != ncclSuccess) first_bad = rs;
+      if (first_bad == ncclSuccess && rr != ncclSuccess) first_bad = rr;
+    }
+    r = R->GroupEnd();
+    if (first_bad != ncclSuccess) return broken("ncclSend/ncclRecv (payload)", first_bad);
+    if (r != ncclSuccess) return broken("ncclGroupEnd (payload)", r);
+  }
+  return done(comm_wait(c, "RCCL payload exchange"));
 }
 
 void target_range(int rank, int world, uint32_t n, uint32_t* lo, uint32_t* hi) {
@@ -218,60 +357,132 @@ void target_range(int rank, int world, uint32_t n, uint32_t* lo, uint32_t* hi) {
   *hi = *lo + base + ((uint32_t)rank < rem ? 1u : 0u);
 }
 
-// this rank's share of the sharded All-Pair: search its targets, exchange by owner of the source, finalise its sources
+// this rank's share of the sharded All-Pair: search its targets, exchange by owner of the source, finalise its sources.
+// pre_rc != 0: the rank failed before it got here (its message is the thread's last error) and only takes part in the
+// exchange to tell its peers.
 int all_pair_sharded(pprhip_comm* c, double alpha, double threshold, int k, pprhip_index_t** own_out,
-                     pprhip_stats_t* stats) {
+                     pprhip_stats_t* stats, int pre_rc = PPRHIP_OK) {
   pprhip_graph* g = c->g;
   const int W = c->world;
-  if (g->n < (uint32_t)W) {
+  int rc = pre_rc;
+  if (rc == PPRHIP_OK && g->n < (uint32_t)W) {
     set_error("sharded All-Pair: fewer nodes (%u) than ranks (%d)", g->n, W);
-    return PPRHIP_ERR_INVALID;
+    rc = PPRHIP_ERR_INVALID;  // every rank sees the same n: all of them return here, nobody is left waiting
+    return rc;
   }
-  uint32_t lo, hi;
+  uint32_t lo = 0, hi = 0;
   target_range(c->rank, W, g->n, &lo, &hi);
   pprhip_stats_t st;
   std::memset(&st, 0, sizeof st);
   DeviceTripleSink sink;
-  PPRHIP_TRY(all_pair_collect(g, alpha, threshold, lo, hi, sink, st));
-  // ---- partition by owner of the source, on the device
   unsigned long long* d_cur = nullptr;
   TripleRec* d_part = nullptr;
   void* d_recv = nullptr;
-  auto done = [&](int rc) {
+  auto done = [&](int code) {
     if (d_cur) (void)hipFree(d_cur);
     if (d_part) (void)hipFree(d_part);
     if (d_recv) (void)hipFree(d_recv);
-    return rc;
+    return code;
   };
-  int rc = alloc_dev((void**)&d_cur, sizeof(unsigned long long) * kBatch * 4);  // >= 64 counters
-  if (rc) return done(rc);
-  if (hipMemsetAsync(d_cur, 0, sizeof(unsigned long long) * 64, g->stream) != hipSuccess) return done(PPRHIP_ERR_HIP);
-  if ((rc = launch_owner_partition(g, sink.rec, sink.count, W, d_cur, nullptr))) return done(rc);
-  std::vector<unsigned long long> cnt((size_t)W, 0), start((size_t)W + 1, 0);
-  if (hipMemcpyAsync(cnt.data(), d_cur, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-      hipStreamSynchronize(g->stream) != hipSuccess)
-    return done(PPRHIP_ERR_HIP);
-  for (int p = 0; p < W; ++p) start[p + 1] = start[p] + cnt[p];
-  if ((rc = alloc_dev((void**)&d_part, sizeof(TripleRec) * std::max<unsigned long long>(1, sink.count)))) return done(rc);
-  if (hipMemcpyAsync(d_cur, start.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, g->stream) != hipSuccess)
-    return done(PPRHIP_ERR_HIP);
-  if ((rc = launch_owner_partition(g, sink.rec, sink.count, W, d_cur, d_part))) return done(rc);
-  if (hipStreamSynchronize(g->stream) != hipSuccess) return done(PPRHIP_ERR_HIP);
+  std::vector<unsigned long long> start((size_t)W + 1, 0);
+  // ---- search, then partition by owner of the source on the device; the first failure skips what is left, and the
+  // rank still goes to the exchange (where its peers learn of it)
+  auto local_part = [&]() -> int {
+    if (fault_injected(c->rank, "search")) return PPRHIP_ERR_STATE;
+    PPRHIP_TRY(all_pair_collect(g, alpha, threshold, lo, hi, sink, st));
+    if (fault_injected(c->rank, "partition")) return PPRHIP_ERR_STATE;
+    PPRHIP_TRY(alloc_dev((void**)&d_cur, sizeof(unsigned long long) * kBatch * 4));  // >= 64 counters
+    PPRHIP_CHECK_HIP(hipMemsetAsync(d_cur, 0, sizeof(unsigned long long) * 64, g->stream));
+    PPRHIP_TRY(launch_owner_partition(g, sink.rec, sink.count, W, d_cur, nullptr));
+    std::vector<unsigned long long> cnt((size_t)W, 0);
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(cnt.data(), d_cur, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    for (int p = 0; p < W; ++p) start[p + 1] = start[p] + cnt[p];
+    PPRHIP_TRY(alloc_dev((void**)&d_part, sizeof(TripleRec) * std::max<unsigned long long>(1, sink.count)));
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(d_cur, start.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, g->stream));
+    PPRHIP_TRY(launch_owner_partition(g, sink.rec, sink.count, W, d_cur, d_part));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    return PPRHIP_OK;
+  };
+  if (rc == PPRHIP_OK) rc = local_part();
   // ---- exchange: every entry goes to the rank that owns its source
-  std::vector<uint64_t> off((size_t)W + 1), roff;
-  for (int p = 0; p <= W; ++p) off[p] = start[p] * sizeof(TripleRec);
-  if ((rc = comm_alltoallv(c, d_part, off, &d_recv, roff))) return done(rc);
+  std::vector<uint64_t> off((size_t)W + 1, 0), roff;
+  if (rc == PPRHIP_OK)
+    for (int p = 0; p <= W; ++p) off[p] = start[p] * sizeof(TripleRec);
+  if ((rc = comm_alltoallv(c, d_part, off, &d_recv, roff, rc))) return done(rc);
   // ---- the entries of this rank's sources cross PCIe once, here
   const uint64_t n_recv = roff[W] / sizeof(TripleRec);
   std::vector<Triple> tr(n_recv);
   if (n_recv && (hipMemcpyAsync(tr.data(), d_recv, roff[W], hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-                 hipStreamSynchronize(g->stream) != hipSuccess))
+                 hipStreamSynchronize(g->stream) != hipSuccess)) {
+    set_error("sharded All-Pair: download of the received entries failed on rank %d", c->rank);
     return done(PPRHIP_ERR_HIP);
+  }
   st.select_bytes = roff[W];          // bytes received in the exchange
   st.mc_sources = sink.count;         // entries this rank found (before the exchange)
-  st.enqueues += 0;
+  // what arrived must be rows this rank owns (a peer's partition or a transport gone wrong must not become an
+  // out-of-range write in the finalisation)
+  for (const Triple& x : tr)
+    if (x.v < (int32_t)lo || x.v >= (int32_t)hi) {
+      set_error("sharded All-Pair: rank %d received an entry of source %d, outside its range [%u, %u)", c->rank, x.v, lo, hi);
+      return done(PPRHIP_ERR_STATE);
+    }
   if ((rc = index_from_triples(g->n, tr, k, own_out))) return done(rc);
   if (stats) *stats = st;
+  return done(PPRHIP_OK);
+}
+
+// pprhip_topk_gather; pre_rc as in all_pair_sharded
+int topk_gather_impl(pprhip_comm* c, const int32_t* ids, const double* vals, int rows, int rows_max, int k,
+                     int32_t* ids_root, double* vals_root, int pre_rc) {
+  pprhip_graph* g = c->g;
+  // one block per rank: rows_max rows of k (id, value) pairs, ids first; short blocks are padded with id -1
+  const size_t blk_ids = sizeof(int32_t) * (size_t)rows_max * k, blk_vals = sizeof(double) * (size_t)rows_max * k;
+  const size_t blk = blk_ids + blk_vals;
+  void *d_send = nullptr, *d_recv = nullptr;
+  auto done = [&](int rc) {
+    if (d_send) (void)hipFree(d_send);
+    if (d_recv) (void)hipFree(d_recv);
+    return rc;
+  };
+  int rc = pre_rc;
+  std::vector<char> h;
+  auto stage = [&]() -> int {
+    if (fault_injected(c->rank, "gather")) return PPRHIP_ERR_STATE;
+    h.resize(blk);
+    int32_t* hi = (int32_t*)h.data();
+    double* hv = (double*)(h.data() + blk_ids);
+    for (size_t i = 0; i < (size_t)rows_max * k; ++i) {
+      hi[i] = i < (size_t)rows * k ? ids[i] : -1;
+      hv[i] = i < (size_t)rows * k ? vals[i] : 0.0;
+    }
+    PPRHIP_TRY(alloc_dev(&d_send, blk));
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(d_send, h.data(), blk, hipMemcpyHostToDevice, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    return PPRHIP_OK;
+  };
+  if (rc == PPRHIP_OK) rc = stage();
+  std::vector<uint64_t> off((size_t)c->world + 1, 0), roff;
+  if (rc == PPRHIP_OK)
+    for (int p = 0; p < c->world; ++p) off[p + 1] = off[p] + (p == 0 ? blk : 0);  // everything goes to rank 0
+  if ((rc = comm_alltoallv(c, d_send, off, &d_recv, roff, rc))) return done(rc);
+  if (c->rank == 0) {
+    if (roff[c->world] != blk * (size_t)c->world) {
+      set_error("pprhip_topk_gather: the ranks sent %llu bytes, %llu expected (rows_max or k differ between ranks)",
+                (unsigned long long)roff[c->world], (unsigned long long)(blk * (size_t)c->world));
+      return done(PPRHIP_ERR_STATE);
+    }
+    std::vector<char> all(roff[c->world]);
+    if (hipMemcpyAsync(all.data(), d_recv, all.size(), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+        hipStreamSynchronize(g->stream) != hipSuccess) {
+      set_error("pprhip_topk_gather: download failed");
+      return done(PPRHIP_ERR_HIP);
+    }
+    for (int p = 0; p < c->world; ++p) {
+      std::memcpy(ids_root + (size_t)p * rows_max * k, all.data() + roff[p], blk_ids);
+      std::memcpy(vals_root + (size_t)p * rows_max * k, all.data() + roff[p] + blk_ids, blk_vals);
+    }
+  }
   return done(PPRHIP_OK);
 }
 
@@ -366,43 +577,17 @@ int pprhip_topk_gather(pprhip_comm_t* c, const int32_t* ids, const double* vals,
     set_error("pprhip_topk_gather: bad arguments (rows %d of %d, k %d)", rows, rows_max, k);
     return PPRHIP_ERR_INVALID;
   }
-  pprhip_graph* g = c->g;
-  PPRHIP_TRY(check_graph(g, "pprhip_topk_gather"));
-  // one block per rank: rows_max rows of k (id, value) pairs, ids first; short blocks are padded with id -1
-  const size_t blk_ids = sizeof(int32_t) * (size_t)rows_max * k, blk_vals = sizeof(double) * (size_t)rows_max * k;
-  const size_t blk = blk_ids + blk_vals;
-  std::vector<char> h(blk);
-  int32_t* hi = (int32_t*)h.data();
-  double* hv = (double*)(h.data() + blk_ids);
-  for (size_t i = 0; i < (size_t)rows_max * k; ++i) {
-    hi[i] = i < (size_t)rows * k ? ids[i] : -1;
-    hv[i] = i < (size_t)rows * k ? vals[i] : 0.0;
+  PPRHIP_TRY(check_graph(c->g, "pprhip_topk_gather"));
+  return topk_gather_impl(c, ids, vals, rows, rows_max, k, ids_root, vals_root, PPRHIP_OK);
+}
+
+int pprhip_comm_abort(pprhip_comm_t* c) {
+  if (!c) {
+    set_error("pprhip_comm_abort: null communicator");
+    return PPRHIP_ERR_INVALID;
   }
-  void* d_send = nullptr;
-  PPRHIP_TRY(alloc_dev(&d_send, blk));
-  void* d_recv = nullptr;
-  auto done = [&](int rc) {
-    (void)hipFree(d_send);
-    if (d_recv) (void)hipFree(d_recv);
-    return rc;
-  };
-  if (hipMemcpyAsync(d_send, h.data(), blk, hipMemcpyHostToDevice, g->stream) != hipSuccess) return done(PPRHIP_ERR_HIP);
-  std::vector<uint64_t> off((size_t)c->world + 1, 0), roff;
-  for (int p = 0; p < c->world; ++p) off[p + 1] = off[p] + (p == 0 ? blk : 0);  // everything goes to rank 0
-  if (hipStreamSynchronize(g->stream) != hipSuccess) return done(PPRHIP_ERR_HIP);
-  int rc = comm_alltoallv(c, d_send, off, &d_recv, roff);
-  if (rc) return done(rc);
-  if (c->rank == 0) {
-    std::vector<char> all(roff[c->world]);
-    if (hipMemcpyAsync(all.data(), d_recv, all.size(), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-        hipStreamSynchronize(g->stream) != hipSuccess)
-      return done(PPRHIP_ERR_HIP);
-    for (int p = 0; p < c->world; ++p) {
-      std::memcpy(ids_root + (size_t)p * rows_max * k, all.data() + roff[p], blk_ids);
-      std::memcpy(vals_root + (size_t)p * rows_max * k, all.data() + roff[p] + blk_ids, blk_vals);
-    }
-  }
-  return done(PPRHIP_OK);
+  if (!c->local) comm_abort(c);
+  return PPRHIP_OK;
 }
 
 }  // extern "C"
@@ -445,6 +630,7 @@ int setup_ranks(pprhip_graph_t* const* per_gpu, int n_gpu, RankSetup& S, const c
   S.local.world = n_gpu;
   S.local.send.assign((size_t)n_gpu, nullptr);
   S.local.send_off.assign((size_t)n_gpu, {});
+  S.local.posted_rc.assign((size_t)n_gpu, PPRHIP_OK);
   for (int r = 0; r < n_gpu; ++r) {
     S.comms[r].g = per_gpu[r];
     S.comms[r].rank = r;
@@ -454,45 +640,66 @@ int setup_ranks(pprhip_graph_t* const* per_gpu, int n_gpu, RankSetup& S, const c
   return PPRHIP_OK;
 }
 
-// one host thread per GPU; fn(rank) returns a code, messages are carried back to the caller's thread
+// One host thread per GPU.  Everything that can fail before the ranks depend on each other happens on the calling
+// thread first: every device is selected once, and the RCCL communicators of all ranks are created by ONE
+// ncclCommInitAll call, so no rank can be left waiting in an initialisation rendezvous that another one never
+// reaches.  fn(rank, pre_rc) returns a code; pre_rc != 0 tells it that this rank's thread could not set itself up
+// and must only take part in the call's exchange.  Messages are carried back to the caller's thread.
 template <class F>
 int run_ranks(RankSetup& S, F fn) {
   const int W = (int)S.comms.size();
-  ncclUniqueId uid;
+  int dev0 = 0;
+  (void)hipGetDevice(&dev0);
+  for (int r = 0; r < W; ++r)
+    if (hipSetDevice(S.comms[r].g->device) != hipSuccess) {
+      set_error("GPU %d: hipSetDevice(%d) failed", r, S.comms[r].g->device);
+      (void)hipSetDevice(dev0);
+      return PPRHIP_ERR_NO_DEVICE;
+    }
+  (void)hipSetDevice(dev0);
   if (S.use_rccl) {
     RcclApi* R = rccl();
     if (!R) {
       set_error("librccl.so.1 could not be loaded");
       return PPRHIP_ERR_NO_DEVICE;
     }
-    PPRHIP_CHECK_RCCL(R->GetUniqueId(&uid));
+    std::vector<ncclComm_t> cs((size_t)W, nullptr);
+    std::vector<int> devs((size_t)W);
+    for (int r = 0; r < W; ++r) devs[r] = S.comms[r].g->device;
+    PPRHIP_CHECK_RCCL(R->CommInitAll(cs.data(), W, devs.data()));
+    for (int r = 0; r < W; ++r) S.comms[r].nccl = cs[r];
+    (void)hipSetDevice(dev0);
   }
   std::vector<std::thread> th;
   for (int r = 0; r < W; ++r)
     th.emplace_back([&, r] {
-      int rc = PPRHIP_OK;
-      if (hipSetDevice(S.comms[r].g->device) != hipSuccess) rc = PPRHIP_ERR_NO_DEVICE;
-      if (rc == PPRHIP_OK && S.use_rccl) {
-        const int e = rccl()->CommInitRank(&S.comms[r].nccl, W, uid, r);
-        if (e != ncclSuccess) {
-          set_error("ncclCommInitRank failed on rank %d: %s", r, rccl()->GetErrorString(e));
-          rc = PPRHIP_ERR_HIP;
-        }
+      int pre = PPRHIP_OK;
+      if (hipSetDevice(S.comms[r].g->device) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed on rank %d's thread", S.comms[r].g->device, r);
+        pre = PPRHIP_ERR_NO_DEVICE;
       }
-      if (rc == PPRHIP_OK) rc = fn(r);
+      const int rc = fn(r, pre);
       if (rc != PPRHIP_OK) S.errs[r] = get_error();
       S.rcs[r] = rc;
-      if (S.comms[r].nccl) {
-        (void)rccl()->CommDestroy(S.comms[r].nccl);
-        S.comms[r].nccl = nullptr;
-      }
     });
   for (auto& t : th) t.join();
   for (int r = 0; r < W; ++r)
-    if (S.rcs[r] != PPRHIP_OK) {
-      set_error("GPU %d (device %d): %s", r, S.comms[r].g->device, S.errs[r].c_str());
-      return S.rcs[r];
+    if (S.comms[r].nccl) {
+      (void)hipSetDevice(S.comms[r].g->device);
+      (void)rccl()->CommDestroy(S.comms[r].nccl);
+      S.comms[r].nccl = nullptr;
     }
+  (void)hipSetDevice(dev0);
+  // the rank whose own failure started it, not a peer that merely heard of it
+  int first = -1;
+  for (int r = 0; r < W; ++r)
+    if (S.rcs[r] != PPRHIP_OK && (first < 0 || (S.errs[first].find("failed before the exchange") != std::string::npos &&
+                                               S.errs[r].find("failed before the exchange") == std::string::npos)))
+      first = r;
+  if (first >= 0) {
+    set_error("GPU %d (device %d): %s", first, S.comms[first].g->device, S.errs[first].c_str());
+    return S.rcs[first];
+  }
   return PPRHIP_OK;
 }
 
@@ -514,7 +721,7 @@ int pprhip_fora_batch(pprhip_graph_t* const* per_gpu, int n_gpu, const int32_t* 
   std::vector<int32_t> ids_root((size_t)W * rows_max * k);
   std::vector<double> vals_root((size_t)W * rows_max * k);
   std::vector<std::vector<int>> nsel((size_t)W);
-  const int rc = run_ranks(S, [&](int r) -> int {
+  const int rc = run_ranks(S, [&](int r, int pre) -> int {
     // query i runs on GPU i mod W (local row i / W)
     std::vector<int32_t> mine;
     for (int i = r; i < q; i += W) mine.push_back(srcs[i]);
@@ -524,14 +731,15 @@ int pprhip_fora_batch(pprhip_graph_t* const* per_gpu, int n_gpu, const int32_t* 
     nsel[r].assign((size_t)std::max(1, rows), 0);
     pprhip_stats_t st;
     std::memset(&st, 0, sizeof st);
-    int e = pprhip_fora_batch_single_source(S.comms[r].g, mine.data(), rows, eps, conf, seed, n_rounds, nullptr, k,
-                                            ids.data(), vals.data(), nsel[r].data(), nullptr, &st);
-    if (stats_per_gpu) stats_per_gpu[r] = st;
-    // the only exchange of the path: the top-k blocks travel to GPU 0 over the fabric
+    int e = pre;
+    if (e == PPRHIP_OK && fault_injected(r, "search")) e = PPRHIP_ERR_STATE;
     if (e == PPRHIP_OK)
-      e = pprhip_topk_gather(&S.comms[r], ids.data(), vals.data(), rows, rows_max, k, ids_root.data(), vals_root.data());
-    if (e != PPRHIP_OK && S.comms[r].local) S.local.abort(e);
-    return e;
+      e = pprhip_fora_batch_single_source(S.comms[r].g, mine.data(), rows, eps, conf, seed, n_rounds, nullptr, k,
+                                          ids.data(), vals.data(), nsel[r].data(), nullptr, &st);
+    if (stats_per_gpu) stats_per_gpu[r] = st;
+    // the only exchange of the path: the top-k blocks travel to GPU 0 over the fabric (a rank that failed takes
+    // part to say so)
+    return topk_gather_impl(&S.comms[r], ids.data(), vals.data(), rows, rows_max, k, ids_root.data(), vals_root.data(), e);
   });
   if (rc != PPRHIP_OK) return rc;
   for (int i = 0; i < q; ++i) {
@@ -552,11 +760,10 @@ int pprhip_all_pair_backward_multi(pprhip_graph_t* const* per_gpu, int n_gpu, do
     return PPRHIP_ERR_INVALID;
   }
   std::vector<pprhip_index_t*> own((size_t)n_gpu, nullptr);
-  int rc = run_ranks(S, [&](int r) -> int {
+  int rc = run_ranks(S, [&](int r, int pre) -> int {
     pprhip_stats_t st;
     std::memset(&st, 0, sizeof st);
-    const int e = all_pair_sharded(&S.comms[r], alpha, threshold, k, &own[r], &st);
-    if (e != PPRHIP_OK && S.comms[r].local) S.local.abort(e);  // the other ranks may wait at the exchange
+    const int e = all_pair_sharded(&S.comms[r], alpha, threshold, k, &own[r], &st, pre);
     if (stats_per_gpu) stats_per_gpu[r] = st;
     return e;
   });

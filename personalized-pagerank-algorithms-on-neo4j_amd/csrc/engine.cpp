@@ -1247,8 +1247,10 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
                   g->nz_rows_o, g->z_rows_o, g->cross_bits_o};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (g->apbs_tables) (void)hipFree(g->apbs_tables);
-  g->apbs_tables = nullptr;
+  if (g->apbs_ws) (void)hipFree(g->apbs_ws);
+  g->apbs_ws = nullptr;
+  if (g->in_rec) (void)hipFree(g->in_rec);
+  g->in_rec = nullptr;
   if (g->sl) {
     void* sp[] = {g->sl->ci, g->sl->flags, g->sl->chunk_starts, g->sl->seg_row};
     for (void* p : sp)

@@ -240,8 +240,11 @@ struct pprhip_graph {
   hipStream_t own_stream = nullptr;   // slot: the stream its worker thread uses
   pprhip::KernelTimer ktimer;         // slot: its worker's kernel-class timer; graph: the sweeps' timer
   std::vector<pprhip_graph*> slots;
-  char* apbs_tables = nullptr;  // All-Pair tier 2: hash tables of apbs_blocks workgroups, kept between calls (9.4 GB:
-  uint32_t apbs_blocks = 0;     // allocating and releasing them per call cost up to seconds)
+  // All-Pair: in-edge records {source, its out-degree} (8 B per edge, built on first use), and tier 2's dense
+  // workspaces of apbs_blocks workgroups (16n bytes + lists each, all-zero between searches), kept between calls
+  void* in_rec = nullptr;
+  char* apbs_ws = nullptr;
+  uint32_t apbs_blocks = 0, apbs_cap_t = 0, apbs_cap_f = 0;
   pprhip::detail::FetchPipe* fetch = nullptr;  // delivery of batched queries' vectors to host memory (engine_internal.hpp)
   double* c8[2] = {nullptr, nullptr};
   int c8cur = 0;
@@ -364,8 +367,9 @@ struct ApbsBuffers {
   int32_t *out_v = nullptr, *out_t = nullptr, *overflow = nullptr;
   double* out_p = nullptr;
   unsigned long long out_cap = 0;
-  char* g_tables = nullptr;  // tier 2: per-workgroup hash tables in HBM (owned by the graph handle, see apbs_tables)
-  uint32_t g_cap = 0, g_blocks = 0;
+  char* ws = nullptr;  // tier 2: per-workgroup dense workspaces (owned by the graph handle, see apbs_ws)
+  uint32_t ws_blocks = 0, cap_t = 0, cap_f = 0;
+  unsigned long long* dbg = nullptr;  // developer switch PPRHIP_APBS_DEBUG: 8 words per workgroup (kernels_apbs.hip)
 };
 struct TripleRec {  // one index entry of All-Pair-Backward-Search on the device: pi(v, t) = p
   int32_t v, t;
@@ -375,8 +379,9 @@ int launch_pack_triples(pprhip_graph* g, const int32_t* v, const int32_t* t, con
                         TripleRec* dst);
 int launch_owner_partition(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int world,
                            unsigned long long* cursors, TripleRec* out);
-size_t apbs_table_bytes(uint32_t g_cap);  // one workgroup's tier-2 table
-int launch_apbs(pprhip_graph* g, bool global_tier, const int32_t* d_targets, uint32_t t_begin, uint32_t n_targets,
+size_t apbs_dense_bytes(uint32_t n, uint32_t cap_t, uint32_t cap_f);  // one workgroup's tier-2 workspace
+int launch_build_in_rec(pprhip_graph* g, void* rec);                  // rec: m records of 8 bytes
+int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint32_t t_begin, uint32_t n_targets,
                 double alpha, double rmax, ApbsBuffers& b);
 
 // ---- kernels_select.hip

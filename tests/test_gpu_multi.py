@@ -88,6 +88,60 @@ def test_rccl_group_of_one(pkg, rmat12, replicas):
         c.close()
 
 
+@pytest.mark.parametrize("where", ["search", "partition", "exchange"])
+@pytest.mark.parametrize("bad", [0, 2])
+def test_all_pair_rank_failure_reaches_every_rank(pkg, rmat12, replicas, where, bad, monkeypatch):
+    """A rank that fails before or inside the exchange must not leave its peers waiting: it takes part in the
+    exchange with an error mark, every rank returns, the call reports the failing rank - and the handles are usable
+    again afterwards (PPRHIP_FAULT_* are the library's test switches)."""
+    monkeypatch.setenv("PPRHIP_FAULT_RANK", str(bad))
+    monkeypatch.setenv("PPRHIP_FAULT_AT", where)
+    with pytest.raises(pkg.PprhipError) as ei:
+        pkg.all_pair_backward_multi(replicas[:3], A, 2e-3, 4)
+    assert "injected fault on rank %d" % bad in str(ei.value)
+    monkeypatch.delenv("PPRHIP_FAULT_RANK")
+    monkeypatch.delenv("PPRHIP_FAULT_AT")
+    ix, _ = pkg.all_pair_backward_multi(replicas[:3], A, 2e-3, 4)
+    ix1, _ = replicas[0].all_pair_backward(A, 2e-3, 4)
+    a, b = ix.arrays(), ix1.arrays()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.max(np.abs(a[2] - b[2])) <= 1e-12
+
+
+@pytest.mark.parametrize("where", ["search", "gather"])
+def test_fora_batch_rank_failure_reaches_every_rank(pkg, rmat12, replicas, where, monkeypatch):
+    srcs = np.arange(10, 21, dtype=np.int32)
+    monkeypatch.setenv("PPRHIP_FAULT_RANK", "1")
+    monkeypatch.setenv("PPRHIP_FAULT_AT", where)
+    with pytest.raises(pkg.PprhipError) as ei:
+        pkg.fora_batch_multi(replicas[:3], srcs, 4, 0.5, A, seed=3)
+    assert "injected fault on rank 1" in str(ei.value)
+    monkeypatch.delenv("PPRHIP_FAULT_RANK")
+    monkeypatch.delenv("PPRHIP_FAULT_AT")
+    ids, vals, nsel, _ = pkg.fora_batch_multi(replicas[:3], srcs, 4, 0.5, A, seed=3)
+    _, ids1, _, nsel1, _, _ = replicas[0].fora_batch_single_source(srcs, 0.5, A, seed=3, k=4)
+    assert np.array_equal(ids, ids1) and np.array_equal(nsel, nsel1)
+
+
+def test_rccl_rank_failure_group_of_one(pkg, rmat12, replicas, monkeypatch):
+    """The same protocol on the RCCL transport (a group of one: the rank posts the error mark to itself)."""
+    c = pkg.Comm(replicas[0], pkg.comm_unique_id(), 0, 1)
+    try:
+        monkeypatch.setenv("PPRHIP_FAULT_RANK", "0")
+        monkeypatch.setenv("PPRHIP_FAULT_AT", "partition")
+        with pytest.raises(pkg.PprhipError) as ei:
+            c.all_pair_backward_sharded(A, 2e-3, 4)
+        assert "injected fault on rank 0" in str(ei.value)
+        monkeypatch.delenv("PPRHIP_FAULT_RANK")
+        own, _ = c.all_pair_backward_sharded(A, 2e-3, 4)       # the communicator survived a failure announced in time
+        ix1, _ = replicas[0].all_pair_backward(A, 2e-3, 4)
+        assert np.array_equal(own.arrays()[1], ix1.arrays()[1])
+        c.abort()                                               # leaving the group: later collectives fail at once
+        with pytest.raises(pkg.PprhipError):
+            c.all_pair_backward_sharded(A, 2e-3, 4)
+    finally:
+        c.close()
+
+
 def test_multi_argument_errors(pkg, rmat12, replicas, got):
     with pytest.raises(pkg.PprhipError):          # the same handle twice
         pkg.fora_batch_multi([replicas[0], replicas[0]], [1, 2], 4, 0.5, A, seed=1)

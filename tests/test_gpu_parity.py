@@ -402,7 +402,7 @@ def test_all_pair_backward_got(pkg, orc, got, dev_got, k):
 
 @pytest.mark.parametrize("tier", ["1", "2", "3"])
 def test_all_pair_tiers_rmat12(pkg, orc, rmat12, dev_rmat12, tier, monkeypatch):
-    """LDS hash tier, HBM hash tier and whole-vector tier give the same index (targets that outgrow
+    """LDS hash tier, dense-vector tier and whole-vector (batch slot) tier give the same index (targets that outgrow
     a tier fall through to the next one on their own; the variable only moves the starting tier)."""
     monkeypatch.setenv("PPRHIP_APBS_TIER", tier)
     og = to_oracle(orc, rmat12)
@@ -414,6 +414,29 @@ def test_all_pair_tiers_rmat12(pkg, orc, rmat12, dev_rmat12, tier, monkeypatch):
         assert np.array_equal(off, ooff) and np.array_equal(tg, otg)
         assert np.max(np.abs(vl - ovl)) <= TOL_PUSH
         ix.close()
+
+
+@pytest.mark.parametrize("cap_t,cap_f", [(8, 4096), (4096, 3), (5, 2)])
+def test_all_pair_dense_tier_list_overflows(pkg, orc, rmat12, cap_t, cap_f, monkeypatch):
+    """The dense tier's lists are bounded: when the clean-up list overflows the search still finishes (the whole
+    vector is cleared instead), when a frontier or the popped-node list overflows the search is handed to the
+    whole-vector tier - and the next search of the same workgroup must find all-zero vectors either way.  A fresh
+    handle, so that the workspace is built with the shrunken lists."""
+    monkeypatch.setenv("PPRHIP_APBS_TIER", "2")
+    monkeypatch.setenv("PPRHIP_APBS_CAP_T", str(cap_t))
+    monkeypatch.setenv("PPRHIP_APBS_CAP_F", str(cap_f))
+    og = to_oracle(orc, rmat12)
+    with pkg.Graph(rmat12) as g:
+        for lo, hi in ((100, 400), (0, 300)):            # twice: the second call starts from the vectors the first left
+            ix, st = g.all_pair_backward(ALPHA, 5e-4, 6, lo, hi)
+            off, tg, vl = ix.arrays()
+            ooff, otg, ovl = og.all_pair_backward(ALPHA, 5e-4, 6, lo, hi, schedule=orc.SYNC)
+            assert np.array_equal(off, ooff) and np.array_equal(tg, otg)
+            assert np.max(np.abs(vl - ovl)) <= TOL_PUSH
+            assert st.rounds == hi - lo                  # every target started in the dense tier
+            if cap_f < 100:
+                assert st.dense_nodes > 0                # and some were handed on
+            ix.close()
 
 
 def test_batch_directions_share_a_handle(pkg, orc, rmat12, dev_rmat12, monkeypatch):
@@ -445,7 +468,7 @@ def test_batch_directions_share_a_handle(pkg, orc, rmat12, dev_rmat12, monkeypat
 
 def test_all_pair_whole_rmat12_counts(pkg, orc, rmat12, dev_rmat12):
     """Every target of the graph in one call; hub targets overflow the LDS table and are finished by the
-    HBM tier.  Pops and edge pushes equal the twin's."""
+    dense tier.  Pops and edge pushes equal the twin's."""
     og = to_oracle(orc, rmat12)
     ix, st = dev_rmat12.all_pair_backward(ALPHA, 1e-3, 4)
     off, tg, vl = ix.arrays()

@@ -167,6 +167,18 @@ def test_tuning_defaults_match_oracle_twin(pkg, orc):
     assert sorted(changed) == ["c_dense_edge_ns", "c_dense_node_ns", "dense_frac", "gs_frac"]
 
 
+def test_index_arrays_are_validated(pkg):
+    """Targets outside [0, n) are an error at the boundary, not an out-of-range write later (the same check guards
+    the entries that arrive from the device and from the exchange, allpair.cpp: index_from_triples)."""
+    off = np.array([0, 1, 2], dtype=np.uint64)
+    with pytest.raises(pkg.PprhipError):
+        pkg.index_from_arrays(2, off, np.array([0, 2], dtype=np.int32), np.array([0.5, 0.5]))
+    with pytest.raises(pkg.PprhipError):
+        pkg.index_from_arrays(2, off, np.array([-1, 1], dtype=np.int32), np.array([0.5, 0.5]))
+    ok = pkg.index_from_arrays(2, off, np.array([1, 0], dtype=np.int32), np.array([0.5, 0.25]))
+    assert pkg.merge_indexes([ok], -1).arrays()[1].tolist() == [1, 0]
+
+
 def test_index_merge_large_runs_on_all_threads(pkg):
     """Enough entries (> 2^16) for the multi-threaded path of the index finalisation: a two-level counting sort by
     source on all threads, then the k rule per source - against a plain numpy restatement of Base_Whole_Graph's rule
@@ -175,12 +187,12 @@ def test_index_merge_large_runs_on_all_threads(pkg):
     n, per = 3000, 64
     shards = []
     rows = {}
-    for sh in range(3):                                  # three target shards with disjoint targets
+    for sh in range(3):                                  # three target shards with disjoint targets (node ids < n)
         off = np.zeros(n + 1, dtype=np.uint64)
         tg, vl = [], []
         for v in range(n):
             cnt = int(rng.integers(0, per)) if v % 7 else 0
-            t = np.sort(rng.choice(np.arange(sh * 100000, sh * 100000 + 5000), size=cnt, replace=False)).astype(np.int32)
+            t = np.sort(rng.choice(np.arange(sh * 1000, sh * 1000 + 1000), size=cnt, replace=False)).astype(np.int32)
             p = np.round(rng.random(cnt), 2)             # many ties
             off[v + 1] = off[v] + cnt
             tg.append(t)
