@@ -18,17 +18,30 @@ Before the line is printed the results of the last timed step are checked on eve
 check prints no line.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): the CSR is replicated, every rank runs its own
-batch per step (weak scaling, no data-path collective) and the per-step top-k blocks are gathered to rank 0 over
-RCCL; `all_pair_scaling` reports the path's other workload, All-Pair-Backward-Search over all n targets, at the same
-N (strong scaling; the exchange by owner of the source runs inside the library over RCCL; every rank's share runs in
-a watched child process, so a collective that hangs or faults costs that sample, not the line).
+batch per step (weak scaling, no data-path collective) and the per-step top-k blocks are gathered on rank 0 by the
+library's own entry point (pprhip_comm_create + pprhip_topk_gather: grouped ncclSend / ncclRecv inside libpprhip.so,
+the exchange Gen_Util.java:208-232's loop needs when it is sharded); torch.distributed only carries the barrier and
+the max-over-ranks of the clock.  `all_pair_scaling` reports the path's other workload, All-Pair-Backward-Search over
+all n targets, at the same N (strong scaling; the exchange by owner of the source runs inside the library over RCCL;
+every rank's share runs in a watched child process, so a collective that hangs or faults costs that sample, not the
+line).
 
-Extra objects on the JSON line: `roofline` (dominant kernel class: HIP-event time on the engine's stream,
-algorithmic bytes from DESIGN.md's byte model, HBM traffic from two `rocprofv3 --pmc` passes of this same build
-run as child processes, useful-edge fraction of the sweeps) and `cpu_baseline` (the reference's algorithm on the
-host cores: hash-map-shaped faithful port, dense-array port, all cores; rank 0 at N = 1 only); after the timed
-region, at N = 1, also `one_query_at_a_time` (the drop-in path, pprhip_fora_single_source), `topk_sample`
-(FORA top-32) and `all_pair_sample` (All-Pair-Backward-Search on 2^18 targets), each with its own `roofline`.
+Extra objects on the JSON line:
+  `roofline`  dominant kernel class (HIP-event time on the engine's stream).  `achieved` / `frac`: the bytes the
+              memory-side counters saw per launch over the launch's duration, against the 8 TB/s HBM peak - measured
+              in this run by `rocprofv3 --pmc` child passes of this build (FETCH_SIZE, WRITE_SIZE, TCC hit / miss; one
+              counter set per pass).  FETCH_SIZE counts requests that left L2, Infinity-Cache hits included, so this is
+              L2-miss traffic: an upper bound of HBM traffic, below the peak by construction of the hardware.
+              `frac_compulsory`: the same with every byte the sweep has to move counted once (a lower bound of its
+              traffic: <= 1 by construction; traffic / compulsory = how often bytes are re-moved); `frac_model`:
+              SURVEY 8(d)'s per-query gather model (counts gathers L2 / LDS serve; can exceed 1; kept for comparison
+              with rounds 1-2).  Without counters (`--no-pmc`) `frac` falls back to the compulsory figure.
+  `cpu_baseline`  the reference's algorithm on the host cores (rank 0, N = 1), run in a background process while the
+              GPU measurements go on: the hash-map-shaped faithful port run to the end of one query on one thread,
+              the dense-array port on three sources, and the array port on every hardware thread at once.
+After the timed region, at N = 1: `one_query_at_a_time` (the drop-in path, pprhip_fora_single_source), `topk_sample`
+(FORA top-32), `all_pair_sample` (All-Pair-Backward-Search on 2^18 targets) and `all_pair_rmat24` (config #5's graph
+on one GPU, in a child process), each with its own `roofline` incl. counter traffic.
 """
 import argparse
 import csv
@@ -50,12 +63,37 @@ sys.path.insert(0, ROOT)
 ALPHA = 0.15
 EPS = 0.5
 TOPK = 32
+AP_THR = 1e-3
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured streaming copy (79 %)
-RANDOM_REQUEST_ROOF_G = 55.0  # random requests beyond L2 per second on MI355X, measured: tools/micro/gather_rate.hip (8-byte
-                              # gathers) and row_gather_rate.hip (rows up to 128 bytes: 52-55 G/s, flat from 128 MB to 2 GB
-                              # tables).  Every such request moves a 128-byte line (profiles/r02_fetch_calibration.txt), so
-                              # this roof is 6.7-7 TB/s of line traffic: the HBM roof met at line granularity.
+RANDOM_REQUEST_ROOF_G = 55.0  # random 128-byte requests beyond L2 per second (tools/micro/gather_rate.hip)
+RANDOM_ATOMIC_ROOF_G = 20.0   # random fp64 read-modify-writes per second, any form, 17-24 G/s by footprint
+                              # (tools/micro/atomic_rate.hip, profiles/r03_atomic_rate.txt)
+
+
+def load_host(pkg, scale):
+    """The R-MAT host CSR (generator seed 1); cached in /tmp so that the child processes of one run (counter passes,
+    All-Pair children, CPU baseline) do not generate it again."""
+    path = "/tmp/pprhip_rmat%d_seed1.npz" % scale
+    if scale <= 22 and os.path.exists(path):
+        try:
+            z = np.load(path)
+            h = pkg.HostCsr.__new__(pkg.HostCsr)
+            h.n, h.m = int(z["n"]), int(z["m"])
+            h.out_rp, h.out_ci, h.in_rp, h.in_ci = z["out_rp"], z["out_ci"], z["in_rp"], z["in_ci"]
+            if h.n == 1 << scale and h.out_rp.size == h.n + 1 and h.out_ci.size == h.m:
+                return h
+        except Exception:
+            pass
+    h = pkg.HostCsr.rmat(scale, 16, seed=1)
+    if scale <= 22:
+        try:
+            tmp = path + ".%d.tmp.npz" % os.getpid()
+            np.savez(tmp, n=h.n, m=h.m, out_rp=h.out_rp, out_ci=h.out_ci, in_rp=h.in_rp, in_ci=h.in_ci)
+            os.replace(tmp, path)
+        except Exception:
+            pass
+    return h
 
 
 def live_draw(rng, live_ids, shape):
@@ -96,15 +134,26 @@ def main():
     ap.add_argument("--rounds", type=int, default=0, help="FORA threshold rounds (0 = cost model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the one-query-at-a-time, top-k and All-Pair samples")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline traffic)")
+    ap.add_argument("--no-rmat24", action="store_true", help="skip the R-MAT 24 All-Pair child sample")
+    ap.add_argument("--rmat24-targets", type=int, default=1 << 22)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--all-pair-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rmat24-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-sources", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-walk-divisor", type=int, default=32)
     ap.add_argument("--tuning", default="", help="cost-model overrides, e.g. c_dense_edge_ns=0.002,max_rounds=30")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
     if args.all_pair_child:
         return all_pair_child(args)
+    if args.rmat24_child:
+        return rmat24_child(args)
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args)
+    if args.pmc_child:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,7 +169,7 @@ def main():
     # one process per GPU; the modulo only matters when a launch is rehearsed on fewer devices (gloo)
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    xdev = "cuda" if args.backend == "nccl" else "cpu"  # where the gathered top-k blocks live
+    xdev = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -132,8 +181,26 @@ def main():
 
     # ---- graph lift (outside the timed region)
     t0 = time.time()
-    host = pkg.HostCsr.rmat(args.scale, 16, seed=1)
+    host = load_host(pkg, args.scale)
     t_gen = time.time() - t0
+    outdeg = np.diff(host.out_rp)
+    live_ids = np.nonzero(outdeg > 0)[0]
+    live_frac_graph = live_ids.size / host.n
+    q = args.queries_per_step
+    total_steps = args.warmup + args.steps
+    rng = np.random.default_rng(2 + 7919 * rank)
+    srcs = live_draw(rng, live_ids, (total_steps, q))
+
+    solo = world == 1 and rank == 0 and args.mode == "batch"
+    # host-only work that runs beside the GPU measurements: the CPU baselines (a process of their own: they take
+    # minutes of CPU time and use every core for a while) and the generation of config #5's graph
+    cpu_child = None
+    if solo and not args.no_cpu_baseline:
+        cpu_child = start_cpu_baseline(args, srcs[args.warmup:].ravel())
+    r24_child = None
+    if solo and not args.no_extras and not args.no_rmat24:
+        r24_child = start_rmat24(args)
+
     t0 = time.time()
     g = pkg.Graph(host, device=local_rank)
     t_lift = time.time() - t0
@@ -143,50 +210,43 @@ def main():
         key, val = kv.split("=")
         setattr(tuning, key, type(getattr(tuning, key))(float(val)))
     g.set_tuning(tuning)
-    outdeg = np.diff(host.out_rp)
-    live_ids = np.nonzero(outdeg > 0)[0]
-    live_frac_graph = live_ids.size / host.n
-
-    q = args.queries_per_step
-    total_steps = args.warmup + args.steps
-    rng = np.random.default_rng(2 + 7919 * rank)
-    srcs = live_draw(rng, live_ids, (total_steps, q))
     store = pkg.Results(g, q) if args.mode == "batch" else None
 
-    ids_blk = torch.empty((q, TOPK), dtype=torch.int32, device=xdev)
-    vals_blk = torch.empty((q, TOPK), dtype=torch.float64, device=xdev)
-    gather_ids = [torch.empty_like(ids_blk) for _ in range(world)] if (world > 1 and rank == 0) else None
-    gather_vals = [torch.empty_like(vals_blk) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # N > 1: the library's communicator for the top-k gather (rank 0 draws the id)
+    comm = None
+    if world > 1:
+        uid = [_quiet_stdout(pkg.comm_unique_id).hex() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        if args.backend == "nccl":
+            comm = _quiet_stdout(lambda: pkg.Comm(g, bytes.fromhex(uid[0]), rank, world))
 
     acc = {"class_ms": [0.0] * 8, "class_bytes": [0] * 8, "class_launches": [0] * 8, "rounds": 0, "queries": 0,
-           "walks": 0, "walk_steps": 0, "levels": 0, "dense_levels": 0, "dense_edges": 0, "push_ms": 0.0, "mc_ms": 0.0}
+           "walks": 0, "walk_steps": 0, "levels": 0, "dense_levels": 0, "dense_edges": 0, "push_ms": 0.0, "mc_ms": 0.0,
+           "sweep_min_bytes": 0, "call_ms": 0.0}
     last = {}
+    gathered = {}
 
     def record_stats(st, nq):
         for c in range(8):
             acc["class_ms"][c] += st.class_ms[c]
             acc["class_bytes"][c] += st.class_bytes[c]
             acc["class_launches"][c] += st.class_launches[c]
-        acc["rounds"] += st.rounds
+        for k in ("rounds", "walks", "walk_steps", "levels", "dense_levels", "dense_edges", "push_ms", "mc_ms",
+                  "sweep_min_bytes"):
+            acc[k] += getattr(st, k)
         acc["queries"] += nq
-        acc["walks"] += st.walks
-        acc["walk_steps"] += st.walk_steps
-        acc["levels"] += st.levels
-        acc["dense_levels"] += st.dense_levels
-        acc["dense_edges"] += st.dense_edges
-        acc["push_ms"] += st.push_ms
-        acc["mc_ms"] += st.mc_ms
+        acc["call_ms"] += st.total_ms
 
     def run_step(i, record):
+        ids_blk = np.full((q, TOPK), -1, dtype=np.int32)
+        vals_blk = np.zeros((q, TOPK))
         if args.mode == "batch":
             _, ids, vals, nsel, pq, st = g.fora_batch_single_source(srcs[i], EPS, ALPHA, seed=3 + i, n_rounds=args.rounds,
                                                                     k=TOPK, conf=conf, keep=store, per_query=True)
             last.update(step=i, ids=ids, vals=vals, nsel=nsel, pq=pq)
             if record:
                 record_stats(st, q)
-            if world > 1:
-                ids_blk.copy_(torch.from_numpy(ids))
-                vals_blk.copy_(torch.from_numpy(vals))
+            ids_blk, vals_blk = ids, vals
         else:
             for j in range(q):
                 s = int(srcs[i, j])
@@ -194,16 +254,19 @@ def main():
                 if record:
                     record_stats(st, 1)
                 nsel, ids, vals, _, _ = g.topk_select(TOPK)
-                if world > 1:
-                    row_i = np.full(TOPK, -1, dtype=np.int32)
-                    row_v = np.zeros(TOPK)
-                    row_i[:len(ids)] = ids
-                    row_v[:len(vals)] = vals
-                    ids_blk[j].copy_(torch.from_numpy(row_i))
-                    vals_blk[j].copy_(torch.from_numpy(row_v))
-        if world > 1:  # the only exchange on the path: top-k blocks to rank 0 (xGMI / RCCL)
-            dist.gather(ids_blk, gather_ids, dst=0)
-            dist.gather(vals_blk, gather_vals, dst=0)
+                ids_blk[j, :len(ids)] = ids
+                vals_blk[j, :len(vals)] = vals
+        if world > 1:  # the only exchange on the path: top-k blocks to rank 0
+            if comm is not None:
+                got = comm.topk_gather(ids_blk, vals_blk, rows_max=q)  # pprhip_topk_gather (RCCL inside the library)
+                if got is not None:
+                    gathered.update(ids=got[0], vals=got[1])
+            else:  # gloo rehearsal on fewer devices than ranks: RCCL refuses two ranks on one device
+                ti, tv = torch.from_numpy(ids_blk), torch.from_numpy(vals_blk)
+                gl_i = [torch.empty_like(ti) for _ in range(world)] if rank == 0 else None
+                gl_v = [torch.empty_like(tv) for _ in range(world)] if rank == 0 else None
+                dist.gather(ti, gl_i, dst=0)
+                dist.gather(tv, gl_v, dst=0)
 
     for i in range(args.warmup):
         run_step(i, False)
@@ -226,9 +289,15 @@ def main():
     check = None
     if args.mode == "batch" and last:
         check = self_check(pkg, store, srcs[last["step"]], last["ids"], last["vals"], last["nsel"], last["pq"], host.n)
+        if world > 1 and rank == 0 and gathered:  # rank 0's own block came back through the library's gather unchanged
+            if not np.array_equal(gathered["ids"][0], last["ids"]) or not np.array_equal(gathered["vals"][0], last["vals"]):
+                raise SystemExit("self-check failed: rank 0's top-k block changed in pprhip_topk_gather")
+            check["gathered_blocks"] = int(gathered["ids"].shape[0])
+    if comm is not None:
+        comm.close()
 
     all_pair_scaling = None
-    if not args.no_extras and not args.pmc_child and args.mode == "batch":
+    if not args.no_extras and args.mode == "batch":
         all_pair_scaling = all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xdev)
 
     if rank == 0:
@@ -238,18 +307,30 @@ def main():
         # dominant kernel = the class with the largest summed HIP-event time over the timed region
         dom = max(range(1, 8), key=lambda c: acc["class_ms"][c])
         dom_ms, dom_bytes, dom_n = acc["class_ms"][dom], acc["class_bytes"][dom], acc["class_launches"][dom]
-        achieved = (dom_bytes / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
+        model = (dom_bytes / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         avg_us = 1e3 * dom_ms / max(1, dom_n)
         useful = acc["dense_edges"] / max(1, acc["dense_levels"] * host.m)
+        is_sweep = dom in (1, 5)
+        comp_bytes = acc["sweep_min_bytes"] / max(1, dom_n) if is_sweep else dom_bytes / max(1, dom_n)
+        comp = comp_bytes / 1e9 / (avg_us / 1e6) if avg_us > 0 else 0.0
+        kernel_ms = sum(acc["class_ms"][c] for c in range(1, 8))
         roofline = {
-            "bound": "hbm", "kernel": pkg.KERNEL_NAMES[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "peak_achievable": HBM_ACHIEVABLE_GBS, "launches": dom_n, "avg_launch_us": round(avg_us, 2),
-            "algorithmic_bytes_per_launch": int(dom_bytes / max(1, dom_n)),
+            "bound": "hbm", "kernel": pkg.KERNEL_NAMES[dom], "achieved": round(comp, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(comp / HBM_PEAK_GBS, 4), "frac_basis": "compulsory bytes (no counters in this run)",
+            "traffic": None, "peak_achievable": HBM_ACHIEVABLE_GBS, "launches": dom_n, "avg_launch_us": round(avg_us, 2),
+            "algorithmic_bytes_per_launch": int(comp_bytes),
+            "algorithmic_note": "compulsory bytes: index stream, every gatherable contribution line once, row sums out "
+                                "and in, next contributions, the busy queries' residues - each counted once "
+                                "(pprhip_stats_t.sweep_min_bytes; DESIGN.md 6)",
+            "achieved_compulsory": round(comp, 1), "frac_compulsory": round(comp / HBM_PEAK_GBS, 4),
+            "model_bytes_per_launch": int(dom_bytes / max(1, dom_n)),
+            "achieved_model": round(model, 1), "frac_model": round(model / HBM_PEAK_GBS, 4),
+            "frac_model_note": "SURVEY 8(d)'s model: 4m + busy x (8m + 36 rows + 4) per sweep - one 8-byte gather per edge "
+                               "and query, although a gathered line serves 16 queries and a third of the gathers hit L2 "
+                               "/ LDS; can exceed 1, kept for comparison with rounds 1-2",
             "useful_edge_fraction": round(useful, 4),
             "useful_note": "frontier edges of the levels run as sweeps / (sweeps x m): the share of a sweep's edge "
-                           "gathers that carry a pushed residue; achieved x useful = %.0f GB/s of the roof spent on "
-                           "real pushes" % (achieved * useful),
+                           "gathers that carry a pushed residue",
             "other_kernels": {
                 pkg.KERNEL_NAMES[c]: {
                     "ms": round(acc["class_ms"][c], 3), "launches": acc["class_launches"][c],
@@ -269,7 +350,8 @@ def main():
                        "mode": "16 queries in flight (pprhip_fora_batch_single_source_resident): every query's vector "
                                "kept in a device-resident store, top-%d per query" % TOPK
                        if args.mode == "batch" else "one query at a time (pprhip_fora_single_source)",
-                       "sharding": "replicated CSR, sources sharded by rank, top-%d gather to rank 0" % TOPK
+                       "sharding": "replicated CSR, sources sharded by rank, top-%d blocks gathered on rank 0 by "
+                                   "pprhip_topk_gather (RCCL inside libpprhip.so)" % TOPK
                        if world > 1 else "single GPU"},
             "ms_per_query": round(1e3 * elapsed / (args.steps * q), 3),
             "live_node_fraction_of_graph": round(live_frac_graph, 4),
@@ -277,6 +359,9 @@ def main():
             "avg_rounds": round(acc["rounds"] / nq, 2),
             "kernel_ms_per_query": {pkg.KERNEL_NAMES[c]: round(acc["class_ms"][c] / nq, 3)
                                     for c in (1, 2, 3, 5) if acc["class_launches"][c]},
+            "host_gap": {"wall_ms_per_query": round(1e3 * elapsed / (args.steps * q), 3),
+                         "kernel_ms_per_query": round(kernel_ms / nq, 3),
+                         "fraction_not_in_kernels": round(1.0 - (kernel_ms / nq) / (1e3 * elapsed / (args.steps * q)), 4)},
             "dense_levels_per_query": round(acc["dense_levels"] / nq, 1),
             "levels_per_query": round(acc["levels"] / nq, 1),
             "walks_per_query": int(acc["walks"] / nq),
@@ -286,50 +371,30 @@ def main():
         }
         if all_pair_scaling is not None:
             out["all_pair_scaling"] = all_pair_scaling
-        extras = world == 1 and args.mode == "batch" and not args.no_extras and not args.pmc_child
+        extras = solo and not args.no_extras
         if extras:
             out.update(delivery_samples(pkg, g, store, rng, live_ids, host, conf, q))
             out["one_query_at_a_time"] = single_mode_sample(pkg, g, srcs[args.warmup], conf, args, host)
             out["topk_sample"] = topk_sample(pkg, g, srcs[args.warmup])
             out["all_pair_sample"] = all_pair_sample(pkg, g, host)
-        if args.pmc_child:  # the profiled child also runs the one-query-at-a-time path, for its kernels' counters
-            single_mode_sample(pkg, g, srcs[args.warmup][:8], conf, args, host)
-        if world == 1 and not args.no_pmc and not args.pmc_child and args.mode == "batch":
-            pmc = pmc_traffic(args, host)
-            roofline["traffic"] = pmc.get("dense_pull_batch")
-            roofline["traffic_source"] = pmc["source"]
-            if pmc.get("calibration") is not None:
-                roofline["fetch_size_calibration"] = pmc["calibration"]
-            if roofline["traffic"]:
-                roofline["achieved_counter"] = round(roofline["traffic"] / 1e9 / (avg_us / 1e6), 1)
-                roofline["frac_counter"] = round(roofline["achieved_counter"] / HBM_PEAK_GBS, 4)
-                roofline["note"] = ("frac is SURVEY 8(d)'s algorithmic byte model over time and counts the gathers that "
-                                    "L2 / LDS serve (a third of them), so it can exceed the HBM roof; frac_counter is "
-                                    "the traffic the memory-side counters saw")
-            if extras and pmc.get("dense_pull"):
-                r1 = out["one_query_at_a_time"]["roofline"]
-                r1["traffic"] = pmc["dense_pull"]
-                r1["achieved_counter"] = round(pmc["dense_pull"] / 1e9 / (r1["avg_launch_us"] / 1e6), 1)
-                r1["frac_counter"] = round(r1["achieved_counter"] / HBM_PEAK_GBS, 4)
-            wk = roofline["other_kernels"].get("walk")
-            if pmc.get("walk") and wk and wk.get("launches"):
-                # the walk kernel's gathers use 4-8 bytes of every 128-byte line they move: bound by lines, not by
-                # algorithmic bytes (writes are a twentieth of its traffic and counted with the lines here)
-                wk["traffic_per_launch"] = pmc["walk"]
-                avg_s = wk["ms"] / 1e3 / wk["launches"]
-                wk["achieved_counter"] = round(pmc["walk"] / 1e9 / avg_s, 1)
-                wk["frac_counter"] = round(wk["achieved_counter"] / HBM_PEAK_GBS, 4)
-                wk["requests_beyond_l2_G_per_s"] = round(pmc["walk"] / 128.0 / avg_s / 1e9, 1)
-                wk["random_request_roof_G_per_s"] = RANDOM_REQUEST_ROOF_G
-                wk["frac_of_request_roof"] = round(wk["requests_beyond_l2_G_per_s"] / RANDOM_REQUEST_ROOF_G, 3)
-        if world == 1 and not args.no_cpu_baseline and not args.pmc_child:
-            out["cpu_baseline"] = cpu_baseline(host, srcs[args.warmup:], args.cpu_walk_divisor)
+        if store is not None:
+            store.close()
+            store = None
+        g.close()  # HBM back before the children that lift graphs of their own
+        g = None
+        if r24_child is not None:
+            out["all_pair_rmat24"] = finish_rmat24(r24_child)
+        if solo and not args.no_pmc:
+            apply_counters(out, pmc_traffic(args, host), avg_us, extras)
+        if cpu_child is not None:
+            out["cpu_baseline"] = finish_cpu_baseline(cpu_child)
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_faithful"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if store is not None:
         store.close()
-    g.close()
+    if g is not None:
+        g.close()
     if world > 1:
         dist.destroy_process_group()
 
@@ -360,13 +425,13 @@ def delivery_samples(pkg, g, store, rng, live_ids, host, conf, q):
                                           % (q, 100.0 * float((np.diff(host.out_rp)[su] == 0).mean()))}
 
 
-def single_mode_sample(pkg, g, srcs, conf, args, host):
+def single_mode_sample(pkg, g, srcs, conf, args, host, count=32):
     """The drop-in path: the same (live) sources through pprhip_fora_single_source, one after another, default
     cost-model profile; outside the timed region."""
     g.set_tuning(pkg.tuning_default())
-    sample = [int(s) for s in srcs[:32]]
+    sample = [int(s) for s in srcs[:count]]
     g.fora_single_source(sample[0], EPS, ALPHA, seed=1, n_rounds=args.rounds, conf=conf, fetch=False)
-    ms, by, n_lv, dl, de = 0.0, 0, 0, 0, 0
+    ms, by, n_lv, dl, de, mb = 0.0, 0, 0, 0, 0, 0
     cls = {1: 0.0, 2: 0.0, 3: 0.0}
     t0 = time.perf_counter()
     for j, s in enumerate(sample):
@@ -376,35 +441,43 @@ def single_mode_sample(pkg, g, srcs, conf, args, host):
         n_lv += st.class_launches[1]
         dl += st.dense_levels
         de += st.dense_edges
+        mb += st.sweep_min_bytes
         for c in cls:
             cls[c] += st.class_ms[c]
     dt = time.perf_counter() - t0
     g.set_tuning(pkg.tuning_batch())
-    ach = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+    avg_s = ms / 1e3 / max(1, n_lv)
+    model = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+    comp = (mb / max(1, n_lv)) / 1e9 / avg_s if avg_s > 0 else 0.0
     return {"value": round(len(sample) / dt, 3), "unit": "queries/s", "queries": len(sample),
             "ms_per_query": round(1e3 * dt / len(sample), 3),
             "kernel_ms_per_query": {pkg.KERNEL_NAMES[c]: round(v / len(sample), 3) for c, v in cls.items()},
             "dense_levels_per_query": round(dl / len(sample), 1),
-            "roofline": {"bound": "hbm", "kernel": "dense_pull", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n_lv,
+            "roofline": {"bound": "hbm", "kernel": "dense_pull", "achieved": round(comp, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(comp / HBM_PEAK_GBS, 4),
+                         "frac_basis": "compulsory bytes (no counters in this run)", "traffic": None, "launches": n_lv,
                          "avg_launch_us": round(1e3 * ms / max(1, n_lv), 2),
-                         "algorithmic_bytes_per_launch": int(by / max(1, n_lv)),
+                         "algorithmic_bytes_per_launch": int(mb / max(1, n_lv)),
+                         "frac_compulsory": round(comp / HBM_PEAK_GBS, 4),
+                         "model_bytes_per_launch": int(by / max(1, n_lv)), "frac_model": round(model / HBM_PEAK_GBS, 4),
+                         "l2_hit_gather_roof_G_per_s": 250.0,
+                         "gathers_G_per_s": round(host.m / avg_s / 1e9, 1) if avg_s > 0 else 0.0,
                          "useful_edge_fraction": round(de / max(1, dl * host.m), 4)}}
 
 
-def topk_sample(pkg, g, srcs):
+def topk_sample(pkg, g, srcs, count=None, single=32):
     """FORA top-k (Fora_Topk, k = 32; configs #3 / #4) on the sources of the first timed step, outside the timed
     region: 16 queries in flight (pprhip_fora_batch_topk), and the first 32 of them one at a time.  Its roofline is
     the whole call's: algorithmic bytes of push (44 pops + 28 edges + 5 enqueues, sweeps 12m + 36n), walks and
     selections over the call's wall time."""
     g.set_tuning(pkg.tuning_default())
-    srcs = np.ascontiguousarray(srcs, dtype=np.int32)
+    srcs = np.ascontiguousarray(srcs[:count] if count else srcs, dtype=np.int32)
     g.fora_batch_topk(srcs[:16], TOPK, EPS, ALPHA, seed=1)
     t0 = time.perf_counter()
     ids, vals, st = g.fora_batch_topk(srcs, TOPK, EPS, ALPHA, seed=7)
     dt = time.perf_counter() - t0
     t1 = time.perf_counter()
-    for j, s in enumerate(srcs[:32]):
+    for j, s in enumerate(srcs[:single]):
         g.fora_topk(int(s), EPS, ALPHA, TOPK, seed=7 + j)
     dt1 = time.perf_counter() - t1
     g.set_tuning(pkg.tuning_batch())
@@ -412,40 +485,51 @@ def topk_sample(pkg, g, srcs):
     ach = by / 1e9 / dt
     return {"value": round(len(srcs) / dt, 1), "unit": "queries/s", "queries": int(len(srcs)), "k": TOPK,
             "rounds_per_query": round(st.rounds / max(1, len(srcs)), 2),
-            "one_at_a_time_queries_per_s": round(32 / dt1, 1),
+            "one_at_a_time_queries_per_s": round(min(single, len(srcs)) / dt1, 1),
             "roofline": {"bound": "hbm", "kernel": "whole call (push + walks + selection)", "achieved": round(ach, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes": int(by),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "frac_basis": "algorithmic bytes over wall time", "traffic": None,
+                         "algorithmic_bytes": int(by), "algorithmic_bytes_per_query": int(by / max(1, len(srcs))),
                          "class_ms": {pkg.KERNEL_NAMES[c]: round(st.class_ms[c], 2) for c in (2, 3, 5)
                                       if st.class_launches[c]}}}
 
 
-def all_pair_sample(pkg, g, host):
+def all_pair_sample(pkg, g, host, nt=1 << 18):
     """The path's other workload, All-Pair-Backward-Search (config #5), on a bounded target range of the same
     graph (outside the timed region): 2^18 targets, threshold 1e-3, k = 32, index finalised on the host.  Roofline
-    of its batched kernel: 44 B per pop + 28 B per edge + 16 B per index entry."""
+    of its batched kernels: 44 B per pop + 28 B per edge + 16 B per index entry; the bound that
+    binds them is the rate of random fp64 read-modify-writes (one per edge), not bytes."""
     g.set_tuning(pkg.tuning_default())
-    nt = min(host.n, 1 << 18)
-    ix, _ = g.all_pair_backward(ALPHA, 1e-3, TOPK, 0, min(nt, 4096))
+    nt = min(host.n, nt)
+    ix, _ = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, min(nt, 4096))
     ix.close()
     t0 = time.perf_counter()
-    ix, st = g.all_pair_backward(ALPHA, 1e-3, TOPK, 0, nt)
+    ix, st = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, nt)
     dt = time.perf_counter() - t0
     entries = int(len(ix.arrays()[1]))
     ix.close()
     g.set_tuning(pkg.tuning_batch())
+    return all_pair_report(pkg, st, nt, dt, entries)
+
+
+def all_pair_report(pkg, st, nt, dt, entries):
     ms, by, nl = st.class_ms[4], st.class_bytes[4], st.class_launches[4]
     ach = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-    return {"value": round(nt / dt, 1), "unit": "targets/s", "targets": nt, "threshold": 1e-3, "k": TOPK,
-            "index_entries": entries, "tier2_targets": int(st.rounds), "tier3_targets": int(st.dense_nodes),
+    return {"value": round(nt / dt, 1), "unit": "targets/s", "targets": nt, "threshold": AP_THR, "k": TOPK,
+            "seconds": round(dt, 3), "index_entries": entries,
+            "tier_census": {"lds_tier_targets": int(nt - st.rounds), "dense_tier_targets": int(st.rounds),
+                            "whole_vector_tier_targets": int(st.dense_nodes)},
             "device_ms": round(st.total_ms, 1), "pops": int(st.pops), "edge_pushes": int(st.edge_pushes),
-            "roofline": {"bound": "hbm", "kernel": "backward_batch (k_apbs)", "achieved": round(ach, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                         "launches": nl, "avg_launch_us": round(1e3 * ms / max(1, nl), 1),
-                         "algorithmic_bytes_per_launch": int(by / max(1, nl)),
-                         "note": "per-target state lives in LDS / HBM hash tables, one workgroup per target: the "
-                                 "kernel is bound by chains of dependent probes and atomics (DESIGN.md 5), not by "
-                                 "HBM streaming"}}
+            "roofline": {"bound": "hbm", "kernel": "backward_batch (k_apbs_lds + k_apbs_dense)", "achieved": round(ach, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "frac_basis": "algorithmic bytes (44 B/pop + 28 B/edge + 16 B/entry) over kernel time",
+                         "traffic": None, "launches": nl, "kernel_ms": round(ms, 2),
+                         "algorithmic_bytes": int(by),
+                         "edges_G_per_s": round(st.edge_pushes / (ms / 1e3) / 1e9, 2) if ms > 0 else 0.0,
+                         "random_rmw_roof_G_per_s": RANDOM_ATOMIC_ROOF_G,
+                         "note": "an edge is one random fp64 read-modify-write (LDS in the first tier, a memory-side "
+                                 "atomic on a dense per-workgroup vector in the second): bound by the chip's 17-24 G "
+                                 "random read-modify-writes per second, not by bytes (DESIGN.md 5)"}}
 
 
 def _quiet_stdout(fn):
@@ -460,6 +544,23 @@ def _quiet_stdout(fn):
         sys.stdout.flush()
         os.dup2(saved, 1)
         os.close(saved)
+
+
+def _child_json(child, limit, what):
+    """One JSON object from a child process, or {'error': ...}; the child is killed at the limit."""
+    try:
+        out, errtxt = child.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        return {"error": "no result from %s after %.0f s" % (what, limit)}
+    lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
+    if child.returncode == 0 and lines:
+        try:
+            return json.loads(lines[-1])
+        except Exception as e:  # noqa: BLE001
+            return {"error": "%s printed no JSON: %s" % (what, e)}
+    return {"error": "%s exited with code %s: %s" % (what, child.returncode, errtxt.decode(errors="replace")[-300:])}
 
 
 def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xdev):
@@ -477,27 +578,16 @@ def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xde
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
     limit = float(os.environ.get("PPRHIP_BENCH_WATCHDOG_S", "600"))
-    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), PPRHIP_COMM_ID=uid[0])
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), PPRHIP_COMM_ID=uid[0],
+               PPRHIP_COMM_TIMEOUT_S=str(int(limit * 0.8)))
     cmd = [sys.executable, os.path.abspath(__file__), "--all-pair-child", "--scale", str(args.scale)]
-    res, err = None, None
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    try:
-        out, errtxt = child.communicate(timeout=limit)
-        lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
-        if child.returncode == 0 and lines:
-            res = json.loads(lines[-1])
-            if "error" in res:
-                err, res = res["error"], None
-        else:
-            err = "child of rank %d exited with code %s: %s" % (rank, child.returncode, errtxt.decode(errors="replace")[-300:])
-    except subprocess.TimeoutExpired:
-        child.kill()
-        child.communicate()
-        err = "no result from rank %d's child after %.0f s" % (rank, limit)
+    res = _child_json(child, limit, "rank %d's All-Pair child" % rank)
+    err = res.get("error")
     # t_all, search seconds, entries found, bytes received, entries kept; a failed rank poisons the sample
     vals = [res["seconds"], res["search_seconds"], res["entries_found"], res["bytes_received"], res["entries_kept"]] \
-        if res else [0.0] * 5
-    stats = torch.tensor(vals + [0.0 if res else 1.0], dtype=torch.float64, device=xdev)
+        if not err else [0.0] * 5
+    stats = torch.tensor(vals + [1.0 if err else 0.0], dtype=torch.float64, device=xdev)
     tmax = stats.clone()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -505,7 +595,7 @@ def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xde
     if float(stats[5]) > 0:
         return {"error": err or "%d of %d ranks failed" % (int(stats[5]), world)}
     n = 1 << args.scale
-    return {"unit": "targets/s", "scaling": "strong", "targets": n, "threshold": 1e-3, "k": TOPK,
+    return {"unit": "targets/s", "scaling": "strong", "targets": n, "threshold": AP_THR, "k": TOPK,
             "value": round(n / float(tmax[0]), 1), "seconds": round(float(tmax[0]), 3),
             "search_seconds_max_rank": round(float(tmax[1]), 3),
             "entries_found": int(stats[2]), "entries_kept_after_k_rule": int(stats[4]),
@@ -521,14 +611,14 @@ def all_pair_child(args):
         import torch  # noqa: F401  first, as in the parent: the library then binds to the same HIP runtime and RCCL build
         pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
         device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, pkg.device_count())
-        host = pkg.HostCsr.rmat(args.scale, 16, seed=1)
+        host = load_host(pkg, args.scale)
         with pkg.Graph(host, device=device) as g:
             comm = _quiet_stdout(lambda: pkg.Comm(g, bytes.fromhex(os.environ["PPRHIP_COMM_ID"]), rank, world))
             lo, hi = pkg.shard_target_range(rank, world, host.n)
-            ix, _ = g.all_pair_backward(ALPHA, 1e-3, TOPK, lo, min(hi, lo + 1024))  # warm-up of the kernels
+            ix, _ = g.all_pair_backward(ALPHA, AP_THR, TOPK, lo, min(hi, lo + 1024))  # warm-up of the kernels
             ix.close()
             t0 = time.perf_counter()
-            own, st = _quiet_stdout(lambda: comm.all_pair_backward_sharded(ALPHA, 1e-3, TOPK))
+            own, st = _quiet_stdout(lambda: comm.all_pair_backward_sharded(ALPHA, AP_THR, TOPK))
             t_all = time.perf_counter() - t0
             res = {"seconds": t_all, "search_seconds": st.total_ms / 1e3, "entries_found": float(st.mc_sources),
                    "bytes_received": float(st.select_bytes), "entries_kept": float(len(own.arrays()[1]))}
@@ -539,154 +629,376 @@ def all_pair_child(args):
     print(json.dumps(res), flush=True)
 
 
+# ---------------------------------------------------------------------------------------------- config #5's graph
+def start_rmat24(args):
+    """Config #5's graph (R-MAT 24: n = 16.7 M, m = 268 M) through All-Pair-Backward-Search on ONE GPU, in a child
+    process (its 4 GB of CSR and the tier-2 workspaces sized for n = 2^24 come and go with it).  The child generates
+    the graph on the host while the parent measures, and waits for a line on its stdin before it touches the GPU."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--rmat24-child", "--rmat24-targets", str(args.rmat24_targets)]
+    return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def finish_rmat24(child):
+    try:
+        child.stdin.write(b"go\n")
+        child.stdin.flush()
+    except Exception:  # noqa: BLE001  (the child has died: _child_json reports how)
+        pass
+    return _child_json(child, float(os.environ.get("PPRHIP_BENCH_RMAT24_S", "420")), "the R-MAT 24 child")
+
+
+def rmat24_child(args):
+    try:
+        pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
+        t0 = time.time()
+        host = pkg.HostCsr.rmat(24, 16, seed=1)
+        t_gen = time.time() - t0
+        sys.stdin.readline()  # the parent's GPU measurements are over
+        import torch  # noqa: F401
+        t0 = time.time()
+        with pkg.Graph(host, device=0) as g:
+            t_lift = time.time() - t0
+            nt = min(host.n, args.rmat24_targets)
+            ix, _ = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, 4096)  # warm-up: workspaces of 2^24-node vectors
+            ix.close()
+            t0 = time.perf_counter()
+            ix, st = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, nt)
+            dt = time.perf_counter() - t0
+            entries = int(len(ix.arrays()[1]))
+            ix.close()
+            res = all_pair_report(pkg, st, nt, dt, entries)
+            res["workload"] = "RMAT scale-24 (n=%d, m=%d, seed 1), All-Pair-Backward-Search on the first %d targets, " \
+                              "threshold %g, k = %d, one GPU" % (host.n, host.m, nt, AP_THR, TOPK)
+            res["graph_lift_s"] = {"generate_and_csr": round(t_gen, 1), "upload_and_tile": round(t_lift, 1)}
+    except Exception as e:  # noqa: BLE001
+        res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    print(json.dumps(res), flush=True)
+
+
 # ---------------------------------------------------------------------------------------------- HBM counters
 def _short(name):
     return name.split("(")[0].replace("void ", "").replace("pprhip::", "").strip()
 
 
-def _pmc_pass(counter, args, workdir):
-    """One `rocprofv3 --pmc <counter>` pass over a short child run of this same file (the program directly after
-    `--`).  Returns {kernel: [values in KB]}."""
-    d = os.path.join(workdir, counter)
-    cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
-           os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "1", "--queries-per-step", "48",
-           "--scale", str(args.scale), "--no-cpu-baseline", "--no-pmc"]
+MARK = "k_walk_batch"  # pprhip_random_walk_batch's kernel: launched by nothing else in the counted child
+
+
+def pmc_child(args):
+    """The program the counter passes profile: every measured path once, in short, with a marker kernel between the
+    phases (pprhip_random_walk_batch of one walk) so that the per-dispatch counter rows can be attributed."""
+    import torch  # noqa: F401
+    pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
+    host = load_host(pkg, args.scale)
+    live_ids = np.nonzero(np.diff(host.out_rp) > 0)[0]
+    rng = np.random.default_rng(2)
+    srcs = live_draw(rng, live_ids, (args.warmup + args.steps, args.queries_per_step))[args.warmup]
+    g = pkg.Graph(host, device=0)
+    conf = pkg.conf_whole_graph(host.n, host.m, ALPHA)
+    tuning = pkg.tuning_batch()
+    for kv in filter(None, args.tuning.split(",")):
+        key, val = kv.split("=")
+        setattr(tuning, key, type(getattr(tuning, key))(float(val)))
+    g.set_tuning(tuning)
+    store = pkg.Results(g, 48)
+
+    def mark():
+        g.random_walks(np.array([int(srcs[0])], dtype=np.int32), np.array([0], dtype=np.uint64), ALPHA, seed=1)
+
+    # phase 0: warm-up (first-use allocations, LDS opt-ins) - not counted
+    g.fora_batch_single_source(srcs[:16], EPS, ALPHA, seed=3, k=TOPK, conf=conf, keep=store)
+    mark()  # 1: the headline path
+    g.fora_batch_single_source(srcs[:48], EPS, ALPHA, seed=4, k=TOPK, conf=conf, keep=store)
+    store.sum(0)  # k_sum_partial: the calibration kernel (reads exactly 8n bytes)
+    mark()  # 2: one query at a time
+    single_mode_sample(pkg, g, srcs, conf, args, host, count=8)
+    mark()  # 3: top-k, 16 in flight
+    g.set_tuning(pkg.tuning_default())
+    g.fora_batch_topk(np.ascontiguousarray(srcs[:16]), TOPK, EPS, ALPHA, seed=7)
+    mark()  # 4: top-k, one at a time
+    for j, s in enumerate(srcs[:4]):
+        g.fora_topk(int(s), EPS, ALPHA, TOPK, seed=7 + j)
+    mark()  # 5: All-Pair, 2^16 targets (warm-up before it would be counted too: first-use work is part of this phase's
+    ix, _ = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, 256)  # kernels but not of the two kernels that are read out)
+    ix.close()
+    mark()  # 6
+    ix, _ = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, 1 << 16)
+    ix.close()
+    mark()
+    store.close()
+    g.close()
+
+
+def _pmc_pass(counters, args, workdir):
+    """One `rocprofv3 --pmc <counters>` pass over pmc_child (the program directly after `--`).  Returns the rows in
+    dispatch order: [(kernel, {counter: value})]."""
+    d = os.path.join(workdir, counters.replace(" ", "_"))
+    cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "--", sys.executable,
+           os.path.abspath(__file__), "--pmc-child", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--queries-per-step", str(args.queries_per_step), "--scale", str(args.scale)]
     if args.tuning:
         cmd += ["--tuning", args.tuning]
     env = dict(os.environ, TMPDIR="/tmp", PPRHIP_BATCH_THREADS="0")
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if r.returncode != 0 or not files:
-        raise RuntimeError("rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-300:]))
-    out = {}
+        raise RuntimeError("rocprofv3 --pmc %s failed (rc %d): %s" % (counters, r.returncode, r.stderr.decode()[-300:]))
+    rows = {}
     for row in csv.DictReader(open(files[0])):
-        if row["Counter_Name"] == counter:
-            out.setdefault(_short(row["Kernel_Name"]), []).append(float(row["Counter_Value"]))
+        did = int(row["Dispatch_Id"])
+        rows.setdefault(did, (_short(row["Kernel_Name"]), {}))[1][row["Counter_Name"]] = float(row["Counter_Value"])
+    return [rows[k] for k in sorted(rows)]
+
+
+def _phases(rows):
+    """Splits the dispatch rows at the marker kernel: phases[i] = rows between marker i-1 and marker i."""
+    out, cur = [], []
+    for name, vals in rows:
+        if name == MARK:
+            out.append(cur)
+            cur = []
+        else:
+            cur.append((name, vals))
+    out.append(cur)
     return out
 
 
 def pmc_traffic(args, host):
-    """HBM-side bytes per launch of the dominant kernel classes, measured on this build in this run: FETCH_SIZE and
-    WRITE_SIZE in separate passes (they do not fit one pass on gfx950), KB units, and the guide's gfx950 correction:
-    FETCH_SIZE = TCC_EA0_RDREQ x 64 B while every memory-side read request of this chip is 128 bytes - a coalesced
-    stream and a random gather alike (profiles/r02_fetch_calibration.txt: TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ for row
-    gathers of 8 ... 512 bytes; FETCH_SIZE = 0.498 of the bytes of 128-byte rows; an 8-byte gather moves 128).  The
-    factor is re-measured in every run on k_sum_partial, which reads exactly 8n bytes:
-    bytes = FETCH_SIZE x 1024 x (8n / FETCH_SIZE(k_sum_partial)) + WRITE_SIZE x 1024."""
+    """Memory-side bytes of every measured path, from counters collected in this run on this build: FETCH_SIZE,
+    WRITE_SIZE and TCC_HIT / TCC_MISS in separate passes (the guide: one counter set per pass), KB units, and the
+    guide's gfx950 correction: FETCH_SIZE = TCC_EA0_RDREQ x 64 B while every memory-side read request of this chip
+    is 128 bytes - a coalesced stream and a random gather alike (profiles/r02_fetch_calibration.txt).  The factor is
+    re-measured in every run on k_sum_partial, which reads exactly 8n bytes:
+    bytes = FETCH_SIZE x 1024 x (8n / FETCH_SIZE(k_sum_partial)) + WRITE_SIZE x 1024.
+    FETCH_SIZE counts what leaves L2, Infinity-Cache hits included: L2-miss traffic, an upper bound of HBM traffic."""
     if shutil.which("rocprofv3") is None:
         return {"source": "unmeasured: rocprofv3 not on PATH"}
     work = tempfile.mkdtemp(prefix="pprhip_pmc_", dir="/tmp")
     try:
-        fetch = _pmc_pass("FETCH_SIZE", args, work)
-        write = _pmc_pass("WRITE_SIZE", args, work)
+        fetch = _phases(_pmc_pass("FETCH_SIZE", args, work))
+        write = _phases(_pmc_pass("WRITE_SIZE", args, work))
     except Exception as e:  # the line is still valid without counters; say why they are missing
         shutil.rmtree(work, ignore_errors=True)
         return {"source": "unmeasured: %s" % str(e)[:200]}
+    try:
+        tcc = _phases(_pmc_pass("TCC_HIT_sum TCC_MISS_sum", args, work))
+    except Exception as e:  # noqa: BLE001
+        tcc = None
+        tcc_err = str(e)[:160]
     shutil.rmtree(work, ignore_errors=True)
     n = host.n
-
-    def avg(d, k):
-        v = d.get(k, [])
-        return sum(v) / len(v) if v else 0.0
-
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this build in this run; read bytes = "
-                     "FETCH_SIZE x the factor measured on k_sum_partial (every memory-side read request is 128 bytes, "
-                     "tallied at 64: MI355X_MICROARCH.md, profiles/r02_fetch_calibration.txt)"}
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum child passes of this build in "
+                     "this run; read bytes = FETCH_SIZE x the factor measured on k_sum_partial (every memory-side read "
+                     "request is 128 bytes, tallied at 64: MI355X_MICROARCH.md, profiles/r02_fetch_calibration.txt); "
+                     "FETCH_SIZE includes Infinity-Cache hits"}
+    if len(fetch) < 8 or len(write) < 8:
+        res["source"] = "unmeasured: the counter rows do not hold the expected phase markers"
+        return res
     factor = 2.0
-    if fetch.get("k_sum_partial"):
-        ratio = avg(fetch, "k_sum_partial") * 1024.0 / (8.0 * n)
+    cal = [v["FETCH_SIZE"] for name, v in fetch[1] if name == "k_sum_partial" and "FETCH_SIZE" in v]
+    if cal:
+        ratio = (sum(cal) / len(cal)) * 1024.0 / (8.0 * n)
         res["calibration"] = round(ratio, 3)
         if 0.4 < ratio < 1.1:
             factor = 1.0 / ratio
 
-    def level_bytes(keys, levels):
-        rd = sum(sum(fetch.get(k, [])) for k in keys) * 1024.0 * factor
-        wr = sum(sum(write.get(k, [])) for k in keys) * 1024.0
-        return int((rd + wr) / max(1.0, levels))
+    def kb(phase_rows, counter, pred):
+        return sum(v.get(counter, 0.0) for name, v in phase_rows if pred(name))
 
-    # a dense level = several launches of the edge / apply kernels (one per Gauss-Seidel block) + one reduce launch
-    bk = [k for k in fetch if k.startswith("k_dense_edges_b<") or k in ("k_dense_apply_batch", "k_dense_reduce_batch")]
-    if bk and "k_dense_reduce_batch" in fetch:
-        res["dense_pull_batch"] = level_bytes(bk, len(fetch["k_dense_reduce_batch"]))
-    sk = [k for k in fetch if k.startswith("k_dense_edges<") or k.startswith("k_dense_apply<") or k == "k_dense_reduce"]
-    if any(k.startswith("k_dense_edges<") for k in sk) and "k_dense_reduce" in fetch:
-        # levels launched behind another one whose frontier had already emptied return at once and fetch next to
-        # nothing: not counted (a counted level = one apply launch per Gauss-Seidel block, two blocks)
-        levels = sum(sum(1 for x in v if x > 256.0) for k, v in fetch.items() if k.startswith("k_dense_apply<")) / 2.0
-        res["dense_pull"] = level_bytes(sk, levels)
-    if "k_mc_walk" in fetch:
-        res["walk"] = int(avg(fetch, "k_mc_walk") * 1024.0 * factor + avg(write, "k_mc_walk") * 1024.0)
+    def count(phase_rows, pred):
+        return sum(1 for name, v in phase_rows if pred(name))
+
+    def traffic(ph, pred):
+        return kb(fetch[ph], "FETCH_SIZE", pred) * 1024.0 * factor + kb(write[ph], "WRITE_SIZE", pred) * 1024.0
+
+    def hit_rate(ph, pred):
+        if tcc is None or len(tcc) <= ph:
+            return None
+        h, m = kb(tcc[ph], "TCC_HIT_sum", pred), kb(tcc[ph], "TCC_MISS_sum", pred)
+        return round(h / (h + m), 4) if h + m > 0 else None
+
+    anyk = lambda name: True  # noqa: E731
+    # phase 1: the headline path; a dense level = several launches of the edge / apply kernels + one reduce launch
+    sweep = lambda k: k.startswith("k_dense_edges_b<") or k in ("k_dense_apply_batch", "k_dense_reduce_batch")  # noqa: E731
+    levels = count(fetch[1], lambda k: k == "k_dense_reduce_batch")
+    if levels:
+        res["dense_pull_batch"] = int(traffic(1, sweep) / levels)
+        res["dense_pull_batch_tcc_hit"] = hit_rate(1, sweep)
+        res["dense_pull_batch_edges_tcc_hit"] = hit_rate(1, lambda k: k.startswith("k_dense_edges_b<"))
+    walks = count(fetch[1], lambda k: k == "k_mc_walk")
+    if walks:
+        res["walk"] = int(traffic(1, lambda k: k == "k_mc_walk") / walks)
+    # phase 2: one query at a time; levels launched behind another one whose frontier had already emptied return at
+    # once and fetch next to nothing: not counted (a counted level = one apply launch per Gauss-Seidel block, two blocks)
+    one = lambda k: k.startswith("k_dense_edges<") or k.startswith("k_dense_apply<") or k == "k_dense_reduce"  # noqa: E731
+    lv = sum(1 for name, v in fetch[2] if name.startswith("k_dense_apply<") and v.get("FETCH_SIZE", 0.0) > 256.0) / 2.0
+    if lv:
+        res["dense_pull"] = int(traffic(2, one) / lv)
+        res["dense_pull_tcc_hit"] = hit_rate(2, one)
+    res["single_query_bytes"] = int(traffic(2, anyk) / 9)  # 8 timed queries + the sample's own warm-up query
+    # phases 3 / 4: top-k, whole phase per query
+    res["topk_batch_bytes_per_query"] = int(traffic(3, anyk) / 16)
+    res["topk_single_bytes_per_query"] = int(traffic(4, anyk) / 4)
+    res["topk_batch_tcc_hit"] = hit_rate(3, anyk)
+    # phase 6: All-Pair on 2^16 targets
+    ap = lambda k: k.startswith("k_apbs")  # noqa: E731
+    res["all_pair_kernel_bytes_2p16"] = int(traffic(6, ap))
+    res["all_pair_phase_bytes_2p16"] = int(traffic(6, anyk))
+    res["all_pair_dense_bytes_2p16"] = int(traffic(6, lambda k: k == "k_apbs_dense"))
+    res["all_pair_tcc_hit"] = hit_rate(6, ap)
+    if tcc is None:
+        res["tcc_note"] = "TCC_HIT / TCC_MISS pass failed: %s" % tcc_err
     return res
 
 
+def apply_counters(out, pmc, avg_us, extras):
+    """Writes the counter figures into the line's roofline objects."""
+    roofline = out["roofline"]
+    roofline["traffic_source"] = pmc["source"]
+    if pmc.get("calibration") is not None:
+        roofline["fetch_size_calibration"] = pmc["calibration"]
+    tr = pmc.get("dense_pull_batch") if roofline["kernel"] == "dense_pull_batch" else None
+    if tr:
+        ach = tr / 1e9 / (avg_us / 1e6)
+        roofline.update(traffic=tr, achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
+                        frac_basis="memory-side counters (FETCH_SIZE x calibration + WRITE_SIZE) per launch over the "
+                                   "launch's duration; FETCH_SIZE includes Infinity-Cache hits: L2-miss traffic",
+                        achieved_counter=round(ach, 1), frac_counter=round(ach / HBM_PEAK_GBS, 4),
+                        traffic_over_compulsory=round(tr / max(1, roofline["algorithmic_bytes_per_launch"]), 2),
+                        tcc_hit_rate=pmc.get("dense_pull_batch_tcc_hit"),
+                        tcc_hit_rate_edge_kernel=pmc.get("dense_pull_batch_edges_tcc_hit"))
+    wk = roofline["other_kernels"].get("walk")
+    if pmc.get("walk") and wk and wk.get("launches"):
+        # the walk kernel's gathers use 4-8 bytes of every 128-byte line they move: bound by lines, not by
+        # algorithmic bytes (writes are a twentieth of its traffic and counted with the lines here)
+        wk["traffic_per_launch"] = pmc["walk"]
+        avg_s = wk["ms"] / 1e3 / wk["launches"]
+        wk["achieved_counter"] = round(pmc["walk"] / 1e9 / avg_s, 1)
+        wk["frac_counter"] = round(wk["achieved_counter"] / HBM_PEAK_GBS, 4)
+        wk["requests_beyond_l2_G_per_s"] = round(pmc["walk"] / 128.0 / avg_s / 1e9, 1)
+        wk["random_request_roof_G_per_s"] = RANDOM_REQUEST_ROOF_G
+        wk["frac_of_request_roof"] = round(wk["requests_beyond_l2_G_per_s"] / RANDOM_REQUEST_ROOF_G, 3)
+    if not extras:
+        return
+    r1 = out["one_query_at_a_time"]["roofline"]
+    if pmc.get("dense_pull"):
+        ach = pmc["dense_pull"] / 1e9 / (r1["avg_launch_us"] / 1e6)
+        r1.update(traffic=pmc["dense_pull"], achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
+                  frac_basis="memory-side counters per level over the level's duration (FETCH_SIZE includes "
+                             "Infinity-Cache hits)", frac_counter=round(ach / HBM_PEAK_GBS, 4),
+                  traffic_over_compulsory=round(pmc["dense_pull"] / max(1, r1["algorithmic_bytes_per_launch"]), 2),
+                  tcc_hit_rate=pmc.get("dense_pull_tcc_hit"), traffic_per_query=pmc.get("single_query_bytes"))
+    rt = out["topk_sample"]["roofline"]
+    if pmc.get("topk_batch_bytes_per_query"):
+        qps = out["topk_sample"]["value"]
+        ach = pmc["topk_batch_bytes_per_query"] * qps / 1e9
+        rt.update(traffic=pmc["topk_batch_bytes_per_query"], traffic_unit="bytes per query, 16 in flight (whole call)",
+                  achieved_counter=round(ach, 1), frac_counter=round(ach / HBM_PEAK_GBS, 4),
+                  traffic_over_algorithmic=round(pmc["topk_batch_bytes_per_query"] / max(1, rt["algorithmic_bytes_per_query"]), 2),
+                  traffic_per_query_one_at_a_time=pmc.get("topk_single_bytes_per_query"),
+                  tcc_hit_rate=pmc.get("topk_batch_tcc_hit"))
+    ra = out["all_pair_sample"]["roofline"]
+    if pmc.get("all_pair_kernel_bytes_2p16"):
+        scale = out["all_pair_sample"]["targets"] / float(1 << 16)
+        tr = pmc["all_pair_kernel_bytes_2p16"] * scale
+        ach = tr / 1e9 / (ra["kernel_ms"] / 1e3) if ra["kernel_ms"] > 0 else 0.0
+        ra.update(traffic=int(tr), traffic_note="counted on the first 2^16 targets of the same range in the counter "
+                                                "passes, scaled to this sample's targets",
+                  achieved_counter=round(ach, 1), frac_counter=round(ach / HBM_PEAK_GBS, 4),
+                  traffic_over_algorithmic=round(tr / max(1, ra["algorithmic_bytes"]), 2),
+                  dense_tier_share_of_traffic=round(pmc.get("all_pair_dense_bytes_2p16", 0) / max(1, pmc["all_pair_kernel_bytes_2p16"]), 3),
+                  tcc_hit_rate=pmc.get("all_pair_tcc_hit"))
+
+
 # ---------------------------------------------------------------------------------------------- CPU baselines
-def cpu_baseline(host, srcs, walk_divisor):
+def start_cpu_baseline(args, live):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--scale", str(args.scale),
+           "--cpu-walk-divisor", str(args.cpu_walk_divisor), "--cpu-sources", ",".join(str(int(s)) for s in live[:300])]
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def finish_cpu_baseline(child):
+    return _child_json(child, float(os.environ.get("PPRHIP_BENCH_CPU_S", "900")), "the CPU baseline child")
+
+
+def cpu_baseline_child(args):
     """The reference's CPU path on this box's host cores; the Java itself cannot run here.
-    `value` is the faithful figure: the hash-map-shaped port, one thread, scaled from a bounded sample."""
-    from oracle import baseline as base
-    from oracle import oracle as orc
-    og = orc.OracleGraph(host.n, host.out_rp, host.out_ci, host.in_rp, host.in_ci)
-    live = [int(s) for s in srcs.ravel()]
-    cores = base.hardware_threads()
+    Three measurements, one after another so that they do not disturb each other:
+      1. the faithful port (hash maps, FIFO deque, hash set, the clock-driven loop with its 400 ns constant:
+         oracle/ppr_baseline.cpp) on ONE thread, ONE query run to the end, every walk walked
+         (Fora_Whole_Graph.java:93-140) - `value`; beside it, on three more threads, the dense-array port on three
+         other sources, in full as well;
+      2. the array port on every hardware thread at once, one query per thread (walks thinned by
+         --cpu-walk-divisor, times scaled back)."""
     try:
-        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
-        model = "unknown"
-    t_start = time.time()
-    conf = og.conf_whole(ALPHA)
-    _, omega = orc.fora_whole_params(conf, EPS)
-    # (1) dense-array port, one core, one query in full (clock-driven loop), every walk_divisor-th walk
-    a = base.fora_array_rounds(og, live[0], EPS, ALPHA, seed=3, walk_divisor=walk_divisor)
-    a_push = sum(a["round_push_s"])
-    a_walk_rate = a["walks_run"] / a["walk_s"] if a["walk_s"] > 0 else 0.0
-    a_query = a_push + (a["walks_total"] / a_walk_rate if a_walk_rate else 0.0)
-    # (2) hash-map-shaped faithful port, one core: bounded sample of the same source -> rates
-    h = base.fora_hashmap(og, live[0], EPS, ALPHA, seed=3, walk_divisor=walk_divisor, push_budget_s=10.0)
-    h_rate = h["edge_pushes"] / h["push_s"] if h["push_s"] > 0 else 0.0
-    h_walk_rate = h["walks_run"] / h["walk_s"] if h["walk_s"] > 0 and h["walks_run"] else a_walk_rate
-    # its clock-driven loop takes the turns whose push work the array port recorded, until push time exceeds
-    # 400 ns x rsum x omega (Fora_Whole_Graph.java:93): slower pushes end the loop earlier, with more walks
-    t_push, turns, rsum = 0.0, 0, conf.rsum
-    for e, rs in zip(a["round_edge_pushes"], a["round_rsum"]):
-        if not (t_push * 1e9 < 400.0 * rsum * omega):
-            break
-        t_push += e / h_rate if h_rate else 0.0
-        rsum = rs
-        turns += 1
-    h_walks = omega * rsum
-    h_query = t_push + (h_walks / h_walk_rate if h_walk_rate else 0.0)
-    # (3) dense-array port over all cores, one query per thread
-    par_srcs = live[1:1 + min(cores, 16)] or live[:1]
-    p = base.fora_array_parallel(og, par_srcs, EPS, ALPHA, seed=3, walk_divisor=walk_divisor, threads=cores)
-    # the run thinned the walks; per_query_s holds every query's time scaled to all of its walks, measured while the
-    # other threads were running theirs: concurrent throughput = sum of the per-thread rates
-    all_cores_qps = sum(1.0 / t for t in p["per_query_s"] if t > 0)
-    wall = time.time() - t_start
-    return {
-        "value": round(1.0 / h_query, 6) if h_query > 0 else None, "unit": "queries/s", "cores": 1, "kind": "port",
-        "sample": "faithful (hash-map-shaped) port of Forward_Push/Fora_Whole_Graph/Monte_Carlo on source %d: %.1f s "
-                  "push sample (%d edge pushes, %.2f M/s; cut by the 10 s budget: %s) and %d walks (%.2f M/s); scaled "
-                  "to one query with the per-turn push work of the array port's full run: %d turn(s) of the "
-                  "clock-driven loop (%.1f s) + %.0f walks (%.1f s) = %.1f s per query; %.0f s of CPU work in all"
-                  % (live[0], h["push_s"], h["edge_pushes"], h_rate / 1e6, h["truncated"], h["walks_run"],
-                     h_walk_rate / 1e6, turns, t_push, h_walks, h_walks / h_walk_rate if h_walk_rate else 0.0,
-                     h_query, wall),
-        "seconds_per_query": round(h_query, 2),
-        "faithful": {"edge_pushes_per_s": round(h_rate), "walks_per_s": round(h_walk_rate), "turns": turns,
-                     "seconds_per_query": round(h_query, 2), "structures": "unordered_map<int64,double> x2, deque, "
-                                                                           "unordered_set (HashMap/ConcurrentLinkedQueue/HashSet)"},
-        "array": {"value": round(1.0 / a_query, 5) if a_query > 0 else None, "cores": 1,
-                  "seconds_per_query": round(a_query, 2), "turns": a["rounds"], "push_s": round(a_push, 2),
-                  "edge_pushes": int(sum(a["round_edge_pushes"])), "walks": int(a["walks_total"]),
-                  "walks_per_s": round(a_walk_rate),
-                  "sample": "source %d, clock-driven loop in full, every %d-th walk" % (live[0], walk_divisor)},
-        "all_cores": {"value": round(all_cores_qps, 5), "cores": int(min(cores, len(par_srcs))),
-                      "queries": len(par_srcs), "wall_s_thinned_walks": round(p["wall_s"], 2),
-                      "seconds_per_query_each": [round(x, 1) for x in p["per_query_s"]],
-                      "sample": "dense-array port, one query per thread on %d live sources at once; per-query times "
-                                "scaled to all walks" % len(par_srcs)},
-        "host": {"nproc": cores, "model": model},
-    }
+        from oracle import baseline as base
+        from oracle import oracle as orc
+        import threading
+        pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
+        host = load_host(pkg, args.scale)
+        og = orc.OracleGraph(host.n, host.out_rp, host.out_ci, host.in_rp, host.in_ci)
+        live = [int(s) for s in args.cpu_sources.split(",") if s]
+        cores = base.hardware_threads()
+        try:
+            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:  # noqa: BLE001
+            model = "unknown"
+        t_start = time.time()
+        conf = og.conf_whole(ALPHA)
+        _, omega = orc.fora_whole_params(conf, EPS)
+        # ---- 1. one faithful query to the end (one thread) + the array port on three sources (three threads)
+        box = {}
+
+        def run_arrays():
+            box["arr"] = base.fora_array_parallel(og, live[1:4], EPS, ALPHA, seed=3, walk_divisor=1, threads=3)
+
+        th = threading.Thread(target=run_arrays)
+        th.start()
+        t0 = time.time()
+        h = base.fora_hashmap(og, live[0], EPS, ALPHA, seed=3, walk_divisor=1, push_budget_s=0.0)
+        h_wall = time.time() - t0
+        th.join()
+        arr = box["arr"]
+        h_query = h["push_s"] + h["walk_s"]
+        # ---- 2. every hardware thread, one query each
+        par_srcs = (live[4:4 + cores] or live[:1])
+        p = base.fora_array_parallel(og, par_srcs, EPS, ALPHA, seed=3, walk_divisor=args.cpu_walk_divisor, threads=cores)
+        # the run thinned the walks; per_query_s holds every query's time scaled to all of its walks, measured while the
+        # other threads were running theirs: concurrent throughput = sum of the per-thread rates
+        all_cores_qps = sum(1.0 / t for t in p["per_query_s"] if t > 0)
+        pq = sorted(p["per_query_s"])
+        wall = time.time() - t_start
+        res = {
+            "value": round(1.0 / h_query, 6) if h_query > 0 else None, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": "faithful (hash-map-shaped) port of Forward_Push/Fora_Whole_Graph/Monte_Carlo, ONE query on source %d "
+                      "run to the end on one thread: %d turn(s) of the clock-driven loop, %.1f s of pushes (%d edge "
+                      "pushes, %.2f M/s), %d walks in %.1f s (%.2f M/s) = %.1f s; beside it the dense-array port on 3 "
+                      "sources in full (3 threads), then the array port on all %d hardware threads; %.0f s of wall time "
+                      "in a background process while the GPU measurements ran"
+                      % (live[0], h["rounds"], h["push_s"], h["edge_pushes"],
+                         h["edge_pushes"] / h["push_s"] / 1e6 if h["push_s"] > 0 else 0.0, h["walks_run"], h["walk_s"],
+                         h["walks_run"] / h["walk_s"] / 1e6 if h["walk_s"] > 0 else 0.0, h_query, cores, wall),
+            "seconds_per_query": round(h_query, 2),
+            "faithful": {"turns": h["rounds"], "push_s": round(h["push_s"], 2), "walk_s": round(h["walk_s"], 2),
+                         "edge_pushes": int(h["edge_pushes"]), "walks": int(h["walks_run"]),
+                         "walks_asked_for": int(h["walks_total"]), "truncated": bool(h["truncated"]),
+                         "wall_s": round(h_wall, 2), "omega": omega,
+                         "structures": "unordered_map<int64,double> x2, deque, unordered_set "
+                                       "(HashMap/ConcurrentLinkedQueue/HashSet)"},
+            "array": {"value": round(len(arr["per_query_s"]) / sum(arr["per_query_s"]), 5) if sum(arr["per_query_s"]) > 0 else None,
+                      "cores": 1, "seconds_per_query_each": [round(x, 2) for x in arr["per_query_s"]],
+                      "sources": [int(s) for s in live[1:4]],
+                      "sample": "dense-array port, three sources in full (every walk), one thread each, while the "
+                                "faithful query ran on a fourth"},
+            "all_cores": {"value": round(all_cores_qps, 5), "cores": int(min(cores, len(par_srcs))),
+                          "queries": len(par_srcs), "wall_s_thinned_walks": round(p["wall_s"], 2),
+                          "seconds_per_query_min_median_max": [round(pq[0], 1), round(pq[len(pq) // 2], 1), round(pq[-1], 1)],
+                          "sample": "dense-array port, one query per hardware thread on %d live sources at once; every "
+                                    "%d-th walk run, per-query times scaled to all walks" % (len(par_srcs), args.cpu_walk_divisor)},
+            "host": {"nproc": cores, "model": model},
+        }
+    except Exception as e:  # noqa: BLE001
+        res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

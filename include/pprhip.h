@@ -85,7 +85,11 @@ typedef struct pprhip_stats {
   uint32_t class_launches[8];
   uint64_t dense_edges;    /* out-edges of the nodes pushed inside dense pull sweeps: the edges a sweep had to serve,
                             * against dense_levels * m edges swept (useful-edge fraction of the sweeps) */
-  uint64_t reserved1[3];
+  uint64_t sweep_min_bytes; /* compulsory bytes of the dense sweeps: every byte a sweep has to read or write counted ONCE
+                            * (index stream, each gathered contribution line once, row sums out and in, next
+                            * contributions, the busy queries' residues) - a lower bound of the sweeps' memory traffic,
+                            * whereas push_bytes' SURVEY 8(d) model counts one gather per edge and query */
+  uint64_t reserved1[2];
 } pprhip_stats_t;
 
 #define PPRHIP_KERNEL_NONE 0

@@ -1,11 +1,16 @@
 // allpair.cpp — All-Pair-Backward-Search (Base_Whole_Graph.preprocessing) and the inverted index.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
+
+#include <unistd.h>
 
 #include "engine_internal.hpp"
 
@@ -222,7 +227,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       if (q) (void)hipFree(q);
   };
   B.out_cap = std::min<unsigned long long>(1ull << 24, std::max<unsigned long long>(1ull << 16, 64ull * g->n));
-  if ((rc = alloc_dev((void**)&cells, sizeof(unsigned long long) * 8)) ||
+  if ((rc = alloc_dev((void**)&cells, sizeof(unsigned long long) * 16)) ||
       (rc = alloc_dev((void**)&B.out_v, sizeof(int32_t) * B.out_cap)) ||
       (rc = alloc_dev((void**)&B.out_t, sizeof(int32_t) * B.out_cap)) ||
       (rc = alloc_dev((void**)&B.out_p, sizeof(double) * B.out_cap)) ||
@@ -237,7 +242,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   B.stat_pops = cells + 4;
   B.stat_edges = cells + 5;
   std::vector<int32_t> h_ovf;
-  unsigned long long h_cells[8];
+  unsigned long long h_cells[16];
 
   // runs one tier over `list` (or the range when list is empty and use_range) until every target
   // has either produced its triples or landed in `give_up`
@@ -257,13 +262,19 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
         if (!d_list) PPRHIP_TRY(alloc_dev((void**)&d_list, sizeof(int32_t) * list.size()));
         PPRHIP_CHECK_HIP(hipMemcpyAsync(d_list, list.data(), sizeof(int32_t) * cnt, hipMemcpyHostToDevice, g->stream));
       }
-      const unsigned long long init[8] = {0, 0, ~0ull, 0, 0, 0, 0, 0};
+      const unsigned long long init[16] = {0, 0, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       PPRHIP_CHECK_HIP(hipMemcpyAsync(cells, init, sizeof init, hipMemcpyHostToDevice, g->stream));
+      if (dense_tier)  // every board entry closed, nothing posted
+        PPRHIP_CHECK_HIP(hipMemsetAsync(B.board, 0, apbs_board_bytes(B.ws_blocks), g->stream));
       ktimer().begin(PPRHIP_KERNEL_BACKWARD_BATCH, 0);
       PPRHIP_TRY(launch_apbs(g, dense_tier, use_range ? nullptr : d_list, t_begin, cnt, alpha, threshold, B));
       ktimer().end();
       PPRHIP_CHECK_HIP(hipMemcpyAsync(h_cells, cells, sizeof h_cells, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      if (h_cells[10]) {
+        set_error("All-Pair dense tier: a workgroup waited more than 30 s for the chunks of a posted level (launch aborted)");
+        return PPRHIP_ERR_STATE;
+      }
       const unsigned long long valid = std::min(std::min(h_cells[1], h_cells[2]), B.out_cap);
       st.pops += h_cells[4];
       st.edge_pushes += h_cells[5];
@@ -316,14 +327,17 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     // whole vector is cleared instead) and a level's frontier.  The workspaces stay with the handle: allocating and
     // zeroing gigabytes per call would cost more than the searches of a small target range.
     if (g->apbs_blocks == 0) {
-      // (PPRHIP_APBS_CAP_T / _CAP_F shrink the lists so that tests reach the overflow paths on small graphs)
+      // (PPRHIP_APBS_CAP_T / _CAP_F shrink the lists so that tests reach the overflow paths on small graphs,
+      // PPRHIP_APBS_CHUNK the chunks of a level's edge space so that small graphs' levels are shared too)
       const char* e_t = getenv("PPRHIP_APBS_CAP_T");
       const char* e_f = getenv("PPRHIP_APBS_CAP_F");
+      const char* e_c = getenv("PPRHIP_APBS_CHUNK");
+      const uint32_t chunk = e_c ? (uint32_t)std::max(16, atoi(e_c)) : apbs_default_chunk();
       const uint32_t cap_t = e_t ? (uint32_t)std::max(1, atoi(e_t)) : std::min<uint32_t>(g->n, 1u << 20) + 4096u;
-      const uint32_t cap_f = e_f ? (uint32_t)std::max(1, atoi(e_f)) : std::min<uint32_t>(g->n, 1u << 18) + 64u;
+      const uint32_t cap_f = e_f ? (uint32_t)std::max(1, atoi(e_f)) : std::min<uint32_t>(g->n, 1u << 20) + 64u;
       const char* per_cu = getenv("PPRHIP_APBS_WGS_PER_CU");
       uint32_t want = (uint32_t)g->n_cus * (uint32_t)std::max(1, std::min(2, per_cu ? atoi(per_cu) : 1));
-      const size_t per = apbs_dense_bytes(g->n, cap_t, cap_f);
+      const size_t per = apbs_dense_bytes(g->n, g->m, cap_t, cap_f, chunk);
       int arc = PPRHIP_ERR_OOM;
       // a device that cannot spare them all runs the tier with fewer workgroups in flight
       for (; want >= 8; want /= 2) {
@@ -337,10 +351,15 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
         set_error("All-Pair: clearing the dense workspaces failed");
         arc = PPRHIP_ERR_HIP;
       }
+      if (arc == PPRHIP_OK && (arc = alloc_dev(&g->apbs_board, apbs_board_bytes(want))) != PPRHIP_OK) {
+        (void)hipFree(g->apbs_ws);
+        g->apbs_ws = nullptr;
+      }
       if (arc == PPRHIP_OK) {
         g->apbs_blocks = want;
         g->apbs_cap_t = cap_t;
         g->apbs_cap_f = cap_f;
+        g->apbs_chunk = chunk;
       } else if (arc != PPRHIP_ERR_OOM) {
         rc = arc;
       }
@@ -350,6 +369,9 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       B.ws_blocks = g->apbs_blocks;
       B.cap_t = g->apbs_cap_t;
       B.cap_f = g->apbs_cap_f;
+      B.chunk = g->apbs_chunk;
+      B.board = g->apbs_board;
+      B.done_targets = cells + 8;  // + 8: targets done, + 9: levels posted, + 10: abort word
       // targets with the most in-edges first: the searches that push the most edges start the level-1 fan-out from
       // hubs, and a workgroup that draws such a search last would finish long after the others
       {
@@ -360,27 +382,60 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
           return irp[a + 1] - irp[a] > irp[b + 1] - irp[b];
         });
       }
+      // Developer switch PPRHIP_APBS_DEBUG: per-workgroup timers and a progress word in HOST memory, and a watchdog
+      // thread that prints the progress words and ends the process when the tier has not come back after 20 s
+      // (a kernel that never ends would otherwise only be seen as a process that cannot be killed).
       const bool debug = getenv("PPRHIP_APBS_DEBUG") != nullptr;
-      if (debug && alloc_dev((void**)&B.dbg, sizeof(unsigned long long) * 8 * g->apbs_blocks) == PPRHIP_OK)
-        (void)hipMemsetAsync(B.dbg, 0, sizeof(unsigned long long) * 8 * g->apbs_blocks, g->stream);
+      std::mutex wd_mu;
+      std::condition_variable wd_cv;
+      bool wd_done = false;
+      std::thread watchdog;
+      if (debug && hipHostMalloc((void**)&B.dbg, sizeof(unsigned long long) * 12 * g->apbs_blocks, hipHostMallocMapped) ==
+                       hipSuccess) {
+        std::memset(B.dbg, 0, sizeof(unsigned long long) * 12 * g->apbs_blocks);
+        const unsigned long long* rows = B.dbg;
+        const uint32_t nb = g->apbs_blocks;
+        watchdog = std::thread([&wd_mu, &wd_cv, &wd_done, rows, nb] {
+          std::unique_lock<std::mutex> lk(wd_mu);
+          if (wd_cv.wait_for(lk, std::chrono::seconds(20), [&] { return wd_done; })) return;
+          fprintf(stderr, "[apbs dense] no end after 20 s; workgroup: stage/detail (1 target, 2 pops, 3 own chunk, 4 waiting "
+                          "for helpers, 5 local chunks, 6 emit, 7 clear, 8 idle, 9 helping owner<<16|chunk, 10 out)\n");
+          for (uint32_t w = 0; w < nb; ++w)
+            if (rows[12 * w + 9])
+              fprintf(stderr, "%u: %llu/%llu%s", w, rows[12 * w + 9] >> 32, rows[12 * w + 9] & 0xffffffffull,
+                      (w % 8 == 7) ? "\n" : "   ");
+          fprintf(stderr, "\n");
+          fflush(stderr);
+          _exit(3);
+        });
+      }
       rc = run_tier(true, to_tier2, false, to_tier3);
+      if (watchdog.joinable()) {
+        {
+          std::lock_guard<std::mutex> lk(wd_mu);
+          wd_done = true;
+        }
+        wd_cv.notify_all();
+        watchdog.join();
+      }
       if (B.dbg) {
-        std::vector<unsigned long long> h((size_t)8 * g->apbs_blocks);
-        if (hipMemcpy(h.data(), B.dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+        std::vector<unsigned long long> h(B.dbg, B.dbg + (size_t)12 * g->apbs_blocks);
+        {
           unsigned long long tot[8] = {0}, t_end_max = 0, t_end_min = ~0ull, e_max = 0;
           for (uint32_t w = 0; w < g->apbs_blocks; ++w) {
-            if (!h[8 * w]) continue;
-            for (int i = 0; i < 7; ++i) tot[i] += h[8 * w + i];
-            t_end_max = std::max(t_end_max, h[8 * w + 7]);
-            t_end_min = std::min(t_end_min, h[8 * w + 7]);
-            e_max = std::max(e_max, h[8 * w + 1]);
+            if (!h[12 * w + 8]) continue;
+            for (int i = 0; i < 8; ++i) tot[i] += h[12 * w + i];
+            t_end_max = std::max(t_end_max, h[12 * w + 8]);
+            t_end_min = std::min(t_end_min, h[12 * w + 8]);
+            e_max = std::max(e_max, h[12 * w + 1]);
           }
-          fprintf(stderr, "[apbs dense] searches %llu edges %llu (max per workgroup %llu); workgroup-ms in pops %.1f scans %.1f "
-                          "edges %.1f emit %.1f clear %.1f; first workgroup ended %.2f ms before the last\n",
-                  tot[0], tot[1], e_max, tot[2] / 1e5, tot[3] / 1e5, tot[4] / 1e5, tot[5] / 1e5, tot[6] / 1e5,
+          fprintf(stderr, "[apbs dense] searches %llu edges %llu (max owned by one workgroup %llu); workgroup-ms in pops+scans %.1f "
+                          "own chunks %.1f waiting for helpers %.1f emit %.1f clear %.1f helping / idle %.1f; first workgroup "
+                          "ended %.2f ms before the last\n",
+                  tot[0], tot[1], e_max, tot[2] / 1e5, tot[3] / 1e5, tot[4] / 1e5, tot[5] / 1e5, tot[6] / 1e5, tot[7] / 1e5,
                   (t_end_max - t_end_min) / 1e5);
         }
-        (void)hipFree(B.dbg);
+        (void)hipHostFree(B.dbg);
         B.dbg = nullptr;
       }
     } else if (rc == PPRHIP_OK) {

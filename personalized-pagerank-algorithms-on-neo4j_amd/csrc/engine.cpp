@@ -84,6 +84,23 @@ double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense) 
 // nothing and are not touched by the single-query sweep (the power method counts the same rows)
 uint64_t dense_level_bytes(const pprhip_graph* g) { return 12ull * g->m + 36ull * host_of(g)->n_nz + 4ull; }
 
+// Compulsory bytes of one sweep: what it has to move when every byte is counted once (pprhip_stats_t.sweep_min_bytes).
+// Single query: column indices + row-start bits, every gatherable contribution once (8 B per node with out-edges),
+// per row with in-edges the row sum out and in (16 B), the next contribution (8 B) and the residue read and written
+// (16 B).  The reserve is touched by crossing rows only and is left out: a lower bound.
+uint64_t dense_level_min_bytes(const pprhip_graph* g) {
+  const pprhip_graph* H = host_of(g);
+  return 4ull * H->m + H->m / 8 + 8ull * H->n_src_live + 40ull * H->n_nz;
+}
+// Batched: the index stream once, every gatherable line c8[v][0..15] once (128 B), per carried row the 128-byte row-sum
+// line out and in and the next-contribution line out, and per busy query the residue of every row with in-edges.
+uint64_t batch_sweep_min_bytes(const pprhip_graph* P, bool backward, int n_active) {
+  const uint64_t rows_nz = backward ? P->n_nz_o : P->n_nz, rows_all = rows_nz + (backward ? P->n_z_o : P->n_zin);
+  const uint64_t gather = backward ? (uint64_t)P->n_nz : (uint64_t)P->n_src_live;
+  return 4ull * P->m + P->m / 8 + 128ull * gather + 256ull * rows_nz + 128ull * rows_all +
+         16ull * rows_nz * (uint64_t)n_active;
+}
+
 // modelled cost of a dense sweep (level_cost's dense branch): also what a sweep costs that only runs because the
 // contribution array has to be flushed
 double dense_sweep_cost(const pprhip_graph* g) {
@@ -280,7 +297,9 @@ int ensure_bwd_layout(pprhip_graph* P);
 
 
 // bookkeeping after a dense level: the frontier it produced becomes the current one
-void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_t nf_next, uint64_t ef_next) {
+void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint64_t min_bytes, uint32_t nf_next,
+                  uint64_t ef_next) {
+  st.sweep_min_bytes += min_bytes;
   // after an entry / in-place sweep the new contributions have reached the later blocks only (nothing is pending
   // when the sweep prepared no node)
   L.gs_dirty = (L.gs_state == kGsEntry || L.gs_state == kGsInPlace) && nf_next > 0;
@@ -398,7 +417,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
           L.gs_state = state;
         }
         const unsigned long long nx = g->h_ctr->dhist[j + 1];
-        finish_dense(L, st, dense_level_bytes(g), (uint32_t)(nx >> kPackShift), nx & kPackMask);
+        finish_dense(L, st, dense_level_bytes(g), dense_level_min_bytes(g), (uint32_t)(nx >> kPackShift), nx & kPackMask);
       }
       continue;
     }
@@ -1215,6 +1234,7 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
     for (uint32_t v = 0; v < n; ++v)
       if (irp[v + 1] == irp[v] && G->h_out_rp[v + 1] > G->h_out_rp[v]) zin.push_back((int32_t)v);
     G->n_zin = (uint32_t)zin.size();
+    for (uint32_t v = 0; v < n; ++v) G->n_src_live += G->h_out_rp[v + 1] > G->h_out_rp[v] ? 1u : 0u;
     if ((rc = up((void**)&G->zin_rows, zin.data(), sizeof(int32_t) * zin.size()))) return fail(rc);
     std::vector<unsigned long long> cross(((size_t)n + 63) / 64 + 1, 0ull);
     for (size_t j = 0; j < nz_rows.size(); ++j) {
@@ -1249,6 +1269,8 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
     if (p) (void)hipFree(p);
   if (g->apbs_ws) (void)hipFree(g->apbs_ws);
   g->apbs_ws = nullptr;
+  if (g->apbs_board) (void)hipFree(g->apbs_board);
+  g->apbs_board = nullptr;
   if (g->in_rec) (void)hipFree(g->in_rec);
   g->in_rec = nullptr;
   if (g->sl) {
@@ -1699,6 +1721,7 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
       st.dense_levels++;
       st.levels++;
       st.push_bytes += dense_level_bytes(g);
+      st.sweep_min_bytes += dense_level_min_bytes(g);
     }
   }
   tm.mark(1);

@@ -244,7 +244,8 @@ struct pprhip_graph {
   // workspaces of apbs_blocks workgroups (16n bytes + lists each, all-zero between searches), kept between calls
   void* in_rec = nullptr;
   char* apbs_ws = nullptr;
-  uint32_t apbs_blocks = 0, apbs_cap_t = 0, apbs_cap_f = 0;
+  void* apbs_board = nullptr;
+  uint32_t apbs_blocks = 0, apbs_cap_t = 0, apbs_cap_f = 0, apbs_chunk = 0;
   pprhip::detail::FetchPipe* fetch = nullptr;  // delivery of batched queries' vectors to host memory (engine_internal.hpp)
   double* c8[2] = {nullptr, nullptr};
   int c8cur = 0;
@@ -261,6 +262,7 @@ struct pprhip_graph {
   unsigned long long* cross_bits = nullptr;  // per row ordinal (non-empty rows first): row spans two 512-edge chunks
   unsigned long long* prep_bits = nullptr;   // [kBatch][tiles]: rows holding a contribution after the last sweep
   uint32_t n_zin = 0;
+  uint32_t n_src_live = 0;  // nodes with out-edges: the contributions a forward sweep can gather
   pprhip::SlotArgs* d_slot_args = nullptr;
   pprhip::SlotArgs* h_slot_args = nullptr;  // pinned
   unsigned long long* sweep_out = nullptr;    // [kBatch] frontier counters a sweep produced
@@ -368,8 +370,10 @@ struct ApbsBuffers {
   double* out_p = nullptr;
   unsigned long long out_cap = 0;
   char* ws = nullptr;  // tier 2: per-workgroup dense workspaces (owned by the graph handle, see apbs_ws)
-  uint32_t ws_blocks = 0, cap_t = 0, cap_f = 0;
-  unsigned long long* dbg = nullptr;  // developer switch PPRHIP_APBS_DEBUG: 8 words per workgroup (kernels_apbs.hip)
+  void* board = nullptr;  // tier 2: one entry per workgroup on which it posts a level for helpers (zero at launch)
+  unsigned long long* done_targets = nullptr;  // tier 2: targets finished in this launch
+  uint32_t ws_blocks = 0, cap_t = 0, cap_f = 0, chunk = 0;
+  unsigned long long* dbg = nullptr;  // developer switch PPRHIP_APBS_DEBUG: 10 words per workgroup (kernels_apbs.hip)
 };
 struct TripleRec {  // one index entry of All-Pair-Backward-Search on the device: pi(v, t) = p
   int32_t v, t;
@@ -379,7 +383,9 @@ int launch_pack_triples(pprhip_graph* g, const int32_t* v, const int32_t* t, con
                         TripleRec* dst);
 int launch_owner_partition(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int world,
                            unsigned long long* cursors, TripleRec* out);
-size_t apbs_dense_bytes(uint32_t n, uint32_t cap_t, uint32_t cap_f);  // one workgroup's tier-2 workspace
+size_t apbs_dense_bytes(uint32_t n, unsigned long long m, uint32_t cap_t, uint32_t cap_f, uint32_t chunk);  // one workgroup's tier-2 workspace
+uint32_t apbs_default_chunk();
+size_t apbs_board_bytes(uint32_t blocks);
 int launch_build_in_rec(pprhip_graph* g, void* rec);                  // rec: m records of 8 bytes
 int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint32_t t_begin, uint32_t n_targets,
                 double alpha, double rmax, ApbsBuffers& b);

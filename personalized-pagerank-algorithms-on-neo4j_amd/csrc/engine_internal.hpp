@@ -99,7 +99,10 @@ int alloc_dev(void** p, size_t bytes);
 double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense);
 uint64_t dense_level_bytes(const pprhip_graph* g);
 double dense_sweep_cost(const pprhip_graph* g);
-void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint32_t nf_next, uint64_t ef_next);
+uint64_t dense_level_min_bytes(const pprhip_graph* g);  // compulsory bytes of one single-query sweep
+uint64_t batch_sweep_min_bytes(const pprhip_graph* P, bool backward, int n_active);  // ... of one batched sweep
+void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint64_t min_bytes, uint32_t nf_next,
+                  uint64_t ef_next);
 int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost,
                bool yield_dense = false, RoundCut* cut = nullptr);
 int reset_query_state(pprhip_graph* g, bool clear_flags);

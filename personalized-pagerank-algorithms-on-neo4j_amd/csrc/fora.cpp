@@ -358,6 +358,7 @@ void add_stats(pprhip_stats_t& sum, const pprhip_stats_t& st) {
   sum.dead_end_pops += st.dead_end_pops; sum.dense_nodes += st.dense_nodes; sum.dense_edges += st.dense_edges;
   sum.levels += st.levels;
   sum.dense_levels += st.dense_levels; sum.rounds += st.rounds; sum.mc_sources += st.mc_sources;
+  sum.sweep_min_bytes += st.sweep_min_bytes;
   sum.walks += st.walks; sum.walk_steps += st.walk_steps; sum.select_passes += st.select_passes;
   sum.push_ms += st.push_ms; sum.mc_ms += st.mc_ms; sum.select_ms += st.select_ms; sum.total_ms += st.total_ms;
   sum.push_bytes += st.push_bytes; sum.mc_bytes += st.mc_bytes; sum.select_bytes += st.select_bytes;
@@ -448,7 +449,8 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
       const unsigned long long pk = P->h_sweep_out[s];
       // the sweep's index stream is shared: each query is charged its own gathers and row work
       finish_dense(r.L, r.st, 8ull * P->m + 36ull * rows + 4ull + 4ull * P->m / (uint64_t)n_active,
-                   (uint32_t)(pk >> kPackShift), pk & kPackMask);
+                   batch_sweep_min_bytes(P, backward, n_active) / (uint64_t)n_active, (uint32_t)(pk >> kPackShift),
+                   pk & kPackMask);
     }
   return PPRHIP_OK;
 }

@@ -357,39 +357,248 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
 }
 
 // ------------------------------------------------------------------------------------------------
-// tier 2: one target's state in dense per-workgroup vectors
+// tier 2: one target's state in dense per-workgroup vectors, big levels shared between workgroups
 // ------------------------------------------------------------------------------------------------
-// Workspace of one workgroup (HBM, all-zero between searches): residue[n], reserve[n], and the lists a search keeps:
-// the nodes whose residue it has made non-zero (for the clean-up), the current / next frontier with the frontier's
-// pending contributions, and the nodes it has popped at least once (the only ones that can hold a reserve).
+// Workspace of one workgroup (HBM, vectors all-zero between searches): residue[n], reserve[n], and the lists a search
+// keeps: the nodes whose residue it has made non-zero (for the clean-up), the current / next frontier, per frontier
+// position the pending contribution, the first in-edge and the exclusive prefix of the in-degrees (the level's edge
+// space), per chunk of that edge space the frontier position it starts in, and the nodes popped at least once (the
+// only ones that can hold a reserve).
+//
+// Work sharing.  The edges are unevenly spread: a handful of searches push millions of edges (one of 2^18 targets of
+// an R-MAT 22 pushes 25 M) and one workgroup moves ~0.3 G edges/s however idle the rest of the chip is, so such a
+// search alone set the kernel's duration (50 of 82 ms with every other workgroup done).  A level's edge space is
+// therefore cut into chunks of kDnChunk edges; a level of at least kDnShareMin chunks is *posted* on the owner's
+// board entry, and workgroups that have run out of targets take chunks of posted levels (compare-and-swap on
+// {sequence, next chunk}) - the residue updates are agent-scope atomics on the owner's vector, the appends go through
+// counters on the owner's board entry, and everything a helper reads or writes in the owner's lists bypasses the
+// (per-XCD, mutually incoherent) L2s.  The owner takes chunks of its own level like everybody else and goes on when
+// all of them are done; a helper never waits for anything, so nobody can wait in a cycle.
 constexpr int kDnThreads = 1024;
 constexpr int kDnWaves = kDnThreads / 64;
-constexpr int kDnFront = 1024;  // frontier nodes per sub-batch: one per thread
-constexpr int kDnIlp = 4;       // edges a thread keeps in flight
+constexpr int kDnStage = 1024;      // frontier entries staged in LDS at a time
+constexpr int kDnIlp = 4;           // edges a thread keeps in flight
+constexpr uint32_t kDnChunkDefault = 32768;  // edges per chunk of a level's edge space (tests shrink it)
+constexpr uint32_t kDnShareMin = 4;          // levels of at least this many chunks are posted
+constexpr unsigned long long kDnWaitTicks = 3000000000ull;  // 30 s of the 100 MHz clock: no wait in the kernel is longer
+uint32_t apbs_default_chunk() { return kDnChunkDefault; }
+
+struct DnBoard {  // one per workgroup, 64 bytes
+  unsigned long long next;  // sequence << 32 | next chunk; the level is open to helpers while the sequence is odd
+  uint32_t n_chunks, nf, which, done;  // which: frontier list the level reads (0 / 1)
+  uint32_t tcount, nnext, giveup, pad0;
+  unsigned long long pad1[3];
+};
+static_assert(sizeof(DnBoard) == 64, "one board entry per 64-byte block");
 
 struct DenseWs {
   double* res;
   double* rsv;
-  double* pend;      // [cap_f] pending contribution of the current frontier, by frontier position
+  double* pend;      // [cap_f] pending contribution, by frontier position
+  uint32_t* frow;    // [cap_f] first in-edge of the frontier node
+  uint32_t* eoff;    // [cap_f + 1] exclusive prefix of the frontier's in-degrees
+  uint32_t* cstart;  // [cap_c] frontier position in which chunk c of the edge space starts
   int32_t* touched;  // [cap_t]
-  int32_t* cur;      // [cap_f]
-  int32_t* nxt;      // [cap_f]
+  int32_t* fr[2];    // [cap_f] frontier lists
   int32_t* plist;    // [cap_f] nodes popped for the first time, in pop order
 };
 
-__host__ __device__ inline size_t dense_ws_bytes(uint32_t n, uint32_t cap_t, uint32_t cap_f) {
-  return ((size_t)8 * (2 * (size_t)n + cap_f) + (size_t)4 * ((size_t)cap_t + 3 * (size_t)cap_f) + 255) & ~(size_t)255;
+// sizes of one workspace: n nodes, list capacities, cap_c = chunks a level can have (m / chunk + 2)
+struct DnDims {
+  uint32_t n, cap_t, cap_f, cap_c, chunk;
+};
+__host__ __device__ inline size_t dense_ws_bytes(const DnDims& D) {
+  return ((size_t)8 * (2 * (size_t)D.n + D.cap_f) +
+          (size_t)4 * ((size_t)D.cap_t + 5 * (size_t)D.cap_f + 1 + D.cap_c) + 255) & ~(size_t)255;
 }
-size_t apbs_dense_bytes(uint32_t n, uint32_t cap_t, uint32_t cap_f) { return dense_ws_bytes(n, cap_t, cap_f); }
+static DnDims dims_of(uint32_t n, unsigned long long m, uint32_t cap_t, uint32_t cap_f, uint32_t chunk) {
+  return DnDims{n, cap_t, cap_f, (uint32_t)(m / chunk) + 2u, chunk};
+}
+size_t apbs_dense_bytes(uint32_t n, unsigned long long m, uint32_t cap_t, uint32_t cap_f, uint32_t chunk) {
+  return dense_ws_bytes(dims_of(n, m, cap_t, cap_f, chunk));
+}
+size_t apbs_board_bytes(uint32_t blocks) { return sizeof(DnBoard) * (size_t)blocks + 64; }
 
-// The residue vector is only ever touched by fp64 atomics (which execute at the memory side and keep nothing in L2)
-// and by accesses that bypass the caches the same way; mixing in cached loads or stores could pair an atomic with a
-// stale line.
-__device__ __forceinline__ double dn_load(const double* p) {
+__device__ __forceinline__ DenseWs dense_ws_of(char* ws_base, uint32_t wg, const DnDims& D) {
+  DenseWs W;
+  char* base = ws_base + (size_t)wg * dense_ws_bytes(D);
+  W.res = (double*)base;
+  W.rsv = W.res + D.n;
+  W.pend = W.rsv + D.n;
+  W.frow = (uint32_t*)(W.pend + D.cap_f);
+  W.eoff = W.frow + D.cap_f;
+  W.cstart = W.eoff + D.cap_f + 1;
+  W.touched = (int32_t*)(W.cstart + D.cap_c);
+  W.fr[0] = W.touched + D.cap_t;
+  W.fr[1] = W.fr[0] + D.cap_f;
+  W.plist = W.fr[1] + D.cap_f;
+  return W;
+}
+
+// Every access to the vectors and lists bypasses L1 / L2 (agent-scope relaxed = sc1): the residue vector is updated by
+// fp64 atomics, which execute at the memory side and keep nothing in L2, and the lists of a posted level are read and
+// extended by workgroups on other XCDs, whose L2s are not coherent with the owner's.
+template <class T>
+__device__ __forceinline__ T dn_load(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void dn_store(double* p, double v) {
+template <class T>
+__device__ __forceinline__ void dn_store(T* p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// A word that is also the target of atomic read-modify-writes (the board's counters) is (re)set by an atomic exchange
+// whose result is waited for: a store followed by an atomic on the same address is not guaranteed to arrive at the
+// memory side in that order, and an atomic that overtakes the reset would act on the value from before it.
+template <class T>
+__device__ __forceinline__ void dn_reset(T* p, T v) {
+  (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the exchange (and every store before it) has been acknowledged before anything that follows is issued.  No cache
+  // maintenance is needed anywhere in this protocol: everything workgroups hand to each other is written and read
+  // with accesses that bypass L1 / L2 (sc1), so only the ORDER of those accesses matters.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Workgroup barrier that also waits for the global stores and atomics of every wave: __syncthreads() alone waits for
+// LDS only (s_waitcnt lgkmcnt(0); the compiler's memory model lets global accesses of one CU order themselves), which
+// is not enough where lane 0 goes on to tell ANOTHER workgroup that the lists the other waves have just written are
+// ready - every storing wave has to have its own stores acknowledged first (they are write-through: sc1).
+__device__ __forceinline__ void dn_barrier_global() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+struct DnLds {  // staging of one workgroup (owner or helper): up to kDnStage frontier entries
+  uint32_t eoff[kDnStage + 1];  // exclusive prefix of the in-degrees (absolute positions in the level's edge space)
+  uint32_t row[kDnStage];       // first in-edge
+  double c[kDnStage];           // pending contribution
+  uint32_t i0;  // frontier position a chunk starts in (read by one lane, so that every wave sees the same value)
+  uint32_t wtot[kDnWaves], wbase;  // shared levels: the waves' append counts of one pass, and the block reserved for them
+};
+
+// where a search's appends are counted: in LDS while the search stays on its own workgroup, on the owner's board entry
+// (global atomics) while a level is shared
+struct DnSinks {
+  uint32_t* tcount;  // nodes listed for the clean-up
+  uint32_t* nnext;   // next frontier
+  uint32_t* giveup;  // a list is full
+};
+
+// Edges [lo, hi) of a level's edge space, which the `cnt` entries staged in L cover: every edge is ONE returning atomic
+// on the residue vector; residues that leave zero and nodes that cross the threshold are appended to the search's
+// lists.  Called by all threads of a workgroup with workgroup-uniform arguments.
+// kWgAgg (shared levels, whose counters are global words that every helper of the owner adds to): the workgroup's
+// waves reserve their clean-up slots with ONE atomic per pass instead of one each.
+template <bool kWgAgg>
+__device__ __forceinline__ void dn_edge_range(const DenseWs& W, DnLds& L, uint32_t cnt, uint32_t lo, uint32_t hi,
+                                              int32_t* nxt, const DnSinks& S, const InRec* __restrict__ in_rec,
+                                              double rmax, uint32_t cap_t, uint32_t cap_f) {
+  const int tid = threadIdx.x, lane = lane_id();
+  // wave-uniform trip count (the appends below are wave-aggregated)
+  for (unsigned long long base0 = lo; base0 < hi; base0 += kDnThreads * kDnIlp) {
+    InRec rc4[kDnIlp];
+    double add[kDnIlp], old[kDnIlp];
+#pragma unroll
+    for (int q = 0; q < kDnIlp; ++q) {
+      const unsigned long long e64 = base0 + (unsigned long long)(kDnThreads * q + tid);
+      const uint32_t e = (uint32_t)e64;
+      rc4[q] = InRec{-1, 1u};
+      add[q] = 0.0;
+      if (e64 < hi) {
+        uint32_t a = 0, z = cnt;  // last staged entry whose edge range starts at or before e
+        while (a < z) {
+          const uint32_t mid = (a + z) >> 1;
+          if (L.eoff[mid] <= e) a = mid + 1; else z = mid;
+        }
+        const uint32_t i = a - 1;
+        rc4[q] = load_rec(in_rec, (size_t)L.row[i] + (e - L.eoff[i]));
+        add[q] = L.c[i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kDnIlp; ++q) {
+      add[q] = add[q] / (double)rc4[q].dout;  // :84-85, every edge's quotient rounds on its own
+      old[q] = 0.0;
+      if (rc4[q].u >= 0) old[q] = atomic_add_ret(&W.res[rc4[q].u], add[q]);
+    }
+    // a residue that leaves zero: the node is remembered for the clean-up (a node popped in between is listed twice,
+    // which only clears it twice).  One reservation per wave for the kDnIlp edges of its lanes.
+    unsigned long long fm[kDnIlp];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int q = 0; q < kDnIlp; ++q) {
+      fm[q] = __ballot(rc4[q].u >= 0 && old[q] == 0.0);
+      tot += (uint32_t)__popcll(fm[q]);
+    }
+    uint32_t wb = 0;
+    if (kWgAgg) {
+      if (lane == 0) L.wtot[wave_id()] = tot;
+      __syncthreads();
+      uint32_t all = 0;
+#pragma unroll
+      for (int w = 0; w < kDnWaves; ++w) {
+        const uint32_t x = L.wtot[w];
+        wb += w < wave_id() ? x : 0u;
+        all += x;
+      }
+      if (tid == 0) L.wbase = all ? atomicAdd(S.tcount, all) : 0u;
+      __syncthreads();
+      wb += L.wbase;
+    } else if (tot) {
+      if (lane == 0) wb = atomicAdd(S.tcount, tot);
+      wb = __shfl(wb, 0);
+    }
+    if (tot) {
+#pragma unroll
+      for (int q = 0; q < kDnIlp; ++q) {
+        if ((fm[q] >> lane) & 1ull) {
+          const uint32_t pos = wb + (uint32_t)__popcll(fm[q] & ((1ull << lane) - 1ull));
+          if (pos < cap_t) dn_store(&W.touched[pos], rc4[q].u);
+        }
+        wb += (uint32_t)__popcll(fm[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kDnIlp; ++q)
+      if (rc4[q].u >= 0 && !(old[q] > rmax) && old[q] + add[q] > rmax) {  // :89 strict, un-normalised; first crossing
+        const uint32_t pos = atomicAdd(S.nnext, 1u);
+        if (pos < cap_f) dn_store(&nxt[pos], rc4[q].u);
+        else atomicOr(S.giveup, 1u);
+      }
+  }
+}
+
+// One chunk [c * chunk, ...) of a POSTED level's edge space, read from the owner's level layout in HBM; appends through
+// the owner's board entry.  Called by all threads of a workgroup (the owner's or a helper's); which / nf / E / c must
+// be workgroup-uniform (the callers hand them round through LDS): the loops below hold barriers.
+__device__ __forceinline__ void dn_chunk(const DenseWs& W, DnBoard* B, uint32_t which, uint32_t nf, uint32_t E,
+                                         uint32_t c, const InRec* __restrict__ in_rec, double rmax, const DnDims& D,
+                                         DnLds& L) {
+  const int tid = threadIdx.x;
+  const uint32_t chunk_lo = c * D.chunk;
+  const uint32_t chunk_hi = (E - chunk_lo > D.chunk) ? chunk_lo + D.chunk : E;
+  if (tid == 0) L.i0 = dn_load(&W.cstart[c]);
+  __syncthreads();
+  uint32_t i0 = L.i0;
+  uint32_t ce = chunk_lo;
+  const DnSinks S{&B->tcount, &B->nnext, &B->giveup};
+  while (ce < chunk_hi) {
+    const uint32_t cnt = nf - i0 < (uint32_t)kDnStage ? nf - i0 : (uint32_t)kDnStage;
+    if (cnt == 0 || i0 >= nf) break;  // (cannot happen: eoff[nf] = E > ce)
+    __syncthreads();                   // the staging arrays of the round before are no longer read
+    if ((uint32_t)tid < cnt) {
+      L.eoff[tid] = dn_load(&W.eoff[i0 + tid]);
+      L.row[tid] = dn_load(&W.frow[i0 + tid]);
+      L.c[tid] = dn_load(&W.pend[i0 + tid]);
+    }
+    if (tid == 0) L.eoff[cnt] = dn_load(&W.eoff[i0 + cnt]);
+    __syncthreads();
+    const uint32_t cov_hi = L.eoff[cnt] < chunk_hi ? L.eoff[cnt] : chunk_hi;
+    if (cov_hi <= ce) break;  // (cannot happen: the staged entries cover ce; a guard against looping on bad data)
+    dn_edge_range<true>(W, L, cnt, ce, cov_hi, W.fr[which ^ 1], S, in_rec, rmax, D.cap_t, D.cap_f);
+    ce = cov_hi;
+    i0 += cnt;
+  }
+  dn_barrier_global();  // every wave's appends have arrived before lane 0 reports the chunk done
 }
 
 __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __restrict__ target_list, uint32_t n_targets,
@@ -398,39 +607,39 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
                                                             const InRec* __restrict__ in_rec,
                                                             const int32_t* __restrict__ old2new,
                                                             const int32_t* __restrict__ new2old, double alpha,
-                                                            double rmax, ApOut O, char* ws_base, uint32_t n,
-                                                            uint32_t cap_t, uint32_t cap_f,
+                                                            double rmax, ApOut O, char* ws_base, DnBoard* board,
+                                                            unsigned long long* done_targets,
+                                                            unsigned long long* n_open,
+                                                            unsigned long long* abort_word, DnDims D, int share,
                                                             unsigned long long* __restrict__ dbg) {
-  // dbg (developer switch PPRHIP_APBS_DEBUG, else nullptr): per workgroup {searches, edges, ticks of the 100 MHz
-  // clock spent in pops, scans, edge loops, emission, clean-up, and the tick at which the workgroup ended}
-  __shared__ uint32_t f_row[kDnFront];
-  __shared__ uint32_t f_off[kDnFront + 1];
-  __shared__ double f_c[kDnFront];
+  // dbg (developer switch PPRHIP_APBS_DEBUG, else nullptr; HOST memory): per workgroup {searches, edges of its own
+  // searches, ticks of the 100 MHz clock spent in pops + scans, own edges, waiting for helpers, emission, clean-up,
+  // helping / idle, the tick at which the workgroup ended, and where it is: stage << 32 | detail (printed by the
+  // host's watchdog when a launch does not come back)}
+  __shared__ DnLds L;
   __shared__ uint32_t s_scan[kDnWaves];
   __shared__ unsigned long long s_scan64[kDnWaves];
-  __shared__ uint32_t s_tcount, s_nnext, s_pcount, s_giveup;
+  __shared__ uint32_t s_pcount, s_carry, s_job[4], s_owner, s_chunk, s_edges, s_gaveup;
+  __shared__ uint32_t s_tcount, s_nnext, s_giveup;  // the search's append counters while it stays on this workgroup
   __shared__ unsigned long long s_t, s_out_base, s_tot;
-  const int tid = threadIdx.x, lane = lane_id();
-
-  DenseWs W;
-  {
-    char* base = ws_base + (size_t)blockIdx.x * dense_ws_bytes(n, cap_t, cap_f);
-    W.res = (double*)base;
-    W.rsv = W.res + n;
-    W.pend = W.rsv + n;
-    W.touched = (int32_t*)(W.pend + cap_f);
-    W.cur = W.touched + cap_t;
-    W.nxt = W.cur + cap_f;
-    W.plist = W.nxt + cap_f;
-  }
+  const int tid = threadIdx.x;
+  const uint32_t n = D.n, cap_t = D.cap_t, cap_f = D.cap_f, chunk = D.chunk;
+  const DenseWs W = dense_ws_of(ws_base, blockIdx.x, D);
+  DnBoard* B = board + blockIdx.x;
+  const DnSinks S_local{&s_tcount, &s_nnext, &s_giveup};
   unsigned long long pops = 0, edges = 0;
-  unsigned long long tk[5] = {0, 0, 0, 0, 0}, t_mark = dbg ? wall_clock64() : 0ull, n_search = 0;
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_mark = dbg ? wall_clock64() : 0ull, n_search = 0;
 #define DN_TICK(i)                                   \
   if (dbg && tid == 0) {                             \
     const unsigned long long now_ = wall_clock64();  \
     tk[i] += now_ - t_mark;                          \
     t_mark = now_;                                   \
   }
+#define DN_AT(stage, detail)                                                                                  \
+  if (dbg && tid == 0)                                                                                        \
+    __hip_atomic_store(dbg + (size_t)blockIdx.x * 12 + 9, ((unsigned long long)(stage) << 32) | (uint32_t)(detail), \
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  uint32_t seq = 0;  // even: this workgroup's board entry is closed
 
   for (;;) {
     if (tid == 0) s_t = atomic_add_u64(next_target, 1ull);
@@ -438,121 +647,182 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     const unsigned long long ti = s_t;
     if (ti >= n_targets) break;
     n_search++;
+    DN_AT(1, ti)
     const int32_t t_old = target_list[ti];
     const int32_t t = old2new[t_old];
-    uint32_t nf = 0;
+    uint32_t nf = 0, which = 0;
     if (tid == 0) {
-      s_tcount = 0;
       s_pcount = 0;
+      s_tcount = 0;
       s_giveup = 0;
       if (in_rp[t + 1] == in_rp[t]) {  // Backward_Search.java:46-49: reserve = {t: 1.0}
         dn_store(&W.rsv[t], 1.0);
-        W.plist[0] = t;
+        dn_store(&W.plist[0], t);
         s_pcount = 1;
       } else {
         dn_store(&W.res[t], 1.0);  // :54-56; the target is pushed unconditionally first
-        W.touched[0] = t;
+        dn_store(&W.touched[0], t);
         s_tcount = 1;
-        W.cur[0] = t;
+        dn_store(&W.fr[0][0], t);
+        nf = 1;
       }
+      s_job[0] = nf;
     }
     __syncthreads();
-    nf = s_tcount;  // 1 when the target has in-edges
+    nf = s_job[0];
 
     while (nf > 0) {
-      // ---- every frontier node gives up its residue (:58-67,72); a node is in a level's frontier at most once
-      for (uint32_t i = tid; i < nf; i += kDnThreads) {
-        const int32_t v = W.cur[i];
-        const double rc = __hip_atomic_exchange(&W.res[v], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double r0 = dn_load(&W.rsv[v]);
-        if (r0 == 0.0) {  // first pop of this node (alpha * rc > 0 ever after)
-          const uint32_t pp = atomicAdd(&s_pcount, 1u);
-          if (pp < cap_f) W.plist[pp] = v;
-          else s_giveup = 1;
-        }
-        dn_store(&W.rsv[v], r0 + rc * alpha);
-        W.pend[i] = (1.0 - alpha) * rc;
+      // ---- every frontier node gives up its residue (:58-67,72; a node is in a level's frontier at most once) and
+      // the level's edge space is laid out, a tile of kDnStage frontier entries at a time: pending contribution, first
+      // in-edge, exclusive prefix of the in-degrees.  A level of one tile stays in LDS; a larger one (or one whose
+      // edges are worth sharing) is written to the workspace, with the frontier position every chunk of edges starts in.
+      const int32_t* cur = W.fr[which];
+      const bool one_tile = nf <= (uint32_t)kDnStage;
+      DN_AT(2, nf)
+      if (tid == 0) {
+        s_carry = 0;
+        s_nnext = 0;
       }
-      if (tid == 0) s_nnext = 0;
-      pops += (tid == 0) ? nf : 0;
       __syncthreads();
-      DN_TICK(0)
-      // ---- in-edges of the frontier, kDnFront frontier nodes at a time
-      for (uint32_t fb = 0; fb < nf; fb += kDnFront) {
-        const uint32_t cnt = nf - fb < (uint32_t)kDnFront ? nf - fb : (uint32_t)kDnFront;
-        uint32_t d = 0;
-        if ((uint32_t)tid < cnt) {
-          const int32_t v = W.cur[fb + tid];
-          const uint32_t b = in_rp[v];
+      for (uint32_t tile = 0; tile < nf; tile += kDnThreads) {
+        const uint32_t i = tile + tid;
+        uint32_t d = 0, b = 0;
+        double pc = 0.0;
+        if (i < nf) {
+          const int32_t v = dn_load(&cur[i]);
+          const double rc = __hip_atomic_exchange(&W.res[v], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double r0 = dn_load(&W.rsv[v]);
+          if (r0 == 0.0) {  // first pop of this node (alpha * rc > 0 ever after)
+            const uint32_t pp = atomicAdd(&s_pcount, 1u);
+            if (pp < cap_f) dn_store(&W.plist[pp], v);
+            else s_giveup = 1;
+          }
+          dn_store(&W.rsv[v], r0 + rc * alpha);
+          pc = (1.0 - alpha) * rc;
+          b = in_rp[v];
           d = in_rp[v + 1] - b;
-          f_row[tid] = b;
-          f_c[tid] = W.pend[fb + tid];
         }
-        uint32_t E = 0;
-        const uint32_t ex = block_excl_scan_n<uint32_t, kDnWaves>(d, s_scan, &E);
-        if ((uint32_t)tid < cnt) f_off[tid] = ex;
-        if (tid == 0) f_off[cnt] = E;
+        uint32_t tile_tot = 0;
+        const uint32_t ex = s_carry + block_excl_scan_n<uint32_t, kDnWaves>(d, s_scan, &tile_tot);
+        if (one_tile) {  // (tile == 0)
+          if (i < nf) {
+            L.eoff[tid] = ex;
+            L.row[tid] = b;
+            L.c[tid] = pc;
+          }
+        } else if (i < nf) {
+          dn_store(&W.pend[i], pc);
+          dn_store(&W.frow[i], b);
+          dn_store(&W.eoff[i], ex);
+          if (d) {  // chunks whose first edge lies in this node's range start here
+            const uint32_t c_lo = (uint32_t)(((unsigned long long)ex + chunk - 1) / chunk);
+            const uint32_t c_hi = (uint32_t)(((unsigned long long)ex + d - 1) / chunk);
+            for (uint32_t c = c_lo; c <= c_hi; ++c) dn_store(&W.cstart[c], i);
+          }
+        }
         __syncthreads();
-        edges += (tid == 0) ? E : 0;
+        if (tid == 0) s_carry += tile_tot;
+        __syncthreads();
+      }
+      const uint32_t E = s_carry;
+      const uint32_t n_chunks = (uint32_t)(((unsigned long long)E + chunk - 1) / chunk);
+      const bool post = !one_tile || (share && n_chunks >= kDnShareMin);
+      pops += (tid == 0) ? nf : 0;
+      edges += (tid == 0) ? E : 0;
+      if (!post) {
+        // ---- the level stays here: edges straight from the LDS tile, appends counted in LDS
+        if (tid == 0) L.eoff[nf] = E;
+        __syncthreads();
+        DN_TICK(0)
+        DN_AT(5, E)
+        dn_edge_range<false>(W, L, nf, 0u, E, W.fr[which ^ 1], S_local, in_rec, rmax, cap_t, cap_f);
+        dn_barrier_global();  // the appends have arrived before the next level reads them
         DN_TICK(1)
-        // wave-uniform trip count (the appends below are wave-aggregated)
-        for (uint32_t base0 = 0; base0 < E; base0 += kDnThreads * kDnIlp) {
-          InRec rc4[kDnIlp];
-          double add[kDnIlp], old[kDnIlp];
-#pragma unroll
-          for (int q = 0; q < kDnIlp; ++q) {
-            const uint32_t e = base0 + (uint32_t)kDnThreads * q + tid;
-            rc4[q] = InRec{-1, 1u};
-            add[q] = 0.0;
-            if (e < E) {
-              uint32_t lo = 0, hi = cnt;  // last frontier entry whose edge range starts at or before e
-              while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (f_off[mid] <= e) lo = mid + 1; else hi = mid;
-              }
-              const uint32_t i = lo - 1;
-              rc4[q] = load_rec(in_rec, (size_t)f_row[i] + (e - f_off[i]));
-              add[q] = f_c[i];
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < kDnIlp; ++q) {
-            add[q] = add[q] / (double)rc4[q].dout;  // :84-85, every edge's quotient rounds on its own
-            old[q] = 0.0;
-            if (rc4[q].u >= 0) old[q] = atomic_add_ret(&W.res[rc4[q].u], add[q]);
-          }
-#pragma unroll
-          for (int q = 0; q < kDnIlp; ++q) {
-            const bool on = rc4[q].u >= 0;
-            // a residue leaves zero: remember the node for the clean-up (a node popped in between is listed twice,
-            // which only clears it twice)
-            const bool first = on && old[q] == 0.0;
-            const unsigned long long fm = __ballot(first);
-            if (fm) {
-              uint32_t wb = 0;
-              if (lane == __ffsll((long long)fm) - 1) wb = atomicAdd(&s_tcount, (uint32_t)__popcll(fm));
-              wb = __shfl(wb, __ffsll((long long)fm) - 1);
-              if (first) {
-                const uint32_t pos = wb + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
-                if (pos < cap_t) W.touched[pos] = rc4[q].u;
-              }
-            }
-            if (on && !(old[q] > rmax) && old[q] + add[q] > rmax) {  // :89 strict, un-normalised; first crossing
-              const uint32_t pos = atomicAdd(&s_nnext, 1u);
-              if (pos < cap_f) W.nxt[pos] = rc4[q].u;
-              else s_giveup = 1;
-            }
+        if (tid == 0) {
+          s_gaveup = (s_giveup || dn_load(abort_word)) ? 1u : 0u;
+          s_job[0] = s_gaveup ? 0u : s_nnext;
+        }
+      } else {
+        // ---- the level goes through the workspace: a one-tile level is written out first
+        if (one_tile && (uint32_t)tid < nf) {
+          const uint32_t ex = L.eoff[tid], nx = (uint32_t)tid + 1 < nf ? L.eoff[tid + 1] : E;
+          dn_store(&W.pend[tid], L.c[tid]);
+          dn_store(&W.frow[tid], L.row[tid]);
+          dn_store(&W.eoff[tid], ex);
+          if (nx > ex) {
+            const uint32_t c_lo = (uint32_t)(((unsigned long long)ex + chunk - 1) / chunk);
+            const uint32_t c_hi = (uint32_t)(((unsigned long long)nx - 1) / chunk);
+            for (uint32_t c = c_lo; c <= c_hi; ++c) dn_store(&W.cstart[c], (uint32_t)tid);
           }
         }
+        if (tid == 0) {
+          dn_store(&W.eoff[nf], E);
+          // the appends of a posted level are counted on the board entry (helpers add to them)
+          dn_reset(&B->tcount, s_tcount);
+          dn_reset(&B->nnext, 0u);
+          dn_reset(&B->giveup, s_giveup);
+        }
+        dn_barrier_global();  // the level's layout has arrived in memory before it is posted or read
+        DN_TICK(0)
+        // post the level; take chunks of it like any helper; go on when all of them are done
+        if (tid == 0) {
+          dn_store(&B->n_chunks, n_chunks);
+          dn_store(&B->nf, nf);
+          dn_store(&B->which, which);
+          dn_reset(&B->done, 0u);  // (includes the release fence for the stores above)
+          seq += 1;                // odd: open
+          dn_reset(&B->next, (unsigned long long)seq << 32);
+          if (share) atomic_add_u64(n_open, 1ull);  // what idle workgroups poll
+          s_job[0] = (uint32_t)atomic_add_u64(&B->next, 1ull);  // first chunk (only helpers need the compare-and-swap)
+        }
         __syncthreads();
+        // NOTE on the shape of this loop (and of every loop in this kernel that holds barriers): a block that only
+        // lane 0 executes must never be the last thing before the back edge while another such block opens the loop -
+        // the compiler then threads the two together, lanes other than 0 loop back to the barrier on a path of their
+        // own, and the waves pass it before lane 0 has written what they are about to read (seen in the ISA of an
+        // earlier form of this loop: every wave re-read chunk 0 for ever).  Lane-0 blocks are followed by a barrier.
+        for (uint32_t c = s_job[0]; c < n_chunks; c = s_job[0]) {
+          __syncthreads();  // s_job[0] has been read by every wave
+          DN_AT(3, c)
+          dn_chunk(W, B, which, nf, E, c, in_rec, rmax, D, L);
+          if (tid == 0) {  // (dn_chunk ended with every wave's stores acknowledged)
+            atomicAdd(&B->done, 1u);
+            s_job[0] = (uint32_t)atomic_add_u64(&B->next, 1ull);
+          }
+          __syncthreads();
+        }
+        __syncthreads();
+        DN_TICK(1)
+        if (tid == 0) {
+          // bounded: a wait that outlasts kDnWaitTicks (a bug, or a helper lost to a fault) raises the launch's abort
+          // word, on which every loop of every workgroup ends; the host turns it into an error
+          DN_AT(4, n_chunks)
+          const unsigned long long t_wait = wall_clock64();
+          while (dn_load(&B->done) < n_chunks && !dn_load(abort_word)) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t_wait > kDnWaitTicks) atomic_add_u64(abort_word, 1ull);
+          }
+          seq += 1;  // even: closed (a helper's compare-and-swap on the old sequence fails from here on)
+          dn_reset(&B->next, (unsigned long long)seq << 32);
+          if (share) atomic_add_u64(n_open, ~0ull);
+          s_tcount = dn_load(&B->tcount);
+          s_giveup = dn_load(&B->giveup);
+          s_gaveup = (s_giveup || dn_load(abort_word)) ? 1u : 0u;
+          s_job[0] = s_gaveup ? 0u : dn_load(&B->nnext);
+        }
         DN_TICK(2)
       }
-      nf = s_giveup ? 0u : s_nnext;
-      int32_t* tmp = W.cur; W.cur = W.nxt; W.nxt = tmp;
+      __syncthreads();
+      nf = s_job[0];
+      which ^= 1;
       __syncthreads();
     }
 
-    const bool gave_up = s_giveup != 0;  // a list is full: the search goes to the whole-vector tier
+    DN_AT(6, 0)
+    // a list is full (or the launch is being aborted): the search goes to the whole-vector tier
+    if (tid == 0) s_gaveup = (s_giveup || dn_load(abort_word)) ? 1u : 0u;
+    __syncthreads();
+    const bool gave_up = s_gaveup != 0;
     const uint32_t np = s_pcount < cap_f ? s_pcount : cap_f;
     // ---- emit entries >= threshold (Base_Whole_Graph.java:80-88): only popped nodes hold a reserve
     bool retry = gave_up;
@@ -561,7 +831,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
       for (uint32_t c0 = 0; c0 < np; c0 += kDnThreads) {
         const uint32_t i = c0 + tid;
         double r = 0.0;
-        if (i < np) r = dn_load(&W.rsv[W.plist[i]]);
+        if (i < np) r = dn_load(&W.rsv[dn_load(&W.plist[i])]);
         run += (r > 0.0 && r >= rmax) ? 1ull : 0ull;
       }
       const unsigned long long total = block_sum_u64(run, s_scan64);  // valid in thread 0
@@ -578,7 +848,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
         unsigned long long at = s_out_base;
         for (uint32_t c0 = 0; c0 < np; c0 += kDnThreads) {
           const uint32_t i = c0 + tid;
-          const int32_t v = i < np ? W.plist[i] : 0;
+          const int32_t v = i < np ? dn_load(&W.plist[i]) : 0;
           const double r = i < np ? dn_load(&W.rsv[v]) : 0.0;
           const bool take = r > 0.0 && r >= rmax;
           unsigned long long chunk_total = 0;
@@ -599,32 +869,101 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     }
     __syncthreads();
     DN_TICK(3)
+    DN_AT(7, 0)
     // ---- hand the vectors back all-zero
-    for (uint32_t i = tid; i < np; i += kDnThreads) dn_store(&W.rsv[W.plist[i]], 0.0);
+    for (uint32_t i = tid; i < np; i += kDnThreads) dn_store(&W.rsv[dn_load(&W.plist[i])], 0.0);
     const uint32_t nt = s_tcount;
     if (nt <= cap_t && s_pcount <= cap_f) {
-      for (uint32_t i = tid; i < nt; i += kDnThreads) dn_store(&W.res[W.touched[i]], 0.0);
+      for (uint32_t i = tid; i < nt; i += kDnThreads) dn_store(&W.res[dn_load(&W.touched[i])], 0.0);
     } else {  // a list overflowed: clear everything
       for (uint32_t i = tid; i < n; i += kDnThreads) {
         dn_store(&W.res[i], 0.0);
         dn_store(&W.rsv[i], 0.0);
       }
     }
-    __syncthreads();
+    dn_barrier_global();  // the zeros have arrived before the next search's atomics can meet them
+    if (tid == 0) atomic_add_u64(done_targets, 1ull);
     DN_TICK(4)
+    __syncthreads();  // (lane-0 blocks never sit next to a back edge: see the note at the chunk loop)
   }
+
+  // ---- out of targets: help with posted levels until every target of the launch is finished
+  if (share) {
+    const unsigned long long t_idle = wall_clock64();
+    DN_AT(8, 0)
+    for (;;) {
+      // (every LDS word below is written in one phase and read in the next, with a barrier between: a word that is
+      // read by all waves is never reused for something else before the barrier that follows the read)
+      if (tid == 0) {
+        s_owner = 0xFFFFFFFFu;  // owner to help
+        if (wall_clock64() - t_idle > 4 * kDnWaitTicks) atomic_add_u64(abort_word, 1ull);
+        s_job[3] = (dn_load(done_targets) >= (unsigned long long)n_targets || dn_load(abort_word)) ? 1u : 0u;
+        s_job[2] = dn_load(n_open) != 0ull ? 1u : 0u;
+      }
+      __syncthreads();
+      // (one word polled while nothing is posted: the board is only scanned when somebody has a level open)
+      if (s_job[2] && (uint32_t)tid < gridDim.x && (uint32_t)tid != blockIdx.x) {
+        const unsigned long long nx = dn_load(&board[tid].next);
+        // the nearest open entry after this workgroup's own: helpers spread over the owners instead of all taking the
+        // first one (every append of a shared level is an atomic on the owner's counters)
+        if (((nx >> 32) & 1ull) && (uint32_t)nx < dn_load(&board[tid].n_chunks))
+          atomicMin(&s_owner, ((uint32_t)tid + gridDim.x - blockIdx.x) % gridDim.x);
+      }
+      __syncthreads();
+      const uint32_t owner = s_owner == 0xFFFFFFFFu ? 0xFFFFFFFFu : (s_owner + blockIdx.x) % gridDim.x;
+      const bool all_done = s_job[3] != 0;
+      if (owner == 0xFFFFFFFFu) {
+        if (all_done) break;
+        for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127);  // ~15 us between polls
+        __syncthreads();
+        continue;
+      }
+      DnBoard* OB = board + owner;
+      if (tid == 0) {
+        // the level's parameters are valid for the sequence read with them iff the compare-and-swap on
+        // {sequence, chunk} succeeds: the owner rewrites them only while the entry is closed
+        const unsigned long long nx = dn_load(&OB->next);
+        const uint32_t nch = dn_load(&OB->n_chunks);
+        s_job[0] = dn_load(&OB->nf);
+        s_job[1] = dn_load(&OB->which);
+        s_edges = dn_load(&dense_ws_of(ws_base, owner, D).eoff[s_job[0] <= D.cap_f ? s_job[0] : 0u]);
+        uint32_t c = 0xFFFFFFFFu;
+        if (((nx >> 32) & 1ull) && (uint32_t)nx < nch) {
+          unsigned long long expect = nx;
+          if (__hip_atomic_compare_exchange_strong(&OB->next, &expect, nx + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)) {
+            c = (uint32_t)nx;
+          }
+        }
+        s_chunk = c;
+      }
+      __syncthreads();
+      const uint32_t c = s_chunk, onf = s_job[0], owhich = s_job[1], oE = s_edges;
+      __syncthreads();
+      if (c == 0xFFFFFFFFu) continue;  // somebody else was faster: look again
+      const DenseWs OW = dense_ws_of(ws_base, owner, D);
+      DN_AT(9, (owner << 16) | (c & 0xFFFFu))
+      dn_chunk(OW, OB, owhich & 1u, onf, oE, c, in_rec, rmax, D, L);
+      DN_AT(8, 1)
+      if (tid == 0) atomicAdd(&OB->done, 1u);  // (dn_chunk ended with every wave's stores acknowledged)
+      __syncthreads();                         // (lane-0 blocks never sit next to a back edge)
+    }
+    DN_TICK(5)
+  }
+  DN_AT(10, 0)
 #undef DN_TICK
+#undef DN_AT
   const unsigned long long ps = block_sum_u64(pops, s_scan64);
   const unsigned long long es = block_sum_u64(edges, s_scan64);
   if (tid == 0) {
     if (ps) atomic_add_u64(O.stat_pops, ps);
     if (es) atomic_add_u64(O.stat_edges, es);
     if (dbg) {
-      unsigned long long* d = dbg + (size_t)blockIdx.x * 8;
+      unsigned long long* d = dbg + (size_t)blockIdx.x * 12;
       d[0] = n_search;
       d[1] = edges;
-      for (int i = 0; i < 5; ++i) d[2 + i] = tk[i];
-      d[7] = wall_clock64();
+      for (int i = 0; i < 6; ++i) d[2 + i] = tk[i];
+      d[8] = wall_clock64();
     }
   }
 }
@@ -735,14 +1074,16 @@ int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint
                 b.stat_pops, b.stat_edges};
   const InRec* rec = (const InRec*)g->in_rec;
   if (dense_tier) {
-    if (!d_targets || !b.ws || !b.ws_blocks) {
+    if (!d_targets || !b.ws || !b.ws_blocks || !b.board || !b.done_targets || !b.chunk) {
       set_error("All-Pair dense tier: no target list or workspace");
       return PPRHIP_ERR_STATE;
     }
-    const uint32_t grid = std::min<uint32_t>(b.ws_blocks, std::max(1u, n_targets));
-    k_apbs_dense<<<dim3(grid), dim3(kDnThreads), 0, g->stream>>>(d_targets, n_targets, b.next_target, g->in_rp, rec,
-                                                                 g->old2new, g->new2old, alpha, rmax, O, b.ws, g->n,
-                                                                 b.cap_t, b.cap_f, b.dbg);
+    const uint32_t grid = std::min<uint32_t>(std::min<uint32_t>(b.ws_blocks, (uint32_t)kDnThreads), std::max(1u, n_targets));
+    const char* sh = getenv("PPRHIP_APBS_SHARE");  // developer switch: 0 = every search stays on its own workgroup
+    const int share = (sh && sh[0] == '0') ? 0 : 1;
+    k_apbs_dense<<<dim3(grid), dim3(kDnThreads), 0, g->stream>>>(
+        d_targets, n_targets, b.next_target, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O, b.ws, (DnBoard*)b.board,
+        b.done_targets, b.done_targets + 1, b.done_targets + 2, dims_of(g->n, (unsigned long long)g->m, b.cap_t, b.cap_f, b.chunk), share, b.dbg);
   } else {
     const uint32_t grid = std::min<uint32_t>((uint32_t)g->n_cus * 2u, std::max(1u, n_targets));
     k_apbs_lds<<<dim3(grid), dim3(256), 0, g->stream>>>(d_targets, t_begin, n_targets, b.next_target, g->in_rp, rec,

@@ -439,6 +439,24 @@ def test_all_pair_dense_tier_list_overflows(pkg, orc, rmat12, cap_t, cap_f, monk
             ix.close()
 
 
+@pytest.mark.parametrize("chunk", [16, 256])
+def test_all_pair_dense_tier_shared_levels(pkg, orc, rmat12, chunk, monkeypatch):
+    """Levels of the dense tier that span several chunks of edges are posted and idle workgroups take chunks of them
+    (kernels_apbs.hip: work sharing).  With chunks of a few edges every level of every search is shared; the index
+    must not depend on who pushed which edge."""
+    monkeypatch.setenv("PPRHIP_APBS_TIER", "2")
+    monkeypatch.setenv("PPRHIP_APBS_CHUNK", str(chunk))
+    og = to_oracle(orc, rmat12)
+    with pkg.Graph(rmat12) as g:
+        for (lo, hi), thr in (((0, 64), 2e-4), ((1000, 1600), 1e-3)):   # few targets: most workgroups only help
+            ix, st = g.all_pair_backward(ALPHA, thr, -1, lo, hi)
+            off, tg, vl = ix.arrays()
+            ooff, otg, ovl = og.all_pair_backward(ALPHA, thr, -1, lo, hi, schedule=orc.SYNC)
+            assert np.array_equal(off, ooff) and np.array_equal(tg, otg)
+            assert np.max(np.abs(vl - ovl)) <= TOL_PUSH
+            ix.close()
+
+
 def test_batch_directions_share_a_handle(pkg, orc, rmat12, dev_rmat12, monkeypatch):
     """Forward batches and batched backward searches (All-Pair tier 3) alternate on one handle: the shared sweep
     arrays are handed over clean in both directions."""

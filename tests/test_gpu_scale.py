@@ -244,3 +244,27 @@ def test_full_size_rmat22_against_cpu_power_method(pkg, orc):
                 assert abs(exact[v] - kth) <= tol
         m = min(int(nsel[0]), 32)
         assert np.array_equal(out[0][ids[0][:m]], vals[0][:m])
+        # ---- Fora_Topk.computeTopKPPR at full size (config #3: k = 32; Fora_Topk.java:102-184): the single entry point
+        # and the batched one, against the same CPU ground truth
+        k = 32
+        order = np.argsort(-exact, kind="stable")
+        kth = exact[order[k - 1]]
+        n_sel, tids, tvals, test_, tst = g.fora_topk(s, 0.5, A, k, seed=5, cap=4 * k, fetch=True)
+        bids, bvals, bst = g.fora_batch_topk(np.array([s, s], dtype=np.int32), k, 0.5, A, seed=5)
+        assert tst.rounds >= 1 and tst.walks > 0 and n_sel >= k
+        assert np.all(np.diff(tvals) <= 0) and np.array_equal(test_[tids], tvals)
+        # query 0 of the batch runs with the same seed as the single call: same rounds, same walks, same list
+        assert np.array_equal(bids[0], tids[:k]) and np.max(np.abs(bvals[0] - tvals[:k])) <= 1e-9
+        for ids_k, vals_k in ((tids[:k], tvals[:k]), (bids[1], bvals[1])):
+            # the stopping rule (:175) bounds the relative error of the reported entries by eps' = eps / 2
+            assert np.all(np.abs(vals_k - exact[ids_k]) <= 0.25 * np.maximum(exact[ids_k], kth))
+            # top-32 identity wherever the exact k-th and (k+1)-th values are further apart than that error (gap guard);
+            # otherwise only entries within the error of the k-th place may differ
+            gap = exact[order[k - 1]] - exact[order[k]]
+            if gap > 2 * 0.25 * kth:
+                assert set(ids_k.tolist()) == set(order[:k].tolist())
+            else:
+                for v in set(ids_k.tolist()) ^ set(order[:k].tolist()):
+                    assert abs(exact[v] - kth) <= 2 * 0.25 * kth
+        # the whole estimate the last round leaves (Fora_Topk.java:143-168) keeps mass 1 up to the undelivered residues
+        assert abs(test_.sum() + (1 - A) * 0 - 1.0) < 1e-6 or test_.sum() <= 1.0 + 1e-9

@@ -20,9 +20,11 @@ for rep in range(2):
     ix, st = g.all_pair_backward(0.15, a.thr, a.k, 0, nt)
     dt = time.time() - t0
     off, tg, vl = ix.arrays()
+    t_arr = time.time() - t0 - dt
     print("scale=%d thr=%g targets=%d wall=%.3fs (%.0f targets/s) device=%.1fms entries=%d pops=%d edges=%d tier2=%d tier3=%d "
-          "batch kernel %.1f ms x%d" % (a.scale, a.thr, nt, dt, nt / dt, st.total_ms, len(tg), st.pops, st.edge_pushes,
-                                       st.rounds, st.dense_nodes, st.class_ms[4], st.class_launches[4]), flush=True)
+          "batch kernel %.1f ms x%d (+ %.3f s copying the index arrays to numpy)"
+          % (a.scale, a.thr, nt, dt, nt / dt, st.total_ms, len(tg), st.pops, st.edge_pushes, st.rounds, st.dense_nodes,
+             st.class_ms[4], st.class_launches[4], t_arr), flush=True)
     ix.close()
 if a.cpu:
     from oracle import oracle as orc
