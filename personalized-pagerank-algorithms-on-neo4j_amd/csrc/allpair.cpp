@@ -42,7 +42,7 @@ void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix)
   const size_t N = tr.size();
   std::vector<uint64_t> start((size_t)n + 1, 0);
   std::vector<Triple> by_v(N);
-  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   const unsigned T = N < (1u << 16) ? 1u : hw;
   auto parallel = [&](unsigned parts, auto&& fn) {  // fn(part) for part in [0, parts), T threads
     std::atomic<unsigned> next{0};
@@ -153,17 +153,14 @@ void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix)
 namespace pprhip {
 namespace detail {
 
-// entries of the searches go to the host right away (single-GPU call) ...
-int HostTripleSink::take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
-                                unsigned long long count) {
-  h_v.resize(count); h_t.resize(count); h_p.resize(count);
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(h_v.data(), d_v, sizeof(int32_t) * count, hipMemcpyDeviceToHost, g->stream));
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(h_t.data(), d_t, sizeof(int32_t) * count, hipMemcpyDeviceToHost, g->stream));
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(h_p.data(), d_p, sizeof(double) * count, hipMemcpyDeviceToHost, g->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+// entries of the searches go to the host right away (single-GPU call): the device records have the host entries'
+// layout, so they land in the vector's tail in one copy ...
+static_assert(sizeof(Triple) == sizeof(TripleRec), "host and device entries share one layout");
+int HostTripleSink::take_device(pprhip_graph* g, const TripleRec* d_rec, unsigned long long count) {
   const size_t at = tr.size();
   tr.resize(at + count);
-  for (unsigned long long i = 0; i < count; ++i) tr[at + i] = Triple{h_v[i], h_t[i], h_p[i]};
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(tr.data() + at, d_rec, sizeof(TripleRec) * count, hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   return PPRHIP_OK;
 }
 int HostTripleSink::take_host(pprhip_graph*, std::vector<Triple>& more) {
@@ -185,18 +182,16 @@ int DeviceTripleSink::reserve(pprhip_graph* g, unsigned long long extra) {
   cap = ncap;
   return PPRHIP_OK;
 }
-int DeviceTripleSink::take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
-                                  unsigned long long n_new) {
+int DeviceTripleSink::take_device(pprhip_graph* g, const TripleRec* d_rec, unsigned long long n_new) {
   PPRHIP_TRY(reserve(g, n_new));
-  PPRHIP_TRY(launch_pack_triples(g, d_v, d_t, d_p, n_new, rec + count));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));  // the source buffers are reused by the next pass
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(rec + count, d_rec, sizeof(TripleRec) * n_new, hipMemcpyDeviceToDevice, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));  // the source buffer is reused by the next pass
   count += n_new;
   return PPRHIP_OK;
 }
 int DeviceTripleSink::take_host(pprhip_graph* g, std::vector<Triple>& more) {
   if (more.empty()) return PPRHIP_OK;
   PPRHIP_TRY(reserve(g, more.size()));
-  static_assert(sizeof(Triple) == sizeof(TripleRec), "host and device entries share one layout");
   PPRHIP_CHECK_HIP(hipMemcpyAsync(rec + count, more.data(), sizeof(TripleRec) * more.size(), hipMemcpyHostToDevice,
                                   g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
@@ -222,15 +217,15 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   unsigned long long* cells = nullptr;  // next_target, out_count, out_valid, overflow_count, pops, edges
   int rc = PPRHIP_OK;
   auto release = [&]() {
-    void* p[] = {cells, B.out_v, B.out_t, B.out_p, B.overflow};
+    void* p[] = {cells, B.out_rec, B.overflow};
     for (void* q : p)
       if (q) (void)hipFree(q);
   };
-  B.out_cap = std::min<unsigned long long>(1ull << 24, std::max<unsigned long long>(1ull << 16, 64ull * g->n));
+  // room for the entries of one pass over the range (16 bytes each; 2 GB at most): a search that finds the buffer
+  // full is not run at all but listed for the next pass
+  B.out_cap = std::min<unsigned long long>(1ull << 27, std::max<unsigned long long>(1ull << 16, 16ull * n_targets));
   if ((rc = alloc_dev((void**)&cells, sizeof(unsigned long long) * 16)) ||
-      (rc = alloc_dev((void**)&B.out_v, sizeof(int32_t) * B.out_cap)) ||
-      (rc = alloc_dev((void**)&B.out_t, sizeof(int32_t) * B.out_cap)) ||
-      (rc = alloc_dev((void**)&B.out_p, sizeof(double) * B.out_cap)) ||
+      (rc = alloc_dev((void**)&B.out_rec, sizeof(TripleRec) * B.out_cap)) ||
       (rc = alloc_dev((void**)&B.overflow, sizeof(int32_t) * std::max<uint32_t>(1, n_targets)))) {
     release();
     return rc;
@@ -281,7 +276,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       const uint64_t bytes = 44ull * h_cells[4] + 28ull * h_cells[5] + 16ull * valid;
       st.push_bytes += bytes;
       if (!ktimer().recs.empty()) ktimer().recs.back().bytes = bytes;
-      if (valid) PPRHIP_TRY(sink.take_device(g, B.out_v, B.out_t, B.out_p, valid));
+      if (valid) PPRHIP_TRY(sink.take_device(g, B.out_rec, valid));
       std::vector<int32_t> again;
       const unsigned long long novf = h_cells[3];
       if (novf) {
@@ -315,9 +310,17 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       return rc;
     }
   }
+  const bool dbg_times = getenv("PPRHIP_APBS_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(now() - t).count();
+  };
+  auto t_phase = now();
   std::vector<int32_t> to_tier2, to_tier3;
   if (first_tier <= 1) {
     rc = run_tier(false, {}, true, to_tier2);
+    if (dbg_times) fprintf(stderr, "[apbs host] tier 1 (kernel passes + hand-over of entries): %.1f ms\n", ms_since(t_phase));
+    t_phase = now();
   } else {
     for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
   }
@@ -370,6 +373,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       B.cap_t = g->apbs_cap_t;
       B.cap_f = g->apbs_cap_f;
       B.chunk = g->apbs_chunk;
+      B.helpers = g->apbs_blocks;
       B.board = g->apbs_board;
       B.done_targets = cells + 8;  // + 8: targets done, + 9: levels posted, + 10: abort word
       // targets with the most in-edges first: the searches that push the most edges start the level-1 fan-out from
@@ -441,7 +445,47 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     } else if (rc == PPRHIP_OK) {
       to_tier3 = to_tier2;  // no memory for the dense tier: everything runs on the batch slots
     }
+    // ---- the searches whose frontier or popped-node list outgrew the workspaces' lists: once more with a few
+    // workspaces whose lists hold every node, all the other workgroups helping with their levels
+    if (rc == PPRHIP_OK && g->apbs_blocks && !to_tier3.empty() && to_tier3.size() < to_tier2.size() &&
+        !getenv("PPRHIP_APBS_NO_XL")) {
+      if (!g->apbs_xl_ws) {
+        const uint32_t xl_t = g->n + 4096u, xl_f = g->n + 64u;
+        uint32_t want = 4;
+        int arc = PPRHIP_ERR_OOM;
+        for (; want >= 1; want /= 2) {
+          arc = alloc_dev((void**)&g->apbs_xl_ws, (size_t)want * apbs_dense_bytes(g->n, g->m, xl_t, xl_f, g->apbs_chunk));
+          if (arc != PPRHIP_ERR_OOM) break;
+          (void)hipGetLastError();
+        }
+        if (arc == PPRHIP_OK &&
+            hipMemsetAsync(g->apbs_xl_ws, 0, (size_t)want * apbs_dense_bytes(g->n, g->m, xl_t, xl_f, g->apbs_chunk), g->stream) !=
+                hipSuccess) {
+          (void)hipFree(g->apbs_xl_ws);
+          g->apbs_xl_ws = nullptr;
+          arc = PPRHIP_ERR_HIP;
+        }
+        if (arc == PPRHIP_OK) {
+          g->apbs_xl_blocks = want;
+          g->apbs_xl_cap_t = xl_t;
+          g->apbs_xl_cap_f = xl_f;
+        }
+      }
+      if (g->apbs_xl_ws) {
+        B.ws = g->apbs_xl_ws;
+        B.ws_blocks = g->apbs_xl_blocks;
+        B.cap_t = g->apbs_xl_cap_t;
+        B.cap_f = g->apbs_xl_cap_f;
+        B.helpers = g->apbs_blocks;
+        std::vector<int32_t> again3;
+        rc = run_tier(true, to_tier3, false, again3);
+        if (dbg_times) fprintf(stderr, "[apbs host] full-size workspaces: %zu targets, %zu left for tier 3\n", to_tier3.size(), again3.size());
+        to_tier3.swap(again3);
+      }
+    }
   }
+  if (dbg_times) fprintf(stderr, "[apbs host] tier 2 (%zu targets): %.1f ms\n", to_tier2.size(), ms_since(t_phase));
+  t_phase = now();
   release();
   if (rc != PPRHIP_OK) return rc;
 
@@ -479,6 +523,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     st.dense_levels += st3.dense_levels;
     st.push_bytes += st3.push_bytes;
   }
+  if (dbg_times) fprintf(stderr, "[apbs host] tier 3 (%zu targets): %.1f ms\n", to_tier3.size(), ms_since(t_phase));
   tm.mark(1);
   tm.finish(st);
   for (int c = 0; c < 8; ++c) {
@@ -491,6 +536,141 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   st.rounds = (uint32_t)(to_tier2.size());      // targets that needed the dense tier
   st.dense_nodes = (uint64_t)to_tier3.size();   // targets that needed the whole-vector path
   return PPRHIP_OK;
+}
+
+// The index from entries already ordered by (source, target) - the device sort's output (kernels_sort.hip): rows are
+// contiguous and in target order, so only Base_Whole_Graph's k rule is left (:112-163; k < 0 keeps everything in
+// target order; k >= 0 keeps the entries >= the k-th largest, value descending, ties in target order).  All hardware
+// threads (up to 64), two passes over ranges of sources with equal shares of the entries.
+int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint64_t N, int k, uint32_t v_lo, uint32_t v_hi,
+                      pprhip_index_t** out) {
+  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
+  if (!ix) return PPRHIP_ERR_OOM;
+  ix->n = n;
+  if (N && ((uint32_t)(keys[0] >> 32) < v_lo || (uint32_t)(keys[N - 1] >> 32) >= v_hi)) {
+    set_error("index entries of sources %u .. %u outside the range [%u, %u) they were collected for",
+              (uint32_t)(keys[0] >> 32), (uint32_t)(keys[N - 1] >> 32), v_lo, v_hi);
+    return PPRHIP_ERR_INVALID;
+  }
+  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  const unsigned T = N < (1u << 16) ? 1u : hw;
+  auto run = [&](auto&& fn) {  // fn(part) for part in [0, T)
+    std::vector<std::thread> th;
+    for (unsigned w = 1; w < T; ++w) th.emplace_back(fn, w);
+    fn(0u);
+    for (auto& x : th) x.join();
+  };
+  // ---- row starts: start[v] = first entry of source v (entries are sorted by source)
+  std::vector<uint64_t> start((size_t)n + 1);
+  std::atomic<int> bad{0};
+  run([&](unsigned w) {
+    const uint64_t lo = N * w / T, hi = N * (w + 1) / T;
+    // sources whose rows begin inside (lo, hi], plus - for the first part - everything up to the first entry's source
+    uint32_t prev = lo ? (uint32_t)(keys[lo - 1] >> 32) : 0u;
+    if (lo == 0) start[0] = 0;
+    for (uint64_t i = lo; i < hi; ++i) {
+      const uint32_t v = (uint32_t)(keys[i] >> 32);
+      if ((uint32_t)keys[i] >= n) bad.store(1);
+      if (v != prev || (i == 0)) {
+        for (uint32_t x = (i == 0 ? 0u : prev + 1); x <= v; ++x) start[x] = i;
+        prev = v;
+      }
+    }
+    if (w + 1 == T) {
+      const uint32_t last = N ? (uint32_t)(keys[N - 1] >> 32) : 0u;
+      for (uint32_t x = N ? last + 1 : 0u; x <= n; ++x) start[x] = N;
+    }
+  });
+  if (bad.load()) {
+    set_error("index entry with a target outside [0, %u)", n);
+    return PPRHIP_ERR_INVALID;
+  }
+  // ranges of sources with equal shares of the entries
+  std::vector<uint32_t> cut(T + 1, 0);
+  for (unsigned w = 1; w < T; ++w)
+    cut[w] = (uint32_t)(std::upper_bound(start.begin(), start.end(), N * w / T) - start.begin() - 1);
+  cut[T] = n;
+  for (unsigned w = 1; w <= T; ++w) cut[w] = std::max(cut[w], cut[w - 1]);
+  if (k < 0) {
+    ix->targets.resize(N);
+    ix->values.resize(N);
+    run([&](unsigned w) {
+      for (uint64_t i = N * w / T; i < N * (w + 1) / T; ++i) {
+        ix->targets[i] = (int32_t)(uint32_t)keys[i];
+        ix->values[i] = vals[i];
+      }
+    });
+    ix->offsets.swap(start);
+    *out = ix.release();
+    return PPRHIP_OK;
+  }
+  // ---- pass 1: per row the k-th largest value (when the row has k entries) and how many entries it keeps
+  std::vector<uint64_t> kept((size_t)n + 1, 0);
+  std::vector<double> kth((size_t)n, 0.0);
+  run([&](unsigned w) {
+    std::vector<double> tmp;
+    for (uint32_t v = cut[w]; v < cut[w + 1]; ++v) {
+      const uint64_t b = start[v], len = start[v + 1] - b;
+      if (len == 0) continue;
+      if (k >= 1 && (uint64_t)k <= len) {
+        tmp.assign(vals + b, vals + b + len);
+        std::nth_element(tmp.begin(), tmp.begin() + (k - 1), tmp.end(), std::greater<double>());
+        const double x = tmp[k - 1];
+        kth[v] = x;
+        uint64_t c = 0;
+        for (uint64_t j = 0; j < len; ++j) c += vals[b + j] >= x ? 1 : 0;
+        kept[v + 1] = c;
+      } else {
+        kth[v] = -1.0;  // fewer than k entries (or k = 0): kth_ppr returns null, everything is kept (:133-139)
+        kept[v + 1] = len;
+      }
+    }
+  });
+  for (uint32_t v = 0; v < n; ++v) kept[v + 1] += kept[v];
+  ix->targets.resize(kept[n]);
+  ix->values.resize(kept[n]);
+  // ---- pass 2: the kept entries, value descending, ties in target order
+  run([&](unsigned w) {
+    std::vector<std::pair<double, int32_t>> row;
+    for (uint32_t v = cut[w]; v < cut[w + 1]; ++v) {
+      const uint64_t b = start[v], len = start[v + 1] - b;
+      if (len == 0) continue;
+      row.clear();
+      for (uint64_t j = 0; j < len; ++j)
+        if (vals[b + j] >= kth[v]) row.emplace_back(vals[b + j], (int32_t)(uint32_t)keys[b + j]);
+      std::stable_sort(row.begin(), row.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+      uint64_t o = kept[v];
+      for (const auto& e : row) {
+        ix->targets[o] = e.second;
+        ix->values[o++] = e.first;
+      }
+    }
+  });
+  ix->offsets.swap(kept);
+  *out = ix.release();
+  return PPRHIP_OK;
+}
+
+// the entries in a device record store -> sorted on the device -> the index (rows of sources in [v_lo, v_hi))
+int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int k, uint32_t v_lo, uint32_t v_hi,
+                      pprhip_index_t** out) {
+  unsigned long long* d_keys = nullptr;
+  double* d_vals = nullptr;
+  PPRHIP_TRY(sort_triples_device(g, rec, count, &d_keys, &d_vals));
+  std::unique_ptr<uint64_t[]> keys(new (std::nothrow) uint64_t[std::max<unsigned long long>(1, count)]);
+  std::unique_ptr<double[]> vals(new (std::nothrow) double[std::max<unsigned long long>(1, count)]);
+  int rc = (keys && vals) ? PPRHIP_OK : PPRHIP_ERR_OOM;
+  if (rc == PPRHIP_OK && count &&
+      (hipMemcpyAsync(keys.get(), d_keys, 8 * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+       hipMemcpyAsync(vals.get(), d_vals, 8 * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+       hipStreamSynchronize(g->stream) != hipSuccess)) {
+    set_error("index: download of the sorted entries failed");
+    rc = PPRHIP_ERR_HIP;
+  }
+  if (d_keys) (void)hipFree(d_keys);
+  if (d_vals) (void)hipFree(d_vals);
+  if (rc != PPRHIP_OK) return rc;
+  return index_from_sorted(g->n, keys.get(), vals.get(), count, k, v_lo, v_hi, out);
 }
 
 // index over all n sources from entries of any targets, rows outside [v_lo, v_hi) must not occur
@@ -546,9 +726,16 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   }
   pprhip_stats_t st;
   std::memset(&st, 0, sizeof st);
-  HostTripleSink sink;
+  // the searches' entries stay in HBM, are put in (source, target) order there, and cross PCIe once, in row order
+  DeviceTripleSink sink;
+  const auto t0 = std::chrono::steady_clock::now();
   PPRHIP_TRY(all_pair_collect(g, alpha, threshold, t_begin, t_end, sink, st));
-  PPRHIP_TRY(index_from_triples(g->n, sink.tr, k, index_out));
+  const auto t1 = std::chrono::steady_clock::now();
+  PPRHIP_TRY(index_from_device(g, sink.rec, sink.count, k, 0u, g->n, index_out));
+  if (getenv("PPRHIP_APBS_DEBUG"))
+    fprintf(stderr, "[apbs host] searches + hand-over %.1f ms, index finalisation %.1f ms\n",
+            std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
   if (stats) *stats = st;
   return PPRHIP_OK;
 }

@@ -410,24 +410,13 @@ int all_pair_sharded(pprhip_comm* c, double alpha, double threshold, int k, pprh
   if (rc == PPRHIP_OK)
     for (int p = 0; p <= W; ++p) off[p] = start[p] * sizeof(TripleRec);
   if ((rc = comm_alltoallv(c, d_part, off, &d_recv, roff, rc))) return done(rc);
-  // ---- the entries of this rank's sources cross PCIe once, here
+  // ---- the entries of this rank's sources are put in row order on the device and cross PCIe once, here; what
+  // arrived must be rows this rank owns (a peer's partition or a transport gone wrong must not become an out-of-range
+  // write in the finalisation: index_from_device checks the range)
   const uint64_t n_recv = roff[W] / sizeof(TripleRec);
-  std::vector<Triple> tr(n_recv);
-  if (n_recv && (hipMemcpyAsync(tr.data(), d_recv, roff[W], hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-                 hipStreamSynchronize(g->stream) != hipSuccess)) {
-    set_error("sharded All-Pair: download of the received entries failed on rank %d", c->rank);
-    return done(PPRHIP_ERR_HIP);
-  }
   st.select_bytes = roff[W];          // bytes received in the exchange
   st.mc_sources = sink.count;         // entries this rank found (before the exchange)
-  // what arrived must be rows this rank owns (a peer's partition or a transport gone wrong must not become an
-  // out-of-range write in the finalisation)
-  for (const Triple& x : tr)
-    if (x.v < (int32_t)lo || x.v >= (int32_t)hi) {
-      set_error("sharded All-Pair: rank %d received an entry of source %d, outside its range [%u, %u)", c->rank, x.v, lo, hi);
-      return done(PPRHIP_ERR_STATE);
-    }
-  if ((rc = index_from_triples(g->n, tr, k, own_out))) return done(rc);
+  if ((rc = index_from_device(g, (const TripleRec*)d_recv, n_recv, k, lo, hi, own_out))) return done(rc);
   if (stats) *stats = st;
   return done(PPRHIP_OK);
 }

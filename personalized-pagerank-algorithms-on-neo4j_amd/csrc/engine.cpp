@@ -6,6 +6,7 @@
 // engine_internal.hpp).
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -35,6 +36,7 @@ int init_device_once(int device) {
   PPRHIP_TRY(init_kernels_walk());
   PPRHIP_TRY(init_kernels_select());
   PPRHIP_TRY(init_kernels_apbs());
+  PPRHIP_TRY(init_kernels_sort());
   if ((size_t)device >= g_dev_inited.size()) g_dev_inited.resize((size_t)device + 1, 0);
   g_dev_inited[device] = 1;
   return PPRHIP_OK;
@@ -286,13 +288,6 @@ static int build_sliced_layout(pprhip_graph* G, const std::vector<int32_t>& in_c
   return PPRHIP_OK;
 }
 
-int write_hist0(pprhip_graph* g, uint32_t nf, uint64_t ef) {
-  g->h_ctr->hist[0] = ((unsigned long long)nf << kPackShift) | ef;
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long),
-                                  hipMemcpyHostToDevice, g->stream));
-  return PPRHIP_OK;
-}
-
 int ensure_bwd_layout(pprhip_graph* P);
 
 
@@ -353,8 +348,8 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
           L.ccur = g->parent->c8cur;  // the slot's column of the shared array is all-zero here
         } else
           PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
-        PPRHIP_TRY(write_hist0(g, L.nf, L.ef));
-        PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, 0, L.nf, dense_thresh, true, L.ccur, L.dslot));
+        PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, 0, L.nf, dense_thresh, true, L.ccur, L.dslot,
+                                         ((unsigned long long)L.nf << kPackShift) | L.ef));
         L.dense_prepared = true;
         L.dense_run = 0;
         L.gs_dirty = false;
@@ -421,17 +416,19 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       }
       continue;
     }
-    // ---- a batch of sparse levels
-    PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->hist[0], 0, sizeof(unsigned long long) * (kMaxBatch + 1), g->stream));
+    // ---- a batch of sparse levels.  The first level's frontier travels as a kernel argument and its prepare kernel
+    // clears the counters of the levels behind it; only after a compaction (which counts on the device) the counters
+    // are cleared by a fill and read from memory.
     const bool first_prepared = L.dense_prepared;
+    unsigned long long pk0 = ((unsigned long long)L.nf << kPackShift) | L.ef;
     if (first_prepared) {
+      PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->hist[0], 0, sizeof(unsigned long long) * (kMaxBatch + 1), g->stream));
       // dense-prepared state -> list form; the compaction recounts (dead-end nodes carry no edges)
       PPRHIP_TRY(launch_compact_prepared(g, L.ccur, L.fcur, &g->ctr->hist[0], bwd));
       L.dense_prepared = false;
+      pk0 = ~0ull;
       // the column must be read (and handed back zeroed) before another sweep may run
       if (g->sync) PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-    } else {
-      PPRHIP_TRY(write_hist0(g, L.nf, L.ef));
     }
     if (g->sync) g->sync->release(g->slot_index);
     // the round-cut check looks at the state after exactly one sparse level
@@ -441,8 +438,9 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     for (int i = 0; i < n_batch; ++i) {
       const int fb = L.fcur ^ (i & 1);
       if (!(i == 0 && first_prepared))
-        PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot));
-      PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot));
+        PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot,
+                                         i == 0 ? pk0 : ~0ull));
+      PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot, i == 0 ? pk0 : ~0ull));
     }
     ktimer().end();
     PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->hist[0], &g->ctr->hist[0], sizeof(unsigned long long) * (kMaxBatch + 1),
@@ -533,8 +531,9 @@ int alloc_workspace(pprhip_graph* G) {
     PPRHIP_TRY(alloc_dev((void**)&G->blk_ndead, sizeof(uint32_t) * nblk));
   }
   G->sel_cap = 1u << 18;
-  PPRHIP_TRY(alloc_dev((void**)&G->sel_ids, sizeof(int32_t) * G->sel_cap));
-  PPRHIP_TRY(alloc_dev((void**)&G->sel_vals, sizeof(double) * G->sel_cap));
+  PPRHIP_TRY(alloc_dev((void**)&G->sel_blob, 16 + sizeof(SelRec) * (size_t)G->sel_cap));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(G->hist, 0, sizeof(uint32_t) * 4096, G->stream));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(G->sel_blob, 0, 16, G->stream));
   PPRHIP_TRY(alloc_dev((void**)&G->ctr, sizeof(DevCounters)));
   if (hipHostMalloc((void**)&G->h_ctr, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) {
     set_error("hipHostMalloc failed");
@@ -558,8 +557,8 @@ int alloc_workspace(pprhip_graph* G) {
 
 void free_workspace(pprhip_graph* g) {
   void* ptrs[] = {g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1],
-                  g->eoff[0], g->eoff[1], g->flags, g->armed, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist, g->sel_ids,
-                  g->sel_vals, g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
+                  g->eoff[0], g->eoff[1], g->flags, g->armed, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist, g->sel_blob,
+                  g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
@@ -745,7 +744,7 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
   } else if (L.nf || kind == 1) {
     // kind 1 also runs for an empty start set: parked nodes below min_rmax still leave the set
     // (Forward_Push.java:241-247)
-    PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->hist[kMaxBatch + 2], 0, sizeof(unsigned long long), g->stream));
+    // (its list counter, hist[kMaxBatch + 2], was cleared by the counting pass above)
     PPRHIP_TRY(launch_seed_list(g, a, kind, L.fcur, &g->ctr->hist[kMaxBatch + 2]));
   }
   return PPRHIP_OK;
@@ -760,20 +759,30 @@ int device_sum(pprhip_graph* g, const double* x, double* out) {
   return PPRHIP_OK;
 }
 
+// The counters a query only needs once, at its end, in one copy: dead-end pops of the push and the steps of the walks
+// run since the workspace was reset (dead_pops, mc_packed, walk_steps are adjacent in DevCounters).
 int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st) {
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->dead_pops, &g->ctr->dead_pops, sizeof(unsigned long long),
+  static_assert(offsetof(DevCounters, walk_steps) == offsetof(DevCounters, dead_pops) + 16, "one copy for both");
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->dead_pops, &g->ctr->dead_pops, 3 * sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  st.push_bytes += 16ull * (g->h_ctr->dead_pops - st.dead_end_pops);
   st.dead_end_pops = g->h_ctr->dead_pops;
-  st.push_bytes += 16ull * st.dead_end_pops;
+  const uint64_t steps = g->h_ctr->walk_steps;  // cumulative over the query's walk phases
+  if (steps > st.walk_steps) {
+    const uint64_t more = 12ull * (steps - st.walk_steps);
+    st.mc_bytes += more;
+    ktimer().add_bytes(PPRHIP_KERNEL_WALK, more);
+    st.walk_steps = steps;
+  }
   return PPRHIP_OK;
 }
 
 // walk phase shared by FORA whole-graph (variant 0) and top-k (variant 1)
+// (the plan counter is zero on entry: reset_query_state clears it and every walk kernel clears it again once the host
+// has read it; the step counter runs on over a query's walk phases and is read once, by read_dead_pops)
 int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,
                    double* target, pprhip_stats_t& st) {
-  PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->mc_packed, 0, sizeof(unsigned long long), g->stream));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->walk_steps, 0, sizeof(unsigned long long), g->stream));
   if ((double)nrw + (double)g->n >= (double)(1ull << kPackShift)) {
     set_error("walk budget %lld exceeds the engine's 2^36 walk limit", nrw);
     return PPRHIP_ERR_INVALID;
@@ -784,18 +793,13 @@ int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   const uint64_t n_src = g->h_ctr->mc_packed >> kPackShift;
   const uint64_t n_walks = g->h_ctr->mc_packed & kPackMask;
-  ktimer().begin(PPRHIP_KERNEL_WALK, 0);
+  const uint64_t bytes = 16ull * n_walks + 12ull * n_src;  // + 12 B per step, added when the step counter is read
+  ktimer().begin(PPRHIP_KERNEL_WALK, bytes);
   PPRHIP_TRY(launch_mc_walk(g, n_src, n_walks, alpha, seed, stream, variant == 0 ? 1 : 0, target));
   ktimer().end();
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->walk_steps, &g->ctr->walk_steps, sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, g->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   st.mc_sources += n_src;
   st.walks += n_walks;
-  st.walk_steps += g->h_ctr->walk_steps;
-  const uint64_t bytes = 12ull * g->h_ctr->walk_steps + 16ull * n_walks + 12ull * n_src;
   st.mc_bytes += bytes;
-  if (!ktimer().recs.empty() && ktimer().recs.back().cls == PPRHIP_KERNEL_WALK) ktimer().recs.back().bytes = bytes;
   return PPRHIP_OK;
 }
 
@@ -857,7 +861,7 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
   uint64_t expected = ~0ull;              // candidates the gather will find, known from the histograms
   for (int pass = 0; pbits < 64; ++pass) {
     const int dbits = std::min(12, 64 - pbits);
-    PPRHIP_TRY(launch_select_hist(g, x, g->n, prefix, pbits, dbits));
+    PPRHIP_TRY(launch_select_hist(g, x, g->n, prefix, pbits, dbits, pass == 0));
     PPRHIP_CHECK_HIP(hipMemcpyAsync(hist.data(), g->hist, sizeof(uint32_t) * (1u << dbits), hipMemcpyDeviceToHost,
                                     g->stream));
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
@@ -898,36 +902,31 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
     expected = above + hist[chosen];
     if (expected <= g->sel_cap) break;  // few enough candidates: finish on the host
   }
-  PPRHIP_TRY(launch_select_gather(g, x, g->n, have ? lower_bits : 1ull));
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, g->stream));
-  // the histograms already say how many candidates there are: fetch them with the counter, one round trip
+  PPRHIP_TRY(launch_select_gather(g, x, g->n, have ? lower_bits : 1ull, false));
+  // the histograms already say how many candidates there are: the count and the records come back in ONE copy
   const bool prefetched = expected > 0 && expected <= g->sel_cap;
-  std::vector<int32_t> pre_ids(prefetched ? expected : 0);
-  std::vector<double> pre_vals(prefetched ? expected : 0);
-  if (prefetched) {
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(pre_ids.data(), g->sel_ids, sizeof(int32_t) * expected, hipMemcpyDeviceToHost,
-                                    g->stream));
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(pre_vals.data(), g->sel_vals, sizeof(double) * expected, hipMemcpyDeviceToHost,
-                                    g->stream));
-  }
+  const size_t want = prefetched ? (size_t)expected : 0;
+  std::vector<char> blob(16 + sizeof(SelRec) * want);
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(blob.data(), g->sel_blob, blob.size(), hipMemcpyDeviceToHost, g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   st.select_bytes += 8ull * g->n;
-  uint64_t cnt = g->h_ctr->sel_count;
+  uint64_t cnt = 0;
+  std::memcpy(&cnt, blob.data(), 8);
   std::vector<IdVal> cand;
+  auto take_recs = [&](const char* p, uint64_t c) {
+    cand.resize(c);
+    const SelRec* r = reinterpret_cast<const SelRec*>(p);
+    for (uint64_t i = 0; i < c; ++i) cand[i] = {host_of(g)->h_new2old[r[i].id], r[i].val};
+  };
   if (prefetched && cnt == expected) {
-    cand.resize(cnt);
-    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {host_of(g)->h_new2old[pre_ids[i]], pre_vals[i]};
+    take_recs(blob.data() + 16, cnt);
   } else if (cnt <= g->sel_cap) {
-    std::vector<int32_t> ids(cnt);
-    std::vector<double> vals(cnt);
+    std::vector<char> more(sizeof(SelRec) * cnt);
     if (cnt) {
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(more.data(), g->sel_blob + 16, more.size(), hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     }
-    cand.resize(cnt);
-    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {host_of(g)->h_new2old[ids[i]], vals[i]};
+    take_recs(more.data(), cnt);
   } else {
     // more ties at the k-th value than the candidate buffer holds: finish on the whole vector
     std::vector<double> all(g->n);
@@ -1271,6 +1270,8 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   g->apbs_ws = nullptr;
   if (g->apbs_board) (void)hipFree(g->apbs_board);
   g->apbs_board = nullptr;
+  if (g->apbs_xl_ws) (void)hipFree(g->apbs_xl_ws);
+  g->apbs_xl_ws = nullptr;
   if (g->in_rec) (void)hipFree(g->in_rec);
   g->in_rec = nullptr;
   if (g->sl) {

@@ -84,6 +84,11 @@ struct SlicedLayout {
 
 enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
 
+struct SelRec {  // one candidate of a top-k selection / one entry >= threshold of a backward search
+  int32_t id, pad;
+  double val;
+};
+
 struct PushArgs {
   double alpha;
   double rmax;
@@ -145,6 +150,8 @@ struct KernelTimer {
     hipEvent_t b = next();
     if (b) (void)hipEventRecord(b, stream);
   }
+  // bytes of launches already recorded that only become known later (a walk kernel's steps)
+  void add_bytes(int cls, uint64_t bytes) { acc_bytes[cls] += bytes; }
   void reset() {
     used = 0;
     recs.clear();
@@ -245,6 +252,8 @@ struct pprhip_graph {
   void* in_rec = nullptr;
   char* apbs_ws = nullptr;
   void* apbs_board = nullptr;
+  char* apbs_xl_ws = nullptr;  // a few workspaces whose lists hold every node, for the searches that outgrow the others
+  uint32_t apbs_xl_blocks = 0, apbs_xl_cap_t = 0, apbs_xl_cap_f = 0;
   uint32_t apbs_blocks = 0, apbs_cap_t = 0, apbs_cap_f = 0, apbs_chunk = 0;
   pprhip::detail::FetchPipe* fetch = nullptr;  // delivery of batched queries' vectors to host memory (engine_internal.hpp)
   double* c8[2] = {nullptr, nullptr};
@@ -291,8 +300,7 @@ struct pprhip_graph {
   unsigned long long* blk_pack = nullptr;  // per-workgroup partial counters of the dense sweep
   double* blk_dead = nullptr;
   uint32_t* blk_ndead = nullptr;
-  int32_t* sel_ids = nullptr;      // candidate list
-  double* sel_vals = nullptr;
+  char* sel_blob = nullptr;        // candidate list: 16-byte header {count, -} + sel_cap records (SelRec)
   uint32_t sel_cap = 0;
   pprhip::DevCounters* ctr = nullptr;    // device
   pprhip::DevCounters* h_ctr = nullptr;  // pinned host mirror
@@ -311,10 +319,13 @@ struct pprhip_graph {
 namespace pprhip {
 
 // ---- kernels_push.hip
+// pk0: level 0's frontier (entries << 36 | edges) handed over as an argument; ~0: read it from ctr->hist[0] (a
+// compaction kernel wrote it)
 int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t nf_upper,
-                          unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot);
+                          unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot,
+                          unsigned long long pk0 = ~0ull);
 int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
-                       unsigned long long dense_thresh, int dead_slot);
+                       unsigned long long dense_thresh, int dead_slot, unsigned long long pk0 = ~0ull);
 // One dense level of a single query, block by block (blocks: nullptr / 1 = the whole sweep at once).  state_in:
 // device cell holding this level's GsState (a level launched behind another one without a host round trip; kGsNone:
 // the kernels return at once), or nullptr: `state0` applies.  hist_out / state_out (nullable) receive the frontier
@@ -363,24 +374,23 @@ int launch_mc_pure(pprhip_graph* g, int32_t src, uint64_t n_walks, double alpha,
                    double* target);
 
 // ---- kernels_apbs.hip
+struct TripleRec {  // one index entry of All-Pair-Backward-Search on the device: pi(v, t) = p
+  int32_t v, t;
+  double p;
+};
 struct ApbsBuffers {
   unsigned long long *next_target = nullptr, *out_count = nullptr, *out_valid = nullptr, *overflow_count = nullptr;
   unsigned long long *stat_pops = nullptr, *stat_edges = nullptr;
-  int32_t *out_v = nullptr, *out_t = nullptr, *overflow = nullptr;
-  double* out_p = nullptr;
+  TripleRec* out_rec = nullptr;  // the searches' entries >= threshold, 16-byte records
+  int32_t* overflow = nullptr;
   unsigned long long out_cap = 0;
   char* ws = nullptr;  // tier 2: per-workgroup dense workspaces (owned by the graph handle, see apbs_ws)
   void* board = nullptr;  // tier 2: one entry per workgroup on which it posts a level for helpers (zero at launch)
   unsigned long long* done_targets = nullptr;  // tier 2: targets finished in this launch
   uint32_t ws_blocks = 0, cap_t = 0, cap_f = 0, chunk = 0;
+  uint32_t helpers = 0;  // tier 2: workgroups a launch may use in all (those beyond ws_blocks only help)
   unsigned long long* dbg = nullptr;  // developer switch PPRHIP_APBS_DEBUG: 10 words per workgroup (kernels_apbs.hip)
 };
-struct TripleRec {  // one index entry of All-Pair-Backward-Search on the device: pi(v, t) = p
-  int32_t v, t;
-  double p;
-};
-int launch_pack_triples(pprhip_graph* g, const int32_t* v, const int32_t* t, const double* p, unsigned long long count,
-                        TripleRec* dst);
 int launch_owner_partition(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int world,
                            unsigned long long* cursors, TripleRec* out);
 size_t apbs_dense_bytes(uint32_t n, unsigned long long m, uint32_t cap_t, uint32_t cap_f, uint32_t chunk);  // one workgroup's tier-2 workspace
@@ -390,9 +400,16 @@ int launch_build_in_rec(pprhip_graph* g, void* rec);                  // rec: m 
 int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint32_t t_begin, uint32_t n_targets,
                 double alpha, double rmax, ApbsBuffers& b);
 
+// ---- kernels_sort.hip
+// rec[0 .. count) -> device arrays of keys (source << 32 | target) and values ordered by (source, target); the caller
+// frees both with hipFree
+int sort_triples_device(pprhip_graph* g, const TripleRec* rec, unsigned long long count, unsigned long long** keys_out,
+                        double** vals_out);
+int init_kernels_sort();
+
 // ---- kernels_select.hip
 int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned long long prefix, int prefix_bits,
-                       int digit_bits);
-int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits);
+                       int digit_bits, bool first_pass);
+int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits, bool zero_count);
 
 }  // namespace pprhip

@@ -226,16 +226,12 @@ int batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* stats_sum);
 // sharded call partitions by owner of the source and exchanges over RCCL before anything crosses PCIe
 struct TripleSink {
   virtual ~TripleSink() = default;
-  virtual int take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
-                          unsigned long long count) = 0;
+  virtual int take_device(pprhip_graph* g, const TripleRec* d_rec, unsigned long long count) = 0;
   virtual int take_host(pprhip_graph* g, std::vector<Triple>& more) = 0;
 };
 struct HostTripleSink : TripleSink {
   std::vector<Triple> tr;
-  std::vector<int32_t> h_v, h_t;
-  std::vector<double> h_p;
-  int take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
-                  unsigned long long count) override;
+  int take_device(pprhip_graph* g, const TripleRec* d_rec, unsigned long long count) override;
   int take_host(pprhip_graph* g, std::vector<Triple>& more) override;
 };
 struct DeviceTripleSink : TripleSink {
@@ -243,13 +239,16 @@ struct DeviceTripleSink : TripleSink {
   unsigned long long count = 0, cap = 0;
   ~DeviceTripleSink() override;
   int reserve(pprhip_graph* g, unsigned long long extra);
-  int take_device(pprhip_graph* g, const int32_t* d_v, const int32_t* d_t, const double* d_p,
-                  unsigned long long count) override;
+  int take_device(pprhip_graph* g, const TripleRec* d_rec, unsigned long long count) override;
   int take_host(pprhip_graph* g, std::vector<Triple>& more) override;
 };
 int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t t_begin, uint32_t t_end,
                      TripleSink& sink, pprhip_stats_t& st);
 int index_from_triples(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index_t** out);
+// the same from records in HBM: sorted by (source, target) on the device, k rule on the host; sources must lie in
+// [v_lo, v_hi)
+int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int k, uint32_t v_lo, uint32_t v_hi,
+                      pprhip_index_t** out);
 int index_concat(const std::vector<pprhip_index_t*>& parts, pprhip_index_t** out);
 
 }  // namespace detail

@@ -161,13 +161,13 @@ int fora_step(ForaRun& r, bool yield_dense) {
     }
     if (r.phase == ForaRun::kWalks) {
       leave_push(r);
-      PPRHIP_TRY(read_dead_pops(g, r.st));
       if (r.tm) r.tm->mark(1);
       // Fora_Whole_Graph.java:112-140
       const double nrw_d = r.omega_local * r.rsum_local;
       const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;
       if (!r.dead_src) PPRHIP_TRY(run_walk_phase(g, 0, r.alpha, r.rsum_local, nrw, r.seed, 0, g->reserve, r.st));
       if (r.tm) r.tm->mark(2);
+      PPRHIP_TRY(read_dead_pops(g, r.st));  // one read-back for the push's dead-end pops and the walks' steps
       r.st.rounds = (uint32_t)r.rounds;
       r.st.rsum = r.rsum_local;
       r.st.rmax_final = r.rmax_used;
@@ -329,11 +329,10 @@ int bwd_step(ForaRun& r, bool yield_dense) {
     const double threshold = r.rmax_local;
     unsigned long long thr_bits = 1ull;
     if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
-    PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits));  // Base_Whole_Graph.java:83 pi >= threshold
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sel_count, &g->ctr->sel_count, sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits, true));  // Base_Whole_Graph.java:83 pi >= threshold
+    unsigned long long cnt = 0;
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(&cnt, g->sel_blob, sizeof cnt, hipMemcpyDeviceToHost, g->stream));
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-    const uint64_t cnt = g->h_ctr->sel_count;
     const std::vector<int32_t>& n2o = host_of(g)->h_new2old;
     if (cnt > g->sel_cap) {
       std::vector<double> all(g->n);
@@ -341,12 +340,10 @@ int bwd_step(ForaRun& r, bool yield_dense) {
       for (uint32_t v = 0; v < g->n; ++v)  // copy_out already returned original ids
         if (all[v] > 0.0 && all[v] >= threshold) r.triples.push_back({(int32_t)v, r.target_orig, all[v]});
     } else if (cnt) {
-      std::vector<int32_t> ids(cnt);
-      std::vector<double> vals(cnt);
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(ids.data(), g->sel_ids, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, g->stream));
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(vals.data(), g->sel_vals, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
+      std::vector<SelRec> recs(cnt);
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(recs.data(), g->sel_blob + 16, sizeof(SelRec) * cnt, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-      for (uint64_t i = 0; i < cnt; ++i) r.triples.push_back({n2o[ids[i]], r.target_orig, vals[i]});
+      for (uint64_t i = 0; i < cnt; ++i) r.triples.push_back({n2o[recs[i].id], r.target_orig, recs[i].val});
     }
     r.phase = ForaRun::kDone;
   }

@@ -125,9 +125,7 @@ __device__ __forceinline__ uint32_t ap_slot(const ApTable& T, int32_t u, uint32_
 
 // output side shared by both tiers: triple buffer, retry list, counters
 struct ApOut {
-  int32_t* out_v;
-  int32_t* out_t;
-  double* out_p;
+  TripleRec* out_rec;
   unsigned long long out_cap;
   unsigned long long* out_count;
   unsigned long long* out_valid;
@@ -178,8 +176,16 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
     if (tid == 0) {
       s_used_count = 0;
       s_overflow = 0;
+      // the record buffer is full (somebody's entries did not fit): a search started now could not hand over its
+      // entries either, so it is not run but listed for the host's next pass
+      s_tot = (__hip_atomic_load(O.out_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ~0ull) ? 1ull : 0ull;
+      if (s_tot) O.overflow_list[atomic_add_u64(O.overflow_count, 1ull)] = -(t_old + 1);
     }
     __syncthreads();
+    if (s_tot) {
+      __syncthreads();
+      continue;
+    }
     uint32_t nf = 0;
     if (in_rp[t + 1] == in_rp[t]) {  // Backward_Search.java:46-49: reserve = {t: 1.0}
       if (tid == 0) {
@@ -318,9 +324,7 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
           const unsigned long long ex =
               block_excl_scan_256<unsigned long long>(take ? 1ull : 0ull, s_scan64, &chunk_total);
           if (take) {
-            O.out_v[at + ex] = new2old[T.keys[s]];
-            O.out_t[at + ex] = t_old;
-            O.out_p[at + ex] = T.rsv[s];
+            O.out_rec[at + ex] = TripleRec{new2old[T.keys[s]], t_old, T.rsv[s]};
           }
           at += chunk_total;
         }
@@ -611,7 +615,11 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
                                                             unsigned long long* done_targets,
                                                             unsigned long long* n_open,
                                                             unsigned long long* abort_word, DnDims D, int share,
+                                                            uint32_t n_owners,
                                                             unsigned long long* __restrict__ dbg) {
+  // n_owners: the workgroups 0 .. n_owners - 1 have a workspace and take targets; the others only help with posted
+  // levels (the pass for the few searches whose lists need room for every node: a handful of full-size workspaces,
+  // the whole chip working on their levels)
   // dbg (developer switch PPRHIP_APBS_DEBUG, else nullptr; HOST memory): per workgroup {searches, edges of its own
   // searches, ticks of the 100 MHz clock spent in pops + scans, own edges, waiting for helpers, emission, clean-up,
   // helping / idle, the tick at which the workgroup ended, and where it is: stage << 32 | detail (printed by the
@@ -642,6 +650,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
   uint32_t seq = 0;  // even: this workgroup's board entry is closed
 
   for (;;) {
+    if (blockIdx.x >= n_owners) break;
     if (tid == 0) s_t = atomic_add_u64(next_target, 1ull);
     __syncthreads();
     const unsigned long long ti = s_t;
@@ -651,6 +660,19 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     const int32_t t_old = target_list[ti];
     const int32_t t = old2new[t_old];
     uint32_t nf = 0, which = 0;
+    if (tid == 0) {
+      // the record buffer is full: not run, listed for the host's next pass (see the LDS tier)
+      s_job[1] = (__hip_atomic_load(O.out_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ~0ull) ? 1u : 0u;
+      if (s_job[1]) {
+        O.overflow_list[atomic_add_u64(O.overflow_count, 1ull)] = -(t_old + 1);
+        atomic_add_u64(done_targets, 1ull);
+      }
+    }
+    __syncthreads();
+    if (s_job[1]) {
+      __syncthreads();
+      continue;
+    }
     if (tid == 0) {
       s_pcount = 0;
       s_tcount = 0;
@@ -855,9 +877,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
           const unsigned long long ex2 =
               block_excl_scan_n<unsigned long long, kDnWaves>(take ? 1ull : 0ull, s_scan64, &chunk_total);
           if (take) {
-            O.out_v[at + ex2] = new2old[v];
-            O.out_t[at + ex2] = t_old;
-            O.out_p[at + ex2] = r;
+            O.out_rec[at + ex2] = TripleRec{new2old[v], t_old, r};
           }
           at += chunk_total;
         }
@@ -902,7 +922,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
       }
       __syncthreads();
       // (one word polled while nothing is posted: the board is only scanned when somebody has a level open)
-      if (s_job[2] && (uint32_t)tid < gridDim.x && (uint32_t)tid != blockIdx.x) {
+      if (s_job[2] && (uint32_t)tid < n_owners && (uint32_t)tid != blockIdx.x) {
         const unsigned long long nx = dn_load(&board[tid].next);
         // the nearest open entry after this workgroup's own: helpers spread over the owners instead of all taking the
         // first one (every append of a shared level is an atomic on the owner's counters)
@@ -971,18 +991,6 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
 // ------------------------------------------------------------------------------------------------
 // sharded All-Pair: index entries as 16-byte records, partitioned by the owner of their source
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_triples(const int32_t* __restrict__ v, const int32_t* __restrict__ t,
-                                                       const double* __restrict__ p, unsigned long long count,
-                                                       TripleRec* __restrict__ dst) {
-  for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256ull) {
-    TripleRec r;
-    r.v = v[i];
-    r.t = t[i];
-    r.p = p[i];
-    dst[i] = r;
-  }
-}
-
 // rank that owns source v when [0, n) is cut into `world` contiguous ranges (the first n % world one longer)
 __device__ __forceinline__ uint32_t owner_of(uint32_t v, uint32_t base, uint32_t rem) {
   const uint32_t cut = rem * (base + 1u);
@@ -1029,15 +1037,6 @@ __global__ __launch_bounds__(256) void k_owner_partition(const TripleRec* __rest
   }
 }
 
-int launch_pack_triples(pprhip_graph* g, const int32_t* v, const int32_t* t, const double* p, unsigned long long count,
-                        TripleRec* dst) {
-  if (!count) return PPRHIP_OK;
-  const uint32_t grid = (uint32_t)std::min<unsigned long long>((count + 255) / 256, 4096ull);
-  k_pack_triples<<<dim3(grid), dim3(256), 0, g->stream>>>(v, t, p, count, dst);
-  PPRHIP_CHECK_HIP(hipGetLastError());
-  return PPRHIP_OK;
-}
-
 // cursors: `world` counters, zero before pass 0 (counts), holding the segment starts before pass 1
 int launch_owner_partition(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int world,
                            unsigned long long* cursors, TripleRec* out) {
@@ -1070,7 +1069,7 @@ int launch_build_in_rec(pprhip_graph* g, void* rec) {
 
 int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint32_t t_begin, uint32_t n_targets,
                 double alpha, double rmax, ApbsBuffers& b) {
-  const ApOut O{b.out_v, b.out_t, b.out_p, b.out_cap, b.out_count, b.out_valid, b.overflow, b.overflow_count,
+  const ApOut O{b.out_rec, b.out_cap, b.out_count, b.out_valid, b.overflow, b.overflow_count,
                 b.stat_pops, b.stat_edges};
   const InRec* rec = (const InRec*)g->in_rec;
   if (dense_tier) {
@@ -1078,12 +1077,15 @@ int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint
       set_error("All-Pair dense tier: no target list or workspace");
       return PPRHIP_ERR_STATE;
     }
-    const uint32_t grid = std::min<uint32_t>(std::min<uint32_t>(b.ws_blocks, (uint32_t)kDnThreads), std::max(1u, n_targets));
     const char* sh = getenv("PPRHIP_APBS_SHARE");  // developer switch: 0 = every search stays on its own workgroup
     const int share = (sh && sh[0] == '0') ? 0 : 1;
+    const uint32_t owners = std::min<uint32_t>(std::min<uint32_t>(b.ws_blocks, (uint32_t)kDnThreads), std::max(1u, n_targets));
+    // helpers beyond the owners (b.helpers: workgroups the launch may use in all) only make sense when levels are shared
+    const uint32_t grid = share ? std::max(owners, std::min<uint32_t>(b.helpers, (uint32_t)kDnThreads)) : owners;
     k_apbs_dense<<<dim3(grid), dim3(kDnThreads), 0, g->stream>>>(
         d_targets, n_targets, b.next_target, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O, b.ws, (DnBoard*)b.board,
-        b.done_targets, b.done_targets + 1, b.done_targets + 2, dims_of(g->n, (unsigned long long)g->m, b.cap_t, b.cap_f, b.chunk), share, b.dbg);
+        b.done_targets, b.done_targets + 1, b.done_targets + 2, dims_of(g->n, (unsigned long long)g->m, b.cap_t, b.cap_f, b.chunk), share,
+        owners, b.dbg);
   } else {
     const uint32_t grid = std::min<uint32_t>((uint32_t)g->n_cus * 2u, std::max(1u, n_targets));
     k_apbs_lds<<<dim3(grid), dim3(256), 0, g->stream>>>(d_targets, t_begin, n_targets, b.next_target, g->in_rp, rec,

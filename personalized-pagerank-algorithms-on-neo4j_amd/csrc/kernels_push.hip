@@ -61,10 +61,14 @@ __global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restric
                                                          double* __restrict__ res, double* __restrict__ reserve,
                                                          double* __restrict__ cF, CView c_dense,
                                                          DevCounters* ctr, int level, unsigned long long dense_thresh,
-                                                         int dead_slot, PushArgs a) {
+                                                         int dead_slot, unsigned long long pk0, PushArgs a) {
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
-  const unsigned long long pk = ctr->hist[level];
+  // the first level of a batch gets its frontier from the host as an argument (pk0 != ~0) and clears the counters of
+  // the levels behind it: no copy and no fill on the stream for what two words and eight zeros say
+  if (level == 0 && pk0 != ~0ull && blockIdx.x == 0 && threadIdx.x == 0)
+    for (int i = 1; i <= kMaxBatch; ++i) ctr->hist[i] = 0ull;
+  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
   if (!level_runs(pk, level, dense_thresh)) return;
   const uint32_t nf = (uint32_t)(pk >> kPackShift);
   double dead = 0.0;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
                                                       int32_t* __restrict__ Fn,
                                                       uint32_t* __restrict__ eoffn, DevCounters* ctr, int level,
                                                       unsigned long long dense_thresh, int dead_slot,
-                                                      unsigned long long comb_min, PushArgs a) {
+                                                      unsigned long long comb_min, unsigned long long pk0, PushArgs a) {
   __shared__ uint32_t s_eoff[kStageCap + 1];
   __shared__ uint32_t s_row[kStageCap];
   __shared__ double s_c[kStageCap];
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
   __shared__ int32_t s_key[kCombSlots];
   __shared__ double s_val[kCombSlots];
   const int tid = threadIdx.x;
-  const unsigned long long pk = ctr->hist[level];
+  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
   if (!level_runs(pk, level, dense_thresh)) return;
   const uint32_t nf = (uint32_t)(pk >> kPackShift);
   const unsigned long long E = pk & kPackMask;
@@ -1155,9 +1159,11 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_count_active(uint32_t n, const double* __restrict__ res,
                                                        const uint32_t* __restrict__ out_rp,
                                                        const uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
-                                                       unsigned long long* __restrict__ blk_pack, PushArgs a) {
+                                                       unsigned long long* __restrict__ blk_pack,
+                                                       unsigned long long* zero_word, PushArgs a) {
   __shared__ unsigned long long s_red2[4];
   unsigned long long pack = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0ull;  // the list counter of the seeding pass that follows
   // wave-uniform trip count: a wave covers 64 consecutive nodes, whose "armed" bits it writes as one 64-bit word
   for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += gridDim.x * blockDim.x) {
     const uint32_t v = base + (threadIdx.x & 63u);
@@ -1351,18 +1357,19 @@ static inline CView cview(pprhip_graph* g, int cbuf) {
   }
 
 int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t nf_upper,
-                          unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot) {
+                          unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot,
+                          unsigned long long pk0) {
   const uint32_t grid = grid_for(nf_upper, 256, 512);
   const CView cd = scatter_dense ? cview(g, cbuf) : CView{nullptr, 1, 0};
   DISPATCH_MODE(a.mode, k_sparse_prepare<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
                             g->F[fbuf], g->out_rp, g->residue, g->reserve, g->cF, cd, g->ctr, level, dense_thresh,
-                            dead_slot, a));
+                            dead_slot, pk0, a));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
 int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
-                       unsigned long long dense_thresh, int dead_slot) {
+                       unsigned long long dense_thresh, int dead_slot, unsigned long long pk0) {
   const uint32_t grid = grid_for(ef_upper, kPushTile, 2048);
   const bool bwd = a.mode == kBackward;
   const uint32_t* trp = bwd ? g->in_rp : g->out_rp;
@@ -1373,7 +1380,7 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
   DISPATCH_MODE(a.mode, k_sparse_push<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
                             g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_ext, g->in_rp, g->residue, g->flags,
                             g->armed, g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot,
-                            comb_min, a));
+                            comb_min, pk0, a));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -1561,10 +1568,10 @@ int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int o
   const uint32_t grid = grid_for(g->n, 256 * 8, 1024);
   if (seed_kind == 0)
     k_count_active<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->armed,
-                                                               g->blk_pack, a);
+                                                               g->blk_pack, &g->ctr->hist[kMaxBatch + 2], a);
   else
     k_count_active<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->armed,
-                                                               g->blk_pack, a);
+                                                               g->blk_pack, &g->ctr->hist[kMaxBatch + 2], a);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return reduce_partials(g, grid, out_slot, 0, false);
 }

@@ -14,8 +14,9 @@ constexpr int kHistBins = 4096;
 
 __global__ __launch_bounds__(256) void k_select_hist(const double* __restrict__ x, uint32_t n,
                                                       unsigned long long prefix, int prefix_bits, int digit_bits,
-                                                      uint32_t* __restrict__ hist) {
+                                                      uint32_t* __restrict__ hist, unsigned long long* zero_word) {
   __shared__ uint32_t s_hist[kHistBins];
+  if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0ull;  // the candidate counter of the gather to come
   const int bins = 1 << digit_bits;
   for (int b = threadIdx.x; b < bins; b += blockDim.x) s_hist[b] = 0;
   __syncthreads();
@@ -34,9 +35,15 @@ __global__ __launch_bounds__(256) void k_select_hist(const double* __restrict__ 
   }
 }
 
+// Candidates are 16-byte records behind a 16-byte header {count, -}: one copy brings the count and the records to the
+// host.  Block 0 leaves the histogram of the select that has just been read out all-zero for the next one.
 __global__ __launch_bounds__(256) void k_select_gather(const double* __restrict__ x, uint32_t n,
-                                                        unsigned long long lower_bits, int32_t* __restrict__ ids,
-                                                        double* __restrict__ vals, uint32_t cap, DevCounters* ctr) {
+                                                        unsigned long long lower_bits, char* __restrict__ blob,
+                                                        uint32_t cap, uint32_t* __restrict__ hist) {
+  unsigned long long* count = reinterpret_cast<unsigned long long*>(blob);
+  SelRec* recs = reinterpret_cast<SelRec*>(blob + 16);
+  if (blockIdx.x == 0)
+    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) hist[b] = 0u;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nround = (n + stride - 1) / stride * stride;
   const int lane = lane_id();
@@ -51,14 +58,11 @@ __global__ __launch_bounds__(256) void k_select_gather(const double* __restrict_
     if (mask == 0) continue;
     const int leader = __ffsll((long long)mask) - 1;
     unsigned long long base = 0;
-    if (lane == leader) base = atomic_add_u64(&ctr->sel_count, (unsigned long long)__popcll(mask));
+    if (lane == leader) base = atomic_add_u64(count, (unsigned long long)__popcll(mask));
     base = __shfl(base, leader);
     if (take) {
       const unsigned long long pos = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-      if (pos < cap) {
-        ids[pos] = (int32_t)i;
-        vals[pos] = v;
-      }
+      if (pos < cap) recs[pos] = SelRec{(int32_t)i, 0, v};
     }
   }
 }
@@ -69,23 +73,25 @@ int init_kernels_select() {  // loads this file's code object on the current dev
   return PPRHIP_OK;
 }
 
+// first_pass: the histogram is all-zero already (the gather of the select before left it so; alloc_workspace zeroes
+// it once) and the pass clears the candidate counter for the gather that follows
 int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned long long prefix, int prefix_bits,
-                       int digit_bits) {
+                       int digit_bits, bool first_pass) {
   uint64_t b = ((uint64_t)n + 256 * 8 - 1) / (256 * 8);
   const uint32_t grid = (uint32_t)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->hist, 0, sizeof(uint32_t) * kHistBins, g->stream));
+  if (!first_pass) PPRHIP_CHECK_HIP(hipMemsetAsync(g->hist, 0, sizeof(uint32_t) * kHistBins, g->stream));
   hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(256), 0, g->stream, x, n, prefix, prefix_bits, digit_bits,
-                     g->hist);
+                     g->hist, first_pass ? reinterpret_cast<unsigned long long*>(g->sel_blob) : nullptr);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
-int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits) {
+int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits, bool zero_count) {
   uint64_t b = ((uint64_t)n + 255) / 256;
   const uint32_t grid = (uint32_t)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->sel_count, 0, sizeof(unsigned long long), g->stream));
-  hipLaunchKernelGGL(k_select_gather, dim3(grid), dim3(256), 0, g->stream, x, n, lower_bits, g->sel_ids, g->sel_vals,
-                     g->sel_cap, g->ctr);
+  if (zero_count) PPRHIP_CHECK_HIP(hipMemsetAsync(g->sel_blob, 0, sizeof(unsigned long long), g->stream));
+  hipLaunchKernelGGL(k_select_gather, dim3(grid), dim3(256), 0, g->stream, x, n, lower_bits, g->sel_blob, g->sel_cap,
+                     g->hist);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

@@ -173,6 +173,8 @@ __global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long l
   __shared__ uint32_t s_e0;
   const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
   unsigned long long steps_total = 0;
+  // the host has read the plan counter (its values are this launch's arguments): cleared for the next plan
+  if (blockIdx.x == 0 && tid == 0) ctr->mc_packed = 0ull;
   const unsigned long long n_chunks = (n_walks + kWalkChunk - 1) / kWalkChunk;
   for (unsigned long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
     const unsigned long long lo = ch * kWalkChunk;

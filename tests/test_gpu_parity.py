@@ -416,15 +416,18 @@ def test_all_pair_tiers_rmat12(pkg, orc, rmat12, dev_rmat12, tier, monkeypatch):
         ix.close()
 
 
-@pytest.mark.parametrize("cap_t,cap_f", [(8, 4096), (4096, 3), (5, 2)])
-def test_all_pair_dense_tier_list_overflows(pkg, orc, rmat12, cap_t, cap_f, monkeypatch):
+@pytest.mark.parametrize("cap_t,cap_f,xl", [(8, 4096, True), (4096, 3, True), (4096, 3, False), (5, 2, False)])
+def test_all_pair_dense_tier_list_overflows(pkg, orc, rmat12, cap_t, cap_f, xl, monkeypatch):
     """The dense tier's lists are bounded: when the clean-up list overflows the search still finishes (the whole
-    vector is cleared instead), when a frontier or the popped-node list overflows the search is handed to the
-    whole-vector tier - and the next search of the same workgroup must find all-zero vectors either way.  A fresh
-    handle, so that the workspace is built with the shrunken lists."""
+    vector is cleared instead); when a frontier or the popped-node list overflows the search is run again on one of
+    the few workspaces whose lists hold every node (the other workgroups helping), or - with that pass switched off -
+    by the whole-vector tier; and the next search of the same workgroup must find all-zero vectors either way.  A
+    fresh handle, so that the workspace is built with the shrunken lists."""
     monkeypatch.setenv("PPRHIP_APBS_TIER", "2")
     monkeypatch.setenv("PPRHIP_APBS_CAP_T", str(cap_t))
     monkeypatch.setenv("PPRHIP_APBS_CAP_F", str(cap_f))
+    if not xl:
+        monkeypatch.setenv("PPRHIP_APBS_NO_XL", "1")
     og = to_oracle(orc, rmat12)
     with pkg.Graph(rmat12) as g:
         for lo, hi in ((100, 400), (0, 300)):            # twice: the second call starts from the vectors the first left
@@ -435,7 +438,7 @@ def test_all_pair_dense_tier_list_overflows(pkg, orc, rmat12, cap_t, cap_f, monk
             assert np.max(np.abs(vl - ovl)) <= TOL_PUSH
             assert st.rounds == hi - lo                  # every target started in the dense tier
             if cap_f < 100:
-                assert st.dense_nodes > 0                # and some were handed on
+                assert (st.dense_nodes > 0) == (not xl)  # handed on to the whole-vector tier only without the full-size pass
             ix.close()
 
 
