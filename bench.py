@@ -204,6 +204,8 @@ def main():
     t0 = time.time()
     g = pkg.Graph(host, device=local_rank)
     t_lift = time.time() - t0
+    if rank == 0:
+        note("graph lifted (%.1f s generate / load, %.1f s lift)" % (t_gen, t_lift))
     conf = pkg.conf_whole_graph(host.n, host.m, ALPHA)
     tuning = pkg.tuning_batch() if args.mode == "batch" else pkg.tuning_default()
     for kv in filter(None, args.tuning.split(",")):
@@ -286,6 +288,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if rank == 0:
+        note("timed region done: %.1f queries/s" % (args.steps * q * world / elapsed))
     check = None
     if args.mode == "batch" and last:
         check = self_check(pkg, store, srcs[last["step"]], last["ids"], last["vals"], last["nsel"], last["pq"], host.n)
@@ -299,6 +303,8 @@ def main():
     all_pair_scaling = None
     if not args.no_extras and args.mode == "batch":
         all_pair_scaling = all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xdev)
+        if rank == 0:
+            note("All-Pair scaling sample done")
 
     if rank == 0:
         n_queries = args.steps * q * world
@@ -374,9 +380,12 @@ def main():
         extras = solo and not args.no_extras
         if extras:
             out.update(delivery_samples(pkg, g, store, rng, live_ids, host, conf, q))
+            note("delivery samples done")
             out["one_query_at_a_time"] = single_mode_sample(pkg, g, srcs[args.warmup], conf, args, host)
             out["topk_sample"] = topk_sample(pkg, g, srcs[args.warmup])
+            note("single-query and top-k samples done")
             out["all_pair_sample"] = all_pair_sample(pkg, g, host)
+            note("All-Pair sample done")
         if store is not None:
             store.close()
             store = None
@@ -384,9 +393,12 @@ def main():
         g = None
         if r24_child is not None:
             out["all_pair_rmat24"] = finish_rmat24(r24_child)
+            note("R-MAT 24 All-Pair child done")
         if solo and not args.no_pmc:
             apply_counters(out, pmc_traffic(args, host), avg_us, extras)
+            note("counter passes done")
         if cpu_child is not None:
+            note("waiting for the CPU baseline child")
             out["cpu_baseline"] = finish_cpu_baseline(cpu_child)
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_faithful"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -544,6 +556,14 @@ def _quiet_stdout(fn):
         sys.stdout.flush()
         os.dup2(saved, 1)
         os.close(saved)
+
+
+def note(msg):
+    """Progress line on stderr (stdout is the one JSON line; a long run that prints nothing looks hung)."""
+    print("[bench %6.1f s] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.time()
 
 
 def _child_json(child, limit, what):
@@ -775,7 +795,9 @@ def pmc_traffic(args, host):
     work = tempfile.mkdtemp(prefix="pprhip_pmc_", dir="/tmp")
     try:
         fetch = _phases(_pmc_pass("FETCH_SIZE", args, work))
+        note("counter pass FETCH_SIZE done")
         write = _phases(_pmc_pass("WRITE_SIZE", args, work))
+        note("counter pass WRITE_SIZE done")
     except Exception as e:  # the line is still valid without counters; say why they are missing
         shutil.rmtree(work, ignore_errors=True)
         return {"source": "unmeasured: %s" % str(e)[:200]}
@@ -945,7 +967,31 @@ def cpu_baseline_child(args):
         t_start = time.time()
         conf = og.conf_whole(ALPHA)
         _, omega = orc.fora_whole_params(conf, EPS)
-        # ---- 1. one faithful query to the end (one thread) + the array port on three sources (three threads)
+        # physical cores (hardware threads / SMT siblings): one query per core
+        try:
+            ids = set()
+            phys = core = None
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        ids.add((phys, core))
+                    phys = core = None
+            pcores = len(ids) or cores
+        except Exception:  # noqa: BLE001
+            pcores = cores
+        # ---- 1. every physical core, one query each (while the parent's GPU measurements run: they need one core)
+        par_srcs = (live[4:4 + pcores] or live[:1])
+        p = base.fora_array_parallel(og, par_srcs, EPS, ALPHA, seed=3, walk_divisor=args.cpu_walk_divisor, threads=pcores)
+        # the run thinned the walks; per_query_s holds every query's time scaled to all of its walks, measured while the
+        # other threads were running theirs: concurrent throughput = sum of the per-thread rates
+        all_cores_qps = sum(1.0 / t for t in p["per_query_s"] if t > 0)
+        pq = sorted(p["per_query_s"])
+        # ---- 2. on the then quiet machine: one faithful query to the end (one thread) + the array port on three
+        # sources (three threads)
         box = {}
 
         def run_arrays():
@@ -959,24 +1005,17 @@ def cpu_baseline_child(args):
         th.join()
         arr = box["arr"]
         h_query = h["push_s"] + h["walk_s"]
-        # ---- 2. every hardware thread, one query each
-        par_srcs = (live[4:4 + cores] or live[:1])
-        p = base.fora_array_parallel(og, par_srcs, EPS, ALPHA, seed=3, walk_divisor=args.cpu_walk_divisor, threads=cores)
-        # the run thinned the walks; per_query_s holds every query's time scaled to all of its walks, measured while the
-        # other threads were running theirs: concurrent throughput = sum of the per-thread rates
-        all_cores_qps = sum(1.0 / t for t in p["per_query_s"] if t > 0)
-        pq = sorted(p["per_query_s"])
         wall = time.time() - t_start
         res = {
             "value": round(1.0 / h_query, 6) if h_query > 0 else None, "unit": "queries/s", "cores": 1, "kind": "port",
             "sample": "faithful (hash-map-shaped) port of Forward_Push/Fora_Whole_Graph/Monte_Carlo, ONE query on source %d "
                       "run to the end on one thread: %d turn(s) of the clock-driven loop, %.1f s of pushes (%d edge "
                       "pushes, %.2f M/s), %d walks in %.1f s (%.2f M/s) = %.1f s; beside it the dense-array port on 3 "
-                      "sources in full (3 threads), then the array port on all %d hardware threads; %.0f s of wall time "
-                      "in a background process while the GPU measurements ran"
+                      "sources in full (3 threads), after the array port had run on all %d physical cores; %.0f s of wall time "
+                      "in a background process beside the GPU measurements"
                       % (live[0], h["rounds"], h["push_s"], h["edge_pushes"],
                          h["edge_pushes"] / h["push_s"] / 1e6 if h["push_s"] > 0 else 0.0, h["walks_run"], h["walk_s"],
-                         h["walks_run"] / h["walk_s"] / 1e6 if h["walk_s"] > 0 else 0.0, h_query, cores, wall),
+                         h["walks_run"] / h["walk_s"] / 1e6 if h["walk_s"] > 0 else 0.0, h_query, pcores, wall),
             "seconds_per_query": round(h_query, 2),
             "faithful": {"turns": h["rounds"], "push_s": round(h["push_s"], 2), "walk_s": round(h["walk_s"], 2),
                          "edge_pushes": int(h["edge_pushes"]), "walks": int(h["walks_run"]),
@@ -989,12 +1028,12 @@ def cpu_baseline_child(args):
                       "sources": [int(s) for s in live[1:4]],
                       "sample": "dense-array port, three sources in full (every walk), one thread each, while the "
                                 "faithful query ran on a fourth"},
-            "all_cores": {"value": round(all_cores_qps, 5), "cores": int(min(cores, len(par_srcs))),
+            "all_cores": {"value": round(all_cores_qps, 5), "cores": int(min(pcores, len(par_srcs))),
                           "queries": len(par_srcs), "wall_s_thinned_walks": round(p["wall_s"], 2),
                           "seconds_per_query_min_median_max": [round(pq[0], 1), round(pq[len(pq) // 2], 1), round(pq[-1], 1)],
-                          "sample": "dense-array port, one query per hardware thread on %d live sources at once; every "
+                          "sample": "dense-array port, one query per physical core on %d live sources at once; every "
                                     "%d-th walk run, per-query times scaled to all walks" % (len(par_srcs), args.cpu_walk_divisor)},
-            "host": {"nproc": cores, "model": model},
+            "host": {"nproc": cores, "physical_cores": pcores, "model": model},
         }
     except Exception as e:  # noqa: BLE001
         res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}

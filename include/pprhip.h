@@ -352,6 +352,16 @@ int pprhip_topk_gather(pprhip_comm_t* c, const int32_t* ids, const double* vals,
  * outside these calls) calls pprhip_comm_abort before pprhip_comm_destroy so that its peers are released.
  * (No reference counterpart: the Java is single-threaded, Gen_Util.java:208-232 / Base_Whole_Graph.java:76-92.) */
 int pprhip_comm_abort(pprhip_comm_t* c);
+/* The exchange's partition rule on the host (what k_owner_partition does to the device records): counts_out[world] =
+ * entries whose source each rank owns, order_out[count] = the entries' indices owner by owner (stable).  With
+ * pprhip_index_from_entries it lets a caller (the CPU multi-process tests, a host-side transport) carry the sharded
+ * All-Pair over a fabric of its own with the library's own rule and finalisation (Base_Whole_Graph.java:84-86). */
+int pprhip_owner_partition(uint32_t n, int world, const int32_t* sources, uint64_t count, uint64_t* counts_out,
+                           uint64_t* order_out);
+/* The finished index (k rule of Base_Whole_Graph.java:112-163 applied per source) from `count` entries
+ * pi(sources[i], targets[i]) = values[i] in any order; ids are validated against [0, n). */
+int pprhip_index_from_entries(uint32_t n, const int32_t* sources, const int32_t* targets, const double* values,
+                              uint64_t count, int k, pprhip_index_t** index_out);
 
 /* ---------------------------------------------------------------- ground truth (a12) */
 /* Power_Method.computeWholeGraphPPR (Power_Method.java:44-101): `iters` synchronous sweeps. */

@@ -78,7 +78,7 @@ EXPORTS = [
     "pprhip_results_info", "pprhip_results_fetch", "pprhip_results_sum", "pprhip_fora_batch_single_source_resident",
     "pprhip_fora_batch", "pprhip_all_pair_backward_multi", "pprhip_comm_unique_id", "pprhip_comm_create",
     "pprhip_comm_destroy", "pprhip_comm_info", "pprhip_shard_target_range", "pprhip_all_pair_backward_sharded",
-    "pprhip_topk_gather", "pprhip_comm_abort",
+    "pprhip_topk_gather", "pprhip_comm_abort", "pprhip_owner_partition", "pprhip_index_from_entries",
 ]
 COMM_ID_BYTES = 128
 
@@ -154,6 +154,8 @@ def lib():
     L.pprhip_all_pair_backward_sharded.argtypes = [vp, dbl, dbl, ci, P(vp), P(Stats)]
     L.pprhip_topk_gather.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
     L.pprhip_comm_abort.argtypes = [vp]
+    L.pprhip_owner_partition.argtypes = [u32, ci, vp, u64, vp, vp]
+    L.pprhip_index_from_entries.argtypes = [u32, vp, vp, vp, u64, ci, P(vp)]
     L.pprhip_backward_push.argtypes = [vp, i32, dbl, dbl, vp, vp, P(Stats)]
     L.pprhip_all_pair_backward.argtypes = [vp, dbl, dbl, ci, u32, u32, P(vp), P(Stats)]
     L.pprhip_index_merge.argtypes = [P(vp), ci, ci, P(vp)]
@@ -357,6 +359,25 @@ def merge_indexes(shards, k):
     arr = (C.c_void_p * len(shards))(*[s.h for s in shards])
     out = C.c_void_p()
     _check(lib().pprhip_index_merge(arr, len(shards), k, C.byref(out)))
+    return Index(out)
+
+
+def owner_partition(n, world, sources):
+    """The sharded All-Pair's partition rule on the host: (counts[world], order[count]) - entries owner by owner."""
+    sources = np.ascontiguousarray(sources, dtype=np.int32)
+    counts = np.zeros(world, dtype=np.uint64)
+    order = np.zeros(max(sources.size, 1), dtype=np.uint64)
+    _check(lib().pprhip_owner_partition(n, world, _ptr(sources), sources.size, _ptr(counts), _ptr(order)))
+    return counts, order[:sources.size]
+
+
+def index_from_entries(n, sources, targets, values, k):
+    """The finished index from (source, target, value) entries in any order (k rule applied per source)."""
+    sources = np.ascontiguousarray(sources, dtype=np.int32)
+    targets = np.ascontiguousarray(targets, dtype=np.int32)
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    out = C.c_void_p()
+    _check(lib().pprhip_index_from_entries(n, _ptr(sources), _ptr(targets), _ptr(values), sources.size, k, C.byref(out)))
     return Index(out)
 
 

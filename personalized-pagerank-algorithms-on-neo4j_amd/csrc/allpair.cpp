@@ -790,6 +790,17 @@ int pprhip_index_from_arrays(uint32_t n, const uint64_t* offsets, const int32_t*
   return PPRHIP_OK;
 }
 
+int pprhip_index_from_entries(uint32_t n, const int32_t* sources, const int32_t* targets, const double* values,
+                              uint64_t count, int k, pprhip_index_t** index_out) {
+  if (!index_out || (count && (!sources || !targets || !values))) {
+    set_error("pprhip_index_from_entries: null argument");
+    return PPRHIP_ERR_INVALID;
+  }
+  std::vector<Triple> tr(count);
+  for (uint64_t i = 0; i < count; ++i) tr[i] = Triple{sources[i], targets[i], values[i]};
+  return index_from_triples(n, tr, k, index_out);  // validates the ids, buckets by source, applies the k rule
+}
+
 int pprhip_index_info(const pprhip_index_t* ix, uint32_t* n, uint64_t* entries) {
   if (!ix) {
     set_error("pprhip_index_info: null index");

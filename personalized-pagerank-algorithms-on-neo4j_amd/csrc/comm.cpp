@@ -570,6 +570,29 @@ int pprhip_topk_gather(pprhip_comm_t* c, const int32_t* ids, const double* vals,
   return topk_gather_impl(c, ids, vals, rows, rows_max, k, ids_root, vals_root, PPRHIP_OK);
 }
 
+int pprhip_owner_partition(uint32_t n, int world, const int32_t* sources, uint64_t count, uint64_t* counts_out,
+                           uint64_t* order_out) {
+  if (world < 1 || n < (uint32_t)world || (count && (!sources || !order_out)) || !counts_out) {
+    set_error("pprhip_owner_partition: bad arguments (n = %u, world = %d)", n, world);
+    return PPRHIP_ERR_INVALID;
+  }
+  const uint32_t base = n / (uint32_t)world, rem = n % (uint32_t)world;
+  std::vector<uint64_t> at((size_t)world + 1, 0);
+  for (uint64_t i = 0; i < count; ++i) {
+    if (sources[i] < 0 || (uint32_t)sources[i] >= n) {
+      set_error("pprhip_owner_partition: source %d outside [0, %u)", sources[i], n);
+      return PPRHIP_ERR_INVALID;
+    }
+    at[owner_of((uint32_t)sources[i], base, rem) + 1]++;
+  }
+  for (int p = 0; p < world; ++p) {
+    counts_out[p] = at[p + 1];
+    at[p + 1] += at[p];
+  }
+  for (uint64_t i = 0; i < count; ++i) order_out[at[owner_of((uint32_t)sources[i], base, rem)]++] = i;  // stable
+  return PPRHIP_OK;
+}
+
 int pprhip_comm_abort(pprhip_comm_t* c) {
   if (!c) {
     set_error("pprhip_comm_abort: null communicator");

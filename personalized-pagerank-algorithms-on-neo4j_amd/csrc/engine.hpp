@@ -374,6 +374,15 @@ int launch_mc_pure(pprhip_graph* g, int32_t src, uint64_t n_walks, double alpha,
                    double* target);
 
 // ---- kernels_apbs.hip
+// rank that owns source v when [0, n) is cut into `world` contiguous ranges, the first n % world one longer
+// (base = n / world, rem = n % world): THE partition rule of the sharded All-Pair - the device partition
+// (k_owner_partition), the ranges ranks search (pprhip_shard_target_range) and the host-side partition the CPU
+// multi-process tests drive (pprhip_owner_partition) all evaluate this one function
+__host__ __device__ inline uint32_t owner_of(uint32_t v, uint32_t base, uint32_t rem) {
+  const uint32_t cut = rem * (base + 1u);
+  return v < cut ? v / (base + 1u) : rem + (v - cut) / base;
+}
+
 struct TripleRec {  // one index entry of All-Pair-Backward-Search on the device: pi(v, t) = p
   int32_t v, t;
   double p;

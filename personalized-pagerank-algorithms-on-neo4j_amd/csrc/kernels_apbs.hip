@@ -991,12 +991,6 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
 // ------------------------------------------------------------------------------------------------
 // sharded All-Pair: index entries as 16-byte records, partitioned by the owner of their source
 // ------------------------------------------------------------------------------------------------
-// rank that owns source v when [0, n) is cut into `world` contiguous ranges (the first n % world one longer)
-__device__ __forceinline__ uint32_t owner_of(uint32_t v, uint32_t base, uint32_t rem) {
-  const uint32_t cut = rem * (base + 1u);
-  return v < cut ? v / (base + 1u) : rem + (v - cut) / base;
-}
-
 constexpr int kMaxWorld = 64;
 constexpr int kPartTile = 2048;  // records per workgroup pass
 
