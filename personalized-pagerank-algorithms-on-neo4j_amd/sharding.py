@@ -8,10 +8,12 @@ loops targets), so the CSR is replicated and the work is sharded with no data-pa
   * All-Pair-Backward-Search: rank r owns the contiguous target range target_range(r).  The result
     is keyed by *source* (Base_Whole_Graph.java:84-86), so one exchange follows: either every shard
     index is gathered to rank 0 and merged there (gather_index: small graphs), or - the form that
-    scales - rank r also owns the sources target_range(r) and every rank sends each owner its rows
-    (exchange_index_by_source: one all-to-all, a message per peer, i.e. per xGMI link), after which
-    each rank merges the partial lists of its own sources with the reference's k rule
-    (pprhip_index_merge) and holds that slice of the index.
+    scales - rank r also owns the sources target_range(r) and every rank sends each owner its entries
+    (exchange_index_by_source: partition by pprhip_owner_partition, one all-to-all per array, finalisation by
+    pprhip_index_from_entries - the library's rule and the library's k rule, only the fabric is torch's), after
+    which each rank holds the finished rows of its own sources.  The production exchange is the library's own
+    (csrc/comm.cpp over RCCL); this module is the same protocol over any torch.distributed backend, which is what
+    the CPU tests (gloo) and a rehearsal on fewer devices than ranks can run.
 
 Backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  Only plain tensors travel.
 """
@@ -25,10 +27,10 @@ def shard_sources(sources, rank, world):
 
 
 def target_range(rank, world, n):
-    """Contiguous target range [begin, end) of rank `rank` for All-Pair-Backward-Search."""
-    base, rem = divmod(n, world)
-    begin = rank * base + min(rank, rem)
-    return begin, begin + base + (1 if rank < rem else 0)
+    """Contiguous target range [begin, end) of rank `rank` for All-Pair-Backward-Search (= the sources it owns):
+    the library's own rule (pprhip_shard_target_range)."""
+    from . import shard_target_range
+    return shard_target_range(rank, world, n)
 
 
 def gather_topk(dist, torch, ids, vals, n_queries, k, rank, world, device="cpu"):
@@ -87,41 +89,34 @@ def gather_index(dist, torch, offsets, targets, values, rank, world, device="cpu
     return out
 
 
-def exchange_index_by_source(dist, torch, offsets, targets, values, rank, world, n, device="cpu"):
-    """All-Pair's exchange by owner of the source.  `offsets/targets/values` is this rank's shard index
-    (rows = all n sources, entries = its own targets).  Returns `world` partial indexes restricted to
-    the sources this rank owns, as (offsets[n + 1], targets, values) ready for index_from_arrays +
-    merge_indexes; rows outside the owned range are empty.  Rows arrive in target-shard order
-    (sender 0 first), which is the reference's target-iteration order."""
+def exchange_index_by_source(dist, torch, offsets, targets, values, rank, world, n, k, device="cpu"):
+    """All-Pair's exchange by owner of the source over torch.distributed - the same three steps as the library's own
+    RCCL exchange (csrc/comm.cpp: all_pair_sharded), with the library's own partition rule and finalisation:
+    this rank's shard index is flattened to (source, target, value) entries, partitioned by owner of the source with
+    pprhip_owner_partition (the function k_owner_partition evaluates on the device), every owner receives its entries
+    in one all-to-all per array, and finalises them with pprhip_index_from_entries (bucketing by source, the
+    reference's k rule).  Returns the finished Index of the sources this rank owns (rows of other sources empty)."""
+    from . import index_from_entries, owner_partition
     offsets = np.asarray(offsets, dtype=np.int64)
     targets = np.asarray(targets, dtype=np.int32)
     values = np.asarray(values, dtype=np.float64)
-    ranges = [target_range(r, world, n) for r in range(world)]
-    lo, hi = ranges[rank]
-    lengths = np.diff(offsets)
+    sources = np.repeat(np.arange(n, dtype=np.int32), np.diff(offsets))
     if world == 1:
-        return [(offsets.astype(np.uint64), targets, values)]
-    # 1) row lengths of every owner's range (split sizes are the range sizes, known everywhere)
-    len_send = torch.as_tensor(lengths, dtype=torch.int64, device=device)
-    len_recv = torch.empty((hi - lo) * world, dtype=torch.int64, device=device)
-    dist.all_to_all_single(len_recv, len_send, output_split_sizes=[hi - lo] * world,
-                           input_split_sizes=[e - b for b, e in ranges])
-    # 2) the entries themselves: to owner o go the entries of rows [begin_o, end_o), contiguous in the CSR-style arrays
-    cnt_send = [int(offsets[e] - offsets[b]) for b, e in ranges]
-    len_recv_np = len_recv.cpu().numpy().reshape(world, hi - lo)
-    cnt_recv = [int(x) for x in len_recv_np.sum(axis=1)]
-    tg_recv = torch.empty(sum(cnt_recv), dtype=torch.int32, device=device)
-    vl_recv = torch.empty(sum(cnt_recv), dtype=torch.float64, device=device)
-    dist.all_to_all_single(tg_recv, torch.as_tensor(targets, device=device), output_split_sizes=cnt_recv,
-                           input_split_sizes=cnt_send)
-    dist.all_to_all_single(vl_recv, torch.as_tensor(values, device=device), output_split_sizes=cnt_recv,
-                           input_split_sizes=cnt_send)
-    tg_np, vl_np = tg_recv.cpu().numpy(), vl_recv.cpu().numpy()
-    parts, at = [], 0
-    for p in range(world):
-        off = np.zeros(n + 1, dtype=np.uint64)
-        off[lo + 1:hi + 1] = np.cumsum(len_recv_np[p])
-        off[hi + 1:] = off[hi]
-        parts.append((off, tg_np[at:at + cnt_recv[p]], vl_np[at:at + cnt_recv[p]]))
-        at += cnt_recv[p]
-    return parts
+        return index_from_entries(n, sources, targets, values, k)
+    counts, order = owner_partition(n, world, sources)
+    order = order.astype(np.int64)
+    cnt_send = [int(c) for c in counts]
+    # 1) sizes: one word per peer
+    c_send = torch.as_tensor(np.asarray(cnt_send, dtype=np.int64), device=device)
+    c_recv = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(c_recv, c_send)
+    cnt_recv = [int(x) for x in c_recv.cpu().numpy()]
+    # 2) the entries, owner by owner
+    got = []
+    for arr, dt in ((sources[order], torch.int32), (targets[order], torch.int32), (values[order], torch.float64)):
+        recv = torch.empty(sum(cnt_recv), dtype=dt, device=device)
+        dist.all_to_all_single(recv, torch.as_tensor(np.ascontiguousarray(arr), device=device),
+                               output_split_sizes=cnt_recv, input_split_sizes=cnt_send)
+        got.append(recv.cpu().numpy())
+    # 3) the owner finalises its rows
+    return index_from_entries(n, got[0], got[1], got[2], k)

@@ -51,8 +51,8 @@ def _worker(rank, world, port, outdir):
         lo, hi = sh.target_range(rank, world, got.n)
         off, tg, vl = rec["off%d" % rank], rec["tg%d" % rank], rec["vl%d" % rank]
         # the exchange that scales: every rank ends with the merged lists of the sources it owns
-        mine_parts = sh.exchange_index_by_source(dist, torch, off, tg, vl, rank, world, got.n)
-        own = pkg.merge_indexes([pkg.index_from_arrays(got.n, o, t, v) for o, t, v in mine_parts], 3)
+        # (partitioned by the library's owner rule, finalised by the library: only the fabric is gloo)
+        own = sh.exchange_index_by_source(dist, torch, off, tg, vl, rank, world, got.n, 3)
         o_off, o_tg, o_vl = own.arrays()
         np.savez(os.path.join(outdir, "own%d.npz" % rank), off=o_off, tg=o_tg, vl=o_vl, lo=lo, hi=hi)
         shards = sh.gather_index(dist, torch, off, tg, vl, rank, world)
@@ -92,6 +92,24 @@ def test_two_rank_gloo(tmp_path, orc, got):
             a, b = int(o["off"][v]), int(o["off"][v + 1])
             c, e = int(off[v]), int(off[v + 1])
             assert np.array_equal(o["tg"][a:b], tg[c:e]) and np.max(np.abs(o["vl"][a:b] - vl[c:e]), initial=0) <= 1e-12
+
+
+def test_owner_partition_is_the_range_rule(pkg):
+    """pprhip_owner_partition (the host form of k_owner_partition's rule) sends source v to the rank whose
+    pprhip_shard_target_range holds v, keeps the entries' order inside an owner's share, and rejects bad ids."""
+    rng = np.random.default_rng(3)
+    for n, w in ((107, 2), (4096, 3), (10, 10), (1000003, 8)):
+        v = rng.integers(0, n, size=5000).astype(np.int32)
+        counts, order = pkg.owner_partition(n, w, v)
+        assert int(counts.sum()) == v.size and sorted(order.tolist()) == list(range(v.size))
+        at = 0
+        for r in range(w):
+            lo, hi = pkg.shard_target_range(r, w, n)
+            mine = order[at:at + int(counts[r])].astype(np.int64)
+            assert np.all((v[mine] >= lo) & (v[mine] < hi)) and np.all(np.diff(mine) > 0)
+            at += int(counts[r])
+    with pytest.raises(pkg.PprhipError):
+        pkg.owner_partition(10, 2, np.array([3, 10], dtype=np.int32))
 
 
 def test_shard_helpers(pkg):

@@ -59,8 +59,7 @@ def main():
     ix, st = g.all_pair_backward(0.15, args.threshold, args.k, lo, hi)
     t_search = time.perf_counter() - t0
     off, tg, vl = ix.arrays()
-    parts = sh.exchange_index_by_source(dist, torch, off, tg, vl, rank, world, host.n, device=xdev)
-    own = pkg.merge_indexes([pkg.index_from_arrays(host.n, o, t, v) for o, t, v in parts], args.k)
+    own = sh.exchange_index_by_source(dist, torch, off, tg, vl, rank, world, host.n, args.k, device=xdev)
     t_all = time.perf_counter() - t0
     times = torch.tensor([t_search, t_all], dtype=torch.float64, device=xdev)
     if world > 1:
