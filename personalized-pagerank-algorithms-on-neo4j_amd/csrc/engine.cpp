@@ -317,8 +317,6 @@ void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint64_
 // levels are launched kMaxBatch at a time and continue on the device (kernels_push.hip).  With
 // yield_dense the function prepares a dense level and returns kYield instead of running it: the
 // batch driver runs one sweep for every slot waiting at that point and calls back in.
-int device_sum(pprhip_graph* g, const double* x, double* out);
-
 int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost,
                bool yield_dense, RoundCut* cut) {
   const bool bwd = a.mode == kBackward;
@@ -493,11 +491,20 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
   return PPRHIP_OK;
 }
 
-int reset_query_state(pprhip_graph* g, bool clear_flags) {
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->residue, 0, sizeof(double) * g->n, g->stream));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->reserve, 0, sizeof(double) * g->n, g->stream));
+int reset_query_state(pprhip_graph* g, bool clear_flags, int32_t node) {
+  // the entries the query before could have written are cleared; the new query's passes cover n_act entries
+  const uint32_t n_live = host_of(g)->n_live;
+  g->n_act = (n_live && node >= 0 && (uint32_t)node < n_live) ? n_live : g->n;
+  const uint32_t clr = std::max(g->n_act, g->n_dirty ? g->n_dirty : g->n);
+  g->n_dirty = g->n_act;
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->residue, 0, sizeof(double) * clr, g->stream));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->reserve, 0, sizeof(double) * clr, g->stream));
   PPRHIP_CHECK_HIP(hipMemsetAsync(g->ctr, 0, sizeof(DevCounters), g->stream));
-  if (clear_flags) PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags, 0, g->n, g->stream));
+  if (clear_flags) PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags, 0, clr, g->stream));
+  // the top-k estimate is rewritten over the new query's n_act entries only: what the query before left beyond them goes
+  if (clr > g->n_act)
+    PPRHIP_CHECK_HIP(hipMemsetAsync(g->est + g->n_act, 0, sizeof(double) * (clr - g->n_act), g->stream));
+  g->mc_parity = 0;  // (both plan cells were just cleared)
   g->result_in_est = false;
   return PPRHIP_OK;
 }
@@ -531,9 +538,9 @@ int alloc_workspace(pprhip_graph* G) {
     PPRHIP_TRY(alloc_dev((void**)&G->blk_ndead, sizeof(uint32_t) * nblk));
   }
   G->sel_cap = 1u << 18;
-  PPRHIP_TRY(alloc_dev((void**)&G->sel_blob, 16 + sizeof(SelRec) * (size_t)G->sel_cap));
+  PPRHIP_TRY(alloc_dev((void**)&G->sel_blob, kSelHeader + sizeof(SelRec) * (size_t)G->sel_cap));
   PPRHIP_CHECK_HIP(hipMemsetAsync(G->hist, 0, sizeof(uint32_t) * 4096, G->stream));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(G->sel_blob, 0, 16, G->stream));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(G->sel_blob, 0, kSelHeader, G->stream));
   PPRHIP_TRY(alloc_dev((void**)&G->ctr, sizeof(DevCounters)));
   if (hipHostMalloc((void**)&G->h_ctr, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) {
     set_error("hipHostMalloc failed");
@@ -604,6 +611,7 @@ int build_batch(pprhip_graph* P) {
     S->n_cus = P->n_cus;
     S->n = P->n;
     S->m = P->m;
+    S->n_live = P->n_live;
     if (hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking) != hipSuccess) {
       set_error("hipStreamCreate failed");
       return PPRHIP_ERR_HIP;
@@ -750,8 +758,8 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
   return PPRHIP_OK;
 }
 
-int device_sum(pprhip_graph* g, const double* x, double* out) {
-  PPRHIP_TRY(launch_sum(g, x, g->n));
+int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count) {
+  PPRHIP_TRY(launch_sum(g, x, count ? count : act_n(g)));
   PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sum_out, &g->ctr->sum_out, sizeof(double), hipMemcpyDeviceToHost,
                                   g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
@@ -759,47 +767,48 @@ int device_sum(pprhip_graph* g, const double* x, double* out) {
   return PPRHIP_OK;
 }
 
-// The counters a query only needs once, at its end, in one copy: dead-end pops of the push and the steps of the walks
-// run since the workspace was reset (dead_pops, mc_packed, walk_steps are adjacent in DevCounters).
+// The counters a query only needs once, at its end, in one copy: dead-end pops of the push, and what the walk phases
+// run since the workspace was reset counted on the device (steps, walks, sources: adjacent in DevCounters).
 int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st) {
-  static_assert(offsetof(DevCounters, walk_steps) == offsetof(DevCounters, dead_pops) + 16, "one copy for both");
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->dead_pops, &g->ctr->dead_pops, 3 * sizeof(unsigned long long),
+  static_assert(offsetof(DevCounters, sources_total) == offsetof(DevCounters, dead_pops) + 24, "one copy for the four");
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->dead_pops, &g->ctr->dead_pops, 4 * sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   st.push_bytes += 16ull * (g->h_ctr->dead_pops - st.dead_end_pops);
   st.dead_end_pops = g->h_ctr->dead_pops;
-  const uint64_t steps = g->h_ctr->walk_steps;  // cumulative over the query's walk phases
-  if (steps > st.walk_steps) {
-    const uint64_t more = 12ull * (steps - st.walk_steps);
+  // cumulative over the query's walk phases: what is new since the last read goes into the statistics
+  const uint64_t steps = g->h_ctr->walk_steps, walks = g->h_ctr->walks_total, srcs = g->h_ctr->sources_total;
+  if (steps >= st.walk_steps && walks >= st.walks && srcs >= st.mc_sources) {
+    const uint64_t more = 12ull * (steps - st.walk_steps) + 16ull * (walks - st.walks) + 12ull * (srcs - st.mc_sources);
     st.mc_bytes += more;
     ktimer().add_bytes(PPRHIP_KERNEL_WALK, more);
     st.walk_steps = steps;
+    st.walks = walks;
+    st.mc_sources = srcs;
   }
   return PPRHIP_OK;
 }
 
-// walk phase shared by FORA whole-graph (variant 0) and top-k (variant 1)
-// (the plan counter is zero on entry: reset_query_state clears it and every walk kernel clears it again once the host
-// has read it; the step counter runs on over a query's walk phases and is read once, by read_dead_pops)
+// Walk phase shared by FORA whole-graph (variant 0) and top-k (variant 1): plan and walks are launched back to back,
+// the walk kernel reads the plan's counts on the device (no host round trip inside the phase; the counts reach the
+// statistics through read_dead_pops at the end of the query).  omega_dev > 0: the plan also derives rsum and the walk
+// budget on the device from the residue sum a device_sum / launch_sum has just left (rsum, nrw are ignored; nrw_bound is
+// the largest budget possible, for the range check).
 int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,
-                   double* target, pprhip_stats_t& st) {
-  if ((double)nrw + (double)g->n >= (double)(1ull << kPackShift)) {
-    set_error("walk budget %lld exceeds the engine's 2^36 walk limit", nrw);
+                   double* target, pprhip_stats_t& st, double omega_dev) {
+  (void)st;
+  // what the host knows about the walk count sizes the grid: the budget itself (every residue entry adds at most one
+  // walk to it), or - with the budget derived on the device - nothing
+  g->walk_hint = omega_dev > 0.0 ? 0ull : (unsigned long long)nrw + act_n(g);
+  const double bound = omega_dev > 0.0 ? omega_dev : (double)nrw;
+  if (bound + (double)g->n >= (double)(1ull << kPackShift)) {
+    set_error("walk budget %.0f exceeds the engine's 2^36 walk limit", bound);
     return PPRHIP_ERR_INVALID;
   }
-  PPRHIP_TRY(launch_mc_plan(g, variant, alpha, rsum, (double)nrw, target));
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->mc_packed, &g->ctr->mc_packed, sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, g->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-  const uint64_t n_src = g->h_ctr->mc_packed >> kPackShift;
-  const uint64_t n_walks = g->h_ctr->mc_packed & kPackMask;
-  const uint64_t bytes = 16ull * n_walks + 12ull * n_src;  // + 12 B per step, added when the step counter is read
-  ktimer().begin(PPRHIP_KERNEL_WALK, bytes);
-  PPRHIP_TRY(launch_mc_walk(g, n_src, n_walks, alpha, seed, stream, variant == 0 ? 1 : 0, target));
+  PPRHIP_TRY(launch_mc_plan(g, variant, alpha, rsum, (double)nrw, omega_dev, target));
+  ktimer().begin(PPRHIP_KERNEL_WALK, 0);  // (its bytes are added when the counters are read)
+  PPRHIP_TRY(launch_mc_walk(g, alpha, seed, stream, variant == 0 ? 1 : 0, target));
   ktimer().end();
-  st.mc_sources += n_src;
-  st.walks += n_walks;
-  st.mc_bytes += bytes;
   return PPRHIP_OK;
 }
 
@@ -848,8 +857,34 @@ struct IdVal {
   double val;
 };
 
-int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
-                double* kth_out, bool* have_kth, pprhip_stats_t& st) {
+// candidates (all entries >= the lower edge of the bin that holds the k-th largest) -> the reference's answer
+static void finish_select(std::vector<IdVal>& cand, bool have, int k, int32_t* ids_out, double* vals_out, int cap,
+                          int* n_out, double* kth_out, bool* have_kth, pprhip_stats_t& st) {
+  std::sort(cand.begin(), cand.end(), [](const IdVal& a, const IdVal& b) {
+    if (a.val != b.val) return a.val > b.val;
+    return a.id < b.id;
+  });
+  size_t n_sel = cand.size();
+  double kth = 0.0;
+  if (have) {
+    kth = cand[(size_t)k - 1].val;
+    n_sel = 0;
+    while (n_sel < cand.size() && cand[n_sel].val >= kth) ++n_sel;
+  }
+  for (size_t i = 0; i < n_sel && (int)i < cap; ++i) {
+    if (ids_out) ids_out[i] = cand[i].id;
+    if (vals_out) vals_out[i] = cand[i].val;
+  }
+  *n_out = (int)n_sel;
+  *have_kth = have;
+  if (kth_out) *kth_out = kth;
+  st.kth_value = kth;
+}
+
+// The multi-pass form: the host reads every histogram and refines the prefix until few enough candidates are left
+// (needed when more than sel_cap entries share the leading 12 bits of the k-th largest).
+static int select_topk_passes(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap,
+                              int* n_out, double* kth_out, bool* have_kth, pprhip_stats_t& st) {
   std::vector<uint32_t> hist(4096);
   unsigned long long prefix = 0;
   int pbits = 0;
@@ -861,7 +896,7 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
   uint64_t expected = ~0ull;              // candidates the gather will find, known from the histograms
   for (int pass = 0; pbits < 64; ++pass) {
     const int dbits = std::min(12, 64 - pbits);
-    PPRHIP_TRY(launch_select_hist(g, x, g->n, prefix, pbits, dbits, pass == 0));
+    PPRHIP_TRY(launch_select_hist(g, x, act_n(g), prefix, pbits, dbits, pass == 0));
     PPRHIP_CHECK_HIP(hipMemcpyAsync(hist.data(), g->hist, sizeof(uint32_t) * (1u << dbits), hipMemcpyDeviceToHost,
                                     g->stream));
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
@@ -870,6 +905,7 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
     if (pass == 0) {
       for (uint32_t b = 0; b < (1u << dbits); ++b) total += hist[b];
       if (total == 0) {
+        PPRHIP_CHECK_HIP(hipMemsetAsync(g->hist, 0, sizeof(uint32_t) * 4096, g->stream));
         *n_out = 0;
         *have_kth = false;
         if (kth_out) *kth_out = 0.0;
@@ -902,11 +938,11 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
     expected = above + hist[chosen];
     if (expected <= g->sel_cap) break;  // few enough candidates: finish on the host
   }
-  PPRHIP_TRY(launch_select_gather(g, x, g->n, have ? lower_bits : 1ull, false));
+  PPRHIP_TRY(launch_select_gather(g, x, act_n(g), have ? lower_bits : 1ull, false));
   // the histograms already say how many candidates there are: the count and the records come back in ONE copy
   const bool prefetched = expected > 0 && expected <= g->sel_cap;
   const size_t want = prefetched ? (size_t)expected : 0;
-  std::vector<char> blob(16 + sizeof(SelRec) * want);
+  std::vector<char> blob(kSelHeader + sizeof(SelRec) * want);
   PPRHIP_CHECK_HIP(hipMemcpyAsync(blob.data(), g->sel_blob, blob.size(), hipMemcpyDeviceToHost, g->stream));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   st.select_bytes += 8ull * g->n;
@@ -919,11 +955,11 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
     for (uint64_t i = 0; i < c; ++i) cand[i] = {host_of(g)->h_new2old[r[i].id], r[i].val};
   };
   if (prefetched && cnt == expected) {
-    take_recs(blob.data() + 16, cnt);
+    take_recs(blob.data() + kSelHeader, cnt);
   } else if (cnt <= g->sel_cap) {
     std::vector<char> more(sizeof(SelRec) * cnt);
     if (cnt) {
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(more.data(), g->sel_blob + 16, more.size(), hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(more.data(), g->sel_blob + kSelHeader, more.size(), hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     }
     take_recs(more.data(), cnt);
@@ -936,25 +972,49 @@ int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, doubl
     for (uint32_t i = 0; i < g->n; ++i)
       if (all[i] > 0.0 && (!have || all[i] >= lb)) cand.push_back({host_of(g)->h_new2old[i], all[i]});
   }
-  std::sort(cand.begin(), cand.end(), [](const IdVal& a, const IdVal& b) {
-    if (a.val != b.val) return a.val > b.val;
-    return a.id < b.id;
-  });
-  size_t n_sel = cand.size();
-  double kth = 0.0;
-  if (have) {
-    kth = cand[(size_t)k - 1].val;
-    n_sel = 0;
-    while (n_sel < cand.size() && cand[n_sel].val >= kth) ++n_sel;
+  finish_select(cand, have, k, ids_out, vals_out, cap, n_out, kth_out, have_kth, st);
+  return PPRHIP_OK;
+}
+
+// k-th largest and the entries >= it (Algo_Util.kth_ppr + retrieveTopK).  One histogram pass over the 12 leading bits,
+// the bin of the k-th largest chosen on the device, the gather of everything from that bin's lower edge up, and ONE
+// read-back (header + the first kPre records; the candidates are then ordered on the host, values descending, ids
+// ascending).  Only when more candidates share those 12 bits than the buffer holds the multi-pass form takes over.
+int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
+                double* kth_out, bool* have_kth, pprhip_stats_t& st) {
+  constexpr size_t kPre = 2048;
+  PPRHIP_TRY(launch_select_hist(g, x, act_n(g), 0ull, 0, 12, true));
+  PPRHIP_TRY(launch_select_choose(g, (unsigned long long)k));
+  PPRHIP_TRY(launch_select_gather(g, x, act_n(g), 0ull, false, true));
+  std::vector<char> blob(kSelHeader + sizeof(SelRec) * kPre);
+  PPRHIP_CHECK_HIP(hipMemcpyAsync(blob.data(), g->sel_blob, blob.size(), hipMemcpyDeviceToHost, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  st.select_passes++;
+  st.select_bytes += 16ull * act_n(g);
+  unsigned long long hdr[5];
+  std::memcpy(hdr, blob.data(), sizeof hdr);
+  const uint64_t cnt = hdr[0], expected = hdr[2], total = hdr[3];
+  const bool have = hdr[4] != 0;
+  if (total == 0) {
+    *n_out = 0;
+    *have_kth = false;
+    if (kth_out) *kth_out = 0.0;
+    return PPRHIP_OK;
   }
-  for (size_t i = 0; i < n_sel && (int)i < cap; ++i) {
-    if (ids_out) ids_out[i] = cand[i].id;
-    if (vals_out) vals_out[i] = cand[i].val;
+  if (expected > g->sel_cap || cnt != expected)  // too many share the leading bits (or the header is not what it should be)
+    return select_topk_passes(g, x, k, ids_out, vals_out, cap, n_out, kth_out, have_kth, st);
+  std::vector<IdVal> cand(cnt);
+  const std::vector<int32_t>& n2o = host_of(g)->h_new2old;
+  if (cnt <= kPre) {
+    const SelRec* r = reinterpret_cast<const SelRec*>(blob.data() + kSelHeader);
+    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {n2o[r[i].id], r[i].val};
+  } else {
+    std::vector<SelRec> more(cnt);
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(more.data(), g->sel_blob + kSelHeader, sizeof(SelRec) * cnt, hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    for (uint64_t i = 0; i < cnt; ++i) cand[i] = {n2o[more[i].id], more[i].val};
   }
-  *n_out = (int)n_sel;
-  *have_kth = have;
-  if (kth_out) *kth_out = kth;
-  st.kth_value = kth;
+  finish_select(cand, have, k, ids_out, vals_out, cap, n_out, kth_out, have_kth, st);
   return PPRHIP_OK;
 }
 
@@ -1233,6 +1293,7 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
     for (uint32_t v = 0; v < n; ++v)
       if (irp[v + 1] == irp[v] && G->h_out_rp[v + 1] > G->h_out_rp[v]) zin.push_back((int32_t)v);
     G->n_zin = (uint32_t)zin.size();
+    G->n_live = G->relabeled ? G->n_nz + G->n_zin : 0u;  // (ids are the caller's without the relabeling: no bound)
     for (uint32_t v = 0; v < n; ++v) G->n_src_live += G->h_out_rp[v + 1] > G->h_out_rp[v] ? 1u : 0u;
     if ((rc = up((void**)&G->zin_rows, zin.data(), sizeof(int32_t) * zin.size()))) return fail(rc);
     std::vector<unsigned long long> cross(((size_t)n + 63) / 64 + 1, 0ull);
@@ -1358,7 +1419,7 @@ int pprhip_forward_push(pprhip_graph_t* g, int32_t src, double alpha, double rma
   pprhip_stats_t st;
   std::memset(&st, 0, sizeof st);
   g->topk_active = false;
-  PPRHIP_TRY(reset_query_state(g, false));
+  PPRHIP_TRY(reset_query_state(g, false, src));
   CallTimer tm(g);
   double rsum = 0.0;
   if (hdeg_out(g, src) == 0) {  // Forward_Push.java:72-76
@@ -1390,7 +1451,7 @@ int pprhip_fwdpush_topk_reset(pprhip_graph_t* g, int32_t src, double alpha) {
   PPRHIP_TRY(check_graph(g, "pprhip_fwdpush_topk_reset"));
   PPRHIP_TRY(check_node(g, src, "pprhip_fwdpush_topk_reset"));
   src = g->h_old2new[src];  // internal (degree-sorted) id
-  PPRHIP_TRY(reset_query_state(g, true));
+  PPRHIP_TRY(reset_query_state(g, true, src));
   // Q = {s} (Fora_Topk.java:117-118): the source starts parked
   PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags + src, 1, 1, g->stream));
   g->topk_active = true;
@@ -1401,7 +1462,9 @@ int pprhip_fwdpush_topk_reset(pprhip_graph_t* g, int32_t src, double alpha) {
   return PPRHIP_OK;
 }
 
-static int topk_round_impl(pprhip_graph_t* g, double min_rmax, double rmax, pprhip_stats_t& st) {
+// read_sum: bring the residue sum to the host (the public round-by-round entry point); otherwise it is left in
+// DevCounters::sum_out for the walk plan
+static int topk_round_impl(pprhip_graph_t* g, double min_rmax, double rmax, pprhip_stats_t& st, bool read_sum = true) {
   const int32_t src = g->topk_src;
   if (hdeg_out(g, src) == 0) {  // Forward_Push.java:149-153
     PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)src, 1.0));
@@ -1413,7 +1476,8 @@ static int topk_round_impl(pprhip_graph_t* g, double min_rmax, double rmax, pprh
   LevelCtx L;
   PPRHIP_TRY(seed_scan(g, a, 1, L));
   PPRHIP_TRY(run_levels(g, a, L, st, nullptr));
-  PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
+  if (read_sum) PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
+  else PPRHIP_TRY(launch_sum(g, g->residue, act_n(g)));
   g->topk_first = false;
   return PPRHIP_OK;
 }
@@ -1534,7 +1598,7 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
   double rsum_local = conf->rsum, omega_local = 0.0, rmax_local = 0.0;
   double push_ms = 0.0, mc_ms = 0.0, sel_ms = 0.0;
   uint32_t round = 0;
-  const size_t nd = sizeof(double) * (size_t)g->n;
+  const size_t nd = sizeof(double) * (size_t)act_n(g);  // (est beyond the query's scan bound is zero and stays so)
   bool dead_src = false;
   while (delta_local >= min_delta) {  // :123
     rmax_local = epsilon * std::sqrt(delta_local / 3.0 / (double)conf->m / std::log(2.0 / conf->pfail));  // :124
@@ -1548,21 +1612,22 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
     }
     rmax_local *= std::sqrt((double)conf->m * rmax_local) * 3.0;  // :133
     (void)hipEventRecord(g->ev[1], g->stream);
-    PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax_local, st));  // :137
-    rsum_local = g->topk_rsum;                                 // :142
+    PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax_local, st, false));  // :137; the residue sum stays on the device
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sum_out, &g->ctr->sum_out, sizeof(double), hipMemcpyDeviceToHost, g->stream));
     (void)hipEventRecord(g->ev[2], g->stream);
     // :143 reserve := copy of the push reserve (walk increments of earlier rounds are dropped)
     PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
-    const double rsum_rw = rsum_local * (1.0 - alpha);  // :148
-    const double nrw_d = omega_local * rsum_rw;
-    const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;  // :151
-    PPRHIP_TRY(run_walk_phase(g, 1, alpha, rsum_rw, nrw, seed, round, g->est, st));  // :155-168
+    // :148-168: the plan derives rsum and the walk budget from the sum on the device, the walk kernel reads the plan's
+    // counts there: no host round trip between the push and the selection
+    PPRHIP_TRY(run_walk_phase(g, 1, alpha, 0.0, 0, seed, round, g->est, st, omega_local));
     (void)hipEventRecord(g->ev[3], g->stream);
     round++;
     double kth = 0.0;
     bool have = false;
     int nsel = 0;
     PPRHIP_TRY(select_topk(g, g->est, conf->k, nullptr, nullptr, 0, &nsel, &kth, &have, st));  // :173
+    g->topk_rsum = g->h_ctr->sum_out;  // (the selection synchronised the stream)
+    rsum_local = g->topk_rsum;         // :142
     if (!have) kth = 0.0;                                                                        // :174
     (void)hipEventRecord(g->ev[4], g->stream);
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
@@ -1612,7 +1677,7 @@ int pprhip_monte_carlo(pprhip_graph_t* g, int32_t src, double eps, const pprhip_
   pprhip_stats_t st;
   std::memset(&st, 0, sizeof st);
   g->topk_active = false;
-  PPRHIP_TRY(reset_query_state(g, false));
+  PPRHIP_TRY(reset_query_state(g, false, src));
   CallTimer tm(g);
   const double omega = 3 * std::log(2 / conf->pfail) / eps / eps / conf->delta;  // Monte_Carlo.java:145
   const uint64_t nw = (uint64_t)std::floor(omega);                                // :149 (i <= omega)
@@ -1624,17 +1689,10 @@ int pprhip_monte_carlo(pprhip_graph_t* g, int32_t src, double eps, const pprhip_
     PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)src, (double)nw / omega));  // every walk returns src (:70-72)
     st.walks = nw;
   } else {
-    PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->walk_steps, 0, sizeof(unsigned long long), g->stream));
     ktimer().begin(PPRHIP_KERNEL_WALK, 0);
     PPRHIP_TRY(launch_mc_pure(g, src, nw, conf->alpha, seed, 1.0 / omega, g->reserve));
     ktimer().end();
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->walk_steps, &g->ctr->walk_steps, sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, g->stream));
-    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-    st.walks = nw;
-    st.walk_steps = g->h_ctr->walk_steps;
-    st.mc_bytes = 12ull * st.walk_steps + 16ull * nw + 12ull;
-    if (!ktimer().recs.empty()) ktimer().recs.back().bytes = st.mc_bytes;
+    PPRHIP_TRY(read_dead_pops(g, st));  // steps, walks (= nw), sources (= 1) as the device counted them
   }
   st.mc_sources = 1;
   st.omega = omega;
@@ -1648,7 +1706,7 @@ int pprhip_monte_carlo(pprhip_graph_t* g, int32_t src, double eps, const pprhip_
 
 // ------------------------------------------------------------------ backward search (a8)
 static int backward_push_impl(pprhip_graph_t* g, int32_t target, double alpha, double rmax, pprhip_stats_t& st) {
-  PPRHIP_TRY(reset_query_state(g, false));
+  PPRHIP_TRY(reset_query_state(g, false, target));
   if (hdeg_in(g, target) == 0) {  // Backward_Search.java:46-49
     PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)target, 1.0));
     return PPRHIP_OK;
@@ -1695,7 +1753,7 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
   pprhip_stats_t st;
   std::memset(&st, 0, sizeof st);
   g->topk_active = false;
-  PPRHIP_TRY(reset_query_state(g, false));
+  PPRHIP_TRY(reset_query_state(g, false, src));
   CallTimer tm(g);
   if (iters > 0) {
     // iteration 1 (Power_Method.java:59-96 with residue = {s: 1})

@@ -12,12 +12,16 @@ struct DevCounters {
   unsigned long long hist[16];    // sparse batch: hist[i] = frontier of level i (entries << 36 | edges)
   unsigned long long packed[2];   // dense level / seeding output: entries << 36 | edge total
   double dead[2];                 // dead-end mass waiting to land on the source
-  unsigned long long dead_pops;   // pushed nodes with out-degree 0
-  unsigned long long mc_packed;   // walk plan: sources << 36 | walks
-  unsigned long long walk_steps;  // edges followed by walks
-  unsigned long long sel_count;   // top-k candidate count
-  double sum_out;                 // reduction result
-  unsigned long long pad[7];
+  // read once per query, in one copy (read_dead_pops): what the push and the walk phases counted since the reset
+  unsigned long long dead_pops;      // pushed nodes with out-degree 0
+  unsigned long long walk_steps;     // edges followed by walks
+  unsigned long long walks_total;    // walks run
+  unsigned long long sources_total;  // residue entries that started walks
+  double sum_out;                    // reduction result (the walk plan reads it on the device)
+  // walk plan of a phase: sources << 36 | walks, counted by the plan kernel, read by the walk kernel on the device.
+  // Two cells used in turn: the walk kernel of one phase clears the cell of the next.
+  unsigned long long mc_plan[2];
+  unsigned long long pad[5];
   unsigned long long dhist[8];    // dense batch: dhist[i] = frontier that dense level i of the batch starts from
   int dstate[8];                  // dense batch: sweep state of level i (kGsNone: the level does not run)
 };
@@ -88,6 +92,7 @@ struct SelRec {  // one candidate of a top-k selection / one entry >= threshold 
   int32_t id, pad;
   double val;
 };
+constexpr int kSelHeader = 64;  // bytes before the records in pprhip_graph::sel_blob (kernels_select.hip)
 
 struct PushArgs {
   double alpha;
@@ -272,6 +277,13 @@ struct pprhip_graph {
   unsigned long long* prep_bits = nullptr;   // [kBatch][tiles]: rows holding a contribution after the last sweep
   uint32_t n_zin = 0;
   uint32_t n_src_live = 0;  // nodes with out-edges: the contributions a forward sweep can gather
+  // Internal ids [0, n_live) are the nodes with at least one edge (the vertex order puts nodes with in-edges first, then
+  // the others by out-degree: isolated nodes - 43 % of an R-MAT 22 - come last).  A query whose source / target is
+  // one of them can only ever hold residue, reserve or walk terminals below n_live, so the passes over "all nodes"
+  // (seeding, sums, walk plan, selection, resets) run over n_act = n_live entries; a query on an isolated node uses n.
+  uint32_t n_live = 0;
+  uint32_t n_act = 0;    // scan bound of the query this workspace is running (0: n)
+  uint32_t n_dirty = 0;  // ... of the query before it (what the reset has to clear)
   pprhip::SlotArgs* d_slot_args = nullptr;
   pprhip::SlotArgs* h_slot_args = nullptr;  // pinned
   unsigned long long* sweep_out = nullptr;    // [kBatch] frontier counters a sweep produced
@@ -291,6 +303,8 @@ struct pprhip_graph {
   // it receives mass, as Forward_Push.java:226-231 enqueues it, although it does not *cross* the threshold
   uint32_t* armed = nullptr;
   // walk plan
+  int mc_parity = 0;  // DevCounters::mc_plan cell of the next walk phase
+  unsigned long long walk_hint = 0;  // upper bound of the next walk phase's walks when the host knows one (grid size)
   int32_t* mc_node = nullptr;
   double* mc_inc = nullptr;
   unsigned long long* mc_woff = nullptr;
@@ -300,7 +314,7 @@ struct pprhip_graph {
   unsigned long long* blk_pack = nullptr;  // per-workgroup partial counters of the dense sweep
   double* blk_dead = nullptr;
   uint32_t* blk_ndead = nullptr;
-  char* sel_blob = nullptr;        // candidate list: 16-byte header {count, -} + sel_cap records (SelRec)
+  char* sel_blob = nullptr;        // candidate list: kSelHeader bytes {count, ...} + sel_cap records (SelRec)
   uint32_t sel_cap = 0;
   pprhip::DevCounters* ctr = nullptr;    // device
   pprhip::DevCounters* h_ctr = nullptr;  // pinned host mirror
@@ -353,6 +367,7 @@ int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int o
 int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter);
 int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbuf, int out_slot, int dead_slot);
 int launch_sum(pprhip_graph* g, const double* x, uint32_t n);  // result -> ctr->sum_out
+inline uint32_t act_n(const pprhip_graph* g) { return g->n_act ? g->n_act : g->n; }  // entries a query's passes cover
 int launch_set_f64(pprhip_graph* g, double* p, uint32_t idx, double value);
 int launch_permute_out(pprhip_graph* g, const double* x, double* out);  // out[old] = x[old2new[old]]
 // Once per device, from the thread that lifts the first graph onto it: loads the code object of every
@@ -365,9 +380,12 @@ int init_kernels_apbs();
 
 // ---- kernels_walk.hip
 int launch_build_walk_rec(pprhip_graph* g);
-int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double* target);
-int launch_mc_walk(pprhip_graph* g, uint64_t n_sources, uint64_t n_walks, double alpha, uint64_t seed, uint32_t stream,
-                   int no_zero_hop, double* target);
+// The walk phase runs without a host round trip: the plan kernel counts sources and walks into DevCounters::mc_plan
+// [g->mc_parity], the walk kernel (a fixed grid) reads them there.  omega_dev > 0: the plan derives rsum and the walk
+// budget itself from the residue sum a reduction left in DevCounters::sum_out (top-k rounds: Fora_Topk.java:148-151);
+// otherwise rsum / nrw are the host's.
+int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double omega_dev, double* target);
+int launch_mc_walk(pprhip_graph* g, double alpha, uint64_t seed, uint32_t stream, int no_zero_hop, double* target);
 int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* d_idx, uint64_t count, double alpha,
                       uint64_t seed, uint32_t stream, int no_zero_hop, int32_t* d_term, uint32_t* d_steps);
 int launch_mc_pure(pprhip_graph* g, int32_t src, uint64_t n_walks, double alpha, uint64_t seed, double inc,
@@ -419,6 +437,8 @@ int init_kernels_sort();
 // ---- kernels_select.hip
 int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned long long prefix, int prefix_bits,
                        int digit_bits, bool first_pass);
-int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits, bool zero_count);
+int launch_select_choose(pprhip_graph* g, unsigned long long k);
+int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits, bool zero_count,
+                         bool lower_from_device = false);
 
 }  // namespace pprhip

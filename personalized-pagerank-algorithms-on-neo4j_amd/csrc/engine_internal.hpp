@@ -105,7 +105,7 @@ void finish_dense(LevelCtx& L, pprhip_stats_t& st, uint64_t level_bytes, uint64_
                   uint64_t ef_next);
 int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& st, double* model_cost,
                bool yield_dense = false, RoundCut* cut = nullptr);
-int reset_query_state(pprhip_graph* g, bool clear_flags);
+int reset_query_state(pprhip_graph* g, bool clear_flags, int32_t node = -1);  // node: the query's source / target (internal id)
 int ensure_batch(pprhip_graph* P);
 void free_batch(pprhip_graph* P);
 int ensure_bwd_layout(pprhip_graph* P);
@@ -114,10 +114,10 @@ const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks);
 unsigned long long gs_thresh_of(const pprhip_graph* g);
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree);
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L);
-int device_sum(pprhip_graph* g, const double* x, double* out);
+int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count = 0);  // count 0: the query's scan bound
 int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st);
 int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,
-                   double* target, pprhip_stats_t& st);
+                   double* target, pprhip_stats_t& st, double omega_dev = 0.0);
 int copy_out(pprhip_graph* g, const double* dev, double* host);
 int check_graph(const pprhip_graph* g, const char* fn);
 int check_node(const pprhip_graph* g, int32_t v, const char* fn);

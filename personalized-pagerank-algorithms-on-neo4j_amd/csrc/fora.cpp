@@ -71,7 +71,7 @@ int fora_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, co
   r.n_rounds = n_rounds;
   std::memset(&r.st, 0, sizeof r.st);
   g->topk_active = false;
-  PPRHIP_TRY(reset_query_state(g, false));
+  PPRHIP_TRY(reset_query_state(g, false, src_internal));
   r.alpha = conf->alpha;
   r.rsum_local = conf->rsum;
   PPRHIP_TRY(pprhip_fora_whole_params(conf, eps, &r.rmax_local, &r.omega_local));  // Fora_Whole_Graph.java:86-87
@@ -188,7 +188,7 @@ int topk_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, co
   r.conf = conf;
   r.seed = seed;
   std::memset(&r.st, 0, sizeof r.st);
-  PPRHIP_TRY(reset_query_state(g, true));
+  PPRHIP_TRY(reset_query_state(g, true, src_internal));
   PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags + src_internal, 1, 1, g->stream));  // Q = {s} (:117-118)
   g->topk_active = true;
   g->topk_first = true;
@@ -217,7 +217,7 @@ int topk_begin(ForaRun& r, pprhip_graph* g, int32_t src_internal, double eps, co
 int topk_step(ForaRun& r, bool yield_dense) {
   pprhip_graph* g = r.g;
   const pprhip_fora_conf_t* conf = r.conf;
-  const size_t nd = sizeof(double) * (size_t)g->n;
+  const size_t nd = sizeof(double) * (size_t)act_n(g);  // (est beyond the query's scan bound is zero and stays so)
   for (;;) {
     if (r.phase == ForaRun::kTopkRoundStart) {
       if (!(r.delta_local >= r.min_delta)) {  // :123
@@ -247,20 +247,22 @@ int topk_step(ForaRun& r, bool yield_dense) {
       const int rc = run_levels(g, r.a, r.L, r.st, nullptr, yield_dense);
       if (rc != PPRHIP_OK) return rc;  // kYield or an error
       leave_push(r);
-      PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
+      // :142-168 without a host round trip: the residue sum stays on the device, where the walk plan derives rsum and
+      // the walk budget from it (:148,151) and the walk kernel reads the plan's counts; the sum reaches the host with
+      // the selection's read-back
+      PPRHIP_TRY(launch_sum(g, g->residue, act_n(g)));
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sum_out, &g->ctr->sum_out, sizeof(double), hipMemcpyDeviceToHost, g->stream));
       g->topk_first = false;
-      r.rsum_local = g->topk_rsum;  // :142
       // :143 reserve := copy of the push reserve (walk increments of earlier rounds are dropped)
       PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
-      const double rsum_rw = r.rsum_local * (1.0 - r.alpha);  // :148
-      const double nrw_d = r.omega_local * rsum_rw;
-      const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;  // :151
-      PPRHIP_TRY(run_walk_phase(g, 1, r.alpha, rsum_rw, nrw, r.seed, r.round, g->est, r.st));  // :155-168
+      PPRHIP_TRY(run_walk_phase(g, 1, r.alpha, 0.0, 0, r.seed, r.round, g->est, r.st, r.omega_local));  // :155-168
       r.round++;
       double kth = 0.0;
       bool have = false;
       int nsel = 0;
       PPRHIP_TRY(select_topk(g, g->est, conf->k, nullptr, nullptr, 0, &nsel, &kth, &have, r.st));  // :173
+      g->topk_rsum = g->h_ctr->sum_out;  // (the selection synchronised the stream)
+      r.rsum_local = g->topk_rsum;       // :142
       if (!have) kth = 0.0;                                                                          // :174
       r.st.kth_value = kth;
       if (kth >= (1 + r.eps_half) * r.delta_local || r.delta_local <= r.min_delta) {  // :175-176
@@ -300,7 +302,7 @@ int bwd_begin(ForaRun& r, pprhip_graph* g, int32_t target_internal, int32_t targ
   r.triples.clear();
   std::memset(&r.st, 0, sizeof r.st);
   g->topk_active = false;
-  PPRHIP_TRY(reset_query_state(g, false));
+  PPRHIP_TRY(reset_query_state(g, false, target_internal));
   r.waiting = false;
   r.in_push = false;
   if (hdeg_in(g, target_internal) == 0) {  // :46-49
@@ -329,7 +331,7 @@ int bwd_step(ForaRun& r, bool yield_dense) {
     const double threshold = r.rmax_local;
     unsigned long long thr_bits = 1ull;
     if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
-    PPRHIP_TRY(launch_select_gather(g, g->reserve, g->n, thr_bits, true));  // Base_Whole_Graph.java:83 pi >= threshold
+    PPRHIP_TRY(launch_select_gather(g, g->reserve, act_n(g), thr_bits, true));  // Base_Whole_Graph.java:83 pi >= threshold
     unsigned long long cnt = 0;
     PPRHIP_CHECK_HIP(hipMemcpyAsync(&cnt, g->sel_blob, sizeof cnt, hipMemcpyDeviceToHost, g->stream));
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
@@ -341,7 +343,7 @@ int bwd_step(ForaRun& r, bool yield_dense) {
         if (all[v] > 0.0 && all[v] >= threshold) r.triples.push_back({(int32_t)v, r.target_orig, all[v]});
     } else if (cnt) {
       std::vector<SelRec> recs(cnt);
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(recs.data(), g->sel_blob + 16, sizeof(SelRec) * cnt, hipMemcpyDeviceToHost, g->stream));
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(recs.data(), g->sel_blob + kSelHeader, sizeof(SelRec) * cnt, hipMemcpyDeviceToHost, g->stream));
       PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
       for (uint64_t i = 0; i < cnt; ++i) r.triples.push_back({n2o[recs[i].id], r.target_orig, recs[i].val});
     }
@@ -1007,7 +1009,7 @@ int pprhip_results_sum(pprhip_results_t* r, int i, double* sum_out) {
     set_error("pprhip_results_sum: null output");
     return PPRHIP_ERR_INVALID;
   }
-  return device_sum(r->g, r->buf + (size_t)i * r->g->n, sum_out);
+  return device_sum(r->g, r->buf + (size_t)i * r->g->n, sum_out, r->g->n);
 }
 
 int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k, double eps, double alpha,

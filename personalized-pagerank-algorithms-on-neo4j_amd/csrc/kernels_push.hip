@@ -1547,7 +1547,7 @@ int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned lo
         backward ? P->nz_rows_o : P->nz_rows, backward ? P->z_rows_o : P->zin_rows, cview(g, cbuf),
         backward ? g->in_rp : g->out_rp, g->F[out_fbuf], g->eoff[out_fbuf], g->cF, d_counter);
   } else {
-    k_compact_prepared<<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, cview(g, cbuf), false,
+    k_compact_prepared<<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), cview(g, cbuf), false,
                                                                 backward ? g->in_rp : g->out_rp, g->F[out_fbuf],
                                                                 g->eoff[out_fbuf], g->cF, d_counter);
   }
@@ -1565,37 +1565,37 @@ static int reduce_partials(pprhip_graph* g, uint32_t n_blocks, int out_slot, int
 }
 
 int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot) {
-  const uint32_t grid = grid_for(g->n, 256 * 8, 1024);
+  const uint32_t grid = grid_for(act_n(g), 256 * 8, 1024);
   if (seed_kind == 0)
-    k_count_active<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->armed,
+    k_count_active<0><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags, g->armed,
                                                                g->blk_pack, &g->ctr->hist[kMaxBatch + 2], a);
   else
-    k_count_active<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->armed,
+    k_count_active<1><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags, g->armed,
                                                                g->blk_pack, &g->ctr->hist[kMaxBatch + 2], a);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return reduce_partials(g, grid, out_slot, 0, false);
 }
 
 int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter) {
-  const uint32_t grid = grid_for(g->n, 1024, 1024);
+  const uint32_t grid = grid_for(act_n(g), 1024, 1024);
   if (seed_kind == 0)
-    k_seed_list<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->F[out_fbuf],
+    k_seed_list<0><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags, g->F[out_fbuf],
                                                             g->eoff[out_fbuf], d_counter, a);
   else
-    k_seed_list<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->out_rp, g->flags, g->F[out_fbuf],
+    k_seed_list<1><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags, g->F[out_fbuf],
                                                             g->eoff[out_fbuf], d_counter, a);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
 int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbuf, int out_slot, int dead_slot) {
-  const uint32_t grid = grid_for(g->n, 256 * 8, 1024);
+  const uint32_t grid = grid_for(act_n(g), 256 * 8, 1024);
   if (seed_kind == 0)
-    k_seed_dense<0><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->reserve, g->out_rp, g->flags,
+    k_seed_dense<0><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->reserve, g->out_rp, g->flags,
                                                              cview(g, cbuf), g->blk_pack, g->blk_dead,
                                                              g->blk_ndead, a);
   else
-    k_seed_dense<1><<<dim3(grid), dim3(256), 0, g->stream>>>(g->n, g->residue, g->reserve, g->out_rp, g->flags,
+    k_seed_dense<1><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->reserve, g->out_rp, g->flags,
                                                              cview(g, cbuf), g->blk_pack, g->blk_dead,
                                                              g->blk_ndead, a);
   PPRHIP_CHECK_HIP(hipGetLastError());

@@ -35,13 +35,71 @@ __global__ __launch_bounds__(256) void k_select_hist(const double* __restrict__ 
   }
 }
 
-// Candidates are 16-byte records behind a 16-byte header {count, -}: one copy brings the count and the records to the
-// host.  Block 0 leaves the histogram of the select that has just been read out all-zero for the next one.
+// After the first histogram pass (the 12 leading bits: sign and exponent): the bin that holds the k-th largest entry,
+// chosen on the device so that the gather can follow without a host round trip.  Header words: [1] the smallest bit
+// pattern the gather takes (the chosen bin's lower edge; 1 = every positive entry when fewer than k exist), [2] how
+// many entries that will be, [3] positive entries in all, [4] 1 when there are at least k.
+__global__ __launch_bounds__(1024) void k_select_choose(const uint32_t* __restrict__ hist, unsigned long long k,
+                                                         unsigned long long* __restrict__ hdr) {
+  __shared__ unsigned long long s_cnt[kHistBins];
+  __shared__ unsigned long long s_part[1024];
+  __shared__ unsigned long long s_total;
+  // suffix sums over the bins: bin b's count of entries in bins >= b
+  unsigned long long mine = 0;
+  for (int j = 0; j < kHistBins / 1024; ++j) {
+    const int b = threadIdx.x * (kHistBins / 1024) + j;
+    s_cnt[b] = hist[b];
+    mine += hist[b];
+  }
+  // exclusive suffix sums of the 1024 per-thread counts (s_part[t] = entries in the bins of the threads above t):
+  // ten doubling steps
+  s_part[threadIdx.x] = mine;
+  __syncthreads();
+  unsigned long long incl = mine;
+  for (int d = 1; d < 1024; d <<= 1) {
+    const unsigned long long add = threadIdx.x + d < 1024 ? s_part[threadIdx.x + d] : 0ull;
+    __syncthreads();
+    incl += add;
+    s_part[threadIdx.x] = incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    hdr[3] = incl;
+    s_total = incl;
+  }
+  __syncthreads();
+  s_part[threadIdx.x] = incl - mine;
+  __syncthreads();
+  const unsigned long long total = s_total;
+  if (threadIdx.x == 0 && (total == 0 || k > total)) {
+    hdr[1] = 1ull;
+    hdr[2] = total;
+    hdr[4] = 0ull;
+  }
+  if (total == 0 || k > total) return;
+  unsigned long long above = s_part[threadIdx.x];
+  for (int j = kHistBins / 1024 - 1; j >= 0; --j) {
+    const int b = threadIdx.x * (kHistBins / 1024) + j;
+    const unsigned long long c = s_cnt[b];
+    if (above < k && above + c >= k) {  // exactly one bin: the k-th largest lies in it
+      hdr[1] = (unsigned long long)b << 52;
+      hdr[2] = above + c;
+      hdr[4] = 1ull;
+    }
+    above += c;
+  }
+}
+
+// Candidates are 16-byte records behind a 64-byte header {count, lower bits, expected, total, have k, -}: one copy
+// brings the header and the records to the host.  lower_dev: take the lower bound from the header (k_select_choose
+// wrote it).  Block 0 leaves the histogram of the select that has just been read out all-zero for the next one.
 __global__ __launch_bounds__(256) void k_select_gather(const double* __restrict__ x, uint32_t n,
-                                                        unsigned long long lower_bits, char* __restrict__ blob,
-                                                        uint32_t cap, uint32_t* __restrict__ hist) {
+                                                        unsigned long long lower_bits, int lower_dev,
+                                                        char* __restrict__ blob, uint32_t cap,
+                                                        uint32_t* __restrict__ hist) {
   unsigned long long* count = reinterpret_cast<unsigned long long*>(blob);
-  SelRec* recs = reinterpret_cast<SelRec*>(blob + 16);
+  SelRec* recs = reinterpret_cast<SelRec*>(blob + kSelHeader);
+  if (lower_dev) lower_bits = count[1];
   if (blockIdx.x == 0)
     for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) hist[b] = 0u;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -86,12 +144,20 @@ int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned lo
   return PPRHIP_OK;
 }
 
-int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits, bool zero_count) {
+int launch_select_choose(pprhip_graph* g, unsigned long long k) {
+  hipLaunchKernelGGL(k_select_choose, dim3(1), dim3(1024), 0, g->stream, g->hist, k,
+                     reinterpret_cast<unsigned long long*>(g->sel_blob));
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits, bool zero_count,
+                         bool lower_from_device) {
   uint64_t b = ((uint64_t)n + 255) / 256;
   const uint32_t grid = (uint32_t)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
   if (zero_count) PPRHIP_CHECK_HIP(hipMemsetAsync(g->sel_blob, 0, sizeof(unsigned long long), g->stream));
-  hipLaunchKernelGGL(k_select_gather, dim3(grid), dim3(256), 0, g->stream, x, n, lower_bits, g->sel_blob, g->sel_cap,
-                     g->hist);
+  hipLaunchKernelGGL(k_select_gather, dim3(grid), dim3(256), 0, g->stream, x, n, lower_bits, lower_from_device ? 1 : 0,
+                     g->sel_blob, g->sel_cap, g->hist);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

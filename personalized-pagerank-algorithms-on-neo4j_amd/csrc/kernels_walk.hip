@@ -9,6 +9,8 @@
 // function, so terminals can be compared walk by walk.
 //
 // Memory-bound random gathers (one packed row extent + one col_idx per step); no MFMA.
+#include <algorithm>
+
 #include "device_utils.hpp"
 #include "engine.hpp"
 
@@ -122,15 +124,23 @@ __device__ __forceinline__ bool plan_entry(double r, double alpha, double rsum, 
 
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __restrict__ res, double* __restrict__ target,
-                                                  double alpha, double rsum, double nrw, int32_t* __restrict__ mc_node,
-                                                  double* __restrict__ mc_inc, unsigned long long* __restrict__ mc_woff,
-                                                  DevCounters* ctr) {
+                                                  double alpha, double rsum, double nrw, double omega_dev,
+                                                  int32_t* __restrict__ mc_node, double* __restrict__ mc_inc,
+                                                  unsigned long long* __restrict__ mc_woff, DevCounters* ctr,
+                                                  int parity) {
   const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = blockIdx.x * per;
   const uint32_t hi = lo + per < n ? lo + per : n;
   if (lo >= hi) return;
+  if (omega_dev > 0.0) {
+    // the budget from the residue sum on the device, with the host's own expressions (Fora_Topk.java:148,151 /
+    // Fora_Whole_Graph.java:112-113): rsum = sum * (1 - alpha); nrw = (long long)(omega * rsum)
+    rsum = ctr->sum_out * (1.0 - alpha);
+    const double nrw_d = omega_dev * rsum;
+    nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (double)(long long)nrw_d : 0.0;
+  }
   block_range_compact(
-      lo, hi, &ctr->mc_packed,
+      lo, hi, &ctr->mc_plan[parity],
       [&](uint32_t v, unsigned long long* w) {
         double incr;
         return plan_entry<VARIANT>(res[v], alpha, rsum, nrw, w, &incr);
@@ -158,23 +168,30 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
 // ------------------------------------------------------------------------------------------------
 constexpr int kWalkChunk = 1024;
 
-__global__ __launch_bounds__(256) void k_mc_walk(uint32_t n_src, unsigned long long n_walks,
-                                                  const int32_t* __restrict__ mc_node,
+__global__ __launch_bounds__(256) void k_mc_walk(const int32_t* __restrict__ mc_node,
                                                   const double* __restrict__ mc_inc,
                                                   const unsigned long long* __restrict__ mc_woff,
                                                   const unsigned long long* __restrict__ out_ext,
                                                   const uint4* __restrict__ walk_rec,
                                                   const int32_t* __restrict__ new2old, double* __restrict__ target,
                                                   double alpha, uint32_t k0, uint32_t k1, uint32_t stream,
-                                                  int no_zero_hop, DevCounters* ctr) {
+                                                  int no_zero_hop, DevCounters* ctr, int parity) {
+  // the plan kernel counted sources and walks into mc_plan[parity]; the other cell (read by the phase before) is
+  // cleared for the plan of the phase after, and the query's totals grow by this phase
+  const unsigned long long plan = ctr->mc_plan[parity];
+  const uint32_t n_src = (uint32_t)(plan >> kPackShift);
+  const unsigned long long n_walks = plan & kPackMask;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctr->mc_plan[parity ^ 1] = 0ull;
+    ctr->walks_total += n_walks;
+    ctr->sources_total += n_src;
+  }
   __shared__ unsigned long long s_woff[kWalkChunk + 1];
   __shared__ int32_t s_node[kWalkChunk];
   __shared__ double s_inc[kWalkChunk];
   __shared__ uint32_t s_e0;
   const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
   unsigned long long steps_total = 0;
-  // the host has read the plan counter (its values are this launch's arguments): cleared for the next plan
-  if (blockIdx.x == 0 && tid == 0) ctr->mc_packed = 0ull;
   const unsigned long long n_chunks = (n_walks + kWalkChunk - 1) / kWalkChunk;
   for (unsigned long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
     const unsigned long long lo = ch * kWalkChunk;
@@ -288,10 +305,12 @@ __global__ __launch_bounds__(256) void k_build_walk_rec(unsigned long long m, co
   }
 }
 
-__global__ void k_plan_single(int32_t src, double inc, int32_t* mc_node, double* mc_inc, unsigned long long* mc_woff) {
+__global__ void k_plan_single(int32_t src, double inc, unsigned long long n_walks, int32_t* mc_node, double* mc_inc,
+                              unsigned long long* mc_woff, DevCounters* ctr, int parity) {
   mc_node[0] = src;
   mc_inc[0] = inc;
   mc_woff[0] = 0;
+  ctr->mc_plan[parity] = (1ull << kPackShift) | n_walks;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,28 +330,36 @@ int launch_build_walk_rec(pprhip_graph* g) {
   return PPRHIP_OK;
 }
 
-int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double* target) {
-  uint64_t b = ((uint64_t)g->n + 1023) / 1024;
+int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double omega_dev, double* target) {
+  const uint32_t n = act_n(g);
+  uint64_t b = ((uint64_t)n + 1023) / 1024;
   const uint32_t grid = (uint32_t)(b > 1024 ? 1024 : b);
   if (variant == 0)
-    hipLaunchKernelGGL(k_mc_plan<0>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, target, alpha, rsum, nrw,
-                       g->mc_node, g->mc_inc, g->mc_woff, g->ctr);
+    hipLaunchKernelGGL(k_mc_plan<0>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
+                       omega_dev, g->mc_node, g->mc_inc, g->mc_woff, g->ctr, g->mc_parity);
   else
-    hipLaunchKernelGGL(k_mc_plan<1>, dim3(grid), dim3(256), 0, g->stream, g->n, g->residue, target, alpha, rsum, nrw,
-                       g->mc_node, g->mc_inc, g->mc_woff, g->ctr);
+    hipLaunchKernelGGL(k_mc_plan<1>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
+                       omega_dev, g->mc_node, g->mc_inc, g->mc_woff, g->ctr, g->mc_parity);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
-int launch_mc_walk(pprhip_graph* g, uint64_t n_sources, uint64_t n_walks, double alpha, uint64_t seed, uint32_t stream,
-                   int no_zero_hop, double* target) {
-  if (n_walks == 0 || n_sources == 0) return PPRHIP_OK;
-  uint64_t chunks = (n_walks + kWalkChunk - 1) / kWalkChunk;
-  const uint32_t grid = (uint32_t)(chunks > (1u << 22) ? (1u << 22) : chunks);  // one chunk per workgroup: the dispatcher balances
-  hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(256), 0, g->stream, (uint32_t)n_sources,
-                     (unsigned long long)n_walks, g->mc_node, g->mc_inc, g->mc_woff, g->out_ext, g->walk_rec, g->new2old, target, alpha,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, g->ctr);
+// The walk count is only known on the device: every workgroup takes the chunks of 1024 walks whose index is congruent to
+// its own.  With a bound from the host (g->walk_hint: the budget) the grid has one workgroup per possible chunk, so
+// that the dispatcher balances walks of uneven length as it did when the count travelled through the host; without
+// one (top-k rounds) a fixed grid.
+int launch_mc_walk(pprhip_graph* g, double alpha, uint64_t seed, uint32_t stream, int no_zero_hop, double* target) {
+  uint32_t grid = (uint32_t)g->n_cus * 32u;
+  if (g->walk_hint) {
+    const unsigned long long chunks = (g->walk_hint + kWalkChunk - 1) / kWalkChunk;
+    grid = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(chunks, 1ull), 1ull << 22);
+  }
+  g->walk_hint = 0;
+  hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(256), 0, g->stream, g->mc_node, g->mc_inc, g->mc_woff, g->out_ext,
+                     g->walk_rec, g->new2old, target, alpha, (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop,
+                     g->ctr, g->mc_parity);
   PPRHIP_CHECK_HIP(hipGetLastError());
+  g->mc_parity ^= 1;
   return PPRHIP_OK;
 }
 
@@ -350,9 +377,10 @@ int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* 
 
 int launch_mc_pure(pprhip_graph* g, int32_t src, uint64_t n_walks, double alpha, uint64_t seed, double inc,
                    double* target) {
-  hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(1), 0, g->stream, src, inc, g->mc_node, g->mc_inc, g->mc_woff);
+  hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(1), 0, g->stream, src, inc, (unsigned long long)n_walks, g->mc_node,
+                     g->mc_inc, g->mc_woff, g->ctr, g->mc_parity);
   PPRHIP_CHECK_HIP(hipGetLastError());
-  return launch_mc_walk(g, 1, n_walks, alpha, seed, 0, 0, target);
+  return launch_mc_walk(g, alpha, seed, 0, 0, target);
 }
 
 }  // namespace pprhip
