@@ -364,7 +364,7 @@ def main():
             "value_vectors_resident": round(value, 3),
             "avg_rounds": round(acc["rounds"] / nq, 2),
             "kernel_ms_per_query": {pkg.KERNEL_NAMES[c]: round(acc["class_ms"][c] / nq, 3)
-                                    for c in (1, 2, 3, 5) if acc["class_launches"][c]},
+                                    for c in (1, 2, 3, 5, 6) if acc["class_launches"][c]},
             "host_gap": {"wall_ms_per_query": round(1e3 * elapsed / (args.steps * q), 3),
                          "kernel_ms_per_query": round(kernel_ms / nq, 3),
                          "fraction_not_in_kernels": round(1.0 - (kernel_ms / nq) / (1e3 * elapsed / (args.steps * q)), 4)},
@@ -818,7 +818,8 @@ def pmc_traffic(args, host):
     factor = 2.0
     cal = [v["FETCH_SIZE"] for name, v in fetch[1] if name == "k_sum_partial" and "FETCH_SIZE" in v]
     if cal:
-        ratio = (sum(cal) / len(cal)) * 1024.0 / (8.0 * n)
+        # the phase's last launch is store.sum(0) over all n values (sums inside the queries stop at the live range)
+        ratio = cal[-1] * 1024.0 / (8.0 * n)
         res["calibration"] = round(ratio, 3)
         if 0.4 < ratio < 1.1:
             factor = 1.0 / ratio

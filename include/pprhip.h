@@ -98,6 +98,9 @@ typedef struct pprhip_stats {
 #define PPRHIP_KERNEL_WALK 3
 #define PPRHIP_KERNEL_BACKWARD_BATCH 4
 #define PPRHIP_KERNEL_DENSE_PULL_BATCH 5 /* one dense level for up to PPRHIP_BATCH queries */
+#define PPRHIP_KERNEL_QUERY_SETUP 6      /* the short kernels around a query's phases: clearing its workspace, seeding a
+                                          * round's frontier, residue sums, the walk plan, top-k selection (one "launch" =
+                                          * one such group) */
 #define PPRHIP_BATCH 16                  /* queries in flight in pprhip_fora_batch_single_source */
 
 /* Engine tuning: the deterministic replacement of the reference's wall-clock push/walk balance

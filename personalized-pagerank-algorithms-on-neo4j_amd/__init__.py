@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libpprhip.so")
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_IO, ERR_STATE = -1, -2, -3, -4, -5, -6
 
-KERNEL_NAMES = {0: "none", 1: "dense_pull", 2: "sparse_push", 3: "walk", 4: "backward_batch", 5: "dense_pull_batch"}
+KERNEL_NAMES = {0: "none", 1: "dense_pull", 2: "sparse_push", 3: "walk", 4: "backward_batch", 5: "dense_pull_batch",
+                6: "query_setup"}
 BATCH = 16  # PPRHIP_BATCH: queries in flight in fora_batch_single_source
 
 

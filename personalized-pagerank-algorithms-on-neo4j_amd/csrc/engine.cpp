@@ -5,6 +5,7 @@
 // points live in fora.cpp, All-Pair and the index in allpair.cpp (shared declarations:
 // engine_internal.hpp).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -37,9 +38,14 @@ int init_device_once(int device) {
   PPRHIP_TRY(init_kernels_select());
   PPRHIP_TRY(init_kernels_apbs());
   PPRHIP_TRY(init_kernels_sort());
+  PPRHIP_TRY(init_kernels_host());
   if ((size_t)device >= g_dev_inited.size()) g_dev_inited.resize((size_t)device + 1, 0);
   g_dev_inited[device] = 1;
   return PPRHIP_OK;
+}
+
+SetupScope::SetupScope(pprhip_graph* g) : t(g_timer_cur->stream == g->stream ? g_timer_cur : nullptr) {
+  if (t) t->begin(PPRHIP_KERNEL_QUERY_SETUP, 0);
 }
 
 int alloc_dev(void** p, size_t bytes) {
@@ -51,10 +57,44 @@ int alloc_dev(void** p, size_t bytes) {
   return PPRHIP_OK;
 }
 
+// A few words the host needs before it can queue the next kernel: published by a kernel into mapped pinned memory and
+// awaited by spinning on the sequence word (kernels_host.hip); after kSpinUs the thread stops spinning and blocks in
+// hipStreamSynchronize, which is also where a faulted kernel is reported.  `bytes`: a multiple of 8.
+int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes) {
+  if (!g->mail || bytes > sizeof(unsigned long long) * kMailWords || (bytes & 7)) {
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    return PPRHIP_OK;
+  }
+  constexpr double kSpinUs = 60.0;
+  const unsigned long long seq = ++g->mail_seq;
+  PPRHIP_TRY(launch_publish(g, dev, (uint32_t)(bytes / 8), seq));
+  const auto t0 = std::chrono::steady_clock::now();
+  bool arrived = false;
+  for (uint32_t spins = 0;; ++spins) {
+    if (__atomic_load_n(&g->mail->seq, __ATOMIC_ACQUIRE) == seq) {
+      arrived = true;
+      break;
+    }
+    __builtin_ia32_pause();
+    if ((spins & 63u) == 63u &&
+        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kSpinUs)
+      break;
+  }
+  if (!arrived) {
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    if (__atomic_load_n(&g->mail->seq, __ATOMIC_ACQUIRE) != seq) {
+      set_error("fetch_small: the stream drained without the published words (sequence %llu, expected %llu)",
+                (unsigned long long)g->mail->seq, seq);
+      return PPRHIP_ERR_STATE;
+    }
+  }
+  std::memcpy(host, g->mail->words, bytes);
+  return PPRHIP_OK;
+}
+
 int read_packed(pprhip_graph* g, int slot, uint32_t* nf, uint64_t* ef) {
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->packed[slot], &g->ctr->packed[slot], sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, g->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  PPRHIP_TRY(fetch_small(g, &g->ctr->packed[slot], &g->h_ctr->packed[slot], sizeof(unsigned long long)));
   const unsigned long long pk = g->h_ctr->packed[slot];
   *nf = (uint32_t)(pk >> kPackShift);
   *ef = pk & kPackMask;
@@ -388,9 +428,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
         if (first_of_phase)
           PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[cc], 0, sizeof(double) * g->n, g->stream));
       }
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->dhist[0], &g->ctr->dhist[0],
-                                      sizeof(unsigned long long) * 8 + sizeof(int) * 8, hipMemcpyDeviceToHost, g->stream));
-      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      PPRHIP_TRY(fetch_small(g, &g->ctr->dhist[0], &g->h_ctr->dhist[0], sizeof(unsigned long long) * 8 + sizeof(int) * 8));
       int state = L.gs_state;
       for (int j = 0; j < kDenseBatch; ++j) {
         if (j > 0) {
@@ -441,9 +479,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot, i == 0 ? pk0 : ~0ull));
     }
     ktimer().end();
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->hist[0], &g->ctr->hist[0], sizeof(unsigned long long) * (kMaxBatch + 1),
-                                    hipMemcpyDeviceToHost, g->stream));
-    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    PPRHIP_TRY(fetch_small(g, &g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long) * (kMaxBatch + 1)));
     uint64_t batch_bytes = 0;
     int ran = 0;
     for (int i = 0; i < n_batch; ++i) {
@@ -497,13 +533,21 @@ int reset_query_state(pprhip_graph* g, bool clear_flags, int32_t node) {
   g->n_act = (n_live && node >= 0 && (uint32_t)node < n_live) ? n_live : g->n;
   const uint32_t clr = std::max(g->n_act, g->n_dirty ? g->n_dirty : g->n);
   g->n_dirty = g->n_act;
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->residue, 0, sizeof(double) * clr, g->stream));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->reserve, 0, sizeof(double) * clr, g->stream));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->ctr, 0, sizeof(DevCounters), g->stream));
-  if (clear_flags) PPRHIP_CHECK_HIP(hipMemsetAsync(g->flags, 0, clr, g->stream));
+  ClearList cl{};  // one launch for all of them (five fill commands before: the device idled between them)
+  auto add = [&](void* p, size_t bytes) {
+    cl.p[cl.n] = p;
+    cl.bytes[cl.n++] = bytes;
+  };
+  add(g->residue, sizeof(double) * clr);
+  add(g->reserve, sizeof(double) * clr);
+  add(g->ctr, sizeof(DevCounters));
+  if (clear_flags) add(g->flags, clr);
   // the top-k estimate is rewritten over the new query's n_act entries only: what the query before left beyond them goes
-  if (clr > g->n_act)
-    PPRHIP_CHECK_HIP(hipMemsetAsync(g->est + g->n_act, 0, sizeof(double) * (clr - g->n_act), g->stream));
+  if (clr > g->n_act) add(g->est + g->n_act, sizeof(double) * (clr - g->n_act));
+  {
+    SetupScope setup(g);
+    PPRHIP_TRY(launch_clear(g, cl));
+  }
   g->mc_parity = 0;  // (both plan cells were just cleared)
   g->result_in_est = false;
   return PPRHIP_OK;
@@ -513,7 +557,7 @@ int reset_query_state(pprhip_graph* g, bool clear_flags, int32_t node) {
 int alloc_workspace(pprhip_graph* G) {
   const uint32_t n = G->n;
   const size_t nd = sizeof(double) * (size_t)n;
-  void** dbl[] = {(void**)&G->residue, (void**)&G->reserve, (void**)&G->est, (void**)&G->cF, (void**)&G->mc_inc};
+  void** dbl[] = {(void**)&G->residue, (void**)&G->reserve, (void**)&G->est, (void**)&G->cF};
   for (void** p : dbl) PPRHIP_TRY(alloc_dev(p, nd));
   if (!G->parent) {  // single-query dense levels; slots use the parent's interleaved arrays
     PPRHIP_TRY(alloc_dev((void**)&G->cdense[0], nd));
@@ -527,8 +571,7 @@ int alloc_workspace(pprhip_graph* G) {
   PPRHIP_TRY(alloc_dev((void**)&G->flags, n));
   PPRHIP_TRY(alloc_dev((void**)&G->armed, sizeof(uint32_t) * ((size_t)n / 32 + 2)));
   PPRHIP_CHECK_HIP(hipMemsetAsync(G->armed, 0, sizeof(uint32_t) * ((size_t)n / 32 + 2), G->stream));
-  PPRHIP_TRY(alloc_dev((void**)&G->mc_node, sizeof(int32_t) * (size_t)n));
-  PPRHIP_TRY(alloc_dev((void**)&G->mc_woff, sizeof(unsigned long long) * (size_t)n));
+  PPRHIP_TRY(alloc_dev((void**)&G->mc_plan_rec, sizeof(WalkPlanRec) * (size_t)n));
   PPRHIP_TRY(alloc_dev((void**)&G->partial, sizeof(double) * 1024));
   PPRHIP_TRY(alloc_dev((void**)&G->hist, sizeof(uint32_t) * 4096));
   {
@@ -547,6 +590,13 @@ int alloc_workspace(pprhip_graph* G) {
     return PPRHIP_ERR_OOM;
   }
   std::memset(G->h_ctr, 0, sizeof(DevCounters));
+  if (hipHostMalloc((void**)&G->mail, sizeof(HostMail), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&G->mail_dev, G->mail, 0) != hipSuccess) {
+    set_error("hipHostMalloc (mapped) failed");
+    return PPRHIP_ERR_OOM;
+  }
+  std::memset(G->mail, 0, sizeof(HostMail));
+  G->mail_seq = 0;
   for (auto& e : G->ev)
     if (hipEventCreate(&e) != hipSuccess) {
       set_error("hipEventCreate failed");
@@ -564,11 +614,13 @@ int alloc_workspace(pprhip_graph* G) {
 
 void free_workspace(pprhip_graph* g) {
   void* ptrs[] = {g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1],
-                  g->eoff[0], g->eoff[1], g->flags, g->armed, g->mc_node, g->mc_inc, g->mc_woff, g->partial, g->hist, g->sel_blob,
+                  g->eoff[0], g->eoff[1], g->flags, g->armed, g->mc_plan_rec, g->partial, g->hist, g->sel_blob,
                   g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
+  if (g->mail) (void)hipHostFree(g->mail);
+  g->mail = g->mail_dev = nullptr;
   for (auto e : g->ev)
     if (e) (void)hipEventDestroy(e);
 }
@@ -735,7 +787,10 @@ int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree) {
 
 // frontier from a predicate over all nodes (round starts)
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
-  PPRHIP_TRY(launch_count_active(g, a, kind, L.pslot));
+  {
+    SetupScope setup(g);
+    PPRHIP_TRY(launch_count_active(g, a, kind, L.pslot));
+  }
   PPRHIP_TRY(read_packed(g, L.pslot, &L.nf, &L.ef));
   L.dense_prepared = false;
   L.gs_dirty = false;
@@ -746,23 +801,30 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
       if (g->sync) g->sync->c8_enter(g->slot_index);
       L.ccur = g->parent->c8cur;
     }
-    PPRHIP_TRY(launch_seed_dense(g, a, kind, L.ccur, L.pslot, L.dslot));
+    {
+      SetupScope setup(g);
+      PPRHIP_TRY(launch_seed_dense(g, a, kind, L.ccur, L.pslot, L.dslot));
+    }
     L.dense_prepared = true;
     L.dense_run = 0;
   } else if (L.nf || kind == 1) {
     // kind 1 also runs for an empty start set: parked nodes below min_rmax still leave the set
     // (Forward_Push.java:241-247)
     // (its list counter, hist[kMaxBatch + 2], was cleared by the counting pass above)
-    PPRHIP_TRY(launch_seed_list(g, a, kind, L.fcur, &g->ctr->hist[kMaxBatch + 2]));
+    {
+      SetupScope setup(g);
+      PPRHIP_TRY(launch_seed_list(g, a, kind, L.fcur, &g->ctr->hist[kMaxBatch + 2]));
+    }
   }
   return PPRHIP_OK;
 }
 
 int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count) {
-  PPRHIP_TRY(launch_sum(g, x, count ? count : act_n(g)));
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sum_out, &g->ctr->sum_out, sizeof(double), hipMemcpyDeviceToHost,
-                                  g->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  {
+    SetupScope setup(g);
+    PPRHIP_TRY(launch_sum(g, x, count ? count : act_n(g)));
+  }
+  PPRHIP_TRY(fetch_small(g, &g->ctr->sum_out, &g->h_ctr->sum_out, sizeof(double)));
   *out = g->h_ctr->sum_out;
   return PPRHIP_OK;
 }
@@ -771,9 +833,7 @@ int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count) {
 // run since the workspace was reset counted on the device (steps, walks, sources: adjacent in DevCounters).
 int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st) {
   static_assert(offsetof(DevCounters, sources_total) == offsetof(DevCounters, dead_pops) + 24, "one copy for the four");
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->dead_pops, &g->ctr->dead_pops, 4 * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, g->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  PPRHIP_TRY(fetch_small(g, &g->ctr->dead_pops, &g->h_ctr->dead_pops, 4 * sizeof(unsigned long long)));
   st.push_bytes += 16ull * (g->h_ctr->dead_pops - st.dead_end_pops);
   st.dead_end_pops = g->h_ctr->dead_pops;
   // cumulative over the query's walk phases: what is new since the last read goes into the statistics
@@ -805,7 +865,10 @@ int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long
     set_error("walk budget %.0f exceeds the engine's 2^36 walk limit", bound);
     return PPRHIP_ERR_INVALID;
   }
-  PPRHIP_TRY(launch_mc_plan(g, variant, alpha, rsum, (double)nrw, omega_dev, target));
+  {
+    SetupScope setup(g);
+    PPRHIP_TRY(launch_mc_plan(g, variant, alpha, rsum, (double)nrw, omega_dev, target));
+  }
   ktimer().begin(PPRHIP_KERNEL_WALK, 0);  // (its bytes are added when the counters are read)
   PPRHIP_TRY(launch_mc_walk(g, alpha, seed, stream, variant == 0 ? 1 : 0, target));
   ktimer().end();
@@ -943,8 +1006,7 @@ static int select_topk_passes(pprhip_graph* g, const double* x, int k, int32_t* 
   const bool prefetched = expected > 0 && expected <= g->sel_cap;
   const size_t want = prefetched ? (size_t)expected : 0;
   std::vector<char> blob(kSelHeader + sizeof(SelRec) * want);
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(blob.data(), g->sel_blob, blob.size(), hipMemcpyDeviceToHost, g->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  PPRHIP_TRY(fetch_small(g, g->sel_blob, blob.data(), blob.size()));
   st.select_bytes += 8ull * g->n;
   uint64_t cnt = 0;
   std::memcpy(&cnt, blob.data(), 8);
@@ -983,12 +1045,14 @@ static int select_topk_passes(pprhip_graph* g, const double* x, int k, int32_t* 
 int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
                 double* kth_out, bool* have_kth, pprhip_stats_t& st) {
   constexpr size_t kPre = 2048;
-  PPRHIP_TRY(launch_select_hist(g, x, act_n(g), 0ull, 0, 12, true));
-  PPRHIP_TRY(launch_select_choose(g, (unsigned long long)k));
-  PPRHIP_TRY(launch_select_gather(g, x, act_n(g), 0ull, false, true));
+  {
+    SetupScope setup(g);
+    PPRHIP_TRY(launch_select_hist(g, x, act_n(g), 0ull, 0, 12, true));
+    PPRHIP_TRY(launch_select_choose(g, (unsigned long long)k));
+    PPRHIP_TRY(launch_select_gather(g, x, act_n(g), 0ull, false, true));
+  }
   std::vector<char> blob(kSelHeader + sizeof(SelRec) * kPre);
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(blob.data(), g->sel_blob, blob.size(), hipMemcpyDeviceToHost, g->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  PPRHIP_TRY(fetch_small(g, g->sel_blob, blob.data(), blob.size()));
   st.select_passes++;
   st.select_bytes += 16ull * act_n(g);
   unsigned long long hdr[5];

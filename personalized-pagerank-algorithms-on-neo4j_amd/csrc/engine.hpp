@@ -208,6 +208,27 @@ struct SlotArgs {
   int32_t gs_state;  // GsState of this slot in this sweep
 };
 
+// Small results the host waits for (kernels_host.hip): mapped pinned memory a kernel writes and the host reads.
+constexpr uint32_t kMailWords = 4112;  // the selection's header and 2048 records fit
+struct HostMail {
+  unsigned long long seq;  // written last; the host spins on it
+  unsigned long long pad[7];
+  unsigned long long words[kMailWords];
+};
+
+struct ClearList {  // ranges one k_clear launch zeroes
+  void* p[6];
+  unsigned long long bytes[6];
+  int n;
+};
+
+struct WalkPlanRec {  // one residue entry of a walk phase (k_mc_plan -> k_mc_walk): 32 bytes
+  unsigned long long woff;  // walks of the entries before it
+  double inc;               // what each of its walks adds at its terminal
+  unsigned long long ext;   // the node's out-row (out_ext: first edge | degree << 32)
+  int32_t node, orig;       // internal id; original id (a word of the walk's Philox counter)
+};
+
 }  // namespace pprhip
 
 namespace pprhip {
@@ -305,9 +326,7 @@ struct pprhip_graph {
   // walk plan
   int mc_parity = 0;  // DevCounters::mc_plan cell of the next walk phase
   unsigned long long walk_hint = 0;  // upper bound of the next walk phase's walks when the host knows one (grid size)
-  int32_t* mc_node = nullptr;
-  double* mc_inc = nullptr;
-  unsigned long long* mc_woff = nullptr;
+  pprhip::WalkPlanRec* mc_plan_rec = nullptr;  // n entries: the residue entries of a walk phase (k_mc_plan)
   // reductions / selection scratch
   double* partial = nullptr;       // 1024 partial sums
   uint32_t* hist = nullptr;        // 4096-bin histogram
@@ -318,6 +337,9 @@ struct pprhip_graph {
   uint32_t sel_cap = 0;
   pprhip::DevCounters* ctr = nullptr;    // device
   pprhip::DevCounters* h_ctr = nullptr;  // pinned host mirror
+  pprhip::HostMail* mail = nullptr;      // mapped pinned memory: small read-backs without a copy command (fetch_small)
+  pprhip::HostMail* mail_dev = nullptr;  // the same, as the device sees it
+  unsigned long long mail_seq = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   pprhip_tuning_t tun{};
   // resumable top-k push session (Forward_Push object state)
@@ -380,6 +402,9 @@ int init_kernels_apbs();
 
 // ---- kernels_walk.hip
 int launch_build_walk_rec(pprhip_graph* g);
+int init_kernels_host();
+int launch_publish(pprhip_graph* g, const void* src, uint32_t n_words, unsigned long long seq);
+int launch_clear(pprhip_graph* g, const ClearList& L);
 // The walk phase runs without a host round trip: the plan kernel counts sources and walks into DevCounters::mc_plan
 // [g->mc_parity], the walk kernel (a fixed grid) reads them there.  omega_dev > 0: the plan derives rsum and the walk
 // budget itself from the residue sum a reduction left in DevCounters::sum_out (top-k rounds: Fora_Topk.java:148-151);

@@ -95,6 +95,16 @@ constexpr int kYield = 1;  // run_levels: the next level is dense and the caller
 extern thread_local KernelTimer* g_timer_cur;
 inline KernelTimer& ktimer() { return *g_timer_cur; }
 
+// Brackets a group of a query's short bookkeeping kernels (class PPRHIP_KERNEL_QUERY_SETUP) for the calling thread's
+// timer - when that timer is watching this handle's stream (workspaces are also reset outside any timed call).
+struct SetupScope {
+  KernelTimer* t;
+  explicit SetupScope(pprhip_graph* g);
+  ~SetupScope() {
+    if (t) t->end();
+  }
+};
+
 int alloc_dev(void** p, size_t bytes);
 double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense);
 uint64_t dense_level_bytes(const pprhip_graph* g);
@@ -114,6 +124,7 @@ const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks);
 unsigned long long gs_thresh_of(const pprhip_graph* g);
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree);
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L);
+int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes);  // a few words, without a copy command
 int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count = 0);  // count 0: the query's scan bound
 int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st);
 int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,

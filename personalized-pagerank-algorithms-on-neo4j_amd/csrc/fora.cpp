@@ -333,8 +333,7 @@ int bwd_step(ForaRun& r, bool yield_dense) {
     if (threshold > 0.0) std::memcpy(&thr_bits, &threshold, 8);
     PPRHIP_TRY(launch_select_gather(g, g->reserve, act_n(g), thr_bits, true));  // Base_Whole_Graph.java:83 pi >= threshold
     unsigned long long cnt = 0;
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(&cnt, g->sel_blob, sizeof cnt, hipMemcpyDeviceToHost, g->stream));
-    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    PPRHIP_TRY(fetch_small(g, g->sel_blob, &cnt, sizeof cnt));
     const std::vector<int32_t>& n2o = host_of(g)->h_new2old;
     if (cnt > g->sel_cap) {
       std::vector<double> all(g->n);
@@ -438,9 +437,7 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
   P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
   PPRHIP_TRY(launch_dense_level_b8(P, backward, gs_blocks, n_gs));
   P->ktimer.end();
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(P->h_sweep_out, P->sweep_out, sizeof(unsigned long long) * kBatch,
-                                  hipMemcpyDeviceToHost, P->stream));
-  PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
+  PPRHIP_TRY(fetch_small(P, P->sweep_out, P->h_sweep_out, sizeof(unsigned long long) * kBatch));
   P->c8cur ^= 1;
   for (int s = 0; s < kBatch; ++s)
     if (active[s]) {
@@ -472,9 +469,13 @@ int finish_query(BatchJob& J, ForaRun& r) {
     r.query = -1;
     return PPRHIP_OK;
   }
-  if (J.keep)  // the vector stays in HBM after the slot moves on (internal order; pprhip_results_fetch permutes)
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(J.keep->buf + (size_t)i * J.P->n, r.kind == 1 ? S->est : S->reserve,
-                                    sizeof(double) * (size_t)J.P->n, hipMemcpyDeviceToDevice, S->stream));
+  if (J.keep) {  // the vector stays in HBM after the slot moves on (internal order; pprhip_results_fetch permutes)
+    {
+      SetupScope setup(S);
+      PPRHIP_CHECK_HIP(hipMemcpyAsync(J.keep->buf + (size_t)i * J.P->n, r.kind == 1 ? S->est : S->reserve,
+                                      sizeof(double) * (size_t)J.P->n, hipMemcpyDeviceToDevice, S->stream));
+    }
+  }
   if (J.reserve_out) {
     double* dst = J.reserve_out + (size_t)i * J.P->n;
     if (J.pipe) PPRHIP_TRY(J.pipe->submit(S, r.kind == 1 ? S->est : S->reserve, dst));

@@ -1,0 +1,59 @@
+// kernels_host.hip — what the host asks of the device between two kernels of a query (gfx950): clearing several
+// ranges in one launch, and handing a few words back without a copy command.
+//
+// A query is a chain of short kernels with the host deciding in between (which level form comes next, how many walks,
+// which histogram bin holds the k-th value).  Each decision used to cost hipMemcpyAsync + hipStreamSynchronize: a blit
+// kernel, the completion interrupt and the wake-up of the waiting thread - 14.4 us per round trip, against 2.9 us
+// between two dependent kernels (tools/micro/roundtrip.hip, profiles/r03_roundtrip.txt).  k_publish writes the words
+// into mapped pinned memory itself and a sequence word after them; the host spins on the sequence word: 6.6 us.
+#include <algorithm>
+
+#include "device_utils.hpp"
+#include "engine.hpp"
+
+namespace pprhip {
+
+__global__ __launch_bounds__(256) void k_publish(const unsigned long long* __restrict__ src, uint32_t n_words,
+                                                  HostMail* mail, unsigned long long seq) {
+  for (uint32_t i = threadIdx.x; i < n_words; i += 256) mail->words[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void k_clear(ClearList L) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  for (int r = 0; r < L.n; ++r) {
+    unsigned long long* p = static_cast<unsigned long long*>(L.p[r]);
+    const size_t words = L.bytes[r] / 8;
+    for (size_t i = t; i < words; i += stride) p[i] = 0ull;
+    if (t < (L.bytes[r] & 7)) static_cast<unsigned char*>(L.p[r])[words * 8 + t] = 0;
+  }
+}
+
+int init_kernels_host() {  // loads this file's code object on the current device (see init_kernels_push)
+  hipFuncAttributes fa;
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_publish)));
+  return PPRHIP_OK;
+}
+
+int launch_publish(pprhip_graph* g, const void* src, uint32_t n_words, unsigned long long seq) {
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, g->stream, static_cast<const unsigned long long*>(src), n_words,
+                     g->mail_dev, seq);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+// every range starts on an 8-byte boundary
+int launch_clear(pprhip_graph* g, const ClearList& L) {
+  size_t total = 0;
+  for (int r = 0; r < L.n; ++r) total += L.bytes[r];
+  if (total == 0) return PPRHIP_OK;
+  const size_t blocks = (total / 8 + 256 * 16 - 1) / (256 * 16);
+  const uint32_t grid = (uint32_t)std::min<size_t>(std::max<size_t>(blocks, 1), (size_t)g->n_cus * 8);
+  hipLaunchKernelGGL(k_clear, dim3(grid), dim3(256), 0, g->stream, L);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+}  // namespace pprhip

@@ -125,9 +125,9 @@ __device__ __forceinline__ bool plan_entry(double r, double alpha, double rsum, 
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __restrict__ res, double* __restrict__ target,
                                                   double alpha, double rsum, double nrw, double omega_dev,
-                                                  int32_t* __restrict__ mc_node, double* __restrict__ mc_inc,
-                                                  unsigned long long* __restrict__ mc_woff, DevCounters* ctr,
-                                                  int parity) {
+                                                  const unsigned long long* __restrict__ out_ext,
+                                                  const int32_t* __restrict__ new2old, WalkPlanRec* __restrict__ plan,
+                                                  DevCounters* ctr, int parity) {
   const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = blockIdx.x * per;
   const uint32_t hi = lo + per < n ? lo + per : n;
@@ -147,11 +147,14 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
       },
       [&](uint32_t v, uint32_t pos, unsigned long long woff, unsigned long long) {
         unsigned long long w;
-        double incr = 0.0;
-        (void)plan_entry<VARIANT>(res[v], alpha, rsum, nrw, &w, &incr);
-        mc_node[pos] = (int32_t)v;
-        mc_inc[pos] = incr;
-        mc_woff[pos] = woff;
+        WalkPlanRec r;
+        r.inc = 0.0;
+        (void)plan_entry<VARIANT>(res[v], alpha, rsum, nrw, &w, &r.inc);
+        r.woff = woff;
+        r.ext = out_ext[v];  // what a walk needs of its start node travels with the entry: the walk kernel reads
+        r.node = (int32_t)v;  // entries as a stream and nothing else before a walk's first step
+        r.orig = new2old[v];
+        plan[pos] = r;
       });
   if (VARIANT == 0) {  // Fora_Whole_Graph.java:122,124-127: every residue entry credits alpha * r to its own reserve
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
@@ -162,20 +165,50 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// walk kernel: a workgroup takes chunks of 1024 consecutive walks; its four waves each own 256 of
-// them; a lane whose walk has stopped immediately takes the wave's next walk, so lanes stay busy
-// although walk lengths are geometric.
+// walk kernel: one wave per workgroup, each with a contiguous share of the phase's walks.  A lane whose walk has
+// stopped takes the wave's next walk at once, so lanes stay busy although walk lengths are geometric, and the wave only
+// drains once, at the end of its share (with a workgroup per 1024 walks, as in round 2, every chunk ended in a tail
+// of ~20 steps with few lanes walking: 36 G steps/s).  The entries of the next 256 walks are staged in LDS (a window);
+// a refill reads LDS only.
 // ------------------------------------------------------------------------------------------------
-constexpr int kWalkChunk = 1024;
+constexpr int kWalkWindow = 256;
+constexpr uint32_t kWalkWavesPerCu = 16;  // 8.5 KB of LDS each
 
-__global__ __launch_bounds__(256) void k_mc_walk(const int32_t* __restrict__ mc_node,
-                                                  const double* __restrict__ mc_inc,
-                                                  const unsigned long long* __restrict__ mc_woff,
-                                                  const unsigned long long* __restrict__ out_ext,
-                                                  const uint4* __restrict__ walk_rec,
-                                                  const int32_t* __restrict__ new2old, double* __restrict__ target,
-                                                  double alpha, uint32_t k0, uint32_t k1, uint32_t stream,
-                                                  int no_zero_hop, DevCounters* ctr, int parity) {
+struct WalkWindow {  // LDS, one per wave
+  unsigned long long woff[kWalkWindow + 1];
+  unsigned long long ext[kWalkWindow];
+  double inc[kWalkWindow];
+  int32_t node[kWalkWindow];
+  int32_t orig[kWalkWindow];
+  uint32_t ent4[kWalkWindow / 4];  // staged entry (one byte) of every walk of the window
+};
+
+// first entry whose walk range starts beyond walk x (woff[0] = 0, so >= 1), 64 probes per round
+__device__ __forceinline__ uint32_t plan_upper_bound(const WalkPlanRec* __restrict__ plan, uint32_t n_src,
+                                                     unsigned long long x, int lane) {
+  uint32_t a = 0, b = n_src;  // the answer lies in [a, b]
+  while (a < b) {
+    const uint32_t step = (b - a + 63u) / 64u;
+    const unsigned long long idx = (unsigned long long)a + (unsigned long long)lane * step;
+    const bool gt = idx >= b || plan[idx].woff > x;
+    const unsigned long long mask = __ballot(gt);
+    if (mask == 0) {  // all 64 probes <= x
+      a = (uint32_t)std::min<unsigned long long>((unsigned long long)a + 63ull * step + 1ull, b);
+      continue;
+    }
+    const uint32_t f = (uint32_t)__builtin_ctzll(mask);
+    const unsigned long long nb = (unsigned long long)a + (unsigned long long)f * step;
+    if (f > 0) a = a + (f - 1u) * step + 1u;
+    b = (uint32_t)std::min<unsigned long long>(nb, b);
+    if (f == 0) b = a;
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(64) void k_mc_walk(const WalkPlanRec* __restrict__ plan_rec,
+                                                 const uint4* __restrict__ walk_rec, double* __restrict__ target,
+                                                 double alpha, uint32_t k0, uint32_t k1, uint32_t stream,
+                                                 int no_zero_hop, DevCounters* ctr, int parity) {
   // the plan kernel counted sources and walks into mc_plan[parity]; the other cell (read by the phase before) is
   // cleared for the plan of the phase after, and the query's totals grow by this phase
   const unsigned long long plan = ctr->mc_plan[parity];
@@ -186,84 +219,118 @@ __global__ __launch_bounds__(256) void k_mc_walk(const int32_t* __restrict__ mc_
     ctr->walks_total += n_walks;
     ctr->sources_total += n_src;
   }
-  __shared__ unsigned long long s_woff[kWalkChunk + 1];
-  __shared__ int32_t s_node[kWalkChunk];
-  __shared__ double s_inc[kWalkChunk];
-  __shared__ uint32_t s_e0;
-  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  __shared__ WalkWindow S;
+  const int lane = threadIdx.x;
+  // this wave's share: whole groups of 64 walks, so that a short phase still spreads over the grid
+  const unsigned long long groups = (n_walks + 63) / 64;
+  const unsigned long long per = (groups + gridDim.x - 1) / gridDim.x * 64;
+  unsigned long long cursor = (unsigned long long)blockIdx.x * per;
+  if (cursor >= n_walks) return;
+  const unsigned long long w_hi = cursor + per < n_walks ? cursor + per : n_walks;
+  uint32_t e = plan_upper_bound(plan_rec, n_src, cursor, lane) - 1u;  // the entry that holds walk `cursor`
+  unsigned long long win_lo = cursor, win_end = cursor;
   unsigned long long steps_total = 0;
-  const unsigned long long n_chunks = (n_walks + kWalkChunk - 1) / kWalkChunk;
-  for (unsigned long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const unsigned long long lo = ch * kWalkChunk;
-    const unsigned long long hi = lo + kWalkChunk < n_walks ? lo + kWalkChunk : n_walks;
-    if (tid == 0) {  // last entry whose walk range starts at or before lo
-      uint32_t a = 0, b = n_src;
-      while (a < b) {
-        const uint32_t mid = (a + b) >> 1;
-        if (mc_woff[mid] <= lo) a = mid + 1; else b = mid;
-      }
-      s_e0 = a - 1;
-    }
-    __syncthreads();
-    const uint32_t e0 = s_e0;
-    // entries overlapping [lo, hi): at most hi - lo of them (every entry owns >= 1 walk)
-    uint32_t cnt = n_src - e0 < (uint32_t)kWalkChunk ? n_src - e0 : (uint32_t)kWalkChunk;
-    for (uint32_t j = tid; j <= cnt; j += 256) {
-      const uint32_t idx = e0 + j;
-      s_woff[j] = idx < n_src ? mc_woff[idx] : n_walks;
-      if (j < cnt) {
-        s_node[j] = mc_node[idx];
-        s_inc[j] = mc_inc[idx];
-      }
-    }
-    __syncthreads();
-    // this wave's share of the chunk
-    unsigned long long cursor = lo + (unsigned long long)wv * (kWalkChunk / 4);
-    unsigned long long wend = cursor + (kWalkChunk / 4);
-    if (cursor > hi) cursor = hi;
-    if (wend > hi) wend = hi;
-    Walker w;
-    double inc = 0.0;
-    bool walking = false;
-    for (;;) {
-      const unsigned long long need = __ballot(!walking);
-      const unsigned long long avail = wend - cursor;
-      if (need && avail) {
-        const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
-        if (!walking && rank < avail) {
-          const unsigned long long gidx = cursor + rank;
-          uint32_t a = 0, b = cnt;  // last staged entry with woff <= gidx
-          while (a < b) {
-            const uint32_t mid = (a + b) >> 1;
-            if (s_woff[mid] <= gidx) a = mid + 1; else b = mid;
-          }
-          const uint32_t j = a - 1;
-          const int32_t start = s_node[j];
-          inc = s_inc[j];
-          const unsigned long long sext = out_ext[start];
-          walker_init(w, start, sext, new2old[start], gidx - s_woff[j], stream, no_zero_hop != 0);
-          if ((sext >> 32) == 0) {
-            atomic_add_noret(&target[start], inc);  // Monte_Carlo.java:70-72 / :106-108
+  Walker w;
+  double inc = 0.0;
+  bool walking = false;
+  for (;;) {
+    const unsigned long long need = __ballot(!walking);
+    if (need && cursor < w_hi) {
+      if (cursor >= win_end) {
+        // stage the entries of walks [cursor, cursor + 256): at most 256 of them from e, which holds walk `cursor`
+        // (every entry owns >= 1 walk)
+        win_lo = cursor;
+        win_end = cursor + kWalkWindow < w_hi ? cursor + kWalkWindow : w_hi;
+        __syncthreads();  // refills of the window before have read it
+        WalkPlanRec r[kWalkWindow / 64];
+#pragma unroll
+        for (int q = 0; q < kWalkWindow / 64; ++q) {
+          const unsigned long long idx = (unsigned long long)e + (unsigned long long)(q * 64 + lane);
+          if (idx < n_src) {
+            r[q] = plan_rec[idx];
           } else {
-            walking = true;
+            r[q].woff = n_walks;
+            r[q].inc = 0.0;
+            r[q].ext = 0ull;
+            r[q].node = 0;
+            r[q].orig = 0;
           }
         }
-        const unsigned long long want = __popcll(need);
-        cursor += want < avail ? want : avail;
+        unsigned long long last = n_walks;
+        if (lane == 0 && (unsigned long long)e + kWalkWindow < n_src) last = plan_rec[(size_t)e + kWalkWindow].woff;
+        S.ent4[lane] = 0u;
+#pragma unroll
+        for (int q = 0; q < kWalkWindow / 64; ++q) {
+          const int j = q * 64 + lane;
+          S.woff[j] = r[q].woff;
+          S.ext[j] = r[q].ext;
+          S.inc[j] = r[q].inc;
+          S.node[j] = r[q].node;
+          S.orig[j] = r[q].orig;
+        }
+        if (lane == 0) S.woff[kWalkWindow] = last;
+        __syncthreads();
+        // entry j > 0 that starts inside the window marks its first walk; a running maximum spreads the marks
+        uint8_t* ent = reinterpret_cast<uint8_t*>(S.ent4);
+#pragma unroll
+        for (int q = 0; q < kWalkWindow / 64; ++q) {
+          const int j = q * 64 + lane;
+          if (j > 0 && r[q].woff >= win_lo && r[q].woff < win_end) ent[r[q].woff - win_lo] = (uint8_t)j;
+        }
+        __syncthreads();
+        const uint32_t x = S.ent4[lane];
+        uint32_t m0 = x & 0xffu, m1 = (x >> 8) & 0xffu, m2 = (x >> 16) & 0xffu, m3 = x >> 24;
+        m1 = m1 > m0 ? m1 : m0;
+        m2 = m2 > m1 ? m2 : m1;
+        m3 = m3 > m2 ? m3 : m2;
+        uint32_t run = m3;  // inclusive maximum over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t o = __shfl_up(run, d);
+          if (lane >= d) run = run > o ? run : o;
+        }
+        uint32_t before = __shfl_up(run, 1);
+        if (lane == 0) before = 0;
+        m0 = m0 > before ? m0 : before;
+        m1 = m1 > before ? m1 : before;
+        m2 = m2 > before ? m2 : before;
+        m3 = m3 > before ? m3 : before;
+        S.ent4[lane] = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+        __syncthreads();
       }
-      if (__ballot(walking) == 0) {
-        if (wend == cursor) break;
-        continue;
-      }
-      if (walking) {
-        if (walker_step(w, walk_rec, alpha, k0, k1)) {
-          atomic_add_noret(&target[w.cur], inc);
-          steps_total += w.moves;
-          walking = false;
+      const unsigned long long avail = win_end - cursor;
+      const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
+      if (!walking && rank < avail) {
+        const unsigned long long gidx = cursor + rank;
+        const uint32_t j = reinterpret_cast<const uint8_t*>(S.ent4)[gidx - win_lo];
+        const int32_t start = S.node[j];
+        inc = S.inc[j];
+        const unsigned long long sext = S.ext[j];
+        walker_init(w, start, sext, S.orig[j], gidx - S.woff[j], stream, no_zero_hop != 0);
+        if ((sext >> 32) == 0) {
+          atomic_add_noret(&target[start], inc);  // Monte_Carlo.java:70-72 / :106-108
+        } else {
+          walking = true;
         }
       }
+      const unsigned long long want = __popcll(need);
+      cursor += want < avail ? want : avail;
+      if (cursor >= win_end) {  // window used up: e becomes the entry of the next walk
+        const uint32_t jl = reinterpret_cast<const uint8_t*>(S.ent4)[win_end - 1 - win_lo];
+        e += S.woff[jl + 1] == win_end ? jl + 1u : jl;
+      }
     }
-    __syncthreads();
+    if (__ballot(walking) == 0) {
+      if (cursor >= w_hi) break;
+      continue;
+    }
+    if (walking) {
+      if (walker_step(w, walk_rec, alpha, k0, k1)) {
+        atomic_add_noret(&target[w.cur], inc);
+        steps_total += w.moves;
+        walking = false;
+      }
+    }
   }
   steps_total = wave_sum_u64(steps_total);
   if (lane == 0 && steps_total) atomic_add_u64(&ctr->walk_steps, steps_total);
@@ -305,11 +372,16 @@ __global__ __launch_bounds__(256) void k_build_walk_rec(unsigned long long m, co
   }
 }
 
-__global__ void k_plan_single(int32_t src, double inc, unsigned long long n_walks, int32_t* mc_node, double* mc_inc,
-                              unsigned long long* mc_woff, DevCounters* ctr, int parity) {
-  mc_node[0] = src;
-  mc_inc[0] = inc;
-  mc_woff[0] = 0;
+__global__ void k_plan_single(int32_t src, double inc, unsigned long long n_walks,
+                              const unsigned long long* __restrict__ out_ext, const int32_t* __restrict__ new2old,
+                              WalkPlanRec* plan, DevCounters* ctr, int parity) {
+  WalkPlanRec r;
+  r.woff = 0ull;
+  r.inc = inc;
+  r.ext = out_ext[src];
+  r.node = src;
+  r.orig = new2old[src];
+  plan[0] = r;
   ctr->mc_plan[parity] = (1ull << kPackShift) | n_walks;
 }
 
@@ -336,28 +408,22 @@ int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, doub
   const uint32_t grid = (uint32_t)(b > 1024 ? 1024 : b);
   if (variant == 0)
     hipLaunchKernelGGL(k_mc_plan<0>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
-                       omega_dev, g->mc_node, g->mc_inc, g->mc_woff, g->ctr, g->mc_parity);
+                       omega_dev, g->out_ext, g->new2old, g->mc_plan_rec, g->ctr, g->mc_parity);
   else
     hipLaunchKernelGGL(k_mc_plan<1>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
-                       omega_dev, g->mc_node, g->mc_inc, g->mc_woff, g->ctr, g->mc_parity);
+                       omega_dev, g->out_ext, g->new2old, g->mc_plan_rec, g->ctr, g->mc_parity);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
-// The walk count is only known on the device: every workgroup takes the chunks of 1024 walks whose index is congruent to
-// its own.  With a bound from the host (g->walk_hint: the budget) the grid has one workgroup per possible chunk, so
-// that the dispatcher balances walks of uneven length as it did when the count travelled through the host; without
-// one (top-k rounds) a fixed grid.
+// The walk count is only known on the device: a fixed grid of waves, each with an equal share of whatever the plan
+// holds (g->walk_hint, the budget when the host knows it, only trims the grid of a short phase).
 int launch_mc_walk(pprhip_graph* g, double alpha, uint64_t seed, uint32_t stream, int no_zero_hop, double* target) {
-  uint32_t grid = (uint32_t)g->n_cus * 32u;
-  if (g->walk_hint) {
-    const unsigned long long chunks = (g->walk_hint + kWalkChunk - 1) / kWalkChunk;
-    grid = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(chunks, 1ull), 1ull << 22);
-  }
+  uint32_t grid = (uint32_t)g->n_cus * kWalkWavesPerCu;
+  if (g->walk_hint) grid = (uint32_t)std::min<unsigned long long>(grid, std::max<unsigned long long>((g->walk_hint + 63) / 64, 1ull));
   g->walk_hint = 0;
-  hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(256), 0, g->stream, g->mc_node, g->mc_inc, g->mc_woff, g->out_ext,
-                     g->walk_rec, g->new2old, target, alpha, (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop,
-                     g->ctr, g->mc_parity);
+  hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(64), 0, g->stream, g->mc_plan_rec, reinterpret_cast<const uint4*>(g->walk_rec),
+                     target, alpha, (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, g->ctr, g->mc_parity);
   PPRHIP_CHECK_HIP(hipGetLastError());
   g->mc_parity ^= 1;
   return PPRHIP_OK;
@@ -377,8 +443,8 @@ int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* 
 
 int launch_mc_pure(pprhip_graph* g, int32_t src, uint64_t n_walks, double alpha, uint64_t seed, double inc,
                    double* target) {
-  hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(1), 0, g->stream, src, inc, (unsigned long long)n_walks, g->mc_node,
-                     g->mc_inc, g->mc_woff, g->ctr, g->mc_parity);
+  hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(1), 0, g->stream, src, inc, (unsigned long long)n_walks, g->out_ext,
+                     g->new2old, g->mc_plan_rec, g->ctr, g->mc_parity);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return launch_mc_walk(g, alpha, seed, 0, 0, target);
 }
