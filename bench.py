@@ -936,22 +936,69 @@ def apply_counters(out, pmc, avg_us, extras):
 def start_cpu_baseline(args, live):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--scale", str(args.scale),
            "--cpu-walk-divisor", str(args.cpu_walk_divisor), "--cpu-sources", ",".join(str(int(s)) for s in live[:300])]
-    return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 
 
 def finish_cpu_baseline(child):
+    # the GPU measurements are over: the child may now take every core this job has (its last measurement)
+    try:
+        child.stdin.write(b"go\n")
+        child.stdin.flush()
+    except Exception:  # noqa: BLE001
+        pass
     return _child_json(child, float(os.environ.get("PPRHIP_BENCH_CPU_S", "900")), "the CPU baseline child")
+
+
+def cpu_share():
+    """Cores this job may use at once: the cgroup's CPU quota where there is one (the GPU boxes give a one-GPU job 16
+    of the host's 256 hardware threads; threads beyond the quota only get throttled), else the physical cores."""
+    try:
+        ids = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    ids.add((phys, core))
+                phys = core = None
+        pcores = len(ids) or (os.cpu_count() or 1)
+    except Exception:  # noqa: BLE001
+        pcores = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            if quota:
+                break
+        except Exception:  # noqa: BLE001
+            continue
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        aff = pcores
+    share = int(max(1, min(pcores, aff, int(quota) if quota else pcores)))
+    return share, pcores, quota
 
 
 def cpu_baseline_child(args):
     """The reference's CPU path on this box's host cores; the Java itself cannot run here.
-    Three measurements, one after another so that they do not disturb each other:
-      1. the faithful port (hash maps, FIFO deque, hash set, the clock-driven loop with its 400 ns constant:
-         oracle/ppr_baseline.cpp) on ONE thread, ONE query run to the end, every walk walked
-         (Fora_Whole_Graph.java:93-140) - `value`; beside it, on three more threads, the dense-array port on three
-         other sources, in full as well;
-      2. the array port on every hardware thread at once, one query per thread (walks thinned by
-         --cpu-walk-divisor, times scaled back)."""
+    Two measurements, one after the other:
+      1. while the parent measures on the GPU (four threads of the job's share): the faithful port (hash maps, FIFO
+         deque, hash set, the clock-driven loop with its 400 ns constant: oracle/ppr_baseline.cpp) on ONE thread, ONE
+         query run to the end, every walk walked (Fora_Whole_Graph.java:93-140) - `value`; beside it, on three more
+         threads, the dense-array port on three other sources, in full as well;
+      2. after the parent's "go" (its GPU measurements are over): the array port on every core the job has, one query
+         per core (walks thinned by --cpu-walk-divisor, times scaled back)."""
     try:
         from oracle import baseline as base
         from oracle import oracle as orc
@@ -968,31 +1015,8 @@ def cpu_baseline_child(args):
         t_start = time.time()
         conf = og.conf_whole(ALPHA)
         _, omega = orc.fora_whole_params(conf, EPS)
-        # physical cores (hardware threads / SMT siblings): one query per core
-        try:
-            ids = set()
-            phys = core = None
-            for line in open("/proc/cpuinfo"):
-                if line.startswith("physical id"):
-                    phys = line.split(":")[1].strip()
-                elif line.startswith("core id"):
-                    core = line.split(":")[1].strip()
-                elif not line.strip():
-                    if phys is not None and core is not None:
-                        ids.add((phys, core))
-                    phys = core = None
-            pcores = len(ids) or cores
-        except Exception:  # noqa: BLE001
-            pcores = cores
-        # ---- 1. every physical core, one query each (while the parent's GPU measurements run: they need one core)
-        par_srcs = (live[4:4 + pcores] or live[:1])
-        p = base.fora_array_parallel(og, par_srcs, EPS, ALPHA, seed=3, walk_divisor=args.cpu_walk_divisor, threads=pcores)
-        # the run thinned the walks; per_query_s holds every query's time scaled to all of its walks, measured while the
-        # other threads were running theirs: concurrent throughput = sum of the per-thread rates
-        all_cores_qps = sum(1.0 / t for t in p["per_query_s"] if t > 0)
-        pq = sorted(p["per_query_s"])
-        # ---- 2. on the then quiet machine: one faithful query to the end (one thread) + the array port on three
-        # sources (three threads)
+        share, pcores, quota = cpu_share()
+        # ---- 1. one faithful query to the end (one thread) + the array port on three sources (three threads)
         box = {}
 
         def run_arrays():
@@ -1006,17 +1030,25 @@ def cpu_baseline_child(args):
         th.join()
         arr = box["arr"]
         h_query = h["push_s"] + h["walk_s"]
+        # ---- 2. every core of the job's share, one query each, once the parent's GPU measurements are over
+        sys.stdin.readline()
+        par_srcs = (live[4:4 + share] or live[:1])
+        p = base.fora_array_parallel(og, par_srcs, EPS, ALPHA, seed=3, walk_divisor=args.cpu_walk_divisor, threads=share)
+        # the run thinned the walks; per_query_s holds every query's time scaled to all of its walks, measured while the
+        # other threads were running theirs: concurrent throughput = sum of the per-thread rates
+        all_cores_qps = sum(1.0 / t for t in p["per_query_s"] if t > 0)
+        pq = sorted(p["per_query_s"])
         wall = time.time() - t_start
         res = {
             "value": round(1.0 / h_query, 6) if h_query > 0 else None, "unit": "queries/s", "cores": 1, "kind": "port",
             "sample": "faithful (hash-map-shaped) port of Forward_Push/Fora_Whole_Graph/Monte_Carlo, ONE query on source %d "
                       "run to the end on one thread: %d turn(s) of the clock-driven loop, %.1f s of pushes (%d edge "
                       "pushes, %.2f M/s), %d walks in %.1f s (%.2f M/s) = %.1f s; beside it the dense-array port on 3 "
-                      "sources in full (3 threads), after the array port had run on all %d physical cores; %.0f s of wall time "
-                      "in a background process beside the GPU measurements"
+                      "sources in full (3 threads); then the array port on all %d cores of the job's share; %.0f s of "
+                      "wall time in a background process, the first part beside the GPU measurements"
                       % (live[0], h["rounds"], h["push_s"], h["edge_pushes"],
                          h["edge_pushes"] / h["push_s"] / 1e6 if h["push_s"] > 0 else 0.0, h["walks_run"], h["walk_s"],
-                         h["walks_run"] / h["walk_s"] / 1e6 if h["walk_s"] > 0 else 0.0, h_query, pcores, wall),
+                         h["walks_run"] / h["walk_s"] / 1e6 if h["walk_s"] > 0 else 0.0, h_query, share, wall),
             "seconds_per_query": round(h_query, 2),
             "faithful": {"turns": h["rounds"], "push_s": round(h["push_s"], 2), "walk_s": round(h["walk_s"], 2),
                          "edge_pushes": int(h["edge_pushes"]), "walks": int(h["walks_run"]),
@@ -1029,12 +1061,16 @@ def cpu_baseline_child(args):
                       "sources": [int(s) for s in live[1:4]],
                       "sample": "dense-array port, three sources in full (every walk), one thread each, while the "
                                 "faithful query ran on a fourth"},
-            "all_cores": {"value": round(all_cores_qps, 5), "cores": int(min(pcores, len(par_srcs))),
+            "all_cores": {"value": round(all_cores_qps, 5), "cores": int(min(share, len(par_srcs))),
                           "queries": len(par_srcs), "wall_s_thinned_walks": round(p["wall_s"], 2),
                           "seconds_per_query_min_median_max": [round(pq[0], 1), round(pq[len(pq) // 2], 1), round(pq[-1], 1)],
-                          "sample": "dense-array port, one query per physical core on %d live sources at once; every "
-                                    "%d-th walk run, per-query times scaled to all walks" % (len(par_srcs), args.cpu_walk_divisor)},
-            "host": {"nproc": cores, "physical_cores": pcores, "model": model},
+                          "sample": "dense-array port, one query per core on %d live sources at once, on every core this "
+                                    "job may use (cgroup quota %s of the host's %d physical cores / %d hardware threads; "
+                                    "with 128 threads under the same quota the box delivered 0.13 queries/s, "
+                                    "profiles/r03_bench_cpu128.json); every %d-th walk run, per-query times scaled to "
+                                    "all walks" % (len(par_srcs), ("%.0f cores" % quota) if quota else "none", pcores, cores,
+                                                   args.cpu_walk_divisor)},
+            "host": {"nproc": cores, "physical_cores": pcores, "cpu_quota_cores": quota, "model": model},
         }
     except Exception as e:  # noqa: BLE001
         res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
