@@ -182,8 +182,8 @@ struct CallTimer {
 // compute stream never waits for PCIe or for the host copy; a query that finishes while all staging buffers are in
 // flight waits for one.
 struct FetchPipe {
-  static constexpr int kRing = 6;
-  static constexpr int kCopiers = 4;
+  static constexpr int kRing = 16;   // one per slot: the queries of a batch tend to finish in bursts (they leave the shared sweeps together)
+  static constexpr int kCopiers = 6;
   pprhip_graph* P = nullptr;
   size_t n = 0;
   hipStream_t cs = nullptr;
@@ -192,6 +192,9 @@ struct FetchPipe {
   hipEvent_t ready[kRing] = {};
   hipEvent_t done[kRing] = {};
   struct Item { int e; double* dst; };
+  struct Arrival { FetchPipe* pipe; Item item; };
+  static void on_copied(void* arrival);  // host callback of the copy stream
+  int pending = 0;                       // copies queued on the copy stream whose callback has not run yet
   std::mutex mu;
   std::condition_variable cv;
   std::deque<int> free_q;
