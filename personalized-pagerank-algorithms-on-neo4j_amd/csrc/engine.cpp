@@ -60,15 +60,22 @@ int alloc_dev(void** p, size_t bytes) {
 // A few words the host needs before it can queue the next kernel: published by a kernel into mapped pinned memory and
 // awaited by spinning on the sequence word (kernels_host.hip); after kSpinUs the thread stops spinning and blocks in
 // hipStreamSynchronize, which is also where a faulted kernel is reported.  `bytes`: a multiple of 8.
-int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes) {
+int fetch_begin(pprhip_graph* g, const void* dev, size_t bytes, unsigned long long* seq_out) {
   if (!g->mail || bytes > sizeof(unsigned long long) * kMailWords || (bytes & 7)) {
+    *seq_out = 0;  // fetch_end copies and synchronises
+    return PPRHIP_OK;
+  }
+  *seq_out = ++g->mail_seq;
+  return launch_publish(g, dev, (uint32_t)(bytes / 8), *seq_out);
+}
+
+int fetch_end(pprhip_graph* g, unsigned long long seq, const void* dev, void* host, size_t bytes) {
+  if (seq == 0) {
     PPRHIP_CHECK_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, g->stream));
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     return PPRHIP_OK;
   }
   constexpr double kSpinUs = 60.0;
-  const unsigned long long seq = ++g->mail_seq;
-  PPRHIP_TRY(launch_publish(g, dev, (uint32_t)(bytes / 8), seq));
   const auto t0 = std::chrono::steady_clock::now();
   bool arrived = false;
   for (uint32_t spins = 0;; ++spins) {
@@ -91,6 +98,12 @@ int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes) {
   }
   std::memcpy(host, g->mail->words, bytes);
   return PPRHIP_OK;
+}
+
+int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes) {
+  unsigned long long seq = 0;
+  PPRHIP_TRY(fetch_begin(g, dev, bytes, &seq));
+  return fetch_end(g, seq, dev, host, bytes);
 }
 
 int read_packed(pprhip_graph* g, int slot, uint32_t* nf, uint64_t* ef) {
@@ -548,7 +561,7 @@ int reset_query_state(pprhip_graph* g, bool clear_flags, int32_t node) {
     SetupScope setup(g);
     PPRHIP_TRY(launch_clear(g, cl));
   }
-  g->mc_parity = 0;  // (both plan cells were just cleared)
+  g->mc_phase = g->mc_last_plan = 0;  // (the plan cells were just cleared)
   g->result_in_est = false;
   return PPRHIP_OK;
 }
@@ -621,6 +634,19 @@ void free_workspace(pprhip_graph* g) {
   if (g->h_ctr) (void)hipHostFree(g->h_ctr);
   if (g->mail) (void)hipHostFree(g->mail);
   g->mail = g->mail_dev = nullptr;
+  if (g->spec_stream) {
+    (void)hipStreamSynchronize(g->spec_stream);
+    (void)hipStreamDestroy(g->spec_stream);
+  }
+  if (g->spec_mail) (void)hipHostFree(g->spec_mail);
+  if (g->mc_plan_rec2) (void)hipFree(g->mc_plan_rec2);
+  g->mc_plan_rec2 = nullptr;
+  for (auto& e : g->spec_ev)
+    if (e) (void)hipEventDestroy(e);
+  g->spec_timer.destroy();
+  g->spec_stream = nullptr;
+  g->spec_mail = g->spec_mail_dev = nullptr;
+  g->spec_ev[0] = g->spec_ev[1] = nullptr;
   for (auto e : g->ev)
     if (e) (void)hipEventDestroy(e);
 }
@@ -787,6 +813,21 @@ int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree) {
 
 // frontier from a predicate over all nodes (round starts)
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
+  if (kind == 1) {
+    // top-k round starts: one pass that lists the start set, writes the armed bits and lets the parked nodes go, and
+    // one read-back of its counter (a start set large enough for a sweep is prepared from the list by run_levels)
+    {
+      SetupScope setup(g);
+      PPRHIP_TRY(launch_seed_list(g, a, 1, L.fcur, &g->ctr->hist[kMaxBatch + 2], true));
+    }
+    unsigned long long pk = 0;
+    PPRHIP_TRY(fetch_small(g, &g->ctr->hist[kMaxBatch + 2], &pk, sizeof pk));
+    L.nf = (uint32_t)(pk >> kPackShift);
+    L.ef = pk & kPackMask;
+    L.dense_prepared = false;
+    L.gs_dirty = false;
+    return PPRHIP_OK;
+  }
   {
     SetupScope setup(g);
     PPRHIP_TRY(launch_count_active(g, a, kind, L.pslot));
@@ -854,9 +895,9 @@ int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st) {
 // statistics through read_dead_pops at the end of the query).  omega_dev > 0: the plan also derives rsum and the walk
 // budget on the device from the residue sum a device_sum / launch_sum has just left (rsum, nrw are ignored; nrw_bound is
 // the largest budget possible, for the range check).
-int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,
-                   double* target, pprhip_stats_t& st, double omega_dev) {
-  (void)st;
+// The walk phase in two halves (a caller may queue other work between them, or run the plan on another stream):
+// the plan of the residue entries, and the walk kernel that runs the latest plan.
+int launch_walk_plan(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, double* target, double omega_dev) {
   // what the host knows about the walk count sizes the grid: the budget itself (every residue entry adds at most one
   // walk to it), or - with the budget derived on the device - nothing
   g->walk_hint = omega_dev > 0.0 ? 0ull : (unsigned long long)nrw + act_n(g);
@@ -865,14 +906,22 @@ int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long
     set_error("walk budget %.0f exceeds the engine's 2^36 walk limit", bound);
     return PPRHIP_ERR_INVALID;
   }
-  {
-    SetupScope setup(g);
-    PPRHIP_TRY(launch_mc_plan(g, variant, alpha, rsum, (double)nrw, omega_dev, target));
-  }
+  SetupScope setup(g);
+  return launch_mc_plan(g, variant, alpha, rsum, (double)nrw, omega_dev, target);
+}
+
+int launch_walk_run(pprhip_graph* g, int variant, double alpha, uint64_t seed, uint32_t stream, double* target) {
   ktimer().begin(PPRHIP_KERNEL_WALK, 0);  // (its bytes are added when the counters are read)
   PPRHIP_TRY(launch_mc_walk(g, alpha, seed, stream, variant == 0 ? 1 : 0, target));
   ktimer().end();
   return PPRHIP_OK;
+}
+
+int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,
+                   double* target, pprhip_stats_t& st, double omega_dev) {
+  (void)st;
+  PPRHIP_TRY(launch_walk_plan(g, variant, alpha, rsum, nrw, target, omega_dev));
+  return launch_walk_run(g, variant, alpha, seed, stream, target);
 }
 
 
@@ -1042,17 +1091,30 @@ static int select_topk_passes(pprhip_graph* g, const double* x, int k, int32_t* 
 // the bin of the k-th largest chosen on the device, the gather of everything from that bin's lower edge up, and ONE
 // read-back (header + the first kPre records; the candidates are then ordered on the host, values descending, ids
 // ascending).  Only when more candidates share those 12 bits than the buffer holds the multi-pass form takes over.
-int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
-                double* kth_out, bool* have_kth, pprhip_stats_t& st) {
-  constexpr size_t kPre = 2048;
+// The selection in two halves, so that a caller can queue other work between launching it and waiting for it.
+constexpr size_t kSelPre = 2048;
+int select_launch(pprhip_graph* g, const double* x, int k, unsigned long long* seq_out) {
   {
     SetupScope setup(g);
     PPRHIP_TRY(launch_select_hist(g, x, act_n(g), 0ull, 0, 12, true));
     PPRHIP_TRY(launch_select_choose(g, (unsigned long long)k));
     PPRHIP_TRY(launch_select_gather(g, x, act_n(g), 0ull, false, true));
   }
+  return fetch_begin(g, g->sel_blob, kSelHeader + sizeof(SelRec) * kSelPre, seq_out);
+}
+
+int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
+                double* kth_out, bool* have_kth, pprhip_stats_t& st) {
+  unsigned long long seq = 0;
+  PPRHIP_TRY(select_launch(g, x, k, &seq));
+  return select_finish(g, seq, x, k, ids_out, vals_out, cap, n_out, kth_out, have_kth, st);
+}
+
+int select_finish(pprhip_graph* g, unsigned long long seq, const double* x, int k, int32_t* ids_out, double* vals_out,
+                  int cap, int* n_out, double* kth_out, bool* have_kth, pprhip_stats_t& st) {
+  constexpr size_t kPre = kSelPre;
   std::vector<char> blob(kSelHeader + sizeof(SelRec) * kPre);
-  PPRHIP_TRY(fetch_small(g, g->sel_blob, blob.data(), blob.size()));
+  PPRHIP_TRY(fetch_end(g, seq, g->sel_blob, blob.data(), blob.size()));
   st.select_passes++;
   st.select_bytes += 16ull * act_n(g);
   unsigned long long hdr[5];
@@ -1526,9 +1588,10 @@ int pprhip_fwdpush_topk_reset(pprhip_graph_t* g, int32_t src, double alpha) {
   return PPRHIP_OK;
 }
 
-// read_sum: bring the residue sum to the host (the public round-by-round entry point); otherwise it is left in
-// DevCounters::sum_out for the walk plan
-static int topk_round_impl(pprhip_graph_t* g, double min_rmax, double rmax, pprhip_stats_t& st, bool read_sum = true) {
+// kSumRead: bring the residue sum to the host (the public round-by-round entry point); kSumLaunch: leave it in
+// DevCounters::sum_out for the walk plan; kSumNone: the caller sums later (a push run ahead of its round)
+enum { kSumRead = 0, kSumLaunch = 1, kSumNone = 2 };
+static int topk_round_impl(pprhip_graph_t* g, double min_rmax, double rmax, pprhip_stats_t& st, int sum_mode = kSumRead) {
   const int32_t src = g->topk_src;
   if (hdeg_out(g, src) == 0) {  // Forward_Push.java:149-153
     PPRHIP_TRY(launch_set_f64(g, g->reserve, (uint32_t)src, 1.0));
@@ -1540,8 +1603,8 @@ static int topk_round_impl(pprhip_graph_t* g, double min_rmax, double rmax, pprh
   LevelCtx L;
   PPRHIP_TRY(seed_scan(g, a, 1, L));
   PPRHIP_TRY(run_levels(g, a, L, st, nullptr));
-  if (read_sum) PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
-  else PPRHIP_TRY(launch_sum(g, g->residue, act_n(g)));
+  if (sum_mode == kSumRead) PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
+  else if (sum_mode == kSumLaunch) PPRHIP_TRY(launch_sum(g, g->residue, act_n(g)));
   g->topk_first = false;
   return PPRHIP_OK;
 }
@@ -1639,6 +1702,67 @@ int pprhip_topk_select(pprhip_graph_t* g, int k, int32_t* ids_out, double* vals_
 }
 
 // ------------------------------------------------------------------ FORA top-k (a6)
+// The second stream of pprhip_fora_topk: a priority of its own gives it a hardware queue of its own (fora.cpp:
+// FetchPipe::ensure has the measurement), so its kernels run beside the compute stream's.
+static int ensure_spec(pprhip_graph* g) {
+  if (g->spec_stream) return PPRHIP_OK;
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (prio_lo == prio_hi) return PPRHIP_ERR_STATE;  // no second queue to be had: the rounds run one after another
+  if (!g->spec_mail) {
+    if (hipHostMalloc((void**)&g->spec_mail, sizeof(HostMail), hipHostMallocMapped) != hipSuccess) {
+      (void)hipGetLastError();
+      g->spec_mail = nullptr;
+      return PPRHIP_ERR_OOM;
+    }
+    std::memset(g->spec_mail, 0, sizeof(HostMail));
+  }
+  if (hipHostGetDevicePointer((void**)&g->spec_mail_dev, g->spec_mail, 0) != hipSuccess) return PPRHIP_ERR_HIP;
+  if (!g->mc_plan_rec2 && alloc_dev((void**)&g->mc_plan_rec2, sizeof(WalkPlanRec) * (size_t)g->n) != PPRHIP_OK) {
+    g->mc_plan_rec2 = nullptr;
+    return PPRHIP_ERR_OOM;
+  }
+  for (auto& e : g->spec_ev)
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      e = nullptr;
+      return PPRHIP_ERR_HIP;
+    }
+  if (hipStreamCreateWithPriority(&g->spec_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+    g->spec_stream = nullptr;
+    return PPRHIP_ERR_HIP;
+  }
+  return PPRHIP_OK;
+}
+
+namespace {
+// While it lives, the handle launches on its second stream, reads back through that stream's mail and the calling
+// thread times with that stream's timer.
+struct SpecContext {
+  pprhip_graph* g;
+  hipStream_t stream;
+  HostMail *mail, *mail_dev;
+  unsigned long long seq;
+  KernelTimer* timer;
+  explicit SpecContext(pprhip_graph* g_) : g(g_), stream(g_->stream), mail(g_->mail), mail_dev(g_->mail_dev), seq(g_->mail_seq), timer(g_timer_cur) {
+    g->stream = g->spec_stream;
+    g->mail = g->spec_mail;
+    g->mail_dev = g->spec_mail_dev;
+    g->mail_seq = g->spec_mail_seq;
+    g->spec_timer.stream = g->spec_stream;
+    g->spec_timer.off = true;  // (its kernels run beside the compute stream's: their time is not the query's)
+    g_timer_cur = &g->spec_timer;
+  }
+  ~SpecContext() {
+    g->spec_mail_seq = g->mail_seq;
+    g->stream = stream;
+    g->mail = mail;
+    g->mail_dev = mail_dev;
+    g->mail_seq = seq;
+    g_timer_cur = timer;
+  }
+};
+}  // namespace
+
 int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf, uint64_t seed,
                      int32_t* ids_out, double* vals_out, int cap, int* n_out, double* reserve_out,
                      pprhip_stats_t* stats) {
@@ -1664,6 +1788,19 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
   uint32_t round = 0;
   const size_t nd = sizeof(double) * (size_t)act_n(g);  // (est beyond the query's scan bound is zero and stays so)
   bool dead_src = false;
+  // A round's walks and selection do not touch what the next round's push works on (residue, reserve, frontier
+  // lists, parked flags: the plan has read the residues and the estimate is a copy of the reserve by then), and the
+  // next threshold is known beforehand (:178).  So while this round's walk kernel - bound by its longest walk, with
+  // most of the chip idle - and selection run on the compute stream, the next round's push runs on a
+  // second stream, with counters of its own that only join the query's when the round turns out to be needed.  The
+  // one push that was not (after the last round) costs no time: it ends before that round's walks do.
+  const char* spec_env = getenv("PPRHIP_TOPK_AHEAD");
+  const bool spec_on = !(spec_env && spec_env[0] == '0') && ensure_spec(g) == PPRHIP_OK;
+  bool pushed_ahead = false;        // this round's push, residue sum and walk plan have already run (second stream)
+  bool ahead_discarded = false;     // the last push ahead was not needed
+  unsigned long long dead_before_ahead = 0;
+  int nsel_round = 0;
+  double kth_prev = -1.0;  // the k-th estimate of the round before (none yet)
   while (delta_local >= min_delta) {  // :123
     rmax_local = epsilon * std::sqrt(delta_local / 3.0 / (double)conf->m / std::log(2.0 / conf->pfail));  // :124
     omega_local = (epsilon + 2.0) * std::log(2.0 / conf->pfail) / epsilon / epsilon / delta_local;          // :125
@@ -1675,46 +1812,106 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
       break;
     }
     rmax_local *= std::sqrt((double)conf->m * rmax_local) * 3.0;  // :133
-    (void)hipEventRecord(g->ev[1], g->stream);
-    PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax_local, st, false));  // :137; the residue sum stays on the device
+    if (!spec_on) (void)hipEventRecord(g->ev[1], g->stream);
+    if (pushed_ahead) {
+      PPRHIP_CHECK_HIP(hipStreamWaitEvent(g->stream, g->spec_ev[1], 0));
+    } else {
+      PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax_local, st, kSumLaunch));  // :137; the residue sum stays on the device
+      // :148-151: the plan derives rsum and the walk budget from the sum on the device
+      PPRHIP_TRY(launch_walk_plan(g, 1, alpha, 0.0, 0, g->est, omega_local));
+    }
+    pushed_ahead = false;
     PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sum_out, &g->ctr->sum_out, sizeof(double), hipMemcpyDeviceToHost, g->stream));
-    (void)hipEventRecord(g->ev[2], g->stream);
+    if (!spec_on) (void)hipEventRecord(g->ev[2], g->stream);
     // :143 reserve := copy of the push reserve (walk increments of earlier rounds are dropped)
     PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
-    // :148-168: the plan derives rsum and the walk budget from the sum on the device, the walk kernel reads the plan's
-    // counts there: no host round trip between the push and the selection
-    PPRHIP_TRY(run_walk_phase(g, 1, alpha, 0.0, 0, seed, round, g->est, st, omega_local));
-    (void)hipEventRecord(g->ev[3], g->stream);
+    if (spec_on) PPRHIP_CHECK_HIP(hipEventRecord(g->spec_ev[0], g->stream));  // residues and reserve have been read
+    // :155-168: the walk kernel reads the plan's counts on the device: no host round trip between push and selection
+    PPRHIP_TRY(launch_walk_run(g, 1, alpha, seed, round, g->est));
+    if (!spec_on) (void)hipEventRecord(g->ev[3], g->stream);
     round++;
     double kth = 0.0;
     bool have = false;
-    int nsel = 0;
-    PPRHIP_TRY(select_topk(g, g->est, conf->k, nullptr, nullptr, 0, &nsel, &kth, &have, st));  // :173
-    g->topk_rsum = g->h_ctr->sum_out;  // (the selection synchronised the stream)
+    unsigned long long sel_seq = 0;
+    PPRHIP_TRY(select_launch(g, g->est, conf->k, &sel_seq));  // :173
+    // ---- the next round's push, residue sum and walk plan, ahead of the decision whether there is a next round
+    const double delta_next = std::max(min_delta, delta_local / 4.0);  // :178
+    pprhip_stats_t st_ahead;
+    std::memset(&st_ahead, 0, sizeof st_ahead);
+    bool ahead = false;
+    // Not when this round is expected to be the last: at min_delta the loop ends whatever the selection says
+    // (:175-176), and the k-th estimate hardly moves from round to round, so a round whose threshold the last k-th
+    // value already meets is (almost always) final - its push ahead would be the largest of the query, and unused.
+    const bool likely_final = delta_local <= min_delta || (kth_prev >= 0.0 && kth_prev >= (1 + epsilon) * delta_local);
+    if (spec_on && !likely_final) {
+      double rmax_next = epsilon * std::sqrt(delta_next / 3.0 / (double)conf->m / std::log(2.0 / conf->pfail));
+      const double omega_next = (epsilon + 2.0) * std::log(2.0 / conf->pfail) / epsilon / epsilon / delta_next;
+      rmax_next *= std::sqrt((double)conf->m * rmax_next) * 3.0;
+      SpecContext ctx(g);  // g->stream, the mail and the calling thread's timer are the second stream's until it ends
+      PPRHIP_CHECK_HIP(hipStreamWaitEvent(g->stream, g->spec_ev[0], 0));
+      PPRHIP_TRY(fetch_small(g, &g->ctr->dead_pops, &dead_before_ahead, sizeof dead_before_ahead));
+      PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax_next, st_ahead, kSumLaunch));
+      PPRHIP_TRY(launch_walk_plan(g, 1, alpha, 0.0, 0, g->est, omega_next));
+      PPRHIP_CHECK_HIP(hipEventRecord(g->spec_ev[1], g->stream));
+      ahead = true;
+    }
+    PPRHIP_TRY(select_finish(g, sel_seq, g->est, conf->k, ids_out, vals_out, cap, &nsel_round, &kth, &have, st));
+    g->topk_rsum = g->h_ctr->sum_out;  // (the selection's read-back came after the copy on the stream)
     rsum_local = g->topk_rsum;         // :142
     if (!have) kth = 0.0;                                                                        // :174
-    (void)hipEventRecord(g->ev[4], g->stream);
-    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
-    push_ms += CallTimer::ms(g->ev[1], g->ev[2]);
-    mc_ms += CallTimer::ms(g->ev[2], g->ev[3]);
-    sel_ms += CallTimer::ms(g->ev[3], g->ev[4]);
+    if (!spec_on) {
+      (void)hipEventRecord(g->ev[4], g->stream);
+      PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      push_ms += CallTimer::ms(g->ev[1], g->ev[2]);
+      mc_ms += CallTimer::ms(g->ev[2], g->ev[3]);
+      sel_ms += CallTimer::ms(g->ev[3], g->ev[4]);
+    }
     st.kth_value = kth;
-    if (kth >= (1 + epsilon) * delta_local || delta_local <= min_delta) break;  // :175-176
-    delta_local = std::max(min_delta, delta_local / 4.0);                       // :178
+    kth_prev = kth;
+    if (kth >= (1 + epsilon) * delta_local || delta_local <= min_delta) {  // :175-176
+      ahead_discarded = ahead;
+      break;
+    }
+    if (ahead) {  // the push ahead was this round's: its counters join the query's
+      st.pops += st_ahead.pops;
+      st.edge_pushes += st_ahead.edge_pushes;
+      st.enqueues += st_ahead.enqueues;
+      st.dense_nodes += st_ahead.dense_nodes;
+      st.dense_edges += st_ahead.dense_edges;
+      st.levels += st_ahead.levels;
+      st.dense_levels += st_ahead.dense_levels;
+      st.sweep_min_bytes += st_ahead.sweep_min_bytes;
+      st.push_bytes += st_ahead.push_bytes;
+      pushed_ahead = true;
+    }
+    delta_local = delta_next;
   }
   if (round == 0 && !dead_src) {  // delta below min_delta from the start: nothing ran
     PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
   }
   g->result_in_est = true;
+  if (ahead_discarded) PPRHIP_CHECK_HIP(hipStreamWaitEvent(g->stream, g->spec_ev[1], 0));  // before the next query clears
   PPRHIP_TRY(read_dead_pops(g, st));
-  int nsel = 0;
-  bool have = false;
-  double kth = 0.0;
+  if (ahead_discarded && st.dead_end_pops >= dead_before_ahead) {  // the unused push's dead-end pops are not the query's
+    st.push_bytes -= 16ull * (st.dead_end_pops - dead_before_ahead);
+    st.dead_end_pops = dead_before_ahead;
+  }
+  int nsel = nsel_round;
   (void)hipEventRecord(g->ev[3], g->stream);
-  PPRHIP_TRY(select_topk(g, g->est, conf->k, ids_out, vals_out, cap, &nsel, &kth, &have, st));
+  if (round == 0 || dead_src) {  // no round selected anything yet (the last round's selection is the result otherwise)
+    bool have = false;
+    double kth = 0.0;
+    PPRHIP_TRY(select_topk(g, g->est, conf->k, ids_out, vals_out, cap, &nsel, &kth, &have, st));
+  }
   (void)hipEventRecord(g->ev[4], g->stream);
   tm.finish(st);
-  sel_ms += CallTimer::ms(g->ev[3], g->ev[4]);
+  if (spec_on) {  // phases of different rounds run side by side: the per-class kernel times stand for the phases
+    push_ms = st.class_ms[PPRHIP_KERNEL_SPARSE_PUSH] + st.class_ms[PPRHIP_KERNEL_DENSE_PULL];
+    mc_ms = st.class_ms[PPRHIP_KERNEL_WALK];
+    sel_ms = st.class_ms[PPRHIP_KERNEL_QUERY_SETUP];
+  } else {
+    sel_ms += CallTimer::ms(g->ev[3], g->ev[4]);
+  }
   st.push_ms = push_ms;
   st.mc_ms = mc_ms;
   st.select_ms = sel_ms;

@@ -19,9 +19,10 @@ struct DevCounters {
   unsigned long long sources_total;  // residue entries that started walks
   double sum_out;                    // reduction result (the walk plan reads it on the device)
   // walk plan of a phase: sources << 36 | walks, counted by the plan kernel, read by the walk kernel on the device.
-  // Two cells used in turn: the walk kernel of one phase clears the cell of the next.
-  unsigned long long mc_plan[2];
-  unsigned long long pad[5];
+  // Three cells used in turn: the plan of phase p counts into cell p % 3 and clears cell (p + 1) % 3, which the walks
+  // of phase p - 2 were the last to read (the plan of phase p + 1 may run while the walks of phase p still start).
+  unsigned long long mc_plan[3];
+  unsigned long long pad[4];
   unsigned long long dhist[8];    // dense batch: dhist[i] = frontier that dense level i of the batch starts from
   int dstate[8];                  // dense batch: sweep state of level i (kGsNone: the level does not run)
 };
@@ -108,6 +109,7 @@ struct PushArgs {
 // has into per-class accumulators and starts over, so neither the pool nor `recs` grows with the call.
 struct KernelTimer {
   static constexpr size_t kMaxEvents = 4096;
+  bool off = false;  // records nothing (work whose time is accounted elsewhere or not at all)
   std::vector<hipEvent_t> ev;
   struct Rec { int cls; size_t i; uint64_t bytes; };
   std::vector<Rec> recs;
@@ -142,6 +144,7 @@ struct KernelTimer {
     if (used + 2 * k > kMaxEvents && hipStreamSynchronize(stream) == hipSuccess) fold();
   }
   void begin(int cls, uint64_t bytes) {
+    if (off) return;
     if (used + 2 > kMaxEvents) {
       if (hipStreamSynchronize(stream) != hipSuccess) return;
       fold();
@@ -152,6 +155,7 @@ struct KernelTimer {
     (void)hipEventRecord(a, stream);
   }
   void end() {
+    if (off) return;
     hipEvent_t b = next();
     if (b) (void)hipEventRecord(b, stream);
   }
@@ -324,7 +328,9 @@ struct pprhip_graph {
   // it receives mass, as Forward_Push.java:226-231 enqueues it, although it does not *cross* the threshold
   uint32_t* armed = nullptr;
   // walk plan
-  int mc_parity = 0;  // DevCounters::mc_plan cell of the next walk phase
+  uint32_t mc_phase = 0;      // walk phases planned since the workspace was reset
+  uint32_t mc_last_plan = 0;  // phase of the latest plan: what the next walk kernel runs
+  pprhip::WalkPlanRec* mc_plan_rec2 = nullptr;  // second record buffer (odd phases) where plans run ahead of walks
   unsigned long long walk_hint = 0;  // upper bound of the next walk phase's walks when the host knows one (grid size)
   pprhip::WalkPlanRec* mc_plan_rec = nullptr;  // n entries: the residue entries of a walk phase (k_mc_plan)
   // reductions / selection scratch
@@ -340,6 +346,14 @@ struct pprhip_graph {
   pprhip::HostMail* mail = nullptr;      // mapped pinned memory: small read-backs without a copy command (fetch_small)
   pprhip::HostMail* mail_dev = nullptr;  // the same, as the device sees it
   unsigned long long mail_seq = 0;
+  // a second stream with its own mail and timer: the next top-k round's push beside this round's walks (engine.cpp:
+  // pprhip_fora_topk); created on first use
+  hipStream_t spec_stream = nullptr;
+  pprhip::HostMail* spec_mail = nullptr;
+  pprhip::HostMail* spec_mail_dev = nullptr;
+  unsigned long long spec_mail_seq = 0;
+  hipEvent_t spec_ev[2] = {nullptr, nullptr};  // plan done (compute stream) / speculative push done (second stream)
+  pprhip::KernelTimer spec_timer;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   pprhip_tuning_t tun{};
   // resumable top-k push session (Forward_Push object state)
@@ -386,7 +400,8 @@ constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply ker
 int launch_dense_level_b8(pprhip_graph* parent, bool backward, const pprhip::GsBlock* blocks = nullptr, int n_blocks = 1);
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);
 int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot);
-int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter);
+int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter,
+                     bool write_armed = false);
 int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbuf, int out_slot, int dead_slot);
 int launch_sum(pprhip_graph* g, const double* x, uint32_t n);  // result -> ctr->sum_out
 inline uint32_t act_n(const pprhip_graph* g) { return g->n_act ? g->n_act : g->n; }  // entries a query's passes cover

@@ -125,10 +125,17 @@ unsigned long long gs_thresh_of(const pprhip_graph* g);
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree);
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L);
 int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes);  // a few words, without a copy command
+int fetch_begin(pprhip_graph* g, const void* dev, size_t bytes, unsigned long long* seq_out);  // ... in two halves
+int fetch_end(pprhip_graph* g, unsigned long long seq, const void* dev, void* host, size_t bytes);
+int select_launch(pprhip_graph* g, const double* x, int k, unsigned long long* seq_out);
+int select_finish(pprhip_graph* g, unsigned long long seq, const double* x, int k, int32_t* ids_out, double* vals_out,
+                  int cap, int* n_out, double* kth_out, bool* have_kth, pprhip_stats_t& st);
 int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count = 0);  // count 0: the query's scan bound
 int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st);
 int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,
                    double* target, pprhip_stats_t& st, double omega_dev = 0.0);
+int launch_walk_plan(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, double* target, double omega_dev);
+int launch_walk_run(pprhip_graph* g, int variant, double alpha, uint64_t seed, uint32_t stream, double* target);
 int copy_out(pprhip_graph* g, const double* dev, double* host);
 int check_graph(const pprhip_graph* g, const char* fn);
 int check_node(const pprhip_graph* g, int32_t v, const char* fn);

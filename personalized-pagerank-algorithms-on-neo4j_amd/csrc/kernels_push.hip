@@ -66,8 +66,10 @@ __global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restric
   __shared__ unsigned long long s_red2[4];
   // the first level of a batch gets its frontier from the host as an argument (pk0 != ~0) and clears the counters of
   // the levels behind it: no copy and no fill on the stream for what two words and eight zeros say
-  if (level == 0 && pk0 != ~0ull && blockIdx.x == 0 && threadIdx.x == 0)
+  if (level == 0 && pk0 != ~0ull && blockIdx.x == 0 && threadIdx.x == 0) {
     for (int i = 1; i <= kMaxBatch; ++i) ctr->hist[i] = 0ull;
+    ctr->hist[kMaxBatch + 2] = 0ull;  // the seeding pass's list counter: the host has read it before this level
+  }
   const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
   if (!level_runs(pk, level, dense_thresh)) return;
   const uint32_t nf = (uint32_t)(pk >> kPackShift);
@@ -1186,15 +1188,19 @@ __global__ __launch_bounds__(256) void k_count_active(uint32_t n, const double* 
   if (threadIdx.x == 0) blk_pack[blockIdx.x] = ps;
 }
 
+// `armed` (top-k round starts that do not count first): the pass also writes the round's "armed" bits, as
+// k_count_active does; the workgroups' ranges are multiples of 256 nodes then, so a wave covers 64 consecutive ids.
 template <int KIND>
 __global__ __launch_bounds__(256) void k_seed_list(uint32_t n, const double* __restrict__ res,
                                                     const uint32_t* __restrict__ out_rp, uint8_t* __restrict__ flags,
                                                     int32_t* __restrict__ Fn, uint32_t* __restrict__ eoffn,
-                                                    unsigned long long* counter, PushArgs a) {
-  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
-  const uint32_t lo = blockIdx.x * per;
-  const uint32_t hi = lo + per < n ? lo + per : n;
-  if (lo >= hi) return;
+                                                    unsigned long long* counter, uint32_t* __restrict__ armed, PushArgs a) {
+  uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  if (armed) per = (per + 255u) & ~255u;
+  const unsigned long long lo64 = (unsigned long long)blockIdx.x * per;
+  if (lo64 >= n) return;
+  const uint32_t lo = (uint32_t)lo64;
+  const uint32_t hi = lo64 + per < n ? lo + per : n;
   block_range_compact(
       lo, hi, counter,
       [&](uint32_t v, unsigned long long* w) {
@@ -1208,7 +1214,25 @@ __global__ __launch_bounds__(256) void k_seed_list(uint32_t n, const double* __r
       });
   if (KIND == 1) {
     __syncthreads();
-    for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) unpark(v, res, out_rp[v + 1] - out_rp[v], flags, a);
+    // wave-uniform trip count: a wave covers 64 consecutive nodes, whose "armed" bits it writes as one 64-bit word
+    for (uint32_t base = lo + (threadIdx.x & ~63u); base < hi; base += 256) {
+      const uint32_t v = base + (threadIdx.x & 63u);
+      bool arm = false;
+      if (v < hi) {
+        const uint32_t d = out_rp[v + 1] - out_rp[v];
+        // meets the round's threshold without being parked (only when rmax < min_rmax); tested before the node leaves
+        // the parked set
+        if (armed) arm = a.rmax < a.min_rmax && !flags[v] && active_fwd(res[v], d, a.rmax);
+        unpark(v, res, d, flags, a);
+      }
+      if (armed) {
+        const unsigned long long bits = __ballot(arm);
+        if ((threadIdx.x & 63u) == 0) {
+          armed[base >> 5] = (uint32_t)bits;
+          armed[(base >> 5) + 1] = (uint32_t)(bits >> 32);
+        }
+      }
+    }
   }
 }
 
@@ -1576,14 +1600,15 @@ int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int o
   return reduce_partials(g, grid, out_slot, 0, false);
 }
 
-int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter) {
+int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter,
+                     bool write_armed) {
   const uint32_t grid = grid_for(act_n(g), 1024, 1024);
   if (seed_kind == 0)
     k_seed_list<0><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags, g->F[out_fbuf],
-                                                            g->eoff[out_fbuf], d_counter, a);
+                                                            g->eoff[out_fbuf], d_counter, nullptr, a);
   else
     k_seed_list<1><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags, g->F[out_fbuf],
-                                                            g->eoff[out_fbuf], d_counter, a);
+                                                            g->eoff[out_fbuf], d_counter, write_armed ? g->armed : nullptr, a);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

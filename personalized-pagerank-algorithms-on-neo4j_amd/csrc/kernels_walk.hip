@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
                                                   double alpha, double rsum, double nrw, double omega_dev,
                                                   const unsigned long long* __restrict__ out_ext,
                                                   const int32_t* __restrict__ new2old, WalkPlanRec* __restrict__ plan,
-                                                  DevCounters* ctr, int parity) {
+                                                  DevCounters* ctr, int parity, int next_cell) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctr->mc_plan[next_cell] = 0ull;  // (engine.hpp: DevCounters::mc_plan)
   const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = blockIdx.x * per;
   const uint32_t hi = lo + per < n ? lo + per : n;
@@ -168,11 +169,11 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
 // walk kernel: one wave per workgroup, each with a contiguous share of the phase's walks.  A lane whose walk has
 // stopped takes the wave's next walk at once, so lanes stay busy although walk lengths are geometric, and the wave only
 // drains once, at the end of its share (with a workgroup per 1024 walks, as in round 2, every chunk ended in a tail
-// of ~20 steps with few lanes walking: 36 G steps/s).  The entries of the next 256 walks are staged in LDS (a window);
+// of ~20 steps with few lanes walking: 36 G steps/s).  The entries of the next kWalkWindow walks are staged in LDS (a window);
 // a refill reads LDS only.
 // ------------------------------------------------------------------------------------------------
-constexpr int kWalkWindow = 256;
-constexpr uint32_t kWalkWavesPerCu = 16;  // 8.5 KB of LDS each
+constexpr int kWalkWindow = 128;
+constexpr uint32_t kWalkWavesPerCu = 16;  // 4.3 KB of LDS each: room for another stream's workgroups on the CU
 
 struct WalkWindow {  // LDS, one per wave
   unsigned long long woff[kWalkWindow + 1];
@@ -180,7 +181,7 @@ struct WalkWindow {  // LDS, one per wave
   double inc[kWalkWindow];
   int32_t node[kWalkWindow];
   int32_t orig[kWalkWindow];
-  uint32_t ent4[kWalkWindow / 4];  // staged entry (one byte) of every walk of the window
+  uint8_t ent[kWalkWindow];  // staged entry of every walk of the window
 };
 
 // first entry whose walk range starts beyond walk x (woff[0] = 0, so >= 1), 64 probes per round
@@ -209,13 +210,11 @@ __global__ __launch_bounds__(64) void k_mc_walk(const WalkPlanRec* __restrict__ 
                                                  const uint4* __restrict__ walk_rec, double* __restrict__ target,
                                                  double alpha, uint32_t k0, uint32_t k1, uint32_t stream,
                                                  int no_zero_hop, DevCounters* ctr, int parity) {
-  // the plan kernel counted sources and walks into mc_plan[parity]; the other cell (read by the phase before) is
-  // cleared for the plan of the phase after, and the query's totals grow by this phase
+  // the plan kernel counted sources and walks into mc_plan[parity]; the query's totals grow by this phase
   const unsigned long long plan = ctr->mc_plan[parity];
   const uint32_t n_src = (uint32_t)(plan >> kPackShift);
   const unsigned long long n_walks = plan & kPackMask;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ctr->mc_plan[parity ^ 1] = 0ull;
     ctr->walks_total += n_walks;
     ctr->sources_total += n_src;
   }
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(64) void k_mc_walk(const WalkPlanRec* __restrict__ 
     const unsigned long long need = __ballot(!walking);
     if (need && cursor < w_hi) {
       if (cursor >= win_end) {
-        // stage the entries of walks [cursor, cursor + 256): at most 256 of them from e, which holds walk `cursor`
+        // stage the entries of walks [cursor, cursor + kWalkWindow): at most that many from e, which holds walk `cursor`
         // (every entry owns >= 1 walk)
         win_lo = cursor;
         win_end = cursor + kWalkWindow < w_hi ? cursor + kWalkWindow : w_hi;
@@ -258,7 +257,8 @@ __global__ __launch_bounds__(64) void k_mc_walk(const WalkPlanRec* __restrict__ 
         }
         unsigned long long last = n_walks;
         if (lane == 0 && (unsigned long long)e + kWalkWindow < n_src) last = plan_rec[(size_t)e + kWalkWindow].woff;
-        S.ent4[lane] = 0u;
+#pragma unroll
+        for (int q = 0; q < kWalkWindow / 64; ++q) S.ent[lane * (kWalkWindow / 64) + q] = 0;
 #pragma unroll
         for (int q = 0; q < kWalkWindow / 64; ++q) {
           const int j = q * 64 + lane;
@@ -271,19 +271,20 @@ __global__ __launch_bounds__(64) void k_mc_walk(const WalkPlanRec* __restrict__ 
         if (lane == 0) S.woff[kWalkWindow] = last;
         __syncthreads();
         // entry j > 0 that starts inside the window marks its first walk; a running maximum spreads the marks
-        uint8_t* ent = reinterpret_cast<uint8_t*>(S.ent4);
 #pragma unroll
         for (int q = 0; q < kWalkWindow / 64; ++q) {
           const int j = q * 64 + lane;
-          if (j > 0 && r[q].woff >= win_lo && r[q].woff < win_end) ent[r[q].woff - win_lo] = (uint8_t)j;
+          if (j > 0 && r[q].woff >= win_lo && r[q].woff < win_end) S.ent[r[q].woff - win_lo] = (uint8_t)j;
         }
         __syncthreads();
-        const uint32_t x = S.ent4[lane];
-        uint32_t m0 = x & 0xffu, m1 = (x >> 8) & 0xffu, m2 = (x >> 16) & 0xffu, m3 = x >> 24;
-        m1 = m1 > m0 ? m1 : m0;
-        m2 = m2 > m1 ? m2 : m1;
-        m3 = m3 > m2 ? m3 : m2;
-        uint32_t run = m3;  // inclusive maximum over the lanes
+        constexpr int kPer = kWalkWindow / 64;  // positions per lane
+        uint32_t m[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          m[q] = S.ent[lane * kPer + q];
+          if (q > 0 && m[q] < m[q - 1]) m[q] = m[q - 1];
+        }
+        uint32_t run = m[kPer - 1];  // inclusive maximum over the lanes
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
           const uint32_t o = __shfl_up(run, d);
@@ -291,18 +292,15 @@ __global__ __launch_bounds__(64) void k_mc_walk(const WalkPlanRec* __restrict__ 
         }
         uint32_t before = __shfl_up(run, 1);
         if (lane == 0) before = 0;
-        m0 = m0 > before ? m0 : before;
-        m1 = m1 > before ? m1 : before;
-        m2 = m2 > before ? m2 : before;
-        m3 = m3 > before ? m3 : before;
-        S.ent4[lane] = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) S.ent[lane * kPer + q] = (uint8_t)(m[q] > before ? m[q] : before);
         __syncthreads();
       }
       const unsigned long long avail = win_end - cursor;
       const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
       if (!walking && rank < avail) {
         const unsigned long long gidx = cursor + rank;
-        const uint32_t j = reinterpret_cast<const uint8_t*>(S.ent4)[gidx - win_lo];
+        const uint32_t j = S.ent[gidx - win_lo];
         const int32_t start = S.node[j];
         inc = S.inc[j];
         const unsigned long long sext = S.ext[j];
@@ -316,7 +314,7 @@ __global__ __launch_bounds__(64) void k_mc_walk(const WalkPlanRec* __restrict__ 
       const unsigned long long want = __popcll(need);
       cursor += want < avail ? want : avail;
       if (cursor >= win_end) {  // window used up: e becomes the entry of the next walk
-        const uint32_t jl = reinterpret_cast<const uint8_t*>(S.ent4)[win_end - 1 - win_lo];
+        const uint32_t jl = S.ent[win_end - 1 - win_lo];
         e += S.woff[jl + 1] == win_end ? jl + 1u : jl;
       }
     }
@@ -374,7 +372,7 @@ __global__ __launch_bounds__(256) void k_build_walk_rec(unsigned long long m, co
 
 __global__ void k_plan_single(int32_t src, double inc, unsigned long long n_walks,
                               const unsigned long long* __restrict__ out_ext, const int32_t* __restrict__ new2old,
-                              WalkPlanRec* plan, DevCounters* ctr, int parity) {
+                              WalkPlanRec* plan, DevCounters* ctr, int parity, int next_cell) {
   WalkPlanRec r;
   r.woff = 0ull;
   r.inc = inc;
@@ -382,6 +380,7 @@ __global__ void k_plan_single(int32_t src, double inc, unsigned long long n_walk
   r.node = src;
   r.orig = new2old[src];
   plan[0] = r;
+  ctr->mc_plan[next_cell] = 0ull;
   ctr->mc_plan[parity] = (1ull << kPackShift) | n_walks;
 }
 
@@ -402,16 +401,24 @@ int launch_build_walk_rec(pprhip_graph* g) {
   return PPRHIP_OK;
 }
 
+// the phase a plan belongs to picks its counter cell and its record buffer; the next walk kernel runs the latest plan
+static WalkPlanRec* plan_rec_of(pprhip_graph* g, uint32_t phase) {
+  return (g->mc_plan_rec2 && (phase & 1u)) ? g->mc_plan_rec2 : g->mc_plan_rec;
+}
+
 int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double omega_dev, double* target) {
+  const uint32_t phase = g->mc_phase++;
+  g->mc_last_plan = phase;
+  const int cell = (int)(phase % 3u), next_cell = (int)((phase + 1u) % 3u);
   const uint32_t n = act_n(g);
   uint64_t b = ((uint64_t)n + 1023) / 1024;
   const uint32_t grid = (uint32_t)(b > 1024 ? 1024 : b);
   if (variant == 0)
     hipLaunchKernelGGL(k_mc_plan<0>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
-                       omega_dev, g->out_ext, g->new2old, g->mc_plan_rec, g->ctr, g->mc_parity);
+                       omega_dev, g->out_ext, g->new2old, plan_rec_of(g, phase), g->ctr, cell, next_cell);
   else
     hipLaunchKernelGGL(k_mc_plan<1>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
-                       omega_dev, g->out_ext, g->new2old, g->mc_plan_rec, g->ctr, g->mc_parity);
+                       omega_dev, g->out_ext, g->new2old, plan_rec_of(g, phase), g->ctr, cell, next_cell);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -422,10 +429,10 @@ int launch_mc_walk(pprhip_graph* g, double alpha, uint64_t seed, uint32_t stream
   uint32_t grid = (uint32_t)g->n_cus * kWalkWavesPerCu;
   if (g->walk_hint) grid = (uint32_t)std::min<unsigned long long>(grid, std::max<unsigned long long>((g->walk_hint + 63) / 64, 1ull));
   g->walk_hint = 0;
-  hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(64), 0, g->stream, g->mc_plan_rec, reinterpret_cast<const uint4*>(g->walk_rec),
-                     target, alpha, (uint32_t)seed, (uint32_t)(seed >> 32), stream, no_zero_hop, g->ctr, g->mc_parity);
+  hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(64), 0, g->stream, plan_rec_of(g, g->mc_last_plan),
+                     reinterpret_cast<const uint4*>(g->walk_rec), target, alpha, (uint32_t)seed, (uint32_t)(seed >> 32), stream,
+                     no_zero_hop, g->ctr, (int)(g->mc_last_plan % 3u));
   PPRHIP_CHECK_HIP(hipGetLastError());
-  g->mc_parity ^= 1;
   return PPRHIP_OK;
 }
 
@@ -443,8 +450,10 @@ int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* 
 
 int launch_mc_pure(pprhip_graph* g, int32_t src, uint64_t n_walks, double alpha, uint64_t seed, double inc,
                    double* target) {
+  const uint32_t phase = g->mc_phase++;
+  g->mc_last_plan = phase;
   hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(1), 0, g->stream, src, inc, (unsigned long long)n_walks, g->out_ext,
-                     g->new2old, g->mc_plan_rec, g->ctr, g->mc_parity);
+                     g->new2old, plan_rec_of(g, phase), g->ctr, (int)(phase % 3u), (int)((phase + 1u) % 3u));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return launch_mc_walk(g, alpha, seed, 0, 0, target);
 }
