@@ -39,6 +39,9 @@ def main():
         if e > busy_end:
             busy_end, last = e, k
     span = t1 - t0
+    # average number of kernels running, and per queue how much of the span it was busy
+    ksum = sum(e - s for s, e, k in rows)
+    print("kernel time / span = %.2f kernels running on average" % (ksum / span))
     print("span %.1f ms, idle %.1f ms (%.1f %%), %d kernels" % (span / 1e6, total_idle / 1e6, 100.0 * total_idle / span, len(rows)))
     for (a, b), v in idle.most_common(25):
         print("  %-26s -> %-26s %8.2f ms  %6d gaps  avg %7.1f us" % (a, b, v / 1e6, idle_n[(a, b)], v / idle_n[(a, b)] / 1e3))
