@@ -78,6 +78,20 @@ def live_sources(host, count, seed):
     return out
 
 
+def exact_ppr_matrix(host, s, alpha):
+    """alpha (I - (1-alpha) P_s)^-1 where dead-end rows of P_s point to the query source s (Forward_Push.java:101-113):
+    row v is the distribution of a walk started at v under the reference's dynamics for source s.  Plain numpy."""
+    n = host.n
+    P = np.zeros((n, n))
+    for v in range(n):
+        nb = host.out_ci[host.out_rp[v]:host.out_rp[v + 1]]
+        if len(nb) == 0:
+            P[v, s] = 1.0
+        else:
+            np.add.at(P[v], nb, 1.0 / len(nb))
+    return alpha * np.linalg.inv(np.eye(n) - (1 - alpha) * P)
+
+
 def topk_gap_ok(exact, k, tol):
     """At least k + 1 exact entries, and the k-th and (k+1)-th values are further apart than twice the tolerance
     (else set identity is not decidable at that tolerance; exact ties by symmetry fall here too)."""
@@ -115,12 +129,23 @@ def test_engine_against_committed_fifo_vectors(golden, got, dev_got):
         q, qr, _ = dev_got.backward_push(s, A, 1e-8)
         assert np.max(np.abs(q - unhex(bp["reserve"]))) <= 2e-8 <= TOL_SPEC, name
         assert qr.max() <= 1e-8
-        # the reference's own first threshold rmax0 (Fora_Whole_Graph.java:86): FIFO and the engine differ
-        # by what the two orders leave behind, which the invariant bounds by the residue sums
+        # the reference's own first threshold rmax0 (Fora_Whole_Graph.java:86): FIFO and the engine stop in different
+        # states; each must be a push state of the SAME exact vector (dense solve, independent of oracle and engine):
+        # pi_s = reserve + sum_v residue(v) pi_s(v, .), every residue below the threshold - so the two reserves differ
+        # by exactly what the two residue vectors still hold
         g0 = e["forward_push_rmax0"]
-        p0, r0, _, _ = dev_got.forward_push(s, A, float.fromhex(g0["rmax"]))
-        bound = r0.sum() + unhex(g0["residue"]).sum()
-        assert np.max(np.abs(p0 - unhex(g0["reserve"]))) <= bound + 1e-15, name
+        rmax0 = float.fromhex(g0["rmax"])
+        p0, r0, _, _ = dev_got.forward_push(s, A, rmax0)
+        pf, rf = unhex(g0["reserve"]), unhex(g0["residue"])
+        od = np.diff(got.out_rp)
+        if od[s] > 0:
+            Pi = exact_ppr_matrix(got, s, A)
+            assert np.max(np.abs(p0 + r0 @ Pi - Pi[s])) < 1e-12, name
+            assert np.max(np.abs(pf + rf @ Pi - Pi[s])) < 1e-12, name
+            assert np.max(np.abs((p0 - pf) - (rf - r0) @ Pi)) < 1e-12, name
+            assert np.all((od == 0) & (r0 == 0) | (od > 0) & (r0 / np.maximum(od, 1) < rmax0)), name
+        else:
+            assert p0[s] == 1.0 and r0.sum() == 0.0 and np.array_equal(p0, pf), name
 
 
 # ------------------------------------------------------------------ (a) push vs FIFO and vs the CPU power method
