@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the one-query-at-a-time, top-k and All-Pair samples")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline traffic)")
     ap.add_argument("--no-rmat24", action="store_true", help="skip the R-MAT 24 All-Pair child sample")
-    ap.add_argument("--rmat24-targets", type=int, default=1 << 22)
+    ap.add_argument("--rmat24-targets", type=int, default=1 << 24)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--all-pair-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rmat24-child", action="store_true", help=argparse.SUPPRESS)
