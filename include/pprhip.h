@@ -196,6 +196,15 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_row_ptr, con
                         const uint32_t* in_row_ptr, const int32_t* in_col_idx, int device,
                         pprhip_graph_t** graph_out);
 void pprhip_graph_destroy(pprhip_graph_t* g);
+/* A handle keeps the workspaces of every entry point it has served (allocating gigabytes per call would cost more than
+ * the call): on first use of the batched entry points 16 query slots + interleaved arrays (R-MAT 22: 6.7 GB), on first
+ * use of All-Pair the in-edge records, the dense per-workgroup vectors and the record buffer (R-MAT 22: 27 GB, R-MAT 24:
+ * 80 GB).  pprhip_graph_release hands them back between phases of a job; the next call of that entry point allocates
+ * them again.  The CSR pair, the walk records and the single-query workspace stay.  Not to be called while another
+ * thread uses the handle. */
+#define PPRHIP_RELEASE_ALL_PAIR 1u
+#define PPRHIP_RELEASE_BATCH 2u
+int pprhip_graph_release(pprhip_graph_t* g, unsigned what);
 int pprhip_graph_info(const pprhip_graph_t* g, uint32_t* n, uint64_t* m, int* device);
 int pprhip_graph_set_tuning(pprhip_graph_t* g, const pprhip_tuning_t* t);
 int pprhip_graph_get_tuning(const pprhip_graph_t* g, pprhip_tuning_t* t);

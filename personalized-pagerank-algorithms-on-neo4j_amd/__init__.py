@@ -68,7 +68,7 @@ EXPORTS = [
     "pprhip_conf_fora_whole_graph", "pprhip_conf_fora_topk", "pprhip_fora_whole_params", "pprhip_fora_topk_params",
     "pprhip_rmat_edges", "pprhip_edgelist_from_neo4j_csv", "pprhip_edgelist_info", "pprhip_edgelist_edges",
     "pprhip_edgelist_node_name", "pprhip_edgelist_destroy", "pprhip_csr_build", "pprhip_graph_create",
-    "pprhip_graph_destroy", "pprhip_graph_info", "pprhip_graph_set_tuning", "pprhip_graph_get_tuning",
+    "pprhip_graph_destroy", "pprhip_graph_release", "pprhip_graph_info", "pprhip_graph_set_tuning", "pprhip_graph_get_tuning",
     "pprhip_get_reserve", "pprhip_get_residue", "pprhip_forward_push", "pprhip_fwdpush_topk_reset",
     "pprhip_fwdpush_topk_round", "pprhip_random_walk_batch", "pprhip_fora_single_source", "pprhip_fora_topk",
     "pprhip_topk_select", "pprhip_monte_carlo", "pprhip_fora_batch_topk", "pprhip_backward_push",
@@ -121,6 +121,7 @@ def lib():
     L.pprhip_graph_create.argtypes = [u32, u64, vp, vp, vp, vp, ci, P(vp)]
     L.pprhip_graph_destroy.argtypes = [vp]
     L.pprhip_graph_destroy.restype = None
+    L.pprhip_graph_release.argtypes = [vp, C.c_uint]
     L.pprhip_graph_info.argtypes = [vp, P(u32), P(u64), P(ci)]
     L.pprhip_graph_set_tuning.argtypes = [vp, P(Tuning)]
     L.pprhip_graph_get_tuning.argtypes = [vp, P(Tuning)]
@@ -507,6 +508,12 @@ class Graph:
         if getattr(self, "h", None):
             lib().pprhip_graph_destroy(self.h)
             self.h = None
+
+    RELEASE_ALL_PAIR, RELEASE_BATCH = 1, 2
+
+    def release(self, what):
+        """Hands the workspaces of the named entry points back (pprhip_graph_release); they come back on next use."""
+        _check(lib().pprhip_graph_release(self.h, what))
 
     def __del__(self):
         self.close()

@@ -1443,6 +1443,27 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
   return PPRHIP_OK;
 }
 
+static void free_all_pair(pprhip_graph* g) {
+  void** ptrs[] = {(void**)&g->apbs_ws, (void**)&g->apbs_board, (void**)&g->apbs_xl_ws, (void**)&g->in_rec};
+  for (void** p : ptrs) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  g->apbs_blocks = 0;  // (all_pair_collect sizes and allocates the workspaces when it finds none)
+}
+
+int pprhip_graph_release(pprhip_graph_t* g, unsigned what) {
+  PPRHIP_TRY(check_graph(g, "pprhip_graph_release"));
+  if (what & ~(PPRHIP_RELEASE_ALL_PAIR | PPRHIP_RELEASE_BATCH)) {
+    set_error("pprhip_graph_release: unknown flag in %u", what);
+    return PPRHIP_ERR_INVALID;
+  }
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  if (what & PPRHIP_RELEASE_ALL_PAIR) free_all_pair(g);
+  if (what & PPRHIP_RELEASE_BATCH) free_batch(g);
+  return PPRHIP_OK;
+}
+
 void pprhip_graph_destroy(pprhip_graph_t* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);

@@ -460,6 +460,28 @@ def test_all_pair_dense_tier_shared_levels(pkg, orc, rmat12, chunk, monkeypatch)
             ix.close()
 
 
+def test_released_workspaces_come_back(pkg, rmat12):
+    """pprhip_graph_release hands the All-Pair and batch workspaces back; the next call of those entry points
+    allocates them again and returns what it returned before."""
+    srcs = sources(rmat12, 5, seed=3)
+    with pkg.Graph(rmat12) as g:
+        g.set_tuning(pkg.tuning_batch())
+        ix, _ = g.all_pair_backward(ALPHA, 1e-3, 8, 0, 512)
+        a0 = [x.copy() for x in ix.arrays()]
+        ix.close()
+        b0 = g.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, k=8, fetch=True)
+        g.release(g.RELEASE_ALL_PAIR | g.RELEASE_BATCH)
+        g.release(g.RELEASE_ALL_PAIR | g.RELEASE_BATCH)  # nothing left to release: still fine
+        ix, _ = g.all_pair_backward(ALPHA, 1e-3, 8, 0, 512)
+        a1 = ix.arrays()
+        assert all(np.array_equal(x, y) for x, y in zip(a0[:2], a1[:2])) and np.max(np.abs(a0[2] - a1[2])) <= TOL_PUSH
+        ix.close()
+        b1 = g.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, k=8, fetch=True)
+        assert np.max(np.abs(b0[0] - b1[0])) <= 1e-9 and np.array_equal(b0[1], b1[1])
+        with pytest.raises(pkg.PprhipError):
+            g.release(64)
+
+
 def test_batch_directions_share_a_handle(pkg, orc, rmat12, dev_rmat12, monkeypatch):
     """Forward batches and batched backward searches (All-Pair tier 3) alternate on one handle: the shared sweep
     arrays are handed over clean in both directions."""
