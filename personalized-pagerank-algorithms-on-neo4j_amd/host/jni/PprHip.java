@@ -102,6 +102,10 @@ public final class PprHip implements AutoCloseable {
     /** Batched calls pay off with the batch cost-model profile (pprhip_tuning_batch); false restores the default. */
     public native void setBatchTuning(boolean on);
 
+    /** Hands the workspaces of All-Pair (1) and / or of the batched calls (2) back to the device between the phases
+     *  of a job (pprhip_graph_release); the next call of those entry points allocates them again. */
+    public native void release(int what);
+
     @Override
     public native void close();
 

@@ -340,6 +340,11 @@ JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_setBatchTuning(JNIEnv* e, 
   if (g) fail(e, pprhip_graph_set_tuning(g, &t));
 }
 
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_release(JNIEnv* e, jobject self, jint what) {
+  pprhip_graph_t* g = G(e, self);
+  if (g) fail(e, pprhip_graph_release(g, (unsigned)what));
+}
+
 JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_close(JNIEnv* e, jobject self) {
   // closing twice is allowed (AutoCloseable): the second call finds both fields 0
   if (pprhip_results_t* r = R(e, self)) pprhip_results_destroy(r);
