@@ -222,6 +222,9 @@ def main():
         if args.backend == "nccl":
             comm = _quiet_stdout(lambda: pkg.Comm(g, bytes.fromhex(uid[0]), rank, world))
 
+    gather_how = ("pprhip_topk_gather (RCCL inside libpprhip.so)" if comm is not None else
+                  "torch.distributed.gather over %s (rehearsal on fewer devices than ranks: RCCL refuses two ranks on "
+                  "one device)" % args.backend)
     acc = {"class_ms": [0.0] * 8, "class_bytes": [0] * 8, "class_launches": [0] * 8, "rounds": 0, "queries": 0,
            "walks": 0, "walk_steps": 0, "levels": 0, "dense_levels": 0, "dense_edges": 0, "push_ms": 0.0, "mc_ms": 0.0,
            "sweep_min_bytes": 0, "call_ms": 0.0}
@@ -356,9 +359,8 @@ def main():
                        "mode": "16 queries in flight (pprhip_fora_batch_single_source_resident): every query's vector "
                                "kept in a device-resident store, top-%d per query" % TOPK
                        if args.mode == "batch" else "one query at a time (pprhip_fora_single_source)",
-                       "sharding": "replicated CSR, sources sharded by rank, top-%d blocks gathered on rank 0 by "
-                                   "pprhip_topk_gather (RCCL inside libpprhip.so)" % TOPK
-                       if world > 1 else "single GPU"},
+                       "sharding": "replicated CSR, sources sharded by rank, top-%d blocks gathered on rank 0 by %s"
+                                   % (TOPK, gather_how) if world > 1 else "single GPU"},
             "ms_per_query": round(1e3 * elapsed / (args.steps * q), 3),
             "live_node_fraction_of_graph": round(live_frac_graph, 4),
             "value_vectors_resident": round(value, 3),
