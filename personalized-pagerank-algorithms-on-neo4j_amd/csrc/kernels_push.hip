@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
         const double nw = old + acc / (double)d;
         if (!(old > a.rmax) && nw > a.rmax) {
           reserve[u] = reserve[u] + nw * a.alpha;
-          res[u] = 0.0;
+          if (old != 0.0) res[u] = 0.0;
           cn = (1.0 - a.alpha) * nw;
           pack = (1ull << kPackShift) | (unsigned long long)(in_rp[u + 1] - in_rp[u]);
         } else {
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
       }
       if (crossing) {  // becomes a frontier node of the next level: prepare it right here
         reserve[u] = reserve[u] + nw * a.alpha;
-        res[u] = 0.0;
+        if (old != 0.0) res[u] = 0.0;
         if (d == 0) {
           dead_next = nw * (1.0 - a.alpha);
           ndead = 1;
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
           const double nw = old + accv[g][i] / (double)d[g];
           if (!(old > a[i].rmax) && nw > a[i].rmax) {
             a[i].reserve[u[g]] = rsvv[g][i] + nw * a[i].alpha;
-            a[i].res[u[g]] = 0.0;
+            if (oldv[g][i] != 0.0) a[i].res[u[g]] = 0.0;  // (rows that cross every sweep hold zero already)
             cn = (1.0 - a[i].alpha) * nw;
             pack[i] += (1ull << kPackShift) | (unsigned long long)din[g];
           } else {
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
           }
           if (crossing) {  // becomes a frontier node of the next level: prepare it right here
             a[i].reserve[u[g]] = rsvv[g][i] + nw * a[i].alpha;
-            a[i].res[u[g]] = 0.0;
+            if (oldv[g][i] != 0.0) a[i].res[u[g]] = 0.0;  // (rows that cross every sweep hold zero already)
             if (d[g] == 0) {
               dead_next[i] += nw * (1.0 - a[i].alpha);
               ndead[i]++;
