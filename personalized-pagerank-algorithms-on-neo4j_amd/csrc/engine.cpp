@@ -1144,6 +1144,77 @@ int select_finish(pprhip_graph* g, unsigned long long seq, const double* x, int 
   return PPRHIP_OK;
 }
 
+// A stream that really runs beside the handle's compute stream.  The runtime spreads streams over a few in-order
+// hardware queues, and which streams share one depends on what else the process has created: a stream that lands on
+// the compute stream's queue never overlaps it (fora.cpp: FetchPipe, tools/exp/copy_overlap.py: kernels ran during
+// 0.0 % of the copies' time).  So candidates are created - plain ones first, then of the other priorities - and each
+// is tried: a kernel holds the compute stream for a moment, a one-word k_publish goes to the candidate, and the
+// candidate is taken if the word arrives while the hold kernel still runs.  Rejected candidates stay alive until the
+// search ends, so that the next one lands elsewhere.  *out stays null when none ran beside.
+int make_side_stream(pprhip_graph* g, hipStream_t* out) {
+  *out = nullptr;
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  HostMail* probe = nullptr;
+  HostMail* probe_dev = nullptr;
+  if (hipHostMalloc((void**)&probe, sizeof(HostMail), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&probe_dev, probe, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    if (probe) (void)hipHostFree(probe);
+    return PPRHIP_ERR_OOM;
+  }
+  std::memset(probe, 0, sizeof(HostMail));
+  hipEvent_t held = nullptr;
+  if (hipEventCreateWithFlags(&held, hipEventDisableTiming) != hipSuccess) {
+    (void)hipHostFree(probe);
+    return PPRHIP_ERR_HIP;
+  }
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  const int prios[] = {0, 0, 0, 0, prio_lo, prio_hi, prio_lo, prio_hi};
+  std::vector<hipStream_t> rejected;
+  unsigned long long seq = 0;
+  for (int p : prios) {
+    hipStream_t cand = nullptr;
+    const hipError_t ce = p == 0 ? hipStreamCreateWithFlags(&cand, hipStreamNonBlocking)
+                                 : hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, p);
+    if (ce != hipSuccess) break;
+    bool beside = false;
+    ++seq;
+    hipStream_t own = g->stream;
+    HostMail *m = g->mail, *md = g->mail_dev;
+    if (launch_hold(own, 30000ull) == PPRHIP_OK && hipEventRecord(held, own) == hipSuccess) {  // ~0.3 ms at 100 MHz
+      g->stream = cand;
+      g->mail = probe;
+      g->mail_dev = probe_dev;
+      const int rc = launch_publish(g, &g->ctr->sum_out, 1, seq);
+      g->stream = own;
+      g->mail = m;
+      g->mail_dev = md;
+      if (rc == PPRHIP_OK) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 150.0) {
+          if (__atomic_load_n(&probe->seq, __ATOMIC_ACQUIRE) == seq) {
+            beside = hipEventQuery(held) == hipErrorNotReady;  // arrived while the hold kernel still runs
+            break;
+          }
+          __builtin_ia32_pause();
+        }
+      }
+    }
+    (void)hipStreamSynchronize(own);
+    (void)hipStreamSynchronize(cand);
+    if (beside) {
+      *out = cand;
+      break;
+    }
+    rejected.push_back(cand);
+  }
+  for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+  (void)hipEventDestroy(held);
+  (void)hipHostFree(probe);
+  return PPRHIP_OK;
+}
+
 }  // namespace detail
 }  // namespace pprhip
 
@@ -1723,10 +1794,11 @@ int pprhip_topk_select(pprhip_graph_t* g, int k, int32_t* ids_out, double* vals_
 }
 
 // ------------------------------------------------------------------ FORA top-k (a6)
-// The second stream of pprhip_fora_topk: a priority of its own gives it a hardware queue of its own (fora.cpp:
-// FetchPipe::ensure has the measurement), so its kernels run beside the compute stream's.
+// The second stream of pprhip_fora_topk (make_side_stream picks one that runs beside the compute stream), its host
+// mail, its plan record buffer and its events.
 static int ensure_spec(pprhip_graph* g) {
   if (g->spec_stream) return PPRHIP_OK;
+  if (g->spec_failed) return PPRHIP_ERR_STATE;
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (prio_lo == prio_hi) return PPRHIP_ERR_STATE;  // no second queue to be had: the rounds run one after another
@@ -1748,9 +1820,10 @@ static int ensure_spec(pprhip_graph* g) {
       e = nullptr;
       return PPRHIP_ERR_HIP;
     }
-  if (hipStreamCreateWithPriority(&g->spec_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
-    g->spec_stream = nullptr;
-    return PPRHIP_ERR_HIP;
+  PPRHIP_TRY(make_side_stream(g, &g->spec_stream));
+  if (!g->spec_stream) {
+    g->spec_failed = true;  // no stream of this process runs beside the compute stream: the rounds run in order
+    return PPRHIP_ERR_STATE;
   }
   return PPRHIP_OK;
 }

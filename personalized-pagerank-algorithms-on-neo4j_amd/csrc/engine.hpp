@@ -352,6 +352,7 @@ struct pprhip_graph {
   pprhip::HostMail* spec_mail = nullptr;
   pprhip::HostMail* spec_mail_dev = nullptr;
   unsigned long long spec_mail_seq = 0;
+  bool spec_failed = false;  // no candidate stream ran beside the compute stream
   hipEvent_t spec_ev[2] = {nullptr, nullptr};  // plan done (compute stream) / speculative push done (second stream)
   pprhip::KernelTimer spec_timer;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -420,6 +421,7 @@ int launch_build_walk_rec(pprhip_graph* g);
 int init_kernels_host();
 int launch_publish(pprhip_graph* g, const void* src, uint32_t n_words, unsigned long long seq);
 int launch_clear(pprhip_graph* g, const ClearList& L);
+int launch_hold(hipStream_t stream, unsigned long long ticks);
 // The walk phase runs without a host round trip: the plan kernel counts sources and walks into DevCounters::mc_plan
 // [g->mc_parity], the walk kernel (a fixed grid) reads them there.  omega_dev > 0: the plan derives rsum and the walk
 // budget itself from the residue sum a reduction left in DevCounters::sum_out (top-k rounds: Fora_Topk.java:148-151);

@@ -124,6 +124,7 @@ const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks);
 unsigned long long gs_thresh_of(const pprhip_graph* g);
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree);
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L);
+int make_side_stream(pprhip_graph* g, hipStream_t* out);  // a stream that runs beside g->stream (self-tested)
 int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes);  // a few words, without a copy command
 int fetch_begin(pprhip_graph* g, const void* dev, size_t bytes, unsigned long long* seq_out);  // ... in two halves
 int fetch_end(pprhip_graph* g, unsigned long long seq, const void* dev, void* host, size_t bytes);

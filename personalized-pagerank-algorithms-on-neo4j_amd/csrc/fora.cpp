@@ -713,12 +713,12 @@ int pprhip::detail::FetchPipe::ensure(pprhip_graph* parent) {
     PPRHIP_CHECK_HIP(hipEventCreateWithFlags(&ready[e], hipEventDisableTiming));
     PPRHIP_CHECK_HIP(hipEventCreateWithFlags(&done[e], hipEventDisableTiming));
   }
-  // A priority of its own gives the copy stream a hardware queue of its own: the runtime spreads streams of equal
-  // priority over a few hardware queues, and on a queue it shared with the compute stream no copy ever overlapped a
-  // kernel (tools/exp/copy_overlap.py: kernels ran during 0.0 % of the copies' time).
-  int prio_lo = 0, prio_hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  PPRHIP_CHECK_HIP(hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, prio_hi));  // last: marks the pipe complete
+  // The copy stream has to sit on another hardware queue than the compute stream: on a shared queue no copy ever
+  // overlapped a kernel (tools/exp/copy_overlap.py: kernels ran during 0.0 % of the copies' time).  make_side_stream
+  // tries candidates until one runs beside the compute stream; without one, a plain stream (copies then run between
+  // kernels, as before round 3).
+  PPRHIP_TRY(make_side_stream(parent, &cs));
+  if (!cs) PPRHIP_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));  // last: marks the pipe complete
   return PPRHIP_OK;
 }
 

@@ -31,6 +31,20 @@ __global__ __launch_bounds__(256) void k_clear(ClearList L) {
   }
 }
 
+// Does a stream run beside another?  The runtime spreads streams over a few in-order hardware queues, and which
+// streams share one depends on what else the process has created.  k_hold keeps the first stream busy for a while,
+// k_publish on the second writes a word to the host; if the word arrives while k_hold still runs, the two overlap.
+__global__ void k_hold(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+int launch_hold(hipStream_t stream, unsigned long long ticks) {
+  hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 0, stream, ticks);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
 int init_kernels_host() {  // loads this file's code object on the current device (see init_kernels_push)
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_publish)));
