@@ -897,7 +897,8 @@ int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st) {
 // the largest budget possible, for the range check).
 // The walk phase in two halves (a caller may queue other work between them, or run the plan on another stream):
 // the plan of the residue entries, and the walk kernel that runs the latest plan.
-int launch_walk_plan(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, double* target, double omega_dev) {
+int launch_walk_plan(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, double* target, double omega_dev,
+                     const double* copy_src, double* copy_dst) {
   // what the host knows about the walk count sizes the grid: the budget itself (every residue entry adds at most one
   // walk to it), or - with the budget derived on the device - nothing
   g->walk_hint = omega_dev > 0.0 ? 0ull : (unsigned long long)nrw + act_n(g);
@@ -907,7 +908,7 @@ int launch_walk_plan(pprhip_graph* g, int variant, double alpha, double rsum, lo
     return PPRHIP_ERR_INVALID;
   }
   SetupScope setup(g);
-  return launch_mc_plan(g, variant, alpha, rsum, (double)nrw, omega_dev, target);
+  return launch_mc_plan(g, variant, alpha, rsum, (double)nrw, omega_dev, target, copy_src, copy_dst);
 }
 
 int launch_walk_run(pprhip_graph* g, int variant, double alpha, uint64_t seed, uint32_t stream, double* target) {
@@ -1093,20 +1094,22 @@ static int select_topk_passes(pprhip_graph* g, const double* x, int k, int32_t* 
 // ascending).  Only when more candidates share those 12 bits than the buffer holds the multi-pass form takes over.
 // The selection in two halves, so that a caller can queue other work between launching it and waiting for it.
 constexpr size_t kSelPre = 2048;
-int select_launch(pprhip_graph* g, const double* x, int k, unsigned long long* seq_out) {
+int select_launch(pprhip_graph* g, const double* x, int k, unsigned long long* seq_out, bool with_plan_sum) {
   {
     SetupScope setup(g);
     PPRHIP_TRY(launch_select_hist(g, x, act_n(g), 0ull, 0, 12, true));
     PPRHIP_TRY(launch_select_choose(g, (unsigned long long)k));
-    PPRHIP_TRY(launch_select_gather(g, x, act_n(g), 0ull, false, true));
+    // with_plan_sum: the residue sum of the round whose plan ran last travels in the header (DevCounters::plan_sum)
+    PPRHIP_TRY(launch_select_gather(g, x, act_n(g), 0ull, false, true,
+                                    with_plan_sum ? &g->ctr->plan_sum[g->mc_last_plan % 3u] : nullptr));
   }
   return fetch_begin(g, g->sel_blob, kSelHeader + sizeof(SelRec) * kSelPre, seq_out);
 }
 
 int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
-                double* kth_out, bool* have_kth, pprhip_stats_t& st) {
+                double* kth_out, bool* have_kth, pprhip_stats_t& st, bool with_plan_sum) {
   unsigned long long seq = 0;
-  PPRHIP_TRY(select_launch(g, x, k, &seq));
+  PPRHIP_TRY(select_launch(g, x, k, &seq, with_plan_sum));
   return select_finish(g, seq, x, k, ids_out, vals_out, cap, n_out, kth_out, have_kth, st);
 }
 
@@ -1117,10 +1120,11 @@ int select_finish(pprhip_graph* g, unsigned long long seq, const double* x, int 
   PPRHIP_TRY(fetch_end(g, seq, g->sel_blob, blob.data(), blob.size()));
   st.select_passes++;
   st.select_bytes += 16ull * act_n(g);
-  unsigned long long hdr[5];
+  unsigned long long hdr[6];
   std::memcpy(hdr, blob.data(), sizeof hdr);
   const uint64_t cnt = hdr[0], expected = hdr[2], total = hdr[3];
   const bool have = hdr[4] != 0;
+  std::memcpy(&g->sel_plan_sum, &hdr[5], sizeof(double));  // (meaningful after select_launch(..., with_plan_sum))
   if (total == 0) {
     *n_out = 0;
     *have_kth = false;
@@ -1911,14 +1915,14 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
       PPRHIP_CHECK_HIP(hipStreamWaitEvent(g->stream, g->spec_ev[1], 0));
     } else {
       PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax_local, st, kSumLaunch));  // :137; the residue sum stays on the device
-      // :148-151: the plan derives rsum and the walk budget from the sum on the device
-      PPRHIP_TRY(launch_walk_plan(g, 1, alpha, 0.0, 0, g->est, omega_local));
+      // :148-151: the plan derives rsum and the walk budget from the sum on the device; :143 the estimate := copy of
+      // the push reserve (walk increments of earlier rounds are dropped), taken in the plan's pass
+      PPRHIP_TRY(launch_walk_plan(g, 1, alpha, 0.0, 0, g->est, omega_local, g->reserve, g->est));
     }
-    pushed_ahead = false;
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sum_out, &g->ctr->sum_out, sizeof(double), hipMemcpyDeviceToHost, g->stream));
     if (!spec_on) (void)hipEventRecord(g->ev[2], g->stream);
-    // :143 reserve := copy of the push reserve (walk increments of earlier rounds are dropped)
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
+    // a plan that ran ahead could not touch the estimate (the round before was still reading it): :143 here
+    if (pushed_ahead) PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
+    pushed_ahead = false;
     if (spec_on) PPRHIP_CHECK_HIP(hipEventRecord(g->spec_ev[0], g->stream));  // residues and reserve have been read
     // :155-168: the walk kernel reads the plan's counts on the device: no host round trip between push and selection
     PPRHIP_TRY(launch_walk_run(g, 1, alpha, seed, round, g->est));
@@ -1927,7 +1931,7 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
     double kth = 0.0;
     bool have = false;
     unsigned long long sel_seq = 0;
-    PPRHIP_TRY(select_launch(g, g->est, conf->k, &sel_seq));  // :173
+    PPRHIP_TRY(select_launch(g, g->est, conf->k, &sel_seq, true));  // :173; the round's residue sum comes back with it
     // ---- the next round's push, residue sum and walk plan, ahead of the decision whether there is a next round
     const double delta_next = std::max(min_delta, delta_local / 4.0);  // :178
     pprhip_stats_t st_ahead;
@@ -1950,8 +1954,8 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
       ahead = true;
     }
     PPRHIP_TRY(select_finish(g, sel_seq, g->est, conf->k, ids_out, vals_out, cap, &nsel_round, &kth, &have, st));
-    g->topk_rsum = g->h_ctr->sum_out;  // (the selection's read-back came after the copy on the stream)
-    rsum_local = g->topk_rsum;         // :142
+    g->topk_rsum = g->sel_plan_sum;  // (the sum this round's plan was derived from, in the selection's header)
+    rsum_local = g->topk_rsum;       // :142
     if (!have) kth = 0.0;                                                                        // :174
     if (!spec_on) {
       (void)hipEventRecord(g->ev[4], g->stream);

@@ -22,7 +22,10 @@ struct DevCounters {
   // Three cells used in turn: the plan of phase p counts into cell p % 3 and clears cell (p + 1) % 3, which the walks
   // of phase p - 2 were the last to read (the plan of phase p + 1 may run while the walks of phase p still start).
   unsigned long long mc_plan[3];
-  unsigned long long pad[4];
+  // the residue sum a top-k round's plan was derived from, kept per phase like the cells above: the selection that
+  // ends the round hands it to the host in its header (no copy command of its own)
+  double plan_sum[3];
+  unsigned long long pad[1];
   unsigned long long dhist[8];    // dense batch: dhist[i] = frontier that dense level i of the batch starts from
   int dstate[8];                  // dense batch: sweep state of level i (kGsNone: the level does not run)
 };
@@ -328,6 +331,7 @@ struct pprhip_graph {
   // it receives mass, as Forward_Push.java:226-231 enqueues it, although it does not *cross* the threshold
   uint32_t* armed = nullptr;
   // walk plan
+  double sel_plan_sum = 0.0;  // the residue sum the last selection's header carried (select_launch with_plan_sum)
   uint32_t mc_phase = 0;      // walk phases planned since the workspace was reset
   uint32_t mc_last_plan = 0;  // phase of the latest plan: what the next walk kernel runs
   pprhip::WalkPlanRec* mc_plan_rec2 = nullptr;  // second record buffer (odd phases) where plans run ahead of walks
@@ -426,7 +430,8 @@ int launch_hold(hipStream_t stream, unsigned long long ticks);
 // [g->mc_parity], the walk kernel (a fixed grid) reads them there.  omega_dev > 0: the plan derives rsum and the walk
 // budget itself from the residue sum a reduction left in DevCounters::sum_out (top-k rounds: Fora_Topk.java:148-151);
 // otherwise rsum / nrw are the host's.
-int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double omega_dev, double* target);
+int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double omega_dev, double* target,
+                   const double* copy_src = nullptr, double* copy_dst = nullptr);
 int launch_mc_walk(pprhip_graph* g, double alpha, uint64_t seed, uint32_t stream, int no_zero_hop, double* target);
 int launch_walk_batch(pprhip_graph* g, const int32_t* d_starts, const uint64_t* d_idx, uint64_t count, double alpha,
                       uint64_t seed, uint32_t stream, int no_zero_hop, int32_t* d_term, uint32_t* d_steps);
@@ -481,6 +486,6 @@ int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned lo
                        int digit_bits, bool first_pass);
 int launch_select_choose(pprhip_graph* g, unsigned long long k);
 int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits, bool zero_count,
-                         bool lower_from_device = false);
+                         bool lower_from_device = false, const double* sum_cell = nullptr);
 
 }  // namespace pprhip

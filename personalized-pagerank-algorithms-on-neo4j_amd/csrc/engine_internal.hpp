@@ -128,14 +128,15 @@ int make_side_stream(pprhip_graph* g, hipStream_t* out);  // a stream that runs 
 int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes);  // a few words, without a copy command
 int fetch_begin(pprhip_graph* g, const void* dev, size_t bytes, unsigned long long* seq_out);  // ... in two halves
 int fetch_end(pprhip_graph* g, unsigned long long seq, const void* dev, void* host, size_t bytes);
-int select_launch(pprhip_graph* g, const double* x, int k, unsigned long long* seq_out);
+int select_launch(pprhip_graph* g, const double* x, int k, unsigned long long* seq_out, bool with_plan_sum = false);
 int select_finish(pprhip_graph* g, unsigned long long seq, const double* x, int k, int32_t* ids_out, double* vals_out,
                   int cap, int* n_out, double* kth_out, bool* have_kth, pprhip_stats_t& st);
 int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count = 0);  // count 0: the query's scan bound
 int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st);
 int run_walk_phase(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, uint64_t seed, uint32_t stream,
                    double* target, pprhip_stats_t& st, double omega_dev = 0.0);
-int launch_walk_plan(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, double* target, double omega_dev);
+int launch_walk_plan(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, double* target, double omega_dev,
+                     const double* copy_src = nullptr, double* copy_dst = nullptr);
 int launch_walk_run(pprhip_graph* g, int variant, double alpha, uint64_t seed, uint32_t stream, double* target);
 int copy_out(pprhip_graph* g, const double* dev, double* host);
 int check_graph(const pprhip_graph* g, const char* fn);
@@ -144,7 +145,7 @@ const pprhip_graph* host_of(const pprhip_graph* g);
 uint32_t hdeg_out(const pprhip_graph* g, int32_t v);
 uint32_t hdeg_in(const pprhip_graph* g, int32_t v);
 int select_topk(pprhip_graph* g, const double* x, int k, int32_t* ids_out, double* vals_out, int cap, int* n_out,
-                double* kth_out, bool* have_kth, pprhip_stats_t& st);
+                double* kth_out, bool* have_kth, pprhip_stats_t& st, bool with_plan_sum = false);
 
 struct CallTimer {
   pprhip_graph* g;

@@ -251,17 +251,17 @@ int topk_step(ForaRun& r, bool yield_dense) {
       // the walk budget from it (:148,151) and the walk kernel reads the plan's counts; the sum reaches the host with
       // the selection's read-back
       PPRHIP_TRY(launch_sum(g, g->residue, act_n(g)));
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(&g->h_ctr->sum_out, &g->ctr->sum_out, sizeof(double), hipMemcpyDeviceToHost, g->stream));
       g->topk_first = false;
-      // :143 reserve := copy of the push reserve (walk increments of earlier rounds are dropped)
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(g->est, g->reserve, nd, hipMemcpyDeviceToDevice, g->stream));
-      PPRHIP_TRY(run_walk_phase(g, 1, r.alpha, 0.0, 0, r.seed, r.round, g->est, r.st, r.omega_local));  // :155-168
+      // :143 the estimate := copy of the push reserve (walk increments of earlier rounds are dropped), taken in the
+      // plan's pass over the same range; :155-168 the walks
+      PPRHIP_TRY(launch_walk_plan(g, 1, r.alpha, 0.0, 0, g->est, r.omega_local, g->reserve, g->est));
+      PPRHIP_TRY(launch_walk_run(g, 1, r.alpha, r.seed, r.round, g->est));
       r.round++;
       double kth = 0.0;
       bool have = false;
       int nsel = 0;
-      PPRHIP_TRY(select_topk(g, g->est, conf->k, nullptr, nullptr, 0, &nsel, &kth, &have, r.st));  // :173
-      g->topk_rsum = g->h_ctr->sum_out;  // (the selection synchronised the stream)
+      PPRHIP_TRY(select_topk(g, g->est, conf->k, nullptr, nullptr, 0, &nsel, &kth, &have, r.st, true));  // :173
+      g->topk_rsum = g->sel_plan_sum;  // (the sum the round's plan was derived from, in the selection's header)
       r.rsum_local = g->topk_rsum;       // :142
       if (!have) kth = 0.0;                                                                          // :174
       r.st.kth_value = kth;

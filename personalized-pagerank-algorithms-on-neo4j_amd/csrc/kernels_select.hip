@@ -90,18 +90,21 @@ __global__ __launch_bounds__(1024) void k_select_choose(const uint32_t* __restri
   }
 }
 
-// Candidates are 16-byte records behind a 64-byte header {count, lower bits, expected, total, have k, -}: one copy
+// Candidates are 16-byte records behind a 64-byte header {count, lower bits, expected, total, have k, the round's
+// residue sum (sum_cell given: top-k rounds)}: one copy
 // brings the header and the records to the host.  lower_dev: take the lower bound from the header (k_select_choose
 // wrote it).  Block 0 leaves the histogram of the select that has just been read out all-zero for the next one.
 __global__ __launch_bounds__(256) void k_select_gather(const double* __restrict__ x, uint32_t n,
                                                         unsigned long long lower_bits, int lower_dev,
                                                         char* __restrict__ blob, uint32_t cap,
-                                                        uint32_t* __restrict__ hist) {
+                                                        uint32_t* __restrict__ hist, const double* sum_cell) {
   unsigned long long* count = reinterpret_cast<unsigned long long*>(blob);
   SelRec* recs = reinterpret_cast<SelRec*>(blob + kSelHeader);
   if (lower_dev) lower_bits = count[1];
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0) {
     for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) hist[b] = 0u;
+    if (sum_cell && threadIdx.x == 0) count[5] = (unsigned long long)__double_as_longlong(*sum_cell);
+  }
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nround = (n + stride - 1) / stride * stride;
   const int lane = lane_id();
@@ -152,12 +155,12 @@ int launch_select_choose(pprhip_graph* g, unsigned long long k) {
 }
 
 int launch_select_gather(pprhip_graph* g, const double* x, uint32_t n, unsigned long long lower_bits, bool zero_count,
-                         bool lower_from_device) {
+                         bool lower_from_device, const double* sum_cell) {
   uint64_t b = ((uint64_t)n + 255) / 256;
   const uint32_t grid = (uint32_t)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
   if (zero_count) PPRHIP_CHECK_HIP(hipMemsetAsync(g->sel_blob, 0, sizeof(unsigned long long), g->stream));
   hipLaunchKernelGGL(k_select_gather, dim3(grid), dim3(256), 0, g->stream, x, n, lower_bits, lower_from_device ? 1 : 0,
-                     g->sel_blob, g->sel_cap, g->hist);
+                     g->sel_blob, g->sel_cap, g->hist, sum_cell);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

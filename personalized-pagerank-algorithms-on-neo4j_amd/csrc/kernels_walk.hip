@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
                                                   double alpha, double rsum, double nrw, double omega_dev,
                                                   const unsigned long long* __restrict__ out_ext,
                                                   const int32_t* __restrict__ new2old, WalkPlanRec* __restrict__ plan,
-                                                  DevCounters* ctr, int parity, int next_cell) {
+                                                  DevCounters* ctr, int parity, int next_cell,
+                                                  const double* __restrict__ copy_src, double* __restrict__ copy_dst) {
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr->mc_plan[next_cell] = 0ull;  // (engine.hpp: DevCounters::mc_plan)
   const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = blockIdx.x * per;
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
   if (omega_dev > 0.0) {
     // the budget from the residue sum on the device, with the host's own expressions (Fora_Topk.java:148,151 /
     // Fora_Whole_Graph.java:112-113): rsum = sum * (1 - alpha); nrw = (long long)(omega * rsum)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->plan_sum[parity] = ctr->sum_out;  // for the round's selection header
     rsum = ctr->sum_out * (1.0 - alpha);
     const double nrw_d = omega_dev * rsum;
     nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (double)(long long)nrw_d : 0.0;
@@ -163,6 +165,10 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
       if (r > 0.0) target[v] = target[v] + r * alpha;
     }
   }
+  // top-k rounds: the estimate the walks add to starts as a copy of the push reserve (Fora_Topk.java:143) - taken here,
+  // in the pass that reads the same range anyway, when the caller has no use for the old estimate any more
+  if (copy_dst)
+    for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) copy_dst[v] = copy_src[v];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -406,7 +412,8 @@ static WalkPlanRec* plan_rec_of(pprhip_graph* g, uint32_t phase) {
   return (g->mc_plan_rec2 && (phase & 1u)) ? g->mc_plan_rec2 : g->mc_plan_rec;
 }
 
-int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double omega_dev, double* target) {
+int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, double nrw, double omega_dev, double* target,
+                   const double* copy_src, double* copy_dst) {
   const uint32_t phase = g->mc_phase++;
   g->mc_last_plan = phase;
   const int cell = (int)(phase % 3u), next_cell = (int)((phase + 1u) % 3u);
@@ -415,10 +422,10 @@ int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, doub
   const uint32_t grid = (uint32_t)(b > 1024 ? 1024 : b);
   if (variant == 0)
     hipLaunchKernelGGL(k_mc_plan<0>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
-                       omega_dev, g->out_ext, g->new2old, plan_rec_of(g, phase), g->ctr, cell, next_cell);
+                       omega_dev, g->out_ext, g->new2old, plan_rec_of(g, phase), g->ctr, cell, next_cell, copy_src, copy_dst);
   else
     hipLaunchKernelGGL(k_mc_plan<1>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
-                       omega_dev, g->out_ext, g->new2old, plan_rec_of(g, phase), g->ctr, cell, next_cell);
+                       omega_dev, g->out_ext, g->new2old, plan_rec_of(g, phase), g->ctr, cell, next_cell, copy_src, copy_dst);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
