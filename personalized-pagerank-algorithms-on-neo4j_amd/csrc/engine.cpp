@@ -730,7 +730,14 @@ void free_batch(pprhip_graph* P) {
     delete P->fetch;
     P->fetch = nullptr;
   }
+  if (P->walk_stream) (void)hipStreamDestroy(P->walk_stream);
+  P->walk_stream = nullptr;
+  P->walk_stream_tried = false;
   for (pprhip_graph* S : P->slots) {
+    for (auto& ev : S->walk_ev) {
+      if (ev) (void)hipEventDestroy(ev);
+      ev = nullptr;
+    }
     free_workspace(S);
     S->ktimer.destroy();
     if (S->own_stream) (void)hipStreamDestroy(S->own_stream);

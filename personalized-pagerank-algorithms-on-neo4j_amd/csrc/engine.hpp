@@ -278,6 +278,12 @@ struct pprhip_graph {
   int slot_index = -1;
   pprhip::BatchSync* sync = nullptr;  // set on a slot while a batched call is running
   hipStream_t own_stream = nullptr;   // slot: the stream its worker thread uses
+  // graph: a stream that runs beside the compute stream (make_side_stream) for the slots' walk phases while sweeps
+  // go on (sequential batch driver); slot: the events around its walk phase on that stream
+  uint32_t walk_waves = 0;  // waves per CU of the next walk kernels (0: the default)
+  hipStream_t walk_stream = nullptr;
+  bool walk_stream_tried = false;
+  hipEvent_t walk_ev[3] = {nullptr, nullptr, nullptr};
   pprhip::KernelTimer ktimer;         // slot: its worker's kernel-class timer; graph: the sweeps' timer
   std::vector<pprhip_graph*> slots;
   // All-Pair: in-edge records {source, its out-degree} (8 B per edge, built on first use), and tier 2's dense

@@ -90,6 +90,7 @@ struct RoundCut {
 // kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
 
 constexpr int kYield = 1;  // run_levels: the next level is dense and the caller runs it (batched sweeps)
+constexpr int kYieldWalk = 2;  // fora_step: the walk phase runs on the handle's side stream; call again when it has ended
 
 // kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
 extern thread_local KernelTimer* g_timer_cur;

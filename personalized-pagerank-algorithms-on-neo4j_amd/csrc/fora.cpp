@@ -35,7 +35,8 @@ struct ForaRun {
   LevelCtx L;
   PushArgs a;
   RoundCut cut;
-  enum Phase { kRoundStart, kLevels, kWalks, kTopkRoundStart, kTopkLevels, kTopkFinal, kBwdLevels, kBwdFinal, kDone } phase = kDone;
+  enum Phase { kRoundStart, kLevels, kWalks, kWalkWait, kTopkRoundStart, kTopkLevels, kTopkFinal, kBwdLevels, kBwdFinal, kDone } phase = kDone;
+  hipStream_t side = nullptr;  // batch driver: the walk phase goes to this stream and the run yields until it has ended
   int query = -1;  // batch driver: index of the query this run serves
   bool waiting = false;
   bool in_push = false;  // between a push phase's start and its end (BatchSync: may hold sweeps off)
@@ -54,6 +55,8 @@ struct ForaRun {
 }  // namespace pprhip
 
 namespace {
+
+constexpr uint32_t kSideWalkWaves = 4;  // waves per CU of a walk phase that runs beside sweeps (batch_sequential)
 
 void leave_push(ForaRun& r) {
   if (r.in_push) {
@@ -165,7 +168,40 @@ int fora_step(ForaRun& r, bool yield_dense) {
       // Fora_Whole_Graph.java:112-140
       const double nrw_d = r.omega_local * r.rsum_local;
       const long long nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (long long)nrw_d : 0;
+      if (!r.dead_src && r.side) {
+        // the walk phase beside the other queries' sweeps: plan and walks on the side stream, behind everything this
+        // query has queued on the compute stream; the driver calls again when walk_ev[2] has passed
+        PPRHIP_CHECK_HIP(hipEventRecord(g->walk_ev[0], g->stream));
+        PPRHIP_CHECK_HIP(hipStreamWaitEvent(r.side, g->walk_ev[0], 0));
+        hipStream_t own = g->stream;
+        KernelTimer* const tsave = g_timer_cur;
+        KernelTimer quiet;
+        quiet.off = true;  // (timed by the events below: the caller's timer watches the compute stream)
+        g_timer_cur = &quiet;
+        g->stream = r.side;
+        g->walk_waves = kSideWalkWaves;
+        int rc = hipEventRecord(g->walk_ev[1], r.side) == hipSuccess ? PPRHIP_OK : PPRHIP_ERR_HIP;
+        if (rc == PPRHIP_OK) rc = run_walk_phase(g, 0, r.alpha, r.rsum_local, nrw, r.seed, 0, g->reserve, r.st);
+        if (rc == PPRHIP_OK && hipEventRecord(g->walk_ev[2], r.side) != hipSuccess) rc = PPRHIP_ERR_HIP;
+        g->stream = own;
+        g->walk_waves = 0;
+        g_timer_cur = tsave;
+        PPRHIP_TRY(rc);
+        r.phase = ForaRun::kWalkWait;
+        return kYieldWalk;
+      }
       if (!r.dead_src) PPRHIP_TRY(run_walk_phase(g, 0, r.alpha, r.rsum_local, nrw, r.seed, 0, g->reserve, r.st));
+      r.phase = ForaRun::kWalkWait;
+    }
+    if (r.phase == ForaRun::kWalkWait) {
+      if (!r.dead_src && r.side) {
+        PPRHIP_CHECK_HIP(hipEventSynchronize(g->walk_ev[2]));  // (the driver has seen it pass)
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g->walk_ev[1], g->walk_ev[2]) == hipSuccess) {
+          ktimer().acc_ms[PPRHIP_KERNEL_WALK] += (double)ms;  // plan + walks, as one launch of the class
+          ktimer().acc_cnt[PPRHIP_KERNEL_WALK]++;
+        }
+      }
       if (r.tm) r.tm->mark(2);
       PPRHIP_TRY(read_dead_pops(g, r.st));  // one read-back for the push's dead-end pops and the walks' steps
       r.st.rounds = (uint32_t)r.rounds;
@@ -527,25 +563,58 @@ int begin_query(BatchJob& J, ForaRun& r, pprhip_graph* S, int i) {
 }
 
 // all slots on the calling thread and the graph's stream, one after another
+// Whole-graph FORA on one host thread: a query's walk phase goes to a side stream and runs beside the other queries'
+// sweeps - with few waves per CU (the walks are bound by the memory system from four waves per CU on,
+// tools/micro/chain_rate.hip), so that the compute stream's kernels find room beside it: 292 -> 327 queries/s on
+// R-MAT 22 (16 waves per CU beside: 307; 2: 300).
+static hipStream_t side_stream_for_walks(pprhip_graph* P) {
+  if (!P->walk_stream_tried) {
+    P->walk_stream_tried = true;
+    const char* e = getenv("PPRHIP_BATCH_WALKS_BESIDE");
+    if (!(e && e[0] == '0') && make_side_stream(P, &P->walk_stream) != PPRHIP_OK) P->walk_stream = nullptr;
+    if (P->walk_stream)
+      for (pprhip_graph* S : P->slots)
+        for (auto& ev : S->walk_ev)
+          if (!ev && hipEventCreate(&ev) != hipSuccess) {
+            ev = nullptr;
+            (void)hipStreamDestroy(P->walk_stream);
+            P->walk_stream = nullptr;
+            return nullptr;
+          }
+  }
+  return P->walk_stream;
+}
+
 int batch_sequential(BatchJob& J, ForaRun* runs) {
   pprhip_graph* P = J.P;
+  hipStream_t side = J.kind == 0 ? side_stream_for_walks(P) : nullptr;
+  bool walking[kBatch] = {false};
   int busy = 0;
   for (;;) {
-    // every slot advances until it waits at a dense level; finished slots take the next query
+    // every slot advances until it waits at a dense level or for its walk phase; finished slots take the next query
     for (int s = 0; s < kBatch; ++s) {
       ForaRun& r = runs[s];
+      if (walking[s]) {
+        if (hipEventQuery(P->slots[s]->walk_ev[2]) == hipErrorNotReady) continue;
+        walking[s] = false;
+      }
       for (;;) {
         if (r.query < 0) {
           const int i = J.next_query.load();
           if (i >= J.q) break;
           J.next_query.store(i + 1);
           PPRHIP_TRY(begin_query(J, r, P->slots[s], i));
+          r.side = side;
           busy++;
         }
         if (r.waiting) break;
         const int rc = run_step(r, true);
         if (rc == kYield) {
           r.waiting = true;
+          break;
+        }
+        if (rc == kYieldWalk) {
+          walking[s] = true;
           break;
         }
         if (rc != PPRHIP_OK) return rc;
@@ -555,10 +624,19 @@ int batch_sequential(BatchJob& J, ForaRun* runs) {
     }
     if (busy == 0) break;
     bool active[kBatch];
-    int n_wait = 0;
+    int n_wait = 0, first_walk = -1;
     for (int s = 0; s < kBatch; ++s) {
       active[s] = runs[s].query >= 0 && runs[s].waiting;
       n_wait += active[s] ? 1 : 0;
+      if (walking[s] && first_walk < 0) first_walk = s;
+    }
+    if (n_wait == 0) {  // nobody stands at a dense level: a walk phase has to end before anything can go on
+      if (first_walk < 0) {
+        set_error("batch driver: %d queries in flight, none waiting", busy);
+        return PPRHIP_ERR_STATE;
+      }
+      PPRHIP_CHECK_HIP(hipEventSynchronize(P->slots[first_walk]->walk_ev[2]));
+      continue;
     }
     PPRHIP_TRY(run_sweep(P, runs, active, n_wait));
     for (int s = 0; s < kBatch; ++s)

@@ -433,7 +433,9 @@ int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, doub
 // The walk count is only known on the device: a fixed grid of waves, each with an equal share of whatever the plan
 // holds (g->walk_hint, the budget when the host knows it, only trims the grid of a short phase).
 int launch_mc_walk(pprhip_graph* g, double alpha, uint64_t seed, uint32_t stream, int no_zero_hop, double* target) {
-  uint32_t grid = (uint32_t)g->n_cus * kWalkWavesPerCu;
+  // (walk_waves: a walk phase that runs beside other kernels leaves them room - the walks are bound by the memory
+  // system from a few waves per CU on, tools/micro/chain_rate.hip)
+  uint32_t grid = (uint32_t)g->n_cus * (g->walk_waves ? g->walk_waves : kWalkWavesPerCu);
   if (g->walk_hint) grid = (uint32_t)std::min<unsigned long long>(grid, std::max<unsigned long long>((g->walk_hint + 63) / 64, 1ull));
   g->walk_hint = 0;
   hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(64), 0, g->stream, plan_rec_of(g, g->mc_last_plan),
