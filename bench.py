@@ -367,9 +367,7 @@ def main():
             "avg_rounds": round(acc["rounds"] / nq, 2),
             "kernel_ms_per_query": {pkg.KERNEL_NAMES[c]: round(acc["class_ms"][c] / nq, 3)
                                     for c in (1, 2, 3, 5, 6) if acc["class_launches"][c]},
-            "host_gap": {"wall_ms_per_query": round(1e3 * elapsed / (args.steps * q), 3),
-                         "kernel_ms_per_query": round(kernel_ms / nq, 3),
-                         "fraction_not_in_kernels": round(1.0 - (kernel_ms / nq) / (1e3 * elapsed / (args.steps * q)), 4)},
+            "host_gap": host_gap(1e3 * elapsed / (args.steps * q), kernel_ms / nq),
             "dense_levels_per_query": round(acc["dense_levels"] / nq, 1),
             "levels_per_query": round(acc["levels"] / nq, 1),
             "walks_per_query": int(acc["walks"] / nq),
@@ -411,6 +409,20 @@ def main():
         g.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def host_gap(wall_ms, kernel_ms):
+    """Wall time per query against the HIP-event time of all kernel classes.  Since round 3 a query's walk phase runs
+    beside the other queries' sweeps, so the classes' times can add up to more than the wall time: the line then
+    reports the overlap instead of a gap."""
+    out = {"wall_ms_per_query": round(wall_ms, 3), "kernel_ms_per_query": round(kernel_ms, 3)}
+    if kernel_ms <= wall_ms:
+        out["fraction_not_in_kernels"] = round(1.0 - kernel_ms / wall_ms, 4)
+    else:
+        out["fraction_not_in_kernels"] = 0.0
+        out["kernel_overlap"] = round(kernel_ms / wall_ms, 3)
+        out["note"] = "walk phases run on a side stream beside the sweeps: the kernel classes overlap (sum / wall > 1)"
+    return out
 
 
 def delivery_samples(pkg, g, store, rng, live_ids, host, conf, q):
