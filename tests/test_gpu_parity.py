@@ -200,13 +200,17 @@ def test_fora_batch_got(pkg, orc, got, dev_got, dense_frac):
         dev_got.set_tuning(pkg.tuning_default())
 
 
-@pytest.mark.parametrize("threads", ["0", "1"])
-def test_fora_batch_rmat12(pkg, orc, rmat12, dev_rmat12, threads, monkeypatch):
-    """Batch profile of the cost model on both sides; one worker thread per slot (1) or all slots on the caller (0)."""
-    monkeypatch.setenv("PPRHIP_BATCH_THREADS", threads)
+@pytest.mark.parametrize("threads", ["0", "1", "0-walks-in-line"])
+def test_fora_batch_rmat12(pkg, orc, rmat12, threads, monkeypatch):
+    """Batch profile of the cost model on both sides; one worker thread per slot (1) or all slots on the caller (0),
+    there with the queries' walk phases on a side stream beside the sweeps (default) or in line with everything else."""
+    monkeypatch.setenv("PPRHIP_BATCH_THREADS", threads[0])
+    if threads.endswith("in-line"):
+        monkeypatch.setenv("PPRHIP_BATCH_WALKS_BESIDE", "0")  # read when the handle's first batch starts
     og = to_oracle(orc, rmat12)
     srcs = sources(rmat12, 21, seed=8)
     t = pkg.tuning_batch()
+    dev_rmat12 = pkg.Graph(rmat12)
     dev_rmat12.set_tuning(t)
     try:
         for n_rounds in (2, 0):
@@ -219,16 +223,17 @@ def test_fora_batch_rmat12(pkg, orc, rmat12, dev_rmat12, threads, monkeypatch):
                                          tuning=to_orc_tuning(orc, t))
                 assert pq[i].rounds == sto.rounds and pq[i].walks == sto.walks and pq[i].levels == sto.levels
                 assert_close(out[i], ref, TOL_MC, "batch src=%d" % s)
-    finally:
         dev_rmat12.set_tuning(pkg.tuning_default())
-    # an empty batch and a batch of dead-end sources only
-    out, _, _, _, _, st = dev_rmat12.fora_batch_single_source([], 0.5, ALPHA, seed=1, fetch=True)
-    assert out.shape == (0, rmat12.n) and st.levels == 0
-    dead = [int(v) for v in np.nonzero(np.diff(rmat12.out_rp) == 0)[0][:3]]
-    if dead:
-        out, _, _, _, _, st = dev_rmat12.fora_batch_single_source(dead, 0.5, ALPHA, seed=1, fetch=True)
-        for i, s in enumerate(dead):
-            assert out[i][s] == 1.0 and out[i].sum() == 1.0
+        # an empty batch and a batch of dead-end sources only
+        out, _, _, _, _, st = dev_rmat12.fora_batch_single_source([], 0.5, ALPHA, seed=1, fetch=True)
+        assert out.shape == (0, rmat12.n) and st.levels == 0
+        dead = [int(v) for v in np.nonzero(np.diff(rmat12.out_rp) == 0)[0][:3]]
+        if dead:
+            out, _, _, _, _, st = dev_rmat12.fora_batch_single_source(dead, 0.5, ALPHA, seed=1, fetch=True)
+            for i, s in enumerate(dead):
+                assert out[i][s] == 1.0 and out[i].sum() == 1.0
+    finally:
+        dev_rmat12.close()
 
 
 def test_fora_batch_rmat15_many_queries(pkg, orc, rmat15, dev_rmat15):
@@ -315,13 +320,19 @@ def test_fora_batch_topk(pkg, orc, got, dev_got, rmat12, dev_rmat12, threads, mo
             dev.set_tuning(pkg.tuning_default())
 
 
-def test_fora_topk_rmat12(pkg, orc, rmat12, dev_rmat12):
+@pytest.mark.parametrize("ahead", ["1", "0"])
+def test_fora_topk_rmat12(pkg, orc, rmat12, dev_rmat12, ahead, monkeypatch):
+    """ahead = 1 (default): the next round's push, sum and plan run on a second stream beside this round's walks and
+    join the query only when the round is needed (engine.cpp: pprhip_fora_topk); 0: the rounds run one after another.
+    Same rounds, walks, level counters and lists either way."""
+    monkeypatch.setenv("PPRHIP_TOPK_AHEAD", ahead)
     og = to_oracle(orc, rmat12)
     for s in sources(rmat12, 3, seed=8):
         nsel, ids, vals, est, st = dev_rmat12.fora_topk(s, 0.5, ALPHA, 32, seed=6, cap=256, fetch=True)
         ref, sto = og.fora_topk(s, 0.5, ALPHA, 32, seed=6, schedule=orc.SYNC)
         assert st.rounds == sto.rounds
         assert st.walks == sto.walks
+        assert st.levels == sto.levels and st.pops == sto.pops and st.dead_end_pops == sto.dead_end_pops
         assert_close(est, ref, TOL_MC, "topk est src=%d" % s)
         cnt, oids, ovals = orc.topk(ref, 32, cap=256)
         assert nsel == cnt and list(ids) == list(oids)
