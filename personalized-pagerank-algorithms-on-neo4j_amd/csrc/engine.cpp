@@ -1932,7 +1932,10 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
     pushed_ahead = false;
     if (spec_on) PPRHIP_CHECK_HIP(hipEventRecord(g->spec_ev[0], g->stream));  // residues and reserve have been read
     // :155-168: the walk kernel reads the plan's counts on the device: no host round trip between push and selection
-    PPRHIP_TRY(launch_walk_run(g, 1, alpha, seed, round, g->est));
+    g->walk_waves = spec_on ? 8u : 0u;  // (the next round's push runs beside these walks: leave it room)
+    const int wrc = launch_walk_run(g, 1, alpha, seed, round, g->est);
+    g->walk_waves = 0;
+    PPRHIP_TRY(wrc);
     if (!spec_on) (void)hipEventRecord(g->ev[3], g->stream);
     round++;
     double kth = 0.0;

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
 // a refill reads LDS only.
 // ------------------------------------------------------------------------------------------------
 constexpr int kWalkWindow = 128;
+constexpr uint32_t kWalkWavesBeside = 4;   // ... of a walk kernel that runs beside other queries' kernels
 constexpr uint32_t kWalkWavesPerCu = 16;  // 4.3 KB of LDS each: room for another stream's workgroups on the CU
 
 struct WalkWindow {  // LDS, one per wave
@@ -435,7 +436,11 @@ int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, doub
 int launch_mc_walk(pprhip_graph* g, double alpha, uint64_t seed, uint32_t stream, int no_zero_hop, double* target) {
   // (walk_waves: a walk phase that runs beside other kernels leaves them room - the walks are bound by the memory
   // system from a few waves per CU on, tools/micro/chain_rate.hip)
-  uint32_t grid = (uint32_t)g->n_cus * (g->walk_waves ? g->walk_waves : kWalkWavesPerCu);
+  // a slot of a threaded batch shares the chip with fifteen others: few waves per CU, like a walk phase beside sweeps
+  // (batched top-k on R-MAT 22: 851 queries/s at 16 waves per CU, 961 / 1 026 / 905 at 2 / 4 / 8)
+  uint32_t grid = (uint32_t)g->n_cus * (g->walk_waves ? g->walk_waves
+                                        : g->sync   ? kWalkWavesBeside
+                                                    : kWalkWavesPerCu);
   if (g->walk_hint) grid = (uint32_t)std::min<unsigned long long>(grid, std::max<unsigned long long>((g->walk_hint + 63) / 64, 1ull));
   g->walk_hint = 0;
   hipLaunchKernelGGL(k_mc_walk, dim3(grid), dim3(64), 0, g->stream, plan_rec_of(g, g->mc_last_plan),
