@@ -1602,7 +1602,7 @@ int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int o
 
 int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter,
                      bool write_armed) {
-  const uint32_t grid = grid_for(act_n(g), 1024, 1024);
+  const uint32_t grid = grid_for(act_n(g), 1024, 16384);  // (1024 nodes per workgroup: fewer or more were slower)
   if (seed_kind == 0)
     k_seed_list<0><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags, g->F[out_fbuf],
                                                             g->eoff[out_fbuf], d_counter, nullptr, a);
