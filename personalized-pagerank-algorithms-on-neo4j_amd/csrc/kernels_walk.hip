@@ -420,7 +420,8 @@ int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, doub
   const int cell = (int)(phase % 3u), next_cell = (int)((phase + 1u) % 3u);
   const uint32_t n = act_n(g);
   uint64_t b = ((uint64_t)n + 1023) / 1024;  // 1024 nodes per workgroup (fewer or more were slower)
-  const uint32_t grid = (uint32_t)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+  const uint64_t cap = g->sync ? 1024 : 16384;  // (a slot of a threaded batch: see launch_seed_list)
+  const uint32_t grid = (uint32_t)(b > cap ? cap : (b < 1 ? 1 : b));
   if (variant == 0)
     hipLaunchKernelGGL(k_mc_plan<0>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
                        omega_dev, g->out_ext, g->new2old, plan_rec_of(g, phase), g->ctr, cell, next_cell, copy_src, copy_dst);
