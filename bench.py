@@ -216,15 +216,46 @@ def main():
 
     # N > 1: the library's communicator for the top-k gather (rank 0 draws the id)
     comm = None
+    comm_error = None
     if world > 1:
         uid = [_quiet_stdout(pkg.comm_unique_id).hex() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         if args.backend == "nccl":
-            comm = _quiet_stdout(lambda: pkg.Comm(g, bytes.fromhex(uid[0]), rank, world))
+            # The library's RCCL transport has never run with more than one rank before this line does (no multi-GPU
+            # box was available to the build): every wait inside it is bounded (PPRHIP_COMM_TIMEOUT_S) and a rank's
+            # failure reaches every peer, so a failure here costs the library gather, not the line - all ranks then
+            # agree (over torch.distributed) to gather with torch.distributed instead, and the line says so.
+            os.environ.setdefault("PPRHIP_COMM_TIMEOUT_S", "120")
+            failed = 0
+            try:
+                comm = _quiet_stdout(lambda: pkg.Comm(g, bytes.fromhex(uid[0]), rank, world))
+                probe = comm.topk_gather(np.full((1, TOPK), rank, dtype=np.int32), np.full((1, TOPK), float(rank)),
+                                         rows_max=1)
+                if rank == 0 and (probe is None or not all(int(probe[0][r][0][0]) == r for r in range(world))):
+                    raise RuntimeError("the probe blocks did not come back rank by rank")
+            except Exception as e:  # noqa: BLE001
+                failed = 1
+                comm_error = "%s: %s" % (type(e).__name__, str(e)[:200])
+            flag = torch.tensor([failed], dtype=torch.int32, device=xdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                if comm is not None:
+                    try:
+                        comm.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                comm = None
+                errs = [None] * world
+                dist.all_gather_object(errs, comm_error)
+                comm_error = "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e) or "a rank failed"
 
-    gather_how = ("pprhip_topk_gather (RCCL inside libpprhip.so)" if comm is not None else
-                  "torch.distributed.gather over %s (rehearsal on fewer devices than ranks: RCCL refuses two ranks on "
-                  "one device)" % args.backend)
+    if comm is not None:
+        gather_how = "pprhip_topk_gather (RCCL inside libpprhip.so)"
+    elif comm_error:
+        gather_how = "torch.distributed.gather over %s, because the library's gather failed its probe (%s)" % (args.backend, comm_error)
+    else:
+        gather_how = ("torch.distributed.gather over %s (rehearsal on fewer devices than ranks: RCCL refuses two ranks on "
+                      "one device)" % args.backend)
     acc = {"class_ms": [0.0] * 8, "class_bytes": [0] * 8, "class_launches": [0] * 8, "rounds": 0, "queries": 0,
            "walks": 0, "walk_steps": 0, "levels": 0, "dense_levels": 0, "dense_edges": 0, "push_ms": 0.0, "mc_ms": 0.0,
            "sweep_min_bytes": 0, "call_ms": 0.0}
