@@ -25,10 +25,12 @@
 // error state; on either the communicator is aborted (ncclCommAbort), which releases the peers' kernels as well.
 // One-process communicators are created with ncclCommInitAll from the calling thread (no rendezvous between
 // threads that one failing rank could leave the others in).
-// STATUS: the RCCL transport with more than one rank has not executed anywhere yet (no multi-GPU box was available
-// to this build; it runs with a group of one in tests/test_gpu_multi.py) - the in-process transport, which shares
-// the partition, the record layout, the sentinel protocol and every line outside comm_alltoallv's transport branch,
-// is what the 2- and 3-rank tests and the fault-injection tests exercise.
+// STATUS: the RCCL transport with more than one rank has not executed on a real fabric yet (no multi-GPU box was
+// available to this build; real RCCL runs with a group of one in tests/test_gpu_multi.py).  Its code has run with 2 and
+// 3 ranks against a test double of the dozen RCCL calls (tests/fixtures/fake_rccl.cpp through PPRHIP_RCCL_LIB: ranks
+// are threads, a send / receive pair is a device copy) - size exchange, sentinel, payload groups, gather, failing and
+// leaving ranks - and the in-process transport, which shares the partition, the record layout and the sentinel
+// protocol, carries the other 2- and 3-rank tests.
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -74,9 +76,16 @@ RcclApi* rccl() {
   static std::once_flag once;
   static bool ok = false;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (api.lib) break;
+    // PPRHIP_RCCL_LIB names the library to bind instead (a site's own build; tests/fixtures/fake_rccl.cpp, the test
+    // double that lets one GPU run the RCCL branch with several ranks)
+    const char* own = getenv("PPRHIP_RCCL_LIB");
+    if (own && *own) {
+      api.lib = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+      }
     }
     if (!api.lib) return;
     auto sym = [&](const char* n) { return dlsym(api.lib, n); };

@@ -142,6 +142,27 @@ def test_rccl_rank_failure_group_of_one(pkg, rmat12, replicas, monkeypatch):
         c.close()
 
 
+def test_rccl_branch_with_several_ranks_on_a_test_double(tmp_path):
+    """comm.cpp's RCCL branch (size exchange with the error sentinel, payload groups, the top-k gather, failing and
+    leaving ranks) with 2 and 3 ranks on the one GPU of this box: in a child process, the library binds
+    tests/fixtures/fake_rccl.cpp - a test double, NOT RCCL (ranks are threads, a send / receive pair is a device
+    copy) - through PPRHIP_RCCL_LIB.  What it cannot show is the fabric; what it does run is every line of ours
+    around the dozen RCCL calls, which no multi-GPU box has executed yet."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path / "libfake_rccl.so")
+    subprocess.run([hipcc, "-O1", "-std=c++17", "-shared", "-fPIC", "-o", lib,
+                    os.path.join(ROOT, "tests", "fixtures", "fake_rccl.cpp")], check=True, timeout=300)
+    env = dict(os.environ, PPRHIP_RCCL_LIB=lib, PPRHIP_COMM_TIMEOUT_S="60", FAKE_RCCL_TIMEOUT_S="20")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fixtures", "rccl_double_run.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_multi_argument_errors(pkg, rmat12, replicas, got):
     with pytest.raises(pkg.PprhipError):          # the same handle twice
         pkg.fora_batch_multi([replicas[0], replicas[0]], [1, 2], 4, 0.5, A, seed=1)
