@@ -647,7 +647,9 @@ int setup_ranks(pprhip_graph_t* const* per_gpu, int n_gpu, RankSetup& S, const c
   S.comms.assign((size_t)n_gpu, pprhip_comm());
   S.errs.assign((size_t)n_gpu, "");
   S.rcs.assign((size_t)n_gpu, PPRHIP_OK);
-  S.use_rccl = distinct && n_gpu > 1;
+  // (PPRHIP_FORCE_RCCL=1, test switch: the RCCL branch although the handles share a device - only the test double of
+  // tests/fixtures/fake_rccl.cpp accepts that)
+  S.use_rccl = (distinct || getenv("PPRHIP_FORCE_RCCL") != nullptr) && n_gpu > 1;
   S.local.world = n_gpu;
   S.local.send.assign((size_t)n_gpu, nullptr);
   S.local.send_off.assign((size_t)n_gpu, {});

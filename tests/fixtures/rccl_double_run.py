@@ -104,6 +104,28 @@ for world in (2, 3):
     for c in comms:
         c.close()
 
+# ---- the one-process entry points (one host thread per replica, communicators from ncclCommInitAll) on the same branch
+os.environ["PPRHIP_FORCE_RCCL"] = "1"
+for world in (2, 3):
+    ix, sts = pkg.all_pair_backward_multi(graphs[:world], A, 2e-3, 4)
+    off, tg, vl = ix.arrays()
+    assert np.array_equal(off, roff) and np.array_equal(tg, rtg) and np.max(np.abs(vl - rvl)) <= 1e-12
+    assert all(st.select_bytes % 16 == 0 for st in sts)
+    ix.close()
+    srcs = np.random.default_rng(5).integers(0, host.n, size=23).astype(np.int32)
+    ids, vals, nsel, sts = pkg.fora_batch_multi(graphs[:world], srcs, 8, 0.5, A, seed=3)
+    _, ids1, vals1, nsel1, _, _ = graphs[0].fora_batch_single_source(srcs, 0.5, A, seed=3, k=8)
+    assert np.array_equal(ids, ids1) and np.array_equal(nsel, nsel1) and np.max(np.abs(vals - vals1)) <= 1e-9
+    os.environ["PPRHIP_FAULT_RANK"] = "1"
+    os.environ["PPRHIP_FAULT_AT"] = "gather"
+    try:
+        pkg.fora_batch_multi(graphs[:world], srcs, 8, 0.5, A, seed=3)
+        raise AssertionError("the injected fault was not reported")
+    except pkg.PprhipError as e:
+        assert "injected fault on rank 1" in str(e)
+    del os.environ["PPRHIP_FAULT_RANK"], os.environ["PPRHIP_FAULT_AT"]
+del os.environ["PPRHIP_FORCE_RCCL"]
+
 for g in graphs:
     g.close()
 print("ok")
