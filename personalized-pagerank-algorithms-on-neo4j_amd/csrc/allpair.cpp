@@ -30,6 +30,29 @@ struct pprhip_index {
 
 namespace {
 
+// Host threads for the index finalisation: what the process may really use at once - its CPU affinity and, where the
+// cgroup sets one, its CPU quota (the GPU boxes give a one-GPU job 16 of 256 hardware threads; more threads than
+// that are throttled, not added) - at most 64.
+static unsigned finalise_threads() {
+  static const unsigned n = [] {
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    if (const char* e = getenv("PPRHIP_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
+    for (const char* path : {"/sys/fs/cgroup/cpu.max"}) {
+      if (FILE* f = fopen(path, "r")) {
+        char q[32] = {0};
+        double period = 0;
+        if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+          const double cores = atof(q) / period;
+          if (cores >= 1.0) hw = std::min(hw, (unsigned)(cores + 0.5));
+        }
+        fclose(f);
+      }
+    }
+    return std::max(1u, std::min(64u, hw));
+  }();
+  return n;
+}
+
 // Base_Whole_Graph.java:112-163: per source, k < 0 keeps insertion (target) order; k >= 0 keeps
 // entries >= the k-th largest (all when fewer than k) sorted descending (stable: ties stay in
 // target order).
@@ -42,7 +65,7 @@ void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix)
   const size_t N = tr.size();
   std::vector<uint64_t> start((size_t)n + 1, 0);
   std::vector<Triple> by_v(N);
-  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  const unsigned hw = finalise_threads();
   const unsigned T = N < (1u << 16) ? 1u : hw;
   auto parallel = [&](unsigned parts, auto&& fn) {  // fn(part) for part in [0, parts), T threads
     std::atomic<unsigned> next{0};
@@ -552,7 +575,7 @@ int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint
               (uint32_t)(keys[0] >> 32), (uint32_t)(keys[N - 1] >> 32), v_lo, v_hi);
     return PPRHIP_ERR_INVALID;
   }
-  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  const unsigned hw = finalise_threads();
   const unsigned T = N < (1u << 16) ? 1u : hw;
   auto run = [&](auto&& fn) {  // fn(part) for part in [0, T)
     std::vector<std::thread> th;
