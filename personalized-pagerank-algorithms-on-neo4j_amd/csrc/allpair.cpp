@@ -21,11 +21,34 @@ using namespace pprhip::detail;
 // All-Pair-Backward-Search (a9) — first correct path: one backward search per target on the
 // global arrays, entries >= threshold compacted on the device, inverted index built on the host.
 // =================================================================================================
+// vectors whose resize() leaves new elements uninitialised: the index arrays are hundreds of megabytes that the
+// finalisation's threads fill in full (a value-initialising resize is a single-threaded pass over fresh pages)
+template <class T>
+struct NoInitAlloc {
+  using value_type = T;
+  NoInitAlloc() = default;
+  template <class U>
+  NoInitAlloc(const NoInitAlloc<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+  void deallocate(T* p, size_t) { ::operator delete(p); }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;  // default-init: nothing for arithmetic types
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+  template <class U>
+  bool operator==(const NoInitAlloc<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+template <class T>
+using RawVec = std::vector<T, NoInitAlloc<T>>;
+
 struct pprhip_index {
   uint32_t n = 0;
-  std::vector<uint64_t> offsets;
-  std::vector<int32_t> targets;
-  std::vector<double> values;
+  RawVec<uint64_t> offsets;
+  RawVec<int32_t> targets;
+  RawVec<double> values;
 };
 
 namespace {
@@ -168,7 +191,7 @@ void finalize_rows(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index* ix)
       }
     }
   });
-  ix->offsets.swap(kept);
+  ix->offsets.assign(kept.begin(), kept.end());
 }
 
 }  // namespace
@@ -583,8 +606,9 @@ int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint
     fn(0u);
     for (auto& x : th) x.join();
   };
-  // ---- row starts: start[v] = first entry of source v (entries are sorted by source)
-  std::vector<uint64_t> start((size_t)n + 1);
+  // ---- row starts: start[v] = first entry of source v (entries are sorted by source); every element is written
+  RawVec<uint64_t> start;
+  start.resize((size_t)n + 1);
   std::atomic<int> bad{0};
   run([&](unsigned w) {
     const uint64_t lo = N * w / T, hi = N * (w + 1) / T;
@@ -628,13 +652,19 @@ int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint
     return PPRHIP_OK;
   }
   // ---- pass 1: per row the k-th largest value (when the row has k entries) and how many entries it keeps
-  std::vector<uint64_t> kept((size_t)n + 1, 0);
-  std::vector<double> kth((size_t)n, 0.0);
+  RawVec<uint64_t> kept;  // kept[v + 1] is written for every v below, kth[v] for the rows that hold entries
+  kept.resize((size_t)n + 1);
+  kept[0] = 0;
+  RawVec<double> kth;
+  kth.resize((size_t)n);
   run([&](unsigned w) {
     std::vector<double> tmp;
     for (uint32_t v = cut[w]; v < cut[w + 1]; ++v) {
       const uint64_t b = start[v], len = start[v + 1] - b;
-      if (len == 0) continue;
+      if (len == 0) {
+        kept[v + 1] = 0;
+        continue;
+      }
       if (k >= 1 && (uint64_t)k <= len) {
         tmp.assign(vals + b, vals + b + len);
         std::nth_element(tmp.begin(), tmp.begin() + (k - 1), tmp.end(), std::greater<double>());
@@ -679,13 +709,47 @@ int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long 
                       pprhip_index_t** out) {
   unsigned long long* d_keys = nullptr;
   double* d_vals = nullptr;
+  const bool dbg = getenv("PPRHIP_APBS_DEBUG") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   PPRHIP_TRY(sort_triples_device(g, rec, count, &d_keys, &d_vals));
-  std::unique_ptr<uint64_t[]> keys(new (std::nothrow) uint64_t[std::max<unsigned long long>(1, count)]);
-  std::unique_ptr<double[]> vals(new (std::nothrow) double[std::max<unsigned long long>(1, count)]);
-  int rc = (keys && vals) ? PPRHIP_OK : PPRHIP_ERR_OOM;
+  if (dbg) {
+    (void)hipStreamSynchronize(g->stream);
+    fprintf(stderr, "[index] sorted on the device at %.1f ms\n", ms());
+  }
+  // The sorted entries cross PCIe into pinned memory that stays with the handle (pprhip_graph_release hands it back):
+  // into pageable memory the copy ran at 9-11 GB/s (46-60 ms for R-MAT 22's 32 M entries).
+  const size_t need = 16 * (size_t)std::max<unsigned long long>(1, count);
+  int rc = PPRHIP_OK;
+  if (g->ix_stage_bytes < need) {
+    if (g->ix_stage) (void)hipHostFree(g->ix_stage);
+    g->ix_stage = nullptr;
+    g->ix_stage_bytes = 0;
+    const size_t want = need + need / 4;
+    if (hipHostMalloc(&g->ix_stage, want, hipHostMallocDefault) == hipSuccess) {
+      g->ix_stage_bytes = want;
+    } else {
+      (void)hipGetLastError();
+      g->ix_stage = nullptr;
+    }
+  }
+  std::unique_ptr<uint64_t[]> own_keys;  // pageable fall-back when the host cannot pin that much
+  std::unique_ptr<double[]> own_vals;
+  uint64_t* keys = nullptr;
+  double* vals = nullptr;
+  if (g->ix_stage) {
+    keys = static_cast<uint64_t*>(g->ix_stage);
+    vals = reinterpret_cast<double*>(static_cast<char*>(g->ix_stage) + 8 * (size_t)std::max<unsigned long long>(1, count));
+  } else {
+    own_keys.reset(new (std::nothrow) uint64_t[std::max<unsigned long long>(1, count)]);
+    own_vals.reset(new (std::nothrow) double[std::max<unsigned long long>(1, count)]);
+    keys = own_keys.get();
+    vals = own_vals.get();
+    if (!keys || !vals) rc = PPRHIP_ERR_OOM;
+  }
   if (rc == PPRHIP_OK && count &&
-      (hipMemcpyAsync(keys.get(), d_keys, 8 * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-       hipMemcpyAsync(vals.get(), d_vals, 8 * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+      (hipMemcpyAsync(keys, d_keys, 8 * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+       hipMemcpyAsync(vals, d_vals, 8 * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
        hipStreamSynchronize(g->stream) != hipSuccess)) {
     set_error("index: download of the sorted entries failed");
     rc = PPRHIP_ERR_HIP;
@@ -693,7 +757,10 @@ int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long 
   if (d_keys) (void)hipFree(d_keys);
   if (d_vals) (void)hipFree(d_vals);
   if (rc != PPRHIP_OK) return rc;
-  return index_from_sorted(g->n, keys.get(), vals.get(), count, k, v_lo, v_hi, out);
+  if (dbg) fprintf(stderr, "[index] on the host at %.1f ms\n", ms());
+  rc = index_from_sorted(g->n, keys, vals, count, k, v_lo, v_hi, out);
+  if (dbg) fprintf(stderr, "[index] k rule applied at %.1f ms\n", ms());
+  return rc;
 }
 
 // index over all n sources from entries of any targets, rows outside [v_lo, v_hi) must not occur

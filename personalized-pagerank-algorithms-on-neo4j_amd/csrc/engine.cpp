@@ -1532,6 +1532,9 @@ static void free_all_pair(pprhip_graph* g) {
     *p = nullptr;
   }
   g->apbs_blocks = 0;  // (all_pair_collect sizes and allocates the workspaces when it finds none)
+  if (g->ix_stage) (void)hipHostFree(g->ix_stage);
+  g->ix_stage = nullptr;
+  g->ix_stage_bytes = 0;
 }
 
 int pprhip_graph_release(pprhip_graph_t* g, unsigned what) {
@@ -1556,14 +1559,7 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
                   g->nz_rows_o, g->z_rows_o, g->cross_bits_o};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (g->apbs_ws) (void)hipFree(g->apbs_ws);
-  g->apbs_ws = nullptr;
-  if (g->apbs_board) (void)hipFree(g->apbs_board);
-  g->apbs_board = nullptr;
-  if (g->apbs_xl_ws) (void)hipFree(g->apbs_xl_ws);
-  g->apbs_xl_ws = nullptr;
-  if (g->in_rec) (void)hipFree(g->in_rec);
-  g->in_rec = nullptr;
+  free_all_pair(g);
   if (g->sl) {
     void* sp[] = {g->sl->ci, g->sl->flags, g->sl->chunk_starts, g->sl->seg_row};
     for (void* p : sp)

@@ -291,6 +291,8 @@ struct pprhip_graph {
   void* in_rec = nullptr;
   char* apbs_ws = nullptr;
   void* apbs_board = nullptr;
+  void* ix_stage = nullptr;  // pinned host memory the sorted index entries are downloaded into (index_from_device)
+  size_t ix_stage_bytes = 0;
   char* apbs_xl_ws = nullptr;  // a few workspaces whose lists hold every node, for the searches that outgrow the others
   uint32_t apbs_xl_blocks = 0, apbs_xl_cap_t = 0, apbs_xl_cap_f = 0;
   uint32_t apbs_blocks = 0, apbs_cap_t = 0, apbs_cap_f = 0, apbs_chunk = 0;
