@@ -363,14 +363,8 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   };
   auto t_phase = now();
   std::vector<int32_t> to_tier2, to_tier3;
-  if (first_tier <= 1) {
-    rc = run_tier(false, {}, true, to_tier2);
-    if (dbg_times) fprintf(stderr, "[apbs host] tier 1 (kernel passes + hand-over of entries): %.1f ms\n", ms_since(t_phase));
-    t_phase = now();
-  } else {
-    for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
-  }
-  if (rc == PPRHIP_OK && !to_tier2.empty()) {
+  // the dense tier for a list of targets (workspaces on first use); what outgrows its lists is appended to to_tier3
+  auto dense_pass = [&](std::vector<int32_t>& list) {
     // Dense workspaces, one per workgroup in flight (kernels_apbs.hip): 16n bytes of vectors + lists.  The lists hold
     // what a search may list before it is handed to tier 3: nodes whose residue left zero (clean-up; on overflow the
     // whole vector is cleared instead) and a level's frontier.  The workspaces stay with the handle: allocating and
@@ -427,7 +421,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       {
         const std::vector<uint32_t>& irp = g->h_in_rp;
         const std::vector<int32_t>& o2n = g->h_old2new;
-        std::stable_sort(to_tier2.begin(), to_tier2.end(), [&](int32_t x, int32_t y) {
+        std::stable_sort(list.begin(), list.end(), [&](int32_t x, int32_t y) {
           const int32_t a = o2n[x], b = o2n[y];
           return irp[a + 1] - irp[a] > irp[b + 1] - irp[b];
         });
@@ -459,7 +453,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
           _exit(3);
         });
       }
-      rc = run_tier(true, to_tier2, false, to_tier3);
+      rc = run_tier(true, list, false, to_tier3);
       if (watchdog.joinable()) {
         {
           std::lock_guard<std::mutex> lk(wd_mu);
@@ -489,8 +483,19 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
         B.dbg = nullptr;
       }
     } else if (rc == PPRHIP_OK) {
-      to_tier3 = to_tier2;  // no memory for the dense tier: everything runs on the batch slots
+      to_tier3.insert(to_tier3.end(), list.begin(), list.end());  // no memory for the dense tier: everything runs on the batch slots
     }
+  };
+  bool piped = false;  // tier 2 has already run, chunk by chunk, beside tier 1 (below)
+  if (first_tier <= 1) {
+    rc = run_tier(false, {}, true, to_tier2);
+    if (dbg_times) fprintf(stderr, "[apbs host] tier 1 (kernel passes + hand-over of entries): %.1f ms\n", ms_since(t_phase));
+    t_phase = now();
+  } else {
+    for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
+  }
+  if (rc == PPRHIP_OK && !to_tier2.empty()) {
+    if (!piped) dense_pass(to_tier2);
     // ---- the searches whose frontier or popped-node list outgrew the workspaces' lists: once more with a few
     // workspaces whose lists hold every node, all the other workgroups helping with their levels
     if (rc == PPRHIP_OK && g->apbs_blocks && !to_tier3.empty() && to_tier3.size() < to_tier2.size() &&
