@@ -1535,6 +1535,9 @@ static void free_all_pair(pprhip_graph* g) {
   if (g->ix_stage) (void)hipHostFree(g->ix_stage);
   g->ix_stage = nullptr;
   g->ix_stage_bytes = 0;
+  if (g->apbs_side_stream) (void)hipStreamDestroy(g->apbs_side_stream);
+  g->apbs_side_stream = nullptr;
+  g->apbs_side_tried = false;
 }
 
 int pprhip_graph_release(pprhip_graph_t* g, unsigned what) {

@@ -291,6 +291,8 @@ struct pprhip_graph {
   void* in_rec = nullptr;
   char* apbs_ws = nullptr;
   void* apbs_board = nullptr;
+  hipStream_t apbs_side_stream = nullptr;  // All-Pair: tier 1 of the next part of a large range runs here beside tier 2
+  bool apbs_side_tried = false;
   void* ix_stage = nullptr;  // pinned host memory the sorted index entries are downloaded into (index_from_device)
   size_t ix_stage_bytes = 0;
   char* apbs_xl_ws = nullptr;  // a few workspaces whose lists hold every node, for the searches that outgrow the others

@@ -150,6 +150,21 @@ def test_backward_push_and_all_pair_sample(orc, rmat20, dev20):
     assert np.array_equal(off2, ooff) and np.array_equal(tg2, otg) and np.max(np.abs(vl2 - ovl)) <= 1e-12
 
 
+def test_all_pair_in_parts_equals_in_sequence(pkg, rmat20, monkeypatch):
+    """Ranges of 2^20 targets and more run tier 1 of the next part on a side stream beside the dense tier of the part
+    before (allpair.cpp); the index must be the one the tiers give one after the other."""
+    with pkg.Graph(rmat20) as g:
+        ix, st = g.all_pair_backward(A, 1e-3, 16)          # n = 2^20 targets: in parts
+        a = [x.copy() for x in ix.arrays()]
+        ix.close()
+        monkeypatch.setenv("PPRHIP_APBS_NO_PIPE", "1")
+        ix, st1 = g.all_pair_backward(A, 1e-3, 16)
+        b = ix.arrays()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.max(np.abs(a[2] - b[2])) <= 1e-12
+        assert st.pops == st1.pops and st.rounds == st1.rounds and len(a[1]) > rmat20.n
+        ix.close()
+
+
 def test_sampled_walks_match_oracle(orc, rmat20, dev20):
     og = to_oracle(orc, rmat20)
     rng = np.random.default_rng(8)
