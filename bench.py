@@ -21,7 +21,8 @@ N > 1 (one process per GPU, launched by torch.distributed.run): the CSR is repli
 batch per step (weak scaling, no data-path collective) and the per-step top-k blocks are gathered on rank 0 by the
 library's own entry point (pprhip_comm_create + pprhip_topk_gather: grouped ncclSend / ncclRecv inside libpprhip.so,
 the exchange Gen_Util.java:208-232's loop needs when it is sharded); torch.distributed only carries the barrier and
-the max-over-ranks of the clock.  `all_pair_scaling` reports the path's other workload, All-Pair-Backward-Search over
+the max-over-ranks of the clock.  The library's gather is probed once before the warm-up; should it fail on any
+rank, all ranks agree to gather with torch.distributed instead and the line's `config.sharding` says why.  `all_pair_scaling` reports the path's other workload, All-Pair-Backward-Search over
 all n targets, at the same N (strong scaling; the exchange by owner of the source runs inside the library over RCCL;
 every rank's share runs in a watched child process, so a collective that hangs or faults costs that sample, not the
 line).
@@ -36,9 +37,10 @@ Extra objects on the JSON line:
               traffic: <= 1 by construction; traffic / compulsory = how often bytes are re-moved); `frac_model`:
               SURVEY 8(d)'s per-query gather model (counts gathers L2 / LDS serve; can exceed 1; kept for comparison
               with rounds 1-2).  Without counters (`--no-pmc`) `frac` falls back to the compulsory figure.
-  `cpu_baseline`  the reference's algorithm on the host cores (rank 0, N = 1), run in a background process while the
-              GPU measurements go on: the hash-map-shaped faithful port run to the end of one query on one thread,
-              the dense-array port on three sources, and the array port on every hardware thread at once.
+  `cpu_baseline`  the reference's algorithm on the host cores (rank 0, N = 1), in a background process: while the GPU
+              measurements go on, the hash-map-shaped faithful port run to the end of one query on one thread and the
+              dense-array port on three sources; after them, the array port on every core this job may use (its cgroup
+              CPU quota), one query per core.
 After the timed region, at N = 1: `one_query_at_a_time` (the drop-in path, pprhip_fora_single_source), `topk_sample`
 (FORA top-32), `all_pair_sample` (All-Pair-Backward-Search on 2^18 targets) and `all_pair_rmat24` (config #5's graph
 on one GPU, in a child process), each with its own `roofline` incl. counter traffic.
