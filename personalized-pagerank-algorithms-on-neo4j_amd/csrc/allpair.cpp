@@ -641,7 +641,21 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
         B.cap_f = g->apbs_xl_cap_f;
         B.helpers = g->apbs_blocks;
         std::vector<int32_t> again3;
+        const bool xdebug = getenv("PPRHIP_APBS_DEBUG") != nullptr;
+        const uint32_t xnb = std::max(g->apbs_blocks, g->apbs_xl_blocks);
+        if (xdebug && hipHostMalloc((void**)&B.dbg, sizeof(unsigned long long) * 12 * xnb, hipHostMallocMapped) == hipSuccess)
+          std::memset(B.dbg, 0, sizeof(unsigned long long) * 12 * xnb);
         rc = run_tier(true, to_tier3, false, again3);
+        if (B.dbg) {
+          unsigned long long tot[8] = {0};
+          for (uint32_t w = 0; w < xnb; ++w)
+            for (int i = 0; i < 8; ++i) tot[i] += B.dbg[12 * w + i];
+          fprintf(stderr, "[apbs dense, full-size pass] searches %llu edges %llu; workgroup-ms in pops+scans %.1f own chunks %.1f "
+                          "waiting for helpers %.1f emit %.1f clear %.1f helping / idle %.1f\n",
+                  tot[0], tot[1], tot[2] / 1e5, tot[3] / 1e5, tot[4] / 1e5, tot[5] / 1e5, tot[6] / 1e5, tot[7] / 1e5);
+          (void)hipHostFree(B.dbg);
+          B.dbg = nullptr;
+        }
         if (dbg_times) fprintf(stderr, "[apbs host] full-size workspaces: %zu targets, %zu left for tier 3\n", to_tier3.size(), again3.size());
         to_tier3.swap(again3);
       }
