@@ -77,7 +77,7 @@ def load_host(pkg, scale):
     """The R-MAT host CSR (generator seed 1); cached in /tmp so that the child processes of one run (counter passes,
     All-Pair children, CPU baseline) do not generate it again."""
     path = "/tmp/pprhip_rmat%d_seed1.npz" % scale
-    if scale <= 22 and os.path.exists(path):
+    if os.path.exists(path):
         try:
             z = np.load(path)
             h = pkg.HostCsr.__new__(pkg.HostCsr)
@@ -88,7 +88,7 @@ def load_host(pkg, scale):
         except Exception:
             pass
     h = pkg.HostCsr.rmat(scale, 16, seed=1)
-    if scale <= 22:
+    if scale <= 24:  # (scale 24: 2.3 GB, read again by the counter passes over config #5's graph)
         try:
             tmp = path + ".%d.tmp.npz" % os.getpid()
             np.savez(tmp, n=h.n, m=h.m, out_rp=h.out_rp, out_ci=h.out_ci, in_rp=h.in_rp, in_ci=h.in_ci)
@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--all-pair-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rmat24-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rmat24-pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sources", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-walk-divisor", type=int, default=32)
@@ -152,6 +153,8 @@ def main():
         return all_pair_child(args)
     if args.rmat24_child:
         return rmat24_child(args)
+    if args.rmat24_pmc_child:
+        return rmat24_pmc_child(args)
     if args.cpu_baseline_child:
         return cpu_baseline_child(args)
     if args.pmc_child:
@@ -241,8 +244,9 @@ def main():
             flag = torch.tensor([failed], dtype=torch.int32, device=xdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()):
-                if comm is not None:
+                if comm is not None:  # the communicator may be broken: leave the group (abort), never a collective destroy
                     try:
+                        comm.abort()
                         comm.close()
                     except Exception:  # noqa: BLE001
                         pass
@@ -430,6 +434,9 @@ def main():
         if solo and not args.no_pmc:
             apply_counters(out, pmc_traffic(args, host), avg_us, extras)
             note("counter passes done")
+            if r24_child is not None and "error" not in out["all_pair_rmat24"]:
+                rmat24_counters(out["all_pair_rmat24"], out["roofline"].get("fetch_size_calibration"))
+                note("R-MAT 24 counter passes done")
         if cpu_child is not None:
             note("waiting for the CPU baseline child")
             out["cpu_baseline"] = finish_cpu_baseline(cpu_child)
@@ -554,6 +561,85 @@ def topk_sample(pkg, g, srcs, count=None, single=32):
                                       if st.class_launches[c]}}}
 
 
+def index_column_check(off, tg, vl, targets, column_of, thr, k, tol=1e-12, slack=0.0, tie=1e-9, source_range=None):
+    """Columns of an All-Pair index against backward searches of the same targets (Base_Whole_Graph.java:76-92 and the
+    k rule of :112-163).  off / tg / vl: the index (CSR by source, rows value-descending); column_of(t) -> the dense
+    reserve vector of a backward search from t at rmax = thr.  For every sampled target t:
+      (1) every index entry (v, t, pi) is an entry of the search: |pi - column[v]| <= tol + slack, column[v] >= thr
+          (less `tie` and slack), and no (v, t) pair occurs twice;
+      (2) every entry the search yields with column[v] >= thr + tie + slack is in row v - unless the k rule cut it:
+          row v then holds >= k entries, all of them >= that value (less tol + slack).
+    slack = 0: the reference search runs the engine's schedule (values differ by summation order only);
+    slack = thr: another push order (FIFO) - both reserves lie in [pi - thr, pi] (Backward_Search.java:89 leaves every
+    residue <= thr).  source_range = (lo, hi): the index holds the rows of these sources only (one rank's share of a
+    sharded run).  Returns counters; raises AssertionError with the first failures."""
+    n = off.size - 1
+    targets = np.unique(np.asarray(targets, dtype=np.int64))
+    sel = np.zeros(n, dtype=bool)
+    sel[targets] = True
+    pos = np.nonzero(sel[tg])[0]
+    rows = np.searchsorted(off, pos, side="right") - 1
+    ptg = tg[pos].astype(np.int64)
+    order = np.argsort(ptg, kind="stable")
+    pos, rows, ptg = pos[order], rows[order], ptg[order]
+    lo = np.searchsorted(ptg, targets, side="left")
+    hi = np.searchsorted(ptg, targets, side="right")
+    stats = {"targets": int(targets.size), "entries_checked": 0, "entries_cut_by_k_rule": 0, "max_abs_diff": 0.0}
+    bad = []
+    for j, t in enumerate(targets.tolist()):
+        col = column_of(t)
+        v_idx = rows[lo[j]:hi[j]]
+        p_idx = vl[pos[lo[j]:hi[j]]]
+        if np.unique(v_idx).size != v_idx.size:
+            bad.append("target %d: a (source, target) pair occurs twice" % t)
+        d = np.abs(p_idx - col[v_idx])
+        if d.size:
+            stats["max_abs_diff"] = max(stats["max_abs_diff"], float(d.max()))
+        w = np.nonzero((d > tol + slack) | (col[v_idx] < thr - tie - slack))[0]
+        for i in w[:3]:
+            bad.append("target %d: index entry (source %d, %.17g) against the search's %.17g" % (t, v_idx[i], p_idx[i], col[v_idx[i]]))
+        want = np.nonzero(col >= thr + tie + slack)[0]
+        if source_range is not None:
+            want = want[(want >= source_range[0]) & (want < source_range[1])]
+        missing = np.setdiff1d(want, v_idx, assume_unique=False)
+        if missing.size:
+            cut = np.zeros(missing.size, dtype=bool)
+            if k >= 1:  # (k < 1 keeps every entry: nothing may be missing)
+                full = (off[missing + 1] - off[missing]).astype(np.int64) >= k
+                if full.any():  # rows are value-descending: the last entry is the row's smallest
+                    row_min = vl[(off[missing[full] + 1] - 1).astype(np.int64)]
+                    cut[full] = row_min >= col[missing[full]] - tol - slack
+            for v in missing[~cut][:3]:
+                bad.append("target %d: entry (source %d, %.17g) of the search is not in the index and the k rule does not "
+                           "explain it" % (t, v, col[v]))
+            stats["entries_cut_by_k_rule"] += int(cut.sum())
+        stats["entries_checked"] += int(v_idx.size)
+        if len(bad) > 20:
+            break
+    if bad:
+        raise AssertionError("All-Pair index disagrees with the backward searches of its targets:\n  " + "\n  ".join(bad[:20]))
+    return stats
+
+
+def all_pair_self_check(g, host, off, tg, vl, t_lo, t_hi, count=64, seed=5, source_range=None):
+    """`count` columns of an index the bench has just built, against the engine's OWN single-target backward search
+    (pprhip_backward_push: whole-vector levels in kernels_push.hip, not the All-Pair kernels; itself held to the
+    oracle by tests/): the targets with the most in-edges of the range (shared levels, the full-size pass), the
+    rest drawn at random.  A sample whose columns disagree raises: the caller prints the error, not a rate."""
+    ind = np.diff(host.in_rp)[t_lo:t_hi]
+    rng = np.random.default_rng(seed)
+    hubs = (np.argsort(-ind.astype(np.int64), kind="stable")[:max(4, count // 8)] + t_lo).tolist()
+    rest = (rng.integers(t_lo, t_hi, size=count - len(hubs))).tolist()
+
+    def column_of(t):
+        p, _, _ = g.backward_push(int(t), ALPHA, AP_THR)
+        return p
+
+    st = index_column_check(off, tg, vl, hubs + rest, column_of, AP_THR, TOPK, source_range=source_range)
+    st.update(status="ok", against="pprhip_backward_push, 1e-12", hub_targets=len(hubs))
+    return st
+
+
 def all_pair_sample(pkg, g, host, nt=1 << 18):
     """The path's other workload, All-Pair-Backward-Search (config #5), on a bounded target range of the same
     graph (outside the timed region): 2^18 targets, threshold 1e-3, k = 32, index finalised on the host.  Roofline
@@ -566,10 +652,17 @@ def all_pair_sample(pkg, g, host, nt=1 << 18):
     t0 = time.perf_counter()
     ix, st = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, nt)
     dt = time.perf_counter() - t0
-    entries = int(len(ix.arrays()[1]))
+    off, tg, vl = ix.arrays()
     ix.close()
+    try:
+        check = all_pair_self_check(g, host, off, tg, vl, 0, nt)
+    except AssertionError as e:  # a wrong index prints its error, not a rate
+        g.set_tuning(pkg.tuning_batch())
+        return {"error": "self-check failed: %s" % str(e)[:600]}
     g.set_tuning(pkg.tuning_batch())
-    return all_pair_report(pkg, st, nt, dt, entries)
+    res = all_pair_report(pkg, st, nt, dt, int(len(tg)))
+    res["self_check"] = check
+    return res
 
 
 def all_pair_report(pkg, st, nt, dt, entries):
@@ -653,9 +746,9 @@ def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xde
     res = _child_json(child, limit, "rank %d's All-Pair child" % rank)
     err = res.get("error")
     # t_all, search seconds, entries found, bytes received, entries kept; a failed rank poisons the sample
-    vals = [res["seconds"], res["search_seconds"], res["entries_found"], res["bytes_received"], res["entries_kept"]] \
-        if not err else [0.0] * 5
-    stats = torch.tensor(vals + [1.0 if err else 0.0], dtype=torch.float64, device=xdev)
+    vals = [res["seconds"], res["search_seconds"], res["entries_found"], res["bytes_received"], res["entries_kept"],
+            res["columns_checked"], res["entries_checked"]] if not err else [0.0] * 7
+    stats = torch.tensor(vals[:5] + [1.0 if err else 0.0] + vals[5:], dtype=torch.float64, device=xdev)
     tmax = stats.clone()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -668,6 +761,8 @@ def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xde
             "search_seconds_max_rank": round(float(tmax[1]), 3),
             "entries_found": int(stats[2]), "entries_kept_after_k_rule": int(stats[4]),
             "exchange_bytes_received": int(stats[3]),
+            "self_check": {"status": "ok", "against": "pprhip_backward_push, 1e-12, on every rank's own rows",
+                           "targets": int(stats[6]), "entries_checked": int(stats[7])},
             "exchange": "owner-of-source, 16-byte records partitioned on the device, grouped ncclSend/ncclRecv inside "
                         "libpprhip.so (pprhip_all_pair_backward_sharded); one child process per rank"}
 
@@ -688,10 +783,14 @@ def all_pair_child(args):
             t0 = time.perf_counter()
             own, st = _quiet_stdout(lambda: comm.all_pair_backward_sharded(ALPHA, AP_THR, TOPK))
             t_all = time.perf_counter() - t0
-            res = {"seconds": t_all, "search_seconds": st.total_ms / 1e3, "entries_found": float(st.mc_sources),
-                   "bytes_received": float(st.select_bytes), "entries_kept": float(len(own.arrays()[1]))}
+            off, tg, vl = own.arrays()
             own.close()
             comm.close()
+            # this rank's rows (sources [lo, hi), targets of every rank) against single-target searches
+            check = all_pair_self_check(g, host, off, tg, vl, 0, host.n, count=64, seed=5 + rank, source_range=(lo, hi))
+            res = {"seconds": t_all, "search_seconds": st.total_ms / 1e3, "entries_found": float(st.mc_sources),
+                   "bytes_received": float(st.select_bytes), "entries_kept": float(len(tg)),
+                   "columns_checked": float(check["targets"]), "entries_checked": float(check["entries_checked"])}
     except Exception as e:  # noqa: BLE001
         res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     print(json.dumps(res), flush=True)
@@ -719,7 +818,7 @@ def rmat24_child(args):
     try:
         pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
         t0 = time.time()
-        host = pkg.HostCsr.rmat(24, 16, seed=1)
+        host = load_host(pkg, 24)
         t_gen = time.time() - t0
         sys.stdin.readline()  # the parent's GPU measurements are over
         import torch  # noqa: F401
@@ -732,15 +831,93 @@ def rmat24_child(args):
             t0 = time.perf_counter()
             ix, st = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, nt)
             dt = time.perf_counter() - t0
-            entries = int(len(ix.arrays()[1]))
+            off, tg, vl = ix.arrays()
             ix.close()
-            res = all_pair_report(pkg, st, nt, dt, entries)
+            check = all_pair_self_check(g, host, off, tg, vl, 0, nt)  # raises: the line then carries the error
+            res = all_pair_report(pkg, st, nt, dt, int(len(tg)))
+            res["self_check"] = check
             res["workload"] = "RMAT scale-24 (n=%d, m=%d, seed 1), All-Pair-Backward-Search on the first %d targets, " \
                               "threshold %g, k = %d, one GPU" % (host.n, host.m, nt, AP_THR, TOPK)
             res["graph_lift_s"] = {"generate_and_csr": round(t_gen, 1), "upload_and_tile": round(t_lift, 1)}
     except Exception as e:  # noqa: BLE001
         res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     print(json.dumps(res), flush=True)
+
+
+R24_PMC_TARGETS = 1 << 20
+
+
+def rmat24_pmc_child(args):
+    """What the counter passes over config #5's graph profile: the graph lifted, a marker, All-Pair on the first 2^20
+    targets, a marker."""
+    import torch  # noqa: F401
+    pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
+    host = load_host(pkg, 24)
+    with pkg.Graph(host, device=0) as g:
+        ix, _ = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, 4096)  # first-use work (workspaces, in-edge records)
+        ix.close()
+        g.random_walks(np.array([0], dtype=np.int32), np.array([0], dtype=np.uint64), ALPHA, seed=1)  # marker
+        ix, st = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, R24_PMC_TARGETS)
+        ix.close()
+        g.random_walks(np.array([0], dtype=np.int32), np.array([0], dtype=np.uint64), ALPHA, seed=1)
+        print(json.dumps({"pops": int(st.pops), "edge_pushes": int(st.edge_pushes), "push_bytes": int(st.push_bytes)}),
+              flush=True)
+
+
+def rmat24_counters(res, calibration):
+    """Counter traffic of All-Pair's kernels on config #5's graph: two time-limited `rocprofv3 --pmc` passes (FETCH_SIZE,
+    WRITE_SIZE) over rmat24_pmc_child, the first 2^20 targets, per algorithmic byte of the same targets, applied to
+    the sample's algorithmic bytes.  calibration: FETCH_SIZE bytes per byte read, as measured by the main counter passes
+    of this run on k_sum_partial (0.5 on gfx950: 128-byte requests tallied at 64)."""
+    ro = res["roofline"]
+    if shutil.which("rocprofv3") is None:
+        ro["traffic_note"] = "unmeasured: rocprofv3 not on PATH"
+        return
+    work = tempfile.mkdtemp(prefix="pprhip_pmc24_", dir="/tmp")
+    limit = float(os.environ.get("PPRHIP_BENCH_RMAT24_PMC_S", "240"))
+    rows, child_out = {}, None
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--rmat24-pmc-child"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=limit)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError("rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-200:]))
+            lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            child_out = json.loads(lines[-1]) if lines else child_out
+            byid = {}
+            for row in csv.DictReader(open(files[0])):
+                byid.setdefault(int(row["Dispatch_Id"]), (_short(row["Kernel_Name"]), {}))[1][row["Counter_Name"]] = \
+                    float(row["Counter_Value"])
+            rows[counter] = _phases([byid[k] for k in sorted(byid)])
+    except Exception as e:  # noqa: BLE001  (the sample stays valid without counters)
+        ro["traffic_note"] = "unmeasured: %s" % str(e)[:200]
+        shutil.rmtree(work, ignore_errors=True)
+        return
+    shutil.rmtree(work, ignore_errors=True)
+    fetch, write = rows["FETCH_SIZE"], rows["WRITE_SIZE"]
+    if len(fetch) < 3 or len(write) < 3 or not child_out:
+        ro["traffic_note"] = "unmeasured: the counter rows do not hold the expected phase markers"
+        return
+    factor = 1.0 / calibration if calibration and 0.4 < calibration < 1.1 else 2.0
+    ap = lambda k: k.startswith("k_apbs")  # noqa: E731
+    kb = lambda ph, c: sum(v.get(c, 0.0) for name, v in ph if ap(name))  # noqa: E731
+    dense = lambda ph, c: sum(v.get(c, 0.0) for name, v in ph if name == "k_apbs_dense")  # noqa: E731
+    tr = kb(fetch[1], "FETCH_SIZE") * 1024.0 * factor + kb(write[1], "WRITE_SIZE") * 1024.0
+    tr_dense = dense(fetch[1], "FETCH_SIZE") * 1024.0 * factor + dense(write[1], "WRITE_SIZE") * 1024.0
+    per_alg = tr / max(1, child_out["push_bytes"])
+    total = per_alg * ro["algorithmic_bytes"]
+    ach = total / 1e9 / (ro["kernel_ms"] / 1e3) if ro["kernel_ms"] > 0 else 0.0
+    ro.update(traffic=int(total),
+              traffic_note="memory-side counters (FETCH_SIZE x %.2f + WRITE_SIZE) of k_apbs_* on the first 2^20 targets of "
+                           "this graph in two rocprofv3 --pmc child passes: %.3g bytes for %.3g algorithmic bytes, applied "
+                           "to this sample's algorithmic bytes" % (factor, tr, child_out["push_bytes"]),
+              achieved_counter=round(ach, 1), frac_counter=round(ach / HBM_PEAK_GBS, 4),
+              traffic_over_algorithmic=round(per_alg, 2),
+              dense_tier_share_of_traffic=round(tr_dense / max(1.0, tr), 3))
 
 
 # ---------------------------------------------------------------------------------------------- HBM counters

@@ -58,7 +58,7 @@ typedef struct pprhip_stats {
   uint32_t levels;         /* frontier levels run (sparse + dense) */
   uint32_t dense_levels;   /* levels run as dense pull sweeps */
   uint32_t rounds;         /* FORA: threshold rounds run (1 + halvings); top-k: delta rounds */
-  uint32_t reserved0;
+  uint32_t xl_targets;     /* All-Pair: searches that outgrew a workspace's lists and ran in the full-size pass */
   uint64_t mc_sources;     /* residue entries that started walks */
   uint64_t walks;          /* random walks run */
   uint64_t walk_steps;     /* edges followed by all walks (dead-end restarts included) */

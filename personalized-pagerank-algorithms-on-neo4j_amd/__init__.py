@@ -31,7 +31,7 @@ class PprhipError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("pops", C.c_uint64), ("edge_pushes", C.c_uint64), ("enqueues", C.c_uint64),
                 ("dead_end_pops", C.c_uint64), ("dense_nodes", C.c_uint64), ("levels", C.c_uint32),
-                ("dense_levels", C.c_uint32), ("rounds", C.c_uint32), ("reserved0", C.c_uint32),
+                ("dense_levels", C.c_uint32), ("rounds", C.c_uint32), ("xl_targets", C.c_uint32),
                 ("mc_sources", C.c_uint64), ("walks", C.c_uint64), ("walk_steps", C.c_uint64),
                 ("select_passes", C.c_uint64), ("rsum", C.c_double), ("rmax_final", C.c_double),
                 ("omega", C.c_double), ("kth_value", C.c_double), ("push_ms", C.c_double), ("mc_ms", C.c_double),

@@ -645,6 +645,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
         const uint32_t xnb = std::max(g->apbs_blocks, g->apbs_xl_blocks);
         if (xdebug && hipHostMalloc((void**)&B.dbg, sizeof(unsigned long long) * 12 * xnb, hipHostMallocMapped) == hipSuccess)
           std::memset(B.dbg, 0, sizeof(unsigned long long) * 12 * xnb);
+        st.xl_targets = (uint32_t)to_tier3.size();
         rc = run_tier(true, to_tier3, false, again3);
         if (B.dbg) {
           unsigned long long tot[8] = {0};
@@ -724,9 +725,8 @@ int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint
   std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
   if (!ix) return PPRHIP_ERR_OOM;
   ix->n = n;
-  if (N && ((uint32_t)(keys[0] >> 32) < v_lo || (uint32_t)(keys[N - 1] >> 32) >= v_hi)) {
-    set_error("index entries of sources %u .. %u outside the range [%u, %u) they were collected for",
-              (uint32_t)(keys[0] >> 32), (uint32_t)(keys[N - 1] >> 32), v_lo, v_hi);
+  if (v_lo > v_hi || v_hi > n) {
+    set_error("index: source range [%u, %u) outside [0, %u)", v_lo, v_hi, n);
     return PPRHIP_ERR_INVALID;
   }
   const unsigned hw = finalise_threads();
@@ -737,7 +737,10 @@ int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint
     fn(0u);
     for (auto& x : th) x.join();
   };
-  // ---- row starts: start[v] = first entry of source v (entries are sorted by source); every element is written
+  // ---- row starts: start[v] = first entry of source v; every element is written.  The entries come from a device
+  // sort over the significant bits only (kernels_sort.hip), possibly of records received from another rank: an id
+  // outside its range sorts by its low bits into the MIDDLE of the array, so every entry is checked - source inside
+  // [v_lo, v_hi), target inside [0, n), sources non-decreasing - BEFORE anything is indexed with it.
   RawVec<uint64_t> start;
   start.resize((size_t)n + 1);
   std::atomic<int> bad{0};
@@ -748,7 +751,10 @@ int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint
     if (lo == 0) start[0] = 0;
     for (uint64_t i = lo; i < hi; ++i) {
       const uint32_t v = (uint32_t)(keys[i] >> 32);
-      if ((uint32_t)keys[i] >= n) bad.store(1);
+      if (v < v_lo || v >= v_hi || (uint32_t)keys[i] >= n || v < prev) {  // (v < prev also catches a bad keys[lo - 1])
+        bad.store(v < prev ? 2 : 1);
+        return;
+      }
       if (v != prev || (i == 0)) {
         for (uint32_t x = (i == 0 ? 0u : prev + 1); x <= v; ++x) start[x] = i;
         prev = v;
@@ -760,7 +766,9 @@ int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint
     }
   });
   if (bad.load()) {
-    set_error("index entry with a target outside [0, %u)", n);
+    set_error(bad.load() == 2 ? "index entries are not in source order (an id outside [0, %u) among them?)"
+                              : "index entry with a source outside [%u, %u) or a target outside [0, %u)",
+              bad.load() == 2 ? n : v_lo, v_hi, n);
     return PPRHIP_ERR_INVALID;
   }
   // ranges of sources with equal shares of the entries

@@ -20,11 +20,20 @@
 //
 // Failure protocol (both transports): an exchange is a collective, so a rank that fails before it still takes part -
 // it posts an error sentinel in the size words it sends, every peer sees it, nobody sends a payload and every rank
-// returns an error (the failing rank its own).  Nothing on this path waits without a bound: RCCL work is awaited by
-// polling the stream with a time limit (PPRHIP_COMM_TIMEOUT_S, default 1800) and the communicator's asynchronous
-// error state; on either the communicator is aborted (ncclCommAbort), which releases the peers' kernels as well.
-// One-process communicators are created with ncclCommInitAll from the calling thread (no rendezvous between
-// threads that one failing rank could leave the others in).
+// returns an error (the failing rank its own).  Exceptions (std::bad_alloc from a rank's host vectors) are caught at
+// the same places and become that rank's error code, so the rank still reaches the exchange.  Waits and their bounds:
+//   * RCCL work queued on a stream: polled with a time limit (PPRHIP_COMM_TIMEOUT_S, default 1800) together with the
+//     communicator's asynchronous error state; on either the communicator is aborted (ncclCommAbort), which releases
+//     the peers' kernels as well;
+//   * the in-process transport's barriers: the same time limit; a rank that gives up marks the group broken and every
+//     rank in it (now or later) returns PPRHIP_ERR_STATE;
+//   * pprhip_comm_create (ncclCommInitRank is a rendezvous of all ranks): runs on a helper thread and is awaited with
+//     the same limit; when a peer never arrives the caller gets PPRHIP_ERR_STATE back and the helper thread stays
+//     parked in RCCL until the process ends (there is no handle yet that could be aborted);
+//   * one-process communicators come from ncclCommInitAll on the calling thread (no rendezvous between threads);
+//   * NOT bounded by this file: the inside of ncclGroupEnd / ncclSend / ncclRecv / ncclCommInitAll / ncclCommDestroy
+//     (RCCL's own blocking sections - they queue work and return; a destroy of an aborted communicator is skipped),
+//     and hipStreamSynchronize on a rank's own stream after purely local work.
 // STATUS: the RCCL transport with more than one rank has not executed on a real fabric yet (no multi-GPU box was
 // available to this build; real RCCL runs with a group of one in tests/test_gpu_multi.py).  Its code has run with 2 and
 // 3 ranks against a test double of the dozen RCCL calls (tests/fixtures/fake_rccl.cpp through PPRHIP_RCCL_LIB: ranks
@@ -124,19 +133,32 @@ struct LocalGroup {
   std::vector<const void*> send;                 // per rank: posted send buffer (device)
   std::vector<std::vector<uint64_t>> send_off;   // per rank: byte offsets per peer, world + 1
   std::vector<int> posted_rc;                    // per rank: the error it entered the exchange with (0: none)
-  // Returns once every rank of the group has arrived.  Every rank takes part in every exchange, failed or not (it
-  // posts its error instead of data), so the count always completes and all ranks leave a barrier together: a send
-  // buffer is never released while a peer may still be copying from it.
-  void barrier() {
+  bool broken = false;
+  // Returns true once every rank of the group has arrived.  Every rank takes part in every exchange, failed or not (it
+  // posts its error instead of data), so the count completes and all ranks leave a barrier together: a send buffer
+  // is never released while a peer may still be copying from it.  A rank that does not see the others within
+  // `limit_s` (a peer's thread died outside the protocol) marks the group broken: it and everybody who is or comes
+  // in a barrier of this group returns false.
+  bool barrier(double limit_s) {
     std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
     const uint64_t my = gen;
     if (++arrived == world) {
       arrived = 0;
       ++gen;
       cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return gen != my; });
+      return true;
     }
+    if (!cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return gen != my || broken; })) {
+      broken = true;
+      cv.notify_all();
+    }
+    return !broken && gen != my;
+  }
+  void fail() {
+    std::lock_guard<std::mutex> lk(mu);
+    broken = true;
+    cv.notify_all();
   }
 };
 
@@ -243,7 +265,11 @@ int comm_alltoallv(pprhip_comm* c, const void* send, const std::vector<uint64_t>
       L->send_off[c->rank] = local_rc == PPRHIP_OK ? off : std::vector<uint64_t>((size_t)W + 1, 0);
       L->posted_rc[c->rank] = local_rc;
     }
-    L->barrier();  // everybody has posted
+    if (!L->barrier(comm_timeout_s())) {  // everybody has posted
+      set_error("in-process exchange: rank %d waited %.0f s for its peers (a rank's thread left the call); group broken",
+                c->rank, comm_timeout_s());
+      return finish(PPRHIP_ERR_STATE);
+    }
     int rc = PPRHIP_OK;
     for (int p = 0; p < W; ++p)
       if (L->posted_rc[p] != PPRHIP_OK && p != c->rank && rc == PPRHIP_OK) {
@@ -270,8 +296,13 @@ int comm_alltoallv(pprhip_comm* c, const void* send, const std::vector<uint64_t>
       }
     }
     const std::string msg = rc != PPRHIP_OK ? std::string(get_error()) : std::string();
-    L->barrier();  // everybody has read: send buffers may go
+    const bool all_read = L->barrier(comm_timeout_s());  // everybody has read: send buffers may go
     if (rc != PPRHIP_OK) set_error("%s", msg.c_str());
+    else if (!all_read) {
+      set_error("in-process exchange: rank %d waited %.0f s for its peers after the copies; group broken", c->rank,
+                comm_timeout_s());
+      rc = PPRHIP_ERR_STATE;
+    }
     return finish(rc);
   }
   if (c->dead) {
@@ -374,9 +405,13 @@ int all_pair_sharded(pprhip_comm* c, double alpha, double threshold, int k, pprh
   pprhip_graph* g = c->g;
   const int W = c->world;
   int rc = pre_rc;
-  if (rc == PPRHIP_OK && g->n < (uint32_t)W) {
-    set_error("sharded All-Pair: fewer nodes (%u) than ranks (%d)", g->n, W);
-    rc = PPRHIP_ERR_INVALID;  // every rank sees the same n: all of them return here, nobody is left waiting
+  if (g->n < (uint32_t)W) {
+    // every rank sees the same n (replicas of one graph): ALL of them return here, a rank that came in with an error
+    // of its own included - nobody goes on to an exchange the others have left
+    if (rc == PPRHIP_OK) {
+      set_error("sharded All-Pair: fewer nodes (%u) than ranks (%d)", g->n, W);
+      rc = PPRHIP_ERR_INVALID;
+    }
     return rc;
   }
   uint32_t lo = 0, hi = 0;
@@ -413,7 +448,14 @@ int all_pair_sharded(pprhip_comm* c, double alpha, double threshold, int k, pprh
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     return PPRHIP_OK;
   };
-  if (rc == PPRHIP_OK) rc = local_part();
+  if (rc == PPRHIP_OK) {
+    try {
+      rc = local_part();
+    } catch (const std::exception& e) {  // (host vectors: the rank still goes to the exchange, as a failed one)
+      set_error("sharded All-Pair: rank %d: %s", c->rank, e.what());
+      rc = PPRHIP_ERR_OOM;
+    }
+  }
   // ---- exchange: every entry goes to the rank that owns its source
   std::vector<uint64_t> off((size_t)W + 1, 0), roff;
   if (rc == PPRHIP_OK)
@@ -425,7 +467,13 @@ int all_pair_sharded(pprhip_comm* c, double alpha, double threshold, int k, pprh
   const uint64_t n_recv = roff[W] / sizeof(TripleRec);
   st.select_bytes = roff[W];          // bytes received in the exchange
   st.mc_sources = sink.count;         // entries this rank found (before the exchange)
-  if ((rc = index_from_device(g, (const TripleRec*)d_recv, n_recv, k, lo, hi, own_out))) return done(rc);
+  try {  // (no collective follows: an error here is this rank's alone)
+    rc = index_from_device(g, (const TripleRec*)d_recv, n_recv, k, lo, hi, own_out);
+  } catch (const std::exception& e) {
+    set_error("sharded All-Pair: rank %d: index finalisation: %s", c->rank, e.what());
+    rc = PPRHIP_ERR_OOM;
+  }
+  if (rc != PPRHIP_OK) return done(rc);
   if (stats) *stats = st;
   return done(PPRHIP_OK);
 }
@@ -459,7 +507,14 @@ int topk_gather_impl(pprhip_comm* c, const int32_t* ids, const double* vals, int
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     return PPRHIP_OK;
   };
-  if (rc == PPRHIP_OK) rc = stage();
+  if (rc == PPRHIP_OK) {
+    try {
+      rc = stage();
+    } catch (const std::exception& e) {
+      set_error("pprhip_topk_gather: rank %d: %s", c->rank, e.what());
+      rc = PPRHIP_ERR_OOM;
+    }
+  }
   std::vector<uint64_t> off((size_t)c->world + 1, 0), roff;
   if (rc == PPRHIP_OK)
     for (int p = 0; p < c->world; ++p) off[p + 1] = off[p] + (p == 0 ? blk : 0);  // everything goes to rank 0
@@ -523,16 +578,49 @@ int pprhip_comm_create(pprhip_graph_t* g, const void* id, int rank, int world, p
   c->g = g;
   c->rank = rank;
   c->world = world;
+  // ncclCommInitRank is a rendezvous: it returns when all `world` ranks have called it.  It runs on a helper thread
+  // and is awaited with the path's time limit, so a peer that never arrives costs this rank an error, not its
+  // process (the helper then stays parked inside RCCL: nothing exists yet that could be aborted).
+  struct Init {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    int r = ncclSuccess;
+    ncclComm_t comm = nullptr;
+  };
+  auto st = std::make_shared<Init>();
   ncclUniqueId uid;
   std::memcpy(&uid, id, sizeof uid);
-  PPRHIP_CHECK_RCCL(R->CommInitRank(&c->nccl, world, uid, rank));
+  const int device = g->device;
+  std::thread([st, R, uid, rank, world, device] {
+    ncclComm_t cm = nullptr;
+    int r = hipSetDevice(device) == hipSuccess ? R->CommInitRank(&cm, world, uid, rank) : 2 /* ncclSystemError */;
+    std::lock_guard<std::mutex> lk(st->mu);
+    st->r = r;
+    st->comm = cm;
+    st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  {
+    std::unique_lock<std::mutex> lk(st->mu);
+    if (!st->cv.wait_for(lk, std::chrono::duration<double>(comm_timeout_s()), [&] { return st->done; })) {
+      set_error("pprhip_comm_create: rank %d of %d waited %.0f s (PPRHIP_COMM_TIMEOUT_S) for its peers in "
+                "ncclCommInitRank; a rank never arrived", rank, world, comm_timeout_s());
+      return PPRHIP_ERR_STATE;
+    }
+    if (st->r != ncclSuccess) {
+      set_error("ncclCommInitRank failed on rank %d of %d: %s", rank, world, R->GetErrorString(st->r));
+      return PPRHIP_ERR_HIP;
+    }
+    c->nccl = st->comm;
+  }
   *comm_out = c.release();
   return PPRHIP_OK;
 }
 
 void pprhip_comm_destroy(pprhip_comm_t* c) {
   if (!c) return;
-  if (c->nccl) {
+  if (c->nccl) {  // (an aborted communicator has no handle left: comm_abort took it)
     (void)hipSetDevice(c->g->device);
     (void)rccl()->CommDestroy(c->nccl);
   }
@@ -701,7 +789,17 @@ int run_ranks(RankSetup& S, F fn) {
         set_error("hipSetDevice(%d) failed on rank %d's thread", S.comms[r].g->device, r);
         pre = PPRHIP_ERR_NO_DEVICE;
       }
-      const int rc = fn(r, pre);
+      int rc;
+      try {
+        rc = fn(r, pre);
+      } catch (const std::exception& e) {
+        // fn's own code catches what can throw before its exchange; this is the last line of defence (nothing may
+        // reach std::terminate): the in-process group is marked broken so that no peer waits for this rank
+        set_error("rank %d: %s", r, e.what());
+        rc = PPRHIP_ERR_OOM;
+        S.local.fail();
+        if (S.comms[r].nccl) comm_abort(&S.comms[r]);
+      }
       if (rc != PPRHIP_OK) S.errs[r] = get_error();
       S.rcs[r] = rc;
     });

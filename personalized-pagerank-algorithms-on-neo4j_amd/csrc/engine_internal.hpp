@@ -205,7 +205,9 @@ struct FetchPipe {
   struct Arrival { FetchPipe* pipe; Item item; };
   static void on_copied(void* arrival);  // host callback of the copy stream
   int pending = 0;                       // copies queued on the copy stream whose callback has not run yet
-  std::mutex mu;
+  std::mutex mu;     // free_q, work, pending, closing, err: bookkeeping only - never held across a HIP call, because
+                     // the copy stream's host callback (on_copied, on a runtime thread) takes it too
+  std::mutex cs_mu;  // orders the slots' threads on the shared copy stream (wait - copy - callback stay together)
   std::condition_variable cv;
   std::deque<int> free_q;
   std::deque<Item> work;

@@ -853,29 +853,66 @@ int pprhip::detail::FetchPipe::submit(pprhip_graph* S, const double* dev_vec, do
     e = free_q.front();
     free_q.pop_front();
   }
-  if (S->relabeled)  // back to the caller's ids: out[old] = x[old2new[old]]
-    PPRHIP_TRY(launch_permute_out(S, dev_vec, dev[e]));
-  else
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(dev[e], dev_vec, sizeof(double) * n, hipMemcpyDeviceToDevice, S->stream));
-  PPRHIP_CHECK_HIP(hipEventRecord(ready[e], S->stream));
+  // A failure from here on hands the ring entry back and marks the pipe failed (finish() then stops waiting for
+  // callbacks that may never run).  No HIP call is made with `mu` held: the copy stream's callback takes `mu` on a
+  // thread of the runtime, and a HIP call that waited for work queued behind a pending callback would never return.
+  auto fail = [&](int rc) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      free_q.push_back(e);
+      if (!err) err = rc;
+    }
+    cv.notify_all();
+    return rc;
+  };
+  int rc = PPRHIP_OK;
+  if (S->relabeled) {  // back to the caller's ids: out[old] = x[old2new[old]]
+    rc = launch_permute_out(S, dev_vec, dev[e]);
+  } else if (hipMemcpyAsync(dev[e], dev_vec, sizeof(double) * n, hipMemcpyDeviceToDevice, S->stream) != hipSuccess) {
+    set_error("delivery of a result vector failed (staging copy)");
+    rc = PPRHIP_ERR_HIP;
+  }
+  if (rc == PPRHIP_OK && hipEventRecord(ready[e], S->stream) != hipSuccess) {
+    set_error("delivery of a result vector failed (event)");
+    rc = PPRHIP_ERR_HIP;
+  }
+  if (rc != PPRHIP_OK) return fail(rc);
+  Arrival* a = new (std::nothrow) Arrival{this, Item{e, dst}};
+  if (!a) return fail(PPRHIP_ERR_OOM);
   {
-    // the copy stream is shared by the slots' threads: order its three calls
-    std::lock_guard<std::mutex> lk(mu);
-    PPRHIP_CHECK_HIP(hipStreamWaitEvent(cs, ready[e], 0));
-    PPRHIP_CHECK_HIP(hipMemcpyAsync(pin[e], dev[e], sizeof(double) * n, hipMemcpyDeviceToHost, cs));
-    pending++;
-    PPRHIP_CHECK_HIP(hipLaunchHostFunc(cs, &FetchPipe::on_copied, new Arrival{this, Item{e, dst}}));
+    // the copy stream is shared by the slots' threads: its three calls stay together
+    std::lock_guard<std::mutex> order(cs_mu);
+    if (hipStreamWaitEvent(cs, ready[e], 0) != hipSuccess ||
+        hipMemcpyAsync(pin[e], dev[e], sizeof(double) * n, hipMemcpyDeviceToHost, cs) != hipSuccess) {
+      set_error("delivery of a result vector failed (copy stream)");
+      delete a;
+      return fail(PPRHIP_ERR_HIP);
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      pending++;
+    }
+    if (hipLaunchHostFunc(cs, &FetchPipe::on_copied, a) != hipSuccess) {  // no callback will run for this entry
+      set_error("delivery of a result vector failed (host callback)");
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        pending--;
+      }
+      delete a;
+      return fail(PPRHIP_ERR_HIP);
+    }
   }
   return PPRHIP_OK;
 }
 
 int pprhip::detail::FetchPipe::finish() {
   // the copy stream drains first (its callbacks queue the last vectors), then the copiers
-  if (cs && hipStreamSynchronize(cs) != hipSuccess && !err) err = PPRHIP_ERR_HIP;
+  const bool drained = !cs || hipStreamSynchronize(cs) == hipSuccess;
   {
     std::lock_guard<std::mutex> lk(mu);
+    if (!drained && !err) err = PPRHIP_ERR_HIP;
     closing = true;
-    if (err) pending = 0;  // a failed copy stream may never run its callbacks
+    if (err) pending = 0;  // a failed copy stream may never run its callbacks: the copiers must not wait for them
   }
   cv.notify_all();
   for (int t = 0; t < kCopiers; ++t)

@@ -98,6 +98,14 @@ int run_ops(std::vector<Op>& ops) {
       else if (o.bytes && (hipMemcpyAsync(o.buf, s.buf, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess ||
                            hipStreamSynchronize(o.stream) != hipSuccess))
         rc = kUnhandled;
+      // FAKE_RCCL_CORRUPT_SRC=<id> (test switch): a payload of 16-byte index records (not an 8-byte size word) arrives
+      // with the source id of its MIDDLE record replaced - what a transport gone wrong or a peer's bad partition would
+      // hand the receiver, whose finalisation must turn it into an error and not into an out-of-range write
+      if (rc == kOk && o.bytes >= 48 && o.bytes % 16 == 0)
+        if (const char* bad = getenv("FAKE_RCCL_CORRUPT_SRC")) {
+          const int v = atoi(bad);
+          (void)hipMemcpy((char*)o.buf + (o.bytes / 16 / 2) * 16, &v, sizeof v, hipMemcpyHostToDevice);
+        }
       {
         std::lock_guard<std::mutex> lk(G->mu);
         G->done[key] = s.ticket;

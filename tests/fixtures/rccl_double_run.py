@@ -38,6 +38,33 @@ def on_ranks(world, fn):
     return out, err
 
 
+def check_sharded(world, graphs, host, thr, k, ref_arrays):
+    """`world` ranks, a communicator each: every rank's rows equal the single-GPU index on the rank's source range and
+    are empty outside it; returns the per-rank (entries owned, entries found)."""
+    roff, rtg, rvl = ref_arrays
+    uid = pkg.comm_unique_id()
+    comms, err = on_ranks(world, lambda r: pkg.Comm(graphs[r], uid, r, world))
+    assert not any(err), err
+    res, err = on_ranks(world, lambda r: comms[r].all_pair_backward_sharded(A, thr, k))
+    assert not any(err), err
+    per_rank = []
+    for r in range(world):
+        own, st = res[r]
+        off, tg, vl = own.arrays()
+        lo, hi = pkg.shard_target_range(r, world, host.n)
+        assert off[lo] == 0 and off[hi] == off[-1]
+        a, b = roff[lo], roff[hi]
+        assert np.array_equal(off[lo:hi + 1] - off[lo], roff[lo:hi + 1] - a)
+        assert np.array_equal(tg, rtg[a:b]) and np.max(np.abs(vl - rvl[a:b]), initial=0.0) <= 1e-12
+        assert st.select_bytes % 16 == 0
+        per_rank.append((len(tg), int(st.mc_sources)))
+        own.close()
+    assert sum(x[0] for x in per_rank) == len(rtg)
+    for c in comms:
+        c.close()
+    return per_rank
+
+
 host = pkg.HostCsr.rmat(12, 16, seed=1)
 graphs = [pkg.Graph(host) for _ in range(3)]
 for g in graphs:
@@ -103,6 +130,65 @@ for world in (2, 3):
     assert all(isinstance(e, pkg.PprhipError) for e in err), err
     for c in comms:
         c.close()
+
+# ---- eight ranks (config #5's rank count), n not divisible by 8: R-MAT 12 plus three isolated nodes (n = 4099: ranges of
+# 513, 513, 513, 512, ...; an isolated target's search is {t: 1.0}, Backward_Search.java:46-49)
+src8, dst8 = pkg.rmat_edges(12, 16, seed=1)
+host8 = pkg.HostCsr(4099, src8, dst8)
+graphs8 = [pkg.Graph(host8) for _ in range(8)]
+ref8, _ = graphs8[0].all_pair_backward(A, 2e-3, 4)
+ref8a = [x.copy() for x in ref8.arrays()]
+ref8.close()
+assert host8.n % 8 != 0 and len({pkg.shard_target_range(r, 8, host8.n)[1] - pkg.shard_target_range(r, 8, host8.n)[0]
+                                 for r in range(8)}) == 2
+per_rank = check_sharded(8, graphs8, host8, 2e-3, 4, ref8a)
+assert all(owned > 0 and found > 0 for owned, found in per_rank)
+# the one-process entry point with eight handles: the merged index IS the single-GPU one
+os.environ["PPRHIP_FORCE_RCCL"] = "1"
+ix8, sts8 = pkg.all_pair_backward_multi(graphs8, A, 2e-3, 4)
+o8, t8, v8 = ix8.arrays()
+assert np.array_equal(o8, ref8a[0]) and np.array_equal(t8, ref8a[1]) and np.max(np.abs(v8 - ref8a[2])) <= 1e-12
+ix8.close()
+del os.environ["PPRHIP_FORCE_RCCL"]
+# ---- a record whose source id is out of range arrives in the MIDDLE of a rank's payload (the device sort orders by the
+# significant bits only, so it lands between valid rows): an error on the receiving ranks, no out-of-range write
+uid = pkg.comm_unique_id()
+comms, err = on_ranks(2, lambda r: pkg.Comm(graphs8[r], uid, r, 2))
+assert not any(err), err
+for bad_id in (host8.n + 5, 1 << 30, -7, 8192 + 1000, 8192 + 3000):  # (the last two sort into the middle of rank 0's / 1's rows)
+    os.environ["FAKE_RCCL_CORRUPT_SRC"] = str(bad_id)
+    res, err = on_ranks(2, lambda r: comms[r].all_pair_backward_sharded(A, 2e-3, 4))
+    del os.environ["FAKE_RCCL_CORRUPT_SRC"]
+    assert all(isinstance(e, pkg.PprhipError) and e.code == pkg.ERR_INVALID for e in err), (bad_id, err)
+res, err = on_ranks(2, lambda r: comms[r].all_pair_backward_sharded(A, 2e-3, 4))   # the group is still usable
+assert not any(err), err
+for x in res:
+    x[0].close()
+for c in comms:
+    c.close()
+for g in graphs8:
+    g.close()
+
+# ---- eight ranks of which one owns no entries and finds none: n = 67 (ranges of 9, 9, 9, 8, ...), threshold 0.5; the
+# nodes of rank 3's range [27, 35) all have an in-edge from node 0, every other node has none.  A target without
+# in-edges yields {t: 1.0}; a target t of rank 3 yields alpha at t and 0.85 / 8 at node 0, both below the threshold.
+lo3, hi3 = pkg.shard_target_range(3, 8, 67)
+assert (lo3, hi3) == (27, 35)
+host67 = pkg.HostCsr(67, np.zeros(hi3 - lo3, dtype=np.int32), np.arange(lo3, hi3, dtype=np.int32))
+graphs67 = [pkg.Graph(host67) for _ in range(8)]
+ref67, _ = graphs67[0].all_pair_backward(A, 0.5, 4)
+ref67a = [x.copy() for x in ref67.arrays()]
+ref67.close()
+assert len(ref67a[1]) == 67 - 8 and np.all(ref67a[2] == 1.0)
+per_rank = check_sharded(8, graphs67, host67, 0.5, 4, ref67a)
+assert per_rank[3] == (0, 0) and all(x[0] > 0 for i, x in enumerate(per_rank) if i != 3)
+os.environ["PPRHIP_FORCE_RCCL"] = "1"
+ix67, _ = pkg.all_pair_backward_multi(graphs67, A, 0.5, 4)
+assert all(np.array_equal(a, b) for a, b in zip(ix67.arrays(), ref67a))
+ix67.close()
+del os.environ["PPRHIP_FORCE_RCCL"]
+for g in graphs67:
+    g.close()
 
 # ---- the one-process entry points (one host thread per replica, communicators from ncclCommInitAll) on the same branch
 os.environ["PPRHIP_FORCE_RCCL"] = "1"

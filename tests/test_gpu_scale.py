@@ -150,13 +150,75 @@ def test_backward_push_and_all_pair_sample(orc, rmat20, dev20):
     assert np.array_equal(off2, ooff) and np.array_equal(tg2, otg) and np.max(np.abs(vl2 - ovl)) <= 1e-12
 
 
-def test_all_pair_in_parts_equals_in_sequence(pkg, rmat20, monkeypatch):
+def column_sample(host, n_hubs, n_ranked, n_random, seed, t_lo=0, t_hi=None):
+    """Targets for a column check: the n_hubs with the most in-edges (the searches whose levels are shared between
+    workgroups and, where the lists overflow, the full-size pass), n_ranked more spread geometrically over the
+    in-degree ranks behind them (the dense tier's middle), n_random drawn uniformly (mostly LDS-tier searches)."""
+    t_hi = host.n if t_hi is None else t_hi
+    ind = np.diff(host.in_rp)[t_lo:t_hi].astype(np.int64)
+    order = np.argsort(-ind, kind="stable") + t_lo
+    ranks = np.unique(np.geomspace(n_hubs + 1, min(order.size - 1, 200000), n_ranked).astype(np.int64))
+    rng = np.random.default_rng(seed)
+    return [int(x) for x in order[:n_hubs]] + [int(order[r]) for r in ranks] + \
+           [int(x) for x in rng.integers(t_lo, t_hi, n_random)]
+
+
+def check_columns_against_oracle(orc, og, arrays, targets, thr, k, fifo_for=None):
+    """Base_Whole_Graph.java:76-92 + the k rule (:112-163), column by column: the oracle's twin schedule to 1e-12 (same
+    entries, same values), and the Java-faithful FIFO order under its bound (both orders leave every residue <= thr, so
+    two reserves of one pair differ by at most thr: Backward_Search.java:89)."""
+    from bench import index_column_check
+    off, tg, vl = arrays
+    touched = {}
+
+    def sync_col(t):
+        p, r, _ = og.backward_push(t, A, thr, orc.SYNC)
+        touched[t] = int(((p > 0) | (r > 0)).sum())
+        return p
+
+    st = index_column_check(off, tg, vl, targets, sync_col, thr, k, tol=1e-12)
+    fifo_for = targets if fifo_for is None else fifo_for
+    st_f = index_column_check(off, tg, vl, fifo_for, lambda t: og.backward_push(t, A, thr, orc.FIFO)[0], thr, k, tol=1e-12,
+                              slack=thr)
+    assert st_f["max_abs_diff"] <= thr
+    return st, st_f, touched
+
+
+@pytest.fixture(scope="module")
+def full_index20(pkg, rmat20):
+    """All 2^20 targets of R-MAT 20 with the default settings: ranges of this size run in parts, tier 1 of the next part
+    on a side stream beside the dense tier of the part before (allpair.cpp), the entries are sorted on the device and
+    the k rule is applied by index_from_sorted."""
+    with pkg.Graph(rmat20) as g:
+        ix, st = g.all_pair_backward(A, 1e-3, 16)
+        arrays = [x.copy() for x in ix.arrays()]
+        ix.close()
+    return arrays, st
+
+
+@pytest.mark.timeout(900)
+def test_all_pair_full_range_columns_against_oracle(orc, rmat20, full_index20):
+    """The index of ALL targets, as the default (pipelined) path builds it, against oracle backward searches of 528
+    targets: the 16 with the most in-edges, 112 across the dense tier's in-degree ranks, 400 at random."""
+    og = to_oracle(orc, rmat20)
+    arrays, st = full_index20
+    targets = column_sample(rmat20, 16, 112, 400, seed=21)
+    assert len(set(targets)) >= 512
+    c, cf, touched = check_columns_against_oracle(orc, og, arrays, targets, 1e-3, 16)
+    # the sample reaches both tiers (the LDS table gives up beyond 1536 nodes) and the k rule really cut entries
+    sizes = np.array(list(touched.values()))
+    assert (sizes <= 1536).sum() >= 100 and (sizes > 1536).sum() >= 100 and sizes.max() > 500000
+    assert c["entries_checked"] > 100000 and c["entries_cut_by_k_rule"] > 0
+    assert st.rounds > 0 and st.dense_nodes == 0          # dense-tier targets; nothing fell through to tier 3
+    off, tg, vl = arrays
+    assert np.all(vl >= 1e-3) and off[-1] == len(tg)
+
+
+def test_all_pair_in_parts_equals_in_sequence(pkg, rmat20, full_index20, monkeypatch):
     """Ranges of 2^20 targets and more run tier 1 of the next part on a side stream beside the dense tier of the part
     before (allpair.cpp); the index must be the one the tiers give one after the other."""
+    a, st = full_index20
     with pkg.Graph(rmat20) as g:
-        ix, st = g.all_pair_backward(A, 1e-3, 16)          # n = 2^20 targets: in parts
-        a = [x.copy() for x in ix.arrays()]
-        ix.close()
         monkeypatch.setenv("PPRHIP_APBS_NO_PIPE", "1")
         ix, st1 = g.all_pair_backward(A, 1e-3, 16)
         b = ix.arrays()
@@ -242,60 +304,88 @@ def test_full_size_rmat24(pkg):
     _full_size_checks(pkg, 24, 3)
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1200)
 def test_full_size_rmat22_against_cpu_power_method(pkg, orc):
-    """Benchmark size against the CPU ground truth (Power_Method.java:44-101, 100 sweeps, ~0.5 min of host time): the
-    GPU power method equals it to 1e-12, FORA (single and batched entry points, eps = 0.5) keeps its relative bound on
-    every node with pi > delta (Fora_Whole_Graph's guarantee; delta = 1/n), and the top-32 agree wherever the exact
-    values are further apart than the estimate's error."""
+    """Benchmark size against the CPU ground truth (Power_Method.java:44-101, 100 sweeps, ~0.5 min of host time per
+    source, the three in parallel) for three sources - the node with the most out-edges, a node with one out-edge and a
+    random live one: the GPU power method equals it to 1e-12, FORA (single and batched entry points, eps = 0.5) keeps
+    its relative bound on every node with pi > delta (Fora_Whole_Graph's guarantee; delta = 1/n), the top-32 agree
+    wherever the exact values are further apart than the estimate's error, and Fora_Topk at k = 32 (config #3;
+    Fora_Topk.java:102-184) through the single and the batched entry point keeps its eps / 2 bound."""
+    from concurrent.futures import ThreadPoolExecutor
     host = pkg.HostCsr.rmat(22, 16, seed=1)
     og = to_oracle(orc, host)
-    s = live_sources(host, 1, 77)[0]
-    exact = og.power_method(s, A, 100)
+    od = np.diff(host.out_rp)
+    srcs = [int(np.argmax(od)), int(np.nonzero(od == 1)[0][1234]), live_sources(host, 1, 77)[0]]
+    assert od[srcs[0]] > 10000 and od[srcs[1]] == 1 and len(set(srcs)) == 3
+    with ThreadPoolExecutor(3) as pool:   # (ctypes calls release the GIL)
+        exacts = list(pool.map(lambda s: og.power_method(s, A, 100), srcs))
+    k = 32
     with pkg.Graph(host) as g:
-        pm, _ = g.power_method(s, A, 100)
-        assert np.max(np.abs(pm - exact)) <= 1e-12
-        big = exact > 1.0 / host.n
-        est, st = g.fora_single_source(s, 0.5, A, seed=5)
         g.set_tuning(pkg.tuning_batch())
         try:
-            out, ids, vals, nsel, _, _ = g.fora_batch_single_source([s, s], 0.5, A, seed=6, k=32, fetch=True, per_query=True)
+            out, ids, vals, nsel, _, _ = g.fora_batch_single_source(srcs, 0.5, A, seed=6, k=k, fetch=True, per_query=True)
         finally:
             g.set_tuning(pkg.tuning_default())
-        for e in (est, out[0]):
-            assert abs(e.sum() - 1.0) < 1e-9
-            err = np.abs(e - exact)
-            assert np.all(err[big] <= 0.5 * exact[big])
-            # top-32: same set up to swaps among values closer than twice the largest error seen on the top entries
-            order = np.argsort(-exact, kind="stable")[:64]
-            tol = 2.0 * err[order].max()
-            top_exact, top_est = set(order[:32].tolist()), set(np.argsort(-e, kind="stable")[:32].tolist())
-            kth = exact[order[31]]
-            for v in top_exact ^ top_est:
-                assert abs(exact[v] - kth) <= tol
-        m = min(int(nsel[0]), 32)
-        assert np.array_equal(out[0][ids[0][:m]], vals[0][:m])
-        # ---- Fora_Topk.computeTopKPPR at full size (config #3: k = 32; Fora_Topk.java:102-184): the single entry point
-        # and the batched one, against the same CPU ground truth
-        k = 32
-        order = np.argsort(-exact, kind="stable")
-        kth = exact[order[k - 1]]
-        n_sel, tids, tvals, test_, tst = g.fora_topk(s, 0.5, A, k, seed=5, cap=4 * k, fetch=True)
-        bids, bvals, bst = g.fora_batch_topk(np.array([s, s], dtype=np.int32), k, 0.5, A, seed=5)
-        assert tst.rounds >= 1 and tst.walks > 0 and n_sel >= k
-        assert np.all(np.diff(tvals) <= 0) and np.array_equal(test_[tids], tvals)
-        # query 0 of the batch runs with the same seed as the single call: same rounds, same walks, same list
-        assert np.array_equal(bids[0], tids[:k]) and np.max(np.abs(bvals[0] - tvals[:k])) <= 1e-9
-        for ids_k, vals_k in ((tids[:k], tvals[:k]), (bids[1], bvals[1])):
-            # the stopping rule (:175) bounds the relative error of the reported entries by eps' = eps / 2
-            assert np.all(np.abs(vals_k - exact[ids_k]) <= 0.25 * np.maximum(exact[ids_k], kth))
-            # top-32 identity wherever the exact k-th and (k+1)-th values are further apart than that error (gap guard);
-            # otherwise only entries within the error of the k-th place may differ
-            gap = exact[order[k - 1]] - exact[order[k]]
-            if gap > 2 * 0.25 * kth:
-                assert set(ids_k.tolist()) == set(order[:k].tolist())
-            else:
-                for v in set(ids_k.tolist()) ^ set(order[:k].tolist()):
-                    assert abs(exact[v] - kth) <= 2 * 0.25 * kth
-        # the whole estimate the last round leaves (Fora_Topk.java:143-168) keeps mass 1 up to the undelivered residues
-        assert abs(test_.sum() + (1 - A) * 0 - 1.0) < 1e-6 or test_.sum() <= 1.0 + 1e-9
+        bids, bvals, bst = g.fora_batch_topk(np.array(srcs + srcs, dtype=np.int32), k, 0.5, A, seed=5)
+        for i, (s, exact) in enumerate(zip(srcs, exacts)):
+            pm, _ = g.power_method(s, A, 100)
+            assert np.max(np.abs(pm - exact)) <= 1e-12
+            big = exact > 1.0 / host.n
+            est, st = g.fora_single_source(s, 0.5, A, seed=5)
+            assert st.walks > 0
+            for e in (est, out[i]):
+                assert abs(e.sum() - 1.0) < 1e-9
+                err = np.abs(e - exact)
+                assert np.all(err[big] <= 0.5 * exact[big])
+                # top-32: same set up to swaps among values closer than twice the largest error seen on the top entries
+                order = np.argsort(-exact, kind="stable")[:64]
+                tol = 2.0 * err[order].max()
+                top_exact, top_est = set(order[:32].tolist()), set(np.argsort(-e, kind="stable")[:32].tolist())
+                kth = exact[order[31]]
+                for v in top_exact ^ top_est:
+                    assert abs(exact[v] - kth) <= tol
+            m = min(int(nsel[i]), k)
+            assert np.array_equal(out[i][ids[i][:m]], vals[i][:m])
+            # ---- Fora_Topk.computeTopKPPR at full size: the single entry point and the batched one
+            order = np.argsort(-exact, kind="stable")
+            kth = exact[order[k - 1]]
+            n_sel, tids, tvals, test_, tst = g.fora_topk(s, 0.5, A, k, seed=5 + i, cap=4 * k, fetch=True)
+            assert tst.rounds >= 1 and tst.walks > 0 and n_sel >= k
+            assert np.all(np.diff(tvals) <= 0) and np.array_equal(test_[tids], tvals)
+            # query i of the batch runs with the same seed as the single call: same rounds, same walks, same list
+            assert np.array_equal(bids[i], tids[:k]) and np.max(np.abs(bvals[i] - tvals[:k])) <= 1e-9
+            for ids_k, vals_k in ((tids[:k], tvals[:k]), (bids[3 + i], bvals[3 + i])):
+                # the stopping rule (:175) bounds the relative error of the reported entries by eps' = eps / 2
+                assert np.all(np.abs(vals_k - exact[ids_k]) <= 0.25 * np.maximum(exact[ids_k], kth))
+                # top-32 identity wherever the exact k-th and (k+1)-th values are further apart than that error (gap
+                # guard); otherwise only entries within the error of the k-th place may differ
+                gap = exact[order[k - 1]] - exact[order[k]]
+                if gap > 2 * 0.25 * kth:
+                    assert set(ids_k.tolist()) == set(order[:k].tolist())
+                else:
+                    for v in set(ids_k.tolist()) ^ set(order[:k].tolist()):
+                        assert abs(exact[v] - kth) <= 2 * 0.25 * kth
+            # the whole estimate the last round leaves (Fora_Topk.java:143-168): every residue's walks deliver all of it
+            # (omega_v = ceil(r W) >= 1 walks of r / omega_v each, :155-167), so reserve + walk increments sum to 1
+            assert abs(test_.sum() - 1.0) < 1e-9
+
+
+@pytest.mark.timeout(1200)
+def test_full_size_rmat22_all_pair_columns_against_oracle(pkg, orc):
+    """All 4.19 M targets of R-MAT 22 (the bench's All-Pair workload: threshold 1e-3, k = 32) on one GPU with the
+    default settings - tiers side by side, levels shared at their natural sizes, the full-size pass for the searches
+    whose lists outgrow a workspace, device sort + index_from_sorted - and 56 of its columns against oracle backward
+    searches: the 8 targets with the most in-edges, 16 across the in-degree ranks, 32 at random
+    (Base_Whole_Graph.java:76-92,112-163; Backward_Search.java:84-89)."""
+    host = pkg.HostCsr.rmat(22, 16, seed=1)
+    og = to_oracle(orc, host)
+    with pkg.Graph(host) as g:
+        ix, st = g.all_pair_backward(A, 1e-3, 32)
+        arrays = ix.arrays()
+        ix.close()
+    assert st.xl_targets >= 1 and st.dense_nodes == 0     # the full-size pass ran; nothing was left for tier 3
+    targets = column_sample(host, 8, 16, 32, seed=22)
+    c, cf, touched = check_columns_against_oracle(orc, og, arrays, targets, 1e-3, 32, fifo_for=targets[:4] + targets[24:40])
+    assert max(touched.values()) > (1 << 20)              # a search beyond the per-workgroup lists was among them
+    assert c["entries_checked"] > 100000 and c["entries_cut_by_k_rule"] > 0
