@@ -89,7 +89,8 @@ typedef struct pprhip_stats {
                             * (index stream, each gathered contribution line once, row sums out and in, next
                             * contributions, the busy queries' residues) - a lower bound of the sweeps' memory traffic,
                             * whereas push_bytes' SURVEY 8(d) model counts one gather per edge and query */
-  uint64_t reserved1[2];
+  uint64_t walk_loads;      /* load instructions the walk kernel's waves issued (one 16-byte edge record per lane) ... */
+  uint64_t walk_load_lanes; /* ... and the lanes those loads carried: 64 per load = every load a full wave */
 } pprhip_stats_t;
 
 #define PPRHIP_KERNEL_NONE 0

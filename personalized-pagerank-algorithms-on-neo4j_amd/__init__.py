@@ -40,7 +40,7 @@ class Stats(C.Structure):
                 ("dominant_kernel_bytes", C.c_uint64), ("dominant_kernel_launches", C.c_uint32),
                 ("dominant_kernel_id", C.c_uint32), ("class_ms", C.c_double * 8), ("class_bytes", C.c_uint64 * 8),
                 ("class_launches", C.c_uint32 * 8), ("dense_edges", C.c_uint64), ("sweep_min_bytes", C.c_uint64),
-                ("reserved1", C.c_uint64 * 2)]
+                ("walk_loads", C.c_uint64), ("walk_load_lanes", C.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved") and not k.startswith("class_")}

@@ -880,8 +880,10 @@ int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count) {
 // The counters a query only needs once, at its end, in one copy: dead-end pops of the push, and what the walk phases
 // run since the workspace was reset counted on the device (steps, walks, sources: adjacent in DevCounters).
 int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st) {
-  static_assert(offsetof(DevCounters, sources_total) == offsetof(DevCounters, dead_pops) + 24, "one copy for the four");
-  PPRHIP_TRY(fetch_small(g, &g->ctr->dead_pops, &g->h_ctr->dead_pops, 4 * sizeof(unsigned long long)));
+  static_assert(offsetof(DevCounters, walk_lanes) == offsetof(DevCounters, dead_pops) + 40, "one copy for the six");
+  PPRHIP_TRY(fetch_small(g, &g->ctr->dead_pops, &g->h_ctr->dead_pops, 6 * sizeof(unsigned long long)));
+  st.walk_loads = g->h_ctr->walk_loads;
+  st.walk_load_lanes = g->h_ctr->walk_lanes;
   st.push_bytes += 16ull * (g->h_ctr->dead_pops - st.dead_end_pops);
   st.dead_end_pops = g->h_ctr->dead_pops;
   // cumulative over the query's walk phases: what is new since the last read goes into the statistics

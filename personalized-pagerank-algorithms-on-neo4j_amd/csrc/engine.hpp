@@ -17,6 +17,8 @@ struct DevCounters {
   unsigned long long walk_steps;     // edges followed by walks
   unsigned long long walks_total;    // walks run
   unsigned long long sources_total;  // residue entries that started walks
+  unsigned long long walk_loads;     // load instructions the walk kernel's waves issued ...
+  unsigned long long walk_lanes;     // ... and the lanes they carried (64 per load = full waves)
   double sum_out;                    // reduction result (the walk plan reads it on the device)
   // walk plan of a phase: sources << 36 | walks, counted by the plan kernel, read by the walk kernel on the device.
   // Three cells used in turn: the plan of phase p counts into cell p % 3 and clears cell (p + 1) % 3, which the walks
