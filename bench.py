@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--no-rmat24", action="store_true", help="skip the R-MAT 24 All-Pair child sample")
     ap.add_argument("--rmat24-targets", type=int, default=1 << 24)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--all-pair-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rmat24-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rmat24-pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -159,6 +160,8 @@ def main():
         return cpu_baseline_child(args)
     if args.pmc_child:
         return pmc_child(args)
+    if args.trace_child:
+        return trace_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -264,7 +267,7 @@ def main():
                       "one device)" % args.backend)
     acc = {"class_ms": [0.0] * 8, "class_bytes": [0] * 8, "class_launches": [0] * 8, "rounds": 0, "queries": 0,
            "walks": 0, "walk_steps": 0, "levels": 0, "dense_levels": 0, "dense_edges": 0, "push_ms": 0.0, "mc_ms": 0.0,
-           "sweep_min_bytes": 0, "call_ms": 0.0}
+           "sweep_min_bytes": 0, "call_ms": 0.0, "walk_loads": 0, "walk_load_lanes": 0}
     last = {}
     gathered = {}
 
@@ -274,7 +277,7 @@ def main():
             acc["class_bytes"][c] += st.class_bytes[c]
             acc["class_launches"][c] += st.class_launches[c]
         for k in ("rounds", "walks", "walk_steps", "levels", "dense_levels", "dense_edges", "push_ms", "mc_ms",
-                  "sweep_min_bytes"):
+                  "sweep_min_bytes", "walk_loads", "walk_load_lanes"):
             acc[k] += getattr(st, k)
         acc["queries"] += nq
         acc["call_ms"] += st.total_ms
@@ -404,10 +407,12 @@ def main():
             "avg_rounds": round(acc["rounds"] / nq, 2),
             "kernel_ms_per_query": {pkg.KERNEL_NAMES[c]: round(acc["class_ms"][c] / nq, 3)
                                     for c in (1, 2, 3, 5, 6) if acc["class_launches"][c]},
-            "host_gap": host_gap(1e3 * elapsed / (args.steps * q), kernel_ms / nq),
+            "kernel_class_time": host_gap(1e3 * elapsed / (args.steps * q), kernel_ms / nq),
             "dense_levels_per_query": round(acc["dense_levels"] / nq, 1),
             "levels_per_query": round(acc["levels"] / nq, 1),
             "walks_per_query": int(acc["walks"] / nq),
+            "walk_steps_G_per_s": round(acc["walk_steps"] / (acc["class_ms"][3] / 1e3) / 1e9, 2) if acc["class_ms"][3] > 0 else None,
+            "walk_lanes_per_load": round(acc["walk_load_lanes"] / max(1, acc["walk_loads"]), 2),
             "graph_lift_s": {"generate_and_csr": round(t_gen, 2), "upload_and_tile": round(t_lift, 2)},
             "self_check": check,
             "roofline": roofline,
@@ -416,6 +421,7 @@ def main():
             out["all_pair_scaling"] = all_pair_scaling
         extras = solo and not args.no_extras
         if extras:
+            out.update(q50_sample(pkg, g, store, rng, live_ids, conf, value))
             out.update(delivery_samples(pkg, g, store, rng, live_ids, host, conf, q))
             note("delivery samples done")
             out["one_query_at_a_time"] = single_mode_sample(pkg, g, srcs[args.warmup], conf, args, host)
@@ -437,6 +443,10 @@ def main():
             if r24_child is not None and "error" not in out["all_pair_rmat24"]:
                 rmat24_counters(out["all_pair_rmat24"], out["roofline"].get("fetch_size_calibration"))
                 note("R-MAT 24 counter passes done")
+            idle = stream_idle(args)
+            out["compute_stream_idle_frac"] = idle.get("compute_stream_idle_frac")
+            out["stream_occupancy"] = idle
+            note("kernel-trace pass done")
         if cpu_child is not None:
             note("waiting for the CPU baseline child")
             out["cpu_baseline"] = finish_cpu_baseline(cpu_child)
@@ -452,17 +462,29 @@ def main():
 
 
 def host_gap(wall_ms, kernel_ms):
-    """Wall time per query against the HIP-event time of all kernel classes.  Since round 3 a query's walk phase runs
-    beside the other queries' sweeps, so the classes' times can add up to more than the wall time: the line then
-    reports the overlap instead of a gap."""
-    out = {"wall_ms_per_query": round(wall_ms, 3), "kernel_ms_per_query": round(kernel_ms, 3)}
-    if kernel_ms <= wall_ms:
-        out["fraction_not_in_kernels"] = round(1.0 - kernel_ms / wall_ms, 4)
-    else:
-        out["fraction_not_in_kernels"] = 0.0
-        out["kernel_overlap"] = round(kernel_ms / wall_ms, 3)
-        out["note"] = "walk phases run on a side stream beside the sweeps: the kernel classes overlap (sum / wall > 1)"
-    return out
+    """Wall time per query beside the summed HIP-event time of all kernel classes.  Since round 3 a query's walk phase
+    runs on a side stream beside the other queries' sweeps, so the classes overlap and their sum says nothing about
+    idle time; `compute_stream_idle_frac` (a kernel trace of the same workload, stream_idle) does."""
+    return {"wall_ms_per_query": round(wall_ms, 3), "kernel_ms_per_query_all_classes": round(kernel_ms, 3),
+            "class_time_over_wall": round(kernel_ms / wall_ms, 3) if wall_ms > 0 else None,
+            "note": "classes overlap (walks beside sweeps): idle time is compute_stream_idle_frac / stream_occupancy"}
+
+
+def q50_sample(pkg, g, store, rng, live_ids, conf, value_128, calls=6):
+    """Config #4 as the reference runs it: 50 sources per call (PPR.java:179, Gen_Util.java:208-232 loops them), the
+    calls one after another; outside the timed region.  50 = 3 x 16 + 2: the last queries of every call run with
+    free slots beside them, which the 128-query steps of the headline dilute."""
+    q = 50
+    srcs = live_draw(rng, live_ids, (calls + 1, q))
+    g.fora_batch_single_source(srcs[0], EPS, ALPHA, seed=21, k=TOPK, conf=conf, keep=store)
+    t0 = time.perf_counter()
+    for i in range(1, calls + 1):
+        g.fora_batch_single_source(srcs[i], EPS, ALPHA, seed=21 + i, k=TOPK, conf=conf, keep=store)
+    dt = time.perf_counter() - t0
+    v = calls * q / dt
+    return {"value_q50": round(v, 3),
+            "value_q50_note": "%d calls of 50 live sources each (config #4's call shape, PPR.java:179), %.1f ms per call; "
+                              "%.3f of the rate of the %d-query steps" % (calls, 1e3 * dt / calls, v / value_128, 128)}
 
 
 def delivery_samples(pkg, g, store, rng, live_ids, host, conf, q):
@@ -498,6 +520,7 @@ def single_mode_sample(pkg, g, srcs, conf, args, host, count=32):
     sample = [int(s) for s in srcs[:count]]
     g.fora_single_source(sample[0], EPS, ALPHA, seed=1, n_rounds=args.rounds, conf=conf, fetch=False)
     ms, by, n_lv, dl, de, mb = 0.0, 0, 0, 0, 0, 0
+    wsteps, wloads, wlanes = 0, 0, 0
     cls = {1: 0.0, 2: 0.0, 3: 0.0}
     t0 = time.perf_counter()
     for j, s in enumerate(sample):
@@ -508,6 +531,9 @@ def single_mode_sample(pkg, g, srcs, conf, args, host, count=32):
         dl += st.dense_levels
         de += st.dense_edges
         mb += st.sweep_min_bytes
+        wsteps += st.walk_steps
+        wloads += st.walk_loads
+        wlanes += st.walk_load_lanes
         for c in cls:
             cls[c] += st.class_ms[c]
     dt = time.perf_counter() - t0
@@ -519,6 +545,8 @@ def single_mode_sample(pkg, g, srcs, conf, args, host, count=32):
             "ms_per_query": round(1e3 * dt / len(sample), 3),
             "kernel_ms_per_query": {pkg.KERNEL_NAMES[c]: round(v / len(sample), 3) for c, v in cls.items()},
             "dense_levels_per_query": round(dl / len(sample), 1),
+            "walk_steps_G_per_s": round(wsteps / (cls[3] / 1e3) / 1e9, 2) if cls[3] > 0 else None,
+            "walk_lanes_per_load": round(wlanes / max(1, wloads), 2),
             "roofline": {"bound": "hbm", "kernel": "dense_pull", "achieved": round(comp, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(comp / HBM_PEAK_GBS, 4),
                          "frac_basis": "compulsory bytes (no counters in this run)", "traffic": None, "launches": n_lv,
@@ -971,6 +999,92 @@ def pmc_child(args):
     mark()
     store.close()
     g.close()
+
+
+def trace_child(args):
+    """What the kernel-trace pass profiles: the headline path as the timed region runs it - warm-up, a marker kernel, two
+    steps of --queries-per-step live sources through pprhip_fora_batch_single_source_resident, a marker."""
+    import torch  # noqa: F401
+    pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
+    host = load_host(pkg, args.scale)
+    live_ids = np.nonzero(np.diff(host.out_rp) > 0)[0]
+    rng = np.random.default_rng(2)
+    srcs = live_draw(rng, live_ids, (args.warmup + args.steps, args.queries_per_step))
+    g = pkg.Graph(host, device=0)
+    conf = pkg.conf_whole_graph(host.n, host.m, ALPHA)
+    tuning = pkg.tuning_batch()
+    for kv in filter(None, args.tuning.split(",")):
+        key, val = kv.split("=")
+        setattr(tuning, key, type(getattr(tuning, key))(float(val)))
+    g.set_tuning(tuning)
+    store = pkg.Results(g, args.queries_per_step)
+    g.fora_batch_single_source(srcs[0], EPS, ALPHA, seed=3, k=TOPK, conf=conf, keep=store)
+    g.random_walks(np.array([int(srcs[0][0])], dtype=np.int32), np.array([0], dtype=np.uint64), ALPHA, seed=1)
+    for i in (args.warmup, args.warmup + 1):
+        g.fora_batch_single_source(srcs[min(i, len(srcs) - 1)], EPS, ALPHA, seed=3 + i, k=TOPK, conf=conf, keep=store)
+    g.random_walks(np.array([int(srcs[0][0])], dtype=np.int32), np.array([0], dtype=np.uint64), ALPHA, seed=1)
+    store.close()
+    g.close()
+
+
+def stream_idle(args):
+    """compute_stream_idle_frac of the headline path: 1 - (union of the kernel intervals on the compute stream / wall
+    time), from a `rocprofv3 --kernel-trace` child pass over two steps of the timed region's workload (trace_child).
+    The compute stream is the one the batched sweeps (k_dense_edges_b) run on; the walk phases run on a side stream
+    beside it, whose busy share is reported as well."""
+    if shutil.which("rocprofv3") is None:
+        return {"source": "unmeasured: rocprofv3 not on PATH"}
+    work = tempfile.mkdtemp(prefix="pprhip_trace_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", work, "--", sys.executable,
+               os.path.abspath(__file__), "--trace-child", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--queries-per-step", str(args.queries_per_step), "--scale", str(args.scale)]
+        if args.tuning:
+            cmd += ["--tuning", args.tuning]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=300)
+        files = glob.glob(os.path.join(work, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return {"source": "unmeasured: rocprofv3 --kernel-trace failed (rc %d): %s" % (r.returncode, r.stderr.decode()[-200:])}
+        rows = list(csv.DictReader(open(files[0])))
+    except Exception as e:  # noqa: BLE001
+        return {"source": "unmeasured: %s" % str(e)[:200]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    key = "Stream_Id" if rows and "Stream_Id" in rows[0] and len({x["Stream_Id"] for x in rows}) > 1 else "Queue_Id"
+    rows.sort(key=lambda x: int(x["Start_Timestamp"]))
+    marks = [i for i, x in enumerate(rows) if _short(x["Kernel_Name"]) == MARK]
+    if len(marks) < 2:
+        return {"source": "unmeasured: the trace does not hold the two marker kernels"}
+    region = rows[marks[-2] + 1:marks[-1]]
+    sweeps = [x for x in region if _short(x["Kernel_Name"]).startswith("k_dense_edges_b")]
+    if not sweeps:
+        return {"source": "unmeasured: no batched sweep in the traced region"}
+    main = max({x[key] for x in sweeps}, key=lambda q: sum(1 for x in sweeps if x[key] == q))
+    t0 = min(int(x["Start_Timestamp"]) for x in region)
+    t1 = max(int(x["End_Timestamp"]) for x in region)
+
+    def union(sel):
+        iv = sorted((int(x["Start_Timestamp"]), int(x["End_Timestamp"])) for x in sel)
+        busy, cur_lo, cur_hi = 0, None, None
+        for lo, hi in iv:
+            if cur_hi is None or lo > cur_hi:
+                if cur_hi is not None:
+                    busy += cur_hi - cur_lo
+                cur_lo, cur_hi = lo, hi
+            else:
+                cur_hi = max(cur_hi, hi)
+        return busy + (cur_hi - cur_lo if cur_hi is not None else 0)
+
+    wall = max(1, t1 - t0)
+    on_main = [x for x in region if x[key] == main]
+    others = [x for x in region if x[key] != main]
+    return {"source": "rocprofv3 --kernel-trace child pass over two steps of the headline workload; intervals grouped by %s" % key,
+            "compute_stream_idle_frac": round(1.0 - union(on_main) / wall, 4),
+            "any_stream_idle_frac": round(1.0 - union(region) / wall, 4),
+            "side_streams_busy_frac": round(union(others) / wall, 4),
+            "wall_ms": round(wall / 1e6, 2), "kernels_on_compute_stream": len(on_main), "kernels_on_side_streams": len(others),
+            "queries": 2 * args.queries_per_step}
 
 
 def _pmc_pass(counters, args, workdir):

@@ -242,7 +242,10 @@ int pprhip_fora_single_source(pprhip_graph_t* g, int32_t src, double eps, const 
 /* Fora_Topk.computeTopKPPR + getTopKNodeIds (Fora_Topk.java:82-199).  Writes at most `cap`
  * (id, value) pairs ordered by value descending then id ascending; *n_out is the number the
  * reference's rule selects (all entries >= the k-th value, can exceed k on ties) and can exceed
- * cap.  reserve_out may be NULL. */
+ * cap.  reserve_out may be NULL.  After the call pprhip_get_reserve returns the estimate of the last round (what
+ * reserve_out receives); the push state behind it (pprhip_get_residue, a following pprhip_fwdpush_topk_round) is
+ * undefined: the engine may have pushed one threshold further than the last round the reference would run
+ * (the next round's push runs ahead, beside the walks, and is dropped when the round is not needed). */
 int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fora_conf_t* conf, uint64_t seed,
                      int32_t* ids_out, double* vals_out, int cap, int* n_out, double* reserve_out,
                      pprhip_stats_t* stats);

@@ -84,6 +84,7 @@ EXPORTS = [
 COMM_ID_BYTES = 128
 
 _lib = None
+_LIVE = {}
 
 
 def lib():
@@ -170,6 +171,10 @@ def lib():
     L.pprhip_index_destroy.restype = None
     L.pprhip_power_method.argtypes = [vp, i32, dbl, ci, vp, P(Stats)]
     _lib = L
+    # the destroy entry points, reachable from destructors that run while the interpreter shuts down (the name `lib`
+    # may already be None then: "TypeError: 'NoneType' object is not callable" out of Index.__del__, round 3)
+    _LIVE.update(graph_destroy=L.pprhip_graph_destroy, results_destroy=L.pprhip_results_destroy,
+                 comm_destroy=L.pprhip_comm_destroy)
     return L
 
 
@@ -313,6 +318,7 @@ class Index:
 
     def __init__(self, handle):
         self.h = handle
+        self._destroy = lib().pprhip_index_destroy  # kept: at interpreter shutdown the module's globals may be gone
 
     def arrays(self):
         n, e = C.c_uint32(), C.c_uint64()
@@ -331,12 +337,15 @@ class Index:
         _check(lib().pprhip_index_write_dir(self.h, path.encode()))
 
     def close(self):
-        if self.h:
-            lib().pprhip_index_destroy(self.h)
+        if getattr(self, "h", None):
+            self._destroy(self.h)
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (a destructor at interpreter shutdown must not raise)
+            pass
 
 
 def index_from_arrays(n, offsets, targets, values):
@@ -429,11 +438,14 @@ class Comm:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().pprhip_comm_destroy(self.h)
+            _LIVE["comm_destroy"](self.h)
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def fora_batch_multi(graphs, srcs, k, eps, alpha, seed, n_rounds=0, conf=None):
@@ -488,11 +500,14 @@ class Results:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().pprhip_results_destroy(self.h)
+            _LIVE["results_destroy"](self.h)
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class Graph:
@@ -506,7 +521,7 @@ class Graph:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().pprhip_graph_destroy(self.h)
+            _LIVE["graph_destroy"](self.h)
             self.h = None
 
     RELEASE_ALL_PAIR, RELEASE_BATCH = 1, 2
@@ -516,7 +531,10 @@ class Graph:
         _check(lib().pprhip_graph_release(self.h, what))
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def __enter__(self):
         return self

@@ -483,16 +483,36 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     // the round-cut check looks at the state after exactly one sparse level
     const bool cut_check = cut && cut->enabled && cut->had_dense && !cut->checked;
     const int n_batch = cut_check ? 1 : kMaxBatch;
+    // The batch's levels in ONE launch (k_sparse_levels) where a grid of modest size serves them: the launch's
+    // workgroups meet at a barrier between the steps, so all of them have to be resident - at most half the CUs'
+    // worth for a query that has the stream to itself, eight for a slot whose fifteen neighbours launch theirs at
+    // the same time.  A level too large for that (or for the grid the launch was given: edge_cap) runs as launches
+    // per step, as all of them did before round 4.  PPRHIP_SPARSE_LEVELS=0 (test switch) keeps that form throughout.
+    const char* lv_env = getenv("PPRHIP_SPARSE_LEVELS");
+    const bool levels_on = !(lv_env && lv_env[0] == '0');
+    const uint32_t g_max = g->sync ? 8u : (uint32_t)std::max(1, std::min(g->n_cus / 2, 128));
+    const uint64_t need_g = std::max<uint64_t>(std::max<uint64_t>((L.ef + 4095) / 4096, ((uint64_t)L.nf + 2047) / 2048), 1);
+    const bool one_launch = levels_on && need_g <= 4ull * g_max;
+    const uint32_t lv_grid = (uint32_t)std::min<uint64_t>(need_g, g_max);
+    const unsigned long long edge_cap = one_launch ? 16384ull * lv_grid : ~0ull;
     ktimer().begin(PPRHIP_KERNEL_SPARSE_PUSH, 0);
-    for (int i = 0; i < n_batch; ++i) {
-      const int fb = L.fcur ^ (i & 1);
-      if (!(i == 0 && first_prepared))
-        PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot,
-                                         i == 0 ? pk0 : ~0ull));
-      PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot, i == 0 ? pk0 : ~0ull));
+    if (one_launch) {
+      PPRHIP_TRY(launch_sparse_levels(g, a, L.fcur, n_batch, first_prepared, lv_grid, edge_cap, dense_thresh, L.dslot, pk0));
+    } else {
+      for (int i = 0; i < n_batch; ++i) {
+        const int fb = L.fcur ^ (i & 1);
+        if (!(i == 0 && first_prepared))
+          PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot,
+                                           i == 0 ? pk0 : ~0ull));
+        PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot, i == 0 ? pk0 : ~0ull));
+      }
     }
     ktimer().end();
-    PPRHIP_TRY(fetch_small(g, &g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long) * (kMaxBatch + 1)));
+    PPRHIP_TRY(fetch_small(g, &g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long) * (kLvAbortCell + 1)));
+    if (g->h_ctr->hist[kLvAbortCell]) {
+      set_error("sparse levels: a workgroup waited more than 4 s at the launch's barrier (launch aborted)");
+      return PPRHIP_ERR_STATE;
+    }
     uint64_t batch_bytes = 0;
     int ran = 0;
     for (int i = 0; i < n_batch; ++i) {
@@ -503,6 +523,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
         bool d2 = false;
         const double ci = level_cost(g, nf_i, ef_i, &d2);
         if (nf_i == 0 || (d2 && !sparse_only)) break;  // the device stopped here too (level_runs)
+        if (ef_i > edge_cap) break;                    // ... or left the level to a larger grid (k_sparse_levels)
         if (model_cost) *model_cost += ci;
       } else if (model_cost) {
         *model_cost += c;
@@ -1904,6 +1925,17 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
   const bool spec_on = !(spec_env && spec_env[0] == '0') && ensure_spec(g) == PPRHIP_OK;
   bool pushed_ahead = false;        // this round's push, residue sum and walk plan have already run (second stream)
   bool ahead_discarded = false;     // the last push ahead was not needed
+  // A push queued ahead on the second stream works on this handle's residues, reserve and lists: whatever way this
+  // function is left - an error return from any call below included - nothing may follow on the compute stream (the
+  // next query's reset first of all) before that push has ended.  Joined: the compute stream waits for spec_ev[1]
+  // (the round is taken, or the unused push is waited for at the end); otherwise the guard drains the second stream.
+  struct SpecJoin {
+    pprhip_graph* g;
+    bool pending = false;
+    ~SpecJoin() {
+      if (pending && g->spec_stream) (void)hipStreamSynchronize(g->spec_stream);
+    }
+  } spec_join{g};
   unsigned long long dead_before_ahead = 0;
   int nsel_round = 0;
   double kth_prev = -1.0;  // the k-th estimate of the round before (none yet)
@@ -1921,6 +1953,7 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
     if (!spec_on) (void)hipEventRecord(g->ev[1], g->stream);
     if (pushed_ahead) {
       PPRHIP_CHECK_HIP(hipStreamWaitEvent(g->stream, g->spec_ev[1], 0));
+      spec_join.pending = false;
     } else {
       PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax_local, st, kSumLaunch));  // :137; the residue sum stays on the device
       // :148-151: the plan derives rsum and the walk budget from the sum on the device; :143 the estimate := copy of
@@ -1958,6 +1991,7 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
       rmax_next *= std::sqrt((double)conf->m * rmax_next) * 3.0;
       SpecContext ctx(g);  // g->stream, the mail and the calling thread's timer are the second stream's until it ends
       PPRHIP_CHECK_HIP(hipStreamWaitEvent(g->stream, g->spec_ev[0], 0));
+      spec_join.pending = true;  // (from the first launch on the second stream on)
       PPRHIP_TRY(fetch_small(g, &g->ctr->dead_pops, &dead_before_ahead, sizeof dead_before_ahead));
       PPRHIP_TRY(topk_round_impl(g, min_rmax, rmax_next, st_ahead, kSumLaunch));
       PPRHIP_TRY(launch_walk_plan(g, 1, alpha, 0.0, 0, g->est, omega_next));
@@ -1999,7 +2033,10 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
     PPRHIP_CHECK_HIP(hipMemsetAsync(g->est, 0, nd, g->stream));
   }
   g->result_in_est = true;
-  if (ahead_discarded) PPRHIP_CHECK_HIP(hipStreamWaitEvent(g->stream, g->spec_ev[1], 0));  // before the next query clears
+  if (ahead_discarded) {  // before the next query clears
+    PPRHIP_CHECK_HIP(hipStreamWaitEvent(g->stream, g->spec_ev[1], 0));
+    spec_join.pending = false;
+  }
   PPRHIP_TRY(read_dead_pops(g, st));
   if (ahead_discarded && st.dead_end_pops >= dead_before_ahead) {  // the unused push's dead-end pops are not the query's
     st.push_bytes -= 16ull * (st.dead_end_pops - dead_before_ahead);

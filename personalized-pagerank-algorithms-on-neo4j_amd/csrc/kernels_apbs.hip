@@ -384,6 +384,8 @@ constexpr int kDnStage = 1024;      // frontier entries staged in LDS at a time
 constexpr int kDnIlp = 4;           // edges a thread keeps in flight
 constexpr uint32_t kDnChunkDefault = 32768;  // edges per chunk of a level's edge space (tests shrink it)
 constexpr uint32_t kDnShareMin = 4;          // levels of at least this many chunks are posted
+constexpr int kDnHotDefault = 8192;          // ids whose residue and reserve live in the owner's LDS (16 bytes each)
+constexpr int kDnHotMax = 8192;
 constexpr unsigned long long kDnWaitTicks = 3000000000ull;  // 30 s of the 100 MHz clock: no wait in the kernel is longer
 uint32_t apbs_default_chunk() { return kDnChunkDefault; }
 
@@ -487,15 +489,23 @@ struct DnSinks {
   uint32_t* giveup;  // a list is full
 };
 
+// Ids below `hot_n` - in the internal order the nodes with the most out-edges, the destinations of a third of all
+// in-edges (tools/exp/apbs_levels.c: 34 % of a dense-tier search's edges end below 8 K, 42 % below 16 K) - have their
+// residue and reserve in the OWNER's LDS for the whole search (hres / hrsv): an edge to one of them is a returning
+// ds_add_f64 instead of a memory-side read-modify-write, it needs no entry in the clean-up list, and a pop of one
+// reads LDS.  Only the owner can reach its LDS, so a level that is posted for helpers moves the hot residues into
+// the (all-zero) head of the global vector first and back afterwards (dn_hot_spill / dn_hot_fill); while a level is
+// shared, hot and cold destinations alike take the memory-side atomic.
+//
 // Edges [lo, hi) of a level's edge space, which the `cnt` entries staged in L cover: every edge is ONE returning atomic
 // on the residue vector; residues that leave zero and nodes that cross the threshold are appended to the search's
 // lists.  Called by all threads of a workgroup with workgroup-uniform arguments.
 // kWgAgg (shared levels, whose counters are global words that every helper of the owner adds to): the workgroup's
-// waves reserve their clean-up slots with ONE atomic per pass instead of one each.
+// waves reserve their clean-up slots with ONE atomic per pass instead of one each; hres == nullptr there.
 template <bool kWgAgg>
 __device__ __forceinline__ void dn_edge_range(const DenseWs& W, DnLds& L, uint32_t cnt, uint32_t lo, uint32_t hi,
                                               int32_t* nxt, const DnSinks& S, const InRec* __restrict__ in_rec,
-                                              double rmax, uint32_t cap_t, uint32_t cap_f) {
+                                              double rmax, uint32_t cap_t, uint32_t cap_f, double* hres, uint32_t hot_n) {
   const int tid = threadIdx.x, lane = lane_id();
   // wave-uniform trip count (the appends below are wave-aggregated)
   for (unsigned long long base0 = lo; base0 < hi; base0 += kDnThreads * kDnIlp) {
@@ -522,15 +532,19 @@ __device__ __forceinline__ void dn_edge_range(const DenseWs& W, DnLds& L, uint32
     for (int q = 0; q < kDnIlp; ++q) {
       add[q] = add[q] / (double)rc4[q].dout;  // :84-85, every edge's quotient rounds on its own
       old[q] = 0.0;
-      if (rc4[q].u >= 0) old[q] = atomic_add_ret(&W.res[rc4[q].u], add[q]);
+      if (rc4[q].u >= 0) {
+        if (!kWgAgg && (uint32_t)rc4[q].u < hot_n) old[q] = atomic_add_ret(&hres[rc4[q].u], add[q]);  // ds_add_rtn_f64
+        else old[q] = atomic_add_ret(&W.res[rc4[q].u], add[q]);
+      }
     }
     // a residue that leaves zero: the node is remembered for the clean-up (a node popped in between is listed twice,
-    // which only clears it twice).  One reservation per wave for the kDnIlp edges of its lanes.
+    // which only clears it twice); hot ids are cleared as a range.  One reservation per wave for the kDnIlp edges of
+    // its lanes.
     unsigned long long fm[kDnIlp];
     uint32_t tot = 0;
 #pragma unroll
     for (int q = 0; q < kDnIlp; ++q) {
-      fm[q] = __ballot(rc4[q].u >= 0 && old[q] == 0.0);
+      fm[q] = __ballot(rc4[q].u >= 0 && (uint32_t)rc4[q].u >= hot_n && old[q] == 0.0);
       tot += (uint32_t)__popcll(fm[q]);
     }
     uint32_t wb = 0;
@@ -571,12 +585,34 @@ __device__ __forceinline__ void dn_edge_range(const DenseWs& W, DnLds& L, uint32
   }
 }
 
+// The owner's hot residues move into the head of its global vector before a level is posted for helpers (the head is
+// all-zero: hot ids never take the global atomic while a search is on its own), and back - leaving the head zero again -
+// when the level has closed.  Called by all threads of the owner's workgroup.
+__device__ __forceinline__ void dn_hot_spill(const DenseWs& W, double* hres, uint32_t hot_n) {
+  for (uint32_t s = threadIdx.x; s < hot_n; s += kDnThreads) {
+    const double v = hres[s];
+    if (v != 0.0) {
+      dn_store(&W.res[s], v);
+      hres[s] = 0.0;
+    }
+  }
+}
+__device__ __forceinline__ void dn_hot_fill(const DenseWs& W, double* hres, uint32_t hot_n) {
+  for (uint32_t s = threadIdx.x; s < hot_n; s += kDnThreads) {
+    const double v = dn_load(&W.res[s]);
+    if (v != 0.0) {
+      hres[s] = v;
+      dn_store(&W.res[s], 0.0);
+    }
+  }
+}
+
 // One chunk [c * chunk, ...) of a POSTED level's edge space, read from the owner's level layout in HBM; appends through
 // the owner's board entry.  Called by all threads of a workgroup (the owner's or a helper's); which / nf / E / c must
 // be workgroup-uniform (the callers hand them round through LDS): the loops below hold barriers.
 __device__ __forceinline__ void dn_chunk(const DenseWs& W, DnBoard* B, uint32_t which, uint32_t nf, uint32_t E,
                                          uint32_t c, const InRec* __restrict__ in_rec, double rmax, const DnDims& D,
-                                         DnLds& L) {
+                                         DnLds& L, uint32_t hot_n) {
   const int tid = threadIdx.x;
   const uint32_t chunk_lo = c * D.chunk;
   const uint32_t chunk_hi = (E - chunk_lo > D.chunk) ? chunk_lo + D.chunk : E;
@@ -598,7 +634,7 @@ __device__ __forceinline__ void dn_chunk(const DenseWs& W, DnBoard* B, uint32_t 
     __syncthreads();
     const uint32_t cov_hi = L.eoff[cnt] < chunk_hi ? L.eoff[cnt] : chunk_hi;
     if (cov_hi <= ce) break;  // (cannot happen: the staged entries cover ce; a guard against looping on bad data)
-    dn_edge_range<true>(W, L, cnt, ce, cov_hi, W.fr[which ^ 1], S, in_rec, rmax, D.cap_t, D.cap_f);
+    dn_edge_range<true>(W, L, cnt, ce, cov_hi, W.fr[which ^ 1], S, in_rec, rmax, D.cap_t, D.cap_f, nullptr, hot_n);
     ce = cov_hi;
     i0 += cnt;
   }
@@ -615,7 +651,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
                                                             unsigned long long* done_targets,
                                                             unsigned long long* n_open,
                                                             unsigned long long* abort_word, DnDims D, int share,
-                                                            uint32_t n_owners,
+                                                            uint32_t n_owners, uint32_t hot_n,
                                                             unsigned long long* __restrict__ dbg) {
   // n_owners: the workgroups 0 .. n_owners - 1 have a workspace and take targets; the others only help with posted
   // levels (the pass for the few searches whose lists need room for every node: a handful of full-size workspaces,
@@ -624,6 +660,11 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
   // searches, ticks of the 100 MHz clock spent in pops + scans, own edges, waiting for helpers, emission, clean-up,
   // helping / idle, the tick at which the workgroup ended, and where it is: stage << 32 | detail (printed by the
   // host's watchdog when a launch does not come back)}
+  // hot_n: ids below it keep residue and reserve in this workgroup's LDS while it owns a search (dn_edge_range);
+  // dynamic LDS: hres[hot_n], hrsv[hot_n]
+  extern __shared__ double dn_hot[];
+  double* const hres = dn_hot;
+  double* const hrsv = dn_hot + hot_n;
   __shared__ DnLds L;
   __shared__ uint32_t s_scan[kDnWaves];
   __shared__ unsigned long long s_scan64[kDnWaves];
@@ -648,6 +689,8 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     __hip_atomic_store(dbg + (size_t)blockIdx.x * 12 + 9, ((unsigned long long)(stage) << 32) | (uint32_t)(detail), \
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   uint32_t seq = 0;  // even: this workgroup's board entry is closed
+  for (uint32_t i = tid; i < 2 * hot_n; i += kDnThreads) dn_hot[i] = 0.0;
+  __syncthreads();
 
   for (;;) {
     if (blockIdx.x >= n_owners) break;
@@ -677,14 +720,23 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
       s_pcount = 0;
       s_tcount = 0;
       s_giveup = 0;
+      const bool hot_t = (uint32_t)t < hot_n;
       if (in_rp[t + 1] == in_rp[t]) {  // Backward_Search.java:46-49: reserve = {t: 1.0}
-        dn_store(&W.rsv[t], 1.0);
-        dn_store(&W.plist[0], t);
-        s_pcount = 1;
+        if (hot_t) {
+          hrsv[t] = 1.0;
+        } else {
+          dn_store(&W.rsv[t], 1.0);
+          dn_store(&W.plist[0], t);
+          s_pcount = 1;
+        }
       } else {
-        dn_store(&W.res[t], 1.0);  // :54-56; the target is pushed unconditionally first
-        dn_store(&W.touched[0], t);
-        s_tcount = 1;
+        if (hot_t) {
+          hres[t] = 1.0;  // :54-56; the target is pushed unconditionally first
+        } else {
+          dn_store(&W.res[t], 1.0);
+          dn_store(&W.touched[0], t);
+          s_tcount = 1;
+        }
         dn_store(&W.fr[0][0], t);
         nf = 1;
       }
@@ -712,14 +764,21 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
         double pc = 0.0;
         if (i < nf) {
           const int32_t v = dn_load(&cur[i]);
-          const double rc = __hip_atomic_exchange(&W.res[v], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const double r0 = dn_load(&W.rsv[v]);
-          if (r0 == 0.0) {  // first pop of this node (alpha * rc > 0 ever after)
-            const uint32_t pp = atomicAdd(&s_pcount, 1u);
-            if (pp < cap_f) dn_store(&W.plist[pp], v);
-            else s_giveup = 1;
+          double rc;
+          if ((uint32_t)v < hot_n) {  // (a node is in a level's frontier once: plain LDS accesses)
+            rc = hres[v];
+            hres[v] = 0.0;
+            hrsv[v] = hrsv[v] + rc * alpha;
+          } else {
+            rc = __hip_atomic_exchange(&W.res[v], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double r0 = dn_load(&W.rsv[v]);
+            if (r0 == 0.0) {  // first pop of this node (alpha * rc > 0 ever after)
+              const uint32_t pp = atomicAdd(&s_pcount, 1u);
+              if (pp < cap_f) dn_store(&W.plist[pp], v);
+              else s_giveup = 1;
+            }
+            dn_store(&W.rsv[v], r0 + rc * alpha);
           }
-          dn_store(&W.rsv[v], r0 + rc * alpha);
           pc = (1.0 - alpha) * rc;
           b = in_rp[v];
           d = in_rp[v + 1] - b;
@@ -757,7 +816,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
         __syncthreads();
         DN_TICK(0)
         DN_AT(5, E)
-        dn_edge_range<false>(W, L, nf, 0u, E, W.fr[which ^ 1], S_local, in_rec, rmax, cap_t, cap_f);
+        dn_edge_range<false>(W, L, nf, 0u, E, W.fr[which ^ 1], S_local, in_rec, rmax, cap_t, cap_f, hres, hot_n);
         dn_barrier_global();  // the appends have arrived before the next level reads them
         DN_TICK(1)
         if (tid == 0) {
@@ -777,6 +836,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
             for (uint32_t c = c_lo; c <= c_hi; ++c) dn_store(&W.cstart[c], (uint32_t)tid);
           }
         }
+        dn_hot_spill(W, hres, hot_n);  // helpers reach the hot residues through the global vector only
         if (tid == 0) {
           dn_store(&W.eoff[nf], E);
           // the appends of a posted level are counted on the board entry (helpers add to them)
@@ -806,7 +866,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
         for (uint32_t c = s_job[0]; c < n_chunks; c = s_job[0]) {
           __syncthreads();  // s_job[0] has been read by every wave
           DN_AT(3, c)
-          dn_chunk(W, B, which, nf, E, c, in_rec, rmax, D, L);
+          dn_chunk(W, B, which, nf, E, c, in_rec, rmax, D, L, hot_n);
           if (tid == 0) {  // (dn_chunk ended with every wave's stores acknowledged)
             atomicAdd(&B->done, 1u);
             s_job[0] = (uint32_t)atomic_add_u64(&B->next, 1ull);
@@ -832,6 +892,9 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
           s_gaveup = (s_giveup || dn_load(abort_word)) ? 1u : 0u;
           s_job[0] = s_gaveup ? 0u : dn_load(&B->nnext);
         }
+        __syncthreads();
+        dn_hot_fill(W, hres, hot_n);  // the level is closed: hot residues back into LDS, the vector's head zero again
+        dn_barrier_global();
         DN_TICK(2)
       }
       __syncthreads();
@@ -849,11 +912,13 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     // ---- emit entries >= threshold (Base_Whole_Graph.java:80-88): only popped nodes hold a reserve
     bool retry = gave_up;
     if (!gave_up) {
+      // (positions [0, np): the popped cold nodes; [np, np + hot_n): the hot ids, whose reserve is in LDS)
       unsigned long long run = 0;
-      for (uint32_t c0 = 0; c0 < np; c0 += kDnThreads) {
+      for (uint32_t c0 = 0; c0 < np + hot_n; c0 += kDnThreads) {
         const uint32_t i = c0 + tid;
         double r = 0.0;
         if (i < np) r = dn_load(&W.rsv[dn_load(&W.plist[i])]);
+        else if (i < np + hot_n) r = hrsv[i - np];
         run += (r > 0.0 && r >= rmax) ? 1ull : 0ull;
       }
       const unsigned long long total = block_sum_u64(run, s_scan64);  // valid in thread 0
@@ -868,10 +933,10 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
         if (tid == 0) atomicMin(O.out_valid, s_out_base);
       } else {
         unsigned long long at = s_out_base;
-        for (uint32_t c0 = 0; c0 < np; c0 += kDnThreads) {
+        for (uint32_t c0 = 0; c0 < np + hot_n; c0 += kDnThreads) {
           const uint32_t i = c0 + tid;
-          const int32_t v = i < np ? dn_load(&W.plist[i]) : 0;
-          const double r = i < np ? dn_load(&W.rsv[v]) : 0.0;
+          const int32_t v = i < np ? dn_load(&W.plist[i]) : (i < np + hot_n ? (int32_t)(i - np) : 0);
+          const double r = i < np ? dn_load(&W.rsv[v]) : (i < np + hot_n ? hrsv[i - np] : 0.0);
           const bool take = r > 0.0 && r >= rmax;
           unsigned long long chunk_total = 0;
           const unsigned long long ex2 =
@@ -890,7 +955,8 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     __syncthreads();
     DN_TICK(3)
     DN_AT(7, 0)
-    // ---- hand the vectors back all-zero
+    // ---- hand the vectors back all-zero (the hot ids' state: LDS; the head of the global vector is zero already)
+    for (uint32_t i = tid; i < 2 * hot_n; i += kDnThreads) dn_hot[i] = 0.0;
     for (uint32_t i = tid; i < np; i += kDnThreads) dn_store(&W.rsv[dn_load(&W.plist[i])], 0.0);
     const uint32_t nt = s_tcount;
     if (nt <= cap_t && s_pcount <= cap_f) {
@@ -963,7 +1029,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
       if (c == 0xFFFFFFFFu) continue;  // somebody else was faster: look again
       const DenseWs OW = dense_ws_of(ws_base, owner, D);
       DN_AT(9, (owner << 16) | (c & 0xFFFFu))
-      dn_chunk(OW, OB, owhich & 1u, onf, oE, c, in_rec, rmax, D, L);
+      dn_chunk(OW, OB, owhich & 1u, onf, oE, c, in_rec, rmax, D, L, hot_n);
       DN_AT(8, 1)
       if (tid == 0) atomicAdd(&OB->done, 1u);  // (dn_chunk ended with every wave's stores acknowledged)
       __syncthreads();                         // (lane-0 blocks never sit next to a back edge)
@@ -1050,6 +1116,8 @@ int init_kernels_apbs() {  // loads this file's code object on the current devic
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_lds)));
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_dense)));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apbs_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(2 * sizeof(double) * kDnHotMax)));
   return PPRHIP_OK;
 }
 
@@ -1076,10 +1144,15 @@ int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint
     const uint32_t owners = std::min<uint32_t>(std::min<uint32_t>(b.ws_blocks, (uint32_t)kDnThreads), std::max(1u, n_targets));
     // helpers beyond the owners (b.helpers: workgroups the launch may use in all) only make sense when levels are shared
     const uint32_t grid = share ? std::max(owners, std::min<uint32_t>(b.helpers, (uint32_t)kDnThreads)) : owners;
-    k_apbs_dense<<<dim3(grid), dim3(kDnThreads), 0, g->stream>>>(
+    // ids whose residue / reserve live in the owner's LDS (dn_edge_range): 8 K by default (128 KB), at most a quarter
+    // of the graph so that small graphs still run both paths (PPRHIP_APBS_HOT: developer / test switch, 0 = none)
+    const char* he = getenv("PPRHIP_APBS_HOT");
+    uint32_t hot_n = he ? (uint32_t)std::max(0, atoi(he)) : (uint32_t)kDnHotDefault;
+    hot_n = std::min<uint32_t>(std::min<uint32_t>(hot_n, (uint32_t)kDnHotMax), g->n / 4);
+    k_apbs_dense<<<dim3(grid), dim3(kDnThreads), 2 * sizeof(double) * (size_t)hot_n, g->stream>>>(
         d_targets, n_targets, b.next_target, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O, b.ws, (DnBoard*)b.board,
         b.done_targets, b.done_targets + 1, b.done_targets + 2, dims_of(g->n, (unsigned long long)g->m, b.cap_t, b.cap_f, b.chunk), share,
-        owners, b.dbg);
+        owners, hot_n, b.dbg);
   } else {
     const uint32_t grid = std::min<uint32_t>((uint32_t)g->n_cus * 2u, std::max(1u, n_targets));
     k_apbs_lds<<<dim3(grid), dim3(256), 0, g->stream>>>(d_targets, t_begin, n_targets, b.next_target, g->in_rp, rec,

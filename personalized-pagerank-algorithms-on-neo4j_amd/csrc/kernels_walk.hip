@@ -177,14 +177,15 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
 // drains once, at the end of its share (with a workgroup per 1024 walks, as in round 2, every chunk ended in a tail
 // of ~20 steps with few lanes walking: 36 G steps/s).  The entries of the next kWalkWindow walks are staged in LDS (a window);
 // a refill reads LDS only.
-// Round 4: EVERY LOAD CARRIES A FULL WAVE.  A decision that issues no gather - the walk stops (alpha), or it stands on a
-// dead end and restarts (52 % of R-MAT 22's nodes have no out-edge) - used to cost its lane the whole trip of the
-// loop, so a wave's load carried 42 of 64 lanes, and the address path charges a load by the instruction, not by
-// the lane (chain_rate.hip reaches 56 G steps/s with full waves, this kernel reached 36-40).  Now the loop has two
-// parts: lanes take decisions (stop -> deposit -> next walk from the LDS window -> its first decision; dead end ->
-// restart -> next decision) until every lane holds the address of a gather or the wave's share has run out, and
-// only then the wave issues its load.  Decisions stay indexed per walk (Philox block k >> 1), so terminals and step
-// counts are what they were, walk by walk (test_walk_terminals_bit_exact).
+// Round 4, tried and taken back: "every load carries a full wave".  A decision that issues no gather - the walk stops
+// (alpha), or it stands on a dead end and restarts (52 % of R-MAT 22's nodes have no out-edge) - costs its lane the
+// whole trip of the loop below, so a wave's load carries 42 of 64 lanes.  A form of the loop in which lanes take
+// decisions (stop -> deposit -> next walk -> first decision; dead end -> restart -> next decision) until every lane
+// holds a gather, and only then the wave loads, carried 60.4 lanes per load (counters walk_loads / walk_lanes) and ran
+// at the SAME rate one query at a time (39.0 G steps/s, 2.54 ms per query against 2.6) and slower beside the sweeps,
+// where a walk kernel has four waves per CU and three to four decision rounds per load are not hidden (24.5 against
+// ~33 G steps/s, headline 312 against 329 queries/s): the rate is what the memory system gives this address stream,
+// not a matter of how full the loads are (gpurun_out/r04b_bench.json).
 // ------------------------------------------------------------------------------------------------
 constexpr int kWalkWindow = 128;
 constexpr uint32_t kWalkWavesBeside = 4;   // ... of a walk kernel that runs beside other queries' kernels
@@ -246,12 +247,9 @@ __global__ __launch_bounds__(64) void k_mc_walk(const WalkPlanRec* __restrict__ 
   unsigned long long steps_total = 0;
   Walker w;
   double inc = 0.0;
-  bool walking = false, pending = false;  // pending: the walk's next move is a gather of walk_rec[addr]
-  uint32_t addr = 0;
+  bool walking = false;
   unsigned long long n_loads = 0, n_lanes = 0;  // (wave-uniform) loads issued, lanes they carried
   for (;;) {
-   // ---- decisions, until every lane holds a gather or the share has run out
-   for (;;) {
     const unsigned long long need = __ballot(!walking);
     if (need && cursor < w_hi) {
       if (cursor >= win_end) {
@@ -337,50 +335,23 @@ __global__ __launch_bounds__(64) void k_mc_walk(const WalkPlanRec* __restrict__ 
         e += S.woff[jl + 1] == win_end ? jl + 1u : jl;
       }
     }
-    if (walking && !pending) {  // one decision (walker_step's, with the gather left to the wave's load below)
-      uint32_t ws, wp;
-      if ((w.k & 1u) == 0) {
-        const Philox p = philox4x32_10(w.c0, w.c1, w.c2, w.k >> 1, k0, k1);
-        ws = p.x[0];
-        wp = p.x[1];
-        w.w_stop2 = p.x[2];
-        w.w_pick2 = p.x[3];
-      } else {
-        ws = w.w_stop2;
-        wp = w.w_pick2;
-      }
-      w.k++;
-      const bool stop = !w.forced && (double)ws * (1.0 / 4294967296.0) < alpha;  // Monte_Carlo.java:76-78
-      w.forced = false;
-      if (stop) {
+    if (__ballot(walking) == 0) {
+      if (cursor >= w_hi) break;
+      continue;
+    }
+    const bool can_load = walking && w.d > 0;  // (a lane that neither stops nor stands on a dead end gathers)
+    bool stopped = false;
+    if (walking) {
+      stopped = walker_step(w, walk_rec, alpha, k0, k1);
+      if (stopped) {
         atomic_add_noret(&target[w.cur], inc);
         steps_total += w.moves;
         walking = false;
-      } else if (w.d > 0) {  // :81-86
-        addr = w.b + (uint32_t)(((unsigned long long)wp * w.d) >> 32);
-        pending = true;
-      } else {  // :87-90 dead end: restart at the walk's start node
-        w.cur = w.start;
-        w.b = w.sb;
-        w.d = w.sd;
-        w.moves++;
       }
     }
-    // again while a lane still has a decision to take, or stands idle with walks left in the share
-    if (__ballot(walking && !pending) == 0 && (__ballot(!walking) == 0 || cursor >= w_hi)) break;
-   }
-    const unsigned long long go = __ballot(pending);
-    if (go == 0) break;  // nobody walks and the share is used up
-    n_loads++;
-    n_lanes += (unsigned long long)__popcll(go);
-    if (pending) {  // the wave's load: one 16-byte edge record per lane (walker_step)
-      const uint4 r = walk_rec[addr];
-      w.cur = (int32_t)r.x;
-      w.b = r.y;
-      w.d = r.z;
-      w.moves++;
-      pending = false;
-    }
+    const unsigned long long loaded = __ballot(can_load && !stopped);
+    n_loads += loaded ? 1ull : 0ull;
+    n_lanes += (unsigned long long)__popcll(loaded);
   }
   steps_total = wave_sum_u64(steps_total);
   if (lane == 0 && steps_total) atomic_add_u64(&ctr->walk_steps, steps_total);

@@ -708,6 +708,52 @@ def test_sparse_push_lds_table(pkg, orc, rmat15, dev_rmat15, monkeypatch):
         dev_rmat15.set_tuning(pkg.tuning_default())
 
 
+@pytest.mark.parametrize("levels", ["1", "0"])
+def test_sparse_levels_in_one_launch_or_per_step(pkg, orc, rmat15, dev_rmat15, got, dev_got, monkeypatch, levels):
+    """A batch of sparse levels runs in ONE launch (k_sparse_levels: workgroups meeting at a barrier between prepare
+    and push, several levels per launch; the default) or as one launch per step (PPRHIP_SPARSE_LEVELS=0, also what a
+    level too large for the launch's grid falls back to): same levels, same counters, same vectors as the twin - for
+    the forward push (sparse levels only, and mixed with sweeps), the resumable top-k push round by round, and the
+    backward search; on GOT (levels of a handful of edges: one workgroup) and R-MAT 15 (levels of 10^5 edges: a grid)."""
+    monkeypatch.setenv("PPRHIP_SPARSE_LEVELS", levels)
+    for host, dev, rmaxes in ((got, dev_got, (7.554e-4, 1e-8)), (rmat15, dev_rmat15, (1e-5, 1e-7))):
+        og = to_oracle(orc, host)
+        od = np.diff(host.out_rp)
+        srcs = [s for s in sources(host, 12, seed=44) if od[s] > 0][:3]
+        for dense_frac in (4.0, 0.05):
+            t = pkg.tuning_default()
+            t.dense_frac = dense_frac
+            dev.set_tuning(t)
+            try:
+                for s in srcs:
+                    for rmax in rmaxes:
+                        p, r, rsum, st = dev.forward_push(s, ALPHA, rmax)
+                        po, ro, rsum_o, sto = og.forward_push(s, ALPHA, rmax, orc.SYNC)
+                        assert_close(p, po, TOL_PUSH, "reserve src=%d rmax=%g" % (s, rmax))
+                        assert_close(r, ro, TOL_PUSH, "residue src=%d rmax=%g" % (s, rmax))
+                        assert st.levels == sto.levels and st.dense_levels == sto.dense_levels
+                        assert st.pops == sto.pops and st.edge_pushes == sto.edge_pushes
+                        assert st.enqueues == sto.enqueues and st.dead_end_pops == sto.dead_end_pops
+                        assert abs(p.sum() + r.sum() - 1.0) < 1e-12
+                    # the resumable push of Fora_Topk's rounds (Forward_Push.java:144-250), thresholds falling by 4
+                    dev.topk_push_reset(s, ALPHA)
+                    tw = og.topk_push(s, ALPHA, orc.SYNC)
+                    min_rmax = rmaxes[1]
+                    for rnd in range(4):
+                        rm = rmaxes[0] / 4.0 ** rnd
+                        rs, st = dev.topk_push_round(min_rmax, rm)
+                        rs_o, sto = tw.round(min_rmax, rm)
+                        assert abs(rs - rs_o) <= 1e-12 and st.levels == sto.levels and st.pops == sto.pops
+                        assert_close(dev.reserve(), tw.reserve, TOL_PUSH, "top-k round %d reserve src=%d" % (rnd, s))
+                        assert_close(dev.residue(), tw.residue, TOL_PUSH, "top-k round %d residue src=%d" % (rnd, s))
+                    pb, rb, stb = dev.backward_push(s, ALPHA, rmaxes[0])
+                    pbo, rbo, stbo = og.backward_push(s, ALPHA, rmaxes[0], orc.SYNC)
+                    assert_close(pb, pbo, TOL_PUSH, "backward reserve target=%d" % s)
+                    assert stb.levels == stbo.levels and stb.pops + stb.dense_nodes == stbo.pops
+            finally:
+                dev.set_tuning(pkg.tuning_default())
+
+
 def test_batched_sweep_sources_without_in_edges(pkg, orc, rmat15, dev_rmat15):
     """The batched sweep carries the rows with in-edges plus the rows without in-edges that have out-edges; a source of
     the second kind holds its own contribution (and the dead-end mass that returns to it) in a row nothing else ever
