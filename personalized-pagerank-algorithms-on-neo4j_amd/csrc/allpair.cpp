@@ -356,6 +356,12 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       return rc;
     }
   }
+  // the sweep layout over the out-CSR that the whole-vector searches' dense levels need: built with the handle's other
+  // first-use work, not inside a later call's searches
+  if ((rc = ensure_bwd_layout(g)) != PPRHIP_OK) {
+    release();
+    return rc;
+  }
   const bool dbg_times = getenv("PPRHIP_APBS_DEBUG") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [&](std::chrono::steady_clock::time_point t) {
@@ -610,6 +616,51 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     if (!piped) dense_pass(to_tier2);
     // ---- the searches whose frontier or popped-node list outgrew the workspaces' lists: once more with a few
     // workspaces whose lists hold every node, all the other workgroups helping with their levels
+    st.xl_targets = (uint32_t)to_tier3.size();  // searches that outgrew a workspace's lists
+    // ---- A handful of such searches (R-MAT 22: the one target with 160 K in-edges, whose search pushes 300 M edges)
+    // run best one at a time on the handle's OWN vectors with the whole chip behind each level: levels that touch a
+    // large part of the graph as pull sweeps over the out-CSR (no atomics at all), the others as sparse pushes -
+    // pprhip_backward_push's path.  Measured (tools/exp/apbs_big_searches.py): 2.5 ms of device time for that target
+    // against 158 ms in the full-size pass below, where one workgroup owns the search and the others help with its
+    // levels at the rate of memory-side atomics.  The entries go from the reserve vector into records on the device.
+    const char* whole_env = getenv("PPRHIP_APBS_WHOLE");
+    const size_t whole_max = whole_env ? (size_t)std::max(0, atoi(whole_env)) : 256;
+    if (rc == PPRHIP_OK && !to_tier3.empty() && to_tier3.size() <= whole_max) {
+      TripleRec* d_rec = nullptr;
+      unsigned long long* d_cnt = nullptr;
+      const unsigned long long cap = std::max<uint32_t>(act_n(g), g->n);
+      auto whole = [&]() -> int {
+        PPRHIP_TRY(alloc_dev((void**)&d_rec, sizeof(TripleRec) * cap));
+        PPRHIP_TRY(alloc_dev((void**)&d_cnt, sizeof(unsigned long long)));
+        const std::vector<int32_t>& o2n = g->h_old2new;
+        for (int32_t t_old : to_tier3) {
+          pprhip_stats_t s1;
+          std::memset(&s1, 0, sizeof s1);
+          PPRHIP_TRY(backward_search_whole(g, g->relabeled ? o2n[t_old] : t_old, alpha, threshold, s1));
+          PPRHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), g->stream));
+          PPRHIP_TRY(launch_emit_reserve(g, g->reserve, g->n, threshold, t_old, d_rec, cap, d_cnt));
+          unsigned long long cnt = 0;
+          PPRHIP_CHECK_HIP(hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, g->stream));
+          PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+          if (cnt > cap) {
+            set_error("All-Pair: a search yields more entries (%llu) than the graph has nodes", cnt);
+            return PPRHIP_ERR_STATE;
+          }
+          if (cnt) PPRHIP_TRY(sink.take_device(g, d_rec, cnt));
+          st.pops += s1.pops + s1.dense_nodes;
+          st.edge_pushes += s1.edge_pushes + s1.dense_edges;
+          st.levels += s1.levels;
+          st.dense_levels += s1.dense_levels;
+          st.push_bytes += s1.push_bytes + 16ull * cnt;
+        }
+        return PPRHIP_OK;
+      };
+      rc = whole();
+      if (d_rec) (void)hipFree(d_rec);
+      if (d_cnt) (void)hipFree(d_cnt);
+      if (dbg_times) fprintf(stderr, "[apbs host] whole-vector searches: %zu targets\n", to_tier3.size());
+      to_tier3.clear();
+    }
     if (rc == PPRHIP_OK && g->apbs_blocks && !to_tier3.empty() && to_tier3.size() < to_tier2.size() &&
         !getenv("PPRHIP_APBS_NO_XL")) {
       if (!g->apbs_xl_ws) {
@@ -645,7 +696,6 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
         const uint32_t xnb = std::max(g->apbs_blocks, g->apbs_xl_blocks);
         if (xdebug && hipHostMalloc((void**)&B.dbg, sizeof(unsigned long long) * 12 * xnb, hipHostMallocMapped) == hipSuccess)
           std::memset(B.dbg, 0, sizeof(unsigned long long) * 12 * xnb);
-        st.xl_targets = (uint32_t)to_tier3.size();
         rc = run_tier(true, to_tier3, false, again3);
         if (B.dbg) {
           unsigned long long tot[8] = {0};

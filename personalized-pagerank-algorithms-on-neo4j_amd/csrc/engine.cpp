@@ -2200,3 +2200,8 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
 }
 
 }  // extern "C"
+
+// (All-Pair's whole-vector searches, allpair.cpp)
+int pprhip::detail::backward_search_whole(pprhip_graph_t* g, int32_t target, double alpha, double rmax, pprhip_stats_t& st) {
+  return backward_push_impl(g, target, alpha, rmax, st);
+}

@@ -493,6 +493,10 @@ size_t apbs_board_bytes(uint32_t blocks);
 int launch_build_in_rec(pprhip_graph* g, void* rec);                  // rec: m records of 8 bytes
 int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint32_t t_begin, uint32_t n_targets,
                 double alpha, double rmax, ApbsBuffers& b);
+// entries >= rmax of a reserve vector (internal ids [0, n)) as records of target t_old; *count counts them all, also
+// beyond cap
+int launch_emit_reserve(pprhip_graph* g, const double* reserve, uint32_t n, double rmax, int32_t t_old, TripleRec* out,
+                        unsigned long long cap, unsigned long long* count);
 
 // ---- kernels_sort.hip
 // rec[0 .. count) -> device arrays of keys (source << 32 | target) and values ordered by (source, target); the caller

@@ -270,6 +270,9 @@ struct DeviceTripleSink : TripleSink {
 };
 int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t t_begin, uint32_t t_end,
                      TripleSink& sink, pprhip_stats_t& st);
+// Backward_Search.backward_search_whole_graph on the handle's own vectors (internal id); reserve / residue stay in HBM
+int backward_search_whole(pprhip_graph_t* g, int32_t target_internal, double alpha, double rmax, pprhip_stats_t& st);
+int ensure_bwd_layout(pprhip_graph* P);
 int index_from_triples(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index_t** out);
 // the same from records in HBM: sorted by (source, target) on the device, k rule on the host; sources must lie in
 // [v_lo, v_hi)

@@ -1112,6 +1112,42 @@ int launch_owner_partition(pprhip_graph* g, const TripleRec* rec, unsigned long 
   return PPRHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// the entries of ONE whole-vector backward search (the handle's own residue / reserve vectors): reserve >= threshold
+// -> 16-byte records, one reservation per wave
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit_reserve(const double* __restrict__ reserve, uint32_t n, double rmax,
+                                                       const int32_t* __restrict__ new2old, int32_t t_old,
+                                                       TripleRec* __restrict__ out, unsigned long long cap,
+                                                       unsigned long long* __restrict__ count) {
+  const int lane = lane_id();
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t v0 = blockIdx.x * 256u; v0 < n; v0 += stride) {  // (wave-uniform trip count)
+    const uint32_t v = v0 + threadIdx.x;
+    const double r = v < n ? reserve[v] : 0.0;
+    const bool take = r > 0.0 && r >= rmax;  // Base_Whole_Graph.java:83 (only entries of the reserve map exist)
+    const unsigned long long mask = __ballot(take);
+    if (!mask) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomic_add_u64(count, (unsigned long long)__popcll(mask));
+    base = __shfl(base, 0);
+    if (take) {
+      const unsigned long long pos = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < cap) out[pos] = TripleRec{new2old ? new2old[v] : (int32_t)v, t_old, r};
+    }
+  }
+}
+
+int launch_emit_reserve(pprhip_graph* g, const double* reserve, uint32_t n, double rmax, int32_t t_old, TripleRec* out,
+                        unsigned long long cap, unsigned long long* count) {
+  if (!n) return PPRHIP_OK;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + 255) / 256, 4096);
+  k_emit_reserve<<<dim3(grid), dim3(256), 0, g->stream>>>(reserve, n, rmax, g->relabeled ? g->new2old : nullptr, t_old, out, cap,
+                                                          count);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
 int init_kernels_apbs() {  // loads this file's code object on the current device (see init_kernels_push)
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_lds)));

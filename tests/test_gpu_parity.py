@@ -427,17 +427,20 @@ def test_all_pair_tiers_rmat12(pkg, orc, rmat12, dev_rmat12, tier, monkeypatch):
         ix.close()
 
 
-@pytest.mark.parametrize("cap_t,cap_f,xl", [(8, 4096, True), (4096, 3, True), (4096, 3, False), (5, 2, False)])
-def test_all_pair_dense_tier_list_overflows(pkg, orc, rmat12, cap_t, cap_f, xl, monkeypatch):
+@pytest.mark.parametrize("cap_t,cap_f,after", [(8, 4096, "xl"), (4096, 3, "xl"), (4096, 3, "tier3"), (5, 2, "tier3"),
+                                               (4096, 3, "whole"), (5, 2, "whole")])
+def test_all_pair_dense_tier_list_overflows(pkg, orc, rmat12, cap_t, cap_f, after, monkeypatch):
     """The dense tier's lists are bounded: when the clean-up list overflows the search still finishes (the whole
-    vector is cleared instead); when a frontier or the popped-node list overflows the search is run again on one of
-    the few workspaces whose lists hold every node (the other workgroups helping), or - with that pass switched off -
-    by the whole-vector tier; and the next search of the same workgroup must find all-zero vectors either way.  A
-    fresh handle, so that the workspace is built with the shrunken lists."""
+    vector is cleared instead); when a frontier or the popped-node list overflows the search is run again - one at a
+    time on the handle's own vectors ("whole", what a handful of such searches get by default), or on one of the few
+    workspaces whose lists hold every node with the other workgroups helping ("xl": more of them than that), or - with
+    both switched off - by the whole-vector tier on the batch slots ("tier3"); and the next search of the same workgroup
+    must find all-zero vectors either way.  A fresh handle, so that the workspace is built with the shrunken lists."""
     monkeypatch.setenv("PPRHIP_APBS_TIER", "2")
     monkeypatch.setenv("PPRHIP_APBS_CAP_T", str(cap_t))
     monkeypatch.setenv("PPRHIP_APBS_CAP_F", str(cap_f))
-    if not xl:
+    monkeypatch.setenv("PPRHIP_APBS_WHOLE", "1000000" if after == "whole" else "0")
+    if after == "tier3":
         monkeypatch.setenv("PPRHIP_APBS_NO_XL", "1")
     og = to_oracle(orc, rmat12)
     with pkg.Graph(rmat12) as g:
@@ -449,17 +452,27 @@ def test_all_pair_dense_tier_list_overflows(pkg, orc, rmat12, cap_t, cap_f, xl, 
             assert np.max(np.abs(vl - ovl)) <= TOL_PUSH
             assert st.rounds == hi - lo                  # every target started in the dense tier
             if cap_f < 100:
-                assert (st.dense_nodes > 0) == (not xl)  # handed on to the whole-vector tier only without the full-size pass
+                assert st.xl_targets > 0                 # searches outgrew the lists ...
+                assert (st.dense_nodes > 0) == (after == "tier3")  # ... and reached the batch slots only with both passes off
             ix.close()
+        # a single-target search on the same handle afterwards (the whole-vector pass used its vectors)
+        p, r, _ = g.backward_push(7, ALPHA, 5e-4)
+        po, ro, _ = og.backward_push(7, ALPHA, 5e-4, orc.SYNC)
+        assert_close(p, po, TOL_PUSH, "backward search after All-Pair")
 
 
+@pytest.mark.parametrize("hot", [None, "0", "64"])
 @pytest.mark.parametrize("chunk", [16, 256])
-def test_all_pair_dense_tier_shared_levels(pkg, orc, rmat12, chunk, monkeypatch):
+def test_all_pair_dense_tier_shared_levels(pkg, orc, rmat12, chunk, hot, monkeypatch):
     """Levels of the dense tier that span several chunks of edges are posted and idle workgroups take chunks of them
     (kernels_apbs.hip: work sharing).  With chunks of a few edges every level of every search is shared; the index
-    must not depend on who pushed which edge."""
+    must not depend on who pushed which edge.  hot: the ids whose residue and reserve live in the owner's LDS while a
+    search is on its own (default: a quarter of this small graph; none; 64) - a posted level moves them into the global
+    vector and back, so both sizes of level meet both kinds of id."""
     monkeypatch.setenv("PPRHIP_APBS_TIER", "2")
     monkeypatch.setenv("PPRHIP_APBS_CHUNK", str(chunk))
+    if hot is not None:
+        monkeypatch.setenv("PPRHIP_APBS_HOT", hot)
     og = to_oracle(orc, rmat12)
     with pkg.Graph(rmat12) as g:
         for (lo, hi), thr in (((0, 64), 2e-4), ((1000, 1600), 1e-3)):   # few targets: most workgroups only help
