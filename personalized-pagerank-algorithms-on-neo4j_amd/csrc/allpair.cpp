@@ -1008,7 +1008,35 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   // the searches' entries stay in HBM, are put in (source, target) order there, and cross PCIe once, in row order
   DeviceTripleSink sink;
   const auto t0 = std::chrono::steady_clock::now();
-  PPRHIP_TRY(all_pair_collect(g, alpha, threshold, t_begin, t_end, sink, st));
+  // The sorted entries are downloaded into pinned host memory that stays with the handle (index_from_device).  Pinning
+  // gigabytes takes as long as the download itself (R-MAT 24: 2.2 GB of entries, 0.45 s), so for a large range a
+  // helper thread pins a buffer for the expected number of entries (a dozen per target at the thresholds the thesis
+  // uses) while the searches run; should the range yield more, index_from_device grows the buffer as before.
+  void* pre = nullptr;
+  size_t pre_bytes = 0;
+  std::thread pin;
+  {
+    const size_t want = 16ull * 12ull * (size_t)(t_end - t_begin);
+    if (t_end - t_begin >= (1u << 18) && g->ix_stage_bytes < want) {
+      const int device = g->device;
+      pin = std::thread([&pre, &pre_bytes, want, device] {
+        if (hipSetDevice(device) == hipSuccess && hipHostMalloc(&pre, want, hipHostMallocDefault) == hipSuccess) {
+          pre_bytes = want;
+        } else {
+          (void)hipGetLastError();
+          pre = nullptr;
+        }
+      });
+    }
+  }
+  const int crc = all_pair_collect(g, alpha, threshold, t_begin, t_end, sink, st);
+  if (pin.joinable()) pin.join();
+  if (pre) {
+    if (g->ix_stage) (void)hipHostFree(g->ix_stage);
+    g->ix_stage = pre;
+    g->ix_stage_bytes = pre_bytes;
+  }
+  PPRHIP_TRY(crc);
   const auto t1 = std::chrono::steady_clock::now();
   PPRHIP_TRY(index_from_device(g, sink.rec, sink.count, k, 0u, g->n, index_out));
   if (getenv("PPRHIP_APBS_DEBUG"))

@@ -490,7 +490,9 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     // per step, as all of them did before round 4.  PPRHIP_SPARSE_LEVELS=0 (test switch) keeps that form throughout.
     const char* lv_env = getenv("PPRHIP_SPARSE_LEVELS");
     const bool levels_on = !(lv_env && lv_env[0] == '0');
-    const uint32_t g_max = g->sync ? 8u : (uint32_t)std::max(1, std::min(g->n_cus / 2, 128));
+    const char* gm_env = getenv("PPRHIP_SPARSE_LEVELS_GMAX");  // developer switch: the largest grid of such a launch
+    const uint32_t g_cap = gm_env ? (uint32_t)std::max(1, atoi(gm_env)) : 128u;
+    const uint32_t g_max = std::min(g_cap, g->sync ? 8u : (uint32_t)std::max(1, std::min(g->n_cus / 2, 128)));
     const uint64_t need_g = std::max<uint64_t>(std::max<uint64_t>((L.ef + 4095) / 4096, ((uint64_t)L.nf + 2047) / 2048), 1);
     const bool one_launch = levels_on && need_g <= 4ull * g_max;
     const uint32_t lv_grid = (uint32_t)std::min<uint64_t>(need_g, g_max);

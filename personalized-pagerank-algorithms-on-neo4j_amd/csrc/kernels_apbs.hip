@@ -722,13 +722,10 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
       s_giveup = 0;
       const bool hot_t = (uint32_t)t < hot_n;
       if (in_rp[t + 1] == in_rp[t]) {  // Backward_Search.java:46-49: reserve = {t: 1.0}
-        if (hot_t) {
-          hrsv[t] = 1.0;
-        } else {
-          dn_store(&W.rsv[t], 1.0);
-          dn_store(&W.plist[0], t);
-          s_pcount = 1;
-        }
+        if (hot_t) hrsv[t] = 1.0;
+        else dn_store(&W.rsv[t], 1.0);
+        dn_store(&W.plist[0], t);
+        s_pcount = 1;
       } else {
         if (hot_t) {
           hres[t] = 1.0;  // :54-56; the target is pushed unconditionally first
@@ -768,7 +765,13 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
           if ((uint32_t)v < hot_n) {  // (a node is in a level's frontier once: plain LDS accesses)
             rc = hres[v];
             hres[v] = 0.0;
-            hrsv[v] = hrsv[v] + rc * alpha;
+            const double r0 = hrsv[v];
+            if (r0 == 0.0) {  // first pop: listed like a cold node (emission and clean-up walk the list)
+              const uint32_t pp = atomicAdd(&s_pcount, 1u);
+              if (pp < cap_f) dn_store(&W.plist[pp], v);
+              else s_giveup = 1;
+            }
+            hrsv[v] = r0 + rc * alpha;
           } else {
             rc = __hip_atomic_exchange(&W.res[v], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double r0 = dn_load(&W.rsv[v]);
@@ -912,13 +915,15 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     // ---- emit entries >= threshold (Base_Whole_Graph.java:80-88): only popped nodes hold a reserve
     bool retry = gave_up;
     if (!gave_up) {
-      // (positions [0, np): the popped cold nodes; [np, np + hot_n): the hot ids, whose reserve is in LDS)
+      // (a popped hot id's reserve is in LDS)
       unsigned long long run = 0;
-      for (uint32_t c0 = 0; c0 < np + hot_n; c0 += kDnThreads) {
+      for (uint32_t c0 = 0; c0 < np; c0 += kDnThreads) {
         const uint32_t i = c0 + tid;
         double r = 0.0;
-        if (i < np) r = dn_load(&W.rsv[dn_load(&W.plist[i])]);
-        else if (i < np + hot_n) r = hrsv[i - np];
+        if (i < np) {
+          const int32_t v = dn_load(&W.plist[i]);
+          r = (uint32_t)v < hot_n ? hrsv[v] : dn_load(&W.rsv[v]);
+        }
         run += (r > 0.0 && r >= rmax) ? 1ull : 0ull;
       }
       const unsigned long long total = block_sum_u64(run, s_scan64);  // valid in thread 0
@@ -933,10 +938,10 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
         if (tid == 0) atomicMin(O.out_valid, s_out_base);
       } else {
         unsigned long long at = s_out_base;
-        for (uint32_t c0 = 0; c0 < np + hot_n; c0 += kDnThreads) {
+        for (uint32_t c0 = 0; c0 < np; c0 += kDnThreads) {
           const uint32_t i = c0 + tid;
-          const int32_t v = i < np ? dn_load(&W.plist[i]) : (i < np + hot_n ? (int32_t)(i - np) : 0);
-          const double r = i < np ? dn_load(&W.rsv[v]) : (i < np + hot_n ? hrsv[i - np] : 0.0);
+          const int32_t v = i < np ? dn_load(&W.plist[i]) : 0;
+          const double r = i < np ? ((uint32_t)v < hot_n ? hrsv[v] : dn_load(&W.rsv[v])) : 0.0;
           const bool take = r > 0.0 && r >= rmax;
           unsigned long long chunk_total = 0;
           const unsigned long long ex2 =
@@ -956,8 +961,12 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     DN_TICK(3)
     DN_AT(7, 0)
     // ---- hand the vectors back all-zero (the hot ids' state: LDS; the head of the global vector is zero already)
-    for (uint32_t i = tid; i < 2 * hot_n; i += kDnThreads) dn_hot[i] = 0.0;
-    for (uint32_t i = tid; i < np; i += kDnThreads) dn_store(&W.rsv[dn_load(&W.plist[i])], 0.0);
+    for (uint32_t i = tid; i < hot_n; i += kDnThreads) hres[i] = 0.0;  // (what the last level left below the threshold)
+    for (uint32_t i = tid; i < np; i += kDnThreads) {
+      const int32_t v = dn_load(&W.plist[i]);
+      if ((uint32_t)v < hot_n) hrsv[v] = 0.0;
+      else dn_store(&W.rsv[v], 0.0);
+    }
     const uint32_t nt = s_tcount;
     if (nt <= cap_t && s_pcount <= cap_f) {
       for (uint32_t i = tid; i < nt; i += kDnThreads) dn_store(&W.res[dn_load(&W.touched[i])], 0.0);
@@ -966,6 +975,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
         dn_store(&W.res[i], 0.0);
         dn_store(&W.rsv[i], 0.0);
       }
+      for (uint32_t i = tid; i < hot_n; i += kDnThreads) hrsv[i] = 0.0;
     }
     dn_barrier_global();  // the zeros have arrived before the next search's atomics can meet them
     if (tid == 0) atomic_add_u64(done_targets, 1ull);
