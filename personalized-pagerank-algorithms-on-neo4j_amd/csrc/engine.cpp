@@ -483,38 +483,16 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     // the round-cut check looks at the state after exactly one sparse level
     const bool cut_check = cut && cut->enabled && cut->had_dense && !cut->checked;
     const int n_batch = cut_check ? 1 : kMaxBatch;
-    // The batch's levels in ONE launch (k_sparse_levels) where a grid of modest size serves them: the launch's
-    // workgroups meet at a barrier between the steps, so all of them have to be resident - at most half the CUs'
-    // worth for a query that has the stream to itself, eight for a slot whose fifteen neighbours launch theirs at
-    // the same time.  A level too large for that (or for the grid the launch was given: edge_cap) runs as launches
-    // per step, as all of them did before round 4.  PPRHIP_SPARSE_LEVELS=0 (test switch) keeps that form throughout.
-    const char* lv_env = getenv("PPRHIP_SPARSE_LEVELS");
-    const bool levels_on = !(lv_env && lv_env[0] == '0');
-    const char* gm_env = getenv("PPRHIP_SPARSE_LEVELS_GMAX");  // developer switch: the largest grid of such a launch
-    const uint32_t g_cap = gm_env ? (uint32_t)std::max(1, atoi(gm_env)) : 128u;
-    const uint32_t g_max = std::min(g_cap, g->sync ? 8u : (uint32_t)std::max(1, std::min(g->n_cus / 2, 128)));
-    const uint64_t need_g = std::max<uint64_t>(std::max<uint64_t>((L.ef + 4095) / 4096, ((uint64_t)L.nf + 2047) / 2048), 1);
-    const bool one_launch = levels_on && need_g <= 4ull * g_max;
-    const uint32_t lv_grid = (uint32_t)std::min<uint64_t>(need_g, g_max);
-    const unsigned long long edge_cap = one_launch ? 16384ull * lv_grid : ~0ull;
     ktimer().begin(PPRHIP_KERNEL_SPARSE_PUSH, 0);
-    if (one_launch) {
-      PPRHIP_TRY(launch_sparse_levels(g, a, L.fcur, n_batch, first_prepared, lv_grid, edge_cap, dense_thresh, L.dslot, pk0));
-    } else {
-      for (int i = 0; i < n_batch; ++i) {
-        const int fb = L.fcur ^ (i & 1);
-        if (!(i == 0 && first_prepared))
-          PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot,
-                                           i == 0 ? pk0 : ~0ull));
-        PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot, i == 0 ? pk0 : ~0ull));
-      }
+    for (int i = 0; i < n_batch; ++i) {
+      const int fb = L.fcur ^ (i & 1);
+      if (!(i == 0 && first_prepared))
+        PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot,
+                                         i == 0 ? pk0 : ~0ull));
+      PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot, i == 0 ? pk0 : ~0ull));
     }
     ktimer().end();
-    PPRHIP_TRY(fetch_small(g, &g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long) * (kLvAbortCell + 1)));
-    if (g->h_ctr->hist[kLvAbortCell]) {
-      set_error("sparse levels: a workgroup waited more than 4 s at the launch's barrier (launch aborted)");
-      return PPRHIP_ERR_STATE;
-    }
+    PPRHIP_TRY(fetch_small(g, &g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long) * (kMaxBatch + 1)));
     uint64_t batch_bytes = 0;
     int ran = 0;
     for (int i = 0; i < n_batch; ++i) {
@@ -525,7 +503,6 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
         bool d2 = false;
         const double ci = level_cost(g, nf_i, ef_i, &d2);
         if (nf_i == 0 || (d2 && !sparse_only)) break;  // the device stopped here too (level_runs)
-        if (ef_i > edge_cap) break;                    // ... or left the level to a larger grid (k_sparse_levels)
         if (model_cost) *model_cost += ci;
       } else if (model_cost) {
         *model_cost += c;

@@ -7,7 +7,6 @@ namespace pprhip {
 
 // Device-side counter block (one per graph handle), mirrored into pinned host memory.
 constexpr int kMaxBatch = 8;  // sparse levels launched per host round trip
-constexpr int kLvAbortCell = kMaxBatch + 3;  // DevCounters::hist cell k_sparse_levels raises when a barrier wait runs out
 
 struct DevCounters {
   unsigned long long hist[16];    // sparse batch: hist[i] = frontier of level i (entries << 36 | edges)
@@ -29,10 +28,6 @@ struct DevCounters {
   // ends the round hands it to the host in its header (no copy command of its own)
   double plan_sum[3];
   unsigned long long pad[1];
-  // k_sparse_levels (several sparse levels in one launch): barrier of its workgroups - arrivals of the barrier in
-  // progress, barriers completed so far; the word a wait that outlasts its bound raises is hist[kLvAbortCell], so that it
-  // comes back with the level counters
-  unsigned long long bar_count, bar_gen;
   unsigned long long dhist[8];    // dense batch: dhist[i] = frontier that dense level i of the batch starts from
   int dstate[8];                  // dense batch: sweep state of level i (kGsNone: the level does not run)
 };
@@ -396,9 +391,6 @@ namespace pprhip {
 int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t nf_upper,
                           unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot,
                           unsigned long long pk0 = ~0ull);
-int launch_sparse_levels(pprhip_graph* g, const PushArgs& a, int fbuf, int n_levels, bool skip_prepare0, uint32_t grid,
-                         unsigned long long edge_cap, unsigned long long dense_thresh, int dead_slot,
-                         unsigned long long pk0);
 int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
                        unsigned long long dense_thresh, int dead_slot, unsigned long long pk0 = ~0ull);
 // One dense level of a single query, block by block (blocks: nullptr / 1 = the whole sweep at once).  state_in:

@@ -13,6 +13,12 @@
 //           device-side history, and a level's kernels return at once when the previous level left
 //           nothing to do (or left so much that the host should switch to the dense shape), so the
 //           host reads counters back once per batch, not once per level.
+//           (Round 4 tried the batch as ONE launch - prepare and push of up to eight levels inside a kernel whose
+//           workgroups meet at a barrier between the steps, shared state read and written past the L2s - and took it
+//           back: with grids of 1 to 128 workgroups it was slower everywhere, 2.11-2.23 ms per top-k query against
+//           2.04, 0.39-0.55 ms of sparse levels per headline query against 0.34 (profiles/r04_sparse_levels_study.txt).
+//           Launches queued back to back overlap their own overhead, and a gated launch costs 3 us; a barrier of
+//           memory-side atomics and levels run by fewer workgroups cost more.)
 //   dense   k_dense_edges + k_dense_apply + k_dense_reduce: a pull sweep over the non-empty rows of
 //           the in-CSR.  Every wave owns 512 consecutive in-edges (8 per lane: two 16-byte column
 //           index loads, 8 contribution gathers in flight), sums them by row with a segmented wave
@@ -55,42 +61,31 @@ __device__ __forceinline__ int dense_state(const int* state_in, int state0) { re
 // ------------------------------------------------------------------------------------------------
 // sparse level, step 1: every frontier node gives up its residue
 // ------------------------------------------------------------------------------------------------
-// Accesses of the level code to data that OTHER workgroups of the same launch have written or will read.  In the
-// classic form (one launch per step, SC1 = false) a kernel boundary lies between writer and reader and plain accesses
-// do; in k_sparse_levels (several levels in one launch, workgroups on different XCDs, SC1 = true) such data is read and
-// written with agent-scope relaxed atomics (sc1: past the per-XCD L2s, which are not coherent with each other) -
-// the discipline of kernels_apbs.hip's shared levels.
-template <bool SC1, class T>
-__device__ __forceinline__ T lv_load(const T* p) {
-  if (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *p;
-}
-template <bool SC1, class T>
-__device__ __forceinline__ void lv_store(T* p, T v) {
-  if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-
-// frontier entries first, first + stride, ... < nf give up their residue (Forward_Push.java:86-117 / Backward_Search.java:58-72)
-template <int MODE, bool SC1>
-__device__ __forceinline__ void sparse_prepare_body(const int32_t* __restrict__ F, const uint32_t* __restrict__ out_rp,
-                                                    double* __restrict__ res, double* __restrict__ reserve,
-                                                    double* __restrict__ cF, CView c_dense, DevCounters* ctr, uint32_t nf,
-                                                    uint32_t first, uint32_t stride, int dead_slot, const PushArgs& a) {
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restrict__ F,
+                                                         const uint32_t* __restrict__ out_rp,
+                                                         double* __restrict__ res, double* __restrict__ reserve,
+                                                         double* __restrict__ cF, CView c_dense,
+                                                         DevCounters* ctr, int level, unsigned long long dense_thresh,
+                                                         int dead_slot, unsigned long long pk0, PushArgs a) {
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
+  // the first level of a batch gets its frontier from the host as an argument (pk0 != ~0) and clears the counters of
+  // the levels behind it: no copy and no fill on the stream for what two words and eight zeros say
+  if (level == 0 && pk0 != ~0ull && blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int i = 1; i <= kMaxBatch; ++i) ctr->hist[i] = 0ull;
+    ctr->hist[kMaxBatch + 2] = 0ull;  // the seeding pass's list counter: the host has read it before this level
+  }
+  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
+  if (!level_runs(pk, level, dense_thresh)) return;
+  const uint32_t nf = (uint32_t)(pk >> kPackShift);
   double dead = 0.0;
   unsigned long long ndead = 0;
-  for (uint32_t i = first; i < nf; i += stride) {
-    const int32_t v = lv_load<SC1>(&F[i]);
-    double rc;
-    if (SC1) {  // (a plain store of zero could still be on its way when another workgroup's atomic reaches res[v])
-      rc = __hip_atomic_exchange(&res[v], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      rc = res[v];
-      res[v] = 0.0;  // Forward_Push.java:89
-    }
-    lv_store<SC1>(&reserve[v], lv_load<SC1>(&reserve[v]) + rc * a.alpha);  // :91-95
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) {
+    const int32_t v = F[i];
+    const double rc = res[v];
+    res[v] = 0.0;                            // Forward_Push.java:89
+    reserve[v] = reserve[v] + rc * a.alpha;  // :91-95
     double c;
     if (MODE == kBackward) {
       c = (1.0 - a.alpha) * rc;  // Backward_Search.java:72 (divided by d_out(u) per edge)
@@ -107,7 +102,7 @@ __device__ __forceinline__ void sparse_prepare_body(const int32_t* __restrict__ 
     if (c_dense.p)
       c_dense.at((uint32_t)v) = c;
     else
-      lv_store<SC1>(&cF[i], c);
+      cF[i] = c;
   }
   if (MODE != kBackward) {
     const double ds = block_sum_f64(dead, s_red);
@@ -117,25 +112,6 @@ __device__ __forceinline__ void sparse_prepare_body(const int32_t* __restrict__ 
       atomic_add_u64(&ctr->dead_pops, nd);
     }
   }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restrict__ F,
-                                                         const uint32_t* __restrict__ out_rp,
-                                                         double* __restrict__ res, double* __restrict__ reserve,
-                                                         double* __restrict__ cF, CView c_dense,
-                                                         DevCounters* ctr, int level, unsigned long long dense_thresh,
-                                                         int dead_slot, unsigned long long pk0, PushArgs a) {
-  // the first level of a batch gets its frontier from the host as an argument (pk0 != ~0) and clears the counters of
-  // the levels behind it: no copy and no fill on the stream for what two words and eight zeros say
-  if (level == 0 && pk0 != ~0ull && blockIdx.x == 0 && threadIdx.x == 0) {
-    for (int i = 1; i <= kMaxBatch; ++i) ctr->hist[i] = 0ull;
-    ctr->hist[kMaxBatch + 2] = 0ull;  // the seeding pass's list counter: the host has read it before this level
-  }
-  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
-  if (!level_runs(pk, level, dense_thresh)) return;
-  sparse_prepare_body<MODE, false>(F, out_rp, res, reserve, cF, c_dense, ctr, (uint32_t)(pk >> kPackShift),
-                                   blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, dead_slot, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -215,7 +191,6 @@ __device__ __forceinline__ bool comb_insert(int32_t* s_key, double* s_val, int32
 
 // Appends the tile's crossings to the next frontier: one packed atomic reserves list slots and
 // the edge range, a workgroup scan turns the degrees into edge offsets.
-template <bool SC1>
 __device__ __forceinline__ void flush_new(NewList* nl, int32_t* __restrict__ Fn, uint32_t* __restrict__ eoffn,
                                           unsigned long long* out_counter) {
   __shared__ unsigned long long s_scan[4];
@@ -240,8 +215,8 @@ __device__ __forceinline__ void flush_new(NewList* nl, int32_t* __restrict__ Fn,
 #pragma unroll
   for (int j = 0; j < kPer; ++j)
     if (b + j < cnt) {
-      lv_store<SC1>(&Fn[pos0 + b + j], nl->node[b + j]);
-      lv_store<SC1>(&eoffn[pos0 + b + j], (uint32_t)e);
+      Fn[pos0 + b + j] = nl->node[b + j];
+      eoffn[pos0 + b + j] = (uint32_t)e;
       e += nl->deg[b + j];
     }
   __syncthreads();
@@ -249,19 +224,17 @@ __device__ __forceinline__ void flush_new(NewList* nl, int32_t* __restrict__ Fn,
   __syncthreads();
 }
 
-// The edges of one level: tiles bid, bid + nblocks, ... of the level's edge space (the body of k_sparse_push; also a
-// level of k_sparse_levels, where SC1 = true, see lv_load).  Called by all threads of a 256-thread workgroup.
-template <int MODE, bool SC1>
-__device__ __forceinline__ void sparse_push_body(const int32_t* __restrict__ F, const double* __restrict__ cF,
-                                                 const uint32_t* __restrict__ eoff, const uint32_t* __restrict__ trp,
-                                                 const int32_t* __restrict__ tci,
-                                                 const unsigned long long* __restrict__ out_ext,
-                                                 const uint32_t* __restrict__ in_rp, double* __restrict__ res,
-                                                 uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
-                                                 int32_t* __restrict__ Fn, uint32_t* __restrict__ eoffn, DevCounters* ctr,
-                                                 uint32_t nf, unsigned long long E, unsigned long long* out_counter,
-                                                 int dead_slot, unsigned long long comb_min, uint32_t bid,
-                                                 uint32_t nblocks, const PushArgs& a) {
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__ F, const double* __restrict__ cF,
+                                                      const uint32_t* __restrict__ eoff,
+                                                      const uint32_t* __restrict__ trp, const int32_t* __restrict__ tci,
+                                                      const unsigned long long* __restrict__ out_ext,
+                                                      const uint32_t* __restrict__ in_rp, double* __restrict__ res,
+                                                      uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
+                                                      int32_t* __restrict__ Fn,
+                                                      uint32_t* __restrict__ eoffn, DevCounters* ctr, int level,
+                                                      unsigned long long dense_thresh, int dead_slot,
+                                                      unsigned long long comb_min, unsigned long long pk0, PushArgs a) {
   __shared__ uint32_t s_eoff[kStageCap + 1];
   __shared__ uint32_t s_row[kStageCap];
   __shared__ double s_c[kStageCap];
@@ -270,6 +243,11 @@ __device__ __forceinline__ void sparse_push_body(const int32_t* __restrict__ F, 
   __shared__ int32_t s_key[kCombSlots];
   __shared__ double s_val[kCombSlots];
   const int tid = threadIdx.x;
+  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
+  if (!level_runs(pk, level, dense_thresh)) return;
+  const uint32_t nf = (uint32_t)(pk >> kPackShift);
+  const unsigned long long E = pk & kPackMask;
+  unsigned long long* out_counter = &ctr->hist[level + 1];
   // Levels with enough edges to repeat destinations (hubs collect a large share of any R-MAT frontier's edges) sum
   // a tile's contributions per destination in LDS first, so a destination costs one returning global atomic and one
   // degree gather per tile instead of one per edge; small levels go straight to memory.
@@ -282,32 +260,27 @@ __device__ __forceinline__ void sparse_push_body(const int32_t* __restrict__ F, 
     }
   __syncthreads();
 
-  if (MODE != kBackward && bid == 0) {
+  if (MODE != kBackward && blockIdx.x == 0) {
     // dead-end mass of this level lands on the source (Forward_Push.java:101-113)
     if (tid == 0) {
-      const double dead = lv_load<SC1>(&ctr->dead[dead_slot]);
+      const double dead = ctr->dead[dead_slot];
       if (dead > 0.0) {
         push_one<MODE>(a.src, dead, out_ext, in_rp, res, flags, armed, &s_new, a);
-        if (SC1) {  // (the next level's atomics add to this cell: the reset has to have arrived before them)
-          (void)__hip_atomic_exchange(&ctr->dead[dead_slot], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-          ctr->dead[dead_slot] = 0.0;
-        }
+        ctr->dead[dead_slot] = 0.0;
       }
     }
-    flush_new<SC1>(&s_new, Fn, eoffn, out_counter);
+    flush_new(&s_new, Fn, eoffn, out_counter);
   }
 
   const unsigned long long n_tiles = (E + kPushTile - 1) / kPushTile;
-  for (unsigned long long t = bid; t < n_tiles; t += nblocks) {
+  for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const unsigned long long tile_lo = t * kPushTile;
     const unsigned long long tile_hi = (tile_lo + kPushTile < E) ? tile_lo + kPushTile : E;
     if (tid == 0) {  // last frontier index whose edge range starts at or before tile_lo
       uint32_t lo = 0, hi = nf;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if ((unsigned long long)lv_load<SC1>(&eoff[mid]) <= tile_lo) lo = mid + 1; else hi = mid;
+        if ((unsigned long long)eoff[mid] <= tile_lo) lo = mid + 1; else hi = mid;
       }
       s_i0 = lo - 1;
     }
@@ -319,10 +292,10 @@ __device__ __forceinline__ void sparse_push_body(const int32_t* __restrict__ F, 
       if (cnt == 0) break;
       for (uint32_t j = tid; j <= cnt; j += 256) {
         const uint32_t idx = ci0 + j;
-        s_eoff[j] = idx < nf ? lv_load<SC1>(&eoff[idx]) : (uint32_t)E;
+        s_eoff[j] = idx < nf ? eoff[idx] : (uint32_t)E;
         if (j < cnt) {
-          s_row[j] = trp[lv_load<SC1>(&F[idx])];
-          s_c[j] = lv_load<SC1>(&cF[idx]);
+          s_row[j] = trp[F[idx]];
+          s_c[j] = cF[idx];
         }
       }
       __syncthreads();
@@ -408,122 +381,7 @@ __device__ __forceinline__ void sparse_push_body(const int32_t* __restrict__ F, 
           if (u[q] >= 0) push_finish<MODE>(u[q], add[q], old[q], du[q], in_rp, flags, armed, &s_new, a);
       }
     }
-    flush_new<SC1>(&s_new, Fn, eoffn, out_counter);
-  }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__ F, const double* __restrict__ cF,
-                                                      const uint32_t* __restrict__ eoff,
-                                                      const uint32_t* __restrict__ trp, const int32_t* __restrict__ tci,
-                                                      const unsigned long long* __restrict__ out_ext,
-                                                      const uint32_t* __restrict__ in_rp, double* __restrict__ res,
-                                                      uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
-                                                      int32_t* __restrict__ Fn,
-                                                      uint32_t* __restrict__ eoffn, DevCounters* ctr, int level,
-                                                      unsigned long long dense_thresh, int dead_slot,
-                                                      unsigned long long comb_min, unsigned long long pk0, PushArgs a) {
-  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
-  if (!level_runs(pk, level, dense_thresh)) return;
-  sparse_push_body<MODE, false>(F, cF, eoff, trp, tci, out_ext, in_rp, res, flags, armed, Fn, eoffn, ctr,
-                                (uint32_t)(pk >> kPackShift), pk & kPackMask, &ctr->hist[level + 1], dead_slot, comb_min,
-                                blockIdx.x, gridDim.x, a);
-}
-
-// ------------------------------------------------------------------------------------------------
-// several sparse levels in ONE launch
-// ------------------------------------------------------------------------------------------------
-// A query's sparse levels are short (a top-k round on R-MAT 22: five to eight levels of a few hundred to a few ten
-// thousand edges), and as launches each of them cost two kernels of 5 + 15 us plus the gaps between them - eight of
-// each per host round trip, run or not (profiles/r03_topk_summary.md: 41 % of the kernel time of a top-k query).
-// k_sparse_levels runs up to kMaxBatch consecutive levels, prepare and push, inside one launch of a few workgroups
-// that meet at a barrier between the steps; the level counters ctr->hist[] are the same as with one launch per step,
-// so the host reads them back as before.  The launch ends at the first level that is empty, dense by the host's
-// rule (level_runs) or larger than this grid was sized for (edge_cap: the host then launches a larger one).
-//
-// Barrier of the launch's workgroups (all of them resident: the host sizes the grid far below what the device
-// holds, also when fifteen other queries' launches run beside it): arrivals are counted, the last one re-opens the
-// counter and bumps the generation the others wait for.  Data the steps hand to each other goes past the L2s (SC1,
-// lv_load), so only the order of accesses matters: every wave has its accesses acknowledged (vmcnt) before its
-// workgroup arrives.  Waits are bounded (kLvWaitTicks of the 100 MHz clock): a wait that runs out raises hist[kLvAbortCell],
-// on which every workgroup leaves, and the host turns the word into PPRHIP_ERR_STATE.
-constexpr unsigned long long kLvWaitTicks = 400000000ull;  // 4 s
-
-__device__ __forceinline__ bool levels_barrier(DevCounters* ctr, unsigned long long* my_gen, uint32_t nblocks) {
-  __shared__ uint32_t s_ok;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t ok = 1;
-    if (nblocks > 1) {
-      const unsigned long long arrived = atomic_add_u64(&ctr->bar_count, 1ull);
-      if (arrived + 1 == (unsigned long long)nblocks) {
-        (void)__hip_atomic_exchange(&ctr->bar_count, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counter is open again before anybody is let go
-        (void)atomic_add_u64(&ctr->bar_gen, 1ull);
-      } else {
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(&ctr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == *my_gen) {
-          if (__hip_atomic_load(&ctr->hist[kLvAbortCell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            ok = 0;
-            break;
-          }
-          if (wall_clock64() - t0 > kLvWaitTicks) {
-            (void)atomic_add_u64(&ctr->hist[kLvAbortCell], 1ull);
-            ok = 0;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
-    }
-    *my_gen += 1;
-    s_ok = ok;
-  }
-  __syncthreads();
-  return s_ok != 0;
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_sparse_levels(int32_t* F0, int32_t* F1, uint32_t* eoff0, uint32_t* eoff1, int fcur,
-                                                        double* __restrict__ cF, const uint32_t* __restrict__ trp,
-                                                        const int32_t* __restrict__ tci, const uint32_t* __restrict__ out_rp,
-                                                        const unsigned long long* __restrict__ out_ext,
-                                                        const uint32_t* __restrict__ in_rp, double* __restrict__ res,
-                                                        double* __restrict__ reserve, uint8_t* __restrict__ flags,
-                                                        uint32_t* __restrict__ armed, DevCounters* ctr, int n_levels,
-                                                        int skip_prepare0, unsigned long long dense_thresh,
-                                                        unsigned long long edge_cap, int dead_slot,
-                                                        unsigned long long comb_min, unsigned long long pk0, PushArgs a) {
-  __shared__ unsigned long long s_gen;
-  const uint32_t nblocks = gridDim.x, bid = blockIdx.x;
-  if (threadIdx.x == 0) s_gen = __hip_atomic_load(&ctr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (pk0 != ~0ull && bid == 0 && threadIdx.x == 0) {
-    // (as k_sparse_prepare's level 0: the counters of the levels behind the first; nobody adds to them before the
-    // first barrier)
-    for (int i = 1; i <= kMaxBatch; ++i) (void)__hip_atomic_exchange(&ctr->hist[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    (void)__hip_atomic_exchange(&ctr->hist[kMaxBatch + 2], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  unsigned long long gen = s_gen;  // (only thread 0's copy is used)
-  int32_t* const Fb[2] = {F0, F1};
-  uint32_t* const eb[2] = {eoff0, eoff1};
-  const CView no_dense{nullptr, 1, 0};
-  for (int level = 0; level < n_levels; ++level) {
-    const unsigned long long pk =
-        (level == 0 && pk0 != ~0ull) ? pk0 : __hip_atomic_load(&ctr->hist[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!level_runs(pk, level, dense_thresh)) break;
-    const uint32_t nf = (uint32_t)(pk >> kPackShift);
-    const unsigned long long E = pk & kPackMask;
-    if (level > 0 && E > edge_cap) break;  // a level for a larger grid: the host launches it
-    const int cur = fcur ^ (level & 1);
-    if (!(level == 0 && skip_prepare0))
-      sparse_prepare_body<MODE, true>(Fb[cur], out_rp, res, reserve, cF, no_dense, ctr, nf, bid * 256u + threadIdx.x,
-                                      nblocks * 256u, dead_slot, a);
-    if (!levels_barrier(ctr, &gen, nblocks)) return;  // every node has given up its residue
-    sparse_push_body<MODE, true>(Fb[cur], cF, eb[cur], trp, tci, out_ext, in_rp, res, flags, armed, Fb[cur ^ 1], eb[cur ^ 1],
-                                 ctr, nf, E, &ctr->hist[level + 1], dead_slot, comb_min, bid, nblocks, a);
-    if (!levels_barrier(ctr, &gen, nblocks)) return;  // the next frontier is complete
+    flush_new(&s_new, Fn, eoffn, out_counter);
   }
 }
 
@@ -1553,23 +1411,6 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
                             g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_ext, g->in_rp, g->residue, g->flags,
                             g->armed, g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot,
                             comb_min, pk0, a));
-  PPRHIP_CHECK_HIP(hipGetLastError());
-  return PPRHIP_OK;
-}
-
-// up to n_levels sparse levels from the frontier in list buffer fbuf, in one launch of `grid` workgroups
-int launch_sparse_levels(pprhip_graph* g, const PushArgs& a, int fbuf, int n_levels, bool skip_prepare0, uint32_t grid,
-                         unsigned long long edge_cap, unsigned long long dense_thresh, int dead_slot,
-                         unsigned long long pk0) {
-  const bool bwd = a.mode == kBackward;
-  const uint32_t* trp = bwd ? g->in_rp : g->out_rp;
-  const int32_t* tci = bwd ? g->in_ci : g->out_ci;
-  const char* comb_env = getenv("PPRHIP_COMB_MIN_EDGES");
-  const unsigned long long comb_min = comb_env ? strtoull(comb_env, nullptr, 10) : (unsigned long long)kCombMinEdges;
-  DISPATCH_MODE(a.mode, k_sparse_levels<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                            g->F[0], g->F[1], g->eoff[0], g->eoff[1], fbuf, g->cF, trp, tci, g->out_rp, g->out_ext, g->in_rp,
-                            g->residue, g->reserve, g->flags, g->armed, g->ctr, n_levels, skip_prepare0 ? 1 : 0,
-                            dense_thresh, edge_cap, dead_slot, comb_min, pk0, a));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

@@ -721,14 +721,11 @@ def test_sparse_push_lds_table(pkg, orc, rmat15, dev_rmat15, monkeypatch):
         dev_rmat15.set_tuning(pkg.tuning_default())
 
 
-@pytest.mark.parametrize("levels", ["1", "0"])
-def test_sparse_levels_in_one_launch_or_per_step(pkg, orc, rmat15, dev_rmat15, got, dev_got, monkeypatch, levels):
-    """A batch of sparse levels runs in ONE launch (k_sparse_levels: workgroups meeting at a barrier between prepare
-    and push, several levels per launch; the default) or as one launch per step (PPRHIP_SPARSE_LEVELS=0, also what a
-    level too large for the launch's grid falls back to): same levels, same counters, same vectors as the twin - for
-    the forward push (sparse levels only, and mixed with sweeps), the resumable top-k push round by round, and the
-    backward search; on GOT (levels of a handful of edges: one workgroup) and R-MAT 15 (levels of 10^5 edges: a grid)."""
-    monkeypatch.setenv("PPRHIP_SPARSE_LEVELS", levels)
+def test_sparse_levels_all_modes(pkg, orc, rmat15, dev_rmat15, got, dev_got):
+    """Batches of sparse levels (prepare + push per level, eight levels per host round trip) in every push mode: same
+    levels, same counters, same vectors as the twin - the forward push (sparse levels only, and mixed with sweeps), the
+    resumable top-k push round by round, and the backward search; on GOT (levels of a handful of edges) and R-MAT 15
+    (levels of 10^5 edges)."""
     for host, dev, rmaxes in ((got, dev_got, (7.554e-4, 1e-8)), (rmat15, dev_rmat15, (1e-5, 1e-7))):
         og = to_oracle(orc, host)
         od = np.diff(host.out_rp)

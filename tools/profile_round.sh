@@ -14,9 +14,9 @@ case $what in
   bench)  prog="$root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extras" ;;
   single) prog="$root/bench.py --mode single --queries-per-step 16 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extras" ;;
   topk)   prog="$root/tools/bench_topk.py 22 64" ;;
-  # All-Pair's tier 3 runs 16 worker threads; rocprofv3's queue interception faults when several host threads submit
-  # at once (attribution of the abort), so the profiled run keeps the slots on one thread
-  apbs)   prog="$root/tools/explore_apbs.py --scale 22 --thr 1e-3 --targets 262144"; export PPRHIP_BATCH_THREADS=0 ;;
+  # (until round 3 this workload ran with PPRHIP_BATCH_THREADS=0, after round 1's abort under the profiler with 16
+  # launching threads; since round 4 it runs as the product does - DESIGN.md 5, "The abort on record")
+  apbs)   prog="$root/tools/explore_apbs.py --scale 22 --thr 1e-3 --targets 262144" ;;
   *) echo "unknown workload $what"; exit 2 ;;
 esac
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${what}_stats -- python3 $prog > $out/${tag}_${what}_stats.log 2>&1 || { echo "stats run failed"; tail -5 $out/${tag}_${what}_stats.log; exit 1; }

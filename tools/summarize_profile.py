@@ -27,7 +27,7 @@ COMMANDS = {
     "single": "python3 bench.py --mode single --queries-per-step 16 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc "
               "--no-extras",
     "topk": "python3 tools/bench_topk.py 22 64",
-    "apbs": "python3 tools/explore_apbs.py --scale 22 --thr 1e-3 --targets 262144   (PPRHIP_BATCH_THREADS=0)",
+    "apbs": "python3 tools/explore_apbs.py --scale 22 --thr 1e-3 --targets 262144",
 }
 
 
