@@ -775,7 +775,7 @@ def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xde
     err = res.get("error")
     # t_all, search seconds, entries found, bytes received, entries kept; a failed rank poisons the sample
     vals = [res["seconds"], res["search_seconds"], res["entries_found"], res["bytes_received"], res["entries_kept"],
-            res["columns_checked"], res["entries_checked"]] if not err else [0.0] * 7
+            res["columns_checked"], res["entries_checked"], res["hbm_in_use_gb"]] if not err else [0.0] * 8
     stats = torch.tensor(vals[:5] + [1.0 if err else 0.0] + vals[5:], dtype=torch.float64, device=xdev)
     tmax = stats.clone()
     if world > 1:
@@ -791,6 +791,7 @@ def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xde
             "exchange_bytes_received": int(stats[3]),
             "self_check": {"status": "ok", "against": "pprhip_backward_push, 1e-12, on every rank's own rows",
                            "targets": int(stats[6]), "entries_checked": int(stats[7])},
+            "hbm_in_use_per_rank_gb_max": round(float(tmax[8]), 2),
             "exchange": "owner-of-source, 16-byte records partitioned on the device, grouped ncclSend/ncclRecv inside "
                         "libpprhip.so (pprhip_all_pair_backward_sharded); one child process per rank"}
 
@@ -816,9 +817,13 @@ def all_pair_child(args):
             comm.close()
             # this rank's rows (sources [lo, hi), targets of every rank) against single-target searches
             check = all_pair_self_check(g, host, off, tg, vl, 0, host.n, count=64, seed=5 + rank, source_range=(lo, hi))
+            # HBM this rank holds at the end of its share (CSR replica, in-edge records, the dense tier's workspaces, the
+            # whole-vector state; the record and exchange buffers have come and gone): what a rank of the sharded job needs
+            free_b, total_b = torch.cuda.mem_get_info(device)
             res = {"seconds": t_all, "search_seconds": st.total_ms / 1e3, "entries_found": float(st.mc_sources),
                    "bytes_received": float(st.select_bytes), "entries_kept": float(len(tg)),
-                   "columns_checked": float(check["targets"]), "entries_checked": float(check["entries_checked"])}
+                   "columns_checked": float(check["targets"]), "entries_checked": float(check["entries_checked"]),
+                   "hbm_in_use_gb": (total_b - free_b) / 1e9}
     except Exception as e:  # noqa: BLE001
         res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     print(json.dumps(res), flush=True)
@@ -864,6 +869,8 @@ def rmat24_child(args):
             check = all_pair_self_check(g, host, off, tg, vl, 0, nt)  # raises: the line then carries the error
             res = all_pair_report(pkg, st, nt, dt, int(len(tg)))
             res["self_check"] = check
+            free_b, total_b = torch.cuda.mem_get_info(0)
+            res["hbm_in_use_gb"] = round((total_b - free_b) / 1e9, 2)  # CSR + records + dense-tier workspaces of n = 2^24
             res["workload"] = "RMAT scale-24 (n=%d, m=%d, seed 1), All-Pair-Backward-Search on the first %d targets, " \
                               "threshold %g, k = %d, one GPU" % (host.n, host.m, nt, AP_THR, TOPK)
             res["graph_lift_s"] = {"generate_and_csr": round(t_gen, 1), "upload_and_tile": round(t_lift, 1)}

@@ -424,13 +424,39 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       B.done_targets = cells + 8;  // + 8: targets done, + 9: levels posted, + 10: abort word
       // targets with the most in-edges first: the searches that push the most edges start the level-1 fan-out from
       // hubs, and a workgroup that draws such a search last would finish long after the others
+      // (a stable counting sort by in-degree, degrees from 65535 up in one bucket that is sorted on its own: a
+      // comparison sort of half a million ids with two indirections per comparison was 15-40 ms of every pass)
       {
         const std::vector<uint32_t>& irp = g->h_in_rp;
         const std::vector<int32_t>& o2n = g->h_old2new;
-        std::stable_sort(list.begin(), list.end(), [&](int32_t x, int32_t y) {
-          const int32_t a = o2n[x], b = o2n[y];
-          return irp[a + 1] - irp[a] > irp[b + 1] - irp[b];
-        });
+        constexpr uint32_t kCapDeg = 65535;
+        const size_t L = list.size();
+        std::vector<uint32_t> deg(L);
+        std::vector<uint32_t> at((size_t)kCapDeg + 2, 0);
+        for (size_t i = 0; i < L; ++i) {
+          const int32_t a = g->relabeled ? o2n[list[i]] : list[i];
+          deg[i] = irp[a + 1] - irp[a];
+          at[kCapDeg - std::min(deg[i], kCapDeg) + 1]++;  // bucket 0: the largest degrees
+        }
+        for (uint32_t b = 0; b <= kCapDeg; ++b) at[b + 1] += at[b];
+        const uint32_t n_top = at[1];
+        std::vector<int32_t> sorted(L);
+        std::vector<uint32_t> sdeg(n_top);
+        for (size_t i = 0; i < L; ++i) {
+          const uint32_t b = kCapDeg - std::min(deg[i], kCapDeg);
+          const uint32_t pos = at[b]++;
+          sorted[pos] = list[i];
+          if (b == 0) sdeg[pos] = deg[i];
+        }
+        if (n_top > 1) {  // the top bucket by exact degree (stable)
+          std::vector<uint32_t> idx(n_top);
+          for (uint32_t i = 0; i < n_top; ++i) idx[i] = i;
+          std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return sdeg[x] > sdeg[y]; });
+          std::vector<int32_t> top(n_top);
+          for (uint32_t i = 0; i < n_top; ++i) top[i] = sorted[idx[i]];
+          std::copy(top.begin(), top.end(), sorted.begin());
+        }
+        list.swap(sorted);
       }
       // Developer switch PPRHIP_APBS_DEBUG: per-workgroup timers and a progress word in HOST memory, and a watchdog
       // thread that prints the progress words and ends the process when the tier has not come back after 20 s
@@ -507,8 +533,22 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     t1_stream = g->apbs_side_stream;
   }
   if (t1_stream) {
-    constexpr uint32_t kParts = 3;  // (R-MAT 22, all targets: 2 or 3 parts 1.083 s, 4: 1.104, 6: 1.141, in sequence 1.145)
-    const uint32_t per = (n_targets + kParts - 1) / kParts;
+    // Three parts; the first one small: its LDS searches are the only ones nothing runs beside (the dense tier has no
+    // work yet), so it is kept to an eighth of the range (R-MAT 22: 86 -> 30 ms of waiting; PPRHIP_APBS_PARTS=a,b
+    // sets the two cuts as fractions of the range - developer switch).  More parts cost more than they hide: every
+    // dense pass ends with its own tail and its own hand-over.
+    constexpr uint32_t kParts = 3;
+    double cut_a = 0.125, cut_b = 0.56;
+    if (const char* pe = getenv("PPRHIP_APBS_PARTS")) {
+      double a = 0, b = 0;
+      if (sscanf(pe, "%lf,%lf", &a, &b) == 2 && a > 0.0 && a < b && b < 1.0) {
+        cut_a = a;
+        cut_b = b;
+      }
+    }
+    const uint32_t part_lo[kParts + 1] = {0u, (uint32_t)(cut_a * n_targets), (uint32_t)(cut_b * n_targets), n_targets};
+    uint32_t per = 0;  // the largest part (buffer sizes)
+    for (uint32_t c = 0; c < kParts; ++c) per = std::max(per, part_lo[c + 1] - part_lo[c]);
     unsigned long long* cells1 = nullptr;
     unsigned long long* h_cells1 = nullptr;
     TripleRec* out1 = nullptr;
@@ -545,7 +585,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     B1.out_cap = cap1;
     // queues tier 1 for part c on the side stream (init words, kernel, counters back into pinned memory)
     auto launch_part = [&](uint32_t c) -> int {
-      const uint32_t lo = c * per, cnt = std::min(per, n_targets - lo);
+      const uint32_t lo = part_lo[c], cnt = part_lo[c + 1] - lo;
       for (int i = 0; i < 16; ++i) h_cells1[16 + i] = 0ull;
       h_cells1[16 + 2] = ~0ull;
       PPRHIP_CHECK_HIP(hipMemcpyAsync(cells1, h_cells1 + 16, sizeof(unsigned long long) * 16, hipMemcpyHostToDevice, t1_stream));
@@ -592,14 +632,20 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       return PPRHIP_OK;
     };
     if (rc == PPRHIP_OK) rc = launch_part(0);
-    for (uint32_t c = 0; c < kParts && rc == PPRHIP_OK && c * per < n_targets; ++c) {
+    for (uint32_t c = 0; c < kParts && rc == PPRHIP_OK; ++c) {
       std::vector<int32_t> left;
+      const auto tp0 = now();
       rc = harvest_part(c, left);
       if (rc != PPRHIP_OK) break;
-      if ((c + 1) * per < n_targets && c + 1 < kParts) rc = launch_part(c + 1);
+      const double ms_harvest = ms_since(tp0);
+      if (c + 1 < kParts) rc = launch_part(c + 1);
       if (rc != PPRHIP_OK) break;
       to_tier2.insert(to_tier2.end(), left.begin(), left.end());
+      const auto tp1 = now();
       if (!left.empty()) dense_pass(left);  // (sets rc)
+      if (dbg_times)
+        fprintf(stderr, "[apbs host] part %u: waited %.1f ms for tier 1 and its entries, dense tier on %zu targets %.1f ms\n", c,
+                ms_harvest, left.size(), ms_since(tp1));
     }
     release1();
     piped = true;
@@ -893,6 +939,103 @@ int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint
   return PPRHIP_OK;
 }
 
+// ---- device -> pageable host memory through a ring of pinned slots and copier threads
+constexpr int kIxSlots = 8;
+constexpr size_t kIxSlotBytes = 8u << 20;
+constexpr int kIxCopiers = 4;
+
+int ensure_ring(pprhip_graph* g) {  // the ring lives in g->ix_stage (kIxSlots * kIxSlotBytes of pinned memory)
+  if (g->ix_stage && g->ix_stage_bytes >= kIxSlots * kIxSlotBytes) return PPRHIP_OK;
+  if (g->ix_stage) (void)hipHostFree(g->ix_stage);
+  g->ix_stage = nullptr;
+  g->ix_stage_bytes = 0;
+  if (hipHostMalloc(&g->ix_stage, kIxSlots * kIxSlotBytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    g->ix_stage = nullptr;
+    return PPRHIP_ERR_OOM;  // (the caller falls back to a plain copy)
+  }
+  g->ix_stage_bytes = kIxSlots * kIxSlotBytes;
+  return PPRHIP_OK;
+}
+
+int ring_download(pprhip_graph* g, const void* d_src, void* h_dst, size_t bytes) {
+  if (!bytes) return PPRHIP_OK;
+  if (bytes < 4 * kIxSlotBytes || ensure_ring(g) != PPRHIP_OK) {  // small, or no pinned memory to be had
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    return PPRHIP_OK;
+  }
+  char* const ring = static_cast<char*>(g->ix_stage);
+  hipEvent_t ev[kIxSlots] = {};
+  for (int i = 0; i < kIxSlots; ++i)
+    if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(ev[j]);
+      set_error("index download: no events");
+      return PPRHIP_ERR_HIP;
+    }
+  const size_t n_chunks = (bytes + kIxSlotBytes - 1) / kIxSlotBytes;
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t issued = 0;                 // chunks whose copy into their slot has been queued
+  size_t taken = 0;                  // next chunk a copier takes
+  size_t freed[kIxSlots] = {};       // per slot: chunks of that slot moved on so far
+  int err = PPRHIP_OK;
+  const int device = g->device;
+  auto copier = [&] {
+    (void)hipSetDevice(device);
+    for (;;) {
+      size_t c;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return taken < issued || taken >= n_chunks || err; });
+        if (err || taken >= n_chunks) return;
+        c = taken++;
+      }
+      const int slot = (int)(c % kIxSlots);
+      const size_t off = c * kIxSlotBytes, len = std::min(kIxSlotBytes, bytes - off);
+      const bool ok = hipEventSynchronize(ev[slot]) == hipSuccess;
+      if (ok) std::memcpy(static_cast<char*>(h_dst) + off, ring + (size_t)slot * kIxSlotBytes, len);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!ok && !err) err = PPRHIP_ERR_HIP;
+        freed[slot]++;
+      }
+      cv.notify_all();
+    }
+  };
+  std::thread th[kIxCopiers];
+  for (auto& t : th) t = std::thread(copier);
+  for (size_t c = 0; c < n_chunks; ++c) {
+    const int slot = (int)(c % kIxSlots);
+    {
+      std::unique_lock<std::mutex> lk(mu);  // the slot's previous chunk has been moved on
+      cv.wait(lk, [&] { return freed[slot] >= c / kIxSlots || err; });
+      if (err) break;
+    }
+    const size_t off = c * kIxSlotBytes, len = std::min(kIxSlotBytes, bytes - off);
+    const bool ok = hipMemcpyAsync(ring + (size_t)slot * kIxSlotBytes, static_cast<const char*>(d_src) + off, len,
+                                   hipMemcpyDeviceToHost, g->stream) == hipSuccess &&
+                    hipEventRecord(ev[slot], g->stream) == hipSuccess;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!ok && !err) err = PPRHIP_ERR_HIP;
+      if (ok) issued = c + 1;
+    }
+    cv.notify_all();
+    if (!ok) break;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (issued < n_chunks && !err) err = PPRHIP_ERR_HIP;
+  }
+  cv.notify_all();
+  for (auto& t : th) t.join();
+  (void)hipStreamSynchronize(g->stream);
+  for (int i = 0; i < kIxSlots; ++i) (void)hipEventDestroy(ev[i]);
+  if (err) set_error("index: download of the sorted entries failed");
+  return err;
+}
+
 // the entries in a device record store -> sorted on the device -> the index (rows of sources in [v_lo, v_hi))
 int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int k, uint32_t v_lo, uint32_t v_hi,
                       pprhip_index_t** out) {
@@ -906,42 +1049,26 @@ int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long 
     (void)hipStreamSynchronize(g->stream);
     fprintf(stderr, "[index] sorted on the device at %.1f ms\n", ms());
   }
-  // The sorted entries cross PCIe into pinned memory that stays with the handle (pprhip_graph_release hands it back):
-  // into pageable memory the copy ran at 9-11 GB/s (46-60 ms for R-MAT 22's 32 M entries).
-  const size_t need = 16 * (size_t)std::max<unsigned long long>(1, count);
+  // The sorted entries cross PCIe through a ring of pinned slots that stays with the handle (kIxSlots x kIxSlotBytes;
+  // pprhip_graph_release hands it back) and are moved on into pageable arrays by a few copier threads.  A plain copy
+  // into pageable memory runs at 9-11 GB/s (one thread of the runtime does the same through its own bounce buffers);
+  // pinning the whole destination - round 3 - made later calls fast and the first one slow: pinning gigabytes runs at
+  // 1-5 GB/s (R-MAT 24: 2.2 GB of entries, 0.5 s and more while kernels run).
   int rc = PPRHIP_OK;
-  if (g->ix_stage_bytes < need) {
-    if (g->ix_stage) (void)hipHostFree(g->ix_stage);
-    g->ix_stage = nullptr;
-    g->ix_stage_bytes = 0;
-    const size_t want = need + need / 4;
-    if (hipHostMalloc(&g->ix_stage, want, hipHostMallocDefault) == hipSuccess) {
-      g->ix_stage_bytes = want;
-    } else {
-      (void)hipGetLastError();
-      g->ix_stage = nullptr;
-    }
+  RawVec<uint64_t> keys_v;
+  RawVec<double> vals_v;
+  try {
+    keys_v.resize((size_t)std::max<unsigned long long>(1, count));
+    vals_v.resize((size_t)std::max<unsigned long long>(1, count));
+  } catch (const std::bad_alloc&) {
+    set_error("index: no host memory for %llu entries", count);
+    rc = PPRHIP_ERR_OOM;
   }
-  std::unique_ptr<uint64_t[]> own_keys;  // pageable fall-back when the host cannot pin that much
-  std::unique_ptr<double[]> own_vals;
-  uint64_t* keys = nullptr;
-  double* vals = nullptr;
-  if (g->ix_stage) {
-    keys = static_cast<uint64_t*>(g->ix_stage);
-    vals = reinterpret_cast<double*>(static_cast<char*>(g->ix_stage) + 8 * (size_t)std::max<unsigned long long>(1, count));
-  } else {
-    own_keys.reset(new (std::nothrow) uint64_t[std::max<unsigned long long>(1, count)]);
-    own_vals.reset(new (std::nothrow) double[std::max<unsigned long long>(1, count)]);
-    keys = own_keys.get();
-    vals = own_vals.get();
-    if (!keys || !vals) rc = PPRHIP_ERR_OOM;
-  }
-  if (rc == PPRHIP_OK && count &&
-      (hipMemcpyAsync(keys, d_keys, 8 * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-       hipMemcpyAsync(vals, d_vals, 8 * count, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
-       hipStreamSynchronize(g->stream) != hipSuccess)) {
-    set_error("index: download of the sorted entries failed");
-    rc = PPRHIP_ERR_HIP;
+  uint64_t* keys = keys_v.data();
+  double* vals = vals_v.data();
+  if (rc == PPRHIP_OK && count) {
+    rc = ring_download(g, d_keys, keys, 8 * (size_t)count);
+    if (rc == PPRHIP_OK) rc = ring_download(g, d_vals, vals, 8 * (size_t)count);
   }
   if (d_keys) (void)hipFree(d_keys);
   if (d_vals) (void)hipFree(d_vals);
@@ -1008,34 +1135,16 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   // the searches' entries stay in HBM, are put in (source, target) order there, and cross PCIe once, in row order
   DeviceTripleSink sink;
   const auto t0 = std::chrono::steady_clock::now();
-  // The sorted entries are downloaded into pinned host memory that stays with the handle (index_from_device).  Pinning
-  // gigabytes takes as long as the download itself (R-MAT 24: 2.2 GB of entries, 0.45 s), so for a large range a
-  // helper thread pins a buffer for the expected number of entries (a dozen per target at the thresholds the thesis
-  // uses) while the searches run; should the range yield more, index_from_device grows the buffer as before.
-  void* pre = nullptr;
-  size_t pre_bytes = 0;
+  // first-use work of the finalisation, beside the searches: the pinned ring the sorted entries are downloaded through
   std::thread pin;
-  {
-    const size_t want = 16ull * 12ull * (size_t)(t_end - t_begin);
-    if (t_end - t_begin >= (1u << 18) && g->ix_stage_bytes < want) {
-      const int device = g->device;
-      pin = std::thread([&pre, &pre_bytes, want, device] {
-        if (hipSetDevice(device) == hipSuccess && hipHostMalloc(&pre, want, hipHostMallocDefault) == hipSuccess) {
-          pre_bytes = want;
-        } else {
-          (void)hipGetLastError();
-          pre = nullptr;
-        }
-      });
-    }
-  }
+  if (!g->ix_stage) pin = std::thread([g] {
+    if (hipSetDevice(g->device) == hipSuccess) (void)ensure_ring(g);
+  });
+  // room for the entries a range of this size usually yields (a dozen per target at the thresholds the thesis uses):
+  // the store then does not grow - allocate, copy, free - while the searches run
+  if (t_end - t_begin >= (1u << 18)) (void)sink.reserve(g, 12ull * (unsigned long long)(t_end - t_begin));
   const int crc = all_pair_collect(g, alpha, threshold, t_begin, t_end, sink, st);
   if (pin.joinable()) pin.join();
-  if (pre) {
-    if (g->ix_stage) (void)hipHostFree(g->ix_stage);
-    g->ix_stage = pre;
-    g->ix_stage_bytes = pre_bytes;
-  }
   PPRHIP_TRY(crc);
   const auto t1 = std::chrono::steady_clock::now();
   PPRHIP_TRY(index_from_device(g, sink.rec, sink.count, k, 0u, g->n, index_out));
