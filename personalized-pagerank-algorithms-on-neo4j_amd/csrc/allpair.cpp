@@ -533,12 +533,12 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     t1_stream = g->apbs_side_stream;
   }
   if (t1_stream) {
-    // Three parts; the first one small: its LDS searches are the only ones nothing runs beside (the dense tier has no
-    // work yet), so it is kept to an eighth of the range (R-MAT 22: 86 -> 30 ms of waiting; PPRHIP_APBS_PARTS=a,b
-    // sets the two cuts as fractions of the range - developer switch).  More parts cost more than they hide: every
-    // dense pass ends with its own tail and its own hand-over.
+    // Three equal parts (PPRHIP_APBS_PARTS=a,b sets the two cuts as fractions of the range - developer switch).  A small
+    // first part shortens the only LDS pass nothing runs beside, but what is saved there comes back as longer dense
+    // passes - LDS searches beside a dense pass slow it down by nearly their own duration (R-MAT 22, cuts at 0.08 /
+    // 0.125 / 0.2 / 0.333: 805 / 801 / 806 / 799 ms for tiers 1 + 2); more parts cost more than they hide.
     constexpr uint32_t kParts = 3;
-    double cut_a = 0.125, cut_b = 0.56;
+    double cut_a = 1.0 / 3.0, cut_b = 2.0 / 3.0;
     if (const char* pe = getenv("PPRHIP_APBS_PARTS")) {
       double a = 0, b = 0;
       if (sscanf(pe, "%lf,%lf", &a, &b) == 2 && a > 0.0 && a < b && b < 1.0) {
@@ -1054,18 +1054,23 @@ int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long 
   // into pageable memory runs at 9-11 GB/s (one thread of the runtime does the same through its own bounce buffers);
   // pinning the whole destination - round 3 - made later calls fast and the first one slow: pinning gigabytes runs at
   // 1-5 GB/s (R-MAT 24: 2.2 GB of entries, 0.5 s and more while kernels run).
+  // The arrays they land in stay with the handle as well (pprhip_graph_release frees them): handing two gigabytes of
+  // pageable memory back to the system after every call cost 0.18 s at R-MAT 24, faulting it in again as much.
   int rc = PPRHIP_OK;
-  RawVec<uint64_t> keys_v;
-  RawVec<double> vals_v;
-  try {
-    keys_v.resize((size_t)std::max<unsigned long long>(1, count));
-    vals_v.resize((size_t)std::max<unsigned long long>(1, count));
-  } catch (const std::bad_alloc&) {
-    set_error("index: no host memory for %llu entries", count);
-    rc = PPRHIP_ERR_OOM;
+  const size_t need = 16 * (size_t)std::max<unsigned long long>(1, count);
+  if (g->ix_host_bytes < need) {
+    if (g->ix_host) free(g->ix_host);
+    g->ix_host_bytes = 0;
+    g->ix_host = malloc(need + need / 8);
+    if (g->ix_host) {
+      g->ix_host_bytes = need + need / 8;
+    } else {
+      set_error("index: no host memory for %llu entries", count);
+      rc = PPRHIP_ERR_OOM;
+    }
   }
-  uint64_t* keys = keys_v.data();
-  double* vals = vals_v.data();
+  uint64_t* keys = static_cast<uint64_t*>(g->ix_host);
+  double* vals = g->ix_host ? reinterpret_cast<double*>(static_cast<char*>(g->ix_host) + 8 * (size_t)std::max<unsigned long long>(1, count)) : nullptr;
   if (rc == PPRHIP_OK && count) {
     rc = ring_download(g, d_keys, keys, 8 * (size_t)count);
     if (rc == PPRHIP_OK) rc = ring_download(g, d_vals, vals, 8 * (size_t)count);

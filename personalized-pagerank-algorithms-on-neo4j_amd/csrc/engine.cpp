@@ -1537,6 +1537,9 @@ static void free_all_pair(pprhip_graph* g) {
   if (g->ix_stage) (void)hipHostFree(g->ix_stage);
   g->ix_stage = nullptr;
   g->ix_stage_bytes = 0;
+  if (g->ix_host) free(g->ix_host);
+  g->ix_host = nullptr;
+  g->ix_host_bytes = 0;
   if (g->apbs_side_stream) (void)hipStreamDestroy(g->apbs_side_stream);
   g->apbs_side_stream = nullptr;
   g->apbs_side_tried = false;

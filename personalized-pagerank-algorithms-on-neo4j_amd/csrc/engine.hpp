@@ -295,8 +295,10 @@ struct pprhip_graph {
   void* apbs_board = nullptr;
   hipStream_t apbs_side_stream = nullptr;  // All-Pair: tier 1 of the next part of a large range runs here beside tier 2
   bool apbs_side_tried = false;
-  void* ix_stage = nullptr;  // pinned host memory the sorted index entries are downloaded into (index_from_device)
+  void* ix_stage = nullptr;  // pinned ring the sorted index entries are downloaded through (index_from_device)
   size_t ix_stage_bytes = 0;
+  void* ix_host = nullptr;   // pageable host memory they land in (keys, then values), kept between calls
+  size_t ix_host_bytes = 0;
   char* apbs_xl_ws = nullptr;  // a few workspaces whose lists hold every node, for the searches that outgrow the others
   uint32_t apbs_xl_blocks = 0, apbs_xl_cap_t = 0, apbs_xl_cap_f = 0;
   uint32_t apbs_blocks = 0, apbs_cap_t = 0, apbs_cap_f = 0, apbs_chunk = 0;
