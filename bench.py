@@ -819,7 +819,7 @@ def all_pair_child(args):
             check = all_pair_self_check(g, host, off, tg, vl, 0, host.n, count=64, seed=5 + rank, source_range=(lo, hi))
             # HBM this rank holds at the end of its share (CSR replica, in-edge records, the dense tier's workspaces, the
             # whole-vector state; the record and exchange buffers have come and gone): what a rank of the sharded job needs
-            free_b, total_b = torch.cuda.mem_get_info(device)
+            free_b, total_b = g.device_memory()
             res = {"seconds": t_all, "search_seconds": st.total_ms / 1e3, "entries_found": float(st.mc_sources),
                    "bytes_received": float(st.select_bytes), "entries_kept": float(len(tg)),
                    "columns_checked": float(check["targets"]), "entries_checked": float(check["entries_checked"]),
@@ -869,7 +869,7 @@ def rmat24_child(args):
             check = all_pair_self_check(g, host, off, tg, vl, 0, nt)  # raises: the line then carries the error
             res = all_pair_report(pkg, st, nt, dt, int(len(tg)))
             res["self_check"] = check
-            free_b, total_b = torch.cuda.mem_get_info(0)
+            free_b, total_b = g.device_memory()
             res["hbm_in_use_gb"] = round((total_b - free_b) / 1e9, 2)  # CSR + records + dense-tier workspaces of n = 2^24
             res["workload"] = "RMAT scale-24 (n=%d, m=%d, seed 1), All-Pair-Backward-Search on the first %d targets, " \
                               "threshold %g, k = %d, one GPU" % (host.n, host.m, nt, AP_THR, TOPK)

@@ -207,6 +207,9 @@ void pprhip_graph_destroy(pprhip_graph_t* g);
 #define PPRHIP_RELEASE_BATCH 2u
 int pprhip_graph_release(pprhip_graph_t* g, unsigned what);
 int pprhip_graph_info(const pprhip_graph_t* g, uint32_t* n, uint64_t* m, int* device);
+/* HBM of the handle's device: bytes free and in all (hipMemGetInfo) - what a job holds at a point of its run is
+ * total - free; bench.py reports it for the All-Pair samples (per rank in the sharded run). */
+int pprhip_device_memory(const pprhip_graph_t* g, uint64_t* free_bytes, uint64_t* total_bytes);
 int pprhip_graph_set_tuning(pprhip_graph_t* g, const pprhip_tuning_t* t);
 int pprhip_graph_get_tuning(const pprhip_graph_t* g, pprhip_tuning_t* t);
 /* Results of the last compute call that left them in HBM. */

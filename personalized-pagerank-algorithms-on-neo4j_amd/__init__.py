@@ -80,6 +80,7 @@ EXPORTS = [
     "pprhip_fora_batch", "pprhip_all_pair_backward_multi", "pprhip_comm_unique_id", "pprhip_comm_create",
     "pprhip_comm_destroy", "pprhip_comm_info", "pprhip_shard_target_range", "pprhip_all_pair_backward_sharded",
     "pprhip_topk_gather", "pprhip_comm_abort", "pprhip_owner_partition", "pprhip_index_from_entries",
+    "pprhip_device_memory",
 ]
 COMM_ID_BYTES = 128
 
@@ -124,6 +125,7 @@ def lib():
     L.pprhip_graph_destroy.restype = None
     L.pprhip_graph_release.argtypes = [vp, C.c_uint]
     L.pprhip_graph_info.argtypes = [vp, P(u32), P(u64), P(ci)]
+    L.pprhip_device_memory.argtypes = [vp, P(u64), P(u64)]
     L.pprhip_graph_set_tuning.argtypes = [vp, P(Tuning)]
     L.pprhip_graph_get_tuning.argtypes = [vp, P(Tuning)]
     L.pprhip_get_reserve.argtypes = [vp, vp]
@@ -541,6 +543,12 @@ class Graph:
 
     def __exit__(self, *a):
         self.close()
+
+    def device_memory(self):
+        """(free, total) bytes of HBM on the handle's device."""
+        f, t = C.c_uint64(), C.c_uint64()
+        _check(lib().pprhip_device_memory(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def set_tuning(self, t):
         _check(lib().pprhip_graph_set_tuning(self.h, C.byref(t)))

@@ -263,7 +263,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   unsigned long long* cells = nullptr;  // next_target, out_count, out_valid, overflow_count, pops, edges
   int rc = PPRHIP_OK;
   auto release = [&]() {
-    void* p[] = {cells, B.out_rec, B.overflow};
+    void* p[] = {cells, B.out_rec, B.overflow, B.list0, B.list1};
     for (void* q : p)
       if (q) (void)hipFree(q);
   };
@@ -272,7 +272,10 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   B.out_cap = std::min<unsigned long long>(1ull << 27, std::max<unsigned long long>(1ull << 16, 16ull * n_targets));
   if ((rc = alloc_dev((void**)&cells, sizeof(unsigned long long) * 16)) ||
       (rc = alloc_dev((void**)&B.out_rec, sizeof(TripleRec) * B.out_cap)) ||
-      (rc = alloc_dev((void**)&B.overflow, sizeof(int32_t) * std::max<uint32_t>(1, n_targets)))) {
+      (rc = alloc_dev((void**)&B.overflow, sizeof(int32_t) * std::max<uint32_t>(1, n_targets))) ||
+      // (tier 1 over a range: the list of targets with in-edges and the small table's give-ups, kernels_apbs.hip)
+      (rc = alloc_dev((void**)&B.list0, sizeof(int32_t) * std::max<uint32_t>(1, n_targets))) ||
+      (rc = alloc_dev((void**)&B.list1, sizeof(int32_t) * std::max<uint32_t>(1, n_targets)))) {
     release();
     return rc;
   }
@@ -555,9 +558,10 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     int32_t* ovf1 = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     const unsigned long long cap1 = std::max<unsigned long long>(1ull << 16, 16ull * per);
+    int32_t *l0 = nullptr, *l1 = nullptr;
     auto release1 = [&]() {
       (void)hipStreamSynchronize(t1_stream);
-      void* p[] = {cells1, out1, ovf1};
+      void* p[] = {cells1, out1, ovf1, l0, l1};
       for (void* q : p)
         if (q) (void)hipFree(q);
       if (h_cells1) (void)hipHostFree(h_cells1);
@@ -566,7 +570,9 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     };
     if ((rc = alloc_dev((void**)&cells1, sizeof(unsigned long long) * 16)) == PPRHIP_OK &&
         (rc = alloc_dev((void**)&out1, sizeof(TripleRec) * cap1)) == PPRHIP_OK &&
-        (rc = alloc_dev((void**)&ovf1, sizeof(int32_t) * per)) == PPRHIP_OK) {
+        (rc = alloc_dev((void**)&ovf1, sizeof(int32_t) * per)) == PPRHIP_OK &&
+        (rc = alloc_dev((void**)&l0, sizeof(int32_t) * per)) == PPRHIP_OK &&
+        (rc = alloc_dev((void**)&l1, sizeof(int32_t) * per)) == PPRHIP_OK) {
       if (hipHostMalloc((void**)&h_cells1, sizeof(unsigned long long) * 32, hipHostMallocDefault) != hipSuccess ||
           hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess) {
         set_error("All-Pair: host buffers of the side stream could not be had");
@@ -582,6 +588,8 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     B1.stat_edges = cells1 + 5;
     B1.out_rec = out1;
     B1.overflow = ovf1;
+    B1.list0 = l0;
+    B1.list1 = l1;
     B1.out_cap = cap1;
     // queues tier 1 for part c on the side stream (init words, kernel, counters back into pinned memory)
     auto launch_part = [&](uint32_t c) -> int {

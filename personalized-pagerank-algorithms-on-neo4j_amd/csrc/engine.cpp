@@ -1580,6 +1580,19 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   delete g;
 }
 
+int pprhip_device_memory(const pprhip_graph_t* g, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (!g) {
+    set_error("pprhip_device_memory: null handle");
+    return PPRHIP_ERR_INVALID;
+  }
+  PPRHIP_CHECK_HIP(hipSetDevice(g->device));
+  size_t f = 0, t = 0;
+  PPRHIP_CHECK_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (uint64_t)f;
+  if (total_bytes) *total_bytes = (uint64_t)t;
+  return PPRHIP_OK;
+}
+
 int pprhip_graph_info(const pprhip_graph_t* g, uint32_t* n, uint64_t* m, int* device) {
   if (!g) {
     set_error("pprhip_graph_info: null graph handle");

@@ -471,6 +471,7 @@ struct ApbsBuffers {
   unsigned long long *stat_pops = nullptr, *stat_edges = nullptr;
   TripleRec* out_rec = nullptr;  // the searches' entries >= threshold, 16-byte records
   int32_t* overflow = nullptr;
+  int32_t *list0 = nullptr, *list1 = nullptr;  // tier 1 over a range: the non-trivial targets, the small table's give-ups
   unsigned long long out_cap = 0;
   char* ws = nullptr;  // tier 2: per-workgroup dense workspaces (owned by the graph handle, see apbs_ws)
   void* board = nullptr;  // tier 2: one entry per workgroup on which it posts a level for helpers (zero at launch)

@@ -394,6 +394,7 @@ void add_stats(pprhip_stats_t& sum, const pprhip_stats_t& st) {
   sum.dense_levels += st.dense_levels; sum.rounds += st.rounds; sum.mc_sources += st.mc_sources;
   sum.sweep_min_bytes += st.sweep_min_bytes;
   sum.walks += st.walks; sum.walk_steps += st.walk_steps; sum.select_passes += st.select_passes;
+  sum.walk_loads += st.walk_loads; sum.walk_load_lanes += st.walk_load_lanes;
   sum.push_ms += st.push_ms; sum.mc_ms += st.mc_ms; sum.select_ms += st.select_ms; sum.total_ms += st.total_ms;
   sum.push_bytes += st.push_bytes; sum.mc_bytes += st.mc_bytes; sum.select_bytes += st.select_bytes;
   for (int c = 0; c < 8; ++c) {

@@ -4,8 +4,13 @@
 // (Backward_Search.java:38-100) per target; the searches are independent.  A persistent workgroup takes one
 // target at a time and keeps that target's whole state (residue, reserve, frontier) to itself:
 //
-//   tier 1  hash table of 2048 entries in LDS (ds_cmpst / ds_add_rtn_f64), two workgroups per CU: nine searches in
-//           ten touch fewer than 1536 nodes (R-MAT 22, threshold 1e-3: 89 % of the targets, 8 % of the edges);
+//   tier 1  hash table in LDS (ds_cmpst / ds_add_rtn_f64).  Round 4 runs it in three steps on the device, because the tier
+//           is bound by latency and barriers and not by anything a search computes (R-MAT 22: 257 ms for 3.6 M searches
+//           on two workgroups per CU): a streaming pass that emits the targets without in-edges - 52 % of R-MAT 22's
+//           nodes; their search is {t: 1.0} - and lists the others; a 512-slot table (20 KB: eight workgroups per
+//           CU) for the searches that touch fewer than 384 nodes, another 20 % of the targets; the 2048-slot table
+//           (76 KB: two per CU) for what the small one gave up.  Nine searches in ten touch fewer than 1536 nodes
+//           (89 % of the targets, 8 % of the edges);
 //   tier 2  the searches tier 1 gave up, on *dense* per-workgroup vectors (residue and reserve indexed by node id,
 //           8n bytes each, zero between searches): an edge is ONE returning fp64 atomic and nothing else random;
 //   tier 3  (host, fallback only) the engine's whole-vector backward search on the batch slots, for a search whose
@@ -34,8 +39,10 @@
 
 namespace pprhip {
 
-constexpr int kApLdsCap = 2048;
+constexpr int kApLdsCap = 2048;   // slots of the large LDS table (two workgroups per CU) ...
 constexpr int kApFront = 512;
+constexpr int kApSmallCap = 512;  // ... and of the small one (eight per CU)
+constexpr int kApSmallFront = 128;
 
 // in-edge record: the source of the edge and its out-degree (Backward_Search.java:84 divides by it per edge), so that
 // an edge costs one coalesced 8-byte read instead of a column index and a gather of the source's row extent
@@ -101,18 +108,19 @@ struct ApTable {  // one target's state in LDS
 // threads that see the flag stop inserting, so the table never fills up - in a full table every further lookup of a
 // new node walks all of it (measured before this check: 4.3 M such walks of 2048 probes each, nine tenths of all
 // the probes of the tier)
+template <int CAP>
 __device__ __forceinline__ uint32_t ap_slot(const ApTable& T, int32_t u, uint32_t* used_count, uint32_t limit,
                                             uint32_t* overflow) {
-  constexpr uint32_t mask = kApLdsCap - 1;
+  constexpr uint32_t mask = CAP - 1;
   uint32_t s = ((uint32_t)u * 2654435761u) >> 7 & mask;
-  for (uint32_t probes = 0; probes < (uint32_t)kApLdsCap; ++probes) {
+  for (uint32_t probes = 0; probes < (uint32_t)CAP; ++probes) {
     const int32_t k = T.keys[s];
     if (k == u) return s;
     if (k == -1) {
       const int32_t prev = atomicCAS(&T.keys[s], -1, u);  // ds_cmpst_rtn_b32
       if (prev == -1) {
         const uint32_t idx = atomicAdd(used_count, 1u);
-        if (idx < (uint32_t)kApLdsCap) T.used[idx] = (uint16_t)s;
+        if (idx < (uint32_t)CAP) T.used[idx] = (uint16_t)s;
         if (idx >= limit) *overflow = 1;
         return s;
       }
@@ -135,11 +143,18 @@ struct ApOut {
   unsigned long long* stat_edges;
 };
 
+// target_list entries: a target id, or -(id + 1) for a target an earlier step has listed for another try (its record
+// buffer was full); n_targets_dev != nullptr: the list's length is read there (written by the step before, on the device)
+template <int CAP, int FRONT>
 __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ target_list, uint32_t t_begin,
-                                                   uint32_t n_targets, unsigned long long* next_target,
+                                                   uint32_t n_targets_arg, const unsigned long long* n_targets_dev,
+                                                   unsigned long long* next_target,
                                                    const uint32_t* __restrict__ in_rp, const InRec* __restrict__ in_rec,
                                                    const int32_t* __restrict__ old2new, const int32_t* __restrict__ new2old,
                                                    double alpha, double rmax, ApOut O) {
+  constexpr int kApLdsCap = CAP;  // (the names the body was written with)
+  constexpr int kApFront = FRONT;
+  static_assert(FRONT % 256 == 0 || FRONT == 128, "the sub-batch code below walks FRONT entries with 256 threads");
   __shared__ int32_t s_keys[kApLdsCap];
   __shared__ double s_res[kApLdsCap];
   __shared__ double s_rsv[kApLdsCap];
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
   __shared__ uint32_t f_row[kApFront];
   __shared__ uint32_t f_off[kApFront + 1];
   __shared__ double f_c[kApFront];
+  const unsigned long long n_targets = n_targets_dev ? *n_targets_dev : (unsigned long long)n_targets_arg;
   __shared__ uint32_t s_scan[4];
   __shared__ unsigned long long s_scan64[4];
   __shared__ uint32_t s_used_count, s_nnext, s_overflow;
@@ -171,7 +187,8 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
     __syncthreads();
     const unsigned long long ti = s_t;
     if (ti >= n_targets) break;
-    const int32_t t_old = target_list ? target_list[ti] : (int32_t)(t_begin + ti);
+    int32_t t_old = target_list ? target_list[ti] : (int32_t)(t_begin + ti);
+    if (t_old < 0) t_old = -(t_old + 1);
     const int32_t t = old2new[t_old];
     if (tid == 0) {
       s_used_count = 0;
@@ -189,12 +206,12 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
     uint32_t nf = 0;
     if (in_rp[t + 1] == in_rp[t]) {  // Backward_Search.java:46-49: reserve = {t: 1.0}
       if (tid == 0) {
-        const uint32_t s = ap_slot(T, t, &s_used_count, limit, &s_overflow);
+        const uint32_t s = ap_slot<CAP>(T, t, &s_used_count, limit, &s_overflow);
         T.rsv[s] = 1.0;
       }
     } else {
       if (tid == 0) {
-        const uint32_t s = ap_slot(T, t, &s_used_count, limit, &s_overflow);
+        const uint32_t s = ap_slot<CAP>(T, t, &s_used_count, limit, &s_overflow);
         T.res[s] = 1.0;  // :54-56; the target is pushed unconditionally first
         T.cur[0] = (uint16_t)s;
       }
@@ -238,9 +255,9 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
           }
         }
         // exclusive prefix of the degrees over the sub-batch (two elements per thread: i, i + 256)
-        uint32_t tot0 = 0, tot1 = 0;
+        uint32_t tot0 = 0, tot1 = 0, e1 = 0;
         const uint32_t e0 = block_excl_scan_256<uint32_t>(d0, s_scan, &tot0);
-        const uint32_t e1 = block_excl_scan_256<uint32_t>(d1, s_scan, &tot1);
+        if (FRONT > 256) e1 = block_excl_scan_256<uint32_t>(d1, s_scan, &tot1);  // (the small table stages 128 entries)
         if ((uint32_t)tid < cnt) f_off[tid] = e0;
         if ((uint32_t)tid + 256 < cnt) f_off[tid + 256] = tot0 + e1;
         if (tid == 0) f_off[cnt] = tot0 + tot1;
@@ -271,7 +288,7 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
           for (int q = 0; q < 4; ++q) {
             if (rc4[q].u < 0 || s_overflow) continue;
             const double add = cc[q] / (double)rc4[q].dout;  // :84-85
-            const uint32_t s = ap_slot(T, rc4[q].u, &s_used_count, limit, &s_overflow);
+            const uint32_t s = ap_slot<CAP>(T, rc4[q].u, &s_used_count, limit, &s_overflow);
             if (s == 0xFFFFFFFFu) {
               s_overflow = 1;
               continue;
@@ -357,6 +374,50 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
   if (tid == 0) {
     if (ps) atomic_add_u64(O.stat_pops, ps);
     if (es) atomic_add_u64(O.stat_edges, es);
+  }
+}
+
+// Tier 1, first step: the targets [t_begin, t_begin + n) in one streaming pass.  A target without in-edges yields
+// {t: 1.0} (Backward_Search.java:46-49: emitted here when 1.0 >= threshold, one reservation per wave); the others are
+// listed for the table kernels.  A record that finds the buffer full sends its target to the list as -(t + 1): the
+// table kernel then runs it like any other (its first branch is the same rule).
+__global__ __launch_bounds__(256) void k_apbs_split(uint32_t t_begin, uint32_t n, const uint32_t* __restrict__ in_rp,
+                                                     const int32_t* __restrict__ old2new, double rmax, ApOut O,
+                                                     int32_t* __restrict__ list, unsigned long long* __restrict__ list_count) {
+  const int lane = lane_id();
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += stride) {  // (wave-uniform trip count)
+    const uint32_t i = i0 + threadIdx.x;
+    const int32_t t_old = (int32_t)(t_begin + i);
+    bool trivial = false;
+    if (i < n) {
+      const int32_t t = old2new[t_old];
+      trivial = in_rp[t + 1] == in_rp[t];
+    }
+    bool listed = i < n && !trivial;
+    bool emit = trivial && 1.0 >= rmax;
+    const unsigned long long em = __ballot(emit);
+    if (em) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomic_add_u64(O.out_count, (unsigned long long)__popcll(em));
+      base = __shfl(base, 0);
+      const unsigned long long pos = base + (unsigned long long)__popcll(em & ((1ull << lane) - 1ull));
+      if (emit) {
+        if (pos < O.out_cap) {
+          O.out_rec[pos] = TripleRec{t_old, t_old, 1.0};
+        } else {  // buffer full: the host drains it and the target runs again
+          atomicMin(O.out_valid, base < O.out_cap ? O.out_cap : base);
+          listed = true;
+        }
+      }
+    }
+    const unsigned long long lm = __ballot(listed);
+    if (lm) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomic_add_u64(list_count, (unsigned long long)__popcll(lm));
+      base = __shfl(base, 0);
+      if (listed) list[base + (unsigned long long)__popcll(lm & ((1ull << lane) - 1ull))] = trivial ? -(t_old + 1) : t_old;
+    }
   }
 }
 
@@ -1160,7 +1221,9 @@ int launch_emit_reserve(pprhip_graph* g, const double* reserve, uint32_t n, doub
 
 int init_kernels_apbs() {  // loads this file's code object on the current device (see init_kernels_push)
   hipFuncAttributes fa;
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_lds)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_lds<kApLdsCap, kApFront>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_lds<kApSmallCap, kApSmallFront>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_split)));
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_dense)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apbs_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(2 * sizeof(double) * kDnHotMax)));
@@ -1199,10 +1262,28 @@ int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint
         d_targets, n_targets, b.next_target, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O, b.ws, (DnBoard*)b.board,
         b.done_targets, b.done_targets + 1, b.done_targets + 2, dims_of(g->n, (unsigned long long)g->m, b.cap_t, b.cap_f, b.chunk), share,
         owners, hot_n, b.dbg);
+  } else if (!d_targets && b.list0 && b.list1) {
+    // a range, in three steps on the device: trivial targets and the list of the others; the small table; the large
+    // table for what the small one gave up (cells: +6 the list's length, +7 the small table's target cursor, +11 the
+    // length of its give-up list; b.next_target is the large table's cursor)
+    unsigned long long* cells = b.next_target;
+    const uint32_t sgrid = (uint32_t)std::min<uint64_t>(((uint64_t)n_targets + 255) / 256, 2048);
+    k_apbs_split<<<dim3(sgrid), dim3(256), 0, g->stream>>>(t_begin, n_targets, g->in_rp, g->old2new, rmax, O, b.list0, cells + 6);
+    PPRHIP_CHECK_HIP(hipGetLastError());
+    ApOut O0 = O;  // the small table's give-ups (and retries) go to the second list
+    O0.overflow_list = b.list1;
+    O0.overflow_count = cells + 11;
+    const uint32_t grid0 = std::min<uint32_t>((uint32_t)g->n_cus * 8u, std::max(1u, n_targets));
+    k_apbs_lds<kApSmallCap, kApSmallFront><<<dim3(grid0), dim3(256), 0, g->stream>>>(
+        b.list0, 0u, 0u, cells + 6, cells + 7, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O0);
+    PPRHIP_CHECK_HIP(hipGetLastError());
+    const uint32_t grid1 = std::min<uint32_t>((uint32_t)g->n_cus * 2u, std::max(1u, n_targets));
+    k_apbs_lds<kApLdsCap, kApFront><<<dim3(grid1), dim3(256), 0, g->stream>>>(
+        b.list1, 0u, 0u, cells + 11, b.next_target, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O);
   } else {
     const uint32_t grid = std::min<uint32_t>((uint32_t)g->n_cus * 2u, std::max(1u, n_targets));
-    k_apbs_lds<<<dim3(grid), dim3(256), 0, g->stream>>>(d_targets, t_begin, n_targets, b.next_target, g->in_rp, rec,
-                                                        g->old2new, g->new2old, alpha, rmax, O);
+    k_apbs_lds<kApLdsCap, kApFront><<<dim3(grid), dim3(256), 0, g->stream>>>(d_targets, t_begin, n_targets, nullptr, b.next_target,
+                                                                             g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O);
   }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
