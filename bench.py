@@ -1086,11 +1086,25 @@ def stream_idle(args):
     wall = max(1, t1 - t0)
     on_main = [x for x in region if x[key] == main]
     others = [x for x in region if x[key] != main]
+    # where the compute stream idles: gaps between consecutive kernels on it, by (kernel before -> kernel after)
+    gaps = {}
+    prev_end, prev_name = None, None
+    for x in on_main:
+        lo, hi, name = int(x["Start_Timestamp"]), int(x["End_Timestamp"]), _short(x["Kernel_Name"]).split("<")[0]
+        if prev_end is not None and lo > prev_end:
+            g = gaps.setdefault("%s -> %s" % (prev_name, name), [0, 0])
+            g[0] += 1
+            g[1] += lo - prev_end
+        if prev_end is None or hi > prev_end:
+            prev_end, prev_name = hi, name
+    top = sorted(gaps.items(), key=lambda kv: -kv[1][1])[:8]
     return {"source": "rocprofv3 --kernel-trace child pass over two steps of the headline workload; intervals grouped by %s" % key,
             "compute_stream_idle_frac": round(1.0 - union(on_main) / wall, 4),
             "any_stream_idle_frac": round(1.0 - union(region) / wall, 4),
             "side_streams_busy_frac": round(union(others) / wall, 4),
             "wall_ms": round(wall / 1e6, 2), "kernels_on_compute_stream": len(on_main), "kernels_on_side_streams": len(others),
+            "largest_gaps_on_compute_stream": [{"between": k, "count": v[0], "ms": round(v[1] / 1e6, 2),
+                                                "avg_us": round(v[1] / 1e3 / v[0], 1)} for k, v in top],
             "queries": 2 * args.queries_per_step}
 
 

@@ -521,145 +521,12 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       to_tier3.insert(to_tier3.end(), list.begin(), list.end());  // no memory for the dense tier: everything runs on the batch slots
     }
   };
-  bool piped = false;  // tier 2 has already run, chunk by chunk, beside tier 1 (below)
-  // ---- Large ranges: tier 1 of the next third of the range runs on a side stream while the dense tier works on
-  // what the third before left over.  The LDS searches are bound by LDS and latency, the dense tier by the rate of
-  // memory-side read-modify-writes (kernels_apbs.hip), and both fit a CU together (one LDS workgroup instead of two),
-  // so two thirds of tier 1's time disappear behind tier 2 - less what every extra dense pass costs at its end, when
-  // the last long searches run with few workgroups: -5 % on R-MAT 22.
-  hipStream_t t1_stream = nullptr;
-  if (first_tier <= 1 && n_targets >= (1u << 20) && !getenv("PPRHIP_APBS_NO_PIPE")) {
-    if (!g->apbs_side_tried) {
-      g->apbs_side_tried = true;
-      if (make_side_stream(g, &g->apbs_side_stream) != PPRHIP_OK) g->apbs_side_stream = nullptr;
-    }
-    t1_stream = g->apbs_side_stream;
-  }
-  if (t1_stream) {
-    // Three equal parts (PPRHIP_APBS_PARTS=a,b sets the two cuts as fractions of the range - developer switch).  A small
-    // first part shortens the only LDS pass nothing runs beside, but what is saved there comes back as longer dense
-    // passes - LDS searches beside a dense pass slow it down by nearly their own duration (R-MAT 22, cuts at 0.08 /
-    // 0.125 / 0.2 / 0.333: 805 / 801 / 806 / 799 ms for tiers 1 + 2); more parts cost more than they hide.
-    constexpr uint32_t kParts = 3;
-    double cut_a = 1.0 / 3.0, cut_b = 2.0 / 3.0;
-    if (const char* pe = getenv("PPRHIP_APBS_PARTS")) {
-      double a = 0, b = 0;
-      if (sscanf(pe, "%lf,%lf", &a, &b) == 2 && a > 0.0 && a < b && b < 1.0) {
-        cut_a = a;
-        cut_b = b;
-      }
-    }
-    const uint32_t part_lo[kParts + 1] = {0u, (uint32_t)(cut_a * n_targets), (uint32_t)(cut_b * n_targets), n_targets};
-    uint32_t per = 0;  // the largest part (buffer sizes)
-    for (uint32_t c = 0; c < kParts; ++c) per = std::max(per, part_lo[c + 1] - part_lo[c]);
-    unsigned long long* cells1 = nullptr;
-    unsigned long long* h_cells1 = nullptr;
-    TripleRec* out1 = nullptr;
-    int32_t* ovf1 = nullptr;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    const unsigned long long cap1 = std::max<unsigned long long>(1ull << 16, 16ull * per);
-    int32_t *l0 = nullptr, *l1 = nullptr;
-    auto release1 = [&]() {
-      (void)hipStreamSynchronize(t1_stream);
-      void* p[] = {cells1, out1, ovf1, l0, l1};
-      for (void* q : p)
-        if (q) (void)hipFree(q);
-      if (h_cells1) (void)hipHostFree(h_cells1);
-      if (ev_a) (void)hipEventDestroy(ev_a);
-      if (ev_b) (void)hipEventDestroy(ev_b);
-    };
-    if ((rc = alloc_dev((void**)&cells1, sizeof(unsigned long long) * 16)) == PPRHIP_OK &&
-        (rc = alloc_dev((void**)&out1, sizeof(TripleRec) * cap1)) == PPRHIP_OK &&
-        (rc = alloc_dev((void**)&ovf1, sizeof(int32_t) * per)) == PPRHIP_OK &&
-        (rc = alloc_dev((void**)&l0, sizeof(int32_t) * per)) == PPRHIP_OK &&
-        (rc = alloc_dev((void**)&l1, sizeof(int32_t) * per)) == PPRHIP_OK) {
-      if (hipHostMalloc((void**)&h_cells1, sizeof(unsigned long long) * 32, hipHostMallocDefault) != hipSuccess ||
-          hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess) {
-        set_error("All-Pair: host buffers of the side stream could not be had");
-        rc = PPRHIP_ERR_OOM;
-      }
-    }
-    ApbsBuffers B1;
-    B1.next_target = cells1;
-    B1.out_count = cells1 + 1;
-    B1.out_valid = cells1 + 2;
-    B1.overflow_count = cells1 + 3;
-    B1.stat_pops = cells1 + 4;
-    B1.stat_edges = cells1 + 5;
-    B1.out_rec = out1;
-    B1.overflow = ovf1;
-    B1.list0 = l0;
-    B1.list1 = l1;
-    B1.out_cap = cap1;
-    // queues tier 1 for part c on the side stream (init words, kernel, counters back into pinned memory)
-    auto launch_part = [&](uint32_t c) -> int {
-      const uint32_t lo = part_lo[c], cnt = part_lo[c + 1] - lo;
-      for (int i = 0; i < 16; ++i) h_cells1[16 + i] = 0ull;
-      h_cells1[16 + 2] = ~0ull;
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(cells1, h_cells1 + 16, sizeof(unsigned long long) * 16, hipMemcpyHostToDevice, t1_stream));
-      PPRHIP_CHECK_HIP(hipEventRecord(ev_a, t1_stream));
-      hipStream_t own = g->stream;
-      g->stream = t1_stream;
-      const int lrc = launch_apbs(g, false, nullptr, t_begin + lo, cnt, alpha, threshold, B1);
-      g->stream = own;
-      PPRHIP_TRY(lrc);
-      PPRHIP_CHECK_HIP(hipEventRecord(ev_b, t1_stream));
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(h_cells1, cells1, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, t1_stream));
-      return PPRHIP_OK;
-    };
-    // waits for part c, hands its entries over and returns the targets it left for the dense tier
-    auto harvest_part = [&](uint32_t c, std::vector<int32_t>& left) -> int {
-      PPRHIP_CHECK_HIP(hipStreamSynchronize(t1_stream));
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ev_a, ev_b) == hipSuccess) {
-        ktimer().acc_ms[PPRHIP_KERNEL_BACKWARD_BATCH] += (double)ms;
-        ktimer().acc_cnt[PPRHIP_KERNEL_BACKWARD_BATCH]++;
-      }
-      const unsigned long long valid = std::min(std::min(h_cells1[1], h_cells1[2]), cap1);
-      st.pops += h_cells1[4];
-      st.edge_pushes += h_cells1[5];
-      const uint64_t bytes = 44ull * h_cells1[4] + 28ull * h_cells1[5] + 16ull * valid;
-      st.push_bytes += bytes;
-      ktimer().acc_bytes[PPRHIP_KERNEL_BACKWARD_BATCH] += bytes;
-      if (valid) {
-        PPRHIP_TRY(sink.take_device(g, out1, valid));
-        PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));  // the next part overwrites the buffer the copy reads
-      }
-      std::vector<int32_t> again;
-      const unsigned long long novf = h_cells1[3];
-      if (novf) {
-        h_ovf.resize(novf);
-        PPRHIP_CHECK_HIP(hipMemcpy(h_ovf.data(), ovf1, sizeof(int32_t) * novf, hipMemcpyDeviceToHost));
-        for (int32_t x : h_ovf) {
-          if (x >= 0) left.push_back(x);
-          else again.push_back(-(x + 1));  // the part's record buffer was full: tier 1 again, on the compute stream
-        }
-      }
-      if (!again.empty()) PPRHIP_TRY(run_tier(false, again, false, left));
-      (void)c;
-      return PPRHIP_OK;
-    };
-    if (rc == PPRHIP_OK) rc = launch_part(0);
-    for (uint32_t c = 0; c < kParts && rc == PPRHIP_OK; ++c) {
-      std::vector<int32_t> left;
-      const auto tp0 = now();
-      rc = harvest_part(c, left);
-      if (rc != PPRHIP_OK) break;
-      const double ms_harvest = ms_since(tp0);
-      if (c + 1 < kParts) rc = launch_part(c + 1);
-      if (rc != PPRHIP_OK) break;
-      to_tier2.insert(to_tier2.end(), left.begin(), left.end());
-      const auto tp1 = now();
-      if (!left.empty()) dense_pass(left);  // (sets rc)
-      if (dbg_times)
-        fprintf(stderr, "[apbs host] part %u: waited %.1f ms for tier 1 and its entries, dense tier on %zu targets %.1f ms\n", c,
-                ms_harvest, left.size(), ms_since(tp1));
-    }
-    release1();
-    piped = true;
-    if (dbg_times) fprintf(stderr, "[apbs host] tiers 1 and 2, part by part: %.1f ms\n", ms_since(t_phase));
-    t_phase = now();
-  } else if (first_tier <= 1) {
+  // (Rounds 3 and 4 ran tier 1 of the next third of a large range on a side stream beside the dense pass of the third
+  // before.  LDS searches beside a dense pass slow it down by nearly their own duration, so it saved 5 % when tier 1 was a
+  // quarter of the job; since tier 1 routes its targets by in-degree it is a seventh of it, and the tiers one after the
+  // other are as fast or faster - R-MAT 22: 655 against 670 ms, R-MAT 24: 1 894 against 1 910 ms - with one pass of each
+  // tier instead of three.  The side-by-side form was taken out.)
+  if (first_tier <= 1) {
     rc = run_tier(false, {}, true, to_tier2);
     if (dbg_times) fprintf(stderr, "[apbs host] tier 1 (kernel passes + hand-over of entries): %.1f ms\n", ms_since(t_phase));
     t_phase = now();
@@ -667,7 +534,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     for (uint32_t t = t_begin; t < t_end; ++t) (first_tier == 2 ? to_tier2 : to_tier3).push_back((int32_t)t);
   }
   if (rc == PPRHIP_OK && !to_tier2.empty()) {
-    if (!piped) dense_pass(to_tier2);
+    dense_pass(to_tier2);
     // ---- the searches whose frontier or popped-node list outgrew the workspaces' lists: once more with a few
     // workspaces whose lists hold every node, all the other workgroups helping with their levels
     st.xl_targets = (uint32_t)to_tier3.size();  // searches that outgrew a workspace's lists

@@ -1540,9 +1540,6 @@ static void free_all_pair(pprhip_graph* g) {
   if (g->ix_host) free(g->ix_host);
   g->ix_host = nullptr;
   g->ix_host_bytes = 0;
-  if (g->apbs_side_stream) (void)hipStreamDestroy(g->apbs_side_stream);
-  g->apbs_side_stream = nullptr;
-  g->apbs_side_tried = false;
 }
 
 int pprhip_graph_release(pprhip_graph_t* g, unsigned what) {

@@ -293,8 +293,6 @@ struct pprhip_graph {
   void* in_rec = nullptr;
   char* apbs_ws = nullptr;
   void* apbs_board = nullptr;
-  hipStream_t apbs_side_stream = nullptr;  // All-Pair: tier 1 of the next part of a large range runs here beside tier 2
-  bool apbs_side_tried = false;
   void* ix_stage = nullptr;  // pinned ring the sorted index entries are downloaded through (index_from_device)
   size_t ix_stage_bytes = 0;
   void* ix_host = nullptr;   // pageable host memory they land in (keys, then values), kept between calls

@@ -8,7 +8,9 @@
 //           is bound by latency and barriers and not by anything a search computes (R-MAT 22: 257 ms for 3.6 M searches
 //           on two workgroups per CU): a streaming pass that emits the targets without in-edges - 52 % of R-MAT 22's
 //           nodes; their search is {t: 1.0} - and lists the others; a 512-slot table (20 KB: eight workgroups per
-//           CU) for the searches that touch fewer than 384 nodes, another 20 % of the targets; the 2048-slot table
+//           CU, ONE WAVE each: a search of a few hundred edges leaves four waves' worth of lanes idle, and every
+//           wave of a workgroup executes every scan and barrier of the search) for the searches that touch fewer
+//           than 384 nodes, another 20 % of the targets; the 2048-slot table
 //           (76 KB: two per CU) for what the small one gave up.  Nine searches in ten touch fewer than 1536 nodes
 //           (89 % of the targets, 8 % of the edges);
 //   tier 2  the searches tier 1 gave up, on *dense* per-workgroup vectors (residue and reserve indexed by node id,
@@ -43,6 +45,7 @@ constexpr int kApLdsCap = 2048;   // slots of the large LDS table (two workgroup
 constexpr int kApFront = 512;
 constexpr int kApSmallCap = 512;  // ... and of the small one (eight per CU)
 constexpr int kApSmallFront = 128;
+constexpr int kApSmallThreads = 64;
 
 // in-edge record: the source of the edge and its out-degree (Backward_Search.java:84 divides by it per edge), so that
 // an edge costs one coalesced 8-byte read instead of a column index and a gather of the source's row extent
@@ -145,8 +148,8 @@ struct ApOut {
 
 // target_list entries: a target id, or -(id + 1) for a target an earlier step has listed for another try (its record
 // buffer was full); n_targets_dev != nullptr: the list's length is read there (written by the step before, on the device)
-template <int CAP, int FRONT>
-__global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ target_list, uint32_t t_begin,
+template <int CAP, int FRONT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_apbs_lds(const int32_t* __restrict__ target_list, uint32_t t_begin,
                                                    uint32_t n_targets_arg, const unsigned long long* n_targets_dev,
                                                    unsigned long long* next_target,
                                                    const uint32_t* __restrict__ in_rp, const InRec* __restrict__ in_rec,
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
                                                    double alpha, double rmax, ApOut O) {
   constexpr int kApLdsCap = CAP;  // (the names the body was written with)
   constexpr int kApFront = FRONT;
-  static_assert(FRONT % 256 == 0 || FRONT == 128, "the sub-batch code below walks FRONT entries with 256 threads");
+  static_assert(THREADS % 64 == 0 && (FRONT == THREADS || FRONT == 2 * THREADS),
+                "the sub-batch code below stages one or two frontier entries per thread");
   __shared__ int32_t s_keys[kApLdsCap];
   __shared__ double s_res[kApLdsCap];
   __shared__ double s_rsv[kApLdsCap];
@@ -166,15 +170,15 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
   __shared__ uint32_t f_off[kApFront + 1];
   __shared__ double f_c[kApFront];
   const unsigned long long n_targets = n_targets_dev ? *n_targets_dev : (unsigned long long)n_targets_arg;
-  __shared__ uint32_t s_scan[4];
-  __shared__ unsigned long long s_scan64[4];
+  __shared__ uint32_t s_scan[THREADS / 64];
+  __shared__ unsigned long long s_scan64[THREADS / 64];
   __shared__ uint32_t s_used_count, s_nnext, s_overflow;
   __shared__ unsigned long long s_t, s_out_base, s_tot;
   const int tid = threadIdx.x;
 
   ApTable T{s_keys, s_res, s_rsv, s_pend, s_used, s_cur, s_nxt};
   const uint32_t limit = kApLdsCap - kApLdsCap / 4;  // give up at 75 % load
-  for (uint32_t i = tid; i < (uint32_t)kApLdsCap; i += 256) {
+  for (uint32_t i = tid; i < (uint32_t)kApLdsCap; i += THREADS) {
     T.keys[i] = -1;
     T.res[i] = 0.0;
     T.rsv[i] = 0.0;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
 
     while (nf > 0 && !s_overflow) {
       // ---- every frontier node gives up its residue (:58-67,72)
-      for (uint32_t i = tid; i < nf; i += 256) {
+      for (uint32_t i = tid; i < nf; i += THREADS) {
         const uint32_t s = T.cur[i];
         const double rc = T.res[s];
         T.res[s] = 0.0;
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
         const uint32_t cnt = nf - fb < (uint32_t)kApFront ? nf - fb : (uint32_t)kApFront;
         uint32_t d0 = 0, d1 = 0;
         {
-          const uint32_t i0 = tid, i1 = tid + 256;
+          const uint32_t i0 = tid, i1 = tid + THREADS;
           if (i0 < cnt) {
             const uint32_t s = T.cur[fb + i0];
             const int32_t v = T.keys[s];
@@ -254,23 +258,24 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
             f_c[i1] = T.pend[s];
           }
         }
-        // exclusive prefix of the degrees over the sub-batch (two elements per thread: i, i + 256)
+        // exclusive prefix of the degrees over the sub-batch (two elements per thread: i, i + THREADS)
         uint32_t tot0 = 0, tot1 = 0, e1 = 0;
-        const uint32_t e0 = block_excl_scan_256<uint32_t>(d0, s_scan, &tot0);
-        if (FRONT > 256) e1 = block_excl_scan_256<uint32_t>(d1, s_scan, &tot1);  // (the small table stages 128 entries)
+        const uint32_t e0 = block_excl_scan_n<uint32_t, THREADS / 64>(d0, s_scan, &tot0);
+        if (FRONT > THREADS) e1 = block_excl_scan_n<uint32_t, THREADS / 64>(d1, s_scan, &tot1);  // (the small table stages 128 entries)
         if ((uint32_t)tid < cnt) f_off[tid] = e0;
-        if ((uint32_t)tid + 256 < cnt) f_off[tid + 256] = tot0 + e1;
+        if ((uint32_t)tid + THREADS < cnt) f_off[tid + THREADS] = tot0 + e1;
         if (tid == 0) f_off[cnt] = tot0 + tot1;
         __syncthreads();
         const uint32_t E = f_off[cnt];
         edges += (tid == 0) ? E : 0;
         // four edges per thread in flight: edge records first, then table updates
-        for (uint32_t base = tid; base < E; base += 1024) {
+        for (uint32_t base = tid; base < E; base += 4 * THREADS) {
+          if (s_overflow) break;  // the search goes to the next step anyway: do not read the rest of a hub's in-edges
           InRec rc4[4];
           double cc[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const uint32_t e = base + 256u * q;
+            const uint32_t e = base + (uint32_t)THREADS * q;
             rc4[q] = InRec{-1, 1u};
             cc[q] = 0.0;
             if (e < E) {
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
     bool retry = ovf;
     if (!ovf) {
       unsigned long long run = 0;
-      for (uint32_t c0 = 0; c0 < used; c0 += 256) {  // count first, one reservation per target
+      for (uint32_t c0 = 0; c0 < used; c0 += THREADS) {  // count first, one reservation per target
         const uint32_t i = c0 + tid;
         const bool take = i < used && T.rsv[T.used[i]] > 0.0 && T.rsv[T.used[i]] >= rmax;
         run += take ? 1ull : 0ull;
@@ -333,13 +338,13 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
         if (tid == 0) atomicMin(O.out_valid, s_out_base);
       } else {
         unsigned long long at = s_out_base;
-        for (uint32_t c0 = 0; c0 < used; c0 += 256) {
+        for (uint32_t c0 = 0; c0 < used; c0 += THREADS) {
           const uint32_t i = c0 + tid;
           const uint32_t s = i < used ? T.used[i] : 0u;
           const bool take = i < used && T.rsv[s] > 0.0 && T.rsv[s] >= rmax;
           unsigned long long chunk_total = 0;
           const unsigned long long ex =
-              block_excl_scan_256<unsigned long long>(take ? 1ull : 0ull, s_scan64, &chunk_total);
+              block_excl_scan_n<unsigned long long, THREADS / 64>(take ? 1ull : 0ull, s_scan64, &chunk_total);
           if (take) {
             O.out_rec[at + ex] = TripleRec{new2old[T.keys[s]], t_old, T.rsv[s]};
           }
@@ -354,13 +359,13 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
     __syncthreads();
     // ---- clear the touched slots (all of them after an overflow)
     if (ovf) {
-      for (uint32_t i = tid; i < (uint32_t)kApLdsCap; i += 256) {
+      for (uint32_t i = tid; i < (uint32_t)kApLdsCap; i += THREADS) {
         T.keys[i] = -1;
         T.res[i] = 0.0;
         T.rsv[i] = 0.0;
       }
     } else {
-      for (uint32_t i = tid; i < used; i += 256) {
+      for (uint32_t i = tid; i < used; i += THREADS) {
         const uint32_t s = T.used[i];
         T.keys[s] = -1;
         T.res[s] = 0.0;
@@ -378,24 +383,32 @@ __global__ __launch_bounds__(256) void k_apbs_lds(const int32_t* __restrict__ ta
 }
 
 // Tier 1, first step: the targets [t_begin, t_begin + n) in one streaming pass.  A target without in-edges yields
-// {t: 1.0} (Backward_Search.java:46-49: emitted here when 1.0 >= threshold, one reservation per wave); the others are
-// listed for the table kernels.  A record that finds the buffer full sends its target to the list as -(t + 1): the
-// table kernel then runs it like any other (its first branch is the same rule).
+// {t: 1.0} (Backward_Search.java:46-49: emitted here when 1.0 >= threshold, one reservation per wave).  The others
+// are routed by their in-degree, which predicts the size of a search well (tools/exp: of R-MAT 22's targets with 1-2
+// in-edges 64-80 % touch fewer than 384 nodes; with 5-8, 74 % fewer than 1536; with 17 and more, 94-100 % outgrow the
+// LDS tables): below deg_big to the small table's list, below deg_dense to the large table's, the rest straight to the
+// give-up list the host hands to the dense tier - a search that starts in a table it is going to outgrow is work done
+// twice.  A wrong guess is only that: every table still hands on what it cannot hold.  A record that finds the buffer
+// full sends its target to the large table's list as -(t + 1) (the table kernel's first branch is the same rule).
 __global__ __launch_bounds__(256) void k_apbs_split(uint32_t t_begin, uint32_t n, const uint32_t* __restrict__ in_rp,
                                                      const int32_t* __restrict__ old2new, double rmax, ApOut O,
-                                                     int32_t* __restrict__ list, unsigned long long* __restrict__ list_count) {
+                                                     int32_t* __restrict__ list_small, unsigned long long* __restrict__ n_small,
+                                                     int32_t* __restrict__ list_big, unsigned long long* __restrict__ n_big,
+                                                     uint32_t deg_big, uint32_t deg_dense) {
   const int lane = lane_id();
   const uint32_t stride = gridDim.x * 256u;
   for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += stride) {  // (wave-uniform trip count)
     const uint32_t i = i0 + threadIdx.x;
     const int32_t t_old = (int32_t)(t_begin + i);
-    bool trivial = false;
+    uint32_t deg = 0;
     if (i < n) {
       const int32_t t = old2new[t_old];
-      trivial = in_rp[t + 1] == in_rp[t];
+      deg = in_rp[t + 1] - in_rp[t];
     }
-    bool listed = i < n && !trivial;
-    bool emit = trivial && 1.0 >= rmax;
+    const bool trivial = i < n && deg == 0;
+    int32_t entry = t_old;
+    int route = (i >= n || trivial) ? -1 : (deg < deg_big ? 0 : (deg < deg_dense ? 1 : 2));
+    const bool emit = trivial && 1.0 >= rmax;
     const unsigned long long em = __ballot(emit);
     if (em) {
       unsigned long long base = 0;
@@ -407,16 +420,21 @@ __global__ __launch_bounds__(256) void k_apbs_split(uint32_t t_begin, uint32_t n
           O.out_rec[pos] = TripleRec{t_old, t_old, 1.0};
         } else {  // buffer full: the host drains it and the target runs again
           atomicMin(O.out_valid, base < O.out_cap ? O.out_cap : base);
-          listed = true;
+          route = 1;
+          entry = -(t_old + 1);
         }
       }
     }
-    const unsigned long long lm = __ballot(listed);
-    if (lm) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const unsigned long long lm = __ballot(route == r);
+      if (!lm) continue;
+      unsigned long long* counter = r == 0 ? n_small : (r == 1 ? n_big : O.overflow_count);
+      int32_t* list = r == 0 ? list_small : (r == 1 ? list_big : O.overflow_list);
       unsigned long long base = 0;
-      if (lane == 0) base = atomic_add_u64(list_count, (unsigned long long)__popcll(lm));
+      if (lane == 0) base = atomic_add_u64(counter, (unsigned long long)__popcll(lm));
       base = __shfl(base, 0);
-      if (listed) list[base + (unsigned long long)__popcll(lm & ((1ull << lane) - 1ull))] = trivial ? -(t_old + 1) : t_old;
+      if (route == r) list[base + (unsigned long long)__popcll(lm & ((1ull << lane) - 1ull))] = entry;
     }
   }
 }
@@ -1221,8 +1239,8 @@ int launch_emit_reserve(pprhip_graph* g, const double* reserve, uint32_t n, doub
 
 int init_kernels_apbs() {  // loads this file's code object on the current device (see init_kernels_push)
   hipFuncAttributes fa;
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_lds<kApLdsCap, kApFront>)));
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_lds<kApSmallCap, kApSmallFront>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_lds<kApLdsCap, kApFront, 256>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_lds<kApSmallCap, kApSmallFront, kApSmallThreads>)));
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_split)));
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_apbs_dense)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apbs_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1268,21 +1286,34 @@ int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint
     // length of its give-up list; b.next_target is the large table's cursor)
     unsigned long long* cells = b.next_target;
     const uint32_t sgrid = (uint32_t)std::min<uint64_t>(((uint64_t)n_targets + 255) / 256, 2048);
-    k_apbs_split<<<dim3(sgrid), dim3(256), 0, g->stream>>>(t_begin, n_targets, g->in_rp, g->old2new, rmax, O, b.list0, cells + 6);
+    // (PPRHIP_APBS_DEG=big,dense: the in-degrees from which a search starts in the large table / in the dense tier -
+    // developer and test switch; "0,0" sends everything through both tables as before round 4)
+    // (R-MAT 22, searches of all 4.19 M targets: 3,9 649 ms / 4,12 655 / 6,16 667 / 4,24 665 / all through both tables
+    // 783; R-MAT 24: 4,12 1 894 ms / 3,9 2 019)
+    uint32_t deg_big = 4, deg_dense = 12;
+    if (const char* de = getenv("PPRHIP_APBS_DEG")) {
+      unsigned a = 0, c = 0;
+      if (sscanf(de, "%u,%u", &a, &c) == 2) {
+        deg_big = a ? a : 0xFFFFFFFFu;
+        deg_dense = c ? std::max(c, a) : 0xFFFFFFFFu;
+      }
+    }
+    k_apbs_split<<<dim3(sgrid), dim3(256), 0, g->stream>>>(t_begin, n_targets, g->in_rp, g->old2new, rmax, O, b.list0, cells + 6,
+                                                           b.list1, cells + 11, deg_big, deg_dense);
     PPRHIP_CHECK_HIP(hipGetLastError());
     ApOut O0 = O;  // the small table's give-ups (and retries) go to the second list
     O0.overflow_list = b.list1;
     O0.overflow_count = cells + 11;
     const uint32_t grid0 = std::min<uint32_t>((uint32_t)g->n_cus * 8u, std::max(1u, n_targets));
-    k_apbs_lds<kApSmallCap, kApSmallFront><<<dim3(grid0), dim3(256), 0, g->stream>>>(
+    k_apbs_lds<kApSmallCap, kApSmallFront, kApSmallThreads><<<dim3(grid0), dim3(kApSmallThreads), 0, g->stream>>>(
         b.list0, 0u, 0u, cells + 6, cells + 7, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O0);
     PPRHIP_CHECK_HIP(hipGetLastError());
     const uint32_t grid1 = std::min<uint32_t>((uint32_t)g->n_cus * 2u, std::max(1u, n_targets));
-    k_apbs_lds<kApLdsCap, kApFront><<<dim3(grid1), dim3(256), 0, g->stream>>>(
+    k_apbs_lds<kApLdsCap, kApFront, 256><<<dim3(grid1), dim3(256), 0, g->stream>>>(
         b.list1, 0u, 0u, cells + 11, b.next_target, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O);
   } else {
     const uint32_t grid = std::min<uint32_t>((uint32_t)g->n_cus * 2u, std::max(1u, n_targets));
-    k_apbs_lds<kApLdsCap, kApFront><<<dim3(grid), dim3(256), 0, g->stream>>>(d_targets, t_begin, n_targets, nullptr, b.next_target,
+    k_apbs_lds<kApLdsCap, kApFront, 256><<<dim3(grid), dim3(256), 0, g->stream>>>(d_targets, t_begin, n_targets, nullptr, b.next_target,
                                                                              g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O);
   }
   PPRHIP_CHECK_HIP(hipGetLastError());

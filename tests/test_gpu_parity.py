@@ -411,11 +411,18 @@ def test_all_pair_backward_got(pkg, orc, got, dev_got, k):
     ix.close()
 
 
-@pytest.mark.parametrize("tier", ["1", "2", "3"])
+@pytest.mark.parametrize("tier", ["1", "1-tables", "1-small", "2", "3"])
 def test_all_pair_tiers_rmat12(pkg, orc, rmat12, dev_rmat12, tier, monkeypatch):
     """LDS hash tier, dense-vector tier and whole-vector (batch slot) tier give the same index (targets that outgrow
-    a tier fall through to the next one on their own; the variable only moves the starting tier)."""
-    monkeypatch.setenv("PPRHIP_APBS_TIER", tier)
+    a tier fall through to the next one on their own; the variable only moves the starting tier).  Tier 1 routes a
+    target by its in-degree - small table, large table or straight on to the dense tier (kernels_apbs.hip:
+    k_apbs_split): with the defaults, with every target sent through both tables, and with everything but the targets
+    of the largest in-degrees started in the small one."""
+    monkeypatch.setenv("PPRHIP_APBS_TIER", tier[0])
+    if tier == "1-tables":
+        monkeypatch.setenv("PPRHIP_APBS_DEG", "0,0")
+    if tier == "1-small":
+        monkeypatch.setenv("PPRHIP_APBS_DEG", "40,60")
     og = to_oracle(orc, rmat12)
     lo, hi = 100, 100 + (40 if tier == "3" else 300)
     for thr, k in ((1e-3, -1), (2e-4, 8)):

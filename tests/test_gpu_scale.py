@@ -186,9 +186,9 @@ def check_columns_against_oracle(orc, og, arrays, targets, thr, k, fifo_for=None
 
 @pytest.fixture(scope="module")
 def full_index20(pkg, rmat20):
-    """All 2^20 targets of R-MAT 20 with the default settings: ranges of this size run in parts, tier 1 of the next part
-    on a side stream beside the dense tier of the part before (allpair.cpp), the entries are sorted on the device and
-    the k rule is applied by index_from_sorted."""
+    """All 2^20 targets of R-MAT 20 with the default settings: tier 1 in its three steps (targets routed by in-degree),
+    the dense tier with levels shared at their natural sizes, the entries sorted on the device and the k rule applied
+    by index_from_sorted."""
     with pkg.Graph(rmat20) as g:
         ix, st = g.all_pair_backward(A, 1e-3, 16)
         arrays = [x.copy() for x in ix.arrays()]
@@ -198,7 +198,7 @@ def full_index20(pkg, rmat20):
 
 @pytest.mark.timeout(900)
 def test_all_pair_full_range_columns_against_oracle(orc, rmat20, full_index20):
-    """The index of ALL targets, as the default (pipelined) path builds it, against oracle backward searches of 528
+    """The index of ALL targets, as the default path builds it, against oracle backward searches of 528
     targets: the 16 with the most in-edges, 112 across the dense tier's in-degree ranks, 400 at random."""
     og = to_oracle(orc, rmat20)
     arrays, st = full_index20
@@ -214,12 +214,13 @@ def test_all_pair_full_range_columns_against_oracle(orc, rmat20, full_index20):
     assert np.all(vl >= 1e-3) and off[-1] == len(tg)
 
 
-def test_all_pair_in_parts_equals_in_sequence(pkg, rmat20, full_index20, monkeypatch):
-    """Ranges of 2^20 targets and more run tier 1 of the next part on a side stream beside the dense tier of the part
-    before (allpair.cpp); the index must be the one the tiers give one after the other."""
+def test_all_pair_routing_does_not_change_the_index(pkg, rmat20, full_index20, monkeypatch):
+    """Tier 1 routes every target by its in-degree - small LDS table, large one, or straight to the dense tier
+    (kernels_apbs.hip: k_apbs_split).  The index of all 2^20 targets must be the one that sending every target through
+    both tables gives (PPRHIP_APBS_DEG=0,0), and the dense tier must see more targets with the routing than without."""
     a, st = full_index20
     with pkg.Graph(rmat20) as g:
-        monkeypatch.setenv("PPRHIP_APBS_NO_PIPE", "1")
+        monkeypatch.setenv("PPRHIP_APBS_DEG", "0,0")
         ix, st1 = g.all_pair_backward(A, 1e-3, 16)
         b = ix.arrays()
         # the same rows with the same entries; inside a row, entries whose values differ in the last bits (the
@@ -233,7 +234,7 @@ def test_all_pair_in_parts_equals_in_sequence(pkg, rmat20, full_index20, monkeyp
             inner = np.ones(len(v), dtype=bool)
             inner[a[0][1:-1][a[0][1:-1] < len(v)].astype(np.int64)] = False  # row starts
             assert np.all((np.diff(v) <= 0) | ~inner[1:])
-        assert st.pops == st1.pops and st.rounds == st1.rounds and len(a[1]) > rmat20.n
+        assert st.rounds >= st1.rounds > 0 and len(a[1]) > rmat20.n
         ix.close()
 
 
@@ -380,8 +381,8 @@ def test_full_size_rmat22_against_cpu_power_method(pkg, orc):
 @pytest.mark.timeout(1200)
 def test_full_size_rmat22_all_pair_columns_against_oracle(pkg, orc):
     """All 4.19 M targets of R-MAT 22 (the bench's All-Pair workload: threshold 1e-3, k = 32) on one GPU with the
-    default settings - tiers side by side, levels shared at their natural sizes, the full-size pass for the searches
-    whose lists outgrow a workspace, device sort + index_from_sorted - and 56 of its columns against oracle backward
+    default settings - targets routed by in-degree, levels shared at their natural sizes, a whole-vector search for the
+    target whose lists outgrow a workspace, device sort + index_from_sorted - and 56 of its columns against oracle backward
     searches: the 8 targets with the most in-edges, 16 across the in-degree ranks, 32 at random
     (Base_Whole_Graph.java:76-92,112-163; Backward_Search.java:84-89)."""
     host = pkg.HostCsr.rmat(22, 16, seed=1)
@@ -390,7 +391,7 @@ def test_full_size_rmat22_all_pair_columns_against_oracle(pkg, orc):
         ix, st = g.all_pair_backward(A, 1e-3, 32)
         arrays = ix.arrays()
         ix.close()
-    assert st.xl_targets >= 1 and st.dense_nodes == 0     # the full-size pass ran; nothing was left for tier 3
+    assert st.xl_targets >= 1 and st.dense_nodes == 0     # a search outgrew the lists; nothing was left for tier 3
     targets = column_sample(host, 8, 16, 32, seed=22)
     c, cf, touched = check_columns_against_oracle(orc, og, arrays, targets, 1e-3, 32, fifo_for=targets[:4] + targets[24:40])
     assert max(touched.values()) > (1 << 20)              # a search beyond the per-workgroup lists was among them
