@@ -808,9 +808,7 @@ int ensure_bwd_layout(pprhip_graph* P) {
 
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree) {
   // frontier = {node}; the first node is pushed unconditionally (Forward_Push.java:81-86)
-  g->h_ctr->pad[0] = (unsigned long long)(uint32_t)node;  // staging for the 4-byte node id
-  PPRHIP_CHECK_HIP(hipMemcpyAsync(g->F[L.fcur], &g->h_ctr->pad[0], sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->eoff[L.fcur], 0, sizeof(uint32_t), g->stream));
+  PPRHIP_TRY(launch_seed_one(g, L.fcur, node));  // (one launch; a 4-byte copy command and a 4-byte fill before)
   L.nf = 1;
   L.ef = degree;
   L.dense_prepared = false;

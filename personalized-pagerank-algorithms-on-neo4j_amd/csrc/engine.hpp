@@ -437,6 +437,8 @@ int launch_build_walk_rec(pprhip_graph* g);
 int init_kernels_host();
 int launch_publish(pprhip_graph* g, const void* src, uint32_t n_words, unsigned long long seq);
 int launch_clear(pprhip_graph* g, const ClearList& L);
+int launch_copy_f64(pprhip_graph* g, const double* src, double* dst, size_t n);  // dst[0 .. n) = src[0 .. n), in HBM
+int launch_seed_one(pprhip_graph* g, int fbuf, int32_t node);                    // frontier list fbuf = {node}
 int launch_hold(hipStream_t stream, unsigned long long ticks);
 // The walk phase runs without a host round trip: the plan kernel counts sources and walks into DevCounters::mc_plan
 // [g->mc_parity], the walk kernel (a fixed grid) reads them there.  omega_dev > 0: the plan derives rsum and the walk

@@ -509,8 +509,7 @@ int finish_query(BatchJob& J, ForaRun& r) {
   if (J.keep) {  // the vector stays in HBM after the slot moves on (internal order; pprhip_results_fetch permutes)
     {
       SetupScope setup(S);
-      PPRHIP_CHECK_HIP(hipMemcpyAsync(J.keep->buf + (size_t)i * J.P->n, r.kind == 1 ? S->est : S->reserve,
-                                      sizeof(double) * (size_t)J.P->n, hipMemcpyDeviceToDevice, S->stream));
+      PPRHIP_TRY(launch_copy_f64(S, r.kind == 1 ? S->est : S->reserve, J.keep->buf + (size_t)i * J.P->n, (size_t)J.P->n));
     }
   }
   if (J.reserve_out) {

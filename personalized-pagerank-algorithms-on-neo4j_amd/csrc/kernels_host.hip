@@ -31,6 +31,33 @@ __global__ __launch_bounds__(256) void k_clear(ClearList L) {
   }
 }
 
+// A vector moved inside HBM (a finished query's vector into the result store) and a frontier of one node set up, as
+// kernels: the runtime's copy and fill commands cost the host 15-30 us each before the next launch is queued
+// (kernel-trace gaps behind k_publish, bench.py: stream_occupancy) - on a path whose kernels take that long themselves.
+__global__ __launch_bounds__(256) void k_copy_f64(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = __builtin_nontemporal_load(&src[i]);
+}
+
+__global__ void k_seed_one(int32_t* __restrict__ F, uint32_t* __restrict__ eoff, int32_t node) {
+  F[0] = node;
+  eoff[0] = 0u;
+}
+
+int launch_copy_f64(pprhip_graph* g, const double* src, double* dst, size_t n) {
+  if (!n) return PPRHIP_OK;
+  const uint32_t grid = (uint32_t)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), (size_t)g->n_cus * 8);
+  hipLaunchKernelGGL(k_copy_f64, dim3(grid), dim3(256), 0, g->stream, src, dst, n);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+int launch_seed_one(pprhip_graph* g, int fbuf, int32_t node) {
+  hipLaunchKernelGGL(k_seed_one, dim3(1), dim3(1), 0, g->stream, g->F[fbuf], g->eoff[fbuf], node);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
 // Does a stream run beside another?  The runtime spreads streams over a few in-order hardware queues, and which
 // streams share one depends on what else the process has created.  k_hold keeps the first stream busy for a while,
 // k_publish on the second writes a word to the host; if the word arrives while k_hold still runs, the two overlap.
