@@ -585,11 +585,20 @@ static hipStream_t side_stream_for_walks(pprhip_graph* P) {
   return P->walk_stream;
 }
 
+// Queries left over when a call's count is not a multiple of the slots: up to kTailSingle of them run one at a time on
+// the handle's own workspace (the single-query path: 10 ms each on R-MAT 22) instead of as a last round of sweeps with
+// nearly all columns empty - a sweep costs the same for 2 busy columns as for 16, so such a round takes a full
+// query latency (~43 ms).  PPR.java:179's 50 queries per call = 3 x 16 + 2: 178 -> 155 ms per call.
+constexpr int kTailSingle = 3;
+
 int batch_sequential(BatchJob& J, ForaRun* runs) {
   pprhip_graph* P = J.P;
   hipStream_t side = J.kind == 0 ? side_stream_for_walks(P) : nullptr;
   bool walking[kBatch] = {false};
   int busy = 0;
+  const int tail = (J.kind == 0 && J.q > kBatch && J.q % kBatch <= kTailSingle && !getenv("PPRHIP_BATCH_NO_TAIL"))
+                       ? J.q % kBatch : 0;
+  const int q_slots = J.q - tail;  // queries the slots run
   for (;;) {
     // every slot advances until it waits at a dense level or for its walk phase; finished slots take the next query
     for (int s = 0; s < kBatch; ++s) {
@@ -601,7 +610,7 @@ int batch_sequential(BatchJob& J, ForaRun* runs) {
       for (;;) {
         if (r.query < 0) {
           const int i = J.next_query.load();
-          if (i >= J.q) break;
+          if (i >= q_slots) break;
           J.next_query.store(i + 1);
           PPRHIP_TRY(begin_query(J, r, P->slots[s], i));
           r.side = side;
@@ -641,6 +650,16 @@ int batch_sequential(BatchJob& J, ForaRun* runs) {
     PPRHIP_TRY(run_sweep(P, runs, active, n_wait));
     for (int s = 0; s < kBatch; ++s)
       if (active[s]) runs[s].waiting = false;
+  }
+  for (int i = q_slots; i < J.q; ++i) {  // the stragglers, one at a time on the handle's own vectors
+    ForaRun r;
+    PPRHIP_TRY(begin_query(J, r, P, i));
+    r.side = nullptr;
+    int rc;
+    while ((rc = run_step(r, false)) == kYield) {
+    }
+    if (rc != PPRHIP_OK) return rc;
+    PPRHIP_TRY(finish_query(J, r));
   }
   return PPRHIP_OK;
 }

@@ -236,6 +236,39 @@ def test_fora_batch_rmat12(pkg, orc, rmat12, threads, monkeypatch):
         dev_rmat12.close()
 
 
+@pytest.mark.parametrize("q", [18, 35])
+def test_fora_batch_leftover_queries_run_singly(pkg, orc, rmat15, dev_rmat15, q, monkeypatch):
+    """A call whose query count leaves one to three queries over after the full rounds of 16 (PPR.java:179's 50 = 3 x 16 +
+    2) runs those on the handle's own workspace, one at a time (fora.cpp: kTailSingle): every query - the leftovers
+    too - equals the twin and what the call gives with the leftovers on the slots (PPRHIP_BATCH_NO_TAIL), vectors kept
+    in a store and delivered to the host alike, top-k per query included."""
+    og = to_oracle(orc, rmat15)
+    srcs = sources(rmat15, q, seed=14)
+    t = pkg.tuning_batch()
+    dev_rmat15.set_tuning(t)
+    store = pkg.Results(dev_rmat15, q)
+    try:
+        out, ids, vals, nsel, pq, st = dev_rmat15.fora_batch_single_source(srcs, 0.5, ALPHA, seed=5, k=8, fetch=True,
+                                                                           per_query=True, keep=store)
+        monkeypatch.setenv("PPRHIP_BATCH_NO_TAIL", "1")
+        out2, ids2, vals2, nsel2, pq2, _ = dev_rmat15.fora_batch_single_source(srcs, 0.5, ALPHA, seed=5, k=8, fetch=True,
+                                                                               per_query=True)
+        assert np.max(np.abs(out - out2)) <= 1e-9 and np.array_equal(nsel, nsel2)
+        for i in list(range(q - 4, q)) + [0, 16]:
+            assert pq[i].walks == pq2[i].walks and pq[i].levels == pq2[i].levels and pq[i].rounds == pq2[i].rounds
+            ref, sto = og.fora_whole(srcs[i], 0.5, ALPHA, seed=5, n_rounds=0, schedule=orc.SYNC,
+                                     tuning=to_orc_tuning(orc, t))
+            assert pq[i].walks == sto.walks and pq[i].levels == sto.levels
+            assert_close(out[i], ref, TOL_MC, "query %d src=%d" % (i, srcs[i]))
+            assert np.max(np.abs(store.fetch(i) - out[i])) == 0.0
+            cnt, oids, ovals = orc.topk(out[i], 8, cap=8)
+            m = min(cnt, 8)
+            assert nsel[i] == cnt and list(ids[i][:m]) == list(oids[:m]) and np.array_equal(vals[i][:m], ovals[:m])
+    finally:
+        store.close()
+        dev_rmat15.set_tuning(pkg.tuning_default())
+
+
 def test_fora_batch_rmat15_many_queries(pkg, orc, rmat15, dev_rmat15):
     """More queries than slots on a graph whose pushes run many dense levels; a sample is checked against the twin,
     every query against mass conservation, and a second call on the same handle gives the same vectors."""
