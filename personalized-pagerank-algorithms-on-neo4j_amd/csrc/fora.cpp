@@ -585,75 +585,81 @@ static hipStream_t side_stream_for_walks(pprhip_graph* P) {
   return P->walk_stream;
 }
 
+// Every slot of [s_lo, s_hi) advances until it waits at a dense level or for its walk phase; finished slots take the
+// next query (below q_slots).  *busy: the slots of the range that hold a query afterwards.
+int advance_slots(BatchJob& J, ForaRun* runs, int s_lo, int s_hi, bool* walking, hipStream_t side, int q_slots, int* busy) {
+  pprhip_graph* P = J.P;
+  for (int s = s_lo; s < s_hi; ++s) {
+    ForaRun& r = runs[s];
+    if (walking[s]) {
+      if (hipEventQuery(P->slots[s]->walk_ev[2]) == hipErrorNotReady) continue;
+      walking[s] = false;
+    }
+    for (;;) {
+      if (r.query < 0) {
+        const int i = J.next_query.fetch_add(1);
+        if (i >= q_slots) break;
+        PPRHIP_TRY(begin_query(J, r, P->slots[s], i));
+        r.side = side;
+      }
+      if (r.waiting) break;
+      const int rc = run_step(r, true);
+      if (rc == kYield) {
+        r.waiting = true;
+        break;
+      }
+      if (rc == kYieldWalk) {
+        walking[s] = true;
+        break;
+      }
+      if (rc != PPRHIP_OK) return rc;
+      PPRHIP_TRY(finish_query(J, r));
+    }
+  }
+  *busy = 0;
+  for (int s = s_lo; s < s_hi; ++s) *busy += runs[s].query >= 0 ? 1 : 0;
+  return PPRHIP_OK;
+}
+
+// what follows when every slot has advanced as far as it can: one sweep for the slots that wait at a dense level - or,
+// when nobody does, the end of a walk phase has to be waited for.  *finished: no query is in flight any more.
+int sweep_or_wait(BatchJob& J, ForaRun* runs, const bool* walking, int busy, bool* finished) {
+  pprhip_graph* P = J.P;
+  *finished = busy == 0;
+  if (busy == 0) return PPRHIP_OK;
+  bool active[kBatch];
+  int n_wait = 0, first_walk = -1;
+  for (int s = 0; s < kBatch; ++s) {
+    active[s] = runs[s].query >= 0 && runs[s].waiting;
+    n_wait += active[s] ? 1 : 0;
+    if (walking[s] && first_walk < 0) first_walk = s;
+  }
+  if (n_wait == 0) {  // nobody stands at a dense level: a walk phase has to end before anything can go on
+    if (first_walk < 0) {
+      set_error("batch driver: %d queries in flight, none waiting", busy);
+      return PPRHIP_ERR_STATE;
+    }
+    PPRHIP_CHECK_HIP(hipEventSynchronize(P->slots[first_walk]->walk_ev[2]));
+    return PPRHIP_OK;
+  }
+  PPRHIP_TRY(run_sweep(P, runs, active, n_wait));
+  for (int s = 0; s < kBatch; ++s)
+    if (active[s]) runs[s].waiting = false;
+  return PPRHIP_OK;
+}
+
 // Queries left over when a call's count is not a multiple of the slots: up to kTailSingle of them run one at a time on
 // the handle's own workspace (the single-query path: 10 ms each on R-MAT 22) instead of as a last round of sweeps with
-// nearly all columns empty - a sweep costs the same for 2 busy columns as for 16, so such a round takes a full
-// query latency (~43 ms).  PPR.java:179's 50 queries per call = 3 x 16 + 2: 178 -> 155 ms per call.
+// nearly all columns empty - a sweep costs the same for 2 busy columns as for 16, so such a round takes most of a
+// query's latency.  PPR.java:179's 50 queries per call = 3 x 16 + 2: 178 -> 172 ms per call.
 constexpr int kTailSingle = 3;
-
-int batch_sequential(BatchJob& J, ForaRun* runs) {
-  pprhip_graph* P = J.P;
-  hipStream_t side = J.kind == 0 ? side_stream_for_walks(P) : nullptr;
-  bool walking[kBatch] = {false};
-  int busy = 0;
-  const int tail = (J.kind == 0 && J.q > kBatch && J.q % kBatch <= kTailSingle && !getenv("PPRHIP_BATCH_NO_TAIL"))
-                       ? J.q % kBatch : 0;
-  const int q_slots = J.q - tail;  // queries the slots run
-  for (;;) {
-    // every slot advances until it waits at a dense level or for its walk phase; finished slots take the next query
-    for (int s = 0; s < kBatch; ++s) {
-      ForaRun& r = runs[s];
-      if (walking[s]) {
-        if (hipEventQuery(P->slots[s]->walk_ev[2]) == hipErrorNotReady) continue;
-        walking[s] = false;
-      }
-      for (;;) {
-        if (r.query < 0) {
-          const int i = J.next_query.load();
-          if (i >= q_slots) break;
-          J.next_query.store(i + 1);
-          PPRHIP_TRY(begin_query(J, r, P->slots[s], i));
-          r.side = side;
-          busy++;
-        }
-        if (r.waiting) break;
-        const int rc = run_step(r, true);
-        if (rc == kYield) {
-          r.waiting = true;
-          break;
-        }
-        if (rc == kYieldWalk) {
-          walking[s] = true;
-          break;
-        }
-        if (rc != PPRHIP_OK) return rc;
-        PPRHIP_TRY(finish_query(J, r));
-        busy--;
-      }
-    }
-    if (busy == 0) break;
-    bool active[kBatch];
-    int n_wait = 0, first_walk = -1;
-    for (int s = 0; s < kBatch; ++s) {
-      active[s] = runs[s].query >= 0 && runs[s].waiting;
-      n_wait += active[s] ? 1 : 0;
-      if (walking[s] && first_walk < 0) first_walk = s;
-    }
-    if (n_wait == 0) {  // nobody stands at a dense level: a walk phase has to end before anything can go on
-      if (first_walk < 0) {
-        set_error("batch driver: %d queries in flight, none waiting", busy);
-        return PPRHIP_ERR_STATE;
-      }
-      PPRHIP_CHECK_HIP(hipEventSynchronize(P->slots[first_walk]->walk_ev[2]));
-      continue;
-    }
-    PPRHIP_TRY(run_sweep(P, runs, active, n_wait));
-    for (int s = 0; s < kBatch; ++s)
-      if (active[s]) runs[s].waiting = false;
-  }
+int tail_queries(const BatchJob& J) {
+  return (J.kind == 0 && J.q > kBatch && J.q % kBatch <= kTailSingle && !getenv("PPRHIP_BATCH_NO_TAIL")) ? J.q % kBatch : 0;
+}
+int run_tail(BatchJob& J, int q_slots) {
   for (int i = q_slots; i < J.q; ++i) {  // the stragglers, one at a time on the handle's own vectors
     ForaRun r;
-    PPRHIP_TRY(begin_query(J, r, P, i));
+    PPRHIP_TRY(begin_query(J, r, J.P, i));
     r.side = nullptr;
     int rc;
     while ((rc = run_step(r, false)) == kYield) {
@@ -663,6 +669,29 @@ int batch_sequential(BatchJob& J, ForaRun* runs) {
   }
   return PPRHIP_OK;
 }
+
+// all slots on the calling thread and the graph's stream, one after another
+int batch_sequential(BatchJob& J, ForaRun* runs) {
+  pprhip_graph* P = J.P;
+  hipStream_t side = J.kind == 0 ? side_stream_for_walks(P) : nullptr;
+  bool walking[kBatch] = {false};
+  const int q_slots = J.q - tail_queries(J);  // queries the slots run
+  for (;;) {
+    int busy = 0;
+    PPRHIP_TRY(advance_slots(J, runs, 0, kBatch, walking, side, q_slots, &busy));
+    bool finished = false;
+    PPRHIP_TRY(sweep_or_wait(J, runs, walking, busy, &finished));
+    if (finished) break;
+  }
+  return run_tail(J, q_slots);
+}
+
+// (Round 4 also ran this driver on 2 - 16 host threads that shared the one compute stream, the slots dealt out between
+// them and the threads meeting once per sweep - the idea being that the transitions of different threads' slots fill
+// each other's gaps in the stream, which idles 12-18 % of the time behind the host's decisions.  It got slower with
+// every thread added: 326 / 322 / 315 / 307 / 301 queries/s with 1 / 2 / 4 / 8 / 16 threads, the sweeps themselves
+// 1 334 -> 1 443 us (profiles/r04_driver_threads_study.txt) - several threads launching into one stream pay more in the
+// runtime than the gaps they close.  Taken out; advance_slots / sweep_or_wait are what is left of the refactoring.)
 
 // one worker thread per slot
 void batch_worker(BatchJob* J, BatchSync* B, ForaRun* runs, int s) {
