@@ -1047,7 +1047,12 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   if (pin.joinable()) pin.join();
   PPRHIP_TRY(crc);
   const auto t1 = std::chrono::steady_clock::now();
-  PPRHIP_TRY(index_from_device(g, sink.rec, sink.count, k, 0u, g->n, index_out));
+  try {  // (the index arrays are host allocations of hundreds of megabytes: no exception leaves the C ABI)
+    PPRHIP_TRY(index_from_device(g, sink.rec, sink.count, k, 0u, g->n, index_out));
+  } catch (const std::exception& e) {
+    set_error("pprhip_all_pair_backward: index finalisation: %s", e.what());
+    return PPRHIP_ERR_OOM;
+  }
   if (getenv("PPRHIP_APBS_DEBUG"))
     fprintf(stderr, "[apbs host] searches + hand-over %.1f ms, index finalisation %.1f ms\n",
             std::chrono::duration<double, std::milli>(t1 - t0).count(),
@@ -1076,7 +1081,12 @@ int pprhip_index_merge(const pprhip_index_t* const* shards, int n_shards, int k,
       for (uint64_t i = shards[s]->offsets[v]; i < shards[s]->offsets[v + 1]; ++i)
         tr.push_back({(int32_t)v, shards[s]->targets[i], shards[s]->values[i]});
   }
-  return index_from_triples(n, tr, k, merged_out);
+  try {
+    return index_from_triples(n, tr, k, merged_out);
+  } catch (const std::exception& e) {
+    set_error("pprhip_index_merge: %s", e.what());
+    return PPRHIP_ERR_OOM;
+  }
 }
 
 int pprhip_index_from_arrays(uint32_t n, const uint64_t* offsets, const int32_t* targets, const double* values,
@@ -1112,9 +1122,14 @@ int pprhip_index_from_entries(uint32_t n, const int32_t* sources, const int32_t*
     set_error("pprhip_index_from_entries: null argument");
     return PPRHIP_ERR_INVALID;
   }
-  std::vector<Triple> tr(count);
-  for (uint64_t i = 0; i < count; ++i) tr[i] = Triple{sources[i], targets[i], values[i]};
-  return index_from_triples(n, tr, k, index_out);  // validates the ids, buckets by source, applies the k rule
+  try {
+    std::vector<Triple> tr(count);
+    for (uint64_t i = 0; i < count; ++i) tr[i] = Triple{sources[i], targets[i], values[i]};
+    return index_from_triples(n, tr, k, index_out);  // validates the ids, buckets by source, applies the k rule
+  } catch (const std::exception& e) {
+    set_error("pprhip_index_from_entries: %s", e.what());
+    return PPRHIP_ERR_OOM;
+  }
 }
 
 int pprhip_index_info(const pprhip_index_t* ix, uint32_t* n, uint64_t* entries) {
