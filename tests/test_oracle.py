@@ -407,3 +407,47 @@ def test_topk_rounds_push_whatever_meets_the_threshold(orc, pkg, got, rmat12):
                         break
                     delta = max(1.0 / host.n, delta / 4.0)
     assert hit > 0  # the case is exercised (GOT's last round)
+
+
+def test_index_column_check_accepts_the_oracle_index_and_rejects_a_changed_one(orc, got, rmat12):
+    """bench.py's index_column_check (the All-Pair samples' self-check; the GPU tests run it against the oracle at full
+    size) on CPU: the oracle's own index passes against the oracle's searches - twin exactly, FIFO under the bound both
+    orders share, entries cut by the k rule accounted for - and an index with an entry removed, a value changed, an
+    entry invented or a pair doubled does not (Base_Whole_Graph.java:76-92,112-163)."""
+    from bench import index_column_check
+    for host, thr, k, targets in ((got, 1e-3, 4, list(range(0, 107, 3))), (rmat12, 2e-3, 3, list(range(0, 4096, 37)))):
+        og = to_oracle(orc, host)
+        off, tg, vl = og.all_pair_backward(0.15, thr, k, schedule=orc.SYNC)
+        col = lambda t: og.backward_push(t, 0.15, thr, orc.SYNC)[0]  # noqa: E731
+        st = index_column_check(off, tg, vl, targets, col, thr, k)
+        assert st["entries_checked"] > 0 and st["max_abs_diff"] == 0.0
+        if host is rmat12:
+            assert st["entries_cut_by_k_rule"] > 0        # k = 3 really cuts rows there
+        st_f = index_column_check(off, tg, vl, targets, lambda t: og.backward_push(t, 0.15, thr, orc.FIFO)[0], thr, k,
+                                  slack=thr)
+        assert st_f["max_abs_diff"] <= thr
+        # a changed index: pick an entry whose target is in the sample and whose row keeps fewer than k entries
+        rows = np.repeat(np.arange(host.n), np.diff(off).astype(np.int64))
+        cand = [i for i in range(len(tg)) if tg[i] in set(targets) and off[rows[i] + 1] - off[rows[i]] < k]
+        assert cand
+        i = cand[len(cand) // 2]
+        v = int(rows[i])
+        # (a) the entry removed
+        off2 = off.copy()
+        off2[v + 1:] -= 1
+        with pytest.raises(AssertionError):
+            index_column_check(off2, np.delete(tg, i), np.delete(vl, i), targets, col, thr, k)
+        # (b) its value changed beyond the tolerance
+        vl2 = vl.copy()
+        vl2[i] *= 1.0 + 1e-6
+        with pytest.raises(AssertionError):
+            index_column_check(off, tg, vl2, targets, col, thr, k)
+        # (c) an entry the search does not yield (a source whose reserve is zero there), (d) the pair doubled
+        t = int(tg[i])
+        zero_src = int(np.nonzero(col(t) == 0.0)[0][0])
+        for src, val in ((zero_src, 2 * thr), (v, float(vl[i]))):
+            at = int(off[src + 1])
+            off3 = off.copy()
+            off3[src + 1:] += 1
+            with pytest.raises(AssertionError):
+                index_column_check(off3, np.insert(tg, at, t), np.insert(vl, at, val), targets, col, thr, k)
