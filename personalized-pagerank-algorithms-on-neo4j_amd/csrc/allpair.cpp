@@ -703,133 +703,6 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   return PPRHIP_OK;
 }
 
-// The index from entries already ordered by (source, target) - the device sort's output (kernels_sort.hip): rows are
-// contiguous and in target order, so only Base_Whole_Graph's k rule is left (:112-163; k < 0 keeps everything in
-// target order; k >= 0 keeps the entries >= the k-th largest, value descending, ties in target order).  All hardware
-// threads (up to 64), two passes over ranges of sources with equal shares of the entries.
-int index_from_sorted(uint32_t n, const uint64_t* keys, const double* vals, uint64_t N, int k, uint32_t v_lo, uint32_t v_hi,
-                      pprhip_index_t** out) {
-  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
-  if (!ix) return PPRHIP_ERR_OOM;
-  ix->n = n;
-  if (v_lo > v_hi || v_hi > n) {
-    set_error("index: source range [%u, %u) outside [0, %u)", v_lo, v_hi, n);
-    return PPRHIP_ERR_INVALID;
-  }
-  const unsigned hw = finalise_threads();
-  const unsigned T = N < (1u << 16) ? 1u : hw;
-  auto run = [&](auto&& fn) {  // fn(part) for part in [0, T)
-    std::vector<std::thread> th;
-    for (unsigned w = 1; w < T; ++w) th.emplace_back(fn, w);
-    fn(0u);
-    for (auto& x : th) x.join();
-  };
-  // ---- row starts: start[v] = first entry of source v; every element is written.  The entries come from a device
-  // sort over the significant bits only (kernels_sort.hip), possibly of records received from another rank: an id
-  // outside its range sorts by its low bits into the MIDDLE of the array, so every entry is checked - source inside
-  // [v_lo, v_hi), target inside [0, n), sources non-decreasing - BEFORE anything is indexed with it.
-  RawVec<uint64_t> start;
-  start.resize((size_t)n + 1);
-  std::atomic<int> bad{0};
-  run([&](unsigned w) {
-    const uint64_t lo = N * w / T, hi = N * (w + 1) / T;
-    // sources whose rows begin inside (lo, hi], plus - for the first part - everything up to the first entry's source
-    uint32_t prev = lo ? (uint32_t)(keys[lo - 1] >> 32) : 0u;
-    if (lo == 0) start[0] = 0;
-    for (uint64_t i = lo; i < hi; ++i) {
-      const uint32_t v = (uint32_t)(keys[i] >> 32);
-      if (v < v_lo || v >= v_hi || (uint32_t)keys[i] >= n || v < prev) {  // (v < prev also catches a bad keys[lo - 1])
-        bad.store(v < prev ? 2 : 1);
-        return;
-      }
-      if (v != prev || (i == 0)) {
-        for (uint32_t x = (i == 0 ? 0u : prev + 1); x <= v; ++x) start[x] = i;
-        prev = v;
-      }
-    }
-    if (w + 1 == T) {
-      const uint32_t last = N ? (uint32_t)(keys[N - 1] >> 32) : 0u;
-      for (uint32_t x = N ? last + 1 : 0u; x <= n; ++x) start[x] = N;
-    }
-  });
-  if (bad.load()) {
-    set_error(bad.load() == 2 ? "index entries are not in source order (an id outside [0, %u) among them?)"
-                              : "index entry with a source outside [%u, %u) or a target outside [0, %u)",
-              bad.load() == 2 ? n : v_lo, v_hi, n);
-    return PPRHIP_ERR_INVALID;
-  }
-  // ranges of sources with equal shares of the entries
-  std::vector<uint32_t> cut(T + 1, 0);
-  for (unsigned w = 1; w < T; ++w)
-    cut[w] = (uint32_t)(std::upper_bound(start.begin(), start.end(), N * w / T) - start.begin() - 1);
-  cut[T] = n;
-  for (unsigned w = 1; w <= T; ++w) cut[w] = std::max(cut[w], cut[w - 1]);
-  if (k < 0) {
-    ix->targets.resize(N);
-    ix->values.resize(N);
-    run([&](unsigned w) {
-      for (uint64_t i = N * w / T; i < N * (w + 1) / T; ++i) {
-        ix->targets[i] = (int32_t)(uint32_t)keys[i];
-        ix->values[i] = vals[i];
-      }
-    });
-    ix->offsets.swap(start);
-    *out = ix.release();
-    return PPRHIP_OK;
-  }
-  // ---- pass 1: per row the k-th largest value (when the row has k entries) and how many entries it keeps
-  RawVec<uint64_t> kept;  // kept[v + 1] is written for every v below, kth[v] for the rows that hold entries
-  kept.resize((size_t)n + 1);
-  kept[0] = 0;
-  RawVec<double> kth;
-  kth.resize((size_t)n);
-  run([&](unsigned w) {
-    std::vector<double> tmp;
-    for (uint32_t v = cut[w]; v < cut[w + 1]; ++v) {
-      const uint64_t b = start[v], len = start[v + 1] - b;
-      if (len == 0) {
-        kept[v + 1] = 0;
-        continue;
-      }
-      if (k >= 1 && (uint64_t)k <= len) {
-        tmp.assign(vals + b, vals + b + len);
-        std::nth_element(tmp.begin(), tmp.begin() + (k - 1), tmp.end(), std::greater<double>());
-        const double x = tmp[k - 1];
-        kth[v] = x;
-        uint64_t c = 0;
-        for (uint64_t j = 0; j < len; ++j) c += vals[b + j] >= x ? 1 : 0;
-        kept[v + 1] = c;
-      } else {
-        kth[v] = -1.0;  // fewer than k entries (or k = 0): kth_ppr returns null, everything is kept (:133-139)
-        kept[v + 1] = len;
-      }
-    }
-  });
-  for (uint32_t v = 0; v < n; ++v) kept[v + 1] += kept[v];
-  ix->targets.resize(kept[n]);
-  ix->values.resize(kept[n]);
-  // ---- pass 2: the kept entries, value descending, ties in target order
-  run([&](unsigned w) {
-    std::vector<std::pair<double, int32_t>> row;
-    for (uint32_t v = cut[w]; v < cut[w + 1]; ++v) {
-      const uint64_t b = start[v], len = start[v + 1] - b;
-      if (len == 0) continue;
-      row.clear();
-      for (uint64_t j = 0; j < len; ++j)
-        if (vals[b + j] >= kth[v]) row.emplace_back(vals[b + j], (int32_t)(uint32_t)keys[b + j]);
-      std::stable_sort(row.begin(), row.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
-      uint64_t o = kept[v];
-      for (const auto& e : row) {
-        ix->targets[o] = e.second;
-        ix->values[o++] = e.first;
-      }
-    }
-  });
-  ix->offsets.swap(kept);
-  *out = ix.release();
-  return PPRHIP_OK;
-}
-
 // ---- device -> pageable host memory through a ring of pinned slots and copier threads
 constexpr int kIxSlots = 8;
 constexpr size_t kIxSlotBytes = 8u << 20;
@@ -927,56 +800,42 @@ int ring_download(pprhip_graph* g, const void* d_src, void* h_dst, size_t bytes)
   return err;
 }
 
-// the entries in a device record store -> sorted on the device -> the index (rows of sources in [v_lo, v_hi))
+// the entries in a device record store -> the index (rows of sources in [v_lo, v_hi)): row order and the k rule on the
+// device (kernels_sort.hip: finalize_rows_device), then the three index arrays cross PCIe as they are - through the
+// ring of pinned slots into the index's own (pageable, huge-page) arrays.  The host does no per-entry and no per-row
+// work: round 3's k rule on the host's threads was 36 ms of R-MAT 22's 53 ms and 160 of R-MAT 24's 240, and its passes
+// over all n rows cost a rank of a sharded job the same whatever its share of the entries.
 int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int k, uint32_t v_lo, uint32_t v_hi,
                       pprhip_index_t** out) {
-  unsigned long long* d_keys = nullptr;
-  double* d_vals = nullptr;
+  if (v_lo > v_hi || v_hi > g->n) {
+    set_error("index: source range [%u, %u) outside [0, %u)", v_lo, v_hi, g->n);
+    return PPRHIP_ERR_INVALID;
+  }
   const bool dbg = getenv("PPRHIP_APBS_DEBUG") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  PPRHIP_TRY(sort_triples_device(g, rec, count, &d_keys, &d_vals));
-  if (dbg) {
-    (void)hipStreamSynchronize(g->stream);
-    fprintf(stderr, "[index] sorted on the device at %.1f ms\n", ms());
+  std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
+  if (!ix) return PPRHIP_ERR_OOM;
+  ix->n = g->n;
+  DeviceRows R;
+  PPRHIP_TRY(finalize_rows_device(g, rec, count, k, v_lo, v_hi, &R));
+  if (dbg) fprintf(stderr, "[index] rows finished on the device at %.1f ms (%llu of %llu entries kept)\n", ms(), R.entries, count);
+  if (!R.offsets) {  // no entries: every row is empty
+    ix->offsets.assign((size_t)g->n + 1, 0);
+    *out = ix.release();
+    return PPRHIP_OK;
   }
-  // The sorted entries cross PCIe through a ring of pinned slots that stays with the handle (kIxSlots x kIxSlotBytes;
-  // pprhip_graph_release hands it back) and are moved on into pageable arrays by a few copier threads.  A plain copy
-  // into pageable memory runs at 9-11 GB/s (one thread of the runtime does the same through its own bounce buffers);
-  // pinning the whole destination - round 3 - made later calls fast and the first one slow: pinning gigabytes runs at
-  // 1-5 GB/s (R-MAT 24: 2.2 GB of entries, 0.5 s and more while kernels run).
-  // The arrays they land in stay with the handle as well (pprhip_graph_release frees them): handing two gigabytes of
-  // pageable memory back to the system after every call cost 0.18 s at R-MAT 24, faulting it in again as much.
-  int rc = PPRHIP_OK;
-  const size_t need = 16 * (size_t)std::max<unsigned long long>(1, count);
-  if (g->ix_host_bytes < need) {
-    if (g->ix_host) free(g->ix_host);
-    g->ix_host_bytes = 0;
-    try {
-      g->ix_host = big_alloc(need + need / 8);
-    } catch (const std::bad_alloc&) {
-      g->ix_host = nullptr;
-    }
-    if (g->ix_host) {
-      g->ix_host_bytes = need + need / 8;
-    } else {
-      set_error("index: no host memory for %llu entries", count);
-      rc = PPRHIP_ERR_OOM;
-    }
-  }
-  uint64_t* keys = static_cast<uint64_t*>(g->ix_host);
-  double* vals = g->ix_host ? reinterpret_cast<double*>(static_cast<char*>(g->ix_host) + 8 * (size_t)std::max<unsigned long long>(1, count)) : nullptr;
-  if (rc == PPRHIP_OK && count) {
-    rc = ring_download(g, d_keys, keys, 8 * (size_t)count);
-    if (rc == PPRHIP_OK) rc = ring_download(g, d_vals, vals, 8 * (size_t)count);
-  }
-  if (d_keys) (void)hipFree(d_keys);
-  if (d_vals) (void)hipFree(d_vals);
+  ix->offsets.resize((size_t)g->n + 1);
+  ix->targets.resize(R.entries);
+  ix->values.resize(R.entries);
+  int rc = ring_download(g, R.offsets, ix->offsets.data(), 8 * ((size_t)g->n + 1));
+  if (rc == PPRHIP_OK) rc = ring_download(g, R.values, ix->values.data(), 8 * (size_t)R.entries);
+  if (rc == PPRHIP_OK) rc = ring_download(g, R.targets, ix->targets.data(), 4 * (size_t)R.entries);
+  device_rows_free(&R);
   if (rc != PPRHIP_OK) return rc;
   if (dbg) fprintf(stderr, "[index] on the host at %.1f ms\n", ms());
-  rc = index_from_sorted(g->n, keys, vals, count, k, v_lo, v_hi, out);
-  if (dbg) fprintf(stderr, "[index] k rule applied at %.1f ms\n", ms());
-  return rc;
+  *out = ix.release();
+  return PPRHIP_OK;
 }
 
 // index over all n sources from entries of any targets, rows outside [v_lo, v_hi) must not occur

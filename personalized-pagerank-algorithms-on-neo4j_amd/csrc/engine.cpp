@@ -1535,9 +1535,6 @@ static void free_all_pair(pprhip_graph* g) {
   if (g->ix_stage) (void)hipHostFree(g->ix_stage);
   g->ix_stage = nullptr;
   g->ix_stage_bytes = 0;
-  if (g->ix_host) free(g->ix_host);
-  g->ix_host = nullptr;
-  g->ix_host_bytes = 0;
 }
 
 int pprhip_graph_release(pprhip_graph_t* g, unsigned what) {

@@ -293,10 +293,8 @@ struct pprhip_graph {
   void* in_rec = nullptr;
   char* apbs_ws = nullptr;
   void* apbs_board = nullptr;
-  void* ix_stage = nullptr;  // pinned ring the sorted index entries are downloaded through (index_from_device)
+  void* ix_stage = nullptr;  // pinned ring the index arrays are downloaded through (index_from_device)
   size_t ix_stage_bytes = 0;
-  void* ix_host = nullptr;   // pageable host memory they land in (keys, then values), kept between calls
-  size_t ix_host_bytes = 0;
   char* apbs_xl_ws = nullptr;  // a few workspaces whose lists hold every node, for the searches that outgrow the others
   uint32_t apbs_xl_blocks = 0, apbs_xl_cap_t = 0, apbs_xl_cap_f = 0;
   uint32_t apbs_blocks = 0, apbs_cap_t = 0, apbs_cap_f = 0, apbs_chunk = 0;
@@ -494,10 +492,19 @@ int launch_emit_reserve(pprhip_graph* g, const double* reserve, uint32_t n, doub
                         unsigned long long cap, unsigned long long* count);
 
 // ---- kernels_sort.hip
-// rec[0 .. count) -> device arrays of keys (source << 32 | target) and values ordered by (source, target); the caller
-// frees both with hipFree
-int sort_triples_device(pprhip_graph* g, const TripleRec* rec, unsigned long long count, unsigned long long** keys_out,
-                        double** vals_out);
+// The index of the rows of sources [v_lo, v_hi) from rec[0 .. count), finished in device memory: rows in the reference's
+// order (Base_Whole_Graph.java:112-163: k < 0 target order; k >= 0 entries >= the k-th largest, value descending, ties in
+// target order), offsets[n + 1] and the kept entries' targets / values.  count == 0: all three null.  A source outside
+// the range or a target outside [0, n) is PPRHIP_ERR_INVALID.  The caller releases the arrays (device_rows_free).
+struct DeviceRows {
+  unsigned long long* offsets = nullptr;
+  int32_t* targets = nullptr;
+  double* values = nullptr;
+  unsigned long long entries = 0;
+};
+int finalize_rows_device(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int k, uint32_t v_lo,
+                         uint32_t v_hi, DeviceRows* out);
+void device_rows_free(DeviceRows* r);
 int init_kernels_sort();
 
 // ---- kernels_select.hip

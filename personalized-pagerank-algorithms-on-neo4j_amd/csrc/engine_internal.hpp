@@ -274,8 +274,8 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
 int backward_search_whole(pprhip_graph_t* g, int32_t target_internal, double alpha, double rmax, pprhip_stats_t& st);
 int ensure_bwd_layout(pprhip_graph* P);
 int index_from_triples(uint32_t n, std::vector<Triple>& tr, int k, pprhip_index_t** out);
-// the same from records in HBM: sorted by (source, target) on the device, k rule on the host; sources must lie in
-// [v_lo, v_hi)
+// the same from records in HBM: row order and k rule on the device (kernels_sort.hip), the index arrays downloaded as
+// they are; sources must lie in [v_lo, v_hi)
 int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long count, int k, uint32_t v_lo, uint32_t v_hi,
                       pprhip_index_t** out);
 int index_concat(const std::vector<pprhip_index_t*>& parts, pprhip_index_t** out);

@@ -720,6 +720,72 @@ __device__ __forceinline__ void dn_chunk(const DenseWs& W, DnBoard* B, uint32_t 
   dn_barrier_global();  // every wave's appends have arrived before lane 0 reports the chunk done
 }
 
+struct DnHelpLds {  // a workgroup's look at the boards (dn_help_once)
+  uint32_t owner, chunk, edges, nf, which, open, done;
+};
+
+// One look at the boards by a workgroup that holds no search: the nearest open level after its own entry, one chunk of
+// it pushed into the owner's vectors.  Returns 2 when a chunk was pushed, 1 when somebody else was faster (look again),
+// 0 when nothing is open; H.done says whether every target of the launch is finished (or the launch is aborted).
+// Every path ends with a barrier behind its last lane-0 block (see the note at the owner's chunk loop).
+__device__ __forceinline__ int dn_help_once(DnHelpLds& H, DnLds& L, DnBoard* board, char* ws_base, const DnDims& D,
+                                            const InRec* __restrict__ in_rec, double rmax, uint32_t hot_n,
+                                            uint32_t n_owners, const unsigned long long* n_open,
+                                            const unsigned long long* done_targets, uint32_t n_targets,
+                                            const unsigned long long* abort_word) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    H.owner = 0xFFFFFFFFu;  // owner to help
+    H.done = (dn_load(done_targets) >= (unsigned long long)n_targets || dn_load(abort_word)) ? 1u : 0u;
+    H.open = (dn_load(n_open) != 0ull && !dn_load(abort_word)) ? 1u : 0u;
+  }
+  __syncthreads();
+  // (one word polled while nothing is posted: the board is only scanned when somebody has a level open)
+  if (!H.open) {
+    __syncthreads();  // (H is not rewritten before every wave has read it)
+    return 0;
+  }
+  if ((uint32_t)tid < n_owners && (uint32_t)tid != blockIdx.x) {
+    const unsigned long long nx = dn_load(&board[tid].next);
+    // the nearest open entry after this workgroup's own: helpers spread over the owners instead of all taking the
+    // first one (every append of a shared level is an atomic on the owner's counters)
+    if (((nx >> 32) & 1ull) && (uint32_t)nx < dn_load(&board[tid].n_chunks))
+      atomicMin(&H.owner, ((uint32_t)tid + gridDim.x - blockIdx.x) % gridDim.x);
+  }
+  __syncthreads();
+  const uint32_t owner = H.owner == 0xFFFFFFFFu ? 0xFFFFFFFFu : (H.owner + blockIdx.x) % gridDim.x;
+  __syncthreads();
+  if (owner == 0xFFFFFFFFu) return 0;
+  DnBoard* OB = board + owner;
+  if (tid == 0) {
+    // the level's parameters are valid for the sequence read with them iff the compare-and-swap on
+    // {sequence, chunk} succeeds: the owner rewrites them only while the entry is closed
+    const unsigned long long nx = dn_load(&OB->next);
+    const uint32_t nch = dn_load(&OB->n_chunks);
+    H.nf = dn_load(&OB->nf);
+    H.which = dn_load(&OB->which);
+    H.edges = dn_load(&dense_ws_of(ws_base, owner, D).eoff[H.nf <= D.cap_f ? H.nf : 0u]);
+    uint32_t c = 0xFFFFFFFFu;
+    if (((nx >> 32) & 1ull) && (uint32_t)nx < nch) {
+      unsigned long long expect = nx;
+      if (__hip_atomic_compare_exchange_strong(&OB->next, &expect, nx + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)) {
+        c = (uint32_t)nx;
+      }
+    }
+    H.chunk = c;
+  }
+  __syncthreads();
+  const uint32_t c = H.chunk, onf = H.nf, owhich = H.which, oE = H.edges;
+  __syncthreads();
+  if (c == 0xFFFFFFFFu) return 1;  // somebody else was faster: look again
+  const DenseWs OW = dense_ws_of(ws_base, owner, D);
+  dn_chunk(OW, OB, owhich & 1u, onf, oE, c, in_rec, rmax, D, L, hot_n);
+  if (tid == 0) atomicAdd(&OB->done, 1u);  // (dn_chunk ended with every wave's stores acknowledged)
+  __syncthreads();                         // (lane-0 blocks never sit next to a back edge)
+  return 2;
+}
+
 __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __restrict__ target_list, uint32_t n_targets,
                                                             unsigned long long* next_target,
                                                             const uint32_t* __restrict__ in_rp,
@@ -730,7 +796,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
                                                             unsigned long long* done_targets,
                                                             unsigned long long* n_open,
                                                             unsigned long long* abort_word, DnDims D, int share,
-                                                            uint32_t n_owners, uint32_t hot_n,
+                                                            uint32_t n_owners, uint32_t hot_n, int help_between,
                                                             unsigned long long* __restrict__ dbg) {
   // n_owners: the workgroups 0 .. n_owners - 1 have a workspace and take targets; the others only help with posted
   // levels (the pass for the few searches whose lists need room for every node: a handful of full-size workspaces,
@@ -747,7 +813,8 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
   __shared__ DnLds L;
   __shared__ uint32_t s_scan[kDnWaves];
   __shared__ unsigned long long s_scan64[kDnWaves];
-  __shared__ uint32_t s_pcount, s_carry, s_job[4], s_owner, s_chunk, s_edges, s_gaveup;
+  __shared__ uint32_t s_pcount, s_carry, s_job[4], s_gaveup;
+  __shared__ DnHelpLds H;
   __shared__ uint32_t s_tcount, s_nnext, s_giveup;  // the search's append counters while it stays on this workgroup
   __shared__ unsigned long long s_t, s_out_base, s_tot;
   const int tid = threadIdx.x;
@@ -1060,6 +1127,16 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     if (tid == 0) atomic_add_u64(done_targets, 1ull);
     DN_TICK(4)
     __syncthreads();  // (lane-0 blocks never sit next to a back edge: see the note at the chunk loop)
+    // ---- between two searches of its own the workgroup holds no state: in a short pass (launch_apbs) levels that are
+    // open on other workgroups' boards come first.  The targets are taken largest first, so the open levels belong to
+    // the searches the launch will end with; pushed early they are not what everybody waits for at the end.
+    if (share && help_between) {
+      DN_AT(8, 2)
+      while (dn_help_once(H, L, board, ws_base, D, in_rec, rmax, hot_n, n_owners, n_open, done_targets, n_targets,
+                          abort_word) != 0) {
+      }
+      DN_TICK(5)
+    }
   }
 
   // ---- out of targets: help with posted levels until every target of the launch is finished
@@ -1067,61 +1144,13 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     const unsigned long long t_idle = wall_clock64();
     DN_AT(8, 0)
     for (;;) {
-      // (every LDS word below is written in one phase and read in the next, with a barrier between: a word that is
-      // read by all waves is never reused for something else before the barrier that follows the read)
-      if (tid == 0) {
-        s_owner = 0xFFFFFFFFu;  // owner to help
-        if (wall_clock64() - t_idle > 4 * kDnWaitTicks) atomic_add_u64(abort_word, 1ull);
-        s_job[3] = (dn_load(done_targets) >= (unsigned long long)n_targets || dn_load(abort_word)) ? 1u : 0u;
-        s_job[2] = dn_load(n_open) != 0ull ? 1u : 0u;
-      }
-      __syncthreads();
-      // (one word polled while nothing is posted: the board is only scanned when somebody has a level open)
-      if (s_job[2] && (uint32_t)tid < n_owners && (uint32_t)tid != blockIdx.x) {
-        const unsigned long long nx = dn_load(&board[tid].next);
-        // the nearest open entry after this workgroup's own: helpers spread over the owners instead of all taking the
-        // first one (every append of a shared level is an atomic on the owner's counters)
-        if (((nx >> 32) & 1ull) && (uint32_t)nx < dn_load(&board[tid].n_chunks))
-          atomicMin(&s_owner, ((uint32_t)tid + gridDim.x - blockIdx.x) % gridDim.x);
-      }
-      __syncthreads();
-      const uint32_t owner = s_owner == 0xFFFFFFFFu ? 0xFFFFFFFFu : (s_owner + blockIdx.x) % gridDim.x;
-      const bool all_done = s_job[3] != 0;
-      if (owner == 0xFFFFFFFFu) {
-        if (all_done) break;
-        for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127);  // ~15 us between polls
-        __syncthreads();
-        continue;
-      }
-      DnBoard* OB = board + owner;
-      if (tid == 0) {
-        // the level's parameters are valid for the sequence read with them iff the compare-and-swap on
-        // {sequence, chunk} succeeds: the owner rewrites them only while the entry is closed
-        const unsigned long long nx = dn_load(&OB->next);
-        const uint32_t nch = dn_load(&OB->n_chunks);
-        s_job[0] = dn_load(&OB->nf);
-        s_job[1] = dn_load(&OB->which);
-        s_edges = dn_load(&dense_ws_of(ws_base, owner, D).eoff[s_job[0] <= D.cap_f ? s_job[0] : 0u]);
-        uint32_t c = 0xFFFFFFFFu;
-        if (((nx >> 32) & 1ull) && (uint32_t)nx < nch) {
-          unsigned long long expect = nx;
-          if (__hip_atomic_compare_exchange_strong(&OB->next, &expect, nx + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT)) {
-            c = (uint32_t)nx;
-          }
-        }
-        s_chunk = c;
-      }
-      __syncthreads();
-      const uint32_t c = s_chunk, onf = s_job[0], owhich = s_job[1], oE = s_edges;
-      __syncthreads();
-      if (c == 0xFFFFFFFFu) continue;  // somebody else was faster: look again
-      const DenseWs OW = dense_ws_of(ws_base, owner, D);
-      DN_AT(9, (owner << 16) | (c & 0xFFFFu))
-      dn_chunk(OW, OB, owhich & 1u, onf, oE, c, in_rec, rmax, D, L, hot_n);
-      DN_AT(8, 1)
-      if (tid == 0) atomicAdd(&OB->done, 1u);  // (dn_chunk ended with every wave's stores acknowledged)
-      __syncthreads();                         // (lane-0 blocks never sit next to a back edge)
+      if (tid == 0 && wall_clock64() - t_idle > 4 * kDnWaitTicks) atomic_add_u64(abort_word, 1ull);
+      const int r = dn_help_once(H, L, board, ws_base, D, in_rec, rmax, hot_n, n_owners, n_open, done_targets, n_targets,
+                                 abort_word);
+      if (r != 0) continue;  // pushed a chunk, or lost one to somebody faster: look again at once
+      if (H.done) break;
+      __syncthreads();  // (H.done has been read by every wave before lane 0 writes it again)
+      for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127);  // ~15 us between polls
     }
     DN_TICK(5)
   }
@@ -1276,10 +1305,17 @@ int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint
     const char* he = getenv("PPRHIP_APBS_HOT");
     uint32_t hot_n = he ? (uint32_t)std::max(0, atoi(he)) : (uint32_t)kDnHotDefault;
     hot_n = std::min<uint32_t>(std::min<uint32_t>(hot_n, (uint32_t)kDnHotMax), g->n / 4);
+    // Workgroups also help between two searches of their own when the pass is short (below 2^17 targets): there the
+    // largest searches are what the launch ends with, and help that comes early shortens the end - R-MAT 22, tier 2 of
+    // 2^18 / 2^19 targets of the range: 49.5 -> 44.3 ms / 79.1 -> 74.9 ms.  A long pass has no idle end to shorten
+    // (17 workgroup-ms of 138 000 at 617 K searches) and pays for the looks at the boards and the races for chunks:
+    // 139 -> 144 ms at 2^20 targets, 540 -> 586 ms at all 2^22.  (PPRHIP_APBS_HELP_BETWEEN=0|1: test switch.)
+    const char* hb = getenv("PPRHIP_APBS_HELP_BETWEEN");
+    const int help_between = hb ? (hb[0] != '0') : (n_targets < (1u << 17));
     k_apbs_dense<<<dim3(grid), dim3(kDnThreads), 2 * sizeof(double) * (size_t)hot_n, g->stream>>>(
         d_targets, n_targets, b.next_target, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O, b.ws, (DnBoard*)b.board,
         b.done_targets, b.done_targets + 1, b.done_targets + 2, dims_of(g->n, (unsigned long long)g->m, b.cap_t, b.cap_f, b.chunk), share,
-        owners, hot_n, b.dbg);
+        owners, hot_n, help_between, b.dbg);
   } else if (!d_targets && b.list0 && b.list1) {
     // a range, in three steps on the device: trivial targets and the list of the others; the small table; the large
     // table for what the small one gave up (cells: +6 the list's length, +7 the small table's target cursor, +11 the

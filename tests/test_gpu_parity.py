@@ -444,6 +444,44 @@ def test_all_pair_backward_got(pkg, orc, got, dev_got, k):
     ix.close()
 
 
+@pytest.mark.parametrize("k", [-1, 0, 1, 2, 5, 9, 40])
+def test_all_pair_k_rule_with_ties(pkg, orc, k):
+    """The k rule of Base_Whole_Graph.java:112-163 where it is decided by ties: a source s with an edge to each of
+    eight leaves (eight equal entries in its row), two parallel edges to h (a larger entry) and one to a chain
+    (smaller ones).  Entries equal to the k-th largest all stay, in target order behind the larger ones; k > entries and
+    k = 0 keep everything (value descending), k < 0 keeps target order.  The rows are ordered and cut on the device
+    (kernels_sort.hip: three stable radix sorts, the rule as a prefix of each row); the oracle does it with a stable
+    host sort."""
+    src, dst = [], []
+    s_, h_, c0 = 0, 1, 2                      # s, h, a chain c0 -> c1 -> c2
+    leaves = list(range(5, 13))
+    for t in leaves[::-1]:                    # (inserted in descending id order: the row order is not the edge order)
+        src.append(s_); dst.append(t)
+    src += [s_, s_, s_, c0, c0 + 1]
+    dst += [h_, h_, c0, c0 + 1, c0 + 2]
+    for t in leaves[:4]:                      # a second source with ties among four of the leaves
+        src.append(13); dst.append(t)
+    src += [13, 14]
+    dst += [s_, 13]
+    host = pkg.HostCsr(15, np.array(src, dtype=np.int32), np.array(dst, dtype=np.int32))
+    og = to_oracle(orc, host)
+    with pkg.Graph(host) as g:
+        ix, _ = g.all_pair_backward(ALPHA, 1e-4, k)
+        off, tg, vl = ix.arrays()
+        ix.close()
+    ooff, otg, ovl = og.all_pair_backward(ALPHA, 1e-4, k, schedule=orc.SYNC)
+    assert np.array_equal(off, ooff) and np.array_equal(tg, otg)
+    assert np.max(np.abs(vl - ovl)) <= TOL_PUSH
+    row = vl[off[s_]:off[s_ + 1]]
+    if k >= 0:
+        assert np.all(np.diff(row) <= 0)                                   # value descending
+    if k == 2:                                                             # s itself, h, and nothing of the eight ties
+        assert len(row) == 2
+    if k == 5:                                                             # the fifth largest is one of eight equal
+        assert len(row) >= 3 + 8 and len(set(row[3:11].tolist())) == 1    # values: all eight stay, in target order
+        assert tg[off[s_] + 3:off[s_] + 11].tolist() == leaves
+
+
 @pytest.mark.parametrize("tier", ["1", "1-tables", "1-small", "2", "3"])
 def test_all_pair_tiers_rmat12(pkg, orc, rmat12, dev_rmat12, tier, monkeypatch):
     """LDS hash tier, dense-vector tier and whole-vector (batch slot) tier give the same index (targets that outgrow
@@ -501,18 +539,21 @@ def test_all_pair_dense_tier_list_overflows(pkg, orc, rmat12, cap_t, cap_f, afte
         assert_close(p, po, TOL_PUSH, "backward search after All-Pair")
 
 
-@pytest.mark.parametrize("hot", [None, "0", "64"])
+@pytest.mark.parametrize("hot,between", [(None, None), ("0", "0"), ("64", "1"), (None, "0")])
 @pytest.mark.parametrize("chunk", [16, 256])
-def test_all_pair_dense_tier_shared_levels(pkg, orc, rmat12, chunk, hot, monkeypatch):
+def test_all_pair_dense_tier_shared_levels(pkg, orc, rmat12, chunk, hot, between, monkeypatch):
     """Levels of the dense tier that span several chunks of edges are posted and idle workgroups take chunks of them
     (kernels_apbs.hip: work sharing).  With chunks of a few edges every level of every search is shared; the index
     must not depend on who pushed which edge.  hot: the ids whose residue and reserve live in the owner's LDS while a
     search is on its own (default: a quarter of this small graph; none; 64) - a posted level moves them into the global
-    vector and back, so both sizes of level meet both kinds of id."""
+    vector and back, so both sizes of level meet both kinds of id.  between: whether workgroups also help between two
+    searches of their own (the default of a short pass) or only once they have run out of targets."""
     monkeypatch.setenv("PPRHIP_APBS_TIER", "2")
     monkeypatch.setenv("PPRHIP_APBS_CHUNK", str(chunk))
     if hot is not None:
         monkeypatch.setenv("PPRHIP_APBS_HOT", hot)
+    if between is not None:
+        monkeypatch.setenv("PPRHIP_APBS_HELP_BETWEEN", between)
     og = to_oracle(orc, rmat12)
     with pkg.Graph(rmat12) as g:
         for (lo, hi), thr in (((0, 64), 2e-4), ((1000, 1600), 1e-3)):   # few targets: most workgroups only help
