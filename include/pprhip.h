@@ -197,6 +197,38 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_row_ptr, con
                         const uint32_t* in_row_ptr, const int32_t* in_col_idx, int device,
                         pprhip_graph_t** graph_out);
 void pprhip_graph_destroy(pprhip_graph_t* g);
+/* The host half of the lift alone, without a device: validation, the internal vertex order (nodes with in-edges first,
+ * then out-degree descending, ties by id), both adjacencies in that order, the pull sweep's row-start flags and the
+ * sliced copy of the in-adjacency - what pprhip_graph_create uploads.  It runs on `threads` host threads (0 = what the
+ * process may use) and yields the same bytes with any count.  For inspection and tests; HeavyGraph's jagged arrays
+ * (Diss. p.25) are the reference's counterpart of these arrays. */
+typedef struct pprhip_lift pprhip_lift_t;
+enum {
+  PPRHIP_LIFT_NEW2OLD = 0,       /* int32[n] */
+  PPRHIP_LIFT_OLD2NEW = 1,       /* int32[n] */
+  PPRHIP_LIFT_OUT_ROW_PTR = 2,   /* uint32[n + 1] */
+  PPRHIP_LIFT_OUT_COL_IDX = 3,   /* int32[m] */
+  PPRHIP_LIFT_IN_ROW_PTR = 4,    /* uint32[n + 1] */
+  PPRHIP_LIFT_IN_COL_IDX = 5,    /* int32[m] */
+  PPRHIP_LIFT_NZ_ROWS = 6,       /* int32[]: nodes with in-edges */
+  PPRHIP_LIFT_ZIN_ROWS = 7,      /* int32[]: nodes without in-edges that have out-edges */
+  PPRHIP_LIFT_ROW_START_FLAGS = 8,   /* uint8[]: bit e = in-edge e is the first of its row */
+  PPRHIP_LIFT_CHUNK_STARTS = 9,      /* uint32[]: rows that start before each 512-edge chunk */
+  PPRHIP_LIFT_CROSS_BITS = 10,       /* uint64[]: bit j = row j holds the last edge of a chunk */
+  PPRHIP_LIFT_SLICE_EDGE_BASE = 11,  /* uint64[S + 1] (empty: no sliced copy) */
+  PPRHIP_LIFT_SLICE_SEG_BASE = 12,   /* uint64[S + 1] */
+  PPRHIP_LIFT_SLICED_COL_IDX = 13,   /* int32[m], slice-major */
+  PPRHIP_LIFT_SLICED_FLAGS = 14,     /* uint8[]: bit e = edge e of the sliced copy starts a segment */
+  PPRHIP_LIFT_SLICED_CHUNK_STARTS = 15, /* uint32[] */
+  PPRHIP_LIFT_SEG_ROW = 16,          /* uint32[segments]: row ordinal */
+  PPRHIP_LIFT_SEG_OFF = 17           /* uint32[segments]: first edge */
+};
+int pprhip_graph_lift_host(uint32_t n, uint64_t m, const uint32_t* out_row_ptr, const int32_t* out_col_idx,
+                           const uint32_t* in_row_ptr, const int32_t* in_col_idx, int threads,
+                           pprhip_lift_t** lift_out);
+/* *data_out points into the lift (valid until pprhip_lift_destroy) */
+int pprhip_lift_array(const pprhip_lift_t* lift, int which, const void** data_out, uint64_t* bytes_out);
+void pprhip_lift_destroy(pprhip_lift_t* lift);
 /* A handle keeps the workspaces of every entry point it has served (allocating gigabytes per call would cost more than
  * the call): on first use of the batched entry points 16 query slots + interleaved arrays (R-MAT 22: 6.7 GB), on first
  * use of All-Pair the in-edge records, the dense per-workgroup vectors and the record buffer (R-MAT 22: 27 GB, R-MAT 24:

@@ -80,7 +80,7 @@ EXPORTS = [
     "pprhip_fora_batch", "pprhip_all_pair_backward_multi", "pprhip_comm_unique_id", "pprhip_comm_create",
     "pprhip_comm_destroy", "pprhip_comm_info", "pprhip_shard_target_range", "pprhip_all_pair_backward_sharded",
     "pprhip_topk_gather", "pprhip_comm_abort", "pprhip_owner_partition", "pprhip_index_from_entries",
-    "pprhip_device_memory",
+    "pprhip_device_memory", "pprhip_graph_lift_host", "pprhip_lift_array", "pprhip_lift_destroy",
 ]
 COMM_ID_BYTES = 128
 
@@ -172,6 +172,10 @@ def lib():
     L.pprhip_index_destroy.argtypes = [vp]
     L.pprhip_index_destroy.restype = None
     L.pprhip_power_method.argtypes = [vp, i32, dbl, ci, vp, P(Stats)]
+    L.pprhip_graph_lift_host.argtypes = [u32, u64, vp, vp, vp, vp, ci, P(vp)]
+    L.pprhip_lift_array.argtypes = [vp, ci, P(vp), P(u64)]
+    L.pprhip_lift_destroy.argtypes = [vp]
+    L.pprhip_lift_destroy.restype = None
     _lib = L
     # the destroy entry points, reachable from destructors that run while the interpreter shuts down (the name `lib`
     # may already be None then: "TypeError: 'NoneType' object is not callable" out of Index.__del__, round 3)
@@ -276,6 +280,36 @@ class HostCsr:
         h = cls(n, src, dst, newest_first=True)  # HeavyGraph lists newest relationships first
         h.names = names
         return h
+
+
+LIFT_ARRAYS = {  # pprhip_lift_array: name -> (id, dtype)
+    "new2old": (0, np.int32), "old2new": (1, np.int32), "out_rp": (2, np.uint32), "out_ci": (3, np.int32),
+    "in_rp": (4, np.uint32), "in_ci": (5, np.int32), "nz_rows": (6, np.int32), "zin_rows": (7, np.int32),
+    "flags": (8, np.uint8), "chunk_starts": (9, np.uint32), "cross": (10, np.uint64), "edge_base": (11, np.uint64),
+    "seg_base": (12, np.uint64), "sl_ci": (13, np.int32), "sl_flags": (14, np.uint8), "sl_chunk_starts": (15, np.uint32),
+    "seg_row": (16, np.uint32), "seg_off": (17, np.uint32),
+}
+
+
+def lift_host(host, threads=0, with_in=True):
+    """The host half of the graph lift (pprhip_graph_lift_host; needs no device): dict of the internal layout's arrays."""
+    h = C.c_void_p()
+    _check(lib().pprhip_graph_lift_host(C.c_uint32(host.n), C.c_uint64(host.m), _ptr(host.out_rp), _ptr(host.out_ci),
+                                        _ptr(host.in_rp) if with_in else None, _ptr(host.in_ci) if with_in else None,
+                                        int(threads), C.byref(h)))
+    try:
+        out = {}
+        for name, (which, dt) in LIFT_ARRAYS.items():
+            p, nb = C.c_void_p(), C.c_uint64()
+            _check(lib().pprhip_lift_array(h, which, C.byref(p), C.byref(nb)))
+            if nb.value:
+                buf = (C.c_uint8 * nb.value).from_address(p.value)
+                out[name] = np.frombuffer(buf, dtype=dt).copy()
+            else:
+                out[name] = np.empty(0, dtype=dt)
+        return out
+    finally:
+        lib().pprhip_lift_destroy(h)
 
 
 # ------------------------------------------------------------------ device graph

@@ -254,89 +254,28 @@ const EdgeWindows* sliced_windows_of(pprhip_graph* g, const GsBlock* blocks, int
   return L->plan.data();
 }
 
-// Builds the sliced copy of the (internal-order) in-CSR.  Slices are ranges of `width` source ids up to the last id
-// that has out-edges; no layout when they fit one slice.
-static int build_sliced_layout(pprhip_graph* G, const std::vector<int32_t>& in_ci) {
-  const uint32_t n = G->n;
-  const uint64_t m = G->m;
-  const char* off = getenv("PPRHIP_SLICED");
-  if (off && off[0] == '0') return PPRHIP_OK;
-  uint32_t n_src = n;  // ids above the last node with out-edges are never gathered
-  while (n_src > 0 && G->h_out_rp[n_src] == G->h_out_rp[n_src - 1]) --n_src;
-  const char* env = getenv("PPRHIP_SLICE_IDS");
-  uint64_t width = env ? strtoull(env, nullptr, 10) : 393216ull;  // 3 MB of contributions per slice
-  if (width < 1) width = 1;
-  uint64_t S = ((uint64_t)n_src + width - 1) / width;
-  if (S < 2 || m == 0 || G->n_nz == 0) return PPRHIP_OK;
-  if (S > (uint64_t)kMaxWindows) {
-    S = kMaxWindows;
-    width = ((uint64_t)n_src + S - 1) / S;
-  }
+// Uploads the sliced copy of the (internal-order) in-CSR the host half of the lift built (lift.cpp); no layout when
+// the source ids fit one slice.
+static int upload_sliced_layout(pprhip_graph* G, HostLift& H) {
+  if (H.S < 2) return PPRHIP_OK;
   std::unique_ptr<SlicedLayout> L(new (std::nothrow) SlicedLayout());
   if (!L) return PPRHIP_ERR_OOM;
-  L->S = (int)S;
-  L->width = (uint32_t)width;
-  const std::vector<uint32_t>& irp = G->h_in_rp;
-  const std::vector<int32_t>& rows = G->h_nz_rows;
-  auto slice_of = [&](int32_t u) {
-    const uint64_t q = (uint64_t)(uint32_t)u / width;
-    return (size_t)(q < S ? q : S - 1);
-  };
-  std::vector<uint64_t> ecnt(S, 0), scnt(S, 0);
-  std::vector<uint32_t> last(S, 0xffffffffu);
-  for (size_t j = 0; j < rows.size(); ++j) {
-    const uint32_t v = (uint32_t)rows[j];
-    for (uint32_t e = irp[v]; e < irp[v + 1]; ++e) {
-      const size_t q = slice_of(in_ci[e]);
-      ecnt[q]++;
-      if (last[q] != (uint32_t)j) {
-        last[q] = (uint32_t)j;
-        scnt[q]++;
-      }
-    }
-  }
-  L->edge_base.assign(S + 1, 0);
-  L->seg_base.assign(S + 1, 0);
-  for (size_t q = 0; q < S; ++q) {
-    L->edge_base[q + 1] = L->edge_base[q] + ecnt[q];
-    L->seg_base[q + 1] = L->seg_base[q] + scnt[q];
-  }
-  if (L->seg_base[S] >= 0xffffffffull) return PPRHIP_OK;  // segment ordinals are 32-bit: keep the row-major sweep
-  L->n_seg = (uint32_t)L->seg_base[S];
-  const size_t n_chunks = ((size_t)m + kChunkPad - 1) / kChunkPad;
-  std::vector<int32_t> ci(((size_t)m + kChunkPad - 1) / kChunkPad * kChunkPad + kChunkPad, 0);
-  std::vector<uint8_t> flags((n_chunks + 1) * (kChunkPad / 8), 0);
-  std::vector<uint32_t> chunk_starts(n_chunks + 1, 0);
-  L->h_seg_row.resize(L->n_seg);
-  L->h_seg_off.resize(L->n_seg);
-  std::vector<uint64_t> epos(L->edge_base.begin(), L->edge_base.end() - 1), spos(L->seg_base.begin(), L->seg_base.end() - 1);
-  std::fill(last.begin(), last.end(), 0xffffffffu);
-  for (size_t j = 0; j < rows.size(); ++j) {
-    const uint32_t v = (uint32_t)rows[j];
-    for (uint32_t e = irp[v]; e < irp[v + 1]; ++e) {
-      const size_t q = slice_of(in_ci[e]);
-      const uint64_t w = epos[q]++;
-      ci[w] = in_ci[e];
-      if (last[q] != (uint32_t)j) {
-        last[q] = (uint32_t)j;
-        const uint64_t sg = spos[q]++;
-        L->h_seg_row[sg] = (uint32_t)j;
-        L->h_seg_off[sg] = (uint32_t)w;
-        flags[w >> 3] |= (uint8_t)(1u << (w & 7));
-        chunk_starts[(size_t)w / kChunkPad + 1]++;
-      }
-    }
-  }
-  for (size_t c = 1; c <= n_chunks; ++c) chunk_starts[c] += chunk_starts[c - 1];
+  L->S = H.S;
+  L->width = H.width;
+  L->n_seg = H.n_seg;
+  L->edge_base = std::move(H.edge_base);
+  L->seg_base = std::move(H.seg_base);
+  L->h_seg_row = std::move(H.seg_row);
+  L->h_seg_off = std::move(H.seg_off);
   auto up = [&](void** dst, const void* src, size_t bytes) -> int {
     PPRHIP_TRY(alloc_dev(dst, bytes));
     if (bytes) PPRHIP_CHECK_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return PPRHIP_OK;
   };
   G->sl = L.release();  // from here on pprhip_graph_destroy frees what has been allocated
-  PPRHIP_TRY(up((void**)&G->sl->ci, ci.data(), sizeof(int32_t) * ci.size()));
-  PPRHIP_TRY(up((void**)&G->sl->flags, flags.data(), flags.size()));
-  PPRHIP_TRY(up((void**)&G->sl->chunk_starts, chunk_starts.data(), sizeof(uint32_t) * chunk_starts.size()));
+  PPRHIP_TRY(up((void**)&G->sl->ci, H.sl_ci.data(), sizeof(int32_t) * H.sl_ci.size()));
+  PPRHIP_TRY(up((void**)&G->sl->flags, H.sl_flags.data(), H.sl_flags.size()));
+  PPRHIP_TRY(up((void**)&G->sl->chunk_starts, H.sl_chunk_starts.data(), sizeof(uint32_t) * H.sl_chunk_starts.size()));
   PPRHIP_TRY(up((void**)&G->sl->seg_row, G->sl->h_seg_row.data(), sizeof(uint32_t) * G->sl->h_seg_row.size()));
   return PPRHIP_OK;
 }
@@ -1356,33 +1295,16 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
     set_error("pprhip_graph_create: in_row_ptr[0] must be 0 and in_row_ptr[n] must equal m");
     return PPRHIP_ERR_INVALID;
   }
-  // caller-supplied arrays are validated before anything indexes with them: monotone row pointers,
-  // column indices in range, and (when given) an in-adjacency that is the transpose's degree sequence
-  for (int side = 0; side < (have_in ? 2 : 1); ++side) {
-    const uint32_t* rp = side ? in_rp : out_rp;
-    const int32_t* ci = side ? in_ci : out_ci;
-    const char* nm = side ? "in" : "out";
-    for (uint32_t v = 0; v < n; ++v)
-      if (rp[v + 1] < rp[v]) {
-        set_error("pprhip_graph_create: %s_row_ptr decreases at node %u (%u -> %u)", nm, v, rp[v], rp[v + 1]);
-        return PPRHIP_ERR_INVALID;
-      }
-    for (uint64_t e = 0; e < m; ++e)
-      if (ci[e] < 0 || (uint32_t)ci[e] >= n) {
-        set_error("pprhip_graph_create: %s_col_idx[%llu] = %d outside [0, %u)", nm, (unsigned long long)e, ci[e], n);
-        return PPRHIP_ERR_INVALID;
-      }
+  // ---- the host half (lift.cpp): validation, internal vertex order, both CSRs in that order, sweep layouts
+  const auto t_lift0 = std::chrono::steady_clock::now();
+  HostLift H;
+  try {
+    PPRHIP_TRY(lift_host(n, m, out_rp, out_ci, in_rp, in_ci, 0, H));
+  } catch (const std::bad_alloc&) {
+    set_error("pprhip_graph_create: out of host memory");
+    return PPRHIP_ERR_OOM;
   }
-  if (have_in) {
-    std::vector<uint32_t> indeg((size_t)n, 0u);
-    for (uint64_t e = 0; e < m; ++e) indeg[out_ci[e]]++;
-    for (uint32_t v = 0; v < n; ++v)
-      if (indeg[v] != in_rp[v + 1] - in_rp[v]) {
-        set_error("pprhip_graph_create: in-adjacency is not the transpose of the out-adjacency (node %u: %u in-edges "
-                  "listed, %u relationships point to it)", v, in_rp[v + 1] - in_rp[v], indeg[v]);
-        return PPRHIP_ERR_INVALID;
-      }
-  }
+  const auto t_lift1 = std::chrono::steady_clock::now();
   std::unique_ptr<pprhip_graph> g(new (std::nothrow) pprhip_graph());
   if (!g) return PPRHIP_ERR_OOM;
   g->device = device;
@@ -1394,72 +1316,17 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       g->n_cus = prop.multiProcessorCount;
   }
-
-  // ---- internal vertex order: nodes with in-edges first, then out-degree descending, ties by original id
-  // (PPRHIP_RELABEL=0 keeps ids).  The rows a sweep applies (nodes with in-edges) are then the ids [0, n_nz): their
-  // residue / reserve / contribution entries are contiguous and every line a sweep touches is used in full; inside
-  // that range the most-gathered contributions (highest out-degree) still come first (hot table, slices).
-  const char* env = getenv("PPRHIP_RELABEL");
-  g->relabeled = !(env && env[0] == '0');
-  g->h_new2old.resize(n);
-  g->h_old2new.resize(n);
-  std::iota(g->h_new2old.begin(), g->h_new2old.end(), 0);
-  if (g->relabeled) {
-    std::vector<uint8_t> no_in((size_t)n, 1);
-    for (uint64_t e = 0; e < m; ++e) no_in[out_ci[e]] = 0;
-    std::stable_sort(g->h_new2old.begin(), g->h_new2old.end(), [&](int32_t x, int32_t y) {
-      if (no_in[x] != no_in[y]) return no_in[x] < no_in[y];
-      return out_rp[x + 1] - out_rp[x] > out_rp[y + 1] - out_rp[y];
-    });
-  }
-  for (uint32_t v = 0; v < n; ++v) g->h_old2new[g->h_new2old[v]] = (int32_t)v;
-  const std::vector<int32_t>& o2n = g->h_old2new;
-  // rows move, entries are renamed, the order inside a row is kept (walks index rows by position)
-  auto relabel_csr = [&](const uint32_t* rp, const int32_t* ci, std::vector<uint32_t>& nrp, std::vector<int32_t>& nci) {
-    nrp.assign((size_t)n + 1, 0);
-    for (uint32_t v = 0; v < n; ++v) {
-      const int32_t o = g->h_new2old[v];
-      nrp[v + 1] = nrp[v] + (rp[o + 1] - rp[o]);
-    }
-    nci.resize(((size_t)m + kChunkPad - 1) / kChunkPad * kChunkPad + kChunkPad, 0);
-    for (uint32_t v = 0; v < n; ++v) {
-      const int32_t o = g->h_new2old[v];
-      uint32_t w = nrp[v];
-      for (uint32_t e = rp[o]; e < rp[o + 1]; ++e) nci[w++] = o2n[ci[e]];
-    }
-  };
-  std::vector<int32_t> n_out_ci, n_in_ci;
-  relabel_csr(out_rp, out_ci, g->h_out_rp, n_out_ci);
-  if (have_in) {
-    relabel_csr(in_rp, in_ci, g->h_in_rp, n_in_ci);
-  } else {
-    // derive the in-adjacency: edges in (new) out-CSR order, grouped by destination
-    std::vector<int32_t> src(m);
-    for (uint32_t v = 0; v < n; ++v)
-      for (uint32_t e = g->h_out_rp[v]; e < g->h_out_rp[v + 1]; ++e) src[e] = (int32_t)v;
-    g->h_in_rp.resize((size_t)n + 1);
-    n_in_ci.assign(((size_t)m + kChunkPad - 1) / kChunkPad * kChunkPad + kChunkPad, 0);
-    int rc = pprhip_csr_build(n, m, n_out_ci.data(), src.data(), 0, g->h_in_rp.data(), n_in_ci.data());
-    if (rc != PPRHIP_OK) return rc;
-  }
-
-  // ---- dense pull-sweep layout: non-empty rows, row-start flags per in-edge, starts before each chunk
-  const std::vector<uint32_t>& irp = g->h_in_rp;
-  std::vector<int32_t> nz_rows;
-  const size_t n_chunks = ((size_t)m + kChunkPad - 1) / kChunkPad;
-  std::vector<uint8_t> flags((n_chunks + 1) * (kChunkPad / 8), 0);
-  std::vector<uint32_t> chunk_starts(n_chunks + 1, 0);
-  for (uint32_t v = 0; v < n; ++v) {
-    if (irp[v + 1] == irp[v]) continue;
-    nz_rows.push_back((int32_t)v);
-    const uint32_t e = irp[v];
-    flags[e >> 3] |= (uint8_t)(1u << (e & 7));
-    chunk_starts[(size_t)e / kChunkPad + 1]++;  // counted into every later chunk by the prefix sum below
-  }
-  for (size_t c = 1; c <= n_chunks; ++c) chunk_starts[c] += chunk_starts[c - 1];
-  g->n_chunks = (uint32_t)n_chunks;
-  g->n_nz = (uint32_t)nz_rows.size();
-  g->h_nz_rows = nz_rows;
+  g->relabeled = H.relabeled;
+  g->h_new2old = std::move(H.new2old);
+  g->h_old2new = std::move(H.old2new);
+  g->h_out_rp = std::move(H.out_rp);
+  g->h_in_rp = std::move(H.in_rp);
+  g->h_nz_rows = std::move(H.nz_rows);
+  g->n_chunks = H.n_chunks;
+  g->n_nz = (uint32_t)g->h_nz_rows.size();
+  g->n_zin = (uint32_t)H.zin_rows.size();
+  g->n_live = g->relabeled ? g->n_nz + g->n_zin : 0u;  // (ids are the caller's without the relabeling: no bound)
+  g->n_src_live = H.n_src_live;
 
   pprhip_graph* G = g.get();
   auto up = [&](void** dst, const void* src, size_t bytes) -> int {
@@ -1473,46 +1340,27 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
     return code;
   };
   if ((rc = up((void**)&G->out_rp, G->h_out_rp.data(), sizeof(uint32_t) * ((size_t)n + 1)))) return fail(rc);
-  if ((rc = up((void**)&G->out_ci, n_out_ci.data(), sizeof(int32_t) * n_out_ci.size()))) return fail(rc);
-  {
-    std::vector<unsigned long long> ext(n);
-    for (uint32_t v = 0; v < n; ++v)
-      ext[v] = (unsigned long long)G->h_out_rp[v] | ((unsigned long long)(G->h_out_rp[v + 1] - G->h_out_rp[v]) << 32);
-    if ((rc = up((void**)&G->out_ext, ext.data(), sizeof(unsigned long long) * (size_t)n))) return fail(rc);
-  }
+  if ((rc = up((void**)&G->out_ci, H.out_ci.data(), sizeof(int32_t) * H.out_ci.size()))) return fail(rc);
+  if ((rc = up((void**)&G->out_ext, H.ext.data(), sizeof(unsigned long long) * (size_t)n))) return fail(rc);
   if ((rc = up((void**)&G->in_rp, G->h_in_rp.data(), sizeof(uint32_t) * ((size_t)n + 1)))) return fail(rc);
-  if ((rc = up((void**)&G->in_ci, n_in_ci.data(), sizeof(int32_t) * n_in_ci.size()))) return fail(rc);
+  if ((rc = up((void**)&G->in_ci, H.in_ci.data(), sizeof(int32_t) * H.in_ci.size()))) return fail(rc);
   if ((rc = up((void**)&G->new2old, G->h_new2old.data(), sizeof(int32_t) * (size_t)n))) return fail(rc);
   if ((rc = up((void**)&G->old2new, G->h_old2new.data(), sizeof(int32_t) * (size_t)n))) return fail(rc);
-  if ((rc = up((void**)&G->start_flags, flags.data(), flags.size()))) return fail(rc);
-  if ((rc = up((void**)&G->chunk_starts, chunk_starts.data(), sizeof(uint32_t) * chunk_starts.size()))) return fail(rc);
-  if ((rc = up((void**)&G->nz_rows, nz_rows.data(), sizeof(int32_t) * nz_rows.size()))) return fail(rc);
-  if ((rc = build_sliced_layout(G, n_in_ci))) return fail(rc);
+  if ((rc = up((void**)&G->start_flags, H.flags.data(), H.flags.size()))) return fail(rc);
+  if ((rc = up((void**)&G->chunk_starts, H.chunk_starts.data(), sizeof(uint32_t) * H.chunk_starts.size()))) return fail(rc);
+  if ((rc = up((void**)&G->nz_rows, G->h_nz_rows.data(), sizeof(int32_t) * G->h_nz_rows.size()))) return fail(rc);
+  if ((rc = upload_sliced_layout(G, H))) return fail(rc);
   if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) {
     set_error("hipStreamCreate failed");
     return fail(PPRHIP_ERR_HIP);
   }
-  {
-    // Rows without in-edges never receive mass, so the only contribution such a row can hold is its own when it is
-    // a query's source - and a dead-end's contribution is zero (Forward_Push.java:101-104).  The batched sweep
-    // therefore carries the rows without in-edges that have out-edges and leaves the isolated ones (43 % of an
-    // R-MAT 22's nodes) out: their entries of the contribution arrays are never written and stay zero.
-    std::vector<int32_t> zin;
-    for (uint32_t v = 0; v < n; ++v)
-      if (irp[v + 1] == irp[v] && G->h_out_rp[v + 1] > G->h_out_rp[v]) zin.push_back((int32_t)v);
-    G->n_zin = (uint32_t)zin.size();
-    G->n_live = G->relabeled ? G->n_nz + G->n_zin : 0u;  // (ids are the caller's without the relabeling: no bound)
-    for (uint32_t v = 0; v < n; ++v) G->n_src_live += G->h_out_rp[v + 1] > G->h_out_rp[v] ? 1u : 0u;
-    if ((rc = up((void**)&G->zin_rows, zin.data(), sizeof(int32_t) * zin.size()))) return fail(rc);
-    std::vector<unsigned long long> cross(((size_t)n + 63) / 64 + 1, 0ull);
-    for (size_t j = 0; j < nz_rows.size(); ++j) {
-      const uint32_t v = (uint32_t)nz_rows[j];
-      // summed with atomics (so cleared after every sweep): rows holding the last edge of a chunk
-      const uint32_t last = irp[v + 1] - 1;
-      if (irp[v] / kChunkPad != last / kChunkPad || (last + 1) % kChunkPad == 0 || (uint64_t)last + 1 == m)
-        cross[j >> 6] |= 1ull << (j & 63);
-    }
-    if ((rc = up((void**)&G->cross_bits, cross.data(), sizeof(unsigned long long) * cross.size()))) return fail(rc);
+  if ((rc = up((void**)&G->zin_rows, H.zin_rows.data(), sizeof(int32_t) * H.zin_rows.size()))) return fail(rc);
+  if ((rc = up((void**)&G->cross_bits, H.cross.data(), sizeof(unsigned long long) * H.cross.size()))) return fail(rc);
+  if (getenv("PPRHIP_LIFT_DEBUG")) {
+    const auto t_up = std::chrono::steady_clock::now();
+    fprintf(stderr, "[pprhip lift] host half %.1f ms, uploads %.1f ms\n",
+            std::chrono::duration<double, std::milli>(t_lift1 - t_lift0).count(),
+            std::chrono::duration<double, std::milli>(t_up - t_lift1).count());
   }
   if ((rc = alloc_dev((void**)&G->walk_rec, sizeof(uint4) * (size_t)m))) return fail(rc);
   if ((rc = launch_build_walk_rec(G))) return fail(rc);

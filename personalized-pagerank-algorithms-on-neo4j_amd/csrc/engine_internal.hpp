@@ -106,6 +106,31 @@ struct SetupScope {
   }
 };
 
+// The host half of the graph lift (lift.cpp): every array of the internal layout in host memory, ready to upload.
+struct HostLift {
+  bool relabeled = true;
+  std::vector<int32_t> new2old, old2new;
+  std::vector<uint32_t> out_rp, in_rp;  // internal order
+  std::vector<int32_t> out_ci, in_ci;   // internal order, padded to whole chunks plus one
+  std::vector<unsigned long long> ext;  // out-row extent per node: first edge | degree << 32
+  std::vector<int32_t> nz_rows, zin_rows;
+  uint32_t n_chunks = 0, n_src_live = 0;
+  std::vector<uint8_t> flags;
+  std::vector<uint32_t> chunk_starts;
+  std::vector<unsigned long long> cross;
+  // sliced copy of the in-CSR (S == 0: none)
+  int S = 0;
+  uint32_t width = 0, n_seg = 0;
+  std::vector<uint64_t> edge_base, seg_base;
+  std::vector<int32_t> sl_ci;
+  std::vector<uint8_t> sl_flags;
+  std::vector<uint32_t> sl_chunk_starts, seg_row, seg_off;
+};
+// threads: 0 = what the process may use (host_threads)
+int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out_ci, const uint32_t* in_rp,
+              const int32_t* in_ci, unsigned threads, HostLift& H);
+unsigned host_threads();  // CPU affinity and cgroup quota of the process, at most 64 (PPRHIP_HOST_THREADS overrides)
+
 int alloc_dev(void** p, size_t bytes);
 double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense);
 uint64_t dense_level_bytes(const pprhip_graph* g);

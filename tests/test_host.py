@@ -211,3 +211,123 @@ def test_index_merge_large_runs_on_all_threads(pkg):
                 r = sorted(r, key=lambda e: -e[1])       # stable: ties stay in target order
             got = list(zip(tg[off[v]:off[v + 1]].tolist(), vl[off[v]:off[v + 1]].tolist()))
             assert got == r, (k, v)
+
+
+# ------------------------------------------------------------------ graph lift, host half (row a11; PPR.java:136-152)
+def _lift_expected(h, width=393216, chunk=512, max_windows=16):
+    """The internal layout restated with numpy (stable sorts instead of the library's counting sort and threaded
+    passes): vertex order = nodes with in-edges first, then out-degree descending, ties by id; rows keep their
+    order; row-start flags; the sliced copy = in-edges in row order, stably partitioned by slice of the source id."""
+    n, m = h.n, h.m
+    od = np.diff(h.out_rp).astype(np.int64)
+    ind = np.diff(h.in_rp).astype(np.int64)
+    key = np.where(ind > 0, 0, 1) * (1 << 40) + ((1 << 32) - od)
+    new2old = np.argsort(key, kind="stable").astype(np.int32)
+    old2new = np.empty(n, dtype=np.int32)
+    old2new[new2old] = np.arange(n, dtype=np.int32)
+
+    def rename(rp, ci):
+        deg = np.diff(rp).astype(np.int64)[new2old]
+        nrp = np.zeros(n + 1, dtype=np.uint32)
+        nrp[1:] = np.cumsum(deg)
+        starts = rp[:-1].astype(np.int64)[new2old]
+        idx = np.repeat(starts - nrp[:-1].astype(np.int64), deg) + np.arange(m, dtype=np.int64)
+        return nrp, old2new[ci[idx]].astype(np.int32)
+
+    out_rp, out_ci = rename(h.out_rp, h.out_ci)
+    in_rp, in_ci = rename(h.in_rp, h.in_ci)
+    indeg, outdeg = np.diff(in_rp), np.diff(out_rp)
+    nz_rows = np.nonzero(indeg > 0)[0].astype(np.int32)
+    zin_rows = np.nonzero((indeg == 0) & (outdeg > 0))[0].astype(np.int32)
+    n_chunks = (m + chunk - 1) // chunk
+
+    def flag_arrays(starts):
+        bits = np.zeros((n_chunks + 1) * chunk, dtype=np.uint8)
+        bits[starts] = 1
+        flags = np.packbits(bits, bitorder="little")
+        cs = np.zeros(n_chunks + 1, dtype=np.uint32)
+        cs[1:] = np.cumsum(np.bincount(np.asarray(starts, dtype=np.int64) // chunk, minlength=n_chunks)[:n_chunks])
+        return flags, cs
+
+    row_first = in_rp[:-1][nz_rows].astype(np.int64)
+    flags, chunk_starts = flag_arrays(row_first)
+    last = in_rp[1:][nz_rows].astype(np.int64) - 1
+    cross_b = (row_first // chunk != last // chunk) | ((last + 1) % chunk == 0) | (last + 1 == m)
+    cross = np.zeros((n + 63) // 64 + 1, dtype=np.uint64)
+    j = np.nonzero(cross_b)[0]
+    np.bitwise_or.at(cross, j >> 6, np.uint64(1) << (j & 63).astype(np.uint64))
+    exp = dict(new2old=new2old, old2new=old2new, out_rp=out_rp, out_ci=out_ci, in_rp=in_rp, in_ci=in_ci, nz_rows=nz_rows,
+               zin_rows=zin_rows, flags=flags, chunk_starts=chunk_starts, cross=cross)
+    n_src = int(np.nonzero(outdeg > 0)[0].max()) + 1 if (outdeg > 0).any() else 0
+    S = (n_src + width - 1) // width
+    if S > max_windows:
+        S = max_windows
+        width = (n_src + S - 1) // S
+    if S >= 2 and m and nz_rows.size:
+        row_of_edge = np.repeat(np.arange(n, dtype=np.int64), indeg)  # (edges of rows without in-edges: none)
+        ordinal = np.cumsum(indeg > 0) - 1
+        sl = np.minimum(in_ci.astype(np.int64) // width, S - 1)
+        perm = np.argsort(sl, kind="stable")
+        sl_ci = in_ci[perm]
+        seg_key = sl[perm] * n + row_of_edge[perm]
+        is_start = np.ones(m, dtype=bool)
+        is_start[1:] = seg_key[1:] != seg_key[:-1]
+        seg_off = np.nonzero(is_start)[0].astype(np.uint32)
+        seg_row = ordinal[row_of_edge[perm][seg_off]].astype(np.uint32)
+        sl_flags, sl_cs = flag_arrays(seg_off.astype(np.int64))
+        edge_base = np.zeros(S + 1, dtype=np.uint64)
+        edge_base[1:] = np.cumsum(np.bincount(sl, minlength=S))
+        seg_base = np.zeros(S + 1, dtype=np.uint64)
+        seg_base[1:] = np.cumsum(np.bincount(sl[perm][seg_off], minlength=S))
+        exp.update(sl_ci=sl_ci, sl_flags=sl_flags, sl_chunk_starts=sl_cs, seg_row=seg_row, seg_off=seg_off,
+                   edge_base=edge_base, seg_base=seg_base)
+    return exp
+
+
+@pytest.mark.parametrize("scale,slice_ids", [(10, 100), (16, 20000), (17, 0)])
+def test_lift_host_matches_numpy_restatement(pkg, monkeypatch, scale, slice_ids):
+    """pprhip_graph_lift_host (what pprhip_graph_create uploads) against an independent numpy restatement of the
+    layout, on one thread and on eight (scale 16/17 are large enough for the threaded passes): same bytes."""
+    if slice_ids:
+        monkeypatch.setenv("PPRHIP_SLICE_IDS", str(slice_ids))
+    h = pkg.HostCsr.rmat(scale, 16, seed=4)
+    exp = _lift_expected(h, width=slice_ids or 393216)
+    for threads in (1, 8):
+        got = pkg.lift_host(h, threads=threads)
+        for name, want in exp.items():
+            assert got[name].shape == want.shape, (name, threads, got[name].shape, want.shape)
+            assert np.array_equal(got[name], want), (name, threads)
+        if "sl_ci" not in exp:
+            assert got["sl_ci"].size == 0 and got["seg_row"].size == 0
+    # without the caller's in-adjacency the lift derives one: same vertex order and out-CSR, and an in-CSR that is
+    # the transpose (rows as multisets; the order inside a derived row follows the renamed out-CSR)
+    own = pkg.lift_host(h, threads=8, with_in=False)
+    assert np.array_equal(own["new2old"], exp["new2old"]) and np.array_equal(own["out_ci"], exp["out_ci"])
+    assert np.array_equal(own["in_rp"], exp["in_rp"])
+    rows = np.repeat(np.arange(h.n), np.diff(exp["in_rp"]))
+    a = np.stack([rows, own["in_ci"]])
+    b = np.stack([rows, exp["in_ci"]])
+    assert np.array_equal(a[:, np.lexsort(a[::-1])], b[:, np.lexsort(b[::-1])])
+
+
+def test_lift_host_reports_the_first_bad_entry(pkg):
+    """Validation runs on several threads; the offence reported is the first in array order, as one thread would."""
+    h = pkg.HostCsr.rmat(16, 16, seed=4)
+    ci = h.out_ci.copy()
+    ci[900001] = h.n  # two offences in different threads' ranges
+    ci[77] = -5
+    bad = type("H", (), dict(n=h.n, m=h.m, out_rp=h.out_rp, out_ci=ci, in_rp=h.in_rp, in_ci=h.in_ci))()
+    with pytest.raises(pkg.PprhipError, match=r"out_col_idx\[77\] = -5"):
+        pkg.lift_host(bad, threads=8)
+    rp = h.in_rp.copy()
+    rp[1000], rp[1001] = rp[1001] + 1, rp[1000]  # (keeps rp[n] == m)
+    bad = type("H", (), dict(n=h.n, m=h.m, out_rp=h.out_rp, out_ci=h.out_ci, in_rp=rp, in_ci=h.in_ci))()
+    with pytest.raises(pkg.PprhipError, match=r"in_row_ptr decreases at node 1000"):
+        pkg.lift_host(bad, threads=8)
+    in_ci = np.roll(h.in_ci, 1)
+    rp2 = h.in_rp.copy()
+    v = int(np.nonzero(np.diff(h.in_rp) > 1)[0][0])
+    rp2[v + 1] -= 1  # one in-edge moves to the next node: degrees no longer those of the transpose
+    bad = type("H", (), dict(n=h.n, m=h.m, out_rp=h.out_rp, out_ci=h.out_ci, in_rp=rp2, in_ci=in_ci))()
+    with pytest.raises(pkg.PprhipError, match=r"not the transpose"):
+        pkg.lift_host(bad, threads=8)
