@@ -482,9 +482,31 @@ def q50_sample(pkg, g, store, rng, live_ids, conf, value_128, calls=6):
         g.fora_batch_single_source(srcs[i], EPS, ALPHA, seed=21 + i, k=TOPK, conf=conf, keep=store)
     dt = time.perf_counter() - t0
     v = calls * q / dt
-    return {"value_q50": round(v, 3),
-            "value_q50_note": "%d calls of 50 live sources each (config #4's call shape, PPR.java:179), %.1f ms per call; "
-                              "%.3f of the rate of the %d-query steps" % (calls, 1e3 * dt / calls, v / value_128, 128)}
+    out = {"value_q50": round(v, 3),
+           "value_q50_note": "%d calls of 50 live sources each (config #4's call shape, PPR.java:179), %.1f ms per call; "
+                             "%.3f of the rate of the %d-query steps" % (calls, 1e3 * dt / calls, v / value_128, 128)}
+    # the same 50-query blocks through the query stream (pprhip_fora_stream_*): submitted as they come, no drain between
+    # them; the top-k blocks of a block are checked against the synchronous call's
+    try:
+        _, ids_ref, vals_ref, _, _, _ = g.fora_batch_single_source(srcs[calls], EPS, ALPHA, seed=21 + calls, k=TOPK,
+                                                                    conf=conf, keep=store)
+        with pkg.QueryStream(g, EPS, ALPHA, k=TOPK, conf=conf) as qs:
+            qs.wait(qs.submit(srcs[0], 21, keep=store))
+            t0 = time.perf_counter()
+            tickets = [qs.submit(srcs[i], 21 + i, keep=store) for i in range(1, calls + 1)]
+            got = [qs.wait(tk) for tk in tickets]
+            dt = time.perf_counter() - t0
+        if not (np.array_equal(got[-1][0], ids_ref) and np.max(np.abs(got[-1][1] - vals_ref)) <= 1e-12):
+            raise RuntimeError("a streamed block's top-k differs from the synchronous call's")
+        vs = calls * q / dt
+        out["value_q50_stream"] = round(vs, 3)
+        out["value_q50_stream_note"] = ("the same %d blocks of 50 submitted to one query stream and waited for in order: "
+                                        "%.3f of the rate of the %d-query steps; last block's top-%d ids identical to the "
+                                        "synchronous call's, values to 1e-12" % (calls, vs / value_128, 128, TOPK))
+    except Exception as e:  # noqa: BLE001
+        out["value_q50_stream"] = None
+        out["value_q50_stream_note"] = "failed: %s" % str(e)[:200]
+    return out
 
 
 def delivery_samples(pkg, g, store, rng, live_ids, host, conf, q):
@@ -1210,6 +1232,11 @@ def pmc_traffic(args, host):
     walks = count(fetch[1], lambda k: k == "k_mc_walk")
     if walks:
         res["walk"] = int(traffic(1, lambda k: k == "k_mc_walk") / walks)
+    # every kernel of the phase (48 queries in one call + the calibration sum over n values)
+    res["headline_bytes_per_query"] = int((traffic(1, anyk) - 8.0 * n) / 48)
+    res["headline_bytes_by_class"] = {
+        "dense_pull_batch": int(traffic(1, sweep) / 48), "walk": int(traffic(1, lambda k: k in ("k_mc_walk", "k_mc_plan<0>")) / 48),
+        "sparse_push": int(traffic(1, lambda k: k.startswith("k_sparse")) / 48)}
     # phase 2: one query at a time; levels launched behind another one whose frontier had already emptied return at
     # once and fetch next to nothing: not counted (a counted level = one apply launch per Gauss-Seidel block, two blocks)
     one = lambda k: k.startswith("k_dense_edges<") or k.startswith("k_dense_apply<") or k == "k_dense_reduce"  # noqa: E731
@@ -1249,6 +1276,19 @@ def apply_counters(out, pmc, avg_us, extras):
                         traffic_over_compulsory=round(tr / max(1, roofline["algorithmic_bytes_per_launch"]), 2),
                         tcc_hit_rate=pmc.get("dense_pull_batch_tcc_hit"),
                         tcc_hit_rate_edge_kernel=pmc.get("dense_pull_batch_edges_tcc_hit"))
+    if pmc.get("headline_bytes_per_query"):
+        # the whole job, every kernel class: what the two-handles experiment says is the binding resource
+        # of the batched path - a second group of 16 queries beside the first adds nothing (325 against 324 queries/s)
+        bq = pmc["headline_bytes_per_query"]
+        ach = bq * out["value"] / 1e9
+        roofline["whole_job"] = {
+            "traffic_per_query": bq, "by_class": pmc.get("headline_bytes_by_class"),
+            "achieved": round(ach, 1), "unit": "GB/s", "frac_of_peak": round(ach / HBM_PEAK_GBS, 4),
+            "frac_of_achievable": round(ach / HBM_ACHIEVABLE_GBS, 4),
+            "note": "memory-side bytes of every kernel of a 48-query call (counter passes) x the timed region's queries/s: "
+                    "the rate at which the whole workload - sweeps, walks beside them, sparse levels, selections - moves "
+                    "lines beyond L2, against the 8 TB/s peak and the streaming rate this chip reaches (%d GB/s)"
+                    % int(HBM_ACHIEVABLE_GBS)}
     wk = roofline["other_kernels"].get("walk")
     if pmc.get("walk") and wk and wk.get("launches"):
         # the walk kernel's gathers use 4-8 bytes of every 128-byte line they move: bound by lines, not by

@@ -323,6 +323,25 @@ int pprhip_fora_batch_single_source_resident(pprhip_graph_t* g, const int32_t* s
                                              pprhip_results_t* keep, double* reserve_out, int k, int32_t* ids_out,
                                              double* vals_out, int* n_out, pprhip_stats_t* per_query,
                                              pprhip_stats_t* stats_sum);
+
+/* The batched driver behind a submit / wait pair (an extension: the reference's harness is synchronous,
+ * Gen_Util.java:208-232).  A synchronous call ends with a drain - its last queries finish at different times and a
+ * sweep costs the same for 2 busy columns as for 16 - so calls of PPR.java:179's 50 queries reach 0.90 of the rate of
+ * long calls.  A stream keeps a driver thread on the handle: the slots a submission's last queries leave take the next
+ * submission's first ones.  Every query runs as pprhip_fora_batch_single_source would run it (same seed and tuning,
+ * same result); per submission: top-k blocks (k > 0: ids_out / vals_out [q * k], n_out [q] or NULL), and / or the
+ * vectors in a device-resident store (`keep` slots keep_first .. keep_first + q - 1).  While a stream is open every
+ * other entry point on the handle returns PPRHIP_ERR_STATE (one handle, one thread: here the driver's); outputs of a
+ * submission may be read after its wait, a store after the close.  submit / wait may be called from any one thread. */
+typedef struct pprhip_stream pprhip_stream_t;
+int pprhip_fora_stream_open(pprhip_graph_t* g, double eps, const pprhip_fora_conf_t* conf, int k,
+                            pprhip_stream_t** stream_out);
+int pprhip_fora_stream_submit(pprhip_stream_t* s, const int32_t* srcs, int q, uint64_t seed, pprhip_results_t* keep,
+                              int keep_first, int32_t* ids_out, double* vals_out, int* n_out, uint64_t* ticket_out);
+/* blocks until every query of the submission has finished; stats_sum: its counters (total_ms = submit to finish) */
+int pprhip_fora_stream_wait(pprhip_stream_t* s, uint64_t ticket, pprhip_stats_t* stats_sum);
+/* finishes everything submitted, ends the driver thread and frees the stream */
+int pprhip_fora_stream_close(pprhip_stream_t* s);
 /* FORA top-k (pprhip_fora_topk) for q sources, up to PPRHIP_BATCH of them in flight: every query runs
  * Fora_Topk's loop on delta unchanged (query i with seed + i), the dense levels of its forward_push_topk
  * rounds share sweeps with the other queries in flight.  ids_out/vals_out are q*k, rows padded with

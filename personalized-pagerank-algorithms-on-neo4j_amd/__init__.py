@@ -81,6 +81,7 @@ EXPORTS = [
     "pprhip_comm_destroy", "pprhip_comm_info", "pprhip_shard_target_range", "pprhip_all_pair_backward_sharded",
     "pprhip_topk_gather", "pprhip_comm_abort", "pprhip_owner_partition", "pprhip_index_from_entries",
     "pprhip_device_memory", "pprhip_graph_lift_host", "pprhip_lift_array", "pprhip_lift_destroy",
+    "pprhip_fora_stream_open", "pprhip_fora_stream_submit", "pprhip_fora_stream_wait", "pprhip_fora_stream_close",
 ]
 COMM_ID_BYTES = 128
 
@@ -176,6 +177,10 @@ def lib():
     L.pprhip_lift_array.argtypes = [vp, ci, P(vp), P(u64)]
     L.pprhip_lift_destroy.argtypes = [vp]
     L.pprhip_lift_destroy.restype = None
+    L.pprhip_fora_stream_open.argtypes = [vp, dbl, P(ForaConf), ci, P(vp)]
+    L.pprhip_fora_stream_submit.argtypes = [vp, vp, ci, u64, vp, ci, vp, vp, vp, P(u64)]
+    L.pprhip_fora_stream_wait.argtypes = [vp, u64, P(Stats)]
+    L.pprhip_fora_stream_close.argtypes = [vp]
     _lib = L
     # the destroy entry points, reachable from destructors that run while the interpreter shuts down (the name `lib`
     # may already be None then: "TypeError: 'NoneType' object is not callable" out of Index.__del__, round 3)
@@ -538,6 +543,56 @@ class Results:
         if getattr(self, "h", None):
             _LIVE["results_destroy"](self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class QueryStream:
+    """pprhip_fora_stream_*: single-source FORA queries submitted in blocks and run by the batched driver without a
+    drain between the blocks.  submit() returns a ticket; wait(ticket) returns (ids[q, k], vals[q, k], n_sel[q], Stats)."""
+
+    def __init__(self, graph, eps, alpha, k=0, conf=None):
+        self.graph = graph
+        self.k = int(k)
+        self.conf = conf or conf_whole_graph(graph.n, graph.m, alpha)
+        self.h = C.c_void_p()
+        self._out = {}
+        _check(lib().pprhip_fora_stream_open(graph.h, eps, C.byref(self.conf), self.k, C.byref(self.h)))
+
+    def submit(self, srcs, seed, keep=None, keep_first=0):
+        srcs = np.ascontiguousarray(srcs, dtype=np.int32)
+        q = int(srcs.size)
+        ids = np.empty((q, self.k), dtype=np.int32) if self.k > 0 else None
+        vals = np.empty((q, self.k)) if self.k > 0 else None
+        nsel = np.zeros(q, dtype=np.int32) if self.k > 0 else None
+        t = C.c_uint64()
+        _check(lib().pprhip_fora_stream_submit(self.h, _ptr(srcs), q, seed, keep.h if keep is not None else None,
+                                               int(keep_first), _ptr(ids), _ptr(vals), _ptr(nsel), C.byref(t)))
+        self._out[t.value] = (ids, vals, nsel)  # (the library writes into these until the wait returns)
+        return t.value
+
+    def wait(self, ticket):
+        st = Stats()
+        _check(lib().pprhip_fora_stream_wait(self.h, ticket, C.byref(st)))
+        ids, vals, nsel = self._out.pop(ticket)
+        return ids, vals, nsel, st
+
+    def close(self):
+        if getattr(self, "h", None):
+            h, self.h = self.h, None
+            self._out.clear()
+            _check(lib().pprhip_fora_stream_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
         try:

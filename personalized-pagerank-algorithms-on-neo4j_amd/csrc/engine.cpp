@@ -889,6 +889,10 @@ int check_graph(const pprhip_graph* g, const char* fn) {
     set_error("%s: null graph handle", fn);
     return PPRHIP_ERR_INVALID;
   }
+  if (g->stream_open) {
+    set_error("%s: a query stream is open on this handle (pprhip_fora_stream_close first)", fn);
+    return PPRHIP_ERR_STATE;
+  }
   hipError_t e = hipSetDevice(g->device);
   if (e != hipSuccess) {
     set_error("%s: hipSetDevice(%d) failed: %s", fn, g->device, hipGetErrorString(e));

@@ -285,6 +285,7 @@ struct pprhip_graph {
   uint32_t walk_waves = 0;  // waves per CU of the next walk kernels (0: the default)
   hipStream_t walk_stream = nullptr;
   bool walk_stream_tried = false;
+  bool stream_open = false;  // a query stream's driver thread owns the handle (fora.cpp: pprhip_stream)
   hipEvent_t walk_ev[3] = {nullptr, nullptr, nullptr};
   pprhip::KernelTimer ktimer;         // slot: its worker's kernel-class timer; graph: the sweeps' timer
   std::vector<pprhip_graph*> slots;

@@ -265,6 +265,7 @@ struct BatchJob {
   double alpha = 0.0, threshold = 0.0;   // kind 2
   std::vector<Triple>* triples = nullptr;  // kind 2: every search's entries >= threshold
   pprhip_results* keep = nullptr;          // kind 0: device-resident store of the queries' vectors
+  int keep_first = 0;                      // ... query i goes to slot keep_first + i of it
   FetchPipe* pipe = nullptr;               // reserve_out given: asynchronous delivery (batch_run opens / closes it)
   pprhip_stats_t sum;
   std::mutex sum_mu;

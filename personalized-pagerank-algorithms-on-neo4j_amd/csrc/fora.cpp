@@ -38,6 +38,7 @@ struct ForaRun {
   enum Phase { kRoundStart, kLevels, kWalks, kWalkWait, kTopkRoundStart, kTopkLevels, kTopkFinal, kBwdLevels, kBwdFinal, kDone } phase = kDone;
   hipStream_t side = nullptr;  // batch driver: the walk phase goes to this stream and the run yields until it has ended
   int query = -1;  // batch driver: index of the query this run serves
+  detail::BatchJob* job = nullptr;  // ... and the call (or stream submission) that query belongs to
   bool waiting = false;
   bool in_push = false;  // between a push phase's start and its end (BatchSync: may hold sweeps off)
   // top-k runs (Fora_Topk.computeTopKPPR, kind 1): the trial-and-error loop on delta
@@ -509,7 +510,8 @@ int finish_query(BatchJob& J, ForaRun& r) {
   if (J.keep) {  // the vector stays in HBM after the slot moves on (internal order; pprhip_results_fetch permutes)
     {
       SetupScope setup(S);
-      PPRHIP_TRY(launch_copy_f64(S, r.kind == 1 ? S->est : S->reserve, J.keep->buf + (size_t)i * J.P->n, (size_t)J.P->n));
+      PPRHIP_TRY(launch_copy_f64(S, r.kind == 1 ? S->est : S->reserve, J.keep->buf + (size_t)(J.keep_first + i) * J.P->n,
+                                 (size_t)J.P->n));
     }
   }
   if (J.reserve_out) {
@@ -559,6 +561,7 @@ int begin_query(BatchJob& J, ForaRun& r, pprhip_graph* S, int i) {
     PPRHIP_TRY(fora_begin(r, S, src, J.eps, J.conf, J.seed, J.n_rounds));
   }
   r.query = i;
+  r.job = &J;
   return PPRHIP_OK;
 }
 
@@ -586,9 +589,11 @@ static hipStream_t side_stream_for_walks(pprhip_graph* P) {
 }
 
 // Every slot of [s_lo, s_hi) advances until it waits at a dense level or for its walk phase; finished slots take the
-// next query (below q_slots).  *busy: the slots of the range that hold a query afterwards.
-int advance_slots(BatchJob& J, ForaRun* runs, int s_lo, int s_hi, bool* walking, hipStream_t side, int q_slots, int* busy) {
-  pprhip_graph* P = J.P;
+// next query from `next` (a call's own counter, or a stream's queue of submissions: false = nothing to start now) and
+// report finished ones to `done`.  *busy: the slots of the range that hold a query afterwards.
+template <class Next, class Done>
+int advance_slots(pprhip_graph* P, ForaRun* runs, int s_lo, int s_hi, bool* walking, hipStream_t side, Next&& next,
+                  Done&& done, int* busy) {
   for (int s = s_lo; s < s_hi; ++s) {
     ForaRun& r = runs[s];
     if (walking[s]) {
@@ -597,9 +602,10 @@ int advance_slots(BatchJob& J, ForaRun* runs, int s_lo, int s_hi, bool* walking,
     }
     for (;;) {
       if (r.query < 0) {
-        const int i = J.next_query.fetch_add(1);
-        if (i >= q_slots) break;
-        PPRHIP_TRY(begin_query(J, r, P->slots[s], i));
+        BatchJob* J = nullptr;
+        int i = -1;
+        if (!next(&J, &i)) break;
+        PPRHIP_TRY(begin_query(*J, r, P->slots[s], i));
         r.side = side;
       }
       if (r.waiting) break;
@@ -613,7 +619,9 @@ int advance_slots(BatchJob& J, ForaRun* runs, int s_lo, int s_hi, bool* walking,
         break;
       }
       if (rc != PPRHIP_OK) return rc;
-      PPRHIP_TRY(finish_query(J, r));
+      BatchJob* const J = r.job;
+      PPRHIP_TRY(finish_query(*J, r));
+      done(J);
     }
   }
   *busy = 0;
@@ -623,8 +631,7 @@ int advance_slots(BatchJob& J, ForaRun* runs, int s_lo, int s_hi, bool* walking,
 
 // what follows when every slot has advanced as far as it can: one sweep for the slots that wait at a dense level - or,
 // when nobody does, the end of a walk phase has to be waited for.  *finished: no query is in flight any more.
-int sweep_or_wait(BatchJob& J, ForaRun* runs, const bool* walking, int busy, bool* finished) {
-  pprhip_graph* P = J.P;
+int sweep_or_wait(pprhip_graph* P, ForaRun* runs, const bool* walking, int busy, bool* finished) {
   *finished = busy == 0;
   if (busy == 0) return PPRHIP_OK;
   bool active[kBatch];
@@ -676,11 +683,16 @@ int batch_sequential(BatchJob& J, ForaRun* runs) {
   hipStream_t side = J.kind == 0 ? side_stream_for_walks(P) : nullptr;
   bool walking[kBatch] = {false};
   const int q_slots = J.q - tail_queries(J);  // queries the slots run
+  auto next = [&](BatchJob** job, int* i) {
+    *i = J.next_query.fetch_add(1);
+    *job = &J;
+    return *i < q_slots;
+  };
   for (;;) {
     int busy = 0;
-    PPRHIP_TRY(advance_slots(J, runs, 0, kBatch, walking, side, q_slots, &busy));
+    PPRHIP_TRY(advance_slots(P, runs, 0, kBatch, walking, side, next, [](BatchJob*) {}, &busy));
     bool finished = false;
-    PPRHIP_TRY(sweep_or_wait(J, runs, walking, busy, &finished));
+    PPRHIP_TRY(sweep_or_wait(P, runs, walking, busy, &finished));
     if (finished) break;
   }
   return run_tail(J, q_slots);
@@ -1222,3 +1234,236 @@ int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k,
   return batch_run(g, J, stats_sum);
 }
 
+
+// ------------------------------------------------------------------ query stream
+// The batched driver behind a submit / wait pair.  A synchronous call of q queries ends with a drain: its last queries
+// finish at different times, the slots they leave stay empty, and a sweep costs the same for 2 busy columns as for 16
+// (config #4's 50-query call, PPR.java:179: 0.90 of the 128-query rate).  A stream keeps one driver thread on the
+// handle; the slots a submission's last queries leave take the next submission's first ones, so queries that arrive
+// continuously - a harness that calls Gen_Util's loop again and again, a server - always find sixteen columns busy.
+// Every query runs exactly as pprhip_fora_batch_single_source would run it (same seed, same tuning, same result).
+#include <deque>
+#include <map>
+#include <memory>
+
+namespace {
+
+struct StreamJob : BatchJob {
+  std::vector<int32_t> own_srcs;  // (the caller's array need not outlive the submit call)
+  uint64_t ticket = 0;
+  int finished = 0;
+  bool done = false;
+  std::chrono::steady_clock::time_point t0;
+};
+
+}  // namespace
+
+struct pprhip_stream {
+  pprhip_graph* g = nullptr;
+  double eps = 0.0;
+  pprhip_fora_conf_t conf;
+  int k = 0;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::deque<std::shared_ptr<StreamJob>> pending;           // submissions with queries still to start
+  std::map<uint64_t, std::shared_ptr<StreamJob>> open;      // ticket -> submission, until it has been waited for
+  uint64_t next_ticket = 1;
+  bool closing = false;
+  int err = PPRHIP_OK;
+  std::string errmsg;
+  std::thread driver;
+};
+
+namespace {
+
+void stream_fail(pprhip_stream* s, int rc) {
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (s->err == PPRHIP_OK) {
+    s->err = rc;
+    s->errmsg = get_error();
+  }
+  s->pending.clear();
+  for (auto& kv : s->open) kv.second->done = true;
+  s->cv_done.notify_all();
+}
+
+void stream_driver(pprhip_stream* s) {
+  pprhip_graph* P = s->g;
+  if (hipSetDevice(P->device) != hipSuccess) {
+    set_error("hipSetDevice(%d) failed in the stream driver", P->device);
+    stream_fail(s, PPRHIP_ERR_HIP);
+    return;
+  }
+  KernelTimer quiet;  // nobody reads kernel-class times of a stream: record no events at all
+  quiet.off = true;
+  KernelTimer* const saved = g_timer_cur;
+  g_timer_cur = &quiet;
+  for (pprhip_graph* S : P->slots) {
+    S->stream = P->stream;
+    S->sync = nullptr;
+  }
+  hipStream_t side = side_stream_for_walks(P);
+  ForaRun runs[kBatch];
+  bool walking[kBatch] = {false};
+  auto next = [&](BatchJob** job, int* i) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->pending.empty()) return false;
+    StreamJob* J = s->pending.front().get();
+    *job = J;
+    *i = J->next_query.fetch_add(1);
+    if (*i + 1 >= J->q) s->pending.pop_front();  // (the open map keeps the submission alive)
+    return true;
+  };
+  auto done = [&](BatchJob* job) {
+    StreamJob* J = static_cast<StreamJob*>(job);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (++J->finished == J->q) {
+      J->sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - J->t0).count();
+      J->done = true;
+      s->cv_done.notify_all();
+    }
+  };
+  int rc = PPRHIP_OK;
+  for (;;) {
+    int busy = 0;
+    if ((rc = advance_slots(P, runs, 0, kBatch, walking, side, next, done, &busy)) != PPRHIP_OK) break;
+    if (busy == 0) {
+      std::unique_lock<std::mutex> lk(s->mu);
+      s->cv_work.wait(lk, [&] { return s->closing || !s->pending.empty(); });
+      if (s->pending.empty()) break;  // closing, and nothing left to start or in flight
+      continue;
+    }
+    bool finished = false;
+    if ((rc = sweep_or_wait(P, runs, walking, busy, &finished)) != PPRHIP_OK) break;
+  }
+  if (rc != PPRHIP_OK) stream_fail(s, rc);
+  (void)hipStreamSynchronize(P->stream);
+  if (P->walk_stream) (void)hipStreamSynchronize(P->walk_stream);
+  g_timer_cur = saved;
+}
+
+int stream_error(pprhip_stream* s, const char* fn) {  // (s->mu held)
+  set_error("%s: the stream has failed: %s", fn, s->errmsg.c_str());
+  return s->err;
+}
+
+}  // namespace
+
+int pprhip_fora_stream_open(pprhip_graph_t* g, double eps, const pprhip_fora_conf_t* conf, int k,
+                            pprhip_stream_t** stream_out) {
+  PPRHIP_TRY(check_graph(g, "pprhip_fora_stream_open"));
+  if (!stream_out || !conf || !(eps > 0.0) || k < 0) {
+    set_error("pprhip_fora_stream_open: bad arguments (eps=%g k=%d)", eps, k);
+    return PPRHIP_ERR_INVALID;
+  }
+  PPRHIP_TRY(ensure_batch(g));
+  std::unique_ptr<pprhip_stream> s(new (std::nothrow) pprhip_stream());
+  if (!s) return PPRHIP_ERR_OOM;
+  s->g = g;
+  s->eps = eps;
+  s->conf = *conf;
+  s->k = k;
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  g->stream_open = true;
+  try {
+    s->driver = std::thread(stream_driver, s.get());
+  } catch (...) {
+    g->stream_open = false;
+    set_error("pprhip_fora_stream_open: no thread for the driver");
+    return PPRHIP_ERR_OOM;
+  }
+  *stream_out = s.release();
+  return PPRHIP_OK;
+}
+
+int pprhip_fora_stream_submit(pprhip_stream_t* s, const int32_t* srcs, int q, uint64_t seed, pprhip_results_t* keep,
+                              int keep_first, int32_t* ids_out, double* vals_out, int* n_out, uint64_t* ticket_out) {
+  if (!s || !ticket_out || q < 1 || !srcs || (s->k > 0 && (!ids_out || !vals_out)) || keep_first < 0) {
+    set_error("pprhip_fora_stream_submit: bad arguments (q=%d)", q);
+    return PPRHIP_ERR_INVALID;
+  }
+  if (keep && (keep->g != s->g || (long long)keep_first + q > keep->capacity)) {
+    set_error("pprhip_fora_stream_submit: the result store belongs to another graph or holds %d < %d + %d queries",
+              keep->capacity, keep_first, q);
+    return PPRHIP_ERR_INVALID;
+  }
+  for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(s->g, srcs[i], "pprhip_fora_stream_submit"));
+  std::shared_ptr<StreamJob> J;
+  try {
+    J = std::make_shared<StreamJob>();
+    J->own_srcs.assign(srcs, srcs + q);
+  } catch (const std::bad_alloc&) {
+    return PPRHIP_ERR_OOM;
+  }
+  J->P = s->g;
+  J->srcs = J->own_srcs.data();
+  J->q = q;
+  J->eps = s->eps;
+  J->conf = &s->conf;
+  J->seed = seed;
+  J->n_rounds = 0;
+  J->reserve_out = nullptr;
+  J->k = s->k;
+  J->ids_out = ids_out;
+  J->vals_out = vals_out;
+  J->n_out = n_out;
+  J->per_query = nullptr;
+  J->keep = keep;
+  J->keep_first = keep_first;
+  std::memset(&J->sum, 0, sizeof J->sum);
+  J->t0 = std::chrono::steady_clock::now();
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (s->err != PPRHIP_OK) return stream_error(s, "pprhip_fora_stream_submit");
+  if (s->closing) {
+    set_error("pprhip_fora_stream_submit: the stream is closing");
+    return PPRHIP_ERR_STATE;
+  }
+  J->ticket = s->next_ticket++;
+  s->open[J->ticket] = J;
+  s->pending.push_back(J);
+  if (keep && keep->count < keep_first + q) keep->count = keep_first + q;
+  *ticket_out = J->ticket;
+  s->cv_work.notify_one();
+  return PPRHIP_OK;
+}
+
+int pprhip_fora_stream_wait(pprhip_stream_t* s, uint64_t ticket, pprhip_stats_t* stats_sum) {
+  if (!s) {
+    set_error("pprhip_fora_stream_wait: null stream");
+    return PPRHIP_ERR_INVALID;
+  }
+  std::unique_lock<std::mutex> lk(s->mu);
+  auto it = s->open.find(ticket);
+  if (it == s->open.end()) {
+    set_error("pprhip_fora_stream_wait: no open submission with ticket %llu", (unsigned long long)ticket);
+    return PPRHIP_ERR_INVALID;
+  }
+  std::shared_ptr<StreamJob> J = it->second;
+  s->cv_done.wait(lk, [&] { return J->done; });
+  s->open.erase(ticket);
+  if (s->err != PPRHIP_OK) return stream_error(s, "pprhip_fora_stream_wait");
+  if (stats_sum) *stats_sum = J->sum;
+  return PPRHIP_OK;
+}
+
+int pprhip_fora_stream_close(pprhip_stream_t* s) {
+  if (!s) return PPRHIP_OK;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->closing = true;
+    s->cv_work.notify_all();
+  }
+  if (s->driver.joinable()) s->driver.join();  // every submitted query has finished (or the stream has failed)
+  pprhip_graph* g = s->g;
+  g->stream_open = false;
+  int rc = PPRHIP_OK;
+  if (s->err != PPRHIP_OK) {
+    const std::string msg = s->errmsg;
+    (void)hipSetDevice(g->device);
+    free_batch(g);  // slots may hold half-pushed levels: the next batched call builds clean ones
+    set_error("pprhip_fora_stream_close: the stream had failed: %s", msg.c_str());
+    rc = s->err;
+  }
+  delete s;
+  return rc;
+}

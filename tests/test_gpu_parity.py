@@ -909,3 +909,54 @@ def test_internal_order_is_invisible(pkg, orc, rmat15, monkeypatch):
     finally:
         g_def.close()
         g_ids.close()
+
+
+@pytest.mark.gpu
+def test_query_stream_equals_batched_calls(pkg, orc, rmat15, dev_rmat15):
+    """pprhip_fora_stream_*: three submissions of ragged sizes run through one driver without a drain between them.
+    Every query equals what the synchronous batched call gives for the same seed (and through it the twin): top-k
+    blocks identical, stored vectors identical; a sample is held to the twin directly.  While the stream is open the
+    handle's other entry points refuse; after the close they work again."""
+    og = to_oracle(orc, rmat15)
+    sizes, seeds = [5, 21, 1, 19], [5, 6, 7, 8]
+    srcs = sources(rmat15, sum(sizes), seed=21)
+    blocks = np.split(srcs, np.cumsum(sizes)[:-1])
+    t = pkg.tuning_batch()
+    dev_rmat15.set_tuning(t)
+    store = pkg.Results(dev_rmat15, sum(sizes))
+    ref_store = pkg.Results(dev_rmat15, max(sizes))
+    try:
+        with pkg.QueryStream(dev_rmat15, 0.5, ALPHA, k=8) as qs:
+            tickets, first = [], 0
+            for b, sd in zip(blocks, seeds):
+                tickets.append(qs.submit(b, sd, keep=store, keep_first=first))
+                first += b.size
+            with pytest.raises(pkg.PprhipError) as ei:  # the driver thread owns the handle
+                dev_rmat15.fora_single_source(int(srcs[0]), 0.5, ALPHA, seed=1)
+            assert ei.value.code == pkg.ERR_STATE and "stream" in str(ei.value)
+            with pytest.raises(pkg.PprhipError):
+                qs.submit(np.array([rmat15.n], dtype=np.int32), 1)  # a source outside the graph: refused at submit
+            with pytest.raises(pkg.PprhipError):
+                qs.wait(999)
+            got = [qs.wait(tk) for tk in reversed(tickets)][::-1]  # waits in any order
+        assert store.info()[1] == sum(sizes)
+        first = 0
+        for b, sd, (ids, vals, nsel, st) in zip(blocks, seeds, got):
+            _, ids2, vals2, nsel2, _, st2 = dev_rmat15.fora_batch_single_source(b, 0.5, ALPHA, seed=sd, k=8, keep=ref_store)
+            # (walk deposits are fp64 atomics: equal up to the order of their sums)
+            assert np.array_equal(nsel, nsel2) and np.array_equal(ids, ids2) and np.max(np.abs(vals - vals2)) <= 1e-12
+            assert st.walks == st2.walks and st.levels == st2.levels and st.total_ms > 0
+            for i in range(b.size):
+                assert np.max(np.abs(store.fetch(first + i) - ref_store.fetch(i))) <= 1e-12
+            ref, sto = og.fora_whole(b[0], 0.5, ALPHA, seed=sd, n_rounds=0, schedule=orc.SYNC, tuning=to_orc_tuning(orc, t))
+            assert_close(store.fetch(first), ref, TOL_MC, "stream block seed %d src=%d" % (sd, b[0]))
+            first += b.size
+        # an empty stream opens and closes; a second stream on the same handle works
+        pkg.QueryStream(dev_rmat15, 0.5, ALPHA, k=0).close()
+        with pkg.QueryStream(dev_rmat15, 0.5, ALPHA, k=4) as qs:
+            ids, vals, nsel, _ = qs.wait(qs.submit(blocks[0], 5))
+        assert np.array_equal(ids[:, 0], got[0][0][:, 0])
+    finally:
+        store.close()
+        ref_store.close()
+        dev_rmat15.set_tuning(pkg.tuning_default())
