@@ -200,6 +200,9 @@ def main():
     srcs = live_draw(rng, live_ids, (total_steps, q))
 
     solo = world == 1 and rank == 0 and args.mode == "batch"
+    t0 = time.time()
+    g = pkg.Graph(host, device=local_rank)  # (before the children below: the lift's host half uses every core it may)
+    t_lift = time.time() - t0
     # host-only work that runs beside the GPU measurements: the CPU baselines (a process of their own: they take
     # minutes of CPU time and use every core for a while) and the generation of config #5's graph
     cpu_child = None
@@ -208,10 +211,6 @@ def main():
     r24_child = None
     if solo and not args.no_extras and not args.no_rmat24:
         r24_child = start_rmat24(args)
-
-    t0 = time.time()
-    g = pkg.Graph(host, device=local_rank)
-    t_lift = time.time() - t0
     if rank == 0:
         note("graph lifted (%.1f s generate / load, %.1f s lift)" % (t_gen, t_lift))
     conf = pkg.conf_whole_graph(host.n, host.m, ALPHA)
@@ -499,6 +498,14 @@ def q50_sample(pkg, g, store, rng, live_ids, conf, value_128, calls=6):
         if not (np.array_equal(got[-1][0], ids_ref) and np.max(np.abs(got[-1][1] - vals_ref)) <= 1e-12):
             raise RuntimeError("a streamed block's top-k differs from the synchronous call's")
         vs = calls * q / dt
+        # ... and the headline's own block size: 4 blocks of 128 through one stream
+        big = live_draw(rng, live_ids, (5, 128))
+        with pkg.QueryStream(g, EPS, ALPHA, k=TOPK, conf=conf) as qs:
+            qs.wait(qs.submit(big[0], 41, keep=store))
+            t0 = time.perf_counter()
+            for tk in [qs.submit(big[i], 41 + i, keep=store) for i in range(1, 5)]:
+                qs.wait(tk)
+            out["value_stream_128"] = round(4 * 128 / (time.perf_counter() - t0), 3)
         out["value_q50_stream"] = round(vs, 3)
         out["value_q50_stream_note"] = ("the same %d blocks of 50 submitted to one query stream and waited for in order: "
                                         "%.3f of the rate of the %d-query steps; last block's top-%d ids identical to the "

@@ -286,6 +286,7 @@ struct pprhip_graph {
   hipStream_t walk_stream = nullptr;
   bool walk_stream_tried = false;
   bool stream_open = false;  // a query stream's driver thread owns the handle (fora.cpp: pprhip_stream)
+  void* stream_obj = nullptr;  // ... that stream (pprhip_graph_destroy closes a stream its owner forgot)
   hipEvent_t walk_ev[3] = {nullptr, nullptr, nullptr};
   pprhip::KernelTimer ktimer;         // slot: its worker's kernel-class timer; graph: the sweeps' timer
   std::vector<pprhip_graph*> slots;

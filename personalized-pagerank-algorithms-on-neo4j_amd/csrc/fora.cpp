@@ -1365,10 +1365,12 @@ int pprhip_fora_stream_open(pprhip_graph_t* g, double eps, const pprhip_fora_con
   s->k = k;
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
   g->stream_open = true;
+  g->stream_obj = s.get();
   try {
     s->driver = std::thread(stream_driver, s.get());
   } catch (...) {
     g->stream_open = false;
+    g->stream_obj = nullptr;
     set_error("pprhip_fora_stream_open: no thread for the driver");
     return PPRHIP_ERR_OOM;
   }
@@ -1418,9 +1420,16 @@ int pprhip_fora_stream_submit(pprhip_stream_t* s, const int32_t* srcs, int q, ui
     set_error("pprhip_fora_stream_submit: the stream is closing");
     return PPRHIP_ERR_STATE;
   }
-  J->ticket = s->next_ticket++;
-  s->open[J->ticket] = J;
-  s->pending.push_back(J);
+  J->ticket = s->next_ticket;
+  try {  // (no exception leaves the C ABI)
+    s->open[J->ticket] = J;
+    s->pending.push_back(J);
+  } catch (const std::bad_alloc&) {
+    s->open.erase(J->ticket);
+    set_error("pprhip_fora_stream_submit: out of host memory");
+    return PPRHIP_ERR_OOM;
+  }
+  s->next_ticket++;
   if (keep && keep->count < keep_first + q) keep->count = keep_first + q;
   *ticket_out = J->ticket;
   s->cv_work.notify_one();
@@ -1456,6 +1465,7 @@ int pprhip_fora_stream_close(pprhip_stream_t* s) {
   if (s->driver.joinable()) s->driver.join();  // every submitted query has finished (or the stream has failed)
   pprhip_graph* g = s->g;
   g->stream_open = false;
+  g->stream_obj = nullptr;
   int rc = PPRHIP_OK;
   if (s->err != PPRHIP_OK) {
     const std::string msg = s->errmsg;
