@@ -10,9 +10,14 @@
 #include <unordered_map>
 #include <vector>
 
+#include <new>
+
 #include "common.hpp"
 
 namespace pprhip {
+namespace detail {
+unsigned host_threads();  // lift.cpp: what the process may use (CPU affinity, cgroup quota; PPRHIP_HOST_THREADS)
+}
 
 static thread_local std::string g_error;
 
@@ -33,11 +38,7 @@ static inline uint64_t splitmix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
-static unsigned worker_count() {
-  unsigned hw = std::thread::hardware_concurrency();
-  if (hw == 0) hw = 4;
-  return std::min(hw, 32u);
-}
+static unsigned worker_count() { return std::min(detail::host_threads(), 32u); }
 
 }  // namespace pprhip
 
@@ -347,23 +348,70 @@ int pprhip_csr_build(uint32_t n, uint64_t m, const int32_t* key, const int32_t* 
     set_error("pprhip_csr_build: bad arguments");
     return PPRHIP_ERR_INVALID;
   }
-  std::vector<uint32_t> cnt((size_t)n + 1, 0);
-  for (uint64_t e = 0; e < m; ++e) {
-    if (key[e] < 0 || (uint32_t)key[e] >= n || val[e] < 0 || (uint32_t)val[e] >= n) {
-      set_error("pprhip_csr_build: edge %llu has an endpoint outside [0, %u)", (unsigned long long)e, n);
+  // A stable counting sort by key on T threads: thread t owns the edges [m t / T, m (t + 1) / T), counts them per
+  // row, and writes them behind the rows' shares of the threads before it (in front of them when the newest edge
+  // comes first), so the order inside a row is the edge order whatever T is.  T x n counters: T shrinks for huge n.
+  unsigned T = m < (1u << 18) ? 1u : pprhip::detail::host_threads();
+  while (T > 1 && (uint64_t)T * n * sizeof(uint32_t) > (2ull << 30)) T /= 2;
+  try {
+    std::vector<std::vector<uint32_t>> cnt(T);
+    std::vector<uint64_t> bad(T, UINT64_MAX);
+    auto e_lo = [&](unsigned t) { return m * t / T; };
+    auto run = [&](auto&& fn) {
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < T; ++t) th.emplace_back(fn, t);
+      fn(0u);
+      for (auto& x : th) x.join();
+    };
+    run([&](unsigned t) {
+      cnt[t].assign((size_t)n, 0u);
+      uint32_t* c = cnt[t].data();
+      for (uint64_t e = e_lo(t); e < e_lo(t + 1); ++e) {
+        if (key[e] < 0 || (uint32_t)key[e] >= n || val[e] < 0 || (uint32_t)val[e] >= n) {
+          bad[t] = e;
+          return;
+        }
+        c[key[e]]++;
+      }
+    });
+    const uint64_t first_bad = *std::min_element(bad.begin(), bad.end());
+    if (first_bad != UINT64_MAX) {
+      set_error("pprhip_csr_build: edge %llu has an endpoint outside [0, %u)", (unsigned long long)first_bad, n);
       return PPRHIP_ERR_INVALID;
     }
-    cnt[(size_t)key[e] + 1]++;
-  }
-  row_ptr_out[0] = 0;
-  for (uint32_t v = 0; v < n; ++v) row_ptr_out[v + 1] = row_ptr_out[v] + cnt[v + 1];
-  std::vector<uint32_t> fill(n);
-  if (newest_first) {
-    for (uint32_t v = 0; v < n; ++v) fill[v] = row_ptr_out[v + 1];
-    for (uint64_t e = 0; e < m; ++e) col_idx_out[--fill[key[e]]] = val[e];
-  } else {
-    for (uint32_t v = 0; v < n; ++v) fill[v] = row_ptr_out[v];
-    for (uint64_t e = 0; e < m; ++e) col_idx_out[fill[key[e]]++] = val[e];
+    // row pointers from the summed counts (sums in node ranges on all threads, then one pass of prefix sums)
+    row_ptr_out[0] = 0;
+    run([&](unsigned t) {
+      const uint32_t v_lo = (uint32_t)((uint64_t)n * t / T), v_hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+      for (uint32_t v = v_lo; v < v_hi; ++v) {
+        uint32_t sum = 0;
+        for (unsigned u = 0; u < T; ++u) sum += cnt[u][v];
+        row_ptr_out[v + 1] = sum;
+      }
+    });
+    for (uint32_t v = 0; v < n; ++v) row_ptr_out[v + 1] += row_ptr_out[v];
+    // cnt[t][v] becomes where thread t starts writing row v
+    run([&](unsigned t) {
+      const uint32_t v_lo = (uint32_t)((uint64_t)n * t / T), v_hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+      for (uint32_t v = v_lo; v < v_hi; ++v) {
+        uint32_t at = newest_first ? row_ptr_out[v + 1] : row_ptr_out[v];
+        for (unsigned u = 0; u < T; ++u) {
+          const uint32_t c = cnt[u][v];
+          cnt[u][v] = at;
+          at = newest_first ? at - c : at + c;
+        }
+      }
+    });
+    run([&](unsigned t) {
+      uint32_t* at = cnt[t].data();
+      if (newest_first)
+        for (uint64_t e = e_lo(t); e < e_lo(t + 1); ++e) col_idx_out[--at[key[e]]] = val[e];
+      else
+        for (uint64_t e = e_lo(t); e < e_lo(t + 1); ++e) col_idx_out[at[key[e]]++] = val[e];
+    });
+  } catch (const std::bad_alloc&) {
+    set_error("pprhip_csr_build: out of host memory");
+    return PPRHIP_ERR_OOM;
   }
   return PPRHIP_OK;
 }
