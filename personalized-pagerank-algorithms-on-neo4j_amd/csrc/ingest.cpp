@@ -201,7 +201,8 @@ int pprhip_edgelist_from_neo4j_store(const char* store_dir, pprhip_edgelist_t** 
     return PPRHIP_ERR_INVALID;
   }
   const std::string dir(store_dir);
-  std::vector<unsigned char> nodes, rels, nid;
+  std::vector<unsigned char> nodes, rels, nid, groups;
+  bool groups_read = false;
   if (!read_file(dir + "/neostore.nodestore.db", nodes) || !read_file(dir + "/neostore.relationshipstore.db", rels)) {
     set_error("cannot read neostore.nodestore.db / neostore.relationshipstore.db under %s", store_dir);
     return PPRHIP_ERR_IO;
@@ -254,12 +255,81 @@ int pprhip_edgelist_from_neo4j_store(const char* store_dir, pprhip_edgelist_t** 
     e->out_rp[v + 1] = e->out_rp[v];
     e->in_rp[v + 1] = e->in_rp[v];
     if (!(x[0] & 1)) continue;
-    if (x[14] & 1) {
-      set_error("%s: node %llu is dense (relationship groups are not supported)", store_dir, (unsigned long long)v);
-      delete e;
-      return PPRHIP_ERR_IO;
-    }
     uint64_t r = be32(x + 1) | ((uint64_t)(x[0] & 0x0E) << 31);
+    if (x[14] & 1) {
+      // A dense node (50 relationships or more by default - the threshold is the group store's header, 0x32 in
+      // got.db's): its record points to a chain of relationship groups, one per relationship type, each with the
+      // heads of three chains - outgoing, incoming, loops (RelationshipGroupRecordFormat: 25 bytes = header byte
+      // {in use, high bits of next and firstOut}, high byte {firstIn, firstLoop}, type u16, next, firstOut, firstIn,
+      // firstLoop u32, owning node u32 + u8; record 0 holds the store header).  Listed as the kernel's traversal
+      // lists them: group by group, the outgoing chain, the incoming chain, then the loops (both directions).
+      if (!groups_read) {
+        groups_read = true;
+        if (!read_file(dir + "/neostore.relationshipgroupstore.db", groups)) {
+          set_error("%s: node %llu is dense and neostore.relationshipgroupstore.db cannot be read", store_dir,
+                    (unsigned long long)v);
+          delete e;
+          return PPRHIP_ERR_IO;
+        }
+      }
+      constexpr size_t kGroup = 25;
+      const uint64_t ngroup = groups.size() / kGroup;
+      auto mod = [](uint32_t low, uint64_t high) {  // BaseRecordFormat.longFromIntAndMod: all ones without high bits = none
+        return (high == 0 && low == 0xFFFFFFFFu) ? kNoRel : ((uint64_t)low | high);
+      };
+      uint64_t gsteps = 0;
+      for (uint64_t gid = (r == kNoRel || (r & 0xFFFFFFFFull) == 0xFFFFFFFFull) ? kNoRel : r; gid != kNoRel; ++gsteps) {
+        if (gid == 0 || gid >= ngroup || gsteps > ngroup) {
+          set_error("%s: broken relationship group chain at node %llu", store_dir, (unsigned long long)v);
+          delete e;
+          return PPRHIP_ERR_IO;
+        }
+        const unsigned char* gx = &groups[gid * kGroup];
+        const uint64_t owner = be32(gx + 20) | ((uint64_t)gx[24] << 32);
+        if (!(gx[0] & 1) || owner != v) {
+          set_error("%s: relationship group %llu on node %llu's chain is unused or belongs to node %llu", store_dir,
+                    (unsigned long long)gid, (unsigned long long)v, (unsigned long long)owner);
+          delete e;
+          return PPRHIP_ERR_IO;
+        }
+        const uint64_t next = mod(be32(gx + 4), (uint64_t)(gx[0] & 0x0E) << 31);
+        const uint64_t heads[3] = {mod(be32(gx + 8), (uint64_t)(gx[0] & 0x70) << 28),    // outgoing
+                                   mod(be32(gx + 12), (uint64_t)(gx[1] & 0x0E) << 31),   // incoming
+                                   mod(be32(gx + 16), (uint64_t)(gx[1] & 0x70) << 28)};  // loops
+        for (int dir3 = 0; dir3 < 3; ++dir3) {
+          uint64_t steps = 0;
+          for (uint64_t q = heads[dir3]; q != kNoRel; ++steps) {
+            if (q >= nrel || steps > m) {
+              set_error("%s: broken relationship chain at dense node %llu", store_dir, (unsigned long long)v);
+              delete e;
+              return PPRHIP_ERR_IO;
+            }
+            const Rel rr = rel(q);
+            const bool ok = rr.in_use && (dir3 == 0 ? (rr.first == v && rr.second != v)
+                                                    : dir3 == 1 ? (rr.second == v && rr.first != v)
+                                                                : (rr.first == v && rr.second == v));
+            if (!ok) {
+              set_error("%s: relationship %llu is on the wrong chain of dense node %llu", store_dir,
+                        (unsigned long long)q, (unsigned long long)v);
+              delete e;
+              return PPRHIP_ERR_IO;
+            }
+            if (dir3 != 1) {
+              e->out_ci.push_back((int32_t)rr.second);
+              e->out_rp[v + 1]++;
+            }
+            if (dir3 != 0) {
+              e->in_ci.push_back((int32_t)rr.first);
+              e->in_rp[v + 1]++;
+            }
+            q = dir3 == 1 ? rr.second_next : rr.first_next;
+            if ((q & 0xFFFFFFFFull) == 0xFFFFFFFFull && q <= 0xFFFFFFFFull) q = kNoRel;
+          }
+        }
+        gid = next;
+      }
+      continue;
+    }
     for (uint64_t steps = 0; r != kNoRel && (r & 0xFFFFFFFFull) != 0xFFFFFFFFull; ++steps) {
       if (r >= nrel || steps > m) {
         set_error("%s: broken relationship chain at node %llu", store_dir, (unsigned long long)v);

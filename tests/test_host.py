@@ -331,3 +331,95 @@ def test_lift_host_reports_the_first_bad_entry(pkg):
     bad = type("H", (), dict(n=h.n, m=h.m, out_rp=h.out_rp, out_ci=h.out_ci, in_rp=rp2, in_ci=in_ci))()
     with pytest.raises(pkg.PprhipError, match=r"not the transpose"):
         pkg.lift_host(bad, threads=8)
+
+
+# ------------------------------------------------------------------ Neo4j store with dense nodes (relationship groups)
+def _write_neo4j_store(path, n, src, dst, dense_threshold=50):
+    """Record files of a Neo4j 3.x store ("standard" format, big-endian) for the given relationships: nodestore (15-byte
+    records), relationshipstore (34), relationshipgroupstore (25; record 0 = the header holding the dense-node threshold,
+    as in the reference's target/got.db: 00 00 00 32).  Nodes whose degree reaches the threshold are dense: their
+    record points to a relationship group with separate outgoing / incoming / loop chains; the others keep one chain.
+    New relationships go to the head of their chains (newest first), as the kernel links them."""
+    import struct
+    NO = 0xFFFFFFFF
+    m = len(src)
+    deg = np.bincount(src, minlength=n) + np.bincount(dst, minlength=n) - np.bincount(src[src == dst], minlength=n)
+    dense = deg >= dense_threshold
+    head = np.full(n, NO, dtype=np.int64)          # sparse nodes: chain head
+    ghead = {int(v): [NO, NO, NO] for v in np.nonzero(dense)[0]}  # dense: [out, in, loop]
+    fnext = np.full(m, NO, dtype=np.int64)
+    snext = np.full(m, NO, dtype=np.int64)
+    for r in range(m):
+        a, b = int(src[r]), int(dst[r])
+        for v, is_first in ((a, True), (b, False)):
+            if a == b and not is_first:
+                continue
+            if dense[v]:
+                slot = 2 if a == b else (0 if is_first else 1)
+                prev, ghead[v][slot] = ghead[v][slot], r
+            else:
+                prev, head[v] = head[v], r
+            if a == b:
+                fnext[r] = snext[r] = prev
+            elif is_first:
+                fnext[r] = prev
+            else:
+                snext[r] = prev
+    gid_of = {v: i + 1 for i, v in enumerate(sorted(ghead))}
+    nodes = bytearray()
+    for v in range(n):
+        nxt = gid_of[v] if dense[v] else int(head[v])
+        nodes += struct.pack(">BII5sB", 1, nxt & NO, NO, b"\0" * 5, 1 if dense[v] else 0)
+    rels = bytearray()
+    for r in range(m):
+        rels += struct.pack(">BIIIIIIIIB", 1, int(src[r]), int(dst[r]), 0, 0, int(fnext[r]), 0, int(snext[r]), NO, 0)
+    groups = bytearray(struct.pack(">I", dense_threshold) + b"\0" * 21)
+    for v in sorted(ghead):
+        o, i, l = ghead[v]
+        groups += struct.pack(">BBHIIIIIB", 1, 0, 0, NO, o, i, l, v, 0)
+    os.makedirs(path, exist_ok=True)
+    for name, blob in (("neostore.nodestore.db", nodes), ("neostore.relationshipstore.db", rels),
+                       ("neostore.relationshipgroupstore.db", groups)):
+        with open(os.path.join(path, name), "wb") as f:
+            f.write(bytes(blob))
+    return dense
+
+
+def test_neo4j_store_reader_dense_nodes(pkg, tmp_path):
+    """Nodes with 50 relationships or more are "dense" in a Neo4j store: their relationships hang off relationship-group
+    records, not off one chain.  got.db has none, every real dataset does (the thesis' GRQC, BlogCatalog, ...: Diss.
+    p.36).  A store written here to the record format - hub nodes, loops on dense and on sparse nodes, parallel edges -
+    is read back: every node's out- / in-list in chain order (dense: outgoing chain, incoming chain, then loops)."""
+    rng = np.random.default_rng(11)
+    n = 300
+    src = np.concatenate([rng.integers(0, n, 900), np.full(80, 7), rng.integers(0, n, 70), [7, 7, 9, 250]])
+    dst = np.concatenate([rng.integers(0, n, 900), rng.integers(0, n, 80), np.full(70, 13), [7, 7, 9, 250]])
+    src, dst = src.astype(np.int64), dst.astype(np.int64)
+    dst[5], src[5] = dst[4], src[4]  # a parallel edge
+    d = str(tmp_path / "dense.db")
+    dense = _write_neo4j_store(d, n, src, dst)
+    assert dense[7] and dense[13] and not dense[9] and dense.sum() >= 2
+    st = pkg.HostCsr.from_neo4j_store(d)
+    assert (st.n, st.m) == (n, src.size)
+    rid = np.arange(src.size)
+    for v in range(n):
+        outs, ins, loops = rid[(src == v) & (dst != v)][::-1], rid[(dst == v) & (src != v)][::-1], rid[(src == v) & (dst == v)][::-1]
+        if dense[v]:
+            exp_out = list(dst[outs]) + [v] * loops.size
+            exp_in = list(src[ins]) + [v] * loops.size
+        else:
+            touch = rid[(src == v) | (dst == v)][::-1]
+            exp_out = [int(dst[r]) for r in touch if src[r] == v]
+            exp_in = [int(src[r]) for r in touch if dst[r] == v]
+        assert list(st.out_ci[st.out_rp[v]:st.out_rp[v + 1]]) == exp_out, v
+        assert list(st.in_ci[st.in_rp[v]:st.in_rp[v + 1]]) == exp_in, v
+    # a group that belongs to another node, and a missing group store, are reported
+    g = os.path.join(d, "neostore.relationshipgroupstore.db")
+    blob = bytearray(open(g, "rb").read())
+    blob[25 + 23] ^= 1  # owning node of group 1
+    open(g, "wb").write(bytes(blob))
+    with pytest.raises(pkg.PprhipError, match="belongs to node"):
+        pkg.HostCsr.from_neo4j_store(d)
+    os.remove(g)
+    with pytest.raises(pkg.PprhipError, match="relationshipgroupstore"):
+        pkg.HostCsr.from_neo4j_store(d)
