@@ -433,8 +433,14 @@ int pprhip_csr_build(uint32_t n, uint64_t m, const int32_t* key, const int32_t* 
       fn(0u);
       for (auto& x : th) x.join();
     };
+    bool oom[64] = {false};  // (host_threads() <= 64; an exception must not leave a worker thread)
     run([&](unsigned t) {
-      cnt[t].assign((size_t)n, 0u);
+      try {
+        cnt[t].assign((size_t)n, 0u);
+      } catch (const std::bad_alloc&) {
+        oom[t] = true;
+        return;
+      }
       uint32_t* c = cnt[t].data();
       for (uint64_t e = e_lo(t); e < e_lo(t + 1); ++e) {
         if (key[e] < 0 || (uint32_t)key[e] >= n || val[e] < 0 || (uint32_t)val[e] >= n) {
@@ -444,6 +450,8 @@ int pprhip_csr_build(uint32_t n, uint64_t m, const int32_t* key, const int32_t* 
         c[key[e]]++;
       }
     });
+    for (unsigned t = 0; t < T; ++t)
+      if (oom[t]) throw std::bad_alloc();
     const uint64_t first_bad = *std::min_element(bad.begin(), bad.end());
     if (first_bad != UINT64_MAX) {
       set_error("pprhip_csr_build: edge %llu has an endpoint outside [0, %u)", (unsigned long long)first_bad, n);
