@@ -423,3 +423,21 @@ def test_neo4j_store_reader_dense_nodes(pkg, tmp_path):
     os.remove(g)
     with pytest.raises(pkg.PprhipError, match="relationshipgroupstore"):
         pkg.HostCsr.from_neo4j_store(d)
+
+
+def test_lift_host_without_relabeling(pkg, monkeypatch):
+    """PPRHIP_RELABEL=0: the caller's ids are the internal order - both CSRs come through unchanged, the sweep's row list
+    is the nodes with in-edges in id order, on one thread and on eight."""
+    monkeypatch.setenv("PPRHIP_RELABEL", "0")
+    h = pkg.HostCsr.rmat(16, 16, seed=9)
+    for threads in (1, 8):
+        got = pkg.lift_host(h, threads=threads)
+        assert np.array_equal(got["new2old"], np.arange(h.n)) and np.array_equal(got["old2new"], np.arange(h.n))
+        for k in ("out_rp", "out_ci", "in_rp", "in_ci"):
+            assert np.array_equal(got[k], getattr(h, k)), k
+        indeg, outdeg = np.diff(h.in_rp), np.diff(h.out_rp)
+        assert np.array_equal(got["nz_rows"], np.nonzero(indeg > 0)[0])
+        assert np.array_equal(got["zin_rows"], np.nonzero((indeg == 0) & (outdeg > 0))[0])
+        starts = h.in_rp[:-1][got["nz_rows"]]
+        bits = np.unpackbits(got["flags"], bitorder="little")
+        assert bits.sum() == starts.size and bits[starts].all()
