@@ -2,7 +2,9 @@
 // CSR construction.  This is the data-format side of the graph lift (PPR.java:136-152 loads the
 // Neo4j store into HeavyGraph's two jagged adjacency arrays); nothing here touches the GPU.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <memory>
 #include <fstream>
 #include <iterator>
 #include <string>
@@ -55,10 +57,17 @@ struct pprhip_edgelist {
 };
 
 static bool read_file(const std::string& path, std::vector<unsigned char>& buf) {
-  std::ifstream f(path, std::ios::binary);
+  FILE* f = fopen(path.c_str(), "rb");  // (one read of the whole file: store files run to gigabytes)
   if (!f) return false;
-  buf.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-  return true;
+  bool ok = fseek(f, 0, SEEK_END) == 0;
+  const long size = ok ? ftell(f) : -1;
+  ok = ok && size >= 0 && fseek(f, 0, SEEK_SET) == 0;
+  if (ok) {
+    buf.resize((size_t)size);
+    ok = size == 0 || fread(buf.data(), 1, (size_t)size, f) == (size_t)size;
+  }
+  fclose(f);
+  return ok;
 }
 static inline uint32_t be32(const unsigned char* p) {
   return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
@@ -195,176 +204,282 @@ int pprhip_edgelist_from_neo4j_csv(const char* nodes_csv, const char* rels_csv, 
   return PPRHIP_OK;
 }
 
+// A Neo4j 3.x store ("standard" record format, big-endian) read without a JVM.  Node records are 15 bytes {in use +
+// high bits, nextRel u32, nextProp u32, labels 5, extra: dense flag}, relationship records 34 bytes {in use + high
+// bits, first node u32, second node u32, type + high bits u32, first prev / next u32, second prev / next u32, nextProp
+// u32, extra}; a node's relationships form a chain through the "next" pointer of whichever end the node is.  A dense
+// node (50 relationships or more by default - the threshold is the group store's header, 0x32 in got.db's) points to a
+// chain of 25-byte relationship groups instead, one per relationship type, each with the heads of three chains -
+// outgoing, incoming, loops (RelationshipGroupRecordFormat: header byte {in use, high bits of next and firstOut}, high
+// byte {firstIn, firstLoop}, type u16, next, firstOut, firstIn, firstLoop u32, owning node u32 + u8; record 0 holds the
+// store header).  Adjacency lists come out in chain order, as HeavyGraph's loader lists them; for a dense node group by
+// group: the outgoing chain, the incoming chain, then the loops (both directions).
+// Every node's chains are independent of every other node's, so the nodes are walked on all host threads: once to count
+// (row pointers), once to fill (the reference's own load takes 9 s for 11.8 M relationships, Diss. Table 27).
+}  // extern "C"
+
+namespace {
+
+constexpr size_t kNodeRec = 15, kRelRec = 34, kGroupRec = 25;
+constexpr uint64_t kNoRel = 0x7FFFFFFFFull;  // all 35 id bits set = "no relationship"
+
+struct StoreView {
+  const char* dir = "";
+  std::vector<unsigned char> nodes, rels, groups;
+  bool have_groups = false;
+  uint64_t n = 0, nrel = 0, ngroup = 0, m = 0;
+};
+
+struct RelRec {
+  bool in_use;
+  uint64_t first, second, first_next, second_next;
+};
+
+inline RelRec rel_at(const StoreView& S, uint64_t id) {
+  const unsigned char* x = &S.rels[id * kRelRec];
+  const uint32_t type_int = be32(x + 9);
+  RelRec r;
+  r.in_use = x[0] & 1;
+  r.first = be32(x + 1) | ((uint64_t)(x[0] & 0x0E) << 31);
+  r.second = be32(x + 5) | ((uint64_t)(type_int & 0x70000000u) << 4);
+  r.first_next = be32(x + 17) | ((uint64_t)(type_int & 0x01C00000u) << 10);
+  r.second_next = be32(x + 25) | ((uint64_t)(type_int & 0x00070000u) << 16);
+  return r;
+}
+
+inline bool no_rel(uint64_t r) { return r == kNoRel || r == 0xFFFFFFFFull; }
+
+std::string fmt(const char* f, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof buf, f, ap);
+  va_end(ap);
+  return buf;
+}
+
+// Calls emit(outgoing, neighbour) for every relationship end of node v in chain order; false + *err on a broken store.
+template <class Emit>
+bool walk_node(const StoreView& S, uint64_t v, Emit&& emit, std::string* err) {
+  const unsigned char* x = &S.nodes[v * kNodeRec];
+  if (!(x[0] & 1)) return true;
+  uint64_t r = be32(x + 1) | ((uint64_t)(x[0] & 0x0E) << 31);
+  if (!(x[14] & 1)) {
+    for (uint64_t steps = 0; !no_rel(r); ++steps) {
+      if (r >= S.nrel || steps > S.m) {
+        *err = fmt("%s: broken relationship chain at node %llu", S.dir, (unsigned long long)v);
+        return false;
+      }
+      const RelRec rr = rel_at(S, r);
+      if (rr.first == v) {
+        emit(true, rr.second);
+        if (rr.second == v) emit(false, v);  // self loop: one record, both directions
+        r = rr.first_next;
+      } else if (rr.second == v) {
+        emit(false, rr.first);
+        r = rr.second_next;
+      } else {
+        *err = fmt("%s: relationship %llu is on node %llu's chain but does not touch it", S.dir, (unsigned long long)r,
+                   (unsigned long long)v);
+        return false;
+      }
+    }
+    return true;
+  }
+  if (!S.have_groups) {
+    *err = fmt("%s: node %llu is dense and neostore.relationshipgroupstore.db cannot be read", S.dir, (unsigned long long)v);
+    return false;
+  }
+  auto mod = [](uint32_t low, uint64_t high) {  // BaseRecordFormat.longFromIntAndMod: all ones without high bits = none
+    return (high == 0 && low == 0xFFFFFFFFu) ? kNoRel : ((uint64_t)low | high);
+  };
+  uint64_t gsteps = 0;
+  for (uint64_t gid = no_rel(r) ? kNoRel : r; gid != kNoRel; ++gsteps) {
+    if (gid == 0 || gid >= S.ngroup || gsteps > S.ngroup) {
+      *err = fmt("%s: broken relationship group chain at node %llu", S.dir, (unsigned long long)v);
+      return false;
+    }
+    const unsigned char* gx = &S.groups[gid * kGroupRec];
+    const uint64_t owner = be32(gx + 20) | ((uint64_t)gx[24] << 32);
+    if (!(gx[0] & 1) || owner != v) {
+      *err = fmt("%s: relationship group %llu on node %llu's chain is unused or belongs to node %llu", S.dir,
+                 (unsigned long long)gid, (unsigned long long)v, (unsigned long long)owner);
+      return false;
+    }
+    const uint64_t next = mod(be32(gx + 4), (uint64_t)(gx[0] & 0x0E) << 31);
+    const uint64_t heads[3] = {mod(be32(gx + 8), (uint64_t)(gx[0] & 0x70) << 28),    // outgoing
+                               mod(be32(gx + 12), (uint64_t)(gx[1] & 0x0E) << 31),   // incoming
+                               mod(be32(gx + 16), (uint64_t)(gx[1] & 0x70) << 28)};  // loops
+    for (int d3 = 0; d3 < 3; ++d3) {
+      uint64_t steps = 0;
+      for (uint64_t q = heads[d3]; !no_rel(q); ++steps) {
+        if (q >= S.nrel || steps > S.m) {
+          *err = fmt("%s: broken relationship chain at dense node %llu", S.dir, (unsigned long long)v);
+          return false;
+        }
+        const RelRec rr = rel_at(S, q);
+        const bool ok = rr.in_use && (d3 == 0 ? (rr.first == v && rr.second != v)
+                                               : d3 == 1 ? (rr.second == v && rr.first != v) : (rr.first == v && rr.second == v));
+        if (!ok) {
+          *err = fmt("%s: relationship %llu is on the wrong chain of dense node %llu", S.dir, (unsigned long long)q,
+                     (unsigned long long)v);
+          return false;
+        }
+        if (d3 != 1) emit(true, rr.second);
+        if (d3 != 0) emit(false, rr.first);
+        q = d3 == 1 ? rr.second_next : rr.first_next;
+      }
+    }
+    gid = next;
+  }
+  return true;
+}
+
+// fn(part) for part in [0, parts) on T threads; false when a part reported an error (the lowest part's message wins)
+template <class F>
+bool store_parts(unsigned parts, unsigned T, std::vector<std::string>& errs, F&& fn) {
+  errs.assign(parts, std::string());
+  std::atomic<unsigned> next{0};
+  auto work = [&]() {
+    for (unsigned p = next.fetch_add(1); p < parts; p = next.fetch_add(1)) {
+      try {
+        fn(p, &errs[p]);
+      } catch (const std::bad_alloc&) {
+        errs[p] = "out of host memory";
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned w = 1; w < std::min(T, parts); ++w) th.emplace_back(work);
+  work();
+  for (auto& x : th) x.join();
+  for (const std::string& e : errs)
+    if (!e.empty()) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
 int pprhip_edgelist_from_neo4j_store(const char* store_dir, pprhip_edgelist_t** out) {
   if (!store_dir || !out) {
     set_error("pprhip_edgelist_from_neo4j_store: null argument");
     return PPRHIP_ERR_INVALID;
   }
   const std::string dir(store_dir);
-  std::vector<unsigned char> nodes, rels, nid, groups;
-  bool groups_read = false;
-  if (!read_file(dir + "/neostore.nodestore.db", nodes) || !read_file(dir + "/neostore.relationshipstore.db", rels)) {
+  StoreView S;
+  S.dir = store_dir;
+  std::vector<unsigned char> nid;
+  if (!read_file(dir + "/neostore.nodestore.db", S.nodes) || !read_file(dir + "/neostore.relationshipstore.db", S.rels)) {
     set_error("cannot read neostore.nodestore.db / neostore.relationshipstore.db under %s", store_dir);
     return PPRHIP_ERR_IO;
   }
-  constexpr size_t kNode = 15, kRel = 34;
-  constexpr uint64_t kNoRel = 0x7FFFFFFFFull;  // all 35 id bits set = "no relationship"
-  uint64_t n = nodes.size() / kNode;
+  S.have_groups = read_file(dir + "/neostore.relationshipgroupstore.db", S.groups);  // (only dense nodes need it)
+  S.ngroup = S.groups.size() / kGroupRec;
+  uint64_t n = S.nodes.size() / kNodeRec;
   if (read_file(dir + "/neostore.nodestore.db.id", nid) && nid.size() >= 9) {  // 1 flag byte + 8-byte high id
     uint64_t hi = 0;
     for (int i = 1; i <= 8; ++i) hi = (hi << 8) | nid[i];
     if (hi <= n) n = hi;
   }
-  while (n > 0 && !(nodes[(n - 1) * kNode] & 1)) --n;  // trailing unused records
-  const uint64_t nrel = rels.size() / kRel;
-  if (n == 0 || n >= (1ull << 28)) {
-    set_error("%s: %llu node records (unsupported)", store_dir, (unsigned long long)n);
+  while (n > 0 && !(S.nodes[(n - 1) * kNodeRec] & 1)) --n;  // trailing unused records
+  S.n = n;
+  S.nrel = S.rels.size() / kRelRec;
+  if (n == 0 || n >= (1ull << 28) || S.nrel >= (1ull << 32) - 1024) {
+    set_error("%s: %llu node records, %llu relationship records (unsupported)", store_dir, (unsigned long long)n,
+              (unsigned long long)S.nrel);
     return PPRHIP_ERR_IO;
   }
-  auto* e = new pprhip_edgelist();
+  std::unique_ptr<pprhip_edgelist> e(new (std::nothrow) pprhip_edgelist());
+  if (!e) return PPRHIP_ERR_OOM;
   e->n = (uint32_t)n;
   e->from_store = true;
-  struct Rel { bool in_use; uint64_t first, second, first_next, second_next; };
-  auto rel = [&](uint64_t id) {
-    const unsigned char* x = &rels[id * kRel];
-    const uint32_t type_int = be32(x + 9);
-    Rel r;
-    r.in_use = x[0] & 1;
-    r.first = be32(x + 1) | ((uint64_t)(x[0] & 0x0E) << 31);
-    r.second = be32(x + 5) | ((uint64_t)(type_int & 0x70000000u) << 4);
-    r.first_next = be32(x + 17) | ((uint64_t)(type_int & 0x01C00000u) << 10);
-    r.second_next = be32(x + 25) | ((uint64_t)(type_int & 0x00070000u) << 16);
-    return r;
+  const unsigned T = (n + S.nrel < (1u << 15)) ? 1u : detail::host_threads();
+  const unsigned parts = T == 1 ? 1u : T * 8u;
+  std::vector<std::string> errs;
+  auto fail = [&](int code) {
+    for (const std::string& m : errs)
+      if (!m.empty()) {
+        set_error("%s", m.c_str());
+        break;
+      }
+    return code;
   };
-  for (uint64_t id = 0; id < nrel; ++id) {  // relationships in id order (= import row order)
-    const Rel r = rel(id);
-    if (!r.in_use) continue;
-    if (r.first >= n || r.second >= n) {
-      set_error("%s: relationship %llu references a node outside the store", store_dir, (unsigned long long)id);
-      delete e;
+  try {
+    // ---- relationships in id order (= import row order): count the used ones per range, then write them
+    std::vector<uint64_t> used(parts + 1, 0);
+    auto r_lo = [&](unsigned p) { return S.nrel * p / parts; };
+    if (!store_parts(parts, T, errs, [&](unsigned p, std::string* err) {
+          uint64_t c = 0;
+          for (uint64_t id = r_lo(p); id < r_lo(p + 1); ++id) {
+            const RelRec r = rel_at(S, id);
+            if (!r.in_use) continue;
+            if (r.first >= n || r.second >= n) {
+              *err = fmt("%s: relationship %llu references a node outside the store", store_dir, (unsigned long long)id);
+              return;
+            }
+            ++c;
+          }
+          used[p + 1] = c;
+        }))
+      return fail(PPRHIP_ERR_IO);
+    for (unsigned p = 0; p < parts; ++p) used[p + 1] += used[p];
+    const uint64_t m = S.m = used[parts];
+    e->src.resize(m);
+    e->dst.resize(m);
+    store_parts(parts, T, errs, [&](unsigned p, std::string*) {
+      uint64_t w = used[p];
+      for (uint64_t id = r_lo(p); id < r_lo(p + 1); ++id) {
+        const RelRec r = rel_at(S, id);
+        if (!r.in_use) continue;
+        e->src[w] = (int32_t)r.first;
+        e->dst[w] = (int32_t)r.second;
+        ++w;
+      }
+    });
+    // ---- every node's chains, as HeavyGraph's loader walks them: degrees first, then the lists
+    e->out_rp.assign(n + 1, 0);
+    e->in_rp.assign(n + 1, 0);
+    auto v_lo = [&](unsigned p) { return n * p / parts; };
+    if (!store_parts(parts, T, errs, [&](unsigned p, std::string* err) {
+          for (uint64_t v = v_lo(p); v < v_lo(p + 1); ++v) {
+            uint32_t od = 0, id = 0;
+            if (!walk_node(S, v, [&](bool outgoing, uint64_t) { (outgoing ? od : id)++; }, err)) return;
+            e->out_rp[v + 1] = od;
+            e->in_rp[v + 1] = id;
+          }
+        }))
+      return fail(PPRHIP_ERR_IO);
+    for (uint64_t v = 0; v < n; ++v) {
+      e->out_rp[v + 1] += e->out_rp[v];
+      e->in_rp[v + 1] += e->in_rp[v];
+    }
+    if (e->out_rp[n] != m || e->in_rp[n] != m) {
+      set_error("%s: chains cover %u out / %u in of %llu relationships", store_dir, e->out_rp[n], e->in_rp[n],
+                (unsigned long long)m);
       return PPRHIP_ERR_IO;
     }
-    e->src.push_back((int32_t)r.first);
-    e->dst.push_back((int32_t)r.second);
-  }
-  const uint64_t m = e->src.size();
-  e->out_rp.assign(n + 1, 0);
-  e->in_rp.assign(n + 1, 0);
-  for (uint64_t v = 0; v < n; ++v) {  // walk every node's relationship chain, as HeavyGraph's loader does
-    const unsigned char* x = &nodes[v * kNode];
-    e->out_rp[v + 1] = e->out_rp[v];
-    e->in_rp[v + 1] = e->in_rp[v];
-    if (!(x[0] & 1)) continue;
-    uint64_t r = be32(x + 1) | ((uint64_t)(x[0] & 0x0E) << 31);
-    if (x[14] & 1) {
-      // A dense node (50 relationships or more by default - the threshold is the group store's header, 0x32 in
-      // got.db's): its record points to a chain of relationship groups, one per relationship type, each with the
-      // heads of three chains - outgoing, incoming, loops (RelationshipGroupRecordFormat: 25 bytes = header byte
-      // {in use, high bits of next and firstOut}, high byte {firstIn, firstLoop}, type u16, next, firstOut, firstIn,
-      // firstLoop u32, owning node u32 + u8; record 0 holds the store header).  Listed as the kernel's traversal
-      // lists them: group by group, the outgoing chain, the incoming chain, then the loops (both directions).
-      if (!groups_read) {
-        groups_read = true;
-        if (!read_file(dir + "/neostore.relationshipgroupstore.db", groups)) {
-          set_error("%s: node %llu is dense and neostore.relationshipgroupstore.db cannot be read", store_dir,
-                    (unsigned long long)v);
-          delete e;
-          return PPRHIP_ERR_IO;
-        }
-      }
-      constexpr size_t kGroup = 25;
-      const uint64_t ngroup = groups.size() / kGroup;
-      auto mod = [](uint32_t low, uint64_t high) {  // BaseRecordFormat.longFromIntAndMod: all ones without high bits = none
-        return (high == 0 && low == 0xFFFFFFFFu) ? kNoRel : ((uint64_t)low | high);
-      };
-      uint64_t gsteps = 0;
-      for (uint64_t gid = (r == kNoRel || (r & 0xFFFFFFFFull) == 0xFFFFFFFFull) ? kNoRel : r; gid != kNoRel; ++gsteps) {
-        if (gid == 0 || gid >= ngroup || gsteps > ngroup) {
-          set_error("%s: broken relationship group chain at node %llu", store_dir, (unsigned long long)v);
-          delete e;
-          return PPRHIP_ERR_IO;
-        }
-        const unsigned char* gx = &groups[gid * kGroup];
-        const uint64_t owner = be32(gx + 20) | ((uint64_t)gx[24] << 32);
-        if (!(gx[0] & 1) || owner != v) {
-          set_error("%s: relationship group %llu on node %llu's chain is unused or belongs to node %llu", store_dir,
-                    (unsigned long long)gid, (unsigned long long)v, (unsigned long long)owner);
-          delete e;
-          return PPRHIP_ERR_IO;
-        }
-        const uint64_t next = mod(be32(gx + 4), (uint64_t)(gx[0] & 0x0E) << 31);
-        const uint64_t heads[3] = {mod(be32(gx + 8), (uint64_t)(gx[0] & 0x70) << 28),    // outgoing
-                                   mod(be32(gx + 12), (uint64_t)(gx[1] & 0x0E) << 31),   // incoming
-                                   mod(be32(gx + 16), (uint64_t)(gx[1] & 0x70) << 28)};  // loops
-        for (int dir3 = 0; dir3 < 3; ++dir3) {
-          uint64_t steps = 0;
-          for (uint64_t q = heads[dir3]; q != kNoRel; ++steps) {
-            if (q >= nrel || steps > m) {
-              set_error("%s: broken relationship chain at dense node %llu", store_dir, (unsigned long long)v);
-              delete e;
-              return PPRHIP_ERR_IO;
-            }
-            const Rel rr = rel(q);
-            const bool ok = rr.in_use && (dir3 == 0 ? (rr.first == v && rr.second != v)
-                                                    : dir3 == 1 ? (rr.second == v && rr.first != v)
-                                                                : (rr.first == v && rr.second == v));
-            if (!ok) {
-              set_error("%s: relationship %llu is on the wrong chain of dense node %llu", store_dir,
-                        (unsigned long long)q, (unsigned long long)v);
-              delete e;
-              return PPRHIP_ERR_IO;
-            }
-            if (dir3 != 1) {
-              e->out_ci.push_back((int32_t)rr.second);
-              e->out_rp[v + 1]++;
-            }
-            if (dir3 != 0) {
-              e->in_ci.push_back((int32_t)rr.first);
-              e->in_rp[v + 1]++;
-            }
-            q = dir3 == 1 ? rr.second_next : rr.first_next;
-            if ((q & 0xFFFFFFFFull) == 0xFFFFFFFFull && q <= 0xFFFFFFFFull) q = kNoRel;
+    e->out_ci.resize(m);
+    e->in_ci.resize(m);
+    if (!store_parts(parts, T, errs, [&](unsigned p, std::string* err) {
+          for (uint64_t v = v_lo(p); v < v_lo(p + 1); ++v) {
+            uint32_t ow = e->out_rp[v], iw = e->in_rp[v];
+            if (!walk_node(S, v, [&](bool outgoing, uint64_t u) {
+                  if (outgoing) e->out_ci[ow++] = (int32_t)u;
+                  else e->in_ci[iw++] = (int32_t)u;
+                }, err))
+              return;
           }
-        }
-        gid = next;
-      }
-      continue;
-    }
-    for (uint64_t steps = 0; r != kNoRel && (r & 0xFFFFFFFFull) != 0xFFFFFFFFull; ++steps) {
-      if (r >= nrel || steps > m) {
-        set_error("%s: broken relationship chain at node %llu", store_dir, (unsigned long long)v);
-        delete e;
-        return PPRHIP_ERR_IO;
-      }
-      const Rel rr = rel(r);
-      if (rr.first == v) {
-        e->out_ci.push_back((int32_t)rr.second);
-        e->out_rp[v + 1]++;
-        if (rr.second == v) {  // self loop: one record, both directions
-          e->in_ci.push_back((int32_t)v);
-          e->in_rp[v + 1]++;
-        }
-        r = rr.first_next;
-      } else if (rr.second == v) {
-        e->in_ci.push_back((int32_t)rr.first);
-        e->in_rp[v + 1]++;
-        r = rr.second_next;
-      } else {
-        set_error("%s: relationship %llu is on node %llu's chain but does not touch it", store_dir,
-                  (unsigned long long)r, (unsigned long long)v);
-        delete e;
-        return PPRHIP_ERR_IO;
-      }
-    }
+        }))
+      return fail(PPRHIP_ERR_IO);
+    e->names.reserve(n);
+    for (uint64_t v = 0; v < n; ++v) e->names.push_back(std::to_string(v));
+  } catch (const std::bad_alloc&) {
+    set_error("%s: out of host memory", store_dir);
+    return PPRHIP_ERR_OOM;
   }
-  if (e->out_ci.size() != m || e->in_ci.size() != m) {
-    set_error("%s: chains cover %zu out / %zu in of %llu relationships", store_dir, e->out_ci.size(), e->in_ci.size(),
-              (unsigned long long)m);
-    delete e;
-    return PPRHIP_ERR_IO;
-  }
-  for (uint64_t v = 0; v < n; ++v) e->names.push_back(std::to_string(v));
-  *out = e;
+  *out = e.release();
   return PPRHIP_OK;
 }
 

@@ -441,3 +441,39 @@ def test_lift_host_without_relabeling(pkg, monkeypatch):
         starts = h.in_rp[:-1][got["nz_rows"]]
         bits = np.unpackbits(got["flags"], bitorder="little")
         assert bits.sum() == starts.size and bits[starts].all()
+
+
+def test_neo4j_store_reader_on_all_threads(pkg, tmp_path):
+    """A store large enough for the reader's threaded passes (relationship ranges, node ranges): 6 000 nodes, 40 000
+    relationships, a few dense hubs - the same lists as one pass in chain order gives."""
+    rng = np.random.default_rng(12)
+    n, m = 6000, 40000
+    src = rng.integers(0, n, m).astype(np.int64)
+    dst = rng.integers(0, n, m).astype(np.int64)
+    src[rng.integers(0, m, 300)] = 17
+    dst[rng.integers(0, m, 300)] = 4242
+    d = str(tmp_path / "big.db")
+    dense = _write_neo4j_store(d, n, src, dst)
+    assert dense[17] and dense[4242]
+    st = pkg.HostCsr.from_neo4j_store(d)
+    assert (st.n, st.m) == (n, m)
+    rid = np.arange(m)
+    for v in [17, 4242] + list(rng.integers(0, n, 200)):
+        outs, ins, loops = rid[(src == v) & (dst != v)][::-1], rid[(dst == v) & (src != v)][::-1], rid[(src == v) & (dst == v)][::-1]
+        if dense[v]:
+            exp_out, exp_in = list(dst[outs]) + [v] * loops.size, list(src[ins]) + [v] * loops.size
+        else:
+            touch = rid[(src == v) | (dst == v)][::-1]
+            exp_out = [int(dst[r]) for r in touch if src[r] == v]
+            exp_in = [int(src[r]) for r in touch if dst[r] == v]
+        assert list(st.out_ci[st.out_rp[v]:st.out_rp[v + 1]]) == exp_out, v
+        assert list(st.in_ci[st.in_rp[v]:st.in_rp[v + 1]]) == exp_in, v
+    assert np.array_equal(np.diff(st.out_rp), np.bincount(src, minlength=n))
+    assert np.array_equal(np.diff(st.in_rp), np.bincount(dst, minlength=n))
+    # a relationship that points outside the store is reported with its id, whichever thread meets it
+    rel = os.path.join(d, "neostore.relationshipstore.db")
+    blob = bytearray(open(rel, "rb").read())
+    blob[34 * 31000 + 1:34 * 31000 + 5] = (n + 5).to_bytes(4, "big")
+    open(rel, "wb").write(bytes(blob))
+    with pytest.raises(pkg.PprhipError, match="relationship 31000 references a node outside"):
+        pkg.HostCsr.from_neo4j_store(d)
