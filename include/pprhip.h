@@ -338,7 +338,8 @@ int pprhip_fora_stream_open(pprhip_graph_t* g, double eps, const pprhip_fora_con
                             pprhip_stream_t** stream_out);
 int pprhip_fora_stream_submit(pprhip_stream_t* s, const int32_t* srcs, int q, uint64_t seed, pprhip_results_t* keep,
                               int keep_first, int32_t* ids_out, double* vals_out, int* n_out, uint64_t* ticket_out);
-/* blocks until every query of the submission has finished; stats_sum: its counters (total_ms = submit to finish) */
+/* blocks until every query of the submission has finished; stats_sum: its counters (total_ms = submit to finish).
+ * A ticket can be waited for once; submissions nobody waits for are finished and released by the close. */
 int pprhip_fora_stream_wait(pprhip_stream_t* s, uint64_t ticket, pprhip_stats_t* stats_sum);
 /* finishes everything submitted, ends the driver thread and frees the stream */
 int pprhip_fora_stream_close(pprhip_stream_t* s);

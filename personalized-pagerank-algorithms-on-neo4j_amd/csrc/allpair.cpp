@@ -69,28 +69,10 @@ struct pprhip_index {
 
 namespace {
 
-// Host threads for the index finalisation: what the process may really use at once - its CPU affinity and, where the
-// cgroup sets one, its CPU quota (the GPU boxes give a one-GPU job 16 of 256 hardware threads; more threads than
-// that are throttled, not added) - at most 64.
-static unsigned finalise_threads() {
-  static const unsigned n = [] {
-    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    if (const char* e = getenv("PPRHIP_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
-    for (const char* path : {"/sys/fs/cgroup/cpu.max"}) {
-      if (FILE* f = fopen(path, "r")) {
-        char q[32] = {0};
-        double period = 0;
-        if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-          const double cores = atof(q) / period;
-          if (cores >= 1.0) hw = std::min(hw, (unsigned)(cores + 0.5));
-        }
-        fclose(f);
-      }
-    }
-    return std::max(1u, std::min(64u, hw));
-  }();
-  return n;
-}
+// Host threads for the index finalisation: what the process may really use at once (lift.cpp: host_threads - CPU
+// affinity and cgroup quota; the GPU boxes give a one-GPU job 16 of 256 hardware threads, and more threads than that
+// are throttled, not added).
+static unsigned finalise_threads() { return host_threads(); }
 
 // Base_Whole_Graph.java:112-163: per source, k < 0 keeps insertion (target) order; k >= 0 keeps
 // entries >= the k-th largest (all when fewer than k) sorted descending (stable: ties stay in

@@ -28,7 +28,7 @@ namespace detail {
 unsigned host_threads() {
   static const unsigned n = [] {
     unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    if (const char* e = getenv("PPRHIP_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
+    if (const char* e = getenv("PPRHIP_HOST_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
       char q[32] = {0};
       double period = 0;
