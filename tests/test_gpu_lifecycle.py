@@ -1,0 +1,79 @@
+"""Lifecycle of handles on the GPU: whatever a handle, a result store, an index, a communicator or a query stream took
+is back when it has been closed - device memory by hipMemGetInfo, host memory by the process's resident set.  A service
+that lifts graphs and answers queries for days (the query stream's use) must not grow."""
+import gc
+import os
+
+import numpy as np
+import pytest
+
+ALPHA = 0.15
+pytestmark = pytest.mark.gpu
+
+
+def _rss_mb():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e6
+
+
+def _one_life(pkg, host, srcs):
+    """Every entry point once on a fresh handle, everything closed afterwards."""
+    with pkg.Graph(host, device=0) as g:
+        g.fora_single_source(int(srcs[0]), 0.5, ALPHA, seed=3)
+        g.fora_topk(int(srcs[1]), 0.5, ALPHA, 8, seed=3, cap=16)
+        g.forward_push(int(srcs[2]), ALPHA, 1e-6)
+        g.backward_push(int(srcs[3]), ALPHA, 1e-4)
+        g.power_method(int(srcs[4]), ALPHA, iters=10)
+        g.monte_carlo(int(srcs[5]), 0.5, ALPHA, seed=3)
+        g.set_tuning(pkg.tuning_batch())
+        store = pkg.Results(g, 24)
+        g.fora_batch_single_source(srcs[:24], 0.5, ALPHA, seed=5, k=8, keep=store, fetch=True)
+        with pkg.QueryStream(g, 0.5, ALPHA, k=8) as qs:
+            t1 = qs.submit(srcs[:20], 6, keep=store)
+            t2 = qs.submit(srcs[20:24], 7, keep=store, keep_first=20)
+            qs.wait(t2)
+            qs.wait(t1)
+        store.sum(3)
+        store.close()
+        g.set_tuning(pkg.tuning_default())
+        g.fora_batch_topk(srcs[:20], 8, 0.5, ALPHA, seed=9)
+        ix, _ = g.all_pair_backward(ALPHA, 1e-3, 8, 0, 4096)
+        ix.arrays()
+        ix.close()
+        g.release(pkg.Graph.RELEASE_ALL_PAIR | pkg.Graph.RELEASE_BATCH)
+        g.fora_batch_single_source(srcs[:5], 0.5, ALPHA, seed=5, k=4)  # workspaces come back after a release
+    gc.collect()
+
+
+def test_handles_give_everything_back(pkg, rmat15, rmat12):
+    rng = np.random.default_rng(3)
+    live = np.nonzero(np.diff(rmat15.out_rp) > 0)[0]
+    srcs = live[rng.integers(0, live.size, 32)].astype(np.int32)
+    with pkg.Graph(rmat12, device=0) as probe:  # a small handle that stays: pprhip_device_memory needs one
+        _one_life(pkg, rmat15, srcs)  # first life: code objects, the runtime's own pools, allocator arenas
+        _one_life(pkg, rmat15, srcs)
+        free0, _ = probe.device_memory()
+        rss0 = _rss_mb()
+        for _ in range(4):
+            _one_life(pkg, rmat15, srcs)
+        free1, _ = probe.device_memory()
+        rss1 = _rss_mb()
+    assert free0 - free1 <= 64 << 20, "device memory not returned: %.1f MB after four more lives" % ((free0 - free1) / 1e6)
+    assert rss1 - rss0 <= 200.0, "host memory grew by %.0f MB over four lives" % (rss1 - rss0)
+
+
+def test_stream_left_open_is_closed_with_its_graph(pkg, rmat12):
+    """pprhip_graph_destroy on a handle whose query stream was never closed ends the driver thread first (the thread
+    uses the handle); the process goes on and a new handle works."""
+    live = np.nonzero(np.diff(rmat12.out_rp) > 0)[0][:8].astype(np.int32)
+    g = pkg.Graph(rmat12, device=0)
+    g.set_tuning(pkg.tuning_batch())
+    qs = pkg.QueryStream(g, 0.5, ALPHA, k=4)
+    tk = qs.submit(live, 5)
+    qs.wait(tk)
+    qs.submit(live, 6)  # still in flight or queued when the graph goes
+    qs.h = None         # (the wrapper forgets the stream: nobody closes it)
+    g.close()
+    with pkg.Graph(rmat12, device=0) as g2:
+        est, _ = g2.fora_single_source(int(live[0]), 0.5, ALPHA, seed=3)
+        assert abs(est.sum() - 1.0) < 1e-9
