@@ -12,6 +12,7 @@ package joezie.fora_neo4j;
  *   PPR.setupAdjMatrix           -> new PprHip(adjM, device)
  *   Fora_Whole_Graph.compute...  -> foraSingleSource + reserve()      (Fora_Whole_Graph.java:82-146)
  *   Gen_Util's query loop        -> foraBatch / foraBatchResident     (Gen_Util.java:208-232)
+ *   ... called block after block  -> streamOpen / streamSubmit / streamWait / streamClose
  *   Fora_Topk.computeTopKPPR     -> foraTopk                          (Fora_Topk.java:102-199)
  *   Forward_Push                 -> forwardPush, fwdpushTopkReset/Round (Forward_Push.java:63-250)
  *   Monte_Carlo                  -> monteCarlo, randomWalks           (Monte_Carlo.java:60-158)
@@ -28,6 +29,7 @@ public final class PprHip implements AutoCloseable {
 
     private long handle; // pprhip_graph_t*
     private long store;  // pprhip_results_t* of the last foraBatchResident call (0 = none)
+    private long stream; // native box of the open query stream (0 = none)
     private final int n;
 
     /** Copies HeavyGraph's adjacency once (what PPR.setupAdjMatrix + set_configuration do, PPR.java:121-152). */
@@ -62,6 +64,19 @@ public final class PprHip implements AutoCloseable {
 
     /** Vector of query i of the last foraBatchResident call (dense, mapped ids). */
     public native double[] batchResult(int i);
+
+    /** Query stream (pprhip_fora_stream_*): blocks of sources submitted as they come; the engine starts a block's first
+     *  queries in the slots the block before leaves, so short blocks (Gen_Util's 50) run at the rate of long ones.
+     *  While a stream is open every other compute method of this object throws; streamClose() finishes what is queued. */
+    public native void streamOpen(double eps, double alpha, int k);
+
+    /** Queues a block; returns its ticket. */
+    public native long streamSubmit(int[] srcs, long seed);
+
+    /** Blocks until the block has finished and copies its q rows of k (id -1 pads) into idsOut / valsOut. */
+    public native void streamWait(long ticket, int[] idsOut, double[] valsOut);
+
+    public native void streamClose();
 
     /** Fora_Topk.computeTopKPPR + getTopKNodeIds: returns the number of entries >= the k-th value (may exceed k). */
     public native int foraTopk(int src, int k, double eps, double alpha, long seed, int[] idsOut, double[] valsOut);

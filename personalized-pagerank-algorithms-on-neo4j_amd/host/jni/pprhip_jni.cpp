@@ -6,6 +6,7 @@
 #include <jni.h>
 
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../../../include/pprhip.h"
@@ -15,19 +16,22 @@ namespace {
 // field ids of PprHip.handle / PprHip.store, looked up once (they stay valid while the class is loaded; two threads
 // racing here store the same values)
 struct FieldIds {
-  jfieldID handle = nullptr, store = nullptr;
+  jfieldID handle = nullptr, store = nullptr, stream = nullptr;
 };
 FieldIds& fields(JNIEnv* e, jobject self) {
   static FieldIds F;
-  if (!F.handle || !F.store) {
+  if (!F.handle || !F.store || !F.stream) {
     jclass c = e->GetObjectClass(self);
     F.handle = e->GetFieldID(c, "handle", "J");
     F.store = e->GetFieldID(c, "store", "J");
+    F.stream = e->GetFieldID(c, "stream", "J");
   }
   return F;
 }
 jfieldID fid_store(JNIEnv* e, jobject self) { return fields(e, self).store; }
 jfieldID fid_handle(JNIEnv* e, jobject self) { return fields(e, self).handle; }
+
+bool fail(JNIEnv* e, int rc);
 
 void throw_new(JNIEnv* e, const char* cls, const char* msg) {
   jclass c = e->FindClass(cls);
@@ -41,6 +45,34 @@ pprhip_graph_t* G(JNIEnv* e, jobject self) {
   if (!g && !e->ExceptionCheck()) throw_new(e, "java/lang/IllegalStateException", "PprHip: the graph handle is closed");
   return g;
 }
+// An open query stream and the output buffers of its submissions: the library writes a submission's top-k block until
+// its wait returns, so the block lives here, not in a Java array that the collector may move.
+struct StreamBox {
+  pprhip_stream_t* s = nullptr;
+  int k = 0;
+  struct Block {
+    std::vector<int32_t> ids;
+    std::vector<double> vals;
+  };
+  std::map<uint64_t, Block*> blocks;
+};
+StreamBox* SB(JNIEnv* e, jobject self) {
+  const jfieldID f = fields(e, self).stream;
+  StreamBox* b = f ? (StreamBox*)e->GetLongField(self, f) : nullptr;
+  if (!b && !e->ExceptionCheck()) throw_new(e, "java/lang/IllegalStateException", "PprHip: no query stream is open");
+  return b;
+}
+void close_stream(JNIEnv* e, jobject self, bool report) {
+  const jfieldID f = fields(e, self).stream;
+  StreamBox* b = f ? (StreamBox*)e->GetLongField(self, f) : nullptr;
+  if (!b) return;
+  e->SetLongField(self, f, 0);
+  const int rc = pprhip_fora_stream_close(b->s);  // finishes everything submitted: nothing writes the blocks any more
+  for (auto& kv : b->blocks) delete kv.second;
+  delete b;
+  if (report) fail(e, rc);
+}
+
 pprhip_results_t* R(JNIEnv* e, jobject self) {
   const jfieldID f = fid_store(e, self);
   return f ? (pprhip_results_t*)e->GetLongField(self, f) : nullptr;
@@ -345,8 +377,79 @@ JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_release(JNIEnv* e, jobject
   if (g) fail(e, pprhip_graph_release(g, (unsigned)what));
 }
 
+// ---- query stream (pprhip_fora_stream_*): Gen_Util's loop called again and again without a drain between the calls
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_streamOpen(JNIEnv* e, jobject self, jdouble eps, jdouble alpha, jint k) {
+  pprhip_graph_t* g = G(e, self);
+  if (!g) return;
+  const jfieldID f = fields(e, self).stream;
+  if (!f || e->GetLongField(self, f)) {
+    throw_new(e, "java/lang/IllegalStateException", "PprHip.streamOpen: a stream is already open");
+    return;
+  }
+  const Dims d = dims(g);
+  pprhip_fora_conf_t conf;
+  if (fail(e, pprhip_conf_fora_whole_graph(d.n, d.m, alpha, &conf))) return;  // Algo_Conf.java:45-53
+  StreamBox* b = new StreamBox();
+  b->k = k;
+  if (fail(e, pprhip_fora_stream_open(g, eps, &conf, k, &b->s))) {
+    delete b;
+    return;
+  }
+  e->SetLongField(self, f, (jlong)b);
+}
+
+JNIEXPORT jlong JNICALL Java_joezie_fora_1neo4j_PprHip_streamSubmit(JNIEnv* e, jobject self, jintArray srcs, jlong seed) {
+  StreamBox* b = SB(e, self);
+  if (!b) return 0;
+  if (!srcs) {
+    throw_new(e, "java/lang/IllegalArgumentException", "PprHip.streamSubmit: null sources");
+    return 0;
+  }
+  const jsize q = e->GetArrayLength(srcs);
+  std::vector<jint> s(q);
+  e->GetIntArrayRegion(srcs, 0, q, s.data());
+  StreamBox::Block* blk = new StreamBox::Block();
+  blk->ids.resize((size_t)q * b->k);
+  blk->vals.resize((size_t)q * b->k);
+  uint64_t ticket = 0;
+  if (fail(e, pprhip_fora_stream_submit(b->s, (const int32_t*)s.data(), q, (uint64_t)seed, nullptr, 0, blk->ids.data(),
+                                        blk->vals.data(), nullptr, &ticket))) {
+    delete blk;
+    return 0;
+  }
+  b->blocks[ticket] = blk;
+  return (jlong)ticket;
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_streamWait(JNIEnv* e, jobject self, jlong ticket, jintArray idsOut,
+                                                                 jdoubleArray valsOut) {
+  StreamBox* b = SB(e, self);
+  if (!b) return;
+  auto it = b->blocks.find((uint64_t)ticket);
+  if (it == b->blocks.end()) {
+    throw_new(e, "java/lang/IllegalArgumentException", "PprHip.streamWait: no open submission with this ticket");
+    return;
+  }
+  StreamBox::Block* blk = it->second;
+  if (b->k > 0 && (!idsOut || !valsOut || (size_t)e->GetArrayLength(idsOut) < blk->ids.size() ||
+                   (size_t)e->GetArrayLength(valsOut) < blk->vals.size())) {
+    throw_new(e, "java/lang/IllegalArgumentException", "PprHip.streamWait: output arrays shorter than q * k");
+    return;
+  }
+  const int rc = pprhip_fora_stream_wait(b->s, (uint64_t)ticket, nullptr);
+  b->blocks.erase(it);
+  if (!fail(e, rc) && b->k > 0) {
+    e->SetIntArrayRegion(idsOut, 0, (jsize)blk->ids.size(), (const jint*)blk->ids.data());
+    e->SetDoubleArrayRegion(valsOut, 0, (jsize)blk->vals.size(), blk->vals.data());
+  }
+  delete blk;
+}
+
+JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_streamClose(JNIEnv* e, jobject self) { close_stream(e, self, true); }
+
 JNIEXPORT void JNICALL Java_joezie_fora_1neo4j_PprHip_close(JNIEnv* e, jobject self) {
-  // closing twice is allowed (AutoCloseable): the second call finds both fields 0
+  // closing twice is allowed (AutoCloseable): the second call finds every field 0
+  close_stream(e, self, false);
   if (pprhip_results_t* r = R(e, self)) pprhip_results_destroy(r);
   if (fid_store(e, self)) e->SetLongField(self, fid_store(e, self), 0);
   const jfieldID fh = fid_handle(e, self);
