@@ -7,6 +7,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # as the product runs (engine.cpp: prefer_device_kernargs)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

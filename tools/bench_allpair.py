@@ -33,6 +33,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # as bench.py runs
     import torch
     import torch.distributed as dist
     local_rank %= max(1, torch.cuda.device_count())

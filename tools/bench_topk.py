@@ -5,6 +5,7 @@ import sys
 import time
 
 import numpy as np
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # as bench.py runs
 import torch  # noqa: F401  (loads the HIP runtime first)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,7 +1,8 @@
 """Times All-Pair-Backward-Search on an R-MAT graph (developer tool)."""
 import argparse, importlib, os, sys, time
 import numpy as np
-import torch  # noqa: F401  (loads the HIP runtime first)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # as bench.py runs
+import torch  # noqa: F401,E402  (loads the HIP runtime first)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
