@@ -21,6 +21,18 @@ using namespace pprhip;
 using namespace pprhip::detail;
 
 namespace pprhip {
+
+std::atomic<int> g_kernel_timing{-1};
+bool kernel_timing_on() {
+  int v = g_kernel_timing.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("PPRHIP_KERNEL_TIMER");
+    v = (e && e[0] == '1') ? 1 : 0;
+    g_kernel_timing.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+
 namespace detail {
 
 thread_local KernelTimer g_timer_own;
@@ -1185,6 +1197,12 @@ int make_side_stream(pprhip_graph* g, hipStream_t* out) {
 // C ABI
 // =================================================================================================
 extern "C" {
+
+int pprhip_set_kernel_timing(int on) {
+  const bool was = kernel_timing_on();
+  g_kernel_timing.store(on ? 1 : 0, std::memory_order_relaxed);
+  return was ? 1 : 0;
+}
 
 int pprhip_device_count(int* count_out) {
   int c = 0;

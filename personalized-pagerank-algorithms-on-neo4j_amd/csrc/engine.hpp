@@ -1,6 +1,9 @@
 // engine.hpp — device-resident graph handle and the kernel launchers the drivers call.
 #pragma once
 
+#include <atomic>
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace pprhip {
@@ -112,8 +115,15 @@ struct PushArgs {
 // created on demand and reused across calls; the pool is capped: a call that records more intervals
 // than kMaxEvents / 2 (All-Pair's tier 3 launches ~1e5 sparse batches) drains the stream, folds what it
 // has into per-class accumulators and starts over, so neither the pool nor `recs` grows with the call.
+// Class *times* are an option (pprhip_set_kernel_timing, PPRHIP_KERNEL_TIMER=1): an interval is two event records in
+// the stream, and between the short kernels of a top-k round or a sparse level those cost the latency-bound paths
+// 2-8 % (round 4: top-k 16 in flight 1 640-1 720 -> 1 800-1 850 queries/s without them).  Without the option the
+// brackets are only counted: class_launches and class_bytes are filled, class_ms stay zero.
+extern std::atomic<int> g_kernel_timing;  // engine.cpp; -1: not decided yet (the environment is read on first use)
+bool kernel_timing_on();
 struct KernelTimer {
   static constexpr size_t kMaxEvents = 4096;
+  static constexpr size_t kNoEvent = ~(size_t)0;
   bool off = false;  // records nothing (work whose time is accounted elsewhere or not at all)
   std::vector<hipEvent_t> ev;
   struct Rec { int cls; size_t i; uint64_t bytes; };
@@ -134,6 +144,11 @@ struct KernelTimer {
   // folds the recorded intervals into the accumulators (the stream must have drained)
   void fold() {
     for (const Rec& r : recs) {
+      if (r.i == kNoEvent) {  // counted, not timed
+        acc_bytes[r.cls] += r.bytes;
+        acc_cnt[r.cls]++;
+        continue;
+      }
       if (r.i + 1 >= used) continue;
       float f = 0.f;
       if (hipEventElapsedTime(&f, ev[r.i], ev[r.i + 1]) != hipSuccess) continue;
@@ -150,6 +165,11 @@ struct KernelTimer {
   }
   void begin(int cls, uint64_t bytes) {
     if (off) return;
+    if (!kernel_timing_on()) {
+      if (recs.size() >= 65536) fold();  // (counting needs no drained stream)
+      recs.push_back({cls, kNoEvent, bytes});
+      return;
+    }
     if (used + 2 > kMaxEvents) {
       if (hipStreamSynchronize(stream) != hipSuccess) return;
       fold();
@@ -160,7 +180,7 @@ struct KernelTimer {
     (void)hipEventRecord(a, stream);
   }
   void end() {
-    if (off) return;
+    if (off || !kernel_timing_on()) return;
     hipEvent_t b = next();
     if (b) (void)hipEventRecord(b, stream);
   }

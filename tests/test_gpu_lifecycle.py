@@ -77,3 +77,25 @@ def test_stream_left_open_is_closed_with_its_graph(pkg, rmat12):
     with pkg.Graph(rmat12, device=0) as g2:
         est, _ = g2.fora_single_source(int(live[0]), 0.5, ALPHA, seed=3)
         assert abs(est.sum() - 1.0) < 1e-9
+
+
+def test_kernel_timing_is_an_option(pkg, rmat15):
+    """pprhip_set_kernel_timing: by default a call only counts its groups of launches (class_launches, class_bytes) and
+    records no events between its kernels; with the option on the same call also reports class times.  Results are the
+    same either way."""
+    live = np.nonzero(np.diff(rmat15.out_rp) > 0)[0]
+    src = int(live[5])
+    with pkg.Graph(rmat15, device=0) as g:
+        was = pkg.set_kernel_timing(False)
+        try:
+            est0, st0 = g.fora_single_source(src, 0.5, ALPHA, seed=3)
+            assert sum(st0.class_launches) > 0 and st0.levels > 0
+            assert st0.class_ms[1] == 0.0 and st0.class_ms[2] == 0.0 and st0.total_ms > 0.0
+            assert pkg.set_kernel_timing(True) is False
+            est1, st1 = g.fora_single_source(src, 0.5, ALPHA, seed=3)
+            assert st1.class_ms[1] + st1.class_ms[2] > 0.0
+            assert list(st1.class_launches) == list(st0.class_launches)
+            assert np.max(np.abs(est0 - est1)) <= 1e-12
+            assert pkg.set_kernel_timing(False) is True
+        finally:
+            pkg.set_kernel_timing(was)

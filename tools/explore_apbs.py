@@ -6,6 +6,7 @@ import torch  # noqa: F401,E402  (loads the HIP runtime first)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("personalized-pagerank-algorithms-on-neo4j_amd")
+pkg.set_kernel_timing(True)  # class times wanted here
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=18)
 ap.add_argument("--thr", type=float, default=1e-3)
