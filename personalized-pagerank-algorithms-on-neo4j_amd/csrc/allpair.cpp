@@ -22,44 +22,6 @@ using namespace pprhip::detail;
 // All-Pair-Backward-Search (a9) — first correct path: one backward search per target on the
 // global arrays, entries >= threshold compacted on the device, inverted index built on the host.
 // =================================================================================================
-static void* big_alloc(size_t bytes) {
-  constexpr size_t kHuge = 2u << 20;
-  if (bytes < 8 * kHuge) {
-    void* p = malloc(bytes ? bytes : 1);
-    if (!p) throw std::bad_alloc();
-    return p;
-  }
-  void* p = nullptr;
-  if (posix_memalign(&p, kHuge, (bytes + kHuge - 1) / kHuge * kHuge) != 0 || !p) throw std::bad_alloc();
-  (void)madvise(p, (bytes + kHuge - 1) / kHuge * kHuge, MADV_HUGEPAGE);
-  return p;
-}
-
-// vectors whose resize() leaves new elements uninitialised: the index arrays are hundreds of megabytes that the
-// finalisation's threads fill in full (a value-initialising resize is a single-threaded pass over fresh pages)
-template <class T>
-struct NoInitAlloc {
-  using value_type = T;
-  NoInitAlloc() = default;
-  template <class U>
-  NoInitAlloc(const NoInitAlloc<U>&) {}
-  // large arrays on 2-MB boundaries with transparent huge pages asked for: the finalisation's threads touch every page
-  // of hundreds of megabytes for the first time, and a 4-KB fault each is a fifth of the k rule's time
-  T* allocate(size_t n) { return static_cast<T*>(big_alloc(n * sizeof(T))); }
-  void deallocate(T* p, size_t) { free(p); }
-  template <class U, class... A>
-  void construct(U* p, A&&... a) {
-    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;  // default-init: nothing for arithmetic types
-    else ::new ((void*)p) U(std::forward<A>(a)...);
-  }
-  template <class U>
-  bool operator==(const NoInitAlloc<U>&) const { return true; }
-  template <class U>
-  bool operator!=(const NoInitAlloc<U>&) const { return false; }
-};
-template <class T>
-using RawVec = std::vector<T, NoInitAlloc<T>>;
-
 struct pprhip_index {
   uint32_t n = 0;
   RawVec<uint64_t> offsets;
