@@ -331,6 +331,17 @@ def test_lift_host_reports_the_first_bad_entry(pkg):
     bad = type("H", (), dict(n=h.n, m=h.m, out_rp=h.out_rp, out_ci=h.out_ci, in_rp=rp2, in_ci=in_ci))()
     with pytest.raises(pkg.PprhipError, match=r"not the transpose"):
         pkg.lift_host(bad, threads=8)
+    # the right number of in-edges at every node, but two of them name the wrong sources: the transpose check compares
+    # the edges themselves (a sum over a mix of every (source, destination) pair), not only the degrees
+    in_ci = h.in_ci.copy()
+    rows = np.nonzero(np.diff(h.in_rp) > 0)[0]
+    a, b = int(h.in_rp[rows[3]]), int(h.in_rp[rows[-3]])
+    assert in_ci[a] != in_ci[b]
+    in_ci[a], in_ci[b] = in_ci[b], in_ci[a]
+    bad = type("H", (), dict(n=h.n, m=h.m, out_rp=h.out_rp, out_ci=h.out_ci, in_rp=h.in_rp, in_ci=in_ci))()
+    for threads in (1, 8):
+        with pytest.raises(pkg.PprhipError, match=r"not from the same sources"):
+            pkg.lift_host(bad, threads=threads)
 
 
 # ------------------------------------------------------------------ Neo4j store with dense nodes (relationship groups)
