@@ -31,3 +31,21 @@ for name, tun in (("default", pkg.tuning_default()), ("batch", pkg.tuning_batch(
     print("batched (%s profile): %.1f queries/s (%.2f ms per live query), rounds %d, dense levels %d, sweeps %d"
           % (name, q / (t1 - t0), 1e3 * (t1 - t0) / live, st.rounds, st.dense_levels, st.class_launches[5]), flush=True)
 g.close()
+
+# walk phases of top-k rounds (short launches): rate and fill of the loads, against the long phases of whole-graph queries
+pkg.set_kernel_timing(True)
+g = pkg.Graph(host)
+tot = {"steps": 0, "loads": 0, "lanes": 0, "ms": 0.0, "launches": 0, "walks": 0}
+for i, s in enumerate(srcs[:32]):
+    _, _, _, _, st = g.fora_topk(int(s), 0.5, 0.15, 32, seed=5 + i)
+    tot["steps"] += st.walk_steps
+    tot["loads"] += st.walk_loads
+    tot["lanes"] += st.walk_load_lanes
+    tot["ms"] += st.class_ms[3]
+    tot["launches"] += st.class_launches[3]
+    tot["walks"] += st.walks
+if tot["launches"]:
+    print("top-k walk phases: %d launches, %.0f us each, %.1f G steps/s, %.1f lanes per load, %.0f walks and %.0f steps per launch"
+          % (tot["launches"], 1e3 * tot["ms"] / tot["launches"], tot["steps"] / (tot["ms"] / 1e3) / 1e9,
+             tot["lanes"] / max(1, tot["loads"]), tot["walks"] / tot["launches"], tot["steps"] / tot["launches"]), flush=True)
+g.close()
