@@ -346,7 +346,8 @@ int pprhip_fora_stream_submit(pprhip_stream_t* s, const int32_t* srcs, int q, ui
 /* blocks until every query of the submission has finished; stats_sum: its counters (total_ms = submit to finish).
  * A ticket can be waited for once; submissions nobody waits for are finished and released by the close. */
 int pprhip_fora_stream_wait(pprhip_stream_t* s, uint64_t ticket, pprhip_stats_t* stats_sum);
-/* finishes everything submitted, ends the driver thread and frees the stream */
+/* finishes everything submitted, ends the driver thread and frees the stream.  (pprhip_graph_destroy on a graph whose
+ * stream is still open ends the driver itself; the stream object then only remains to be freed by this call.) */
 int pprhip_fora_stream_close(pprhip_stream_t* s);
 /* FORA top-k (pprhip_fora_topk) for q sources, up to PPRHIP_BATCH of them in flight: every query runs
  * Fora_Topk's loop on delta unchanged (query i with seed + i), the dense levels of its forward_push_topk

@@ -1430,7 +1430,7 @@ int pprhip_graph_release(pprhip_graph_t* g, unsigned what) {
 
 void pprhip_graph_destroy(pprhip_graph_t* g) {
   if (!g) return;
-  if (g->stream_obj) (void)pprhip_fora_stream_close((pprhip_stream_t*)g->stream_obj);  // (its driver thread uses the handle)
+  if (g->stream_obj) stream_detach(g->stream_obj);  // (its driver thread uses the handle; the stream object stays its owner's)
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   free_batch(g);

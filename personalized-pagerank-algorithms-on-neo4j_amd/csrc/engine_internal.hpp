@@ -174,6 +174,7 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
               const int32_t* in_ci, unsigned threads, HostLift& H);
 unsigned host_threads();  // CPU affinity and cgroup quota of the process, at most 64 (PPRHIP_HOST_THREADS overrides)
 
+void stream_detach(void* stream_obj);  // fora.cpp: ends a query stream's driver before its graph goes
 int alloc_dev(void** p, size_t bytes);
 double level_cost(const pprhip_graph* g, uint64_t nf, uint64_t ef, bool* dense);
 uint64_t dense_level_bytes(const pprhip_graph* g);

@@ -1305,13 +1305,23 @@ void stream_driver(pprhip_stream* s) {
   hipStream_t side = side_stream_for_walks(P);
   ForaRun runs[kBatch];
   bool walking[kBatch] = {false};
+  // test switch: PPRHIP_STREAM_FAULT_AT=<n> makes the driver fail when it is about to start the stream's n-th query
+  // (0-based), as a failing kernel launch would: every open and later submission ends with the driver's error
+  long fault_at = -1, started = 0;
+  if (const char* fe = getenv("PPRHIP_STREAM_FAULT_AT")) fault_at = atol(fe);
+  bool injected = false;
   auto next = [&](BatchJob** job, int* i) {
+    if (fault_at >= 0 && started == fault_at) {
+      injected = true;
+      return false;
+    }
     std::lock_guard<std::mutex> lk(s->mu);
     if (s->pending.empty()) return false;
     StreamJob* J = s->pending.front().get();
     *job = J;
     *i = J->next_query.fetch_add(1);
     if (*i + 1 >= J->q) s->pending.pop_front();  // (the open map keeps the submission alive)
+    ++started;
     return true;
   };
   auto done = [&](BatchJob* job) {
@@ -1327,6 +1337,11 @@ void stream_driver(pprhip_stream* s) {
   for (;;) {
     int busy = 0;
     if ((rc = advance_slots(P, runs, 0, kBatch, walking, side, next, done, &busy)) != PPRHIP_OK) break;
+    if (injected) {
+      set_error("query stream: injected failure before query %ld (PPRHIP_STREAM_FAULT_AT)", fault_at);
+      rc = PPRHIP_ERR_STATE;
+      break;
+    }
     if (busy == 0) {
       std::unique_lock<std::mutex> lk(s->mu);
       s->cv_work.wait(lk, [&] { return s->closing || !s->pending.empty(); });
@@ -1388,6 +1403,10 @@ int pprhip_fora_stream_submit(pprhip_stream_t* s, const int32_t* srcs, int q, ui
     set_error("pprhip_fora_stream_submit: the result store belongs to another graph or holds %d < %d + %d queries",
               keep->capacity, keep_first, q);
     return PPRHIP_ERR_INVALID;
+  }
+  if (!s->g) {
+    set_error("pprhip_fora_stream_submit: the stream's graph has been destroyed");
+    return PPRHIP_ERR_STATE;
   }
   for (int i = 0; i < q; ++i) PPRHIP_TRY(check_node(s->g, srcs[i], "pprhip_fora_stream_submit"));
   std::shared_ptr<StreamJob> J;
@@ -1455,25 +1474,53 @@ int pprhip_fora_stream_wait(pprhip_stream_t* s, uint64_t ticket, pprhip_stats_t*
   return PPRHIP_OK;
 }
 
-int pprhip_fora_stream_close(pprhip_stream_t* s) {
-  if (!s) return PPRHIP_OK;
+// Ends the driver thread and takes the stream off its graph; the stream object stays (a later close frees it).
+static int stream_shutdown(pprhip_stream* s) {
+  pprhip_graph* g = s->g;
+  if (!g) return s->err;
   {
     std::lock_guard<std::mutex> lk(s->mu);
     s->closing = true;
     s->cv_work.notify_all();
   }
   if (s->driver.joinable()) s->driver.join();  // every submitted query has finished (or the stream has failed)
-  pprhip_graph* g = s->g;
   g->stream_open = false;
   g->stream_obj = nullptr;
-  int rc = PPRHIP_OK;
+  s->g = nullptr;
   if (s->err != PPRHIP_OK) {
-    const std::string msg = s->errmsg;
     (void)hipSetDevice(g->device);
     free_batch(g);  // slots may hold half-pushed levels: the next batched call builds clean ones
-    set_error("pprhip_fora_stream_close: the stream had failed: %s", msg.c_str());
-    rc = s->err;
+  }
+  return s->err;
+}
+
+namespace pprhip {
+namespace detail {
+// pprhip_graph_destroy on a handle whose stream is still open: the driver thread uses the handle, so it ends first.  The
+// stream object is not freed here - its owner may still call pprhip_fora_stream_close on it (which then only frees it).
+void stream_detach(void* stream_obj) {
+  pprhip_stream* s = static_cast<pprhip_stream*>(stream_obj);
+  (void)stream_shutdown(s);
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (s->err == PPRHIP_OK) {
+    s->err = PPRHIP_ERR_STATE;
+    s->errmsg = "the stream's graph has been destroyed";
+  }
+  for (auto& kv : s->open) kv.second->done = true;
+  s->cv_done.notify_all();
+}
+}  // namespace detail
+}  // namespace pprhip
+
+int pprhip_fora_stream_close(pprhip_stream_t* s) {
+  if (!s) return PPRHIP_OK;
+  const bool attached = s->g != nullptr;
+  const int rc = stream_shutdown(s);
+  int out = PPRHIP_OK;
+  if (attached && rc != PPRHIP_OK) {
+    set_error("pprhip_fora_stream_close: the stream had failed: %s", s->errmsg.c_str());
+    out = rc;
   }
   delete s;
-  return rc;
+  return out;
 }

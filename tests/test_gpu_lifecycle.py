@@ -63,8 +63,9 @@ def test_handles_give_everything_back(pkg, rmat15, rmat12):
 
 
 def test_stream_left_open_is_closed_with_its_graph(pkg, rmat12):
-    """pprhip_graph_destroy on a handle whose query stream was never closed ends the driver thread first (the thread
-    uses the handle); the process goes on and a new handle works."""
+    """pprhip_graph_destroy on a handle whose query stream is still open ends the driver thread first (the thread uses the
+    handle) and leaves the stream object to its owner: later calls on it fail cleanly, its close frees it; a new handle
+    works."""
     live = np.nonzero(np.diff(rmat12.out_rp) > 0)[0][:8].astype(np.int32)
     g = pkg.Graph(rmat12, device=0)
     g.set_tuning(pkg.tuning_batch())
@@ -72,8 +73,10 @@ def test_stream_left_open_is_closed_with_its_graph(pkg, rmat12):
     tk = qs.submit(live, 5)
     qs.wait(tk)
     qs.submit(live, 6)  # still in flight or queued when the graph goes
-    qs.h = None         # (the wrapper forgets the stream: nobody closes it)
-    g.close()
+    g.close()           # ends the driver first; the stream object stays its owner's
+    with pytest.raises(pkg.PprhipError, match="graph has been destroyed"):
+        qs.submit(live, 7)
+    qs.close()          # only frees the object now
     with pkg.Graph(rmat12, device=0) as g2:
         est, _ = g2.fora_single_source(int(live[0]), 0.5, ALPHA, seed=3)
         assert abs(est.sum() - 1.0) < 1e-9
@@ -99,3 +102,29 @@ def test_kernel_timing_is_an_option(pkg, rmat15):
             assert pkg.set_kernel_timing(False) is True
         finally:
             pkg.set_kernel_timing(was)
+
+
+def test_stream_failure_reaches_every_submission(pkg, rmat12, monkeypatch):
+    """A failure inside the stream's driver thread (injected: PPRHIP_STREAM_FAULT_AT) ends every open submission and every
+    later call with the driver's error instead of leaving a waiter blocked; the close reports it, frees the batch state,
+    and the handle answers queries again afterwards - through a new stream too."""
+    live = np.nonzero(np.diff(rmat12.out_rp) > 0)[0][:40].astype(np.int32)
+    with pkg.Graph(rmat12, device=0) as g:
+        g.set_tuning(pkg.tuning_batch())
+        monkeypatch.setenv("PPRHIP_STREAM_FAULT_AT", "21")
+        qs = pkg.QueryStream(g, 0.5, ALPHA, k=4)
+        ids1, _, _, _ = qs.wait(qs.submit(live[:20], 5))  # queries 0 .. 19 of the stream
+        assert (ids1[:, 0] >= 0).all()
+        t2 = qs.submit(live[20:], 6)   # query 21 of the stream is never started: the stream fails with t2 in flight
+        with pytest.raises(pkg.PprhipError, match="injected failure"):
+            qs.wait(t2)
+        with pytest.raises(pkg.PprhipError, match="injected failure"):
+            qs.submit(live[:4], 7)
+        with pytest.raises(pkg.PprhipError, match="injected failure"):
+            qs.close()
+        monkeypatch.delenv("PPRHIP_STREAM_FAULT_AT")
+        _, ids, _, _, _, _ = g.fora_batch_single_source(live[:20], 0.5, ALPHA, seed=5, k=4)
+        assert np.array_equal(ids[:, 0], ids1[:, 0])
+        with pkg.QueryStream(g, 0.5, ALPHA, k=4) as qs2:
+            ids2, _, _, _ = qs2.wait(qs2.submit(live[:20], 5))
+        assert np.array_equal(ids2[:, 0], ids1[:, 0])
