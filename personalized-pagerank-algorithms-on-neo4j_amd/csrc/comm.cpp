@@ -186,6 +186,7 @@ bool fault_injected(int rank, const char* at) {
 
 struct pprhip_comm {
   pprhip_graph* g = nullptr;
+  int device = 0;  // (kept here: the communicator may be destroyed after its graph)
   int rank = 0, world = 1;
   ncclComm_t nccl = nullptr;
   LocalGroup* local = nullptr;  // not owned
@@ -576,6 +577,7 @@ int pprhip_comm_create(pprhip_graph_t* g, const void* id, int rank, int world, p
   std::unique_ptr<pprhip_comm> c(new (std::nothrow) pprhip_comm());
   if (!c) return PPRHIP_ERR_OOM;
   c->g = g;
+  c->device = g->device;
   c->rank = rank;
   c->world = world;
   // ncclCommInitRank is a rendezvous: it returns when all `world` ranks have called it.  It runs on a helper thread
@@ -621,7 +623,7 @@ int pprhip_comm_create(pprhip_graph_t* g, const void* id, int rank, int world, p
 void pprhip_comm_destroy(pprhip_comm_t* c) {
   if (!c) return;
   if (c->nccl) {  // (an aborted communicator has no handle left: comm_abort took it)
-    (void)hipSetDevice(c->g->device);
+    (void)hipSetDevice(c->device);
     (void)rccl()->CommDestroy(c->nccl);
   }
   delete c;

@@ -19,6 +19,7 @@
 // Device-resident result vectors of a batched call (pprhip_results_create): slot i = query i, internal vertex order.
 struct pprhip_results {
   pprhip_graph* g = nullptr;
+  int device = 0;  // (kept here: the store may be destroyed after its graph)
   int capacity = 0, count = 0;
   double* buf = nullptr;  // capacity x n
 };

@@ -1152,6 +1152,7 @@ int pprhip_results_create(pprhip_graph_t* g, int capacity, pprhip_results_t** re
   pprhip_results* r = new (std::nothrow) pprhip_results();
   if (!r) return PPRHIP_ERR_OOM;
   r->g = g;
+  r->device = g->device;
   r->capacity = capacity;
   const int rc = alloc_dev((void**)&r->buf, sizeof(double) * (size_t)capacity * g->n);
   if (rc != PPRHIP_OK) {
@@ -1164,7 +1165,7 @@ int pprhip_results_create(pprhip_graph_t* g, int capacity, pprhip_results_t** re
 
 void pprhip_results_destroy(pprhip_results_t* r) {
   if (!r) return;
-  (void)hipSetDevice(r->g->device);
+  (void)hipSetDevice(r->device);
   if (r->buf) (void)hipFree(r->buf);
   delete r;
 }

@@ -128,3 +128,17 @@ def test_stream_failure_reaches_every_submission(pkg, rmat12, monkeypatch):
         with pkg.QueryStream(g, 0.5, ALPHA, k=4) as qs2:
             ids2, _, _, _ = qs2.wait(qs2.submit(live[:20], 5))
         assert np.array_equal(ids2[:, 0], ids1[:, 0])
+
+
+def test_store_and_communicator_outlive_their_graph(pkg, rmat12):
+    """A result store or a communicator destroyed after the graph it was made for: their destructors need the device,
+    not the graph (an order a garbage-collected host - the JVM, Python - easily produces)."""
+    g = pkg.Graph(rmat12, device=0)
+    store = pkg.Results(g, 4)
+    comm = pkg.Comm(g, pkg.comm_unique_id(), 0, 1)
+    g.close()
+    store.close()
+    comm.close()
+    with pkg.Graph(rmat12, device=0) as g2:
+        est, _ = g2.fora_single_source(int(np.nonzero(np.diff(rmat12.out_rp) > 0)[0][0]), 0.5, ALPHA, seed=3)
+        assert abs(est.sum() - 1.0) < 1e-9
