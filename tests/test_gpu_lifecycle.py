@@ -58,6 +58,7 @@ def test_handles_give_everything_back(pkg, rmat15, rmat12):
             _one_life(pkg, rmat15, srcs)
         free1, _ = probe.device_memory()
         rss1 = _rss_mb()
+    print("four more lives: device %+.1f MB, host RSS %+.1f MB" % ((free0 - free1) / 1e6, rss1 - rss0))
     assert free0 - free1 <= 64 << 20, "device memory not returned: %.1f MB after four more lives" % ((free0 - free1) / 1e6)
     assert rss1 - rss0 <= 200.0, "host memory grew by %.0f MB over four lives" % (rss1 - rss0)
 
