@@ -488,3 +488,25 @@ def test_neo4j_store_reader_on_all_threads(pkg, tmp_path):
     open(rel, "wb").write(bytes(blob))
     with pytest.raises(pkg.PprhipError, match="relationship 31000 references a node outside"):
         pkg.HostCsr.from_neo4j_store(d)
+
+
+def test_lift_host_small_random_graphs(pkg, monkeypatch):
+    """Small random multigraphs - self loops, parallel edges, isolated nodes, nodes without in- or out-edges, no edge at
+    all - through the host lift with narrow slices, against the numpy restatement."""
+    rng = np.random.default_rng(23)
+    for trial in range(60):
+        n = int(rng.integers(1, 40))
+        m = int(rng.integers(0, 120)) if trial % 7 else 0
+        width = int(rng.integers(1, 12))
+        monkeypatch.setenv("PPRHIP_SLICE_IDS", str(width))
+        lo = int(rng.integers(0, n))
+        hi = int(rng.integers(lo, n)) + 1
+        src = rng.integers(lo, hi, m).astype(np.int32)   # (a range of sources only: the others have no out-edges)
+        dst = rng.integers(0, n, m).astype(np.int32)
+        h = pkg.HostCsr(n, src, dst)
+        got = pkg.lift_host(h, threads=1)
+        exp = _lift_expected(h, width=width)
+        for name, want in exp.items():
+            assert np.array_equal(got[name], want), (trial, name, n, m, width)
+        if "sl_ci" not in exp:
+            assert got["seg_row"].size == 0
