@@ -1335,6 +1335,7 @@ void stream_driver(pprhip_stream* s) {
     }
   };
   int rc = PPRHIP_OK;
+  try {  // (no exception leaves the driver thread: it would end the process)
   for (;;) {
     int busy = 0;
     if ((rc = advance_slots(P, runs, 0, kBatch, walking, side, next, done, &busy)) != PPRHIP_OK) break;
@@ -1351,6 +1352,10 @@ void stream_driver(pprhip_stream* s) {
     }
     bool finished = false;
     if ((rc = sweep_or_wait(P, runs, walking, busy, &finished)) != PPRHIP_OK) break;
+  }
+  } catch (const std::exception& ex) {
+    set_error("query stream: %s in the driver thread", ex.what());
+    rc = PPRHIP_ERR_OOM;
   }
   if (rc != PPRHIP_OK) stream_fail(s, rc);
   (void)hipStreamSynchronize(P->stream);
