@@ -592,8 +592,12 @@ class QueryStream:
     def close(self):
         if getattr(self, "h", None):
             h, self.h = self.h, None
-            self._out.clear()
-            _check(lib().pprhip_fora_stream_close(h))
+            # The close runs every submission that nobody waited for, and the driver writes their top-k blocks
+            # into the arrays of _out: those must outlive the call (pprhip_jni.cpp: close_stream has the same order).
+            try:
+                _check(lib().pprhip_fora_stream_close(h))
+            finally:
+                self._out.clear()
 
     def __enter__(self):
         return self

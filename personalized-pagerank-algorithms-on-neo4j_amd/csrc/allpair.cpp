@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <system_error>
 #include <thread>
 
 #include <sys/mman.h>
@@ -712,7 +713,17 @@ int ring_download(pprhip_graph* g, const void* d_src, void* h_dst, size_t bytes)
     }
   };
   std::thread th[kIxCopiers];
-  for (auto& t : th) t = std::thread(copier);
+  int n_th = 0;
+  try {
+    for (; n_th < kIxCopiers; ++n_th) th[n_th] = std::thread(copier);
+  } catch (const std::system_error&) {  // (no exception leaves the C ABI; the copiers that did start go on)
+  }
+  if (n_th == 0) {  // no thread to be had: the plain copy
+    for (int i = 0; i < kIxSlots; ++i) (void)hipEventDestroy(ev[i]);
+    PPRHIP_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g->stream));
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    return PPRHIP_OK;
+  }
   for (size_t c = 0; c < n_chunks; ++c) {
     const int slot = (int)(c % kIxSlots);
     {
@@ -737,7 +748,7 @@ int ring_download(pprhip_graph* g, const void* d_src, void* h_dst, size_t bytes)
     if (issued < n_chunks && !err) err = PPRHIP_ERR_HIP;
   }
   cv.notify_all();
-  for (auto& t : th) t.join();
+  for (int i = 0; i < n_th; ++i) th[i].join();
   (void)hipStreamSynchronize(g->stream);
   for (int i = 0; i < kIxSlots; ++i) (void)hipEventDestroy(ev[i]);
   if (err) set_error("index: download of the sorted entries failed");
@@ -769,9 +780,15 @@ int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long 
     *out = ix.release();
     return PPRHIP_OK;
   }
-  ix->offsets.resize((size_t)g->n + 1);
-  ix->targets.resize(R.entries);
-  ix->values.resize(R.entries);
+  try {
+    ix->offsets.resize((size_t)g->n + 1);
+    ix->targets.resize(R.entries);
+    ix->values.resize(R.entries);
+  } catch (const std::bad_alloc&) {  // (up to 12 bytes of HBM per entry must not stay behind)
+    set_error("index: no host memory for %llu entries", R.entries);
+    device_rows_free(&R);
+    return PPRHIP_ERR_OOM;
+  }
   int rc = ring_download(g, R.offsets, ix->offsets.data(), 8 * ((size_t)g->n + 1));
   if (rc == PPRHIP_OK) rc = ring_download(g, R.values, ix->values.data(), 8 * (size_t)R.entries);
   if (rc == PPRHIP_OK) rc = ring_download(g, R.targets, ix->targets.data(), 4 * (size_t)R.entries);
@@ -840,9 +857,14 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
   const auto t0 = std::chrono::steady_clock::now();
   // first-use work of the finalisation, beside the searches: the pinned ring the sorted entries are downloaded through
   std::thread pin;
-  if (!g->ix_stage) pin = std::thread([g] {
-    if (hipSetDevice(g->device) == hipSuccess) (void)ensure_ring(g);
-  });
+  if (!g->ix_stage) {
+    try {
+      pin = std::thread([g] {
+        if (hipSetDevice(g->device) == hipSuccess) (void)ensure_ring(g);
+      });
+    } catch (const std::system_error&) {  // (no helper thread: the download pins its ring when it gets there)
+    }
+  }
   // room for the entries a range of this size usually yields (a dozen per target at the thresholds the thesis uses):
   // the store then does not grow - allocate, copy, free - while the searches run
   if (t_end - t_begin >= (1u << 18)) (void)sink.reserve(g, 12ull * (unsigned long long)(t_end - t_begin));

@@ -41,10 +41,10 @@ thread_local KernelTimer* g_timer_cur = &g_timer_own;
 // Kernel arguments in device memory (the HIP runtime's HIP_FORCE_DEV_KERNARG switch, read when the runtime
 // initialises): a launch then costs the command processor a read of HBM instead of a read of host memory over PCIe.
 // The paths that are chains of short kernels gain 4-10 % (R-MAT 22: top-k one at a time 804 -> 880 queries/s, 16 in
-// flight 1 602 -> 1 692, one whole-graph query at a time 94.8 -> 98.5, headline 320 -> 323; tools/exp/r04_job_z.sh).
-// Set when the library is loaded, unless the process has decided otherwise; a host that initialises HIP before it
-// loads libpprhip.so (Python with torch imported first) sets the variable itself (bench.py, tests/conftest.py).
-__attribute__((constructor)) static void prefer_device_kernargs() { (void)setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+// flight 1 602 -> 1 692, one whole-graph query at a time 94.8 -> 98.5, headline 320 -> 323).  The library does NOT set
+// it (rounds 4's load-time setenv is gone: setenv inside a JVM that already runs threads races with their getenv, and
+// a library should not change the runtime for the process's other HIP users); the launchers do, before any thread or
+// HIP call exists: host/ppr_main.cpp, bench.py, tests/conftest.py, and the java launcher line of INTEGRATION.md.
 
 // One-time work per device: code objects loaded and kernel attributes set by the thread that lifts the
 // first graph onto the device, under a lock, so that the launch paths (which worker threads run

@@ -160,13 +160,21 @@ struct KernelTimer {
     recs.clear();
   }
   // room for k more intervals without a fold in between (callers that keep indices into `recs`)
+  // - in counting mode as well, where begin() folds at kMaxCounted records: a fold between reserve() and the use of
+  // an index would let the index name another record
+  static constexpr size_t kMaxCounted = 65536;
   void reserve(size_t k) {
+    if (off) return;
+    if (!kernel_timing_on()) {
+      if (recs.size() + k > kMaxCounted) fold();
+      return;
+    }
     if (used + 2 * k > kMaxEvents && hipStreamSynchronize(stream) == hipSuccess) fold();
   }
   void begin(int cls, uint64_t bytes) {
     if (off) return;
     if (!kernel_timing_on()) {
-      if (recs.size() >= 65536) fold();  // (counting needs no drained stream)
+      if (recs.size() >= kMaxCounted) fold();  // (counting needs no drained stream)
       recs.push_back({cls, kNoEvent, bytes});
       return;
     }

@@ -1357,9 +1357,12 @@ void stream_driver(pprhip_stream* s) {
     set_error("query stream: %s in the driver thread", ex.what());
     rc = PPRHIP_ERR_OOM;
   }
-  if (rc != PPRHIP_OK) stream_fail(s, rc);
+  // Drain before anybody is woken: a waiter that returns the error may free its result store or its output block at
+  // once, and copies or selections of other slots' queries can still be queued against those buffers.
   (void)hipStreamSynchronize(P->stream);
   if (P->walk_stream) (void)hipStreamSynchronize(P->walk_stream);
+  if (side && side != P->stream && side != P->walk_stream) (void)hipStreamSynchronize(side);
+  if (rc != PPRHIP_OK) stream_fail(s, rc);
   g_timer_cur = saved;
 }
 

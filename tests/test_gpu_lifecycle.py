@@ -83,6 +83,27 @@ def test_stream_left_open_is_closed_with_its_graph(pkg, rmat12):
         assert abs(est.sum() - 1.0) < 1e-9
 
 
+def test_stream_closed_with_a_submission_nobody_waited_for(pkg, rmat12):
+    """The close runs every queued submission to its end and the driver writes their top-k blocks: the output arrays of
+    a submission that was never waited for must live until the close has returned (QueryStream.close
+    dropped them first, and the driver then wrote into freed numpy memory).  The blocks are checked after the close."""
+    live = np.nonzero(np.diff(rmat12.out_rp) > 0)[0][:24].astype(np.int32)
+    with pkg.Graph(rmat12, device=0) as g:
+        g.set_tuning(pkg.tuning_batch())
+        _, want, _, _, _, _ = g.fora_batch_single_source(live, 0.5, ALPHA, seed=5, k=4)
+        qs = pkg.QueryStream(g, 0.5, ALPHA, k=4)
+        tk = qs.submit(live, 5)
+        held = qs._out[tk]  # what the library writes into; the test keeps a reference to look at it afterwards
+        qs.close()          # no wait: the close finishes the block
+        assert not qs._out
+        assert np.array_equal(held[0], want), "the block of an un-waited submission was not finished by the close"
+        with pkg.QueryStream(g, 0.5, ALPHA, k=4) as qs2:
+            for s in range(3):
+                qs2.submit(live, 5 + s)   # leaves the with-block with three blocks queued or in flight
+        est, _ = g.fora_single_source(int(live[0]), 0.5, ALPHA, seed=3)
+        assert abs(est.sum() - 1.0) < 1e-9
+
+
 def test_kernel_timing_is_an_option(pkg, rmat15):
     """pprhip_set_kernel_timing: by default a call only counts its groups of launches (class_launches, class_bytes) and
     records no events between its kernels; with the option on the same call also reports class times.  Results are the
