@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpprhip.so")
+# PPRHIP_LIB_PATH: another build of the SAME sources (the Makefile's sanitizer build, `make asan-test`); never a fallback
+LIB_PATH = os.environ.get("PPRHIP_LIB_PATH") or os.path.join(_HERE, "libpprhip.so")
 
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_IO, ERR_STATE = -1, -2, -3, -4, -5, -6

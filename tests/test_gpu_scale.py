@@ -163,23 +163,42 @@ def column_sample(host, n_hubs, n_ranked, n_random, seed, t_lo=0, t_hi=None):
            [int(x) for x in rng.integers(t_lo, t_hi, n_random)]
 
 
-def check_columns_against_oracle(orc, og, arrays, targets, thr, k, fifo_for=None):
+def check_columns_against_oracle(orc, og, arrays, targets, thr, k, fifo_for=None, workers=1):
     """Base_Whole_Graph.java:76-92 + the k rule (:112-163), column by column: the oracle's twin schedule to 1e-12 (same
     entries, same values), and the Java-faithful FIFO order under its bound (both orders leave every residue <= thr, so
-    two reserves of one pair differ by at most thr: Backward_Search.java:89)."""
+    two reserves of one pair differ by at most thr: Backward_Search.java:89).  workers > 1: the oracle's searches run on
+    that many host threads beforehand (ctypes calls release the GIL) and are kept as (ids, values) until they are
+    compared - at R-MAT 24 a dense column is 134 MB and a hub's search takes the CPU seconds."""
     from bench import index_column_check
     off, tg, vl = arrays
+    n = off.size - 1
     touched = {}
-
-    def sync_col(t):
-        p, r, _ = og.backward_push(t, A, thr, orc.SYNC)
-        touched[t] = int(((p > 0) | (r > 0)).sum())
-        return p
-
-    st = index_column_check(off, tg, vl, targets, sync_col, thr, k, tol=1e-12)
     fifo_for = targets if fifo_for is None else fifo_for
-    st_f = index_column_check(off, tg, vl, fifo_for, lambda t: og.backward_push(t, A, thr, orc.FIFO)[0], thr, k, tol=1e-12,
-                              slack=thr)
+
+    def sparse_col(job):
+        t, schedule = job
+        p, r, _ = og.backward_push(t, A, thr, schedule)
+        if schedule == orc.SYNC:
+            touched[t] = int(((p > 0) | (r > 0)).sum())
+        idx = np.nonzero(p)[0]
+        return (t, schedule), (idx, p[idx])
+
+    cache = {}
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        jobs = [(int(t), orc.SYNC) for t in targets] + [(int(t), orc.FIFO) for t in fifo_for]
+        with ThreadPoolExecutor(workers) as pool:
+            cache = dict(pool.map(sparse_col, jobs))
+
+    def column(t, schedule):
+        key = (int(t), schedule)
+        idx, val = cache.pop(key) if key in cache else sparse_col(key)[1]
+        col = np.zeros(n)
+        col[idx] = val
+        return col
+
+    st = index_column_check(off, tg, vl, targets, lambda t: column(t, orc.SYNC), thr, k, tol=1e-12)
+    st_f = index_column_check(off, tg, vl, fifo_for, lambda t: column(t, orc.FIFO), thr, k, tol=1e-12, slack=thr)
     assert st_f["max_abs_diff"] <= thr
     return st, st_f, touched
 
@@ -249,7 +268,7 @@ def test_sampled_walks_match_oracle(orc, rmat20, dev20):
 
 
 # ------------------------------------------------------------------ BASELINE.json's full sizes (configs #3-#5)
-def _full_size_checks(pkg, scale, n_batch):
+def _full_size_checks(pkg, scale, n_batch, more=None):
     """Size-independent properties at a benchmark size: the 36-bit packed (nodes | edges) counters, the uint32 edge
     offsets and the chunked sweep layout work on more than 2^26 edges; results conserve mass, meet the threshold,
     repeat, and the batched entry point equals the single-query one."""
@@ -292,6 +311,8 @@ def _full_size_checks(pkg, scale, n_batch):
         off, tg, vl = ix.arrays()
         assert np.all(vl >= 1e-3) and np.all((tg >= t0) & (tg < t0 + 2048)) and sta.pops >= 2048
         ix.close()
+        if more is not None:
+            more(host, g)
 
 
 @pytest.mark.timeout(900)
@@ -300,9 +321,35 @@ def test_full_size_rmat22(pkg):
 
 
 @pytest.mark.timeout(1500)
-def test_full_size_rmat24(pkg):
-    """config #5's graph (n = 16.7 M, m = 268 M)."""
-    _full_size_checks(pkg, 24, 3)
+def test_full_size_rmat24(pkg, orc):
+    """config #5's graph (n = 16.7 M, m = 268 M) - and config #5's own workload held to the oracle: the index of ALL
+    16.7 M targets (threshold 1e-3, k = 32, default settings: Base_Whole_Graph.java:76-92 and the k rule of :112-163),
+    32 of its columns against oracle backward searches (Backward_Search.java:38-100) - the 8 targets with the most
+    in-edges, 8 across the in-degree ranks, 16 at random: the twin schedule to 1e-12 with exact membership both ways,
+    the Java-faithful FIFO order under the bound the two orders share (:84-89), entries missing from a row accepted
+    only where the k rule cut them."""
+    def all_pair_all_targets(host, g):
+        batch = g.RELEASE_BATCH
+        g.release(batch)   # (the batched queries' workspaces are not needed beside All-Pair's 77 GB)
+        ix, st = g.all_pair_backward(A, 1e-3, 32)
+        arrays = [x.copy() for x in ix.arrays()]
+        ix.close()
+        g.release(g.RELEASE_ALL_PAIR)
+        off, tg, vl = arrays
+        assert off[-1] == len(tg) > host.n and np.all(vl >= 1e-3) and st.pops >= host.n
+        assert st.dense_nodes == 0                          # nothing was left for tier 3
+        og = to_oracle(orc, host)
+        targets = column_sample(host, 8, 8, 16, seed=24)
+        assert len(set(targets)) >= 30
+        c, cf, touched = check_columns_against_oracle(orc, og, arrays, targets, 1e-3, 32, workers=8)
+        sizes = np.array(list(touched.values()))
+        print("R-MAT 24 All-Pair: %d entries, %d columns checked (%d entries, %d cut by the k rule), searches touch %d .. %d nodes,"
+              " max |diff| twin %.2e, FIFO %.2e" % (len(tg), c["targets"], c["entries_checked"], c["entries_cut_by_k_rule"],
+                                                   sizes.min(), sizes.max(), c["max_abs_diff"], cf["max_abs_diff"]))
+        assert sizes.max() > (1 << 20) and (sizes <= 1536).sum() >= 4   # both ends of the tiers are in the sample
+        assert c["entries_checked"] > 50000 and c["entries_cut_by_k_rule"] > 0
+
+    _full_size_checks(pkg, 24, 3, more=all_pair_all_targets)
 
 
 @pytest.mark.timeout(1200)
@@ -396,3 +443,52 @@ def test_full_size_rmat22_all_pair_columns_against_oracle(pkg, orc):
     c, cf, touched = check_columns_against_oracle(orc, og, arrays, targets, 1e-3, 32, fifo_for=targets[:4] + targets[24:40])
     assert max(touched.values()) > (1 << 20)              # a search beyond the per-workgroup lists was among them
     assert c["entries_checked"] > 100000 and c["entries_cut_by_k_rule"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_full_size_rmat22_fifty_query_call_and_stream(pkg, orc):
+    """Config #4's call shape at its own size: ONE call of 50 sources (PPR.java:179's default; the loop of
+    Gen_Util.java:208-232) through pprhip_fora_batch_single_source_resident - three full rounds of 16 slots and the two
+    leftover queries that run singly - and the same 50 sources as one submission of a query stream.  Three of the 50
+    (the first, leftover query 49, one from the middle) are held to the CPU power method (Power_Method.java:44-101) under
+    FORA's (eps, delta) bound; the stream must equal the synchronous call: same top-32 lists, vectors to 1e-12."""
+    from concurrent.futures import ThreadPoolExecutor
+    host = pkg.HostCsr.rmat(22, 16, seed=1)
+    og = to_oracle(orc, host)
+    srcs = np.array(live_sources(host, 50, 404), dtype=np.int32)
+    held = [0, 23, 49]
+    with ThreadPoolExecutor(3) as pool:
+        exact_f = [pool.submit(og.power_method, int(srcs[i]), A, 100) for i in held]
+        with pkg.Graph(host) as g:
+            g.set_tuning(pkg.tuning_batch())
+            sync_store, stream_store = pkg.Results(g, 50), pkg.Results(g, 50)
+            try:
+                _, ids, vals, nsel, pq, st = g.fora_batch_single_source(srcs, 0.5, A, seed=9, k=32, keep=sync_store,
+                                                                        per_query=True)
+                assert st.class_launches[5] > 0 and all(p.walks > 0 or p.omega * p.rsum < 1.0 for p in pq)
+                with pkg.QueryStream(g, 0.5, A, k=32) as qs:
+                    ids_s, vals_s, nsel_s, st_s = qs.wait(qs.submit(srcs, 9, keep=stream_store))
+                assert np.array_equal(nsel, nsel_s) and np.array_equal(ids, ids_s)
+                assert np.max(np.abs(vals - vals_s)) <= 1e-12 and st_s.walks == st.walks
+                for i in range(50):
+                    s_sync, s_stream = sync_store.sum(i), stream_store.sum(i)
+                    lost = pq[i].rsum if pq[i].walks == 0 else 0.0   # (floor(omega rsum) = 0 walks leave the residues)
+                    assert abs(s_sync + lost - 1.0) < 1e-9 and abs(s_stream - s_sync) < 1e-11
+                    m = min(int(nsel[i]), 32)
+                    assert m == 32 and np.all(np.diff(vals[i][:m]) <= 0)
+                for i, fut in zip(held, exact_f):
+                    exact = fut.result()
+                    v_sync, v_stream = sync_store.fetch(i), stream_store.fetch(i)
+                    assert np.max(np.abs(v_sync - v_stream)) <= 1e-12
+                    assert np.array_equal(v_sync[ids[i]], vals[i])
+                    big = exact > 1.0 / host.n                      # Fora_Whole_Graph's guarantee: pi > delta = 1/n
+                    err = np.abs(v_sync - exact)
+                    assert np.all(err[big] <= 0.5 * exact[big]), "query %d (source %d) leaves FORA's bound" % (i, srcs[i])
+                    order = np.argsort(-exact, kind="stable")[:64]
+                    tol = 2.0 * err[order].max()
+                    for v in set(order[:32].tolist()) ^ set(ids[i].tolist()):
+                        assert abs(exact[v] - exact[order[31]]) <= tol
+            finally:
+                sync_store.close()
+                stream_store.close()
+                g.set_tuning(pkg.tuning_default())
