@@ -612,6 +612,7 @@ void free_workspace(pprhip_graph* g) {
 }
 
 void free_batch(pprhip_graph* P);
+static int build_part_layout_device(pprhip_graph* P);
 
 // Batch slots and the interleaved dense-level arrays, created on the first batched call.
 int build_batch(pprhip_graph* P) {
@@ -639,6 +640,7 @@ int build_batch(pprhip_graph* P) {
   PPRHIP_TRY(alloc_dev((void**)&P->blk_dead8, sizeof(double) * kBatch * kApplyBlocks8));
   PPRHIP_TRY(alloc_dev((void**)&P->blk_ndead8, sizeof(uint32_t) * kBatch * kApplyBlocks8));
   P->c8cur = 0;
+  PPRHIP_TRY(build_part_layout_device(P));
   for (int s = 0; s < kBatch; ++s) {
     pprhip_graph* S = new (std::nothrow) pprhip_graph();
     if (!S) return PPRHIP_ERR_OOM;
@@ -677,6 +679,67 @@ int build_batch(pprhip_graph* P) {
   return PPRHIP_OK;
 }
 
+// Source-partitioned copy of the in-CSR for the batched forward sweep (engine_internal.hpp: HostPartLayout).  The
+// internal-order column indices live on the device only (the lift's host arrays are gone by now): they come back once,
+// the host builds the copy on all its threads, and it goes up again - R-MAT 22: 0.27 GB down, ~0.1 s of host work,
+// 0.3 GB up, once per handle (the copy stays when the batch workspaces are released).
+// PPRHIP_SWEEP_PARTS=0 / 1 switches it off / on for any size (tests run small graphs both ways); by default graphs
+// from 2^22 edges on use it - below that the whole contribution array fits every L2 anyway.
+static int build_part_layout_device(pprhip_graph* P) {
+  const char* e = getenv("PPRHIP_SWEEP_PARTS");
+  const bool want = e ? e[0] == '1' : false;  // (off by default until it is the faster layout: profiles/r05_pmc_sweep_first.txt)
+  if (!want || P->m == 0 || P->n_nz == 0) return PPRHIP_OK;
+  if (!P->pl) {
+    HostPartLayout H;
+    std::unique_ptr<PartLayout> L(new (std::nothrow) PartLayout());
+    if (!L) return PPRHIP_ERR_OOM;
+    try {
+      RawVec<int32_t> ci((size_t)P->m);
+      PPRHIP_CHECK_HIP(hipMemcpy(ci.data(), P->in_ci, sizeof(int32_t) * (size_t)P->m, hipMemcpyDeviceToHost));
+      PPRHIP_TRY(build_part_layout(P->n, P->m, P->h_in_rp.data(), ci.data(), P->h_nz_rows.data(), P->n_nz, 0, H));
+      L->h_tile_edge0 = std::move(H.tile_edge0);
+    } catch (const std::bad_alloc&) {
+      set_error("source-partitioned sweep layout: out of host memory");
+      return PPRHIP_ERR_OOM;
+    }
+    auto up = [&](void** d, const void* h, size_t bytes) -> int {
+      PPRHIP_TRY(alloc_dev(d, bytes));
+      PPRHIP_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+      return PPRHIP_OK;
+    };
+    int rc = PPRHIP_OK;
+    if ((rc = up((void**)&L->ci, H.ci.data(), sizeof(int32_t) * H.ci.size())) ||
+        (rc = up((void**)&L->flags, H.flags.data(), H.flags.size())) ||
+        (rc = up((void**)&L->chunk_starts, H.chunk_starts.data(), sizeof(uint32_t) * H.chunk_starts.size())) ||
+        (rc = up((void**)&L->tile_seg0, H.tile_seg0.data(), sizeof(uint32_t) * H.tile_seg0.size())) ||
+        (rc = up((void**)&L->tile_mask, H.tile_mask.data(), sizeof(unsigned long long) * std::max<size_t>(1, H.tile_mask.size()))) ||
+        (rc = up((void**)&L->tile_cross, H.tile_cross.data(), sizeof(unsigned long long) * std::max<size_t>(1, H.tile_cross.size())))) {
+      void* ptrs[] = {L->ci, L->flags, L->chunk_starts, L->tile_seg0, L->tile_mask, L->tile_cross};
+      for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+      return rc;
+    }
+    std::memcpy(L->chunk_base, H.chunk_base, sizeof L->chunk_base);
+    std::memcpy(L->seg_base, H.seg_base, sizeof L->seg_base);
+    L->n_tiles = H.n_tiles;
+    L->n_seg = H.seg_base[kParts];
+    P->pl = L.release();
+  }
+  const size_t bytes = sizeof(double) * ((size_t)P->pl->n_seg + 1) * kBatch;
+  PPRHIP_TRY(alloc_dev((void**)&P->part_acc, bytes));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_acc, 0, bytes, P->stream));
+  return PPRHIP_OK;
+}
+
+void free_part_layout(pprhip_graph* P) {
+  if (!P->pl) return;
+  void* ptrs[] = {P->pl->ci, P->pl->flags, P->pl->chunk_starts, P->pl->tile_seg0, P->pl->tile_mask, P->pl->tile_cross};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete P->pl;
+  P->pl = nullptr;
+}
+
 int ensure_batch(pprhip_graph* P) {
   if (!P->slots.empty()) return PPRHIP_OK;
   const int rc = build_batch(P);
@@ -706,7 +769,8 @@ void free_batch(pprhip_graph* P) {
   P->ktimer.destroy();
   P->slots.clear();
   void* ptrs[] = {P->c8[0], P->c8[1], P->acc8, P->prep_bits, P->d_slot_args, P->sweep_out, P->blk_pack8, P->blk_dead8,
-                  P->blk_ndead8};
+                  P->blk_ndead8, P->part_acc};
+  P->part_acc = nullptr;
   if (P->h_sweep_out) (void)hipHostFree(P->h_sweep_out);
   P->sweep_out = P->h_sweep_out = nullptr;
   P->prep_bits = nullptr;
@@ -1434,6 +1498,7 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   free_batch(g);
+  free_part_layout(g);
   void* ptrs[] = {g->walk_rec, g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags,
                   g->chunk_starts, g->nz_rows, g->zin_rows, g->cross_bits, g->start_flags_o, g->chunk_starts_o,
                   g->nz_rows_o, g->z_rows_o, g->cross_bits_o};

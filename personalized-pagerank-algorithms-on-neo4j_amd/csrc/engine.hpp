@@ -95,6 +95,25 @@ struct SlicedLayout {
   int plan_B = -1;
 };
 
+// The source-partitioned copy of the in-CSR on the device (engine_internal.hpp: HostPartLayout; batched forward sweep).
+struct PartLayout {
+  int32_t* ci = nullptr;
+  uint8_t* flags = nullptr;
+  uint32_t* chunk_starts = nullptr;
+  uint32_t* tile_seg0 = nullptr;             // [kParts][n_tiles + 1]
+  unsigned long long* tile_mask = nullptr;   // [kParts][n_tiles]
+  unsigned long long* tile_cross = nullptr;  // [kParts][n_tiles]
+  uint32_t chunk_base[kParts + 1] = {0}, seg_base[kParts + 1] = {0};
+  uint32_t n_tiles = 0, n_seg = 0;
+  std::vector<unsigned long long> h_tile_edge0;  // host: [kParts][n_tiles + 1], the Gauss-Seidel blocks' edge windows
+};
+// what one launch of the partitioned edge kernel walks: per partition the chunks [c_lo, c_hi) and, inside their first
+// and last chunk, the edges [e_lo, e_hi) (the rows of one Gauss-Seidel block)
+struct PartWindows {
+  uint32_t c_lo[kParts], c_hi[kParts];
+  unsigned long long e_lo[kParts], e_hi[kParts];
+};
+
 enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
 
 struct SelRec {  // one candidate of a top-k selection / one entry >= threshold of a backward search
@@ -331,6 +350,8 @@ struct pprhip_graph {
   pprhip::detail::FetchPipe* fetch = nullptr;  // delivery of batched queries' vectors to host memory (engine_internal.hpp)
   double* c8[2] = {nullptr, nullptr};
   int c8cur = 0;
+  pprhip::PartLayout* pl = nullptr;  // source-partitioned copy of the in-CSR (forward batched sweeps), with the batch state
+  double* part_acc = nullptr;        // [segments + 1][kBatch] partial row sums of its (row, partition) segments
   double* acc8 = nullptr;      // [row ordinal][kBatch] row sums
   int acc8_dir = 0;            // layout the row sums were last written in (0 forward, 1 backward)
   int32_t* zin_rows = nullptr;  // rows without in-edges

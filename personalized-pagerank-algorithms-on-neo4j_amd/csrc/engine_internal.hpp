@@ -170,6 +170,33 @@ struct HostLift {
   std::vector<uint8_t> sl_flags;
   std::vector<uint32_t> sl_chunk_starts, seg_row, seg_off;
 };
+// Source-partitioned copy of the in-CSR for the batched forward sweep (round 5).  Why: a batched gather moves one
+// 128-byte line c8[u][0..15] per in-edge, and the sweep is bound by the lines that leave L2 (46 M of 67 M per sweep on
+// R-MAT 22, 52-55 G/s); every XCD has an L2 of its own and all eight held the same hottest 32 K lines.  Here the edges
+// are grouped by part_of(source): partition p's edges (rows ascending, a row's edges in their CSR order) form a chunked
+// layout of their own - a "row" of it is a SEGMENT (row, p) - and workgroup b of the edge kernel walks partition b % 8,
+// i.e. the workgroups of XCD x only ever gather lines of partition x (workgroups are dealt to the XCDs round-robin:
+// tools/micro/xcd_affine_rate.hip reads XCC_ID), so eight L2s hold eight different hot sets.  A segment's sum is a
+// partial row sum: it is stored to part_acc[segment ordinal] (a stream per partition) and the apply kernel adds a
+// row's up to eight partials, found through per-tile (64 rows) masks and first-segment ordinals.
+// All partitions are concatenated: partition p owns the chunks [chunk_base[p], chunk_base[p+1]) and the segment ordinals
+// [seg_base[p], seg_base[p+1]); chunk_starts holds GLOBAL ordinals, so the kernel indexes part_acc directly.
+struct HostPartLayout {
+  uint32_t n_nz = 0, n_tiles = 0;    // rows with in-edges, tiles of kTileRows of them
+  uint32_t chunk_base[kParts + 1] = {0};
+  uint32_t seg_base[kParts + 1] = {0};
+  RawVec<int32_t> ci;                        // (chunk_base[kParts] + 1) * 512 source ids, padding zero
+  std::vector<uint8_t> flags;                // bit e: edge e of the copy is the first of its segment
+  std::vector<uint32_t> chunk_starts;        // [chunks + 1]: segments that start before each chunk (global ordinals)
+  std::vector<uint32_t> tile_seg0;           // [kParts][n_tiles + 1]: first segment of p among the rows >= 64 t
+  std::vector<unsigned long long> tile_mask;   // [kParts][n_tiles]: rows of tile t that have a segment in p
+  std::vector<unsigned long long> tile_cross;  // [kParts][n_tiles]: ... whose segment is summed with atomics
+  std::vector<unsigned long long> tile_edge0;  // [kParts][n_tiles + 1]: first edge of p among the rows >= 64 t
+};
+// in_rp / in_ci: the internal-order in-CSR; nz_rows: its non-empty rows, ascending (row ordinal -> node)
+int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,
+                      uint32_t n_nz, unsigned threads, HostPartLayout& L);
+
 // threads: 0 = what the process may use (host_threads)
 int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out_ci, const uint32_t* in_rp,
               const int32_t* in_ci, unsigned threads, HostLift& H);

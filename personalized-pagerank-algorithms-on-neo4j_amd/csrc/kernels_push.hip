@@ -604,8 +604,9 @@ __device__ __forceinline__ ChunkRegsB<G> load_chunk_b(const int32_t* __restrict_
   return r;
 }
 
-// 8 edges of the group: the indices sit in lane JB of the group
-template <bool HOT, int G, int JB>
+// 8 edges of the group: the indices sit in lane JB of the group.  PART: the launch walks one partition of the
+// source-partitioned copy (PartLayout): its LDS table holds the hottest lines of that partition, at part_local(id).
+template <bool HOT, int G, int JB, bool PART>
 __device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const double* __restrict__ cB,
                                               const double* s_hot, uint32_t n_hot, int s, bool tail,
                                               unsigned long long e_first, unsigned long long e_lo,
@@ -622,7 +623,7 @@ __device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const do
     for (int i = 0; i < 8; ++i) gl[i] = cB[(size_t)(v[i] < n_hot ? 0u : v[i]) * G + s];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const double hv = s_hot[(v[i] < n_hot ? v[i] : 0u) * G + s];
+      const double hv = s_hot[(v[i] < n_hot ? (PART ? part_local(v[i]) : v[i]) : 0u) * G + s];
       val[i] = v[i] < n_hot ? hv : gl[i];
     }
   } else {
@@ -648,39 +649,55 @@ __device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const do
   }
 }
 
-template <bool HOT, int G, int JB>
+template <bool HOT, int G, int JB, bool PART>
 struct EdgeBlocks {
   static __device__ __forceinline__ void run(const ChunkRegsB<G>& cur, const double* __restrict__ cB,
                                              const double* s_hot, uint32_t n_hot, int s, bool tail,
                                              unsigned long long e_first, unsigned long long e_lo,
                                              unsigned long long e_hi, uint32_t before,
                                              double* __restrict__ accB, double& seg, double& first_seg, uint32_t& k) {
-    EdgeBlocks<HOT, G, JB - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
-    edges_b_block<HOT, G, JB>(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
+    EdgeBlocks<HOT, G, JB - 1, PART>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
+    edges_b_block<HOT, G, JB, PART>(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
   }
 };
-template <bool HOT, int G>
-struct EdgeBlocks<HOT, G, -1> {
+template <bool HOT, int G, bool PART>
+struct EdgeBlocks<HOT, G, -1, PART> {
   static __device__ __forceinline__ void run(const ChunkRegsB<G>&, const double*, const double*, uint32_t, int, bool,
                                              unsigned long long, unsigned long long, unsigned long long, uint32_t,
                                              double*, double&, double&, uint32_t&) {}
 };
 
-// G = queries per sweep = lanes per edge; the wave's 64 / G lane groups walk 8 * G edges each
-template <bool HOT, int G>
+// G = queries per sweep = lanes per edge; the wave's 64 / G lane groups walk 8 * G edges each.
+// PART (forward sweeps of graphs that have a PartLayout): the arrays are the source-partitioned copy, workgroup b walks
+// partition b % kParts - workgroups are dealt to the XCDs round-robin (tools/micro/xcd_affine_rate.hip reads XCC_ID:
+// 4096 of 4096), so the workgroups of one XCD only ever gather contribution lines of one partition and the eight L2s
+// hold eight different hot sets (placement decides the speed, never the result).  A "row" of the copy is a segment
+// (row, partition): accB is the partial-sum array, indexed by the global segment ordinals chunk_starts holds.  n_hot
+// is the bound of the hot ids (8 x the table's lines: every partition keeps the hottest lines of its own).
+template <bool HOT, int G, bool PART>
 __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restrict__ in_ci,
                                                          const unsigned long long* __restrict__ flags64,
                                                          const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
                                                          unsigned long long m, const double* __restrict__ cB,
                                                          double* __restrict__ accB, uint32_t n_hot, uint32_t c_lo,
-                                                         unsigned long long e_lo, unsigned long long e_hi) {
+                                                         unsigned long long e_lo, unsigned long long e_hi, uint32_t n,
+                                                         PartWindows W) {
   // one block of a sweep: chunks [c_lo, n_chunks) holding the in-edges [e_lo, e_hi) (see k_dense_edges)
   extern __shared__ __attribute__((aligned(16))) double s_hot[];
   const int lane = lane_id();
   const int grp = lane / G, s = lane & (G - 1);
   const uint32_t waves_per_block = blockDim.x >> 6;
-  const uint32_t stride = gridDim.x * waves_per_block;
+  uint32_t stride = gridDim.x * waves_per_block;
   uint32_t c = c_lo + blockIdx.x * waves_per_block + (uint32_t)wave_id();
+  const uint32_t part = PART ? blockIdx.x % (uint32_t)kParts : 0u;
+  if (PART) {
+    const uint32_t rank = blockIdx.x / (uint32_t)kParts, wgs = gridDim.x / (uint32_t)kParts;
+    stride = wgs * waves_per_block;
+    c = W.c_lo[part] + rank * waves_per_block + (uint32_t)wave_id();
+    n_chunks = W.c_hi[part];
+    e_lo = W.e_lo[part];
+    e_hi = W.e_hi[part];
+  }
   ChunkRegsB<G> cur;
   if (c < n_chunks) cur = load_chunk_b<G>(in_ci, flags64, c, lane);
   if (HOT) {
@@ -688,12 +705,17 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const uint32_t i = threadIdx.x + j * 1024u;
-      t[j] = i < n_hot * G ? cB[i] : 0.0;
+      if (PART) {
+        const uint32_t id = part_global(i / G, part);  // line i / G of this partition's table
+        t[j] = id < n_hot && id < n ? cB[(size_t)id * G + (i % G)] : 0.0;
+      } else {
+        t[j] = i < n_hot * G ? cB[i] : 0.0;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const uint32_t i = threadIdx.x + j * 1024u;
-      if (i < n_hot * G) s_hot[i] = t[j];
+      if (PART || i < n_hot * G) s_hot[i] = t[j];
     }
     __syncthreads();
   }
@@ -712,7 +734,7 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
     const bool tail = c_e0 < e_lo || c_e0 + kChunkEdges > e_hi;  // first / last chunk of the block: edges outside count 0
     double seg = 0.0, first_seg = 0.0;
     uint32_t k = 0;
-    EdgeBlocks<HOT, G, G - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
+    EdgeBlocks<HOT, G, G - 1, PART>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
     // segmented scan over the lane groups: S(g) = tail(g) + (group g holds a row start ? 0 : S(g-1))
     const bool h = k != 0;
     double S = seg;
@@ -869,6 +891,10 @@ constexpr int kApplyGroups = 2;  // tiles of kApplyRows rows a workgroup carries
 constexpr int kApplyThreads = 512;  // 8 waves, 2 slots each: few enough slot arguments to stay in SGPRs
 constexpr int kSlotsPerWave = kBatch / (kApplyThreads / 64);
 
+// PART: the row sums arrive as partial sums of the row's (row, partition) segments (PartLayout): tile t of partition p
+// holds the segments tile_seg0[p][t] ... in row order for the rows of tile_mask[p][t]; up to kParts lines per row are
+// added here, and the segments summed with atomics (tile_cross) are cleared as they are read.
+template <bool PART>
 __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
                                                             const int32_t* __restrict__ zin_rows, uint32_t n_zin,
                                                             double* __restrict__ acc8,
@@ -883,7 +909,11 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
                                                             unsigned long long* __restrict__ blk_pack8,
                                                             double* __restrict__ blk_dead8,
                                                             uint32_t* __restrict__ blk_ndead8, uint32_t part_base,
-                                                            uint32_t part_stride) {
+                                                            uint32_t part_stride, double* __restrict__ part_acc,
+                                                            const uint32_t* __restrict__ tile_seg0,
+                                                            const unsigned long long* __restrict__ tile_mask,
+                                                            const unsigned long long* __restrict__ tile_cross,
+                                                            uint32_t n_tiles_nz, uint32_t n_seg) {
   // tiles [tile_lo, tile_hi) of one block of the sweep.  gs_mask: slots whose state writes the current array in place
   // (entry / in-place / flush, engine.hpp: GsState); entry_mask: those of them that add to what it holds.
   __shared__ double tile[kApplyGroups][kApplyRows][kBatch + 1];
@@ -915,6 +945,41 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
       const uint32_t tl = tl0 + g;
       const bool in = tl < tile_hi;
       const uint32_t row0 = tl * kApplyRows;
+      if (PART) {
+        const bool have = in && tl < n_tiles_nz;  // (the tiles behind the rows with in-edges hold no sums)
+        unsigned long long mk[kParts], cr[kParts];
+        uint32_t s0[kParts];
+#pragma unroll
+        for (int p = 0; p < kParts; ++p) {
+          mk[p] = have ? tile_mask[(size_t)p * n_tiles_nz + tl] : 0ull;
+          cr[p] = have ? tile_cross[(size_t)p * n_tiles_nz + tl] : 0ull;
+          s0[p] = have ? tile_seg0[(size_t)p * (n_tiles_nz + 1) + tl] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
+          const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
+          const uint32_t r = idx / kBatch, s = idx % kBatch;
+          // all of a row's partial lines are requested together: rows without a segment in a partition read the
+          // all-zero line behind the last segment instead of branching around the load
+          double x[kParts];
+          size_t at[kParts];
+#pragma unroll
+          for (int p = 0; p < kParts; ++p) {
+            const bool has = (mk[p] >> r) & 1ull;
+            const uint32_t ord = has ? s0[p] + (uint32_t)__popcll(mk[p] & ((1ull << r) - 1ull)) : n_seg;
+            at[p] = (size_t)ord * kBatch + s;
+            x[p] = __builtin_nontemporal_load(&part_acc[at[p]]);
+          }
+          double v = 0.0;
+#pragma unroll
+          for (int p = 0; p < kParts; ++p) {
+            v += x[p];
+            if (x[p] != 0.0 && ((cr[p] >> r) & 1ull)) part_acc[at[p]] = 0.0;
+          }
+          tile[g][r][s] = v;
+        }
+        continue;
+      }
       // rows inside one 512-edge chunk are rewritten by plain stores every sweep; only the rows that
       // cross a chunk boundary are summed with atomics and have to be cleared for the next sweep
       const unsigned long long cw = in ? cross_bits[tl] : 0ull;
@@ -1501,15 +1566,49 @@ static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8
   const uint32_t c_hi = (uint32_t)((B.e_hi + kChunkEdges - 1) / kChunkEdges);
   const uint32_t want = (c_hi - c_lo + 15) / 16;
   const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(start_flags);
+  const PartWindows none{};
   if (n_hot) {
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
-    k_dense_edges_b<true, G><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * G, g->stream>>>(
-        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, n_hot, c_lo, B.e_lo, B.e_hi);
+    k_dense_edges_b<true, G, false><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * G, g->stream>>>(
+        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, n_hot, c_lo, B.e_lo, B.e_hi, g->n, none);
   } else {
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
-    k_dense_edges_b<false, G><<<dim3(grid), dim3(1024), 0, g->stream>>>(
-        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, 0u, c_lo, B.e_lo, B.e_hi);
+    k_dense_edges_b<false, G, false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
+        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, 0u, c_lo, B.e_lo, B.e_hi, g->n, none);
   }
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+// the same block over the source-partitioned copy: one launch, workgroup b on partition b % kParts
+template <int G>
+static int launch_dense_edges_part(pprhip_graph* g, const double* cB, const GsBlock& B) {
+  const PartLayout& L = *g->pl;
+  const uint32_t NT = L.n_tiles;
+  // block boundaries are multiples of 256 row ordinals (or the end of the rows): whole tiles
+  const uint32_t t_lo = B.j_lo / kTileRows, t_hi = std::min<uint32_t>(NT, (B.j_hi + kTileRows - 1) / kTileRows);
+  PartWindows W{};
+  uint32_t most = 0;
+  for (int p = 0; p < kParts; ++p) {
+    const unsigned long long e_lo = L.h_tile_edge0[(size_t)p * (NT + 1) + t_lo];
+    const unsigned long long e_hi = L.h_tile_edge0[(size_t)p * (NT + 1) + t_hi];
+    W.e_lo[p] = e_lo;
+    W.e_hi[p] = e_hi;
+    W.c_lo[p] = (uint32_t)(e_lo / kChunkEdges);
+    W.c_hi[p] = e_hi > e_lo ? (uint32_t)((e_hi + kChunkEdges - 1) / kChunkEdges) : W.c_lo[p];
+    most = std::max(most, W.c_hi[p] - W.c_lo[p]);
+  }
+  if (!most) return PPRHIP_OK;
+  const uint32_t lines = (uint32_t)(kHotBytes / (8 * G));                       // per partition
+  const uint32_t n_hot = g->relabeled ? lines * (uint32_t)kParts : 0u;          // bound of the hot ids
+  const uint32_t per_part = std::max(1u, std::min<uint32_t>((most + 15) / 16, (uint32_t)g->n_cus / kParts));
+  const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(L.flags);
+  if (n_hot)
+    k_dense_edges_b<true, G, true><<<dim3(per_part * kParts), dim3(1024), kHotBytes, g->stream>>>(
+        L.ci, flags64, L.chunk_starts, 0u, (unsigned long long)g->m, cB, g->part_acc, n_hot, 0u, 0ull, 0ull, g->n, W);
+  else
+    k_dense_edges_b<false, G, true><<<dim3(per_part * kParts), dim3(1024), 0, g->stream>>>(
+        L.ci, flags64, L.chunk_starts, 0u, (unsigned long long)g->m, cB, g->part_acc, 0u, 0u, 0ull, 0ull, g->n, W);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -1537,13 +1636,15 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_bloc
   const uint32_t n_rows = n_nz + n_z;
   const uint32_t n_tiles = (n_rows + kApplyRows - 1) / kApplyRows;
   const GsBlock whole{0u, n_nz, 0ull, (unsigned long long)P->m};
+  const bool part = !backward && P->pl && P->part_acc;  // forward sweeps walk the source-partitioned copy
   const bool cut = gs_mask && gs_blocks && n_gs_blocks > 1 && !backward;
   const GsBlock* blocks = cut ? gs_blocks : &whole;
   const int nb = cut ? n_gs_blocks : 1;
   uint32_t part_base = 0;
   for (int b = 0; b < nb; ++b) {
     const GsBlock& B = blocks[b];
-    PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8, B));
+    if (part) PPRHIP_TRY(launch_dense_edges_part<kBatch>(P, P->c8[P->c8cur], B));
+    else PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8, B));
     // block boundaries are multiples of 256 row ordinals, so tiles never straddle; the rows without in-edges
     // follow the last block.  The last block's rows are read by nobody again in this sweep (the next sweep reads the
     // other array), so only the blocks before it write the current array in place.
@@ -1552,10 +1653,17 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_bloc
     if (t_hi <= t_lo) continue;
     const uint32_t quota = kApplyBlocks8 / (uint32_t)nb;
     const uint32_t grid = std::max(1u, std::min((t_hi - t_lo + kApplyGroups - 1) / kApplyGroups, quota));
-    k_dense_apply_batch<<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
-        nz, n_nz, zr, n_z, P->acc8, P->out_rp, backward ? P->in_rp : nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo,
-        t_hi, b == nb - 1 ? 0u : gs_mask, b == nb - 1 ? 0u : entry_mask, P->d_slot_args, cross, P->prep_bits, P->blk_pack8, P->blk_dead8, P->blk_ndead8,
-        part_base, kApplyBlocks8);
+    if (part)
+      k_dense_apply_batch<true><<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
+          nz, n_nz, zr, n_z, P->acc8, P->out_rp, nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo, t_hi,
+          b == nb - 1 ? 0u : gs_mask, b == nb - 1 ? 0u : entry_mask, P->d_slot_args, cross, P->prep_bits, P->blk_pack8,
+          P->blk_dead8, P->blk_ndead8, part_base, kApplyBlocks8, P->part_acc, P->pl->tile_seg0, P->pl->tile_mask,
+          P->pl->tile_cross, P->pl->n_tiles, P->pl->n_seg);
+    else
+      k_dense_apply_batch<false><<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
+          nz, n_nz, zr, n_z, P->acc8, P->out_rp, backward ? P->in_rp : nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo,
+          t_hi, b == nb - 1 ? 0u : gs_mask, b == nb - 1 ? 0u : entry_mask, P->d_slot_args, cross, P->prep_bits,
+          P->blk_pack8, P->blk_dead8, P->blk_ndead8, part_base, kApplyBlocks8, nullptr, nullptr, nullptr, nullptr, 0u, 0u);
     PPRHIP_CHECK_HIP(hipGetLastError());
     part_base += grid;
   }
@@ -1656,11 +1764,14 @@ int init_kernels_push() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
-  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch>),
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sparse_push<kBackward>)));
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch<false>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch<true>)));
   return PPRHIP_OK;
 }
 

@@ -443,6 +443,126 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
   return PPRHIP_OK;
 }
 
+// ---- source-partitioned copy of the in-CSR (engine_internal.hpp: HostPartLayout).  Three passes: (A) edges per (row,
+// partition), on all threads over row ranges of equal edge counts; (B) per partition - one thread each - the running
+// offsets of its rows, its segment ordinals, flags, chunk starts and tile words; (C) the edges themselves, on all
+// threads again, every row writing at the offsets pass B fixed - so the arrays are the same with any thread count.
+int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,
+                      uint32_t n_nz, unsigned threads, HostPartLayout& L) {
+  (void)n;
+  PhaseClock clk;
+  const unsigned T = (m < (1u << 20)) ? 1u : std::max(1u, threads ? threads : host_threads());
+  L.n_nz = n_nz;
+  L.n_tiles = (n_nz + kTileRows - 1) / kTileRows;
+  const size_t NT = L.n_tiles;
+  // (A) cnt[p * n_nz + j]: edges of row ordinal j whose source lies in partition p
+  RawVec<uint32_t> cnt((size_t)kParts * n_nz);
+  std::vector<uint32_t> rb(1, 0);  // row-ordinal ranges of about equal edge counts
+  {
+    const unsigned parts = T == 1 ? 1u : T * 8u;
+    uint64_t acc = 0;
+    for (uint32_t j = 0; j + 1 < n_nz; ++j) {
+      const uint32_t v = (uint32_t)nz_rows[j];
+      acc += in_rp[v + 1] - in_rp[v];
+      if (rb.size() < parts && acc >= m / parts * rb.size()) rb.push_back(j + 1);
+    }
+    rb.push_back(n_nz);
+  }
+  const unsigned n_ranges = (unsigned)rb.size() - 1;
+  parallel_parts(n_ranges, T, [&](unsigned r) {
+    for (uint32_t j = rb[r]; j < rb[r + 1]; ++j) {
+      const uint32_t v = (uint32_t)nz_rows[j];
+      uint32_t c[kParts] = {0};
+      for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) c[part_of((uint32_t)in_ci[e])]++;
+      for (int p = 0; p < kParts; ++p) cnt[(size_t)p * n_nz + j] = c[p];
+    }
+  });
+  clk.mark("partition: counts");
+  // sizes: chunks and segments per partition
+  uint64_t edges_p[kParts] = {0}, segs_p[kParts] = {0};
+  parallel_parts(kParts, T, [&](unsigned p) {
+    uint64_t e = 0, sg = 0;
+    const uint32_t* c = cnt.data() + (size_t)p * n_nz;
+    for (uint32_t j = 0; j < n_nz; ++j) {
+      e += c[j];
+      sg += c[j] ? 1u : 0u;
+    }
+    edges_p[p] = e;
+    segs_p[p] = sg;
+  });
+  L.chunk_base[0] = 0;
+  L.seg_base[0] = 0;
+  for (int p = 0; p < kParts; ++p) {
+    L.chunk_base[p + 1] = L.chunk_base[p] + (uint32_t)((edges_p[p] + kChunkPad - 1) / kChunkPad);
+    L.seg_base[p + 1] = L.seg_base[p] + (uint32_t)segs_p[p];
+  }
+  const size_t n_chunks = L.chunk_base[kParts];
+  L.ci.resize((n_chunks + 1) * (size_t)kChunkPad);
+  L.flags.assign((n_chunks + 1) * (size_t)(kChunkPad / 8), 0);
+  L.chunk_starts.assign(n_chunks + 1, 0);
+  L.tile_seg0.assign((size_t)kParts * (NT + 1), 0);
+  L.tile_mask.assign((size_t)kParts * NT, 0ull);
+  L.tile_cross.assign((size_t)kParts * NT, 0ull);
+  L.tile_edge0.assign((size_t)kParts * (NT + 1), 0ull);
+  // (B) per partition: cnt becomes the row's first edge (relative to the partition's base); everything that follows
+  // from the segment boundaries
+  parallel_parts(kParts, T, [&](unsigned p) {
+    uint32_t* c = cnt.data() + (size_t)p * n_nz;
+    const uint64_t e_base = (uint64_t)L.chunk_base[p] * kChunkPad, e_end = e_base + edges_p[p];
+    uint64_t e = e_base;
+    uint32_t sg = L.seg_base[p];
+    uint32_t* cst = L.chunk_starts.data();
+    for (uint32_t j = 0; j < n_nz; ++j) {
+      const size_t t = j / kTileRows;
+      if (j % kTileRows == 0) {
+        L.tile_seg0[(size_t)p * (NT + 1) + t] = sg;
+        L.tile_edge0[(size_t)p * (NT + 1) + t] = e;
+      }
+      const uint32_t k = c[j];
+      c[j] = (uint32_t)(e - e_base);
+      if (!k) continue;
+      const uint64_t last = e + k - 1;
+      L.flags[e >> 3] |= (uint8_t)(1u << (e & 7));
+      cst[e / kChunkPad + 1]++;  // (a chunk belongs to one partition: no other thread counts here)
+      L.tile_mask[(size_t)p * NT + t] |= 1ull << (j % kTileRows);
+      // summed with atomics, so cleared when it is read: a segment that holds the last edge of a chunk (spans two
+      // chunks, or ends where a chunk or the partition ends) - the rule of HostLift::cross for rows
+      if (e / kChunkPad != last / kChunkPad || (last + 1) % kChunkPad == 0 || last + 1 == e_end)
+        L.tile_cross[(size_t)p * NT + t] |= 1ull << (j % kTileRows);
+      e += k;
+      sg++;
+    }
+    L.tile_seg0[(size_t)p * (NT + 1) + NT] = sg;
+    L.tile_edge0[(size_t)p * (NT + 1) + NT] = e;
+    // padding of the partition's last chunk
+    const uint64_t pad_end = (uint64_t)L.chunk_base[p + 1] * kChunkPad;
+    std::fill(L.ci.begin() + (size_t)e_end, L.ci.begin() + (size_t)pad_end, 0);
+  });
+  std::fill(L.ci.begin() + n_chunks * (size_t)kChunkPad, L.ci.end(), 0);
+  {  // chunk starts: counts -> segments before each chunk, as global ordinals
+    uint32_t run = 0;
+    for (size_t ch = 0; ch <= n_chunks; ++ch) {
+      run += L.chunk_starts[ch];
+      L.chunk_starts[ch] = run;
+    }
+  }
+  clk.mark("partition: offsets");
+  // (C) the edges
+  parallel_parts(n_ranges, T, [&](unsigned r) {
+    for (uint32_t j = rb[r]; j < rb[r + 1]; ++j) {
+      const uint32_t v = (uint32_t)nz_rows[j];
+      uint64_t w[kParts];
+      for (int p = 0; p < kParts; ++p) w[p] = (uint64_t)L.chunk_base[p] * kChunkPad + cnt[(size_t)p * n_nz + j];
+      for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) {
+        const int32_t u = in_ci[e];
+        L.ci[w[part_of((uint32_t)u)]++] = u;
+      }
+    }
+  });
+  clk.mark("partition: edges");
+  return PPRHIP_OK;
+}
+
 }  // namespace detail
 }  // namespace pprhip
 
@@ -451,6 +571,9 @@ struct pprhip_lift {
   HostLift H;
   uint32_t n = 0;
   uint64_t m = 0;
+  int threads = 0;
+  mutable bool have_part = false;  // the source-partitioned copy is built when one of its arrays is first asked for
+  mutable HostPartLayout part;
 };
 
 extern "C" {
@@ -472,6 +595,7 @@ int pprhip_graph_lift_host(uint32_t n, uint64_t m, const uint32_t* out_row_ptr, 
     std::unique_ptr<pprhip_lift> L(new pprhip_lift());
     L->n = n;
     L->m = m;
+    L->threads = threads;
     PPRHIP_TRY(lift_host(n, m, out_row_ptr, out_col_idx, in_row_ptr, in_col_idx, (unsigned)threads, L->H));
     *lift_out = L.release();
     return PPRHIP_OK;
@@ -493,6 +617,30 @@ int pprhip_lift_array(const pprhip_lift_t* lift, int which, const void** data_ou
     return PPRHIP_OK;
   };
 #define PPRHIP_LIFT_VEC(v) give((v).data(), (v).size() * sizeof((v)[0]))
+  if (which >= PPRHIP_LIFT_PART_BASES && which <= PPRHIP_LIFT_PART_TILE_EDGE0) {
+    if (!lift->have_part) {
+      try {
+        PPRHIP_TRY(build_part_layout(lift->n, lift->m, H.in_rp.data(), H.in_ci.data(), H.nz_rows.data(),
+                                     (uint32_t)H.nz_rows.size(), (unsigned)lift->threads, lift->part));
+      } catch (const std::bad_alloc&) {
+        set_error("pprhip_lift_array: out of host memory");
+        return PPRHIP_ERR_OOM;
+      }
+      lift->have_part = true;
+    }
+    const HostPartLayout& L = lift->part;
+    switch (which) {
+      case PPRHIP_LIFT_PART_BASES: return give(L.chunk_base, sizeof L.chunk_base + sizeof L.seg_base);
+      case PPRHIP_LIFT_PART_COL_IDX: return PPRHIP_LIFT_VEC(L.ci);
+      case PPRHIP_LIFT_PART_FLAGS: return PPRHIP_LIFT_VEC(L.flags);
+      case PPRHIP_LIFT_PART_CHUNK_STARTS: return PPRHIP_LIFT_VEC(L.chunk_starts);
+      case PPRHIP_LIFT_PART_TILE_SEG0: return PPRHIP_LIFT_VEC(L.tile_seg0);
+      case PPRHIP_LIFT_PART_TILE_MASK: return PPRHIP_LIFT_VEC(L.tile_mask);
+      case PPRHIP_LIFT_PART_TILE_CROSS: return PPRHIP_LIFT_VEC(L.tile_cross);
+      case PPRHIP_LIFT_PART_TILE_EDGE0: return PPRHIP_LIFT_VEC(L.tile_edge0);
+      default: break;
+    }
+  }
   switch (which) {
     case PPRHIP_LIFT_NEW2OLD: return PPRHIP_LIFT_VEC(H.new2old);
     case PPRHIP_LIFT_OLD2NEW: return PPRHIP_LIFT_VEC(H.old2new);

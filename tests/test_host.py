@@ -214,6 +214,66 @@ def test_index_merge_large_runs_on_all_threads(pkg):
 
 
 # ------------------------------------------------------------------ graph lift, host half (row a11; PPR.java:136-152)
+def _part_expected(n, m, in_rp, in_ci, nz_rows, chunk=512, parts=8, tile=64):
+    """The source-partitioned copy of the in-CSR (engine_internal.hpp: HostPartLayout) restated with numpy: in-edges in
+    row order, stably grouped by partition of the source id ((id >> 6) & 7), every partition padded to whole chunks; a
+    segment = the edges of one row inside one partition."""
+    indeg = np.diff(in_rp).astype(np.int64)
+    n_nz = nz_rows.size
+    n_tiles = (n_nz + tile - 1) // tile
+    row_of_edge = np.repeat(np.arange(n, dtype=np.int64), indeg)
+    ordinal = np.cumsum(indeg > 0) - 1                    # node -> row ordinal
+    part = (in_ci.astype(np.int64) >> 6) & (parts - 1)
+    perm = np.argsort(part, kind="stable")
+    counts = np.bincount(part, minlength=parts)
+    chunk_base = np.zeros(parts + 1, dtype=np.int64)
+    chunk_base[1:] = np.cumsum((counts + chunk - 1) // chunk)
+    n_chunks = int(chunk_base[-1])
+    ci = np.zeros((n_chunks + 1) * chunk, dtype=np.int32)
+    edge_lo = np.zeros(parts + 1, dtype=np.int64)
+    edge_lo[1:] = np.cumsum(counts)
+    pos = np.empty(m, dtype=np.int64)                      # position of every (grouped) edge in the padded copy
+    for p in range(parts):
+        pos[edge_lo[p]:edge_lo[p + 1]] = chunk_base[p] * chunk + np.arange(counts[p])
+    ci[pos] = in_ci[perm]
+    rows_g = ordinal[row_of_edge[perm]]
+    key = part[perm] * (n_nz + 1) + rows_g
+    start = np.ones(m, dtype=bool)
+    start[1:] = key[1:] != key[:-1]
+    seg_pos = pos[start]                                   # first edge of every segment, in global segment order
+    seg_part, seg_row = part[perm][start], rows_g[start]
+    seg_len = np.diff(np.append(np.nonzero(start)[0], m))
+    seg_last = seg_pos + seg_len - 1
+    bits = np.zeros((n_chunks + 1) * chunk, dtype=np.uint8)
+    bits[seg_pos] = 1
+    flags = np.packbits(bits, bitorder="little")
+    cs = np.zeros(n_chunks + 1, dtype=np.uint32)
+    cs[1:] = np.cumsum(np.bincount(seg_pos // chunk, minlength=n_chunks)[:n_chunks])
+    seg_base = np.zeros(parts + 1, dtype=np.int64)
+    seg_base[1:] = np.cumsum(np.bincount(seg_part, minlength=parts))
+    part_end = chunk_base[:-1] * chunk + counts            # one past the last edge of each partition
+    cross_b = (seg_pos // chunk != seg_last // chunk) | ((seg_last + 1) % chunk == 0) | (seg_last + 1 == part_end[seg_part])
+    tile_seg0 = np.zeros((parts, n_tiles + 1), dtype=np.uint32)
+    tile_edge0 = np.zeros((parts, n_tiles + 1), dtype=np.uint64)
+    tile_mask = np.zeros((parts, n_tiles), dtype=np.uint64)
+    tile_cross = np.zeros((parts, n_tiles), dtype=np.uint64)
+    for p in range(parts):
+        sel = seg_part == p
+        r = seg_row[sel]
+        # segments of p among the rows before 64 t
+        before = np.searchsorted(r, np.arange(n_tiles + 1) * tile, side="left")
+        tile_seg0[p] = seg_base[p] + before
+        ends = np.append(seg_pos[sel], part_end[p])
+        tile_edge0[p] = ends[before]
+        bit = np.uint64(1) << (r % tile).astype(np.uint64)
+        np.bitwise_or.at(tile_mask[p], r // tile, bit)
+        c = cross_b[sel]
+        np.bitwise_or.at(tile_cross[p], r[c] // tile, bit[c])
+    return dict(part_bases=np.concatenate([chunk_base, seg_base]).astype(np.uint32), part_ci=ci, part_flags=flags,
+                part_chunk_starts=cs, part_tile_seg0=tile_seg0.ravel(), part_tile_mask=tile_mask.ravel(),
+                part_tile_cross=tile_cross.ravel(), part_tile_edge0=tile_edge0.ravel())
+
+
 def _lift_expected(h, width=393216, chunk=512, max_windows=16):
     """The internal layout restated with numpy (stable sorts instead of the library's counting sort and threaded
     passes): vertex order = nodes with in-edges first, then out-degree descending, ties by id; rows keep their
@@ -258,6 +318,7 @@ def _lift_expected(h, width=393216, chunk=512, max_windows=16):
     np.bitwise_or.at(cross, j >> 6, np.uint64(1) << (j & 63).astype(np.uint64))
     exp = dict(new2old=new2old, old2new=old2new, out_rp=out_rp, out_ci=out_ci, in_rp=in_rp, in_ci=in_ci, nz_rows=nz_rows,
                zin_rows=zin_rows, flags=flags, chunk_starts=chunk_starts, cross=cross)
+    exp.update(_part_expected(n, m, in_rp, in_ci, nz_rows, chunk))
     n_src = int(np.nonzero(outdeg > 0)[0].max()) + 1 if (outdeg > 0).any() else 0
     S = (n_src + width - 1) // width
     if S > max_windows:
