@@ -227,7 +227,7 @@ enum {
   PPRHIP_LIFT_SLICED_CHUNK_STARTS = 15, /* uint32[] */
   PPRHIP_LIFT_SEG_ROW = 16,          /* uint32[segments]: row ordinal */
   PPRHIP_LIFT_SEG_OFF = 17,          /* uint32[segments]: first edge */
-  /* the source-partitioned copy of the in-CSR the batched sweep walks (8 partitions by (source id >> 6) & 7, concatenated;
+  /* the source-partitioned copy of the in-CSR the batched sweep walks (8 partitions by source id & 7, concatenated;
    * a "segment" = the edges of one row inside one partition; built when first asked for) */
   PPRHIP_LIFT_PART_BASES = 18,        /* uint32[9] first chunk of each partition, then uint32[9] first segment ordinal */
   PPRHIP_LIFT_PART_COL_IDX = 19,      /* int32[(chunks + 1) * 512]: source ids, partitions padded to whole chunks */
@@ -421,6 +421,16 @@ void pprhip_comm_destroy(pprhip_comm_t* c);
 int pprhip_comm_info(const pprhip_comm_t* c, int* rank, int* world);
 /* contiguous share [begin, end) of rank `rank` when [0, n) is cut into `world` ranges (targets and owned sources) */
 int pprhip_shard_target_range(int rank, int world, uint32_t n, uint32_t* begin, uint32_t* end);
+/* The target ranges a sharded All-Pair run searches: cuts_out[world + 1], rank r takes the targets
+ * [cuts_out[r], cuts_out[r + 1]).  mode 0: equal counts (pprhip_shard_target_range); mode 1: by work - a pilot measures
+ * the searches of the 16 targets with the most in-edges and of 48 more across the in-degree ranks on this handle,
+ * every other target is estimated from its in-degree, and the cuts fall at equal shares of the running sum (a store
+ * whose ids follow its in-degrees gives rank 0 every hub under equal counts: Base_Whole_Graph.java:76-92 iterates the
+ * targets in id order); mode 2: what pprhip_all_pair_backward_sharded does - by work when equal counts would leave one
+ * rank with more than 1.15 x the mean of the modelled work (skew_out, may be NULL), else equal counts.  The sources a
+ * rank owns stay equal counts in every mode. */
+int pprhip_shard_target_cuts(pprhip_graph_t* g, int world, double alpha, double threshold, int mode, uint32_t* cuts_out,
+                             double* skew_out);
 /* Collective: this rank searches its target range, entries are exchanged by owner of the source on the device, and
  * own_out receives the finished rows (k rule applied) of the sources this rank owns (rows of other sources empty).
  * stats: this rank's search; stats->mc_sources = entries it found, stats->select_bytes = bytes it received. */

@@ -83,7 +83,7 @@ EXPORTS = [
     "pprhip_topk_gather", "pprhip_comm_abort", "pprhip_owner_partition", "pprhip_index_from_entries",
     "pprhip_device_memory", "pprhip_graph_lift_host", "pprhip_lift_array", "pprhip_lift_destroy",
     "pprhip_fora_stream_open", "pprhip_fora_stream_submit", "pprhip_fora_stream_wait", "pprhip_fora_stream_close",
-    "pprhip_set_kernel_timing",
+    "pprhip_set_kernel_timing", "pprhip_shard_target_cuts",
 ]
 COMM_ID_BYTES = 128
 
@@ -159,6 +159,7 @@ def lib():
     L.pprhip_comm_destroy.restype = None
     L.pprhip_comm_info.argtypes = [vp, P(ci), P(ci)]
     L.pprhip_shard_target_range.argtypes = [ci, ci, u32, P(u32), P(u32)]
+    L.pprhip_shard_target_cuts.argtypes = [vp, ci, dbl, dbl, ci, vp, P(dbl)]
     L.pprhip_all_pair_backward_sharded.argtypes = [vp, dbl, dbl, ci, P(vp), P(Stats)]
     L.pprhip_topk_gather.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
     L.pprhip_comm_abort.argtypes = [vp]
@@ -450,6 +451,18 @@ def shard_target_range(rank, world, n):
     b, e = C.c_uint32(), C.c_uint32()
     _check(lib().pprhip_shard_target_range(rank, world, n, C.byref(b), C.byref(e)))
     return b.value, e.value
+
+
+CUT_EQUAL, CUT_BY_WORK, CUT_AUTO = 0, 1, 2
+
+
+def shard_target_cuts(graph, world, alpha, threshold, mode=CUT_AUTO):
+    """pprhip_shard_target_cuts: (cuts[world + 1], skew) - the target ranges a sharded All-Pair run searches and the
+    largest share of the modelled work equal counts would give one rank (x the mean)."""
+    cuts = np.zeros(world + 1, dtype=np.uint32)
+    skew = C.c_double()
+    _check(lib().pprhip_shard_target_cuts(graph.h, world, alpha, threshold, mode, _ptr(cuts), C.byref(skew)))
+    return cuts, skew.value
 
 
 def comm_unique_id():

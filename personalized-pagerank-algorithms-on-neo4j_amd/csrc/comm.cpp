@@ -44,6 +44,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -398,6 +399,180 @@ void target_range(int rank, int world, uint32_t n, uint32_t* lo, uint32_t* hi) {
   *hi = *lo + base + ((uint32_t)rank < rem ? 1u : 0u);
 }
 
+// ---- work-weighted cut of the TARGET ranges (round 5).  Equal counts of contiguous ids balance the searches only
+// while ids and in-degrees are unrelated: a search's cost follows its target's in-degree (R-MAT 18 - 20 at 1e-3: ~110 -
+// 215 edge pushes per in-edge up to a few thousand in-edges, ten times that for the hubs, whose searches saturate the
+// graph; tools/exp/apbs_cost_fit.py), and a store whose ids follow the import order of a degree-sorted dump gives rank
+// 0 all of the hubs: 7.6 x the mean on R-MAT 18, with the other ranks idle.  No function of the in-degree alone
+// predicts the hubs' cost (the ratio depends on graph and threshold: best of six forms 1.5 x the mean), so the hubs
+// are MEASURED: a pilot runs the kPilotTop targets with the most in-edges and kPilotRanks more, spread geometrically
+// over the in-degree ranks, as whole-vector searches on this handle (pprhip_backward_push's path) and counts their
+// edge pushes and pops; a target's estimate is its own measurement if it has one, else the log-log interpolation of the
+// measured means per in-degree class (half octaves, made monotone); the cuts fall where the running sum of the
+// estimates in id order passes k / W of the total.  On the R-MAT 18 census every rank then holds 0.89 - 1.10 of the
+// mean.  The sources a rank OWNS stay equal counts (owner_of): rows cost the same whoever finds their entries.
+// Rank 0 decides and the others receive its cuts (cuts taken from every rank's own pilot could differ by a search
+// whose residue lands within an ulp of the threshold, and ranges that do not tile [0, n) would be a wrong index).
+constexpr int kPilotTop = 16, kPilotRanks = 48;
+
+// >= `trigger` x the mean: the largest share of the modelled work (in-edges, hubs weighted up) that equal counts would
+// give one rank - the cheap test that decides whether the pilot is worth its searches (PPRHIP_SHARD_CUT=count / work
+// forces either)
+double equal_count_skew(const pprhip_graph* g, int W) {
+  const uint32_t n = g->n;
+  const double d_star = std::max(64.0, (double)n / 256.0);
+  std::vector<double> share((size_t)W, 0.0);
+  double total = 0.0;
+  for (int r = 0; r < W; ++r) {
+    uint32_t lo, hi;
+    target_range(r, W, n, &lo, &hi);
+    double s = 0.0;
+    for (uint32_t t = lo; t < hi; ++t) {
+      const double d = (double)hdeg_in(g, g->h_old2new[t]);
+      s += 1.0 + d * (1.0 + d / d_star);
+    }
+    share[r] = s;
+    total += s;
+  }
+  double mx = 0.0;
+  for (double s : share) mx = std::max(mx, s);
+  return total > 0.0 ? mx / (total / W) : 1.0;
+}
+
+int weighted_target_cuts(pprhip_graph* g, int W, double alpha, double threshold, std::vector<uint32_t>& cuts) {
+  const uint32_t n = g->n;
+  cuts.assign((size_t)W + 1, n);
+  cuts[0] = 0;
+  std::vector<uint32_t> deg(n);
+  for (uint32_t t = 0; t < n; ++t) deg[t] = hdeg_in(g, g->h_old2new[t]);
+  std::vector<uint32_t> order(n);
+  for (uint32_t t = 0; t < n; ++t) order[t] = t;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return deg[a] > deg[b]; });
+  uint32_t nz = 0;
+  while (nz < n && deg[order[nz]] > 0) ++nz;
+  std::vector<double> est(n, 1.0);  // a target without in-edges is one entry and no search
+  if (nz > 0) {
+    // the pilot's targets: ranks 0 .. kPilotTop - 1, then geometrically up to the last target with in-edges
+    std::vector<uint32_t> ranks;
+    for (uint32_t r = 0; r < std::min<uint32_t>(kPilotTop, nz); ++r) ranks.push_back(r);
+    if (nz > (uint32_t)kPilotTop) {
+      const double a = std::log((double)kPilotTop + 1.0), b = std::log((double)nz);
+      for (int i = 0; i < kPilotRanks; ++i) {
+        const uint32_t r = std::min<uint32_t>(nz - 1, (uint32_t)std::exp(a + (b - a) * i / (kPilotRanks - 1)) - 1u);
+        if (r > ranks.back()) ranks.push_back(r);
+      }
+    }
+    std::vector<double> cost(ranks.size(), 0.0);
+    for (size_t i = 0; i < ranks.size(); ++i) {
+      pprhip_stats_t st;
+      std::memset(&st, 0, sizeof st);
+      const uint32_t t = order[ranks[i]];
+      PPRHIP_TRY(backward_search_whole(g, g->h_old2new[t], alpha, threshold, st));
+      cost[i] = 1.0 + (double)(st.edge_pushes + st.dense_edges) + 4.0 * (double)(st.pops + st.dense_nodes);
+    }
+    PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    // measured means per half octave of the in-degree -> monotone log-log table
+    std::vector<double> xs, ys;
+    {
+      size_t i = 0;
+      while (i < ranks.size()) {
+        const double cls = std::floor(std::log2((double)deg[order[ranks[i]]]) * 2.0);
+        double sd = 0.0, sc = 0.0;
+        size_t k = 0;
+        while (i < ranks.size() && std::floor(std::log2((double)deg[order[ranks[i]]]) * 2.0) == cls) {
+          sd += (double)deg[order[ranks[i]]];
+          sc += cost[i];
+          ++k;
+          ++i;
+        }
+        xs.push_back(std::log(sd / (double)k));
+        ys.push_back(std::log(sc / (double)k));
+      }
+      // (ranks run from high in-degree to low: make the table ascending in x, then monotone in y)
+      std::reverse(xs.begin(), xs.end());
+      std::reverse(ys.begin(), ys.end());
+      for (size_t j = 1; j < ys.size(); ++j) ys[j] = std::max(ys[j], ys[j - 1]);
+    }
+    auto interp = [&](double d) {
+      const double x = std::log(d);
+      if (x <= xs.front()) return std::exp(ys.front());
+      if (x >= xs.back()) return std::exp(ys.back());
+      const size_t j = (size_t)(std::upper_bound(xs.begin(), xs.end(), x) - xs.begin());
+      const double f = (x - xs[j - 1]) / (xs[j] - xs[j - 1]);
+      return std::exp(ys[j - 1] + f * (ys[j] - ys[j - 1]));
+    };
+    for (uint32_t t = 0; t < n; ++t)
+      if (deg[t]) est[t] = interp((double)deg[t]);
+    for (size_t i = 0; i < ranks.size(); ++i) est[order[ranks[i]]] = cost[i];
+  }
+  double total = 0.0;
+  for (double e : est) total += e;
+  double run = 0.0;
+  int k = 1;
+  for (uint32_t t = 0; t < n && k < W; ++t) {
+    run += est[t];
+    while (k < W && run >= total * (double)k / (double)W) cuts[(size_t)k++] = t + 1;
+  }
+  return PPRHIP_OK;
+}
+
+// the target ranges of a sharded All-Pair run: cuts[r] .. cuts[r + 1] for rank r.  Rank 0 decides - equal counts, or the
+// work-weighted cut when equal counts would leave one rank with more than 1.15 x the mean of the modelled work - and
+// every rank receives its decision through the exchange every rank takes part in anyway (failure protocol included).
+int decide_target_cuts(pprhip_comm* c, double alpha, double threshold, std::vector<uint32_t>& cuts, int pre_rc) {
+  pprhip_graph* g = c->g;
+  const int W = c->world;
+  cuts.assign((size_t)W + 1, 0);
+  int rc = pre_rc;
+  uint32_t* d_send = nullptr;
+  void* d_recv = nullptr;
+  std::vector<uint64_t> off((size_t)W + 1, 0), roff;
+  if (c->rank == 0 && rc == PPRHIP_OK) {
+    try {
+      const char* e = getenv("PPRHIP_SHARD_CUT");
+      const bool by_work = e ? (e[0] == 'w') : equal_count_skew(g, W) > 1.15;
+      if (by_work) {
+        rc = weighted_target_cuts(g, W, alpha, threshold, cuts);
+      } else {
+        for (int r = 0; r < W; ++r) target_range(r, W, g->n, &cuts[(size_t)r], &cuts[(size_t)r + 1]);
+      }
+      if (rc == PPRHIP_OK) {
+        std::vector<uint32_t> all((size_t)W * (W + 1));
+        for (int p = 0; p < W; ++p) std::copy(cuts.begin(), cuts.end(), all.begin() + (size_t)p * (W + 1));
+        rc = alloc_dev((void**)&d_send, sizeof(uint32_t) * all.size());
+        if (rc == PPRHIP_OK && hipMemcpy(d_send, all.data(), sizeof(uint32_t) * all.size(), hipMemcpyHostToDevice) != hipSuccess) {
+          set_error("sharded All-Pair: upload of the target cuts failed");
+          rc = PPRHIP_ERR_HIP;
+        }
+        for (int p = 0; p <= W; ++p) off[(size_t)p] = (uint64_t)p * sizeof(uint32_t) * (W + 1);
+      }
+    } catch (const std::exception& ex) {
+      set_error("sharded All-Pair: target cuts: %s", ex.what());
+      rc = PPRHIP_ERR_OOM;
+    }
+  }
+  rc = comm_alltoallv(c, d_send, off, &d_recv, roff, rc);
+  if (rc == PPRHIP_OK) {
+    if (roff[(size_t)W] != sizeof(uint32_t) * (size_t)(W + 1)) {
+      set_error("sharded All-Pair: rank %d received %llu bytes of target cuts", c->rank, (unsigned long long)roff[(size_t)W]);
+      rc = PPRHIP_ERR_STATE;
+    } else if (hipMemcpy(cuts.data(), d_recv, sizeof(uint32_t) * (size_t)(W + 1), hipMemcpyDeviceToHost) != hipSuccess) {
+      set_error("sharded All-Pair: download of the target cuts failed");
+      rc = PPRHIP_ERR_HIP;
+    } else {
+      bool ok = cuts[0] == 0 && cuts[(size_t)W] == g->n;
+      for (int r = 0; r < W; ++r) ok = ok && cuts[(size_t)r] <= cuts[(size_t)r + 1];
+      if (!ok) {
+        set_error("sharded All-Pair: rank %d received target cuts that do not tile [0, %u)", c->rank, g->n);
+        rc = PPRHIP_ERR_STATE;
+      }
+    }
+  }
+  if (d_send) (void)hipFree(d_send);
+  if (d_recv) (void)hipFree(d_recv);
+  return rc;
+}
+
 // this rank's share of the sharded All-Pair: search its targets, exchange by owner of the source, finalise its sources.
 // pre_rc != 0: the rank failed before it got here (its message is the thread's last error) and only takes part in the
 // exchange to tell its peers.
@@ -415,8 +590,17 @@ int all_pair_sharded(pprhip_comm* c, double alpha, double threshold, int k, pprh
     }
     return rc;
   }
-  uint32_t lo = 0, hi = 0;
+  // the sources this rank owns: equal counts; the targets it searches: rank 0's cut (equal counts, or by modelled work)
+  uint32_t lo = 0, hi = 0, t_lo = 0, t_hi = 0;
   target_range(c->rank, W, g->n, &lo, &hi);
+  {
+    std::vector<uint32_t> cuts;
+    rc = decide_target_cuts(c, alpha, threshold, cuts, rc);
+    if (rc == PPRHIP_OK) {
+      t_lo = cuts[(size_t)c->rank];
+      t_hi = cuts[(size_t)c->rank + 1];
+    }
+  }
   pprhip_stats_t st;
   std::memset(&st, 0, sizeof st);
   DeviceTripleSink sink;
@@ -434,7 +618,7 @@ int all_pair_sharded(pprhip_comm* c, double alpha, double threshold, int k, pprh
   // rank still goes to the exchange (where its peers learn of it)
   auto local_part = [&]() -> int {
     if (fault_injected(c->rank, "search")) return PPRHIP_ERR_STATE;
-    PPRHIP_TRY(all_pair_collect(g, alpha, threshold, lo, hi, sink, st));
+    PPRHIP_TRY(all_pair_collect(g, alpha, threshold, t_lo, t_hi, sink, st));
     if (fault_injected(c->rank, "partition")) return PPRHIP_ERR_STATE;
     PPRHIP_TRY(alloc_dev((void**)&d_cur, sizeof(unsigned long long) * kBatch * 4));  // >= 64 counters
     PPRHIP_CHECK_HIP(hipMemsetAsync(d_cur, 0, sizeof(unsigned long long) * 64, g->stream));
@@ -645,6 +829,30 @@ int pprhip_shard_target_range(int rank, int world, uint32_t n, uint32_t* begin, 
     return PPRHIP_ERR_INVALID;
   }
   target_range(rank, world, n, begin, end);
+  return PPRHIP_OK;
+}
+
+int pprhip_shard_target_cuts(pprhip_graph_t* g, int world, double alpha, double threshold, int mode, uint32_t* cuts_out,
+                             double* skew_out) {
+  PPRHIP_TRY(check_graph(g, "pprhip_shard_target_cuts"));
+  if (world < 1 || !cuts_out || mode < 0 || mode > 2 || !(threshold > 0.0)) {
+    set_error("pprhip_shard_target_cuts: bad arguments (world %d, mode %d)", world, mode);
+    return PPRHIP_ERR_INVALID;
+  }
+  try {
+    const double skew = equal_count_skew(g, world);
+    if (skew_out) *skew_out = skew;
+    std::vector<uint32_t> cuts((size_t)world + 1, 0);
+    if (mode == 1 || (mode == 2 && skew > 1.15)) {
+      PPRHIP_TRY(weighted_target_cuts(g, world, alpha, threshold, cuts));
+    } else {
+      for (int r = 0; r < world; ++r) target_range(r, world, g->n, &cuts[(size_t)r], &cuts[(size_t)r + 1]);
+    }
+    std::copy(cuts.begin(), cuts.end(), cuts_out);
+  } catch (const std::bad_alloc&) {
+    set_error("pprhip_shard_target_cuts: out of host memory");
+    return PPRHIP_ERR_OOM;
+  }
   return PPRHIP_OK;
 }
 

@@ -36,18 +36,16 @@ constexpr int kChunkPad = 512;  // in-edges one wave of the dense pull sweep own
 constexpr int kBlock = 256;
 
 // Batched forward sweep, source-partitioned (engine_internal.hpp: HostPartLayout): the in-edges are cut into kParts
-// groups by the partition of their SOURCE id, 64 consecutive ids (8 KB of contribution lines) to a partition in turn.
+// groups by the partition of their SOURCE id, id mod kParts - line by line in turn, so that every partition gets the same
+// share of the hot ids (runs of 64 ids gave partition 0, which held the 64 hottest ids, 15 % more edges than the
+// average, and the launch waits for its slowest partition; by single lines: 1.3 %).  The L2's channel selection does
+// not mind the stride of eight lines (tools/micro/xcd_affine_rate.hip: 102 G lines/s by single lines, 91-94 by runs of
+// 8 or 64).
 constexpr int kParts = 8;       // = XCDs of an MI355X: workgroup b of the edge kernel walks partition b % 8
-constexpr int kPartShift = 6;
-__host__ __device__ inline uint32_t part_of(uint32_t id) { return (id >> kPartShift) & (uint32_t)(kParts - 1); }
-// position of an id among the ids of its own partition
-__host__ __device__ inline uint32_t part_local(uint32_t id) {
-  return ((id >> (kPartShift + 3)) << kPartShift) | (id & ((1u << kPartShift) - 1u));
-}
-// ... and back: the id at position `local` of partition p
-__host__ __device__ inline uint32_t part_global(uint32_t local, uint32_t p) {
-  return ((local >> kPartShift) << (kPartShift + 3)) | (p << kPartShift) | (local & ((1u << kPartShift) - 1u));
-}
+__host__ __device__ inline uint32_t part_of(uint32_t id) { return id & (uint32_t)(kParts - 1); }
+// position of an id among the ids of its own partition, and back
+__host__ __device__ inline uint32_t part_local(uint32_t id) { return id >> 3; }
+__host__ __device__ inline uint32_t part_global(uint32_t local, uint32_t p) { return (local << 3) | p; }
 constexpr int kTileRows = 64;   // rows per tile of the batched apply kernel (kernels_push.hip: kApplyRows)
 
 // packed frontier counter: entries in the high 28 bits, edge total in the low 36 bits

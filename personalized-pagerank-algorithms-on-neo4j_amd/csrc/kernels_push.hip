@@ -771,6 +771,223 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_dense_edges_q (round 5): the batched edge kernel with FOUR lanes per edge, four slots per lane.
+// k_dense_edges_b spends sixteen lanes on an edge, and every one of them repeats the edge's index, address and flag
+// arithmetic for its one slot: ~15 vector instructions per four edges of a wave.  That was hidden while the kernel
+// waited for lines beyond L2 (row-major layout: 23 M misses per launch); over the source-partitioned copy the misses
+// fall by 60 % and the kernel turns out issue-bound - SQ_ACTIVE_INST_ANY x 4 waves = 0.9 of the SIMD cycles, 533 us per
+// launch against 463 (profiles/r05_pmc_sweep_first.txt).  Here a QUAD of lanes shares an edge, lane t of it holding the
+// slots 4t .. 4t+3 (32 bytes of the line: two 16-byte loads), so a wave instruction serves sixteen edges instead of
+// four and the per-edge arithmetic is paid once per quad lane instead of once per slot.  The wave still owns a
+// 512-edge chunk: quad q walks its edges [32q, 32q + 32), whose indices sit in the quad's own registers (8 per lane,
+// broadcast with DPP quad_perm) and whose 32 row-start bits are one word; sums close inside the quad where a segment
+// starts and ends there, cross quads with a segmented scan over the sixteen quads, and only segments that cross the
+// chunk boundary use atomics - the rules of k_dense_edges_b, so the layouts, accB and the apply kernel are the same.
+// ------------------------------------------------------------------------------------------------
+constexpr int kQuad = 4;                         // lanes per edge
+constexpr int kQSlots = kBatch / kQuad;          // slots (doubles) per lane
+static_assert(kBatch == 16 && kQSlots == 4, "k_dense_edges_q is written for sixteen slots");
+
+struct ChunkRegsQ {
+  int4 ia, ib;   // the lane's 8 column indices
+  uint32_t fl;   // row-start bits of the quad's 32 edges
+};
+
+__device__ __forceinline__ ChunkRegsQ load_chunk_q(const int32_t* __restrict__ in_ci, const uint32_t* __restrict__ flags32,
+                                                   uint32_t c, int lane) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i* q = reinterpret_cast<const v4i*>(in_ci + (unsigned long long)c * kChunkEdges + 8ull * lane);
+  const v4i x = __builtin_nontemporal_load(q), y = __builtin_nontemporal_load(q + 1);
+  ChunkRegsQ r;
+  r.ia = make_int4(x.x, x.y, x.z, x.w);
+  r.ib = make_int4(y.x, y.y, y.z, y.w);
+  r.fl = __builtin_nontemporal_load(&flags32[(size_t)c * (kChunkEdges / 32) + (size_t)(lane >> 2)]);
+  return r;
+}
+
+// value of lane K of the caller's quad
+template <int K>
+__device__ __forceinline__ int quad_bcast(int x) {
+  return dpp_i32<K * 0x55, 0xf>(x);  // quad_perm:[K,K,K,K]
+}
+
+struct Quad4 {
+  double v[kQSlots];
+};
+
+// the caller's 32 bytes of vertex u's line: from the LDS table when u is hot, from memory otherwise (a quad is uniform)
+template <bool HOT, bool PART>
+__device__ __forceinline__ Quad4 load_quarter(const double* __restrict__ cB, const double* s_hot, uint32_t n_hot, uint32_t u,
+                                              int t) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d a, b;
+  if (HOT && u < n_hot) {
+    const v2d* p = reinterpret_cast<const v2d*>(s_hot + (size_t)(PART ? part_local(u) : u) * kBatch + kQSlots * t);
+    a = p[0];
+    b = p[1];
+  } else {
+    const v2d* p = reinterpret_cast<const v2d*>(cB + (size_t)u * kBatch + kQSlots * t);
+    a = p[0];
+    b = p[1];
+  }
+  Quad4 r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+  return r;
+}
+
+template <bool HOT, bool PART>
+__global__ __launch_bounds__(1024) void k_dense_edges_q(const int32_t* __restrict__ in_ci,
+                                                         const uint32_t* __restrict__ flags32,
+                                                         const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
+                                                         const double* __restrict__ cB, double* __restrict__ accB,
+                                                         uint32_t n_hot, uint32_t c_lo, unsigned long long e_lo,
+                                                         unsigned long long e_hi, uint32_t n, PartWindows W) {
+  extern __shared__ __attribute__((aligned(16))) double s_hot[];
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const int lane = lane_id();
+  const int q = lane >> 2, t = lane & 3;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  uint32_t stride = gridDim.x * waves_per_block;
+  uint32_t c = c_lo + blockIdx.x * waves_per_block + (uint32_t)wave_id();
+  const uint32_t part = PART ? blockIdx.x % (uint32_t)kParts : 0u;
+  if (PART) {
+    const uint32_t rank = blockIdx.x / (uint32_t)kParts, wgs = gridDim.x / (uint32_t)kParts;
+    stride = wgs * waves_per_block;
+    c = W.c_lo[part] + rank * waves_per_block + (uint32_t)wave_id();
+    n_chunks = W.c_hi[part];
+    e_lo = W.e_lo[part];
+    e_hi = W.e_hi[part];
+  }
+  ChunkRegsQ cur;
+  if (c < n_chunks) cur = load_chunk_q(in_ci, flags32, c, lane);
+  if (HOT) {
+    double tv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t i = threadIdx.x + j * 1024u;
+      if (PART) {
+        const uint32_t id = part_global(i / kBatch, part);  // line i / 16 of this partition's table
+        tv[j] = id < n_hot && id < n ? cB[(size_t)id * kBatch + (i % kBatch)] : 0.0;
+      } else {
+        tv[j] = i < n_hot * kBatch ? cB[i] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t i = threadIdx.x + j * 1024u;
+      if (PART || i < n_hot * kBatch) s_hot[i] = tv[j];
+    }
+    __syncthreads();
+  }
+  for (; c < n_chunks; c += stride) {
+    ChunkRegsQ nxt = cur;
+    const uint32_t cn = c + stride;
+    if (cn < n_chunks) nxt = load_chunk_q(in_ci, flags32, cn, lane);
+    const uint32_t cs = chunk_starts[c];
+    const uint32_t fl = cur.fl;
+    const uint32_t pc = (uint32_t)__popc(fl);
+    const uint32_t incl = wave_incl_scan_u32_dpp(t == 0 ? pc : 0u);  // segment starts up to and including this quad
+    const uint32_t before = cs + incl - pc;
+    const unsigned long long c_e0 = (unsigned long long)c * kChunkEdges;
+    const unsigned long long e_first = c_e0 + 32ull * q;
+    const bool tail = c_e0 < e_lo || c_e0 + kChunkEdges > e_hi;  // first / last chunk of the block: edges outside count 0
+    const int32_t own[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
+    double seg[kQSlots] = {0.0, 0.0, 0.0, 0.0}, first_seg[kQSlots] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t k = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {  // four edges per trip: 4b .. 4b + 3, held by lane b / 2 of the quad
+      uint32_t u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = own[(b & 1) * 4 + i];
+        u[i] = (uint32_t)((b >> 1) == 0 ? quad_bcast<0>(x) : (b >> 1) == 1 ? quad_bcast<1>(x) : (b >> 1) == 2 ? quad_bcast<2>(x) : quad_bcast<3>(x));
+      }
+      Quad4 val[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) val[i] = load_quarter<HOT, PART>(cB, s_hot, n_hot, u[i], t);
+      if (tail) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (e_first + 4 * b + i < e_lo || e_first + 4 * b + i >= e_hi) {
+#pragma unroll
+            for (int x = 0; x < kQSlots; ++x) val[i].v[x] = 0.0;
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((fl >> (4 * b + i)) & 1u) {
+          if (k == 0) {
+#pragma unroll
+            for (int x = 0; x < kQSlots; ++x) first_seg[x] = seg[x];  // closes the segment carried in from earlier quads
+          } else {  // a segment that starts and ends inside this quad
+            v2d* dst = reinterpret_cast<v2d*>(accB + (size_t)(before + k - 1) * kBatch + kQSlots * t);
+            v2d lo, hi;
+            lo.x = seg[0]; lo.y = seg[1]; hi.x = seg[2]; hi.y = seg[3];
+            __builtin_nontemporal_store(lo, dst);
+            __builtin_nontemporal_store(hi, dst + 1);
+          }
+#pragma unroll
+          for (int x = 0; x < kQSlots; ++x) seg[x] = 0.0;
+          ++k;
+        }
+#pragma unroll
+        for (int x = 0; x < kQSlots; ++x) seg[x] += val[i].v[x];
+      }
+    }
+    // segmented scan over the quads: S(q) = tail(q) + (quad q holds a segment start ? 0 : S(q - 1))
+    const bool h = k != 0;
+    double S[kQSlots];
+#pragma unroll
+    for (int x = 0; x < kQSlots; ++x) S[x] = seg[x];
+    int F = h ? 1 : 0;
+#pragma unroll
+    for (int d = kQuad; d < 64; d <<= 1) {
+      double ps[kQSlots];
+#pragma unroll
+      for (int x = 0; x < kQSlots; ++x) ps[x] = __shfl_up(S[x], d);
+      const int pf = __shfl_up(F, d);
+      if (lane >= d) {
+        if (!F) {
+#pragma unroll
+          for (int x = 0; x < kQSlots; ++x) S[x] += ps[x];
+        }
+        F |= pf;
+      }
+    }
+    double carry[kQSlots];
+#pragma unroll
+    for (int x = 0; x < kQSlots; ++x) {
+      carry[x] = __shfl_up(S[x], kQuad);
+      if (lane < kQuad) carry[x] = 0.0;
+    }
+    const unsigned long long hmask = __ballot(h);
+    if (h) {
+      const bool nonempty = q > 0 || (fl & 1u) == 0;
+      if (nonempty && before > 0) {
+        const bool started_here = (hmask & ((1ull << (q * kQuad)) - 1ull)) != 0;
+        double* dst = accB + (size_t)(before - 1) * kBatch + kQSlots * t;
+        if (started_here) {
+#pragma unroll
+          for (int x = 0; x < kQSlots; ++x) dst[x] = carry[x] + first_seg[x];
+        } else {  // began in an earlier chunk
+#pragma unroll
+          for (int x = 0; x < kQSlots; ++x) atomic_add_noret(dst + x, carry[x] + first_seg[x]);
+        }
+      }
+    }
+    if (q == 64 / kQuad - 1) {  // the segment still open at the end of the chunk
+      const uint32_t starts = cs + incl;
+      if (starts > 0) {
+#pragma unroll
+        for (int x = 0; x < kQSlots; ++x)
+          if (S[x] != 0.0) atomic_add_noret(&accB[(size_t)(starts - 1) * kBatch + kQSlots * t + x], S[x]);
+      }
+    }
+    cur = nxt;
+  }
+}
+
 // k_dense_apply: one thread per non-empty row (plus one for a source without in-edges, which
 // only ever receives returned dead-end mass): lands the row sum, detects the threshold crossing
 // and prepares the row for the next level in place.
@@ -1600,15 +1817,26 @@ static int launch_dense_edges_part(pprhip_graph* g, const double* cB, const GsBl
   }
   if (!most) return PPRHIP_OK;
   const uint32_t lines = (uint32_t)(kHotBytes / (8 * G));                       // per partition
-  const uint32_t n_hot = g->relabeled ? lines * (uint32_t)kParts : 0u;          // bound of the hot ids
+  static const bool no_hot = getenv("PPRHIP_SWEEP_NO_HOT") != nullptr;          // (measurement switch: no LDS table)
+  const uint32_t n_hot = g->relabeled && !no_hot ? lines * (uint32_t)kParts : 0u;  // bound of the hot ids
   const uint32_t per_part = std::max(1u, std::min<uint32_t>((most + 15) / 16, (uint32_t)g->n_cus / kParts));
   const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(L.flags);
-  if (n_hot)
-    k_dense_edges_b<true, G, true><<<dim3(per_part * kParts), dim3(1024), kHotBytes, g->stream>>>(
-        L.ci, flags64, L.chunk_starts, 0u, (unsigned long long)g->m, cB, g->part_acc, n_hot, 0u, 0ull, 0ull, g->n, W);
-  else
-    k_dense_edges_b<false, G, true><<<dim3(per_part * kParts), dim3(1024), 0, g->stream>>>(
-        L.ci, flags64, L.chunk_starts, 0u, (unsigned long long)g->m, cB, g->part_acc, 0u, 0u, 0ull, 0ull, g->n, W);
+  static const bool old_kernel = getenv("PPRHIP_SWEEP_EDGES_B") != nullptr;  // (measurement switch: sixteen lanes per edge)
+  const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(L.flags);
+  if (old_kernel) {
+    if (n_hot)
+      k_dense_edges_b<true, G, true><<<dim3(per_part * kParts), dim3(1024), kHotBytes, g->stream>>>(
+          L.ci, flags64, L.chunk_starts, 0u, (unsigned long long)g->m, cB, g->part_acc, n_hot, 0u, 0ull, 0ull, g->n, W);
+    else
+      k_dense_edges_b<false, G, true><<<dim3(per_part * kParts), dim3(1024), 0, g->stream>>>(
+          L.ci, flags64, L.chunk_starts, 0u, (unsigned long long)g->m, cB, g->part_acc, 0u, 0u, 0ull, 0ull, g->n, W);
+  } else if (n_hot) {
+    k_dense_edges_q<true, true><<<dim3(per_part * kParts), dim3(1024), kHotBytes, g->stream>>>(
+        L.ci, flags32, L.chunk_starts, 0u, cB, g->part_acc, n_hot, 0u, 0ull, 0ull, g->n, W);
+  } else {
+    k_dense_edges_q<false, true><<<dim3(per_part * kParts), dim3(1024), 0, g->stream>>>(
+        L.ci, flags32, L.chunk_starts, 0u, cB, g->part_acc, 0u, 0u, 0ull, 0ull, g->n, W);
+  }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -1767,6 +1995,10 @@ int init_kernels_push() {
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_q<true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_q<true, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sparse_push<kBackward>)));

@@ -172,3 +172,64 @@ def test_multi_argument_errors(pkg, rmat12, replicas, got):
             pkg.all_pair_backward_multi([replicas[0], other], A, 1e-3, 4)
     finally:
         other.close()
+
+
+@pytest.mark.timeout(900)
+def test_work_weighted_target_cut_balances_a_degree_sorted_store(pkg, monkeypatch):
+    """Eight ranks, a graph whose ids follow its in-degrees (what the import of a degree-sorted dump leaves in a store:
+    Base_Whole_Graph.java:76-92 walks the targets in id order).  Equal counts of contiguous targets give rank 0 every hub;
+    the work-weighted cut (pprhip_shard_target_cuts: a pilot measures the hubs' searches, the others are estimated from
+    their in-degree) must leave every rank within 15 % of the mean of the edge pushes - and the merged index must be the
+    single-GPU one either way.  The eight replicas share the box's one GPU (in-process transport)."""
+    base = pkg.HostCsr.rmat(18, 16, seed=1)
+    n = base.n
+    ind = np.diff(base.in_rp).astype(np.int64)
+    rank_of = np.empty(n, dtype=np.int64)
+    rank_of[np.argsort(-ind, kind="stable")] = np.arange(n)            # new id = in-degree rank
+    src = rank_of[np.repeat(np.arange(n), np.diff(base.out_rp))].astype(np.int32)
+    dst = rank_of[base.out_ci].astype(np.int32)
+    host = pkg.HostCsr(n, src, dst, False)
+    assert np.all(np.diff(np.diff(host.in_rp).astype(np.int64)) <= 0)   # ids are in in-degree order
+    thr, k, W = 1e-3, 16, 8
+    gs = [pkg.Graph(host) for _ in range(W)]
+    try:
+        cuts_eq, skew = pkg.shard_target_cuts(gs[0], W, A, thr, pkg.CUT_EQUAL)
+        cuts_w, _ = pkg.shard_target_cuts(gs[0], W, A, thr, pkg.CUT_BY_WORK)
+        cuts_auto, _ = pkg.shard_target_cuts(gs[0], W, A, thr, pkg.CUT_AUTO)
+        assert skew > 2.0 and np.array_equal(cuts_auto, cuts_w) and not np.array_equal(cuts_w, cuts_eq)
+        assert cuts_w[0] == 0 and cuts_w[-1] == n and np.all(np.diff(cuts_w.astype(np.int64)) > 0)
+        ix1, st1 = gs[0].all_pair_backward(A, thr, k)
+        ref = [x.copy() for x in ix1.arrays()]
+        ix1.close()
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ref[0]).astype(np.int64))
+        o_ref = np.argsort(rows * n + ref[1], kind="stable")
+
+        def same_index(a):
+            # the same rows with the same entries; inside a row, entries whose values differ in the last bits (the
+            # atomics' order) may swap places in the value order: compare by (row, target)
+            if not (np.array_equal(a[0], ref[0]) and len(a[1]) == len(ref[1])):
+                return False
+            o = np.argsort(rows * n + a[1], kind="stable")
+            return np.array_equal(a[1][o], ref[1][o_ref]) and np.max(np.abs(a[2][o] - ref[2][o_ref])) <= 1e-12
+
+        shares = {}
+        for mode in ("count", "work"):
+            monkeypatch.setenv("PPRHIP_SHARD_CUT", mode)
+            ix, sts = pkg.all_pair_backward_multi(gs, A, thr, k)
+            assert same_index(ix.arrays()), "the index of eight ranks (cut by %s) is not the single-GPU one" % mode
+            ix.close()
+            e = np.array([st.edge_pushes for st in sts], dtype=np.float64)
+            assert abs(e.sum() - st1.edge_pushes) <= 0.02 * st1.edge_pushes     # the same searches, dealt out differently
+            shares[mode] = e / e.mean()
+        monkeypatch.delenv("PPRHIP_SHARD_CUT")
+        print("edge pushes per rank / mean: equal counts %s, by work %s" % (np.round(shares["count"], 2), np.round(shares["work"], 2)))
+        assert shares["count"].max() > 3.0                                       # rank 0 holds the hubs
+        assert shares["work"].max() <= 1.15 and shares["work"].min() >= 0.85
+        # the default decides by the modelled skew: here by work
+        ix, sts = pkg.all_pair_backward_multi(gs, A, thr, k)
+        e = np.array([st.edge_pushes for st in sts], dtype=np.float64)
+        assert (e / e.mean()).max() <= 1.15
+        ix.close()
+    finally:
+        for g in gs:
+            g.close()

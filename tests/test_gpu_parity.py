@@ -298,7 +298,7 @@ def test_fora_batch_rmat15_many_queries(pkg, orc, rmat15, dev_rmat15):
 @pytest.mark.parametrize("graph,relabel", [("got", "1"), ("rmat12", "1"), ("rmat15", "1"), ("rmat15", "0")])
 def test_source_partitioned_batched_sweep(pkg, orc, got, rmat12, rmat15, graph, relabel, monkeypatch):
     """The batched forward sweep over the source-partitioned copy of the in-CSR (round 5: eight partitions by
-    (source id >> 6) & 7, workgroup b on partition b % 8, a row's up to eight partial sums added by the apply kernel;
+    source id & 7, workgroup b on partition b % 8, a row's up to eight partial sums added by the apply kernel;
     PPRHIP_SWEEP_PARTS=1 forces it on graphs below its default size): Jacobi sweeps and 2- and 3-block Gauss-Seidel
     sweeps, level for level and value for value the twin's, and the same as the row-major layout's (PPRHIP_SWEEP_PARTS=0)
     up to the order of the sums; with the LDS table of the partitions' hottest lines and (PPRHIP_RELABEL=0) without."""

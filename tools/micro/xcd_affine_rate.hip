@@ -71,6 +71,46 @@ __global__ __launch_bounds__(256) void k_rows_il(const double* __restrict__ tab,
   if (acc == 0.12345) out[0] = acc;
 }
 
+// the shapes of the two batched edge kernels, one 1024-thread workgroup per CU (LDS bytes of dynamic shared memory keep a
+// second one off the CU), XCD-affine rows of a 32 MB table (every 8th line):
+//   LPR = 16: sixteen lanes per row, 8 bytes each (k_dense_edges_b), IN rows in flight per lane group
+//   LPR = 4:  four lanes per row, 2 x 16 bytes each (k_dense_edges_q)
+template <int LPR, int IN>
+__global__ __launch_bounds__(1024) void k_shape(const double* __restrict__ tab, uint32_t rows_per_slice, int steps, double* out) {
+  extern __shared__ double s_pad[];
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const uint32_t grp = (blockIdx.x * 1024u + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
+  const uint32_t slice = blockIdx.x % 8u;
+  double acc = 0.0;
+  uint32_t s = mix(grp + 0x9e3779b9u);
+  if (threadIdx.x == 0) s_pad[0] = 0.0;
+  for (int t = 0; t < steps; ++t) {
+    if (LPR == 16) {
+      double v[IN];
+#pragma unroll
+      for (int i = 0; i < IN; ++i) {
+        const uint32_t h = mix(s + 0x85ebca6bu * (uint32_t)(i + 1)) % rows_per_slice;
+        v[i] = tab[(size_t)((h << 3) | slice) * 16u + sub];
+      }
+#pragma unroll
+      for (int i = 0; i < IN; ++i) acc += v[i];
+    } else {
+      v2d a[IN], b[IN];
+#pragma unroll
+      for (int i = 0; i < IN; ++i) {
+        const uint32_t h = mix(s + 0x85ebca6bu * (uint32_t)(i + 1)) % rows_per_slice;
+        const v2d* p = reinterpret_cast<const v2d*>(tab + (size_t)((h << 3) | slice) * 16u + 4u * sub);
+        a[i] = p[0];
+        b[i] = p[1];
+      }
+#pragma unroll
+      for (int i = 0; i < IN; ++i) acc += a[i].x + a[i].y + b[i].x + b[i].y;
+    }
+    s = mix(s + 1u);
+  }
+  if (acc == 0.12345) out[0] = acc + s_pad[0];
+}
+
 enum { kAtomic = 0, kStore, kLoadAddStore };
 template <int KIND>
 __global__ __launch_bounds__(256) void k_row_update(double* __restrict__ tab, uint32_t rows, int steps, double* out) {
@@ -143,6 +183,28 @@ int main() {
     const float t3 = best_of([&] { k_rows_il<3><<<grid, 256>>>(tab, rps, steps, out); });
     const float t6 = best_of([&] { k_rows_il<6><<<grid, 256>>>(tab, rps, steps, out); });
     printf("%8zu %10.1f %10.1f %10.1f\n", mb, n_rows / (t0 * 1e-3) / 1e9, n_rows / (t3 * 1e-3) / 1e9, n_rows / (t6 * 1e-3) / 1e9);
+  }
+  {
+    const uint32_t rps = (uint32_t)(((size_t)32 << 20) / 128 / 8);
+    const int g1 = 256, st = 64;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shape<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shape<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shape<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shape<16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    for (int lds_kb : {0, 128}) {
+      const float tb = best_of([&] { k_shape<16, 8><<<g1, 1024, lds_kb * 1024>>>(tab, rps, st, out); });
+      const float tb16 = best_of([&] { k_shape<16, 16><<<g1, 1024, lds_kb * 1024>>>(tab, rps, st, out); });
+      const float tq4 = best_of([&] { k_shape<4, 4><<<g1, 1024, lds_kb * 1024>>>(tab, rps, st, out); });
+      const float tq8 = best_of([&] { k_shape<4, 8><<<g1, 1024, lds_kb * 1024>>>(tab, rps, st, out); });
+      const double rb = (double)g1 * 1024 / 16 * st * 8, rb16 = (double)g1 * 1024 / 16 * st * 16;
+      const double rq4 = (double)g1 * 1024 / 4 * st * 4, rq8 = (double)g1 * 1024 / 4 * st * 8;
+      printf("one 1024-thread workgroup per CU, %3d KB LDS, affine 32 MB: 16 lanes x 8 B, 8 in flight %.1f; 16 in flight %.1f; "
+             "4 lanes x 32 B, 4 in flight %.1f; 8 in flight %.1f G lines/s\n", lds_kb, rb / (tb * 1e-3) / 1e9,
+             rb16 / (tb16 * 1e-3) / 1e9, rq4 / (tq4 * 1e-3) / 1e9, rq8 / (tq8 * 1e-3) / 1e9);
+    }
+    // and with four such workgroups' worth of waves per CU (grid 1024, no LDS): occupancy 16 waves per SIMD if registers allow
+    const float tq = best_of([&] { k_shape<4, 4><<<1024, 1024, 0>>>(tab, rps, st, out); });
+    printf("grid 1024 x 1024 threads, no LDS: 4 lanes x 32 B, 4 in flight %.1f G lines/s\n", (double)1024 * 1024 / 4 * st * 4 / (tq * 1e-3) / 1e9);
   }
   // --- (2) row updates on a 256 MB table
   const uint32_t rows = (uint32_t)(((size_t)256 << 20) / 128);
