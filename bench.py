@@ -38,8 +38,8 @@ Extra objects on the JSON line:
               SURVEY 8(d)'s per-query gather model (counts gathers L2 / LDS serve; can exceed 1; kept for comparison
               with rounds 1-2).  Without counters (`--no-pmc`) `frac` falls back to the compulsory figure.
   `cpu_baseline`  the reference's algorithm on the host cores (rank 0, N = 1), in a background process: while the GPU
-              measurements go on, the hash-map-shaped faithful port run to the end of one query on one thread and the
-              dense-array port on three sources; after them, the array port on every core this job may use (its cgroup
+              measurements go on, the hash-map-shaped faithful port run to the end of two queries (one thread each,
+              both times printed) and the dense-array port on two sources; after them, the array port on every core this job may use (its cgroup
               CPU quota), one query per core.
 After the timed region, at N = 1: `one_query_at_a_time` (the drop-in path, pprhip_fora_single_source), `topk_sample`
 (FORA top-32), `all_pair_sample` (All-Pair-Backward-Search on 2^18 targets) and `all_pair_rmat24` (config #5's graph
@@ -376,7 +376,12 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": pkg.KERNEL_NAMES[dom], "achieved": round(comp, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(comp / HBM_PEAK_GBS, 4), "frac_basis": "compulsory bytes (no counters in this run)",
-            "traffic": None, "peak_achievable": HBM_ACHIEVABLE_GBS, "launches": dom_n, "avg_launch_us": round(avg_us, 2),
+            "frac_basis_short": "compulsory",
+            "traffic": None, "peak_achievable": HBM_ACHIEVABLE_GBS,
+            # one "launch" of the class dense_pull_batch is one SWEEP: per Gauss-Seidel block an edge kernel and an apply
+            # kernel, then one reduce kernel (roofline.kernels names them as rocprofv3 does, with their own durations)
+            ("sweeps" if dom == 5 else "launches"): dom_n,
+            ("avg_sweep_us" if dom == 5 else "avg_launch_us"): round(avg_us, 2),
             "algorithmic_bytes_per_launch": int(comp_bytes),
             "algorithmic_note": "compulsory bytes: index stream, every gatherable contribution line once, row sums out "
                                 "and in, next contributions, the busy queries' residues - each counted once "
@@ -456,6 +461,8 @@ def main():
                 note("R-MAT 24 counter passes done")
             idle = stream_idle(args)
             out["compute_stream_idle_frac"] = idle.get("compute_stream_idle_frac")
+            if idle.get("sweep_kernels"):
+                out["roofline"]["kernels"] = idle.pop("sweep_kernels")
             out["stream_occupancy"] = idle
             note("kernel-trace pass done")
         if cpu_child is not None:
@@ -843,8 +850,10 @@ def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xde
             res["columns_checked"], res["entries_checked"], res["hbm_in_use_gb"]] if not err else [0.0] * 8
     stats = torch.tensor(vals[:5] + [1.0 if err else 0.0] + vals[5:], dtype=torch.float64, device=xdev)
     tmax = stats.clone()
+    tmin = stats.clone()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     if float(stats[5]) > 0:
         return {"error": err or "%d of %d ranks failed" % (int(stats[5]), world)}
@@ -852,6 +861,10 @@ def all_pair_scaling_sample(pkg, args, dist, torch, rank, world, local_rank, xde
     return {"unit": "targets/s", "scaling": "strong", "targets": n, "threshold": AP_THR, "k": TOPK,
             "value": round(n / float(tmax[0]), 1), "seconds": round(float(tmax[0]), 3),
             "search_seconds_max_rank": round(float(tmax[1]), 3),
+            # imbalance between the ranks' shares (the targets are cut by modelled work when equal counts of ids would
+            # leave one rank with more than 1.15 x the mean: pprhip_shard_target_cuts)
+            "search_seconds_min_mean_max": [round(float(tmin[1]), 3), round(float(stats[1]) / world, 3),
+                                            round(float(tmax[1]), 3)],
             "entries_found": int(stats[2]), "entries_kept_after_k_rule": int(stats[4]),
             "exchange_bytes_received": int(stats[3]),
             "self_check": {"status": "ok", "against": "pprhip_backward_push, 1e-12, on every rank's own rows",
@@ -1131,7 +1144,7 @@ def stream_idle(args):
     if len(marks) < 2:
         return {"source": "unmeasured: the trace does not hold the two marker kernels"}
     region = rows[marks[-2] + 1:marks[-1]]
-    sweeps = [x for x in region if _short(x["Kernel_Name"]).startswith("k_dense_edges_b")]
+    sweeps = [x for x in region if _short(x["Kernel_Name"]).startswith(("k_dense_edges_b", "k_dense_edges_q"))]
     if not sweeps:
         return {"source": "unmeasured: no batched sweep in the traced region"}
     main = max({x[key] for x in sweeps}, key=lambda q: sum(1 for x in sweeps if x[key] == q))
@@ -1165,7 +1178,21 @@ def stream_idle(args):
         if prev_end is None or hi > prev_end:
             prev_end, prev_name = hi, name
     top = sorted(gaps.items(), key=lambda kv: -kv[1][1])[:8]
-    return {"source": "rocprofv3 --kernel-trace child pass over two steps of the headline workload; intervals grouped by %s" % key,
+    # the kernels one sweep of the batched path is made of, under the names rocprofv3 prints, with their own durations
+    per = {}
+    for x in region:
+        name = _short(x["Kernel_Name"])
+        if name.startswith(("k_dense_edges_b", "k_dense_edges_q", "k_dense_apply_batch", "k_dense_reduce_batch")):
+            e = per.setdefault(name, [0, 0])
+            e[0] += 1
+            e[1] += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
+    n_sweeps = max(1, sum(v[0] for k, v in per.items() if k.startswith("k_dense_reduce_batch")))
+    sweep_kernels = {"sweeps_traced": n_sweeps,
+                     "per_sweep_us": round(sum(v[1] for v in per.values()) / 1e3 / n_sweeps, 1),
+                     "kernels": [{"name": k, "launches_per_sweep": round(v[0] / n_sweeps, 2),
+                                  "avg_launch_us": round(v[1] / 1e3 / v[0], 1)} for k, v in sorted(per.items())]}
+    return {"sweep_kernels": sweep_kernels,
+            "source": "rocprofv3 --kernel-trace child pass over two steps of the headline workload; intervals grouped by %s" % key,
             "compute_stream_idle_frac": round(1.0 - union(on_main) / wall, 4),
             "any_stream_idle_frac": round(1.0 - union(region) / wall, 4),
             "side_streams_busy_frac": round(union(others) / wall, 4),
@@ -1315,6 +1342,7 @@ def apply_counters(out, pmc, avg_us, extras):
     if tr:
         ach = tr / 1e9 / (avg_us / 1e6)
         roofline.update(traffic=tr, achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
+                        frac_basis_short="counter",
                         frac_basis="memory-side counters (FETCH_SIZE x calibration + WRITE_SIZE) per launch over the "
                                    "launch's duration; FETCH_SIZE includes Infinity-Cache hits: L2-miss traffic",
                         achieved_counter=round(ach, 1), frac_counter=round(ach / HBM_PEAK_GBS, 4),
@@ -1461,20 +1489,31 @@ def cpu_baseline_child(args):
         conf = og.conf_whole(ALPHA)
         _, omega = orc.fora_whole_params(conf, EPS)
         share, pcores, quota = cpu_share()
-        # ---- 1. one faithful query to the end (one thread) + the array port on three sources (three threads)
+        # ---- 1. two faithful queries to the end (one thread each: the port's time varies by a factor of 1.7 with the
+        # source and with what else runs on the shared host - 110 s in round 3, 193 s in round 4 - so one sample says
+        # little) + the array port on two sources (two threads)
         box = {}
 
         def run_arrays():
-            box["arr"] = base.fora_array_parallel(og, live[1:4], EPS, ALPHA, seed=3, walk_divisor=1, threads=3)
+            box["arr"] = base.fora_array_parallel(og, live[2:4], EPS, ALPHA, seed=3, walk_divisor=1, threads=2)
 
-        th = threading.Thread(target=run_arrays)
-        th.start()
+        def run_second():
+            t1 = time.time()
+            box["h2"] = base.fora_hashmap(og, live[1], EPS, ALPHA, seed=3, walk_divisor=1, push_budget_s=0.0)
+            box["h2_wall"] = time.time() - t1
+
+        th = [threading.Thread(target=run_arrays), threading.Thread(target=run_second)]
+        for x in th:
+            x.start()
         t0 = time.time()
         h = base.fora_hashmap(og, live[0], EPS, ALPHA, seed=3, walk_divisor=1, push_budget_s=0.0)
         h_wall = time.time() - t0
-        th.join()
-        arr = box["arr"]
+        for x in th:
+            x.join()
+        arr, h2 = box["arr"], box["h2"]
         h_query = h["push_s"] + h["walk_s"]
+        h2_query = h2["push_s"] + h2["walk_s"]
+        both = [h_query, h2_query]
         # ---- 2. every core of the job's share, one query each, once the parent's GPU measurements are over
         sys.stdin.readline()
         par_srcs = (live[4:4 + share] or live[:1])
@@ -1485,16 +1524,22 @@ def cpu_baseline_child(args):
         pq = sorted(p["per_query_s"])
         wall = time.time() - t_start
         res = {
-            "value": round(1.0 / h_query, 6) if h_query > 0 else None, "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": "faithful (hash-map-shaped) port of Forward_Push/Fora_Whole_Graph/Monte_Carlo, ONE query on source %d "
-                      "run to the end on one thread: %d turn(s) of the clock-driven loop, %.1f s of pushes (%d edge "
-                      "pushes, %.2f M/s), %d walks in %.1f s (%.2f M/s) = %.1f s; beside it the dense-array port on 3 "
-                      "sources in full (3 threads); then the array port on all %d cores of the job's share; %.0f s of "
+            "value": round(len(both) / sum(both), 6) if min(both) > 0 else None, "unit": "queries/s", "cores": 1,
+            "kind": "port",
+            "sample": "faithful (hash-map-shaped) port of Forward_Push/Fora_Whole_Graph/Monte_Carlo, TWO queries (sources %d "
+                      "and %d) each run to the end on a thread of its own: %.1f s and %.1f s; value = queries per second "
+                      "of one core = 2 / their sum.  The first: %d turn(s) of the clock-driven loop, %.1f s of pushes (%d "
+                      "edge pushes, %.2f M/s), %d walks in %.1f s (%.2f M/s); beside them the dense-array port on 2 "
+                      "sources in full (2 threads); then the array port on all %d cores of the job's share; %.0f s of "
                       "wall time in a background process, the first part beside the GPU measurements"
-                      % (live[0], h["rounds"], h["push_s"], h["edge_pushes"],
+                      % (live[0], live[1], h_query, h2_query, h["rounds"], h["push_s"], h["edge_pushes"],
                          h["edge_pushes"] / h["push_s"] / 1e6 if h["push_s"] > 0 else 0.0, h["walks_run"], h["walk_s"],
-                         h["walks_run"] / h["walk_s"] / 1e6 if h["walk_s"] > 0 else 0.0, h_query, share, wall),
-            "seconds_per_query": round(h_query, 2),
+                         h["walks_run"] / h["walk_s"] / 1e6 if h["walk_s"] > 0 else 0.0, share, wall),
+            "seconds_per_query": round(sum(both) / len(both), 2),
+            "seconds_per_query_each": [round(x, 2) for x in both], "sources": [int(live[0]), int(live[1])],
+            "faithful_second": {"turns": h2["rounds"], "push_s": round(h2["push_s"], 2), "walk_s": round(h2["walk_s"], 2),
+                                "edge_pushes": int(h2["edge_pushes"]), "walks": int(h2["walks_run"]),
+                                "truncated": bool(h2["truncated"]), "wall_s": round(box["h2_wall"], 2)},
             "faithful": {"turns": h["rounds"], "push_s": round(h["push_s"], 2), "walk_s": round(h["walk_s"], 2),
                          "edge_pushes": int(h["edge_pushes"]), "walks": int(h["walks_run"]),
                          "walks_asked_for": int(h["walks_total"]), "truncated": bool(h["truncated"]),
@@ -1503,9 +1548,9 @@ def cpu_baseline_child(args):
                                        "(HashMap/ConcurrentLinkedQueue/HashSet)"},
             "array": {"value": round(len(arr["per_query_s"]) / sum(arr["per_query_s"]), 5) if sum(arr["per_query_s"]) > 0 else None,
                       "cores": 1, "seconds_per_query_each": [round(x, 2) for x in arr["per_query_s"]],
-                      "sources": [int(s) for s in live[1:4]],
-                      "sample": "dense-array port, three sources in full (every walk), one thread each, while the "
-                                "faithful query ran on a fourth"},
+                      "sources": [int(s) for s in live[2:4]],
+                      "sample": "dense-array port, two sources in full (every walk), one thread each, while the two "
+                                "faithful queries ran on two more"},
             "all_cores": {"value": round(all_cores_qps, 5), "cores": int(min(share, len(par_srcs))),
                           "queries": len(par_srcs), "wall_s_thinned_walks": round(p["wall_s"], 2),
                           "seconds_per_query_min_median_max": [round(pq[0], 1), round(pq[len(pq) // 2], 1), round(pq[-1], 1)],

@@ -815,43 +815,151 @@ __device__ __forceinline__ int quad_bcast(int x) {
 struct Quad4 {
   double v[kQSlots];
 };
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+struct QuadRaw {  // the two 16-byte loads of a quad lane, as they come back
+  v2d_t a, b;
+};
 
-// the caller's 32 bytes of vertex u's line: from the LDS table when u is hot, from memory otherwise (a quad is uniform)
-template <bool HOT, bool PART>
-__device__ __forceinline__ Quad4 load_quarter(const double* __restrict__ cB, const double* s_hot, uint32_t n_hot, uint32_t u,
-                                              int t) {
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  v2d a, b;
-  if (HOT && u < n_hot) {
-    const v2d* p = reinterpret_cast<const v2d*>(s_hot + (size_t)(PART ? part_local(u) : u) * kBatch + kQSlots * t);
-    a = p[0];
-    b = p[1];
-  } else {
-    const v2d* p = reinterpret_cast<const v2d*>(cB + (size_t)u * kBatch + kQSlots * t);
-    a = p[0];
-    b = p[1];
-  }
-  Quad4 r;
-  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+// the caller's 32 bytes of vertex u's line.  Plain global loads on purpose: a lane-dependent choice between the LDS
+// table and memory compiles to FLAT loads, which tick both memory counters, so the loads of the next edges cannot be
+// waited for separately and every batch of edges becomes a full round trip (first form of this kernel: 500 us per
+// launch, profiles/r05_quad_kernel_study.txt).  With the partitions' lines resident in their XCD's L2 the quad shape
+// reaches 234 G lines/s from L2 alone (tools/micro/xcd_affine_rate.hip), 2.4 x what sixteen lanes per line do.
+__device__ __forceinline__ QuadRaw load_quarter(const double* __restrict__ cB, uint32_t u, int t) {
+  const v2d_t* p = reinterpret_cast<const v2d_t*>(cB + (size_t)u * kBatch + kQSlots * t);
+  QuadRaw r;
+  r.a = p[0];
+  r.b = p[1];
   return r;
 }
 
-template <bool HOT, bool PART>
+// one 512-edge chunk of the wave.  TAIL: the chunk holds edges outside the launch's window [e_lo, e_hi) (first / last
+// chunk of a block), which count as zero.
+template <bool TAIL>
+__device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, uint32_t cs, const double* __restrict__ cB,
+                                           double* __restrict__ accB, unsigned long long e_lo, unsigned long long e_hi,
+                                           int lane, int dbg) {
+  const int q = lane >> 2, t = lane & 3;
+  const uint32_t fl = cur.fl;
+  const uint32_t pc = (uint32_t)__popc(fl);
+  const uint32_t incl = wave_incl_scan_u32_dpp(t == 0 ? pc : 0u);  // segment starts up to and including this quad
+  const uint32_t before = cs + incl - pc;
+  const unsigned long long e_first = (unsigned long long)c * kChunkEdges + 32ull * q;
+  const int32_t own[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
+  double seg[kQSlots] = {0.0, 0.0, 0.0, 0.0}, first_seg[kQSlots] = {0.0, 0.0, 0.0, 0.0};
+  uint32_t k = 0;
+  // four edges per trip (4b .. 4b + 3, held by lane b / 2 of the quad); the loads of trip b + 1 are issued before the
+  // sums of trip b, so a wave always has eight to sixteen 16-byte loads in flight
+  QuadRaw nx[4];
+  auto issue = [&](int b, QuadRaw* dst) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = own[(b & 1) * 4 + i];
+      uint32_t u = (uint32_t)((b >> 1) == 0 ? quad_bcast<0>(x) : (b >> 1) == 1 ? quad_bcast<1>(x) : (b >> 1) == 2 ? quad_bcast<2>(x) : quad_bcast<3>(x));
+      if (dbg & 2) u &= 0x7fffu;  // (measurement: every gather inside 4 MB)
+      dst[i] = load_quarter(cB, u, t);
+    }
+  };
+  issue(0, nx);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    QuadRaw now[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) now[i] = nx[i];
+    if (b < 7) issue(b + 1, nx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double val[kQSlots] = {now[i].a.x, now[i].a.y, now[i].b.x, now[i].b.y};
+      if (TAIL) {
+        if (e_first + 4 * b + i < e_lo || e_first + 4 * b + i >= e_hi) {
+#pragma unroll
+          for (int x = 0; x < kQSlots; ++x) val[x] = 0.0;
+        }
+      }
+      if ((fl >> (4 * b + i)) & 1u) {
+        if (k == 0) {
+#pragma unroll
+          for (int x = 0; x < kQSlots; ++x) first_seg[x] = seg[x];  // closes the segment carried in from earlier quads
+        } else if (!(dbg & 1)) {  // a segment that starts and ends inside this quad
+          v2d_t* dst = reinterpret_cast<v2d_t*>(accB + (size_t)(before + k - 1) * kBatch + kQSlots * t);
+          v2d_t lo, hi;
+          lo.x = seg[0]; lo.y = seg[1]; hi.x = seg[2]; hi.y = seg[3];
+          __builtin_nontemporal_store(lo, dst);
+          __builtin_nontemporal_store(hi, dst + 1);
+        }
+#pragma unroll
+        for (int x = 0; x < kQSlots; ++x) seg[x] = 0.0;
+        ++k;
+      }
+#pragma unroll
+      for (int x = 0; x < kQSlots; ++x) seg[x] += val[x];
+    }
+  }
+  // segmented scan over the quads: S(q) = tail(q) + (quad q holds a segment start ? 0 : S(q - 1))
+  const bool h = k != 0;
+  double S[kQSlots];
+#pragma unroll
+  for (int x = 0; x < kQSlots; ++x) S[x] = seg[x];
+  int F = h ? 1 : 0;
+#pragma unroll
+  for (int d = kQuad; d < 64; d <<= 1) {
+    double ps[kQSlots];
+#pragma unroll
+    for (int x = 0; x < kQSlots; ++x) ps[x] = __shfl_up(S[x], d);
+    const int pf = __shfl_up(F, d);
+    if (lane >= d) {
+      if (!F) {
+#pragma unroll
+        for (int x = 0; x < kQSlots; ++x) S[x] += ps[x];
+      }
+      F |= pf;
+    }
+  }
+  double carry[kQSlots];
+#pragma unroll
+  for (int x = 0; x < kQSlots; ++x) {
+    carry[x] = __shfl_up(S[x], kQuad);
+    if (lane < kQuad) carry[x] = 0.0;
+  }
+  const unsigned long long hmask = __ballot(h);
+  if (h) {
+    const bool nonempty = q > 0 || (fl & 1u) == 0;
+    if (nonempty && before > 0) {
+      const bool started_here = (hmask & ((1ull << (q * kQuad)) - 1ull)) != 0;
+      double* dst = accB + (size_t)(before - 1) * kBatch + kQSlots * t;
+      if (started_here) {
+#pragma unroll
+        for (int x = 0; x < kQSlots; ++x) dst[x] = carry[x] + first_seg[x];
+      } else {  // began in an earlier chunk
+#pragma unroll
+        for (int x = 0; x < kQSlots; ++x) atomic_add_noret(dst + x, carry[x] + first_seg[x]);
+      }
+    }
+  }
+  if (q == 64 / kQuad - 1) {  // the segment still open at the end of the chunk
+    const uint32_t starts = cs + incl;
+    if (starts > 0) {
+#pragma unroll
+      for (int x = 0; x < kQSlots; ++x)
+        if (S[x] != 0.0) atomic_add_noret(&accB[(size_t)(starts - 1) * kBatch + kQSlots * t + x], S[x]);
+    }
+  }
+}
+
+// PART: workgroup b walks partition b % kParts of the source-partitioned copy (see k_dense_edges_b)
+template <bool PART>
 __global__ __launch_bounds__(1024) void k_dense_edges_q(const int32_t* __restrict__ in_ci,
                                                          const uint32_t* __restrict__ flags32,
                                                          const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
                                                          const double* __restrict__ cB, double* __restrict__ accB,
-                                                         uint32_t n_hot, uint32_t c_lo, unsigned long long e_lo,
-                                                         unsigned long long e_hi, uint32_t n, PartWindows W) {
-  extern __shared__ __attribute__((aligned(16))) double s_hot[];
-  typedef double v2d __attribute__((ext_vector_type(2)));
+                                                         uint32_t c_lo, unsigned long long e_lo, unsigned long long e_hi,
+                                                         PartWindows W, int dbg) {
   const int lane = lane_id();
-  const int q = lane >> 2, t = lane & 3;
   const uint32_t waves_per_block = blockDim.x >> 6;
   uint32_t stride = gridDim.x * waves_per_block;
   uint32_t c = c_lo + blockIdx.x * waves_per_block + (uint32_t)wave_id();
-  const uint32_t part = PART ? blockIdx.x % (uint32_t)kParts : 0u;
   if (PART) {
+    const uint32_t part = blockIdx.x % (uint32_t)kParts;
     const uint32_t rank = blockIdx.x / (uint32_t)kParts, wgs = gridDim.x / (uint32_t)kParts;
     stride = wgs * waves_per_block;
     c = W.c_lo[part] + rank * waves_per_block + (uint32_t)wave_id();
@@ -861,129 +969,14 @@ __global__ __launch_bounds__(1024) void k_dense_edges_q(const int32_t* __restric
   }
   ChunkRegsQ cur;
   if (c < n_chunks) cur = load_chunk_q(in_ci, flags32, c, lane);
-  if (HOT) {
-    double tv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t i = threadIdx.x + j * 1024u;
-      if (PART) {
-        const uint32_t id = part_global(i / kBatch, part);  // line i / 16 of this partition's table
-        tv[j] = id < n_hot && id < n ? cB[(size_t)id * kBatch + (i % kBatch)] : 0.0;
-      } else {
-        tv[j] = i < n_hot * kBatch ? cB[i] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t i = threadIdx.x + j * 1024u;
-      if (PART || i < n_hot * kBatch) s_hot[i] = tv[j];
-    }
-    __syncthreads();
-  }
   for (; c < n_chunks; c += stride) {
     ChunkRegsQ nxt = cur;
     const uint32_t cn = c + stride;
     if (cn < n_chunks) nxt = load_chunk_q(in_ci, flags32, cn, lane);
     const uint32_t cs = chunk_starts[c];
-    const uint32_t fl = cur.fl;
-    const uint32_t pc = (uint32_t)__popc(fl);
-    const uint32_t incl = wave_incl_scan_u32_dpp(t == 0 ? pc : 0u);  // segment starts up to and including this quad
-    const uint32_t before = cs + incl - pc;
     const unsigned long long c_e0 = (unsigned long long)c * kChunkEdges;
-    const unsigned long long e_first = c_e0 + 32ull * q;
-    const bool tail = c_e0 < e_lo || c_e0 + kChunkEdges > e_hi;  // first / last chunk of the block: edges outside count 0
-    const int32_t own[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
-    double seg[kQSlots] = {0.0, 0.0, 0.0, 0.0}, first_seg[kQSlots] = {0.0, 0.0, 0.0, 0.0};
-    uint32_t k = 0;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {  // four edges per trip: 4b .. 4b + 3, held by lane b / 2 of the quad
-      uint32_t u[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int x = own[(b & 1) * 4 + i];
-        u[i] = (uint32_t)((b >> 1) == 0 ? quad_bcast<0>(x) : (b >> 1) == 1 ? quad_bcast<1>(x) : (b >> 1) == 2 ? quad_bcast<2>(x) : quad_bcast<3>(x));
-      }
-      Quad4 val[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) val[i] = load_quarter<HOT, PART>(cB, s_hot, n_hot, u[i], t);
-      if (tail) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (e_first + 4 * b + i < e_lo || e_first + 4 * b + i >= e_hi) {
-#pragma unroll
-            for (int x = 0; x < kQSlots; ++x) val[i].v[x] = 0.0;
-          }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if ((fl >> (4 * b + i)) & 1u) {
-          if (k == 0) {
-#pragma unroll
-            for (int x = 0; x < kQSlots; ++x) first_seg[x] = seg[x];  // closes the segment carried in from earlier quads
-          } else {  // a segment that starts and ends inside this quad
-            v2d* dst = reinterpret_cast<v2d*>(accB + (size_t)(before + k - 1) * kBatch + kQSlots * t);
-            v2d lo, hi;
-            lo.x = seg[0]; lo.y = seg[1]; hi.x = seg[2]; hi.y = seg[3];
-            __builtin_nontemporal_store(lo, dst);
-            __builtin_nontemporal_store(hi, dst + 1);
-          }
-#pragma unroll
-          for (int x = 0; x < kQSlots; ++x) seg[x] = 0.0;
-          ++k;
-        }
-#pragma unroll
-        for (int x = 0; x < kQSlots; ++x) seg[x] += val[i].v[x];
-      }
-    }
-    // segmented scan over the quads: S(q) = tail(q) + (quad q holds a segment start ? 0 : S(q - 1))
-    const bool h = k != 0;
-    double S[kQSlots];
-#pragma unroll
-    for (int x = 0; x < kQSlots; ++x) S[x] = seg[x];
-    int F = h ? 1 : 0;
-#pragma unroll
-    for (int d = kQuad; d < 64; d <<= 1) {
-      double ps[kQSlots];
-#pragma unroll
-      for (int x = 0; x < kQSlots; ++x) ps[x] = __shfl_up(S[x], d);
-      const int pf = __shfl_up(F, d);
-      if (lane >= d) {
-        if (!F) {
-#pragma unroll
-          for (int x = 0; x < kQSlots; ++x) S[x] += ps[x];
-        }
-        F |= pf;
-      }
-    }
-    double carry[kQSlots];
-#pragma unroll
-    for (int x = 0; x < kQSlots; ++x) {
-      carry[x] = __shfl_up(S[x], kQuad);
-      if (lane < kQuad) carry[x] = 0.0;
-    }
-    const unsigned long long hmask = __ballot(h);
-    if (h) {
-      const bool nonempty = q > 0 || (fl & 1u) == 0;
-      if (nonempty && before > 0) {
-        const bool started_here = (hmask & ((1ull << (q * kQuad)) - 1ull)) != 0;
-        double* dst = accB + (size_t)(before - 1) * kBatch + kQSlots * t;
-        if (started_here) {
-#pragma unroll
-          for (int x = 0; x < kQSlots; ++x) dst[x] = carry[x] + first_seg[x];
-        } else {  // began in an earlier chunk
-#pragma unroll
-          for (int x = 0; x < kQSlots; ++x) atomic_add_noret(dst + x, carry[x] + first_seg[x]);
-        }
-      }
-    }
-    if (q == 64 / kQuad - 1) {  // the segment still open at the end of the chunk
-      const uint32_t starts = cs + incl;
-      if (starts > 0) {
-#pragma unroll
-        for (int x = 0; x < kQSlots; ++x)
-          if (S[x] != 0.0) atomic_add_noret(&accB[(size_t)(starts - 1) * kBatch + kQSlots * t + x], S[x]);
-      }
-    }
+    if (c_e0 < e_lo || c_e0 + kChunkEdges > e_hi) quad_chunk<true>(cur, c, cs, cB, accB, e_lo, e_hi, lane, dbg);
+    else quad_chunk<false>(cur, c, cs, cB, accB, e_lo, e_hi, lane, dbg);
     cur = nxt;
   }
 }
@@ -1797,6 +1790,22 @@ static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8
   return PPRHIP_OK;
 }
 
+static int q_dbg() {  // PPRHIP_Q_DBG (measurement switch; results are wrong with it): 1 no stores, 2 gathers inside 4 MB
+  static const int v = [] {
+    const char* e = getenv("PPRHIP_Q_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+static uint32_t edge_wgs_per_cu() {  // PPRHIP_SWEEP_WGS (measurement switch): workgroups of the quad kernel per CU
+  static const uint32_t v = [] {
+    const char* e = getenv("PPRHIP_SWEEP_WGS");
+    return e ? (uint32_t)std::max(1, atoi(e)) : 1u;
+  }();
+  return v;
+}
+
 // the same block over the source-partitioned copy: one launch, workgroup b on partition b % kParts
 template <int G>
 static int launch_dense_edges_part(pprhip_graph* g, const double* cB, const GsBlock& B) {
@@ -1830,12 +1839,11 @@ static int launch_dense_edges_part(pprhip_graph* g, const double* cB, const GsBl
     else
       k_dense_edges_b<false, G, true><<<dim3(per_part * kParts), dim3(1024), 0, g->stream>>>(
           L.ci, flags64, L.chunk_starts, 0u, (unsigned long long)g->m, cB, g->part_acc, 0u, 0u, 0ull, 0ull, g->n, W);
-  } else if (n_hot) {
-    k_dense_edges_q<true, true><<<dim3(per_part * kParts), dim3(1024), kHotBytes, g->stream>>>(
-        L.ci, flags32, L.chunk_starts, 0u, cB, g->part_acc, n_hot, 0u, 0ull, 0ull, g->n, W);
   } else {
-    k_dense_edges_q<false, true><<<dim3(per_part * kParts), dim3(1024), 0, g->stream>>>(
-        L.ci, flags32, L.chunk_starts, 0u, cB, g->part_acc, 0u, 0u, 0ull, 0ull, g->n, W);
+    // (no LDS table: two workgroups fit a CU when the registers allow)
+    const uint32_t wgs = std::max(1u, std::min<uint32_t>((most + 15) / 16, (uint32_t)g->n_cus / kParts * edge_wgs_per_cu()));
+    k_dense_edges_q<true><<<dim3(wgs * kParts), dim3(1024), 0, g->stream>>>(L.ci, flags32, L.chunk_starts, 0u, cB,
+                                                                            g->part_acc, 0u, 0ull, 0ull, W, q_dbg());
   }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
@@ -1996,10 +2004,8 @@ int init_kernels_push() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
-  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_q<true, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
-  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_q<true, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
+  hipFuncAttributes fa0;
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_q<true>)));
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sparse_push<kBackward>)));
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch<false>)));
