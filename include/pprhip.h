@@ -179,8 +179,10 @@ int pprhip_edgelist_from_neo4j_csv(const char* nodes_csv, const char* rels_csv, 
  * bit, first relationship of the chain, dense flag) and neostore.relationshipstore.db (34-byte
  * records: first/second node, type, the four chain pointers); what PPR.createDb + setupAdjMatrix
  * get through the Neo4j kernel (PPR.java:52-60,136-152).  Node id = record id.  The adjacency
- * order is the relationship-chain order HeavyGraph sees.  Dense nodes (relationship groups) are
- * not supported and reported as PPRHIP_ERR_IO. */
+ * order is the relationship-chain order HeavyGraph sees.  Dense nodes (50 relationships or more: the node record
+ * points to a chain of 25-byte relationship-group records, neostore.relationshipgroupstore.db, with separate
+ * outgoing / incoming / loop chains per type) are read as well; a group of the wrong owner or a missing group store
+ * is PPRHIP_ERR_IO. */
 int pprhip_edgelist_from_neo4j_store(const char* store_dir, pprhip_edgelist_t** out);
 int pprhip_edgelist_info(const pprhip_edgelist_t* e, uint32_t* n, uint64_t* m);
 /* Out- (incoming = 0) or in-adjacency (incoming = 1) of an edge list in the order HeavyGraph

@@ -230,7 +230,12 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   };
   // room for the entries of one pass over the range (16 bytes each; 2 GB at most): a search that finds the buffer
   // full is not run at all but listed for the next pass
-  B.out_cap = std::min<unsigned long long>(1ull << 27, std::max<unsigned long long>(1ull << 16, 16ull * n_targets));
+  // The buffer must hold what ONE search can emit (up to n entries: a hub's column), or that search would find it
+  // full on every pass: until round 5 a range of a few hub targets - 6 of R-MAT 18's in a work-weighted rank's share -
+  // was sized for 65 536 entries, the hubs' searches were repeated a thousand times (44 G edge pushes) and then
+  // dropped without an error.  Four entries per node also keeps a range of hubs from running pass after pass.
+  B.out_cap = std::min<unsigned long long>(
+      1ull << 27, std::max<unsigned long long>(std::max<unsigned long long>(1ull << 16, 16ull * n_targets), 4ull * g->n + 1024));
   if ((rc = alloc_dev((void**)&cells, sizeof(unsigned long long) * 16)) ||
       (rc = alloc_dev((void**)&B.out_rec, sizeof(TripleRec) * B.out_cap)) ||
       (rc = alloc_dev((void**)&B.overflow, sizeof(int32_t) * std::max<uint32_t>(1, n_targets))) ||
@@ -297,11 +302,21 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
           else again.push_back(-(x + 1));    // triple buffer was full: same tier again
         }
       }
+      // a search that found the buffer full although it came first in an empty one cannot ever fit: an error, not a
+      // silent loss of its entries (a pass that emitted nothing and still lists searches for another pass)
+      if (!again.empty() && valid == 0 && again.size() == (use_range ? (size_t)n_targets : list.size())) {
+        set_error("All-Pair: a search yields more than the %llu entries the record buffer holds", B.out_cap);
+        return PPRHIP_ERR_STATE;
+      }
       list.swap(again);
       use_range = false;
       if (d_list && list.size()) {
         (void)hipFree(d_list);
         d_list = nullptr;
+      }
+      if (pass == 999 && !list.empty()) {
+        set_error("All-Pair: %zu searches still waited for room in the record buffer after 1000 passes", list.size());
+        return PPRHIP_ERR_STATE;
       }
     }
     return PPRHIP_OK;

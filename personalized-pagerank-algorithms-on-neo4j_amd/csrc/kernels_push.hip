@@ -820,13 +820,17 @@ struct QuadRaw {  // the two 16-byte loads of a quad lane, as they come back
   v2d_t a, b;
 };
 
-// the caller's 32 bytes of vertex u's line.  Plain global loads on purpose: a lane-dependent choice between the LDS
+// the caller's 32 bytes of vertex u's line.  Plain global loads on purpose: a lane-dependent choice between an LDS
 // table and memory compiles to FLAT loads, which tick both memory counters, so the loads of the next edges cannot be
 // waited for separately and every batch of edges becomes a full round trip (first form of this kernel: 500 us per
 // launch, profiles/r05_quad_kernel_study.txt).  With the partitions' lines resident in their XCD's L2 the quad shape
 // reaches 234 G lines/s from L2 alone (tools/micro/xcd_affine_rate.hip), 2.4 x what sixteen lanes per line do.
-__device__ __forceinline__ QuadRaw load_quarter(const double* __restrict__ cB, uint32_t u, int t) {
-  const v2d_t* p = reinterpret_cast<const v2d_t*>(cB + (size_t)u * kBatch + kQSlots * t);
+// `lane_base` = cB + the lane's 32 bytes inside a line; the line's offset is 32-bit arithmetic where the array is
+// below 4 GB (n < 2^25: one v_lshlrev instead of a 64-bit shift and add per edge).
+template <bool WIDE>
+__device__ __forceinline__ QuadRaw load_quarter(const char* __restrict__ lane_base, uint32_t u) {
+  const v2d_t* p = WIDE ? reinterpret_cast<const v2d_t*>(lane_base + ((size_t)u << 7))
+                        : reinterpret_cast<const v2d_t*>(lane_base + (size_t)(uint32_t)(u << 7));
   QuadRaw r;
   r.a = p[0];
   r.b = p[1];
@@ -835,7 +839,11 @@ __device__ __forceinline__ QuadRaw load_quarter(const double* __restrict__ cB, u
 
 // one 512-edge chunk of the wave.  TAIL: the chunk holds edges outside the launch's window [e_lo, e_hi) (first / last
 // chunk of a block), which count as zero.
-template <bool TAIL>
+// The kernel is bound by the instructions it issues, not by memory (every gather inside 4 MB: 472 us per launch against
+// 597, profiles/r05_quad_kernel_study.txt: ~1 850 instructions per chunk, 4 cycles each on a 16-lane SIMD), so this
+// loop is written to issue few: two register sets of four edges filled in turn (no copies), the loads of trip b + 1
+// issued before the sums of trip b, one 32-bit shift per address.
+template <bool TAIL, bool WIDE>
 __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, uint32_t cs, const double* __restrict__ cB,
                                            double* __restrict__ accB, unsigned long long e_lo, unsigned long long e_hi,
                                            int lane, int dbg) {
@@ -846,30 +854,22 @@ __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, ui
   const uint32_t before = cs + incl - pc;
   const unsigned long long e_first = (unsigned long long)c * kChunkEdges + 32ull * q;
   const int32_t own[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
+  const char* lane_base = reinterpret_cast<const char*>(cB) + 32 * t;
   double seg[kQSlots] = {0.0, 0.0, 0.0, 0.0}, first_seg[kQSlots] = {0.0, 0.0, 0.0, 0.0};
   uint32_t k = 0;
-  // four edges per trip (4b .. 4b + 3, held by lane b / 2 of the quad); the loads of trip b + 1 are issued before the
-  // sums of trip b, so a wave always has eight to sixteen 16-byte loads in flight
-  QuadRaw nx[4];
-  auto issue = [&](int b, QuadRaw* dst) {
+  auto issue = [&](int b, QuadRaw* dst) {  // four edges: 4b .. 4b + 3, held by lane b / 2 of the quad
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int x = own[(b & 1) * 4 + i];
       uint32_t u = (uint32_t)((b >> 1) == 0 ? quad_bcast<0>(x) : (b >> 1) == 1 ? quad_bcast<1>(x) : (b >> 1) == 2 ? quad_bcast<2>(x) : quad_bcast<3>(x));
       if (dbg & 2) u &= 0x7fffu;  // (measurement: every gather inside 4 MB)
-      dst[i] = load_quarter(cB, u, t);
+      dst[i] = load_quarter<WIDE>(lane_base, u);
     }
   };
-  issue(0, nx);
-#pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    QuadRaw now[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) now[i] = nx[i];
-    if (b < 7) issue(b + 1, nx);
+  auto consume = [&](int b, const QuadRaw* src) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      double val[kQSlots] = {now[i].a.x, now[i].a.y, now[i].b.x, now[i].b.y};
+      double val[kQSlots] = {src[i].a.x, src[i].a.y, src[i].b.x, src[i].b.y};
       if (TAIL) {
         if (e_first + 4 * b + i < e_lo || e_first + 4 * b + i >= e_hi) {
 #pragma unroll
@@ -887,13 +887,24 @@ __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, ui
           __builtin_nontemporal_store(lo, dst);
           __builtin_nontemporal_store(hi, dst + 1);
         }
-#pragma unroll
-        for (int x = 0; x < kQSlots; ++x) seg[x] = 0.0;
         ++k;
-      }
+        // the new segment starts with this edge
 #pragma unroll
-      for (int x = 0; x < kQSlots; ++x) seg[x] += val[x];
+        for (int x = 0; x < kQSlots; ++x) seg[x] = val[x];
+      } else {
+#pragma unroll
+        for (int x = 0; x < kQSlots; ++x) seg[x] += val[x];
+      }
     }
+  };
+  QuadRaw ra[4], rb[4];
+  issue(0, ra);
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb) {
+    issue(2 * bb + 1, rb);
+    consume(2 * bb, ra);
+    if (bb < 3) issue(2 * bb + 2, ra);
+    consume(2 * bb + 1, rb);
   }
   // segmented scan over the quads: S(q) = tail(q) + (quad q holds a segment start ? 0 : S(q - 1))
   const bool h = k != 0;
@@ -946,8 +957,9 @@ __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, ui
   }
 }
 
-// PART: workgroup b walks partition b % kParts of the source-partitioned copy (see k_dense_edges_b)
-template <bool PART>
+// PART: workgroup b walks partition b % kParts of the source-partitioned copy (see k_dense_edges_b); WIDE: the
+// contribution array is 4 GB or more (64-bit line offsets)
+template <bool PART, bool WIDE>
 __global__ __launch_bounds__(1024) void k_dense_edges_q(const int32_t* __restrict__ in_ci,
                                                          const uint32_t* __restrict__ flags32,
                                                          const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
@@ -975,8 +987,8 @@ __global__ __launch_bounds__(1024) void k_dense_edges_q(const int32_t* __restric
     if (cn < n_chunks) nxt = load_chunk_q(in_ci, flags32, cn, lane);
     const uint32_t cs = chunk_starts[c];
     const unsigned long long c_e0 = (unsigned long long)c * kChunkEdges;
-    if (c_e0 < e_lo || c_e0 + kChunkEdges > e_hi) quad_chunk<true>(cur, c, cs, cB, accB, e_lo, e_hi, lane, dbg);
-    else quad_chunk<false>(cur, c, cs, cB, accB, e_lo, e_hi, lane, dbg);
+    if (c_e0 < e_lo || c_e0 + kChunkEdges > e_hi) quad_chunk<true, WIDE>(cur, c, cs, cB, accB, e_lo, e_hi, lane, dbg);
+    else quad_chunk<false, WIDE>(cur, c, cs, cB, accB, e_lo, e_hi, lane, dbg);
     cur = nxt;
   }
 }
@@ -1842,8 +1854,12 @@ static int launch_dense_edges_part(pprhip_graph* g, const double* cB, const GsBl
   } else {
     // (no LDS table: two workgroups fit a CU when the registers allow)
     const uint32_t wgs = std::max(1u, std::min<uint32_t>((most + 15) / 16, (uint32_t)g->n_cus / kParts * edge_wgs_per_cu()));
-    k_dense_edges_q<true><<<dim3(wgs * kParts), dim3(1024), 0, g->stream>>>(L.ci, flags32, L.chunk_starts, 0u, cB,
-                                                                            g->part_acc, 0u, 0ull, 0ull, W, q_dbg());
+    if ((uint64_t)g->n * kBatch * sizeof(double) >= (1ull << 32))
+      k_dense_edges_q<true, true><<<dim3(wgs * kParts), dim3(1024), 0, g->stream>>>(L.ci, flags32, L.chunk_starts, 0u, cB,
+                                                                                    g->part_acc, 0u, 0ull, 0ull, W, q_dbg());
+    else
+      k_dense_edges_q<true, false><<<dim3(wgs * kParts), dim3(1024), 0, g->stream>>>(L.ci, flags32, L.chunk_starts, 0u, cB,
+                                                                                     g->part_acc, 0u, 0ull, 0ull, W, q_dbg());
   }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
@@ -2005,7 +2021,8 @@ int init_kernels_push() {
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
   hipFuncAttributes fa0;
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_q<true>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_q<true, false>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_q<true, true>)));
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sparse_push<kBackward>)));
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch<false>)));

@@ -212,6 +212,15 @@ def test_work_weighted_target_cut_balances_a_degree_sorted_store(pkg, monkeypatc
             o = np.argsort(rows * n + a[1], kind="stable")
             return np.array_equal(a[1][o], ref[1][o_ref]) and np.max(np.abs(a[2][o] - ref[2][o_ref])) <= 1e-12
 
+        # the ranges of the weighted cut one after the other on ONE handle, merged: a range of a few hub targets yields
+        # more entries than the record buffer of a small range used to hold (round 5: the hubs' searches were repeated
+        # a thousand times and then dropped without an error)
+        shards = [gs[0].all_pair_backward(A, thr, -1, int(cuts_w[r]), int(cuts_w[r + 1]))[0] for r in range(W)]
+        assert len(shards[0].arrays()[1]) > (1 << 16)
+        merged = pkg.merge_indexes(shards, k)
+        assert same_index(merged.arrays()), "ranges of the weighted cut, merged, are not the full index"
+        for x in shards + [merged]:
+            x.close()
         shares = {}
         for mode in ("count", "work"):
             monkeypatch.setenv("PPRHIP_SHARD_CUT", mode)
