@@ -1661,7 +1661,7 @@ static int topk_round_impl(pprhip_graph_t* g, double min_rmax, double rmax, pprh
   PPRHIP_TRY(seed_scan(g, a, 1, L));
   PPRHIP_TRY(run_levels(g, a, L, st, nullptr));
   if (sum_mode == kSumRead) PPRHIP_TRY(device_sum(g, g->residue, &g->topk_rsum));
-  else if (sum_mode == kSumLaunch) PPRHIP_TRY(launch_sum(g, g->residue, act_n(g)));
+  else if (sum_mode == kSumLaunch) PPRHIP_TRY(launch_sum_partial(g, g->residue, act_n(g)));  // (the plan adds them up)
   g->topk_first = false;
   return PPRHIP_OK;
 }

@@ -400,6 +400,7 @@ struct pprhip_graph {
   pprhip::WalkPlanRec* mc_plan_rec = nullptr;  // n entries: the residue entries of a walk phase (k_mc_plan)
   // reductions / selection scratch
   double* partial = nullptr;       // 1024 partial sums
+  uint32_t sum_np = 0;             // partial sums a launch_sum_partial has left for the walk plan that follows
   uint32_t* hist = nullptr;        // 4096-bin histogram
   unsigned long long* blk_pack = nullptr;  // per-workgroup partial counters of the dense sweep
   double* blk_dead = nullptr;
@@ -470,6 +471,8 @@ int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_
                      bool write_armed = false);
 int launch_seed_dense(pprhip_graph* g, const PushArgs& a, int seed_kind, int cbuf, int out_slot, int dead_slot);
 int launch_sum(pprhip_graph* g, const double* x, uint32_t n);  // result -> ctr->sum_out
+int launch_sum_partial(pprhip_graph* g, const double* x, uint32_t n);  // partial sums -> g->partial, for the plan that follows
+bool old_small_kernels();
 inline uint32_t act_n(const pprhip_graph* g) { return g->n_act ? g->n_act : g->n; }  // entries a query's passes cover
 int launch_set_f64(pprhip_graph* g, double* p, uint32_t idx, double value);
 int launch_permute_out(pprhip_graph* g, const double* x, double* out);  // out[old] = x[old2new[old]]

@@ -287,7 +287,7 @@ int topk_step(ForaRun& r, bool yield_dense) {
       // :142-168 without a host round trip: the residue sum stays on the device, where the walk plan derives rsum and
       // the walk budget from it (:148,151) and the walk kernel reads the plan's counts; the sum reaches the host with
       // the selection's read-back
-      PPRHIP_TRY(launch_sum(g, g->residue, act_n(g)));
+      PPRHIP_TRY(launch_sum_partial(g, g->residue, act_n(g)));  // (the plan adds the partial sums up)
       g->topk_first = false;
       // :143 the estimate := copy of the push reserve (walk increments of earlier rounds are dropped), taken in the
       // plan's pass over the same range; :155-168 the walks

@@ -24,10 +24,19 @@ __global__ __launch_bounds__(256) void k_publish(const unsigned long long* __res
 __global__ __launch_bounds__(256) void k_clear(ClearList L) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
   for (int r = 0; r < L.n; ++r) {
-    unsigned long long* p = static_cast<unsigned long long*>(L.p[r]);
-    const size_t words = L.bytes[r] / 8;
-    for (size_t i = t; i < words; i += stride) p[i] = 0ull;
-    if (t < (L.bytes[r] & 7)) static_cast<unsigned char*>(L.p[r])[words * 8 + t] = 0;
+    char* base = static_cast<char*>(L.p[r]);
+    const size_t bytes = L.bytes[r];
+    // 16-byte stores over the aligned middle (the ranges are device allocations or 8-byte offsets into them), 8- and
+    // 1-byte stores for what is left at the ends
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15;
+    const size_t h = head < bytes ? head : bytes;
+    if (t < h) base[t] = 0;
+    const size_t quads = (bytes - h) / 16;
+    ulonglong2* q = reinterpret_cast<ulonglong2*>(base + h);
+    const ulonglong2 z = make_ulonglong2(0ull, 0ull);
+    for (size_t i = t; i < quads; i += stride) q[i] = z;
+    const size_t done = h + quads * 16;
+    if (t < bytes - done) base[done + t] = 0;
   }
 }
 

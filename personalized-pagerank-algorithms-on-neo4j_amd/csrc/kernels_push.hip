@@ -1529,6 +1529,82 @@ __global__ __launch_bounds__(256) void k_seed_list(uint32_t n, const double* __r
   }
 }
 
+// k_seed_list<1> in one pass (round 5): a workgroup takes tiles of 2048 consecutive nodes, a thread 8 consecutive ones -
+// its flags are one 8-byte load, its residues four 16-byte loads, its row pointers three - lists the round's start set
+// (block_tile_compact), writes the armed bits of its 8 nodes as one byte and lets the parked nodes go with one 8-byte
+// store.  Same list order (ascending ids), same bits, same flags as the two-pass kernel; 41 -> ~10 us on R-MAT 22.
+constexpr int kSeedItems = 8;
+__global__ __launch_bounds__(256) void k_seed_list_topk(uint32_t n, const double* __restrict__ res,
+                                                         const uint32_t* __restrict__ out_rp, uint8_t* __restrict__ flags,
+                                                         int32_t* __restrict__ Fn, uint32_t* __restrict__ eoffn,
+                                                         unsigned long long* counter, uint32_t* __restrict__ armed, PushArgs a) {
+  const uint32_t tile = 256u * kSeedItems;
+  const uint32_t n_tiles = (n + tile - 1) / tile;
+  for (uint32_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const uint32_t v0 = tl * tile + threadIdx.x * kSeedItems;
+    bool take[kSeedItems];
+    unsigned long long w[kSeedItems];
+    double r[kSeedItems];
+    uint32_t deg[kSeedItems];
+    uint8_t fl[kSeedItems];
+    if (v0 + kSeedItems <= n) {  // (n + 1 row pointers and n flags exist: whole groups of 8 load as vectors)
+      const unsigned long long f8 = *reinterpret_cast<const unsigned long long*>(flags + v0);
+#pragma unroll
+      for (int i = 0; i < kSeedItems; ++i) fl[i] = (uint8_t)(f8 >> (8 * i));
+      const double2* r2 = reinterpret_cast<const double2*>(res + v0);
+#pragma unroll
+      for (int i = 0; i < kSeedItems / 2; ++i) {
+        const double2 x = r2[i];
+        r[2 * i] = x.x;
+        r[2 * i + 1] = x.y;
+      }
+      const uint4* p4 = reinterpret_cast<const uint4*>(out_rp + v0);  // (v0 is a multiple of 8: 32-byte aligned)
+      const uint4 x0 = p4[0], x1 = p4[1];
+      const uint32_t last = out_rp[v0 + 8];
+      deg[0] = x0.y - x0.x; deg[1] = x0.z - x0.y; deg[2] = x0.w - x0.z; deg[3] = x1.x - x0.w;
+      deg[4] = x1.y - x1.x; deg[5] = x1.z - x1.y; deg[6] = x1.w - x1.z; deg[7] = last - x1.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < kSeedItems; ++i) {
+        const bool in = v0 + i < n;
+        fl[i] = in ? flags[v0 + i] : 0;
+        r[i] = in ? res[v0 + i] : 0.0;
+        deg[i] = in ? out_rp[v0 + i + 1] - out_rp[v0 + i] : 0u;
+      }
+    }
+    uint32_t arm_bits = 0;
+    unsigned long long f_new = 0;
+#pragma unroll
+    for (int i = 0; i < kSeedItems; ++i) {
+      const uint32_t d = deg[i];
+      const bool in = v0 + i < n;
+      const bool act = in && active_fwd(r[i], d, a.rmax);
+      take[i] = act && fl[i];  // seed_pred<1>
+      w[i] = d;
+      // meets the round's threshold without being parked (only when rmax < min_rmax): tested before the node leaves the set
+      if (a.rmax < a.min_rmax && !fl[i] && act) arm_bits |= 1u << i;
+      // unpark: parked nodes that start the round leave the set; those below min_rmax are dropped
+      uint8_t f = fl[i];
+      if (f && (act || !active_fwd(r[i], d, a.min_rmax))) f = 0;
+      f_new |= (unsigned long long)f << (8 * i);
+    }
+    block_tile_compact<kSeedItems>(take, w, counter, [&](int i, uint32_t pos, unsigned long long eo) {
+      Fn[pos] = (int32_t)(v0 + i);
+      eoffn[pos] = (uint32_t)eo;
+    });
+    if (v0 < n) {
+      if (armed) reinterpret_cast<uint8_t*>(armed)[v0 >> 3] = (uint8_t)arm_bits;
+      if (v0 + kSeedItems <= n) {
+        *reinterpret_cast<unsigned long long*>(flags + v0) = f_new;
+      } else {
+#pragma unroll
+        for (int i = 0; i < kSeedItems; ++i)
+          if (v0 + i < n) flags[v0 + i] = (uint8_t)(f_new >> (8 * i));
+      }
+    }
+  }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void k_seed_dense(uint32_t n, double* __restrict__ res, double* __restrict__ reserve,
                                                      const uint32_t* __restrict__ out_rp, uint8_t* __restrict__ flags,
@@ -1966,6 +2042,11 @@ int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int o
   return reduce_partials(g, grid, out_slot, 0, false);
 }
 
+bool old_small_kernels() {  // PPRHIP_TOPK_OLD_PASSES=1 (measurement switch): the two-pass kernels of rounds 1-4
+  static const bool v = getenv("PPRHIP_TOPK_OLD_PASSES") != nullptr;
+  return v;
+}
+
 int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter,
                      bool write_armed) {
   // 1024 nodes per workgroup (fewer or more were slower); a slot of a threaded batch keeps the cap of 1024
@@ -1974,7 +2055,13 @@ int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_
   if (seed_kind == 0)
     k_seed_list<0><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags, g->F[out_fbuf],
                                                             g->eoff[out_fbuf], d_counter, nullptr, a);
-  else
+  else if (write_armed && !old_small_kernels()) {
+    // (the one-pass form always rewrites the flags and the armed bits of every node: the round-start call)
+    const uint32_t tiles = (act_n(g) + 256u * kSeedItems - 1) / (256u * kSeedItems);
+    k_seed_list_topk<<<dim3(std::max(1u, tiles)), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags,
+                                                                            g->F[out_fbuf], g->eoff[out_fbuf], d_counter,
+                                                                            g->armed, a);
+  } else
     k_seed_list<1><<<dim3(grid), dim3(256), 0, g->stream>>>(act_n(g), g->residue, g->out_rp, g->flags, g->F[out_fbuf],
                                                             g->eoff[out_fbuf], d_counter, write_armed ? g->armed : nullptr, a);
   PPRHIP_CHECK_HIP(hipGetLastError());
@@ -2000,6 +2087,18 @@ int launch_sum(pprhip_graph* g, const double* x, uint32_t n) {
   k_sum_partial<<<dim3(np), dim3(256), 0, g->stream>>>(x, n, g->partial);
   k_sum_final<<<dim3(1), dim3(256), 0, g->stream>>>(g->partial, np, g->ctr);
   PPRHIP_CHECK_HIP(hipGetLastError());
+  g->sum_np = 0;
+  return PPRHIP_OK;
+}
+
+// the partial sums only: the walk plan that follows (launch_mc_plan with the budget derived on the device) adds them up
+// itself, in every workgroup - one launch less on the chain of a top-k round
+int launch_sum_partial(pprhip_graph* g, const double* x, uint32_t n) {
+  if (old_small_kernels()) return launch_sum(g, x, n);
+  const uint32_t np = grid_for(n, 256 * 8, 1024);
+  k_sum_partial<<<dim3(np), dim3(256), 0, g->stream>>>(x, n, g->partial);
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  g->sum_np = np;
   return PPRHIP_OK;
 }
 

@@ -12,6 +12,13 @@ namespace pprhip {
 
 constexpr int kHistBins = 4096;
 
+// AGG (the first pass, whose digit is sign + exponent): the entries of a query's estimate lie within a few dozen
+// exponents, so the 64 lanes of a wave hit a handful of bins and their LDS atomics on one address are served one after
+// the other; here the lanes that hold the leader's bin are counted with a ballot and the leader adds them at once - a
+// few trips per wave instead of up to 64 (round 5: 21 -> ~9 us per pass over R-MAT 22's live range).  Later passes
+// (mantissa digits: uniform bins) keep one atomic per lane.  A thread takes 4 consecutive entries per trip (two
+// 16-byte loads in flight).
+template <bool AGG>
 __global__ __launch_bounds__(256) void k_select_hist(const double* __restrict__ x, uint32_t n,
                                                       unsigned long long prefix, int prefix_bits, int digit_bits,
                                                       uint32_t* __restrict__ hist, unsigned long long* zero_word) {
@@ -21,12 +28,38 @@ __global__ __launch_bounds__(256) void k_select_hist(const double* __restrict__ 
   for (int b = threadIdx.x; b < bins; b += blockDim.x) s_hist[b] = 0;
   __syncthreads();
   const int shift = 64 - prefix_bits - digit_bits;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const double v = x[i];
-    if (!(v > 0.0)) continue;
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-    if (prefix_bits > 0 && (bits >> (64 - prefix_bits)) != prefix) continue;
-    atomicAdd(&s_hist[(bits >> shift) & (unsigned long long)(bins - 1)], 1u);
+  const int lane = lane_id();
+  const uint32_t n4 = (n + 3u) / 4u;  // groups of 4 entries (the array is allocated for n rounded up: engine.cpp)
+  for (uint32_t g4 = blockIdx.x * blockDim.x + threadIdx.x; g4 - threadIdx.x % 64u < n4; g4 += gridDim.x * blockDim.x) {
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (g4 < n4) {
+      if (4u * g4 + 4u <= n) {
+        const double2* p = reinterpret_cast<const double2*>(x + 4u * (size_t)g4);
+        const double2 a = p[0], b = p[1];
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+      } else {
+        for (int i = 0; i < 4; ++i)
+          if (4u * g4 + i < n) v[i] = x[4u * (size_t)g4 + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(v[i]);
+      const bool valid = v[i] > 0.0 && !(prefix_bits > 0 && (bits >> (64 - prefix_bits)) != prefix);
+      const uint32_t bin = (uint32_t)((bits >> shift) & (unsigned long long)(bins - 1));
+      if (AGG) {
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
+          const unsigned long long same = __ballot(valid && bin == lb);
+          if (lane == leader) atomicAdd(&s_hist[lb], (uint32_t)__popcll(same));
+          todo &= ~same;
+        }
+      } else if (valid) {
+        atomicAdd(&s_hist[bin], 1u);
+      }
+    }
   }
   __syncthreads();
   for (int b = threadIdx.x; b < bins; b += blockDim.x) {
@@ -130,7 +163,8 @@ __global__ __launch_bounds__(256) void k_select_gather(const double* __restrict_
 
 int init_kernels_select() {  // loads this file's code object on the current device (see init_kernels_push)
   hipFuncAttributes fa;
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_select_hist)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_select_hist<true>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_select_hist<false>)));
   return PPRHIP_OK;
 }
 
@@ -141,8 +175,12 @@ int launch_select_hist(pprhip_graph* g, const double* x, uint32_t n, unsigned lo
   uint64_t b = ((uint64_t)n + 256 * 8 - 1) / (256 * 8);
   const uint32_t grid = (uint32_t)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
   if (!first_pass) PPRHIP_CHECK_HIP(hipMemsetAsync(g->hist, 0, sizeof(uint32_t) * kHistBins, g->stream));
-  hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(256), 0, g->stream, x, n, prefix, prefix_bits, digit_bits,
-                     g->hist, first_pass ? reinterpret_cast<unsigned long long*>(g->sel_blob) : nullptr);
+  if (prefix_bits == 0)
+    hipLaunchKernelGGL(k_select_hist<true>, dim3(grid), dim3(256), 0, g->stream, x, n, prefix, prefix_bits, digit_bits,
+                       g->hist, first_pass ? reinterpret_cast<unsigned long long*>(g->sel_blob) : nullptr);
+  else
+    hipLaunchKernelGGL(k_select_hist<false>, dim3(grid), dim3(256), 0, g->stream, x, n, prefix, prefix_bits, digit_bits,
+                       g->hist, first_pass ? reinterpret_cast<unsigned long long*>(g->sel_blob) : nullptr);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

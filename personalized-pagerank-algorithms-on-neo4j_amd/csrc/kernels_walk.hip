@@ -171,6 +171,89 @@ __global__ __launch_bounds__(256) void k_mc_plan(uint32_t n, const double* __res
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) copy_dst[v] = copy_src[v];
 }
 
+// k_mc_plan<1> with the device-side budget, in one pass (round 5; top-k rounds, Fora_Topk.java:148-159).  What the
+// two-pass kernel did in 44 us for 2 M nodes - and the two sum kernels in front of it in 20 - happens here per tile of
+// 2048 consecutive nodes, 8 per thread: every workgroup first adds up the `np` partial sums k_sum_partial has left (the
+// same additions in the same order in every workgroup, so all of them derive the same budget; no k_sum_final launch),
+// then a thread loads its 8 residues (and 8 reserves, when the estimate is to start as their copy: 16-byte loads),
+// evaluates its entries once, and the tile is compacted with one workgroup scan and one packed atomic.
+constexpr int kPlanItems = 8;
+__global__ __launch_bounds__(256) void k_mc_plan_topk(uint32_t n, const double* __restrict__ res, double alpha,
+                                                       double omega_dev, const double* __restrict__ partial, uint32_t np,
+                                                       const unsigned long long* __restrict__ out_ext,
+                                                       const int32_t* __restrict__ new2old, WalkPlanRec* __restrict__ plan,
+                                                       DevCounters* ctr, int parity, int next_cell,
+                                                       const double* __restrict__ copy_src, double* __restrict__ copy_dst) {
+  __shared__ double s_red[4];
+  __shared__ double s_sum;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctr->mc_plan[next_cell] = 0ull;  // (engine.hpp: DevCounters::mc_plan)
+  {
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < np; i += 256) acc += partial[i];
+    const double sum = block_sum_f64(acc, s_red);
+    if (threadIdx.x == 0) s_sum = sum;
+    __syncthreads();
+  }
+  const double sum = s_sum;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctr->sum_out = sum;
+    ctr->plan_sum[parity] = sum;  // for the round's selection header
+  }
+  // the budget with the host's own expressions: rsum = sum * (1 - alpha); nrw = (long long)(omega * rsum)
+  const double rsum = sum * (1.0 - alpha);
+  const double nrw_d = omega_dev * rsum;
+  const double nrw = (nrw_d == nrw_d && nrw_d > 0.0) ? (double)(long long)nrw_d : 0.0;
+  const uint32_t tile = 256u * kPlanItems;
+  const uint32_t n_tiles = (n + tile - 1) / tile;
+  for (uint32_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const uint32_t v0 = tl * tile + threadIdx.x * kPlanItems;
+    double r[kPlanItems];
+    if (v0 + kPlanItems <= n) {
+      const double2* r2 = reinterpret_cast<const double2*>(res + v0);
+#pragma unroll
+      for (int i = 0; i < kPlanItems / 2; ++i) {
+        const double2 x = r2[i];
+        r[2 * i] = x.x;
+        r[2 * i + 1] = x.y;
+      }
+      if (copy_dst) {
+        const double2* s2 = reinterpret_cast<const double2*>(copy_src + v0);
+        double2* d2 = reinterpret_cast<double2*>(copy_dst + v0);
+        double2 y[kPlanItems / 2];
+#pragma unroll
+        for (int i = 0; i < kPlanItems / 2; ++i) y[i] = s2[i];
+#pragma unroll
+        for (int i = 0; i < kPlanItems / 2; ++i) d2[i] = y[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kPlanItems; ++i) {
+        r[i] = v0 + i < n ? res[v0 + i] : 0.0;
+        if (copy_dst && v0 + i < n) copy_dst[v0 + i] = copy_src[v0 + i];
+      }
+    }
+    bool take[kPlanItems];
+    unsigned long long w[kPlanItems];
+    double inc[kPlanItems];
+#pragma unroll
+    for (int i = 0; i < kPlanItems; ++i) {
+      w[i] = 0;
+      inc[i] = 0.0;
+      take[i] = plan_entry<1>(r[i], alpha, rsum, nrw, &w[i], &inc[i]);
+    }
+    block_tile_compact<kPlanItems>(take, w, &ctr->mc_plan[parity], [&](int i, uint32_t pos, unsigned long long woff) {
+      const uint32_t v = v0 + (uint32_t)i;
+      WalkPlanRec rec;
+      rec.inc = inc[i];
+      rec.woff = woff;
+      rec.ext = out_ext[v];
+      rec.node = (int32_t)v;
+      rec.orig = new2old[v];
+      plan[pos] = rec;
+    });
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // walk kernel: one wave per workgroup, each with a contiguous share of the phase's walks.  A lane whose walk has
 // stopped takes the wave's next walk at once, so lanes stay busy although walk lengths are geometric, and the wave only
@@ -442,7 +525,14 @@ int launch_mc_plan(pprhip_graph* g, int variant, double alpha, double rsum, doub
   uint64_t b = ((uint64_t)n + 1023) / 1024;  // 1024 nodes per workgroup (fewer or more were slower)
   const uint64_t cap = g->sync ? 1024 : 16384;  // (a slot of a threaded batch: see launch_seed_list)
   const uint32_t grid = (uint32_t)(b > cap ? cap : (b < 1 ? 1 : b));
-  if (variant == 0)
+  const uint32_t np = g->sum_np;  // partial sums a launch_sum_partial has just left for this plan (0: none)
+  g->sum_np = 0;
+  if (variant == 1 && omega_dev > 0.0 && np > 0) {
+    const uint32_t tiles = (n + 256u * kPlanItems - 1) / (256u * kPlanItems);
+    hipLaunchKernelGGL(k_mc_plan_topk, dim3(std::max(1u, tiles)), dim3(256), 0, g->stream, n, g->residue, alpha, omega_dev,
+                       g->partial, np, g->out_ext, g->new2old, plan_rec_of(g, phase), g->ctr, cell, next_cell, copy_src,
+                       copy_dst);
+  } else if (variant == 0)
     hipLaunchKernelGGL(k_mc_plan<0>, dim3(grid), dim3(256), 0, g->stream, n, g->residue, target, alpha, rsum, nrw,
                        omega_dev, g->out_ext, g->new2old, plan_rec_of(g, phase), g->ctr, cell, next_cell, copy_src, copy_dst);
   else
