@@ -46,6 +46,10 @@ __host__ __device__ inline uint32_t part_of(uint32_t id) { return id & (uint32_t
 // position of an id among the ids of its own partition, and back
 __host__ __device__ inline uint32_t part_local(uint32_t id) { return id >> 3; }
 __host__ __device__ inline uint32_t part_global(uint32_t local, uint32_t p) { return (local << 3) | p; }
+// Rows of at most kPartWholeRow in-edges are not cut: all their edges go to the partition of their row ordinal (one
+// segment, one partial line) - on R-MAT 22 that leaves 4.8 M segments of 7.7 M for 8 % of the edges gathered off
+// their source's partition.
+constexpr uint32_t kPartWholeRow = 16;
 constexpr int kTileRows = 64;   // rows per tile of the batched apply kernel (kernels_push.hip: kApplyRows)
 
 // packed frontier counter: entries in the high 28 bits, edge total in the low 36 bits

@@ -809,7 +809,8 @@ __device__ __forceinline__ ChunkRegsQ load_chunk_q(const int32_t* __restrict__ i
 // value of lane K of the caller's quad
 template <int K>
 __device__ __forceinline__ int quad_bcast(int x) {
-  return dpp_i32<K * 0x55, 0xf>(x);  // quad_perm:[K,K,K,K]
+  // quad_perm:[K,K,K,K]; every lane has a source, so the "old" operand is never used: passing x saves its v_mov
+  return __builtin_amdgcn_update_dpp(x, x, K * 0x55, 0xf, 0xf, false);
 }
 
 struct Quad4 {
@@ -828,14 +829,22 @@ struct QuadRaw {  // the two 16-byte loads of a quad lane, as they come back
 // `lane_base` = cB + the lane's 32 bytes inside a line; the line's offset is 32-bit arithmetic where the array is
 // below 4 GB (n < 2^25: one v_lshlrev instead of a 64-bit shift and add per edge).
 template <bool WIDE>
-__device__ __forceinline__ QuadRaw load_quarter(const char* __restrict__ lane_base, uint32_t u) {
-  const v2d_t* p = WIDE ? reinterpret_cast<const v2d_t*>(lane_base + ((size_t)u << 7))
-                        : reinterpret_cast<const v2d_t*>(lane_base + (size_t)(uint32_t)(u << 7));
+__device__ __forceinline__ QuadRaw load_quarter(const double* __restrict__ cB, uint32_t u, uint32_t lane_off) {
+  // uniform base + 32-bit per-lane offset (the saddr form of global_load: one v_lshl_add_u32 per edge) where the array
+  // is below 4 GB; 64-bit arithmetic otherwise
+  const v2d_t* p = WIDE ? reinterpret_cast<const v2d_t*>(reinterpret_cast<const char*>(cB) + (((size_t)u << 7) + lane_off))
+                        : reinterpret_cast<const v2d_t*>(reinterpret_cast<const char*>(cB) + (size_t)(uint32_t)((u << 7) + lane_off));
   QuadRaw r;
-  r.a = p[0];
-  r.b = p[1];
+  r.a = p[0];  // the line's first 64 bytes: the quad's four lanes read them as one contiguous piece
+  r.b = p[4];  // ... and its second 64 bytes
   return r;
 }
+
+// lane t of a quad holds the slots 2t, 2t + 1 (first half of the line) and 8 + 2t, 9 + 2t (second half): each of its two
+// 16-byte accesses is then part of 64 contiguous bytes per quad.  (With 32 contiguous bytes per lane every instruction
+// touched four 16-byte pieces 32 bytes apart: 15.2 M write requests for 3.8 M partial-sum lines per launch,
+// profiles/r05_pmc_sweep_quad.txt.)
+__device__ __forceinline__ int qslot(int t, int x) { return x < 2 ? 2 * t + x : 8 + 2 * t + (x - 2); }
 
 // one 512-edge chunk of the wave.  TAIL: the chunk holds edges outside the launch's window [e_lo, e_hi) (first / last
 // chunk of a block), which count as zero.
@@ -846,7 +855,7 @@ __device__ __forceinline__ QuadRaw load_quarter(const char* __restrict__ lane_ba
 template <bool TAIL, bool WIDE>
 __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, uint32_t cs, const double* __restrict__ cB,
                                            double* __restrict__ accB, unsigned long long e_lo, unsigned long long e_hi,
-                                           int lane, int dbg) {
+                                           int lane, v2d_t* my_first) {
   const int q = lane >> 2, t = lane & 3;
   const uint32_t fl = cur.fl;
   const uint32_t pc = (uint32_t)__popc(fl);
@@ -854,16 +863,15 @@ __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, ui
   const uint32_t before = cs + incl - pc;
   const unsigned long long e_first = (unsigned long long)c * kChunkEdges + 32ull * q;
   const int32_t own[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
-  const char* lane_base = reinterpret_cast<const char*>(cB) + 32 * t;
-  double seg[kQSlots] = {0.0, 0.0, 0.0, 0.0}, first_seg[kQSlots] = {0.0, 0.0, 0.0, 0.0};
+  const uint32_t lane_off = 16u * (uint32_t)t;
+  double seg[kQSlots] = {0.0, 0.0, 0.0, 0.0};
   uint32_t k = 0;
   auto issue = [&](int b, QuadRaw* dst) {  // four edges: 4b .. 4b + 3, held by lane b / 2 of the quad
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int x = own[(b & 1) * 4 + i];
-      uint32_t u = (uint32_t)((b >> 1) == 0 ? quad_bcast<0>(x) : (b >> 1) == 1 ? quad_bcast<1>(x) : (b >> 1) == 2 ? quad_bcast<2>(x) : quad_bcast<3>(x));
-      if (dbg & 2) u &= 0x7fffu;  // (measurement: every gather inside 4 MB)
-      dst[i] = load_quarter<WIDE>(lane_base, u);
+      const uint32_t u = (uint32_t)((b >> 1) == 0 ? quad_bcast<0>(x) : (b >> 1) == 1 ? quad_bcast<1>(x) : (b >> 1) == 2 ? quad_bcast<2>(x) : quad_bcast<3>(x));
+      dst[i] = load_quarter<WIDE>(cB, u, lane_off);
     }
   };
   auto consume = [&](int b, const QuadRaw* src) {
@@ -877,24 +885,25 @@ __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, ui
         }
       }
       if ((fl >> (4 * b + i)) & 1u) {
+        v2d_t lo, hi;
+        lo.x = seg[0]; lo.y = seg[1]; hi.x = seg[2]; hi.y = seg[3];
         if (k == 0) {
-#pragma unroll
-          for (int x = 0; x < kQSlots; ++x) first_seg[x] = seg[x];  // closes the segment carried in from earlier quads
-        } else if (!(dbg & 1)) {  // a segment that starts and ends inside this quad
-          v2d_t* dst = reinterpret_cast<v2d_t*>(accB + (size_t)(before + k - 1) * kBatch + kQSlots * t);
-          v2d_t lo, hi;
-          lo.x = seg[0]; lo.y = seg[1]; hi.x = seg[2]; hi.y = seg[3];
+          // closes the segment carried in from earlier quads: parked in the lane's own 32 bytes of LDS until the scan
+          // (kept in registers, the compiler merges this branch with the store below through eight 64-bit moves per
+          // segment start)
+          my_first[0] = lo;
+          my_first[1] = hi;
+        } else {  // a segment that starts and ends inside this quad
+          v2d_t* dst = reinterpret_cast<v2d_t*>(accB + (size_t)(before + k - 1) * kBatch + 2 * t);
           __builtin_nontemporal_store(lo, dst);
-          __builtin_nontemporal_store(hi, dst + 1);
+          __builtin_nontemporal_store(hi, dst + 4);
         }
         ++k;
-        // the new segment starts with this edge
 #pragma unroll
-        for (int x = 0; x < kQSlots; ++x) seg[x] = val[x];
-      } else {
-#pragma unroll
-        for (int x = 0; x < kQSlots; ++x) seg[x] += val[x];
+        for (int x = 0; x < kQSlots; ++x) seg[x] = 0.0;
       }
+#pragma unroll
+      for (int x = 0; x < kQSlots; ++x) seg[x] += val[x];
     }
   };
   QuadRaw ra[4], rb[4];
@@ -908,6 +917,11 @@ __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, ui
   }
   // segmented scan over the quads: S(q) = tail(q) + (quad q holds a segment start ? 0 : S(q - 1))
   const bool h = k != 0;
+  double first_seg[kQSlots] = {0.0, 0.0, 0.0, 0.0};
+  if (h) {  // (the lane's own stores: no barrier)
+    const v2d_t lo = my_first[0], hi = my_first[1];
+    first_seg[0] = lo.x; first_seg[1] = lo.y; first_seg[2] = hi.x; first_seg[3] = hi.y;
+  }
   double S[kQSlots];
 #pragma unroll
   for (int x = 0; x < kQSlots; ++x) S[x] = seg[x];
@@ -937,13 +951,13 @@ __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, ui
     const bool nonempty = q > 0 || (fl & 1u) == 0;
     if (nonempty && before > 0) {
       const bool started_here = (hmask & ((1ull << (q * kQuad)) - 1ull)) != 0;
-      double* dst = accB + (size_t)(before - 1) * kBatch + kQSlots * t;
+      double* dst = accB + (size_t)(before - 1) * kBatch;
       if (started_here) {
 #pragma unroll
-        for (int x = 0; x < kQSlots; ++x) dst[x] = carry[x] + first_seg[x];
+        for (int x = 0; x < kQSlots; ++x) dst[qslot(t, x)] = carry[x] + first_seg[x];
       } else {  // began in an earlier chunk
 #pragma unroll
-        for (int x = 0; x < kQSlots; ++x) atomic_add_noret(dst + x, carry[x] + first_seg[x]);
+        for (int x = 0; x < kQSlots; ++x) atomic_add_noret(dst + qslot(t, x), carry[x] + first_seg[x]);
       }
     }
   }
@@ -952,7 +966,7 @@ __device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, ui
     if (starts > 0) {
 #pragma unroll
       for (int x = 0; x < kQSlots; ++x)
-        if (S[x] != 0.0) atomic_add_noret(&accB[(size_t)(starts - 1) * kBatch + kQSlots * t + x], S[x]);
+        if (S[x] != 0.0) atomic_add_noret(&accB[(size_t)(starts - 1) * kBatch + qslot(t, x)], S[x]);
     }
   }
 }
@@ -965,8 +979,10 @@ __global__ __launch_bounds__(1024) void k_dense_edges_q(const int32_t* __restric
                                                          const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
                                                          const double* __restrict__ cB, double* __restrict__ accB,
                                                          uint32_t c_lo, unsigned long long e_lo, unsigned long long e_hi,
-                                                         PartWindows W, int dbg) {
+                                                         PartWindows W) {
+  __shared__ v2d_t s_first[1024 * 2];  // per lane: the carried-in segment's partial sum until the chunk's scan (32 KB)
   const int lane = lane_id();
+  v2d_t* my_first = &s_first[2 * threadIdx.x];
   const uint32_t waves_per_block = blockDim.x >> 6;
   uint32_t stride = gridDim.x * waves_per_block;
   uint32_t c = c_lo + blockIdx.x * waves_per_block + (uint32_t)wave_id();
@@ -987,8 +1003,8 @@ __global__ __launch_bounds__(1024) void k_dense_edges_q(const int32_t* __restric
     if (cn < n_chunks) nxt = load_chunk_q(in_ci, flags32, cn, lane);
     const uint32_t cs = chunk_starts[c];
     const unsigned long long c_e0 = (unsigned long long)c * kChunkEdges;
-    if (c_e0 < e_lo || c_e0 + kChunkEdges > e_hi) quad_chunk<true, WIDE>(cur, c, cs, cB, accB, e_lo, e_hi, lane, dbg);
-    else quad_chunk<false, WIDE>(cur, c, cs, cB, accB, e_lo, e_hi, lane, dbg);
+    if (c_e0 < e_lo || c_e0 + kChunkEdges > e_hi) quad_chunk<true, WIDE>(cur, c, cs, cB, accB, e_lo, e_hi, lane, my_first);
+    else quad_chunk<false, WIDE>(cur, c, cs, cB, accB, e_lo, e_hi, lane, my_first);
     cur = nxt;
   }
 }
@@ -1169,34 +1185,41 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
       const uint32_t row0 = tl * kApplyRows;
       if (PART) {
         const bool have = in && tl < n_tiles_nz;  // (the tiles behind the rows with in-edges hold no sums)
-        unsigned long long mk[kParts], cr[kParts];
-        uint32_t s0[kParts];
-#pragma unroll
-        for (int p = 0; p < kParts; ++p) {
-          mk[p] = have ? tile_mask[(size_t)p * n_tiles_nz + tl] : 0ull;
-          cr[p] = have ? tile_cross[(size_t)p * n_tiles_nz + tl] : 0ull;
-          s0[p] = have ? tile_seg0[(size_t)p * (n_tiles_nz + 1) + tl] : 0u;
-        }
+        // lane s < kParts of a row's 16 lanes derives the row's segment ordinal in partition s (one mask word, one
+        // popcount) and the others receive it with a swizzle: eight ordinals per ROW instead of per element
+        const int sl = tid & (kBatch - 1);
+        const int pp = sl & (kParts - 1);
+        const unsigned long long mk = have ? tile_mask[(size_t)pp * n_tiles_nz + tl] : 0ull;
+        const unsigned long long cr = have ? tile_cross[(size_t)pp * n_tiles_nz + tl] : 0ull;
+        const uint32_t s0 = have ? tile_seg0[(size_t)pp * (n_tiles_nz + 1) + tl] : 0u;
 #pragma unroll
         for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
           const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
           const uint32_t r = idx / kBatch, s = idx % kBatch;
+          const bool has = (mk >> r) & 1ull;
+          // bit 31: the segment is one that is summed with atomics (cleared when read)
+          const uint32_t mine = has ? ((s0 + (uint32_t)__popcll(mk & ((1ull << r) - 1ull))) | (((cr >> r) & 1ull) ? 0x80000000u : 0u))
+                                    : n_seg;
           // all of a row's partial lines are requested together: rows without a segment in a partition read the
           // all-zero line behind the last segment instead of branching around the load
           double x[kParts];
-          size_t at[kParts];
+          uint32_t ord[kParts];
+          ord[0] = (uint32_t)group_bcast<kBatch, 0>((int)mine);
+          ord[1] = (uint32_t)group_bcast<kBatch, 1>((int)mine);
+          ord[2] = (uint32_t)group_bcast<kBatch, 2>((int)mine);
+          ord[3] = (uint32_t)group_bcast<kBatch, 3>((int)mine);
+          ord[4] = (uint32_t)group_bcast<kBatch, 4>((int)mine);
+          ord[5] = (uint32_t)group_bcast<kBatch, 5>((int)mine);
+          ord[6] = (uint32_t)group_bcast<kBatch, 6>((int)mine);
+          ord[7] = (uint32_t)group_bcast<kBatch, 7>((int)mine);
 #pragma unroll
-          for (int p = 0; p < kParts; ++p) {
-            const bool has = (mk[p] >> r) & 1ull;
-            const uint32_t ord = has ? s0[p] + (uint32_t)__popcll(mk[p] & ((1ull << r) - 1ull)) : n_seg;
-            at[p] = (size_t)ord * kBatch + s;
-            x[p] = __builtin_nontemporal_load(&part_acc[at[p]]);
-          }
+          for (int p = 0; p < kParts; ++p)
+            x[p] = __builtin_nontemporal_load(&part_acc[(size_t)(ord[p] & 0x7fffffffu) * kBatch + s]);
           double v = 0.0;
 #pragma unroll
           for (int p = 0; p < kParts; ++p) {
             v += x[p];
-            if (x[p] != 0.0 && ((cr[p] >> r) & 1ull)) part_acc[at[p]] = 0.0;
+            if (x[p] != 0.0 && (ord[p] & 0x80000000u)) part_acc[(size_t)(ord[p] & 0x7fffffffu) * kBatch + s] = 0.0;
           }
           tile[g][r][s] = v;
         }
@@ -1878,14 +1901,6 @@ static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8
   return PPRHIP_OK;
 }
 
-static int q_dbg() {  // PPRHIP_Q_DBG (measurement switch; results are wrong with it): 1 no stores, 2 gathers inside 4 MB
-  static const int v = [] {
-    const char* e = getenv("PPRHIP_Q_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
 static uint32_t edge_wgs_per_cu() {  // PPRHIP_SWEEP_WGS (measurement switch): workgroups of the quad kernel per CU
   static const uint32_t v = [] {
     const char* e = getenv("PPRHIP_SWEEP_WGS");
@@ -1932,10 +1947,10 @@ static int launch_dense_edges_part(pprhip_graph* g, const double* cB, const GsBl
     const uint32_t wgs = std::max(1u, std::min<uint32_t>((most + 15) / 16, (uint32_t)g->n_cus / kParts * edge_wgs_per_cu()));
     if ((uint64_t)g->n * kBatch * sizeof(double) >= (1ull << 32))
       k_dense_edges_q<true, true><<<dim3(wgs * kParts), dim3(1024), 0, g->stream>>>(L.ci, flags32, L.chunk_starts, 0u, cB,
-                                                                                    g->part_acc, 0u, 0ull, 0ull, W, q_dbg());
+                                                                                    g->part_acc, 0u, 0ull, 0ull, W);
     else
       k_dense_edges_q<true, false><<<dim3(wgs * kParts), dim3(1024), 0, g->stream>>>(L.ci, flags32, L.chunk_starts, 0u, cB,
-                                                                                     g->part_acc, 0u, 0ull, 0ull, W, q_dbg());
+                                                                                     g->part_acc, 0u, 0ull, 0ull, W);
   }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;

@@ -473,7 +473,10 @@ int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32
     for (uint32_t j = rb[r]; j < rb[r + 1]; ++j) {
       const uint32_t v = (uint32_t)nz_rows[j];
       uint32_t c[kParts] = {0};
-      for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) c[part_of((uint32_t)in_ci[e])]++;
+      const uint32_t deg = in_rp[v + 1] - in_rp[v];
+      if (deg <= kPartWholeRow) c[part_of(j)] = deg;  // a short row stays whole, in the partition of its ordinal
+      else
+        for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) c[part_of((uint32_t)in_ci[e])]++;
       for (int p = 0; p < kParts; ++p) cnt[(size_t)p * n_nz + j] = c[p];
     }
   });
@@ -553,9 +556,10 @@ int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32
       const uint32_t v = (uint32_t)nz_rows[j];
       uint64_t w[kParts];
       for (int p = 0; p < kParts; ++p) w[p] = (uint64_t)L.chunk_base[p] * kChunkPad + cnt[(size_t)p * n_nz + j];
+      const bool whole = in_rp[v + 1] - in_rp[v] <= kPartWholeRow;
       for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) {
         const int32_t u = in_ci[e];
-        L.ci[w[part_of((uint32_t)u)]++] = u;
+        L.ci[w[whole ? part_of(j) : part_of((uint32_t)u)]++] = u;
       }
     }
   });

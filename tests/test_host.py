@@ -216,14 +216,17 @@ def test_index_merge_large_runs_on_all_threads(pkg):
 # ------------------------------------------------------------------ graph lift, host half (row a11; PPR.java:136-152)
 def _part_expected(n, m, in_rp, in_ci, nz_rows, chunk=512, parts=8, tile=64):
     """The source-partitioned copy of the in-CSR (engine_internal.hpp: HostPartLayout) restated with numpy: in-edges in
-    row order, stably grouped by partition of the source id (id & 7), every partition padded to whole chunks; a
-    segment = the edges of one row inside one partition."""
+    row order, stably grouped by partition - of the source id (id & 7) for rows of more than 16 in-edges, of the row's
+    ordinal for the shorter ones -, every partition padded to whole chunks; a segment = the edges of one row inside one
+    partition."""
     indeg = np.diff(in_rp).astype(np.int64)
     n_nz = nz_rows.size
     n_tiles = (n_nz + tile - 1) // tile
     row_of_edge = np.repeat(np.arange(n, dtype=np.int64), indeg)
     ordinal = np.cumsum(indeg > 0) - 1                    # node -> row ordinal
     part = in_ci.astype(np.int64) & (parts - 1)
+    short = indeg[row_of_edge] <= 16                     # rows of <= 16 in-edges stay whole, in the partition of their ordinal
+    part[short] = ordinal[row_of_edge[short]] & (parts - 1)
     perm = np.argsort(part, kind="stable")
     counts = np.bincount(part, minlength=parts)
     chunk_base = np.zeros(parts + 1, dtype=np.int64)
