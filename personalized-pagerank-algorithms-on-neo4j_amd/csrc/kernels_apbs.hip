@@ -1060,7 +1060,62 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     const uint32_t np = s_pcount < cap_f ? s_pcount : cap_f;
     // ---- emit entries >= threshold (Base_Whole_Graph.java:80-88): only popped nodes hold a reserve
     bool retry = gave_up;
-    if (!gave_up) {
+    // Round 5: a search of up to kDnEmitRegs * 1024 pops (all but the hubs') reads its reserves ONCE: they stay in
+    // registers between the count and the emission, and the cleared value goes back in the same walk - the count
+    // pass, the emission pass and the clean-up's pass over the pop list were three gathers of the same scattered
+    // entries (emission 6 % + clean-up 15 % of the tier's workgroup time, profiles/r05_apbs_summary.md).
+    constexpr int kDnEmitRegs = 4;
+    bool rsv_cleared = false;
+    if (!gave_up && np <= (uint32_t)kDnEmitRegs * kDnThreads) {
+      int32_t pv[kDnEmitRegs];
+      double pr[kDnEmitRegs];
+      unsigned long long run = 0;
+#pragma unroll
+      for (int j = 0; j < kDnEmitRegs; ++j) {
+        const uint32_t i = (uint32_t)j * kDnThreads + tid;
+        pv[j] = i < np ? dn_load(&W.plist[i]) : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < kDnEmitRegs; ++j) {
+        pr[j] = 0.0;
+        if (pv[j] >= 0) {
+          if ((uint32_t)pv[j] < hot_n) {
+            pr[j] = hrsv[pv[j]];
+            hrsv[pv[j]] = 0.0;
+          } else {
+            pr[j] = dn_load(&W.rsv[pv[j]]);
+          }
+        }
+        run += (pr[j] > 0.0 && pr[j] >= rmax) ? 1ull : 0ull;
+      }
+#pragma unroll
+      for (int j = 0; j < kDnEmitRegs; ++j)
+        if (pv[j] >= 0 && (uint32_t)pv[j] >= hot_n) dn_store(&W.rsv[pv[j]], 0.0);  // (a node is popped-listed once)
+      rsv_cleared = true;
+      const unsigned long long total = block_sum_u64(run, s_scan64);  // valid in thread 0
+      if (tid == 0) {
+        s_tot = total;
+        s_out_base = total ? atomic_add_u64(O.out_count, total) : 0ull;
+      }
+      __syncthreads();
+      const unsigned long long tot = s_tot;
+      if (s_out_base + tot > O.out_cap) {
+        retry = true;  // the triple buffer is full: the host drains it and runs this target again
+        if (tid == 0) atomicMin(O.out_valid, s_out_base);
+      } else if (tot) {
+        unsigned long long at = s_out_base;
+#pragma unroll
+        for (int j = 0; j < kDnEmitRegs; ++j) {
+          if ((uint32_t)j * kDnThreads >= np) break;  // (uniform)
+          const bool take = pr[j] > 0.0 && pr[j] >= rmax;
+          unsigned long long chunk_total = 0;
+          const unsigned long long ex2 =
+              block_excl_scan_n<unsigned long long, kDnWaves>(take ? 1ull : 0ull, s_scan64, &chunk_total);
+          if (take) O.out_rec[at + ex2] = TripleRec{new2old[pv[j]], t_old, pr[j]};
+          at += chunk_total;
+        }
+      }
+    } else if (!gave_up) {
       // (a popped hot id's reserve is in LDS)
       unsigned long long run = 0;
       for (uint32_t c0 = 0; c0 < np; c0 += kDnThreads) {
@@ -1087,7 +1142,16 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
         for (uint32_t c0 = 0; c0 < np; c0 += kDnThreads) {
           const uint32_t i = c0 + tid;
           const int32_t v = i < np ? dn_load(&W.plist[i]) : 0;
-          const double r = i < np ? ((uint32_t)v < hot_n ? hrsv[v] : dn_load(&W.rsv[v])) : 0.0;
+          double r = 0.0;
+          if (i < np) {  // read for the last time: the cleared value goes back in the same walk
+            if ((uint32_t)v < hot_n) {
+              r = hrsv[v];
+              hrsv[v] = 0.0;
+            } else {
+              r = dn_load(&W.rsv[v]);
+              dn_store(&W.rsv[v], 0.0);
+            }
+          }
           const bool take = r > 0.0 && r >= rmax;
           unsigned long long chunk_total = 0;
           const unsigned long long ex2 =
@@ -1097,6 +1161,7 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
           }
           at += chunk_total;
         }
+        rsv_cleared = true;
       }
     }
     if (retry && tid == 0) {  // lists full: +t, triple buffer full: -(t + 1)
@@ -1108,10 +1173,12 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     DN_AT(7, 0)
     // ---- hand the vectors back all-zero (the hot ids' state: LDS; the head of the global vector is zero already)
     for (uint32_t i = tid; i < hot_n; i += kDnThreads) hres[i] = 0.0;  // (what the last level left below the threshold)
-    for (uint32_t i = tid; i < np; i += kDnThreads) {
-      const int32_t v = dn_load(&W.plist[i]);
-      if ((uint32_t)v < hot_n) hrsv[v] = 0.0;
-      else dn_store(&W.rsv[v], 0.0);
+    if (!rsv_cleared) {
+      for (uint32_t i = tid; i < np; i += kDnThreads) {
+        const int32_t v = dn_load(&W.plist[i]);
+        if ((uint32_t)v < hot_n) hrsv[v] = 0.0;
+        else dn_store(&W.rsv[v], 0.0);
+      }
     }
     const uint32_t nt = s_tcount;
     if (nt <= cap_t && s_pcount <= cap_f) {
