@@ -1295,12 +1295,13 @@ def pmc_traffic(args, host):
 
     anyk = lambda name: True  # noqa: E731
     # phase 1: the headline path; a dense level = several launches of the edge / apply kernels + one reduce launch
-    sweep = lambda k: k.startswith("k_dense_edges_b<") or k in ("k_dense_apply_batch", "k_dense_reduce_batch")  # noqa: E731
+    # (the kernels of one sweep under rocprofv3's names: both are templates since round 5)
+    sweep = lambda k: k.startswith(("k_dense_edges_b<", "k_dense_edges_q<", "k_dense_apply_batch", "k_dense_reduce_batch"))  # noqa: E731
     levels = count(fetch[1], lambda k: k == "k_dense_reduce_batch")
     if levels:
         res["dense_pull_batch"] = int(traffic(1, sweep) / levels)
         res["dense_pull_batch_tcc_hit"] = hit_rate(1, sweep)
-        res["dense_pull_batch_edges_tcc_hit"] = hit_rate(1, lambda k: k.startswith("k_dense_edges_b<"))
+        res["dense_pull_batch_edges_tcc_hit"] = hit_rate(1, lambda k: k.startswith(("k_dense_edges_b<", "k_dense_edges_q<")))
     walks = count(fetch[1], lambda k: k == "k_mc_walk")
     if walks:
         res["walk"] = int(traffic(1, lambda k: k == "k_mc_walk") / walks)

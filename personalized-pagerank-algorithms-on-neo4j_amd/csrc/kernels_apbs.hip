@@ -1182,6 +1182,9 @@ __global__ __launch_bounds__(kDnThreads) void k_apbs_dense(const int32_t* __rest
     }
     const uint32_t nt = s_tcount;
     if (nt <= cap_t && s_pcount <= cap_f) {
+      // (tried in round 5: eight lanes per listed node zeroing the 64 aligned bytes around it, so that the memory side
+      // sees whole 64-byte writes - 545 / 512 ms against 563 / 527 ms for R-MAT 22's tier, 1 668 / 1 643 against 1 646 /
+      // 1 618 ms for R-MAT 24's on the same box: no difference beyond the noise; the 8-byte stores stay)
       for (uint32_t i = tid; i < nt; i += kDnThreads) dn_store(&W.res[dn_load(&W.touched[i])], 0.0);
     } else {  // a list overflowed: clear everything
       for (uint32_t i = tid; i < n; i += kDnThreads) {
