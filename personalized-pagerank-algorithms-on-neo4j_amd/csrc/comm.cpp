@@ -419,6 +419,8 @@ constexpr int kPilotTop = 16, kPilotRanks = 48;
 // give one rank - the cheap test that decides whether the pilot is worth its searches (PPRHIP_SHARD_CUT=count / work
 // forces either)
 double equal_count_skew(const pprhip_graph* g, int W) {
+  // (every 8th id of a range stands for the range: the test only has to tell a degree-sorted store from a scrambled one,
+  // and rank 0 runs it while its peers wait - 3 ms instead of 20 for R-MAT 22)
   const uint32_t n = g->n;
   const double d_star = std::max(64.0, (double)n / 256.0);
   std::vector<double> share((size_t)W, 0.0);
@@ -427,10 +429,12 @@ double equal_count_skew(const pprhip_graph* g, int W) {
     uint32_t lo, hi;
     target_range(r, W, n, &lo, &hi);
     double s = 0.0;
-    for (uint32_t t = lo; t < hi; ++t) {
+    const uint32_t step = hi - lo >= 4096 ? 8u : 1u;
+    for (uint32_t t = lo; t < hi; t += step) {
       const double d = (double)hdeg_in(g, g->h_old2new[t]);
       s += 1.0 + d * (1.0 + d / d_star);
     }
+    s *= (double)step;
     share[r] = s;
     total += s;
   }

@@ -44,8 +44,13 @@ def test_fora_batch_over_replicas_equals_single_gpu(pkg, rmat12, replicas, n_gpu
         assert all(st.levels > 0 for st in sts)            # every replica took part
 
 
+@pytest.mark.parametrize("cut", ["auto", "work"])
 @pytest.mark.parametrize("n_gpu,k", [(1, -1), (2, -1), (3, 4), (2, 0)])
-def test_all_pair_over_replicas_equals_single_gpu(pkg, orc, rmat12, replicas, n_gpu, k):
+def test_all_pair_over_replicas_equals_single_gpu(pkg, orc, rmat12, replicas, n_gpu, k, cut, monkeypatch):
+    """(cut: the target ranges as the call decides them, and forced by work - PPRHIP_SHARD_CUT=work: the pilot's searches
+    on rank 0's handle before its own share, ranges of any size and alignment)"""
+    if cut == "work":
+        monkeypatch.setenv("PPRHIP_SHARD_CUT", "work")
     thr = 2e-3
     ix, sts = pkg.all_pair_backward_multi(replicas[:n_gpu], A, thr, k)
     off, tg, vl = ix.arrays()
@@ -241,6 +246,25 @@ def test_work_weighted_target_cut_balances_a_degree_sorted_store(pkg, monkeypatc
         e = np.array([st.edge_pushes + st.dense_edges for st in sts], dtype=np.float64)
         assert (e / e.mean()).max() <= 1.15
         ix.close()
+    finally:
+        for g in gs:
+            g.close()
+
+
+def test_work_cut_on_a_tiny_graph_with_more_ranks_than_hubs(pkg, orc, got, monkeypatch):
+    """Game of Thrones (107 nodes) on eight ranks, cut by work: ranges of a handful of targets, possibly none - the
+    merged index is the single-GPU one, and the cuts tile [0, n)."""
+    gs = [pkg.Graph(got) for _ in range(8)]
+    try:
+        monkeypatch.setenv("PPRHIP_SHARD_CUT", "work")
+        cuts, _ = pkg.shard_target_cuts(gs[0], 8, A, 1e-2, pkg.CUT_BY_WORK)
+        assert cuts[0] == 0 and cuts[-1] == got.n and np.all(np.diff(cuts.astype(np.int64)) >= 0)
+        ix, sts = pkg.all_pair_backward_multi(gs, A, 1e-2, 5)
+        ix1, _ = gs[0].all_pair_backward(A, 1e-2, 5)
+        a, b = ix.arrays(), ix1.arrays()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.max(np.abs(a[2] - b[2])) <= 1e-12
+        ooff, otg, ovl = to_oracle(orc, got).all_pair_backward(A, 1e-2, 5, schedule=orc.SYNC)
+        assert np.array_equal(a[0], ooff) and np.array_equal(a[1], otg) and np.max(np.abs(a[2] - ovl)) <= 1e-12
     finally:
         for g in gs:
             g.close()
