@@ -69,6 +69,40 @@ SetupScope::SetupScope(pprhip_graph* g) : t(g_timer_cur->stream == g->stream ? g
   if (t) t->begin(PPRHIP_KERNEL_QUERY_SETUP, 0);
 }
 
+C8Scope::C8Scope(pprhip_graph* g_, bool back_) : g(g_), back(back_) {
+  if (!g->parent || !g->c8_via_parent || g->stream == g->parent->stream) return;
+  for (auto& e : g->c8_ev)
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      e = nullptr;
+      set_error("hipEventCreate failed (slot %d)", g->slot_index);
+      rc = PPRHIP_ERR_HIP;
+      return;
+    }
+  // (the slots share one stream: a wait for it is a wait for whatever another slot has just queued there, so a slot
+  // that is known to have nothing pending - it comes out of a sweep, or stood waiting for its column - does not ask)
+  if (!g->c8_settled && (hipEventRecord(g->c8_ev[0], g->stream) != hipSuccess ||
+                         hipStreamWaitEvent(g->parent->stream, g->c8_ev[0], 0) != hipSuccess)) {
+    set_error("slot %d: its stream could not be joined to the sweeps' stream", g->slot_index);
+    rc = PPRHIP_ERR_HIP;
+    return;
+  }
+  own = g->stream;
+  g->stream = g->parent->stream;
+  on = true;
+}
+
+int C8Scope::leave() {
+  if (!on) return rc;
+  on = false;
+  g->stream = own;
+  if (back && (hipEventRecord(g->c8_ev[1], g->parent->stream) != hipSuccess ||
+               hipStreamWaitEvent(own, g->c8_ev[1], 0) != hipSuccess)) {
+    set_error("slot %d: the sweeps' stream could not be joined to its stream", g->slot_index);
+    rc = PPRHIP_ERR_HIP;
+  }
+  return rc;
+}
+
 int alloc_dev(void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes ? bytes : 8);
   if (e != hipSuccess) {
@@ -96,7 +130,12 @@ int fetch_end(pprhip_graph* g, unsigned long long seq, const void* dev, void* ho
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
     return PPRHIP_OK;
   }
-  constexpr double kSpinUs = 60.0;
+  // A slot of the sequential batch driver waits here while a sweep runs on the compute stream: the driver's hook is
+  // called between looks at the mailbox, so that the sweep's end is noticed - and the next sweep launched - at once
+  // instead of after this slot's step (kernel trace: the compute stream waited 97 us per sweep for the host).
+  pprhip_graph* const H = g->parent;
+  const bool hooked = H && H->idle_hook;
+  const double kSpinUs = hooked ? 2e6 : 60.0;
   const auto t0 = std::chrono::steady_clock::now();
   bool arrived = false;
   for (uint32_t spins = 0;; ++spins) {
@@ -105,12 +144,14 @@ int fetch_end(pprhip_graph* g, unsigned long long seq, const void* dev, void* ho
       break;
     }
     __builtin_ia32_pause();
+    if (hooked && (spins & 7u) == 7u) H->idle_hook(H->idle_arg);
     if ((spins & 63u) == 63u &&
         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kSpinUs)
       break;
   }
   if (!arrived) {
     PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+    if (H && H->stream != g->stream) PPRHIP_CHECK_HIP(hipStreamSynchronize(H->stream));  // (a C8Scope publication)
     if (__atomic_load_n(&g->mail->seq, __ATOMIC_ACQUIRE) != seq) {
       set_error("fetch_small: the stream drained without the published words (sequence %llu, expected %llu)",
                 (unsigned long long)g->mail->seq, seq);
@@ -350,10 +391,19 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       c = dense_sweep_cost(g);
     }
     if (dense) {
+      if (!L.dense_prepared && slot && g->col_cell && *g->col_cell != g->ws_index) {
+        // twin workspaces: a column of c8 serves one of them at a time (nothing has been decided or queued yet: the
+        // driver calls again when the column is free)
+        if (*g->col_cell >= 0) return kYieldColumn;
+        *g->col_cell = g->ws_index;
+      }
       if (model_cost) *model_cost += c;
       if (cut) cut->had_dense = true;
       if (bwd && !slot) PPRHIP_TRY(ensure_bwd_layout(g));  // sweep layout over the out-CSR, built on first use
+      if (!bwd && !slot) PPRHIP_TRY(ensure_part_single(g));  // (the source-partitioned copy, where it is switched on)
       if (!L.dense_prepared) {
+        C8Scope c8(g, false);
+        PPRHIP_TRY(c8.rc);
         if (slot) {
           if (g->sync) g->sync->c8_enter(g->slot_index);
           L.ccur = g->parent->c8cur;  // the slot's column of the shared array is all-zero here
@@ -361,6 +411,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
           PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
         PPRHIP_TRY(launch_sparse_prepare(g, a, L.fcur, 0, L.nf, dense_thresh, true, L.ccur, L.dslot,
                                          ((unsigned long long)L.nf << kPackShift) | L.ef));
+        PPRHIP_TRY(c8.leave());
         L.dense_prepared = true;
         L.dense_run = 0;
         L.gs_dirty = false;
@@ -428,17 +479,36 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     // ---- a batch of sparse levels.  The first level's frontier travels as a kernel argument and its prepare kernel
     // clears the counters of the levels behind it; only after a compaction (which counts on the device) the counters
     // are cleared by a fill and read from memory.
-    const bool first_prepared = L.dense_prepared;
+    const bool first_prepared = L.dense_prepared || L.compacted;
     unsigned long long pk0 = ((unsigned long long)L.nf << kPackShift) | L.ef;
-    if (first_prepared) {
-      PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->hist[0], 0, sizeof(unsigned long long) * (kMaxBatch + 1), g->stream));
-      // dense-prepared state -> list form; the compaction recounts (dead-end nodes carry no edges)
-      PPRHIP_TRY(launch_compact_prepared(g, L.ccur, L.fcur, &g->ctr->hist[0], bwd));
+    if (L.dense_prepared) {
+      {
+        // A slot beside the sweeps queues this on the compute stream and learns of its end through its mailbox: an
+        // event recorded there for the slot's stream to wait on held the compute stream up for ~90 us per compaction
+        // (kernel trace: nothing ran between the compaction and the kernel queued right behind the record).
+        C8Scope c8(g, false);
+        PPRHIP_TRY(c8.rc);
+        PPRHIP_CHECK_HIP(hipMemsetAsync(&g->ctr->hist[0], 0, sizeof(unsigned long long) * (kMaxBatch + 1), g->stream));
+        // dense-prepared state -> list form; the compaction recounts (dead-end nodes carry no edges)
+        PPRHIP_TRY(launch_compact_prepared(g, L.ccur, L.fcur, &g->ctr->hist[0], bwd));
+        L.compact_seq = 0;
+        if (c8.on) PPRHIP_TRY(fetch_begin(g, &g->ctr->hist[0], sizeof(unsigned long long), &L.compact_seq));
+        if (c8.on && !L.compact_seq) c8.back = true;  // (no mailbox: the slot's stream waits for an event after all)
+        PPRHIP_TRY(c8.leave());
+      }
       L.dense_prepared = false;
-      pk0 = ~0ull;
+      L.compacted = true;
       // the column must be read (and handed back zeroed) before another sweep may run
       if (g->sync) PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+      if (L.defer_compact) return kYieldDefer;  // (queued ahead of the next sweep; the levels follow beside it)
     }
+    if (first_prepared) pk0 = ~0ull;
+    if (L.compacted && L.compact_seq) {  // the list must be there before the slot's own stream reads it
+      unsigned long long pk = 0;
+      PPRHIP_TRY(fetch_end(g, L.compact_seq, &g->ctr->hist[0], &pk, sizeof pk));
+      L.compact_seq = 0;
+    }
+    L.compacted = false;
     if (g->sync) g->sync->release(g->slot_index);
     // the round-cut check looks at the state after exactly one sparse level
     const bool cut_check = cut && cut->enabled && cut->had_dense && !cut->checked;
@@ -446,6 +516,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     ktimer().begin(PPRHIP_KERNEL_SPARSE_PUSH, 0);
     for (int i = 0; i < n_batch; ++i) {
       const int fb = L.fcur ^ (i & 1);
+      poll_idle(g);
       if (!(i == 0 && first_prepared))
         PPRHIP_TRY(launch_sparse_prepare(g, a, fb, i, i == 0 ? L.nf : 32768, dense_thresh, false, 0, L.dslot,
                                          i == 0 ? pk0 : ~0ull));
@@ -501,6 +572,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
 }
 
 int reset_query_state(pprhip_graph* g, bool clear_flags, int32_t node) {
+  poll_idle(g);
   // the entries the query before could have written are cleared; the new query's passes cover n_act entries
   const uint32_t n_live = host_of(g)->n_live;
   g->n_act = (n_live && node >= 0 && (uint32_t)node < n_live) ? n_live : g->n;
@@ -614,6 +686,50 @@ void free_workspace(pprhip_graph* g) {
 void free_batch(pprhip_graph* P);
 static int build_part_layout_device(pprhip_graph* P);
 
+// one batch workspace: slots[w] works on column w % kBatch of the interleaved arrays
+static int make_slot(pprhip_graph* P, int w) {
+  pprhip_graph* S = new (std::nothrow) pprhip_graph();
+  if (!S) return PPRHIP_ERR_OOM;
+  P->slots.push_back(S);
+  S->parent = P;
+  S->slot_index = w % kBatch;
+  S->ws_index = w;
+  S->device = P->device;
+  S->n_cus = P->n_cus;
+  S->n = P->n;
+  S->m = P->m;
+  S->n_live = P->n_live;
+  if (hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    return PPRHIP_ERR_HIP;
+  }
+  S->stream = P->stream;
+  S->out_rp = P->out_rp;
+  S->in_rp = P->in_rp;
+  S->out_ext = P->out_ext;
+  S->out_ci = P->out_ci;
+  S->in_ci = P->in_ci;
+  S->walk_rec = P->walk_rec;
+  S->relabeled = P->relabeled;
+  S->new2old = P->new2old;
+  S->old2new = P->old2new;
+  S->start_flags = P->start_flags;
+  S->chunk_starts = P->chunk_starts;
+  S->n_chunks = P->n_chunks;
+  S->nz_rows = P->nz_rows;
+  S->n_nz = P->n_nz;
+  S->sl = P->sl;
+  S->tun = P->tun;
+  PPRHIP_TRY(alloc_workspace(S));
+  return PPRHIP_OK;
+}
+
+int ensure_twins(pprhip_graph* P) {
+  while ((int)P->slots.size() < 2 * kBatch) PPRHIP_TRY(make_slot(P, (int)P->slots.size()));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
+  return PPRHIP_OK;
+}
+
 // Batch slots and the interleaved dense-level arrays, created on the first batched call.
 int build_batch(pprhip_graph* P) {
   const size_t n = P->n;
@@ -642,38 +758,8 @@ int build_batch(pprhip_graph* P) {
   P->c8cur = 0;
   PPRHIP_TRY(build_part_layout_device(P));
   for (int s = 0; s < kBatch; ++s) {
-    pprhip_graph* S = new (std::nothrow) pprhip_graph();
-    if (!S) return PPRHIP_ERR_OOM;
-    P->slots.push_back(S);
-    S->parent = P;
-    S->slot_index = s;
-    S->device = P->device;
-    S->n_cus = P->n_cus;
-    S->n = P->n;
-    S->m = P->m;
-    S->n_live = P->n_live;
-    if (hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking) != hipSuccess) {
-      set_error("hipStreamCreate failed");
-      return PPRHIP_ERR_HIP;
-    }
-    S->stream = P->stream;
-    S->out_rp = P->out_rp;
-    S->in_rp = P->in_rp;
-    S->out_ext = P->out_ext;
-    S->out_ci = P->out_ci;
-    S->in_ci = P->in_ci;
-    S->walk_rec = P->walk_rec;
-    S->relabeled = P->relabeled;
-    S->new2old = P->new2old;
-    S->old2new = P->old2new;
-    S->start_flags = P->start_flags;
-    S->chunk_starts = P->chunk_starts;
-    S->n_chunks = P->n_chunks;
-    S->nz_rows = P->nz_rows;
-    S->n_nz = P->n_nz;
-    S->sl = P->sl;
-    S->tun = P->tun;
-    PPRHIP_TRY(alloc_workspace(S));
+    P->col_owner[s] = -1;
+    PPRHIP_TRY(make_slot(P, s));
   }
   PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
   return PPRHIP_OK;
@@ -685,49 +771,69 @@ int build_batch(pprhip_graph* P) {
 // 0.3 GB up, once per handle (the copy stays when the batch workspaces are released).
 // PPRHIP_SWEEP_PARTS=0 / 1 switches it off / on for any size (tests run small graphs both ways); by default graphs
 // from 2^22 edges on use it - below that the whole contribution array fits every L2 anyway.
+// the copy itself, built once per handle (kept until the handle goes)
+static int ensure_part_layout(pprhip_graph* P) {
+  if (P->pl) return PPRHIP_OK;
+  HostPartLayout H;
+  std::unique_ptr<PartLayout> L(new (std::nothrow) PartLayout());
+  if (!L) return PPRHIP_ERR_OOM;
+  try {
+    RawVec<int32_t> ci((size_t)P->m);
+    PPRHIP_CHECK_HIP(hipMemcpy(ci.data(), P->in_ci, sizeof(int32_t) * (size_t)P->m, hipMemcpyDeviceToHost));
+    PPRHIP_TRY(build_part_layout(P->n, P->m, P->h_in_rp.data(), ci.data(), P->h_nz_rows.data(), P->n_nz, 0, H));
+    L->h_tile_edge0 = std::move(H.tile_edge0);
+  } catch (const std::bad_alloc&) {
+    set_error("source-partitioned sweep layout: out of host memory");
+    return PPRHIP_ERR_OOM;
+  }
+  auto up = [&](void** d, const void* h, size_t bytes) -> int {
+    PPRHIP_TRY(alloc_dev(d, bytes));
+    PPRHIP_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return PPRHIP_OK;
+  };
+  int rc = PPRHIP_OK;
+  if ((rc = up((void**)&L->ci, H.ci.data(), sizeof(int32_t) * H.ci.size())) ||
+      (rc = up((void**)&L->flags, H.flags.data(), H.flags.size())) ||
+      (rc = up((void**)&L->chunk_starts, H.chunk_starts.data(), sizeof(uint32_t) * H.chunk_starts.size())) ||
+      (rc = up((void**)&L->tile_seg0, H.tile_seg0.data(), sizeof(uint32_t) * H.tile_seg0.size())) ||
+      (rc = up((void**)&L->tile_mask, H.tile_mask.data(), sizeof(unsigned long long) * std::max<size_t>(1, H.tile_mask.size()))) ||
+      (rc = up((void**)&L->tile_cross, H.tile_cross.data(), sizeof(unsigned long long) * std::max<size_t>(1, H.tile_cross.size())))) {
+    void* ptrs[] = {L->ci, L->flags, L->chunk_starts, L->tile_seg0, L->tile_mask, L->tile_cross};
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+    return rc;
+  }
+  std::memcpy(L->chunk_base, H.chunk_base, sizeof L->chunk_base);
+  std::memcpy(L->seg_base, H.seg_base, sizeof L->seg_base);
+  L->n_tiles = H.n_tiles;
+  L->n_seg = H.seg_base[kParts];
+  P->pl = L.release();
+  return PPRHIP_OK;
+}
+
 static int build_part_layout_device(pprhip_graph* P) {
   const char* e = getenv("PPRHIP_SWEEP_PARTS");
-  const bool want = e ? e[0] == '1' : false;  // (off by default until it is the faster layout: profiles/r05_pmc_sweep_first.txt)
+  const bool want = e ? e[0] == '1' : false;  // (off by default until it is the faster layout: profiles/r05_quad_kernel_study.txt)
   if (!want || P->m == 0 || P->n_nz == 0) return PPRHIP_OK;
-  if (!P->pl) {
-    HostPartLayout H;
-    std::unique_ptr<PartLayout> L(new (std::nothrow) PartLayout());
-    if (!L) return PPRHIP_ERR_OOM;
-    try {
-      RawVec<int32_t> ci((size_t)P->m);
-      PPRHIP_CHECK_HIP(hipMemcpy(ci.data(), P->in_ci, sizeof(int32_t) * (size_t)P->m, hipMemcpyDeviceToHost));
-      PPRHIP_TRY(build_part_layout(P->n, P->m, P->h_in_rp.data(), ci.data(), P->h_nz_rows.data(), P->n_nz, 0, H));
-      L->h_tile_edge0 = std::move(H.tile_edge0);
-    } catch (const std::bad_alloc&) {
-      set_error("source-partitioned sweep layout: out of host memory");
-      return PPRHIP_ERR_OOM;
-    }
-    auto up = [&](void** d, const void* h, size_t bytes) -> int {
-      PPRHIP_TRY(alloc_dev(d, bytes));
-      PPRHIP_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
-      return PPRHIP_OK;
-    };
-    int rc = PPRHIP_OK;
-    if ((rc = up((void**)&L->ci, H.ci.data(), sizeof(int32_t) * H.ci.size())) ||
-        (rc = up((void**)&L->flags, H.flags.data(), H.flags.size())) ||
-        (rc = up((void**)&L->chunk_starts, H.chunk_starts.data(), sizeof(uint32_t) * H.chunk_starts.size())) ||
-        (rc = up((void**)&L->tile_seg0, H.tile_seg0.data(), sizeof(uint32_t) * H.tile_seg0.size())) ||
-        (rc = up((void**)&L->tile_mask, H.tile_mask.data(), sizeof(unsigned long long) * std::max<size_t>(1, H.tile_mask.size()))) ||
-        (rc = up((void**)&L->tile_cross, H.tile_cross.data(), sizeof(unsigned long long) * std::max<size_t>(1, H.tile_cross.size())))) {
-      void* ptrs[] = {L->ci, L->flags, L->chunk_starts, L->tile_seg0, L->tile_mask, L->tile_cross};
-      for (void* p : ptrs)
-        if (p) (void)hipFree(p);
-      return rc;
-    }
-    std::memcpy(L->chunk_base, H.chunk_base, sizeof L->chunk_base);
-    std::memcpy(L->seg_base, H.seg_base, sizeof L->seg_base);
-    L->n_tiles = H.n_tiles;
-    L->n_seg = H.seg_base[kParts];
-    P->pl = L.release();
-  }
+  PPRHIP_TRY(ensure_part_layout(P));
   const size_t bytes = sizeof(double) * ((size_t)P->pl->n_seg + 1) * kBatch;
   PPRHIP_TRY(alloc_dev((void**)&P->part_acc, bytes));
   PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_acc, 0, bytes, P->stream));
+  return PPRHIP_OK;
+}
+
+// The single-query sweep over the same copy (kernels_push.hip: k_dense_edges_p): the copy and one double per segment,
+// on the first dense level of a forward push.  PPRHIP_SWEEP1_PARTS=0 / 1 switches it off / on for any size.
+int ensure_part_single(pprhip_graph* g) {
+  if (g->part1 || g->part1_tried) return PPRHIP_OK;
+  g->part1_tried = true;
+  const char* e = getenv("PPRHIP_SWEEP1_PARTS");
+  const bool want = e ? e[0] == '1' : false;
+  if (!want || g->parent || g->m == 0 || g->n_nz == 0) return PPRHIP_OK;
+  PPRHIP_TRY(ensure_part_layout(g));
+  const size_t bytes = sizeof(double) * ((size_t)g->pl->n_seg + 1);
+  PPRHIP_TRY(alloc_dev((void**)&g->part1, bytes));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->part1, 0, bytes, g->stream));
   return PPRHIP_OK;
 }
 
@@ -756,11 +862,20 @@ void free_batch(pprhip_graph* P) {
   if (P->walk_stream) (void)hipStreamDestroy(P->walk_stream);
   P->walk_stream = nullptr;
   P->walk_stream_tried = false;
+  if (P->slot_stream) (void)hipStreamDestroy(P->slot_stream);
+  P->slot_stream = nullptr;
+  P->slot_stream_tried = false;
   for (pprhip_graph* S : P->slots) {
     for (auto& ev : S->walk_ev) {
       if (ev) (void)hipEventDestroy(ev);
       ev = nullptr;
     }
+    for (auto& ev : S->c8_ev) {
+      if (ev) (void)hipEventDestroy(ev);
+      ev = nullptr;
+    }
+    if (S->col_ev) (void)hipEventDestroy(S->col_ev);
+    S->col_ev = nullptr;
     free_workspace(S);
     S->ktimer.destroy();
     if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
@@ -866,7 +981,12 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
   L.gs_dirty = false;
   bool dense = false;
   if (L.nf) (void)level_cost(g, L.nf, L.ef, &dense);
+  // (a twin workspace that does not hold its column lists the start set instead; run_levels prepares the level from
+  // the list once the column is its own)
+  if (dense && g->parent && g->col_cell && *g->col_cell != g->ws_index) dense = false;
   if (dense) {
+    C8Scope c8(g, false);
+    PPRHIP_TRY(c8.rc);
     if (g->parent) {
       if (g->sync) g->sync->c8_enter(g->slot_index);
       L.ccur = g->parent->c8cur;
@@ -875,6 +995,7 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
       SetupScope setup(g);
       PPRHIP_TRY(launch_seed_dense(g, a, kind, L.ccur, L.pslot, L.dslot));
     }
+    PPRHIP_TRY(c8.leave());
     L.dense_prepared = true;
     L.dense_run = 0;
   } else if (L.nf || kind == 1) {
@@ -890,6 +1011,7 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
 }
 
 int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count) {
+  poll_idle(g);
   {
     SetupScope setup(g);
     PPRHIP_TRY(launch_sum(g, x, count ? count : act_n(g)));
@@ -902,6 +1024,7 @@ int device_sum(pprhip_graph* g, const double* x, double* out, uint32_t count) {
 // The counters a query only needs once, at its end, in one copy: dead-end pops of the push, and what the walk phases
 // run since the workspace was reset counted on the device (steps, walks, sources: adjacent in DevCounters).
 int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st) {
+  poll_idle(g);
   static_assert(offsetof(DevCounters, walk_lanes) == offsetof(DevCounters, dead_pops) + 40, "one copy for the six");
   PPRHIP_TRY(fetch_small(g, &g->ctr->dead_pops, &g->h_ctr->dead_pops, 6 * sizeof(unsigned long long)));
   st.walk_loads = g->h_ctr->walk_loads;
@@ -930,6 +1053,7 @@ int read_dead_pops(pprhip_graph* g, pprhip_stats_t& st) {
 // the plan of the residue entries, and the walk kernel that runs the latest plan.
 int launch_walk_plan(pprhip_graph* g, int variant, double alpha, double rsum, long long nrw, double* target, double omega_dev,
                      const double* copy_src, double* copy_dst) {
+  poll_idle(g);
   // what the host knows about the walk count sizes the grid: the budget itself (every residue entry adds at most one
   // walk to it), or - with the budget derived on the device - nothing
   g->walk_hint = omega_dev > 0.0 ? 0ull : (unsigned long long)nrw + act_n(g);
@@ -943,6 +1067,7 @@ int launch_walk_plan(pprhip_graph* g, int variant, double alpha, double rsum, lo
 }
 
 int launch_walk_run(pprhip_graph* g, int variant, double alpha, uint64_t seed, uint32_t stream, double* target) {
+  poll_idle(g);
   ktimer().begin(PPRHIP_KERNEL_WALK, 0);  // (its bytes are added when the counters are read)
   PPRHIP_TRY(launch_mc_walk(g, alpha, seed, stream, variant == 0 ? 1 : 0, target));
   ktimer().end();
@@ -1130,6 +1255,7 @@ static int select_topk_passes(pprhip_graph* g, const double* x, int k, int32_t* 
 // The selection in two halves, so that a caller can queue other work between launching it and waiting for it.
 constexpr size_t kSelPre = 2048;
 int select_launch(pprhip_graph* g, const double* x, int k, unsigned long long* seq_out, bool with_plan_sum) {
+  poll_idle(g);
   {
     SetupScope setup(g);
     PPRHIP_TRY(launch_select_hist(g, x, act_n(g), 0ull, 0, 12, true));
@@ -1190,7 +1316,7 @@ int select_finish(pprhip_graph* g, unsigned long long seq, const double* x, int 
 // is tried: a kernel holds the compute stream for a moment, a one-word k_publish goes to the candidate, and the
 // candidate is taken if the word arrives while the hold kernel still runs.  Rejected candidates stay alive until the
 // search ends, so that the next one lands elsewhere.  *out stays null when none ran beside.
-int make_side_stream(pprhip_graph* g, hipStream_t* out) {
+int make_side_stream(pprhip_graph* g, hipStream_t* out, hipStream_t also) {
   *out = nullptr;
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -1203,12 +1329,15 @@ int make_side_stream(pprhip_graph* g, hipStream_t* out) {
     return PPRHIP_ERR_OOM;
   }
   std::memset(probe, 0, sizeof(HostMail));
-  hipEvent_t held = nullptr;
-  if (hipEventCreateWithFlags(&held, hipEventDisableTiming) != hipSuccess) {
+  hipEvent_t held = nullptr, held2 = nullptr;
+  if (hipEventCreateWithFlags(&held, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&held2, hipEventDisableTiming) != hipSuccess) {
+    if (held) (void)hipEventDestroy(held);
     (void)hipHostFree(probe);
     return PPRHIP_ERR_HIP;
   }
   PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  if (also) PPRHIP_CHECK_HIP(hipStreamSynchronize(also));
   const int prios[] = {0, 0, 0, 0, prio_lo, prio_hi, prio_lo, prio_hi};
   std::vector<hipStream_t> rejected;
   unsigned long long seq = 0;
@@ -1221,7 +1350,8 @@ int make_side_stream(pprhip_graph* g, hipStream_t* out) {
     ++seq;
     hipStream_t own = g->stream;
     HostMail *m = g->mail, *md = g->mail_dev;
-    if (launch_hold(own, 30000ull) == PPRHIP_OK && hipEventRecord(held, own) == hipSuccess) {  // ~0.3 ms at 100 MHz
+    const bool also_held = !also || (launch_hold(also, 30000ull) == PPRHIP_OK && hipEventRecord(held2, also) == hipSuccess);
+    if (also_held && launch_hold(own, 30000ull) == PPRHIP_OK && hipEventRecord(held, own) == hipSuccess) {  // ~0.3 ms at 100 MHz
       g->stream = cand;
       g->mail = probe;
       g->mail_dev = probe_dev;
@@ -1233,7 +1363,8 @@ int make_side_stream(pprhip_graph* g, hipStream_t* out) {
         const auto t0 = std::chrono::steady_clock::now();
         while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 150.0) {
           if (__atomic_load_n(&probe->seq, __ATOMIC_ACQUIRE) == seq) {
-            beside = hipEventQuery(held) == hipErrorNotReady;  // arrived while the hold kernel still runs
+            // arrived while the hold kernel(s) still run
+            beside = hipEventQuery(held) == hipErrorNotReady && (!also || hipEventQuery(held2) == hipErrorNotReady);
             break;
           }
           __builtin_ia32_pause();
@@ -1241,6 +1372,7 @@ int make_side_stream(pprhip_graph* g, hipStream_t* out) {
       }
     }
     (void)hipStreamSynchronize(own);
+    if (also) (void)hipStreamSynchronize(also);
     (void)hipStreamSynchronize(cand);
     if (beside) {
       *out = cand;
@@ -1250,6 +1382,7 @@ int make_side_stream(pprhip_graph* g, hipStream_t* out) {
   }
   for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
   (void)hipEventDestroy(held);
+  (void)hipEventDestroy(held2);
   (void)hipHostFree(probe);
   return PPRHIP_OK;
 }
@@ -1499,6 +1632,8 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   free_batch(g);
   free_part_layout(g);
+  if (g->part1) (void)hipFree(g->part1);
+  g->part1 = nullptr;
   void* ptrs[] = {g->walk_rec, g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags,
                   g->chunk_starts, g->nz_rows, g->zin_rows, g->cross_bits, g->start_flags_o, g->chunk_starts_o,
                   g->nz_rows_o, g->z_rows_o, g->cross_bits_o};
@@ -2096,6 +2231,7 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
   CallTimer tm(g);
   if (iters > 0) {
     // iteration 1 (Power_Method.java:59-96 with residue = {s: 1})
+    PPRHIP_TRY(ensure_part_single(g));
     LevelCtx L;
     PushArgs a{alpha, 0.0, 0.0, src, kPower};
     PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));

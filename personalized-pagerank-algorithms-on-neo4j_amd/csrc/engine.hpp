@@ -327,6 +327,24 @@ struct pprhip_graph {
   int slot_index = -1;
   pprhip::BatchSync* sync = nullptr;  // set on a slot while a batched call is running
   hipStream_t own_stream = nullptr;   // slot: the stream its worker thread uses
+  // Sequential batch driver (fora.cpp: SlotDriver): graph: the one stream all slots work on beside the sweeps
+  // (sparse levels, seeds, sums, selections; make_side_stream); slot: its c8-touching kernels go to the parent's stream
+  // (engine_internal.hpp: C8Scope) and the events that order them
+  hipStream_t slot_stream = nullptr;
+  bool slot_stream_tried = false;
+  bool c8_via_parent = false;
+  bool c8_settled = false;  // nothing of this slot is pending on its stream: C8Scope need not wait for that stream
+  hipEvent_t c8_ev[2] = {nullptr, nullptr};
+  hipEvent_t col_ev = nullptr;  // recorded on the slot's stream when it began to wait for its column
+  // Twin workspaces (SlotDriver): slots[kBatch + c] shares column c of c8 with slots[c].  graph: who holds each
+  // column (-1: nobody; an index into `slots`); slot: its own index there and the cell it has to win before it
+  // prepares a dense level (nullptr: the column is its own, as in the threaded driver)
+  int col_owner[pprhip::kBatch];
+  // graph: called by a slot's small read-backs while they wait (fetch_end): the driver looks after the sweep in flight
+  void (*idle_hook)(void*) = nullptr;
+  void* idle_arg = nullptr;
+  int ws_index = -1;
+  int* col_cell = nullptr;
   // graph: a stream that runs beside the compute stream (make_side_stream) for the slots' walk phases while sweeps
   // go on (sequential batch driver); slot: the events around its walk phase on that stream
   uint32_t walk_waves = 0;  // waves per CU of the next walk kernels (0: the default)
@@ -352,6 +370,8 @@ struct pprhip_graph {
   int c8cur = 0;
   pprhip::PartLayout* pl = nullptr;  // source-partitioned copy of the in-CSR (forward batched sweeps), with the batch state
   double* part_acc = nullptr;        // [segments + 1][kBatch] partial row sums of its (row, partition) segments
+  double* part1 = nullptr;           // [segments + 1] the same for the single-query sweep over the copy (k_dense_edges_p)
+  bool part1_tried = false;
   double* acc8 = nullptr;      // [row ordinal][kBatch] row sums
   int acc8_dir = 0;            // layout the row sums were last written in (0 forward, 1 backward)
   int32_t* zin_rows = nullptr;  // rows without in-edges

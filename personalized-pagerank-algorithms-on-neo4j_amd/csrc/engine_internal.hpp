@@ -78,6 +78,13 @@ struct LevelCtx {
   // dense sweep - in place or flushing - has to follow whatever the frontier looks like)
   int gs_state = kGsJacobi;
   bool gs_dirty = false;
+  // Batch driver with the slots on a stream of their own (fora.cpp: SlotDriver).  defer_compact: run_levels returns
+  // kYieldDefer as soon as the way back to list form is queued (the compaction runs on the parent's stream, before the
+  // next sweep; the sparse levels behind it are launched when the driver calls again, beside that sweep).
+  // compacted: that compaction has been queued, the list form is (about to be) there.
+  bool defer_compact = false;
+  bool compacted = false;
+  unsigned long long compact_seq = 0;  // mailbox sequence the compaction's end is published under (0: stream order)
 };
 
 // FORA rounds that are certain to be followed by another halving do not need their sparse tail: what it
@@ -94,6 +101,8 @@ struct RoundCut {
 // kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
 
 constexpr int kYield = 1;  // run_levels: the next level is dense and the caller runs it (batched sweeps)
+constexpr int kYieldColumn = 4;  // run_levels: the level is dense and the slot's column of c8 is held by its twin workspace
+constexpr int kYieldDefer = 3;  // run_levels: the compaction is queued, the sparse levels behind it wait for the next call (LevelCtx)
 constexpr int kYieldWalk = 2;  // fora_step: the walk phase runs on the handle's side stream; call again when it has ended
 
 // kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
@@ -102,6 +111,28 @@ inline KernelTimer& ktimer() { return *g_timer_cur; }
 
 // Brackets a group of a query's short bookkeeping kernels (class PPRHIP_KERNEL_QUERY_SETUP) for the calling thread's
 // timer - when that timer is watching this handle's stream (workspaces are also reset outside any timed call).
+// A slot's kernels that touch the shared contribution array c8 (dense prepare, dense seeding, the compaction back to
+// list form) while the slot runs on a stream of its own beside the sweeps (c8_via_parent): they go to the parent's
+// stream, behind everything the slot has queued so far, and so take their place between two sweeps in stream order.
+// back: the slot's stream goes on behind them (the compaction's list is read by the sparse levels); a prepared dense
+// level needs no way back - the slot's next work comes after the sweep it waits for has been collected by the host.
+struct C8Scope {
+  pprhip_graph* g;
+  hipStream_t own = nullptr;
+  bool on = false, back = false;
+  int rc = PPRHIP_OK;
+  C8Scope(pprhip_graph* g_, bool back_);
+  ~C8Scope() { (void)leave(); }
+  int leave();
+};
+
+// A slot of the sequential batch driver gives the driver a look at the sweep in flight (pprhip_graph::idle_hook) -
+// called between the launches of the slot's longer sequences, which keep the host busy for 100 us and more
+inline void poll_idle(pprhip_graph* g) {
+  pprhip_graph* const H = g->parent;
+  if (H && H->idle_hook) H->idle_hook(H->idle_arg);
+}
+
 struct SetupScope {
   KernelTimer* t;
   explicit SetupScope(pprhip_graph* g);
@@ -217,12 +248,15 @@ int reset_query_state(pprhip_graph* g, bool clear_flags, int32_t node = -1);  //
 int ensure_batch(pprhip_graph* P);
 void free_batch(pprhip_graph* P);
 int ensure_bwd_layout(pprhip_graph* P);
+int ensure_part_single(pprhip_graph* g);  // the source-partitioned copy for the single-query sweep, where switched on
 // blocks of the forward Gauss-Seidel sweep for the handle's tuning (nullptr / 1 block when switched off)
 const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks);
 unsigned long long gs_thresh_of(const pprhip_graph* g);
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree);
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L);
-int make_side_stream(pprhip_graph* g, hipStream_t* out);  // a stream that runs beside g->stream (self-tested)
+int ensure_twins(pprhip_graph* P);  // a second workspace per column of c8 (fora.cpp: SlotDriver)
+// a stream that runs beside g->stream - and beside `also`, when given - (self-tested)
+int make_side_stream(pprhip_graph* g, hipStream_t* out, hipStream_t also = nullptr);
 int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes);  // a few words, without a copy command
 int fetch_begin(pprhip_graph* g, const void* dev, size_t bytes, unsigned long long* seq_out);  // ... in two halves
 int fetch_end(pprhip_graph* g, unsigned long long seq, const void* dev, void* host, size_t bytes);

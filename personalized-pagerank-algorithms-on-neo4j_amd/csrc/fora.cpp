@@ -5,7 +5,10 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -57,7 +60,16 @@ struct ForaRun {
 
 namespace {
 
-constexpr uint32_t kSideWalkWaves = 4;  // waves per CU of a walk phase that runs beside sweeps (batch_sequential)
+constexpr uint32_t kSideWalkWavesDefault = 4;  // waves per CU of a walk phase that runs beside sweeps (batch_sequential)
+static uint32_t side_walk_waves() {  // PPRHIP_SIDE_WALK_WAVES: measurement switch
+  static const uint32_t v = [] {
+    const char* e = getenv("PPRHIP_SIDE_WALK_WAVES");
+    const long x = e ? atol(e) : 0;
+    return x > 0 && x <= 32 ? (uint32_t)x : kSideWalkWavesDefault;
+  }();
+  return v;
+}
+#define kSideWalkWaves side_walk_waves()
 
 void leave_push(ForaRun& r) {
   if (r.in_push) {
@@ -191,7 +203,13 @@ int fora_step(ForaRun& r, bool yield_dense) {
         r.phase = ForaRun::kWalkWait;
         return kYieldWalk;
       }
-      if (!r.dead_src) PPRHIP_TRY(run_walk_phase(g, 0, r.alpha, r.rsum_local, nrw, r.seed, 0, g->reserve, r.st));
+      if (!r.dead_src) {
+        // (a worker's walks run beside the other slots' sweeps as well: the same narrow grid as on the side stream)
+        if (g->sync && !getenv("PPRHIP_WORKER_WALK_WIDE")) g->walk_waves = kSideWalkWaves;
+        const int rc = run_walk_phase(g, 0, r.alpha, r.rsum_local, nrw, r.seed, 0, g->reserve, r.st);
+        g->walk_waves = 0;
+        PPRHIP_TRY(rc);
+      }
       r.phase = ForaRun::kWalkWait;
     }
     if (r.phase == ForaRun::kWalkWait) {
@@ -434,10 +452,27 @@ namespace {
 // One batched dense level for the slots flagged in `active`: stages their arguments, orders the
 // parent stream behind the slots' prepare work, runs the sweep and brings the new frontier counters
 // back.  The caller holds the sweep exclusively (sequential driver, or BatchSync::sweeping).
-int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) {
+// launch: queues one batched sweep for the slots in `active` and the read-back of its counters; P->c8cur names the
+// array the NEXT sweep reads from here on, so that whatever is queued on the parent's stream after this point - another
+// slot's prepared level (C8Scope) - lands where that sweep will look.  collect: waits for the counters and does the
+// slots' bookkeeping.
+struct SweepTicket {
+  bool active[kBatch] = {false};
+  int ws[kBatch] = {0};  // the workspace at each column
+  int n_active = 0;
+  bool backward = false;
+  uint64_t rows = 0;
+  unsigned long long seq = 0;
+};
+
+// ws: the workspace (index into P->slots and `runs`) that stands at each active column; nullptr: column c = slots[c]
+int launch_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active, SweepTicket* T, const int* ws = nullptr) {
+  T->n_active = n_active;
   for (int s = 0; s < kBatch; ++s) {
-    pprhip_graph* S = P->slots[s];
+    T->ws[s] = (ws && active[s]) ? ws[s] : s;
+    pprhip_graph* S = P->slots[T->ws[s]];
     SlotArgs& sa = P->h_slot_args[s];
+    T->active[s] = active[s];
     sa.res = S->residue;
     sa.reserve = S->reserve;
     sa.flags = S->flags;
@@ -445,7 +480,7 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
     sa.ctr = S->ctr;
     sa.active = active[s] ? 1 : 0;
     if (!active[s]) continue;
-    const ForaRun& r = runs[s];
+    const ForaRun& r = runs[T->ws[s]];
     sa.alpha = r.a.alpha;
     sa.rmax = r.a.rmax;
     sa.min_rmax = r.a.min_rmax;
@@ -454,16 +489,19 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
     sa.dead_slot = r.L.dslot;
     sa.out_slot = r.L.pslot ^ 1;
     sa.gs_state = r.L.gs_state;
-    if (S->stream != P->stream) {
+    // (a slot of the sequential driver has put its prepared level on the parent's stream itself: C8Scope)
+    if (S->stream != P->stream && !S->c8_via_parent) {
       PPRHIP_CHECK_HIP(hipEventRecord(S->ev[3], S->stream));
       PPRHIP_CHECK_HIP(hipStreamWaitEvent(P->stream, S->ev[3], 0));
     }
   }
   bool backward = false;
   for (int s = 0; s < kBatch; ++s)
-    if (active[s] && runs[s].a.mode == kBackward) backward = true;  // a job's runs all push the same way
+    if (active[s] && runs[T->ws[s]].a.mode == kBackward) backward = true;  // a job's runs all push the same way
+  T->backward = backward;
   // SURVEY 8(d) sweep model with n = the rows the sweep carries (launch_dense_level_b8: isolated nodes are left out)
   const uint64_t rows = backward ? (uint64_t)P->n_nz_o + P->n_z_o : (uint64_t)P->n_nz + P->n_zin;
+  T->rows = rows;
   const uint64_t sweep_bytes = 4ull * P->m + (uint64_t)n_active * (8ull * P->m + 36ull * rows + 4ull);
   if ((int)backward != P->acc8_dir) {
     // rows summed with atomics are cleared by the apply kernel of their own layout only: start clean
@@ -475,18 +513,33 @@ int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) 
   P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
   PPRHIP_TRY(launch_dense_level_b8(P, backward, gs_blocks, n_gs));
   P->ktimer.end();
-  PPRHIP_TRY(fetch_small(P, P->sweep_out, P->h_sweep_out, sizeof(unsigned long long) * kBatch));
   P->c8cur ^= 1;
+  return fetch_begin(P, P->sweep_out, sizeof(unsigned long long) * kBatch, &T->seq);
+}
+
+// true when the counters of a sweep in flight have arrived (collect_sweep would not wait)
+bool sweep_arrived(const pprhip_graph* P, const SweepTicket& T) {
+  return T.seq != 0 && P->mail && __atomic_load_n(&P->mail->seq, __ATOMIC_ACQUIRE) == T.seq;
+}
+
+int collect_sweep(pprhip_graph* P, ForaRun* runs, const SweepTicket& T) {
+  PPRHIP_TRY(fetch_end(P, T.seq, P->sweep_out, P->h_sweep_out, sizeof(unsigned long long) * kBatch));
   for (int s = 0; s < kBatch; ++s)
-    if (active[s]) {
-      ForaRun& r = runs[s];
+    if (T.active[s]) {
+      ForaRun& r = runs[T.ws[s]];
       const unsigned long long pk = P->h_sweep_out[s];
       // the sweep's index stream is shared: each query is charged its own gathers and row work
-      finish_dense(r.L, r.st, 8ull * P->m + 36ull * rows + 4ull + 4ull * P->m / (uint64_t)n_active,
-                   batch_sweep_min_bytes(P, backward, n_active) / (uint64_t)n_active, (uint32_t)(pk >> kPackShift),
+      finish_dense(r.L, r.st, 8ull * P->m + 36ull * T.rows + 4ull + 4ull * P->m / (uint64_t)T.n_active,
+                   batch_sweep_min_bytes(P, T.backward, T.n_active) / (uint64_t)T.n_active, (uint32_t)(pk >> kPackShift),
                    pk & kPackMask);
     }
   return PPRHIP_OK;
+}
+
+int run_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_active) {
+  SweepTicket T;
+  PPRHIP_TRY(launch_sweep(P, runs, active, n_active, &T));
+  return collect_sweep(P, runs, T);
 }
 
 
@@ -507,6 +560,7 @@ int finish_query(BatchJob& J, ForaRun& r) {
     r.query = -1;
     return PPRHIP_OK;
   }
+  poll_idle(S);
   if (J.keep) {  // the vector stays in HBM after the slot moves on (internal order; pprhip_results_fetch permutes)
     {
       SetupScope setup(S);
@@ -575,85 +629,304 @@ static hipStream_t side_stream_for_walks(pprhip_graph* P) {
     P->walk_stream_tried = true;
     const char* e = getenv("PPRHIP_BATCH_WALKS_BESIDE");
     if (!(e && e[0] == '0') && make_side_stream(P, &P->walk_stream) != PPRHIP_OK) P->walk_stream = nullptr;
-    if (P->walk_stream)
-      for (pprhip_graph* S : P->slots)
-        for (auto& ev : S->walk_ev)
-          if (!ev && hipEventCreate(&ev) != hipSuccess) {
-            ev = nullptr;
-            (void)hipStreamDestroy(P->walk_stream);
-            P->walk_stream = nullptr;
-            return nullptr;
-          }
   }
+  if (P->walk_stream)  // (every call: twin workspaces may have joined since)
+    for (pprhip_graph* S : P->slots)
+      for (auto& ev : S->walk_ev)
+        if (!ev && hipEventCreate(&ev) != hipSuccess) {
+          ev = nullptr;
+          (void)hipStreamDestroy(P->walk_stream);
+          P->walk_stream = nullptr;
+          return nullptr;
+        }
   return P->walk_stream;
 }
 
-// Every slot of [s_lo, s_hi) advances until it waits at a dense level or for its walk phase; finished slots take the
-// next query from `next` (a call's own counter, or a stream's queue of submissions: false = nothing to start now) and
-// report finished ones to `done`.  *busy: the slots of the range that hold a query afterwards.
-template <class Next, class Done>
-int advance_slots(pprhip_graph* P, ForaRun* runs, int s_lo, int s_hi, bool* walking, hipStream_t side, Next&& next,
-                  Done&& done, int* busy) {
-  for (int s = s_lo; s < s_hi; ++s) {
-    ForaRun& r = runs[s];
-    if (walking[s]) {
-      if (hipEventQuery(P->slots[s]->walk_ev[2]) == hipErrorNotReady) continue;
-      walking[s] = false;
+// The stream the slots of the sequential driver work on: it has to run beside the compute stream (the sweeps) and
+// beside the walk stream.  PPRHIP_BATCH_SLOTS_BESIDE=0: the slots stay on the compute stream (the driver of rounds 1-4).
+static hipStream_t stream_for_slots(pprhip_graph* P) {
+  if (!P->slot_stream_tried) {
+    P->slot_stream_tried = true;
+    const char* e = getenv("PPRHIP_BATCH_SLOTS_BESIDE");
+    if (!(e && e[0] == '0')) {
+      if (make_side_stream(P, &P->slot_stream, P->walk_stream) != PPRHIP_OK) P->slot_stream = nullptr;
+      if (!P->slot_stream && P->walk_stream && make_side_stream(P, &P->slot_stream) != PPRHIP_OK) P->slot_stream = nullptr;
+    }
+  }
+  return P->slot_stream;
+}
+
+// The sequential batch driver: kBatch resumable runs on one host thread, their dense levels served by batched sweeps on
+// the handle's compute stream.  Until round 4 everything the slots did ran on that stream too, one blocking step after
+// the other: the stream spent a quarter of its time in a query's sparse levels, round ends, seeds and selections - a
+// few workgroups each, with a host round trip in between - while fifteen queries waited for the next sweep (kernel
+// trace: 12.5 % idle + 14 % in small kernels).  Now a sweep is only LAUNCHED, and while it runs the host takes the
+// slots that are not in it through their steps on a second stream (slot_stream; blocking there does not hold the
+// sweep up).  What such a slot does to the shared contribution array goes to the compute stream instead (C8Scope:
+// the dense prepare of its next level; the compaction back to list form), where stream order places it between two
+// sweeps.  A cycle: collect the sweep in flight -> the slots that were in it say what they do next without touching the
+// device (another dense level: they wait again; back to list form: the compaction is queued and the rest deferred) ->
+// launch the next sweep for those who wait -> the other slots' steps (new queries, sparse levels, round ends, walk
+// phases that have ended), until the sweep's counters arrive.
+//
+// Twin workspaces (whole-graph FORA): a column of c8 is only needed between a query's first dense level and its last,
+// 26 of the ~40 sweep periods a query spent in its slot on R-MAT 22 - the rest went to its first sparse levels, its
+// sparse tail, the walk phase and the selection.  So every column has two workspaces (slots[c] and slots[kBatch + c]):
+// while one query holds the column, the next one is taken through its first levels in the other workspace and stands
+// ready (kYieldColumn) when the column is let go - which happens as soon as its holder leaves a sweep without asking for
+// another (the compaction that empties the column is queued first; the twin's prepared level lands behind it).
+constexpr int kMaxWs = 2 * kBatch;
+
+struct SlotDriver {
+  pprhip_graph* P = nullptr;
+  ForaRun runs[kMaxWs];
+  int n_ws = kBatch;
+  hipStream_t side = nullptr;  // the walk phases' stream (whole-graph FORA)
+  bool walking[kMaxWs] = {false};
+  bool col_marked[kMaxWs] = {false};  // col_ev of the workspace has been recorded since it began to wait for its column
+  bool flying = false;
+  SweepTicket ticket;
+  int rr = 0;  // where the pass over the other workspaces starts (round robin: an early end must not starve anybody)
+  std::function<bool(BatchJob**, int*)> next;  // the next query to start (false: none right now)
+  std::function<void(BatchJob*)> done;         // a query of that job has finished
+  int cur_ws = -1;          // the workspace whose step is under way (the hook must not step it again)
+  bool in_turn = false;
+  int hook_rc = PPRHIP_OK;  // what a turn taken from inside a step's wait came to
+  std::string hook_msg;
+
+  // twins: two workspaces per column; slots_on: the stream the workspaces run on from here on (nullptr / P->stream:
+  // everything in stream order, as before round 5)
+  int setup(pprhip_graph* P_, bool twins, hipStream_t slots_on) {
+    P = P_;
+    n_ws = kBatch;
+    if (twins && !getenv("PPRHIP_BATCH_NO_TWINS")) {
+      if (ensure_twins(P) == PPRHIP_OK) n_ws = kMaxWs;
+      else if ((int)P->slots.size() > kBatch) {  // (no memory for them: one workspace per column)
+        (void)hipGetLastError();
+      }
+    }
+    for (int c = 0; c < kBatch; ++c) P->col_owner[c] = -1;
+    for (size_t w = 0; w < P->slots.size(); ++w) {
+      pprhip_graph* S = P->slots[w];
+      S->stream = slots_on ? slots_on : P->stream;
+      S->c8_via_parent = S->stream != P->stream;
+      S->sync = nullptr;
+      S->col_cell = (int)w < n_ws ? &P->col_owner[S->slot_index] : nullptr;
+    }
+    // the workspaces' read-backs look after the sweep in flight while they wait (only worth it when they wait on
+    // another stream than the sweep's)
+    if (slots_on && slots_on != P->stream && !getenv("PPRHIP_BATCH_NO_HOOK")) {
+      P->idle_hook = &SlotDriver::on_idle;
+      P->idle_arg = this;
+    }
+    return PPRHIP_OK;
+  }
+  void teardown() {
+    prof.print();
+    P->idle_hook = nullptr;
+    P->idle_arg = nullptr;
+    if (P->slot_stream) (void)hipStreamSynchronize(P->slot_stream);
+    for (pprhip_graph* S : P->slots) S->col_cell = nullptr;
+  }
+  static void on_idle(void* self) {
+    SlotDriver* D = static_cast<SlotDriver*>(self);
+    if (D->in_turn || !D->flying || D->hook_rc != PPRHIP_OK || !sweep_arrived(D->P, D->ticket)) return;
+    D->prof.n[5]++;
+    const int rc = D->turn();
+    if (rc != PPRHIP_OK) {
+      D->hook_rc = rc;
+      D->hook_msg = get_error();
+    }
+  }
+
+  // a workspace that holds its column without standing at a dense level lets it go (its column is all-zero, or the
+  // compaction that makes it so is queued on the compute stream)
+  void release_if_idle(int w) {
+    const int c = P->slots[w]->slot_index;
+    if (P->col_owner[c] == w && !(runs[w].query >= 0 && runs[w].waiting)) P->col_owner[c] = -1;
+  }
+
+  // one workspace as far as it gets: until it waits at a dense level, for its column or for its walk phase, or there is
+  // nothing to start.  defer: it must not wait for the device (the next sweep is not launched yet).
+  int step_ws(int w, bool defer) {
+    ForaRun& r = runs[w];
+    int rc = PPRHIP_OK;
+    const int outer = cur_ws;
+    if (!defer) {
+      cur_ws = w;
+      col_marked[w] = false;
     }
     for (;;) {
       if (r.query < 0) {
+        if (defer) break;
         BatchJob* J = nullptr;
         int i = -1;
         if (!next(&J, &i)) break;
-        PPRHIP_TRY(begin_query(*J, r, P->slots[s], i));
+        if ((rc = begin_query(*J, r, P->slots[w], i)) != PPRHIP_OK) break;
         r.side = side;
       }
       if (r.waiting) break;
-      const int rc = run_step(r, true);
+      if (defer) {
+        // only a run that stands between two levels of a push can answer without the device: a frontier it can
+        // sweep (again), or one that goes back to list form (the compaction is queued; the levels follow later)
+        const bool in_levels =
+            r.phase == ForaRun::kLevels || r.phase == ForaRun::kTopkLevels || r.phase == ForaRun::kBwdLevels;
+        if (!in_levels || r.L.nf == 0 || r.L.compacted) break;
+        if (!r.L.dense_prepared) {  // (a run that stood waiting for its column: its next level is a dense one)
+          bool dense = false;
+          (void)level_cost(r.g, r.L.nf, r.L.ef, &dense);
+          if (!dense) break;
+        }
+        r.L.defer_compact = true;
+      }
+      P->slots[w]->c8_settled = defer;
+      rc = run_step(r, true);
+      P->slots[w]->c8_settled = false;
+      r.L.defer_compact = false;
       if (rc == kYield) {
         r.waiting = true;
+        rc = PPRHIP_OK;
+        break;
+      }
+      if (rc == kYieldColumn && !defer) {
+        // what it has queued so far must have ended before it may take the column without waiting for the stream
+        pprhip_graph* S = P->slots[w];
+        if (!S->col_ev && hipEventCreateWithFlags(&S->col_ev, hipEventDisableTiming) != hipSuccess) S->col_ev = nullptr;
+        col_marked[w] = S->col_ev && hipEventRecord(S->col_ev, S->stream) == hipSuccess;
+      }
+      if (rc == kYieldDefer || rc == kYieldColumn) {
+        rc = PPRHIP_OK;
         break;
       }
       if (rc == kYieldWalk) {
-        walking[s] = true;
+        walking[w] = true;
+        rc = PPRHIP_OK;
         break;
       }
-      if (rc != PPRHIP_OK) return rc;
+      if (rc != PPRHIP_OK) break;
       BatchJob* const J = r.job;
-      PPRHIP_TRY(finish_query(*J, r));
+      if ((rc = finish_query(*J, r)) != PPRHIP_OK) break;
       done(J);
     }
-  }
-  *busy = 0;
-  for (int s = s_lo; s < s_hi; ++s) *busy += runs[s].query >= 0 ? 1 : 0;
-  return PPRHIP_OK;
-}
-
-// what follows when every slot has advanced as far as it can: one sweep for the slots that wait at a dense level - or,
-// when nobody does, the end of a walk phase has to be waited for.  *finished: no query is in flight any more.
-int sweep_or_wait(pprhip_graph* P, ForaRun* runs, const bool* walking, int busy, bool* finished) {
-  *finished = busy == 0;
-  if (busy == 0) return PPRHIP_OK;
-  bool active[kBatch];
-  int n_wait = 0, first_walk = -1;
-  for (int s = 0; s < kBatch; ++s) {
-    active[s] = runs[s].query >= 0 && runs[s].waiting;
-    n_wait += active[s] ? 1 : 0;
-    if (walking[s] && first_walk < 0) first_walk = s;
-  }
-  if (n_wait == 0) {  // nobody stands at a dense level: a walk phase has to end before anything can go on
-    if (first_walk < 0) {
-      set_error("batch driver: %d queries in flight, none waiting", busy);
-      return PPRHIP_ERR_STATE;
+    if (!defer) cur_ws = outer;
+    release_if_idle(w);
+    if (rc == PPRHIP_OK && hook_rc != PPRHIP_OK) {
+      set_error("%s", hook_msg.c_str());
+      rc = hook_rc;
     }
-    PPRHIP_CHECK_HIP(hipEventSynchronize(P->slots[first_walk]->walk_ev[2]));
+    return rc;
+  }
+
+  // collect the sweep in flight, let its queries (and the twins of those that let their column go) say what they do
+  // next, launch the next sweep: nothing in here waits for the device beyond the sweep's counters
+  int turn() {
+    in_turn = true;
+    const int rc = turn_body();
+    in_turn = false;
+    return rc;
+  }
+  // PPRHIP_DRIVER_PROFILE=1: host time of a turn by part, printed when the driver ends (developer switch)
+  struct Prof {
+    bool on = getenv("PPRHIP_DRIVER_PROFILE") != nullptr;
+    double us[6] = {0};
+    unsigned long long n[6] = {0};
+    std::chrono::steady_clock::time_point t;
+    void start() {
+      if (on) t = std::chrono::steady_clock::now();
+    }
+    void lap(int i) {
+      if (!on) return;
+      const auto now = std::chrono::steady_clock::now();
+      us[i] += std::chrono::duration<double, std::micro>(now - t).count();
+      n[i]++;
+      t = now;
+    }
+    void print() const {
+      if (!on) return;
+      static const char* names[6] = {"collect", "owner goes on (kYield)", "owner leaves (compaction)", "twin takes over", "launch", "turn from a wait"};
+      for (int i = 0; i < 6; ++i)
+        if (n[i]) fprintf(stderr, "[driver] %-28s %8llu x %8.1f us\n", names[i], n[i], us[i] / (double)n[i]);
+    }
+  } prof;
+  int turn_body() {
+    prof.start();
+    if (flying) {
+      PPRHIP_TRY(collect_sweep(P, runs, ticket));
+      flying = false;
+      prof.lap(0);
+      for (int c = 0; c < kBatch; ++c)
+        if (ticket.active[c]) {
+          const int w = ticket.ws[c];
+          runs[w].waiting = false;
+          PPRHIP_TRY(step_ws(w, true));
+          prof.lap(runs[w].waiting ? 1 : 2);
+          // the column has been let go: its twin, if it stands ready, prepares its level behind the compaction
+          const int tw = (w + kBatch) % kMaxWs;
+          if (P->col_owner[c] < 0 && tw < n_ws && tw != cur_ws && runs[tw].query >= 0 && !walking[tw] &&
+              !runs[tw].waiting && col_marked[tw] && hipEventQuery(P->slots[tw]->col_ev) == hipSuccess) {
+            PPRHIP_TRY(step_ws(tw, true));
+            prof.lap(3);
+          }
+        }
+    }
+    bool active[kBatch];
+    int ws[kBatch];
+    int n_wait = 0;
+    for (int c = 0; c < kBatch; ++c) {
+      const int w = P->col_owner[c];
+      active[c] = w >= 0 && runs[w].query >= 0 && runs[w].waiting;
+      ws[c] = active[c] ? w : c;
+      n_wait += active[c] ? 1 : 0;
+    }
+    if (n_wait) {
+      prof.start();
+      PPRHIP_TRY(launch_sweep(P, runs, active, n_wait, &ticket, ws));
+      flying = true;
+      prof.lap(4);
+    }
     return PPRHIP_OK;
   }
-  PPRHIP_TRY(run_sweep(P, runs, active, n_wait));
-  for (int s = 0; s < kBatch; ++s)
-    if (active[s]) runs[s].waiting = false;
-  return PPRHIP_OK;
-}
+
+  // One cycle (see above).  *busy: the workspaces that hold a query afterwards; with none and nothing to start the
+  // caller is done (or waits for work).
+  int cycle(int* busy) {
+    PPRHIP_TRY(turn());
+    // the workspaces that are not in the sweep
+    const int first = rr;
+    for (int t = 0; t < n_ws; ++t) {
+      const int w = (first + t) % n_ws;
+      if (runs[w].query >= 0 && runs[w].waiting) continue;  // in the sweep
+      if (flying && sweep_arrived(P, ticket)) {  // the compute stream is idle: the sweep's queries come first
+        rr = w;
+        break;
+      }
+      if (walking[w]) {
+        if (hipEventQuery(P->slots[w]->walk_ev[2]) == hipErrorNotReady) continue;
+        walking[w] = false;
+      }
+      PPRHIP_TRY(step_ws(w, false));
+    }
+    *busy = 0;
+    int n_wait = 0, n_pending = 0, first_walk = -1;
+    for (int w = 0; w < n_ws; ++w) {
+      const bool has = runs[w].query >= 0;
+      *busy += has ? 1 : 0;
+      n_wait += (has && runs[w].waiting) ? 1 : 0;
+      // (left behind by a turn taken from inside this pass, after the pass had gone by: the next cycle takes it on)
+      n_pending += (has && !runs[w].waiting && !walking[w]) ? 1 : 0;
+      if (walking[w] && first_walk < 0) first_walk = w;
+    }
+    if (*busy > 0 && !flying && n_wait == 0 && n_pending == 0) {
+      // nobody stands at a dense level and no sweep is on its way: a walk phase has to end before anything can go on
+      if (first_walk < 0) {
+        set_error("batch driver: %d queries in flight, none waiting", *busy);
+        return PPRHIP_ERR_STATE;
+      }
+      PPRHIP_CHECK_HIP(hipEventSynchronize(P->slots[first_walk]->walk_ev[2]));
+    }
+    return PPRHIP_OK;
+  }
+};
 
 // Queries left over when a call's count is not a multiple of the slots: up to kTailSingle of them run one at a time on
 // the handle's own workspace (the single-query path: 10 ms each on R-MAT 22) instead of as a last round of sweeps with
@@ -677,23 +950,36 @@ int run_tail(BatchJob& J, int q_slots) {
   return PPRHIP_OK;
 }
 
-// all slots on the calling thread and the graph's stream, one after another
-int batch_sequential(BatchJob& J, ForaRun* runs) {
+// all queries on the calling thread (SlotDriver)
+int batch_sequential(BatchJob& J) {
   pprhip_graph* P = J.P;
-  hipStream_t side = J.kind == 0 ? side_stream_for_walks(P) : nullptr;
-  bool walking[kBatch] = {false};
+  std::unique_ptr<SlotDriver> Dp(new (std::nothrow) SlotDriver());
+  if (!Dp) return PPRHIP_ERR_OOM;
+  SlotDriver& D = *Dp;
+  D.side = J.kind == 0 ? side_stream_for_walks(P) : nullptr;
+  PPRHIP_TRY(D.setup(P, J.kind == 0 && J.q > kBatch, stream_for_slots(P)));
+  if (D.side) D.side = side_stream_for_walks(P);  // (the twins' events)
+  KernelTimer& tm = ktimer();  // (the call's timer watches the stream the workspaces' kernels run on ...)
+  tm.stream = P->slots[0]->stream;
   const int q_slots = J.q - tail_queries(J);  // queries the slots run
-  auto next = [&](BatchJob** job, int* i) {
+  D.next = [&](BatchJob** job, int* i) {
     *i = J.next_query.fetch_add(1);
     *job = &J;
     return *i < q_slots;
   };
+  D.done = [](BatchJob*) {};
+  int rc = PPRHIP_OK;
   for (;;) {
     int busy = 0;
-    PPRHIP_TRY(advance_slots(P, runs, 0, kBatch, walking, side, next, [](BatchJob*) {}, &busy));
-    bool finished = false;
-    PPRHIP_TRY(sweep_or_wait(P, runs, walking, busy, &finished));
-    if (finished) break;
+    if ((rc = D.cycle(&busy)) != PPRHIP_OK) break;
+    if (busy == 0) break;
+  }
+  D.teardown();
+  if (rc != PPRHIP_OK) return rc;
+  if (tm.stream != P->stream) {  // (... and the stragglers' on the handle's own)
+    (void)hipStreamSynchronize(P->stream);
+    tm.fold();
+    tm.stream = P->stream;
   }
   return run_tail(J, q_slots);
 }
@@ -703,7 +989,7 @@ int batch_sequential(BatchJob& J, ForaRun* runs) {
 // each other's gaps in the stream, which idles 12-18 % of the time behind the host's decisions.  It got slower with
 // every thread added: 326 / 322 / 315 / 307 / 301 queries/s with 1 / 2 / 4 / 8 / 16 threads, the sweeps themselves
 // 1 334 -> 1 443 us (profiles/r04_driver_threads_study.txt) - several threads launching into one stream pay more in the
-// runtime than the gaps they close.  Taken out; advance_slots / sweep_or_wait are what is left of the refactoring.)
+// runtime than the gaps they close.  Taken out.  Round 5 closes the gaps from ONE thread instead: SlotDriver.)
 
 // one worker thread per slot
 void batch_worker(BatchJob* J, BatchSync* B, ForaRun* runs, int s) {
@@ -1033,6 +1319,7 @@ int pprhip::detail::batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* st
     B.runs = runs;
     for (pprhip_graph* S : g->slots) {
       S->stream = S->own_stream;
+      S->c8_via_parent = false;
       S->sync = &B;
     }
     B.n_workers = kBatch;
@@ -1052,13 +1339,14 @@ int pprhip::detail::batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* st
   } else {
     for (pprhip_graph* S : g->slots) {
       S->stream = g->stream;
+      S->c8_via_parent = false;
       S->sync = nullptr;
     }
     KernelTimer local;  // the caller's timer may be in use (All-Pair times its own tiers)
     KernelTimer* const saved = g_timer_cur;
     g_timer_cur = &local;
     local.stream = g->stream;
-    rc = batch_sequential(J, runs);
+    rc = batch_sequential(J);
     (void)hipStreamSynchronize(g->stream);
     local.resolve(tot, bytes, cnt);
     local.destroy();
@@ -1244,6 +1532,7 @@ int pprhip_fora_batch_topk(pprhip_graph_t* g, const int32_t* srcs, int q, int k,
 // continuously - a harness that calls Gen_Util's loop again and again, a server - always find sixteen columns busy.
 // Every query runs exactly as pprhip_fora_batch_single_source would run it (same seed, same tuning, same result).
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 
@@ -1299,19 +1588,24 @@ void stream_driver(pprhip_stream* s) {
   quiet.off = true;
   KernelTimer* const saved = g_timer_cur;
   g_timer_cur = &quiet;
-  for (pprhip_graph* S : P->slots) {
-    S->stream = P->stream;
-    S->sync = nullptr;
+  std::unique_ptr<SlotDriver> Dp(new (std::nothrow) SlotDriver());
+  if (!Dp) {
+    set_error("query stream: no memory for the driver's state");
+    stream_fail(s, PPRHIP_ERR_OOM);
+    g_timer_cur = saved;
+    return;
   }
-  hipStream_t side = side_stream_for_walks(P);
-  ForaRun runs[kBatch];
-  bool walking[kBatch] = {false};
+  SlotDriver& D = *Dp;
+  D.side = side_stream_for_walks(P);
+  (void)D.setup(P, true, stream_for_slots(P));
+  if (D.side) D.side = side_stream_for_walks(P);  // (the twins' events)
+  hipStream_t side = D.side;
   // test switch: PPRHIP_STREAM_FAULT_AT=<n> makes the driver fail when it is about to start the stream's n-th query
   // (0-based), as a failing kernel launch would: every open and later submission ends with the driver's error
   long fault_at = -1, started = 0;
   if (const char* fe = getenv("PPRHIP_STREAM_FAULT_AT")) fault_at = atol(fe);
   bool injected = false;
-  auto next = [&](BatchJob** job, int* i) {
+  D.next = [&](BatchJob** job, int* i) {
     if (fault_at >= 0 && started == fault_at) {
       injected = true;
       return false;
@@ -1325,7 +1619,7 @@ void stream_driver(pprhip_stream* s) {
     ++started;
     return true;
   };
-  auto done = [&](BatchJob* job) {
+  D.done = [&](BatchJob* job) {
     StreamJob* J = static_cast<StreamJob*>(job);
     std::lock_guard<std::mutex> lk(s->mu);
     if (++J->finished == J->q) {
@@ -1338,7 +1632,7 @@ void stream_driver(pprhip_stream* s) {
   try {  // (no exception leaves the driver thread: it would end the process)
   for (;;) {
     int busy = 0;
-    if ((rc = advance_slots(P, runs, 0, kBatch, walking, side, next, done, &busy)) != PPRHIP_OK) break;
+    if ((rc = D.cycle(&busy)) != PPRHIP_OK) break;
     if (injected) {
       set_error("query stream: injected failure before query %ld (PPRHIP_STREAM_FAULT_AT)", fault_at);
       rc = PPRHIP_ERR_STATE;
@@ -1350,8 +1644,6 @@ void stream_driver(pprhip_stream* s) {
       if (s->pending.empty()) break;  // closing, and nothing left to start or in flight
       continue;
     }
-    bool finished = false;
-    if ((rc = sweep_or_wait(P, runs, walking, busy, &finished)) != PPRHIP_OK) break;
   }
   } catch (const std::exception& ex) {
     set_error("query stream: %s in the driver thread", ex.what());
@@ -1360,6 +1652,7 @@ void stream_driver(pprhip_stream* s) {
   // Drain before anybody is woken: a waiter that returns the error may free its result store or its output block at
   // once, and copies or selections of other slots' queries can still be queued against those buffers.
   (void)hipStreamSynchronize(P->stream);
+  D.teardown();
   if (P->walk_stream) (void)hipStreamSynchronize(P->walk_stream);
   if (side && side != P->stream && side != P->walk_stream) (void)hipStreamSynchronize(side);
   if (rc != PPRHIP_OK) stream_fail(s, rc);

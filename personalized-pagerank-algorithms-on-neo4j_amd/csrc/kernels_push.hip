@@ -556,6 +556,117 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
   }
 }
 
+// k_dense_edges_p (round 5): the single-query edge kernel over the source-partitioned copy of the in-CSR (PartLayout,
+// built for the batched sweep).  Workgroup b walks partition b % kParts - so the workgroups of one XCD only ever gather
+// contributions of ids = p mod 8 - and its LDS table holds the 16 384 hottest contributions OF ITS PARTITION: ids below
+// 131 072 (three quarters of R-MAT 22's in-edges) are served from LDS instead of the 42 % a table of the 16 384 hottest
+// ids overall serves, and what is left of a partition's contributions (2.3 MB) stays in its XCD's L2.  A "row" of
+// the copy is a (row, partition) segment whose sum is a plain 8-byte store into part1[segment] (only segments that
+// cross a chunk use an atomic) - the sliced copy's kernel adds every (row, slice) segment to the row's accumulator
+// with a memory-side atomic - and k_dense_apply<.., PART> adds a row's up to eight partials.  Rows of at most
+// kPartWholeRow in-edges sit whole in the partition of their ordinal: their sources can belong to any partition, so
+// the table is only used for ids of the workgroup's own.
+template <bool HOT>
+__global__ __launch_bounds__(1024) void k_dense_edges_p(const int32_t* __restrict__ in_ci,
+                                                         const uint8_t* __restrict__ start_flags,
+                                                         const uint32_t* __restrict__ chunk_starts, PartWindows W,
+                                                         const double* __restrict__ c_cur, double* __restrict__ part1,
+                                                         uint32_t n_hot, uint32_t n, const int* state_in) {
+  extern __shared__ __attribute__((aligned(16))) double s_hot[];
+  if (dense_state(state_in, kGsJacobi) == kGsNone) return;
+  const int lane = lane_id();
+  const uint32_t part = blockIdx.x % (uint32_t)kParts;
+  const uint32_t rank = blockIdx.x / (uint32_t)kParts, wgs = gridDim.x / (uint32_t)kParts;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  const uint32_t stride = wgs * waves_per_block;
+  const uint32_t c_end = W.c_hi[part];
+  const unsigned long long e_lo = W.e_lo[part], e_hi = W.e_hi[part];
+  uint32_t c = W.c_lo[part] + rank * waves_per_block + (uint32_t)__builtin_amdgcn_readfirstlane(wave_id());
+  ChunkRegs cur;
+  if (c < c_end) cur = load_chunk(in_ci, start_flags, c, lane);  // in flight while the hot table loads
+  if (HOT) {
+    double t[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t i = threadIdx.x + j * 1024u;          // position in the partition's table
+      const uint32_t id = part_global(i, part);
+      t[j] = (i < n_hot && id < n) ? c_cur[id] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t i = threadIdx.x + j * 1024u;
+      if (i < n_hot) s_hot[i] = t[j];
+    }
+    __syncthreads();
+  }
+  for (; c < c_end; c += stride) {
+    ChunkRegs nxt = cur;
+    if (c + stride < c_end) nxt = load_chunk(in_ci, start_flags, c + stride, lane);
+    const uint32_t cs = chunk_starts[c];
+    const unsigned long long e0 = (unsigned long long)c * kChunkEdges + 8ull * lane;
+    const uint32_t fb = cur.fb;
+    const int32_t idx[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
+    double v[8];
+    if (HOT) {
+      // branch-free, as in k_dense_edges: every lane issues both loads so that its 8 gathers stay in flight together
+      bool hot[8];
+      double gl[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t u = (uint32_t)idx[i];
+        hot[i] = part_of(u) == part && part_local(u) < n_hot;
+        gl[i] = c_cur[hot[i] ? 0u : u];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double hv = s_hot[hot[i] ? part_local((uint32_t)idx[i]) : 0u];
+        v[i] = hot[i] ? hv : gl[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = c_cur[idx[i]];
+    }
+    if (e0 < e_lo || e0 + 8 > e_hi) {  // first / last chunk of the block's window only
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (e0 + i < e_lo || e0 + i >= e_hi) v[i] = 0.0;
+    }
+    const uint32_t pc = __popc(fb);
+    const uint32_t incl = wave_incl_scan_u32_dpp(pc);
+    const uint32_t before = cs + incl - pc;  // segment starts before this lane's first edge (global ordinals)
+    double seg = 0.0, first_seg = 0.0;
+    uint32_t k = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if ((fb >> i) & 1u) {
+        if (k == 0) first_seg = seg;                 // closes the segment carried in from earlier lanes
+        else part1[before + k - 1] = seg;            // a segment that starts and ends inside this lane
+        seg = 0.0;
+        ++k;
+      }
+      seg += v[i];
+    }
+    const bool h = k != 0;
+    const double sval = wave_seg_scan_f64_dpp(seg, h);
+    const double carry = wave_prev_f64_dpp(sval);
+    const unsigned long long hmask = __ballot(h);
+    if (h) {
+      const bool nonempty = lane > 0 || (fb & 1u) == 0;
+      if (nonempty && before > 0) {
+        const double tot = carry + first_seg;
+        const bool started_here = (hmask & ((1ull << lane) - 1ull)) != 0;
+        if (started_here) part1[before - 1] = tot;
+        else atomic_add_noret(&part1[before - 1], tot);  // began in an earlier chunk
+      }
+    }
+    if (lane == 63) {  // the segment still open at the end of the chunk
+      const uint32_t starts = cs + incl;
+      if (starts > 0 && sval != 0.0) atomic_add_noret(&part1[starts - 1], sval);
+    }
+    cur = nxt;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // batched dense level: kBatch queries per sweep
 // ------------------------------------------------------------------------------------------------
@@ -1012,9 +1123,19 @@ __global__ __launch_bounds__(1024) void k_dense_edges_q(const int32_t* __restric
 // k_dense_apply: one thread per non-empty row (plus one for a source without in-edges, which
 // only ever receives returned dead-end mass): lands the row sum, detects the threshold crossing
 // and prepares the row for the next level in place.
-template <int MODE>
+// PART: the row sums arrive as the partial sums of the row's (row, partition) segments (k_dense_edges_p): tile t of
+// partition p holds the segments tile_seg0[p][t] ... in row order for the rows of tile_mask[p][t]; segments summed with
+// atomics (tile_cross) are cleared as they are read.  (acc_nz is the partial-sum array then.)
+struct PartTiles {
+  const uint32_t* seg0;               // [kParts][n_tiles + 1]
+  const unsigned long long* mask;     // [kParts][n_tiles]
+  const unsigned long long* cross;    // [kParts][n_tiles]
+  uint32_t n_tiles, n_seg;
+};
+
+template <int MODE, bool PART>
 __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__ nz_rows, uint32_t j_lo, uint32_t n_nz,
-                                                      double* __restrict__ acc_nz,
+                                                      double* __restrict__ acc_nz, PartTiles PT,
                                                       const uint32_t* __restrict__ out_rp,
                                                       const uint32_t* __restrict__ in_rp,
                                                       double* __restrict__ c_cur, double* __restrict__ c_next,
@@ -1037,8 +1158,29 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
   double acc = 0.0;
   if (j < n_nz) {
     u = nz_rows[j];
-    acc = acc_nz[j];
-    acc_nz[j] = 0.0;
+    if (PART) {
+      // (a wave covers the 64 rows of one tile: the tile's words are the same address for all its lanes)
+      const uint32_t tl = j / (uint32_t)kTileRows, r = j % (uint32_t)kTileRows;
+      double x[kParts];
+      uint32_t at[kParts];
+      bool clr[kParts];
+#pragma unroll
+      for (int p = 0; p < kParts; ++p) {
+        const unsigned long long mk = PT.mask[(size_t)p * PT.n_tiles + tl];
+        const bool has = (mk >> r) & 1ull;
+        at[p] = has ? PT.seg0[(size_t)p * (PT.n_tiles + 1) + tl] + (uint32_t)__popcll(mk & ((1ull << r) - 1ull)) : PT.n_seg;
+        clr[p] = has && ((PT.cross[(size_t)p * PT.n_tiles + tl] >> r) & 1ull);
+        x[p] = acc_nz[at[p]];  // (rows without a segment in p read the all-zero slot behind the last segment)
+      }
+#pragma unroll
+      for (int p = 0; p < kParts; ++p) {
+        acc += x[p];
+        if (clr[p] && x[p] != 0.0) acc_nz[at[p]] = 0.0;
+      }
+    } else {
+      acc = acc_nz[j];
+      acc_nz[j] = 0.0;
+    }
     have = true;
   } else if (j == n_nz && src_extra) {
     u = a.src;
@@ -1816,8 +1958,12 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   const GsBlock* blocks = (dl.blocks && dl.n_blocks > 1 && !bwd) ? dl.blocks : &whole;
   const int nb = blocks == &whole ? 1 : dl.n_blocks;
   const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
-  // forward sweeps of a graph whose sources span several slices walk the sliced copy of the in-CSR
-  const SlicedLayout* sl = bwd ? nullptr : g->sl;
+  // forward sweeps of a handle with the source-partitioned copy (PPRHIP_SWEEP1_PARTS, engine.cpp: ensure_part_single) walk
+  // that; otherwise those of a graph whose sources span several slices walk the sliced copy of the in-CSR.  (A batch
+  // slot borrows its parent's copy and has partial sums of its own.)
+  pprhip_graph* pl_owner = g->parent ? g->parent : g;
+  const bool part = !bwd && pl_owner->pl && g->part1;
+  const SlicedLayout* sl = (bwd || part) ? nullptr : g->sl;
   const EdgeWindows* wins = sl ? detail::sliced_windows_of(g, blocks == &whole ? nullptr : blocks, nb) : nullptr;
   if (sl) {
     ci = sl->ci;
@@ -1838,7 +1984,39 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     }
     const EdgeWindows& W = sl ? wins[b] : one;
     const uint32_t n_ch = W.n ? W.c_pre[W.n] : 0u;
-    if (g->n_chunks && n_ch) {
+    if (part) {
+      // the source-partitioned copy: one launch, workgroup b on partition b % kParts (launch_dense_edges_part)
+      const PartLayout& L = *pl_owner->pl;
+      const uint32_t NT = L.n_tiles;
+      const uint32_t t_lo = B.j_lo / kTileRows, t_hi = std::min<uint32_t>(NT, (B.j_hi + kTileRows - 1) / kTileRows);
+      PartWindows PW{};
+      uint32_t most = 0;
+      for (int p = 0; p < kParts; ++p) {
+        const unsigned long long e_lo = L.h_tile_edge0[(size_t)p * (NT + 1) + t_lo];
+        const unsigned long long e_hi = L.h_tile_edge0[(size_t)p * (NT + 1) + t_hi];
+        PW.e_lo[p] = e_lo;
+        PW.e_hi[p] = e_hi;
+        PW.c_lo[p] = (uint32_t)(e_lo / kChunkEdges);
+        PW.c_hi[p] = e_hi > e_lo ? (uint32_t)((e_hi + kChunkEdges - 1) / kChunkEdges) : PW.c_lo[p];
+        most = std::max(most, PW.c_hi[p] - PW.c_lo[p]);
+      }
+      if (most) {
+        // PPRHIP_SWEEP1_HOT (measurement switch): lines of the partition's LDS table; half a table lets two workgroups share a CU
+        static const uint32_t hot_lines = [] {
+          const char* e = getenv("PPRHIP_SWEEP1_HOT");
+          return e ? (uint32_t)std::max(64, std::min((int)kHotMax, atoi(e))) : (uint32_t)kHotMax;
+        }();
+        const uint32_t per_cu = hot_lines * 2 <= (uint32_t)kHotMax ? 2u : 1u;
+        const uint32_t per_part = std::max(1u, std::min<uint32_t>((most + 15) / 16, (uint32_t)g->n_cus / kParts * per_cu));
+        if (n_hot)
+          k_dense_edges_p<true><<<dim3(per_part * kParts), dim3(1024), sizeof(double) * hot_lines, g->stream>>>(
+              L.ci, L.flags, L.chunk_starts, PW, g->cdense[cbuf], g->part1, hot_lines, g->n, dl.state_in);
+        else
+          k_dense_edges_p<false><<<dim3(per_part * kParts), dim3(1024), 0, g->stream>>>(
+              L.ci, L.flags, L.chunk_starts, PW, g->cdense[cbuf], g->part1, 0u, g->n, dl.state_in);
+        PPRHIP_CHECK_HIP(hipGetLastError());
+      }
+    } else if (g->n_chunks && n_ch) {
       // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
       const uint32_t want = (n_ch + 15) / 16;
       const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * (n_hot ? 1u : 2u));
@@ -1861,11 +2039,22 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     const uint32_t rows = B.j_hi - B.j_lo + (uint32_t)extra;
     const uint32_t grid = (rows + 255) / 256;
     if (grid) {
-      DISPATCH_MODE(a.mode, k_dense_apply<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                                nz, B.j_lo, B.j_hi, g->acc_nz, g->out_rp, g->in_rp, g->cdense[cbuf], g->cdense[cbuf ^ 1],
-                                g->residue, g->reserve, g->flags, g->armed, g->ctr, g->blk_pack + part_base,
-                                g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot, extra, a, dl.state_in,
-                                dl.state0, b == nb - 1 ? 1 : 0));
+      if (part) {
+        const PartLayout& L = *pl_owner->pl;
+        const PartTiles PT{L.tile_seg0, L.tile_mask, L.tile_cross, L.n_tiles, L.n_seg};
+        DISPATCH_MODE(a.mode, (k_dense_apply<M, true><<<dim3(grid), dim3(256), 0, g->stream>>>(
+                                  nz, B.j_lo, B.j_hi, g->part1, PT, g->out_rp, g->in_rp, g->cdense[cbuf], g->cdense[cbuf ^ 1],
+                                  g->residue, g->reserve, g->flags, g->armed, g->ctr, g->blk_pack + part_base,
+                                  g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot, extra, a, dl.state_in,
+                                  dl.state0, b == nb - 1 ? 1 : 0)));
+      } else {
+        const PartTiles none{nullptr, nullptr, nullptr, 0u, 0u};
+        DISPATCH_MODE(a.mode, (k_dense_apply<M, false><<<dim3(grid), dim3(256), 0, g->stream>>>(
+                                  nz, B.j_lo, B.j_hi, g->acc_nz, none, g->out_rp, g->in_rp, g->cdense[cbuf], g->cdense[cbuf ^ 1],
+                                  g->residue, g->reserve, g->flags, g->armed, g->ctr, g->blk_pack + part_base,
+                                  g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot, extra, a, dl.state_in,
+                                  dl.state0, b == nb - 1 ? 1 : 0)));
+      }
       PPRHIP_CHECK_HIP(hipGetLastError());
       part_base += grid;
     }
@@ -2129,6 +2318,8 @@ int init_kernels_push() {
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_p<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));

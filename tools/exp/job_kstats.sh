@@ -7,7 +7,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/ks_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$tag -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extras > /tmp/ks_$tag.log 2>&1 || echo "(the profiled program failed - a measurement switch that breaks the results? - its kernel times follow)"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$tag -- python3 $root/bench.py ${KSTATS_ARGS:---steps 2 --warmup 1} --no-cpu-baseline --no-pmc --no-extras > /tmp/ks_$tag.log 2>&1 || echo "(the profiled program failed - a measurement switch that breaks the results? - its kernel times follow)"
 python3 - "$tag" > $out/${tag}_kstats.txt <<'PY'
 import csv, glob, sys
 f = glob.glob("/tmp/ks_%s/**/*kernel_stats.csv" % sys.argv[1], recursive=True)
