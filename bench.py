@@ -459,6 +459,8 @@ def main():
             if r24_child is not None and "error" not in out["all_pair_rmat24"]:
                 rmat24_counters(out["all_pair_rmat24"], out["roofline"].get("fetch_size_calibration"))
                 note("R-MAT 24 counter passes done")
+            sweeps_alone(args, out["roofline"])
+            note("sweeps-alone child done")
             idle = stream_idle(args)
             out["compute_stream_idle_frac"] = idle.get("compute_stream_idle_frac")
             if idle.get("sweep_kernels"):
@@ -1331,6 +1333,36 @@ def pmc_traffic(args, host):
     if tcc is None:
         res["tcc_note"] = "TCC_HIT / TCC_MISS pass failed: %s" % tcc_err
     return res
+
+
+def sweeps_alone(args, roofline):
+    """roofline.sweeps_alone: the same workload in a child process with everything in stream order (the driver of
+    rounds 1-4: PPRHIP_BATCH_SLOTS_BESIDE=0, PPRHIP_BATCH_WALKS_BESIDE=0), where a sweep has the memory system to
+    itself.  Since round 5 the timed region's sweeps share it with the walk phases and the sparse levels of the
+    queries that hold no column, so `frac` (measured live, as the contract asks) is the sweep's share of a busier chip;
+    this is what the kernels reach on their own, with the throughput that ordering gives."""
+    if roofline.get("kernel") != "dense_pull_batch":
+        return
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--scale", str(args.scale),
+           "--queries-per-step", str(args.queries_per_step), "--no-cpu-baseline", "--no-pmc", "--no-extras", "--no-rmat24"]
+    if args.tuning:
+        cmd += ["--tuning", args.tuning]
+    env = dict(os.environ, PPRHIP_BATCH_SLOTS_BESIDE="0", PPRHIP_BATCH_WALKS_BESIDE="0")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    res = _child_json(child, 240, "the sweeps-alone child")
+    if "error" in res:
+        roofline["sweeps_alone"] = res
+        return
+    us = res["roofline"].get("avg_sweep_us")
+    per = roofline.get("traffic") or roofline["algorithmic_bytes_per_launch"]
+    ach = per / 1e9 / (us / 1e6) if us else 0.0
+    roofline["sweeps_alone"] = {
+        "avg_sweep_us": us, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+        "bytes_per_sweep": "counter traffic" if roofline.get("traffic") else "compulsory",
+        "value_in_stream_order": res["value"],
+        "note": "child run with every kernel of the job on one stream (no walk phase or sparse level beside a sweep): "
+                "the sweep kernels' own rate, and the queries/s that ordering gives; `frac` above is measured live in the "
+                "timed region, where the sweeps share the memory system with that other work"}
 
 
 def apply_counters(out, pmc, avg_us, extras):

@@ -391,11 +391,15 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       c = dense_sweep_cost(g);
     }
     if (dense) {
-      if (!L.dense_prepared && slot && g->col_cell && *g->col_cell != g->ws_index) {
-        // twin workspaces: a column of c8 serves one of them at a time (nothing has been decided or queued yet: the
-        // driver calls again when the column is free)
-        if (*g->col_cell >= 0) return kYieldColumn;
-        *g->col_cell = g->ws_index;
+      if (!L.dense_prepared && slot && g->pooled && !g->has_col) {
+        // workspace pool: the level needs a column of c8 (nothing has been decided or queued yet: the driver calls
+        // again when one is free)
+        int c = 0;
+        while (c < kBatch && g->parent->col_owner[c] >= 0) ++c;
+        if (c == kBatch) return kYieldColumn;
+        g->parent->col_owner[c] = g->ws_index;
+        g->slot_index = c;
+        g->has_col = true;
       }
       if (model_cost) *model_cost += c;
       if (cut) cut->had_dense = true;
@@ -724,8 +728,8 @@ static int make_slot(pprhip_graph* P, int w) {
   return PPRHIP_OK;
 }
 
-int ensure_twins(pprhip_graph* P) {
-  while ((int)P->slots.size() < 2 * kBatch) PPRHIP_TRY(make_slot(P, (int)P->slots.size()));
+int ensure_workspaces(pprhip_graph* P, int count) {
+  while ((int)P->slots.size() < count) PPRHIP_TRY(make_slot(P, (int)P->slots.size()));
   PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
   return PPRHIP_OK;
 }
@@ -981,9 +985,9 @@ int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L) {
   L.gs_dirty = false;
   bool dense = false;
   if (L.nf) (void)level_cost(g, L.nf, L.ef, &dense);
-  // (a twin workspace that does not hold its column lists the start set instead; run_levels prepares the level from
-  // the list once the column is its own)
-  if (dense && g->parent && g->col_cell && *g->col_cell != g->ws_index) dense = false;
+  // (a pooled workspace that holds no column lists the start set instead; run_levels prepares the level from the
+  // list once it has one)
+  if (dense && g->parent && g->pooled && !g->has_col) dense = false;
   if (dense) {
     C8Scope c8(g, false);
     PPRHIP_TRY(c8.rc);

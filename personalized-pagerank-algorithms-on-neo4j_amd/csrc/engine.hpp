@@ -336,15 +336,17 @@ struct pprhip_graph {
   bool c8_settled = false;  // nothing of this slot is pending on its stream: C8Scope need not wait for that stream
   hipEvent_t c8_ev[2] = {nullptr, nullptr};
   hipEvent_t col_ev = nullptr;  // recorded on the slot's stream when it began to wait for its column
-  // Twin workspaces (SlotDriver): slots[kBatch + c] shares column c of c8 with slots[c].  graph: who holds each
-  // column (-1: nobody; an index into `slots`); slot: its own index there and the cell it has to win before it
-  // prepares a dense level (nullptr: the column is its own, as in the threaded driver)
+  // Workspace pool (SlotDriver): more workspaces than columns of c8.  graph: who holds each column (-1: nobody; an
+  // index into `slots`); slot: its own index there; pooled: it has to win a free column - which becomes its
+  // slot_index - before it prepares a dense level, and the driver takes the column back when it leaves the sweeps
+  // (not pooled: column ws_index % kBatch is its own, as in the threaded driver)
   int col_owner[pprhip::kBatch];
+  int ws_index = -1;
+  bool pooled = false;
+  bool has_col = false;
   // graph: called by a slot's small read-backs while they wait (fetch_end): the driver looks after the sweep in flight
   void (*idle_hook)(void*) = nullptr;
   void* idle_arg = nullptr;
-  int ws_index = -1;
-  int* col_cell = nullptr;
   // graph: a stream that runs beside the compute stream (make_side_stream) for the slots' walk phases while sweeps
   // go on (sequential batch driver); slot: the events around its walk phase on that stream
   uint32_t walk_waves = 0;  // waves per CU of the next walk kernels (0: the default)

@@ -101,7 +101,7 @@ struct RoundCut {
 // kernel-class timer of the calling thread: its own, or the slot's while it works for a batch
 
 constexpr int kYield = 1;  // run_levels: the next level is dense and the caller runs it (batched sweeps)
-constexpr int kYieldColumn = 4;  // run_levels: the level is dense and the slot's column of c8 is held by its twin workspace
+constexpr int kYieldColumn = 4;  // run_levels: the level is dense and no column of c8 is free (workspace pool)
 constexpr int kYieldDefer = 3;  // run_levels: the compaction is queued, the sparse levels behind it wait for the next call (LevelCtx)
 constexpr int kYieldWalk = 2;  // fora_step: the walk phase runs on the handle's side stream; call again when it has ended
 
@@ -254,7 +254,7 @@ const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks);
 unsigned long long gs_thresh_of(const pprhip_graph* g);
 int seed_single(pprhip_graph* g, LevelCtx& L, int32_t node, uint32_t degree);
 int seed_scan(pprhip_graph* g, const PushArgs& a, int kind, LevelCtx& L);
-int ensure_twins(pprhip_graph* P);  // a second workspace per column of c8 (fora.cpp: SlotDriver)
+int ensure_workspaces(pprhip_graph* P, int count);  // more workspaces than columns of c8 (fora.cpp: SlotDriver)
 // a stream that runs beside g->stream - and beside `also`, when given - (self-tested)
 int make_side_stream(pprhip_graph* g, hipStream_t* out, hipStream_t also = nullptr);
 int fetch_small(pprhip_graph* g, const void* dev, void* host, size_t bytes);  // a few words, without a copy command

@@ -630,7 +630,7 @@ static hipStream_t side_stream_for_walks(pprhip_graph* P) {
     const char* e = getenv("PPRHIP_BATCH_WALKS_BESIDE");
     if (!(e && e[0] == '0') && make_side_stream(P, &P->walk_stream) != PPRHIP_OK) P->walk_stream = nullptr;
   }
-  if (P->walk_stream)  // (every call: twin workspaces may have joined since)
+  if (P->walk_stream)  // (every call: workspaces may have joined since)
     for (pprhip_graph* S : P->slots)
       for (auto& ev : S->walk_ev)
         if (!ev && hipEventCreate(&ev) != hipSuccess) {
@@ -669,13 +669,15 @@ static hipStream_t stream_for_slots(pprhip_graph* P) {
 // launch the next sweep for those who wait -> the other slots' steps (new queries, sparse levels, round ends, walk
 // phases that have ended), until the sweep's counters arrive.
 //
-// Twin workspaces (whole-graph FORA): a column of c8 is only needed between a query's first dense level and its last,
+// Workspace pool (whole-graph FORA): a column of c8 is only needed between a query's first dense level and its last,
 // 26 of the ~40 sweep periods a query spent in its slot on R-MAT 22 - the rest went to its first sparse levels, its
-// sparse tail, the walk phase and the selection.  So every column has two workspaces (slots[c] and slots[kBatch + c]):
-// while one query holds the column, the next one is taken through its first levels in the other workspace and stands
-// ready (kYieldColumn) when the column is let go - which happens as soon as its holder leaves a sweep without asking for
-// another (the compaction that empties the column is queued first; the twin's prepared level lands behind it).
-constexpr int kMaxWs = 2 * kBatch;
+// sparse tail, the walk phase and the selection.  So there are more workspaces than columns (2 x by default,
+// PPRHIP_BATCH_WORKSPACES): while sixteen queries hold the columns, the next ones are taken through their first levels
+// and stand ready (kYieldColumn) when a column is let go - which happens as soon as its holder leaves a sweep without
+// asking for another (the compaction that empties the column is queued first; the newcomer's prepared level lands
+// behind it).  Any workspace takes any free column: at the end of a call nobody waits for a column while others idle.
+constexpr int kMaxWs = 3 * kBatch;
+constexpr int kDefaultWs = 2 * kBatch;
 
 struct SlotDriver {
   pprhip_graph* P = nullptr;
@@ -689,21 +691,25 @@ struct SlotDriver {
   int rr = 0;  // where the pass over the other workspaces starts (round robin: an early end must not starve anybody)
   std::function<bool(BatchJob**, int*)> next;  // the next query to start (false: none right now)
   std::function<void(BatchJob*)> done;         // a query of that job has finished
+  int ready_rr = 0;         // where the search for a workspace that stands ready for a free column starts
   int cur_ws = -1;          // the workspace whose step is under way (the hook must not step it again)
   bool in_turn = false;
   int hook_rc = PPRHIP_OK;  // what a turn taken from inside a step's wait came to
   std::string hook_msg;
 
-  // twins: two workspaces per column; slots_on: the stream the workspaces run on from here on (nullptr / P->stream:
-  // everything in stream order, as before round 5)
-  int setup(pprhip_graph* P_, bool twins, hipStream_t slots_on) {
+  // pool: more workspaces than columns; slots_on: the stream the workspaces run on from here on (nullptr /
+  // P->stream: everything in stream order, as before round 5)
+  int setup(pprhip_graph* P_, bool pool, hipStream_t slots_on) {
     P = P_;
     n_ws = kBatch;
-    if (twins && !getenv("PPRHIP_BATCH_NO_TWINS")) {
-      if (ensure_twins(P) == PPRHIP_OK) n_ws = kMaxWs;
-      else if ((int)P->slots.size() > kBatch) {  // (no memory for them: one workspace per column)
+    if (pool) {
+      int want = kDefaultWs;
+      if (const char* e = getenv("PPRHIP_BATCH_WORKSPACES")) want = std::max(kBatch, std::min(kMaxWs, atoi(e)));
+      if (want > kBatch && ensure_workspaces(P, want) != PPRHIP_OK) {  // (no memory for them: one per column)
         (void)hipGetLastError();
+        want = kBatch;
       }
+      n_ws = want;
     }
     for (int c = 0; c < kBatch; ++c) P->col_owner[c] = -1;
     for (size_t w = 0; w < P->slots.size(); ++w) {
@@ -711,7 +717,8 @@ struct SlotDriver {
       S->stream = slots_on ? slots_on : P->stream;
       S->c8_via_parent = S->stream != P->stream;
       S->sync = nullptr;
-      S->col_cell = (int)w < n_ws ? &P->col_owner[S->slot_index] : nullptr;
+      S->pooled = (int)w < n_ws;
+      S->has_col = false;
     }
     // the workspaces' read-backs look after the sweep in flight while they wait (only worth it when they wait on
     // another stream than the sweep's)
@@ -726,11 +733,23 @@ struct SlotDriver {
     P->idle_hook = nullptr;
     P->idle_arg = nullptr;
     if (P->slot_stream) (void)hipStreamSynchronize(P->slot_stream);
-    for (pprhip_graph* S : P->slots) S->col_cell = nullptr;
+    for (size_t w = 0; w < P->slots.size(); ++w) {  // (as the other drivers expect them)
+      P->slots[w]->pooled = P->slots[w]->has_col = false;
+      P->slots[w]->slot_index = (int)(w % kBatch);
+    }
   }
   static void on_idle(void* self) {
     SlotDriver* D = static_cast<SlotDriver*>(self);
-    if (D->in_turn || !D->flying || D->hook_rc != PPRHIP_OK || !sweep_arrived(D->P, D->ticket)) return;
+    if (D->in_turn || D->hook_rc != PPRHIP_OK) return;
+    if (D->flying) {
+      if (!sweep_arrived(D->P, D->ticket)) return;
+    } else {  // nothing on the compute stream (a call's first queries are still starting): whoever stands ready goes
+      static const bool early = getenv("PPRHIP_BATCH_NO_EARLY") == nullptr;
+      if (!early) return;
+      bool any = false;
+      for (int w = 0; w < D->n_ws && !any; ++w) any = D->runs[w].query >= 0 && D->runs[w].waiting;
+      if (!any) return;
+    }
     D->prof.n[5]++;
     const int rc = D->turn();
     if (rc != PPRHIP_OK) {
@@ -742,8 +761,11 @@ struct SlotDriver {
   // a workspace that holds its column without standing at a dense level lets it go (its column is all-zero, or the
   // compaction that makes it so is queued on the compute stream)
   void release_if_idle(int w) {
-    const int c = P->slots[w]->slot_index;
-    if (P->col_owner[c] == w && !(runs[w].query >= 0 && runs[w].waiting)) P->col_owner[c] = -1;
+    pprhip_graph* S = P->slots[w];
+    if (S->has_col && !(runs[w].query >= 0 && runs[w].waiting)) {
+      P->col_owner[S->slot_index] = -1;
+      S->has_col = false;
+    }
   }
 
   // one workspace as far as it gets: until it waits at a dense level, for its column or for its walk phase, or there is
@@ -817,7 +839,7 @@ struct SlotDriver {
     return rc;
   }
 
-  // collect the sweep in flight, let its queries (and the twins of those that let their column go) say what they do
+  // collect the sweep in flight, let its queries (and the ones that stand ready for the columns let go) say what they do
   // next, launch the next sweep: nothing in here waits for the device beyond the sweep's counters
   int turn() {
     in_turn = true;
@@ -843,7 +865,7 @@ struct SlotDriver {
     }
     void print() const {
       if (!on) return;
-      static const char* names[6] = {"collect", "owner goes on (kYield)", "owner leaves (compaction)", "twin takes over", "launch", "turn from a wait"};
+      static const char* names[6] = {"collect", "owner goes on (kYield)", "owner leaves (compaction)", "newcomer takes a column", "launch", "turn from a wait"};
       for (int i = 0; i < 6; ++i)
         if (n[i]) fprintf(stderr, "[driver] %-28s %8llu x %8.1f us\n", names[i], n[i], us[i] / (double)n[i]);
     }
@@ -860,14 +882,22 @@ struct SlotDriver {
           runs[w].waiting = false;
           PPRHIP_TRY(step_ws(w, true));
           prof.lap(runs[w].waiting ? 1 : 2);
-          // the column has been let go: its twin, if it stands ready, prepares its level behind the compaction
-          const int tw = (w + kBatch) % kMaxWs;
-          if (P->col_owner[c] < 0 && tw < n_ws && tw != cur_ws && runs[tw].query >= 0 && !walking[tw] &&
-              !runs[tw].waiting && col_marked[tw] && hipEventQuery(P->slots[tw]->col_ev) == hipSuccess) {
-            PPRHIP_TRY(step_ws(tw, true));
-            prof.lap(3);
-          }
         }
+      // columns have been let go: workspaces that stand ready prepare their levels behind the compactions
+      int n_free = 0;
+      for (int c = 0; c < kBatch; ++c) n_free += P->col_owner[c] < 0 ? 1 : 0;
+      for (int t = 0; t < n_ws && n_free > 0; ++t) {
+        const int w = (ready_rr + t) % n_ws;
+        if (w == cur_ws || runs[w].query < 0 || walking[w] || runs[w].waiting || !col_marked[w] ||
+            hipEventQuery(P->slots[w]->col_ev) != hipSuccess)
+          continue;
+        PPRHIP_TRY(step_ws(w, true));
+        prof.lap(3);
+        if (runs[w].waiting) {
+          n_free--;
+          ready_rr = (w + 1) % n_ws;
+        }
+      }
     }
     bool active[kBatch];
     int ws[kBatch];
@@ -903,6 +933,11 @@ struct SlotDriver {
       if (walking[w]) {
         if (hipEventQuery(P->slots[w]->walk_ev[2]) == hipErrorNotReady) continue;
         walking[w] = false;
+      }
+      if (col_marked[w]) {  // it stands ready for a column: nothing to do for it while none is free
+        bool any_free = false;
+        for (int c = 0; c < kBatch && !any_free; ++c) any_free = P->col_owner[c] < 0;
+        if (!any_free) continue;
       }
       PPRHIP_TRY(step_ws(w, false));
     }
@@ -958,7 +993,7 @@ int batch_sequential(BatchJob& J) {
   SlotDriver& D = *Dp;
   D.side = J.kind == 0 ? side_stream_for_walks(P) : nullptr;
   PPRHIP_TRY(D.setup(P, J.kind == 0 && J.q > kBatch, stream_for_slots(P)));
-  if (D.side) D.side = side_stream_for_walks(P);  // (the twins' events)
+  if (D.side) D.side = side_stream_for_walks(P);  // (the new workspaces' events)
   KernelTimer& tm = ktimer();  // (the call's timer watches the stream the workspaces' kernels run on ...)
   tm.stream = P->slots[0]->stream;
   const int q_slots = J.q - tail_queries(J);  // queries the slots run
@@ -1598,7 +1633,7 @@ void stream_driver(pprhip_stream* s) {
   SlotDriver& D = *Dp;
   D.side = side_stream_for_walks(P);
   (void)D.setup(P, true, stream_for_slots(P));
-  if (D.side) D.side = side_stream_for_walks(P);  // (the twins' events)
+  if (D.side) D.side = side_stream_for_walks(P);  // (the new workspaces' events)
   hipStream_t side = D.side;
   // test switch: PPRHIP_STREAM_FAULT_AT=<n> makes the driver fail when it is about to start the stream's n-th query
   // (0-based), as a failing kernel launch would: every open and later submission ends with the driver's error

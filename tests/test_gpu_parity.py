@@ -295,6 +295,52 @@ def test_fora_batch_rmat15_many_queries(pkg, orc, rmat15, dev_rmat15):
         dev_rmat15.set_tuning(pkg.tuning_default())
 
 
+@pytest.mark.parametrize("env", [{"PPRHIP_BATCH_WORKSPACES": "16"}, {"PPRHIP_BATCH_WORKSPACES": "19"},
+                                 {"PPRHIP_BATCH_WORKSPACES": "48"}, {"PPRHIP_BATCH_SLOTS_BESIDE": "0"},
+                                 {"PPRHIP_BATCH_NO_HOOK": "1"}, {"PPRHIP_BATCH_NO_EARLY": "1", "PPRHIP_BATCH_WALKS_BESIDE": "0"}])
+def test_batch_driver_variants(pkg, orc, rmat15, env, monkeypatch):
+    """The sequential batch driver of round 5 (fora.cpp: SlotDriver): sweeps launched and collected separately, the
+    queries outside a sweep stepped on a second stream beside it, a pool of workspaces (default 32) for the 16 columns
+    of the contribution array, turns taken from inside a workspace's read-back wait.  Each query is the single-query
+    algorithm whatever the driver does around it: with one workspace per column, an odd number of them, three per
+    column, the workspaces on the sweeps' own stream, no turns from inside waits, no early first sweep and the walks in
+    line, every query has the levels, rounds and walks of the default configuration and its vector to 1e-12 (sums that
+    cross a chunk are atomic), with threshold rounds fixed at 3 (round starts of workspaces that hold no column list
+    their start set) and chosen by the cost model; a sample is held to the twin."""
+    og = to_oracle(orc, rmat15)
+    srcs = sources(rmat15, 45, seed=31)
+    t = pkg.tuning_batch()
+    ref_g = pkg.Graph(rmat15)
+    ref_g.set_tuning(t)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = pkg.Graph(rmat15)
+    g.set_tuning(t)
+    try:
+        for n_rounds in (3, 0):
+            out, _, _, _, pq, st = g.fora_batch_single_source(srcs, 0.5, ALPHA, seed=6, n_rounds=n_rounds, fetch=True,
+                                                              per_query=True)
+            for k in env:
+                monkeypatch.delenv(k)
+            out0, _, _, _, pq0, st0 = ref_g.fora_batch_single_source(srcs, 0.5, ALPHA, seed=6, n_rounds=n_rounds,
+                                                                     fetch=True, per_query=True)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            assert st.dense_levels == st0.dense_levels and st.class_launches[5] > 0
+            assert np.max(np.abs(out - out0)) <= 1e-12
+            for i in range(len(srcs)):
+                assert (pq[i].levels, pq[i].rounds, pq[i].walks, pq[i].dense_levels) == \
+                       (pq0[i].levels, pq0[i].rounds, pq0[i].walks, pq0[i].dense_levels)
+            for i in (0, 17, 44):
+                ref, sto = og.fora_whole(srcs[i], 0.5, ALPHA, seed=6, n_rounds=n_rounds, schedule=orc.SYNC,
+                                         tuning=to_orc_tuning(orc, t))
+                assert pq[i].rounds == sto.rounds and pq[i].walks == sto.walks and pq[i].levels == sto.levels
+                assert_close(out[i], ref, TOL_MC, "batch src=%d" % srcs[i])
+    finally:
+        g.close()
+        ref_g.close()
+
+
 @pytest.mark.parametrize("graph,relabel", [("got", "1"), ("rmat12", "1"), ("rmat15", "1"), ("rmat15", "0")])
 def test_source_partitioned_batched_sweep(pkg, orc, got, rmat12, rmat15, graph, relabel, monkeypatch):
     """The batched forward sweep over the source-partitioned copy of the in-CSR (round 5: eight partitions by
