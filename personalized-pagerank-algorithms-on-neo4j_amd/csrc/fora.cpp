@@ -510,6 +510,11 @@ int launch_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_activ
   }
   int n_gs = 1;
   const GsBlock* gs_blocks = backward ? nullptr : gs_blocks_of(P->slots[0], &n_gs);  // slots carry the call's tuning
+  // (Tried against the ~30 us between two sweeps, round 5: the slots' arguments passed to the kernels by value instead
+  // of through a copy command, and the reduce kernel writing the counters into the mailbox itself instead of a
+  // k_publish behind it - the sweep took 20-35 us longer either way (1 636-1 651 against 1 613-1 618 us on one box:
+  // the apply kernel indexes the by-value block per wave; sixteen workgroups' system-scope fences cost more than one
+  // small kernel).  Taken out.)
   P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
   PPRHIP_TRY(launch_dense_level_b8(P, backward, gs_blocks, n_gs));
   P->ktimer.end();
@@ -805,6 +810,7 @@ struct SlotDriver {
       rc = run_step(r, true);
       P->slots[w]->c8_settled = false;
       r.L.defer_compact = false;
+      if (rc != kYieldColumn) col_marked[w] = false;  // (it no longer stands ready for a column)
       if (rc == kYield) {
         r.waiting = true;
         rc = PPRHIP_OK;
