@@ -683,6 +683,12 @@ __global__ __launch_bounds__(1024) void k_dense_edges_p(const int32_t* __restric
 // crossing the chunk boundary use atomics.  (Measured on R-MAT 22, all slots busy: 0.69 ms per
 // sweep at G = 8, 0.83 ms at G = 16, 1.85 ms at G = 32.)
 constexpr int kHotBytes = 128 * 1024;  // LDS table of the hottest vertices' lines (2048 x 64 B or 1024 x 128 B)
+// The batched edge kernel takes 32 KB of it (256 lines) since round 5: the table's size never mattered to the sweep
+// itself (0 / 256 / 512 / 1024 lines within 0.5 %, round 2), but a workgroup that holds 128 of a CU's 160 KB keeps
+// every kernel with a larger LDS block of its own - the sparse push's 48 KB - off the CU while it runs, and the
+// queries that work beside the sweeps (fora.cpp: SlotDriver) wait for the gaps between the sweep's kernels:
+// k_sparse_push took 99 us per launch beside the sweeps against 14 us alone.  128 -> 32 KB: 344-347 -> 352 queries/s.
+constexpr int kHotDefaultBytes = 32 * 1024;
 
 // value of lane K of the caller's lane group (G = 8 or 16 lanes)
 template <int G, int K>
@@ -2066,11 +2072,21 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   return PPRHIP_OK;
 }
 
+// LDS table of the batched edge kernel.  PPRHIP_SWEEP_HOT_KB (measurement switch): its size in KB, at most 128.
+static uint32_t sweep_hot_bytes() {
+  static const uint32_t v = [] {
+    const char* e = getenv("PPRHIP_SWEEP_HOT_KB");
+    const long kb = e ? atol(e) : 0;
+    return kb >= 0 && e && kb * 1024 <= kHotBytes ? (uint32_t)(kb * 1024) : (uint32_t)kHotDefaultBytes;
+  }();
+  return v;
+}
+
 template <int G>
 static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8_t* start_flags,
                                  const uint32_t* chunk_starts, const double* cB, double* accB, const GsBlock& B) {
   if (!g->n_chunks || B.e_hi <= B.e_lo) return PPRHIP_OK;
-  const uint32_t hot_max = (uint32_t)(kHotBytes / (8 * G));
+  const uint32_t hot_max = sweep_hot_bytes() / (8 * G);
   const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, hot_max) : 0u;
   const uint32_t c_lo = (uint32_t)(B.e_lo / kChunkEdges);
   const uint32_t c_hi = (uint32_t)((B.e_hi + kChunkEdges - 1) / kChunkEdges);
