@@ -238,18 +238,24 @@ def test_fora_batch_rmat12(pkg, orc, rmat12, threads, monkeypatch):
 
 @pytest.mark.parametrize("q", [18, 35])
 def test_fora_batch_leftover_queries_run_singly(pkg, orc, rmat15, dev_rmat15, q, monkeypatch):
-    """A call whose query count leaves one to three queries over after the full rounds of 16 (PPR.java:179's 50 = 3 x 16 +
-    2) runs those on the handle's own workspace, one at a time (fora.cpp: kTailSingle): every query - the leftovers
-    too - equals the twin and what the call gives with the leftovers on the slots (PPRHIP_BATCH_NO_TAIL), vectors kept
-    in a store and delivered to the host alike, top-k per query included."""
+    """With one workspace per column (PPRHIP_BATCH_WORKSPACES=16: a device without room for the pool) a call whose query
+    count leaves one to three queries over after the full rounds of 16 (PPR.java:179's 50 = 3 x 16 + 2) runs those on the
+    handle's own workspace, one at a time (fora.cpp: kTailSingle): every query - the leftovers too - equals the twin
+    and what the call gives with the leftovers on the slots (PPRHIP_BATCH_NO_TAIL) and with the pool (the default, which
+    has no such rule), vectors kept in a store and delivered to the host alike, top-k per query included."""
     og = to_oracle(orc, rmat15)
     srcs = sources(rmat15, q, seed=14)
     t = pkg.tuning_batch()
     dev_rmat15.set_tuning(t)
     store = pkg.Results(dev_rmat15, q)
     try:
+        out3, ids3, vals3, nsel3, pq3, _ = dev_rmat15.fora_batch_single_source(srcs, 0.5, ALPHA, seed=5, k=8, fetch=True,
+                                                                               per_query=True)
+        monkeypatch.setenv("PPRHIP_BATCH_WORKSPACES", "16")
         out, ids, vals, nsel, pq, st = dev_rmat15.fora_batch_single_source(srcs, 0.5, ALPHA, seed=5, k=8, fetch=True,
                                                                            per_query=True, keep=store)
+        assert np.max(np.abs(out - out3)) <= 1e-9 and np.array_equal(nsel, nsel3)
+        assert all(pq[i].walks == pq3[i].walks and pq[i].levels == pq3[i].levels for i in range(q))
         monkeypatch.setenv("PPRHIP_BATCH_NO_TAIL", "1")
         out2, ids2, vals2, nsel2, pq2, _ = dev_rmat15.fora_batch_single_source(srcs, 0.5, ALPHA, seed=5, k=8, fetch=True,
                                                                                per_query=True)
