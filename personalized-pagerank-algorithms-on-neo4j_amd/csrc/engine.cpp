@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -517,8 +518,18 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     // the round-cut check looks at the state after exactly one sparse level
     const bool cut_check = cut && cut->enabled && cut->had_dense && !cut->checked;
     const int n_batch = cut_check ? 1 : kMaxBatch;
+    // The batch's levels from wg_from on run in ONE launch on one workgroup as long as they stay small
+    // (k_sparse_levels_wg): from the first level when that is small itself, else behind one or two levels of the
+    // usual two launches each - a frontier of 2^16 entries + edges or more rarely falls below the cap in one level.
+    static const bool wg_on = !(getenv("PPRHIP_SPARSE_WG") && getenv("PPRHIP_SPARSE_WG")[0] == '0');
+    constexpr unsigned long long kWgCap = 4096;
+    const unsigned long long size0 = (unsigned long long)L.nf + L.ef;
+    const int wg_from = (!wg_on || cut_check) ? n_batch
+                        : (!first_prepared && size0 < kWgCap) ? 0
+                        : size0 < 65536                        ? 1
+                                                               : 2;
     ktimer().begin(PPRHIP_KERNEL_SPARSE_PUSH, 0);
-    for (int i = 0; i < n_batch; ++i) {
+    for (int i = 0; i < std::min(n_batch, wg_from); ++i) {
       const int fb = L.fcur ^ (i & 1);
       poll_idle(g);
       if (!(i == 0 && first_prepared))
@@ -526,6 +537,9 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
                                          i == 0 ? pk0 : ~0ull));
       PPRHIP_TRY(launch_sparse_push(g, a, fb, i, i == 0 ? L.ef : (1u << 20), dense_thresh, L.dslot, i == 0 ? pk0 : ~0ull));
     }
+    if (wg_from < n_batch)
+      PPRHIP_TRY(launch_sparse_levels_wg(g, a, L.fcur, wg_from, n_batch - 1, dense_thresh, kWgCap, L.dslot,
+                                         wg_from == 0 ? pk0 : ~0ull));
     ktimer().end();
     PPRHIP_TRY(fetch_small(g, &g->ctr->hist[0], &g->h_ctr->hist[0], sizeof(unsigned long long) * (kMaxBatch + 1)));
     uint64_t batch_bytes = 0;
@@ -538,11 +552,14 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
         bool d2 = false;
         const double ci = level_cost(g, nf_i, ef_i, &d2);
         if (nf_i == 0 || (d2 && !sparse_only)) break;  // the device stopped here too (level_runs)
+        if (i >= wg_from && (unsigned long long)nf_i + ef_i >= kWgCap) break;  // ... too large for the one workgroup
         if (model_cost) *model_cost += ci;
       } else if (model_cost) {
         *model_cost += c;
       }
       const uint32_t nf_next = (uint32_t)(g->h_ctr->hist[i + 1] >> kPackShift);
+      static const bool level_trace = getenv("PPRHIP_LEVEL_TRACE") != nullptr;  // developer switch: a line per sparse level
+      if (level_trace) fprintf(stderr, "[level] mode %d batch-level %d nf %u ef %llu\n", a.mode, i, nf_i, (unsigned long long)ef_i);
       st.pops += nf_i;
       st.edge_pushes += ef_i;
       st.levels++;

@@ -463,6 +463,11 @@ namespace pprhip {
 int launch_sparse_prepare(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t nf_upper,
                           unsigned long long dense_thresh, bool scatter_dense, int cbuf, int dead_slot,
                           unsigned long long pk0 = ~0ull);
+// levels first .. last of a batch on one workgroup, while they stay below wg_cap entries + edges (k_sparse_levels_wg);
+// fbuf0: the list buffer that holds level 0's frontier
+int launch_sparse_levels_wg(pprhip_graph* g, const pprhip::PushArgs& a, int fbuf0, int first, int last,
+                            unsigned long long dense_thresh, unsigned long long wg_cap, int dead_slot,
+                            unsigned long long pk0);
 int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, uint64_t ef_upper,
                        unsigned long long dense_thresh, int dead_slot, unsigned long long pk0 = ~0ull);
 // One dense level of a single query, block by block (blocks: nullptr / 1 = the whole sweep at once).  state_in:

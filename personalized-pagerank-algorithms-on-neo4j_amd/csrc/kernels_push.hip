@@ -61,27 +61,26 @@ __device__ __forceinline__ int dense_state(const int* state_in, int state0) { re
 // ------------------------------------------------------------------------------------------------
 // sparse level, step 1: every frontier node gives up its residue
 // ------------------------------------------------------------------------------------------------
+// (the body of k_sparse_prepare for workgroup `bid` of `nblk`: the one-workgroup kernel that runs several small levels
+// in one launch, k_sparse_levels_wg, calls it with 0 of 1; pk: the level's frontier, entries << 36 | edges)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restrict__ F,
-                                                         const uint32_t* __restrict__ out_rp,
-                                                         double* __restrict__ res, double* __restrict__ reserve,
-                                                         double* __restrict__ cF, CView c_dense,
-                                                         DevCounters* ctr, int level, unsigned long long dense_thresh,
-                                                         int dead_slot, unsigned long long pk0, PushArgs a) {
+__device__ __forceinline__ void sparse_prepare_body(const int32_t* __restrict__ F, const uint32_t* __restrict__ out_rp,
+                                                    double* __restrict__ res, double* __restrict__ reserve,
+                                                    double* __restrict__ cF, CView c_dense, DevCounters* ctr, int level,
+                                                    int dead_slot, unsigned long long pk0, unsigned long long pk,
+                                                    const PushArgs& a, uint32_t bid, uint32_t nblk) {
   __shared__ double s_red[4];
   __shared__ unsigned long long s_red2[4];
   // the first level of a batch gets its frontier from the host as an argument (pk0 != ~0) and clears the counters of
   // the levels behind it: no copy and no fill on the stream for what two words and eight zeros say
-  if (level == 0 && pk0 != ~0ull && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (level == 0 && pk0 != ~0ull && bid == 0 && threadIdx.x == 0) {
     for (int i = 1; i <= kMaxBatch; ++i) ctr->hist[i] = 0ull;
     ctr->hist[kMaxBatch + 2] = 0ull;  // the seeding pass's list counter: the host has read it before this level
   }
-  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
-  if (!level_runs(pk, level, dense_thresh)) return;
   const uint32_t nf = (uint32_t)(pk >> kPackShift);
   double dead = 0.0;
   unsigned long long ndead = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) {
+  for (uint32_t i = bid * blockDim.x + threadIdx.x; i < nf; i += nblk * blockDim.x) {
     const int32_t v = F[i];
     const double rc = res[v];
     res[v] = 0.0;                            // Forward_Push.java:89
@@ -112,6 +111,21 @@ __global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restric
       atomic_add_u64(&ctr->dead_pops, nd);
     }
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sparse_prepare(const int32_t* __restrict__ F,
+                                                         const uint32_t* __restrict__ out_rp,
+                                                         double* __restrict__ res, double* __restrict__ reserve,
+                                                         double* __restrict__ cF, CView c_dense,
+                                                         DevCounters* ctr, int level, unsigned long long dense_thresh,
+                                                         int dead_slot, unsigned long long pk0, PushArgs a) {
+  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
+  if (!level_runs(pk, level, dense_thresh)) {
+    // (the counters behind a first level that does not run - it always runs - need no clearing)
+    return;
+  }
+  sparse_prepare_body<MODE>(F, out_rp, res, reserve, cF, c_dense, ctr, level, dead_slot, pk0, pk, a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -224,17 +238,17 @@ __device__ __forceinline__ void flush_new(NewList* nl, int32_t* __restrict__ Fn,
   __syncthreads();
 }
 
+// (the body of k_sparse_push for workgroup `bid` of `nblk`, see sparse_prepare_body)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__ F, const double* __restrict__ cF,
-                                                      const uint32_t* __restrict__ eoff,
-                                                      const uint32_t* __restrict__ trp, const int32_t* __restrict__ tci,
-                                                      const unsigned long long* __restrict__ out_ext,
-                                                      const uint32_t* __restrict__ in_rp, double* __restrict__ res,
-                                                      uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
-                                                      int32_t* __restrict__ Fn,
-                                                      uint32_t* __restrict__ eoffn, DevCounters* ctr, int level,
-                                                      unsigned long long dense_thresh, int dead_slot,
-                                                      unsigned long long comb_min, unsigned long long pk0, PushArgs a) {
+__device__ __forceinline__ void sparse_push_body(const int32_t* __restrict__ F, const double* __restrict__ cF,
+                                                 const uint32_t* __restrict__ eoff, const uint32_t* __restrict__ trp,
+                                                 const int32_t* __restrict__ tci,
+                                                 const unsigned long long* __restrict__ out_ext,
+                                                 const uint32_t* __restrict__ in_rp, double* __restrict__ res,
+                                                 uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
+                                                 int32_t* __restrict__ Fn, uint32_t* __restrict__ eoffn, DevCounters* ctr,
+                                                 int level, int dead_slot, unsigned long long comb_min,
+                                                 unsigned long long pk, const PushArgs& a, uint32_t bid, uint32_t nblk) {
   __shared__ uint32_t s_eoff[kStageCap + 1];
   __shared__ uint32_t s_row[kStageCap];
   __shared__ double s_c[kStageCap];
@@ -243,8 +257,6 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
   __shared__ int32_t s_key[kCombSlots];
   __shared__ double s_val[kCombSlots];
   const int tid = threadIdx.x;
-  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
-  if (!level_runs(pk, level, dense_thresh)) return;
   const uint32_t nf = (uint32_t)(pk >> kPackShift);
   const unsigned long long E = pk & kPackMask;
   unsigned long long* out_counter = &ctr->hist[level + 1];
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
     }
   __syncthreads();
 
-  if (MODE != kBackward && blockIdx.x == 0) {
+  if (MODE != kBackward && bid == 0) {
     // dead-end mass of this level lands on the source (Forward_Push.java:101-113)
     if (tid == 0) {
       const double dead = ctr->dead[dead_slot];
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
   }
 
   const unsigned long long n_tiles = (E + kPushTile - 1) / kPushTile;
-  for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  for (unsigned long long t = bid; t < n_tiles; t += nblk) {
     const unsigned long long tile_lo = t * kPushTile;
     const unsigned long long tile_hi = (tile_lo + kPushTile < E) ? tile_lo + kPushTile : E;
     if (tid == 0) {  // last frontier index whose edge range starts at or before tile_lo
@@ -382,6 +394,66 @@ __global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__
       }
     }
     flush_new(&s_new, Fn, eoffn, out_counter);
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sparse_push(const int32_t* __restrict__ F, const double* __restrict__ cF,
+                                                      const uint32_t* __restrict__ eoff,
+                                                      const uint32_t* __restrict__ trp, const int32_t* __restrict__ tci,
+                                                      const unsigned long long* __restrict__ out_ext,
+                                                      const uint32_t* __restrict__ in_rp, double* __restrict__ res,
+                                                      uint8_t* __restrict__ flags, uint32_t* __restrict__ armed,
+                                                      int32_t* __restrict__ Fn,
+                                                      uint32_t* __restrict__ eoffn, DevCounters* ctr, int level,
+                                                      unsigned long long dense_thresh, int dead_slot,
+                                                      unsigned long long comb_min, unsigned long long pk0, PushArgs a) {
+  const unsigned long long pk = (level == 0 && pk0 != ~0ull) ? pk0 : ctr->hist[level];
+  if (!level_runs(pk, level, dense_thresh)) return;
+  sparse_push_body<MODE>(F, cF, eoff, trp, tci, out_ext, in_rp, res, flags, armed, Fn, eoffn, ctr, level, dead_slot, comb_min,
+                         pk, a, blockIdx.x, gridDim.x);
+}
+
+// Several SMALL sparse levels in one launch, on one workgroup: levels first .. last of a batch, each as long as the
+// level before it left a frontier that is worth a sparse level (level_runs) and small enough for one workgroup
+// (entries + edges < wg_cap; the first level is the host's choice).  A top-k round's push is 8.4 levels on R-MAT 22, three
+// quarters of them below 4 096 entries + edges (60 % below 512), and each cost two launches and ~21 us of stream time
+// whatever its size; here a level costs its dependent memory accesses.  Between the levels (and between a level's two
+// steps) the workgroup's waves meet at a barrier with a release fence before it and an acquire fence behind it: what one
+// wave wrote - list entries, contributions, counters - the others read from L2.  The host reads the batch's counters
+// as before and applies the same two rules to tell which levels ran.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sparse_levels_wg(int32_t* F0, int32_t* F1, uint32_t* eoff0, uint32_t* eoff1,
+                                                           const uint32_t* __restrict__ out_rp, double* res,
+                                                           double* reserve, double* cF, const uint32_t* __restrict__ trp,
+                                                           const int32_t* __restrict__ tci,
+                                                           const unsigned long long* __restrict__ out_ext,
+                                                           const uint32_t* __restrict__ in_rp, uint8_t* flags,
+                                                           uint32_t* armed, DevCounters* ctr, int fb0, int first, int last,
+                                                           unsigned long long dense_thresh, unsigned long long wg_cap,
+                                                           int dead_slot, unsigned long long comb_min,
+                                                           unsigned long long pk0, PushArgs a) {
+  for (int level = first; level <= last; ++level) {
+    const unsigned long long pk =
+        (level == 0 && pk0 != ~0ull)
+            ? pk0
+            : __hip_atomic_load(&ctr->hist[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!level_runs(pk, level, dense_thresh)) return;
+    if (level > 0 && (pk >> kPackShift) + (pk & kPackMask) >= wg_cap) return;  // too large for one workgroup
+    const int fb = fb0 ^ (level & 1);
+    int32_t* const F = fb ? F1 : F0;
+    int32_t* const Fn = fb ? F0 : F1;
+    uint32_t* const eo = fb ? eoff1 : eoff0;
+    uint32_t* const eon = fb ? eoff0 : eoff1;
+    sparse_prepare_body<MODE>(F, out_rp, res, reserve, cF, CView{nullptr, 1, 0}, ctr, level, dead_slot, pk0, pk, a, 0u, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    sparse_push_body<MODE>(F, cF, eo, trp, tci, out_ext, in_rp, res, flags, armed, Fn, eon, ctr, level, dead_slot, comb_min, pk,
+                           a, 0u, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
 }
 
@@ -1945,6 +2017,22 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
                             g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_ext, g->in_rp, g->residue, g->flags,
                             g->armed, g->F[fbuf ^ 1], g->eoff[fbuf ^ 1], g->ctr, level, dense_thresh, dead_slot,
                             comb_min, pk0, a));
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  return PPRHIP_OK;
+}
+
+int launch_sparse_levels_wg(pprhip_graph* g, const PushArgs& a, int fbuf0, int first, int last,
+                            unsigned long long dense_thresh, unsigned long long wg_cap, int dead_slot,
+                            unsigned long long pk0) {
+  const bool bwd = a.mode == kBackward;
+  const uint32_t* trp = bwd ? g->in_rp : g->out_rp;
+  const int32_t* tci = bwd ? g->in_ci : g->out_ci;
+  const char* comb_env = getenv("PPRHIP_COMB_MIN_EDGES");
+  const unsigned long long comb_min = comb_env ? strtoull(comb_env, nullptr, 10) : (unsigned long long)kCombMinEdges;
+  DISPATCH_MODE(a.mode, k_sparse_levels_wg<M><<<dim3(1), dim3(256), 0, g->stream>>>(
+                            g->F[0], g->F[1], g->eoff[0], g->eoff[1], g->out_rp, g->residue, g->reserve, g->cF, trp, tci,
+                            g->out_ext, g->in_rp, g->flags, g->armed, g->ctr, fbuf0, first, last, dense_thresh, wg_cap,
+                            dead_slot, comb_min, pk0, a));
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
