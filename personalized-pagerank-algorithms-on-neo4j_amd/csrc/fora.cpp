@@ -905,6 +905,11 @@ struct SlotDriver {
         }
       }
     }
+    // (Tried for the end of a call, round 5: with nothing left to start and at most 2 / 3 / 4 queries still in their
+    // push, those queries took their column of c8 into vectors of their own and finished with the single-query level
+    // kernels - 0.36 ms per level each against 1.6 ms per sweep for any number of columns.  Parity-green and without
+    // effect: 350-353 against 351-354 queries/s, the same 857-859 sweeps - a call's last sweeps run at 4-12 busy
+    // columns for most of the drain and at <= 4 only for its last few levels.  Taken out.)
     bool active[kBatch];
     int ws[kBatch];
     int n_wait = 0;
