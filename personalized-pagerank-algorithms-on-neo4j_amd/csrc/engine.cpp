@@ -2054,7 +2054,11 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
     pushed_ahead = false;
     if (spec_on) PPRHIP_CHECK_HIP(hipEventRecord(g->spec_ev[0], g->stream));  // residues and reserve have been read
     // :155-168: the walk kernel reads the plan's counts on the device: no host round trip between push and selection
-    g->walk_waves = spec_on ? 8u : 0u;  // (the next round's push runs beside these walks: leave it room)
+    static const uint32_t topk_waves = [] {  // PPRHIP_TOPK_WALK_WAVES: measurement switch
+      const char* e = getenv("PPRHIP_TOPK_WALK_WAVES");
+      return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 8u;
+    }();
+    g->walk_waves = spec_on ? topk_waves : 0u;  // (the next round's push runs beside these walks: leave it room)
     const int wrc = launch_walk_run(g, 1, alpha, seed, round, g->est);
     g->walk_waves = 0;
     PPRHIP_TRY(wrc);
