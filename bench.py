@@ -196,7 +196,13 @@ def main():
     # the timed region, and the bandwidth-bound headline loses ~1 % - as do the All-Pair samples; the one-query-at-a-time
     # and top-k samples take their rates without them (as a caller gets them by default) and their class times in a
     # second pass.
-    pkg.set_kernel_timing(True)
+    # Round 5: the timed region times the dense sweeps only (level 2: two records per sweep of 1.6 ms - the roofline's
+    # class) and counts every other class; one more step outside the timed region runs with every class timed and
+    # gives the per-class breakdown (kernel_ms_per_query, other_kernels).  The batch driver is one host thread that
+    # feeds three streams: ~60 records per query on the small kernels' stream cost it 1.5 % (347-348 -> 353).
+    # PPRHIP_BENCH_TIMING=0 / 1: developer A/B (no records at all / every class in the timed region, as until round 4).
+    bench_timing = os.environ.get("PPRHIP_BENCH_TIMING", "2")
+    pkg.set_kernel_timing({"0": False, "1": True}.get(bench_timing, 2))
 
     # ---- graph lift (outside the timed region)
     t0 = time.time()
@@ -207,8 +213,9 @@ def main():
     live_frac_graph = live_ids.size / host.n
     q = args.queries_per_step
     total_steps = args.warmup + args.steps
+    extra_step = 1 if args.mode == "batch" else 0  # (the step with every class timed, behind the timed region)
     rng = np.random.default_rng(2 + 7919 * rank)
-    srcs = live_draw(rng, live_ids, (total_steps, q))
+    srcs = live_draw(rng, live_ids, (total_steps + extra_step, q))
 
     solo = world == 1 and rank == 0 and args.mode == "batch"
     t0 = time.time()
@@ -341,6 +348,18 @@ def main():
 
     if rank == 0:
         note("timed region done: %.1f queries/s" % (args.steps * q * world / elapsed))
+    acc_timed = acc
+    if extra_step and bench_timing == "2":
+        # per-class times of the same workload: one more step, every class timed, outside the timed region
+        acc = {k: (list(v) if isinstance(v, list) else v) for k, v in acc.items()}
+        for k in acc:
+            acc[k] = [type(x)(0) for x in acc[k]] if isinstance(acc[k], list) else type(acc[k])(0)
+        was_t = pkg.set_kernel_timing(True)
+        run_step(total_steps, True)  # (the self-check below then looks at this step's results: they are what the store holds)
+        pkg.set_kernel_timing(was_t)
+        acc_classes, acc = acc, acc_timed
+    else:
+        acc_classes = acc
     if solo and not args.no_extras and not args.no_rmat24:
         r24_child = start_rmat24(args)
     check = None
@@ -372,7 +391,8 @@ def main():
         is_sweep = dom in (1, 5)
         comp_bytes = acc["sweep_min_bytes"] / max(1, dom_n) if is_sweep else dom_bytes / max(1, dom_n)
         comp = comp_bytes / 1e9 / (avg_us / 1e6) if avg_us > 0 else 0.0
-        kernel_ms = sum(acc["class_ms"][c] for c in range(1, 8))
+        nq_c = max(1, acc_classes["queries"])
+        kernel_ms = sum(acc_classes["class_ms"][c] for c in range(1, 8)) * (nq / nq_c)  # (scaled to the timed region's queries)
         roofline = {
             "bound": "hbm", "kernel": pkg.KERNEL_NAMES[dom], "achieved": round(comp, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(comp / HBM_PEAK_GBS, 4), "frac_basis": "compulsory bytes (no counters in this run)",
@@ -397,10 +417,12 @@ def main():
                            "gathers that carry a pushed residue",
             "other_kernels": {
                 pkg.KERNEL_NAMES[c]: {
-                    "ms": round(acc["class_ms"][c], 3), "launches": acc["class_launches"][c],
-                    "achieved_GBps": round((acc["class_bytes"][c] / 1e9) / (acc["class_ms"][c] / 1e3), 1)
-                    if acc["class_ms"][c] > 0 else 0.0}
-                for c in (1, 2, 3, 5) if c != dom and acc["class_launches"][c]},
+                    "ms": round(acc_classes["class_ms"][c], 3), "launches": acc_classes["class_launches"][c],
+                    "achieved_GBps": round((acc_classes["class_bytes"][c] / 1e9) / (acc_classes["class_ms"][c] / 1e3), 1)
+                    if acc_classes["class_ms"][c] > 0 else 0.0}
+                for c in (1, 2, 3, 5) if c != dom and acc_classes["class_launches"][c]},
+            "other_kernels_note": "class times of one more step of the same workload with every class timed, outside the "
+                                  "timed region (which times the sweeps only)" if acc_classes is not acc else None,
         }
         out = {
             "metric": "single-source PPR queries/sec (FORA, alpha=0.15, eps=0.5)", "value": round(value, 3),
@@ -421,13 +443,14 @@ def main():
             "live_node_fraction_of_graph": round(live_frac_graph, 4),
             "value_vectors_resident": round(value, 3),
             "avg_rounds": round(acc["rounds"] / nq, 2),
-            "kernel_ms_per_query": {pkg.KERNEL_NAMES[c]: round(acc["class_ms"][c] / nq, 3)
-                                    for c in (1, 2, 3, 5, 6) if acc["class_launches"][c]},
+            "kernel_ms_per_query": {pkg.KERNEL_NAMES[c]: round(acc_classes["class_ms"][c] / nq_c, 3)
+                                    for c in (1, 2, 3, 5, 6) if acc_classes["class_launches"][c]},
             "kernel_class_time": host_gap(1e3 * elapsed / (args.steps * q), kernel_ms / nq),
             "dense_levels_per_query": round(acc["dense_levels"] / nq, 1),
             "levels_per_query": round(acc["levels"] / nq, 1),
             "walks_per_query": int(acc["walks"] / nq),
-            "walk_steps_G_per_s": round(acc["walk_steps"] / (acc["class_ms"][3] / 1e3) / 1e9, 2) if acc["class_ms"][3] > 0 else None,
+            "walk_steps_G_per_s": round(acc_classes["walk_steps"] / (acc_classes["class_ms"][3] / 1e3) / 1e9, 2)
+            if acc_classes["class_ms"][3] > 0 else None,
             "walk_lanes_per_load": round(acc["walk_load_lanes"] / max(1, acc["walk_loads"]), 2),
             "graph_lift_s": {"generate_and_csr": round(t_gen, 2), "upload_and_tile": round(t_lift, 2)},
             "self_check": check,

@@ -147,7 +147,9 @@ int pprhip_device_count(int* count_out);
 /* Kernel-class times (pprhip_stats_t.class_ms, dominant_kernel_*) are measured with HIP events around every group of
  * launches; between the short kernels of the latency-bound paths those records cost 2-8 %, so they are an
  * option of the process: off unless PPRHIP_KERNEL_TIMER=1 is set or this is called with on != 0.  Off, the groups are
- * still counted (class_launches, class_bytes).  Not to be switched while a call is in flight.  Returns the old state. */
+ * still counted (class_launches, class_bytes).  on == 2: only the dense sweeps are timed (PPRHIP_KERNEL_DENSE_PULL and
+ * _DENSE_PULL_BATCH: two records per sweep of a millisecond), every other class counted - what bench.py's timed region
+ * uses.  Not to be switched while a call is in flight.  Returns the old state (0, 1 or 2). */
 int pprhip_set_kernel_timing(int on);
 void pprhip_tuning_default(pprhip_tuning_t* t);
 /* Cost-model constants for pprhip_fora_batch_single_source: a dense level costs a query 1/PPRHIP_BATCH

@@ -204,8 +204,10 @@ def _ptr(a):
 
 def set_kernel_timing(on):
     """Kernel-class times in Stats.class_ms (HIP events around every group of launches): off by default - they cost the
-    latency-bound paths 2-8 %.  Returns the previous state."""
-    return bool(lib().pprhip_set_kernel_timing(1 if on else 0))
+    latency-bound paths 2-8 %; on == 2 ("sweeps"): only the dense sweeps are timed, every other class counted.  Returns
+    the previous state (False, True or 2), which can be passed back."""
+    was = lib().pprhip_set_kernel_timing(2 if (on == 2 and on is not True) else (1 if on else 0))
+    return 2 if was == 2 else bool(was)
 
 
 def device_count():

@@ -33,6 +33,10 @@ bool kernel_timing_on() {
   }
   return v != 0;
 }
+int kernel_timing_level() {
+  (void)kernel_timing_on();  // (decides on first use)
+  return g_kernel_timing.load(std::memory_order_relaxed);
+}
 
 namespace detail {
 
@@ -1417,9 +1421,9 @@ int make_side_stream(pprhip_graph* g, hipStream_t* out, hipStream_t also) {
 extern "C" {
 
 int pprhip_set_kernel_timing(int on) {
-  const bool was = kernel_timing_on();
-  g_kernel_timing.store(on ? 1 : 0, std::memory_order_relaxed);
-  return was ? 1 : 0;
+  const int was = kernel_timing_level();
+  g_kernel_timing.store(on == 2 ? 2 : (on ? 1 : 0), std::memory_order_relaxed);
+  return was;
 }
 
 int pprhip_device_count(int* count_out) {

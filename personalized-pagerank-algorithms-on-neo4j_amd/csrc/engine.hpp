@@ -140,10 +140,12 @@ struct PushArgs {
 // brackets are only counted: class_launches and class_bytes are filled, class_ms stay zero.
 extern std::atomic<int> g_kernel_timing;  // engine.cpp; -1: not decided yet (the environment is read on first use)
 bool kernel_timing_on();
+int kernel_timing_level();  // 0: counted only; 1: every class timed; 2: the dense sweeps (classes 1 and 5) timed only
 struct KernelTimer {
   static constexpr size_t kMaxEvents = 4096;
   static constexpr size_t kNoEvent = ~(size_t)0;
   bool off = false;  // records nothing (work whose time is accounted elsewhere or not at all)
+  bool last_timed = false;  // the bracket opened last recorded an event (end() records its partner)
   std::vector<hipEvent_t> ev;
   struct Rec { int cls; size_t i; uint64_t bytes; };
   std::vector<Rec> recs;
@@ -192,8 +194,13 @@ struct KernelTimer {
   }
   void begin(int cls, uint64_t bytes) {
     if (off) return;
-    if (!kernel_timing_on()) {
-      if (recs.size() >= kMaxCounted) fold();  // (counting needs no drained stream)
+    const int lvl = kernel_timing_level();
+    last_timed = lvl == 1 || (lvl == 2 && (cls == 1 || cls == 5));  // (PPRHIP_KERNEL_DENSE_PULL / _DENSE_PULL_BATCH)
+    if (!last_timed) {
+      if (recs.size() >= kMaxCounted) {  // (counting needs no drained stream - unless timed brackets are pending too)
+        if (used && hipStreamSynchronize(stream) != hipSuccess) return;
+        fold();
+      }
       recs.push_back({cls, kNoEvent, bytes});
       return;
     }
@@ -207,7 +214,8 @@ struct KernelTimer {
     (void)hipEventRecord(a, stream);
   }
   void end() {
-    if (off || !kernel_timing_on()) return;
+    if (off || !last_timed) return;
+    last_timed = false;
     hipEvent_t b = next();
     if (b) (void)hipEventRecord(b, stream);
   }
