@@ -106,8 +106,8 @@ def test_stream_closed_with_a_submission_nobody_waited_for(pkg, rmat12):
 
 def test_kernel_timing_is_an_option(pkg, rmat15):
     """pprhip_set_kernel_timing: by default a call only counts its groups of launches (class_launches, class_bytes) and
-    records no events between its kernels; with the option on the same call also reports class times.  Results are the
-    same either way."""
+    records no events between its kernels; with the option on the same call also reports class times; at level 2 only
+    the dense sweeps' (what bench.py's timed region runs with).  Results are the same either way."""
     live = np.nonzero(np.diff(rmat15.out_rp) > 0)[0]
     src = int(live[5])
     with pkg.Graph(rmat15, device=0) as g:
@@ -121,7 +121,11 @@ def test_kernel_timing_is_an_option(pkg, rmat15):
             assert st1.class_ms[1] + st1.class_ms[2] > 0.0
             assert list(st1.class_launches) == list(st0.class_launches)
             assert np.max(np.abs(est0 - est1)) <= 1e-12
-            assert pkg.set_kernel_timing(False) is True
+            assert pkg.set_kernel_timing(2) is True
+            est2, st2 = g.fora_single_source(src, 0.5, ALPHA, seed=3)
+            assert st2.dense_levels > 0 and st2.class_ms[1] > 0.0 and st2.class_ms[2] == 0.0   # sweeps timed, sparse levels counted
+            assert list(st2.class_launches) == list(st0.class_launches) and np.max(np.abs(est0 - est2)) <= 1e-12
+            assert pkg.set_kernel_timing(False) == 2
         finally:
             pkg.set_kernel_timing(was)
 
