@@ -109,6 +109,18 @@ int C8Scope::leave() {
 }
 
 int alloc_dev(void** p, size_t bytes) {
+  // test switch: PPRHIP_FAIL_ALLOC_AFTER=<n> makes the n-th device allocation made while it is set fail as the device
+  // running out of memory would (the count starts over whenever the variable is not there)
+  static std::atomic<long> armed_count{0};
+  if (const char* fe = getenv("PPRHIP_FAIL_ALLOC_AFTER")) {
+    if (armed_count.fetch_add(1) + 1 == atol(fe)) {
+      *p = nullptr;
+      set_error("hipMalloc(%zu bytes) failed: injected (PPRHIP_FAIL_ALLOC_AFTER)", bytes);
+      return PPRHIP_ERR_OOM;
+    }
+  } else {
+    armed_count.store(0);
+  }
   hipError_t e = hipMalloc(p, bytes ? bytes : 8);
   if (e != hipSuccess) {
     set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
@@ -749,8 +761,37 @@ static int make_slot(pprhip_graph* P, int w) {
   return PPRHIP_OK;
 }
 
+static void drop_slot(pprhip_graph* S) {
+  for (auto& ev : S->walk_ev) {
+    if (ev) (void)hipEventDestroy(ev);
+    ev = nullptr;
+  }
+  for (auto& ev : S->c8_ev) {
+    if (ev) (void)hipEventDestroy(ev);
+    ev = nullptr;
+  }
+  if (S->col_ev) (void)hipEventDestroy(S->col_ev);
+  S->col_ev = nullptr;
+  free_workspace(S);
+  S->ktimer.destroy();
+  if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
+  delete S;
+}
+
 int ensure_workspaces(pprhip_graph* P, int count) {
-  while ((int)P->slots.size() < count) PPRHIP_TRY(make_slot(P, (int)P->slots.size()));
+  while ((int)P->slots.size() < count) {
+    const size_t before = P->slots.size();
+    const int rc = make_slot(P, (int)before);
+    if (rc != PPRHIP_OK) {
+      // a workspace that could not be completed (out of memory, mostly) must not stay in the list: the driver falls
+      // back to the workspaces there are, and a later call tries again from a clean state
+      if (P->slots.size() > before) {
+        drop_slot(P->slots.back());
+        P->slots.pop_back();
+      }
+      return rc;
+    }
+  }
   PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
   return PPRHIP_OK;
 }
@@ -890,22 +931,7 @@ void free_batch(pprhip_graph* P) {
   if (P->slot_stream) (void)hipStreamDestroy(P->slot_stream);
   P->slot_stream = nullptr;
   P->slot_stream_tried = false;
-  for (pprhip_graph* S : P->slots) {
-    for (auto& ev : S->walk_ev) {
-      if (ev) (void)hipEventDestroy(ev);
-      ev = nullptr;
-    }
-    for (auto& ev : S->c8_ev) {
-      if (ev) (void)hipEventDestroy(ev);
-      ev = nullptr;
-    }
-    if (S->col_ev) (void)hipEventDestroy(S->col_ev);
-    S->col_ev = nullptr;
-    free_workspace(S);
-    S->ktimer.destroy();
-    if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
-    delete S;
-  }
+  for (pprhip_graph* S : P->slots) drop_slot(S);
   P->ktimer.destroy();
   P->slots.clear();
   void* ptrs[] = {P->c8[0], P->c8[1], P->acc8, P->prep_bits, P->d_slot_args, P->sweep_out, P->blk_pack8, P->blk_dead8,

@@ -1018,10 +1018,15 @@ int batch_sequential(BatchJob& J) {
   };
   D.done = [](BatchJob*) {};
   int rc = PPRHIP_OK;
-  for (;;) {
-    int busy = 0;
-    if ((rc = D.cycle(&busy)) != PPRHIP_OK) break;
-    if (busy == 0) break;
+  try {  // (no exception may cross the C ABI: the driver's containers and callbacks allocate)
+    for (;;) {
+      int busy = 0;
+      if ((rc = D.cycle(&busy)) != PPRHIP_OK) break;
+      if (busy == 0) break;
+    }
+  } catch (const std::exception& ex) {
+    set_error("batch driver: %s", ex.what());
+    rc = PPRHIP_ERR_OOM;
   }
   D.teardown();
   if (rc != PPRHIP_OK) return rc;

@@ -130,6 +130,35 @@ def test_kernel_timing_is_an_option(pkg, rmat15):
             pkg.set_kernel_timing(was)
 
 
+def test_workspace_pool_without_memory_falls_back(pkg, rmat15, monkeypatch):
+    """The batch driver's extra workspaces (32 for the 16 columns) are an option of the device's memory: when one of them
+    cannot be completed (injected: the 5th device allocation of the call fails, PPRHIP_FAIL_ALLOC_AFTER) the half-built
+    workspace is dropped, the call runs with the workspaces there are and gives the same results; the next call builds
+    the pool, and releasing the batch state returns all of it."""
+    live = np.nonzero(np.diff(rmat15.out_rp) > 0)[0][:40].astype(np.int32)
+    with pkg.Graph(rmat15, device=0) as g, pkg.Graph(rmat15, device=0) as ref:
+        t = pkg.tuning_batch()
+        g.set_tuning(t)
+        ref.set_tuning(t)
+        out0, _, _, _, pq0, _ = ref.fora_batch_single_source(live, 0.5, ALPHA, seed=4, fetch=True, per_query=True)
+        g.fora_batch_single_source(live[:8], 0.5, ALPHA, seed=4, fetch=True)   # the 16 workspaces of a small call
+        free_small, _ = g.device_memory()
+        monkeypatch.setenv("PPRHIP_FAIL_ALLOC_AFTER", "5")
+        out1, _, _, _, pq1, _ = g.fora_batch_single_source(live, 0.5, ALPHA, seed=4, fetch=True, per_query=True)
+        monkeypatch.delenv("PPRHIP_FAIL_ALLOC_AFTER")
+        free_after_fail, _ = g.device_memory()
+        assert np.max(np.abs(out1 - out0)) <= 1e-12
+        assert all(pq1[i].levels == pq0[i].levels and pq1[i].walks == pq0[i].walks for i in range(len(live)))
+        assert free_small - free_after_fail < (64 << 20)           # nothing of the dropped workspace stays behind
+        out2, _, _, _, _, _ = g.fora_batch_single_source(live, 0.5, ALPHA, seed=4, fetch=True)
+        free_pool, _ = g.device_memory()
+        assert np.max(np.abs(out2 - out0)) <= 1e-12
+        assert free_after_fail - free_pool > 16 * 8 * 8 * rmat15.n  # the pool is there now (>= 8 vectors of n doubles each)
+        g.release(g.RELEASE_BATCH)
+        free_end, _ = g.device_memory()
+        assert free_end >= free_small
+
+
 def test_stream_failure_reaches_every_submission(pkg, rmat12, monkeypatch):
     """A failure inside the stream's driver thread (injected: PPRHIP_STREAM_FAULT_AT) ends every open submission and every
     later call with the driver's error instead of leaving a waiter blocked; the close reports it, frees the batch state,
