@@ -1009,7 +1009,15 @@ int batch_sequential(BatchJob& J) {
   tm.stream = P->slots[0]->stream;
   // queries the workspaces run (the leftover rule is for one workspace per column: with the pool there are no rounds
   // of 16 whose last one would be nearly empty - 50 / 51 / 35 sources per call: 306 / 302 / 281 queries/s without
-  // the rule, 306 / 292 / 270 with it)
+  // the rule, 306 / 292 / 270 with it).
+  // (A query is a chain of ~26 dense levels and a column serves one level per sweep: 50 queries on 16 columns cost two
+  // columns four queries' worth of sweeps, ~104, whatever the order.  Tried against that, round 5: the q mod 16 <= 4
+  // leftovers on a helper thread and a stream of their own BESIDE the batch, each on a workspace that runs
+  // single-query dense levels over vectors of its own, so that the other 48 take three queries' worth.  Parity-green
+  // and no faster - 50 / 51 / 35 / 20 sources per call: 314 / 304 / 281 / 225 queries/s against 310 / 306 / 285 / 252: the
+  // single-query edge kernel (a 1024-thread workgroup with a 128-KB table per CU) does not fit on a CU beside the
+  // batched one, so its levels run in the gaps between the sweeps' kernels, one per sweep period - as in a column.
+  // Taken out; the query stream is the answer for calls that follow one another: 351-362 queries/s on blocks of 50.)
   const int q_slots = J.q - (D.n_ws > kBatch ? 0 : tail_queries(J));
   D.next = [&](BatchJob** job, int* i) {
     *i = J.next_query.fetch_add(1);
