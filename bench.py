@@ -1381,6 +1381,7 @@ def sweeps_alone(args, roofline):
     ach = per / 1e9 / (us / 1e6) if us else 0.0
     roofline["sweeps_alone"] = {
         "avg_sweep_us": us, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+        "frac_of_achievable": round(ach / HBM_ACHIEVABLE_GBS, 4),
         "bytes_per_sweep": "counter traffic" if roofline.get("traffic") else "compulsory",
         "value_in_stream_order": res["value"],
         "note": "child run with every kernel of the job on one stream (no walk phase or sparse level beside a sweep): "
@@ -1398,7 +1399,7 @@ def apply_counters(out, pmc, avg_us, extras):
     if tr:
         ach = tr / 1e9 / (avg_us / 1e6)
         roofline.update(traffic=tr, achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
-                        frac_basis_short="counter",
+                        frac_of_achievable=round(ach / HBM_ACHIEVABLE_GBS, 4), frac_basis_short="counter",
                         frac_basis="memory-side counters (FETCH_SIZE x calibration + WRITE_SIZE) per launch over the "
                                    "launch's duration; FETCH_SIZE includes Infinity-Cache hits: L2-miss traffic",
                         achieved_counter=round(ach, 1), frac_counter=round(ach / HBM_PEAK_GBS, 4),
