@@ -930,6 +930,13 @@ struct SlotDriver {
 
   // One cycle (see above).  *busy: the workspaces that hold a query afterwards; with none and nothing to start the
   // caller is done (or waits for work).
+  // (The pass over the other workspaces takes them through their steps one after the other, each step waiting for its
+  // own read-backs.  Tried, round 5: batches of sparse levels launched and collected separately - run_levels returned
+  // behind the launches and was called again when the mailbox had the counters, so that all workspaces' first levels
+  // were in flight together, with the first sweep of a call held until the others stood ready.  Parity-green and no
+  // faster: R-MAT 22 355-356 against 358-359 queries/s, R-MAT 20 1 175 against 1 194, 50 per call 310.7 against 311.8 -
+  // a call's length is set by the chain of sweeps each column's queries need, not by how fast the first ones start.
+  // Taken out.)
   int cycle(int* busy) {
     PPRHIP_TRY(turn());
     // the workspaces that are not in the sweep
