@@ -231,16 +231,16 @@ enum {
   PPRHIP_LIFT_SLICED_CHUNK_STARTS = 15, /* uint32[] */
   PPRHIP_LIFT_SEG_ROW = 16,          /* uint32[segments]: row ordinal */
   PPRHIP_LIFT_SEG_OFF = 17,          /* uint32[segments]: first edge */
-  /* the source-partitioned copy of the in-CSR the batched sweep walks (8 partitions by source id & 7, concatenated;
-   * a "segment" = the edges of one row inside one partition; built when first asked for) */
-  PPRHIP_LIFT_PART_BASES = 18,        /* uint32[9] first chunk of each partition, then uint32[9] first segment ordinal */
-  PPRHIP_LIFT_PART_COL_IDX = 19,      /* int32[(chunks + 1) * 512]: source ids, partitions padded to whole chunks */
-  PPRHIP_LIFT_PART_FLAGS = 20,        /* uint8[]: bit e = edge e of the copy is the first of its segment */
-  PPRHIP_LIFT_PART_CHUNK_STARTS = 21, /* uint32[chunks + 1]: segments (global ordinals) that start before each chunk */
-  PPRHIP_LIFT_PART_TILE_SEG0 = 22,    /* uint32[8][tiles + 1]: first segment of the partition among rows >= 64 t */
-  PPRHIP_LIFT_PART_TILE_MASK = 23,    /* uint64[8][tiles]: rows of tile t with a segment in the partition */
-  PPRHIP_LIFT_PART_TILE_CROSS = 24,   /* uint64[8][tiles]: ... whose segment holds the last edge of a chunk */
-  PPRHIP_LIFT_PART_TILE_EDGE0 = 25    /* uint64[8][tiles + 1]: first edge of the partition among rows >= 64 t */
+  /* the source-partitioned copy of the in-CSR the batched sweep walks, a sliced ELL (built when first asked for): 8
+   * partitions by source id & 7 (rows of <= 16 in-edges whole, in the partition of their ordinal); a row's edges in a
+   * partition are cut into pieces of <= 64 edges, numbered row by row; the pieces of 256 consecutive rows in one
+   * partition, sorted by length, sit sixteen to a slice */
+  PPRHIP_LIFT_PART_SIZES = 18,        /* uint64[4]: row groups, slices, pieces, index steps (of 4 edges x 16 pieces) */
+  PPRHIP_LIFT_PART_IDX = 19,          /* int32[steps * 64]: [step][piece of the slice][4] source ids, padding = n */
+  PPRHIP_LIFT_PART_SLICE_OFF = 20,    /* uint32[slices + 1]: first index step of every slice */
+  PPRHIP_LIFT_PART_DST = 21,          /* uint32[slices * 16]: piece ordinal of every quad, = pieces for an empty one */
+  PPRHIP_LIFT_PART_ROW_PIECE0 = 22,   /* uint32[rows + 1]: first piece ordinal of every row with in-edges */
+  PPRHIP_LIFT_PART_GROUP_SLICE0 = 23  /* uint32[8][groups + 1]: first slice of the partition among the groups >= g */
 };
 int pprhip_graph_lift_host(uint32_t n, uint64_t m, const uint32_t* out_row_ptr, const int32_t* out_col_idx,
                            const uint32_t* in_row_ptr, const int32_t* in_col_idx, int threads,

@@ -306,9 +306,8 @@ LIFT_ARRAYS = {  # pprhip_lift_array: name -> (id, dtype)
     "seg_base": (12, np.uint64), "sl_ci": (13, np.int32), "sl_flags": (14, np.uint8), "sl_chunk_starts": (15, np.uint32),
     "seg_row": (16, np.uint32), "seg_off": (17, np.uint32),
     # the source-partitioned copy the batched sweep walks (built when first asked for)
-    "part_bases": (18, np.uint32), "part_ci": (19, np.int32), "part_flags": (20, np.uint8),
-    "part_chunk_starts": (21, np.uint32), "part_tile_seg0": (22, np.uint32), "part_tile_mask": (23, np.uint64),
-    "part_tile_cross": (24, np.uint64), "part_tile_edge0": (25, np.uint64),
+    "part_sizes": (18, np.uint64), "part_idx": (19, np.int32), "part_slice_off": (20, np.uint32),
+    "part_dst": (21, np.uint32), "part_row_piece0": (22, np.uint32), "part_group_slice0": (23, np.uint32),
 }
 
 

@@ -43,13 +43,18 @@ constexpr int kBlock = 256;
 // 8 or 64).
 constexpr int kParts = 8;       // = XCDs of an MI355X: workgroup b of the edge kernel walks partition b % 8
 __host__ __device__ inline uint32_t part_of(uint32_t id) { return id & (uint32_t)(kParts - 1); }
-// position of an id among the ids of its own partition, and back
-__host__ __device__ inline uint32_t part_local(uint32_t id) { return id >> 3; }
-__host__ __device__ inline uint32_t part_global(uint32_t local, uint32_t p) { return (local << 3) | p; }
 // Rows of at most kPartWholeRow in-edges are not cut: all their edges go to the partition of their row ordinal (one
 // segment, one partial line) - on R-MAT 22 that leaves 4.8 M segments of 7.7 M for 8 % of the edges gathered off
 // their source's partition.
 constexpr uint32_t kPartWholeRow = 16;
+// The copy is a sliced ELL (round 6): a (row, partition) segment is cut into PIECES of at most kPieceMax edges (256
+// left the hub rows' block with one slice of 4 096 edges per wave: a serial chain of 64 gather latencies and no way to
+// balance the waves), the
+// pieces of a group of kGroupRows consecutive rows in one partition are sorted by length and packed sixteen at a time
+// into SLICES - one quad of lanes per piece, the slice as wide as its longest piece.
+constexpr uint32_t kPieceMax = 64;
+constexpr uint32_t kGroupRows = 256;  // = the granularity of the Gauss-Seidel blocks' row boundaries
+constexpr int kSliceQuads = 16;       // pieces per slice = quads of a wave
 constexpr int kTileRows = 64;   // rows per tile of the batched apply kernel (kernels_push.hip: kApplyRows)
 
 // packed frontier counter: entries in the high 28 bits, edge total in the low 36 bits

@@ -421,7 +421,6 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       if (model_cost) *model_cost += c;
       if (cut) cut->had_dense = true;
       if (bwd && !slot) PPRHIP_TRY(ensure_bwd_layout(g));  // sweep layout over the out-CSR, built on first use
-      if (!bwd && !slot) PPRHIP_TRY(ensure_part_single(g));  // (the source-partitioned copy, where it is switched on)
       if (!L.dense_prepared) {
         C8Scope c8(g, false);
         PPRHIP_TRY(c8.rc);
@@ -800,8 +799,9 @@ int ensure_workspaces(pprhip_graph* P, int count) {
 int build_batch(pprhip_graph* P) {
   const size_t n = P->n;
   for (int i = 0; i < 2; ++i) {
-    PPRHIP_TRY(alloc_dev((void**)&P->c8[i], sizeof(double) * n * kBatch));
-    PPRHIP_CHECK_HIP(hipMemsetAsync(P->c8[i], 0, sizeof(double) * n * kBatch, P->stream));
+    // (n + 1 lines: line n is never written and stays zero - the padding of the sliced ELL copy gathers it)
+    PPRHIP_TRY(alloc_dev((void**)&P->c8[i], sizeof(double) * (n + 1) * kBatch));
+    PPRHIP_CHECK_HIP(hipMemsetAsync(P->c8[i], 0, sizeof(double) * (n + 1) * kBatch, P->stream));
   }
   PPRHIP_TRY(alloc_dev((void**)&P->acc8, sizeof(double) * (n + 1) * kBatch));
   PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * (n + 1) * kBatch, P->stream));
@@ -834,10 +834,9 @@ int build_batch(pprhip_graph* P) {
 // Source-partitioned copy of the in-CSR for the batched forward sweep (engine_internal.hpp: HostPartLayout).  The
 // internal-order column indices live on the device only (the lift's host arrays are gone by now): they come back once,
 // the host builds the copy on all its threads, and it goes up again - R-MAT 22: 0.27 GB down, ~0.1 s of host work,
-// 0.3 GB up, once per handle (the copy stays when the batch workspaces are released).
+// 0.35 GB up, once per handle (the copy stays when the batch workspaces are released).
 // PPRHIP_SWEEP_PARTS=0 / 1 switches it off / on for any size (tests run small graphs both ways); by default graphs
 // from 2^22 edges on use it - below that the whole contribution array fits every L2 anyway.
-// the copy itself, built once per handle (kept until the handle goes)
 static int ensure_part_layout(pprhip_graph* P) {
   if (P->pl) return PPRHIP_OK;
   HostPartLayout H;
@@ -847,65 +846,56 @@ static int ensure_part_layout(pprhip_graph* P) {
     RawVec<int32_t> ci((size_t)P->m);
     PPRHIP_CHECK_HIP(hipMemcpy(ci.data(), P->in_ci, sizeof(int32_t) * (size_t)P->m, hipMemcpyDeviceToHost));
     PPRHIP_TRY(build_part_layout(P->n, P->m, P->h_in_rp.data(), ci.data(), P->h_nz_rows.data(), P->n_nz, 0, H));
-    L->h_tile_edge0 = std::move(H.tile_edge0);
+    L->h_group_slice0 = std::move(H.group_slice0);
   } catch (const std::bad_alloc&) {
     set_error("source-partitioned sweep layout: out of host memory");
     return PPRHIP_ERR_OOM;
   }
+  if (!H.n_pieces || !H.n_slices) return PPRHIP_OK;  // (ordinals beyond 32 bits: the row-major sweep stays)
   auto up = [&](void** d, const void* h, size_t bytes) -> int {
     PPRHIP_TRY(alloc_dev(d, bytes));
     PPRHIP_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
     return PPRHIP_OK;
   };
   int rc = PPRHIP_OK;
-  if ((rc = up((void**)&L->ci, H.ci.data(), sizeof(int32_t) * H.ci.size())) ||
-      (rc = up((void**)&L->flags, H.flags.data(), H.flags.size())) ||
-      (rc = up((void**)&L->chunk_starts, H.chunk_starts.data(), sizeof(uint32_t) * H.chunk_starts.size())) ||
-      (rc = up((void**)&L->tile_seg0, H.tile_seg0.data(), sizeof(uint32_t) * H.tile_seg0.size())) ||
-      (rc = up((void**)&L->tile_mask, H.tile_mask.data(), sizeof(unsigned long long) * std::max<size_t>(1, H.tile_mask.size()))) ||
-      (rc = up((void**)&L->tile_cross, H.tile_cross.data(), sizeof(unsigned long long) * std::max<size_t>(1, H.tile_cross.size())))) {
-    void* ptrs[] = {L->ci, L->flags, L->chunk_starts, L->tile_seg0, L->tile_mask, L->tile_cross};
+  if ((rc = up((void**)&L->idx, H.idx.data(), sizeof(int32_t) * H.idx.size())) ||
+      (rc = up((void**)&L->slice_off, H.slice_off.data(), sizeof(uint32_t) * H.slice_off.size())) ||
+      (rc = up((void**)&L->dst, H.dst.data(), sizeof(uint32_t) * H.dst.size())) ||
+      (rc = up((void**)&L->row_piece0, H.row_piece0.data(), sizeof(uint32_t) * H.row_piece0.size()))) {
+    void* ptrs[] = {L->idx, L->slice_off, L->dst, L->row_piece0};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     return rc;
   }
-  std::memcpy(L->chunk_base, H.chunk_base, sizeof L->chunk_base);
-  std::memcpy(L->seg_base, H.seg_base, sizeof L->seg_base);
-  L->n_tiles = H.n_tiles;
-  L->n_seg = H.seg_base[kParts];
+  L->n_groups = H.n_groups;
+  L->n_slices = H.n_slices;
+  L->n_pieces = H.n_pieces;
   P->pl = L.release();
   return PPRHIP_OK;
 }
 
-static int build_part_layout_device(pprhip_graph* P) {
+static bool want_part_layout(const pprhip_graph* P) {
   const char* e = getenv("PPRHIP_SWEEP_PARTS");
-  const bool want = e ? e[0] == '1' : false;  // (off by default until it is the faster layout: profiles/r05_quad_kernel_study.txt)
-  if (!want || P->m == 0 || P->n_nz == 0) return PPRHIP_OK;
-  PPRHIP_TRY(ensure_part_layout(P));
-  const size_t bytes = sizeof(double) * ((size_t)P->pl->n_seg + 1) * kBatch;
-  PPRHIP_TRY(alloc_dev((void**)&P->part_acc, bytes));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_acc, 0, bytes, P->stream));
-  return PPRHIP_OK;
+  return e ? e[0] == '1' : P->m >= (1ull << 22);
 }
 
-// The single-query sweep over the same copy (kernels_push.hip: k_dense_edges_p): the copy and one double per segment,
-// on the first dense level of a forward push.  PPRHIP_SWEEP1_PARTS=0 / 1 switches it off / on for any size.
-int ensure_part_single(pprhip_graph* g) {
-  if (g->part1 || g->part1_tried) return PPRHIP_OK;
-  g->part1_tried = true;
-  const char* e = getenv("PPRHIP_SWEEP1_PARTS");
-  const bool want = e ? e[0] == '1' : false;
-  if (!want || g->parent || g->m == 0 || g->n_nz == 0) return PPRHIP_OK;
-  PPRHIP_TRY(ensure_part_layout(g));
-  const size_t bytes = sizeof(double) * ((size_t)g->pl->n_seg + 1);
-  PPRHIP_TRY(alloc_dev((void**)&g->part1, bytes));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->part1, 0, bytes, g->stream));
+static int build_part_layout_device(pprhip_graph* P) {
+  if (!want_part_layout(P) || P->m == 0 || P->n_nz == 0) return PPRHIP_OK;
+  PPRHIP_TRY(ensure_part_layout(P));
+  if (!P->pl) return PPRHIP_OK;
+  const size_t bytes = sizeof(double) * ((size_t)P->pl->n_pieces + 1) * kBatch;
+  PPRHIP_TRY(alloc_dev((void**)&P->part_acc, bytes));
+  // (only the line behind the last piece has to be zero: the apply kernel reads it in place of pieces a row does not have)
+  PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_acc + (size_t)P->pl->n_pieces * kBatch, 0, sizeof(double) * kBatch, P->stream));
+  PPRHIP_TRY(alloc_dev((void**)&P->part_ctr, sizeof(uint32_t) * kParts * kPartCtrStride));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_ctr, 0, sizeof(uint32_t) * kParts * kPartCtrStride, P->stream));
+  std::memset(P->part_ctr_next, 0, sizeof P->part_ctr_next);
   return PPRHIP_OK;
 }
 
 void free_part_layout(pprhip_graph* P) {
   if (!P->pl) return;
-  void* ptrs[] = {P->pl->ci, P->pl->flags, P->pl->chunk_starts, P->pl->tile_seg0, P->pl->tile_mask, P->pl->tile_cross};
+  void* ptrs[] = {P->pl->idx, P->pl->slice_off, P->pl->dst, P->pl->row_piece0};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete P->pl;
@@ -935,8 +925,9 @@ void free_batch(pprhip_graph* P) {
   P->ktimer.destroy();
   P->slots.clear();
   void* ptrs[] = {P->c8[0], P->c8[1], P->acc8, P->prep_bits, P->d_slot_args, P->sweep_out, P->blk_pack8, P->blk_dead8,
-                  P->blk_ndead8, P->part_acc};
+                  P->blk_ndead8, P->part_acc, P->part_ctr};
   P->part_acc = nullptr;
+  P->part_ctr = nullptr;
   if (P->h_sweep_out) (void)hipHostFree(P->h_sweep_out);
   P->sweep_out = P->h_sweep_out = nullptr;
   P->prep_bits = nullptr;
@@ -1683,8 +1674,6 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   free_batch(g);
   free_part_layout(g);
-  if (g->part1) (void)hipFree(g->part1);
-  g->part1 = nullptr;
   void* ptrs[] = {g->walk_rec, g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags,
                   g->chunk_starts, g->nz_rows, g->zin_rows, g->cross_bits, g->start_flags_o, g->chunk_starts_o,
                   g->nz_rows_o, g->z_rows_o, g->cross_bits_o};
@@ -2286,7 +2275,6 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
   CallTimer tm(g);
   if (iters > 0) {
     // iteration 1 (Power_Method.java:59-96 with residue = {s: 1})
-    PPRHIP_TRY(ensure_part_single(g));
     LevelCtx L;
     PushArgs a{alpha, 0.0, 0.0, src, kPower};
     PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));
@@ -2321,6 +2309,54 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
   if (stats) *stats = st;
   return PPRHIP_OK;
 }
+
+#ifdef PPRHIP_TEST_HOOKS
+// Test / tuning hook (libpprhip_hooks.so only): the edge kernel of block `block` of `n_blocks` Gauss-Seidel blocks of a
+// batched forward sweep (n_blocks <= 1: the whole sweep), `reps` launches back to back; average microseconds per launch.
+// part != 0: over the source-partitioned copy (an error when the handle has none).
+int pprhip_hook_time_sweep_edges(pprhip_graph_t* g, int part, int block, int n_blocks, int reps, double* us_out) {
+  if (!g || !us_out || reps <= 0 || g->parent) {
+    set_error("pprhip_hook_time_sweep_edges: bad arguments");
+    return PPRHIP_ERR_INVALID;
+  }
+  PPRHIP_CHECK_HIP(hipSetDevice(g->device));
+  PPRHIP_TRY(ensure_batch(g));
+  if (part && !(g->pl && g->part_acc)) {
+    set_error("pprhip_hook_time_sweep_edges: no source-partitioned copy on this handle");
+    return PPRHIP_ERR_INVALID;
+  }
+  GsBlock B{0u, g->n_nz, 0ull, (unsigned long long)g->m};
+  if (n_blocks > 1) {
+    pprhip_tuning_t keep = g->slots[0]->tun;
+    g->slots[0]->tun.gs_blocks = n_blocks;
+    int nb = 1;
+    const GsBlock* blocks = gs_blocks_of(g->slots[0], &nb);
+    g->slots[0]->tun = keep;
+    if (!blocks || block < 0 || block >= nb) {
+      set_error("pprhip_hook_time_sweep_edges: no block %d of %d", block, n_blocks);
+      return PPRHIP_ERR_INVALID;
+    }
+    B = blocks[block];
+  }
+  hipEvent_t e0, e1;
+  PPRHIP_CHECK_HIP(hipEventCreate(&e0));
+  PPRHIP_CHECK_HIP(hipEventCreate(&e1));
+  PPRHIP_TRY(launch_sweep_edges_only(g, B, part != 0));  // warm-up
+  PPRHIP_CHECK_HIP(hipEventRecord(e0, g->stream));
+  for (int i = 0; i < reps; ++i) PPRHIP_TRY(launch_sweep_edges_only(g, B, part != 0));
+  PPRHIP_CHECK_HIP(hipEventRecord(e1, g->stream));
+  PPRHIP_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PPRHIP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *us_out = (double)ms * 1e3 / reps;
+  // (the row-major kernel adds into acc8 with atomics where rows cross chunks: start the next sweep clean)
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->acc8, 0, sizeof(double) * ((size_t)g->n + 1) * kBatch, g->stream));
+  PPRHIP_CHECK_HIP(hipStreamSynchronize(g->stream));
+  return PPRHIP_OK;
+}
+#endif
 
 }  // extern "C"
 

@@ -95,24 +95,23 @@ struct SlicedLayout {
   int plan_B = -1;
 };
 
-// The source-partitioned copy of the in-CSR on the device (engine_internal.hpp: HostPartLayout; batched forward sweep).
+// The source-partitioned copy of the in-CSR on the device, a sliced ELL (engine_internal.hpp: HostPartLayout; batched
+// forward sweep).
 struct PartLayout {
-  int32_t* ci = nullptr;
-  uint8_t* flags = nullptr;
-  uint32_t* chunk_starts = nullptr;
-  uint32_t* tile_seg0 = nullptr;             // [kParts][n_tiles + 1]
-  unsigned long long* tile_mask = nullptr;   // [kParts][n_tiles]
-  unsigned long long* tile_cross = nullptr;  // [kParts][n_tiles]
-  uint32_t chunk_base[kParts + 1] = {0}, seg_base[kParts + 1] = {0};
-  uint32_t n_tiles = 0, n_seg = 0;
-  std::vector<unsigned long long> h_tile_edge0;  // host: [kParts][n_tiles + 1], the Gauss-Seidel blocks' edge windows
+  int32_t* idx = nullptr;          // [n_step4 * 64] source ids: [step][quad][4]; padding = zero_id (= n)
+  uint32_t* slice_off = nullptr;   // [n_slices + 1] first index step of every slice
+  uint32_t* dst = nullptr;         // [n_slices * 16] partial line of every quad's piece (n_pieces: none)
+  uint32_t* row_piece0 = nullptr;  // [n_nz + 1] a row's partial lines are [row_piece0[j], row_piece0[j + 1])
+  uint32_t n_groups = 0, n_slices = 0, n_pieces = 0;
+  std::vector<uint32_t> h_group_slice0;  // host: [kParts][n_groups + 1], the Gauss-Seidel blocks' slice windows
 };
-// what one launch of the partitioned edge kernel walks: per partition the chunks [c_lo, c_hi) and, inside their first
-// and last chunk, the edges [e_lo, e_hi) (the rows of one Gauss-Seidel block)
+// what one launch of the partitioned edge kernel walks: per partition the slices [lo, hi) (the rows of one
+// Gauss-Seidel block: whole groups of kGroupRows rows)
 struct PartWindows {
-  uint32_t c_lo[kParts], c_hi[kParts];
-  unsigned long long e_lo[kParts], e_hi[kParts];
+  uint32_t lo[kParts], hi[kParts];
+  uint32_t base[kParts];  // value of the partition's slice counter (part_ctr) when the launch starts
 };
+constexpr int kPartCtrStride = 32;  // uint32 per partition counter: a line each
 
 enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
 
@@ -379,9 +378,11 @@ struct pprhip_graph {
   double* c8[2] = {nullptr, nullptr};
   int c8cur = 0;
   pprhip::PartLayout* pl = nullptr;  // source-partitioned copy of the in-CSR (forward batched sweeps), with the batch state
-  double* part_acc = nullptr;        // [segments + 1][kBatch] partial row sums of its (row, partition) segments
-  double* part1 = nullptr;           // [segments + 1] the same for the single-query sweep over the copy (k_dense_edges_p)
-  bool part1_tried = false;
+  double* part_acc = nullptr;        // [pieces + 1][kBatch] partial row sums (the line behind the last stays zero)
+  // the partitions' slice queues: the waves of a launch take slices in turn (atomicAdd); the counters only ever grow,
+  // the host keeps what they will hold when the next launch starts (every wave's last, failing take included)
+  uint32_t* part_ctr = nullptr;      // [kParts * kPartCtrStride]
+  uint32_t part_ctr_next[pprhip::kParts] = {0};
   double* acc8 = nullptr;      // [row ordinal][kBatch] row sums
   int acc8_dir = 0;            // layout the row sums were last written in (0 forward, 1 backward)
   int32_t* zin_rows = nullptr;  // rows without in-edges
@@ -500,6 +501,10 @@ const EdgeWindows* sliced_windows_of(pprhip_graph* g, const GsBlock* blocks, int
 constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply kernel (per-slot partials each)
 // slot arguments already staged in parent->h_slot_args; blocks: Gauss-Seidel blocks (nullptr / 1: one launch)
 int launch_dense_level_b8(pprhip_graph* parent, bool backward, const pprhip::GsBlock* blocks = nullptr, int n_blocks = 1);
+#ifdef PPRHIP_TEST_HOOKS
+int launch_sweep_edges_only(pprhip_graph* parent, const pprhip::GsBlock& B, bool part);
+int launch_count_live_lines(pprhip_graph* P, unsigned long long* d_out);
+#endif
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);
 int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_slot);
 int launch_seed_list(pprhip_graph* g, const PushArgs& a, int seed_kind, int out_fbuf, unsigned long long* d_counter,

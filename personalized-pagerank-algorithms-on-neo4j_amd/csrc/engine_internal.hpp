@@ -201,28 +201,35 @@ struct HostLift {
   std::vector<uint8_t> sl_flags;
   std::vector<uint32_t> sl_chunk_starts, seg_row, seg_off;
 };
-// Source-partitioned copy of the in-CSR for the batched forward sweep (round 5).  Why: a batched gather moves one
+// Source-partitioned copy of the in-CSR for the batched forward sweep (rounds 5-6).  Why: a batched gather moves one
 // 128-byte line c8[u][0..15] per in-edge, and the sweep is bound by the lines that leave L2 (46 M of 67 M per sweep on
 // R-MAT 22, 52-55 G/s); every XCD has an L2 of its own and all eight held the same hottest 32 K lines.  Here the edges
-// are grouped by part_of(source): partition p's edges (rows ascending, a row's edges in their CSR order) form a chunked
-// layout of their own - a "row" of it is a SEGMENT (row, p) - and workgroup b of the edge kernel walks partition b % 8,
-// i.e. the workgroups of XCD x only ever gather lines of partition x (workgroups are dealt to the XCDs round-robin:
-// tools/micro/xcd_affine_rate.hip reads XCC_ID), so eight L2s hold eight different hot sets.  A segment's sum is a
-// partial row sum: it is stored to part_acc[segment ordinal] (a stream per partition) and the apply kernel adds a
-// row's up to eight partials, found through per-tile (64 rows) masks and first-segment ordinals.
-// All partitions are concatenated: partition p owns the chunks [chunk_base[p], chunk_base[p+1]) and the segment ordinals
-// [seg_base[p], seg_base[p+1]); chunk_starts holds GLOBAL ordinals, so the kernel indexes part_acc directly.
+// are grouped by part_of(source) and workgroup b of the edge kernel walks partition b % 8, i.e. the workgroups of XCD x
+// only ever gather lines of partition x (workgroups are dealt to the XCDs round-robin: tools/micro/xcd_affine_rate.hip
+// reads XCC_ID), so eight L2s hold eight different hot sets.
+// Round 5 kept every partition as a chunked CSR whose "rows" were (row, partition) segments: a segment ended every 8.8
+// edges, and flags, scans and mid-chunk stores made the edge kernel issue-bound (profiles/r05_quad_kernel_study.txt).
+// Round 6: a sliced ELL.  A row's edges in one partition (its SEGMENT; rows of <= kPartWholeRow in-edges stay whole in
+// the partition of their ordinal) are cut into PIECES of at most kPieceMax edges.  A row's pieces are numbered
+// consecutively (partition ascending, then position), pieces of all rows in row order: piece o's sum is the partial
+// line part_acc[o], and the apply kernel adds the lines [row_piece0[j], row_piece0[j + 1]) of row j - a stream.  The
+// pieces of partition p among the rows of GROUP g (kGroupRows consecutive ordinals: the Gauss-Seidel blocks' boundaries
+// are multiples of it) are sorted by (length descending, ordinal ascending) and packed sixteen at a time into SLICES:
+// one quad of lanes per piece, every quad walking its own piece in step, the slice as wide as its first (longest)
+// piece rounded up to four edges; shorter pieces and the empty quads of a cell's last slice are padded with zero_id,
+// the id of a contribution line that is always zero.  No row-start flags, no scans, no stores before a piece's end.
+// Slices are numbered partition-major, then by group, then in their cell's order; slice s keeps its indices at
+// idx[(off + j4) * 64 + 4 * q + i] = source of edge 4 * j4 + i of its q-th piece, j4 < w4.
 struct HostPartLayout {
-  uint32_t n_nz = 0, n_tiles = 0;    // rows with in-edges, tiles of kTileRows of them
-  uint32_t chunk_base[kParts + 1] = {0};
-  uint32_t seg_base[kParts + 1] = {0};
-  RawVec<int32_t> ci;                        // (chunk_base[kParts] + 1) * 512 source ids, padding zero
-  std::vector<uint8_t> flags;                // bit e: edge e of the copy is the first of its segment
-  std::vector<uint32_t> chunk_starts;        // [chunks + 1]: segments that start before each chunk (global ordinals)
-  std::vector<uint32_t> tile_seg0;           // [kParts][n_tiles + 1]: first segment of p among the rows >= 64 t
-  std::vector<unsigned long long> tile_mask;   // [kParts][n_tiles]: rows of tile t that have a segment in p
-  std::vector<unsigned long long> tile_cross;  // [kParts][n_tiles]: ... whose segment is summed with atomics
-  std::vector<unsigned long long> tile_edge0;  // [kParts][n_tiles + 1]: first edge of p among the rows >= 64 t
+  uint32_t n_nz = 0, n_groups = 0;           // rows with in-edges, groups of kGroupRows of them
+  uint32_t n_slices = 0, n_pieces = 0;
+  uint64_t n_step4 = 0;                      // sum of the slices' w4
+  uint32_t zero_id = 0;                      // = n: padding index
+  RawVec<int32_t> idx;                       // [n_step4 * 64]
+  std::vector<uint32_t> slice_off;           // [n_slices + 1] first step4 of every slice (w4 = difference)
+  std::vector<uint32_t> dst;                 // [n_slices * 16] piece ordinal of every quad; n_pieces for an empty quad
+  std::vector<uint32_t> row_piece0;          // [n_nz + 1]
+  std::vector<uint32_t> group_slice0;        // [kParts][n_groups + 1] first slice of p among the groups >= g
 };
 // in_rp / in_ci: the internal-order in-CSR; nz_rows: its non-empty rows, ascending (row ordinal -> node)
 int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,
@@ -248,7 +255,6 @@ int reset_query_state(pprhip_graph* g, bool clear_flags, int32_t node = -1);  //
 int ensure_batch(pprhip_graph* P);
 void free_batch(pprhip_graph* P);
 int ensure_bwd_layout(pprhip_graph* P);
-int ensure_part_single(pprhip_graph* g);  // the source-partitioned copy for the single-query sweep, where switched on
 // blocks of the forward Gauss-Seidel sweep for the handle's tuning (nullptr / 1 block when switched off)
 const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks);
 unsigned long long gs_thresh_of(const pprhip_graph* g);

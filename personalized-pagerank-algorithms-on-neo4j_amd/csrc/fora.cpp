@@ -515,6 +515,26 @@ int launch_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_activ
   // k_publish behind it - the sweep took 20-35 us longer either way (1 636-1 651 against 1 613-1 618 us on one box:
   // the apply kernel indexes the by-value block per wave; sixteen workgroups' system-scope fences cost more than one
   // small kernel).  Taken out.)
+#ifdef PPRHIP_TEST_HOOKS
+  {  // PPRHIP_COUNT_LIVE=1 (measurement): share of a sweep's gathers that fetch a line with a non-zero, on stderr
+    static const bool on = getenv("PPRHIP_COUNT_LIVE") != nullptr;
+    static unsigned long long* d_cnt = nullptr;
+    static unsigned long long sweeps = 0;
+    if (on && !backward) {
+      if (!d_cnt) {
+        PPRHIP_CHECK_HIP(hipMalloc((void**)&d_cnt, 16));
+        PPRHIP_CHECK_HIP(hipMemset(d_cnt, 0, 16));
+      }
+      PPRHIP_TRY(launch_count_live_lines(P, d_cnt));
+      if (++sweeps % 200 == 0) {
+        unsigned long long h[2];
+        PPRHIP_CHECK_HIP(hipMemcpy(h, d_cnt, 16, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pprhip live lines] %llu sweeps: gathers of live lines %.3f of m, live lines %.3f of the sources, busy columns now %d\n",
+                sweeps, (double)h[0] / (double)sweeps / (double)P->m, (double)h[1] / (double)sweeps / (double)P->n_src_live, n_active);
+      }
+    }
+  }
+#endif
   P->ktimer.begin(PPRHIP_KERNEL_DENSE_PULL_BATCH, sweep_bytes);
   PPRHIP_TRY(launch_dense_level_b8(P, backward, gs_blocks, n_gs));
   P->ktimer.end();

@@ -628,117 +628,6 @@ __global__ __launch_bounds__(1024) void k_dense_edges(const int32_t* __restrict_
   }
 }
 
-// k_dense_edges_p (round 5): the single-query edge kernel over the source-partitioned copy of the in-CSR (PartLayout,
-// built for the batched sweep).  Workgroup b walks partition b % kParts - so the workgroups of one XCD only ever gather
-// contributions of ids = p mod 8 - and its LDS table holds the 16 384 hottest contributions OF ITS PARTITION: ids below
-// 131 072 (three quarters of R-MAT 22's in-edges) are served from LDS instead of the 42 % a table of the 16 384 hottest
-// ids overall serves, and what is left of a partition's contributions (2.3 MB) stays in its XCD's L2.  A "row" of
-// the copy is a (row, partition) segment whose sum is a plain 8-byte store into part1[segment] (only segments that
-// cross a chunk use an atomic) - the sliced copy's kernel adds every (row, slice) segment to the row's accumulator
-// with a memory-side atomic - and k_dense_apply<.., PART> adds a row's up to eight partials.  Rows of at most
-// kPartWholeRow in-edges sit whole in the partition of their ordinal: their sources can belong to any partition, so
-// the table is only used for ids of the workgroup's own.
-template <bool HOT>
-__global__ __launch_bounds__(1024) void k_dense_edges_p(const int32_t* __restrict__ in_ci,
-                                                         const uint8_t* __restrict__ start_flags,
-                                                         const uint32_t* __restrict__ chunk_starts, PartWindows W,
-                                                         const double* __restrict__ c_cur, double* __restrict__ part1,
-                                                         uint32_t n_hot, uint32_t n, const int* state_in) {
-  extern __shared__ __attribute__((aligned(16))) double s_hot[];
-  if (dense_state(state_in, kGsJacobi) == kGsNone) return;
-  const int lane = lane_id();
-  const uint32_t part = blockIdx.x % (uint32_t)kParts;
-  const uint32_t rank = blockIdx.x / (uint32_t)kParts, wgs = gridDim.x / (uint32_t)kParts;
-  const uint32_t waves_per_block = blockDim.x >> 6;
-  const uint32_t stride = wgs * waves_per_block;
-  const uint32_t c_end = W.c_hi[part];
-  const unsigned long long e_lo = W.e_lo[part], e_hi = W.e_hi[part];
-  uint32_t c = W.c_lo[part] + rank * waves_per_block + (uint32_t)__builtin_amdgcn_readfirstlane(wave_id());
-  ChunkRegs cur;
-  if (c < c_end) cur = load_chunk(in_ci, start_flags, c, lane);  // in flight while the hot table loads
-  if (HOT) {
-    double t[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t i = threadIdx.x + j * 1024u;          // position in the partition's table
-      const uint32_t id = part_global(i, part);
-      t[j] = (i < n_hot && id < n) ? c_cur[id] : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t i = threadIdx.x + j * 1024u;
-      if (i < n_hot) s_hot[i] = t[j];
-    }
-    __syncthreads();
-  }
-  for (; c < c_end; c += stride) {
-    ChunkRegs nxt = cur;
-    if (c + stride < c_end) nxt = load_chunk(in_ci, start_flags, c + stride, lane);
-    const uint32_t cs = chunk_starts[c];
-    const unsigned long long e0 = (unsigned long long)c * kChunkEdges + 8ull * lane;
-    const uint32_t fb = cur.fb;
-    const int32_t idx[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
-    double v[8];
-    if (HOT) {
-      // branch-free, as in k_dense_edges: every lane issues both loads so that its 8 gathers stay in flight together
-      bool hot[8];
-      double gl[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t u = (uint32_t)idx[i];
-        hot[i] = part_of(u) == part && part_local(u) < n_hot;
-        gl[i] = c_cur[hot[i] ? 0u : u];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const double hv = s_hot[hot[i] ? part_local((uint32_t)idx[i]) : 0u];
-        v[i] = hot[i] ? hv : gl[i];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = c_cur[idx[i]];
-    }
-    if (e0 < e_lo || e0 + 8 > e_hi) {  // first / last chunk of the block's window only
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (e0 + i < e_lo || e0 + i >= e_hi) v[i] = 0.0;
-    }
-    const uint32_t pc = __popc(fb);
-    const uint32_t incl = wave_incl_scan_u32_dpp(pc);
-    const uint32_t before = cs + incl - pc;  // segment starts before this lane's first edge (global ordinals)
-    double seg = 0.0, first_seg = 0.0;
-    uint32_t k = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if ((fb >> i) & 1u) {
-        if (k == 0) first_seg = seg;                 // closes the segment carried in from earlier lanes
-        else part1[before + k - 1] = seg;            // a segment that starts and ends inside this lane
-        seg = 0.0;
-        ++k;
-      }
-      seg += v[i];
-    }
-    const bool h = k != 0;
-    const double sval = wave_seg_scan_f64_dpp(seg, h);
-    const double carry = wave_prev_f64_dpp(sval);
-    const unsigned long long hmask = __ballot(h);
-    if (h) {
-      const bool nonempty = lane > 0 || (fb & 1u) == 0;
-      if (nonempty && before > 0) {
-        const double tot = carry + first_seg;
-        const bool started_here = (hmask & ((1ull << lane) - 1ull)) != 0;
-        if (started_here) part1[before - 1] = tot;
-        else atomic_add_noret(&part1[before - 1], tot);  // began in an earlier chunk
-      }
-    }
-    if (lane == 63) {  // the segment still open at the end of the chunk
-      const uint32_t starts = cs + incl;
-      if (starts > 0 && sval != 0.0) atomic_add_noret(&part1[starts - 1], sval);
-    }
-    cur = nxt;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // batched dense level: kBatch queries per sweep
 // ------------------------------------------------------------------------------------------------
@@ -793,9 +682,8 @@ __device__ __forceinline__ ChunkRegsB<G> load_chunk_b(const int32_t* __restrict_
   return r;
 }
 
-// 8 edges of the group: the indices sit in lane JB of the group.  PART: the launch walks one partition of the
-// source-partitioned copy (PartLayout): its LDS table holds the hottest lines of that partition, at part_local(id).
-template <bool HOT, int G, int JB, bool PART>
+// 8 edges of the group: the indices sit in lane JB of the group.
+template <bool HOT, int G, int JB>
 __device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const double* __restrict__ cB,
                                               const double* s_hot, uint32_t n_hot, int s, bool tail,
                                               unsigned long long e_first, unsigned long long e_lo,
@@ -812,7 +700,7 @@ __device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const do
     for (int i = 0; i < 8; ++i) gl[i] = cB[(size_t)(v[i] < n_hot ? 0u : v[i]) * G + s];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const double hv = s_hot[(v[i] < n_hot ? (PART ? part_local(v[i]) : v[i]) : 0u) * G + s];
+      const double hv = s_hot[(v[i] < n_hot ? v[i] : 0u) * G + s];
       val[i] = v[i] < n_hot ? hv : gl[i];
     }
   } else {
@@ -838,55 +726,39 @@ __device__ __forceinline__ void edges_b_block(const ChunkRegsB<G>& cur, const do
   }
 }
 
-template <bool HOT, int G, int JB, bool PART>
+template <bool HOT, int G, int JB>
 struct EdgeBlocks {
   static __device__ __forceinline__ void run(const ChunkRegsB<G>& cur, const double* __restrict__ cB,
                                              const double* s_hot, uint32_t n_hot, int s, bool tail,
                                              unsigned long long e_first, unsigned long long e_lo,
                                              unsigned long long e_hi, uint32_t before,
                                              double* __restrict__ accB, double& seg, double& first_seg, uint32_t& k) {
-    EdgeBlocks<HOT, G, JB - 1, PART>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
-    edges_b_block<HOT, G, JB, PART>(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
+    EdgeBlocks<HOT, G, JB - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
+    edges_b_block<HOT, G, JB>(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
   }
 };
-template <bool HOT, int G, bool PART>
-struct EdgeBlocks<HOT, G, -1, PART> {
+template <bool HOT, int G>
+struct EdgeBlocks<HOT, G, -1> {
   static __device__ __forceinline__ void run(const ChunkRegsB<G>&, const double*, const double*, uint32_t, int, bool,
                                              unsigned long long, unsigned long long, unsigned long long, uint32_t,
                                              double*, double&, double&, uint32_t&) {}
 };
 
 // G = queries per sweep = lanes per edge; the wave's 64 / G lane groups walk 8 * G edges each.
-// PART (forward sweeps of graphs that have a PartLayout): the arrays are the source-partitioned copy, workgroup b walks
-// partition b % kParts - workgroups are dealt to the XCDs round-robin (tools/micro/xcd_affine_rate.hip reads XCC_ID:
-// 4096 of 4096), so the workgroups of one XCD only ever gather contribution lines of one partition and the eight L2s
-// hold eight different hot sets (placement decides the speed, never the result).  A "row" of the copy is a segment
-// (row, partition): accB is the partial-sum array, indexed by the global segment ordinals chunk_starts holds.  n_hot
-// is the bound of the hot ids (8 x the table's lines: every partition keeps the hottest lines of its own).
-template <bool HOT, int G, bool PART>
+template <bool HOT, int G>
 __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restrict__ in_ci,
                                                          const unsigned long long* __restrict__ flags64,
                                                          const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
                                                          unsigned long long m, const double* __restrict__ cB,
                                                          double* __restrict__ accB, uint32_t n_hot, uint32_t c_lo,
-                                                         unsigned long long e_lo, unsigned long long e_hi, uint32_t n,
-                                                         PartWindows W) {
+                                                         unsigned long long e_lo, unsigned long long e_hi, uint32_t n) {
   // one block of a sweep: chunks [c_lo, n_chunks) holding the in-edges [e_lo, e_hi) (see k_dense_edges)
   extern __shared__ __attribute__((aligned(16))) double s_hot[];
   const int lane = lane_id();
   const int grp = lane / G, s = lane & (G - 1);
   const uint32_t waves_per_block = blockDim.x >> 6;
-  uint32_t stride = gridDim.x * waves_per_block;
+  const uint32_t stride = gridDim.x * waves_per_block;
   uint32_t c = c_lo + blockIdx.x * waves_per_block + (uint32_t)wave_id();
-  const uint32_t part = PART ? blockIdx.x % (uint32_t)kParts : 0u;
-  if (PART) {
-    const uint32_t rank = blockIdx.x / (uint32_t)kParts, wgs = gridDim.x / (uint32_t)kParts;
-    stride = wgs * waves_per_block;
-    c = W.c_lo[part] + rank * waves_per_block + (uint32_t)wave_id();
-    n_chunks = W.c_hi[part];
-    e_lo = W.e_lo[part];
-    e_hi = W.e_hi[part];
-  }
   ChunkRegsB<G> cur;
   if (c < n_chunks) cur = load_chunk_b<G>(in_ci, flags64, c, lane);
   if (HOT) {
@@ -894,17 +766,12 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const uint32_t i = threadIdx.x + j * 1024u;
-      if (PART) {
-        const uint32_t id = part_global(i / G, part);  // line i / G of this partition's table
-        t[j] = id < n_hot && id < n ? cB[(size_t)id * G + (i % G)] : 0.0;
-      } else {
-        t[j] = i < n_hot * G ? cB[i] : 0.0;
-      }
+      t[j] = i < n_hot * G ? cB[i] : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const uint32_t i = threadIdx.x + j * 1024u;
-      if (PART || i < n_hot * G) s_hot[i] = t[j];
+      if (i < n_hot * G) s_hot[i] = t[j];
     }
     __syncthreads();
   }
@@ -923,7 +790,7 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
     const bool tail = c_e0 < e_lo || c_e0 + kChunkEdges > e_hi;  // first / last chunk of the block: edges outside count 0
     double seg = 0.0, first_seg = 0.0;
     uint32_t k = 0;
-    EdgeBlocks<HOT, G, G - 1, PART>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
+    EdgeBlocks<HOT, G, G - 1>::run(cur, cB, s_hot, n_hot, s, tail, e_first, e_lo, e_hi, before, accB, seg, first_seg, k);
     // segmented scan over the lane groups: S(g) = tail(g) + (group g holds a row start ? 0 : S(g-1))
     const bool h = k != 0;
     double S = seg;
@@ -961,259 +828,144 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_dense_edges_q (round 5): the batched edge kernel with FOUR lanes per edge, four slots per lane.
-// k_dense_edges_b spends sixteen lanes on an edge, and every one of them repeats the edge's index, address and flag
-// arithmetic for its one slot: ~15 vector instructions per four edges of a wave.  That was hidden while the kernel
-// waited for lines beyond L2 (row-major layout: 23 M misses per launch); over the source-partitioned copy the misses
-// fall by 60 % and the kernel turns out issue-bound - SQ_ACTIVE_INST_ANY x 4 waves = 0.9 of the SIMD cycles, 533 us per
-// launch against 463 (profiles/r05_pmc_sweep_first.txt).  Here a QUAD of lanes shares an edge, lane t of it holding the
-// slots 4t .. 4t+3 (32 bytes of the line: two 16-byte loads), so a wave instruction serves sixteen edges instead of
-// four and the per-edge arithmetic is paid once per quad lane instead of once per slot.  The wave still owns a
-// 512-edge chunk: quad q walks its edges [32q, 32q + 32), whose indices sit in the quad's own registers (8 per lane,
-// broadcast with DPP quad_perm) and whose 32 row-start bits are one word; sums close inside the quad where a segment
-// starts and ends there, cross quads with a segmented scan over the sixteen quads, and only segments that cross the
-// chunk boundary use atomics - the rules of k_dense_edges_b, so the layouts, accB and the apply kernel are the same.
+// k_dense_edges_ell (round 6): the batched edge kernel over the source-partitioned sliced ELL (engine_internal.hpp:
+// HostPartLayout).  Workgroup b walks partition b % kParts, so the workgroups of one XCD only ever gather contribution
+// lines of one partition and the eight L2s hold eight different hot sets.  A wave takes a SLICE: sixteen pieces of
+// rows, one per quad of lanes, lane t of a quad holding the slots 2t, 2t+1, 8+2t, 8+2t+1 of the running sum: two 16-byte
+// loads per edge, each of which reads one contiguous 64-byte half of the line across the quad.  Every quad walks its own piece in step with the others - the slice is as wide as its longest
+// piece, shorter ones gather the all-zero line `zero_id` - so there are no row-start flags, no scans and no stores
+// before the piece's end: per four edges of a quad one 16-byte index load (the quad's lanes read the same four ids),
+// per edge one shift, two loads, four adds.  A piece's sum is one 128-byte line part_acc[piece], written with plain
+// stores; k_dense_apply_batch<true> adds a row's lines.  (Round 5's form of this copy kept row-start flags per edge and
+// was issue-bound: ~1 900 instructions per 512 edges, profiles/r05_quad_kernel_study.txt; this loop has ~35 per 64.)
 // ------------------------------------------------------------------------------------------------
-constexpr int kQuad = 4;                         // lanes per edge
-constexpr int kQSlots = kBatch / kQuad;          // slots (doubles) per lane
-static_assert(kBatch == 16 && kQSlots == 4, "k_dense_edges_q is written for sixteen slots");
+constexpr int kEllThreads = 256;
 
-struct ChunkRegsQ {
-  int4 ia, ib;   // the lane's 8 column indices
-  uint32_t fl;   // row-start bits of the quad's 32 edges
-};
-
-__device__ __forceinline__ ChunkRegsQ load_chunk_q(const int32_t* __restrict__ in_ci, const uint32_t* __restrict__ flags32,
-                                                   uint32_t c, int lane) {
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  const v4i* q = reinterpret_cast<const v4i*>(in_ci + (unsigned long long)c * kChunkEdges + 8ull * lane);
-  const v4i x = __builtin_nontemporal_load(q), y = __builtin_nontemporal_load(q + 1);
-  ChunkRegsQ r;
-  r.ia = make_int4(x.x, x.y, x.z, x.w);
-  r.ib = make_int4(y.x, y.y, y.z, y.w);
-  r.fl = __builtin_nontemporal_load(&flags32[(size_t)c * (kChunkEdges / 32) + (size_t)(lane >> 2)]);
-  return r;
-}
-
-// value of lane K of the caller's quad
-template <int K>
-__device__ __forceinline__ int quad_bcast(int x) {
-  // quad_perm:[K,K,K,K]; every lane has a source, so the "old" operand is never used: passing x saves its v_mov
-  return __builtin_amdgcn_update_dpp(x, x, K * 0x55, 0xf, 0xf, false);
-}
-
-struct Quad4 {
-  double v[kQSlots];
-};
-typedef double v2d_t __attribute__((ext_vector_type(2)));
-struct QuadRaw {  // the two 16-byte loads of a quad lane, as they come back
-  v2d_t a, b;
-};
-
-// the caller's 32 bytes of vertex u's line.  Plain global loads on purpose: a lane-dependent choice between an LDS
-// table and memory compiles to FLAT loads, which tick both memory counters, so the loads of the next edges cannot be
-// waited for separately and every batch of edges becomes a full round trip (first form of this kernel: 500 us per
-// launch, profiles/r05_quad_kernel_study.txt).  With the partitions' lines resident in their XCD's L2 the quad shape
-// reaches 234 G lines/s from L2 alone (tools/micro/xcd_affine_rate.hip), 2.4 x what sixteen lanes per line do.
-// `lane_base` = cB + the lane's 32 bytes inside a line; the line's offset is 32-bit arithmetic where the array is
-// below 4 GB (n < 2^25: one v_lshlrev instead of a 64-bit shift and add per edge).
 template <bool WIDE>
-__device__ __forceinline__ QuadRaw load_quarter(const double* __restrict__ cB, uint32_t u, uint32_t lane_off) {
-  // uniform base + 32-bit per-lane offset (the saddr form of global_load: one v_lshl_add_u32 per edge) where the array
-  // is below 4 GB; 64-bit arithmetic otherwise
-  const v2d_t* p = WIDE ? reinterpret_cast<const v2d_t*>(reinterpret_cast<const char*>(cB) + (((size_t)u << 7) + lane_off))
-                        : reinterpret_cast<const v2d_t*>(reinterpret_cast<const char*>(cB) + (size_t)(uint32_t)((u << 7) + lane_off));
-  QuadRaw r;
-  r.a = p[0];  // the line's first 64 bytes: the quad's four lanes read them as one contiguous piece
-  r.b = p[4];  // ... and its second 64 bytes
-  return r;
+__device__ __forceinline__ const double2* ell_line(const double* __restrict__ cB, uint32_t u, uint32_t lane_off) {
+  // (the contribution array is below 4 GB unless WIDE: a 32-bit byte offset next to the uniform base address)
+  if (WIDE) return reinterpret_cast<const double2*>(reinterpret_cast<const char*>(cB) + (((size_t)u << 7) | lane_off));
+  return reinterpret_cast<const double2*>(reinterpret_cast<const char*>(cB) + ((u << 7) | lane_off));
 }
 
-// lane t of a quad holds the slots 2t, 2t + 1 (first half of the line) and 8 + 2t, 9 + 2t (second half): each of its two
-// 16-byte accesses is then part of 64 contiguous bytes per quad.  (With 32 contiguous bytes per lane every instruction
-// touched four 16-byte pieces 32 bytes apart: 15.2 M write requests for 3.8 M partial-sum lines per launch,
-// profiles/r05_pmc_sweep_quad.txt.)
-__device__ __forceinline__ int qslot(int t, int x) { return x < 2 ? 2 * t + x : 8 + 2 * t + (x - 2); }
+// Slices are handed out by a counter per partition (the waves of a launch take the next one as they finish theirs:
+// slices differ in width by a factor of sixteen, and the queries that work beside the sweeps slow some CUs down); the
+// counter only ever grows, W.base holds its value at launch, and a wave asks for its next slice before it walks the one
+// it has, so the atomic's round trip is hidden.
+__device__ __forceinline__ uint32_t ell_take(uint32_t* ctr) {
+  uint32_t v = 0;
+  if (lane_id() == 0) v = atomicAdd(ctr, 1u);
+  return v;
+}
 
-// one 512-edge chunk of the wave.  TAIL: the chunk holds edges outside the launch's window [e_lo, e_hi) (first / last
-// chunk of a block), which count as zero.
-// The kernel is bound by the instructions it issues, not by memory (every gather inside 4 MB: 472 us per launch against
-// 597, profiles/r05_quad_kernel_study.txt: ~1 850 instructions per chunk, 4 cycles each on a 16-lane SIMD), so this
-// loop is written to issue few: two register sets of four edges filled in turn (no copies), the loads of trip b + 1
-// issued before the sums of trip b, one 32-bit shift per address.
-template <bool TAIL, bool WIDE>
-__device__ __forceinline__ void quad_chunk(const ChunkRegsQ& cur, uint32_t c, uint32_t cs, const double* __restrict__ cB,
-                                           double* __restrict__ accB, unsigned long long e_lo, unsigned long long e_hi,
-                                           int lane, v2d_t* my_first) {
-  const int q = lane >> 2, t = lane & 3;
-  const uint32_t fl = cur.fl;
-  const uint32_t pc = (uint32_t)__popc(fl);
-  const uint32_t incl = wave_incl_scan_u32_dpp(t == 0 ? pc : 0u);  // segment starts up to and including this quad
-  const uint32_t before = cs + incl - pc;
-  const unsigned long long e_first = (unsigned long long)c * kChunkEdges + 32ull * q;
-  const int32_t own[8] = {cur.ia.x, cur.ia.y, cur.ia.z, cur.ia.w, cur.ib.x, cur.ib.y, cur.ib.z, cur.ib.w};
-  const uint32_t lane_off = 16u * (uint32_t)t;
-  double seg[kQSlots] = {0.0, 0.0, 0.0, 0.0};
-  uint32_t k = 0;
-  auto issue = [&](int b, QuadRaw* dst) {  // four edges: 4b .. 4b + 3, held by lane b / 2 of the quad
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int x = own[(b & 1) * 4 + i];
-      const uint32_t u = (uint32_t)((b >> 1) == 0 ? quad_bcast<0>(x) : (b >> 1) == 1 ? quad_bcast<1>(x) : (b >> 1) == 2 ? quad_bcast<2>(x) : quad_bcast<3>(x));
-      dst[i] = load_quarter<WIDE>(cB, u, lane_off);
-    }
-  };
-  auto consume = [&](int b, const QuadRaw* src) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      double val[kQSlots] = {src[i].a.x, src[i].a.y, src[i].b.x, src[i].b.y};
-      if (TAIL) {
-        if (e_first + 4 * b + i < e_lo || e_first + 4 * b + i >= e_hi) {
-#pragma unroll
-          for (int x = 0; x < kQSlots; ++x) val[x] = 0.0;
-        }
-      }
-      if ((fl >> (4 * b + i)) & 1u) {
-        v2d_t lo, hi;
-        lo.x = seg[0]; lo.y = seg[1]; hi.x = seg[2]; hi.y = seg[3];
-        if (k == 0) {
-          // closes the segment carried in from earlier quads: parked in the lane's own 32 bytes of LDS until the scan
-          // (kept in registers, the compiler merges this branch with the store below through eight 64-bit moves per
-          // segment start)
-          my_first[0] = lo;
-          my_first[1] = hi;
-        } else {  // a segment that starts and ends inside this quad
-          v2d_t* dst = reinterpret_cast<v2d_t*>(accB + (size_t)(before + k - 1) * kBatch + 2 * t);
-          __builtin_nontemporal_store(lo, dst);
-          __builtin_nontemporal_store(hi, dst + 4);
-        }
-        ++k;
-#pragma unroll
-        for (int x = 0; x < kQSlots; ++x) seg[x] = 0.0;
-      }
-#pragma unroll
-      for (int x = 0; x < kQSlots; ++x) seg[x] += val[x];
-    }
-  };
-  QuadRaw ra[4], rb[4];
-  issue(0, ra);
-#pragma unroll
-  for (int bb = 0; bb < 4; ++bb) {
-    issue(2 * bb + 1, rb);
-    consume(2 * bb, ra);
-    if (bb < 3) issue(2 * bb + 2, ra);
-    consume(2 * bb + 1, rb);
-  }
-  // segmented scan over the quads: S(q) = tail(q) + (quad q holds a segment start ? 0 : S(q - 1))
-  const bool h = k != 0;
-  double first_seg[kQSlots] = {0.0, 0.0, 0.0, 0.0};
-  if (h) {  // (the lane's own stores: no barrier)
-    const v2d_t lo = my_first[0], hi = my_first[1];
-    first_seg[0] = lo.x; first_seg[1] = lo.y; first_seg[2] = hi.x; first_seg[3] = hi.y;
-  }
-  double S[kQSlots];
-#pragma unroll
-  for (int x = 0; x < kQSlots; ++x) S[x] = seg[x];
-  int F = h ? 1 : 0;
-#pragma unroll
-  for (int d = kQuad; d < 64; d <<= 1) {
-    double ps[kQSlots];
-#pragma unroll
-    for (int x = 0; x < kQSlots; ++x) ps[x] = __shfl_up(S[x], d);
-    const int pf = __shfl_up(F, d);
-    if (lane >= d) {
-      if (!F) {
-#pragma unroll
-        for (int x = 0; x < kQSlots; ++x) S[x] += ps[x];
-      }
-      F |= pf;
-    }
-  }
-  double carry[kQSlots];
-#pragma unroll
-  for (int x = 0; x < kQSlots; ++x) {
-    carry[x] = __shfl_up(S[x], kQuad);
-    if (lane < kQuad) carry[x] = 0.0;
-  }
-  const unsigned long long hmask = __ballot(h);
-  if (h) {
-    const bool nonempty = q > 0 || (fl & 1u) == 0;
-    if (nonempty && before > 0) {
-      const bool started_here = (hmask & ((1ull << (q * kQuad)) - 1ull)) != 0;
-      double* dst = accB + (size_t)(before - 1) * kBatch;
-      if (started_here) {
-#pragma unroll
-        for (int x = 0; x < kQSlots; ++x) dst[qslot(t, x)] = carry[x] + first_seg[x];
-      } else {  // began in an earlier chunk
-#pragma unroll
-        for (int x = 0; x < kQSlots; ++x) atomic_add_noret(dst + qslot(t, x), carry[x] + first_seg[x]);
-      }
-    }
-  }
-  if (q == 64 / kQuad - 1) {  // the segment still open at the end of the chunk
-    const uint32_t starts = cs + incl;
-    if (starts > 0) {
-#pragma unroll
-      for (int x = 0; x < kQSlots; ++x)
-        if (S[x] != 0.0) atomic_add_noret(&accB[(size_t)(starts - 1) * kBatch + qslot(t, x)], S[x]);
-    }
+// one edge's two half lines; COLD_NT: ids from `hot` on are loaded non-temporal, so that the many lines gathered
+// once or twice per sweep do not push the few gathered thousands of times out of L2
+template <bool WIDE, bool COLD_NT>
+__device__ __forceinline__ void ell_edge(const double* __restrict__ cB, uint32_t u, uint32_t lane_off, uint32_t hot,
+                                         double2& x, double2& y) {
+#ifdef PPRHIP_TEST_HOOKS
+  if (!COLD_NT) u &= hot;  // (measurement, PPRHIP_ELL_MASK: every gather inside the first ids - the kernel's own ceiling)
+#endif
+  const double2* l = ell_line<WIDE>(cB, u, lane_off);
+  if (COLD_NT && u >= hot) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d* ln = reinterpret_cast<const v2d*>(l);
+    const v2d a = __builtin_nontemporal_load(ln), b = __builtin_nontemporal_load(ln + 4);
+    x = make_double2(a.x, a.y);
+    y = make_double2(b.x, b.y);
+  } else {
+    x = l[0];
+    y = l[4];
   }
 }
 
-// PART: workgroup b walks partition b % kParts of the source-partitioned copy (see k_dense_edges_b); WIDE: the
-// contribution array is 4 GB or more (64-bit line offsets)
-template <bool PART, bool WIDE>
-__global__ __launch_bounds__(1024) void k_dense_edges_q(const int32_t* __restrict__ in_ci,
-                                                         const uint32_t* __restrict__ flags32,
-                                                         const uint32_t* __restrict__ chunk_starts, uint32_t n_chunks,
-                                                         const double* __restrict__ cB, double* __restrict__ accB,
-                                                         uint32_t c_lo, unsigned long long e_lo, unsigned long long e_hi,
-                                                         PartWindows W) {
-  __shared__ v2d_t s_first[1024 * 2];  // per lane: the carried-in segment's partial sum until the chunk's scan (32 KB)
+template <bool WIDE, bool COLD_NT, int UNROLL>
+__global__ __launch_bounds__(kEllThreads) void k_dense_edges_ell(const int32_t* __restrict__ idx,
+                                                                 const uint32_t* __restrict__ slice_off,
+                                                                 const uint32_t* __restrict__ dst, PartWindows W,
+                                                                 const double* __restrict__ cB,
+                                                                 double* __restrict__ part_acc, uint32_t n_pieces,
+                                                                 uint32_t* __restrict__ part_ctr, uint32_t hot, uint32_t dbg) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
   const int lane = lane_id();
-  v2d_t* my_first = &s_first[2 * threadIdx.x];
-  const uint32_t waves_per_block = blockDim.x >> 6;
-  uint32_t stride = gridDim.x * waves_per_block;
-  uint32_t c = c_lo + blockIdx.x * waves_per_block + (uint32_t)wave_id();
-  if (PART) {
-    const uint32_t part = blockIdx.x % (uint32_t)kParts;
-    const uint32_t rank = blockIdx.x / (uint32_t)kParts, wgs = gridDim.x / (uint32_t)kParts;
-    stride = wgs * waves_per_block;
-    c = W.c_lo[part] + rank * waves_per_block + (uint32_t)wave_id();
-    n_chunks = W.c_hi[part];
-    e_lo = W.e_lo[part];
-    e_hi = W.e_hi[part];
-  }
-  ChunkRegsQ cur;
-  if (c < n_chunks) cur = load_chunk_q(in_ci, flags32, c, lane);
-  for (; c < n_chunks; c += stride) {
-    ChunkRegsQ nxt = cur;
-    const uint32_t cn = c + stride;
-    if (cn < n_chunks) nxt = load_chunk_q(in_ci, flags32, cn, lane);
-    const uint32_t cs = chunk_starts[c];
-    const unsigned long long c_e0 = (unsigned long long)c * kChunkEdges;
-    if (c_e0 < e_lo || c_e0 + kChunkEdges > e_hi) quad_chunk<true, WIDE>(cur, c, cs, cB, accB, e_lo, e_hi, lane, my_first);
-    else quad_chunk<false, WIDE>(cur, c, cs, cB, accB, e_lo, e_hi, lane, my_first);
-    cur = nxt;
+  const uint32_t q = (uint32_t)lane >> 2, lane_off = ((uint32_t)lane & 3u) * 16u;
+  const uint32_t part = blockIdx.x % (uint32_t)kParts;
+  const uint32_t s_lo = W.lo[part], count = W.hi[part] - s_lo, base = W.base[part];
+  uint32_t* ctr = part_ctr + part * (uint32_t)kPartCtrStride;
+  const uint32_t dbg_stride = (gridDim.x / (uint32_t)kParts) * (blockDim.x >> 6);
+  uint32_t cur = (dbg & 1u) ? (blockIdx.x / (uint32_t)kParts) * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane(wave_id())
+                            : (uint32_t)__builtin_amdgcn_readfirstlane(ell_take(ctr)) - base;
+  while (cur < count) {
+    const uint32_t s = s_lo + cur;
+    const uint32_t nxt = (dbg & 1u) ? cur + dbg_stride + base : ell_take(ctr);
+    const uint32_t off = slice_off[s], w4 = slice_off[s + 1] - off;
+    // the index stream is read once per sweep: non-temporal, so that it does not push gathered lines out of L2
+    const v4i* ip = reinterpret_cast<const v4i*>(idx) + (size_t)off * kSliceQuads + q;
+    const uint32_t o = __builtin_nontemporal_load(&dst[(size_t)s * kSliceQuads + q]);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    uint32_t j = 0;
+    if (UNROLL == 2) {
+      // eight edges per turn: sixteen gathers in flight per lane
+      for (; j + 2 <= w4; j += 2) {
+        const v4i ix = __builtin_nontemporal_load(ip + (size_t)j * kSliceQuads);
+        const v4i iy = __builtin_nontemporal_load(ip + (size_t)(j + 1) * kSliceQuads);
+        double2 x[8], y[8];
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.x, lane_off, hot, x[0], y[0]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.y, lane_off, hot, x[1], y[1]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.z, lane_off, hot, x[2], y[2]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.w, lane_off, hot, x[3], y[3]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)iy.x, lane_off, hot, x[4], y[4]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)iy.y, lane_off, hot, x[5], y[5]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)iy.z, lane_off, hot, x[6], y[6]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)iy.w, lane_off, hot, x[7], y[7]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          a0 += x[e].x; a1 += x[e].y; a2 += y[e].x; a3 += y[e].y;
+        }
+      }
+    }
+    if (j < w4) {
+      v4i ix = (dbg & 4u) ? ip[(size_t)j * kSliceQuads] : __builtin_nontemporal_load(ip + (size_t)j * kSliceQuads);
+      for (; j < w4; ++j) {
+        v4i nx = ix;
+        if (j + 1 < w4) nx = (dbg & 4u) ? ip[(size_t)(j + 1) * kSliceQuads] : __builtin_nontemporal_load(ip + (size_t)(j + 1) * kSliceQuads);  // in flight beside the gathers
+        double2 x[4], y[4];
+        if (dbg & 2u) {
+          x[0] = y[0] = make_double2((double)ix.x, 0.0);
+          x[1] = y[1] = make_double2((double)ix.y, 0.0);
+          x[2] = y[2] = make_double2((double)ix.z, 0.0);
+          x[3] = y[3] = make_double2((double)ix.w, 0.0);
+        } else {
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.x, lane_off, hot, x[0], y[0]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.y, lane_off, hot, x[1], y[1]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.z, lane_off, hot, x[2], y[2]);
+        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.w, lane_off, hot, x[3], y[3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0 += x[e].x; a1 += x[e].y; a2 += y[e].x; a3 += y[e].y;
+        }
+        ix = nx;
+      }
+    }
+    if (o != n_pieces) {  // (an empty quad of a cell's last slice)
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      v2d* out = reinterpret_cast<v2d*>(reinterpret_cast<char*>(part_acc) + (((size_t)o << 7) | lane_off));
+      v2d lo2, hi2;
+      lo2.x = a0; lo2.y = a1; hi2.x = a2; hi2.y = a3;
+      __builtin_nontemporal_store(lo2, out);
+      __builtin_nontemporal_store(hi2, out + 4);
+    }
+    cur = (uint32_t)__builtin_amdgcn_readfirstlane(nxt) - base;
   }
 }
 
 // k_dense_apply: one thread per non-empty row (plus one for a source without in-edges, which
 // only ever receives returned dead-end mass): lands the row sum, detects the threshold crossing
 // and prepares the row for the next level in place.
-// PART: the row sums arrive as the partial sums of the row's (row, partition) segments (k_dense_edges_p): tile t of
-// partition p holds the segments tile_seg0[p][t] ... in row order for the rows of tile_mask[p][t]; segments summed with
-// atomics (tile_cross) are cleared as they are read.  (acc_nz is the partial-sum array then.)
-struct PartTiles {
-  const uint32_t* seg0;               // [kParts][n_tiles + 1]
-  const unsigned long long* mask;     // [kParts][n_tiles]
-  const unsigned long long* cross;    // [kParts][n_tiles]
-  uint32_t n_tiles, n_seg;
-};
-
-template <int MODE, bool PART>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__ nz_rows, uint32_t j_lo, uint32_t n_nz,
-                                                      double* __restrict__ acc_nz, PartTiles PT,
+                                                      double* __restrict__ acc_nz,
                                                       const uint32_t* __restrict__ out_rp,
                                                       const uint32_t* __restrict__ in_rp,
                                                       double* __restrict__ c_cur, double* __restrict__ c_next,
@@ -1236,29 +988,8 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
   double acc = 0.0;
   if (j < n_nz) {
     u = nz_rows[j];
-    if (PART) {
-      // (a wave covers the 64 rows of one tile: the tile's words are the same address for all its lanes)
-      const uint32_t tl = j / (uint32_t)kTileRows, r = j % (uint32_t)kTileRows;
-      double x[kParts];
-      uint32_t at[kParts];
-      bool clr[kParts];
-#pragma unroll
-      for (int p = 0; p < kParts; ++p) {
-        const unsigned long long mk = PT.mask[(size_t)p * PT.n_tiles + tl];
-        const bool has = (mk >> r) & 1ull;
-        at[p] = has ? PT.seg0[(size_t)p * (PT.n_tiles + 1) + tl] + (uint32_t)__popcll(mk & ((1ull << r) - 1ull)) : PT.n_seg;
-        clr[p] = has && ((PT.cross[(size_t)p * PT.n_tiles + tl] >> r) & 1ull);
-        x[p] = acc_nz[at[p]];  // (rows without a segment in p read the all-zero slot behind the last segment)
-      }
-#pragma unroll
-      for (int p = 0; p < kParts; ++p) {
-        acc += x[p];
-        if (clr[p] && x[p] != 0.0) acc_nz[at[p]] = 0.0;
-      }
-    } else {
-      acc = acc_nz[j];
-      acc_nz[j] = 0.0;
-    }
+    acc = acc_nz[j];
+    acc_nz[j] = 0.0;
     have = true;
   } else if (j == n_nz && src_extra) {
     u = a.src;
@@ -1349,9 +1080,8 @@ constexpr int kApplyGroups = 2;  // tiles of kApplyRows rows a workgroup carries
 constexpr int kApplyThreads = 512;  // 8 waves, 2 slots each: few enough slot arguments to stay in SGPRs
 constexpr int kSlotsPerWave = kBatch / (kApplyThreads / 64);
 
-// PART: the row sums arrive as partial sums of the row's (row, partition) segments (PartLayout): tile t of partition p
-// holds the segments tile_seg0[p][t] ... in row order for the rows of tile_mask[p][t]; up to kParts lines per row are
-// added here, and the segments summed with atomics (tile_cross) are cleared as they are read.
+// PART: the row sums arrive as the partial sums of the row's pieces (PartLayout, k_dense_edges_ell): the lines
+// [row_piece0[j], row_piece0[j + 1]) of part_acc, consecutive for consecutive rows - a stream; the line n_pieces is zero.
 template <bool PART>
 __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
                                                             const int32_t* __restrict__ zin_rows, uint32_t n_zin,
@@ -1367,11 +1097,10 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
                                                             unsigned long long* __restrict__ blk_pack8,
                                                             double* __restrict__ blk_dead8,
                                                             uint32_t* __restrict__ blk_ndead8, uint32_t part_base,
-                                                            uint32_t part_stride, double* __restrict__ part_acc,
-                                                            const uint32_t* __restrict__ tile_seg0,
-                                                            const unsigned long long* __restrict__ tile_mask,
-                                                            const unsigned long long* __restrict__ tile_cross,
-                                                            uint32_t n_tiles_nz, uint32_t n_seg) {
+                                                            uint32_t part_stride,
+                                                            const double* __restrict__ part_acc,
+                                                            const uint32_t* __restrict__ row_piece0,
+                                                            uint32_t n_pieces) {
   // tiles [tile_lo, tile_hi) of one block of the sweep.  gs_mask: slots whose state writes the current array in place
   // (entry / in-place / flush, engine.hpp: GsState); entry_mask: those of them that add to what it holds.
   __shared__ double tile[kApplyGroups][kApplyRows][kBatch + 1];
@@ -1404,44 +1133,35 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
       const bool in = tl < tile_hi;
       const uint32_t row0 = tl * kApplyRows;
       if (PART) {
-        const bool have = in && tl < n_tiles_nz;  // (the tiles behind the rows with in-edges hold no sums)
-        // lane s < kParts of a row's 16 lanes derives the row's segment ordinal in partition s (one mask word, one
-        // popcount) and the others receive it with a swizzle: eight ordinals per ROW instead of per element
-        const int sl = tid & (kBatch - 1);
-        const int pp = sl & (kParts - 1);
-        const unsigned long long mk = have ? tile_mask[(size_t)pp * n_tiles_nz + tl] : 0ull;
-        const unsigned long long cr = have ? tile_cross[(size_t)pp * n_tiles_nz + tl] : 0ull;
-        const uint32_t s0 = have ? tile_seg0[(size_t)pp * (n_tiles_nz + 1) + tl] : 0u;
+        constexpr int kPer = kApplyRows * kBatch / kApplyThreads;  // rows a thread serves per tile
+        uint32_t pa[kPer], pb[kPer];
+        double x[kPer][4];
 #pragma unroll
-        for (int i = 0; i < kApplyRows * kBatch / kApplyThreads; ++i) {
-          const uint32_t idx = (uint32_t)i * (uint32_t)kApplyThreads + tid;
-          const uint32_t r = idx / kBatch, s = idx % kBatch;
-          const bool has = (mk >> r) & 1ull;
-          // bit 31: the segment is one that is summed with atomics (cleared when read)
-          const uint32_t mine = has ? ((s0 + (uint32_t)__popcll(mk & ((1ull << r) - 1ull))) | (((cr >> r) & 1ull) ? 0x80000000u : 0u))
-                                    : n_seg;
-          // all of a row's partial lines are requested together: rows without a segment in a partition read the
-          // all-zero line behind the last segment instead of branching around the load
-          double x[kParts];
-          uint32_t ord[kParts];
-          ord[0] = (uint32_t)group_bcast<kBatch, 0>((int)mine);
-          ord[1] = (uint32_t)group_bcast<kBatch, 1>((int)mine);
-          ord[2] = (uint32_t)group_bcast<kBatch, 2>((int)mine);
-          ord[3] = (uint32_t)group_bcast<kBatch, 3>((int)mine);
-          ord[4] = (uint32_t)group_bcast<kBatch, 4>((int)mine);
-          ord[5] = (uint32_t)group_bcast<kBatch, 5>((int)mine);
-          ord[6] = (uint32_t)group_bcast<kBatch, 6>((int)mine);
-          ord[7] = (uint32_t)group_bcast<kBatch, 7>((int)mine);
+        for (int i = 0; i < kPer; ++i) {
+          const uint32_t j = row0 + ((uint32_t)i * (uint32_t)kApplyThreads + tid) / kBatch;
+          const bool have = in && j < n_nz;
+          pa[i] = have ? row_piece0[j] : 0u;
+          pb[i] = have ? row_piece0[j + 1] : 0u;
+        }
+        const uint32_t sl = tid % kBatch;
+        // the first four lines of every row are requested together (most rows have one): rows with fewer read the
+        // all-zero line behind the last piece instead of branching around the load
 #pragma unroll
-          for (int p = 0; p < kParts; ++p)
-            x[p] = __builtin_nontemporal_load(&part_acc[(size_t)(ord[p] & 0x7fffffffu) * kBatch + s]);
-          double v = 0.0;
+        for (int i = 0; i < kPer; ++i)
 #pragma unroll
-          for (int p = 0; p < kParts; ++p) {
-            v += x[p];
-            if (x[p] != 0.0 && (ord[p] & 0x80000000u)) part_acc[(size_t)(ord[p] & 0x7fffffffu) * kBatch + s] = 0.0;
+          for (int k = 0; k < 4; ++k)
+            x[i][k] = __builtin_nontemporal_load(&part_acc[(size_t)(pa[i] + k < pb[i] ? pa[i] + k : n_pieces) * kBatch + sl]);
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+          double v = ((x[i][0] + x[i][1]) + x[i][2]) + x[i][3];
+          for (uint32_t p = pa[i] + 4; p < pb[i]; p += 4) {
+            double y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              y[k] = __builtin_nontemporal_load(&part_acc[(size_t)(p + k < pb[i] ? p + k : n_pieces) * kBatch + sl]);
+            v = (((v + y[0]) + y[1]) + y[2]) + y[3];
           }
-          tile[g][r][s] = v;
+          tile[g][((uint32_t)i * (uint32_t)kApplyThreads + tid) / kBatch][sl] = v;
         }
         continue;
       }
@@ -2052,12 +1772,8 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   const GsBlock* blocks = (dl.blocks && dl.n_blocks > 1 && !bwd) ? dl.blocks : &whole;
   const int nb = blocks == &whole ? 1 : dl.n_blocks;
   const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
-  // forward sweeps of a handle with the source-partitioned copy (PPRHIP_SWEEP1_PARTS, engine.cpp: ensure_part_single) walk
-  // that; otherwise those of a graph whose sources span several slices walk the sliced copy of the in-CSR.  (A batch
-  // slot borrows its parent's copy and has partial sums of its own.)
-  pprhip_graph* pl_owner = g->parent ? g->parent : g;
-  const bool part = !bwd && pl_owner->pl && g->part1;
-  const SlicedLayout* sl = (bwd || part) ? nullptr : g->sl;
+  // forward sweeps of a graph whose sources span several slices walk the sliced copy of the in-CSR
+  const SlicedLayout* sl = bwd ? nullptr : g->sl;
   const EdgeWindows* wins = sl ? detail::sliced_windows_of(g, blocks == &whole ? nullptr : blocks, nb) : nullptr;
   if (sl) {
     ci = sl->ci;
@@ -2078,39 +1794,7 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     }
     const EdgeWindows& W = sl ? wins[b] : one;
     const uint32_t n_ch = W.n ? W.c_pre[W.n] : 0u;
-    if (part) {
-      // the source-partitioned copy: one launch, workgroup b on partition b % kParts (launch_dense_edges_part)
-      const PartLayout& L = *pl_owner->pl;
-      const uint32_t NT = L.n_tiles;
-      const uint32_t t_lo = B.j_lo / kTileRows, t_hi = std::min<uint32_t>(NT, (B.j_hi + kTileRows - 1) / kTileRows);
-      PartWindows PW{};
-      uint32_t most = 0;
-      for (int p = 0; p < kParts; ++p) {
-        const unsigned long long e_lo = L.h_tile_edge0[(size_t)p * (NT + 1) + t_lo];
-        const unsigned long long e_hi = L.h_tile_edge0[(size_t)p * (NT + 1) + t_hi];
-        PW.e_lo[p] = e_lo;
-        PW.e_hi[p] = e_hi;
-        PW.c_lo[p] = (uint32_t)(e_lo / kChunkEdges);
-        PW.c_hi[p] = e_hi > e_lo ? (uint32_t)((e_hi + kChunkEdges - 1) / kChunkEdges) : PW.c_lo[p];
-        most = std::max(most, PW.c_hi[p] - PW.c_lo[p]);
-      }
-      if (most) {
-        // PPRHIP_SWEEP1_HOT (measurement switch): lines of the partition's LDS table; half a table lets two workgroups share a CU
-        static const uint32_t hot_lines = [] {
-          const char* e = getenv("PPRHIP_SWEEP1_HOT");
-          return e ? (uint32_t)std::max(64, std::min((int)kHotMax, atoi(e))) : (uint32_t)kHotMax;
-        }();
-        const uint32_t per_cu = hot_lines * 2 <= (uint32_t)kHotMax ? 2u : 1u;
-        const uint32_t per_part = std::max(1u, std::min<uint32_t>((most + 15) / 16, (uint32_t)g->n_cus / kParts * per_cu));
-        if (n_hot)
-          k_dense_edges_p<true><<<dim3(per_part * kParts), dim3(1024), sizeof(double) * hot_lines, g->stream>>>(
-              L.ci, L.flags, L.chunk_starts, PW, g->cdense[cbuf], g->part1, hot_lines, g->n, dl.state_in);
-        else
-          k_dense_edges_p<false><<<dim3(per_part * kParts), dim3(1024), 0, g->stream>>>(
-              L.ci, L.flags, L.chunk_starts, PW, g->cdense[cbuf], g->part1, 0u, g->n, dl.state_in);
-        PPRHIP_CHECK_HIP(hipGetLastError());
-      }
-    } else if (g->n_chunks && n_ch) {
+    if (g->n_chunks && n_ch) {
       // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
       const uint32_t want = (n_ch + 15) / 16;
       const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * (n_hot ? 1u : 2u));
@@ -2133,22 +1817,11 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     const uint32_t rows = B.j_hi - B.j_lo + (uint32_t)extra;
     const uint32_t grid = (rows + 255) / 256;
     if (grid) {
-      if (part) {
-        const PartLayout& L = *pl_owner->pl;
-        const PartTiles PT{L.tile_seg0, L.tile_mask, L.tile_cross, L.n_tiles, L.n_seg};
-        DISPATCH_MODE(a.mode, (k_dense_apply<M, true><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                                  nz, B.j_lo, B.j_hi, g->part1, PT, g->out_rp, g->in_rp, g->cdense[cbuf], g->cdense[cbuf ^ 1],
-                                  g->residue, g->reserve, g->flags, g->armed, g->ctr, g->blk_pack + part_base,
-                                  g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot, extra, a, dl.state_in,
-                                  dl.state0, b == nb - 1 ? 1 : 0)));
-      } else {
-        const PartTiles none{nullptr, nullptr, nullptr, 0u, 0u};
-        DISPATCH_MODE(a.mode, (k_dense_apply<M, false><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                                  nz, B.j_lo, B.j_hi, g->acc_nz, none, g->out_rp, g->in_rp, g->cdense[cbuf], g->cdense[cbuf ^ 1],
-                                  g->residue, g->reserve, g->flags, g->armed, g->ctr, g->blk_pack + part_base,
-                                  g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot, extra, a, dl.state_in,
-                                  dl.state0, b == nb - 1 ? 1 : 0)));
-      }
+      DISPATCH_MODE(a.mode, (k_dense_apply<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
+                                nz, B.j_lo, B.j_hi, g->acc_nz, g->out_rp, g->in_rp, g->cdense[cbuf], g->cdense[cbuf ^ 1],
+                                g->residue, g->reserve, g->flags, g->armed, g->ctr, g->blk_pack + part_base,
+                                g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot, extra, a, dl.state_in,
+                                dl.state0, b == nb - 1 ? 1 : 0)));
       PPRHIP_CHECK_HIP(hipGetLastError());
       part_base += grid;
     }
@@ -2180,74 +1853,102 @@ static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8
   const uint32_t c_hi = (uint32_t)((B.e_hi + kChunkEdges - 1) / kChunkEdges);
   const uint32_t want = (c_hi - c_lo + 15) / 16;
   const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(start_flags);
-  const PartWindows none{};
   if (n_hot) {
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus);
-    k_dense_edges_b<true, G, false><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * G, g->stream>>>(
-        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, n_hot, c_lo, B.e_lo, B.e_hi, g->n, none);
+    k_dense_edges_b<true, G><<<dim3(grid), dim3(1024), sizeof(double) * n_hot * G, g->stream>>>(
+        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, n_hot, c_lo, B.e_lo, B.e_hi, g->n);
   } else {
     const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * 2u);
-    k_dense_edges_b<false, G, false><<<dim3(grid), dim3(1024), 0, g->stream>>>(
-        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, 0u, c_lo, B.e_lo, B.e_hi, g->n, none);
+    k_dense_edges_b<false, G><<<dim3(grid), dim3(1024), 0, g->stream>>>(
+        ci, flags64, chunk_starts, c_hi, (unsigned long long)g->m, cB, accB, 0u, c_lo, B.e_lo, B.e_hi, g->n);
   }
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
 
-static uint32_t edge_wgs_per_cu() {  // PPRHIP_SWEEP_WGS (measurement switch): workgroups of the quad kernel per CU
+// PPRHIP_SWEEP_WGS (tuning): workgroups (of four waves) of the partitioned edge kernel per CU; the default fills a CU
+static uint32_t edge_wgs_per_cu() {
   static const uint32_t v = [] {
     const char* e = getenv("PPRHIP_SWEEP_WGS");
-    return e ? (uint32_t)std::max(1, atoi(e)) : 1u;
+    return e ? (uint32_t)std::max(1, std::min(8, atoi(e))) : 8u;
   }();
   return v;
 }
 
 // the same block over the source-partitioned copy: one launch, workgroup b on partition b % kParts
-template <int G>
 static int launch_dense_edges_part(pprhip_graph* g, const double* cB, const GsBlock& B) {
   const PartLayout& L = *g->pl;
-  const uint32_t NT = L.n_tiles;
-  // block boundaries are multiples of 256 row ordinals (or the end of the rows): whole tiles
-  const uint32_t t_lo = B.j_lo / kTileRows, t_hi = std::min<uint32_t>(NT, (B.j_hi + kTileRows - 1) / kTileRows);
+  const uint32_t NG = L.n_groups;
+  // block boundaries are multiples of kGroupRows row ordinals (or the end of the rows): whole groups
+  const uint32_t g_lo = B.j_lo / kGroupRows, g_hi = std::min<uint32_t>(NG, (B.j_hi + kGroupRows - 1) / kGroupRows);
   PartWindows W{};
   uint32_t most = 0;
   for (int p = 0; p < kParts; ++p) {
-    const unsigned long long e_lo = L.h_tile_edge0[(size_t)p * (NT + 1) + t_lo];
-    const unsigned long long e_hi = L.h_tile_edge0[(size_t)p * (NT + 1) + t_hi];
-    W.e_lo[p] = e_lo;
-    W.e_hi[p] = e_hi;
-    W.c_lo[p] = (uint32_t)(e_lo / kChunkEdges);
-    W.c_hi[p] = e_hi > e_lo ? (uint32_t)((e_hi + kChunkEdges - 1) / kChunkEdges) : W.c_lo[p];
-    most = std::max(most, W.c_hi[p] - W.c_lo[p]);
+    W.lo[p] = L.h_group_slice0[(size_t)p * (NG + 1) + g_lo];
+    W.hi[p] = L.h_group_slice0[(size_t)p * (NG + 1) + g_hi];
+    W.base[p] = g->part_ctr_next[p];
+    most = std::max(most, W.hi[p] - W.lo[p]);
   }
   if (!most) return PPRHIP_OK;
-  const uint32_t lines = (uint32_t)(kHotBytes / (8 * G));                       // per partition
-  static const bool no_hot = getenv("PPRHIP_SWEEP_NO_HOT") != nullptr;          // (measurement switch: no LDS table)
-  const uint32_t n_hot = g->relabeled && !no_hot ? lines * (uint32_t)kParts : 0u;  // bound of the hot ids
-  const uint32_t per_part = std::max(1u, std::min<uint32_t>((most + 15) / 16, (uint32_t)g->n_cus / kParts));
-  const unsigned long long* flags64 = reinterpret_cast<const unsigned long long*>(L.flags);
-  static const bool old_kernel = getenv("PPRHIP_SWEEP_EDGES_B") != nullptr;  // (measurement switch: sixteen lanes per edge)
-  const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(L.flags);
-  if (old_kernel) {
-    if (n_hot)
-      k_dense_edges_b<true, G, true><<<dim3(per_part * kParts), dim3(1024), kHotBytes, g->stream>>>(
-          L.ci, flags64, L.chunk_starts, 0u, (unsigned long long)g->m, cB, g->part_acc, n_hot, 0u, 0ull, 0ull, g->n, W);
-    else
-      k_dense_edges_b<false, G, true><<<dim3(per_part * kParts), dim3(1024), 0, g->stream>>>(
-          L.ci, flags64, L.chunk_starts, 0u, (unsigned long long)g->m, cB, g->part_acc, 0u, 0u, 0ull, 0ull, g->n, W);
-  } else {
-    // (no LDS table: two workgroups fit a CU when the registers allow)
-    const uint32_t wgs = std::max(1u, std::min<uint32_t>((most + 15) / 16, (uint32_t)g->n_cus / kParts * edge_wgs_per_cu()));
-    if ((uint64_t)g->n * kBatch * sizeof(double) >= (1ull << 32))
-      k_dense_edges_q<true, true><<<dim3(wgs * kParts), dim3(1024), 0, g->stream>>>(L.ci, flags32, L.chunk_starts, 0u, cB,
-                                                                                    g->part_acc, 0u, 0ull, 0ull, W);
-    else
-      k_dense_edges_q<true, false><<<dim3(wgs * kParts), dim3(1024), 0, g->stream>>>(L.ci, flags32, L.chunk_starts, 0u, cB,
-                                                                                     g->part_acc, 0u, 0ull, 0ull, W);
+  const uint32_t wpb = kEllThreads / 64;
+  const uint32_t wgs = std::max(1u, std::min<uint32_t>((most + wpb - 1) / wpb, (uint32_t)g->n_cus / kParts * edge_wgs_per_cu()));
+  const bool wide = ((uint64_t)g->n + 1) * kBatch * sizeof(double) >= (1ull << 32);
+  static const int variant = getenv("PPRHIP_ELL_VARIANT") ? atoi(getenv("PPRHIP_ELL_VARIANT")) : 0;  // bit 0: cold nt, bit 1: unroll 2
+  static const uint32_t hot_env = getenv("PPRHIP_ELL_HOT") ? (uint32_t)atol(getenv("PPRHIP_ELL_HOT")) : 131072u;
+  static const uint32_t mask_env = getenv("PPRHIP_ELL_MASK") ? (uint32_t)strtoul(getenv("PPRHIP_ELL_MASK"), nullptr, 0) : 0xffffffffu;
+  const uint32_t hot = (variant & 1) ? hot_env : mask_env;
+  static const uint32_t dbg = getenv("PPRHIP_ELL_DBG") ? (uint32_t)atoi(getenv("PPRHIP_ELL_DBG")) : 0u;
+#define PPRHIP_ELL_LAUNCH(WIDE, NT, UN)                                                                              \
+  k_dense_edges_ell<WIDE, NT, UN><<<dim3(wgs * kParts), dim3(kEllThreads), 0, g->stream>>>(L.idx, L.slice_off, L.dst, W, cB, \
+                                                                                        g->part_acc, L.n_pieces, g->part_ctr, hot, dbg)
+  if (wide) PPRHIP_ELL_LAUNCH(true, false, 1);
+  else if (variant == 1) PPRHIP_ELL_LAUNCH(false, true, 1);
+  else if (variant == 2) PPRHIP_ELL_LAUNCH(false, false, 2);
+  else if (variant == 3) PPRHIP_ELL_LAUNCH(false, true, 2);
+  else PPRHIP_ELL_LAUNCH(false, false, 1);
+#undef PPRHIP_ELL_LAUNCH
+  PPRHIP_CHECK_HIP(hipGetLastError());
+  // every wave takes slices until one is beyond the window: the partition's slices + one failing take per wave
+  for (int p = 0; p < kParts; ++p) g->part_ctr_next[p] += (W.hi[p] - W.lo[p]) + wgs * wpb;
+  return PPRHIP_OK;
+}
+
+#ifdef PPRHIP_TEST_HOOKS
+// measurement (PPRHIP_COUNT_LIVE): how many of a sweep's gathers fetch a line that is zero in every column?
+// out[0] += out-degrees of the nodes whose line holds a non-zero, out[1] += such nodes
+__global__ __launch_bounds__(256) void k_count_live_lines(const double* __restrict__ c8, const uint32_t* __restrict__ out_rp,
+                                                          uint32_t n, unsigned long long* out) {
+  __shared__ unsigned long long s_red[4];
+  const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+  unsigned long long d = 0, c = 0;
+  if (v < n) {
+    bool live = false;
+    for (int s = 0; s < kBatch; ++s) live |= c8[(size_t)v * kBatch + s] != 0.0;
+    if (live) {
+      d = out_rp[v + 1] - out_rp[v];
+      c = 1;
+    }
   }
+  const unsigned long long ds = block_sum_u64(d, s_red), cs = block_sum_u64(c, s_red);
+  if (threadIdx.x == 0 && (ds | cs)) {
+    atomicAdd(&out[0], ds);
+    atomicAdd(&out[1], cs);
+  }
+}
+int launch_count_live_lines(pprhip_graph* P, unsigned long long* d_out) {
+  k_count_live_lines<<<dim3((P->n + 255) / 256), dim3(256), 0, P->stream>>>(P->c8[P->c8cur], P->out_rp, P->n, d_out);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
+#endif
+
+#ifdef PPRHIP_TEST_HOOKS
+// the edge kernel of one block of a batched forward sweep alone (pprhip_hook_time_sweep_edges)
+int launch_sweep_edges_only(pprhip_graph* P, const GsBlock& B, bool part) {
+  if (part) return launch_dense_edges_part(P, P->c8[P->c8cur], B);
+  return launch_dense_edges_bG<kBatch>(P, P->in_ci, P->start_flags, P->chunk_starts, P->c8[P->c8cur], P->acc8, B);
+}
+#endif
 
 int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_blocks, int n_gs_blocks) {
   PPRHIP_CHECK_HIP(hipMemcpyAsync(P->d_slot_args, P->h_slot_args, sizeof(SlotArgs) * kBatch, hipMemcpyHostToDevice,
@@ -2279,7 +1980,7 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_bloc
   uint32_t part_base = 0;
   for (int b = 0; b < nb; ++b) {
     const GsBlock& B = blocks[b];
-    if (part) PPRHIP_TRY(launch_dense_edges_part<kBatch>(P, P->c8[P->c8cur], B));
+    if (part) PPRHIP_TRY(launch_dense_edges_part(P, P->c8[P->c8cur], B));
     else PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8, B));
     // block boundaries are multiples of 256 row ordinals, so tiles never straddle; the rows without in-edges
     // follow the last block.  The last block's rows are read by nobody again in this sweep (the next sweep reads the
@@ -2293,13 +1994,12 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_bloc
       k_dense_apply_batch<true><<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
           nz, n_nz, zr, n_z, P->acc8, P->out_rp, nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo, t_hi,
           b == nb - 1 ? 0u : gs_mask, b == nb - 1 ? 0u : entry_mask, P->d_slot_args, cross, P->prep_bits, P->blk_pack8,
-          P->blk_dead8, P->blk_ndead8, part_base, kApplyBlocks8, P->part_acc, P->pl->tile_seg0, P->pl->tile_mask,
-          P->pl->tile_cross, P->pl->n_tiles, P->pl->n_seg);
+          P->blk_dead8, P->blk_ndead8, part_base, kApplyBlocks8, P->part_acc, P->pl->row_piece0, P->pl->n_pieces);
     else
       k_dense_apply_batch<false><<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
           nz, n_nz, zr, n_z, P->acc8, P->out_rp, backward ? P->in_rp : nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo,
           t_hi, b == nb - 1 ? 0u : gs_mask, b == nb - 1 ? 0u : entry_mask, P->d_slot_args, cross, P->prep_bits,
-          P->blk_pack8, P->blk_dead8, P->blk_ndead8, part_base, kApplyBlocks8, nullptr, nullptr, nullptr, nullptr, 0u, 0u);
+          P->blk_pack8, P->blk_dead8, P->blk_ndead8, part_base, kApplyBlocks8, nullptr, nullptr, 0u);
     PPRHIP_CHECK_HIP(hipGetLastError());
     part_base += grid;
   }
@@ -2423,15 +2123,11 @@ int init_kernels_push() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges<true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
-  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_p<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
-  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
-  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch, true>),
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
   hipFuncAttributes fa0;
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_q<true, false>)));
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_q<true, true>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_ell<false, false, 1>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_ell<true, false, 1>)));
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sparse_push<kBackward>)));
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch<false>)));

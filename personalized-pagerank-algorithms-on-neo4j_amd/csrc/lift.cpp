@@ -443,127 +443,183 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
   return PPRHIP_OK;
 }
 
-// ---- source-partitioned copy of the in-CSR (engine_internal.hpp: HostPartLayout).  Three passes: (A) edges per (row,
-// partition), on all threads over row ranges of equal edge counts; (B) per partition - one thread each - the running
-// offsets of its rows, its segment ordinals, flags, chunk starts and tile words; (C) the edges themselves, on all
-// threads again, every row writing at the offsets pass B fixed - so the arrays are the same with any thread count.
+// ---- source-partitioned copy of the in-CSR as a sliced ELL (engine_internal.hpp: HostPartLayout).  Passes: (A) edges
+// and pieces per (row, partition), the rows' first piece ordinals; (B) per group of rows, the slices and index steps
+// of its eight cells (a histogram of the piece lengths gives them without sorting), then the running offsets of every
+// cell; (C) per group again, on all threads: edges bucketed by partition, the cell's pieces sorted, its slices written
+// at the offsets pass B fixed - so the arrays are the same with any thread count.
+namespace {
+struct EllPiece {
+  uint32_t len, ord;
+  const int32_t* src;  // the piece's sources, in the row's CSR order
+};
+inline uint32_t pieces_of(uint32_t edges) { return (edges + kPieceMax - 1) / kPieceMax; }
+}  // namespace
+
 int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,
                       uint32_t n_nz, unsigned threads, HostPartLayout& L) {
-  (void)n;
   PhaseClock clk;
   const unsigned T = (m < (1u << 20)) ? 1u : std::max(1u, threads ? threads : host_threads());
   L.n_nz = n_nz;
-  L.n_tiles = (n_nz + kTileRows - 1) / kTileRows;
-  const size_t NT = L.n_tiles;
-  // (A) cnt[p * n_nz + j]: edges of row ordinal j whose source lies in partition p
+  L.n_groups = (n_nz + kGroupRows - 1) / kGroupRows;
+  L.zero_id = n;
+  const size_t NG = L.n_groups;
+  // (A) cnt[j * kParts + p]: edges of row ordinal j that lie in partition p
   RawVec<uint32_t> cnt((size_t)kParts * n_nz);
-  std::vector<uint32_t> rb(1, 0);  // row-ordinal ranges of about equal edge counts
+  L.row_piece0.assign((size_t)n_nz + 1, 0);
+  const unsigned tasks = T == 1 ? 1u : (unsigned)std::min<size_t>(NG, (size_t)T * 16u);
+  std::vector<uint32_t> gb(tasks + 1, (uint32_t)NG);  // group ranges of about equal edge counts
   {
-    const unsigned parts = T == 1 ? 1u : T * 8u;
+    gb[0] = 0;
+    unsigned k = 1;
     uint64_t acc = 0;
-    for (uint32_t j = 0; j + 1 < n_nz; ++j) {
-      const uint32_t v = (uint32_t)nz_rows[j];
-      acc += in_rp[v + 1] - in_rp[v];
-      if (rb.size() < parts && acc >= m / parts * rb.size()) rb.push_back(j + 1);
+    for (size_t g = 0; g < NG && k < tasks; ++g) {
+      const uint32_t j_hi = (uint32_t)std::min<size_t>(n_nz, (g + 1) * kGroupRows);
+      acc = (uint64_t)in_rp[(uint32_t)nz_rows[j_hi - 1] + 1];
+      while (k < tasks && acc >= m / tasks * k) gb[k++] = (uint32_t)g + 1;
     }
-    rb.push_back(n_nz);
   }
-  const unsigned n_ranges = (unsigned)rb.size() - 1;
-  parallel_parts(n_ranges, T, [&](unsigned r) {
-    for (uint32_t j = rb[r]; j < rb[r + 1]; ++j) {
+  parallel_parts(tasks, T, [&](unsigned r) {
+    for (uint32_t j = gb[r] * kGroupRows; j < std::min<uint64_t>(n_nz, (uint64_t)gb[r + 1] * kGroupRows); ++j) {
       const uint32_t v = (uint32_t)nz_rows[j];
       uint32_t c[kParts] = {0};
       const uint32_t deg = in_rp[v + 1] - in_rp[v];
       if (deg <= kPartWholeRow) c[part_of(j)] = deg;  // a short row stays whole, in the partition of its ordinal
       else
         for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) c[part_of((uint32_t)in_ci[e])]++;
-      for (int p = 0; p < kParts; ++p) cnt[(size_t)p * n_nz + j] = c[p];
+      uint32_t np = 0;
+      for (int p = 0; p < kParts; ++p) {
+        cnt[(size_t)j * kParts + p] = c[p];
+        np += pieces_of(c[p]);
+      }
+      L.row_piece0[j + 1] = np;
     }
   });
+  {
+    uint64_t run = 0;
+    for (uint32_t j = 0; j < n_nz; ++j) {
+      run += L.row_piece0[j + 1];
+      if (run >= 0xfffffff0ull) return PPRHIP_OK;  // piece ordinals are 32-bit: keep the row-major sweep (n_pieces = 0)
+      L.row_piece0[j + 1] = (uint32_t)run;
+    }
+  }
   clk.mark("partition: counts");
-  // sizes: chunks and segments per partition
-  uint64_t edges_p[kParts] = {0}, segs_p[kParts] = {0};
-  parallel_parts(kParts, T, [&](unsigned p) {
-    uint64_t e = 0, sg = 0;
-    const uint32_t* c = cnt.data() + (size_t)p * n_nz;
-    for (uint32_t j = 0; j < n_nz; ++j) {
-      e += c[j];
-      sg += c[j] ? 1u : 0u;
+  // (B) per cell (p, g): slices and index steps
+  std::vector<uint32_t> cell_slices((size_t)kParts * NG, 0);
+  std::vector<uint64_t> cell_step4((size_t)kParts * NG, 0);
+  parallel_parts(tasks, T, [&](unsigned r) {
+    std::vector<uint32_t> hist(kPieceMax + 1);
+    for (uint32_t g = gb[r]; g < gb[r + 1]; ++g) {
+      const uint32_t j_lo = g * kGroupRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(g + 1) * kGroupRows);
+      for (int p = 0; p < kParts; ++p) {
+        std::fill(hist.begin(), hist.end(), 0u);
+        uint32_t np = 0;
+        for (uint32_t j = j_lo; j < j_hi; ++j) {
+          const uint32_t c = cnt[(size_t)j * kParts + p];
+          if (!c) continue;
+          const uint32_t k = pieces_of(c);
+          hist[kPieceMax] += k - 1;
+          hist[c - (k - 1) * kPieceMax]++;
+          np += k;
+        }
+        // the slices' first pieces are those of rank 0, 16, 32 ... by length descending
+        uint64_t s4 = 0;
+        uint32_t rank = 0, next = 0;
+        for (uint32_t len = kPieceMax; len >= 1 && next < np; --len) {
+          rank += hist[len];
+          while (next < rank) {
+            s4 += (len + 3) / 4;
+            next += kSliceQuads;
+          }
+        }
+        cell_slices[(size_t)p * NG + g] = (np + kSliceQuads - 1) / kSliceQuads;
+        cell_step4[(size_t)p * NG + g] = s4;
+      }
     }
-    edges_p[p] = e;
-    segs_p[p] = sg;
   });
-  L.chunk_base[0] = 0;
-  L.seg_base[0] = 0;
+  L.group_slice0.assign((size_t)kParts * (NG + 1), 0);
+  std::vector<uint64_t> cell_off((size_t)kParts * NG, 0);
+  uint64_t slices = 0, step4 = 0;
   for (int p = 0; p < kParts; ++p) {
-    L.chunk_base[p + 1] = L.chunk_base[p] + (uint32_t)((edges_p[p] + kChunkPad - 1) / kChunkPad);
-    L.seg_base[p + 1] = L.seg_base[p] + (uint32_t)segs_p[p];
-  }
-  const size_t n_chunks = L.chunk_base[kParts];
-  L.ci.resize((n_chunks + 1) * (size_t)kChunkPad);
-  L.flags.assign((n_chunks + 1) * (size_t)(kChunkPad / 8), 0);
-  L.chunk_starts.assign(n_chunks + 1, 0);
-  L.tile_seg0.assign((size_t)kParts * (NT + 1), 0);
-  L.tile_mask.assign((size_t)kParts * NT, 0ull);
-  L.tile_cross.assign((size_t)kParts * NT, 0ull);
-  L.tile_edge0.assign((size_t)kParts * (NT + 1), 0ull);
-  // (B) per partition: cnt becomes the row's first edge (relative to the partition's base); everything that follows
-  // from the segment boundaries
-  parallel_parts(kParts, T, [&](unsigned p) {
-    uint32_t* c = cnt.data() + (size_t)p * n_nz;
-    const uint64_t e_base = (uint64_t)L.chunk_base[p] * kChunkPad, e_end = e_base + edges_p[p];
-    uint64_t e = e_base;
-    uint32_t sg = L.seg_base[p];
-    uint32_t* cst = L.chunk_starts.data();
-    for (uint32_t j = 0; j < n_nz; ++j) {
-      const size_t t = j / kTileRows;
-      if (j % kTileRows == 0) {
-        L.tile_seg0[(size_t)p * (NT + 1) + t] = sg;
-        L.tile_edge0[(size_t)p * (NT + 1) + t] = e;
-      }
-      const uint32_t k = c[j];
-      c[j] = (uint32_t)(e - e_base);
-      if (!k) continue;
-      const uint64_t last = e + k - 1;
-      L.flags[e >> 3] |= (uint8_t)(1u << (e & 7));
-      cst[e / kChunkPad + 1]++;  // (a chunk belongs to one partition: no other thread counts here)
-      L.tile_mask[(size_t)p * NT + t] |= 1ull << (j % kTileRows);
-      // summed with atomics, so cleared when it is read: a segment that holds the last edge of a chunk (spans two
-      // chunks, or ends where a chunk or the partition ends) - the rule of HostLift::cross for rows
-      if (e / kChunkPad != last / kChunkPad || (last + 1) % kChunkPad == 0 || last + 1 == e_end)
-        L.tile_cross[(size_t)p * NT + t] |= 1ull << (j % kTileRows);
-      e += k;
-      sg++;
+    for (size_t g = 0; g < NG; ++g) {
+      L.group_slice0[(size_t)p * (NG + 1) + g] = (uint32_t)slices;
+      cell_off[(size_t)p * NG + g] = step4;
+      slices += cell_slices[(size_t)p * NG + g];
+      step4 += cell_step4[(size_t)p * NG + g];
     }
-    L.tile_seg0[(size_t)p * (NT + 1) + NT] = sg;
-    L.tile_edge0[(size_t)p * (NT + 1) + NT] = e;
-    // padding of the partition's last chunk
-    const uint64_t pad_end = (uint64_t)L.chunk_base[p + 1] * kChunkPad;
-    std::fill(L.ci.begin() + (size_t)e_end, L.ci.begin() + (size_t)pad_end, 0);
-  });
-  std::fill(L.ci.begin() + n_chunks * (size_t)kChunkPad, L.ci.end(), 0);
-  {  // chunk starts: counts -> segments before each chunk, as global ordinals
-    uint32_t run = 0;
-    for (size_t ch = 0; ch <= n_chunks; ++ch) {
-      run += L.chunk_starts[ch];
-      L.chunk_starts[ch] = run;
-    }
+    L.group_slice0[(size_t)p * (NG + 1) + NG] = (uint32_t)slices;
   }
+  if (step4 >= 0xfffffff0ull || slices >= 0x0ffffff0ull) return PPRHIP_OK;  // (offsets are 32-bit)
+  L.n_slices = (uint32_t)slices;
+  L.n_step4 = step4;
+  L.n_pieces = L.row_piece0[n_nz];
+  L.idx.resize((size_t)step4 * 64);
+  L.slice_off.assign((size_t)slices + 1, 0);
+  L.slice_off[slices] = (uint32_t)step4;
+  L.dst.assign((size_t)slices * kSliceQuads, L.n_pieces);
   clk.mark("partition: offsets");
-  // (C) the edges
-  parallel_parts(n_ranges, T, [&](unsigned r) {
-    for (uint32_t j = rb[r]; j < rb[r + 1]; ++j) {
-      const uint32_t v = (uint32_t)nz_rows[j];
-      uint64_t w[kParts];
-      for (int p = 0; p < kParts; ++p) w[p] = (uint64_t)L.chunk_base[p] * kChunkPad + cnt[(size_t)p * n_nz + j];
-      const bool whole = in_rp[v + 1] - in_rp[v] <= kPartWholeRow;
-      for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) {
-        const int32_t u = in_ci[e];
-        L.ci[w[whole ? part_of(j) : part_of((uint32_t)u)]++] = u;
+  // (C) the slices
+  parallel_parts(tasks, T, [&](unsigned r) {
+    std::vector<int32_t> bucket[kParts];
+    std::vector<EllPiece> pc[kParts];
+    struct Seg { uint32_t ord, len; size_t at; int p; };
+    std::vector<Seg> segs;
+    for (uint32_t g = gb[r]; g < gb[r + 1]; ++g) {
+      const uint32_t j_lo = g * kGroupRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(g + 1) * kGroupRows);
+      for (int p = 0; p < kParts; ++p) {
+        bucket[p].clear();
+        pc[p].clear();
+      }
+      segs.clear();
+      for (uint32_t j = j_lo; j < j_hi; ++j) {
+        const uint32_t v = (uint32_t)nz_rows[j];
+        const uint32_t deg = in_rp[v + 1] - in_rp[v];
+        uint32_t ord = L.row_piece0[j];
+        if (deg <= kPartWholeRow) {
+          pc[part_of(j)].push_back(EllPiece{deg, ord, in_ci + in_rp[v]});
+          continue;
+        }
+        const uint32_t* c = &cnt[(size_t)j * kParts];
+        size_t at[kParts];
+        for (int p = 0; p < kParts; ++p) {
+          at[p] = bucket[p].size();
+          if (c[p]) segs.push_back(Seg{ord, c[p], at[p], p});
+          ord += pieces_of(c[p]);
+          bucket[p].resize(at[p] + c[p]);
+        }
+        for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) {
+          const int32_t u = in_ci[e];
+          bucket[part_of((uint32_t)u)][at[part_of((uint32_t)u)]++] = u;
+        }
+      }
+      // (the buckets do not move any more: pieces may point into them)
+      for (const Seg& sg : segs)
+        for (uint32_t k = 0, left = sg.len; left; ++k, left -= std::min(left, kPieceMax))
+          pc[sg.p].push_back(EllPiece{std::min(left, kPieceMax), sg.ord + k, bucket[sg.p].data() + sg.at + (size_t)k * kPieceMax});
+      for (int p = 0; p < kParts; ++p) {
+        std::vector<EllPiece>& P = pc[p];
+        std::sort(P.begin(), P.end(), [](const EllPiece& a, const EllPiece& b) {
+          return a.len != b.len ? a.len > b.len : a.ord < b.ord;
+        });
+        uint32_t sl = L.group_slice0[(size_t)p * (NG + 1) + g];
+        uint64_t off = cell_off[(size_t)p * NG + g];
+        for (size_t i = 0; i < P.size(); i += kSliceQuads, ++sl) {
+          const uint32_t w4 = (P[i].len + 3) / 4;
+          L.slice_off[sl] = (uint32_t)off;
+          int32_t* out = L.idx.data() + (size_t)off * 64;
+          for (int q = 0; q < kSliceQuads; ++q) {
+            const bool have = i + q < P.size();
+            const uint32_t len = have ? P[i + q].len : 0u;
+            if (have) L.dst[(size_t)sl * kSliceQuads + q] = P[i + q].ord;
+            for (uint32_t e = 0; e < w4 * 4; ++e)
+              out[(size_t)(e >> 2) * 64 + (size_t)q * 4 + (e & 3)] = e < len ? P[i + q].src[e] : (int32_t)n;
+          }
+          off += w4;
+        }
       }
     }
   });
-  clk.mark("partition: edges");
+  clk.mark("partition: slices");
   return PPRHIP_OK;
 }
 
@@ -578,6 +634,7 @@ struct pprhip_lift {
   int threads = 0;
   mutable bool have_part = false;  // the source-partitioned copy is built when one of its arrays is first asked for
   mutable HostPartLayout part;
+  mutable uint64_t part_sizes[4] = {0, 0, 0, 0};  // groups, slices, pieces, index steps
 };
 
 extern "C" {
@@ -621,7 +678,7 @@ int pprhip_lift_array(const pprhip_lift_t* lift, int which, const void** data_ou
     return PPRHIP_OK;
   };
 #define PPRHIP_LIFT_VEC(v) give((v).data(), (v).size() * sizeof((v)[0]))
-  if (which >= PPRHIP_LIFT_PART_BASES && which <= PPRHIP_LIFT_PART_TILE_EDGE0) {
+  if (which >= PPRHIP_LIFT_PART_SIZES && which <= PPRHIP_LIFT_PART_GROUP_SLICE0) {
     if (!lift->have_part) {
       try {
         PPRHIP_TRY(build_part_layout(lift->n, lift->m, H.in_rp.data(), H.in_ci.data(), H.nz_rows.data(),
@@ -630,18 +687,20 @@ int pprhip_lift_array(const pprhip_lift_t* lift, int which, const void** data_ou
         set_error("pprhip_lift_array: out of host memory");
         return PPRHIP_ERR_OOM;
       }
+      lift->part_sizes[0] = lift->part.n_groups;
+      lift->part_sizes[1] = lift->part.n_slices;
+      lift->part_sizes[2] = lift->part.n_pieces;
+      lift->part_sizes[3] = lift->part.n_step4;
       lift->have_part = true;
     }
     const HostPartLayout& L = lift->part;
     switch (which) {
-      case PPRHIP_LIFT_PART_BASES: return give(L.chunk_base, sizeof L.chunk_base + sizeof L.seg_base);
-      case PPRHIP_LIFT_PART_COL_IDX: return PPRHIP_LIFT_VEC(L.ci);
-      case PPRHIP_LIFT_PART_FLAGS: return PPRHIP_LIFT_VEC(L.flags);
-      case PPRHIP_LIFT_PART_CHUNK_STARTS: return PPRHIP_LIFT_VEC(L.chunk_starts);
-      case PPRHIP_LIFT_PART_TILE_SEG0: return PPRHIP_LIFT_VEC(L.tile_seg0);
-      case PPRHIP_LIFT_PART_TILE_MASK: return PPRHIP_LIFT_VEC(L.tile_mask);
-      case PPRHIP_LIFT_PART_TILE_CROSS: return PPRHIP_LIFT_VEC(L.tile_cross);
-      case PPRHIP_LIFT_PART_TILE_EDGE0: return PPRHIP_LIFT_VEC(L.tile_edge0);
+      case PPRHIP_LIFT_PART_SIZES: return give(lift->part_sizes, sizeof lift->part_sizes);
+      case PPRHIP_LIFT_PART_IDX: return PPRHIP_LIFT_VEC(L.idx);
+      case PPRHIP_LIFT_PART_SLICE_OFF: return PPRHIP_LIFT_VEC(L.slice_off);
+      case PPRHIP_LIFT_PART_DST: return PPRHIP_LIFT_VEC(L.dst);
+      case PPRHIP_LIFT_PART_ROW_PIECE0: return PPRHIP_LIFT_VEC(L.row_piece0);
+      case PPRHIP_LIFT_PART_GROUP_SLICE0: return PPRHIP_LIFT_VEC(L.group_slice0);
       default: break;
     }
   }

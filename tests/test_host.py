@@ -214,67 +214,72 @@ def test_index_merge_large_runs_on_all_threads(pkg):
 
 
 # ------------------------------------------------------------------ graph lift, host half (row a11; PPR.java:136-152)
-def _part_expected(n, m, in_rp, in_ci, nz_rows, chunk=512, parts=8, tile=64):
-    """The source-partitioned copy of the in-CSR (engine_internal.hpp: HostPartLayout) restated with numpy: in-edges in
-    row order, stably grouped by partition - of the source id (id & 7) for rows of more than 16 in-edges, of the row's
-    ordinal for the shorter ones -, every partition padded to whole chunks; a segment = the edges of one row inside one
-    partition."""
+def _part_expected(n, m, in_rp, in_ci, nz_rows, parts=8, whole=16, piece_max=64, group=256, quads=16):
+    """The source-partitioned copy of the in-CSR (engine_internal.hpp: HostPartLayout, a sliced ELL) restated with numpy
+    sorts: a row's in-edges are stably grouped by partition - of the source id (id & 7) for rows of more than 16 in-edges,
+    of the row's ordinal for the shorter ones -, every (row, partition) segment is cut into pieces of <= 64 edges,
+    numbered row by row; the pieces of 256 consecutive rows in one partition, sorted by (length descending, ordinal),
+    fill slices of sixteen; a slice stores its pieces' sources step-major, four edges per quad and step."""
     indeg = np.diff(in_rp).astype(np.int64)
     n_nz = nz_rows.size
-    n_tiles = (n_nz + tile - 1) // tile
+    n_groups = (n_nz + group - 1) // group
     row_of_edge = np.repeat(np.arange(n, dtype=np.int64), indeg)
     ordinal = np.cumsum(indeg > 0) - 1                    # node -> row ordinal
+    j_of_edge = ordinal[row_of_edge]
     part = in_ci.astype(np.int64) & (parts - 1)
-    short = indeg[row_of_edge] <= 16                     # rows of <= 16 in-edges stay whole, in the partition of their ordinal
-    part[short] = ordinal[row_of_edge[short]] & (parts - 1)
-    perm = np.argsort(part, kind="stable")
-    counts = np.bincount(part, minlength=parts)
-    chunk_base = np.zeros(parts + 1, dtype=np.int64)
-    chunk_base[1:] = np.cumsum((counts + chunk - 1) // chunk)
-    n_chunks = int(chunk_base[-1])
-    ci = np.zeros((n_chunks + 1) * chunk, dtype=np.int32)
-    edge_lo = np.zeros(parts + 1, dtype=np.int64)
-    edge_lo[1:] = np.cumsum(counts)
-    pos = np.empty(m, dtype=np.int64)                      # position of every (grouped) edge in the padded copy
-    for p in range(parts):
-        pos[edge_lo[p]:edge_lo[p + 1]] = chunk_base[p] * chunk + np.arange(counts[p])
-    ci[pos] = in_ci[perm]
-    rows_g = ordinal[row_of_edge[perm]]
-    key = part[perm] * (n_nz + 1) + rows_g
+    short = indeg[row_of_edge] <= whole
+    part[short] = j_of_edge[short] & (parts - 1)
+    # edges in (row, partition, CSR position) order
+    perm = np.lexsort((np.arange(m), part, j_of_edge))
+    e_row, e_part, e_src = j_of_edge[perm], part[perm], in_ci[perm]
+    seg_key = e_row * parts + e_part
     start = np.ones(m, dtype=bool)
-    start[1:] = key[1:] != key[:-1]
-    seg_pos = pos[start]                                   # first edge of every segment, in global segment order
-    seg_part, seg_row = part[perm][start], rows_g[start]
-    seg_len = np.diff(np.append(np.nonzero(start)[0], m))
-    seg_last = seg_pos + seg_len - 1
-    bits = np.zeros((n_chunks + 1) * chunk, dtype=np.uint8)
-    bits[seg_pos] = 1
-    flags = np.packbits(bits, bitorder="little")
-    cs = np.zeros(n_chunks + 1, dtype=np.uint32)
-    cs[1:] = np.cumsum(np.bincount(seg_pos // chunk, minlength=n_chunks)[:n_chunks])
-    seg_base = np.zeros(parts + 1, dtype=np.int64)
-    seg_base[1:] = np.cumsum(np.bincount(seg_part, minlength=parts))
-    part_end = chunk_base[:-1] * chunk + counts            # one past the last edge of each partition
-    cross_b = (seg_pos // chunk != seg_last // chunk) | ((seg_last + 1) % chunk == 0) | (seg_last + 1 == part_end[seg_part])
-    tile_seg0 = np.zeros((parts, n_tiles + 1), dtype=np.uint32)
-    tile_edge0 = np.zeros((parts, n_tiles + 1), dtype=np.uint64)
-    tile_mask = np.zeros((parts, n_tiles), dtype=np.uint64)
-    tile_cross = np.zeros((parts, n_tiles), dtype=np.uint64)
+    start[1:] = seg_key[1:] != seg_key[:-1]
+    seg_first = np.nonzero(start)[0]
+    seg_len = np.diff(np.append(seg_first, m))
+    seg_row, seg_part = e_row[seg_first], e_part[seg_first]
+    seg_pieces = (seg_len + piece_max - 1) // piece_max
+    n_pieces = int(seg_pieces.sum())
+    # pieces, in ordinal order = (row, partition, position)
+    pc_seg = np.repeat(np.arange(seg_len.size), seg_pieces)
+    pc_k = np.arange(n_pieces) - np.repeat(np.cumsum(seg_pieces) - seg_pieces, seg_pieces)
+    pc_len = np.minimum(piece_max, seg_len[pc_seg] - pc_k * piece_max)
+    pc_first = seg_first[pc_seg] + pc_k * piece_max        # first edge (position in the sorted edge list)
+    pc_row, pc_part = seg_row[pc_seg], seg_part[pc_seg]
+    row_piece0 = np.zeros(n_nz + 1, dtype=np.uint32)
+    row_piece0[1:] = np.cumsum(np.bincount(pc_row, minlength=n_nz))
+    # slices: pieces by (partition, group, length descending, ordinal)
+    order = np.lexsort((np.arange(n_pieces), -pc_len, pc_row // group, pc_part))
+    cell = pc_part[order] * n_groups + pc_row[order] // group
+    cell_start = np.ones(n_pieces, dtype=bool)
+    cell_start[1:] = cell[1:] != cell[:-1]
+    cell_first = np.nonzero(cell_start)[0]
+    in_cell = np.arange(n_pieces) - np.repeat(cell_first, np.diff(np.append(cell_first, n_pieces)))
+    head = in_cell % quads == 0                            # first (longest) piece of every slice
+    slice_of = np.cumsum(head) - 1
+    n_slices = int(head.sum())
+    w4 = (pc_len[order][head] + 3) // 4
+    slice_off = np.zeros(n_slices + 1, dtype=np.uint32)
+    slice_off[1:] = np.cumsum(w4)
+    n_step4 = int(slice_off[-1])
+    group_slice0 = np.zeros((parts, n_groups + 1), dtype=np.uint32)
+    sl_cell = cell[head]
+    per_cell = np.bincount(sl_cell, minlength=parts * n_groups)
+    group_slice0_flat = np.concatenate([[0], np.cumsum(per_cell)])
     for p in range(parts):
-        sel = seg_part == p
-        r = seg_row[sel]
-        # segments of p among the rows before 64 t
-        before = np.searchsorted(r, np.arange(n_tiles + 1) * tile, side="left")
-        tile_seg0[p] = seg_base[p] + before
-        ends = np.append(seg_pos[sel], part_end[p])
-        tile_edge0[p] = ends[before]
-        bit = np.uint64(1) << (r % tile).astype(np.uint64)
-        np.bitwise_or.at(tile_mask[p], r // tile, bit)
-        c = cross_b[sel]
-        np.bitwise_or.at(tile_cross[p], r[c] // tile, bit[c])
-    return dict(part_bases=np.concatenate([chunk_base, seg_base]).astype(np.uint32), part_ci=ci, part_flags=flags,
-                part_chunk_starts=cs, part_tile_seg0=tile_seg0.ravel(), part_tile_mask=tile_mask.ravel(),
-                part_tile_cross=tile_cross.ravel(), part_tile_edge0=tile_edge0.ravel())
+        group_slice0[p] = group_slice0_flat[p * n_groups:(p + 1) * n_groups + 1]
+    dst = np.full(n_slices * quads, n_pieces, dtype=np.uint32)
+    quad = in_cell % quads
+    dst[slice_of * quads + quad] = order
+    idx = np.full(n_step4 * 64, n, dtype=np.int32)
+    # every edge of every piece: position e inside the piece -> idx[(off + e // 4) * 64 + quad * 4 + e % 4]
+    lens = pc_len[order]
+    e_in = np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens)
+    base = np.repeat(slice_off[:-1].astype(np.int64)[slice_of] * 64 + quad * 4, lens)
+    idx[base + (e_in // 4) * 64 + e_in % 4] = e_src[np.repeat(pc_first[order], lens) + e_in]
+    return dict(part_sizes=np.array([n_groups, n_slices, n_pieces, n_step4], dtype=np.uint64), part_idx=idx,
+                part_slice_off=slice_off, part_dst=dst, part_row_piece0=row_piece0,
+                part_group_slice0=group_slice0.ravel())
 
 
 def _lift_expected(h, width=393216, chunk=512, max_windows=16):
@@ -321,7 +326,7 @@ def _lift_expected(h, width=393216, chunk=512, max_windows=16):
     np.bitwise_or.at(cross, j >> 6, np.uint64(1) << (j & 63).astype(np.uint64))
     exp = dict(new2old=new2old, old2new=old2new, out_rp=out_rp, out_ci=out_ci, in_rp=in_rp, in_ci=in_ci, nz_rows=nz_rows,
                zin_rows=zin_rows, flags=flags, chunk_starts=chunk_starts, cross=cross)
-    exp.update(_part_expected(n, m, in_rp, in_ci, nz_rows, chunk))
+    exp.update(_part_expected(n, m, in_rp, in_ci, nz_rows))
     n_src = int(np.nonzero(outdeg > 0)[0].max()) + 1 if (outdeg > 0).any() else 0
     S = (n_src + width - 1) // width
     if S > max_windows:

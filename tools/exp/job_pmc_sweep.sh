@@ -16,7 +16,7 @@ f = glob.glob("/tmp/ps_%s/**/*counter_collection.csv" % sys.argv[1], recursive=T
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pprhip::", "")
-    if k.startswith(("k_dense_edges_b", "k_dense_edges_q", "k_dense_apply_batch")):
+    if k.startswith(("k_dense_edges_b", "k_dense_edges_ell", "k_dense_apply_batch")):
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc:
     print("parts=%s" % sys.argv[2], k, {c: round(sum(v) / len(v), 1) for c, v in acc[k].items()}, flush=True)
