@@ -231,16 +231,15 @@ enum {
   PPRHIP_LIFT_SLICED_CHUNK_STARTS = 15, /* uint32[] */
   PPRHIP_LIFT_SEG_ROW = 16,          /* uint32[segments]: row ordinal */
   PPRHIP_LIFT_SEG_OFF = 17,          /* uint32[segments]: first edge */
-  /* the source-partitioned copy of the in-CSR the batched sweep walks, a sliced ELL (built when first asked for): 8
-   * partitions by source id & 7 (rows of <= 16 in-edges whole, in the partition of their ordinal); a row's edges in a
-   * partition are cut into pieces of <= 64 edges, numbered row by row; the pieces of 256 consecutive rows in one
-   * partition, sorted by length, sit sixteen to a slice */
-  PPRHIP_LIFT_PART_SIZES = 18,        /* uint64[4]: row groups, slices, pieces, index steps (of 4 edges x 16 pieces) */
-  PPRHIP_LIFT_PART_IDX = 19,          /* int32[steps * 64]: [step][piece of the slice][4] source ids, padding = n */
-  PPRHIP_LIFT_PART_SLICE_OFF = 20,    /* uint32[slices + 1]: first index step of every slice */
-  PPRHIP_LIFT_PART_DST = 21,          /* uint32[slices * 16]: piece ordinal of every quad, = pieces for an empty one */
-  PPRHIP_LIFT_PART_ROW_PIECE0 = 22,   /* uint32[rows + 1]: first piece ordinal of every row with in-edges */
-  PPRHIP_LIFT_PART_GROUP_SLICE0 = 23  /* uint32[8][groups + 1]: first slice of the partition among the groups >= g */
+  /* the row-panel copy of the in-CSR the batched sweep walks (built when first asked for): panels of 1024 consecutive
+   * rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more than 32 768 edges is cut into parts
+   * of equal edge counts; every part (item) padded to whole turns of 1024 edges with (n, 0) */
+  PPRHIP_LIFT_PANEL_SIZES = 18,       /* uint64[4]: panels, items, partial lines, edges with padding */
+  PPRHIP_LIFT_PANEL_SRC = 19,         /* int32[edges]: sources, padding = n */
+  PPRHIP_LIFT_PANEL_ROW = 20,         /* uint16[edges]: row ordinal - first ordinal of the panel */
+  PPRHIP_LIFT_PANEL_ITEMS = 21,       /* uint32[items][8]: first edge / 1024, turns, panel, first partial line, parts of the panel, 0, 0, 0 */
+  PPRHIP_LIFT_PANEL_ITEM0 = 22,       /* uint32[panels + 1]: first item of every panel */
+  PPRHIP_LIFT_PANEL_ROW_PIECE0 = 23   /* uint32[rows + 1]: first partial line of every row with in-edges */
 };
 int pprhip_graph_lift_host(uint32_t n, uint64_t m, const uint32_t* out_row_ptr, const int32_t* out_col_idx,
                            const uint32_t* in_row_ptr, const int32_t* in_col_idx, int threads,

@@ -831,12 +831,11 @@ int build_batch(pprhip_graph* P) {
   return PPRHIP_OK;
 }
 
-// Source-partitioned copy of the in-CSR for the batched forward sweep (engine_internal.hpp: HostPartLayout).  The
-// internal-order column indices live on the device only (the lift's host arrays are gone by now): they come back once,
-// the host builds the copy on all its threads, and it goes up again - R-MAT 22: 0.27 GB down, ~0.1 s of host work,
-// 0.35 GB up, once per handle (the copy stays when the batch workspaces are released).
-// PPRHIP_SWEEP_PARTS=0 / 1 switches it off / on for any size (tests run small graphs both ways); by default graphs
-// from 2^22 edges on use it - below that the whole contribution array fits every L2 anyway.
+// Row-panel copy of the in-CSR for the batched forward sweep (engine_internal.hpp: HostPartLayout).  The internal-order
+// column indices live on the device only (the lift's host arrays are gone by now): they come back once, the host builds
+// the copy on all its threads, and it goes up again, once per handle (the copy stays when the batch workspaces are
+// released).  PPRHIP_SWEEP_PANELS=0 / 1 switches it off / on for any size (tests run small graphs both ways); by default
+// graphs from 2^22 edges on use it - below that the whole contribution array fits every L2 anyway.
 static int ensure_part_layout(pprhip_graph* P) {
   if (P->pl) return PPRHIP_OK;
   HostPartLayout H;
@@ -846,36 +845,36 @@ static int ensure_part_layout(pprhip_graph* P) {
     RawVec<int32_t> ci((size_t)P->m);
     PPRHIP_CHECK_HIP(hipMemcpy(ci.data(), P->in_ci, sizeof(int32_t) * (size_t)P->m, hipMemcpyDeviceToHost));
     PPRHIP_TRY(build_part_layout(P->n, P->m, P->h_in_rp.data(), ci.data(), P->h_nz_rows.data(), P->n_nz, 0, H));
-    L->h_group_slice0 = std::move(H.group_slice0);
+    L->h_panel_item0 = std::move(H.panel_item0);
   } catch (const std::bad_alloc&) {
-    set_error("source-partitioned sweep layout: out of host memory");
+    set_error("row-panel sweep layout: out of host memory");
     return PPRHIP_ERR_OOM;
   }
-  if (!H.n_pieces || !H.n_slices) return PPRHIP_OK;  // (ordinals beyond 32 bits: the row-major sweep stays)
+  if (!H.n_pieces || !H.n_items) return PPRHIP_OK;  // (ordinals beyond 32 bits: the row-major sweep stays)
   auto up = [&](void** d, const void* h, size_t bytes) -> int {
     PPRHIP_TRY(alloc_dev(d, bytes));
     PPRHIP_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
     return PPRHIP_OK;
   };
   int rc = PPRHIP_OK;
-  if ((rc = up((void**)&L->idx, H.idx.data(), sizeof(int32_t) * H.idx.size())) ||
-      (rc = up((void**)&L->slice_off, H.slice_off.data(), sizeof(uint32_t) * H.slice_off.size())) ||
-      (rc = up((void**)&L->dst, H.dst.data(), sizeof(uint32_t) * H.dst.size())) ||
+  if ((rc = up((void**)&L->src, H.src.data(), sizeof(int32_t) * H.src.size())) ||
+      (rc = up((void**)&L->rloc, H.rloc.data(), sizeof(uint16_t) * H.rloc.size())) ||
+      (rc = up((void**)&L->items, H.items.data(), sizeof(PanelItem) * H.items.size())) ||
       (rc = up((void**)&L->row_piece0, H.row_piece0.data(), sizeof(uint32_t) * H.row_piece0.size()))) {
-    void* ptrs[] = {L->idx, L->slice_off, L->dst, L->row_piece0};
+    void* ptrs[] = {L->src, L->rloc, L->items, L->row_piece0};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     return rc;
   }
-  L->n_groups = H.n_groups;
-  L->n_slices = H.n_slices;
+  L->n_panels = H.n_panels;
+  L->n_items = H.n_items;
   L->n_pieces = H.n_pieces;
   P->pl = L.release();
   return PPRHIP_OK;
 }
 
 static bool want_part_layout(const pprhip_graph* P) {
-  const char* e = getenv("PPRHIP_SWEEP_PARTS");
+  const char* e = getenv("PPRHIP_SWEEP_PANELS");
   return e ? e[0] == '1' : P->m >= (1ull << 22);
 }
 
@@ -885,17 +884,17 @@ static int build_part_layout_device(pprhip_graph* P) {
   if (!P->pl) return PPRHIP_OK;
   const size_t bytes = sizeof(double) * ((size_t)P->pl->n_pieces + 1) * kBatch;
   PPRHIP_TRY(alloc_dev((void**)&P->part_acc, bytes));
-  // (only the line behind the last piece has to be zero: the apply kernel reads it in place of pieces a row does not have)
+  // (only the line behind the last piece has to be zero: the apply kernel reads it in place of lines a row does not have)
   PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_acc + (size_t)P->pl->n_pieces * kBatch, 0, sizeof(double) * kBatch, P->stream));
-  PPRHIP_TRY(alloc_dev((void**)&P->part_ctr, sizeof(uint32_t) * kParts * kPartCtrStride));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_ctr, 0, sizeof(uint32_t) * kParts * kPartCtrStride, P->stream));
-  std::memset(P->part_ctr_next, 0, sizeof P->part_ctr_next);
+  PPRHIP_TRY(alloc_dev((void**)&P->part_ctr, 128));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_ctr, 0, 128, P->stream));
+  P->part_ctr_next = 0;
   return PPRHIP_OK;
 }
 
 void free_part_layout(pprhip_graph* P) {
   if (!P->pl) return;
-  void* ptrs[] = {P->pl->idx, P->pl->slice_off, P->pl->dst, P->pl->row_piece0};
+  void* ptrs[] = {P->pl->src, P->pl->rloc, P->pl->items, P->pl->row_piece0};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete P->pl;

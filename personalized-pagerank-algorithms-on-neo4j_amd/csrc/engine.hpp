@@ -95,23 +95,15 @@ struct SlicedLayout {
   int plan_B = -1;
 };
 
-// The source-partitioned copy of the in-CSR on the device, a sliced ELL (engine_internal.hpp: HostPartLayout; batched
-// forward sweep).
+// The row-panel copy of the in-CSR on the device (engine_internal.hpp: HostPartLayout; batched forward sweep).
 struct PartLayout {
-  int32_t* idx = nullptr;          // [n_step4 * 64] source ids: [step][quad][4]; padding = zero_id (= n)
-  uint32_t* slice_off = nullptr;   // [n_slices + 1] first index step of every slice
-  uint32_t* dst = nullptr;         // [n_slices * 16] partial line of every quad's piece (n_pieces: none)
+  int32_t* src = nullptr;          // [n_edges] sources, item-major; padding = zero_id (= n)
+  uint16_t* rloc = nullptr;        // [n_edges] row ordinal inside the panel
+  PanelItem* items = nullptr;      // [n_items]
   uint32_t* row_piece0 = nullptr;  // [n_nz + 1] a row's partial lines are [row_piece0[j], row_piece0[j + 1])
-  uint32_t n_groups = 0, n_slices = 0, n_pieces = 0;
-  std::vector<uint32_t> h_group_slice0;  // host: [kParts][n_groups + 1], the Gauss-Seidel blocks' slice windows
+  uint32_t n_panels = 0, n_items = 0, n_pieces = 0;
+  std::vector<uint32_t> h_panel_item0;  // host: [n_panels + 1], the Gauss-Seidel blocks' item windows
 };
-// what one launch of the partitioned edge kernel walks: per partition the slices [lo, hi) (the rows of one
-// Gauss-Seidel block: whole groups of kGroupRows rows)
-struct PartWindows {
-  uint32_t lo[kParts], hi[kParts];
-  uint32_t base[kParts];  // value of the partition's slice counter (part_ctr) when the launch starts
-};
-constexpr int kPartCtrStride = 32;  // uint32 per partition counter: a line each
 
 enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
 
@@ -379,10 +371,10 @@ struct pprhip_graph {
   int c8cur = 0;
   pprhip::PartLayout* pl = nullptr;  // source-partitioned copy of the in-CSR (forward batched sweeps), with the batch state
   double* part_acc = nullptr;        // [pieces + 1][kBatch] partial row sums (the line behind the last stays zero)
-  // the partitions' slice queues: the waves of a launch take slices in turn (atomicAdd); the counters only ever grow,
-  // the host keeps what they will hold when the next launch starts (every wave's last, failing take included)
-  uint32_t* part_ctr = nullptr;      // [kParts * kPartCtrStride]
-  uint32_t part_ctr_next[pprhip::kParts] = {0};
+  // the items' queue: the workgroups of a launch take items in turn (atomicAdd); the counter only ever grows, the host
+  // keeps what it will hold when the next launch starts (every workgroup's last, failing take included)
+  uint32_t* part_ctr = nullptr;
+  uint32_t part_ctr_next = 0;
   double* acc8 = nullptr;      // [row ordinal][kBatch] row sums
   int acc8_dir = 0;            // layout the row sums were last written in (0 forward, 1 backward)
   int32_t* zin_rows = nullptr;  // rows without in-edges

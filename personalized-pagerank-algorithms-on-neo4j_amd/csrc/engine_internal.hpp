@@ -201,35 +201,30 @@ struct HostLift {
   std::vector<uint8_t> sl_flags;
   std::vector<uint32_t> sl_chunk_starts, seg_row, seg_off;
 };
-// Source-partitioned copy of the in-CSR for the batched forward sweep (rounds 5-6).  Why: a batched gather moves one
-// 128-byte line c8[u][0..15] per in-edge, and the sweep is bound by the lines that leave L2 (46 M of 67 M per sweep on
-// R-MAT 22, 52-55 G/s); every XCD has an L2 of its own and all eight held the same hottest 32 K lines.  Here the edges
-// are grouped by part_of(source) and workgroup b of the edge kernel walks partition b % 8, i.e. the workgroups of XCD x
-// only ever gather lines of partition x (workgroups are dealt to the XCDs round-robin: tools/micro/xcd_affine_rate.hip
-// reads XCC_ID), so eight L2s hold eight different hot sets.
-// Round 5 kept every partition as a chunked CSR whose "rows" were (row, partition) segments: a segment ended every 8.8
-// edges, and flags, scans and mid-chunk stores made the edge kernel issue-bound (profiles/r05_quad_kernel_study.txt).
-// Round 6: a sliced ELL.  A row's edges in one partition (its SEGMENT; rows of <= kPartWholeRow in-edges stay whole in
-// the partition of their ordinal) are cut into PIECES of at most kPieceMax edges.  A row's pieces are numbered
-// consecutively (partition ascending, then position), pieces of all rows in row order: piece o's sum is the partial
-// line part_acc[o], and the apply kernel adds the lines [row_piece0[j], row_piece0[j + 1]) of row j - a stream.  The
-// pieces of partition p among the rows of GROUP g (kGroupRows consecutive ordinals: the Gauss-Seidel blocks' boundaries
-// are multiples of it) are sorted by (length descending, ordinal ascending) and packed sixteen at a time into SLICES:
-// one quad of lanes per piece, every quad walking its own piece in step, the slice as wide as its first (longest)
-// piece rounded up to four edges; shorter pieces and the empty quads of a cell's last slice are padded with zero_id,
-// the id of a contribution line that is always zero.  No row-start flags, no scans, no stores before a piece's end.
-// Slices are numbered partition-major, then by group, then in their cell's order; slice s keeps its indices at
-// idx[(off + j4) * 64 + 4 * q + i] = source of edge 4 * j4 + i of its q-th piece, j4 < w4.
+// Row-panel copy of the in-CSR for the batched forward sweep (round 6).  Why: a batched gather moves one 128-byte line
+// c8[u][0..15] per in-edge, a CU keeps ~256 lines in flight, and a line beyond L2 holds its slot four times as long as
+// one that hits (profiles/r06_ell_sweep_study.txt): the sweep is bound by the NUMBER of line requests and by how many of
+// them leave L2.  Rounds 5 and 6 tried to make the requests cheaper (one L2 per partition of the sources); this layout
+// makes them fewer.  The rows with in-edges are cut into PANELS of kPanelRows consecutive ordinals whose sixteen-column
+// sums fit a CU's LDS (128 KB); a panel's in-edges are sorted by (source, row), so that the edges of one source stand
+// together: the quads of a wave that meet the same source in one instruction share one request, and the 27 K hub rows
+// that hold half of R-MAT 22's in-edges ask for each line once per panel instead of once per row (4.0 x fewer requests
+// there, 1.5 x in the other rows).  The sums go to LDS with ds_add_f64 (rotated by the row, so that sixteen quads on
+// sixteen rows spread over the banks) and leave it once, as whole lines.
+// A panel of more than kItemEdges edges is cut into S parts of equal edge counts (ITEMS: the hub panels of R-MAT 22 have
+// up to 10 M edges); each part sums into LDS of its own and writes partial lines: row j's lines are
+// [row_piece0[j], row_piece0[j] + S), part k at + k - the apply kernel adds them (most rows: one line, which IS the sum).
+// Every item's edges are padded to whole turns of kPanelStep with (zero_id, row 0): zero_id = n names a contribution line
+// that is always zero.
 struct HostPartLayout {
-  uint32_t n_nz = 0, n_groups = 0;           // rows with in-edges, groups of kGroupRows of them
-  uint32_t n_slices = 0, n_pieces = 0;
-  uint64_t n_step4 = 0;                      // sum of the slices' w4
-  uint32_t zero_id = 0;                      // = n: padding index
-  RawVec<int32_t> idx;                       // [n_step4 * 64]
-  std::vector<uint32_t> slice_off;           // [n_slices + 1] first step4 of every slice (w4 = difference)
-  std::vector<uint32_t> dst;                 // [n_slices * 16] piece ordinal of every quad; n_pieces for an empty quad
+  uint32_t n_nz = 0, n_panels = 0, n_items = 0, n_pieces = 0;
+  uint64_t n_edges = 0;                      // with padding
+  uint32_t zero_id = 0;                      // = n
+  RawVec<int32_t> src;                       // [n_edges] sources, item-major, inside an item sorted by (source, row)
+  RawVec<uint16_t> rloc;                     // [n_edges] row ordinal - first ordinal of the panel
+  std::vector<PanelItem> items;              // [n_items], panel-major
+  std::vector<uint32_t> panel_item0;         // [n_panels + 1]
   std::vector<uint32_t> row_piece0;          // [n_nz + 1]
-  std::vector<uint32_t> group_slice0;        // [kParts][n_groups + 1] first slice of p among the groups >= g
 };
 // in_rp / in_ci: the internal-order in-CSR; nz_rows: its non-empty rows, ascending (row ordinal -> node)
 int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,

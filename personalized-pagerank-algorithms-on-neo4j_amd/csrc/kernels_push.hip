@@ -828,136 +828,153 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_dense_edges_ell (round 6): the batched edge kernel over the source-partitioned sliced ELL (engine_internal.hpp:
-// HostPartLayout).  Workgroup b walks partition b % kParts, so the workgroups of one XCD only ever gather contribution
-// lines of one partition and the eight L2s hold eight different hot sets.  A wave takes a SLICE: sixteen pieces of
-// rows, one per quad of lanes, lane t of a quad holding the slots 2t, 2t+1, 8+2t, 8+2t+1 of the running sum: two 16-byte
-// loads per edge, each of which reads one contiguous 64-byte half of the line across the quad.  Every quad walks its own piece in step with the others - the slice is as wide as its longest
-// piece, shorter ones gather the all-zero line `zero_id` - so there are no row-start flags, no scans and no stores
-// before the piece's end: per four edges of a quad one 16-byte index load (the quad's lanes read the same four ids),
-// per edge one shift, two loads, four adds.  A piece's sum is one 128-byte line part_acc[piece], written with plain
-// stores; k_dense_apply_batch<true> adds a row's lines.  (Round 5's form of this copy kept row-start flags per edge and
-// was issue-bound: ~1 900 instructions per 512 edges, profiles/r05_quad_kernel_study.txt; this loop has ~35 per 64.)
+// k_dense_edges_panel (round 6): the batched edge kernel over the row-panel copy (engine_internal.hpp: HostPartLayout).
+// A workgroup takes an ITEM - a panel of kPanelRows rows, or one part of a hub panel - and sums its edges into
+// accumulators in LDS: acc[row][column], 128 KB.  The item's edges are sorted by source; a quad of lanes takes four
+// consecutive edges per turn (lane t of a quad holds the columns 2t, 2t+1, 8+2t, 9+2t: two 16-byte loads per edge, each
+// one contiguous 64-byte half of the line across the quad), the 256 quads of the workgroup 1 024 consecutive edges, so
+// the edges of one source meet in the same instructions and share their line requests (a CU keeps ~256 of them in
+// flight: profiles/r06_ell_sweep_study.txt).  Sums land with ds_add_f64; a row's sixteen columns are stored rotated by
+// the row ordinal, so that the quads of an instruction - sixteen rows, the same column - spread over the banks.
+// At the end the rows leave LDS as whole 128-byte lines: part_acc[line0 + row * stride], which k_dense_apply_batch<true>
+// adds up per row (stride = parts of the panel; 1 for all but the hub panels).  Rows outside [j_lo, j_hi) - the
+// Gauss-Seidel block of the launch, whose bounds may cut a panel - are left out: their edges gather the zero line.
+// Items are handed out by a counter that only ever grows (`base` = its value at launch).
 // ------------------------------------------------------------------------------------------------
-constexpr int kEllThreads = 256;
+constexpr int kPanelThreads = 1024;
+constexpr int kPanelLdsBytes = (int)(kPanelRows * kBatch * sizeof(double));
+static_assert(kPanelStep == kPanelThreads / 4 * 4 && kPanelRows == (uint32_t)kPanelThreads, "one row and four edges per quad");
 
 template <bool WIDE>
-__device__ __forceinline__ const double2* ell_line(const double* __restrict__ cB, uint32_t u, uint32_t lane_off) {
+__device__ __forceinline__ const double2* panel_line(const double* __restrict__ cB, uint32_t u, uint32_t lane_off) {
   // (the contribution array is below 4 GB unless WIDE: a 32-bit byte offset next to the uniform base address)
   if (WIDE) return reinterpret_cast<const double2*>(reinterpret_cast<const char*>(cB) + (((size_t)u << 7) | lane_off));
   return reinterpret_cast<const double2*>(reinterpret_cast<const char*>(cB) + ((u << 7) | lane_off));
 }
 
-// Slices are handed out by a counter per partition (the waves of a launch take the next one as they finish theirs:
-// slices differ in width by a factor of sixteen, and the queries that work beside the sweeps slow some CUs down); the
-// counter only ever grows, W.base holds its value at launch, and a wave asks for its next slice before it walks the one
-// it has, so the atomic's round trip is hidden.
-__device__ __forceinline__ uint32_t ell_take(uint32_t* ctr) {
-  uint32_t v = 0;
-  if (lane_id() == 0) v = atomicAdd(ctr, 1u);
-  return v;
+__device__ __forceinline__ void panel_add(double* acc, uint32_t r, uint32_t t, const double2& x, const double2& y) {
+  double* row = acc + r * (uint32_t)kBatch;
+  atomic_add_noret(&row[(2u * t + r) & 15u], x.x);
+  atomic_add_noret(&row[(2u * t + 1u + r) & 15u], x.y);
+  atomic_add_noret(&row[(8u + 2u * t + r) & 15u], y.x);
+  atomic_add_noret(&row[(9u + 2u * t + r) & 15u], y.y);
 }
 
-// one edge's two half lines; COLD_NT: ids from `hot` on are loaded non-temporal, so that the many lines gathered
-// once or twice per sweep do not push the few gathered thousands of times out of L2
-template <bool WIDE, bool COLD_NT>
-__device__ __forceinline__ void ell_edge(const double* __restrict__ cB, uint32_t u, uint32_t lane_off, uint32_t hot,
-                                         double2& x, double2& y) {
-#ifdef PPRHIP_TEST_HOOKS
-  if (!COLD_NT) u &= hot;  // (measurement, PPRHIP_ELL_MASK: every gather inside the first ids - the kernel's own ceiling)
-#endif
-  const double2* l = ell_line<WIDE>(cB, u, lane_off);
-  if (COLD_NT && u >= hot) {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    const v2d* ln = reinterpret_cast<const v2d*>(l);
-    const v2d a = __builtin_nontemporal_load(ln), b = __builtin_nontemporal_load(ln + 4);
-    x = make_double2(a.x, a.y);
-    y = make_double2(b.x, b.y);
-  } else {
-    x = l[0];
-    y = l[4];
-  }
-}
-
-template <bool WIDE, bool COLD_NT, int UNROLL>
-__global__ __launch_bounds__(kEllThreads) void k_dense_edges_ell(const int32_t* __restrict__ idx,
-                                                                 const uint32_t* __restrict__ slice_off,
-                                                                 const uint32_t* __restrict__ dst, PartWindows W,
-                                                                 const double* __restrict__ cB,
-                                                                 double* __restrict__ part_acc, uint32_t n_pieces,
-                                                                 uint32_t* __restrict__ part_ctr, uint32_t hot, uint32_t dbg) {
+template <bool WIDE>
+__global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32_t* __restrict__ src,
+                                                                     const uint16_t* __restrict__ rloc,
+                                                                     const PanelItem* __restrict__ items,
+                                                                     uint32_t item_lo, uint32_t n_items, uint32_t base,
+                                                                     uint32_t* __restrict__ ctr,
+                                                                     const double* __restrict__ cB,
+                                                                     double* __restrict__ part_acc, uint32_t j_lo,
+                                                                     uint32_t j_hi, uint32_t n_nz, uint32_t zero_id,
+                                                                     uint32_t dbg) {
+  extern __shared__ __attribute__((aligned(16))) double acc[];
+  __shared__ uint32_t s_take;
   typedef int v4i __attribute__((ext_vector_type(4)));
-  const int lane = lane_id();
-  const uint32_t q = (uint32_t)lane >> 2, lane_off = ((uint32_t)lane & 3u) * 16u;
-  const uint32_t part = blockIdx.x % (uint32_t)kParts;
-  const uint32_t s_lo = W.lo[part], count = W.hi[part] - s_lo, base = W.base[part];
-  uint32_t* ctr = part_ctr + part * (uint32_t)kPartCtrStride;
-  const uint32_t dbg_stride = (gridDim.x / (uint32_t)kParts) * (blockDim.x >> 6);
-  uint32_t cur = (dbg & 1u) ? (blockIdx.x / (uint32_t)kParts) * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane(wave_id())
-                            : (uint32_t)__builtin_amdgcn_readfirstlane(ell_take(ctr)) - base;
-  while (cur < count) {
-    const uint32_t s = s_lo + cur;
-    const uint32_t nxt = (dbg & 1u) ? cur + dbg_stride + base : ell_take(ctr);
-    const uint32_t off = slice_off[s], w4 = slice_off[s + 1] - off;
-    // the index stream is read once per sweep: non-temporal, so that it does not push gathered lines out of L2
-    const v4i* ip = reinterpret_cast<const v4i*>(idx) + (size_t)off * kSliceQuads + q;
-    const uint32_t o = __builtin_nontemporal_load(&dst[(size_t)s * kSliceQuads + q]);
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    uint32_t j = 0;
-    if (UNROLL == 2) {
-      // eight edges per turn: sixteen gathers in flight per lane
-      for (; j + 2 <= w4; j += 2) {
-        const v4i ix = __builtin_nontemporal_load(ip + (size_t)j * kSliceQuads);
-        const v4i iy = __builtin_nontemporal_load(ip + (size_t)(j + 1) * kSliceQuads);
-        double2 x[8], y[8];
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.x, lane_off, hot, x[0], y[0]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.y, lane_off, hot, x[1], y[1]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.z, lane_off, hot, x[2], y[2]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.w, lane_off, hot, x[3], y[3]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)iy.x, lane_off, hot, x[4], y[4]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)iy.y, lane_off, hot, x[5], y[5]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)iy.z, lane_off, hot, x[6], y[6]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)iy.w, lane_off, hot, x[7], y[7]);
+  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+  const uint32_t tid = threadIdx.x, t = tid & 3u, gq = tid >> 2, lane_off = t * 16u;
+  if (tid == 0) s_take = atomicAdd(ctr, 1u) - base;
+  __syncthreads();
+  uint32_t cur = s_take;
+  while (cur < n_items) {
+    const PanelItem I = items[item_lo + cur];
+    {  // clear the accumulators; the next item is asked for meanwhile
+      double2* a2 = reinterpret_cast<double2*>(acc);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          a0 += x[e].x; a1 += x[e].y; a2 += y[e].x; a3 += y[e].y;
+      for (int k = 0; k < (int)(kPanelRows * kBatch / 2 / kPanelThreads); ++k) a2[(uint32_t)k * kPanelThreads + tid] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();  // (everybody has read s_take)
+    if (tid == 0) s_take = atomicAdd(ctr, 1u) - base;
+    const uint32_t row0 = I.panel * kPanelRows;
+    const uint32_t r_lo = j_lo > row0 ? j_lo - row0 : 0u;
+    const uint32_t r_hi = j_hi > row0 ? min(j_hi - row0, kPanelRows) : 0u;
+    const bool cut = r_lo > 0u || r_hi < min(n_nz - row0, kPanelRows);
+    const v4i* sp = reinterpret_cast<const v4i*>(src + (size_t)I.edge0 * kPanelStep) + gq;
+    const v2u* rp = reinterpret_cast<const v2u*>(rloc + (size_t)I.edge0 * kPanelStep) + gq;
+    // the index streams are read once per sweep: non-temporal, so that they do not push gathered lines out of L2
+    v4i ix = __builtin_nontemporal_load(sp);
+    v2u rx = __builtin_nontemporal_load(rp);
+    for (uint32_t i = 0; i < I.steps; ++i) {
+      v4i nx = ix;
+      v2u nr = rx;
+      if (i + 1 < I.steps) {  // in flight beside the gathers
+        nx = __builtin_nontemporal_load(sp + (size_t)(i + 1) * (kPanelStep / 4));
+        nr = __builtin_nontemporal_load(rp + (size_t)(i + 1) * (kPanelStep / 4));
+      }
+      const uint32_t r0 = rx.x & 0xffffu, r1 = rx.x >> 16, r2 = rx.y & 0xffffu, r3 = rx.y >> 16;
+      uint32_t u0 = (uint32_t)ix.x, u1 = (uint32_t)ix.y, u2 = (uint32_t)ix.z, u3 = (uint32_t)ix.w;
+      if (cut) {
+        if (r0 < r_lo || r0 >= r_hi) u0 = zero_id;
+        if (r1 < r_lo || r1 >= r_hi) u1 = zero_id;
+        if (r2 < r_lo || r2 >= r_hi) u2 = zero_id;
+        if (r3 < r_lo || r3 >= r_hi) u3 = zero_id;
+      }
+#ifdef PPRHIP_TEST_HOOKS
+      if (dbg >> 8) { u0 &= dbg >> 8; u1 &= dbg >> 8; u2 &= dbg >> 8; u3 &= dbg >> 8; }  // (measurement: every gather inside the first ids)
+#endif
+      double2 x0, y0, x1, y1, x2, y2, x3, y3;
+      if (dbg & 1u) {  // (measurement: no gathers)
+        x0 = y0 = make_double2((double)u0, 1.0); x1 = y1 = make_double2((double)u1, 1.0);
+        x2 = y2 = make_double2((double)u2, 1.0); x3 = y3 = make_double2((double)u3, 1.0);
+      } else {
+        const double2* l0 = panel_line<WIDE>(cB, u0, lane_off);
+        const double2* l1 = panel_line<WIDE>(cB, u1, lane_off);
+        const double2* l2 = panel_line<WIDE>(cB, u2, lane_off);
+        const double2* l3 = panel_line<WIDE>(cB, u3, lane_off);
+        x0 = l0[0]; y0 = l0[4]; x1 = l1[0]; y1 = l1[4]; x2 = l2[0]; y2 = l2[4]; x3 = l3[0]; y3 = l3[4];
+      }
+      if (dbg & 2u) {  // (measurement: no LDS sums - one store keeps the loads alive)
+        const double z = ((x0.x + y0.y) + (x1.x + y1.y)) + ((x2.x + y2.y) + (x3.x + y3.y));
+        if (z == 12345.678) acc[tid] = z;
+      } else {
+        panel_add(acc, r0, t, x0, y0);
+        panel_add(acc, r1, t, x1, y1);
+        panel_add(acc, r2, t, x2, y2);
+        panel_add(acc, r3, t, x3, y3);
+      }
+      ix = nx;
+      rx = nr;
+    }
+    __syncthreads();
+    // the rows leave as whole lines: sixteen lanes per row, four rows per wave instruction
+    {
+      const uint32_t s = tid & 15u;
+#pragma unroll 4
+      for (uint32_t r = tid >> 4; r < kPanelRows; r += kPanelThreads / 16) {
+        if (r >= r_lo && r < r_hi && row0 + r < n_nz) {
+          const double v = acc[r * (uint32_t)kBatch + ((s + r) & 15u)];
+          __builtin_nontemporal_store(v, &part_acc[((size_t)I.line0 + (size_t)r * I.stride) * kBatch + s]);
         }
       }
     }
-    if (j < w4) {
-      v4i ix = (dbg & 4u) ? ip[(size_t)j * kSliceQuads] : __builtin_nontemporal_load(ip + (size_t)j * kSliceQuads);
-      for (; j < w4; ++j) {
-        v4i nx = ix;
-        if (j + 1 < w4) nx = (dbg & 4u) ? ip[(size_t)(j + 1) * kSliceQuads] : __builtin_nontemporal_load(ip + (size_t)(j + 1) * kSliceQuads);  // in flight beside the gathers
-        double2 x[4], y[4];
-        if (dbg & 2u) {
-          x[0] = y[0] = make_double2((double)ix.x, 0.0);
-          x[1] = y[1] = make_double2((double)ix.y, 0.0);
-          x[2] = y[2] = make_double2((double)ix.z, 0.0);
-          x[3] = y[3] = make_double2((double)ix.w, 0.0);
-        } else {
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.x, lane_off, hot, x[0], y[0]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.y, lane_off, hot, x[1], y[1]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.z, lane_off, hot, x[2], y[2]);
-        ell_edge<WIDE, COLD_NT>(cB, (uint32_t)ix.w, lane_off, hot, x[3], y[3]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a0 += x[e].x; a1 += x[e].y; a2 += y[e].x; a3 += y[e].y;
-        }
-        ix = nx;
-      }
-    }
-    if (o != n_pieces) {  // (an empty quad of a cell's last slice)
-      typedef double v2d __attribute__((ext_vector_type(2)));
-      v2d* out = reinterpret_cast<v2d*>(reinterpret_cast<char*>(part_acc) + (((size_t)o << 7) | lane_off));
-      v2d lo2, hi2;
-      lo2.x = a0; lo2.y = a1; hi2.x = a2; hi2.y = a3;
-      __builtin_nontemporal_store(lo2, out);
-      __builtin_nontemporal_store(hi2, out + 4);
-    }
-    cur = (uint32_t)__builtin_amdgcn_readfirstlane(nxt) - base;
+    __syncthreads();  // (the accumulators are read; s_take is written)
+    cur = s_take;
   }
+}
+
+// The hub panels' parts: row j of a panel cut into S parts has S partial lines (one per item); this kernel adds them
+// into the first one, so that k_dense_apply_batch<true> reads one line per row (at stride S) whatever the panel.  A lane
+// per (row, column), the S loads of a lane independent of one another: a stream, not a chain.
+__global__ __launch_bounds__(256) void k_panel_reduce(double* __restrict__ part_acc, const uint32_t* __restrict__ row_piece0,
+                                                      uint32_t j_lo, uint32_t j_hi) {
+  const uint32_t j = j_lo + (blockIdx.x * 256u + threadIdx.x) / (uint32_t)kBatch, s = threadIdx.x % (uint32_t)kBatch;
+  if (j >= j_hi) return;
+  const uint32_t base = row_piece0[j], S = row_piece0[j + 1] - base;
+  if (S <= 1) return;
+  const double* p = part_acc + (size_t)base * kBatch + s;
+  double v = 0.0;
+  uint32_t k = 0;
+  for (; k + 8 <= S; k += 8) {
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(p + (size_t)(k + i) * kBatch);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v += x[i];
+  }
+  for (; k < S; ++k) v += __builtin_nontemporal_load(p + (size_t)k * kBatch);
+  part_acc[(size_t)base * kBatch + s] = v;
 }
 
 // k_dense_apply: one thread per non-empty row (plus one for a source without in-edges, which
@@ -1080,8 +1097,8 @@ constexpr int kApplyGroups = 2;  // tiles of kApplyRows rows a workgroup carries
 constexpr int kApplyThreads = 512;  // 8 waves, 2 slots each: few enough slot arguments to stay in SGPRs
 constexpr int kSlotsPerWave = kBatch / (kApplyThreads / 64);
 
-// PART: the row sums arrive as the partial sums of the row's pieces (PartLayout, k_dense_edges_ell): the lines
-// [row_piece0[j], row_piece0[j + 1]) of part_acc, consecutive for consecutive rows - a stream; the line n_pieces is zero.
+// PART: the row sums arrive from k_dense_edges_panel (PartLayout): the lines [row_piece0[j], row_piece0[j + 1]) of
+// part_acc - one line for most rows, one per part of its panel for the hub rows; the line n_pieces is zero.
 template <bool PART>
 __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
                                                             const int32_t* __restrict__ zin_rows, uint32_t n_zin,
@@ -1133,35 +1150,18 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
       const bool in = tl < tile_hi;
       const uint32_t row0 = tl * kApplyRows;
       if (PART) {
+        // a tile lies inside one panel: its rows have the same number S of partial lines, row r of the tile the lines
+        // base + r * S ... (S = 1 for all but the hub panels)
         constexpr int kPer = kApplyRows * kBatch / kApplyThreads;  // rows a thread serves per tile
-        uint32_t pa[kPer], pb[kPer];
-        double x[kPer][4];
-#pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-          const uint32_t j = row0 + ((uint32_t)i * (uint32_t)kApplyThreads + tid) / kBatch;
-          const bool have = in && j < n_nz;
-          pa[i] = have ? row_piece0[j] : 0u;
-          pb[i] = have ? row_piece0[j + 1] : 0u;
-        }
+        const bool any = in && row0 < n_nz;
+        const uint32_t base = any ? row_piece0[row0] : 0u;
+        const uint32_t S = any ? row_piece0[row0 + 1] - base : 0u;
         const uint32_t sl = tid % kBatch;
-        // the first four lines of every row are requested together (most rows have one): rows with fewer read the
-        // all-zero line behind the last piece instead of branching around the load
-#pragma unroll
-        for (int i = 0; i < kPer; ++i)
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            x[i][k] = __builtin_nontemporal_load(&part_acc[(size_t)(pa[i] + k < pb[i] ? pa[i] + k : n_pieces) * kBatch + sl]);
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
-          double v = ((x[i][0] + x[i][1]) + x[i][2]) + x[i][3];
-          for (uint32_t p = pa[i] + 4; p < pb[i]; p += 4) {
-            double y[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              y[k] = __builtin_nontemporal_load(&part_acc[(size_t)(p + k < pb[i] ? p + k : n_pieces) * kBatch + sl]);
-            v = (((v + y[0]) + y[1]) + y[2]) + y[3];
-          }
-          tile[g][((uint32_t)i * (uint32_t)kApplyThreads + tid) / kBatch][sl] = v;
+          const uint32_t r = ((uint32_t)i * (uint32_t)kApplyThreads + tid) / kBatch;
+          // (the parts of a hub panel's rows were added into their first line by k_panel_reduce)
+          tile[g][r][sl] = (any && row0 + r < n_nz) ? __builtin_nontemporal_load(&part_acc[((size_t)base + (size_t)r * S) * kBatch + sl]) : 0.0;
         }
         continue;
       }
@@ -1866,50 +1866,41 @@ static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8
   return PPRHIP_OK;
 }
 
-// PPRHIP_SWEEP_WGS (tuning): workgroups (of four waves) of the partitioned edge kernel per CU; the default fills a CU
-static uint32_t edge_wgs_per_cu() {
-  static const uint32_t v = [] {
-    const char* e = getenv("PPRHIP_SWEEP_WGS");
-    return e ? (uint32_t)std::max(1, std::min(8, atoi(e))) : 8u;
-  }();
-  return v;
-}
-
-// the same block over the source-partitioned copy: one launch, workgroup b on partition b % kParts
+// the same block over the row-panel copy: one launch, a workgroup per CU, items handed out by the queue
 static int launch_dense_edges_part(pprhip_graph* g, const double* cB, const GsBlock& B) {
   const PartLayout& L = *g->pl;
-  const uint32_t NG = L.n_groups;
-  // block boundaries are multiples of kGroupRows row ordinals (or the end of the rows): whole groups
-  const uint32_t g_lo = B.j_lo / kGroupRows, g_hi = std::min<uint32_t>(NG, (B.j_hi + kGroupRows - 1) / kGroupRows);
-  PartWindows W{};
-  uint32_t most = 0;
-  for (int p = 0; p < kParts; ++p) {
-    W.lo[p] = L.h_group_slice0[(size_t)p * (NG + 1) + g_lo];
-    W.hi[p] = L.h_group_slice0[(size_t)p * (NG + 1) + g_hi];
-    W.base[p] = g->part_ctr_next[p];
-    most = std::max(most, W.hi[p] - W.lo[p]);
-  }
-  if (!most) return PPRHIP_OK;
-  const uint32_t wpb = kEllThreads / 64;
-  const uint32_t wgs = std::max(1u, std::min<uint32_t>((most + wpb - 1) / wpb, (uint32_t)g->n_cus / kParts * edge_wgs_per_cu()));
-  const bool wide = ((uint64_t)g->n + 1) * kBatch * sizeof(double) >= (1ull << 32);
-  static const int variant = getenv("PPRHIP_ELL_VARIANT") ? atoi(getenv("PPRHIP_ELL_VARIANT")) : 0;  // bit 0: cold nt, bit 1: unroll 2
-  static const uint32_t hot_env = getenv("PPRHIP_ELL_HOT") ? (uint32_t)atol(getenv("PPRHIP_ELL_HOT")) : 131072u;
-  static const uint32_t mask_env = getenv("PPRHIP_ELL_MASK") ? (uint32_t)strtoul(getenv("PPRHIP_ELL_MASK"), nullptr, 0) : 0xffffffffu;
-  const uint32_t hot = (variant & 1) ? hot_env : mask_env;
-  static const uint32_t dbg = getenv("PPRHIP_ELL_DBG") ? (uint32_t)atoi(getenv("PPRHIP_ELL_DBG")) : 0u;
-#define PPRHIP_ELL_LAUNCH(WIDE, NT, UN)                                                                              \
-  k_dense_edges_ell<WIDE, NT, UN><<<dim3(wgs * kParts), dim3(kEllThreads), 0, g->stream>>>(L.idx, L.slice_off, L.dst, W, cB, \
-                                                                                        g->part_acc, L.n_pieces, g->part_ctr, hot, dbg)
-  if (wide) PPRHIP_ELL_LAUNCH(true, false, 1);
-  else if (variant == 1) PPRHIP_ELL_LAUNCH(false, true, 1);
-  else if (variant == 2) PPRHIP_ELL_LAUNCH(false, false, 2);
-  else if (variant == 3) PPRHIP_ELL_LAUNCH(false, true, 2);
-  else PPRHIP_ELL_LAUNCH(false, false, 1);
-#undef PPRHIP_ELL_LAUNCH
+  const uint32_t p_lo = B.j_lo / kPanelRows, p_hi = std::min<uint32_t>(L.n_panels, (B.j_hi + kPanelRows - 1) / kPanelRows);
+  if (p_hi <= p_lo) return PPRHIP_OK;
+  const uint32_t i_lo = L.h_panel_item0[p_lo], i_hi = L.h_panel_item0[p_hi];
+  if (i_hi <= i_lo) return PPRHIP_OK;
+  const uint32_t grid = std::min<uint32_t>(i_hi - i_lo, (uint32_t)g->n_cus);
+#ifdef PPRHIP_TEST_HOOKS
+  static const uint32_t dbg = getenv("PPRHIP_PANEL_DBG") ? (uint32_t)strtoul(getenv("PPRHIP_PANEL_DBG"), nullptr, 0) : 0u;
+#else
+  const uint32_t dbg = 0u;
+#endif
+  if (((uint64_t)g->n + 1) * kBatch * sizeof(double) >= (1ull << 32))
+    k_dense_edges_panel<true><<<dim3(grid), dim3(kPanelThreads), kPanelLdsBytes, g->stream>>>(
+        L.src, L.rloc, L.items, i_lo, i_hi - i_lo, g->part_ctr_next, g->part_ctr, cB, g->part_acc, B.j_lo, B.j_hi, g->n_nz, g->n, dbg);
+  else
+    k_dense_edges_panel<false><<<dim3(grid), dim3(kPanelThreads), kPanelLdsBytes, g->stream>>>(
+        L.src, L.rloc, L.items, i_lo, i_hi - i_lo, g->part_ctr_next, g->part_ctr, cB, g->part_acc, B.j_lo, B.j_hi, g->n_nz, g->n, dbg);
   PPRHIP_CHECK_HIP(hipGetLastError());
-  // every wave takes slices until one is beyond the window: the partition's slices + one failing take per wave
-  for (int p = 0; p < kParts; ++p) g->part_ctr_next[p] += (W.hi[p] - W.lo[p]) + wgs * wpb;
+  // every workgroup takes items until one is beyond the window: the window's items + one failing take per workgroup
+  g->part_ctr_next += (i_hi - i_lo) + grid;
+  // rows of panels that were cut into parts: the parts' lines -> the row's first line (the panels are ordered by their
+  // edge counts, so the cut ones are the first: host-side bound)
+  uint32_t p_cut = p_lo;
+  while (p_cut < p_hi && L.h_panel_item0[p_cut + 1] - L.h_panel_item0[p_cut] > 1) ++p_cut;
+  for (uint32_t p = p_cut; p < p_hi; ++p)
+    if (L.h_panel_item0[p + 1] - L.h_panel_item0[p] > 1) p_cut = p + 1;  // (any order of panels: cover the last cut one)
+  if (p_cut > p_lo) {
+    const uint32_t r_lo = std::max(B.j_lo, p_lo * kPanelRows), r_hi = std::min(std::min(B.j_hi, g->n_nz), p_cut * kPanelRows);
+    if (r_hi > r_lo) {
+      k_panel_reduce<<<dim3(((r_hi - r_lo) * kBatch + 255) / 256), dim3(256), 0, g->stream>>>(g->part_acc, L.row_piece0, r_lo, r_hi);
+      PPRHIP_CHECK_HIP(hipGetLastError());
+    }
+  }
   return PPRHIP_OK;
 }
 
@@ -2125,9 +2116,10 @@ int init_kernels_push() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
-  hipFuncAttributes fa0;
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_ell<false, false, 1>)));
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa0, reinterpret_cast<const void*>(&k_dense_edges_ell<true, false, 1>)));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_panel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLdsBytes));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_panel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLdsBytes));
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sparse_push<kBackward>)));
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch<false>)));

@@ -443,183 +443,93 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
   return PPRHIP_OK;
 }
 
-// ---- source-partitioned copy of the in-CSR as a sliced ELL (engine_internal.hpp: HostPartLayout).  Passes: (A) edges
-// and pieces per (row, partition), the rows' first piece ordinals; (B) per group of rows, the slices and index steps
-// of its eight cells (a histogram of the piece lengths gives them without sorting), then the running offsets of every
-// cell; (C) per group again, on all threads: edges bucketed by partition, the cell's pieces sorted, its slices written
-// at the offsets pass B fixed - so the arrays are the same with any thread count.
-namespace {
-struct EllPiece {
-  uint32_t len, ord;
-  const int32_t* src;  // the piece's sources, in the row's CSR order
-};
-inline uint32_t pieces_of(uint32_t edges) { return (edges + kPieceMax - 1) / kPieceMax; }
-}  // namespace
-
+// ---- row-panel copy of the in-CSR (engine_internal.hpp: HostPartLayout).  Pass A, one thread: edges, parts and
+// offsets per panel; pass B, all threads, panels handed out in order: a panel's edges as keys source << 16 | local row,
+// sorted, written part by part with the padding - the arrays are the same with any thread count.
 int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,
                       uint32_t n_nz, unsigned threads, HostPartLayout& L) {
   PhaseClock clk;
   const unsigned T = (m < (1u << 20)) ? 1u : std::max(1u, threads ? threads : host_threads());
   L.n_nz = n_nz;
-  L.n_groups = (n_nz + kGroupRows - 1) / kGroupRows;
+  L.n_panels = (n_nz + kPanelRows - 1) / kPanelRows;
   L.zero_id = n;
-  const size_t NG = L.n_groups;
-  // (A) cnt[j * kParts + p]: edges of row ordinal j that lie in partition p
-  RawVec<uint32_t> cnt((size_t)kParts * n_nz);
+  const size_t NP = L.n_panels;
+  L.panel_item0.assign(NP + 1, 0);
   L.row_piece0.assign((size_t)n_nz + 1, 0);
-  const unsigned tasks = T == 1 ? 1u : (unsigned)std::min<size_t>(NG, (size_t)T * 16u);
-  std::vector<uint32_t> gb(tasks + 1, (uint32_t)NG);  // group ranges of about equal edge counts
-  {
-    gb[0] = 0;
-    unsigned k = 1;
-    uint64_t acc = 0;
-    for (size_t g = 0; g < NG && k < tasks; ++g) {
-      const uint32_t j_hi = (uint32_t)std::min<size_t>(n_nz, (g + 1) * kGroupRows);
-      acc = (uint64_t)in_rp[(uint32_t)nz_rows[j_hi - 1] + 1];
-      while (k < tasks && acc >= m / tasks * k) gb[k++] = (uint32_t)g + 1;
+  std::vector<uint64_t> panel_edges(NP, 0);
+  uint64_t items = 0, steps = 0, pieces = 0;
+  for (size_t t = 0; t < NP; ++t) {
+    const uint32_t j_lo = (uint32_t)t * kPanelRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(t + 1) * kPanelRows);
+    uint64_t e = 0;
+    for (uint32_t j = j_lo; j < j_hi; ++j) e += in_rp[(uint32_t)nz_rows[j] + 1] - in_rp[(uint32_t)nz_rows[j]];
+    panel_edges[t] = e;
+    const uint64_t S = std::max<uint64_t>(1, (e + kItemEdges - 1) / kItemEdges);
+    L.panel_item0[t] = (uint32_t)items;
+    for (uint32_t j = j_lo; j < j_hi; ++j) L.row_piece0[j] = (uint32_t)(pieces + (uint64_t)(j - j_lo) * S);
+    for (uint64_t k = 0; k < S; ++k) {
+      const uint64_t part = e * (k + 1) / S - e * k / S;
+      steps += (part + kPanelStep - 1) / kPanelStep;
+    }
+    items += S;
+    pieces += (uint64_t)(j_hi - j_lo) * S;
+    if (pieces >= 0xfffffff0ull || items >= 0xfffffff0ull || steps >= 0xfffffff0ull) {
+      L.n_pieces = L.n_items = 0;  // ordinals are 32-bit: keep the row-major sweep
+      return PPRHIP_OK;
     }
   }
-  parallel_parts(tasks, T, [&](unsigned r) {
-    for (uint32_t j = gb[r] * kGroupRows; j < std::min<uint64_t>(n_nz, (uint64_t)gb[r + 1] * kGroupRows); ++j) {
+  L.panel_item0[NP] = (uint32_t)items;
+  L.row_piece0[n_nz] = (uint32_t)pieces;
+  L.n_items = (uint32_t)items;
+  L.n_pieces = (uint32_t)pieces;
+  L.n_edges = steps * kPanelStep;
+  L.items.assign((size_t)items, PanelItem{0, 0, 0, 0, 0, {0, 0, 0}});
+  {
+    uint64_t st = 0;
+    for (size_t t = 0; t < NP; ++t) {
+      const uint32_t i0 = L.panel_item0[t], S = L.panel_item0[t + 1] - i0;
+      const uint64_t e = panel_edges[t];
+      for (uint32_t k = 0; k < S; ++k) {
+        const uint64_t part = e * (k + 1) / S - e * k / S;
+        PanelItem& I = L.items[(size_t)i0 + k];
+        I.edge0 = (uint32_t)st;
+        I.steps = (uint32_t)((part + kPanelStep - 1) / kPanelStep);
+        I.panel = (uint32_t)t;
+        I.line0 = L.row_piece0[(size_t)t * kPanelRows] + k;
+        I.stride = S;
+        st += I.steps;
+      }
+    }
+  }
+  L.src.resize((size_t)L.n_edges);
+  L.rloc.resize((size_t)L.n_edges);
+  clk.mark("panels: offsets");
+  parallel_parts((unsigned)NP, T, [&](unsigned t) {
+    const uint32_t j_lo = t * kPanelRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(t + 1) * kPanelRows);
+    std::vector<uint64_t> key;
+    key.reserve((size_t)panel_edges[t]);
+    for (uint32_t j = j_lo; j < j_hi; ++j) {
       const uint32_t v = (uint32_t)nz_rows[j];
-      uint32_t c[kParts] = {0};
-      const uint32_t deg = in_rp[v + 1] - in_rp[v];
-      if (deg <= kPartWholeRow) c[part_of(j)] = deg;  // a short row stays whole, in the partition of its ordinal
-      else
-        for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) c[part_of((uint32_t)in_ci[e])]++;
-      uint32_t np = 0;
-      for (int p = 0; p < kParts; ++p) {
-        cnt[(size_t)j * kParts + p] = c[p];
-        np += pieces_of(c[p]);
+      for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) key.push_back((uint64_t)(uint32_t)in_ci[e] << 16 | (j - j_lo));
+    }
+    std::sort(key.begin(), key.end());
+    const uint32_t i0 = L.panel_item0[t], S = L.panel_item0[t + 1] - i0;
+    const uint64_t e = key.size();
+    for (uint32_t k = 0; k < S; ++k) {
+      const PanelItem& I = L.items[(size_t)i0 + k];
+      const uint64_t lo = e * k / S, hi = e * (k + 1) / S;
+      int32_t* so = L.src.data() + (size_t)I.edge0 * kPanelStep;
+      uint16_t* ro = L.rloc.data() + (size_t)I.edge0 * kPanelStep;
+      for (uint64_t x = lo; x < hi; ++x) {
+        so[x - lo] = (int32_t)(key[x] >> 16);
+        ro[x - lo] = (uint16_t)(key[x] & 0xffffu);
       }
-      L.row_piece0[j + 1] = np;
-    }
-  });
-  {
-    uint64_t run = 0;
-    for (uint32_t j = 0; j < n_nz; ++j) {
-      run += L.row_piece0[j + 1];
-      if (run >= 0xfffffff0ull) return PPRHIP_OK;  // piece ordinals are 32-bit: keep the row-major sweep (n_pieces = 0)
-      L.row_piece0[j + 1] = (uint32_t)run;
-    }
-  }
-  clk.mark("partition: counts");
-  // (B) per cell (p, g): slices and index steps
-  std::vector<uint32_t> cell_slices((size_t)kParts * NG, 0);
-  std::vector<uint64_t> cell_step4((size_t)kParts * NG, 0);
-  parallel_parts(tasks, T, [&](unsigned r) {
-    std::vector<uint32_t> hist(kPieceMax + 1);
-    for (uint32_t g = gb[r]; g < gb[r + 1]; ++g) {
-      const uint32_t j_lo = g * kGroupRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(g + 1) * kGroupRows);
-      for (int p = 0; p < kParts; ++p) {
-        std::fill(hist.begin(), hist.end(), 0u);
-        uint32_t np = 0;
-        for (uint32_t j = j_lo; j < j_hi; ++j) {
-          const uint32_t c = cnt[(size_t)j * kParts + p];
-          if (!c) continue;
-          const uint32_t k = pieces_of(c);
-          hist[kPieceMax] += k - 1;
-          hist[c - (k - 1) * kPieceMax]++;
-          np += k;
-        }
-        // the slices' first pieces are those of rank 0, 16, 32 ... by length descending
-        uint64_t s4 = 0;
-        uint32_t rank = 0, next = 0;
-        for (uint32_t len = kPieceMax; len >= 1 && next < np; --len) {
-          rank += hist[len];
-          while (next < rank) {
-            s4 += (len + 3) / 4;
-            next += kSliceQuads;
-          }
-        }
-        cell_slices[(size_t)p * NG + g] = (np + kSliceQuads - 1) / kSliceQuads;
-        cell_step4[(size_t)p * NG + g] = s4;
+      for (uint64_t x = hi - lo; x < (uint64_t)I.steps * kPanelStep; ++x) {
+        so[x] = (int32_t)n;
+        ro[x] = 0;
       }
     }
   });
-  L.group_slice0.assign((size_t)kParts * (NG + 1), 0);
-  std::vector<uint64_t> cell_off((size_t)kParts * NG, 0);
-  uint64_t slices = 0, step4 = 0;
-  for (int p = 0; p < kParts; ++p) {
-    for (size_t g = 0; g < NG; ++g) {
-      L.group_slice0[(size_t)p * (NG + 1) + g] = (uint32_t)slices;
-      cell_off[(size_t)p * NG + g] = step4;
-      slices += cell_slices[(size_t)p * NG + g];
-      step4 += cell_step4[(size_t)p * NG + g];
-    }
-    L.group_slice0[(size_t)p * (NG + 1) + NG] = (uint32_t)slices;
-  }
-  if (step4 >= 0xfffffff0ull || slices >= 0x0ffffff0ull) return PPRHIP_OK;  // (offsets are 32-bit)
-  L.n_slices = (uint32_t)slices;
-  L.n_step4 = step4;
-  L.n_pieces = L.row_piece0[n_nz];
-  L.idx.resize((size_t)step4 * 64);
-  L.slice_off.assign((size_t)slices + 1, 0);
-  L.slice_off[slices] = (uint32_t)step4;
-  L.dst.assign((size_t)slices * kSliceQuads, L.n_pieces);
-  clk.mark("partition: offsets");
-  // (C) the slices
-  parallel_parts(tasks, T, [&](unsigned r) {
-    std::vector<int32_t> bucket[kParts];
-    std::vector<EllPiece> pc[kParts];
-    struct Seg { uint32_t ord, len; size_t at; int p; };
-    std::vector<Seg> segs;
-    for (uint32_t g = gb[r]; g < gb[r + 1]; ++g) {
-      const uint32_t j_lo = g * kGroupRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(g + 1) * kGroupRows);
-      for (int p = 0; p < kParts; ++p) {
-        bucket[p].clear();
-        pc[p].clear();
-      }
-      segs.clear();
-      for (uint32_t j = j_lo; j < j_hi; ++j) {
-        const uint32_t v = (uint32_t)nz_rows[j];
-        const uint32_t deg = in_rp[v + 1] - in_rp[v];
-        uint32_t ord = L.row_piece0[j];
-        if (deg <= kPartWholeRow) {
-          pc[part_of(j)].push_back(EllPiece{deg, ord, in_ci + in_rp[v]});
-          continue;
-        }
-        const uint32_t* c = &cnt[(size_t)j * kParts];
-        size_t at[kParts];
-        for (int p = 0; p < kParts; ++p) {
-          at[p] = bucket[p].size();
-          if (c[p]) segs.push_back(Seg{ord, c[p], at[p], p});
-          ord += pieces_of(c[p]);
-          bucket[p].resize(at[p] + c[p]);
-        }
-        for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) {
-          const int32_t u = in_ci[e];
-          bucket[part_of((uint32_t)u)][at[part_of((uint32_t)u)]++] = u;
-        }
-      }
-      // (the buckets do not move any more: pieces may point into them)
-      for (const Seg& sg : segs)
-        for (uint32_t k = 0, left = sg.len; left; ++k, left -= std::min(left, kPieceMax))
-          pc[sg.p].push_back(EllPiece{std::min(left, kPieceMax), sg.ord + k, bucket[sg.p].data() + sg.at + (size_t)k * kPieceMax});
-      for (int p = 0; p < kParts; ++p) {
-        std::vector<EllPiece>& P = pc[p];
-        std::sort(P.begin(), P.end(), [](const EllPiece& a, const EllPiece& b) {
-          return a.len != b.len ? a.len > b.len : a.ord < b.ord;
-        });
-        uint32_t sl = L.group_slice0[(size_t)p * (NG + 1) + g];
-        uint64_t off = cell_off[(size_t)p * NG + g];
-        for (size_t i = 0; i < P.size(); i += kSliceQuads, ++sl) {
-          const uint32_t w4 = (P[i].len + 3) / 4;
-          L.slice_off[sl] = (uint32_t)off;
-          int32_t* out = L.idx.data() + (size_t)off * 64;
-          for (int q = 0; q < kSliceQuads; ++q) {
-            const bool have = i + q < P.size();
-            const uint32_t len = have ? P[i + q].len : 0u;
-            if (have) L.dst[(size_t)sl * kSliceQuads + q] = P[i + q].ord;
-            for (uint32_t e = 0; e < w4 * 4; ++e)
-              out[(size_t)(e >> 2) * 64 + (size_t)q * 4 + (e & 3)] = e < len ? P[i + q].src[e] : (int32_t)n;
-          }
-          off += w4;
-        }
-      }
-    }
-  });
-  clk.mark("partition: slices");
+  clk.mark("panels: edges");
   return PPRHIP_OK;
 }
 
@@ -634,7 +544,7 @@ struct pprhip_lift {
   int threads = 0;
   mutable bool have_part = false;  // the source-partitioned copy is built when one of its arrays is first asked for
   mutable HostPartLayout part;
-  mutable uint64_t part_sizes[4] = {0, 0, 0, 0};  // groups, slices, pieces, index steps
+  mutable uint64_t part_sizes[4] = {0, 0, 0, 0};  // panels, items, partial lines, edges with padding
 };
 
 extern "C" {
@@ -678,7 +588,7 @@ int pprhip_lift_array(const pprhip_lift_t* lift, int which, const void** data_ou
     return PPRHIP_OK;
   };
 #define PPRHIP_LIFT_VEC(v) give((v).data(), (v).size() * sizeof((v)[0]))
-  if (which >= PPRHIP_LIFT_PART_SIZES && which <= PPRHIP_LIFT_PART_GROUP_SLICE0) {
+  if (which >= PPRHIP_LIFT_PANEL_SIZES && which <= PPRHIP_LIFT_PANEL_ROW_PIECE0) {
     if (!lift->have_part) {
       try {
         PPRHIP_TRY(build_part_layout(lift->n, lift->m, H.in_rp.data(), H.in_ci.data(), H.nz_rows.data(),
@@ -687,20 +597,20 @@ int pprhip_lift_array(const pprhip_lift_t* lift, int which, const void** data_ou
         set_error("pprhip_lift_array: out of host memory");
         return PPRHIP_ERR_OOM;
       }
-      lift->part_sizes[0] = lift->part.n_groups;
-      lift->part_sizes[1] = lift->part.n_slices;
+      lift->part_sizes[0] = lift->part.n_panels;
+      lift->part_sizes[1] = lift->part.n_items;
       lift->part_sizes[2] = lift->part.n_pieces;
-      lift->part_sizes[3] = lift->part.n_step4;
+      lift->part_sizes[3] = lift->part.n_edges;
       lift->have_part = true;
     }
     const HostPartLayout& L = lift->part;
     switch (which) {
-      case PPRHIP_LIFT_PART_SIZES: return give(lift->part_sizes, sizeof lift->part_sizes);
-      case PPRHIP_LIFT_PART_IDX: return PPRHIP_LIFT_VEC(L.idx);
-      case PPRHIP_LIFT_PART_SLICE_OFF: return PPRHIP_LIFT_VEC(L.slice_off);
-      case PPRHIP_LIFT_PART_DST: return PPRHIP_LIFT_VEC(L.dst);
-      case PPRHIP_LIFT_PART_ROW_PIECE0: return PPRHIP_LIFT_VEC(L.row_piece0);
-      case PPRHIP_LIFT_PART_GROUP_SLICE0: return PPRHIP_LIFT_VEC(L.group_slice0);
+      case PPRHIP_LIFT_PANEL_SIZES: return give(lift->part_sizes, sizeof lift->part_sizes);
+      case PPRHIP_LIFT_PANEL_SRC: return PPRHIP_LIFT_VEC(L.src);
+      case PPRHIP_LIFT_PANEL_ROW: return PPRHIP_LIFT_VEC(L.rloc);
+      case PPRHIP_LIFT_PANEL_ITEMS: return PPRHIP_LIFT_VEC(L.items);
+      case PPRHIP_LIFT_PANEL_ITEM0: return PPRHIP_LIFT_VEC(L.panel_item0);
+      case PPRHIP_LIFT_PANEL_ROW_PIECE0: return PPRHIP_LIFT_VEC(L.row_piece0);
       default: break;
     }
   }

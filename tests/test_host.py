@@ -214,72 +214,49 @@ def test_index_merge_large_runs_on_all_threads(pkg):
 
 
 # ------------------------------------------------------------------ graph lift, host half (row a11; PPR.java:136-152)
-def _part_expected(n, m, in_rp, in_ci, nz_rows, parts=8, whole=16, piece_max=64, group=256, quads=16):
-    """The source-partitioned copy of the in-CSR (engine_internal.hpp: HostPartLayout, a sliced ELL) restated with numpy
-    sorts: a row's in-edges are stably grouped by partition - of the source id (id & 7) for rows of more than 16 in-edges,
-    of the row's ordinal for the shorter ones -, every (row, partition) segment is cut into pieces of <= 64 edges,
-    numbered row by row; the pieces of 256 consecutive rows in one partition, sorted by (length descending, ordinal),
-    fill slices of sixteen; a slice stores its pieces' sources step-major, four edges per quad and step."""
+def _part_expected(n, m, in_rp, in_ci, nz_rows, panel=1024, step=1024, item_edges=32768):
+    """The row-panel copy of the in-CSR (engine_internal.hpp: HostPartLayout) restated with numpy sorts: panels of 1024
+    consecutive rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more than 32 768 edges is
+    cut into S = ceil(edges / 32 768) parts [e k / S, e (k + 1) / S); every part padded to whole turns of 1024 edges with
+    (n, 0); row j of a panel with S parts owns the partial lines [base + (j - first) S, + S)."""
     indeg = np.diff(in_rp).astype(np.int64)
     n_nz = nz_rows.size
-    n_groups = (n_nz + group - 1) // group
+    n_panels = (n_nz + panel - 1) // panel
     row_of_edge = np.repeat(np.arange(n, dtype=np.int64), indeg)
-    ordinal = np.cumsum(indeg > 0) - 1                    # node -> row ordinal
+    ordinal = np.cumsum(indeg > 0) - 1
     j_of_edge = ordinal[row_of_edge]
-    part = in_ci.astype(np.int64) & (parts - 1)
-    short = indeg[row_of_edge] <= whole
-    part[short] = j_of_edge[short] & (parts - 1)
-    # edges in (row, partition, CSR position) order
-    perm = np.lexsort((np.arange(m), part, j_of_edge))
-    e_row, e_part, e_src = j_of_edge[perm], part[perm], in_ci[perm]
-    seg_key = e_row * parts + e_part
-    start = np.ones(m, dtype=bool)
-    start[1:] = seg_key[1:] != seg_key[:-1]
-    seg_first = np.nonzero(start)[0]
-    seg_len = np.diff(np.append(seg_first, m))
-    seg_row, seg_part = e_row[seg_first], e_part[seg_first]
-    seg_pieces = (seg_len + piece_max - 1) // piece_max
-    n_pieces = int(seg_pieces.sum())
-    # pieces, in ordinal order = (row, partition, position)
-    pc_seg = np.repeat(np.arange(seg_len.size), seg_pieces)
-    pc_k = np.arange(n_pieces) - np.repeat(np.cumsum(seg_pieces) - seg_pieces, seg_pieces)
-    pc_len = np.minimum(piece_max, seg_len[pc_seg] - pc_k * piece_max)
-    pc_first = seg_first[pc_seg] + pc_k * piece_max        # first edge (position in the sorted edge list)
-    pc_row, pc_part = seg_row[pc_seg], seg_part[pc_seg]
-    row_piece0 = np.zeros(n_nz + 1, dtype=np.uint32)
-    row_piece0[1:] = np.cumsum(np.bincount(pc_row, minlength=n_nz))
-    # slices: pieces by (partition, group, length descending, ordinal)
-    order = np.lexsort((np.arange(n_pieces), -pc_len, pc_row // group, pc_part))
-    cell = pc_part[order] * n_groups + pc_row[order] // group
-    cell_start = np.ones(n_pieces, dtype=bool)
-    cell_start[1:] = cell[1:] != cell[:-1]
-    cell_first = np.nonzero(cell_start)[0]
-    in_cell = np.arange(n_pieces) - np.repeat(cell_first, np.diff(np.append(cell_first, n_pieces)))
-    head = in_cell % quads == 0                            # first (longest) piece of every slice
-    slice_of = np.cumsum(head) - 1
-    n_slices = int(head.sum())
-    w4 = (pc_len[order][head] + 3) // 4
-    slice_off = np.zeros(n_slices + 1, dtype=np.uint32)
-    slice_off[1:] = np.cumsum(w4)
-    n_step4 = int(slice_off[-1])
-    group_slice0 = np.zeros((parts, n_groups + 1), dtype=np.uint32)
-    sl_cell = cell[head]
-    per_cell = np.bincount(sl_cell, minlength=parts * n_groups)
-    group_slice0_flat = np.concatenate([[0], np.cumsum(per_cell)])
-    for p in range(parts):
-        group_slice0[p] = group_slice0_flat[p * n_groups:(p + 1) * n_groups + 1]
-    dst = np.full(n_slices * quads, n_pieces, dtype=np.uint32)
-    quad = in_cell % quads
-    dst[slice_of * quads + quad] = order
-    idx = np.full(n_step4 * 64, n, dtype=np.int32)
-    # every edge of every piece: position e inside the piece -> idx[(off + e // 4) * 64 + quad * 4 + e % 4]
-    lens = pc_len[order]
-    e_in = np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens)
-    base = np.repeat(slice_off[:-1].astype(np.int64)[slice_of] * 64 + quad * 4, lens)
-    idx[base + (e_in // 4) * 64 + e_in % 4] = e_src[np.repeat(pc_first[order], lens) + e_in]
-    return dict(part_sizes=np.array([n_groups, n_slices, n_pieces, n_step4], dtype=np.uint64), part_idx=idx,
-                part_slice_off=slice_off, part_dst=dst, part_row_piece0=row_piece0,
-                part_group_slice0=group_slice0.ravel())
+    p_of_edge = j_of_edge // panel
+    perm = np.lexsort((j_of_edge, in_ci, p_of_edge))       # panel, then source, then row
+    e_src, e_row, e_pan = in_ci[perm], (j_of_edge % panel)[perm], p_of_edge[perm]
+    edges_p = np.bincount(p_of_edge, minlength=n_panels).astype(np.int64)
+    S = np.maximum(1, (edges_p + item_edges - 1) // item_edges)
+    item0 = np.zeros(n_panels + 1, dtype=np.int64)
+    item0[1:] = np.cumsum(S)
+    n_items = int(item0[-1])
+    rows_p = np.minimum(panel, n_nz - np.arange(n_panels) * panel)
+    base = np.zeros(n_panels + 1, dtype=np.int64)
+    base[1:] = np.cumsum(rows_p * S)
+    j = np.arange(n_nz)
+    row_piece0 = np.append(base[j // panel] + (j % panel) * S[j // panel], base[-1]).astype(np.uint32)
+    items = np.zeros((n_items, 8), dtype=np.uint32)
+    first_edge = np.zeros(n_panels + 1, dtype=np.int64)
+    first_edge[1:] = np.cumsum(edges_p)
+    src_out, row_out = [], []
+    st = 0
+    for t in range(n_panels):
+        e = int(edges_p[t])
+        for k in range(int(S[t])):
+            lo, hi = e * k // int(S[t]), e * (k + 1) // int(S[t])
+            steps = (hi - lo + step - 1) // step
+            items[item0[t] + k, :5] = (st, steps, t, base[t] + k, S[t])
+            pad = steps * step - (hi - lo)
+            src_out += [e_src[first_edge[t] + lo:first_edge[t] + hi], np.full(pad, n, dtype=np.int32)]
+            row_out += [e_row[first_edge[t] + lo:first_edge[t] + hi].astype(np.uint16), np.zeros(pad, dtype=np.uint16)]
+            st += steps
+    src = np.concatenate(src_out).astype(np.int32) if src_out else np.empty(0, dtype=np.int32)
+    row = np.concatenate(row_out).astype(np.uint16) if row_out else np.empty(0, dtype=np.uint16)
+    return dict(panel_sizes=np.array([n_panels, n_items, base[-1], st * step], dtype=np.uint64), panel_src=src,
+                panel_row=row, panel_items=items.ravel(), panel_item0=item0.astype(np.uint32), panel_row_piece0=row_piece0)
 
 
 def _lift_expected(h, width=393216, chunk=512, max_windows=16):

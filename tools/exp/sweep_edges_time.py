@@ -19,7 +19,7 @@ def main():
     lib = pkg.lib()
     lib.pprhip_hook_time_sweep_edges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     for part in (1, 0):
-        os.environ["PPRHIP_SWEEP_PARTS"] = str(part)
+        os.environ["PPRHIP_SWEEP_PANELS"] = str(part)
         with pkg.Graph(h, device=0) as g:
             g.set_tuning(pkg.tuning_batch())
             out = []
