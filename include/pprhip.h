@@ -230,16 +230,7 @@ enum {
   PPRHIP_LIFT_SLICED_FLAGS = 14,     /* uint8[]: bit e = edge e of the sliced copy starts a segment */
   PPRHIP_LIFT_SLICED_CHUNK_STARTS = 15, /* uint32[] */
   PPRHIP_LIFT_SEG_ROW = 16,          /* uint32[segments]: row ordinal */
-  PPRHIP_LIFT_SEG_OFF = 17,          /* uint32[segments]: first edge */
-  /* the row-panel copy of the in-CSR the batched sweep walks (built when first asked for): panels of 1024 consecutive
-   * rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more than 32 768 edges is cut into parts
-   * of equal edge counts; every part (item) padded to whole turns of 1024 edges with (n, 0) */
-  PPRHIP_LIFT_PANEL_SIZES = 18,       /* uint64[4]: panels, items, partial lines, edges with padding */
-  PPRHIP_LIFT_PANEL_SRC = 19,         /* int32[edges]: sources, padding = n */
-  PPRHIP_LIFT_PANEL_ROW = 20,         /* uint16[edges]: row ordinal - first ordinal of the panel */
-  PPRHIP_LIFT_PANEL_ITEMS = 21,       /* uint32[items][8]: first edge / 1024, turns, panel, first partial line, parts of the panel, 0, 0, 0 */
-  PPRHIP_LIFT_PANEL_ITEM0 = 22,       /* uint32[panels + 1]: first item of every panel */
-  PPRHIP_LIFT_PANEL_ROW_PIECE0 = 23   /* uint32[rows + 1]: first partial line of every row with in-edges */
+  PPRHIP_LIFT_SEG_OFF = 17           /* uint32[segments]: first edge */
 };
 int pprhip_graph_lift_host(uint32_t n, uint64_t m, const uint32_t* out_row_ptr, const int32_t* out_col_idx,
                            const uint32_t* in_row_ptr, const int32_t* in_col_idx, int threads,

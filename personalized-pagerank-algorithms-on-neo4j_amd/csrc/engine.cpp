@@ -799,9 +799,8 @@ int ensure_workspaces(pprhip_graph* P, int count) {
 int build_batch(pprhip_graph* P) {
   const size_t n = P->n;
   for (int i = 0; i < 2; ++i) {
-    // (n + 1 lines: line n is never written and stays zero - the padding of the sliced ELL copy gathers it)
-    PPRHIP_TRY(alloc_dev((void**)&P->c8[i], sizeof(double) * (n + 1) * kBatch));
-    PPRHIP_CHECK_HIP(hipMemsetAsync(P->c8[i], 0, sizeof(double) * (n + 1) * kBatch, P->stream));
+    PPRHIP_TRY(alloc_dev((void**)&P->c8[i], sizeof(double) * n * kBatch));
+    PPRHIP_CHECK_HIP(hipMemsetAsync(P->c8[i], 0, sizeof(double) * n * kBatch, P->stream));
   }
   PPRHIP_TRY(alloc_dev((void**)&P->acc8, sizeof(double) * (n + 1) * kBatch));
   PPRHIP_CHECK_HIP(hipMemsetAsync(P->acc8, 0, sizeof(double) * (n + 1) * kBatch, P->stream));
@@ -822,83 +821,12 @@ int build_batch(pprhip_graph* P) {
   PPRHIP_TRY(alloc_dev((void**)&P->blk_dead8, sizeof(double) * kBatch * kApplyBlocks8));
   PPRHIP_TRY(alloc_dev((void**)&P->blk_ndead8, sizeof(uint32_t) * kBatch * kApplyBlocks8));
   P->c8cur = 0;
-  PPRHIP_TRY(build_part_layout_device(P));
   for (int s = 0; s < kBatch; ++s) {
     P->col_owner[s] = -1;
     PPRHIP_TRY(make_slot(P, s));
   }
   PPRHIP_CHECK_HIP(hipStreamSynchronize(P->stream));
   return PPRHIP_OK;
-}
-
-// Row-panel copy of the in-CSR for the batched forward sweep (engine_internal.hpp: HostPartLayout).  The internal-order
-// column indices live on the device only (the lift's host arrays are gone by now): they come back once, the host builds
-// the copy on all its threads, and it goes up again, once per handle (the copy stays when the batch workspaces are
-// released).  PPRHIP_SWEEP_PANELS=0 / 1 switches it off / on for any size (tests run small graphs both ways); by default
-// graphs from 2^22 edges on use it - below that the whole contribution array fits every L2 anyway.
-static int ensure_part_layout(pprhip_graph* P) {
-  if (P->pl) return PPRHIP_OK;
-  HostPartLayout H;
-  std::unique_ptr<PartLayout> L(new (std::nothrow) PartLayout());
-  if (!L) return PPRHIP_ERR_OOM;
-  try {
-    RawVec<int32_t> ci((size_t)P->m);
-    PPRHIP_CHECK_HIP(hipMemcpy(ci.data(), P->in_ci, sizeof(int32_t) * (size_t)P->m, hipMemcpyDeviceToHost));
-    PPRHIP_TRY(build_part_layout(P->n, P->m, P->h_in_rp.data(), ci.data(), P->h_nz_rows.data(), P->n_nz, 0, H));
-    L->h_panel_item0 = std::move(H.panel_item0);
-  } catch (const std::bad_alloc&) {
-    set_error("row-panel sweep layout: out of host memory");
-    return PPRHIP_ERR_OOM;
-  }
-  if (!H.n_pieces || !H.n_items) return PPRHIP_OK;  // (ordinals beyond 32 bits: the row-major sweep stays)
-  auto up = [&](void** d, const void* h, size_t bytes) -> int {
-    PPRHIP_TRY(alloc_dev(d, bytes));
-    PPRHIP_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
-    return PPRHIP_OK;
-  };
-  int rc = PPRHIP_OK;
-  if ((rc = up((void**)&L->src, H.src.data(), sizeof(int32_t) * H.src.size())) ||
-      (rc = up((void**)&L->rloc, H.rloc.data(), sizeof(uint16_t) * H.rloc.size())) ||
-      (rc = up((void**)&L->items, H.items.data(), sizeof(PanelItem) * H.items.size())) ||
-      (rc = up((void**)&L->row_piece0, H.row_piece0.data(), sizeof(uint32_t) * H.row_piece0.size()))) {
-    void* ptrs[] = {L->src, L->rloc, L->items, L->row_piece0};
-    for (void* p : ptrs)
-      if (p) (void)hipFree(p);
-    return rc;
-  }
-  L->n_panels = H.n_panels;
-  L->n_items = H.n_items;
-  L->n_pieces = H.n_pieces;
-  P->pl = L.release();
-  return PPRHIP_OK;
-}
-
-static bool want_part_layout(const pprhip_graph* P) {
-  const char* e = getenv("PPRHIP_SWEEP_PANELS");
-  return e ? e[0] == '1' : P->m >= (1ull << 22);
-}
-
-static int build_part_layout_device(pprhip_graph* P) {
-  if (!want_part_layout(P) || P->m == 0 || P->n_nz == 0) return PPRHIP_OK;
-  PPRHIP_TRY(ensure_part_layout(P));
-  if (!P->pl) return PPRHIP_OK;
-  const size_t bytes = sizeof(double) * ((size_t)P->pl->n_pieces + 1) * kBatch;
-  PPRHIP_TRY(alloc_dev((void**)&P->part_acc, bytes));
-  // (only the line behind the last piece has to be zero: the apply kernel reads it in place of lines a row does not have)
-  PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_acc + (size_t)P->pl->n_pieces * kBatch, 0, sizeof(double) * kBatch, P->stream));
-  PPRHIP_TRY(alloc_dev((void**)&P->part_ctr, 128));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(P->part_ctr, 0, 128, P->stream));
-  P->part_ctr_next = 0;
-  return PPRHIP_OK;
-}
-
-void free_part_layout(pprhip_graph* P) {
-  if (!P->pl) return;
-  void* ptrs[] = {P->pl->src, P->pl->rloc, P->pl->items, P->pl->row_piece0};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
-  delete P->pl;
-  P->pl = nullptr;
 }
 
 int ensure_batch(pprhip_graph* P) {
@@ -924,9 +852,7 @@ void free_batch(pprhip_graph* P) {
   P->ktimer.destroy();
   P->slots.clear();
   void* ptrs[] = {P->c8[0], P->c8[1], P->acc8, P->prep_bits, P->d_slot_args, P->sweep_out, P->blk_pack8, P->blk_dead8,
-                  P->blk_ndead8, P->part_acc, P->part_ctr};
-  P->part_acc = nullptr;
-  P->part_ctr = nullptr;
+                  P->blk_ndead8};
   if (P->h_sweep_out) (void)hipHostFree(P->h_sweep_out);
   P->sweep_out = P->h_sweep_out = nullptr;
   P->prep_bits = nullptr;
@@ -1672,7 +1598,6 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   free_batch(g);
-  free_part_layout(g);
   void* ptrs[] = {g->walk_rec, g->out_ext, g->out_rp, g->out_ci, g->in_rp, g->in_ci, g->new2old, g->old2new, g->start_flags,
                   g->chunk_starts, g->nz_rows, g->zin_rows, g->cross_bits, g->start_flags_o, g->chunk_starts_o,
                   g->nz_rows_o, g->z_rows_o, g->cross_bits_o};
@@ -2312,18 +2237,13 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
 #ifdef PPRHIP_TEST_HOOKS
 // Test / tuning hook (libpprhip_hooks.so only): the edge kernel of block `block` of `n_blocks` Gauss-Seidel blocks of a
 // batched forward sweep (n_blocks <= 1: the whole sweep), `reps` launches back to back; average microseconds per launch.
-// part != 0: over the source-partitioned copy (an error when the handle has none).
-int pprhip_hook_time_sweep_edges(pprhip_graph_t* g, int part, int block, int n_blocks, int reps, double* us_out) {
+int pprhip_hook_time_sweep_edges(pprhip_graph_t* g, int block, int n_blocks, int reps, double* us_out) {
   if (!g || !us_out || reps <= 0 || g->parent) {
     set_error("pprhip_hook_time_sweep_edges: bad arguments");
     return PPRHIP_ERR_INVALID;
   }
   PPRHIP_CHECK_HIP(hipSetDevice(g->device));
   PPRHIP_TRY(ensure_batch(g));
-  if (part && !(g->pl && g->part_acc)) {
-    set_error("pprhip_hook_time_sweep_edges: no source-partitioned copy on this handle");
-    return PPRHIP_ERR_INVALID;
-  }
   GsBlock B{0u, g->n_nz, 0ull, (unsigned long long)g->m};
   if (n_blocks > 1) {
     pprhip_tuning_t keep = g->slots[0]->tun;
@@ -2340,9 +2260,9 @@ int pprhip_hook_time_sweep_edges(pprhip_graph_t* g, int part, int block, int n_b
   hipEvent_t e0, e1;
   PPRHIP_CHECK_HIP(hipEventCreate(&e0));
   PPRHIP_CHECK_HIP(hipEventCreate(&e1));
-  PPRHIP_TRY(launch_sweep_edges_only(g, B, part != 0));  // warm-up
+  PPRHIP_TRY(launch_sweep_edges_only(g, B));  // warm-up
   PPRHIP_CHECK_HIP(hipEventRecord(e0, g->stream));
-  for (int i = 0; i < reps; ++i) PPRHIP_TRY(launch_sweep_edges_only(g, B, part != 0));
+  for (int i = 0; i < reps; ++i) PPRHIP_TRY(launch_sweep_edges_only(g, B));
   PPRHIP_CHECK_HIP(hipEventRecord(e1, g->stream));
   PPRHIP_CHECK_HIP(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -95,16 +95,6 @@ struct SlicedLayout {
   int plan_B = -1;
 };
 
-// The row-panel copy of the in-CSR on the device (engine_internal.hpp: HostPartLayout; batched forward sweep).
-struct PartLayout {
-  int32_t* src = nullptr;          // [n_edges] sources, item-major; padding = zero_id (= n)
-  uint16_t* rloc = nullptr;        // [n_edges] row ordinal inside the panel
-  PanelItem* items = nullptr;      // [n_items]
-  uint32_t* row_piece0 = nullptr;  // [n_nz + 1] a row's partial lines are [row_piece0[j], row_piece0[j + 1])
-  uint32_t n_panels = 0, n_items = 0, n_pieces = 0;
-  std::vector<uint32_t> h_panel_item0;  // host: [n_panels + 1], the Gauss-Seidel blocks' item windows
-};
-
 enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
 
 struct SelRec {  // one candidate of a top-k selection / one entry >= threshold of a backward search
@@ -369,12 +359,6 @@ struct pprhip_graph {
   pprhip::detail::FetchPipe* fetch = nullptr;  // delivery of batched queries' vectors to host memory (engine_internal.hpp)
   double* c8[2] = {nullptr, nullptr};
   int c8cur = 0;
-  pprhip::PartLayout* pl = nullptr;  // source-partitioned copy of the in-CSR (forward batched sweeps), with the batch state
-  double* part_acc = nullptr;        // [pieces + 1][kBatch] partial row sums (the line behind the last stays zero)
-  // the items' queue: the workgroups of a launch take items in turn (atomicAdd); the counter only ever grows, the host
-  // keeps what it will hold when the next launch starts (every workgroup's last, failing take included)
-  uint32_t* part_ctr = nullptr;
-  uint32_t part_ctr_next = 0;
   double* acc8 = nullptr;      // [row ordinal][kBatch] row sums
   int acc8_dir = 0;            // layout the row sums were last written in (0 forward, 1 backward)
   int32_t* zin_rows = nullptr;  // rows without in-edges
@@ -494,7 +478,7 @@ constexpr uint32_t kApplyBlocks8 = 2048;  // workgroups of the batched apply ker
 // slot arguments already staged in parent->h_slot_args; blocks: Gauss-Seidel blocks (nullptr / 1: one launch)
 int launch_dense_level_b8(pprhip_graph* parent, bool backward, const pprhip::GsBlock* blocks = nullptr, int n_blocks = 1);
 #ifdef PPRHIP_TEST_HOOKS
-int launch_sweep_edges_only(pprhip_graph* parent, const pprhip::GsBlock& B, bool part);
+int launch_sweep_edges_only(pprhip_graph* parent, const pprhip::GsBlock& B);
 int launch_count_live_lines(pprhip_graph* P, unsigned long long* d_out);
 #endif
 int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned long long* d_counter, bool backward);

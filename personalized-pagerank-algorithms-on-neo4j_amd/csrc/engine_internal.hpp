@@ -201,35 +201,6 @@ struct HostLift {
   std::vector<uint8_t> sl_flags;
   std::vector<uint32_t> sl_chunk_starts, seg_row, seg_off;
 };
-// Row-panel copy of the in-CSR for the batched forward sweep (round 6).  Why: a batched gather moves one 128-byte line
-// c8[u][0..15] per in-edge, a CU keeps ~256 lines in flight, and a line beyond L2 holds its slot four times as long as
-// one that hits (profiles/r06_ell_sweep_study.txt): the sweep is bound by the NUMBER of line requests and by how many of
-// them leave L2.  Rounds 5 and 6 tried to make the requests cheaper (one L2 per partition of the sources); this layout
-// makes them fewer.  The rows with in-edges are cut into PANELS of kPanelRows consecutive ordinals whose sixteen-column
-// sums fit a CU's LDS (128 KB); a panel's in-edges are sorted by (source, row), so that the edges of one source stand
-// together: the quads of a wave that meet the same source in one instruction share one request, and the 27 K hub rows
-// that hold half of R-MAT 22's in-edges ask for each line once per panel instead of once per row (4.0 x fewer requests
-// there, 1.5 x in the other rows).  The sums go to LDS with ds_add_f64 (rotated by the row, so that sixteen quads on
-// sixteen rows spread over the banks) and leave it once, as whole lines.
-// A panel of more than kItemEdges edges is cut into S parts of equal edge counts (ITEMS: the hub panels of R-MAT 22 have
-// up to 10 M edges); each part sums into LDS of its own and writes partial lines: row j's lines are
-// [row_piece0[j], row_piece0[j] + S), part k at + k - the apply kernel adds them (most rows: one line, which IS the sum).
-// Every item's edges are padded to whole turns of kPanelStep with (zero_id, row 0): zero_id = n names a contribution line
-// that is always zero.
-struct HostPartLayout {
-  uint32_t n_nz = 0, n_panels = 0, n_items = 0, n_pieces = 0;
-  uint64_t n_edges = 0;                      // with padding
-  uint32_t zero_id = 0;                      // = n
-  RawVec<int32_t> src;                       // [n_edges] sources, item-major, inside an item sorted by (source, row)
-  RawVec<uint16_t> rloc;                     // [n_edges] row ordinal - first ordinal of the panel
-  std::vector<PanelItem> items;              // [n_items], panel-major
-  std::vector<uint32_t> panel_item0;         // [n_panels + 1]
-  std::vector<uint32_t> row_piece0;          // [n_nz + 1]
-};
-// in_rp / in_ci: the internal-order in-CSR; nz_rows: its non-empty rows, ascending (row ordinal -> node)
-int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,
-                      uint32_t n_nz, unsigned threads, HostPartLayout& L);
-
 // threads: 0 = what the process may use (host_threads)
 int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out_ci, const uint32_t* in_rp,
               const int32_t* in_ci, unsigned threads, HostLift& H);

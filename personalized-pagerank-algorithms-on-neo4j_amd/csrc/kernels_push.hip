@@ -827,156 +827,6 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_dense_edges_panel (round 6): the batched edge kernel over the row-panel copy (engine_internal.hpp: HostPartLayout).
-// A workgroup takes an ITEM - a panel of kPanelRows rows, or one part of a hub panel - and sums its edges into
-// accumulators in LDS: acc[row][column], 128 KB.  The item's edges are sorted by source; a quad of lanes takes four
-// consecutive edges per turn (lane t of a quad holds the columns 2t, 2t+1, 8+2t, 9+2t: two 16-byte loads per edge, each
-// one contiguous 64-byte half of the line across the quad), the 256 quads of the workgroup 1 024 consecutive edges, so
-// the edges of one source meet in the same instructions and share their line requests (a CU keeps ~256 of them in
-// flight: profiles/r06_ell_sweep_study.txt).  Sums land with ds_add_f64; a row's sixteen columns are stored rotated by
-// the row ordinal, so that the quads of an instruction - sixteen rows, the same column - spread over the banks.
-// At the end the rows leave LDS as whole 128-byte lines: part_acc[line0 + row * stride], which k_dense_apply_batch<true>
-// adds up per row (stride = parts of the panel; 1 for all but the hub panels).  Rows outside [j_lo, j_hi) - the
-// Gauss-Seidel block of the launch, whose bounds may cut a panel - are left out: their edges gather the zero line.
-// Items are handed out by a counter that only ever grows (`base` = its value at launch).
-// ------------------------------------------------------------------------------------------------
-constexpr int kPanelThreads = 1024;
-constexpr int kPanelLdsBytes = (int)(kPanelRows * kBatch * sizeof(double));
-static_assert(kPanelStep == kPanelThreads / 4 * 4 && kPanelRows == (uint32_t)kPanelThreads, "one row and four edges per quad");
-
-template <bool WIDE>
-__device__ __forceinline__ const double2* panel_line(const double* __restrict__ cB, uint32_t u, uint32_t lane_off) {
-  // (the contribution array is below 4 GB unless WIDE: a 32-bit byte offset next to the uniform base address)
-  if (WIDE) return reinterpret_cast<const double2*>(reinterpret_cast<const char*>(cB) + (((size_t)u << 7) | lane_off));
-  return reinterpret_cast<const double2*>(reinterpret_cast<const char*>(cB) + ((u << 7) | lane_off));
-}
-
-__device__ __forceinline__ void panel_add(double* acc, uint32_t r, uint32_t t, const double2& x, const double2& y) {
-  double* row = acc + r * (uint32_t)kBatch;
-  atomic_add_noret(&row[(2u * t + r) & 15u], x.x);
-  atomic_add_noret(&row[(2u * t + 1u + r) & 15u], x.y);
-  atomic_add_noret(&row[(8u + 2u * t + r) & 15u], y.x);
-  atomic_add_noret(&row[(9u + 2u * t + r) & 15u], y.y);
-}
-
-template <bool WIDE>
-__global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32_t* __restrict__ src,
-                                                                     const uint16_t* __restrict__ rloc,
-                                                                     const PanelItem* __restrict__ items,
-                                                                     uint32_t item_lo, uint32_t n_items, uint32_t base,
-                                                                     uint32_t* __restrict__ ctr,
-                                                                     const double* __restrict__ cB,
-                                                                     double* __restrict__ part_acc, uint32_t j_lo,
-                                                                     uint32_t j_hi, uint32_t n_nz, uint32_t zero_id,
-                                                                     uint32_t dbg) {
-  extern __shared__ __attribute__((aligned(16))) double acc[];
-  __shared__ uint32_t s_take;
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-  const uint32_t tid = threadIdx.x, t = tid & 3u, gq = tid >> 2, lane_off = t * 16u;
-  if (tid == 0) s_take = atomicAdd(ctr, 1u) - base;
-  __syncthreads();
-  uint32_t cur = s_take;
-  while (cur < n_items) {
-    const PanelItem I = items[item_lo + cur];
-    {  // clear the accumulators; the next item is asked for meanwhile
-      double2* a2 = reinterpret_cast<double2*>(acc);
-#pragma unroll
-      for (int k = 0; k < (int)(kPanelRows * kBatch / 2 / kPanelThreads); ++k) a2[(uint32_t)k * kPanelThreads + tid] = make_double2(0.0, 0.0);
-    }
-    __syncthreads();  // (everybody has read s_take)
-    if (tid == 0) s_take = atomicAdd(ctr, 1u) - base;
-    const uint32_t row0 = I.panel * kPanelRows;
-    const uint32_t r_lo = j_lo > row0 ? j_lo - row0 : 0u;
-    const uint32_t r_hi = j_hi > row0 ? min(j_hi - row0, kPanelRows) : 0u;
-    const bool cut = r_lo > 0u || r_hi < min(n_nz - row0, kPanelRows);
-    const v4i* sp = reinterpret_cast<const v4i*>(src + (size_t)I.edge0 * kPanelStep) + gq;
-    const v2u* rp = reinterpret_cast<const v2u*>(rloc + (size_t)I.edge0 * kPanelStep) + gq;
-    // the index streams are read once per sweep: non-temporal, so that they do not push gathered lines out of L2
-    v4i ix = __builtin_nontemporal_load(sp);
-    v2u rx = __builtin_nontemporal_load(rp);
-    for (uint32_t i = 0; i < I.steps; ++i) {
-      v4i nx = ix;
-      v2u nr = rx;
-      if (i + 1 < I.steps) {  // in flight beside the gathers
-        nx = __builtin_nontemporal_load(sp + (size_t)(i + 1) * (kPanelStep / 4));
-        nr = __builtin_nontemporal_load(rp + (size_t)(i + 1) * (kPanelStep / 4));
-      }
-      const uint32_t r0 = rx.x & 0xffffu, r1 = rx.x >> 16, r2 = rx.y & 0xffffu, r3 = rx.y >> 16;
-      uint32_t u0 = (uint32_t)ix.x, u1 = (uint32_t)ix.y, u2 = (uint32_t)ix.z, u3 = (uint32_t)ix.w;
-      if (cut) {
-        if (r0 < r_lo || r0 >= r_hi) u0 = zero_id;
-        if (r1 < r_lo || r1 >= r_hi) u1 = zero_id;
-        if (r2 < r_lo || r2 >= r_hi) u2 = zero_id;
-        if (r3 < r_lo || r3 >= r_hi) u3 = zero_id;
-      }
-#ifdef PPRHIP_TEST_HOOKS
-      if (dbg >> 8) { u0 &= dbg >> 8; u1 &= dbg >> 8; u2 &= dbg >> 8; u3 &= dbg >> 8; }  // (measurement: every gather inside the first ids)
-#endif
-      double2 x0, y0, x1, y1, x2, y2, x3, y3;
-      if (dbg & 1u) {  // (measurement: no gathers)
-        x0 = y0 = make_double2((double)u0, 1.0); x1 = y1 = make_double2((double)u1, 1.0);
-        x2 = y2 = make_double2((double)u2, 1.0); x3 = y3 = make_double2((double)u3, 1.0);
-      } else {
-        const double2* l0 = panel_line<WIDE>(cB, u0, lane_off);
-        const double2* l1 = panel_line<WIDE>(cB, u1, lane_off);
-        const double2* l2 = panel_line<WIDE>(cB, u2, lane_off);
-        const double2* l3 = panel_line<WIDE>(cB, u3, lane_off);
-        x0 = l0[0]; y0 = l0[4]; x1 = l1[0]; y1 = l1[4]; x2 = l2[0]; y2 = l2[4]; x3 = l3[0]; y3 = l3[4];
-      }
-      if (dbg & 2u) {  // (measurement: no LDS sums - one store keeps the loads alive)
-        const double z = ((x0.x + y0.y) + (x1.x + y1.y)) + ((x2.x + y2.y) + (x3.x + y3.y));
-        if (z == 12345.678) acc[tid] = z;
-      } else {
-        panel_add(acc, r0, t, x0, y0);
-        panel_add(acc, r1, t, x1, y1);
-        panel_add(acc, r2, t, x2, y2);
-        panel_add(acc, r3, t, x3, y3);
-      }
-      ix = nx;
-      rx = nr;
-    }
-    __syncthreads();
-    // the rows leave as whole lines: sixteen lanes per row, four rows per wave instruction
-    {
-      const uint32_t s = tid & 15u;
-#pragma unroll 4
-      for (uint32_t r = tid >> 4; r < kPanelRows; r += kPanelThreads / 16) {
-        if (r >= r_lo && r < r_hi && row0 + r < n_nz) {
-          const double v = acc[r * (uint32_t)kBatch + ((s + r) & 15u)];
-          __builtin_nontemporal_store(v, &part_acc[((size_t)I.line0 + (size_t)r * I.stride) * kBatch + s]);
-        }
-      }
-    }
-    __syncthreads();  // (the accumulators are read; s_take is written)
-    cur = s_take;
-  }
-}
-
-// The hub panels' parts: row j of a panel cut into S parts has S partial lines (one per item); this kernel adds them
-// into the first one, so that k_dense_apply_batch<true> reads one line per row (at stride S) whatever the panel.  A lane
-// per (row, column), the S loads of a lane independent of one another: a stream, not a chain.
-__global__ __launch_bounds__(256) void k_panel_reduce(double* __restrict__ part_acc, const uint32_t* __restrict__ row_piece0,
-                                                      uint32_t j_lo, uint32_t j_hi) {
-  const uint32_t j = j_lo + (blockIdx.x * 256u + threadIdx.x) / (uint32_t)kBatch, s = threadIdx.x % (uint32_t)kBatch;
-  if (j >= j_hi) return;
-  const uint32_t base = row_piece0[j], S = row_piece0[j + 1] - base;
-  if (S <= 1) return;
-  const double* p = part_acc + (size_t)base * kBatch + s;
-  double v = 0.0;
-  uint32_t k = 0;
-  for (; k + 8 <= S; k += 8) {
-    double x[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(p + (size_t)(k + i) * kBatch);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v += x[i];
-  }
-  for (; k < S; ++k) v += __builtin_nontemporal_load(p + (size_t)k * kBatch);
-  part_acc[(size_t)base * kBatch + s] = v;
-}
-
 // k_dense_apply: one thread per non-empty row (plus one for a source without in-edges, which
 // only ever receives returned dead-end mass): lands the row sum, detects the threshold crossing
 // and prepares the row for the next level in place.
@@ -1097,9 +947,6 @@ constexpr int kApplyGroups = 2;  // tiles of kApplyRows rows a workgroup carries
 constexpr int kApplyThreads = 512;  // 8 waves, 2 slots each: few enough slot arguments to stay in SGPRs
 constexpr int kSlotsPerWave = kBatch / (kApplyThreads / 64);
 
-// PART: the row sums arrive from k_dense_edges_panel (PartLayout): the lines [row_piece0[j], row_piece0[j + 1]) of
-// part_acc - one line for most rows, one per part of its panel for the hub rows; the line n_pieces is zero.
-template <bool PART>
 __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32_t* __restrict__ nz_rows, uint32_t n_nz,
                                                             const int32_t* __restrict__ zin_rows, uint32_t n_zin,
                                                             double* __restrict__ acc8,
@@ -1114,10 +961,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
                                                             unsigned long long* __restrict__ blk_pack8,
                                                             double* __restrict__ blk_dead8,
                                                             uint32_t* __restrict__ blk_ndead8, uint32_t part_base,
-                                                            uint32_t part_stride,
-                                                            const double* __restrict__ part_acc,
-                                                            const uint32_t* __restrict__ row_piece0,
-                                                            uint32_t n_pieces) {
+                                                            uint32_t part_stride) {
   // tiles [tile_lo, tile_hi) of one block of the sweep.  gs_mask: slots whose state writes the current array in place
   // (entry / in-place / flush, engine.hpp: GsState); entry_mask: those of them that add to what it holds.
   __shared__ double tile[kApplyGroups][kApplyRows][kBatch + 1];
@@ -1149,22 +993,6 @@ __global__ __launch_bounds__(kApplyThreads) void k_dense_apply_batch(const int32
       const uint32_t tl = tl0 + g;
       const bool in = tl < tile_hi;
       const uint32_t row0 = tl * kApplyRows;
-      if (PART) {
-        // a tile lies inside one panel: its rows have the same number S of partial lines, row r of the tile the lines
-        // base + r * S ... (S = 1 for all but the hub panels)
-        constexpr int kPer = kApplyRows * kBatch / kApplyThreads;  // rows a thread serves per tile
-        const bool any = in && row0 < n_nz;
-        const uint32_t base = any ? row_piece0[row0] : 0u;
-        const uint32_t S = any ? row_piece0[row0 + 1] - base : 0u;
-        const uint32_t sl = tid % kBatch;
-#pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-          const uint32_t r = ((uint32_t)i * (uint32_t)kApplyThreads + tid) / kBatch;
-          // (the parts of a hub panel's rows were added into their first line by k_panel_reduce)
-          tile[g][r][sl] = (any && row0 + r < n_nz) ? __builtin_nontemporal_load(&part_acc[((size_t)base + (size_t)r * S) * kBatch + sl]) : 0.0;
-        }
-        continue;
-      }
       // rows inside one 512-edge chunk are rewritten by plain stores every sweep; only the rows that
       // cross a chunk boundary are summed with atomics and have to be cleared for the next sweep
       const unsigned long long cw = in ? cross_bits[tl] : 0ull;
@@ -1866,44 +1694,6 @@ static int launch_dense_edges_bG(pprhip_graph* g, const int32_t* ci, const uint8
   return PPRHIP_OK;
 }
 
-// the same block over the row-panel copy: one launch, a workgroup per CU, items handed out by the queue
-static int launch_dense_edges_part(pprhip_graph* g, const double* cB, const GsBlock& B) {
-  const PartLayout& L = *g->pl;
-  const uint32_t p_lo = B.j_lo / kPanelRows, p_hi = std::min<uint32_t>(L.n_panels, (B.j_hi + kPanelRows - 1) / kPanelRows);
-  if (p_hi <= p_lo) return PPRHIP_OK;
-  const uint32_t i_lo = L.h_panel_item0[p_lo], i_hi = L.h_panel_item0[p_hi];
-  if (i_hi <= i_lo) return PPRHIP_OK;
-  const uint32_t grid = std::min<uint32_t>(i_hi - i_lo, (uint32_t)g->n_cus);
-#ifdef PPRHIP_TEST_HOOKS
-  static const uint32_t dbg = getenv("PPRHIP_PANEL_DBG") ? (uint32_t)strtoul(getenv("PPRHIP_PANEL_DBG"), nullptr, 0) : 0u;
-#else
-  const uint32_t dbg = 0u;
-#endif
-  if (((uint64_t)g->n + 1) * kBatch * sizeof(double) >= (1ull << 32))
-    k_dense_edges_panel<true><<<dim3(grid), dim3(kPanelThreads), kPanelLdsBytes, g->stream>>>(
-        L.src, L.rloc, L.items, i_lo, i_hi - i_lo, g->part_ctr_next, g->part_ctr, cB, g->part_acc, B.j_lo, B.j_hi, g->n_nz, g->n, dbg);
-  else
-    k_dense_edges_panel<false><<<dim3(grid), dim3(kPanelThreads), kPanelLdsBytes, g->stream>>>(
-        L.src, L.rloc, L.items, i_lo, i_hi - i_lo, g->part_ctr_next, g->part_ctr, cB, g->part_acc, B.j_lo, B.j_hi, g->n_nz, g->n, dbg);
-  PPRHIP_CHECK_HIP(hipGetLastError());
-  // every workgroup takes items until one is beyond the window: the window's items + one failing take per workgroup
-  g->part_ctr_next += (i_hi - i_lo) + grid;
-  // rows of panels that were cut into parts: the parts' lines -> the row's first line (the panels are ordered by their
-  // edge counts, so the cut ones are the first: host-side bound)
-  uint32_t p_cut = p_lo;
-  while (p_cut < p_hi && L.h_panel_item0[p_cut + 1] - L.h_panel_item0[p_cut] > 1) ++p_cut;
-  for (uint32_t p = p_cut; p < p_hi; ++p)
-    if (L.h_panel_item0[p + 1] - L.h_panel_item0[p] > 1) p_cut = p + 1;  // (any order of panels: cover the last cut one)
-  if (p_cut > p_lo) {
-    const uint32_t r_lo = std::max(B.j_lo, p_lo * kPanelRows), r_hi = std::min(std::min(B.j_hi, g->n_nz), p_cut * kPanelRows);
-    if (r_hi > r_lo) {
-      k_panel_reduce<<<dim3(((r_hi - r_lo) * kBatch + 255) / 256), dim3(256), 0, g->stream>>>(g->part_acc, L.row_piece0, r_lo, r_hi);
-      PPRHIP_CHECK_HIP(hipGetLastError());
-    }
-  }
-  return PPRHIP_OK;
-}
-
 #ifdef PPRHIP_TEST_HOOKS
 // measurement (PPRHIP_COUNT_LIVE): how many of a sweep's gathers fetch a line that is zero in every column?
 // out[0] += out-degrees of the nodes whose line holds a non-zero, out[1] += such nodes
@@ -1935,8 +1725,7 @@ int launch_count_live_lines(pprhip_graph* P, unsigned long long* d_out) {
 
 #ifdef PPRHIP_TEST_HOOKS
 // the edge kernel of one block of a batched forward sweep alone (pprhip_hook_time_sweep_edges)
-int launch_sweep_edges_only(pprhip_graph* P, const GsBlock& B, bool part) {
-  if (part) return launch_dense_edges_part(P, P->c8[P->c8cur], B);
+int launch_sweep_edges_only(pprhip_graph* P, const GsBlock& B) {
   return launch_dense_edges_bG<kBatch>(P, P->in_ci, P->start_flags, P->chunk_starts, P->c8[P->c8cur], P->acc8, B);
 }
 #endif
@@ -1964,15 +1753,13 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_bloc
   const uint32_t n_rows = n_nz + n_z;
   const uint32_t n_tiles = (n_rows + kApplyRows - 1) / kApplyRows;
   const GsBlock whole{0u, n_nz, 0ull, (unsigned long long)P->m};
-  const bool part = !backward && P->pl && P->part_acc;  // forward sweeps walk the source-partitioned copy
   const bool cut = gs_mask && gs_blocks && n_gs_blocks > 1 && !backward;
   const GsBlock* blocks = cut ? gs_blocks : &whole;
   const int nb = cut ? n_gs_blocks : 1;
   uint32_t part_base = 0;
   for (int b = 0; b < nb; ++b) {
     const GsBlock& B = blocks[b];
-    if (part) PPRHIP_TRY(launch_dense_edges_part(P, P->c8[P->c8cur], B));
-    else PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8, B));
+    PPRHIP_TRY(launch_dense_edges_bG<kBatch>(P, ci, flags, cstarts, P->c8[P->c8cur], P->acc8, B));
     // block boundaries are multiples of 256 row ordinals, so tiles never straddle; the rows without in-edges
     // follow the last block.  The last block's rows are read by nobody again in this sweep (the next sweep reads the
     // other array), so only the blocks before it write the current array in place.
@@ -1981,16 +1768,10 @@ int launch_dense_level_b8(pprhip_graph* P, bool backward, const GsBlock* gs_bloc
     if (t_hi <= t_lo) continue;
     const uint32_t quota = kApplyBlocks8 / (uint32_t)nb;
     const uint32_t grid = std::max(1u, std::min((t_hi - t_lo + kApplyGroups - 1) / kApplyGroups, quota));
-    if (part)
-      k_dense_apply_batch<true><<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
-          nz, n_nz, zr, n_z, P->acc8, P->out_rp, nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo, t_hi,
-          b == nb - 1 ? 0u : gs_mask, b == nb - 1 ? 0u : entry_mask, P->d_slot_args, cross, P->prep_bits, P->blk_pack8,
-          P->blk_dead8, P->blk_ndead8, part_base, kApplyBlocks8, P->part_acc, P->pl->row_piece0, P->pl->n_pieces);
-    else
-      k_dense_apply_batch<false><<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
+    k_dense_apply_batch<<<dim3(grid), dim3(kApplyThreads), 0, P->stream>>>(
           nz, n_nz, zr, n_z, P->acc8, P->out_rp, backward ? P->in_rp : nullptr, P->c8[P->c8cur], P->c8[P->c8cur ^ 1], t_lo,
           t_hi, b == nb - 1 ? 0u : gs_mask, b == nb - 1 ? 0u : entry_mask, P->d_slot_args, cross, P->prep_bits,
-          P->blk_pack8, P->blk_dead8, P->blk_ndead8, part_base, kApplyBlocks8, nullptr, nullptr, 0u);
+          P->blk_pack8, P->blk_dead8, P->blk_ndead8, part_base, kApplyBlocks8);
     PPRHIP_CHECK_HIP(hipGetLastError());
     part_base += grid;
   }
@@ -2116,14 +1897,9 @@ int init_kernels_push() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
-  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_panel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLdsBytes));
-  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_panel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLdsBytes));
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sparse_push<kBackward>)));
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch<false>)));
-  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch<true>)));
+  PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch)));
   return PPRHIP_OK;
 }
 

@@ -443,96 +443,6 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
   return PPRHIP_OK;
 }
 
-// ---- row-panel copy of the in-CSR (engine_internal.hpp: HostPartLayout).  Pass A, one thread: edges, parts and
-// offsets per panel; pass B, all threads, panels handed out in order: a panel's edges as keys source << 16 | local row,
-// sorted, written part by part with the padding - the arrays are the same with any thread count.
-int build_part_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,
-                      uint32_t n_nz, unsigned threads, HostPartLayout& L) {
-  PhaseClock clk;
-  const unsigned T = (m < (1u << 20)) ? 1u : std::max(1u, threads ? threads : host_threads());
-  L.n_nz = n_nz;
-  L.n_panels = (n_nz + kPanelRows - 1) / kPanelRows;
-  L.zero_id = n;
-  const size_t NP = L.n_panels;
-  L.panel_item0.assign(NP + 1, 0);
-  L.row_piece0.assign((size_t)n_nz + 1, 0);
-  std::vector<uint64_t> panel_edges(NP, 0);
-  uint64_t items = 0, steps = 0, pieces = 0;
-  for (size_t t = 0; t < NP; ++t) {
-    const uint32_t j_lo = (uint32_t)t * kPanelRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(t + 1) * kPanelRows);
-    uint64_t e = 0;
-    for (uint32_t j = j_lo; j < j_hi; ++j) e += in_rp[(uint32_t)nz_rows[j] + 1] - in_rp[(uint32_t)nz_rows[j]];
-    panel_edges[t] = e;
-    const uint64_t S = std::max<uint64_t>(1, (e + kItemEdges - 1) / kItemEdges);
-    L.panel_item0[t] = (uint32_t)items;
-    for (uint32_t j = j_lo; j < j_hi; ++j) L.row_piece0[j] = (uint32_t)(pieces + (uint64_t)(j - j_lo) * S);
-    for (uint64_t k = 0; k < S; ++k) {
-      const uint64_t part = e * (k + 1) / S - e * k / S;
-      steps += (part + kPanelStep - 1) / kPanelStep;
-    }
-    items += S;
-    pieces += (uint64_t)(j_hi - j_lo) * S;
-    if (pieces >= 0xfffffff0ull || items >= 0xfffffff0ull || steps >= 0xfffffff0ull) {
-      L.n_pieces = L.n_items = 0;  // ordinals are 32-bit: keep the row-major sweep
-      return PPRHIP_OK;
-    }
-  }
-  L.panel_item0[NP] = (uint32_t)items;
-  L.row_piece0[n_nz] = (uint32_t)pieces;
-  L.n_items = (uint32_t)items;
-  L.n_pieces = (uint32_t)pieces;
-  L.n_edges = steps * kPanelStep;
-  L.items.assign((size_t)items, PanelItem{0, 0, 0, 0, 0, {0, 0, 0}});
-  {
-    uint64_t st = 0;
-    for (size_t t = 0; t < NP; ++t) {
-      const uint32_t i0 = L.panel_item0[t], S = L.panel_item0[t + 1] - i0;
-      const uint64_t e = panel_edges[t];
-      for (uint32_t k = 0; k < S; ++k) {
-        const uint64_t part = e * (k + 1) / S - e * k / S;
-        PanelItem& I = L.items[(size_t)i0 + k];
-        I.edge0 = (uint32_t)st;
-        I.steps = (uint32_t)((part + kPanelStep - 1) / kPanelStep);
-        I.panel = (uint32_t)t;
-        I.line0 = L.row_piece0[(size_t)t * kPanelRows] + k;
-        I.stride = S;
-        st += I.steps;
-      }
-    }
-  }
-  L.src.resize((size_t)L.n_edges);
-  L.rloc.resize((size_t)L.n_edges);
-  clk.mark("panels: offsets");
-  parallel_parts((unsigned)NP, T, [&](unsigned t) {
-    const uint32_t j_lo = t * kPanelRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(t + 1) * kPanelRows);
-    std::vector<uint64_t> key;
-    key.reserve((size_t)panel_edges[t]);
-    for (uint32_t j = j_lo; j < j_hi; ++j) {
-      const uint32_t v = (uint32_t)nz_rows[j];
-      for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) key.push_back((uint64_t)(uint32_t)in_ci[e] << 16 | (j - j_lo));
-    }
-    std::sort(key.begin(), key.end());
-    const uint32_t i0 = L.panel_item0[t], S = L.panel_item0[t + 1] - i0;
-    const uint64_t e = key.size();
-    for (uint32_t k = 0; k < S; ++k) {
-      const PanelItem& I = L.items[(size_t)i0 + k];
-      const uint64_t lo = e * k / S, hi = e * (k + 1) / S;
-      int32_t* so = L.src.data() + (size_t)I.edge0 * kPanelStep;
-      uint16_t* ro = L.rloc.data() + (size_t)I.edge0 * kPanelStep;
-      for (uint64_t x = lo; x < hi; ++x) {
-        so[x - lo] = (int32_t)(key[x] >> 16);
-        ro[x - lo] = (uint16_t)(key[x] & 0xffffu);
-      }
-      for (uint64_t x = hi - lo; x < (uint64_t)I.steps * kPanelStep; ++x) {
-        so[x] = (int32_t)n;
-        ro[x] = 0;
-      }
-    }
-  });
-  clk.mark("panels: edges");
-  return PPRHIP_OK;
-}
-
 }  // namespace detail
 }  // namespace pprhip
 
@@ -542,9 +452,6 @@ struct pprhip_lift {
   uint32_t n = 0;
   uint64_t m = 0;
   int threads = 0;
-  mutable bool have_part = false;  // the source-partitioned copy is built when one of its arrays is first asked for
-  mutable HostPartLayout part;
-  mutable uint64_t part_sizes[4] = {0, 0, 0, 0};  // panels, items, partial lines, edges with padding
 };
 
 extern "C" {
@@ -588,32 +495,6 @@ int pprhip_lift_array(const pprhip_lift_t* lift, int which, const void** data_ou
     return PPRHIP_OK;
   };
 #define PPRHIP_LIFT_VEC(v) give((v).data(), (v).size() * sizeof((v)[0]))
-  if (which >= PPRHIP_LIFT_PANEL_SIZES && which <= PPRHIP_LIFT_PANEL_ROW_PIECE0) {
-    if (!lift->have_part) {
-      try {
-        PPRHIP_TRY(build_part_layout(lift->n, lift->m, H.in_rp.data(), H.in_ci.data(), H.nz_rows.data(),
-                                     (uint32_t)H.nz_rows.size(), (unsigned)lift->threads, lift->part));
-      } catch (const std::bad_alloc&) {
-        set_error("pprhip_lift_array: out of host memory");
-        return PPRHIP_ERR_OOM;
-      }
-      lift->part_sizes[0] = lift->part.n_panels;
-      lift->part_sizes[1] = lift->part.n_items;
-      lift->part_sizes[2] = lift->part.n_pieces;
-      lift->part_sizes[3] = lift->part.n_edges;
-      lift->have_part = true;
-    }
-    const HostPartLayout& L = lift->part;
-    switch (which) {
-      case PPRHIP_LIFT_PANEL_SIZES: return give(lift->part_sizes, sizeof lift->part_sizes);
-      case PPRHIP_LIFT_PANEL_SRC: return PPRHIP_LIFT_VEC(L.src);
-      case PPRHIP_LIFT_PANEL_ROW: return PPRHIP_LIFT_VEC(L.rloc);
-      case PPRHIP_LIFT_PANEL_ITEMS: return PPRHIP_LIFT_VEC(L.items);
-      case PPRHIP_LIFT_PANEL_ITEM0: return PPRHIP_LIFT_VEC(L.panel_item0);
-      case PPRHIP_LIFT_PANEL_ROW_PIECE0: return PPRHIP_LIFT_VEC(L.row_piece0);
-      default: break;
-    }
-  }
   switch (which) {
     case PPRHIP_LIFT_NEW2OLD: return PPRHIP_LIFT_VEC(H.new2old);
     case PPRHIP_LIFT_OLD2NEW: return PPRHIP_LIFT_VEC(H.old2new);

@@ -347,58 +347,6 @@ def test_batch_driver_variants(pkg, orc, rmat15, env, monkeypatch):
         ref_g.close()
 
 
-@pytest.mark.parametrize("graph,relabel", [("got", "1"), ("rmat12", "1"), ("rmat15", "1"), ("rmat15", "0")])
-def test_source_partitioned_batched_sweep(pkg, orc, got, rmat12, rmat15, graph, relabel, monkeypatch):
-    """The batched forward sweep over the source-partitioned copy of the in-CSR (a sliced ELL since round 6: eight
-    partitions by source id & 7, workgroup b on partition b % 8, a quad of lanes per piece of a row, the pieces' partial
-    sums added by the apply kernel; PPRHIP_SWEEP_PANELS=1 forces it on graphs below its default size): Jacobi sweeps and
-    2- and 3-block Gauss-Seidel sweeps, level for level and value for value the twin's, and the same as the row-major
-    layout's (PPRHIP_SWEEP_PANELS=0) up to the order of the sums; in the degree-sorted vertex order and (PPRHIP_RELABEL=0)
-    in the caller's."""
-    host = {"got": got, "rmat12": rmat12, "rmat15": rmat15}[graph]
-    og = to_oracle(orc, host)
-    monkeypatch.setenv("PPRHIP_RELABEL", relabel)
-    monkeypatch.setenv("PPRHIP_SWEEP_PANELS", "1")
-    g_part = pkg.Graph(host)
-    srcs = ([0, 17, 42, 106, 90, 3] if graph == "got" else []) + sources(host, 15, seed=23)
-    g_row = pkg.Graph(host)
-    try:
-        for B in (1, 2, 3):
-            t = pkg.tuning_batch()
-            t.gs_blocks = B
-            if graph == "got":
-                t.dense_frac = 0.01
-            g_part.set_tuning(t)
-            g_row.set_tuning(t)
-            monkeypatch.setenv("PPRHIP_SWEEP_PANELS", "1")   # (read when a handle's batch state is built)
-            g_part.release(g_part.RELEASE_BATCH)
-            out, _, _, _, pq, st = g_part.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, fetch=True, per_query=True)
-            assert st.class_launches[5] > 0 and st.dense_levels > st.class_launches[5]    # sweeps shared by several queries
-            monkeypatch.setenv("PPRHIP_SWEEP_PANELS", "0")
-            g_row.release(g_row.RELEASE_BATCH)
-            out0, _, _, _, pq0, st0 = g_row.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, fetch=True, per_query=True)
-            # (how many sweeps served the levels depends on which queries stood ready when: the driver does not wait)
-            assert st0.dense_levels == st.dense_levels
-            assert np.max(np.abs(out - out0)) <= 1e-9
-            for i, s in enumerate(srcs):
-                assert pq[i].levels == pq0[i].levels and pq[i].walks == pq0[i].walks
-                if relabel == "1" and i % 3 == 0:
-                    ref, sto = og.fora_whole(s, 0.5, ALPHA, seed=9, n_rounds=0, schedule=orc.SYNC,
-                                             tuning=to_orc_tuning(orc, t))
-                    assert pq[i].rounds == sto.rounds and pq[i].walks == sto.walks and pq[i].levels == sto.levels
-                    assert_close(out[i], ref, TOL_MC, "partitioned sweep B=%d src=%d" % (B, s))
-        # a second call on the same batch state, and a rebuilt one
-        out2, _, _, _, _, _ = g_part.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, fetch=True)
-        monkeypatch.setenv("PPRHIP_SWEEP_PANELS", "1")
-        g_part.release(g_part.RELEASE_BATCH)
-        out3, _, _, _, _, _ = g_part.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, fetch=True)
-        out4, _, _, _, _, _ = g_part.fora_batch_single_source(srcs, 0.5, ALPHA, seed=9, fetch=True)
-        assert np.max(np.abs(out3 - out4)) <= 1e-12 and np.max(np.abs(out3 - out2)) <= 1e-9
-    finally:
-        g_part.close()
-        g_row.close()
-
-
 # ------------------------------------------------------------------ FORA top-k (a6, a7)
 @pytest.mark.parametrize("k", [1, 10, 50, 200])
 def test_fora_topk_got(pkg, orc, got, dev_got, k):

@@ -214,51 +214,6 @@ def test_index_merge_large_runs_on_all_threads(pkg):
 
 
 # ------------------------------------------------------------------ graph lift, host half (row a11; PPR.java:136-152)
-def _part_expected(n, m, in_rp, in_ci, nz_rows, panel=1024, step=1024, item_edges=32768):
-    """The row-panel copy of the in-CSR (engine_internal.hpp: HostPartLayout) restated with numpy sorts: panels of 1024
-    consecutive rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more than 32 768 edges is
-    cut into S = ceil(edges / 32 768) parts [e k / S, e (k + 1) / S); every part padded to whole turns of 1024 edges with
-    (n, 0); row j of a panel with S parts owns the partial lines [base + (j - first) S, + S)."""
-    indeg = np.diff(in_rp).astype(np.int64)
-    n_nz = nz_rows.size
-    n_panels = (n_nz + panel - 1) // panel
-    row_of_edge = np.repeat(np.arange(n, dtype=np.int64), indeg)
-    ordinal = np.cumsum(indeg > 0) - 1
-    j_of_edge = ordinal[row_of_edge]
-    p_of_edge = j_of_edge // panel
-    perm = np.lexsort((j_of_edge, in_ci, p_of_edge))       # panel, then source, then row
-    e_src, e_row, e_pan = in_ci[perm], (j_of_edge % panel)[perm], p_of_edge[perm]
-    edges_p = np.bincount(p_of_edge, minlength=n_panels).astype(np.int64)
-    S = np.maximum(1, (edges_p + item_edges - 1) // item_edges)
-    item0 = np.zeros(n_panels + 1, dtype=np.int64)
-    item0[1:] = np.cumsum(S)
-    n_items = int(item0[-1])
-    rows_p = np.minimum(panel, n_nz - np.arange(n_panels) * panel)
-    base = np.zeros(n_panels + 1, dtype=np.int64)
-    base[1:] = np.cumsum(rows_p * S)
-    j = np.arange(n_nz)
-    row_piece0 = np.append(base[j // panel] + (j % panel) * S[j // panel], base[-1]).astype(np.uint32)
-    items = np.zeros((n_items, 8), dtype=np.uint32)
-    first_edge = np.zeros(n_panels + 1, dtype=np.int64)
-    first_edge[1:] = np.cumsum(edges_p)
-    src_out, row_out = [], []
-    st = 0
-    for t in range(n_panels):
-        e = int(edges_p[t])
-        for k in range(int(S[t])):
-            lo, hi = e * k // int(S[t]), e * (k + 1) // int(S[t])
-            steps = (hi - lo + step - 1) // step
-            items[item0[t] + k, :5] = (st, steps, t, base[t] + k, S[t])
-            pad = steps * step - (hi - lo)
-            src_out += [e_src[first_edge[t] + lo:first_edge[t] + hi], np.full(pad, n, dtype=np.int32)]
-            row_out += [e_row[first_edge[t] + lo:first_edge[t] + hi].astype(np.uint16), np.zeros(pad, dtype=np.uint16)]
-            st += steps
-    src = np.concatenate(src_out).astype(np.int32) if src_out else np.empty(0, dtype=np.int32)
-    row = np.concatenate(row_out).astype(np.uint16) if row_out else np.empty(0, dtype=np.uint16)
-    return dict(panel_sizes=np.array([n_panels, n_items, base[-1], st * step], dtype=np.uint64), panel_src=src,
-                panel_row=row, panel_items=items.ravel(), panel_item0=item0.astype(np.uint32), panel_row_piece0=row_piece0)
-
-
 def _lift_expected(h, width=393216, chunk=512, max_windows=16):
     """The internal layout restated with numpy (stable sorts instead of the library's counting sort and threaded
     passes): vertex order = nodes with in-edges first, then out-degree descending, ties by id; rows keep their
@@ -303,7 +258,6 @@ def _lift_expected(h, width=393216, chunk=512, max_windows=16):
     np.bitwise_or.at(cross, j >> 6, np.uint64(1) << (j & 63).astype(np.uint64))
     exp = dict(new2old=new2old, old2new=old2new, out_rp=out_rp, out_ci=out_ci, in_rp=in_rp, in_ci=in_ci, nz_rows=nz_rows,
                zin_rows=zin_rows, flags=flags, chunk_starts=chunk_starts, cross=cross)
-    exp.update(_part_expected(n, m, in_rp, in_ci, nz_rows))
     n_src = int(np.nonzero(outdeg > 0)[0].max()) + 1 if (outdeg > 0).any() else 0
     S = (n_src + width - 1) // width
     if S > max_windows:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel times of the headline workload (one `rocprofv3 --kernel-trace --stats` pass, two timed steps), for A/B runs:
-#   gpurun -- 'PPRHIP_SWEEP_PANELS=1 tools/exp/job_kstats.sh tag'      -> gpurun_out/<tag>_kstats.txt (top kernels)
+#   gpurun -- 'tools/exp/job_kstats.sh tag'      -> gpurun_out/<tag>_kstats.txt (top kernels)
 set -o pipefail
 tag=${1:-kstats}
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out

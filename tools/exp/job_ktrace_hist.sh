@@ -1,6 +1,6 @@
 #!/bin/bash
 # Duration distribution of one kernel's launches in the headline workload (rocprofv3 --kernel-trace, two timed steps):
-#   gpurun -- 'PPRHIP_SWEEP_PANELS=1 tools/exp/job_ktrace_hist.sh tag k_dense_edges_ell k_dense_apply_batch'
+#   gpurun -- 'tools/exp/job_ktrace_hist.sh tag k_dense_edges_ell k_dense_apply_batch'
 #   -> gpurun_out/<tag>_khist.txt: per kernel name, launches grouped by grid size with min / median / mean / max us
 set -o pipefail
 tag=${1:-khist}; shift

@@ -1,5 +1,5 @@
 """Times the batched sweep's edge kernel alone on R-MAT `scale` (libpprhip_hooks.so: pprhip_hook_time_sweep_edges):
-whole sweep, block 0 and block 1 of two Gauss-Seidel blocks, row-major and source-partitioned.
+whole sweep, block 0 and block 1 of two Gauss-Seidel blocks.
     PPRHIP_LIB_PATH=.../libpprhip_hooks.so python tools/exp/sweep_edges_time.py [scale] [reps]"""
 import ctypes as C
 import importlib
@@ -17,20 +17,16 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     h = pkg.HostCsr.rmat(scale)
     lib = pkg.lib()
-    lib.pprhip_hook_time_sweep_edges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
-    for part in (1, 0):
-        os.environ["PPRHIP_SWEEP_PANELS"] = str(part)
-        with pkg.Graph(h, device=0) as g:
-            g.set_tuning(pkg.tuning_batch())
-            out = []
-            for block, nb in ((0, 1), (0, 2), (1, 2)):
-                us = C.c_double()
-                pkg._check(lib.pprhip_hook_time_sweep_edges(g.h, part, block, nb, reps, C.byref(us)))
-                out.append(us.value)
-            print("%s parts=%d: whole %.1f us, block 0 of 2 %.1f us, block 1 of 2 %.1f us" %
-                  (os.environ.get("TAG", ""), part, out[0], out[1], out[2]), flush=True)
-        if os.environ.get("ONLY_PART"):
-            break
+    lib.pprhip_hook_time_sweep_edges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    with pkg.Graph(h, device=0) as g:
+        g.set_tuning(pkg.tuning_batch())
+        out = []
+        for block, nb in ((0, 1), (0, 2), (1, 2)):
+            us = C.c_double()
+            pkg._check(lib.pprhip_hook_time_sweep_edges(g.h, block, nb, reps, C.byref(us)))
+            out.append(us.value)
+        print("%s whole %.1f us, block 0 of 2 %.1f us, block 1 of 2 %.1f us" % (os.environ.get("TAG", ""), out[0], out[1], out[2]),
+              flush=True)
 
 
 if __name__ == "__main__":
