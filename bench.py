@@ -66,6 +66,8 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+PKG_NAME = "personalized-pagerank-algorithms-on-neo4j_amd"
+HOOKS_LIB = os.path.join(ROOT, PKG_NAME, "libpprhip_hooks.so")  # the same sources with the test / measurement switches
 
 ALPHA = 0.15
 EPS = 0.5
@@ -148,6 +150,7 @@ def main():
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--all-pair-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rmat24-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--topk-ab-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rmat24-pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sources", default="", help=argparse.SUPPRESS)
@@ -159,6 +162,8 @@ def main():
         return all_pair_child(args)
     if args.rmat24_child:
         return rmat24_child(args)
+    if args.topk_ab_child:
+        return topk_ab_child(args)
     if args.rmat24_pmc_child:
         return rmat24_pmc_child(args)
     if args.cpu_baseline_child:
@@ -484,6 +489,9 @@ def main():
                 note("R-MAT 24 counter passes done")
             sweeps_alone(args, out["roofline"])
             note("sweeps-alone child done")
+            if extras and "topk_sample" in out:
+                out["topk_sample"]["same_box_ab"] = topk_same_box_ab(args)
+                note("top-k A/B children done")
             idle = stream_idle(args)
             out["compute_stream_idle_frac"] = idle.get("compute_stream_idle_frac")
             if idle.get("sweep_kernels"):
@@ -686,6 +694,42 @@ def topk_sample(pkg, g, srcs, count=None, single=32):
                                       if st.class_launches[c]}}}
 
 
+def topk_ab_child(args):
+    """One leg of topk_sample.same_box_ab: FORA top-k (k = 32) one query at a time on 48 live sources, rate on stdout."""
+    pkg = importlib.import_module(PKG_NAME)
+    host = load_host(pkg, args.scale)
+    live_ids = np.nonzero(np.diff(host.out_rp) > 0)[0].astype(np.int32)
+    srcs = live_draw(np.random.default_rng(2), live_ids, 128)[:48]
+    with pkg.Graph(host, device=0) as g:
+        g.set_tuning(pkg.tuning_default())
+        for s in srcs[:4]:
+            g.fora_topk(int(s), EPS, ALPHA, TOPK, seed=1)
+        best = 0.0
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for j, s in enumerate(srcs):
+                g.fora_topk(int(s), EPS, ALPHA, TOPK, seed=7 + j)
+            best = max(best, len(srcs) / (time.perf_counter() - t0))
+    print(json.dumps({"queries_per_s": round(best, 1)}), flush=True)
+
+
+def topk_same_box_ab(args):
+    """round 5's one-pass round-start kernels against the two-pass ones of rounds 1-4
+    (PPRHIP_TOPK_OLD_PASSES=1) on THIS box, back to back: two children on libpprhip_hooks.so (the switch is a measurement
+    switch, which the product library does not read), identical but for the variable."""
+    out = {}
+    for name, extra in (("one_pass", {}), ("old_passes", {"PPRHIP_TOPK_OLD_PASSES": "1"})):
+        env = dict(os.environ, PPRHIP_LIB_PATH=HOOKS_LIB, **extra)
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--topk-ab-child", "--scale", str(args.scale)],
+                                 env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        res = _child_json(child, 150, "the top-k A/B child (%s)" % name)
+        out[name] = res.get("queries_per_s", res)
+    if all(isinstance(v, float) for v in out.values()):
+        out["one_pass_over_old"] = round(out["one_pass"] / out["old_passes"], 3)
+    out["what"] = "one query at a time, 48 live sources, best of two passes, libpprhip_hooks.so in child processes"
+    return out
+
+
 def index_column_check(off, tg, vl, targets, column_of, thr, k, tol=1e-12, slack=0.0, tie=1e-9, source_range=None):
     """Columns of an All-Pair index against backward searches of the same targets (Base_Whole_Graph.java:76-92 and the
     k rule of :112-163).  off / tg / vl: the index (CSR by source, rows value-descending); column_of(t) -> the dense
@@ -774,9 +818,13 @@ def all_pair_sample(pkg, g, host, nt=1 << 18):
     nt = min(host.n, nt)
     ix, _ = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, min(nt, 4096))
     ix.close()
+    # every class timed around this call (the parent runs at level 2 - the sweeps only - since round 5, which left this
+    # sample's kernel time, rate and roofline at zero in BENCH_r05.json)
+    was = pkg.set_kernel_timing(True)
     t0 = time.perf_counter()
     ix, st = g.all_pair_backward(ALPHA, AP_THR, TOPK, 0, nt)
     dt = time.perf_counter() - t0
+    pkg.set_kernel_timing(was)
     off, tg, vl = ix.arrays()
     ix.close()
     try:
@@ -792,6 +840,9 @@ def all_pair_sample(pkg, g, host, nt=1 << 18):
 
 def all_pair_report(pkg, st, nt, dt, entries):
     ms, by, nl = st.class_ms[4], st.class_bytes[4], st.class_launches[4]
+    if nl > 0 and not ms > 0:  # launches counted but not timed: a roofline of zeros would be a lie, say so instead
+        return {"error": "backward_batch: %d launches with no kernel time (kernel timing was not on around the call)" % nl,
+                "value": round(nt / dt, 1), "unit": "targets/s", "targets": nt, "seconds": round(dt, 3)}
     ach = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
     return {"value": round(nt / dt, 1), "unit": "targets/s", "targets": nt, "threshold": AP_THR, "k": TOPK,
             "seconds": round(dt, 3), "index_entries": entries,
@@ -1370,7 +1421,9 @@ def sweeps_alone(args, roofline):
            "--queries-per-step", str(args.queries_per_step), "--no-cpu-baseline", "--no-pmc", "--no-extras", "--no-rmat24"]
     if args.tuning:
         cmd += ["--tuning", args.tuning]
-    env = dict(os.environ, PPRHIP_BATCH_SLOTS_BESIDE="0", PPRHIP_BATCH_WALKS_BESIDE="0")
+    # (the two switches are measurement switches: read by libpprhip_hooks.so only - the same sources with the test hooks)
+    env = dict(os.environ, PPRHIP_BATCH_SLOTS_BESIDE="0", PPRHIP_BATCH_WALKS_BESIDE="0",
+               PPRHIP_LIB_PATH=HOOKS_LIB)
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     res = _child_json(child, 240, "the sweeps-alone child")
     if "error" in res:

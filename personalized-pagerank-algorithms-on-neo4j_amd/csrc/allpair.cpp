@@ -217,7 +217,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
   CallTimer tm(g);
   const uint32_t n_targets = t_end - t_begin;
   // PPRHIP_APBS_TIER = 2 / 3 starts at a later tier (tests exercise every tier that way)
-  const int first_tier = getenv("PPRHIP_APBS_TIER") ? atoi(getenv("PPRHIP_APBS_TIER")) : 1;
+  const int first_tier = hook_env("PPRHIP_APBS_TIER") ? atoi(hook_env("PPRHIP_APBS_TIER")) : 1;
 
   // ---- device buffers of this call
   ApbsBuffers B;
@@ -341,7 +341,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     release();
     return rc;
   }
-  const bool dbg_times = getenv("PPRHIP_APBS_DEBUG") != nullptr;
+  const bool dbg_times = hook_env("PPRHIP_APBS_DEBUG") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [&](std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<double, std::milli>(now() - t).count();
@@ -357,13 +357,13 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     if (g->apbs_blocks == 0) {
       // (PPRHIP_APBS_CAP_T / _CAP_F shrink the lists so that tests reach the overflow paths on small graphs,
       // PPRHIP_APBS_CHUNK the chunks of a level's edge space so that small graphs' levels are shared too)
-      const char* e_t = getenv("PPRHIP_APBS_CAP_T");
-      const char* e_f = getenv("PPRHIP_APBS_CAP_F");
-      const char* e_c = getenv("PPRHIP_APBS_CHUNK");
+      const char* e_t = hook_env("PPRHIP_APBS_CAP_T");
+      const char* e_f = hook_env("PPRHIP_APBS_CAP_F");
+      const char* e_c = hook_env("PPRHIP_APBS_CHUNK");
       const uint32_t chunk = e_c ? (uint32_t)std::max(16, atoi(e_c)) : apbs_default_chunk();
       const uint32_t cap_t = e_t ? (uint32_t)std::max(1, atoi(e_t)) : std::min<uint32_t>(g->n, 1u << 20) + 4096u;
       const uint32_t cap_f = e_f ? (uint32_t)std::max(1, atoi(e_f)) : std::min<uint32_t>(g->n, 1u << 20) + 64u;
-      const char* per_cu = getenv("PPRHIP_APBS_WGS_PER_CU");
+      const char* per_cu = hook_env("PPRHIP_APBS_WGS_PER_CU");
       uint32_t want = (uint32_t)g->n_cus * (uint32_t)std::max(1, std::min(2, per_cu ? atoi(per_cu) : 1));
       const size_t per = apbs_dense_bytes(g->n, g->m, cap_t, cap_f, chunk);
       int arc = PPRHIP_ERR_OOM;
@@ -440,7 +440,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       // Developer switch PPRHIP_APBS_DEBUG: per-workgroup timers and a progress word in HOST memory, and a watchdog
       // thread that prints the progress words and ends the process when the tier has not come back after 20 s
       // (a kernel that never ends would otherwise only be seen as a process that cannot be killed).
-      const bool debug = getenv("PPRHIP_APBS_DEBUG") != nullptr;
+      const bool debug = hook_env("PPRHIP_APBS_DEBUG") != nullptr;
       std::mutex wd_mu;
       std::condition_variable wd_cv;
       bool wd_done = false;
@@ -520,7 +520,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
     // pprhip_backward_push's path.  Measured (tools/exp/apbs_big_searches.py): 2.5 ms of device time for that target
     // against 158 ms in the full-size pass below, where one workgroup owns the search and the others help with its
     // levels at the rate of memory-side atomics.  The entries go from the reserve vector into records on the device.
-    const char* whole_env = getenv("PPRHIP_APBS_WHOLE");
+    const char* whole_env = hook_env("PPRHIP_APBS_WHOLE");
     const size_t whole_max = whole_env ? (size_t)std::max(0, atoi(whole_env)) : 256;
     if (rc == PPRHIP_OK && !to_tier3.empty() && to_tier3.size() <= whole_max) {
       TripleRec* d_rec = nullptr;
@@ -559,7 +559,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
       to_tier3.clear();
     }
     if (rc == PPRHIP_OK && g->apbs_blocks && !to_tier3.empty() && to_tier3.size() < to_tier2.size() &&
-        !getenv("PPRHIP_APBS_NO_XL")) {
+        !hook_env("PPRHIP_APBS_NO_XL")) {
       if (!g->apbs_xl_ws) {
         const uint32_t xl_t = g->n + 4096u, xl_f = g->n + 64u;
         uint32_t want = 4;
@@ -589,7 +589,7 @@ int all_pair_collect(pprhip_graph_t* g, double alpha, double threshold, uint32_t
         B.cap_f = g->apbs_xl_cap_f;
         B.helpers = g->apbs_blocks;
         std::vector<int32_t> again3;
-        const bool xdebug = getenv("PPRHIP_APBS_DEBUG") != nullptr;
+        const bool xdebug = hook_env("PPRHIP_APBS_DEBUG") != nullptr;
         const uint32_t xnb = std::max(g->apbs_blocks, g->apbs_xl_blocks);
         if (xdebug && hipHostMalloc((void**)&B.dbg, sizeof(unsigned long long) * 12 * xnb, hipHostMallocMapped) == hipSuccess)
           std::memset(B.dbg, 0, sizeof(unsigned long long) * 12 * xnb);
@@ -781,7 +781,7 @@ int index_from_device(pprhip_graph* g, const TripleRec* rec, unsigned long long 
     set_error("index: source range [%u, %u) outside [0, %u)", v_lo, v_hi, g->n);
     return PPRHIP_ERR_INVALID;
   }
-  const bool dbg = getenv("PPRHIP_APBS_DEBUG") != nullptr;
+  const bool dbg = hook_env("PPRHIP_APBS_DEBUG") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   std::unique_ptr<pprhip_index> ix(new (std::nothrow) pprhip_index());
@@ -893,7 +893,7 @@ int pprhip_all_pair_backward(pprhip_graph_t* g, double alpha, double threshold, 
     set_error("pprhip_all_pair_backward: index finalisation: %s", e.what());
     return PPRHIP_ERR_OOM;
   }
-  if (getenv("PPRHIP_APBS_DEBUG"))
+  if (hook_env("PPRHIP_APBS_DEBUG"))
     fprintf(stderr, "[apbs host] searches + hand-over %.1f ms, index finalisation %.1f ms\n",
             std::chrono::duration<double, std::milli>(t1 - t0).count(),
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());

@@ -88,7 +88,7 @@ RcclApi* rccl() {
   std::call_once(once, [] {
     // PPRHIP_RCCL_LIB names the library to bind instead (a site's own build; tests/fixtures/fake_rccl.cpp, the test
     // double that lets one GPU run the RCCL branch with several ranks)
-    const char* own = getenv("PPRHIP_RCCL_LIB");
+    const char* own = tuning_env("PPRHIP_RCCL_LIB");
     if (own && *own) {
       api.lib = dlopen(own, RTLD_NOW | RTLD_LOCAL);
     } else {
@@ -166,7 +166,7 @@ struct LocalGroup {
 constexpr unsigned long long kFailedWord = ~0ull;  // size word of a rank that takes part in an exchange only to say it failed
 
 double comm_timeout_s() {
-  const char* e = getenv("PPRHIP_COMM_TIMEOUT_S");
+  const char* e = tuning_env("PPRHIP_COMM_TIMEOUT_S");
   const double v = e ? atof(e) : 0.0;
   return v > 0.0 ? v : 1800.0;
 }
@@ -175,9 +175,9 @@ double comm_timeout_s() {
 // ("search", the default: before anything was found; "partition": after the search, before the exchange;
 // "exchange": inside the exchange, after the sizes are known), so that the failure protocol can be exercised
 bool fault_injected(int rank, const char* at) {
-  const char* r = getenv("PPRHIP_FAULT_RANK");
+  const char* r = hook_env("PPRHIP_FAULT_RANK");
   if (!r || atoi(r) != rank) return false;
-  const char* where = getenv("PPRHIP_FAULT_AT");
+  const char* where = hook_env("PPRHIP_FAULT_AT");
   if (strcmp(where ? where : "search", at) != 0) return false;
   set_error("injected fault on rank %d (%s)", rank, at);
   return true;
@@ -533,7 +533,7 @@ int decide_target_cuts(pprhip_comm* c, double alpha, double threshold, std::vect
   std::vector<uint64_t> off((size_t)W + 1, 0), roff;
   if (c->rank == 0 && rc == PPRHIP_OK) {
     try {
-      const char* e = getenv("PPRHIP_SHARD_CUT");
+      const char* e = tuning_env("PPRHIP_SHARD_CUT");
       const bool by_work = e ? (e[0] == 'w') : equal_count_skew(g, W) > 1.15;
       if (by_work) {
         rc = weighted_target_cuts(g, W, alpha, threshold, cuts);
@@ -951,7 +951,7 @@ int setup_ranks(pprhip_graph_t* const* per_gpu, int n_gpu, RankSetup& S, const c
   S.rcs.assign((size_t)n_gpu, PPRHIP_OK);
   // (PPRHIP_FORCE_RCCL=1, test switch: the RCCL branch although the handles share a device - only the test double of
   // tests/fixtures/fake_rccl.cpp accepts that)
-  S.use_rccl = (distinct || getenv("PPRHIP_FORCE_RCCL") != nullptr) && n_gpu > 1;
+  S.use_rccl = (distinct || hook_env("PPRHIP_FORCE_RCCL") != nullptr) && n_gpu > 1;
   S.local.world = n_gpu;
   S.local.send.assign((size_t)n_gpu, nullptr);
   S.local.send_off.assign((size_t)n_gpu, {});

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,16 @@ const char* get_error();
     int _rc = (expr);          \
     if (_rc != PPRHIP_OK) return _rc; \
   } while (0)
+
+// Environment.  The product library (libpprhip.so) reads the six tuning variables that include/pprhip.h documents and no
+// others; fault injection, diagnostics on stderr and the measurement switches of the A/B runs are read by
+// libpprhip_hooks.so only (the same sources with -DPPRHIP_TEST_HOOKS: the tests that need them and tools/exp load that).
+inline const char* tuning_env(const char* name) { return getenv(name); }
+#ifdef PPRHIP_TEST_HOOKS
+inline const char* hook_env(const char* name) { return getenv(name); }
+#else
+inline const char* hook_env(const char*) { return nullptr; }
+#endif
 
 // Layout constants shared by graph build (host) and kernels (device).
 constexpr int kChunkPad = 512;  // in-edges one wave of the dense pull sweep owns (8 per lane)

@@ -27,7 +27,7 @@ std::atomic<int> g_kernel_timing{-1};
 bool kernel_timing_on() {
   int v = g_kernel_timing.load(std::memory_order_relaxed);
   if (v < 0) {
-    const char* e = getenv("PPRHIP_KERNEL_TIMER");
+    const char* e = hook_env("PPRHIP_KERNEL_TIMER");
     v = (e && e[0] == '1') ? 1 : 0;
     g_kernel_timing.store(v, std::memory_order_relaxed);
   }
@@ -112,7 +112,7 @@ int alloc_dev(void** p, size_t bytes) {
   // test switch: PPRHIP_FAIL_ALLOC_AFTER=<n> makes the n-th device allocation made while it is set fail as the device
   // running out of memory would (the count starts over whenever the variable is not there)
   static std::atomic<long> armed_count{0};
-  if (const char* fe = getenv("PPRHIP_FAIL_ALLOC_AFTER")) {
+  if (const char* fe = hook_env("PPRHIP_FAIL_ALLOC_AFTER")) {
     if (armed_count.fetch_add(1) + 1 == atol(fe)) {
       *p = nullptr;
       set_error("hipMalloc(%zu bytes) failed: injected (PPRHIP_FAIL_ALLOC_AFTER)", bytes);
@@ -536,7 +536,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
     // The batch's levels from wg_from on run in ONE launch on one workgroup as long as they stay small
     // (k_sparse_levels_wg): from the first level when that is small itself, else behind one or two levels of the
     // usual two launches each - a frontier of 2^16 entries + edges or more rarely falls below the cap in one level.
-    static const bool wg_on = !(getenv("PPRHIP_SPARSE_WG") && getenv("PPRHIP_SPARSE_WG")[0] == '0');
+    static const bool wg_on = !(hook_env("PPRHIP_SPARSE_WG") && hook_env("PPRHIP_SPARSE_WG")[0] == '0');
     constexpr unsigned long long kWgCap = 4096;
     const unsigned long long size0 = (unsigned long long)L.nf + L.ef;
     const int wg_from = (!wg_on || cut_check) ? n_batch
@@ -573,7 +573,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
         *model_cost += c;
       }
       const uint32_t nf_next = (uint32_t)(g->h_ctr->hist[i + 1] >> kPackShift);
-      static const bool level_trace = getenv("PPRHIP_LEVEL_TRACE") != nullptr;  // developer switch: a line per sparse level
+      static const bool level_trace = hook_env("PPRHIP_LEVEL_TRACE") != nullptr;  // developer switch: a line per sparse level
       if (level_trace) fprintf(stderr, "[level] mode %d batch-level %d nf %u ef %llu\n", a.mode, i, nf_i, (unsigned long long)ef_i);
       st.pops += nf_i;
       st.edge_pushes += ef_i;
@@ -1551,7 +1551,7 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
   }
   if ((rc = up((void**)&G->zin_rows, H.zin_rows.data(), sizeof(int32_t) * H.zin_rows.size()))) return fail(rc);
   if ((rc = up((void**)&G->cross_bits, H.cross.data(), sizeof(unsigned long long) * H.cross.size()))) return fail(rc);
-  if (getenv("PPRHIP_LIFT_DEBUG")) {
+  if (hook_env("PPRHIP_LIFT_DEBUG")) {
     const auto t_up = std::chrono::steady_clock::now();
     fprintf(stderr, "[pprhip lift] host half %.1f ms, uploads %.1f ms\n",
             std::chrono::duration<double, std::milli>(t_lift1 - t_lift0).count(),
@@ -1952,7 +1952,7 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
   // most of the chip idle - and selection run on the compute stream, the next round's push runs on a
   // second stream, with counters of its own that only join the query's when the round turns out to be needed.  The
   // one push that was not (after the last round) costs no time: it ends before that round's walks do.
-  const char* spec_env = getenv("PPRHIP_TOPK_AHEAD");
+  const char* spec_env = hook_env("PPRHIP_TOPK_AHEAD");
   const bool spec_on = !(spec_env && spec_env[0] == '0') && ensure_spec(g) == PPRHIP_OK;
   bool pushed_ahead = false;        // this round's push, residue sum and walk plan have already run (second stream)
   bool ahead_discarded = false;     // the last push ahead was not needed
@@ -1998,7 +1998,7 @@ int pprhip_fora_topk(pprhip_graph_t* g, int32_t src, double eps, const pprhip_fo
     if (spec_on) PPRHIP_CHECK_HIP(hipEventRecord(g->spec_ev[0], g->stream));  // residues and reserve have been read
     // :155-168: the walk kernel reads the plan's counts on the device: no host round trip between push and selection
     static const uint32_t topk_waves = [] {  // PPRHIP_TOPK_WALK_WAVES: measurement switch
-      const char* e = getenv("PPRHIP_TOPK_WALK_WAVES");
+      const char* e = hook_env("PPRHIP_TOPK_WALK_WAVES");
       return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 8u;
     }();
     g->walk_waves = spec_on ? topk_waves : 0u;  // (the next round's push runs beside these walks: leave it room)

@@ -63,7 +63,7 @@ namespace {
 constexpr uint32_t kSideWalkWavesDefault = 4;  // waves per CU of a walk phase that runs beside sweeps (batch_sequential)
 static uint32_t side_walk_waves() {  // PPRHIP_SIDE_WALK_WAVES: measurement switch
   static const uint32_t v = [] {
-    const char* e = getenv("PPRHIP_SIDE_WALK_WAVES");
+    const char* e = hook_env("PPRHIP_SIDE_WALK_WAVES");
     const long x = e ? atol(e) : 0;
     return x > 0 && x <= 32 ? (uint32_t)x : kSideWalkWavesDefault;
   }();
@@ -205,7 +205,7 @@ int fora_step(ForaRun& r, bool yield_dense) {
       }
       if (!r.dead_src) {
         // (a worker's walks run beside the other slots' sweeps as well: the same narrow grid as on the side stream)
-        if (g->sync && !getenv("PPRHIP_WORKER_WALK_WIDE")) g->walk_waves = kSideWalkWaves;
+        if (g->sync && !hook_env("PPRHIP_WORKER_WALK_WIDE")) g->walk_waves = kSideWalkWaves;
         const int rc = run_walk_phase(g, 0, r.alpha, r.rsum_local, nrw, r.seed, 0, g->reserve, r.st);
         g->walk_waves = 0;
         PPRHIP_TRY(rc);
@@ -517,7 +517,7 @@ int launch_sweep(pprhip_graph* P, ForaRun* runs, const bool* active, int n_activ
   // small kernel).  Taken out.)
 #ifdef PPRHIP_TEST_HOOKS
   {  // PPRHIP_COUNT_LIVE=1 (measurement): share of a sweep's gathers that fetch a line with a non-zero, on stderr
-    static const bool on = getenv("PPRHIP_COUNT_LIVE") != nullptr;
+    static const bool on = hook_env("PPRHIP_COUNT_LIVE") != nullptr;
     static unsigned long long* d_cnt = nullptr;
     static unsigned long long sweeps = 0;
     if (on && !backward) {
@@ -652,7 +652,7 @@ int begin_query(BatchJob& J, ForaRun& r, pprhip_graph* S, int i) {
 static hipStream_t side_stream_for_walks(pprhip_graph* P) {
   if (!P->walk_stream_tried) {
     P->walk_stream_tried = true;
-    const char* e = getenv("PPRHIP_BATCH_WALKS_BESIDE");
+    const char* e = hook_env("PPRHIP_BATCH_WALKS_BESIDE");
     if (!(e && e[0] == '0') && make_side_stream(P, &P->walk_stream) != PPRHIP_OK) P->walk_stream = nullptr;
   }
   if (P->walk_stream)  // (every call: workspaces may have joined since)
@@ -672,7 +672,7 @@ static hipStream_t side_stream_for_walks(pprhip_graph* P) {
 static hipStream_t stream_for_slots(pprhip_graph* P) {
   if (!P->slot_stream_tried) {
     P->slot_stream_tried = true;
-    const char* e = getenv("PPRHIP_BATCH_SLOTS_BESIDE");
+    const char* e = hook_env("PPRHIP_BATCH_SLOTS_BESIDE");
     if (!(e && e[0] == '0')) {
       if (make_side_stream(P, &P->slot_stream, P->walk_stream) != PPRHIP_OK) P->slot_stream = nullptr;
       if (!P->slot_stream && P->walk_stream && make_side_stream(P, &P->slot_stream) != PPRHIP_OK) P->slot_stream = nullptr;
@@ -729,7 +729,7 @@ struct SlotDriver {
     n_ws = kBatch;
     if (pool) {
       int want = kDefaultWs;
-      if (const char* e = getenv("PPRHIP_BATCH_WORKSPACES")) want = std::max(kBatch, std::min(kMaxWs, atoi(e)));
+      if (const char* e = tuning_env("PPRHIP_BATCH_WORKSPACES")) want = std::max(kBatch, std::min(kMaxWs, atoi(e)));
       if (want > kBatch && ensure_workspaces(P, want) != PPRHIP_OK) {  // (no memory for them: one per column)
         (void)hipGetLastError();
         want = kBatch;
@@ -747,7 +747,7 @@ struct SlotDriver {
     }
     // the workspaces' read-backs look after the sweep in flight while they wait (only worth it when they wait on
     // another stream than the sweep's)
-    if (slots_on && slots_on != P->stream && !getenv("PPRHIP_BATCH_NO_HOOK")) {
+    if (slots_on && slots_on != P->stream && !hook_env("PPRHIP_BATCH_NO_HOOK")) {
       P->idle_hook = &SlotDriver::on_idle;
       P->idle_arg = this;
     }
@@ -769,7 +769,7 @@ struct SlotDriver {
     if (D->flying) {
       if (!sweep_arrived(D->P, D->ticket)) return;
     } else {  // nothing on the compute stream (a call's first queries are still starting): whoever stands ready goes
-      static const bool early = getenv("PPRHIP_BATCH_NO_EARLY") == nullptr;
+      static const bool early = hook_env("PPRHIP_BATCH_NO_EARLY") == nullptr;
       if (!early) return;
       bool any = false;
       for (int w = 0; w < D->n_ws && !any; ++w) any = D->runs[w].query >= 0 && D->runs[w].waiting;
@@ -875,7 +875,7 @@ struct SlotDriver {
   }
   // PPRHIP_DRIVER_PROFILE=1: host time of a turn by part, printed when the driver ends (developer switch)
   struct Prof {
-    bool on = getenv("PPRHIP_DRIVER_PROFILE") != nullptr;
+    bool on = hook_env("PPRHIP_DRIVER_PROFILE") != nullptr;
     double us[6] = {0};
     unsigned long long n[6] = {0};
     std::chrono::steady_clock::time_point t;
@@ -1007,7 +1007,7 @@ struct SlotDriver {
 // query's latency.  PPR.java:179's 50 queries per call = 3 x 16 + 2: 178 -> 172 ms per call.
 constexpr int kTailSingle = 3;
 int tail_queries(const BatchJob& J) {
-  return (J.kind == 0 && J.q > kBatch && J.q % kBatch <= kTailSingle && !getenv("PPRHIP_BATCH_NO_TAIL")) ? J.q % kBatch : 0;
+  return (J.kind == 0 && J.q > kBatch && J.q % kBatch <= kTailSingle && !hook_env("PPRHIP_BATCH_NO_TAIL")) ? J.q % kBatch : 0;
 }
 int run_tail(BatchJob& J, int q_slots) {
   for (int i = q_slots; i < J.q; ++i) {  // the stragglers, one at a time on the handle's own vectors
@@ -1376,7 +1376,7 @@ int pprhip::detail::batch_run(pprhip_graph_t* g, BatchJob& J, pprhip_stats_t* st
   const int q = J.q;
   // Worker threads pay off where queries are latency-bound (top-k: short rounds of sparse levels, walks
   // and selections, 2.4x on R-MAT 22); whole-graph FORA keeps the memory system busy from one thread.
-  const char* env = getenv("PPRHIP_BATCH_THREADS");
+  const char* env = tuning_env("PPRHIP_BATCH_THREADS");
   const bool threaded = q > 1 && (env ? env[0] == '1' : J.kind != 0);
   std::memset(&J.sum, 0, sizeof J.sum);
   // vectors go to the caller's memory behind the queries' backs (a synchronous copy of 8n bytes to pageable memory per
@@ -1692,7 +1692,7 @@ void stream_driver(pprhip_stream* s) {
   // test switch: PPRHIP_STREAM_FAULT_AT=<n> makes the driver fail when it is about to start the stream's n-th query
   // (0-based), as a failing kernel launch would: every open and later submission ends with the driver's error
   long fault_at = -1, started = 0;
-  if (const char* fe = getenv("PPRHIP_STREAM_FAULT_AT")) fault_at = atol(fe);
+  if (const char* fe = hook_env("PPRHIP_STREAM_FAULT_AT")) fault_at = atol(fe);
   bool injected = false;
   D.next = [&](BatchJob** job, int* i) {
     if (fault_at >= 0 && started == fault_at) {

@@ -1365,14 +1365,14 @@ int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint
       set_error("All-Pair dense tier: no target list or workspace");
       return PPRHIP_ERR_STATE;
     }
-    const char* sh = getenv("PPRHIP_APBS_SHARE");  // developer switch: 0 = every search stays on its own workgroup
+    const char* sh = hook_env("PPRHIP_APBS_SHARE");  // developer switch: 0 = every search stays on its own workgroup
     const int share = (sh && sh[0] == '0') ? 0 : 1;
     const uint32_t owners = std::min<uint32_t>(std::min<uint32_t>(b.ws_blocks, (uint32_t)kDnThreads), std::max(1u, n_targets));
     // helpers beyond the owners (b.helpers: workgroups the launch may use in all) only make sense when levels are shared
     const uint32_t grid = share ? std::max(owners, std::min<uint32_t>(b.helpers, (uint32_t)kDnThreads)) : owners;
     // ids whose residue / reserve live in the owner's LDS (dn_edge_range): 8 K by default (128 KB), at most a quarter
     // of the graph so that small graphs still run both paths (PPRHIP_APBS_HOT: developer / test switch, 0 = none)
-    const char* he = getenv("PPRHIP_APBS_HOT");
+    const char* he = hook_env("PPRHIP_APBS_HOT");
     uint32_t hot_n = he ? (uint32_t)std::max(0, atoi(he)) : (uint32_t)kDnHotDefault;
     hot_n = std::min<uint32_t>(std::min<uint32_t>(hot_n, (uint32_t)kDnHotMax), g->n / 4);
     // Workgroups also help between two searches of their own when the pass is short (below 2^17 targets): there the
@@ -1380,7 +1380,7 @@ int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint
     // 2^18 / 2^19 targets of the range: 49.5 -> 44.3 ms / 79.1 -> 74.9 ms.  A long pass has no idle end to shorten
     // (17 workgroup-ms of 138 000 at 617 K searches) and pays for the looks at the boards and the races for chunks:
     // 139 -> 144 ms at 2^20 targets, 540 -> 586 ms at all 2^22.  (PPRHIP_APBS_HELP_BETWEEN=0|1: test switch.)
-    const char* hb = getenv("PPRHIP_APBS_HELP_BETWEEN");
+    const char* hb = hook_env("PPRHIP_APBS_HELP_BETWEEN");
     const int help_between = hb ? (hb[0] != '0') : (n_targets < (1u << 17));
     k_apbs_dense<<<dim3(grid), dim3(kDnThreads), 2 * sizeof(double) * (size_t)hot_n, g->stream>>>(
         d_targets, n_targets, b.next_target, g->in_rp, rec, g->old2new, g->new2old, alpha, rmax, O, b.ws, (DnBoard*)b.board,
@@ -1397,7 +1397,7 @@ int launch_apbs(pprhip_graph* g, bool dense_tier, const int32_t* d_targets, uint
     // (R-MAT 22, searches of all 4.19 M targets: 3,9 649 ms / 4,12 655 / 6,16 667 / 4,24 665 / all through both tables
     // 783; R-MAT 24: 4,12 1 894 ms / 3,9 2 019)
     uint32_t deg_big = 4, deg_dense = 12;
-    if (const char* de = getenv("PPRHIP_APBS_DEG")) {
+    if (const char* de = hook_env("PPRHIP_APBS_DEG")) {
       unsigned a = 0, c = 0;
       if (sscanf(de, "%u,%u", &a, &c) == 2) {
         deg_big = a ? a : 0xFFFFFFFFu;

@@ -1559,7 +1559,7 @@ int launch_sparse_push(pprhip_graph* g, const PushArgs& a, int fbuf, int level, 
   const uint32_t* trp = bwd ? g->in_rp : g->out_rp;
   const int32_t* tci = bwd ? g->in_ci : g->out_ci;
   // (the override exists for the tests, which run the table on graphs far below the default switch-over)
-  const char* comb_env = getenv("PPRHIP_COMB_MIN_EDGES");
+  const char* comb_env = hook_env("PPRHIP_COMB_MIN_EDGES");
   const unsigned long long comb_min = comb_env ? strtoull(comb_env, nullptr, 10) : (unsigned long long)kCombMinEdges;
   DISPATCH_MODE(a.mode, k_sparse_push<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
                             g->F[fbuf], g->cF, g->eoff[fbuf], trp, tci, g->out_ext, g->in_rp, g->residue, g->flags,
@@ -1575,7 +1575,7 @@ int launch_sparse_levels_wg(pprhip_graph* g, const PushArgs& a, int fbuf0, int f
   const bool bwd = a.mode == kBackward;
   const uint32_t* trp = bwd ? g->in_rp : g->out_rp;
   const int32_t* tci = bwd ? g->in_ci : g->out_ci;
-  const char* comb_env = getenv("PPRHIP_COMB_MIN_EDGES");
+  const char* comb_env = hook_env("PPRHIP_COMB_MIN_EDGES");
   const unsigned long long comb_min = comb_env ? strtoull(comb_env, nullptr, 10) : (unsigned long long)kCombMinEdges;
   DISPATCH_MODE(a.mode, k_sparse_levels_wg<M><<<dim3(1), dim3(256), 0, g->stream>>>(
                             g->F[0], g->F[1], g->eoff[0], g->eoff[1], g->out_rp, g->residue, g->reserve, g->cF, trp, tci,
@@ -1664,7 +1664,7 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
 // LDS table of the batched edge kernel.  PPRHIP_SWEEP_HOT_KB (measurement switch): its size in KB, at most 128.
 static uint32_t sweep_hot_bytes() {
   static const uint32_t v = [] {
-    const char* e = getenv("PPRHIP_SWEEP_HOT_KB");
+    const char* e = hook_env("PPRHIP_SWEEP_HOT_KB");
     const long kb = e ? atol(e) : 0;
     return kb >= 0 && e && kb * 1024 <= kHotBytes ? (uint32_t)(kb * 1024) : (uint32_t)kHotDefaultBytes;
   }();
@@ -1823,7 +1823,7 @@ int launch_count_active(pprhip_graph* g, const PushArgs& a, int seed_kind, int o
 }
 
 bool old_small_kernels() {  // PPRHIP_TOPK_OLD_PASSES=1 (measurement switch): the two-pass kernels of rounds 1-4
-  static const bool v = getenv("PPRHIP_TOPK_OLD_PASSES") != nullptr;
+  static const bool v = hook_env("PPRHIP_TOPK_OLD_PASSES") != nullptr;
   return v;
 }
 

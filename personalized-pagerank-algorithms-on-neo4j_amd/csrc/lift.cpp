@@ -28,7 +28,7 @@ namespace detail {
 unsigned host_threads() {
   static const unsigned n = [] {
     unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    if (const char* e = getenv("PPRHIP_HOST_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));
+    if (const char* e = tuning_env("PPRHIP_HOST_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
       char q[32] = {0};
       double period = 0;
@@ -51,7 +51,7 @@ namespace {
 struct PhaseClock {  // PPRHIP_LIFT_DEBUG=1: phase times of the lift on stderr
   bool on;
   std::chrono::steady_clock::time_point t;
-  PhaseClock() : on(getenv("PPRHIP_LIFT_DEBUG") != nullptr), t(std::chrono::steady_clock::now()) {}
+  PhaseClock() : on(hook_env("PPRHIP_LIFT_DEBUG") != nullptr), t(std::chrono::steady_clock::now()) {}
   void mark(const char* what) {
     if (!on) return;
     const auto now = std::chrono::steady_clock::now();
@@ -215,7 +215,7 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
   // (PPRHIP_RELABEL=0 keeps ids).  The rows a sweep applies (nodes with in-edges) are then the ids [0, n_nz): their
   // residue / reserve / contribution entries are contiguous and every line a sweep touches is used in full; inside
   // that range the most-gathered contributions (highest out-degree) still come first (hot table, slices).
-  const char* env = getenv("PPRHIP_RELABEL");
+  const char* env = hook_env("PPRHIP_RELABEL");
   H.relabeled = !(env && env[0] == '0');
   H.new2old.resize(n);
   H.old2new.resize(n);
@@ -328,11 +328,11 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
   // has out-edges; no layout when they fit one slice.
   H.S = 0;
   H.n_seg = 0;
-  const char* off = getenv("PPRHIP_SLICED");
+  const char* off = hook_env("PPRHIP_SLICED");
   if (off && off[0] == '0') return PPRHIP_OK;
   uint32_t n_src = n;  // ids above the last node with out-edges are never gathered
   while (n_src > 0 && orp[n_src] == orp[n_src - 1]) --n_src;
-  const char* wenv = getenv("PPRHIP_SLICE_IDS");
+  const char* wenv = hook_env("PPRHIP_SLICE_IDS");
   uint64_t width = wenv ? strtoull(wenv, nullptr, 10) : 393216ull;  // 3 MB of contributions per slice
   if (width < 1) width = 1;
   uint64_t S = ((uint64_t)n_src + width - 1) / width;

@@ -1,7 +1,10 @@
 """Shared fixtures.  GPU tests are marked `gpu` and call the HIP engine through the C ABI;
 everything else runs on CPU (oracle, host logic, library load/export checks)."""
 import importlib
+import importlib.util
+import inspect
 import os
+import re
 import sys
 
 import numpy as np
@@ -17,17 +20,70 @@ GOT_NODES = os.path.join(ROOT, "tests", "golden", "got", "GOT_Nodes.csv")
 GOT_RELS = os.path.join(ROOT, "tests", "golden", "got", "GOT_Rels.csv")
 
 
+# The product library reads six tuning variables (include/pprhip.h, "Environment").  Every other PPRHIP_* switch - fault
+# injection, layout and driver variants, measurement switches - exists in libpprhip_hooks.so only (the same sources built
+# with -DPPRHIP_TEST_HOOKS).  A test whose body names such a switch (or that is marked `hooks`) gets the package bound to
+# that library; every other test runs the product, libpprhip.so.  Both live in this process side by side.
+PRODUCT_ENV = {"PPRHIP_HOST_THREADS", "PPRHIP_COMM_TIMEOUT_S", "PPRHIP_RCCL_LIB", "PPRHIP_BATCH_WORKSPACES",
+               "PPRHIP_BATCH_THREADS", "PPRHIP_SHARD_CUT", "PPRHIP_LIB_PATH", "PPRHIP_FUZZ_SEEDS"}
+HOOKS_LIB = os.path.join(ROOT, PKG_NAME, "libpprhip_hooks.so")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "hooks: runs on libpprhip_hooks.so (test switches compiled in)")
 
 
 def load_pkg():
     return importlib.import_module(PKG_NAME)
 
 
+_hooks_mod = None
+
+
+def load_hooks_pkg():
+    """The package a second time, bound to libpprhip_hooks.so (a make asan-test run points both at its own build)."""
+    global _hooks_mod
+    if _hooks_mod is None:
+        if os.environ.get("PPRHIP_LIB_PATH"):
+            _hooks_mod = load_pkg()
+            return _hooks_mod
+        pkg_dir = os.path.join(ROOT, PKG_NAME)
+        spec = importlib.util.spec_from_file_location("pprhip_hooks_pkg", os.path.join(pkg_dir, "__init__.py"),
+                                                      submodule_search_locations=[pkg_dir])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["pprhip_hooks_pkg"] = mod
+        os.environ["PPRHIP_LIB_PATH"] = HOOKS_LIB
+        try:
+            spec.loader.exec_module(mod)
+        finally:
+            del os.environ["PPRHIP_LIB_PATH"]
+        _patch_set_tuning(mod)
+        _hooks_mod = mod
+    return _hooks_mod
+
+
+def wants_hooks(node):
+    if node.get_closest_marker("hooks") is not None:
+        return True
+    fn = getattr(node, "function", None)
+    try:
+        src = inspect.getsource(fn) if fn is not None else ""
+    except (OSError, TypeError):
+        src = ""
+    names = set(re.findall(r"PPRHIP_[A-Z][A-Z0-9_]*[A-Z0-9]", src))
+    names = {x for x in names if not x.startswith(("PPRHIP_OK", "PPRHIP_ERR", "PPRHIP_RELEASE", "PPRHIP_KERNEL_", "PPRHIP_LIFT_"))}
+    return bool(names - PRODUCT_ENV)
+
+
 @pytest.fixture(scope="session")
-def pkg():
+def pkg_product():
     return load_pkg()
+
+
+@pytest.fixture
+def pkg(request, pkg_product):
+    return load_hooks_pkg() if wants_hooks(request.node) else pkg_product
 
 
 @pytest.fixture(scope="session")
@@ -48,12 +104,13 @@ def to_oracle(orc, host):
 
 
 @pytest.fixture(scope="session")
-def got(pkg):
-    return pkg.HostCsr.from_neo4j_csv(GOT_NODES, GOT_RELS)
+def got(pkg_product):
+    return pkg_product.HostCsr.from_neo4j_csv(GOT_NODES, GOT_RELS)
 
 
 @pytest.fixture(scope="session")
-def toy_graphs(pkg):
+def toy_graphs(pkg_product):
+    pkg = pkg_product
     """Small graphs with closed-form answers / awkward structure."""
     g = {}
     g["two_node"] = edges_to_host(pkg, 2, [(0, 1)])                      # Dissertation p.13-14
@@ -65,29 +122,36 @@ def toy_graphs(pkg):
 
 
 @pytest.fixture(scope="session")
-def rmat12(pkg):
-    return pkg.HostCsr.rmat(12, 16, seed=1)
+def rmat12(pkg_product):
+    return pkg_product.HostCsr.rmat(12, 16, seed=1)
 
 
 @pytest.fixture(scope="session")
-def rmat15(pkg):
-    return pkg.HostCsr.rmat(15, 16, seed=1)
+def rmat15(pkg_product):
+    return pkg_product.HostCsr.rmat(15, 16, seed=1)
 
 
-@pytest.fixture(autouse=True, scope="session")
-def _twin_follows_engine_tuning(pkg):
-    """Since the Gauss-Seidel sweeps the level shapes (dense_frac, gs_blocks, gs_frac) change the push schedule, so
-    the twin's entry points that take no tuning argument (forward_push, topk_push, fora_topk) must run with the
-    tuning the engine was given: every Graph.set_tuning in a test also sets the twin's."""
+def _patch_set_tuning(mod):
     from oracle import oracle
-    oracle.build()
-    orig = pkg.Graph.set_tuning
+    orig = mod.Graph.set_tuning
 
     def set_tuning(self, t):
         orig(self, t)
         oracle.set_sync_tuning(t)
 
-    pkg.Graph.set_tuning = set_tuning
+    mod.Graph.set_tuning = set_tuning
+    return orig
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _twin_follows_engine_tuning(pkg_product):
+    """Since the Gauss-Seidel sweeps the level shapes (dense_frac, gs_blocks, gs_frac) change the push schedule, so
+    the twin's entry points that take no tuning argument (forward_push, topk_push, fora_topk) must run with the
+    tuning the engine was given: every Graph.set_tuning in a test also sets the twin's (load_hooks_pkg does the same
+    for the package bound to the hooks library)."""
+    from oracle import oracle
+    oracle.build()
+    orig = _patch_set_tuning(pkg_product)
     yield
-    pkg.Graph.set_tuning = orig
+    pkg_product.Graph.set_tuning = orig
     oracle.set_sync_tuning(None)

@@ -15,7 +15,8 @@ A = 0.15
 
 
 @pytest.fixture(scope="module")
-def replicas(pkg, rmat12):
+def replicas(pkg_product, rmat12):
+    pkg = pkg_product
     gs = [pkg.Graph(rmat12) for _ in range(3)]
     for g in gs:
         g.set_tuning(pkg.tuning_batch())

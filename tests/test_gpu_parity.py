@@ -20,21 +20,24 @@ TOL_MC = 1e-9
 
 
 @pytest.fixture(scope="module")
-def dev_got(pkg, got):
+def dev_got(pkg_product, got):
+    pkg = pkg_product
     g = pkg.Graph(got)
     yield g
     g.close()
 
 
 @pytest.fixture(scope="module")
-def dev_rmat12(pkg, rmat12):
+def dev_rmat12(pkg_product, rmat12):
+    pkg = pkg_product
     g = pkg.Graph(rmat12)
     yield g
     g.close()
 
 
 @pytest.fixture(scope="module")
-def dev_rmat15(pkg, rmat15):
+def dev_rmat15(pkg_product, rmat15):
+    pkg = pkg_product
     g = pkg.Graph(rmat15)
     yield g
     g.close()

@@ -42,21 +42,24 @@ def golden():
 
 
 @pytest.fixture(scope="module")
-def dev_got(pkg, got):
+def dev_got(pkg_product, got):
+    pkg = pkg_product
     g = pkg.Graph(got)
     yield g
     g.close()
 
 
 @pytest.fixture(scope="module")
-def dev_rmat12(pkg, rmat12):
+def dev_rmat12(pkg_product, rmat12):
+    pkg = pkg_product
     g = pkg.Graph(rmat12)
     yield g
     g.close()
 
 
 @pytest.fixture(scope="module")
-def got_undirected(pkg, got):
+def got_undirected(pkg_product, got):
+    pkg = pkg_product
     """GOT with every relationship in both directions: no dead ends, the setting the thesis states for
     backward search (Diss. p.19, p.31), so that its columns equal the power method's."""
     e = []

@@ -13,12 +13,14 @@ A = 0.15
 
 
 @pytest.fixture(scope="module")
-def rmat20(pkg):
+def rmat20(pkg_product):
+    pkg = pkg_product
     return pkg.HostCsr.rmat(20, 16, seed=1)
 
 
 @pytest.fixture(scope="module")
-def dev20(pkg, rmat20):
+def dev20(pkg_product, rmat20):
+    pkg = pkg_product
     g = pkg.Graph(rmat20)
     yield g
     g.close()
@@ -204,7 +206,8 @@ def check_columns_against_oracle(orc, og, arrays, targets, thr, k, fifo_for=None
 
 
 @pytest.fixture(scope="module")
-def full_index20(pkg, rmat20):
+def full_index20(pkg_product, rmat20):
+    pkg = pkg_product
     """All 2^20 targets of R-MAT 20 with the default settings: tier 1 in its three steps (targets routed by in-degree),
     the dense tier with levels shared at their natural sizes, the entries sorted on the device and the k rule applied
     by index_from_sorted."""

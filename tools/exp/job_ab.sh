@@ -4,6 +4,7 @@
 #   -> gpurun_out/<tag>_ab.txt: one line per configuration (value, ms per step, sweeps per query)
 set -o pipefail
 tag=$1; shift
+export PPRHIP_LIB_PATH=${PPRHIP_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/personalized-pagerank-algorithms-on-neo4j_amd/libpprhip_hooks.so}  # (the switches these jobs set are test hooks)
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out
 : > $out/${tag}_ab.txt
 for cfg in "$@"; do

@@ -3,6 +3,7 @@
 #   gpurun -- 'tools/exp/job_kstats.sh tag'      -> gpurun_out/<tag>_kstats.txt (top kernels)
 set -o pipefail
 tag=${1:-kstats}
+export PPRHIP_LIB_PATH=${PPRHIP_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/personalized-pagerank-algorithms-on-neo4j_amd/libpprhip_hooks.so}  # (the switches these jobs set are test hooks)
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out
 export TMPDIR=/tmp
 cd /tmp

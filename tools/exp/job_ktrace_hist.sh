@@ -4,6 +4,7 @@
 #   -> gpurun_out/<tag>_khist.txt: per kernel name, launches grouped by grid size with min / median / mean / max us
 set -o pipefail
 tag=${1:-khist}; shift
+export PPRHIP_LIB_PATH=${PPRHIP_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/personalized-pagerank-algorithms-on-neo4j_amd/libpprhip_hooks.so}  # (the switches these jobs set are test hooks)
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out
 export TMPDIR=/tmp
 cd /tmp

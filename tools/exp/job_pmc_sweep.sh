@@ -2,6 +2,7 @@
 # Issue and memory-path counters of the batched sweep's kernels (k_dense_edges_b / k_dense_apply_batch) in the headline
 # workload, one rocprofv3 --pmc pass per counter set (own runs, no trace domains).   gpurun -- tools/exp/job_pmc_sweep.sh
 set -o pipefail
+export PPRHIP_LIB_PATH=${PPRHIP_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/personalized-pagerank-algorithms-on-neo4j_amd/libpprhip_hooks.so}  # (the switches these jobs set are test hooks)
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
