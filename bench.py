@@ -466,6 +466,8 @@ def main():
         extras = solo and not args.no_extras
         if extras:
             out.update(q50_sample(pkg, g, store, rng, live_ids, conf, value))
+            out["config4_share_rates"] = config4_share_sample(pkg, g, store, rng, live_ids, conf)
+            note("config #4 share rates done")
             out.update(delivery_samples(pkg, g, store, rng, live_ids, host, conf, q))
             note("delivery samples done")
             out["one_query_at_a_time"] = single_mode_sample(pkg, g, srcs[args.warmup], conf, args, host)
@@ -573,6 +575,42 @@ def _q50_sample(pkg, g, store, rng, live_ids, conf, value_128, calls, q, srcs):
     except Exception as e:  # noqa: BLE001
         out["value_q50_stream"] = None
         out["value_q50_stream_note"] = "failed: %s" % str(e)[:200]
+    return out
+
+
+def config4_share_sample(pkg, g, store, rng, live_ids, conf, calls=5):
+    """Config #4 sharded over N GPUs gives every GPU a call of ceil(50 / N) queries (Gen_Util.java:208-232: 50 queries;
+    SURVEY 8(e): GPU g takes the sources i mod N = g): calls of 25, 13 and 7 live sources on THIS GPU, under the plain batch
+    profile and under pprhip_tuning_batch_for(q), which values a dense level by the columns a call of q can fill.  From the
+    times, what N such GPUs would deliver for the 50 queries (the slowest share decides; the gather of 50 x 32 pairs is
+    microseconds) - a prediction from one GPU, not a measurement of N."""
+    was = pkg.set_kernel_timing(False)
+    out = {"what": "calls of q live sources, %d calls each, vectors kept on the device, top-%d per query" % (calls, TOPK),
+           "shares": {}}
+    try:
+        t50 = None
+        for q in (50, 25, 13, 7):
+            srcs = live_draw(rng, live_ids, (calls + 1, q))
+            row = {}
+            for name, tun in (("batch_profile", pkg.tuning_batch()), ("profile_for_q", pkg.tuning_batch_for(q))):
+                g.set_tuning(tun)
+                g.fora_batch_single_source(srcs[0], EPS, ALPHA, seed=61, k=TOPK, conf=conf, keep=store)
+                t0 = time.perf_counter()
+                for i in range(1, calls + 1):
+                    g.fora_batch_single_source(srcs[i], EPS, ALPHA, seed=61 + i, k=TOPK, conf=conf, keep=store)
+                dt = (time.perf_counter() - t0) / calls
+                row[name] = {"queries_per_s": round(q / dt, 1), "ms_per_call": round(1e3 * dt, 2)}
+            best = min(row["batch_profile"]["ms_per_call"], row["profile_for_q"]["ms_per_call"])
+            if q == 50:
+                t50 = best
+            else:
+                n_gpus = {25: 2, 13: 4, 7: 8}[q]
+                row["predicted_strong_scaling"] = {"gpus": n_gpus, "queries_per_s": round(50 / (best / 1e3), 1),
+                                                   "speedup_over_one_gpu": round(t50 / best, 2)}
+            out["shares"]["q%d" % q] = row
+    finally:
+        g.set_tuning(pkg.tuning_batch())
+        pkg.set_kernel_timing(was)
     return out
 
 

@@ -155,6 +155,11 @@ void pprhip_tuning_default(pprhip_tuning_t* t);
 /* Cost-model constants for pprhip_fora_batch_single_source: a dense level costs a query 1/PPRHIP_BATCH
  * of a sweep, so the model values it lower and lets levels go dense earlier. */
 void pprhip_tuning_batch(pprhip_tuning_t* t);
+/* The batch profile for a call of q queries (Gen_Util.java:208-232 runs 50; sharded over 8 GPUs a call holds 6-7): with
+ * fewer than PPRHIP_BATCH - 1 busy columns a dense level costs each query more, so the dense constants, dense_frac and
+ * gs_frac grow with 14.5 / q, up to the single-query profile's values.  q >= 15: pprhip_tuning_batch.  The caller sets it
+ * (pprhip_graph_set_tuning) before the call; every query of the call then is pprhip_fora_single_source under it. */
+void pprhip_tuning_batch_for(int q, pprhip_tuning_t* t);
 
 /* ---------------------------------------------------------------- parameter derivation (a10) */
 /* Algo_Conf.set_conf_fora_whole_graph (Algo_Conf.java:45-53): delta = pfail = 1/n, rsum = 1. */

@@ -76,7 +76,7 @@ EXPORTS = [
     "pprhip_all_pair_backward", "pprhip_index_merge", "pprhip_index_info", "pprhip_index_arrays",
     "pprhip_index_write_dir", "pprhip_index_destroy", "pprhip_power_method", "pprhip_index_from_arrays",
     "pprhip_format_double", "pprhip_edgelist_from_neo4j_store", "pprhip_edgelist_build_csr",
-    "pprhip_fora_batch_single_source", "pprhip_tuning_batch", "pprhip_results_create", "pprhip_results_destroy",
+    "pprhip_fora_batch_single_source", "pprhip_tuning_batch", "pprhip_tuning_batch_for", "pprhip_results_create", "pprhip_results_destroy",
     "pprhip_results_info", "pprhip_results_fetch", "pprhip_results_sum", "pprhip_fora_batch_single_source_resident",
     "pprhip_fora_batch", "pprhip_all_pair_backward_multi", "pprhip_comm_unique_id", "pprhip_comm_create",
     "pprhip_comm_destroy", "pprhip_comm_info", "pprhip_shard_target_range", "pprhip_all_pair_backward_sharded",
@@ -108,6 +108,8 @@ def lib():
     L.pprhip_tuning_default.restype = None
     L.pprhip_tuning_batch.argtypes = [P(Tuning)]
     L.pprhip_tuning_batch.restype = None
+    L.pprhip_tuning_batch_for.argtypes = [ci, P(Tuning)]
+    L.pprhip_tuning_batch_for.restype = None
     L.pprhip_conf_fora_whole_graph.argtypes = [u32, u64, dbl, P(ForaConf)]
     L.pprhip_conf_fora_topk.argtypes = [u32, u64, ci, dbl, P(ForaConf)]
     L.pprhip_fora_whole_params.argtypes = [P(ForaConf), dbl, P(dbl), P(dbl)]
@@ -363,6 +365,13 @@ def tuning_default():
 def tuning_batch():
     t = Tuning()
     lib().pprhip_tuning_batch(C.byref(t))
+    return t
+
+
+def tuning_batch_for(q):
+    """The batch profile for a call of q queries (pprhip_tuning_batch_for)."""
+    t = Tuning()
+    lib().pprhip_tuning_batch_for(int(q), C.byref(t))
     return t
 
 

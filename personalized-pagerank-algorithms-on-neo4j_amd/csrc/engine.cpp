@@ -1405,6 +1405,23 @@ void pprhip_tuning_batch(pprhip_tuning_t* t) {
   t->gs_frac = 0.05;
 }
 
+// The batch profile for a call of q queries on one GPU (config #4's shares: 50 queries over 8 GPUs are 6-7 per call).  A
+// sweep costs the same whatever the number of busy columns, so a dense level costs each query of a small call more:
+// the dense constants and the level-shape thresholds scale with 14.5 / min(q, 14.5) columns, up to the single-query
+// profile's values (a call of one IS the single-query path).  Chosen by the caller before the first query starts, so
+// every query of the call is pprhip_fora_single_source under the same tuning.
+void pprhip_tuning_batch_for(int q, pprhip_tuning_t* t) {
+  pprhip_tuning_batch(t);
+  if (!t || q >= 15) return;
+  pprhip_tuning_t one;
+  pprhip_tuning_default(&one);
+  const double scale = 14.5 / (double)std::max(1, q);
+  t->c_dense_edge_ns = std::min(one.c_dense_edge_ns, t->c_dense_edge_ns * scale);
+  t->c_dense_node_ns = std::min(one.c_dense_node_ns, t->c_dense_node_ns * scale);
+  t->dense_frac = std::min(one.dense_frac, t->dense_frac * scale);
+  t->gs_frac = std::min(one.gs_frac, t->gs_frac * scale);
+}
+
 int pprhip_conf_fora_whole_graph(uint32_t n, uint64_t m, double alpha, pprhip_fora_conf_t* c) {
   if (!c || n == 0) {
     set_error("pprhip_conf_fora_whole_graph: bad arguments");

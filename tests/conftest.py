@@ -86,6 +86,24 @@ def pkg(request, pkg_product):
     return load_hooks_pkg() if wants_hooks(request.node) else pkg_product
 
 
+@pytest.fixture(scope="module")
+def dev_cache():
+    """Device graphs a module's tests share, one per (name, library): a test on the hooks library gets handles of that
+    library, never the product's (its switches would not reach them)."""
+    cache = {}
+    yield cache
+    for v in cache.values():
+        for g in (v if isinstance(v, list) else [v]):
+            g.close()
+
+
+def shared_graph(cache, pkg, name, make):
+    key = (name, pkg.__name__)
+    if key not in cache:
+        cache[key] = make()
+    return cache[key]
+
+
 @pytest.fixture(scope="session")
 def orc():
     from oracle import oracle

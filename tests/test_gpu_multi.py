@@ -8,21 +8,20 @@ grouped exchange).  Results must be identical to the single-GPU entry points."""
 import numpy as np
 import pytest
 
-from conftest import to_oracle
+from conftest import shared_graph, to_oracle
 
 pytestmark = pytest.mark.gpu
 A = 0.15
 
 
-@pytest.fixture(scope="module")
-def replicas(pkg_product, rmat12):
-    pkg = pkg_product
-    gs = [pkg.Graph(rmat12) for _ in range(3)]
-    for g in gs:
-        g.set_tuning(pkg.tuning_batch())
-    yield gs
-    for g in gs:
-        g.close()
+@pytest.fixture
+def replicas(pkg, rmat12, dev_cache):
+    def make():
+        gs = [pkg.Graph(rmat12) for _ in range(3)]
+        for g in gs:
+            g.set_tuning(pkg.tuning_batch())
+        return gs
+    return shared_graph(dev_cache, pkg, "replicas", make)
 
 
 def test_shard_ranges(pkg):

@@ -9,7 +9,7 @@ summed in a different order; TOL_SPEC = 1e-6 is asserted as the contractual bar 
 import numpy as np
 import pytest
 
-from conftest import to_oracle
+from conftest import shared_graph, to_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -19,28 +19,19 @@ TOL_PUSH = 1e-12
 TOL_MC = 1e-9
 
 
-@pytest.fixture(scope="module")
-def dev_got(pkg_product, got):
-    pkg = pkg_product
-    g = pkg.Graph(got)
-    yield g
-    g.close()
+@pytest.fixture
+def dev_got(pkg, got, dev_cache):
+    return shared_graph(dev_cache, pkg, "dev_got", lambda: pkg.Graph(got))
 
 
-@pytest.fixture(scope="module")
-def dev_rmat12(pkg_product, rmat12):
-    pkg = pkg_product
-    g = pkg.Graph(rmat12)
-    yield g
-    g.close()
+@pytest.fixture
+def dev_rmat12(pkg, rmat12, dev_cache):
+    return shared_graph(dev_cache, pkg, "dev_rmat12", lambda: pkg.Graph(rmat12))
 
 
-@pytest.fixture(scope="module")
-def dev_rmat15(pkg_product, rmat15):
-    pkg = pkg_product
-    g = pkg.Graph(rmat15)
-    yield g
-    g.close()
+@pytest.fixture
+def dev_rmat15(pkg, rmat15, dev_cache):
+    return shared_graph(dev_cache, pkg, "dev_rmat15", lambda: pkg.Graph(rmat15))
 
 
 def assert_close(a, b, tol, what):

@@ -6,7 +6,7 @@ mass (power method), agreement of the two vertex orders, and a sampled compariso
 import numpy as np
 import pytest
 
-from conftest import to_oracle
+from conftest import shared_graph, to_oracle
 
 pytestmark = pytest.mark.gpu
 A = 0.15
@@ -18,12 +18,9 @@ def rmat20(pkg_product):
     return pkg.HostCsr.rmat(20, 16, seed=1)
 
 
-@pytest.fixture(scope="module")
-def dev20(pkg_product, rmat20):
-    pkg = pkg_product
-    g = pkg.Graph(rmat20)
-    yield g
-    g.close()
+@pytest.fixture
+def dev20(pkg, rmat20, dev_cache):
+    return shared_graph(dev_cache, pkg, "dev20", lambda: pkg.Graph(rmat20))
 
 
 def live_sources(host, count, seed):
