@@ -93,6 +93,7 @@ C8Scope::C8Scope(pprhip_graph* g_, bool back_) : g(g_), back(back_) {
   }
   own = g->stream;
   g->stream = g->parent->stream;
+  g->parent->in_c8++;
   on = true;
 }
 
@@ -100,6 +101,7 @@ int C8Scope::leave() {
   if (!on) return rc;
   on = false;
   g->stream = own;
+  g->parent->in_c8--;
   if (back && (hipEventRecord(g->c8_ev[1], g->parent->stream) != hipSuccess ||
                hipStreamWaitEvent(own, g->c8_ev[1], 0) != hipSuccess)) {
     set_error("slot %d: the sweeps' stream could not be joined to its stream", g->slot_index);

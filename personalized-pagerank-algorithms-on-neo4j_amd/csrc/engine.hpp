@@ -126,7 +126,8 @@ struct KernelTimer {
   static constexpr size_t kMaxEvents = 4096;
   static constexpr size_t kNoEvent = ~(size_t)0;
   bool off = false;  // records nothing (work whose time is accounted elsewhere or not at all)
-  bool last_timed = false;  // the bracket opened last recorded an event (end() records its partner)
+  bool last_timed = false;  // the outermost open bracket recorded an event (its end() records the partner)
+  int depth = 0;            // brackets open
   std::vector<hipEvent_t> ev;
   struct Rec { int cls; size_t i; uint64_t bytes; };
   std::vector<Rec> recs;
@@ -173,11 +174,16 @@ struct KernelTimer {
     }
     if (used + 2 * k > kMaxEvents && hipStreamSynchronize(stream) == hipSuccess) fold();
   }
+  // Brackets on one timer do not nest: a bracket's interval is the pair (begin event, next event).  One opened while
+  // another is open - a driver turn taken from inside a wait that a longer bracket spans - is counted, not timed, so
+  // the outer pair stays a pair (its time then includes the inner launches: they ran inside it).
   void begin(int cls, uint64_t bytes) {
     if (off) return;
+    const bool nested = depth++ > 0;
     const int lvl = kernel_timing_level();
-    last_timed = lvl == 1 || (lvl == 2 && (cls == 1 || cls == 5));  // (PPRHIP_KERNEL_DENSE_PULL / _DENSE_PULL_BATCH)
-    if (!last_timed) {
+    const bool timed = !nested && (lvl == 1 || (lvl == 2 && (cls == 1 || cls == 5)));  // (PPRHIP_KERNEL_DENSE_PULL / _DENSE_PULL_BATCH)
+    if (!nested) last_timed = timed;
+    if (!timed) {
       if (recs.size() >= kMaxCounted) {  // (counting needs no drained stream - unless timed brackets are pending too)
         if (used && hipStreamSynchronize(stream) != hipSuccess) return;
         fold();
@@ -195,7 +201,9 @@ struct KernelTimer {
     (void)hipEventRecord(a, stream);
   }
   void end() {
-    if (off || !last_timed) return;
+    if (off) return;
+    if (depth > 0 && --depth > 0) return;  // (the end of a nested bracket)
+    if (!last_timed) return;
     last_timed = false;
     hipEvent_t b = next();
     if (b) (void)hipEventRecord(b, stream);
@@ -204,6 +212,8 @@ struct KernelTimer {
   void add_bytes(int cls, uint64_t bytes) { acc_bytes[cls] += bytes; }
   void reset() {
     used = 0;
+    depth = 0;  // (a call that failed between a begin and its end left one open)
+    last_timed = false;
     recs.clear();
     for (int c = 0; c < 8; ++c) {
       acc_ms[c] = 0.0;
@@ -335,6 +345,7 @@ struct pprhip_graph {
   bool has_col = false;
   // graph: called by a slot's small read-backs while they wait (fetch_end): the driver looks after the sweep in flight
   void (*idle_hook)(void*) = nullptr;
+  int in_c8 = 0;  // C8Scopes open on this handle's slots (poll_idle: the hook stays out while a slot borrows the sweeps' stream)
   void* idle_arg = nullptr;
   // graph: a stream that runs beside the compute stream (make_side_stream) for the slots' walk phases while sweeps
   // go on (sequential batch driver); slot: the events around its walk phase on that stream

@@ -127,10 +127,14 @@ struct C8Scope {
 };
 
 // A slot of the sequential batch driver gives the driver a look at the sweep in flight (pprhip_graph::idle_hook) -
-// called between the launches of the slot's longer sequences, which keep the host busy for 100 us and more
+// called between the launches of the slot's longer sequences, which keep the host busy for 100 us and more.
+// The hook runs a whole driver turn (collect the sweep, other workspaces' deferred steps, the next sweep) on the
+// caller's thread, so it must never be entered while a slot has its stream swapped for the sweeps' (C8Scope): what the
+// turn queues for that slot would land on the wrong stream.  No caller does; the counter makes that an invariant the
+// code checks instead of one it relies on (SlotDriver::on_idle also refuses to nest, and keeps the sweeps' own timer).
 inline void poll_idle(pprhip_graph* g) {
   pprhip_graph* const H = g->parent;
-  if (H && H->idle_hook) H->idle_hook(H->idle_arg);
+  if (H && H->idle_hook && H->in_c8 == 0) H->idle_hook(H->idle_arg);
 }
 
 struct SetupScope {

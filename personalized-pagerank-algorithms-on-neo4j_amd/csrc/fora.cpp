@@ -719,6 +719,7 @@ struct SlotDriver {
   int ready_rr = 0;         // where the search for a workspace that stands ready for a free column starts
   int cur_ws = -1;          // the workspace whose step is under way (the hook must not step it again)
   bool in_turn = false;
+  KernelTimer* own_timer = g_timer_cur;  // the timer of the thread that runs the driver (turns taken from the hook restore it)
   int hook_rc = PPRHIP_OK;  // what a turn taken from inside a step's wait came to
   std::string hook_msg;
 
@@ -776,7 +777,12 @@ struct SlotDriver {
       if (!any) return;
     }
     D->prof.n[5]++;
+    // (a turn taken from inside a workspace's wait may find that workspace's timer swapped in - a walk phase on the
+    // side stream runs under a quiet one: the turn's own brackets belong to the timer the driver was started under)
+    KernelTimer* const caller_timer = g_timer_cur;
+    g_timer_cur = D->own_timer;
     const int rc = D->turn();
+    g_timer_cur = caller_timer;
     if (rc != PPRHIP_OK) {
       D->hook_rc = rc;
       D->hook_msg = get_error();

@@ -268,3 +268,37 @@ def test_work_cut_on_a_tiny_graph_with_more_ranks_than_hubs(pkg, orc, got, monke
     finally:
         for g in gs:
             g.close()
+
+
+@pytest.mark.timeout(600)
+def test_work_weighted_cut_with_empty_target_ranges(pkg, monkeypatch):
+    """one target whose search outweighs total / W - a star: every node points at node 0, plus a ring so
+    that the other searches find something - makes the work-weighted cut place several cuts at the same id: some of the
+    eight ranks get an EMPTY target range, collect nothing and still take part in the exchange.  The merged index must be
+    the single-GPU one, every rank returns."""
+    n = 3000
+    src = np.concatenate([np.arange(1, n), np.arange(n)]).astype(np.int32)
+    dst = np.concatenate([np.zeros(n - 1, dtype=np.int64), (np.arange(n) + 1) % n]).astype(np.int32)
+    host = pkg.HostCsr(n, src, dst, False)
+    thr, k, W = 1e-4, 8, 8
+    gs = [pkg.Graph(host) for _ in range(W)]
+    try:
+        cuts_w, _ = pkg.shard_target_cuts(gs[0], W, A, thr, pkg.CUT_BY_WORK)
+        widths = np.diff(cuts_w.astype(np.int64))
+        assert cuts_w[0] == 0 and cuts_w[-1] == n and np.all(widths >= 0)
+        assert (widths == 0).any(), "the star's hub should leave at least one rank without targets: %s" % cuts_w
+        ix1, _ = gs[0].all_pair_backward(A, thr, k)
+        ref = [x.copy() for x in ix1.arrays()]
+        ix1.close()
+        monkeypatch.setenv("PPRHIP_SHARD_CUT", "work")
+        ix, sts = pkg.all_pair_backward_multi(gs, A, thr, k)
+        got = ix.arrays()
+        assert np.array_equal(got[0], ref[0]) and len(got[1]) == len(ref[1])
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ref[0]).astype(np.int64))
+        o, o_ref = np.argsort(rows * n + got[1], kind="stable"), np.argsort(rows * n + ref[1], kind="stable")
+        assert np.array_equal(got[1][o], ref[1][o_ref]) and np.max(np.abs(got[2][o] - ref[2][o_ref])) <= 1e-12
+        ix.close()
+        assert len(sts) == W
+    finally:
+        for g in gs:
+            g.close()
