@@ -307,6 +307,9 @@ LIFT_ARRAYS = {  # pprhip_lift_array: name -> (id, dtype)
     "flags": (8, np.uint8), "chunk_starts": (9, np.uint32), "cross": (10, np.uint64), "edge_base": (11, np.uint64),
     "seg_base": (12, np.uint64), "sl_ci": (13, np.int32), "sl_flags": (14, np.uint8), "sl_chunk_starts": (15, np.uint32),
     "seg_row": (16, np.uint32), "seg_off": (17, np.uint32),
+    # the row-panel copy the single-query sweep walks (empty when the graph has none)
+    "panel_sizes": (18, np.uint64), "panel_src": (19, np.int32), "panel_row": (20, np.uint16),
+    "panel_items": (21, np.uint32), "panel_desc": (22, np.uint32), "panel_item0": (23, np.uint32),
 }
 
 

@@ -361,6 +361,33 @@ static int upload_sliced_layout(pprhip_graph* G, HostLift& H) {
   return PPRHIP_OK;
 }
 
+static int upload_panel_layout(pprhip_graph* G, HostLift& H) {
+  if (!H.pn.n_items) return PPRHIP_OK;
+  std::unique_ptr<PanelLayout> L(new (std::nothrow) PanelLayout());
+  if (!L) return PPRHIP_ERR_OOM;
+  L->n_panels = H.pn.n_panels;
+  L->n_items = H.pn.n_items;
+  L->n_part = H.pn.n_part;
+  L->h_panel_item0 = std::move(H.pn.panel_item0);
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+    PPRHIP_TRY(alloc_dev(dst, bytes));
+    if (bytes) PPRHIP_CHECK_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return PPRHIP_OK;
+  };
+  G->pn = L.release();  // from here on pprhip_graph_destroy frees what has been allocated
+  PPRHIP_TRY(up((void**)&G->pn->src, H.pn.src.data(), sizeof(int32_t) * H.pn.src.size()));
+  PPRHIP_TRY(up((void**)&G->pn->rloc, H.pn.rloc.data(), sizeof(uint16_t) * H.pn.rloc.size()));
+  PPRHIP_TRY(up((void**)&G->pn->items, H.pn.items.data(), sizeof(PanelItem) * H.pn.items.size()));
+  PPRHIP_TRY(up((void**)&G->pn->panels, H.pn.panels.data(), sizeof(PanelDesc) * H.pn.panels.size()));
+  return PPRHIP_OK;
+}
+
+// the buffer the items of a panel sweep leave their sums in: per handle, on its first forward dense level
+int ensure_panel_part(pprhip_graph* g) {
+  if (!g->pn || g->pn_part) return PPRHIP_OK;
+  return alloc_dev((void**)&g->pn_part, sizeof(double) * (size_t)g->pn->n_part);
+}
+
 int ensure_bwd_layout(pprhip_graph* P);
 
 
@@ -423,6 +450,7 @@ int run_levels(pprhip_graph* g, const PushArgs& a, LevelCtx& L, pprhip_stats_t& 
       if (model_cost) *model_cost += c;
       if (cut) cut->had_dense = true;
       if (bwd && !slot) PPRHIP_TRY(ensure_bwd_layout(g));  // sweep layout over the out-CSR, built on first use
+      if (!bwd && !slot) PPRHIP_TRY(ensure_panel_part(g));  // (graphs with the row-panel copy)
       if (!L.dense_prepared) {
         C8Scope c8(g, false);
         PPRHIP_TRY(c8.rc);
@@ -696,7 +724,7 @@ int alloc_workspace(pprhip_graph* G) {
 }
 
 void free_workspace(pprhip_graph* g) {
-  void* ptrs[] = {g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1],
+  void* ptrs[] = {g->pn_part, g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1],
                   g->eoff[0], g->eoff[1], g->flags, g->armed, g->mc_plan_rec, g->partial, g->hist, g->sel_blob,
                   g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
   for (void* p : ptrs)
@@ -757,6 +785,7 @@ static int make_slot(pprhip_graph* P, int w) {
   S->nz_rows = P->nz_rows;
   S->n_nz = P->n_nz;
   S->sl = P->sl;
+  S->pn = nullptr;  // (slots run no dense levels of their own: the parent's shared sweeps serve them)
   S->tun = P->tun;
   PPRHIP_TRY(alloc_workspace(S));
   return PPRHIP_OK;
@@ -1564,6 +1593,7 @@ int pprhip_graph_create(uint32_t n, uint64_t m, const uint32_t* out_rp, const in
   if ((rc = up((void**)&G->chunk_starts, H.chunk_starts.data(), sizeof(uint32_t) * H.chunk_starts.size()))) return fail(rc);
   if ((rc = up((void**)&G->nz_rows, G->h_nz_rows.data(), sizeof(int32_t) * G->h_nz_rows.size()))) return fail(rc);
   if ((rc = upload_sliced_layout(G, H))) return fail(rc);
+  if ((rc = upload_panel_layout(G, H))) return fail(rc);
   if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) {
     set_error("hipStreamCreate failed");
     return fail(PPRHIP_ERR_HIP);
@@ -1629,6 +1659,13 @@ void pprhip_graph_destroy(pprhip_graph_t* g) {
       if (p) (void)hipFree(p);
     delete g->sl;
     g->sl = nullptr;
+  }
+  if (g->pn) {
+    void* pp[] = {g->pn->src, g->pn->rloc, g->pn->items, g->pn->panels};
+    for (void* p : pp)
+      if (p) (void)hipFree(p);
+    delete g->pn;
+    g->pn = nullptr;
   }
   free_workspace(g);
   if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -2218,6 +2255,7 @@ int pprhip_power_method(pprhip_graph_t* g, int32_t src, double alpha, int iters,
   CallTimer tm(g);
   if (iters > 0) {
     // iteration 1 (Power_Method.java:59-96 with residue = {s: 1})
+    PPRHIP_TRY(ensure_panel_part(g));
     LevelCtx L;
     PushArgs a{alpha, 0.0, 0.0, src, kPower};
     PPRHIP_CHECK_HIP(hipMemsetAsync(g->cdense[L.ccur], 0, sizeof(double) * g->n, g->stream));

@@ -95,6 +95,17 @@ struct SlicedLayout {
   int plan_B = -1;
 };
 
+// The row-panel copy of the in-CSR on the device (engine_internal.hpp: HostPanelLayout; single-query forward sweep).
+struct PanelLayout {
+  int32_t* src = nullptr;          // [n_edges] sources, item-major
+  uint16_t* rloc = nullptr;        // [n_edges] row ordinal inside the panel (0xffff: padding)
+  PanelItem* items = nullptr;      // [n_items]
+  PanelDesc* panels = nullptr;     // [n_panels]
+  uint32_t n_panels = 0, n_items = 0;
+  uint64_t n_part = 0;             // doubles a handle's buffer of the parts' sums holds
+  std::vector<uint32_t> h_panel_item0;  // host: [n_panels + 1], the Gauss-Seidel blocks' item windows
+};
+
 enum PushMode : int { kFwdWhole = 0, kFwdTopk = 1, kBackward = 2, kPower = 3 };
 
 struct SelRec {  // one candidate of a top-k selection / one entry >= threshold of a backward search
@@ -319,7 +330,9 @@ struct pprhip_graph {
   std::vector<pprhip::GsBlock> gs_plan;   // blocks of the forward sweep for gs_plan_B blocks (built on demand)
   int gs_plan_B = 0;
   double* acc_nz = nullptr;  // per non-empty row: sum of this level's contributions
-  pprhip::SlicedLayout* sl = nullptr;  // single-query sweep layout (owned by the lifted graph, borrowed by slots)
+  pprhip::SlicedLayout* sl = nullptr;
+  pprhip::PanelLayout* pn = nullptr;   // row-panel copy of the in-CSR (shared with the batch slots), or none
+  double* pn_part = nullptr;           // [pn->n_part] the items' sums of this handle's sweep (first forward dense level)  // single-query sweep layout (owned by the lifted graph, borrowed by slots)
   // batched queries: kBatch workspaces ("slots") borrow this handle's CSR and stream; their dense
   // levels run as one sweep over the interleaved contribution array c8[v][slot]
   pprhip_graph* parent = nullptr;  // set on a slot

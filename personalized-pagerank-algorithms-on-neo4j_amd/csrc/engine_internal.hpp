@@ -185,6 +185,30 @@ template <class T>
 using RawVec = std::vector<T, NoInitAlloc<T>>;
 
 
+// Row-panel copy of the in-CSR for the single-query forward sweep (round 6).  Why: the sweep gathers one 8-byte
+// contribution per in-edge, every gather asks the L1 for a 128-byte line, and a CU keeps ~256 lines in flight
+// (TCP_PENDING_STALL_CYCLES: 0.69 of k_dense_edges<true, true>'s cycles; profiles/r06_ell_sweep_study.txt for the model):
+// the row-major and the sliced copy ask for 18 M lines per half sweep of R-MAT 22's 33.5 M edges.  Here the rows are cut
+// into PANELS of kPanelRows consecutive ordinals whose sums fit a CU's LDS (128 KB), and a panel's in-edges are sorted by
+// (source, row): neighbouring lanes gather neighbouring sources, so the sixteen sources of a line are served by one
+// request, and a workgroup walks the contribution array front to back - all workgroups at about the same place, so a
+// line leaves HBM once per XCD and sweep.  R-MAT 22: 3.5 M distinct (item, line) pairs per sweep for 67 M edges.
+// A panel of more than kItemEdges edges is cut into S parts of equal edge counts (ITEMS); part k sums into LDS of its own
+// and leaves part[base + k * rows + local row]; k_dense_apply adds a row's S values.  Every item's edges are padded to
+// whole turns of kPanelStep with (source 0, row 0xffff): a row ordinal no panel has, skipped by the kernel.
+struct HostPanelLayout {
+  uint32_t n_nz = 0, n_panels = 0, n_items = 0;
+  uint64_t n_edges = 0;                      // with padding
+  uint64_t n_part = 0;                       // doubles of the parts' sums
+  RawVec<int32_t> src;                       // [n_edges] sources, item-major, inside an item sorted by (source, row)
+  RawVec<uint16_t> rloc;                     // [n_edges] row ordinal - first ordinal of the panel; 0xffff: padding
+  std::vector<PanelItem> items;              // [n_items], panel-major
+  std::vector<PanelDesc> panels;             // [n_panels]
+  std::vector<uint32_t> panel_item0;         // [n_panels + 1]
+};
+int build_panel_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,
+                       uint32_t n_nz, unsigned threads, HostPanelLayout& L);
+
 // The host half of the graph lift (lift.cpp): every array of the internal layout in host memory, ready to upload.
 struct HostLift {
   bool relabeled = true;
@@ -204,6 +228,8 @@ struct HostLift {
   RawVec<int32_t> sl_ci;
   std::vector<uint8_t> sl_flags;
   std::vector<uint32_t> sl_chunk_starts, seg_row, seg_off;
+  // row-panel copy of the in-CSR (n_items == 0: none; graphs that have it have no sliced copy)
+  HostPanelLayout pn;
 };
 // threads: 0 = what the process may use (host_threads)
 int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out_ci, const uint32_t* in_rp,
@@ -225,6 +251,7 @@ int reset_query_state(pprhip_graph* g, bool clear_flags, int32_t node = -1);  //
 int ensure_batch(pprhip_graph* P);
 void free_batch(pprhip_graph* P);
 int ensure_bwd_layout(pprhip_graph* P);
+int ensure_panel_part(pprhip_graph* g);  // the buffer of the panel sweep's partial sums (first forward dense level)
 // blocks of the forward Gauss-Seidel sweep for the handle's tuning (nullptr / 1 block when switched off)
 const GsBlock* gs_blocks_of(pprhip_graph* g, int* n_blocks);
 unsigned long long gs_thresh_of(const pprhip_graph* g);

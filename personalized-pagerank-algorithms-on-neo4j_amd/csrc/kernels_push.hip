@@ -827,12 +827,84 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_dense_edges_panel (round 6): the single-query forward edge kernel over the row-panel copy (engine_internal.hpp:
+// HostPanelLayout).  A workgroup takes an ITEM - at most kItemEdges edges of one panel of kPanelRows rows, sorted by
+// source - and sums it into acc[row] in LDS (128 KB).  A lane takes four consecutive edges per turn, a wave 256, the
+// workgroup 4 096: neighbouring lanes gather neighbouring sources, so the sixteen contributions of a 128-byte line are
+// one request to the L1 (which keeps ~256 lines in flight per CU - what bounds the row-major and the sliced kernel:
+// TCP_PENDING_STALL_CYCLES 0.69 of their cycles), and every workgroup walks the contribution array front to back.  Sums
+// land with ds_add_f64 (zero contributions are skipped: a dense level's frontier is a part of the nodes); at the end
+// the item's rows leave as one contiguous block part[part0 + row]; k_dense_apply<.., true> adds a row's parts.
+// Rows outside [j_lo, j_hi) - the Gauss-Seidel block of the launch, whose bounds may cut a panel - are left out.
+// Items are dealt to the workgroups in turn (they are of one size: the parts of a panel hold equal edge counts).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPanelThreads = 1024;
+constexpr int kPanelLdsBytes = (int)(kPanelRows * sizeof(double));
+static_assert(kPanelStep == (uint32_t)kPanelThreads * 4u, "four edges per lane and turn");
+
+__global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32_t* __restrict__ src,
+                                                                     const uint16_t* __restrict__ rloc,
+                                                                     const PanelItem* __restrict__ items,
+                                                                     uint32_t item_lo, uint32_t item_hi,
+                                                                     const double* __restrict__ c_cur,
+                                                                     double* __restrict__ part, uint32_t j_lo,
+                                                                     uint32_t j_hi, uint32_t n_nz, const int* state_in) {
+  extern __shared__ __attribute__((aligned(16))) double acc[];
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+  if (dense_state(state_in, kGsJacobi) == kGsNone) return;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t it = item_lo + blockIdx.x; it < item_hi; it += gridDim.x) {
+    const PanelItem I = items[it];
+    {
+      double2* a2 = reinterpret_cast<double2*>(acc);
+#pragma unroll
+      for (int k = 0; k < (int)(kPanelRows / 2 / kPanelThreads); ++k) a2[(uint32_t)k * kPanelThreads + tid] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const uint32_t row0 = I.panel * kPanelRows;
+    const uint32_t r_lo = j_lo > row0 ? j_lo - row0 : 0u;
+    const uint32_t r_hi = j_hi > row0 ? min(min(j_hi, n_nz) - row0, kPanelRows) : 0u;  // (padding: row 0xffff >= r_hi)
+    const v4i* sp = reinterpret_cast<const v4i*>(src + (size_t)I.edge0 * kPanelStep) + tid;
+    const v2u* rp = reinterpret_cast<const v2u*>(rloc + (size_t)I.edge0 * kPanelStep) + tid;
+    // the index streams are read once per sweep: non-temporal, so that they do not push gathered lines out of L2
+    v4i ix = __builtin_nontemporal_load(sp);
+    v2u rx = __builtin_nontemporal_load(rp);
+    for (uint32_t i = 0; i < I.steps; ++i) {
+      v4i nx = ix;
+      v2u nr = rx;
+      if (i + 1 < I.steps) {  // in flight beside the gathers
+        nx = __builtin_nontemporal_load(sp + (size_t)(i + 1) * kPanelThreads);
+        nr = __builtin_nontemporal_load(rp + (size_t)(i + 1) * kPanelThreads);
+      }
+      const uint32_t r0 = rx.x & 0xffffu, r1 = rx.x >> 16, r2 = rx.y & 0xffffu, r3 = rx.y >> 16;
+      const bool in0 = r0 >= r_lo && r0 < r_hi, in1 = r1 >= r_lo && r1 < r_hi, in2 = r2 >= r_lo && r2 < r_hi,
+                 in3 = r3 >= r_lo && r3 < r_hi;
+      // (rows outside the block and the padding gather the first contribution - one shared line - and add nothing)
+      const double v0 = c_cur[in0 ? ix.x : 0], v1 = c_cur[in1 ? ix.y : 0], v2 = c_cur[in2 ? ix.z : 0], v3 = c_cur[in3 ? ix.w : 0];
+      if (in0 && v0 != 0.0) atomic_add_noret(&acc[r0], v0);
+      if (in1 && v1 != 0.0) atomic_add_noret(&acc[r1], v1);
+      if (in2 && v2 != 0.0) atomic_add_noret(&acc[r2], v2);
+      if (in3 && v3 != 0.0) atomic_add_noret(&acc[r3], v3);
+      ix = nx;
+      rx = nr;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t r = tid; r < kPanelRows; r += kPanelThreads)
+      if (r >= r_lo && r < r_hi) part[(size_t)I.part0 + r] = acc[r];
+    __syncthreads();  // (the accumulators are read: the next item clears them)
+  }
+}
+
 // k_dense_apply: one thread per non-empty row (plus one for a source without in-edges, which
 // only ever receives returned dead-end mass): lands the row sum, detects the threshold crossing
 // and prepares the row for the next level in place.
-template <int MODE>
+// PANEL: the row sum arrives as the S parts k_dense_edges_panel's items left (acc_nz = their buffer; panels = PanelDesc).
+template <int MODE, bool PANEL>
 __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__ nz_rows, uint32_t j_lo, uint32_t n_nz,
-                                                      double* __restrict__ acc_nz,
+                                                      double* __restrict__ acc_nz, const PanelDesc* __restrict__ panels,
                                                       const uint32_t* __restrict__ out_rp,
                                                       const uint32_t* __restrict__ in_rp,
                                                       double* __restrict__ c_cur, double* __restrict__ c_next,
@@ -855,8 +927,14 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
   double acc = 0.0;
   if (j < n_nz) {
     u = nz_rows[j];
-    acc = acc_nz[j];
-    acc_nz[j] = 0.0;
+    if (PANEL) {
+      const PanelDesc P = panels[j / kPanelRows];  // (a wave's rows lie in one panel or two: uniform loads)
+      const double* p = acc_nz + (size_t)P.base + (j % kPanelRows);
+      for (uint32_t k = 0; k < P.parts; ++k) acc += p[(size_t)k * P.rows];
+    } else {
+      acc = acc_nz[j];
+      acc_nz[j] = 0.0;
+    }
     have = true;
   } else if (j == n_nz && src_extra) {
     u = a.src;
@@ -1600,8 +1678,10 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   const GsBlock* blocks = (dl.blocks && dl.n_blocks > 1 && !bwd) ? dl.blocks : &whole;
   const int nb = blocks == &whole ? 1 : dl.n_blocks;
   const uint32_t n_hot = g->relabeled ? std::min<uint32_t>(g->n, (uint32_t)kHotMax) : 0u;
-  // forward sweeps of a graph whose sources span several slices walk the sliced copy of the in-CSR
-  const SlicedLayout* sl = bwd ? nullptr : g->sl;
+  // forward sweeps walk the row-panel copy of the in-CSR where the graph has one (from 2^20 edges on), else - a graph
+  // whose sources span several slices - the sliced copy
+  const PanelLayout* pn = (!bwd && g->pn && g->pn_part) ? g->pn : nullptr;
+  const SlicedLayout* sl = (bwd || pn) ? nullptr : g->sl;
   const EdgeWindows* wins = sl ? detail::sliced_windows_of(g, blocks == &whole ? nullptr : blocks, nb) : nullptr;
   if (sl) {
     ci = sl->ci;
@@ -1622,7 +1702,17 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     }
     const EdgeWindows& W = sl ? wins[b] : one;
     const uint32_t n_ch = W.n ? W.c_pre[W.n] : 0u;
-    if (g->n_chunks && n_ch) {
+    if (pn) {
+      // block boundaries are multiples of 256 row ordinals and may cut a panel: the kernel leaves the other rows out
+      const uint32_t p_lo = B.j_lo / kPanelRows, p_hi = std::min<uint32_t>(pn->n_panels, (B.j_hi + kPanelRows - 1) / kPanelRows);
+      const uint32_t i_lo = p_hi > p_lo ? pn->h_panel_item0[p_lo] : 0u, i_hi = p_hi > p_lo ? pn->h_panel_item0[p_hi] : 0u;
+      if (i_hi > i_lo) {
+        const uint32_t grid = std::min<uint32_t>(i_hi - i_lo, (uint32_t)g->n_cus);
+        k_dense_edges_panel<<<dim3(grid), dim3(kPanelThreads), kPanelLdsBytes, g->stream>>>(
+            pn->src, pn->rloc, pn->items, i_lo, i_hi, g->cdense[cbuf], g->pn_part, B.j_lo, B.j_hi, n_nz, dl.state_in);
+        PPRHIP_CHECK_HIP(hipGetLastError());
+      }
+    } else if (g->n_chunks && n_ch) {
       // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use
       const uint32_t want = (n_ch + 15) / 16;
       const uint32_t grid = std::min<uint32_t>(want, (uint32_t)g->n_cus * (n_hot ? 1u : 2u));
@@ -1645,11 +1735,19 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
     const uint32_t rows = B.j_hi - B.j_lo + (uint32_t)extra;
     const uint32_t grid = (rows + 255) / 256;
     if (grid) {
-      DISPATCH_MODE(a.mode, (k_dense_apply<M><<<dim3(grid), dim3(256), 0, g->stream>>>(
-                                nz, B.j_lo, B.j_hi, g->acc_nz, g->out_rp, g->in_rp, g->cdense[cbuf], g->cdense[cbuf ^ 1],
-                                g->residue, g->reserve, g->flags, g->armed, g->ctr, g->blk_pack + part_base,
-                                g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot, extra, a, dl.state_in,
-                                dl.state0, b == nb - 1 ? 1 : 0)));
+      if (pn) {
+        DISPATCH_MODE(a.mode, (k_dense_apply<M, true><<<dim3(grid), dim3(256), 0, g->stream>>>(
+                                  nz, B.j_lo, B.j_hi, g->pn_part, pn->panels, g->out_rp, g->in_rp, g->cdense[cbuf],
+                                  g->cdense[cbuf ^ 1], g->residue, g->reserve, g->flags, g->armed, g->ctr,
+                                  g->blk_pack + part_base, g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot,
+                                  extra, a, dl.state_in, dl.state0, b == nb - 1 ? 1 : 0)));
+      } else {
+        DISPATCH_MODE(a.mode, (k_dense_apply<M, false><<<dim3(grid), dim3(256), 0, g->stream>>>(
+                                  nz, B.j_lo, B.j_hi, g->acc_nz, nullptr, g->out_rp, g->in_rp, g->cdense[cbuf],
+                                  g->cdense[cbuf ^ 1], g->residue, g->reserve, g->flags, g->armed, g->ctr,
+                                  g->blk_pack + part_base, g->blk_dead + part_base, g->blk_ndead + part_base, dead_slot,
+                                  extra, a, dl.state_in, dl.state0, b == nb - 1 ? 1 : 0)));
+      }
       PPRHIP_CHECK_HIP(hipGetLastError());
       part_base += grid;
     }
@@ -1897,6 +1995,8 @@ int init_kernels_push() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kHotMax)));
   PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_b<true, kBatch>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kHotBytes));
+  PPRHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_edges_panel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLdsBytes));
   hipFuncAttributes fa;
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sparse_push<kBackward>)));
   PPRHIP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_dense_apply_batch)));

@@ -328,6 +328,16 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
   // has out-edges; no layout when they fit one slice.
   H.S = 0;
   H.n_seg = 0;
+  // ---- row-panel copy (the single-query forward sweep's layout from 2^20 edges on; PPRHIP_SWEEP1_PANELS=0 / 1, a test
+  // switch, forces it off / on at any size): graphs that have it need no sliced copy
+  {
+    const char* pe = hook_env("PPRHIP_SWEEP1_PANELS");
+    const bool want = pe ? pe[0] == '1' : m >= (1ull << 20);
+    if (want && m > 0 && !H.nz_rows.empty()) {
+      PPRHIP_TRY(build_panel_layout(n, m, irp.data(), H.in_ci.data(), H.nz_rows.data(), (uint32_t)H.nz_rows.size(), T, H.pn));
+      if (H.pn.n_items) return PPRHIP_OK;
+    }
+  }
   const char* off = hook_env("PPRHIP_SLICED");
   if (off && off[0] == '0') return PPRHIP_OK;
   uint32_t n_src = n;  // ids above the last node with out-edges are never gathered
@@ -443,6 +453,90 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
   return PPRHIP_OK;
 }
 
+// ---- row-panel copy of the in-CSR (engine_internal.hpp: HostPanelLayout).  Pass A, one thread: edges, parts and
+// offsets per panel; pass B, all threads, panels handed out in order: a panel's edges as keys source << 16 | local row,
+// sorted, written part by part with the padding - the arrays are the same with any thread count.
+int build_panel_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int32_t* in_ci, const int32_t* nz_rows,
+                       uint32_t n_nz, unsigned threads, HostPanelLayout& L) {
+  (void)n;
+  PhaseClock clk;
+  const unsigned T = (m < (1u << 20)) ? 1u : std::max(1u, threads ? threads : host_threads());
+  L.n_nz = n_nz;
+  L.n_panels = (n_nz + kPanelRows - 1) / kPanelRows;
+  const size_t NP = L.n_panels;
+  L.panel_item0.assign(NP + 1, 0);
+  L.panels.assign(NP, PanelDesc{0, 0, 0, 0});
+  std::vector<uint64_t> panel_edges(NP, 0);
+  uint64_t items = 0, steps = 0, part = 0;
+  for (size_t t = 0; t < NP; ++t) {
+    const uint32_t j_lo = (uint32_t)t * kPanelRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(t + 1) * kPanelRows);
+    uint64_t e = 0;
+    for (uint32_t j = j_lo; j < j_hi; ++j) e += in_rp[(uint32_t)nz_rows[j] + 1] - in_rp[(uint32_t)nz_rows[j]];
+    panel_edges[t] = e;
+    const uint64_t S = std::max<uint64_t>(1, (e + kItemEdges - 1) / kItemEdges);
+    L.panel_item0[t] = (uint32_t)items;
+    L.panels[t] = PanelDesc{(uint32_t)part, (uint32_t)S, j_hi - j_lo, 0u};
+    for (uint64_t k = 0; k < S; ++k) steps += (e * (k + 1) / S - e * k / S + kPanelStep - 1) / kPanelStep;
+    items += S;
+    part += (uint64_t)(j_hi - j_lo) * S;
+    if (part >= 0xfffffff0ull || items >= 0xfffffff0ull || steps >= 0xfffffff0ull) {
+      L.n_items = 0;  // offsets are 32-bit: the other layouts stay
+      return PPRHIP_OK;
+    }
+  }
+  L.panel_item0[NP] = (uint32_t)items;
+  L.n_items = (uint32_t)items;
+  L.n_part = part;
+  L.n_edges = steps * kPanelStep;
+  L.items.assign((size_t)items, PanelItem{0, 0, 0, 0});
+  {
+    uint64_t st = 0;
+    for (size_t t = 0; t < NP; ++t) {
+      const uint32_t i0 = L.panel_item0[t], S = L.panel_item0[t + 1] - i0;
+      const uint64_t e = panel_edges[t];
+      for (uint32_t k = 0; k < S; ++k) {
+        PanelItem& I = L.items[(size_t)i0 + k];
+        I.edge0 = (uint32_t)st;
+        I.steps = (uint32_t)((e * (k + 1) / S - e * k / S + kPanelStep - 1) / kPanelStep);
+        I.panel = (uint32_t)t;
+        I.part0 = L.panels[t].base + k * L.panels[t].rows;
+        st += I.steps;
+      }
+    }
+  }
+  L.src.resize((size_t)L.n_edges);
+  L.rloc.resize((size_t)L.n_edges);
+  clk.mark("panels: offsets");
+  parallel_parts((unsigned)NP, T, [&](unsigned t) {
+    const uint32_t j_lo = t * kPanelRows, j_hi = (uint32_t)std::min<uint64_t>(n_nz, (uint64_t)(t + 1) * kPanelRows);
+    std::vector<uint64_t> key;
+    key.reserve((size_t)panel_edges[t]);
+    for (uint32_t j = j_lo; j < j_hi; ++j) {
+      const uint32_t v = (uint32_t)nz_rows[j];
+      for (uint32_t e = in_rp[v]; e < in_rp[v + 1]; ++e) key.push_back((uint64_t)(uint32_t)in_ci[e] << 16 | (j - j_lo));
+    }
+    std::sort(key.begin(), key.end());
+    const uint32_t i0 = L.panel_item0[t], S = L.panel_item0[t + 1] - i0;
+    const uint64_t e = key.size();
+    for (uint32_t k = 0; k < S; ++k) {
+      const PanelItem& I = L.items[(size_t)i0 + k];
+      const uint64_t lo = e * k / S, hi = e * (k + 1) / S;
+      int32_t* so = L.src.data() + (size_t)I.edge0 * kPanelStep;
+      uint16_t* ro = L.rloc.data() + (size_t)I.edge0 * kPanelStep;
+      for (uint64_t x = lo; x < hi; ++x) {
+        so[x - lo] = (int32_t)(key[x] >> 16);
+        ro[x - lo] = (uint16_t)(key[x] & 0xffffu);
+      }
+      for (uint64_t x = hi - lo; x < (uint64_t)I.steps * kPanelStep; ++x) {
+        so[x] = 0;
+        ro[x] = 0xffffu;
+      }
+    }
+  });
+  clk.mark("panels: edges");
+  return PPRHIP_OK;
+}
+
 }  // namespace detail
 }  // namespace pprhip
 
@@ -452,6 +546,7 @@ struct pprhip_lift {
   uint32_t n = 0;
   uint64_t m = 0;
   int threads = 0;
+  mutable uint64_t panel_sizes[4] = {0, 0, 0, 0};  // panels, items, doubles of partial sums, edges with padding
 };
 
 extern "C" {
@@ -496,6 +591,17 @@ int pprhip_lift_array(const pprhip_lift_t* lift, int which, const void** data_ou
   };
 #define PPRHIP_LIFT_VEC(v) give((v).data(), (v).size() * sizeof((v)[0]))
   switch (which) {
+    case PPRHIP_LIFT_PANEL_SIZES:
+      lift->panel_sizes[0] = H.pn.n_panels;
+      lift->panel_sizes[1] = H.pn.n_items;
+      lift->panel_sizes[2] = H.pn.n_part;
+      lift->panel_sizes[3] = H.pn.n_edges;
+      return give(lift->panel_sizes, H.pn.n_items ? sizeof lift->panel_sizes : 0);
+    case PPRHIP_LIFT_PANEL_SRC: return PPRHIP_LIFT_VEC(H.pn.src);
+    case PPRHIP_LIFT_PANEL_ROW: return PPRHIP_LIFT_VEC(H.pn.rloc);
+    case PPRHIP_LIFT_PANEL_ITEMS: return PPRHIP_LIFT_VEC(H.pn.items);
+    case PPRHIP_LIFT_PANEL_DESC: return PPRHIP_LIFT_VEC(H.pn.panels);
+    case PPRHIP_LIFT_PANEL_ITEM0: return PPRHIP_LIFT_VEC(H.pn.panel_item0);
     case PPRHIP_LIFT_NEW2OLD: return PPRHIP_LIFT_VEC(H.new2old);
     case PPRHIP_LIFT_OLD2NEW: return PPRHIP_LIFT_VEC(H.old2new);
     case PPRHIP_LIFT_OUT_ROW_PTR: return PPRHIP_LIFT_VEC(H.out_rp);

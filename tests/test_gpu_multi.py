@@ -272,13 +272,13 @@ def test_work_cut_on_a_tiny_graph_with_more_ranks_than_hubs(pkg, orc, got, monke
 
 @pytest.mark.timeout(600)
 def test_work_weighted_cut_with_empty_target_ranges(pkg, monkeypatch):
-    """one target whose search outweighs total / W - a star: every node points at node 0, plus a ring so
-    that the other searches find something - makes the work-weighted cut place several cuts at the same id: some of the
-    eight ranks get an EMPTY target range, collect nothing and still take part in the exchange.  The merged index must be
-    the single-GPU one, every rank returns."""
+    """one target whose search outweighs total / W - a star: every node points at node 0, and a short chain
+    behind the last node so that a few other searches find something - makes the work-weighted cut place several cuts at
+    the same id: some of the eight ranks get an EMPTY target range, collect nothing and still take part in the exchange.
+    The merged index must be the single-GPU one, every rank returns."""
     n = 3000
-    src = np.concatenate([np.arange(1, n), np.arange(n)]).astype(np.int32)
-    dst = np.concatenate([np.zeros(n - 1, dtype=np.int64), (np.arange(n) + 1) % n]).astype(np.int32)
+    src = np.concatenate([np.arange(1, n), np.arange(n - 40, n - 1)]).astype(np.int32)
+    dst = np.concatenate([np.zeros(n - 1, dtype=np.int64), np.arange(n - 39, n)]).astype(np.int32)
     host = pkg.HostCsr(n, src, dst, False)
     thr, k, W = 1e-4, 8, 8
     gs = [pkg.Graph(host) for _ in range(W)]

@@ -341,6 +341,60 @@ def test_batch_driver_variants(pkg, orc, rmat15, env, monkeypatch):
         ref_g.close()
 
 
+@pytest.mark.parametrize("graph,relabel", [("got", "1"), ("rmat12", "1"), ("rmat15", "1"), ("rmat15", "0")])
+def test_row_panel_single_query_sweep(pkg, orc, got, rmat12, rmat15, graph, relabel, monkeypatch):
+    """The single-query dense level over the row-panel copy of the in-CSR (round 6: k_dense_edges_panel - a workgroup
+    sums an item of one panel's source-sorted edges into accumulators in LDS, the apply kernel adds a row's parts; the
+    layout of graphs from 2^20 edges on, forced here with PPRHIP_SWEEP1_PANELS=1): forward push with Jacobi and 2- /
+    3-block Gauss-Seidel sweeps (whose bounds cut the one panel these graphs have), the power method, whole-graph FORA
+    and FORA top-k, level for level and value for value the twin's (with PPRHIP_RELABEL=0: the other layout's) - on a
+    handle that has run a query before (stale partial sums)."""
+    host = {"got": got, "rmat12": rmat12, "rmat15": rmat15}[graph]
+    og = to_oracle(orc, host)
+    od = np.diff(host.out_rp).astype(np.float64)
+    monkeypatch.setenv("PPRHIP_RELABEL", relabel)
+    monkeypatch.setenv("PPRHIP_SWEEP1_PANELS", "1")
+    g_part = pkg.Graph(host)
+    monkeypatch.setenv("PPRHIP_SWEEP1_PANELS", "0")
+    g_ref = pkg.Graph(host)
+    srcs = [s for s in ([0, 17, 42] if graph == "got" else []) + list(sources(host, 8, seed=27)) if od[s] > 0][:4]
+    try:
+        for B in (1, 2, 3):
+            t = pkg.tuning_batch()       # (dense levels from 2 % of m)
+            t.gs_blocks = B
+            if graph == "got":
+                t.dense_frac = 0.01
+            g_part.set_tuning(t)
+            g_ref.set_tuning(t)
+            for s in srcs:
+                p, r, rsum, st = g_part.forward_push(s, ALPHA, 1e-8)
+                p0, r0, _, st0 = g_ref.forward_push(s, ALPHA, 1e-8)
+                assert (st.dense_levels > 0 or graph == "got") and st.levels == st0.levels and st.dense_levels == st0.dense_levels
+                assert_close(p, p0, TOL_PUSH, "reserve vs the other layout B=%d src=%d" % (B, s))
+                assert_close(r, r0, TOL_PUSH, "residue vs the other layout B=%d src=%d" % (B, s))
+                if relabel == "1":
+                    po, ro, _, sto = og.forward_push(s, ALPHA, 1e-8, orc.SYNC)
+                    assert st.levels == sto.levels and st.dense_levels == sto.dense_levels
+                    assert_close(p, po, TOL_PUSH, "reserve B=%d src=%d" % (B, s))
+                    assert_close(r, ro, TOL_PUSH, "residue B=%d src=%d" % (B, s))
+                est, stf = g_part.fora_single_source(s, 0.5, ALPHA, seed=3)
+                est0, stf0 = g_ref.fora_single_source(s, 0.5, ALPHA, seed=3)
+                assert stf.walks == stf0.walks and stf.levels == stf0.levels
+                assert_close(est, est0, TOL_MC, "FORA vs the other layout B=%d src=%d" % (B, s))
+        g_part.set_tuning(pkg.tuning_default())
+        g_ref.set_tuning(pkg.tuning_default())
+        for s in srcs[:2]:
+            pm, _ = g_part.power_method(s, ALPHA, 30)
+            assert_close(pm, og.power_method(s, ALPHA, 30), TOL_PUSH, "power method src=%d" % s)
+            nsel, ids, vals, est, st = g_part.fora_topk(s, 0.5, ALPHA, 10, seed=4, cap=host.n, fetch=True)
+            nsel0, ids0, vals0, est0, st0 = g_ref.fora_topk(s, 0.5, ALPHA, 10, seed=4, cap=host.n, fetch=True)
+            assert nsel == nsel0 and list(ids) == list(ids0) and st.rounds == st0.rounds
+            assert_close(est, est0, TOL_MC, "top-k estimate src=%d" % s)
+    finally:
+        g_part.close()
+        g_ref.close()
+
+
 # ------------------------------------------------------------------ FORA top-k (a6, a7)
 @pytest.mark.parametrize("k", [1, 10, 50, 200])
 def test_fora_topk_got(pkg, orc, got, dev_got, k):

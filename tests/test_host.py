@@ -214,7 +214,50 @@ def test_index_merge_large_runs_on_all_threads(pkg):
 
 
 # ------------------------------------------------------------------ graph lift, host half (row a11; PPR.java:136-152)
-def _lift_expected(h, width=393216, chunk=512, max_windows=16):
+def _panel_expected(n, m, in_rp, in_ci, nz_rows, panel=16384, step=4096, item_edges=65536):
+    """The row-panel copy of the in-CSR (engine_internal.hpp: HostPanelLayout) restated with numpy sorts: panels of
+    16 384 consecutive rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more than 65 536 edges
+    is cut into S = ceil(edges / 65 536) parts [e k / S, e (k + 1) / S); every part padded to whole turns of 4 096 edges
+    with (0, 0xffff); part k of a panel of `rows` rows leaves its sums at base + k rows + local row."""
+    indeg = np.diff(in_rp).astype(np.int64)
+    n_nz = nz_rows.size
+    n_panels = (n_nz + panel - 1) // panel
+    row_of_edge = np.repeat(np.arange(n, dtype=np.int64), indeg)
+    ordinal = np.cumsum(indeg > 0) - 1
+    j_of_edge = ordinal[row_of_edge]
+    p_of_edge = j_of_edge // panel
+    perm = np.lexsort((j_of_edge, in_ci, p_of_edge))       # panel, then source, then row
+    e_src, e_row = in_ci[perm], (j_of_edge % panel)[perm]
+    edges_p = np.bincount(p_of_edge, minlength=n_panels).astype(np.int64)
+    S = np.maximum(1, (edges_p + item_edges - 1) // item_edges)
+    item0 = np.zeros(n_panels + 1, dtype=np.int64)
+    item0[1:] = np.cumsum(S)
+    rows_p = np.minimum(panel, n_nz - np.arange(n_panels) * panel)
+    base = np.zeros(n_panels + 1, dtype=np.int64)
+    base[1:] = np.cumsum(rows_p * S)
+    desc = np.zeros((n_panels, 4), dtype=np.uint32)
+    desc[:, 0], desc[:, 1], desc[:, 2] = base[:-1], S, rows_p
+    items = np.zeros((int(item0[-1]), 4), dtype=np.uint32)
+    first_edge = np.zeros(n_panels + 1, dtype=np.int64)
+    first_edge[1:] = np.cumsum(edges_p)
+    src_out, row_out = [], []
+    st = 0
+    for t in range(n_panels):
+        e = int(edges_p[t])
+        for k in range(int(S[t])):
+            lo, hi = e * k // int(S[t]), e * (k + 1) // int(S[t])
+            steps = (hi - lo + step - 1) // step
+            items[item0[t] + k] = (st, steps, t, base[t] + k * rows_p[t])
+            pad = steps * step - (hi - lo)
+            src_out += [e_src[first_edge[t] + lo:first_edge[t] + hi], np.zeros(pad, dtype=np.int32)]
+            row_out += [e_row[first_edge[t] + lo:first_edge[t] + hi].astype(np.uint16), np.full(pad, 0xffff, dtype=np.uint16)]
+            st += steps
+    return dict(panel_sizes=np.array([n_panels, item0[-1], base[-1], st * step], dtype=np.uint64),
+                panel_src=np.concatenate(src_out).astype(np.int32), panel_row=np.concatenate(row_out).astype(np.uint16),
+                panel_items=items.ravel(), panel_desc=desc.ravel(), panel_item0=item0.astype(np.uint32))
+
+
+def _lift_expected(h, width=393216, chunk=512, max_windows=16, panels=None):
     """The internal layout restated with numpy (stable sorts instead of the library's counting sort and threaded
     passes): vertex order = nodes with in-edges first, then out-degree descending, ties by id; rows keep their
     order; row-start flags; the sliced copy = in-edges in row order, stably partitioned by slice of the source id."""
@@ -258,6 +301,11 @@ def _lift_expected(h, width=393216, chunk=512, max_windows=16):
     np.bitwise_or.at(cross, j >> 6, np.uint64(1) << (j & 63).astype(np.uint64))
     exp = dict(new2old=new2old, old2new=old2new, out_rp=out_rp, out_ci=out_ci, in_rp=in_rp, in_ci=in_ci, nz_rows=nz_rows,
                zin_rows=zin_rows, flags=flags, chunk_starts=chunk_starts, cross=cross)
+    if panels is None:
+        panels = m >= (1 << 20)
+    if panels and m and nz_rows.size:  # graphs with the row-panel copy have no sliced one
+        exp.update(_panel_expected(n, m, in_rp, in_ci, nz_rows))
+        return exp
     n_src = int(np.nonzero(outdeg > 0)[0].max()) + 1 if (outdeg > 0).any() else 0
     S = (n_src + width - 1) // width
     if S > max_windows:
@@ -284,14 +332,17 @@ def _lift_expected(h, width=393216, chunk=512, max_windows=16):
     return exp
 
 
-@pytest.mark.parametrize("scale,slice_ids", [(10, 100), (16, 20000), (17, 0)])
-def test_lift_host_matches_numpy_restatement(pkg, monkeypatch, scale, slice_ids):
+@pytest.mark.parametrize("scale,slice_ids,panels", [(10, 100, None), (10, 0, "1"), (16, 20000, "0"), (16, 0, None), (17, 0, None)])
+def test_lift_host_matches_numpy_restatement(pkg, monkeypatch, scale, slice_ids, panels):
     """pprhip_graph_lift_host (what pprhip_graph_create uploads) against an independent numpy restatement of the
-    layout, on one thread and on eight (scale 16/17 are large enough for the threaded passes): same bytes."""
+    layout, on one thread and on eight (scale 16/17 are large enough for the threaded passes): same bytes.  Graphs from
+    2^20 edges on get the row-panel copy instead of the sliced one (PPRHIP_SWEEP1_PANELS=0 / 1 forces either)."""
     if slice_ids:
         monkeypatch.setenv("PPRHIP_SLICE_IDS", str(slice_ids))
+    if panels is not None:
+        monkeypatch.setenv("PPRHIP_SWEEP1_PANELS", panels)
     h = pkg.HostCsr.rmat(scale, 16, seed=4)
-    exp = _lift_expected(h, width=slice_ids or 393216)
+    exp = _lift_expected(h, width=slice_ids or 393216, panels=None if panels is None else panels == "1")
     for threads in (1, 8):
         got = pkg.lift_host(h, threads=threads)
         for name, want in exp.items():
@@ -299,6 +350,8 @@ def test_lift_host_matches_numpy_restatement(pkg, monkeypatch, scale, slice_ids)
             assert np.array_equal(got[name], want), (name, threads)
         if "sl_ci" not in exp:
             assert got["sl_ci"].size == 0 and got["seg_row"].size == 0
+        if "panel_src" not in exp:
+            assert got["panel_src"].size == 0 and got["panel_sizes"].size == 0
     # without the caller's in-adjacency the lift derives one: same vertex order and out-CSR, and an in-CSR that is
     # the transpose (rows as multisets; the order inside a derived row follows the renamed out-CSR)
     own = pkg.lift_host(h, threads=8, with_in=False)
