@@ -238,13 +238,13 @@ enum {
   PPRHIP_LIFT_SEG_OFF = 17,          /* uint32[segments]: first edge */
   /* the row-panel copy of the in-adjacency the single-query sweep walks (graphs from 2^20 edges on; they have no sliced
    * copy): panels of 16 384 consecutive rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more
-   * than 65 536 edges is cut into parts of equal edge counts; every part (item) padded to whole turns of 4 096 edges
+   * than 65 536 edges is cut into parts of equal edge counts; every part (item) padded to whole turns of 8 192 edges
    * with (0, 0xffff).  All empty when the graph has none. */
   PPRHIP_LIFT_PANEL_SIZES = 18,      /* uint64[4]: panels, items, doubles of partial sums, edges with padding */
   PPRHIP_LIFT_PANEL_SRC = 19,        /* int32[edges]: sources */
   PPRHIP_LIFT_PANEL_ROW = 20,        /* uint16[edges]: row ordinal - first ordinal of the panel; 0xffff: padding */
-  PPRHIP_LIFT_PANEL_ITEMS = 21,      /* uint32[items][4]: first edge / 4096, turns, panel, offset of the item's sums */
-  PPRHIP_LIFT_PANEL_DESC = 22,       /* uint32[panels][4]: offset of the panel's sums, parts, rows, 0 */
+  PPRHIP_LIFT_PANEL_ITEMS = 21,      /* uint32[items][4]: first edge / 8192, turns, panel, offset of the item's sums */
+  PPRHIP_LIFT_PANEL_DESC = 22,       /* uint32[panels][4]: offset of the panel's sums, parts, rows, offset of their sums 32 at a time (or ~0) */
   PPRHIP_LIFT_PANEL_ITEM0 = 23       /* uint32[panels + 1]: first item of every panel */
 };
 int pprhip_graph_lift_host(uint32_t n, uint64_t m, const uint32_t* out_row_ptr, const int32_t* out_col_idx,

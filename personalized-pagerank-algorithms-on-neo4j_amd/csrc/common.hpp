@@ -50,7 +50,7 @@ constexpr int kBlock = 256;
 // cut into panels of kPanelRows consecutive ordinals whose sums fit a CU's LDS, a panel's in-edges are kept sorted by
 // source, and a workgroup sums an ITEM - a part of at most kItemEdges edges of one panel - into accumulators in LDS.
 constexpr uint32_t kPanelRows = 16384;   // x 8 B = 128 KB of a CU's 160 KB
-constexpr uint32_t kPanelStep = 4096;    // edges a workgroup takes per turn (1024 lanes x 4): items are padded to it
+constexpr uint32_t kPanelStep = 8192;    // edges a workgroup takes per turn (1024 lanes x 8): items are padded to it
 constexpr uint32_t kItemEdges = 65536;   // a panel with more edges is cut into parts of about this many
 struct PanelItem {                       // one unit of work of the edge kernel
   uint32_t edge0;                        // first edge, in units of kPanelStep
@@ -58,9 +58,12 @@ struct PanelItem {                       // one unit of work of the edge kernel
   uint32_t panel;                        // rows [panel * kPanelRows, ...)
   uint32_t part0;                        // where the item's sums go: part[part0 + local row]
 };
-struct PanelDesc {                       // per panel: its S parts' sums are part[base + k * rows + local row], k < S
-  uint32_t base, parts, rows, pad;
-};
+constexpr uint32_t kFoldParts = 32;      // a panel of more than kFoldMin parts has them added kFoldParts at a time first
+constexpr uint32_t kFoldMin = 16;
+constexpr uint32_t kNoFold = 0xffffffffu;
+struct PanelDesc {                       // per panel: its S parts' sums are part[base + k * rows + local row], k < S;
+  uint32_t base, parts, rows, fold;      // fold != kNoFold: ceil(S / kFoldParts) sums of kFoldParts parts each at
+};                                       // part[fold + g * rows + local row] (k_panel_fold)
 constexpr int kTileRows = 64;   // rows per tile of the batched apply kernel (kernels_push.hip: kApplyRows)
 
 // packed frontier counter: entries in the high 28 bits, edge total in the low 36 bits

@@ -830,8 +830,8 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
 // ------------------------------------------------------------------------------------------------
 // k_dense_edges_panel (round 6): the single-query forward edge kernel over the row-panel copy (engine_internal.hpp:
 // HostPanelLayout).  A workgroup takes an ITEM - at most kItemEdges edges of one panel of kPanelRows rows, sorted by
-// source - and sums it into acc[row] in LDS (128 KB).  A lane takes four consecutive edges per turn, a wave 256, the
-// workgroup 4 096: neighbouring lanes gather neighbouring sources, so the sixteen contributions of a 128-byte line are
+// source - and sums it into acc[row] in LDS (128 KB).  A wave takes 512 consecutive edges per turn, lane l the edges l,
+// l + 64, ... of them (stored as the lane's 32 bytes), the workgroup 8 192: neighbouring lanes gather neighbouring sources, so the sixteen contributions of a 128-byte line are
 // one request to the L1 (which keeps ~256 lines in flight per CU - what bounds the row-major and the sliced kernel:
 // TCP_PENDING_STALL_CYCLES 0.69 of their cycles), and every workgroup walks the contribution array front to back.  Sums
 // land with ds_add_f64 (zero contributions are skipped: a dense level's frontier is a part of the nodes); at the end
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(1024) void k_dense_edges_b(const int32_t* __restric
 // ------------------------------------------------------------------------------------------------
 constexpr int kPanelThreads = 1024;
 constexpr int kPanelLdsBytes = (int)(kPanelRows * sizeof(double));
-static_assert(kPanelStep == (uint32_t)kPanelThreads * 4u, "four edges per lane and turn");
+static_assert(kPanelStep == (uint32_t)kPanelThreads * 8u, "eight edges per lane and turn");
 
 __global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32_t* __restrict__ src,
                                                                      const uint16_t* __restrict__ rloc,
@@ -852,7 +852,6 @@ __global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32
                                                                      uint32_t j_hi, uint32_t n_nz, const int* state_in) {
   extern __shared__ __attribute__((aligned(16))) double acc[];
   typedef int v4i __attribute__((ext_vector_type(4)));
-  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
   if (dense_state(state_in, kGsJacobi) == kGsNone) return;
   const uint32_t tid = threadIdx.x;
   for (uint32_t it = item_lo + blockIdx.x; it < item_hi; it += gridDim.x) {
@@ -866,28 +865,35 @@ __global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32
     const uint32_t row0 = I.panel * kPanelRows;
     const uint32_t r_lo = j_lo > row0 ? j_lo - row0 : 0u;
     const uint32_t r_hi = j_hi > row0 ? min(min(j_hi, n_nz) - row0, kPanelRows) : 0u;  // (padding: row 0xffff >= r_hi)
-    const v4i* sp = reinterpret_cast<const v4i*>(src + (size_t)I.edge0 * kPanelStep) + tid;
-    const v2u* rp = reinterpret_cast<const v2u*>(rloc + (size_t)I.edge0 * kPanelStep) + tid;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4i* sp = reinterpret_cast<const v4i*>(src + (size_t)I.edge0 * kPanelStep) + 2u * tid;
+    const v4u* rp = reinterpret_cast<const v4u*>(rloc + (size_t)I.edge0 * kPanelStep) + tid;
     // the index streams are read once per sweep: non-temporal, so that they do not push gathered lines out of L2
-    v4i ix = __builtin_nontemporal_load(sp);
-    v2u rx = __builtin_nontemporal_load(rp);
+    v4i ia = __builtin_nontemporal_load(sp), ib = __builtin_nontemporal_load(sp + 1);
+    v4u rx = __builtin_nontemporal_load(rp);
     for (uint32_t i = 0; i < I.steps; ++i) {
-      v4i nx = ix;
-      v2u nr = rx;
+      v4i na = ia, nb = ib;
+      v4u nr = rx;
       if (i + 1 < I.steps) {  // in flight beside the gathers
-        nx = __builtin_nontemporal_load(sp + (size_t)(i + 1) * kPanelThreads);
+        na = __builtin_nontemporal_load(sp + (size_t)(i + 1) * (2 * kPanelThreads));
+        nb = __builtin_nontemporal_load(sp + (size_t)(i + 1) * (2 * kPanelThreads) + 1);
         nr = __builtin_nontemporal_load(rp + (size_t)(i + 1) * kPanelThreads);
       }
-      const uint32_t r0 = rx.x & 0xffffu, r1 = rx.x >> 16, r2 = rx.y & 0xffffu, r3 = rx.y >> 16;
-      const bool in0 = r0 >= r_lo && r0 < r_hi, in1 = r1 >= r_lo && r1 < r_hi, in2 = r2 >= r_lo && r2 < r_hi,
-                 in3 = r3 >= r_lo && r3 < r_hi;
+      const int32_t u[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+      const uint32_t r[8] = {rx.x & 0xffffu, rx.x >> 16, rx.y & 0xffffu, rx.y >> 16,
+                             rx.z & 0xffffu, rx.z >> 16, rx.w & 0xffffu, rx.w >> 16};
+      bool in[8];
+      double v[8];
       // (rows outside the block and the padding gather the first contribution - one shared line - and add nothing)
-      const double v0 = c_cur[in0 ? ix.x : 0], v1 = c_cur[in1 ? ix.y : 0], v2 = c_cur[in2 ? ix.z : 0], v3 = c_cur[in3 ? ix.w : 0];
-      if (in0 && v0 != 0.0) atomic_add_noret(&acc[r0], v0);
-      if (in1 && v1 != 0.0) atomic_add_noret(&acc[r1], v1);
-      if (in2 && v2 != 0.0) atomic_add_noret(&acc[r2], v2);
-      if (in3 && v3 != 0.0) atomic_add_noret(&acc[r3], v3);
-      ix = nx;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) in[e] = r[e] >= r_lo && r[e] < r_hi;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = c_cur[in[e] ? u[e] : 0];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (in[e] && v[e] != 0.0) atomic_add_noret(&acc[r[e]], v[e]);
+      ia = na;
+      ib = nb;
       rx = nr;
     }
     __syncthreads();
@@ -896,6 +902,28 @@ __global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32
       if (r >= r_lo && r < r_hi) part[(size_t)I.part0 + r] = acc[r];
     __syncthreads();  // (the accumulators are read: the next item clears them)
   }
+}
+
+// The hub panels' parts: a panel of S > kFoldMin parts has them added kFoldParts at a time first - workgroup (x, g)
+// adds the parts [g kFoldParts, ...) of 256 rows, the loads of a lane independent of one another - so that k_dense_apply
+// adds ceil(S / kFoldParts) values per row instead of hundreds in a chain.  Rows outside [j_lo, j_hi) are left alone.
+__global__ __launch_bounds__(256) void k_panel_fold(double* __restrict__ part, const PanelDesc* __restrict__ panels,
+                                                    uint32_t panel, uint32_t j_lo, uint32_t j_hi, const int* state_in) {
+  if (dense_state(state_in, kGsJacobi) == kGsNone) return;
+  panel += blockIdx.z;
+  const PanelDesc P = panels[panel];
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x, g = blockIdx.y, j = panel * kPanelRows + r;
+  if (P.fold == kNoFold || r >= P.rows || j < j_lo || j >= j_hi) return;
+  const uint32_t k0 = g * kFoldParts, k1 = min(P.parts, k0 + kFoldParts);
+  if (k0 >= P.parts) return;
+  const double* p = part + (size_t)P.base + r;
+  double x[kFoldParts];
+#pragma unroll
+  for (uint32_t k = 0; k < kFoldParts; ++k) x[k] = k0 + k < k1 ? p[(size_t)(k0 + k) * P.rows] : 0.0;
+  double v = 0.0;
+#pragma unroll
+  for (uint32_t k = 0; k < kFoldParts; ++k) v += x[k];
+  part[(size_t)P.fold + (size_t)g * P.rows + r] = v;
 }
 
 // k_dense_apply: one thread per non-empty row (plus one for a source without in-edges, which
@@ -929,8 +957,16 @@ __global__ __launch_bounds__(256) void k_dense_apply(const int32_t* __restrict__
     u = nz_rows[j];
     if (PANEL) {
       const PanelDesc P = panels[j / kPanelRows];  // (a wave's rows lie in one panel or two: uniform loads)
-      const double* p = acc_nz + (size_t)P.base + (j % kPanelRows);
-      for (uint32_t k = 0; k < P.parts; ++k) acc += p[(size_t)k * P.rows];
+      const bool folded = P.fold != kNoFold;
+      const double* p = acc_nz + (size_t)(folded ? P.fold : P.base) + (j % kPanelRows);
+      const uint32_t cnt = folded ? (P.parts + kFoldParts - 1) / kFoldParts : P.parts;
+      uint32_t k = 0;
+      for (; k + 4 <= cnt; k += 4) {
+        const double x0 = p[(size_t)k * P.rows], x1 = p[(size_t)(k + 1) * P.rows], x2 = p[(size_t)(k + 2) * P.rows],
+                     x3 = p[(size_t)(k + 3) * P.rows];
+        acc = (((acc + x0) + x1) + x2) + x3;
+      }
+      for (; k < cnt; ++k) acc += p[(size_t)k * P.rows];
     } else {
       acc = acc_nz[j];
       acc_nz[j] = 0.0;
@@ -1711,6 +1747,20 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
         k_dense_edges_panel<<<dim3(grid), dim3(kPanelThreads), kPanelLdsBytes, g->stream>>>(
             pn->src, pn->rloc, pn->items, i_lo, i_hi, g->cdense[cbuf], g->pn_part, B.j_lo, B.j_hi, n_nz, dl.state_in);
         PPRHIP_CHECK_HIP(hipGetLastError());
+        // panels of many parts (the hub rows': the first few - rows are ordered by degree, so parts do not grow)
+        uint32_t p_fold = p_lo, s_max = 0;
+        for (uint32_t p = p_lo; p < p_hi; ++p) {
+          const uint32_t S = pn->h_panel_item0[p + 1] - pn->h_panel_item0[p];
+          if (S > kFoldMin) {
+            p_fold = p + 1;
+            s_max = std::max(s_max, S);
+          }
+        }
+        if (p_fold > p_lo) {
+          k_panel_fold<<<dim3(kPanelRows / 256, (s_max + kFoldParts - 1) / kFoldParts, p_fold - p_lo), dim3(256), 0, g->stream>>>(
+              g->pn_part, pn->panels, p_lo, B.j_lo, B.j_hi, dl.state_in);
+          PPRHIP_CHECK_HIP(hipGetLastError());
+        }
       }
     } else if (g->n_chunks && n_ch) {
       // persistent workgroups: one 1024-thread workgroup per CU when the LDS hot table is in use

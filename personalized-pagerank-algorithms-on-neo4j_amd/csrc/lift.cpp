@@ -475,7 +475,7 @@ int build_panel_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int3
     panel_edges[t] = e;
     const uint64_t S = std::max<uint64_t>(1, (e + kItemEdges - 1) / kItemEdges);
     L.panel_item0[t] = (uint32_t)items;
-    L.panels[t] = PanelDesc{(uint32_t)part, (uint32_t)S, j_hi - j_lo, 0u};
+    L.panels[t] = PanelDesc{(uint32_t)part, (uint32_t)S, j_hi - j_lo, kNoFold};
     for (uint64_t k = 0; k < S; ++k) steps += (e * (k + 1) / S - e * k / S + kPanelStep - 1) / kPanelStep;
     items += S;
     part += (uint64_t)(j_hi - j_lo) * S;
@@ -484,6 +484,16 @@ int build_panel_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int3
       return PPRHIP_OK;
     }
   }
+  // panels of many parts (the hub rows'): room behind the parts for their sums kFoldParts at a time
+  for (size_t t = 0; t < NP; ++t)
+    if (L.panels[t].parts > kFoldMin) {
+      L.panels[t].fold = (uint32_t)part;
+      part += (uint64_t)L.panels[t].rows * ((L.panels[t].parts + kFoldParts - 1) / kFoldParts);
+      if (part >= 0xfffffff0ull) {
+        L.n_items = 0;
+        return PPRHIP_OK;
+      }
+    }
   L.panel_item0[NP] = (uint32_t)items;
   L.n_items = (uint32_t)items;
   L.n_part = part;
@@ -523,13 +533,16 @@ int build_panel_layout(uint32_t n, uint64_t m, const uint32_t* in_rp, const int3
       const uint64_t lo = e * k / S, hi = e * (k + 1) / S;
       int32_t* so = L.src.data() + (size_t)I.edge0 * kPanelStep;
       uint16_t* ro = L.rloc.data() + (size_t)I.edge0 * kPanelStep;
+      // a wave takes 512 consecutive edges per turn, lane l the edges l, l + 64, ... of them (eight gathers, each over 64
+      // consecutive edges: the lines of one instruction are no other's) - stored so that they are the lane's 32 bytes
+      auto at = [](uint64_t x) { return (x & ~511ull) | ((x & 63ull) << 3) | ((x >> 6) & 7ull); };
       for (uint64_t x = lo; x < hi; ++x) {
-        so[x - lo] = (int32_t)(key[x] >> 16);
-        ro[x - lo] = (uint16_t)(key[x] & 0xffffu);
+        so[at(x - lo)] = (int32_t)(key[x] >> 16);
+        ro[at(x - lo)] = (uint16_t)(key[x] & 0xffffu);
       }
       for (uint64_t x = hi - lo; x < (uint64_t)I.steps * kPanelStep; ++x) {
-        so[x] = 0;
-        ro[x] = 0xffffu;
+        so[at(x)] = 0;
+        ro[at(x)] = 0xffffu;
       }
     }
   });

@@ -214,11 +214,12 @@ def test_index_merge_large_runs_on_all_threads(pkg):
 
 
 # ------------------------------------------------------------------ graph lift, host half (row a11; PPR.java:136-152)
-def _panel_expected(n, m, in_rp, in_ci, nz_rows, panel=16384, step=4096, item_edges=65536):
+def _panel_expected(n, m, in_rp, in_ci, nz_rows, panel=16384, step=8192, item_edges=65536, fold_parts=32, fold_min=16):
     """The row-panel copy of the in-CSR (engine_internal.hpp: HostPanelLayout) restated with numpy sorts: panels of
     16 384 consecutive rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more than 65 536 edges
-    is cut into S = ceil(edges / 65 536) parts [e k / S, e (k + 1) / S); every part padded to whole turns of 4 096 edges
-    with (0, 0xffff); part k of a panel of `rows` rows leaves its sums at base + k rows + local row."""
+    is cut into S = ceil(edges / 65 536) parts [e k / S, e (k + 1) / S); every part padded to whole turns of 8 192 edges
+    with (0, 0xffff); part k of a panel of `rows` rows leaves its sums at base + k rows + local row; a panel of more than 16
+    parts has room behind all parts for their sums 32 at a time."""
     indeg = np.diff(in_rp).astype(np.int64)
     n_nz = nz_rows.size
     n_panels = (n_nz + panel - 1) // panel
@@ -236,7 +237,11 @@ def _panel_expected(n, m, in_rp, in_ci, nz_rows, panel=16384, step=4096, item_ed
     base = np.zeros(n_panels + 1, dtype=np.int64)
     base[1:] = np.cumsum(rows_p * S)
     desc = np.zeros((n_panels, 4), dtype=np.uint32)
-    desc[:, 0], desc[:, 1], desc[:, 2] = base[:-1], S, rows_p
+    desc[:, 0], desc[:, 1], desc[:, 2], desc[:, 3] = base[:-1], S, rows_p, 0xffffffff
+    n_part = int(base[-1])
+    for t in np.nonzero(S > fold_min)[0]:                  # room for the sums of 32 parts at a time, behind all parts
+        desc[t, 3] = n_part
+        n_part += int(rows_p[t]) * int((S[t] + fold_parts - 1) // fold_parts)
     items = np.zeros((int(item0[-1]), 4), dtype=np.uint32)
     first_edge = np.zeros(n_panels + 1, dtype=np.int64)
     first_edge[1:] = np.cumsum(edges_p)
@@ -252,8 +257,10 @@ def _panel_expected(n, m, in_rp, in_ci, nz_rows, panel=16384, step=4096, item_ed
             src_out += [e_src[first_edge[t] + lo:first_edge[t] + hi], np.zeros(pad, dtype=np.int32)]
             row_out += [e_row[first_edge[t] + lo:first_edge[t] + hi].astype(np.uint16), np.full(pad, 0xffff, dtype=np.uint16)]
             st += steps
-    return dict(panel_sizes=np.array([n_panels, item0[-1], base[-1], st * step], dtype=np.uint64),
-                panel_src=np.concatenate(src_out).astype(np.int32), panel_row=np.concatenate(row_out).astype(np.uint16),
+    # a wave's 512 edges of a turn are stored lane by lane: lane l holds the edges l, l + 64, ... (eight of them)
+    lanes = lambda a: a.reshape(-1, 8, 64).transpose(0, 2, 1).ravel()
+    return dict(panel_sizes=np.array([n_panels, item0[-1], n_part, st * step], dtype=np.uint64),
+                panel_src=lanes(np.concatenate(src_out).astype(np.int32)), panel_row=lanes(np.concatenate(row_out).astype(np.uint16)),
                 panel_items=items.ravel(), panel_desc=desc.ravel(), panel_item0=item0.astype(np.uint32))
 
 
