@@ -236,10 +236,11 @@ enum {
   PPRHIP_LIFT_SLICED_CHUNK_STARTS = 15, /* uint32[] */
   PPRHIP_LIFT_SEG_ROW = 16,          /* uint32[segments]: row ordinal */
   PPRHIP_LIFT_SEG_OFF = 17,          /* uint32[segments]: first edge */
-  /* the row-panel copy of the in-adjacency the single-query sweep walks (graphs from 2^20 edges on; they have no sliced
-   * copy): panels of 16 384 consecutive rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more
-   * than 65 536 edges is cut into parts of equal edge counts; every part (item) padded to whole turns of 8 192 edges
-   * with (0, 0xffff).  All empty when the graph has none. */
+  /* the row-panel copy of the in-adjacency the single-query sweep walks (graphs from 2^26 edges on; they have no sliced
+   * copy): panels of 8 192 consecutive rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more
+   * than 32 768 edges is cut into parts of equal edge counts; every part (item) padded to whole turns of 8 192 edges
+   * with (0, 0xffff), a wave's 512 edges of a turn stored lane by lane (lane l: the edges l, l + 64, ...).  All empty
+   * when the graph has none. */
   PPRHIP_LIFT_PANEL_SIZES = 18,      /* uint64[4]: panels, items, doubles of partial sums, edges with padding */
   PPRHIP_LIFT_PANEL_SRC = 19,        /* int32[edges]: sources */
   PPRHIP_LIFT_PANEL_ROW = 20,        /* uint16[edges]: row ordinal - first ordinal of the panel; 0xffff: padding */

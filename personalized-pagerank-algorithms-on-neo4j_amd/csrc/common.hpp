@@ -49,9 +49,9 @@ constexpr int kBlock = 256;
 // Single-query forward sweep over ROW PANELS (engine_internal.hpp: HostPanelLayout, round 6): the rows with in-edges are
 // cut into panels of kPanelRows consecutive ordinals whose sums fit a CU's LDS, a panel's in-edges are kept sorted by
 // source, and a workgroup sums an ITEM - a part of at most kItemEdges edges of one panel - into accumulators in LDS.
-constexpr uint32_t kPanelRows = 16384;   // x 8 B = 128 KB of a CU's 160 KB
+constexpr uint32_t kPanelRows = 8192;    // x 8 B = 64 KB: two workgroups share a CU's 160 KB
 constexpr uint32_t kPanelStep = 8192;    // edges a workgroup takes per turn (1024 lanes x 8): items are padded to it
-constexpr uint32_t kItemEdges = 65536;   // a panel with more edges is cut into parts of about this many
+constexpr uint32_t kItemEdges = 32768;   // a panel with more edges is cut into parts of about this many
 struct PanelItem {                       // one unit of work of the edge kernel
   uint32_t edge0;                        // first edge, in units of kPanelStep
   uint32_t steps;                        // turns

@@ -385,6 +385,8 @@ static int upload_panel_layout(pprhip_graph* G, HostLift& H) {
 // the buffer the items of a panel sweep leave their sums in: per handle, on its first forward dense level
 int ensure_panel_part(pprhip_graph* g) {
   if (!g->pn || g->pn_part) return PPRHIP_OK;
+  PPRHIP_TRY(alloc_dev((void**)&g->pn_ctr, 4 * sizeof(uint32_t)));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->pn_ctr, 0, 4 * sizeof(uint32_t), g->stream));
   return alloc_dev((void**)&g->pn_part, sizeof(double) * (size_t)g->pn->n_part);
 }
 
@@ -724,7 +726,7 @@ int alloc_workspace(pprhip_graph* G) {
 }
 
 void free_workspace(pprhip_graph* g) {
-  void* ptrs[] = {g->pn_part, g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1],
+  void* ptrs[] = {g->pn_part, g->pn_ctr, g->acc_nz, g->residue, g->reserve, g->est, g->cdense[0], g->cdense[1], g->cF, g->F[0], g->F[1],
                   g->eoff[0], g->eoff[1], g->flags, g->armed, g->mc_plan_rec, g->partial, g->hist, g->sel_blob,
                   g->ctr, g->blk_pack, g->blk_dead, g->blk_ndead};
   for (void* p : ptrs)

@@ -332,7 +332,8 @@ struct pprhip_graph {
   double* acc_nz = nullptr;  // per non-empty row: sum of this level's contributions
   pprhip::SlicedLayout* sl = nullptr;
   pprhip::PanelLayout* pn = nullptr;   // row-panel copy of the in-CSR (shared with the batch slots), or none
-  double* pn_part = nullptr;           // [pn->n_part] the items' sums of this handle's sweep (first forward dense level)  // single-query sweep layout (owned by the lifted graph, borrowed by slots)
+  double* pn_part = nullptr;           // [pn->n_part] the items' sums of this handle's sweep (first forward dense level)
+  uint32_t* pn_ctr = nullptr;          // [4] item queues of a level's edge launches (one per Gauss-Seidel block); k_dense_reduce zeroes them  // single-query sweep layout (owned by the lifted graph, borrowed by slots)
   // batched queries: kBatch workspaces ("slots") borrow this handle's CSR and stream; their dense
   // levels run as one sweep over the interleaved contribution array c8[v][slot]
   pprhip_graph* parent = nullptr;  // set on a slot

@@ -189,10 +189,10 @@ using RawVec = std::vector<T, NoInitAlloc<T>>;
 // contribution per in-edge, every gather asks the L1 for a 128-byte line, and a CU keeps ~256 lines in flight
 // (TCP_PENDING_STALL_CYCLES: 0.69 of k_dense_edges<true, true>'s cycles; profiles/r06_ell_sweep_study.txt for the model):
 // the row-major and the sliced copy ask for 18 M lines per half sweep of R-MAT 22's 33.5 M edges.  Here the rows are cut
-// into PANELS of kPanelRows consecutive ordinals whose sums fit a CU's LDS (128 KB), and a panel's in-edges are sorted by
-// (source, row): neighbouring lanes gather neighbouring sources, so the sixteen sources of a line are served by one
-// request, and a workgroup walks the contribution array front to back - all workgroups at about the same place, so a
-// line leaves HBM once per XCD and sweep.  R-MAT 22: 3.5 M distinct (item, line) pairs per sweep for 67 M edges.
+// into PANELS of kPanelRows consecutive ordinals whose sums fit half a CU's LDS (64 KB: two workgroups share a CU), and a
+// panel's in-edges are sorted by (source, row): neighbouring lanes gather neighbouring sources, so the sources of a line
+// are served by one request, and a workgroup walks its part of the contribution array front to back.  R-MAT 22:
+// 4.6 M requests to L2 per half sweep where the sliced copy makes 18.1 M (counters: profiles/r06_pmc_single_*.txt).
 // A panel of more than kItemEdges edges is cut into S parts of equal edge counts (ITEMS); part k sums into LDS of its own
 // and leaves part[base + k * rows + local row]; k_dense_apply adds a row's S values.  Every item's edges are padded to
 // whole turns of kPanelStep with (source 0, row 0xffff): a row ordinal no panel has, skipped by the kernel.

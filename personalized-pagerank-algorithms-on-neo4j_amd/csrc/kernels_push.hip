@@ -843,19 +843,25 @@ constexpr int kPanelThreads = 1024;
 constexpr int kPanelLdsBytes = (int)(kPanelRows * sizeof(double));
 static_assert(kPanelStep == (uint32_t)kPanelThreads * 8u, "eight edges per lane and turn");
 
-__global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32_t* __restrict__ src,
+__global__ __launch_bounds__(kPanelThreads, 8) void k_dense_edges_panel(const int32_t* __restrict__ src,
                                                                      const uint16_t* __restrict__ rloc,
                                                                      const PanelItem* __restrict__ items,
                                                                      uint32_t item_lo, uint32_t item_hi,
                                                                      const double* __restrict__ c_cur,
                                                                      double* __restrict__ part, uint32_t j_lo,
-                                                                     uint32_t j_hi, uint32_t n_nz, const int* state_in) {
+                                                                     uint32_t j_hi, uint32_t n_nz, const int* state_in,
+                                                                     uint32_t* __restrict__ queue) {
   extern __shared__ __attribute__((aligned(16))) double acc[];
+  __shared__ uint32_t s_take;
   typedef int v4i __attribute__((ext_vector_type(4)));
-  if (dense_state(state_in, kGsJacobi) == kGsNone) return;
+  if (dense_state(state_in, kGsJacobi) == kGsNone) return;  // (the queue stays at zero: k_dense_reduce left it so)
   const uint32_t tid = threadIdx.x;
-  for (uint32_t it = item_lo + blockIdx.x; it < item_hi; it += gridDim.x) {
+  // items are handed out by a counter (they differ in size by the panels' rounding, and the last round of a static deal
+  // would leave most CUs idle); the level's k_dense_reduce zeroes it behind the launch
+  uint32_t it = item_lo + blockIdx.x;
+  while (it < item_hi) {
     const PanelItem I = items[it];
+    if (tid == 0) s_take = atomicAdd(queue, 1u);
     {
       double2* a2 = reinterpret_cast<double2*>(acc);
 #pragma unroll
@@ -869,16 +875,18 @@ __global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32
     const v4i* sp = reinterpret_cast<const v4i*>(src + (size_t)I.edge0 * kPanelStep) + 2u * tid;
     const v4u* rp = reinterpret_cast<const v4u*>(rloc + (size_t)I.edge0 * kPanelStep) + tid;
     // the index streams are read once per sweep: non-temporal, so that they do not push gathered lines out of L2
+    // (two turns ahead: a turn's index loads are asked for behind the gathers of the turn before the last, so that the
+    // wait for a turn's gathers - loads return in order - never waits for the stream from HBM)
     v4i ia = __builtin_nontemporal_load(sp), ib = __builtin_nontemporal_load(sp + 1);
     v4u rx = __builtin_nontemporal_load(rp);
+    v4i na = ia, nb = ib;
+    v4u nr = rx;
+    if (I.steps > 1) {
+      na = __builtin_nontemporal_load(sp + (size_t)(2 * kPanelThreads));
+      nb = __builtin_nontemporal_load(sp + (size_t)(2 * kPanelThreads) + 1);
+      nr = __builtin_nontemporal_load(rp + (size_t)kPanelThreads);
+    }
     for (uint32_t i = 0; i < I.steps; ++i) {
-      v4i na = ia, nb = ib;
-      v4u nr = rx;
-      if (i + 1 < I.steps) {  // in flight beside the gathers
-        na = __builtin_nontemporal_load(sp + (size_t)(i + 1) * (2 * kPanelThreads));
-        nb = __builtin_nontemporal_load(sp + (size_t)(i + 1) * (2 * kPanelThreads) + 1);
-        nr = __builtin_nontemporal_load(rp + (size_t)(i + 1) * kPanelThreads);
-      }
       const int32_t u[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
       const uint32_t r[8] = {rx.x & 0xffffu, rx.x >> 16, rx.y & 0xffffu, rx.y >> 16,
                              rx.z & 0xffffu, rx.z >> 16, rx.w & 0xffffu, rx.w >> 16};
@@ -889,18 +897,30 @@ __global__ __launch_bounds__(kPanelThreads) void k_dense_edges_panel(const int32
       for (int e = 0; e < 8; ++e) in[e] = r[e] >= r_lo && r[e] < r_hi;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = c_cur[in[e] ? u[e] : 0];
+      v4i fa = na, fb = nb;
+      v4u fr = nr;
+      if (i + 2 < I.steps) {
+        fa = __builtin_nontemporal_load(sp + (size_t)(i + 2) * (2 * kPanelThreads));
+        fb = __builtin_nontemporal_load(sp + (size_t)(i + 2) * (2 * kPanelThreads) + 1);
+        fr = __builtin_nontemporal_load(rp + (size_t)(i + 2) * kPanelThreads);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         if (in[e] && v[e] != 0.0) atomic_add_noret(&acc[r[e]], v[e]);
       ia = na;
       ib = nb;
       rx = nr;
+      na = fa;
+      nb = fb;
+      nr = fr;
     }
     __syncthreads();
+    const uint32_t taken = s_take;  // (written before the barrier above; the next write comes behind the barrier below)
 #pragma unroll 4
     for (uint32_t r = tid; r < kPanelRows; r += kPanelThreads)
       if (r >= r_lo && r < r_hi) part[(size_t)I.part0 + r] = acc[r];
     __syncthreads();  // (the accumulators are read: the next item clears them)
+    it = item_lo + gridDim.x + taken;
   }
 }
 
@@ -1303,9 +1323,10 @@ __global__ __launch_bounds__(1024) void k_dense_reduce(const unsigned long long*
                                                         DevCounters* ctr, int out_slot, int dead_slot_next,
                                                         const int* state_in, int state0, unsigned long long* hist_out,
                                                         int* state_out, unsigned long long dense_thresh,
-                                                        unsigned long long gs_thresh) {
+                                                        unsigned long long gs_thresh, uint32_t* queues) {
   __shared__ double s_red[16];
   __shared__ unsigned long long s_red2[16];
+  if (queues && threadIdx.x < 4) queues[threadIdx.x] = 0u;  // the item queues of this level's panel launches
   const int state = dense_state(state_in, state0);
   if (state == kGsNone) {
     if (threadIdx.x == 0 && state_out) *state_out = kGsNone;
@@ -1743,9 +1764,10 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
       const uint32_t p_lo = B.j_lo / kPanelRows, p_hi = std::min<uint32_t>(pn->n_panels, (B.j_hi + kPanelRows - 1) / kPanelRows);
       const uint32_t i_lo = p_hi > p_lo ? pn->h_panel_item0[p_lo] : 0u, i_hi = p_hi > p_lo ? pn->h_panel_item0[p_hi] : 0u;
       if (i_hi > i_lo) {
-        const uint32_t grid = std::min<uint32_t>(i_hi - i_lo, (uint32_t)g->n_cus);
+        const uint32_t grid = std::min<uint32_t>(i_hi - i_lo, (uint32_t)g->n_cus * (uint32_t)(160 * 1024 / (kPanelLdsBytes + 1024)));
         k_dense_edges_panel<<<dim3(grid), dim3(kPanelThreads), kPanelLdsBytes, g->stream>>>(
-            pn->src, pn->rloc, pn->items, i_lo, i_hi, g->cdense[cbuf], g->pn_part, B.j_lo, B.j_hi, n_nz, dl.state_in);
+            pn->src, pn->rloc, pn->items, i_lo, i_hi, g->cdense[cbuf], g->pn_part, B.j_lo, B.j_hi, n_nz, dl.state_in,
+            g->pn_ctr + std::min(b, 3));
         PPRHIP_CHECK_HIP(hipGetLastError());
         // panels of many parts (the hub rows': the first few - rows are ordered by degree, so parts do not grow)
         uint32_t p_fold = p_lo, s_max = 0;
@@ -1804,7 +1826,7 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
   }
   k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, g->blk_dead, g->blk_ndead, part_base, g->ctr,
                                                         out_slot, dead_slot ^ 1, dl.state_in, dl.state0, dl.hist_out,
-                                                        dl.state_out, dl.dense_thresh, dl.gs_thresh);
+                                                        dl.state_out, dl.dense_thresh, dl.gs_thresh, pn ? g->pn_ctr : nullptr);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }
@@ -1953,7 +1975,7 @@ int launch_compact_prepared(pprhip_graph* g, int cbuf, int out_fbuf, unsigned lo
 static int reduce_partials(pprhip_graph* g, uint32_t n_blocks, int out_slot, int dead_slot, bool with_dead) {
   k_dense_reduce<<<dim3(1), dim3(1024), 0, g->stream>>>(g->blk_pack, with_dead ? g->blk_dead : nullptr, g->blk_ndead,
                                                         n_blocks, g->ctr, out_slot, dead_slot, nullptr, kGsJacobi, nullptr,
-                                                        nullptr, 0ull, ~0ull);
+                                                        nullptr, 0ull, ~0ull, nullptr);
   PPRHIP_CHECK_HIP(hipGetLastError());
   return PPRHIP_OK;
 }

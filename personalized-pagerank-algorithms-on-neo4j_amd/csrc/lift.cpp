@@ -328,11 +328,12 @@ int lift_host(uint32_t n, uint64_t m, const uint32_t* out_rp, const int32_t* out
   // has out-edges; no layout when they fit one slice.
   H.S = 0;
   H.n_seg = 0;
-  // ---- row-panel copy (the single-query forward sweep's layout from 2^20 edges on; PPRHIP_SWEEP1_PANELS=0 / 1, a test
-  // switch, forces it off / on at any size): graphs that have it need no sliced copy
+  // ---- row-panel copy (the single-query forward sweep's layout from 2^26 edges on - measured per dense level, panels
+  // against the sliced copy: R-MAT 21 185 / 183 us, 22 290 / 361, 23 538 / 781, 24 1 101 / 1 781; PPRHIP_SWEEP1_PANELS=0 /
+  // 1, a test switch, forces it off / on at any size): graphs that have it need no sliced copy
   {
     const char* pe = hook_env("PPRHIP_SWEEP1_PANELS");
-    const bool want = pe ? pe[0] == '1' : m >= (1ull << 20);
+    const bool want = pe ? pe[0] == '1' : m >= (1ull << 26);
     if (want && m > 0 && !H.nz_rows.empty()) {
       PPRHIP_TRY(build_panel_layout(n, m, irp.data(), H.in_ci.data(), H.nz_rows.data(), (uint32_t)H.nz_rows.size(), T, H.pn));
       if (H.pn.n_items) return PPRHIP_OK;

@@ -214,10 +214,10 @@ def test_index_merge_large_runs_on_all_threads(pkg):
 
 
 # ------------------------------------------------------------------ graph lift, host half (row a11; PPR.java:136-152)
-def _panel_expected(n, m, in_rp, in_ci, nz_rows, panel=16384, step=8192, item_edges=65536, fold_parts=32, fold_min=16):
+def _panel_expected(n, m, in_rp, in_ci, nz_rows, panel=8192, step=8192, item_edges=32768, fold_parts=32, fold_min=16):
     """The row-panel copy of the in-CSR (engine_internal.hpp: HostPanelLayout) restated with numpy sorts: panels of
-    16 384 consecutive rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more than 65 536 edges
-    is cut into S = ceil(edges / 65 536) parts [e k / S, e (k + 1) / S); every part padded to whole turns of 8 192 edges
+    8 192 consecutive rows with in-edges, a panel's in-edges sorted by (source, row); a panel of more than 32 768 edges
+    is cut into S = ceil(edges / 32 768) parts [e k / S, e (k + 1) / S); every part padded to whole turns of 8 192 edges
     with (0, 0xffff); part k of a panel of `rows` rows leaves its sums at base + k rows + local row; a panel of more than 16
     parts has room behind all parts for their sums 32 at a time."""
     indeg = np.diff(in_rp).astype(np.int64)
@@ -309,7 +309,7 @@ def _lift_expected(h, width=393216, chunk=512, max_windows=16, panels=None):
     exp = dict(new2old=new2old, old2new=old2new, out_rp=out_rp, out_ci=out_ci, in_rp=in_rp, in_ci=in_ci, nz_rows=nz_rows,
                zin_rows=zin_rows, flags=flags, chunk_starts=chunk_starts, cross=cross)
     if panels is None:
-        panels = m >= (1 << 20)
+        panels = m >= (1 << 26)
     if panels and m and nz_rows.size:  # graphs with the row-panel copy have no sliced one
         exp.update(_panel_expected(n, m, in_rp, in_ci, nz_rows))
         return exp
@@ -339,11 +339,11 @@ def _lift_expected(h, width=393216, chunk=512, max_windows=16, panels=None):
     return exp
 
 
-@pytest.mark.parametrize("scale,slice_ids,panels", [(10, 100, None), (10, 0, "1"), (16, 20000, "0"), (16, 0, None), (17, 0, None)])
+@pytest.mark.parametrize("scale,slice_ids,panels", [(10, 100, None), (10, 0, "1"), (16, 20000, None), (16, 0, "1"), (17, 0, "1")])
 def test_lift_host_matches_numpy_restatement(pkg, monkeypatch, scale, slice_ids, panels):
     """pprhip_graph_lift_host (what pprhip_graph_create uploads) against an independent numpy restatement of the
     layout, on one thread and on eight (scale 16/17 are large enough for the threaded passes): same bytes.  Graphs from
-    2^20 edges on get the row-panel copy instead of the sliced one (PPRHIP_SWEEP1_PANELS=0 / 1 forces either)."""
+    2^26 edges on get the row-panel copy instead of the sliced one (PPRHIP_SWEEP1_PANELS=0 / 1 forces either)."""
     if slice_ids:
         monkeypatch.setenv("PPRHIP_SLICE_IDS", str(slice_ids))
     if panels is not None:

@@ -16,7 +16,7 @@ f = glob.glob("/tmp/ps_%s/**/*counter_collection.csv" % sys.argv[1], recursive=T
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pprhip::", "")
-    if k.startswith(("k_dense_edges<", "k_dense_apply<", "k_dense_reduce")):
+    if k.startswith(("k_dense_edges<", "k_dense_edges_panel", "k_panel_fold", "k_dense_apply<", "k_dense_reduce")):
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc:
     print(k, {c: round(sum(v) / len(v), 1) for c, v in acc[k].items()}, "launches", len(next(iter(acc[k].values()))), flush=True)
