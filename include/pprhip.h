@@ -21,6 +21,20 @@
  *     with pprhip_get_reserve / pprhip_get_residue;
  *   - there is NO CPU fallback: every compute entry point fails with PPRHIP_ERR_NO_DEVICE when
  *     no gfx950 device is usable.
+ *
+ * Environment.  libpprhip.so reads these six variables and no others:
+ *   PPRHIP_HOST_THREADS=<n>      host threads of the graph lift and the index finalisation (default: the CPU affinity /
+ *                                cgroup quota of the process, at most 64)
+ *   PPRHIP_BATCH_WORKSPACES=<n>  query workspaces of the batch driver, 16-48 (default 32; 0.33 GB each at R-MAT 22)
+ *   PPRHIP_BATCH_THREADS=0|1     batched top-k / All-Pair's third tier: one host thread per slot (default 1) or one in all
+ *   PPRHIP_SHARD_CUT=count|work  target ranges of the sharded All-Pair: equal counts, or cut by measured work (default:
+ *                                by work when equal counts would leave a rank more than 1.15 x the mean)
+ *   PPRHIP_COMM_TIMEOUT_S=<s>    time limit of an exchange between ranks (default 1800)
+ *   PPRHIP_RCCL_LIB=<path>       the librccl.so to load on first multi-GPU use (default: the loader's search)
+ * (HIP_FORCE_DEV_KERNARG=1, a HIP runtime variable, is what the launchers set before the runtime starts: INTEGRATION.md.)
+ * Fault injection, layout / driver variants, diagnostics on stderr and the measurement switches of the A/B runs exist only
+ * in libpprhip_hooks.so - the same sources built with -DPPRHIP_TEST_HOOKS (make builds both) - which the tests that need
+ * them and tools/exp load; the product ignores those variables.
  */
 #ifndef PPRHIP_H
 #define PPRHIP_H
