@@ -1258,7 +1258,7 @@ def stream_idle(args):
     if len(marks) < 2:
         return {"source": "unmeasured: the trace does not hold the two marker kernels"}
     region = rows[marks[-2] + 1:marks[-1]]
-    sweeps = [x for x in region if _short(x["Kernel_Name"]).startswith(("k_dense_edges_b", "k_dense_edges_q"))]
+    sweeps = [x for x in region if _short(x["Kernel_Name"]).startswith("k_dense_edges_b")]
     if not sweeps:
         return {"source": "unmeasured: no batched sweep in the traced region"}
     main = max({x[key] for x in sweeps}, key=lambda q: sum(1 for x in sweeps if x[key] == q))
@@ -1296,7 +1296,7 @@ def stream_idle(args):
     per = {}
     for x in region:
         name = _short(x["Kernel_Name"])
-        if name.startswith(("k_dense_edges_b", "k_dense_edges_q", "k_dense_apply_batch", "k_dense_reduce_batch")):
+        if name.startswith(("k_dense_edges_b", "k_dense_apply_batch", "k_dense_reduce_batch")):
             e = per.setdefault(name, [0, 0])
             e[0] += 1
             e[1] += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
@@ -1410,12 +1410,12 @@ def pmc_traffic(args, host):
     anyk = lambda name: True  # noqa: E731
     # phase 1: the headline path; a dense level = several launches of the edge / apply kernels + one reduce launch
     # (the kernels of one sweep under rocprofv3's names: both are templates since round 5)
-    sweep = lambda k: k.startswith(("k_dense_edges_b<", "k_dense_edges_q<", "k_dense_apply_batch", "k_dense_reduce_batch"))  # noqa: E731
+    sweep = lambda k: k.startswith(("k_dense_edges_b<", "k_dense_apply_batch", "k_dense_reduce_batch"))  # noqa: E731
     levels = count(fetch[1], lambda k: k == "k_dense_reduce_batch")
     if levels:
         res["dense_pull_batch"] = int(traffic(1, sweep) / levels)
         res["dense_pull_batch_tcc_hit"] = hit_rate(1, sweep)
-        res["dense_pull_batch_edges_tcc_hit"] = hit_rate(1, lambda k: k.startswith(("k_dense_edges_b<", "k_dense_edges_q<")))
+        res["dense_pull_batch_edges_tcc_hit"] = hit_rate(1, lambda k: k.startswith("k_dense_edges_b<"))
     walks = count(fetch[1], lambda k: k == "k_mc_walk")
     if walks:
         res["walk"] = int(traffic(1, lambda k: k == "k_mc_walk") / walks)
@@ -1426,7 +1426,8 @@ def pmc_traffic(args, host):
         "sparse_push": int(traffic(1, lambda k: k.startswith("k_sparse")) / 48)}
     # phase 2: one query at a time; levels launched behind another one whose frontier had already emptied return at
     # once and fetch next to nothing: not counted (a counted level = one apply launch per Gauss-Seidel block, two blocks)
-    one = lambda k: k.startswith("k_dense_edges<") or k.startswith("k_dense_apply<") or k == "k_dense_reduce"  # noqa: E731
+    one = lambda k: (k.startswith(("k_dense_edges<", "k_dense_edges_panel", "k_panel_fold", "k_dense_apply<"))  # noqa: E731
+                     or k == "k_dense_reduce")
     lv = sum(1 for name, v in fetch[2] if name.startswith("k_dense_apply<") and v.get("FETCH_SIZE", 0.0) > 256.0) / 2.0
     if lv:
         res["dense_pull"] = int(traffic(2, one) / lv)
