@@ -374,6 +374,35 @@ def main():
             if not np.array_equal(gathered["ids"][0], last["ids"]) or not np.array_equal(gathered["vals"][0], last["vals"]):
                 raise SystemExit("self-check failed: rank 0's top-k block changed in pprhip_topk_gather")
             check["gathered_blocks"] = int(gathered["ids"].shape[0])
+    # N > 1: config #4 as BASELINE.json words it - 50 queries IN TOTAL over the N GPUs (strong scaling; SURVEY 8(e): GPU g
+    # takes the sources i mod N = g), every rank under pprhip_tuning_batch_for(its share), the 50 x 32 pairs gathered on
+    # rank 0 through the library when its communicator stands; beside the weak-scaling `value`, outside the timed region
+    config4_strong = None
+    if world > 1 and args.mode == "batch" and not args.no_extras:
+        try:
+            all50 = live_draw(np.random.default_rng(50), live_ids, 50)          # the same 50 sources on every rank
+            mine = np.ascontiguousarray(all50[rank::world], dtype=np.int32)
+            g.set_tuning(pkg.tuning_batch_for(len(mine)))
+            was_t = pkg.set_kernel_timing(False)
+            g.fora_batch_single_source(mine, EPS, ALPHA, seed=71, k=TOPK, conf=conf, keep=store)  # warm-up of this shape
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, ids50, vals50, _, _, _ = g.fora_batch_single_source(mine, EPS, ALPHA, seed=72, k=TOPK, conf=conf, keep=store)
+            if comm is not None:
+                comm.topk_gather(ids50, vals50, rows_max=(50 + world - 1) // world)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t50 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=xdev)
+            dist.all_reduce(t50, op=dist.ReduceOp.MAX)
+            pkg.set_kernel_timing(was_t)
+            g.set_tuning(tuning)
+            config4_strong = {"queries_total": 50, "gpus": world, "queries_per_gpu_max": int((50 + world - 1) // world),
+                              "seconds": round(float(t50.item()), 4), "queries_per_s": round(50 / float(t50.item()), 1),
+                              "scaling": "strong", "gather": "pprhip_topk_gather" if comm is not None else "none (no library communicator in this run)"}
+        except Exception as e:  # noqa: BLE001  (a sample must not cost the line)
+            config4_strong = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            g.set_tuning(tuning)
     if comm is not None:
         comm.close()
 
@@ -463,6 +492,8 @@ def main():
         }
         if all_pair_scaling is not None:
             out["all_pair_scaling"] = all_pair_scaling
+        if config4_strong is not None:
+            out["config4_strong_scaling"] = config4_strong
         extras = solo and not args.no_extras
         if extras:
             out.update(q50_sample(pkg, g, store, rng, live_ids, conf, value))
