@@ -492,3 +492,33 @@ def test_full_size_rmat22_fifty_query_call_and_stream(pkg, orc):
                 sync_store.close()
                 stream_store.close()
                 g.set_tuning(pkg.tuning_default())
+
+
+@pytest.mark.timeout(900)
+def test_full_size_rmat22_row_panel_sweep_equals_sliced_sweep(pkg, monkeypatch):
+    """The single-query forward sweep's two layouts at BASELINE's size (R-MAT 22: the row-panel copy is the default from
+    2^26 edges on, PPRHIP_SWEEP1_PANELS=0 forces the sliced copy): forward push, the power method and whole-graph FORA
+    from a hub, a degree-1 source and a random live one - the same levels, the same walks, vectors equal up to the order
+    of the sums (1e-12), mass conserved."""
+    host = pkg.HostCsr.rmat(22, 16, seed=1)
+    od = np.diff(host.out_rp)
+    srcs = [int(np.argmax(od)), int(np.nonzero(od == 1)[0][0]), live_sources(host, 1, 4)[0]]
+    results = {}
+    for layout in ("1", "0"):
+        monkeypatch.setenv("PPRHIP_SWEEP1_PANELS", layout)
+        with pkg.Graph(host) as g:
+            out = []
+            for s in srcs:
+                p, r, rsum, st = g.forward_push(s, A, 5.07e-9)
+                assert st.dense_levels > 0 and abs(p.sum() + r.sum() - 1.0) < 1e-11
+                est, stf = g.fora_single_source(s, 0.5, A, seed=3)
+                assert abs(est.sum() - 1.0) < 1e-9
+                out.append((p, r, st.levels, st.dense_levels, est, stf.walks, stf.levels))
+            pm, _ = g.power_method(srcs[0], A, 20)
+            out.append(pm)
+        results[layout] = out
+    for a, b in zip(results["1"][:-1], results["0"][:-1]):
+        assert a[2] == b[2] and a[3] == b[3] and a[5] == b[5] and a[6] == b[6]
+        assert np.max(np.abs(a[0] - b[0])) <= 1e-12 and np.max(np.abs(a[1] - b[1])) <= 1e-12
+        assert np.max(np.abs(a[4] - b[4])) <= 1e-9
+    assert np.max(np.abs(results["1"][-1] - results["0"][-1])) <= 1e-12
