@@ -385,8 +385,8 @@ static int upload_panel_layout(pprhip_graph* G, HostLift& H) {
 // the buffer the items of a panel sweep leave their sums in: per handle, on its first forward dense level
 int ensure_panel_part(pprhip_graph* g) {
   if (!g->pn || g->pn_part) return PPRHIP_OK;
-  PPRHIP_TRY(alloc_dev((void**)&g->pn_ctr, 4 * sizeof(uint32_t)));
-  PPRHIP_CHECK_HIP(hipMemsetAsync(g->pn_ctr, 0, 4 * sizeof(uint32_t), g->stream));
+  PPRHIP_TRY(alloc_dev((void**)&g->pn_ctr, kPanelQueues * sizeof(uint32_t)));
+  PPRHIP_CHECK_HIP(hipMemsetAsync(g->pn_ctr, 0, kPanelQueues * sizeof(uint32_t), g->stream));
   return alloc_dev((void**)&g->pn_part, sizeof(double) * (size_t)g->pn->n_part);
 }
 

@@ -95,6 +95,7 @@ struct SlicedLayout {
   int plan_B = -1;
 };
 
+constexpr int kPanelQueues = 64;  // = the most Gauss-Seidel blocks a sweep can have
 // The row-panel copy of the in-CSR on the device (engine_internal.hpp: HostPanelLayout; single-query forward sweep).
 struct PanelLayout {
   int32_t* src = nullptr;          // [n_edges] sources, item-major
@@ -333,7 +334,7 @@ struct pprhip_graph {
   pprhip::SlicedLayout* sl = nullptr;
   pprhip::PanelLayout* pn = nullptr;   // row-panel copy of the in-CSR (shared with the batch slots), or none
   double* pn_part = nullptr;           // [pn->n_part] the items' sums of this handle's sweep (first forward dense level)
-  uint32_t* pn_ctr = nullptr;          // [4] item queues of a level's edge launches (one per Gauss-Seidel block); k_dense_reduce zeroes them  // single-query sweep layout (owned by the lifted graph, borrowed by slots)
+  uint32_t* pn_ctr = nullptr;          // [kPanelQueues] item queues of a level's edge launches (one per Gauss-Seidel block); k_dense_reduce zeroes them  // single-query sweep layout (owned by the lifted graph, borrowed by slots)
   // batched queries: kBatch workspaces ("slots") borrow this handle's CSR and stream; their dense
   // levels run as one sweep over the interleaved contribution array c8[v][slot]
   pprhip_graph* parent = nullptr;  // set on a slot

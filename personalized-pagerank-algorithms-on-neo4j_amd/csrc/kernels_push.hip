@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(1024) void k_dense_reduce(const unsigned long long*
                                                         unsigned long long gs_thresh, uint32_t* queues) {
   __shared__ double s_red[16];
   __shared__ unsigned long long s_red2[16];
-  if (queues && threadIdx.x < 4) queues[threadIdx.x] = 0u;  // the item queues of this level's panel launches
+  if (queues && threadIdx.x < kPanelQueues) queues[threadIdx.x] = 0u;  // the item queues of this level's panel launches
   const int state = dense_state(state_in, state0);
   if (state == kGsNone) {
     if (threadIdx.x == 0 && state_out) *state_out = kGsNone;
@@ -1767,7 +1767,7 @@ int launch_dense_level(pprhip_graph* g, const PushArgs& a, int cbuf, int out_slo
         const uint32_t grid = std::min<uint32_t>(i_hi - i_lo, (uint32_t)g->n_cus * (uint32_t)(160 * 1024 / (kPanelLdsBytes + 1024)));
         k_dense_edges_panel<<<dim3(grid), dim3(kPanelThreads), kPanelLdsBytes, g->stream>>>(
             pn->src, pn->rloc, pn->items, i_lo, i_hi, g->cdense[cbuf], g->pn_part, B.j_lo, B.j_hi, n_nz, dl.state_in,
-            g->pn_ctr + std::min(b, 3));
+            g->pn_ctr + std::min(b, kPanelQueues - 1));
         PPRHIP_CHECK_HIP(hipGetLastError());
         // panels of many parts (the hub rows': the first few - rows are ordered by degree, so parts do not grow)
         uint32_t p_fold = p_lo, s_max = 0;

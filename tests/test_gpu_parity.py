@@ -359,7 +359,7 @@ def test_row_panel_single_query_sweep(pkg, orc, got, rmat12, rmat15, graph, rela
     g_ref = pkg.Graph(host)
     srcs = [s for s in ([0, 17, 42] if graph == "got" else []) + list(sources(host, 8, seed=27)) if od[s] > 0][:4]
     try:
-        for B in (1, 2, 3):
+        for B in (1, 2, 3, 6):
             t = pkg.tuning_batch()       # (dense levels from 2 % of m)
             t.gs_blocks = B
             if graph == "got":
